@@ -1,0 +1,158 @@
+/* smgpu.h -- C-ABI of the MI355X (gfx950) smoothing-iteration engine.
+ *
+ * Drop-in boundary for the hot path of tkeskita/smoothMesh: the body of the smoothing loop
+ * src/smoothMesh.C:2257-2437 (cell-centre recompute, centroidalSmoothing :96-166,
+ * aspectRatioSmoothing :548-593, constrainMaxStepLength :684-754, restrictEdgeShortening
+ * :602-652, restrictMinEdgeAngleDecrease :900-930, restrictFaceAngleDeterioration :1320-1437,
+ * restore/count :2384-2392, calculateResidual :1546-1570, mesh.movePoints :2399).
+ *
+ * The reference has no FFI: those are free functions over OpenFOAM types (const fvMesh&,
+ * pointField&, boolList&) called from main().  A host (the bundled `smoothMesh` front-end in
+ * smoothmesh_amd/csrc/host, or an OpenFOAM-linked main) hands over what a
+ * polyMesh directory contains -- points, faces, owner, neighbour, point masks -- as plain
+ * arrays; all other addressing is derived inside the library.
+ *
+ * Conventions: every call returns 0 on success, non-zero on error (message through
+ * smgpu_last_error); the reference aborts the process on FatalError, the host does the same.
+ * Host arrays are borrowed for the duration of the call only.  A handle owns one HIP device
+ * stream and all its device memory; it is not thread-safe.  label = int32, scalar = f64,
+ * point = 3 x f64 (AoS), boolList = 1 byte per element.
+ */
+#ifndef SMGPU_H
+#define SMGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smgpu_handle smgpu_handle;
+
+/* What createMesh.H (SM.C:1814-1818) + findInternalMeshPoints (SM.C:40-91) +
+ * classifyBoundaryPoints (BPS.C:269-441) give the loop. */
+typedef struct smgpu_mesh_desc {
+    int32_t nPoints, nCells, nFaces, nInternalFaces;
+    const double* points;           /* [3*nPoints]            mesh.points()                  */
+    const int32_t* faceOffsets;     /* [nFaces+1]             CSR of mesh.faces()            */
+    const int32_t* facePoints;      /* [faceOffsets[nFaces]]                                  */
+    const int32_t* owner;           /* [nFaces]               polyMesh::faceOwner()          */
+    const int32_t* neighbour;       /* [nInternalFaces]       polyMesh::faceNeighbour()      */
+    const uint8_t* isInternalPoint;          /* [nPoints]  SM.C:1978-1979                    */
+    const uint8_t* isSmoothingSurfacePoint;  /* [nPoints]  BPS.C:404-412; NULL = all false   */
+    int32_t device;                 /* HIP device ordinal                                     */
+    void* stream;                   /* hipStream_t to run on; NULL = library creates one      */
+} smgpu_mesh_desc;
+
+/* Loop parameters, SM.C:1861-1890 (names as the command-line options). */
+typedef struct smgpu_params {
+    double maxStepLength;
+    double relStepFrac;
+    double minEdgeLength;
+    int32_t totalMinFreeze;
+    int32_t edgeAngleConstraint;
+    int32_t faceAngleConstraint;
+    double minAngle;   /* degrees */
+    double maxAngle;   /* degrees */
+} smgpu_params;
+
+/* One line of "Smoothing iteration=N nFrozenPoints=M residual=R" (SM.C:2396). */
+typedef struct smgpu_iter_stats {
+    double residual;
+    int32_t nFrozenPoints;
+    int32_t pad;
+} smgpu_iter_stats;
+
+/* Mesh sizes derived by the library (for byte accounting and logs). */
+typedef struct smgpu_sizes {
+    int64_t nPoints, nCells, nFaces, nInternalFaces, nEdges;
+    int64_t nnzFacePoints, nnzPointCells, nnzPointPoints, nnzPointFaces, nnzEdgeFaces, nnzEdgeCells, nnzCellFaces;
+    int64_t deviceBytes;
+} smgpu_sizes;
+
+/* Per-kernel accumulated device time (hipEvent, milliseconds) and launch counts. */
+#define SMGPU_MAX_KERNELS 16
+typedef struct smgpu_counters {
+    int32_t nKernels;
+    const char* name[SMGPU_MAX_KERNELS];
+    double ms[SMGPU_MAX_KERNELS];
+    int64_t launches[SMGPU_MAX_KERNELS];
+    int64_t algoBytesPerLaunch[SMGPU_MAX_KERNELS];
+} smgpu_counters;
+
+const char* smgpu_last_error(void);
+const char* smgpu_version(void);
+
+/* Build addressing on the host, upload everything.  Replaces the setup SM.C:1978-2021. */
+int smgpu_create(const smgpu_mesh_desc* desc, smgpu_handle** out);
+int smgpu_destroy(smgpu_handle* h);
+
+int smgpu_get_sizes(smgpu_handle* h, smgpu_sizes* out);
+/* getMeshStats (SM.C:1478-1541): min / max edge length of the current coordinates. */
+int smgpu_mesh_stats(smgpu_handle* h, double* minEdgeLength, double* maxEdgeLength);
+int smgpu_set_params(smgpu_handle* h, const smgpu_params* p);
+
+/* The loop SM.C:2257-2437 on one rank: up to nIters iterations, stops after the first iteration
+ * whose residual < relTol (SM.C:2401).  stats (host, [nIters], may be NULL) receives one entry
+ * per iteration done.  No host synchronisation happens inside the loop. */
+int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_stats* stats, int32_t* nDone);
+
+int smgpu_get_points(smgpu_handle* h, double* outPoints /* [3*nPoints] */);
+int smgpu_set_points(smgpu_handle* h, const double* points /* [3*nPoints] */);
+
+/* Timing: when enabled every kernel launch is bracketed by hipEvents on the handle's stream. */
+int smgpu_enable_timing(smgpu_handle* h, int32_t on);
+int smgpu_get_counters(smgpu_handle* h, smgpu_counters* out);
+int smgpu_reset_counters(smgpu_handle* h);
+
+/* ---- multi-rank (domain decomposition, one handle per rank/GPU) --------------------------
+ * Replaces syncTools::syncPointList at SM.C:134,142,402,429,455,472 (one fused exchange "A")
+ * and SM.C:2374 (exchange "F").  The library packs/unpacks; the host moves the buffers
+ * (RCCL all_to_all over xGMI) between the calls.  All buffers are DEVICE pointers owned by the
+ * caller.  Record of exchange A = 13 doubles per slot {sum xyz, r1 xyz, r2 xyz, r3 xyz,
+ * (int32 count, int32 hasCommonCell)}; record of exchange F = 1 int32 per slot. */
+#define SMGPU_HALO_A_DOUBLES 13
+typedef struct smgpu_halo_desc {
+    int32_t nShared;              /* points of this rank shared with >= 1 other rank          */
+    const int32_t* sharedLocal;   /* [nShared] local point ids                                */
+    int32_t nSend;                /* send slots (concatenated by destination rank, ascending) */
+    const int32_t* sendShared;    /* [nSend]   index into sharedLocal of each send slot       */
+    int32_t nRecv;                /* recv slots (concatenated by source rank, ascending)      */
+    const int32_t* combOffsets;   /* [nShared+1] CSR over sharers of each shared point        */
+    const int32_t* combSlots;     /* recv slot of each sharer, ascending rank; -1 = this rank */
+    void* sendA; void* recvA;     /* device, nSend / nRecv records of 13 doubles              */
+    void* sendF; void* recvF;     /* device, nSend / nRecv int32                              */
+    void* localStats;             /* device, 2 doubles {residual, nFrozenPoints} per iteration */
+} smgpu_halo_desc;
+int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d);
+int smgpu_iter_begin(smgpu_handle* h);   /* geometry + local partial sums / closest points -> sendA */
+int smgpu_iter_mid(smgpu_handle* h);     /* combine recvA, proposal, constraints -> sendF           */
+int smgpu_iter_end(smgpu_handle* h);     /* or recvF, restore, residual -> localStats; movePoints   */
+
+/* ---- debug / parity access (device -> host copy of an internal field) -----------------------
+ * name: "cellCentres" [3C], "faceCentres" [3F], "faceAreas" [3F], "newPoints" [3P] (proposal of the
+ * last iteration before restore), "isFrozenPoint" [P], "edgeMinAngle"/"edgeMaxAngle" [E],
+ * "pointMinAngle"/"pointMaxAngle" [P].  Values are converted to double.  Returns the element
+ * count through *n; out may be NULL to query the size. */
+int smgpu_debug_get_field(smgpu_handle* h, const char* name, double* out, int64_t* n);
+/* kind: pointCells, pointPoints, pointFaces, pointEdges, edgeFaces, edgeCells, edges (2/row).
+ * offsets/values may be NULL to query nnz. */
+int smgpu_debug_get_addressing(smgpu_handle* h, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz);
+/* Run one iteration up to (not including) restore/movePoints so "newPoints"/"isFrozenPoint"
+ * can be compared with the oracle's phaseA/phaseB. */
+int smgpu_debug_propose(smgpu_handle* h);
+
+
+/* ---- host-only addressing build (no device needed; used by the CPU test-suite and hosts that
+ * want the derived lists, e.g. to compute getMeshStats defaults before choosing a device) ------- */
+typedef struct smgpu_topology smgpu_topology;
+int smgpu_topology_create(const smgpu_mesh_desc* desc, smgpu_topology** out);
+int smgpu_topology_get(smgpu_topology* t, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz);
+int smgpu_topology_num_edges(smgpu_topology* t, int32_t* nEdges);
+int smgpu_topology_destroy(smgpu_topology* t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMGPU_H */

@@ -1,0 +1,172 @@
+// oracle_capi.cpp -- plain C entry points over the oracle for ctypes (tests, smoke, bench's
+// cpu_baseline leg only).  TEST INFRASTRUCTURE ONLY; PARITY UNPINNED (see smooth_oracle.hpp).
+#include <cstring>
+#include <string>
+
+#include "smooth_oracle.hpp"
+
+using namespace orc;
+
+extern "C" {
+
+void* orc_create(int nPoints, int nCells, int nFaces, int nInternalFaces, const double* points,
+                 const int* faceOffsets, const int* facePoints, const int* owner, const int* neighbour,
+                 const unsigned char* isInternalPoint, const unsigned char* isSmoothingSurfacePoint) {
+    Domain* d = new Domain();
+    d->nPoints = nPoints;
+    d->nCells = nCells;
+    d->points.resize(nPoints);
+    std::memcpy(d->points.data(), points, sizeof(double) * 3 * size_t(nPoints));
+    d->faces.resize(nFaces);
+    for (int f = 0; f < nFaces; ++f) d->faces[f].assign(facePoints + faceOffsets[f], facePoints + faceOffsets[f + 1]);
+    d->owner.assign(owner, owner + nFaces);
+    d->neighbour.assign(neighbour, neighbour + nInternalFaces);
+    d->isInternalPoint.assign(isInternalPoint, isInternalPoint + nPoints);
+    if (isSmoothingSurfacePoint) d->isSmoothingSurfacePoint.assign(isSmoothingSurfacePoint, isSmoothingSurfacePoint + nPoints);
+    else d->isSmoothingSurfacePoint.assign(nPoints, 0);
+    d->build();
+    return d;
+}
+
+void orc_destroy(void* h) { delete static_cast<Domain*>(h); }
+
+void orc_set_params(void* h, double maxStepLength, double relStepFrac, double minEdgeLength, int totalMinFreeze,
+                    int edgeAngleConstraint, int faceAngleConstraint, double minAngle, double maxAngle) {
+    Domain* d = static_cast<Domain*>(h);
+    d->prm.maxStepLength = maxStepLength;
+    d->prm.relStepFrac = relStepFrac;
+    d->prm.minEdgeLength = minEdgeLength;
+    d->prm.totalMinFreeze = totalMinFreeze != 0;
+    d->prm.edgeAngleConstraint = edgeAngleConstraint != 0;
+    d->prm.faceAngleConstraint = faceAngleConstraint != 0;
+    d->prm.minAngle = minAngle;
+    d->prm.maxAngle = maxAngle;
+}
+
+void orc_mesh_stats(void* h, double* minEdge, double* maxEdge) { static_cast<Domain*>(h)->meshStats(*minEdge, *maxEdge); }
+
+int orc_iterate(void* h, int nIters, double relTol, double* residuals, int* nFrozen) {
+    return static_cast<Domain*>(h)->iterate(nIters, relTol, residuals, nFrozen);
+}
+
+const char* orc_last_error(void* h) { return static_cast<Domain*>(h)->error.c_str(); }
+
+void orc_set_points(void* h, const double* pts) {
+    Domain* d = static_cast<Domain*>(h);
+    std::memcpy(d->points.data(), pts, sizeof(double) * 3 * size_t(d->nPoints));
+}
+
+int orc_num_edges(void* h) { return int(static_cast<Domain*>(h)->edges.size()); }
+
+// run one iteration's phases without committing (operator-level parity checks)
+void orc_phaseA(void* h) { static_cast<Domain*>(h)->phaseA(); }
+void orc_phaseB(void* h) { static_cast<Domain*>(h)->phaseB(); }
+void orc_phaseC(void* h) { static_cast<Domain*>(h)->phaseC(); }
+void orc_commit(void* h) { static_cast<Domain*>(h)->commit(); }
+
+static long long copyVec(const std::vector<Vec3>& v, double* out) {
+    if (out) std::memcpy(out, v.data(), sizeof(Vec3) * v.size());
+    return (long long)v.size() * 3;
+}
+static long long copyD(const std::vector<double>& v, double* out) {
+    if (out) std::memcpy(out, v.data(), sizeof(double) * v.size());
+    return (long long)v.size();
+}
+static long long copyU8(const std::vector<unsigned char>& v, double* out) {
+    if (out) for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (long long)v.size();
+}
+static long long copyI(const std::vector<int>& v, double* out) {
+    if (out) for (size_t i = 0; i < v.size(); ++i) out[i] = v[i];
+    return (long long)v.size();
+}
+
+// Copy a named field as doubles; returns its length (call with out == NULL to size it), -1 if unknown.
+long long orc_get_field(void* h, const char* name, double* out) {
+    Domain* d = static_cast<Domain*>(h);
+    const std::string n(name);
+    if (n == "points") return copyVec(d->points, out);
+    if (n == "faceCentres") return copyVec(d->faceCentres, out);
+    if (n == "faceAreas") return copyVec(d->faceAreas, out);
+    if (n == "cellCentres") return copyVec(d->cellCentres, out);
+    if (n == "cellSum") return copyVec(d->cellSum, out);
+    if (n == "cellCount") return copyI(d->cellCount, out);
+    if (n == "closest1") return copyVec(d->closest1, out);
+    if (n == "closest2") return copyVec(d->closest2, out);
+    if (n == "closest3") return copyVec(d->closest3, out);
+    if (n == "hasCommonCell") return copyU8(d->hasCommonCell, out);
+    if (n == "centroidalPoints") return copyVec(d->centroidalPoints, out);
+    if (n == "arPoints") return copyVec(d->arPoints, out);
+    if (n == "newPoints") return copyVec(d->newPoints, out);
+    if (n == "isFrozenPoint") return copyU8(d->isFrozenPoint, out);
+    if (n == "frozenAfterEdgeLen") return copyU8(d->frozenAfterEdgeLen, out);
+    if (n == "frozenAfterEdgeAngle") return copyU8(d->frozenAfterEdgeAngle, out);
+    if (n == "frozenAfterFaceAngle") return copyU8(d->frozenAfterFaceAngle, out);
+    if (n == "edgeMinAngle") return copyD(d->edgeMinAngle, out);
+    if (n == "edgeMaxAngle") return copyD(d->edgeMaxAngle, out);
+    if (n == "pointMinAngle") return copyD(d->pointMinAngle, out);
+    if (n == "pointMaxAngle") return copyD(d->pointMaxAngle, out);
+    if (n == "eaMinC") return copyD(d->eaMinC, out);
+    if (n == "eaMinN") return copyD(d->eaMinN, out);
+    return -1;
+}
+
+// Addressing as CSR (offsets has n+1 entries).  kind: pointCells, pointFaces, pointEdges, pointPoints,
+// edgeFaces, edgeCells, cellFaces, edges (returned as 2 per row).  Returns nnz; call with NULLs to size.
+long long orc_get_addressing(void* h, const char* kind, int* offsets, int* values) {
+    Domain* d = static_cast<Domain*>(h);
+    const std::string n(kind);
+    const std::vector<std::vector<int>>* ll = nullptr;
+    if (n == "pointCells") ll = &d->pointCells;
+    else if (n == "pointFaces") ll = &d->pointFaces;
+    else if (n == "pointEdges") ll = &d->pointEdges;
+    else if (n == "pointPoints") ll = &d->pointPoints;
+    else if (n == "edgeFaces") ll = &d->edgeFaces;
+    else if (n == "edgeCells") ll = &d->edgeCells;
+    else if (n == "cellFaces") ll = &d->cellFaces;
+    else if (n == "edges") {
+        if (values) for (size_t e = 0; e < d->edges.size(); ++e) { values[2 * e] = d->edges[e][0]; values[2 * e + 1] = d->edges[e][1]; }
+        return (long long)d->edges.size() * 2;
+    } else return -1;
+    long long nnz = 0;
+    for (size_t i = 0; i < ll->size(); ++i) {
+        if (offsets) offsets[i] = int(nnz);
+        for (int v : (*ll)[i]) { if (values) values[nnz] = v; ++nnz; }
+    }
+    if (offsets) offsets[ll->size()] = int(nnz);
+    return nnz;
+}
+
+// scalar building blocks for known-answer tests
+double orc_edgeEdgeAngle(const double* c, const double* p1, const double* p2) {
+    return edgeEdgeAngle({c[0], c[1], c[2]}, {p1[0], p1[1], p1[2]}, {p2[0], p2[1], p2[2]});
+}
+double orc_calcEdgeCenterEdgeAngle(const double* p0, const double* cC, const double* p1) {
+    return calcEdgeCenterEdgeAngle({p0[0], p0[1], p0[2]}, {cC[0], cC[1], cC[2]}, {p1[0], p1[1], p1[2]});
+}
+int orc_isCloserPoint(const double* a, const double* b) {
+    return isCloserPoint({a[0], a[1], a[2]}, {b[0], b[1], b[2]}) ? 1 : 0;
+}
+
+// ---- multi-domain ----------------------------------------------------------------------
+void* orc_multi_create(int nDomains, void** handles) {
+    MultiDomain* m = new MultiDomain();
+    for (int i = 0; i < nDomains; ++i) m->dom.push_back(static_cast<Domain*>(handles[i]));
+    return m;
+}
+void orc_multi_destroy(void* m) { delete static_cast<MultiDomain*>(m); }
+// shared points as CSR: for shared point s, entries [off[s], off[s+1]) give (domain, local) pairs,
+// ascending domain id
+void orc_multi_set_shared(void* mh, int nShared, const int* off, const int* domain, const int* local) {
+    MultiDomain* m = static_cast<MultiDomain*>(mh);
+    m->shared.resize(nShared);
+    for (int s = 0; s < nShared; ++s) {
+        m->shared[s].domain.assign(domain + off[s], domain + off[s + 1]);
+        m->shared[s].local.assign(local + off[s], local + off[s + 1]);
+    }
+}
+int orc_multi_iterate(void* mh, int nIters, double relTol, double* residuals, int* nFrozen) {
+    return static_cast<MultiDomain*>(mh)->iterate(nIters, relTol, residuals, nFrozen);
+}
+
+}  // extern "C"

@@ -1,0 +1,195 @@
+"""ctypes wrapper over oracle/liboracle.so.  TEST INFRASTRUCTURE ONLY: imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by smoothmesh_amd/.
+PARITY UNPINNED (see oracle/smooth_oracle.hpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+_lib = None
+f64p = C.POINTER(C.c_double)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+
+
+def build():
+    subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        l = C.CDLL(LIB_PATH)
+        l.orc_create.restype = C.c_void_p
+        l.orc_create.argtypes = [C.c_int] * 4 + [f64p, i32p, i32p, i32p, i32p, u8p, u8p]
+        l.orc_destroy.argtypes = [C.c_void_p]
+        l.orc_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
+        l.orc_mesh_stats.argtypes = [C.c_void_p, f64p, f64p]
+        l.orc_iterate.restype = C.c_int
+        l.orc_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, f64p, i32p]
+        l.orc_last_error.restype = C.c_char_p
+        l.orc_last_error.argtypes = [C.c_void_p]
+        l.orc_set_points.argtypes = [C.c_void_p, f64p]
+        l.orc_num_edges.restype = C.c_int
+        l.orc_num_edges.argtypes = [C.c_void_p]
+        for n in ("orc_phaseA", "orc_phaseB", "orc_phaseC", "orc_commit"):
+            getattr(l, n).argtypes = [C.c_void_p]
+        l.orc_get_field.restype = C.c_longlong
+        l.orc_get_field.argtypes = [C.c_void_p, C.c_char_p, f64p]
+        l.orc_get_addressing.restype = C.c_longlong
+        l.orc_get_addressing.argtypes = [C.c_void_p, C.c_char_p, i32p, i32p]
+        l.orc_edgeEdgeAngle.restype = C.c_double
+        l.orc_edgeEdgeAngle.argtypes = [f64p, f64p, f64p]
+        l.orc_calcEdgeCenterEdgeAngle.restype = C.c_double
+        l.orc_calcEdgeCenterEdgeAngle.argtypes = [f64p, f64p, f64p]
+        l.orc_isCloserPoint.restype = C.c_int
+        l.orc_isCloserPoint.argtypes = [f64p, f64p]
+        l.orc_multi_create.restype = C.c_void_p
+        l.orc_multi_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+        l.orc_multi_destroy.argtypes = [C.c_void_p]
+        l.orc_multi_set_shared.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
+        l.orc_multi_iterate.restype = C.c_int
+        l.orc_multi_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, f64p, i32p]
+        _lib = l
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _v(x):
+    a = np.ascontiguousarray(x, dtype=np.float64)
+    return a, _p(a, f64p)
+
+
+class Oracle:
+    """One Domain of the restatement (one rank's mesh)."""
+
+    def __init__(self, mesh, isInternalPoint=None, isSmoothingSurfacePoint=None):
+        self._lib = lib()
+        if isInternalPoint is None:
+            isInternalPoint = mesh.find_internal_points()
+        ip = np.ascontiguousarray(isInternalPoint, dtype=np.uint8)
+        sp = None if isSmoothingSurfacePoint is None else np.ascontiguousarray(isSmoothingSurfacePoint, dtype=np.uint8)
+        pts = np.ascontiguousarray(mesh.points, dtype=np.float64)
+        self.nPoints, self.nCells, self.nFaces = mesh.nPoints, mesh.nCells, mesh.nFaces
+        self._h = self._lib.orc_create(mesh.nPoints, mesh.nCells, mesh.nFaces, mesh.nInternalFaces, _p(pts, f64p),
+                                       _p(mesh.faceOffsets, i32p), _p(mesh.facePoints, i32p), _p(mesh.owner, i32p),
+                                       _p(mesh.neighbour, i32p), _p(ip, u8p), _p(sp, u8p) if sp is not None else None)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_params(self, p):
+        self._lib.orc_set_params(self._h, p.maxStepLength, p.relStepFrac, p.minEdgeLength, int(p.totalMinFreeze),
+                                 int(p.edgeAngleConstraint), int(p.faceAngleConstraint), p.minAngle, p.maxAngle)
+
+    def mesh_stats(self):
+        a, b = C.c_double(), C.c_double()
+        self._lib.orc_mesh_stats(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def iterate(self, nIters, relTol=0.02):
+        res = np.zeros(max(nIters, 1), np.float64)
+        frz = np.zeros(max(nIters, 1), np.int32)
+        n = self._lib.orc_iterate(self._h, nIters, relTol, _p(res, f64p), _p(frz, i32p))
+        if n < 0:
+            raise RuntimeError(self._lib.orc_last_error(self._h).decode())
+        return n, res[:n].copy(), frz[:n].astype(np.int64)
+
+    def set_points(self, pts):
+        a, p = _v(pts)
+        self._lib.orc_set_points(self._h, p)
+
+    def phaseA(self): self._lib.orc_phaseA(self._h)
+    def phaseB(self): self._lib.orc_phaseB(self._h)
+    def phaseC(self): self._lib.orc_phaseC(self._h)
+    def commit(self): self._lib.orc_commit(self._h)
+
+    def error(self):
+        return self._lib.orc_last_error(self._h).decode()
+
+    def field(self, name):
+        n = self._lib.orc_get_field(self._h, name.encode(), None)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n, np.float64)
+        self._lib.orc_get_field(self._h, name.encode(), _p(out, f64p))
+        return out
+
+    def points(self):
+        return self.field("points").reshape(-1, 3)
+
+    def num_edges(self):
+        return self._lib.orc_num_edges(self._h)
+
+    def addressing(self, kind):
+        nnz = self._lib.orc_get_addressing(self._h, kind.encode(), None, None)
+        if nnz < 0:
+            raise KeyError(kind)
+        vals = np.empty(nnz, np.int32)
+        if kind == "edges":
+            self._lib.orc_get_addressing(self._h, kind.encode(), None, _p(vals, i32p))
+            return None, vals.reshape(-1, 2)
+        rows = {"pointCells": self.nPoints, "pointFaces": self.nPoints, "pointEdges": self.nPoints,
+                "pointPoints": self.nPoints, "edgeFaces": self.num_edges(), "edgeCells": self.num_edges(),
+                "cellFaces": self.nCells}[kind]
+        off = np.empty(rows + 1, np.int32)
+        self._lib.orc_get_addressing(self._h, kind.encode(), _p(off, i32p), _p(vals, i32p))
+        return off, vals
+
+
+class MultiOracle:
+    """Several Domains in lock-step with syncPointList semantics (the reference under mpirun)."""
+
+    def __init__(self, oracles, sharedOff, sharedDomain, sharedLocal):
+        self._lib = lib()
+        self._oracles = oracles
+        arr = (C.c_void_p * len(oracles))(*[o._h for o in oracles])
+        self._h = self._lib.orc_multi_create(len(oracles), arr)
+        so = np.ascontiguousarray(sharedOff, np.int32)
+        sd = np.ascontiguousarray(sharedDomain, np.int32)
+        sl = np.ascontiguousarray(sharedLocal, np.int32)
+        self._lib.orc_multi_set_shared(self._h, len(so) - 1, _p(so, i32p), _p(sd, i32p), _p(sl, i32p))
+
+    def iterate(self, nIters, relTol=0.02):
+        res = np.zeros(max(nIters, 1), np.float64)
+        frz = np.zeros(max(nIters, 1), np.int32)
+        n = self._lib.orc_multi_iterate(self._h, nIters, relTol, _p(res, f64p), _p(frz, i32p))
+        if n < 0:
+            raise RuntimeError("oracle multi-domain iterate failed")
+        return n, res[:n].copy(), frz[:n].astype(np.int64)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.orc_multi_destroy(self._h)
+            self._h = None
+
+
+def edgeEdgeAngle(c, p1, p2):
+    a, pa = _v(c); b, pb = _v(p1); d, pd = _v(p2)
+    return lib().orc_edgeEdgeAngle(pa, pb, pd)
+
+
+def calcEdgeCenterEdgeAngle(p0, cC, p1):
+    a, pa = _v(p0); b, pb = _v(cC); d, pd = _v(p1)
+    return lib().orc_calcEdgeCenterEdgeAngle(pa, pb, pd)
+
+
+def isCloserPoint(a, b):
+    x, px = _v(a); y, py = _v(b)
+    return bool(lib().orc_isCloserPoint(px, py))

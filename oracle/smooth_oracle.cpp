@@ -1,0 +1,748 @@
+// smooth_oracle.cpp -- CPU restatement of the reference's smoothing iteration loop.
+// TEST INFRASTRUCTURE ONLY (see smooth_oracle.hpp).  PARITY UNPINNED (see header).
+//
+// Build: g++ -O2 -std=c++17 -ffp-contract=off  (no FMA contraction, no fast-math: the
+// x86-64 reference build evaluates every expression in plain IEEE f64, left to right).
+//
+// Every function cites the reference lines it follows (SM.C = src/smoothMesh.C).
+#include "smooth_oracle.hpp"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <map>
+#include <numeric>
+#include <stack>
+
+namespace orc {
+
+// ---- OpenFOAM Vector<double> algebra (VectorI.H / VectorSpaceI.H semantics) ----------
+static inline Vec3 operator+(const Vec3& a, const Vec3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+static inline Vec3 operator-(const Vec3& a, const Vec3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+static inline Vec3 operator*(double s, const Vec3& a) { return {s * a.x, s * a.y, s * a.z}; }
+static inline Vec3 operator/(const Vec3& a, double s) { return {a.x / s, a.y / s, a.z / s}; }
+static inline Vec3& operator+=(Vec3& a, const Vec3& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
+static inline Vec3& operator/=(Vec3& a, double s) { a.x /= s; a.y /= s; a.z /= s; return a; }
+static inline bool operator==(const Vec3& a, const Vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+static inline bool operator!=(const Vec3& a, const Vec3& b) { return !(a == b); }
+static inline double dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // operator&
+static inline Vec3 cross(const Vec3& a, const Vec3& b) {                                              // operator^
+    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+static inline double magSqr(const Vec3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+static inline double mag(const Vec3& a) { return std::sqrt(magSqr(a)); }
+static const Vec3 ZERO_VECTOR{0.0, 0.0, 0.0};          // COM.H:16
+static const Vec3 UNDEF_VECTOR{GREAT, GREAT, GREAT};   // COM.H:15
+
+// SM.C:172-180
+static inline double getPointDistance(const Vec3& coords1, const Vec3& coords2) {
+    const Vec3 v = coords2 - coords1;
+    return mag(v);
+}
+
+// SM.C:766-786
+double edgeEdgeAngle(const Vec3& cCoords, const Vec3& p1Coords, const Vec3& p2Coords) {
+    Vec3 vec1 = (p1Coords - cCoords);
+    Vec3 vec2 = (p2Coords - cCoords);
+    vec1 /= mag(vec1);
+    vec2 /= mag(vec2);
+    const double cosA = dot(vec1, vec2);
+    const double MAX = 0.99999;
+    // std::max/std::min argument order kept: a NaN cosA maps to +MAX
+    const double cosAlpha = std::max(-MAX, std::min(MAX, cosA));
+    return std::acos(cosAlpha);
+}
+
+// SM.C:980-998
+double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1) {
+    const double cosA0 = dot(p0, cC);
+    const double cosA1 = dot(cC, p1);
+    const double MAX = 0.99999;
+    const double cosAlpha0 = std::max(-MAX, std::min(MAX, cosA0));
+    const double angle0 = std::acos(cosAlpha0);
+    const double cosAlpha1 = std::max(-MAX, std::min(MAX, cosA1));
+    const double angle1 = std::acos(cosAlpha1);
+    return angle0 + angle1;
+}
+
+// SM.C:222-239
+static bool isSmallerByVectorElements(const Vec3& v1, const Vec3& v2) {
+    const double a[3] = {v1.x, v1.y, v1.z}, b[3] = {v2.x, v2.y, v2.z};
+    for (int i = 0; i < 3; ++i) {
+        if (a[i] < b[i]) return true;
+        else if (a[i] > b[i]) return false;
+    }
+    return false;
+}
+
+// SM.C:246-272
+bool isCloserPoint(const Vec3& point1, const Vec3& point2) {
+    if (point1 == point2) return false;
+    const double deltaDistance = mag(point1) - mag(point2);
+    if (deltaDistance < VSMALL) return true;
+    else if ((std::abs(deltaDistance) < VSMALL) && isSmallerByVectorElements(point1, point2)) return true;
+    return false;
+}
+
+// ---- addressing -----------------------------------------------------------------------
+static int findIndex(const std::vector<int>& l, int v) {
+    for (size_t i = 0; i < l.size(); ++i)
+        if (l[i] == v) return int(i);
+    return -1;
+}
+
+void Domain::build() {
+    error.clear();
+    nFaces = int(faces.size());
+    nInternalFaces = int(neighbour.size());
+
+    // OpenFOAM primitiveMesh::calcCells: owned faces ascending, then neighboured faces ascending
+    std::vector<std::vector<int>> cells(nCells);
+    for (int f = 0; f < nFaces; ++f) cells[owner[f]].push_back(f);
+    for (int f = 0; f < nInternalFaces; ++f) cells[neighbour[f]].push_back(f);
+
+    // cellPoints: cell::labels(faces) = first-appearance order walking the cell's faces
+    cellPoints.assign(nCells, {});
+    for (int c = 0; c < nCells; ++c)
+        for (int f : cells[c])
+            for (int p : faces[f])
+                if (findIndex(cellPoints[c], p) < 0) cellPoints[c].push_back(p);
+
+    // pointCells: OpenFOAM calcPointCells walks cells ascending -> ascending cell id
+    pointCells.assign(nPoints, {});
+    for (int c = 0; c < nCells; ++c)
+        for (int p : cellPoints[c]) pointCells[p].push_back(c);
+
+    // pointFaces: invertManyToMany(nPoints, faces) -> ascending face id
+    pointFaces.assign(nPoints, {});
+    for (int f = 0; f < nFaces; ++f)
+        for (int p : faces[f]) pointFaces[p].push_back(f);
+
+    // edges: OpenFOAM primitiveMesh::calcEdges, unsorted-points branch (nInternalPoints_ == -1):
+    // edges stored (min,max) and renumbered into upper-triangular order (start ascending,
+    // then end ascending); pointEdges sorted ascending; pointPoints[p][i] = other end of
+    // pointEdges[p][i]  (=> ascending neighbour point id).
+    std::map<std::pair<int, int>, int> edgeMap;
+    for (int f = 0; f < nFaces; ++f) {
+        const auto& fp = faces[f];
+        const int n = int(fp.size());
+        for (int i = 0; i < n; ++i) {
+            const int a = fp[i], b = fp[(i + 1) % n];
+            edgeMap.emplace(std::make_pair(std::min(a, b), std::max(a, b)), 0);
+        }
+    }
+    edges.clear();
+    edges.reserve(edgeMap.size());
+    for (auto& kv : edgeMap) {
+        kv.second = int(edges.size());
+        edges.push_back({kv.first.first, kv.first.second});
+    }
+    const int nEdges = int(edges.size());
+    pointEdges.assign(nPoints, {});
+    for (int e = 0; e < nEdges; ++e) {
+        pointEdges[edges[e][0]].push_back(e);
+        pointEdges[edges[e][1]].push_back(e);
+    }
+    pointPoints.assign(nPoints, {});
+    for (int p = 0; p < nPoints; ++p)
+        for (int e : pointEdges[p]) pointPoints[p].push_back(edges[e][0] == p ? edges[e][1] : edges[e][0]);
+
+    // edgeFaces: ascending face id
+    edgeFaces.assign(nEdges, {});
+    for (int f = 0; f < nFaces; ++f) {
+        const auto& fp = faces[f];
+        const int n = int(fp.size());
+        for (int i = 0; i < n; ++i) {
+            const int a = fp[i], b = fp[(i + 1) % n];
+            const int e = edgeMap[std::make_pair(std::min(a, b), std::max(a, b))];
+            edgeFaces[e].push_back(f);
+        }
+    }
+    // edgeCells: primitiveMesh::edgeCells(edgeI, storage) on-the-fly form = first appearance
+    // walking edgeFaces (owner then neighbour).  Only min/max reductions consume it.
+    edgeCells.assign(nEdges, {});
+    for (int e = 0; e < nEdges; ++e)
+        for (int f : edgeFaces[e]) {
+            if (findIndex(edgeCells[e], owner[f]) < 0) edgeCells[e].push_back(owner[f]);
+            if (f < nInternalFaces && findIndex(edgeCells[e], neighbour[f]) < 0) edgeCells[e].push_back(neighbour[f]);
+        }
+
+    // SM.C:1575-1620 generateCellFaces: internal faces by owner, internal faces by neighbour,
+    // then boundary faces patch by patch (= ascending face id)
+    cellFaces.assign(nCells, {});
+    for (int f = 0; f < nInternalFaces; ++f) cellFaces[owner[f]].push_back(f);
+    for (int f = 0; f < nInternalFaces; ++f) cellFaces[neighbour[f]].push_back(f);
+    for (int f = nInternalFaces; f < nFaces; ++f) cellFaces[owner[f]].push_back(f);
+
+    // SM.C:190-217 generatePointNeighPoints
+    pointNeighPoints.assign(nPoints, {});
+    for (int p = 0; p < nPoints; ++p)
+        for (int c : pointCells[p])
+            for (int q : cellPoints[c]) {
+                if (p == q) continue;
+                if (findIndex(pointNeighPoints[p], q) == -1) pointNeighPoints[p].push_back(q);
+            }
+
+    isFrozenPoint.assign(nPoints, 0);
+}
+
+// SM.C:1478-1541 (edge length part)
+void Domain::meshStats(double& minEdge, double& maxEdge) const {
+    double minLength = VGREAT, maxLength = 0.0;
+    for (const auto& e : edges) {
+        const Vec3 startCoords = points[e[0]];
+        const Vec3 endCoords = points[e[1]];
+        const double length = mag(endCoords - startCoords);
+        if (length < minLength) minLength = length;
+        if (length > maxLength) maxLength = length;
+    }
+    minEdge = minLength;
+    maxEdge = maxLength;
+}
+
+// ---- OpenFOAM primitiveMesh geometry (triggered by mesh.cellCentres(), SM.C:129) -------
+void Domain::updateGeometry() {
+    const std::vector<Vec3>& p = points;
+    faceCentres.resize(nFaces);
+    faceAreas.resize(nFaces);
+    // primitiveMesh::makeFaceCentresAndAreas (.com v2412)
+    for (int facei = 0; facei < nFaces; ++facei) {
+        const std::vector<int>& f = faces[facei];
+        const int nP = int(f.size());
+        if (nP == 3) {
+            faceCentres[facei] = (1.0 / 3.0) * (p[f[0]] + p[f[1]] + p[f[2]]);
+            faceAreas[facei] = 0.5 * cross(p[f[1]] - p[f[0]], p[f[2]] - p[f[0]]);
+        } else {
+            Vec3 sumN = ZERO_VECTOR;
+            double sumA = 0.0;
+            Vec3 sumAc = ZERO_VECTOR;
+            Vec3 fCentre = p[f[0]];
+            for (int pi = 1; pi < nP; ++pi) fCentre += p[f[pi]];
+            fCentre /= double(nP);
+            for (int pi = 0; pi < nP; ++pi) {
+                const int nextPi = (pi == nP - 1 ? 0 : pi + 1);
+                const Vec3 nextPoint = p[f[nextPi]];
+                const Vec3 thisPoint = p[f[pi]];
+                const Vec3 c = thisPoint + nextPoint + fCentre;
+                const Vec3 n = cross(nextPoint - thisPoint, fCentre - thisPoint);
+                const double a = mag(n);
+                sumN += n;
+                sumA += a;
+                sumAc += a * c;
+            }
+            if (sumA < ROOTVSMALL) {
+                faceCentres[facei] = fCentre;
+                faceAreas[facei] = ZERO_VECTOR;
+            } else {
+                faceCentres[facei] = ((1.0 / 3.0) * sumAc) / sumA;
+                faceAreas[facei] = 0.5 * sumN;
+            }
+        }
+    }
+    // primitiveMesh::makeCellCentresAndVols (.com v2412)
+    std::vector<Vec3> cEst(nCells, ZERO_VECTOR);
+    std::vector<int> nCellFaces(nCells, 0);
+    cellCentres.assign(nCells, ZERO_VECTOR);
+    std::vector<double> cellVols(nCells, 0.0);
+    for (int facei = 0; facei < nFaces; ++facei) {
+        cEst[owner[facei]] += faceCentres[facei];
+        ++nCellFaces[owner[facei]];
+    }
+    for (int facei = 0; facei < nInternalFaces; ++facei) {
+        cEst[neighbour[facei]] += faceCentres[facei];
+        ++nCellFaces[neighbour[facei]];
+    }
+    for (int celli = 0; celli < nCells; ++celli) cEst[celli] /= double(nCellFaces[celli]);
+    for (int facei = 0; facei < nFaces; ++facei) {
+        const Vec3 fc = faceCentres[facei];
+        const Vec3 fA = faceAreas[facei];
+        const double pyr3Vol = dot(fA, fc - cEst[owner[facei]]);
+        const Vec3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst[owner[facei]];
+        cellCentres[owner[facei]] += pyr3Vol * pc;
+        cellVols[owner[facei]] += pyr3Vol;
+    }
+    for (int facei = 0; facei < nInternalFaces; ++facei) {
+        const Vec3 fc = faceCentres[facei];
+        const Vec3 fA = faceAreas[facei];
+        const double pyr3Vol = dot(fA, cEst[neighbour[facei]] - fc);
+        const Vec3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst[neighbour[facei]];
+        cellCentres[neighbour[facei]] += pyr3Vol * pc;
+        cellVols[neighbour[facei]] += pyr3Vol;
+    }
+    for (int celli = 0; celli < nCells; ++celli) {
+        if (std::abs(cellVols[celli]) > VSMALL) cellCentres[celli] /= cellVols[celli];
+        else cellCentres[celli] = cEst[celli];
+    }
+}
+
+// SM.C:277-308
+static int findAppropriateClosestPointLabel(const std::vector<int>& pointPoints, const std::vector<int>& sLabels,
+                                            int pointI, const std::vector<unsigned char>& isInternalPoint,
+                                            int stride) {
+    const bool isThisInternalPoint = isInternalPoint[pointI];
+    int counter = 0;
+    for (size_t i = 0; i < sLabels.size(); ++i) {
+        const int labelI = sLabels[i];
+        if ((!isThisInternalPoint) && (isInternalPoint[pointPoints[labelI]])) continue;
+        if (counter == stride) return labelI;
+        ++counter;
+    }
+    return -1;  // UNDEF_LABEL
+}
+
+// SM.C:489-543
+static double calcARSmoothingRatio(const Vec3& closestPoint1, const Vec3& closestPoint2, const Vec3& closestPoint3,
+                                   bool hasCommonCell, bool isInternalPoint) {
+    if (hasCommonCell) return 0.0;
+    if ((closestPoint1 == ZERO_VECTOR) || (closestPoint2 == ZERO_VECTOR)) return 0.0;
+    const double lengthRatio1 = mag(closestPoint2) / mag(closestPoint1);
+    const double lengthRatio2 = mag(closestPoint3) / mag(closestPoint2);
+    if (isInternalPoint) {
+        const double minRatio = 1.5;
+        const double maxRatio = 3.0;
+        if ((lengthRatio1 < minRatio) && (lengthRatio2 > minRatio)) {
+            const double frac = (lengthRatio2 - minRatio) / (maxRatio - minRatio);
+            const double blendFrac = std::min(1.0, std::max(0.0, frac));
+            return blendFrac;
+        }
+    } else {
+        const double minRatio = 1.0;
+        const double maxRatio = 2.0;
+        const double frac = (lengthRatio1 - minRatio) / (maxRatio - minRatio);
+        const double blendFrac = std::min(1.0, std::max(0.0, frac));
+        return blendFrac;
+    }
+    return 0.0;
+}
+
+void Domain::phaseA() {
+    // SM.C:2262 reset frozen points
+    isFrozenPoint.assign(nPoints, 0);
+    updateGeometry();
+
+    // SM.C:108-131 (doBoundarySmoothing == false: internal points only)
+    cellSum.assign(nPoints, ZERO_VECTOR);
+    cellCount.assign(nPoints, 0);
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (!isInternalPoint[pointI]) continue;
+        const std::vector<int>& pCells = pointCells[pointI];
+        cellCount[pointI] = int(pCells.size());
+        for (int celli : pCells) cellSum[pointI] += cellCentres[celli];
+    }
+
+    // SM.C:325-387 local closest edge points
+    closest1.assign(nPoints, ZERO_VECTOR);
+    closest2.assign(nPoints, ZERO_VECTOR);
+    closest3.assign(nPoints, ZERO_VECTOR);
+    hasCommonCell.assign(nPoints, 0);
+    std::vector<double> edgeLengths;
+    std::vector<int> sLabels;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        const Vec3 cCoords = points[pointI];
+        const std::vector<int>& pp = pointPoints[pointI];
+        const int n = int(pp.size());
+        edgeLengths.assign(n, 0.0);
+        for (int i = 0; i < n; ++i) edgeLengths[i] = getPointDistance(points[pp[i]], cCoords);
+        // Foam::sortedOrder = stable sort of indices by value
+        sLabels.resize(n);
+        std::iota(sLabels.begin(), sLabels.end(), 0);
+        std::stable_sort(sLabels.begin(), sLabels.end(),
+                         [&](int a, int b) { return edgeLengths[a] < edgeLengths[b]; });
+        const int cLabel1 = findAppropriateClosestPointLabel(pp, sLabels, pointI, isInternalPoint, 0);
+        const int cLabel2 = findAppropriateClosestPointLabel(pp, sLabels, pointI, isInternalPoint, 1);
+        const int cLabel3 = findAppropriateClosestPointLabel(pp, sLabels, pointI, isInternalPoint, 2);
+        if (cLabel1 < 0 || cLabel2 < 0) {
+            error = "Failed to find cLabel1/cLabel2 for pointI " + std::to_string(pointI);  // SM.C:354-362
+            return;
+        }
+        closest1[pointI] = points[pp[cLabel1]] - cCoords;
+        closest2[pointI] = points[pp[cLabel2]] - cCoords;
+        if (cLabel3 < 0) closest3[pointI] = UNDEF_VECTOR;
+        else closest3[pointI] = points[pp[cLabel3]] - cCoords;
+        hasCommonCell[pointI] = (findIndex(pointNeighPoints[pp[cLabel1]], pp[cLabel2]) >= 0) ? 1 : 0;
+    }
+}
+
+// SM.C:1135-1231 (with calcFaceCenter :1103-1130, findCellFacePair :1042-1097,
+// calcMinMaxFinalProjectedAngle :1003-1037)
+void Domain::calcMinMaxFaceAngleForEdge(int edgeI, double& minFaceAngle, double& maxFaceAngle, int pointI1,
+                                        const Vec3& coords1, int pointI2, const Vec3& coords2) const {
+    const std::vector<int>& eFaces = edgeFaces[edgeI];
+    const int nF = int(eFaces.size());
+    const int e0I = edges[edgeI][0];
+    Vec3 e0 = points[e0I];
+    if ((pointI1 >= 0) && (e0I == pointI1)) e0 = coords1;
+    else if ((pointI2 >= 0) && (e0I == pointI2)) e0 = coords2;
+    const int e1I = edges[edgeI][1];
+    Vec3 e1 = points[e1I];
+    if ((pointI1 >= 0) && (e1I == pointI1)) e1 = coords1;
+    else if ((pointI2 >= 0) && (e1I == pointI2)) e1 = coords2;
+
+    const Vec3 cCoords = 0.5 * (e0 + e1);
+    const Vec3 eVec = (e1 - e0) / mag(e1 - e0);
+
+    std::vector<Vec3> pVecs(nF, UNDEF_VECTOR);
+    for (int i = 0; i < nF; ++i) {
+        const int faceI = eFaces[i];
+        // calcFaceCenter SM.C:1103-1130
+        Vec3 center{0, 0, 0};
+        for (int pointI : faces[faceI]) {
+            if ((pointI1 >= 0) && (pointI == pointI1)) center += coords1;
+            else if ((pointI2 >= 0) && (pointI == pointI2)) center += coords2;
+            else center += points[pointI];
+        }
+        center /= double(faces[faceI].size());
+        const Vec3 fCoords = center;
+        const Vec3 cf = cCoords - fCoords;
+        const double dotProd = dot(cf, eVec);
+        const Vec3 pCoords = fCoords + dotProd * eVec;
+        const Vec3 cp = (pCoords - cCoords) / mag(pCoords - cCoords);
+        pVecs[i] = cp;
+    }
+
+    double minAngle = 2.0 * M_PI;
+    double maxAngle = 0.0;
+    for (int cellI : edgeCells[edgeI]) {
+        // findCellFacePair
+        int face0I = -1, face1I = -1;
+        for (int faceI : cellFaces[cellI]) {
+            const int faceIsI = findIndex(eFaces, faceI);
+            if (faceIsI >= 0) {
+                if (face0I == -1) face0I = faceIsI;
+                else if (face1I == -1) face1I = faceIsI;
+                else { const_cast<Domain*>(this)->error = "more than two edge faces belong to same cell"; return; }
+            }
+        }
+        if (face0I == -1 || face1I == -1 || face0I == face1I) {
+            const_cast<Domain*>(this)->error = "didn't find face pairs for cell " + std::to_string(cellI);
+            return;
+        }
+        const Vec3 cellCenter = cellCentres[cellI];  // mesh.C()[cellI], SM.C:1218
+        const Vec3 cf = cCoords - cellCenter;
+        const double dotProd = dot(cf, eVec);
+        const Vec3 pCoords = cellCenter + dotProd * eVec;
+        const Vec3 cp = (pCoords - cCoords) / mag(pCoords - cCoords);
+        const double angle = calcEdgeCenterEdgeAngle(pVecs[face0I], cp, pVecs[face1I]);
+        if (angle < minAngle) minAngle = angle;
+        if (angle > maxAngle) maxAngle = angle;
+    }
+    minFaceAngle = minAngle;
+    maxFaceAngle = maxAngle;
+}
+
+// SM.C:1276-1308
+void Domain::calcMinMaxFaceAngleForPoint(int pointI1, const Vec3& coords1, int pointI2, const Vec3& coords2,
+                                         double& minFaceAngle, double& maxFaceAngle) const {
+    minFaceAngle = 2.0 * M_PI;
+    maxFaceAngle = 0.0;
+    for (int edgeI : pointEdges[pointI1]) {
+        double minAngle, maxAngle;
+        calcMinMaxFaceAngleForEdge(edgeI, minAngle, maxAngle, pointI1, coords1, pointI2, coords2);
+        if (minFaceAngle > minAngle) minFaceAngle = minAngle;
+        if (maxFaceAngle < maxAngle) maxFaceAngle = maxAngle;
+    }
+}
+
+void Domain::phaseB() {
+    const std::vector<Vec3>& mp = points;
+
+    // SM.C:150-163
+    centroidalPoints = points;
+    for (int pointI = 0; pointI < nPoints; ++pointI)
+        if (cellCount[pointI]) centroidalPoints[pointI] = cellSum[pointI] / double(cellCount[pointI]);
+
+    // SM.C:566-590 aspectRatioSmoothing
+    newPoints = centroidalPoints;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        const double blendFrac = calcARSmoothingRatio(closest1[pointI], closest2[pointI], closest3[pointI],
+                                                      hasCommonCell[pointI], isInternalPoint[pointI]);
+        if (blendFrac > 0.0) {
+            const Vec3 aCoords = mp[pointI] + (closest1[pointI] + closest2[pointI]) / 2.0;
+            const Vec3 newCoords = (1.0 - blendFrac) * centroidalPoints[pointI] + blendFrac * aCoords;
+            newPoints[pointI] = newCoords;
+        }
+    }
+    arPoints = newPoints;
+
+    // SM.C:684-754 constrainMaxStepLength(doGlobalScaling = false)
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        const Vec3 cCoords = mp[pointI];
+        const Vec3 stepDir = newPoints[pointI] - cCoords;
+        double globalScale;
+        if (mag(stepDir) > prm.maxStepLength) globalScale = prm.maxStepLength / (mag(stepDir) * prm.relStepFrac);
+        else globalScale = 1.0;
+        const Vec3 nCoords = cCoords + (prm.relStepFrac * globalScale) * stepDir;
+        newPoints[pointI] = nCoords;
+    }
+
+    // SM.C:602-652 restrictEdgeShortening
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (isFrozenPoint[pointI]) continue;
+        const Vec3 cCoords = mp[pointI];
+        const Vec3 nCoords = newPoints[pointI];
+        double shortestCurrentEdgeLength = GREAT;
+        double shortestNewEdgeLength = GREAT;
+        for (int neighI : pointPoints[pointI]) {
+            const double testCurrentLength = getPointDistance(mp[neighI], cCoords);
+            if (testCurrentLength < shortestCurrentEdgeLength) shortestCurrentEdgeLength = testCurrentLength;
+            const double testNewLength = getPointDistance(mp[neighI], nCoords);
+            if (testNewLength < shortestNewEdgeLength) shortestNewEdgeLength = testNewLength;
+        }
+        const double shortestLength = std::min(shortestNewEdgeLength, shortestCurrentEdgeLength);
+        if (prm.totalMinFreeze && (shortestLength < prm.minEdgeLength)) isFrozenPoint[pointI] = 1;
+        else if ((shortestNewEdgeLength < prm.minEdgeLength) && (shortestNewEdgeLength < shortestCurrentEdgeLength))
+            isFrozenPoint[pointI] = 1;
+    }
+    frozenAfterEdgeLen = isFrozenPoint;
+
+    // SM.C:900-930 restrictMinEdgeAngleDecrease (+ calc_min_edge_angles :837-894,
+    // getNeighbourPoints :793-831)
+    eaMinC.assign(nPoints, 0.0);
+    eaMinN.assign(nPoints, 0.0);
+    if (prm.edgeAngleConstraint) {
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            if (isFrozenPoint[pointI]) continue;
+            double minCAngle = DBL_MAX;
+            double minNAngle = DBL_MAX;
+            for (int faceI : pointFaces[pointI]) {
+                const std::vector<int>& facePoints = faces[faceI];
+                const int nP = int(facePoints.size());
+                int neighPI1 = 0, neighPI2 = 0;
+                for (int i = 0; i < nP; ++i) {
+                    if (facePoints[i] == pointI) {
+                        const int prevI = (i == 0) ? nP - 1 : i - 1;
+                        const int nextI = (i == nP - 1) ? 0 : i + 1;
+                        neighPI1 = facePoints[prevI];
+                        neighPI2 = facePoints[nextI];
+                        break;
+                    }
+                }
+                const Vec3 cp0 = mp[pointI];
+                const Vec3 cp1 = mp[neighPI1];
+                const Vec3 cp2 = mp[neighPI2];
+                const double cAngle = edgeEdgeAngle(cp0, cp1, cp2);
+                const Vec3 np0 = newPoints[pointI];
+                const double nAngle0 = edgeEdgeAngle(np0, cp1, cp2);
+                const Vec3 np1 = newPoints[neighPI1];
+                const Vec3 np2 = newPoints[neighPI2];
+                const double nAngle1 = edgeEdgeAngle(np0, np1, np2);
+                const double nAngle2 = edgeEdgeAngle(np0, cp1, np2);
+                const double nAngle3 = edgeEdgeAngle(np0, np1, cp2);
+                const double nAngle = std::min(std::min(std::min(nAngle0, nAngle1), nAngle2), nAngle3);
+                if (cAngle < minCAngle) minCAngle = cAngle;
+                if (nAngle < minNAngle) minNAngle = nAngle;
+            }
+            eaMinC[pointI] = minCAngle;
+            eaMinN[pointI] = minNAngle;
+            const double smallAngle = M_PI * prm.minAngle / 180.0;
+            if ((minNAngle < smallAngle) && (minNAngle < minCAngle)) isFrozenPoint[pointI] = 1;
+        }
+    }
+    frozenAfterEdgeAngle = isFrozenPoint;
+
+    // SM.C:1320-1437 restrictFaceAngleDeterioration
+    if (prm.faceAngleConstraint) {
+        const int nEdges = int(edges.size());
+        edgeMinAngle.assign(nEdges, GREAT);
+        edgeMaxAngle.assign(nEdges, GREAT);
+        // SM.C:1252-1270
+        for (int edgeI = 0; edgeI < nEdges; ++edgeI) {
+            double minAngle, maxAngle;
+            calcMinMaxFaceAngleForEdge(edgeI, minAngle, maxAngle, -1, ZERO_VECTOR, -1, ZERO_VECTOR);
+            if (!error.empty()) return;
+            edgeMinAngle[edgeI] = minAngle;
+            edgeMaxAngle[edgeI] = maxAngle;
+        }
+        // SM.C:938-975
+        pointMinAngle.assign(nPoints, 2.0 * M_PI);
+        pointMaxAngle.assign(nPoints, 0.0);
+        for (int edgeI = 0; edgeI < nEdges; ++edgeI) {
+            for (int k = 0; k < 2; ++k) {
+                const int pointI = edges[edgeI][k];
+                if (pointMinAngle[pointI] > edgeMinAngle[edgeI]) pointMinAngle[pointI] = edgeMinAngle[edgeI];
+                if (pointMaxAngle[pointI] < edgeMaxAngle[edgeI]) pointMaxAngle[pointI] = edgeMaxAngle[edgeI];
+            }
+        }
+        // SM.C:1347-1434 stack walk
+        std::stack<int> pointStack;
+        for (int pointI = 0; pointI < nPoints; ++pointI) pointStack.push(pointI);
+        const double smallAngle = M_PI * prm.minAngle / 180.0;
+        const double largeAngle = M_PI * prm.maxAngle / 180.0;
+        while (!pointStack.empty()) {
+            const int pointI = pointStack.top();
+            pointStack.pop();
+            if ((pointMinAngle[pointI] > smallAngle) && (pointMaxAngle[pointI] < largeAngle)) continue;
+            const Vec3 cCoords = mp[pointI];
+            Vec3 nCoords = newPoints[pointI];
+            if (isFrozenPoint[pointI]) nCoords = cCoords;
+            if (nCoords != cCoords) {
+                double newMinFaceAngle, newMaxFaceAngle;
+                calcMinMaxFaceAngleForPoint(pointI, nCoords, -1, nCoords, newMinFaceAngle, newMaxFaceAngle);
+                if (((newMinFaceAngle < smallAngle) && (newMinFaceAngle < pointMinAngle[pointI])) ||
+                    ((newMaxFaceAngle > largeAngle) && (newMaxFaceAngle > pointMaxAngle[pointI]))) {
+                    nCoords = cCoords;
+                    isFrozenPoint[pointI] = 1;
+                }
+            }
+            for (int neighPointI : pointPoints[pointI]) {
+                const Vec3 neighCoords = newPoints[neighPointI];
+                if (isFrozenPoint[neighPointI]) continue;
+                if (neighCoords == mp[neighPointI]) continue;
+                double newMinFaceAngle, newMaxFaceAngle;
+                calcMinMaxFaceAngleForPoint(pointI, nCoords, neighPointI, neighCoords, newMinFaceAngle,
+                                            newMaxFaceAngle);
+                if (((newMinFaceAngle < smallAngle) && (newMinFaceAngle < pointMinAngle[pointI])) ||
+                    ((newMaxFaceAngle > largeAngle) && (newMaxFaceAngle > pointMaxAngle[pointI]))) {
+                    isFrozenPoint[neighPointI] = 1;
+                    pointStack.push(neighPointI);
+                }
+            }
+        }
+    }
+    frozenAfterFaceAngle = isFrozenPoint;
+}
+
+void Domain::phaseC() {
+    // SM.C:2384-2392
+    nFrozenLocal = 0;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (isFrozenPoint[pointI] || ((!isInternalPoint[pointI]) && (!isSmoothingSurfacePoint[pointI]))) {
+            newPoints[pointI] = points[pointI];
+            ++nFrozenLocal;
+        }
+    }
+    // SM.C:1546-1565
+    double maxStep = 0.0;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        const double distance = mag(newPoints[pointI] - points[pointI]) / prm.maxStepLength;
+        if (distance > maxStep) maxStep = distance;
+    }
+    residualLocal = maxStep;
+}
+
+void Domain::commit() { points = newPoints; }  // SM.C:2399 mesh.movePoints
+
+// SM.C:2257-2437 (single rank: every syncPointList/returnReduce is the identity)
+int Domain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) {
+    int done = 0;
+    for (int i = 0; i < nIters; ++i) {
+        phaseA();
+        if (!error.empty()) return -1;
+        phaseB();
+        if (!error.empty()) return -1;
+        phaseC();
+        const double res = residualLocal;
+        if (residuals) residuals[i] = res;
+        if (nFrozen) nFrozen[i] = nFrozenLocal;
+        commit();
+        ++done;
+        if (res < relTol) break;  // SM.C:2401-2405
+    }
+    return done;
+}
+
+// ---- multi-domain (MPI ranks of the reference, emulated in one process) ---------------
+// syncTools::syncPointList model used here (OpenFOAM is not in the reference tree):
+//  * plusEqOp: all partial values are summed in ascending domain order, same result on
+//    every sharer;
+//  * minMagSqrEqOp (ops.H: x = (magSqr(x) <= magSqr(y) ? x : y)): every sharer folds
+//    starting from ITS OWN value, then the other sharers' values in ascending domain order
+//    (processor-patch exchange: cop(myValue, nbrValue)), so an exact tie keeps the own value;
+//  * orEqOp: logical or.
+void MultiDomain::syncA() {
+    for (const SharedPoint& sp : shared) {
+        const int n = int(sp.domain.size());
+        // SM.C:134-148
+        Vec3 s = ZERO_VECTOR;
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) {
+            s += dom[sp.domain[j]]->cellSum[sp.local[j]];
+            cnt += dom[sp.domain[j]]->cellCount[sp.local[j]];
+        }
+        for (int j = 0; j < n; ++j) {
+            dom[sp.domain[j]]->cellSum[sp.local[j]] = s;
+            dom[sp.domain[j]]->cellCount[sp.local[j]] = cnt;
+        }
+        // SM.C:391-478: three sequential min-magnitude syncs + or-sync
+        std::vector<Vec3> r1(n), r2(n), r3(n);
+        std::vector<unsigned char> hc(n);
+        for (int j = 0; j < n; ++j) {
+            const Domain* d = dom[sp.domain[j]];
+            r1[j] = d->closest1[sp.local[j]];
+            r2[j] = d->closest2[sp.local[j]];
+            r3[j] = d->closest3[sp.local[j]];
+            hc[j] = d->hasCommonCell[sp.local[j]];
+        }
+        auto fold = [&](const std::vector<Vec3>& v, int self) {
+            Vec3 x = v[self];
+            for (int k = 0; k < n; ++k) {
+                if (k == self) continue;
+                x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
+            }
+            return x;
+        };
+        {   // position 1, SM.C:397-419
+            std::vector<Vec3> sent = r1;
+            for (int j = 0; j < n; ++j) {
+                const Vec3 sv = fold(sent, j);
+                if (isCloserPoint(sv, r1[j])) { r3[j] = r2[j]; r2[j] = r1[j]; r1[j] = sv; hc[j] = 0; }
+            }
+        }
+        {   // position 2, SM.C:424-445
+            std::vector<Vec3> sent = r2;
+            for (int j = 0; j < n; ++j) {
+                const Vec3 sv = fold(sent, j);
+                if (isCloserPoint(sv, r2[j])) { r3[j] = r2[j]; r2[j] = sv; hc[j] = 0; }
+            }
+        }
+        {   // position 3, SM.C:450-469
+            std::vector<Vec3> sent = r3;
+            for (int j = 0; j < n; ++j) {
+                const Vec3 sv = fold(sent, j);
+                if (isCloserPoint(sv, r3[j])) { r3[j] = sv; }
+            }
+        }
+        unsigned char any = 0;  // SM.C:472-478
+        for (int j = 0; j < n; ++j) any |= hc[j];
+        for (int j = 0; j < n; ++j) {
+            Domain* d = dom[sp.domain[j]];
+            d->closest1[sp.local[j]] = r1[j];
+            d->closest2[sp.local[j]] = r2[j];
+            d->closest3[sp.local[j]] = r3[j];
+            d->hasCommonCell[sp.local[j]] = any;
+        }
+    }
+}
+
+void MultiDomain::syncFrozen() {  // SM.C:2374-2380
+    for (const SharedPoint& sp : shared) {
+        unsigned char any = 0;
+        for (size_t j = 0; j < sp.domain.size(); ++j) any |= dom[sp.domain[j]]->isFrozenPoint[sp.local[j]];
+        for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->isFrozenPoint[sp.local[j]] = any;
+    }
+}
+
+int MultiDomain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) {
+    int done = 0;
+    for (int i = 0; i < nIters; ++i) {
+        for (Domain* d : dom) { d->phaseA(); if (!d->error.empty()) return -1; }
+        syncA();
+        for (Domain* d : dom) { d->phaseB(); if (!d->error.empty()) return -1; }
+        syncFrozen();
+        double res = 0.0;
+        int nf = 0;
+        for (Domain* d : dom) {
+            d->phaseC();
+            if (d->residualLocal > res) res = d->residualLocal;  // returnReduce max, SM.C:1567
+            nf += d->nFrozenLocal;                               // returnReduce sum, SM.C:2396
+        }
+        if (residuals) residuals[i] = res;
+        if (nFrozen) nFrozen[i] = nf;
+        for (Domain* d : dom) d->commit();
+        ++done;
+        if (res < relTol) break;
+    }
+    return done;
+}
+
+}  // namespace orc

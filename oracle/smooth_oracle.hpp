@@ -1,0 +1,128 @@
+// smooth_oracle.hpp -- CPU restatement of tkeskita/smoothMesh's centroidal smoothing
+// iteration loop.  TEST INFRASTRUCTURE ONLY: this is the parity oracle and the timed
+// CPU baseline.  Nothing under smoothmesh_amd/ (the product) may include, link or
+// call anything in this directory; only tests/, __graft_entry__.smoke() and
+// bench.py's cpu_baseline leg do.
+//
+// PARITY UNPINNED: the reference (OpenFOAM application, src/smoothMesh.C) cannot be
+// compiled or run in this environment (no OpenFOAM, no MPI) and ships no golden
+// vectors (run_tests.sh only checks for crashes).  This restatement follows the
+// reference function by function (citations below and in the .cpp) and is pinned
+// only by analytic known answers and invariances (tests/test_oracle_*.py).
+//
+// Reference citations are relative to /root/reference/ (SM.C = src/smoothMesh.C,
+// BPS.C = src/boundaryPointSmoothing.C, COM.H = src/smoothMeshCommon.H).
+// OpenFOAM's primitiveMesh geometry/addressing is third-party code that is NOT in the
+// reference tree; it is restated from OpenFOAM (.com v2412 variant, one of the
+// versions accepted by Allwmake:47): primitiveMeshFaceCentresAndAreas.C,
+// primitiveMeshCellCentresAndVols.C, primitiveMeshEdges.C, primitiveMeshPointCells.C.
+#pragma once
+#include <array>
+#include <string>
+#include <vector>
+
+namespace orc {
+
+// OpenFOAM double-precision constants (doubleScalar.H), used at SM.C:259,621,1333,1486.
+constexpr double GREAT = 1.0e+15;
+constexpr double VGREAT = 1.0e+300;
+constexpr double SMALL = 1.0e-15;
+constexpr double VSMALL = 1.0e-300;
+constexpr double ROOTVSMALL = 1.0e-150;
+
+struct Vec3 {
+    double x, y, z;
+};
+
+struct Params {
+    double maxStepLength = 0.0;   // SM.C:1864
+    double relStepFrac = 0.5;     // SM.C:1874
+    double minEdgeLength = 0.0;   // SM.C:1861
+    bool totalMinFreeze = false;  // SM.C:1877
+    bool edgeAngleConstraint = true;  // SM.C:1886
+    bool faceAngleConstraint = true;  // SM.C:1889
+    double minAngle = 35.0;       // SM.C:1880 (degrees)
+    double maxAngle = 160.0;      // SM.C:1883 (degrees)
+};
+
+// One mesh (= one MPI rank's sub-domain in the reference).
+class Domain {
+public:
+    // topology + coordinates (polyMesh content)
+    int nPoints = 0, nCells = 0, nFaces = 0, nInternalFaces = 0;
+    std::vector<Vec3> points;
+    std::vector<std::vector<int>> faces;  // face -> point loop
+    std::vector<int> owner;               // size nFaces (polyMesh::faceOwner)
+    std::vector<int> neighbour;           // size nInternalFaces
+    std::vector<unsigned char> isInternalPoint;          // SM.C:40-91
+    std::vector<unsigned char> isSmoothingSurfacePoint;  // BPS.C:404-412 (all false when
+                                                         // boundary smoothing is off)
+    Params prm;
+
+    // derived addressing (OpenFOAM primitiveMesh orderings)
+    std::vector<std::array<int, 2>> edges;
+    std::vector<std::vector<int>> pointCells, pointFaces, pointEdges, pointPoints;
+    std::vector<std::vector<int>> edgeFaces, edgeCells, cellFaces, cellPoints;
+    std::vector<std::vector<int>> pointNeighPoints;  // SM.C:190-217
+
+    // geometry (OpenFOAM primitiveMesh)
+    std::vector<Vec3> faceCentres, faceAreas, cellCentres;
+
+    // per-iteration fields kept for operator-level parity checks
+    std::vector<Vec3> cellSum;            // SM.C:108 "cellPoints"
+    std::vector<int> cellCount;           // SM.C:110 "nPoints"
+    std::vector<Vec3> closest1, closest2, closest3;  // SM.C:559-561
+    std::vector<unsigned char> hasCommonCell;        // SM.C:564
+    std::vector<Vec3> centroidalPoints;   // SM.C:2269
+    std::vector<Vec3> arPoints;           // after aspectRatioSmoothing, SM.C:2276
+    std::vector<Vec3> newPoints;          // proposal after constrainMaxStepLength, SM.C:2280
+    std::vector<unsigned char> isFrozenPoint;        // SM.C:2009
+    std::vector<unsigned char> frozenAfterEdgeLen, frozenAfterEdgeAngle, frozenAfterFaceAngle;
+    std::vector<double> edgeMinAngle, edgeMaxAngle;    // SM.C:1333-1335
+    std::vector<double> pointMinAngle, pointMaxAngle;  // SM.C:1339-1341
+    std::vector<double> eaMinC, eaMinN;                // SM.C:914-916 per point
+    int nFrozenLocal = 0;
+    double residualLocal = 0.0;
+    std::string error;
+
+    void build();  // addressing from faces/owner/neighbour
+    void meshStats(double& minEdge, double& maxEdge) const;  // SM.C:1478-1541
+
+    void updateGeometry();           // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols
+    void phaseA();                   // geometry, SM.C:108-131 partial sums, SM.C:325-387 local closest
+    void phaseB();                   // SM.C:155-163, 580-590, 684-754, 602-652, 900-930, 1320-1437
+    void phaseC();                   // SM.C:2384-2392 restore+count, SM.C:1556-1565 residual
+    void commit();                   // mesh.movePoints, SM.C:2399
+
+    // single-domain loop SM.C:2257-2437; returns iterations done
+    int iterate(int nIters, double relTol, double* residuals, int* nFrozen);
+
+    // building blocks (public so tests can call them on hand-made inputs)
+    void calcMinMaxFaceAngleForEdge(int edgeI, double& minA, double& maxA, int pointI1,
+                                    const Vec3& coords1, int pointI2, const Vec3& coords2) const;
+    void calcMinMaxFaceAngleForPoint(int pointI1, const Vec3& coords1, int pointI2,
+                                     const Vec3& coords2, double& minA, double& maxA) const;
+};
+
+// Several domains iterated in lock-step with OpenFOAM syncTools::syncPointList
+// semantics at shared points (SM.C:134,142,402-478,2374) and returnReduce (SM.C:1567,2396).
+struct SharedPoint {
+    // one entry per global point that is shared by >= 2 domains
+    std::vector<int> domain;  // ascending domain id
+    std::vector<int> local;   // local point id in that domain
+};
+
+class MultiDomain {
+public:
+    std::vector<Domain*> dom;
+    std::vector<SharedPoint> shared;
+    int iterate(int nIters, double relTol, double* residuals, int* nFrozen);
+    void syncA();
+    void syncFrozen();
+};
+
+double edgeEdgeAngle(const Vec3& c, const Vec3& p1, const Vec3& p2);   // SM.C:766-786
+double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1);  // SM.C:980-998
+bool isCloserPoint(const Vec3& a, const Vec3& b);  // SM.C:246-272
+
+}  // namespace orc

@@ -1,0 +1,104 @@
+"""ctypes binding of include/smgpu.h (the drop-in boundary).  No torch types cross it."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmgpu.so")
+
+c_i32p = C.POINTER(C.c_int32)
+c_f64p = C.POINTER(C.c_double)
+c_u8p = C.POINTER(C.c_uint8)
+
+
+class MeshDesc(C.Structure):
+    _fields_ = [
+        ("nPoints", C.c_int32), ("nCells", C.c_int32), ("nFaces", C.c_int32), ("nInternalFaces", C.c_int32),
+        ("points", c_f64p), ("faceOffsets", c_i32p), ("facePoints", c_i32p), ("owner", c_i32p),
+        ("neighbour", c_i32p), ("isInternalPoint", c_u8p), ("isSmoothingSurfacePoint", c_u8p),
+        ("device", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("maxStepLength", C.c_double), ("relStepFrac", C.c_double), ("minEdgeLength", C.c_double),
+        ("totalMinFreeze", C.c_int32), ("edgeAngleConstraint", C.c_int32), ("faceAngleConstraint", C.c_int32),
+        ("minAngle", C.c_double), ("maxAngle", C.c_double),
+    ]
+
+
+class IterStats(C.Structure):
+    _fields_ = [("residual", C.c_double), ("nFrozenPoints", C.c_int32), ("pad", C.c_int32)]
+
+
+class Sizes(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "nPoints", "nCells", "nFaces", "nInternalFaces", "nEdges", "nnzFacePoints", "nnzPointCells",
+        "nnzPointPoints", "nnzPointFaces", "nnzEdgeFaces", "nnzEdgeCells", "nnzCellFaces", "deviceBytes")]
+
+
+MAX_KERNELS = 16
+
+
+class Counters(C.Structure):
+    _fields_ = [
+        ("nKernels", C.c_int32), ("name", C.c_char_p * MAX_KERNELS), ("ms", C.c_double * MAX_KERNELS),
+        ("launches", C.c_int64 * MAX_KERNELS), ("algoBytesPerLaunch", C.c_int64 * MAX_KERNELS),
+    ]
+
+
+class HaloDesc(C.Structure):
+    _fields_ = [
+        ("nShared", C.c_int32), ("sharedLocal", c_i32p), ("nSend", C.c_int32), ("sendShared", c_i32p),
+        ("nRecv", C.c_int32), ("combOffsets", c_i32p), ("combSlots", c_i32p),
+        ("sendA", C.c_void_p), ("recvA", C.c_void_p), ("sendF", C.c_void_p), ("recvF", C.c_void_p),
+        ("localStats", C.c_void_p),
+    ]
+
+
+# every symbol include/smgpu.h declares: (restype, argtypes)
+SYMBOLS = {
+    "smgpu_last_error": (C.c_char_p, []),
+    "smgpu_version": (C.c_char_p, []),
+    "smgpu_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
+    "smgpu_destroy": (C.c_int, [C.c_void_p]),
+    "smgpu_get_sizes": (C.c_int, [C.c_void_p, C.POINTER(Sizes)]),
+    "smgpu_mesh_stats": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
+    "smgpu_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
+    "smgpu_iterate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(IterStats), c_i32p]),
+    "smgpu_get_points": (C.c_int, [C.c_void_p, c_f64p]),
+    "smgpu_set_points": (C.c_int, [C.c_void_p, c_f64p]),
+    "smgpu_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "smgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),
+    "smgpu_reset_counters": (C.c_int, [C.c_void_p]),
+    "smgpu_halo_configure": (C.c_int, [C.c_void_p, C.POINTER(HaloDesc)]),
+    "smgpu_iter_begin": (C.c_int, [C.c_void_p]),
+    "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
+    "smgpu_iter_end": (C.c_int, [C.c_void_p]),
+    "smgpu_debug_get_field": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p, C.POINTER(C.c_int64)]),
+    "smgpu_debug_get_addressing": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i32p, C.POINTER(C.c_int64)]),
+    "smgpu_debug_propose": (C.c_int, [C.c_void_p]),
+    "smgpu_topology_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
+    "smgpu_topology_get": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i32p, C.POINTER(C.c_int64)]),
+    "smgpu_topology_num_edges": (C.c_int, [C.c_void_p, c_i32p]),
+    "smgpu_topology_destroy": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load csrc/libsmgpu.so.  There is no fallback: a missing library is an error."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C smoothmesh_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(l, name)  # AttributeError = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib

@@ -1,0 +1,698 @@
+// kernels.hpp -- HIP kernels (gfx950, wave64) for the smoothing iteration.
+//
+// Compiled with -ffp-contract=off: every expression keeps the reference's evaluation order so
+// that coordinates are bit-comparable with the x86-64 reference arithmetic (sqrt and division
+// are correctly rounded on both; only acos, which feeds threshold comparisons only, differs in
+// its last bits between glibc and ROCm's ocml).
+//
+// Reference lines restated by each kernel are cited at the kernel (SM.C = src/smoothMesh.C).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/smgpu.h"
+#include "vec3.hpp"
+
+namespace smgpu {
+
+constexpr int kBlock = 256;
+
+// point flag bits
+constexpr uint8_t PF_INTERNAL = 1;   // isInternalPoint, SM.C:40-91
+constexpr uint8_t PF_SMOOTHSURF = 2; // isSmoothingSurfacePoint, BPS.C:404-412
+
+struct MeshView {
+    int nPoints, nCells, nFaces, nInternalFaces, nEdges;
+    const int* faceOff; const int* facePts;
+    const int* cfOff; const int* cfVal;          // cell -> faces, geometry order, bit31 = neighbour side
+    const int* pcOff; const int* pcVal;          // pointCells
+    const int* ppOff; const int* ppPt; const int* peEdge;  // pointPoints / pointEdges (shared offsets)
+    const int* pfOff; const int* pfPrev; const int* pfNext;  // pointFaces entries -> prev/next vertex
+    const int* edges;                             // 2 per edge
+    const int* efOff; const int* efFace;          // edgeFaces
+    const int* ecOff; const int* ecCell; const uint8_t* ecF0; const uint8_t* ecF1;  // edgeCells + face pair
+    const uint8_t* pflags;
+};
+
+struct Accum {                 // per-iteration device accumulators
+    unsigned long long resBits;  // max over points of |new-cur| / maxStepLength, as f64 bits (>= 0)
+    int nFrozen;
+    int nActive;               // face-angle walk: points outside the good range
+    int stop;                  // set once residual < relTol (SM.C:2401)
+    int err;                   // 1 = fewer than two closest points (SM.C:354-362)
+    int pad;
+};
+
+struct State {
+    double* ptsCur; double* ptsNext; double* prop;
+    double* fCtr; double* fArea; double* fAvg; double* cellCtr;
+    uint8_t* frozen;
+    double* edgeMin; double* edgeMax; double* ptMin; double* ptMax;
+    uint8_t* faActive; uint8_t* faS; uint8_t* faN; int* walkStack;
+    Accum* acc;
+    smgpu_iter_stats* stats;
+    const int* sharedSlot;     // multi-rank: per point slot into combA, or -1 (NULL on one rank)
+    const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
+};
+
+struct Prm {
+    double maxStep, relStepFrac, minEdge;
+    int totalMinFreeze;
+    double smallAngle, largeAngle;   // M_PI * deg / 180.0  (SM.C:921, 1364-1365)
+};
+
+// ---------------------------------------------------------------------------------------------
+// SM.C:766-786 edgeEdgeAngle
+__device__ __forceinline__ double clampAcos(double cosA) {
+    const double MAXC = 0.99999;
+    // std::max(-MAX, std::min(MAX, cosA)) with the std:: comparison forms (NaN -> +MAX)
+    const double t = (cosA < MAXC) ? cosA : MAXC;
+    const double c = (-MAXC < t) ? t : -MAXC;
+    return acos(c);
+}
+__device__ __forceinline__ V3 unitTo(const V3& from, const V3& to) {
+    const V3 v = to - from;
+    return v / mag(v);
+}
+
+// ---------------------------------------------------------------------------------------------
+// OpenFOAM primitiveMesh::makeFaceCentresAndAreas (.com v2412) -- one thread per face.
+// Also emits the plain vertex average (calcFaceCenter SM.C:1103-1130 on current coordinates),
+// which the face-angle pass reuses.
+__global__ void __launch_bounds__(kBlock) k_face_geom(MeshView m, State s, int wantAvg) {
+    if (s.acc->stop) return;
+    const int f = blockIdx.x * kBlock + threadIdx.x;
+    if (f >= m.nFaces) return;
+    const int b = m.faceOff[f];
+    const int n = m.faceOff[f + 1] - b;
+    const double* __restrict__ P = s.ptsCur;
+    V3 ctr, area;
+    V3 fCentre = ldv(P, m.facePts[b]);
+    for (int i = 1; i < n; ++i) fCentre = fCentre + ldv(P, m.facePts[b + i]);
+    fCentre = fCentre / double(n);
+    if (n == 3) {
+        const V3 p0 = ldv(P, m.facePts[b]), p1 = ldv(P, m.facePts[b + 1]), p2 = ldv(P, m.facePts[b + 2]);
+        ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
+        area = 0.5 * cross(p1 - p0, p2 - p0);
+    } else {
+        V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
+        double sumA = 0.0;
+        V3 thisPoint = ldv(P, m.facePts[b]);
+        const V3 first = thisPoint;
+        for (int i = 0; i < n; ++i) {
+            const V3 nextPoint = (i == n - 1) ? first : ldv(P, m.facePts[b + i + 1]);
+            const V3 c = (thisPoint + nextPoint) + fCentre;
+            const V3 nn = cross(nextPoint - thisPoint, fCentre - thisPoint);
+            const double a = mag(nn);
+            sumN = sumN + nn;
+            sumA += a;
+            sumAc = sumAc + a * c;
+            thisPoint = nextPoint;
+        }
+        if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
+        else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
+    }
+    stv(s.fCtr, f, ctr);
+    stv(s.fArea, f, area);
+    if (wantAvg) stv(s.fAvg, f, fCentre);
+}
+
+// OpenFOAM primitiveMesh::makeCellCentresAndVols (.com v2412) -- one thread per cell, faces in
+// the accumulation order of the two forAll loops (owned ascending, then neighboured ascending).
+__global__ void __launch_bounds__(kBlock) k_cell_centres(MeshView m, State s) {
+    if (s.acc->stop) return;
+    const int c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= m.nCells) return;
+    const int b = m.cfOff[c], e = m.cfOff[c + 1];
+    V3 cEst = v3(0, 0, 0);
+    for (int k = b; k < e; ++k) cEst = cEst + ldv(s.fCtr, m.cfVal[k] & 0x7fffffff);
+    cEst = cEst / double(e - b);
+    V3 ctr = v3(0, 0, 0);
+    double vol = 0.0;
+    for (int k = b; k < e; ++k) {
+        const int v = m.cfVal[k];
+        const int f = v & 0x7fffffff;
+        const V3 fc = ldv(s.fCtr, f);
+        const V3 fA = ldv(s.fArea, f);
+        const double pyr3Vol = (v < 0) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
+        const V3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst;
+        ctr = ctr + pyr3Vol * pc;
+        vol += pyr3Vol;
+    }
+    if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
+    else ctr = cEst;
+    stv(s.cellCtr, c, ctr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-point record of the local part of centroidalSmoothing + findClosestPoints.
+struct PointLocal {
+    V3 sum; int count;       // SM.C:121-130
+    V3 r1, r2, r3; int hc;   // SM.C:325-387
+};
+
+__device__ __forceinline__ bool shareCell(const MeshView& m, int q1, int q2) {
+    // (q2 in pointNeighPoints[q1]) <=> pointCells(q1) and pointCells(q2) intersect (SM.C:196-214, 383)
+    int a = m.pcOff[q1], ae = m.pcOff[q1 + 1];
+    int b = m.pcOff[q2], be = m.pcOff[q2 + 1];
+    if (a >= ae || b >= be) return false;
+    int ca = m.pcVal[a], cb = m.pcVal[b];
+    while (true) {
+        if (ca == cb) return true;
+        if (ca < cb) { if (++a >= ae) return false; ca = m.pcVal[a]; }
+        else { if (++b >= be) return false; cb = m.pcVal[b]; }
+    }
+}
+
+__device__ __forceinline__ void pointLocal(const MeshView& m, const State& s, int p, const V3& cur, bool internal,
+                                           PointLocal& L, int& err) {
+    // SM.C:116-130: only internal points gather (doBoundarySmoothing == false)
+    L.sum = v3(0, 0, 0);
+    L.count = 0;
+    if (internal) {
+        const int b = m.pcOff[p], e = m.pcOff[p + 1];
+        L.count = e - b;
+        for (int k = b; k < e; ++k) L.sum = L.sum + ldv(s.cellCtr, m.pcVal[k]);
+    }
+    // SM.C:325-352: three shortest incident edges in stable (length, list position) order;
+    // boundary points only look at boundary neighbours (SM.C:294)
+    double l1 = 0, l2 = 0, l3 = 0;
+    int q1 = -1, q2 = -1, q3 = -1;
+    const int b = m.ppOff[p], e = m.ppOff[p + 1];
+    for (int k = b; k < e; ++k) {
+        const int q = m.ppPt[k];
+        if (!internal && (m.pflags[q] & PF_INTERNAL)) continue;
+        const double len = mag(cur - ldv(s.ptsCur, q));  // getPointDistance(neigh, cCoords)
+        if (q1 < 0 || len < l1) { l3 = l2; q3 = q2; l2 = l1; q2 = q1; l1 = len; q1 = q; }
+        else if (q2 < 0 || len < l2) { l3 = l2; q3 = q2; l2 = len; q2 = q; }
+        else if (q3 < 0 || len < l3) { l3 = len; q3 = q; }
+    }
+    if (q2 < 0) { err = 1; L.r1 = L.r2 = L.r3 = v3(0, 0, 0); L.hc = 0; return; }  // SM.C:354-362
+    L.r1 = ldv(s.ptsCur, q1) - cur;
+    L.r2 = ldv(s.ptsCur, q2) - cur;
+    L.r3 = (q3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldv(s.ptsCur, q3) - cur;  // SM.C:373-380
+    L.hc = shareCell(m, q1, q2) ? 1 : 0;
+}
+
+// SM.C:489-543
+__device__ __forceinline__ double arRatio(const V3& c1, const V3& c2, const V3& c3, bool hasCommonCell, bool internal) {
+    if (hasCommonCell) return 0.0;
+    const V3 z = v3(0, 0, 0);
+    if ((c1 == z) || (c2 == z)) return 0.0;
+    const double lengthRatio1 = mag(c2) / mag(c1);
+    const double lengthRatio2 = mag(c3) / mag(c2);
+    if (internal) {
+        const double minRatio = 1.5, maxRatio = 3.0;
+        if ((lengthRatio1 < minRatio) && (lengthRatio2 > minRatio)) {
+            const double frac = (lengthRatio2 - minRatio) / (maxRatio - minRatio);
+            const double t = (0.0 > frac) ? 0.0 : frac;   // Foam::max
+            return (1.0 < t) ? 1.0 : t;                   // Foam::min
+        }
+        return 0.0;
+    } else {
+        const double minRatio = 1.0, maxRatio = 2.0;
+        const double frac = (lengthRatio1 - minRatio) / (maxRatio - minRatio);
+        const double t = (0.0 > frac) ? 0.0 : frac;
+        return (1.0 < t) ? 1.0 : t;
+    }
+}
+
+__device__ __forceinline__ void blockAccumulate(State& s, double dist, int frozenCount) {
+    // residual = max over points (SM.C:1556-1565), nFrozenPoints = count (SM.C:2384-2392)
+    __shared__ double shMax[kBlock / 64];
+    __shared__ int shCnt[kBlock / 64];
+    if (!(dist > 0.0)) dist = 0.0;  // NaN never wins "distance > maxStep"
+    for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_down(dist, o, 64);
+        const int oc = __shfl_down(frozenCount, o, 64);
+        dist = (od > dist) ? od : dist;
+        frozenCount += oc;
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { shMax[w] = dist; shCnt[w] = frozenCount; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double d = shMax[0]; int c = shCnt[0];
+        for (int i = 1; i < kBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
+        if (d > 0.0) atomicMax(&s.acc->resBits, (unsigned long long)__double_as_longlong(d));
+        if (c) atomicAdd(&s.acc->nFrozen, c);
+    }
+}
+
+// The fused per-point proposal kernel: centroidalSmoothing SM.C:96-166, aspectRatioSmoothing
+// SM.C:548-593 (+ findClosestPoints/calcARSmoothingRatio), constrainMaxStepLength SM.C:684-754,
+// restrictEdgeShortening SM.C:602-652.  FINAL = true additionally does restore/count SM.C:2384-2392,
+// residual SM.C:1546-1565 and movePoints (write into the other coordinate buffer); valid only when
+// no later evaluator reads neighbours' proposals (angle constraints off, one rank).
+template <bool FINAL>
+__global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    double dist = 0.0;
+    int fcount = 0;
+    if (p < m.nPoints) {
+        const uint8_t fl = m.pflags[p];
+        const bool internal = fl & PF_INTERNAL;
+        const V3 cur = ldv(s.ptsCur, p);
+        PointLocal L;
+        int err = 0;
+        const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
+        if (slot >= 0) {
+            // multi-rank: values already combined over all sharing ranks (syncPointList, SM.C:134-148,391-478)
+            const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
+            L.sum = v3(r[0], r[1], r[2]);
+            L.r1 = v3(r[3], r[4], r[5]);
+            L.r2 = v3(r[6], r[7], r[8]);
+            L.r3 = v3(r[9], r[10], r[11]);
+            const long long pk = __double_as_longlong(r[12]);
+            L.count = (int)(pk & 0xffffffffll);
+            L.hc = (int)(pk >> 32);
+        } else {
+            pointLocal(m, s, p, cur, internal, L, err);
+            if (err) s.acc->err = 1;
+        }
+        // SM.C:155-163
+        V3 np = cur;
+        if (L.count) np = L.sum / double(L.count);
+        // SM.C:580-590
+        const double blendFrac = arRatio(L.r1, L.r2, L.r3, L.hc != 0, internal);
+        if (blendFrac > 0.0) {
+            const V3 aCoords = cur + (L.r1 + L.r2) / 2.0;
+            np = (1.0 - blendFrac) * np + blendFrac * aCoords;
+        }
+        // SM.C:722-745
+        {
+            const V3 stepDir = np - cur;
+            const double len = mag(stepDir);
+            const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
+            np = cur + (prm.relStepFrac * globalScale) * stepDir;
+        }
+        // SM.C:611-648 (isFrozenPoint is all false here: reset at SM.C:2262)
+        bool frozen = false;
+        {
+            double shortestCur = SMGPU_GREAT, shortestNew = SMGPU_GREAT;
+            const int b = m.ppOff[p], e = m.ppOff[p + 1];
+            for (int k = b; k < e; ++k) {
+                const V3 nb = ldv(s.ptsCur, m.ppPt[k]);
+                const double tc = mag(cur - nb);
+                if (tc < shortestCur) shortestCur = tc;
+                const double tn = mag(np - nb);
+                if (tn < shortestNew) shortestNew = tn;
+            }
+            const double shortest = (shortestNew < shortestCur) ? shortestNew : shortestCur;
+            if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
+            else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
+        }
+        if (FINAL) {
+            if (frozen || (!internal && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
+            dist = mag(np - cur) / prm.maxStep;
+            stv(s.ptsNext, p, np);
+        } else {
+            stv(s.prop, p, np);
+            s.frozen[p] = frozen ? 1 : 0;
+        }
+    }
+    if (FINAL) blockAccumulate(s, dist, fcount);
+}
+
+// restrictMinEdgeAngleDecrease SM.C:900-930 (+ calc_min_edge_angles :837-894) -- one thread per point.
+// The six distinct unit vectors of the five edgeEdgeAngle calls are each formed once (same
+// operations, same results as forming them per call).
+__global__ void __launch_bounds__(kBlock) k_edge_angle(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    if (s.frozen[p]) return;
+    const V3 cp0 = ldv(s.ptsCur, p);
+    const V3 np0 = ldv(s.prop, p);
+    double minC = 1.7976931348623157e308, minN = 1.7976931348623157e308;  // DBL_MAX
+    const int b = m.pfOff[p], e = m.pfOff[p + 1];
+    for (int k = b; k < e; ++k) {
+        const int a1 = m.pfPrev[k], a2 = m.pfNext[k];
+        const V3 cp1 = ldv(s.ptsCur, a1), cp2 = ldv(s.ptsCur, a2);
+        const V3 np1 = ldv(s.prop, a1), np2 = ldv(s.prop, a2);
+        const double cAngle = clampAcos(dot(unitTo(cp0, cp1), unitTo(cp0, cp2)));
+        const V3 uc1 = unitTo(np0, cp1), uc2 = unitTo(np0, cp2), un1 = unitTo(np0, np1), un2 = unitTo(np0, np2);
+        const double nAngle0 = clampAcos(dot(uc1, uc2));
+        const double nAngle1 = clampAcos(dot(un1, un2));
+        const double nAngle2 = clampAcos(dot(uc1, un2));
+        const double nAngle3 = clampAcos(dot(un1, uc2));
+        double nAngle = (nAngle0 < nAngle1) ? nAngle0 : nAngle1;
+        nAngle = (nAngle < nAngle2) ? nAngle : nAngle2;
+        nAngle = (nAngle < nAngle3) ? nAngle : nAngle3;
+        if (cAngle < minC) minC = cAngle;
+        if (nAngle < minN) minN = nAngle;
+    }
+    if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// calcMinMaxFaceAngleForEdge SM.C:1135-1231 for one edge, with optional substitution of the
+// coordinates of two points (i1 -> c1, i2 -> c2; i = -1 disables).  SUBST = false is the
+// current-mesh form (SM.C:1235-1247) and uses the per-face vertex averages from k_face_geom.
+template <bool SUBST>
+__device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s, int e, int i1, const V3& c1, int i2,
+                                               const V3& c2, double& minA, double& maxA) {
+    const int e0I = m.edges[2 * e], e1I = m.edges[2 * e + 1];
+    V3 e0 = ldv(s.ptsCur, e0I), e1 = ldv(s.ptsCur, e1I);
+    if (SUBST) {
+        if (i1 >= 0 && e0I == i1) e0 = c1; else if (i2 >= 0 && e0I == i2) e0 = c2;
+        if (i1 >= 0 && e1I == i1) e1 = c1; else if (i2 >= 0 && e1I == i2) e1 = c2;
+    }
+    const V3 cC = 0.5 * (e0 + e1);
+    const V3 d = e1 - e0;
+    const V3 eVec = d / mag(d);
+    const int fb = m.efOff[e];
+    auto faceVec = [&](int f) -> V3 {
+        V3 fc;
+        if (SUBST) {
+            // calcFaceCenter SM.C:1103-1130
+            fc = v3(0, 0, 0);
+            const int b = m.faceOff[f], n = m.faceOff[f + 1] - b;
+            for (int i = 0; i < n; ++i) {
+                const int q = m.facePts[b + i];
+                if (i1 >= 0 && q == i1) fc = fc + c1;
+                else if (i2 >= 0 && q == i2) fc = fc + c2;
+                else fc = fc + ldv(s.ptsCur, q);
+            }
+            fc = fc / double(n);
+        } else {
+            fc = ldv(s.fAvg, f);
+        }
+        const V3 cf = cC - fc;
+        const double dp = dot(cf, eVec);
+        const V3 pC = fc + dp * eVec;
+        const V3 w = pC - cC;
+        return w / mag(w);
+    };
+    minA = 2.0 * SMGPU_PI;
+    maxA = 0.0;
+    const int cb = m.ecOff[e], ce = m.ecOff[e + 1];
+    for (int k = cb; k < ce; ++k) {
+        const V3 p0 = faceVec(m.efFace[fb + m.ecF0[k]]);
+        const V3 p1 = faceVec(m.efFace[fb + m.ecF1[k]]);
+        const V3 cc = ldv(s.cellCtr, m.ecCell[k]);  // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+        const V3 cf = cC - cc;
+        const double dp = dot(cf, eVec);
+        const V3 pC = cc + dp * eVec;
+        const V3 w = pC - cC;
+        const V3 cV = w / mag(w);
+        // calcEdgeCenterEdgeAngle SM.C:980-998
+        const double angle = clampAcos(dot(p0, cV)) + clampAcos(dot(cV, p1));
+        if (angle < minA) minA = angle;
+        if (angle > maxA) maxA = angle;
+    }
+}
+
+// calcCurrentMinMaxFaceAnglesForEdges SM.C:1252-1270 -- one thread per edge.
+__global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s) {
+    if (s.acc->stop) return;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m.nEdges) return;
+    double mn, mx;
+    const V3 z = v3(0, 0, 0);
+    edgeFaceAngles<false>(m, s, e, -1, z, -1, z, mn, mx);
+    s.edgeMin[e] = mn;
+    s.edgeMax[e] = mx;
+}
+
+// mapCurrentMinMaxFaceAnglesToPoints SM.C:938-975 as a gather over pointEdges, plus the
+// good-range test SM.C:1367-1369 -- one thread per point.
+__global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    double mn = 2.0 * SMGPU_PI, mx = 0.0;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+        const int e = m.peEdge[k];
+        const double a = s.edgeMin[e], b = s.edgeMax[e];
+        if (mn > a) mn = a;
+        if (mx < b) mx = b;
+    }
+    s.ptMin[p] = mn;
+    s.ptMax[p] = mx;
+    const bool good = (mn > prm.smallAngle) && (mx < prm.largeAngle);
+    s.faActive[p] = good ? 0 : 1;
+    if (!good) atomicAdd(&s.acc->nActive, 1);
+}
+
+// calcMinMaxFaceAngleForPoint SM.C:1276-1308
+__device__ __forceinline__ void pointFaceAngles(const MeshView& m, const State& s, int p, const V3& c1, int i2,
+                                                const V3& c2, double& mn, double& mx) {
+    mn = 2.0 * SMGPU_PI;
+    mx = 0.0;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+        double a, b;
+        edgeFaceAngles<true>(m, s, m.peEdge[k], p, c1, i2, c2, a, b);
+        if (mn > a) mn = a;
+        if (mx < b) mx = b;
+    }
+}
+
+// Geometric predicates of the stack walk SM.C:1347-1434 for every point outside the good range.
+// They are pure functions of (current coordinates, proposals), so they are evaluated in parallel
+// here; k_fa_walk then replays the reference's stack order over these bits.
+//   faS[p]  bit0: self move deteriorates (SM.C:1391-1394)   bit1: proposal differs from current
+//   faN[k]  (k = pointPoints entry p->n)  bit0: n's move hurts p with p at its proposal
+//           bit1: n's move hurts p with p at its current position   bit2: n is moving (SM.C:1414)
+__global__ void __launch_bounds__(kBlock) k_fa_pred(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    if (s.acc->nActive == 0) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    if (!s.faActive[p]) return;
+    const V3 cur = ldv(s.ptsCur, p);
+    const V3 np = ldv(s.prop, p);
+    const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+    auto bad = [&](double mn, double mx) {
+        return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+    };
+    const bool moved = (np != cur);
+    uint8_t sb = moved ? 2 : 0;
+    if (moved) {
+        double mn, mx;
+        pointFaceAngles(m, s, p, np, -1, np, mn, mx);
+        if (bad(mn, mx)) sb |= 1;
+    }
+    s.faS[p] = sb;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+        const int q = m.ppPt[k];
+        const V3 nq = ldv(s.prop, q);
+        uint8_t nb = 0;
+        if (nq != ldv(s.ptsCur, q)) {
+            nb = 4;
+            double mn, mx;
+            pointFaceAngles(m, s, p, cur, q, nq, mn, mx);
+            const bool badF = bad(mn, mx);
+            if (badF) nb |= 2;
+            if (moved) {
+                pointFaceAngles(m, s, p, np, q, nq, mn, mx);
+                if (bad(mn, mx)) nb |= 1;
+            } else if (badF) nb |= 1;
+        }
+        s.faN[k] = nb;
+    }
+}
+
+// Ordered replay of the stack walk SM.C:1347-1434: one wave; all lanes scan 64 flags at a time
+// (ballot), lane 0 performs the sequential freeze logic.  Points are visited from the highest
+// index down (the reference pushes 0..P-1 and pops from the top); a point frozen by a neighbour
+// is re-visited before the walk continues (LIFO re-push, SM.C:1431).
+__global__ void __launch_bounds__(64) k_fa_walk(MeshView m, State s) {
+    if (s.acc->stop) return;
+    if (s.acc->nActive == 0) return;
+    const int lane = threadIdx.x;
+    const int nChunks = (m.nPoints + 63) / 64;
+    for (int c = nChunks - 1; c >= 0; --c) {
+        const int idx = c * 64 + lane;
+        const bool act = (idx < m.nPoints) && s.faActive[idx];
+        unsigned long long mask = __ballot(act);
+        if (mask == 0ull) continue;
+        if (lane == 0) {
+            while (mask) {
+                const int bit = 63 - __clzll((long long)mask);
+                mask &= ~(1ull << bit);
+                int sp = 0;
+                s.walkStack[sp++] = c * 64 + bit;
+                while (sp > 0) {
+                    const int p = s.walkStack[--sp];
+                    if (!s.faActive[p]) continue;                  // SM.C:1367-1369
+                    const uint8_t sb = s.faS[p];
+                    bool useNew = (!s.frozen[p]) && (sb & 2);      // SM.C:1376-1385
+                    if (useNew && (sb & 1)) { s.frozen[p] = 1; useNew = false; }  // SM.C:1391-1399
+                    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {           // SM.C:1406-1433
+                        const int q = m.ppPt[k];
+                        const uint8_t nb = s.faN[k];
+                        if (s.frozen[q]) continue;
+                        if (!(nb & 4)) continue;
+                        if (useNew ? (nb & 1) : (nb & 2)) { s.frozen[q] = 1; s.walkStack[sp++] = q; }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// restore + count SM.C:2384-2392, residual SM.C:1546-1565, movePoints SM.C:2399 -- one thread per point
+__global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    double dist = 0.0;
+    int fcount = 0;
+    if (p < m.nPoints) {
+        const uint8_t fl = m.pflags[p];
+        const V3 cur = ldv(s.ptsCur, p);
+        V3 np = ldv(s.prop, p);
+        if (s.frozen[p] || (!(fl & PF_INTERNAL) && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
+        dist = mag(np - cur) / prm.maxStep;
+        stv(s.ptsNext, p, np);
+    }
+    blockAccumulate(s, dist, fcount);
+}
+
+// End of iteration: publish the log-line values (SM.C:2396), stop test (SM.C:2401), reset accumulators.
+__global__ void k_finish(State s, int iter, double relTol, double* localStats) {
+    Accum* a = s.acc;
+    if (a->stop) return;
+    const double res = __longlong_as_double((long long)a->resBits);
+    if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = a->nFrozen; s.stats[iter].pad = 1; }
+    if (localStats) { localStats[0] = res; localStats[1] = (double)a->nFrozen; }
+    if (res < relTol) a->stop = 1;
+    a->resBits = 0ull;
+    a->nFrozen = 0;
+    a->nActive = 0;
+}
+
+// ---- multi-rank pack / combine -------------------------------------------------------------------
+// exchange A: local partial sums and closest points of the shared points (SM.C:108-131, 325-387)
+__global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, const int* sharedLocal, double* ownA, int nShared) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    // own records first (one per shared point); k_halo_copyA then fills the send slots from them
+    if (i < nShared) {
+        const int p = sharedLocal[i];
+        const V3 cur = ldv(s.ptsCur, p);
+        PointLocal L;
+        int err = 0;
+        pointLocal(m, s, p, cur, m.pflags[p] & PF_INTERNAL, L, err);
+        if (err) s.acc->err = 1;
+        double* r = ownA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+        r[0] = L.sum.x; r[1] = L.sum.y; r[2] = L.sum.z;
+        r[3] = L.r1.x; r[4] = L.r1.y; r[5] = L.r1.z;
+        r[6] = L.r2.x; r[7] = L.r2.y; r[8] = L.r2.z;
+        r[9] = L.r3.x; r[10] = L.r3.y; r[11] = L.r3.z;
+        r[12] = __longlong_as_double(((long long)L.hc << 32) | (long long)(unsigned int)L.count);
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_halo_copyA(int nSend, const int* sendShared, const double* ownA, double* sendA) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nSend * SMGPU_HALO_A_DOUBLES) return;
+    const int slot = i / SMGPU_HALO_A_DOUBLES, j = i % SMGPU_HALO_A_DOUBLES;
+    sendA[i] = ownA[(size_t)sendShared[slot] * SMGPU_HALO_A_DOUBLES + j];
+}
+
+// SM.C:246-272 isCloserPoint
+__device__ __forceinline__ bool isCloserPoint(const V3& a, const V3& b) {
+    if (a == b) return false;
+    const double delta = mag(a) - mag(b);
+    if (delta < SMGPU_VSMALL) return true;
+    return false;  // the |delta| < VSMALL branch (SM.C:266) cannot be reached once the test above failed
+}
+
+constexpr int kMaxSharers = 16;
+
+// syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
+// plusEqOp in ascending rank order; minMagSqrEqOp folds from the own value (ties keep own).
+__global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
+                                                          const double* ownA, const double* recvA, double* combA, int* err) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    const int b = combOff[i], n = combOff[i + 1] - b;
+    if (n > kMaxSharers) { *err = 2; return; }
+    V3 r1[kMaxSharers], r2[kMaxSharers], r3[kMaxSharers];
+    int hc[kMaxSharers];
+    V3 sum = v3(0, 0, 0);
+    int cnt = 0, self = 0;
+    for (int j = 0; j < n; ++j) {
+        const int sl = combSlots[b + j];
+        const double* r = (sl < 0) ? ownA + (size_t)i * SMGPU_HALO_A_DOUBLES : recvA + (size_t)sl * SMGPU_HALO_A_DOUBLES;
+        if (sl < 0) self = j;
+        sum = sum + v3(r[0], r[1], r[2]);
+        r1[j] = v3(r[3], r[4], r[5]);
+        r2[j] = v3(r[6], r[7], r[8]);
+        r3[j] = v3(r[9], r[10], r[11]);
+        const long long pk = __double_as_longlong(r[12]);
+        cnt += (int)(pk & 0xffffffffll);
+        hc[j] = (int)(pk >> 32);
+    }
+    auto fold = [&](const V3* v, int me) {
+        V3 x = v[me];
+        for (int k = 0; k < n; ++k) {
+            if (k == me) continue;
+            x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
+        }
+        return x;
+    };
+    V3 sent[kMaxSharers];
+    for (int j = 0; j < n; ++j) sent[j] = r1[j];
+    for (int j = 0; j < n; ++j) {            // SM.C:397-419
+        const V3 sv = fold(sent, j);
+        if (isCloserPoint(sv, r1[j])) { r3[j] = r2[j]; r2[j] = r1[j]; r1[j] = sv; hc[j] = 0; }
+    }
+    for (int j = 0; j < n; ++j) sent[j] = r2[j];
+    for (int j = 0; j < n; ++j) {            // SM.C:424-445
+        const V3 sv = fold(sent, j);
+        if (isCloserPoint(sv, r2[j])) { r3[j] = r2[j]; r2[j] = sv; hc[j] = 0; }
+    }
+    for (int j = 0; j < n; ++j) sent[j] = r3[j];
+    for (int j = 0; j < n; ++j) {            // SM.C:450-469
+        const V3 sv = fold(sent, j);
+        if (isCloserPoint(sv, r3[j])) r3[j] = sv;
+    }
+    int any = 0;                             // SM.C:472-478
+    for (int j = 0; j < n; ++j) any |= hc[j];
+    double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+    o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+    o[3] = r1[self].x; o[4] = r1[self].y; o[5] = r1[self].z;
+    o[6] = r2[self].x; o[7] = r2[self].y; o[8] = r2[self].z;
+    o[9] = r3[self].x; o[10] = r3[self].y; o[11] = r3[self].z;
+    o[12] = __longlong_as_double(((long long)any << 32) | (long long)(unsigned int)cnt);
+}
+
+// exchange F: isFrozenPoint of shared points, orEqOp (SM.C:2374-2380)
+__global__ void __launch_bounds__(kBlock) k_halo_packF(int nSend, const int* sendShared, const int* sharedLocal,
+                                                       const uint8_t* frozen, int* sendF) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nSend) return;
+    sendF[i] = frozen[sharedLocal[sendShared[i]]];
+}
+__global__ void __launch_bounds__(kBlock) k_halo_orF(int nShared, const int* sharedLocal, const int* combOff,
+                                                     const int* combSlots, const int* recvF, uint8_t* frozen) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    int any = 0;
+    for (int k = combOff[i]; k < combOff[i + 1]; ++k) {
+        const int sl = combSlots[k];
+        if (sl >= 0) any |= recvF[sl];
+    }
+    if (any) frozen[sharedLocal[i]] = 1;
+}
+
+// getMeshStats SM.C:1495-1510: min / max edge length
+__global__ void __launch_bounds__(kBlock) k_edge_stats(MeshView m, const double* pts, unsigned long long* minBits,
+                                                       unsigned long long* maxBits) {
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    double len = -1.0;
+    if (e < m.nEdges) len = mag(ldv(pts, m.edges[2 * e + 1]) - ldv(pts, m.edges[2 * e]));
+    double mn = (len >= 0.0) ? len : 1.0e300, mx = (len >= 0.0) ? len : 0.0;
+    for (int o = 32; o > 0; o >>= 1) {
+        const double a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
+        mn = (a < mn) ? a : mn;
+        mx = (b > mx) ? b : mx;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(minBits, (unsigned long long)__double_as_longlong(mn));
+        atomicMax(maxBits, (unsigned long long)__double_as_longlong(mx));
+    }
+}
+
+}  // namespace smgpu

@@ -1,0 +1,618 @@
+// smgpu.hip -- C-ABI implementation (see include/smgpu.h): host-side addressing build, device
+// residency, kernel sequencing of one smoothing iteration (src/smoothMesh.C:2257-2437).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "topology.hpp"
+
+using namespace smgpu;
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e__ = (expr);                                                                       \
+        if (e__ != hipSuccess)                                                                         \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e__) + " (" __FILE__ ":" +       \
+                        std::to_string(__LINE__) + ")");                                               \
+    } while (0)
+
+enum KernelId { K_FACE_GEOM = 0, K_CELL_CENTRES, K_SMOOTH_FINAL, K_SMOOTH_PROP, K_EDGE_ANGLE, K_FA_EDGES,
+                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_COUNT };
+static const char* kKernelNames[K_COUNT] = {"k_face_geom", "k_cell_centres", "k_smooth<final>", "k_smooth<proposal>",
+                                            "k_edge_angle", "k_fa_edges", "k_fa_points", "k_fa_pred", "k_fa_walk",
+                                            "k_apply", "k_finish", "k_halo_*"};
+
+struct smgpu_handle {
+    Topology topo;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    std::vector<void*> allocs;
+    int64_t deviceBytes = 0;
+    MeshView mv{};
+    State st{};
+    double* bufA = nullptr;  // coordinate double buffer
+    double* bufB = nullptr;
+    smgpu_params prm{};
+    bool prmSet = false;
+    smgpu_iter_stats* dStats = nullptr;
+    int statsCap = 0;
+    // timing
+    bool timing = false;
+    struct Pending { int k; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> freeEvents;
+    double ms[K_COUNT] = {0};
+    int64_t launches[K_COUNT] = {0};
+    int64_t algoBytes[K_COUNT] = {0};
+    // halo
+    bool haloOn = false;
+    int nShared = 0, nSend = 0, nRecv = 0;
+    int *dSharedLocal = nullptr, *dSendShared = nullptr, *dCombOff = nullptr, *dCombSlots = nullptr, *dSharedSlot = nullptr;
+    double *dOwnA = nullptr, *dCombA = nullptr;
+    double *sendA = nullptr, *recvA = nullptr;
+    int *sendF = nullptr, *recvF = nullptr;
+    double* localStats = nullptr;
+    int haloIter = 0;
+};
+
+template <typename T>
+static int devAlloc(smgpu_handle* h, T** out, size_t n) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    HIP_OK(hipMalloc(&p, bytes));
+    h->allocs.push_back(p);
+    h->deviceBytes += (int64_t)bytes;
+    *out = (T*)p;
+    return 0;
+}
+template <typename T>
+static int devUpload(smgpu_handle* h, const T** out, const std::vector<T>& v) {
+    T* p = nullptr;
+    if (devAlloc(h, &p, v.size())) return 1;
+    if (!v.empty()) HIP_OK(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *out = p;
+    return 0;
+}
+
+static Prm makePrm(const smgpu_params& p) {
+    Prm r;
+    r.maxStep = p.maxStepLength;
+    r.relStepFrac = p.relStepFrac;
+    r.minEdge = p.minEdgeLength;
+    r.totalMinFreeze = p.totalMinFreeze;
+    r.smallAngle = SMGPU_PI * p.minAngle / 180.0;   // SM.C:921,1364
+    r.largeAngle = SMGPU_PI * p.maxAngle / 180.0;   // SM.C:1365
+    return r;
+}
+
+static inline int gridFor(int64_t n) { return (int)((n + kBlock - 1) / kBlock); }
+
+// Launch helper: optional hipEvent bracketing on the handle's stream.
+template <typename F>
+static int launchK(smgpu_handle* h, int k, F&& f) {
+    if (h->timing) {
+        hipEvent_t a, b;
+        for (hipEvent_t* ev : {&a, &b}) {
+            if (!h->freeEvents.empty()) { *ev = h->freeEvents.back(); h->freeEvents.pop_back(); }
+            else HIP_OK(hipEventCreate(ev));
+        }
+        HIP_OK(hipEventRecord(a, h->stream));
+        f();
+        HIP_OK(hipEventRecord(b, h->stream));
+        h->pending.push_back({k, a, b});
+    } else {
+        f();
+    }
+    h->launches[k]++;
+    return 0;
+}
+
+static int drainTimers(smgpu_handle* h) {
+    if (h->pending.empty()) return 0;
+    HIP_OK(hipStreamSynchronize(h->stream));
+    for (auto& p : h->pending) {
+        float ms = 0.f;
+        HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
+        h->ms[p.k] += ms;
+        h->freeEvents.push_back(p.a);
+        h->freeEvents.push_back(p.b);
+    }
+    h->pending.clear();
+    return 0;
+}
+
+static void computeAlgoBytes(smgpu_handle* h) {
+    const Topology& t = h->topo;
+    const int64_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
+    const int64_t nfp = t.facePoints.nnz(), npc = t.pointCells.nnz(), npp = t.pointEdges.nnz(), npf = t.pointFaces.nnz();
+    const int64_t nef = t.edgeFaces.nnz(), nec = t.edgeCells.nnz(), ncf = t.cellFacesGeom.nnz();
+    const bool fa = h->prm.faceAngleConstraint;
+    int64_t* b = h->algoBytes;
+    b[K_FACE_GEOM] = 24 * P + 4 * (F + 1) + 4 * nfp + 48 * F + (fa ? 24 * F : 0);
+    b[K_CELL_CENTRES] = 4 * (C + 1) + 4 * ncf + 48 * F + 24 * C;
+    const int64_t smooth = 4 * (P + 1) + 4 * npc + 24 * C + 4 * (P + 1) + 4 * npp + 24 * P + P + 24 * P;
+    b[K_SMOOTH_FINAL] = smooth;
+    b[K_SMOOTH_PROP] = smooth + P;
+    b[K_EDGE_ANGLE] = 4 * (P + 1) + 8 * npf + 24 * P + 24 * P + 2 * P;
+    b[K_FA_EDGES] = 8 * E + 4 * (E + 1) + 4 * nef + 4 * (E + 1) + 6 * nec + 24 * P + 24 * F + 24 * C + 16 * E;
+    b[K_FA_POINTS] = 4 * (P + 1) + 4 * npp + 16 * E + 16 * P + P;
+    b[K_FA_PRED] = P;   // good meshes: the flag scan only
+    b[K_FA_WALK] = P;
+    b[K_APPLY] = 24 * P + 24 * P + 2 * P + 24 * P;
+    b[K_FINISH] = 64;
+    b[K_HALO] = 0;
+}
+
+extern "C" {
+
+const char* smgpu_last_error(void) { return g_err.c_str(); }
+const char* smgpu_version(void) { return "smgpu 0.1 (gfx950)"; }
+
+int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
+    if (!d || !out) return fail("smgpu_create: null argument");
+    *out = nullptr;
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) return fail("smgpu_create: no HIP device available");
+    if (d->device < 0 || d->device >= nDev) return fail("smgpu_create: device ordinal out of range");
+    smgpu_handle* h = new smgpu_handle();
+    h->device = d->device;
+    const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets,
+                                           d->facePoints, d->owner, d->neighbour);
+    if (!terr.empty()) { delete h; return fail("smgpu_create: " + terr); }
+    auto cleanup = [&](int rc) { smgpu_destroy(h); return rc; };
+    if (hipSetDevice(h->device) != hipSuccess) return cleanup(fail("hipSetDevice failed"));
+    if (d->stream) h->stream = (hipStream_t)d->stream;
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("hipStreamCreate failed"));
+        h->ownStream = true;
+    }
+    const Topology& t = h->topo;
+    MeshView& m = h->mv;
+    m.nPoints = t.nPoints; m.nCells = t.nCells; m.nFaces = t.nFaces; m.nInternalFaces = t.nInternalFaces; m.nEdges = t.nEdges;
+    std::vector<uint8_t> flags(t.nPoints);
+    for (int p = 0; p < t.nPoints; ++p)
+        flags[p] = (d->isInternalPoint[p] ? PF_INTERNAL : 0) |
+                   ((d->isSmoothingSurfacePoint && d->isSmoothingSurfacePoint[p]) ? PF_SMOOTHSURF : 0);
+    int rc = 0;
+    rc |= devUpload(h, &m.faceOff, t.facePoints.off);
+    rc |= devUpload(h, &m.facePts, t.facePoints.val);
+    rc |= devUpload(h, &m.cfOff, t.cellFacesGeom.off);
+    rc |= devUpload(h, &m.cfVal, t.cellFacesGeom.val);
+    rc |= devUpload(h, &m.pcOff, t.pointCells.off);
+    rc |= devUpload(h, &m.pcVal, t.pointCells.val);
+    rc |= devUpload(h, &m.ppOff, t.pointEdges.off);
+    rc |= devUpload(h, &m.ppPt, t.pointPoints);
+    rc |= devUpload(h, &m.peEdge, t.pointEdges.val);
+    rc |= devUpload(h, &m.pfOff, t.pointFaces.off);
+    rc |= devUpload(h, &m.pfPrev, t.pfPrev);
+    rc |= devUpload(h, &m.pfNext, t.pfNext);
+    rc |= devUpload(h, &m.edges, t.edges);
+    rc |= devUpload(h, &m.efOff, t.edgeFaces.off);
+    rc |= devUpload(h, &m.efFace, t.edgeFaces.val);
+    rc |= devUpload(h, &m.ecOff, t.edgeCells.off);
+    rc |= devUpload(h, &m.ecCell, t.edgeCells.val);
+    rc |= devUpload(h, &m.ecF0, t.ecFace0);
+    rc |= devUpload(h, &m.ecF1, t.ecFace1);
+    rc |= devUpload(h, &m.pflags, flags);
+    if (rc) return cleanup(1);
+    State& s = h->st;
+    const size_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
+    rc |= devAlloc(h, &h->bufA, 3 * P);
+    rc |= devAlloc(h, &h->bufB, 3 * P);
+    rc |= devAlloc(h, &s.prop, 3 * P);
+    rc |= devAlloc(h, &s.fCtr, 3 * F);
+    rc |= devAlloc(h, &s.fArea, 3 * F);
+    rc |= devAlloc(h, &s.fAvg, 3 * F);
+    rc |= devAlloc(h, &s.cellCtr, 3 * C);
+    rc |= devAlloc(h, &s.frozen, P);
+    rc |= devAlloc(h, &s.edgeMin, E);
+    rc |= devAlloc(h, &s.edgeMax, E);
+    rc |= devAlloc(h, &s.ptMin, P);
+    rc |= devAlloc(h, &s.ptMax, P);
+    rc |= devAlloc(h, &s.faActive, P);
+    rc |= devAlloc(h, &s.faS, P);
+    rc |= devAlloc(h, &s.faN, (size_t)t.pointEdges.nnz());
+    rc |= devAlloc(h, &s.walkStack, P + 64);
+    rc |= devAlloc(h, &s.acc, 1);
+    if (rc) return cleanup(1);
+    if (hipMemset(s.acc, 0, sizeof(Accum)) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    if (hipMemset(s.frozen, 0, P) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    if (hipMemcpy(h->bufA, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail("upload of points failed"));
+    if (hipMemcpy(s.prop, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail("upload of points failed"));
+    s.ptsCur = h->bufA;
+    s.ptsNext = h->bufB;
+    s.stats = nullptr;
+    s.sharedSlot = nullptr;
+    s.combA = nullptr;
+    computeAlgoBytes(h);
+    *out = h;
+    return 0;
+}
+
+int smgpu_destroy(smgpu_handle* h) {
+    if (!h) return 0;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (auto e : h->freeEvents) (void)hipEventDestroy(e);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return 0;
+}
+
+int smgpu_get_sizes(smgpu_handle* h, smgpu_sizes* o) {
+    if (!h || !o) return fail("null argument");
+    const Topology& t = h->topo;
+    o->nPoints = t.nPoints; o->nCells = t.nCells; o->nFaces = t.nFaces; o->nInternalFaces = t.nInternalFaces; o->nEdges = t.nEdges;
+    o->nnzFacePoints = t.facePoints.nnz(); o->nnzPointCells = t.pointCells.nnz(); o->nnzPointPoints = t.pointEdges.nnz();
+    o->nnzPointFaces = t.pointFaces.nnz(); o->nnzEdgeFaces = t.edgeFaces.nnz(); o->nnzEdgeCells = t.edgeCells.nnz();
+    o->nnzCellFaces = t.cellFacesGeom.nnz();
+    o->deviceBytes = h->deviceBytes;
+    return 0;
+}
+
+int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
+    if (!h) return fail("null handle");
+    HIP_OK(hipSetDevice(h->device));
+    unsigned long long* d = nullptr;
+    HIP_OK(hipMalloc((void**)&d, 16));
+    const double big = 1.0e300, zero = 0.0;
+    unsigned long long init[2];
+    std::memcpy(&init[0], &big, 8);
+    std::memcpy(&init[1], &zero, 8);
+    HIP_OK(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_edge_stats, dim3(gridFor(h->mv.nEdges)), dim3(kBlock), 0, h->stream, h->mv, h->st.ptsCur, d, d + 1);
+    unsigned long long out[2];
+    HIP_OK(hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    HIP_OK(hipFree(d));
+    std::memcpy(minEdge, &out[0], 8);
+    std::memcpy(maxEdge, &out[1], 8);
+    return 0;
+}
+
+int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
+    if (!h || !p) return fail("null argument");
+    if (!(p->maxStepLength > 0.0)) return fail("maxStepLength must be > 0");
+    h->prm = *p;
+    h->prmSet = true;
+    computeAlgoBytes(h);
+    return 0;
+}
+
+// geometry of the current coordinates: OpenFOAM face centres/areas + cell centres
+static int runGeometry(smgpu_handle* h) {
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const int wantAvg = h->prm.faceAngleConstraint ? 1 : 0;
+    if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg); })) return 1;
+    if (launchK(h, K_CELL_CENTRES, [&] { hipLaunchKernelGGL(k_cell_centres, dim3(gridFor(m.nCells)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
+    return 0;
+}
+
+// proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
+static int runProposalAndConstraints(smgpu_handle* h) {
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const Prm prm = makePrm(h->prm);
+    const int gP = gridFor(m.nPoints);
+    if (launchK(h, K_SMOOTH_PROP, [&] { hipLaunchKernelGGL(k_smooth<false>, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    if (h->prm.edgeAngleConstraint)
+        if (launchK(h, K_EDGE_ANGLE, [&] { hipLaunchKernelGGL(k_edge_angle, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    if (h->prm.faceAngleConstraint) {
+        if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
+        if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        if (launchK(h, K_FA_PRED, [&] { hipLaunchKernelGGL(k_fa_pred, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        if (launchK(h, K_FA_WALK, [&] { hipLaunchKernelGGL(k_fa_walk, dim3(1), dim3(64), 0, h->stream, m, s); })) return 1;
+    }
+    return 0;
+}
+
+static int checkDeviceError(smgpu_handle* h) {
+    Accum a;
+    HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
+    if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
+    return 0;
+}
+
+int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_stats* stats, int32_t* nDone) {
+    if (!h) return fail("null handle");
+    if (!h->prmSet) return fail("smgpu_set_params has not been called");
+    if (h->haloOn) return fail("smgpu_iterate is the single-rank loop; use smgpu_iter_begin/mid/end with a halo");
+    if (nIters < 0) return fail("nIters < 0");
+    if (nDone) *nDone = 0;
+    if (nIters == 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    if (h->statsCap < nIters) {
+        if (devAlloc(h, &h->dStats, (size_t)nIters)) return 1;
+        h->statsCap = nIters;
+    }
+    HIP_OK(hipMemsetAsync(h->dStats, 0, sizeof(smgpu_iter_stats) * (size_t)nIters, h->stream));
+    HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
+    h->st.stats = h->dStats;
+    const MeshView& m = h->mv;
+    const Prm prm = makePrm(h->prm);
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    const int gP = gridFor(m.nPoints);
+    double* const buf0 = h->st.ptsCur;
+    double* const buf1 = h->st.ptsNext;
+    int launched = 0;
+    for (int i = 0; i < nIters; ++i) {
+        if (runGeometry(h)) return 1;
+        State s = h->st;
+        if (fused) {
+            if (launchK(h, K_SMOOTH_FINAL, [&] { hipLaunchKernelGGL(k_smooth<true>, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        } else {
+            if (runProposalAndConstraints(h)) return 1;
+            if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        }
+        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, h->stream, s, i, relTol, (double*)nullptr); })) return 1;
+        std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
+        ++launched;
+        // a positive relTol can stop the loop: poll the device flag now and then so a converged run
+        // does not queue thousands of no-op launches (relTol <= 0 can never stop: residual >= 0)
+        if (relTol > 0.0 && (i % 8) == 7 && i + 1 < nIters) {
+            int stop = 0;
+            HIP_OK(hipMemcpyAsync(&stop, &h->st.acc->stop, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+            if (stop) break;
+        }
+    }
+    std::vector<smgpu_iter_stats> hs((size_t)launched);
+    HIP_OK(hipMemcpyAsync(hs.data(), h->dStats, sizeof(smgpu_iter_stats) * (size_t)launched, hipMemcpyDeviceToHost, h->stream));
+    if (checkDeviceError(h)) return 1;
+    int done = 0;
+    while (done < launched && hs[done].pad == 1) ++done;
+    for (int i = 0; i < done; ++i) hs[i].pad = 0;
+    if (stats) std::memcpy(stats, hs.data(), sizeof(smgpu_iter_stats) * (size_t)done);
+    if (nDone) *nDone = done;
+    // the coordinates of iteration `done` live in buf1 when done is odd, buf0 when even
+    h->st.ptsCur = (done & 1) ? buf1 : buf0;
+    h->st.ptsNext = (done & 1) ? buf0 : buf1;
+    h->st.stats = nullptr;
+    if (drainTimers(h)) return 1;
+    return 0;
+}
+
+int smgpu_get_points(smgpu_handle* h, double* out) {
+    if (!h || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemcpyAsync(out, h->st.ptsCur, sizeof(double) * 3 * (size_t)h->mv.nPoints, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smgpu_set_points(smgpu_handle* h, const double* pts) {
+    if (!h || !pts) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemcpyAsync(h->st.ptsCur, pts, sizeof(double) * 3 * (size_t)h->mv.nPoints, hipMemcpyHostToDevice, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int smgpu_enable_timing(smgpu_handle* h, int32_t on) {
+    if (!h) return fail("null handle");
+    if (!on && drainTimers(h)) return 1;
+    h->timing = on != 0;
+    return 0;
+}
+
+int smgpu_get_counters(smgpu_handle* h, smgpu_counters* o) {
+    if (!h || !o) return fail("null argument");
+    if (drainTimers(h)) return 1;
+    o->nKernels = K_COUNT;
+    for (int k = 0; k < K_COUNT; ++k) {
+        o->name[k] = kKernelNames[k];
+        o->ms[k] = h->ms[k];
+        o->launches[k] = h->launches[k];
+        o->algoBytesPerLaunch[k] = h->algoBytes[k];
+    }
+    return 0;
+}
+
+int smgpu_reset_counters(smgpu_handle* h) {
+    if (!h) return fail("null handle");
+    if (drainTimers(h)) return 1;
+    for (int k = 0; k < K_COUNT; ++k) { h->ms[k] = 0; h->launches[k] = 0; }
+    return 0;
+}
+
+// ---- multi-rank ----------------------------------------------------------------------------------
+int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
+    if (!h || !d) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    h->nShared = d->nShared; h->nSend = d->nSend; h->nRecv = d->nRecv;
+    const int P = h->mv.nPoints;
+    std::vector<int> sharedLocal(d->sharedLocal, d->sharedLocal + d->nShared);
+    std::vector<int> sendShared(d->sendShared, d->sendShared + d->nSend);
+    std::vector<int> combOff(d->combOffsets, d->combOffsets + d->nShared + 1);
+    std::vector<int> combSlots(d->combSlots, d->combSlots + combOff[d->nShared]);
+    std::vector<int> slot((size_t)P, -1);
+    for (int i = 0; i < d->nShared; ++i) {
+        if (sharedLocal[i] < 0 || sharedLocal[i] >= P) return fail("halo: shared point id out of range");
+        slot[sharedLocal[i]] = i;
+        if (combOff[i + 1] - combOff[i] > kMaxSharers) return fail("halo: more than 16 ranks share a point");
+    }
+    for (int v : sendShared) if (v < 0 || v >= d->nShared) return fail("halo: sendShared out of range");
+    for (int v : combSlots) if (v < -1 || v >= d->nRecv) return fail("halo: combSlots out of range");
+    const int *a = nullptr, *b = nullptr, *c = nullptr, *e = nullptr, *f = nullptr;
+    if (devUpload(h, &a, sharedLocal) || devUpload(h, &b, sendShared) || devUpload(h, &c, combOff) ||
+        devUpload(h, &e, combSlots) || devUpload(h, &f, slot)) return 1;
+    h->dSharedLocal = (int*)a; h->dSendShared = (int*)b; h->dCombOff = (int*)c; h->dCombSlots = (int*)e; h->dSharedSlot = (int*)f;
+    if (devAlloc(h, &h->dOwnA, (size_t)d->nShared * SMGPU_HALO_A_DOUBLES)) return 1;
+    if (devAlloc(h, &h->dCombA, (size_t)d->nShared * SMGPU_HALO_A_DOUBLES)) return 1;
+    h->sendA = (double*)d->sendA; h->recvA = (double*)d->recvA;
+    h->sendF = (int*)d->sendF; h->recvF = (int*)d->recvF;
+    h->localStats = (double*)d->localStats;
+    if ((d->nSend && (!h->sendA || !h->sendF)) || (d->nRecv && (!h->recvA || !h->recvF)) || !h->localStats)
+        return fail("halo: null exchange buffer");
+    h->st.sharedSlot = h->dSharedSlot;
+    h->st.combA = h->dCombA;
+    h->haloOn = true;
+    h->haloIter = 0;
+    HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
+    return 0;
+}
+
+int smgpu_iter_begin(smgpu_handle* h) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    if (!h->prmSet) return fail("smgpu_set_params has not been called");
+    HIP_OK(hipSetDevice(h->device));
+    if (runGeometry(h)) return 1;
+    State s = h->st;
+    const MeshView& m = h->mv;
+    if (h->nShared)
+        if (launchK(h, K_HALO, [&] {
+                hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared);
+                if (h->nSend)
+                    hipLaunchKernelGGL(k_halo_copyA, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_A_DOUBLES)), dim3(kBlock), 0, h->stream,
+                                       h->nSend, h->dSendShared, h->dOwnA, h->sendA);
+            })) return 1;
+    return 0;
+}
+
+int smgpu_iter_mid(smgpu_handle* h) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    if (h->nShared)
+        if (launchK(h, K_HALO, [&] {
+                hipLaunchKernelGGL(k_halo_combineA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
+                                   h->dCombSlots, h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err);
+            })) return 1;
+    if (runProposalAndConstraints(h)) return 1;
+    if (h->nSend)
+        if (launchK(h, K_HALO, [&] {
+                hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
+                                   h->dSharedLocal, h->st.frozen, h->sendF);
+            })) return 1;
+    return 0;
+}
+
+int smgpu_iter_end(smgpu_handle* h) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const Prm prm = makePrm(h->prm);
+    if (h->nShared && h->nRecv)
+        if (launchK(h, K_HALO, [&] {
+                hipLaunchKernelGGL(k_halo_orF, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dSharedLocal,
+                                   h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen);
+            })) return 1;
+    if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
+    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, h->stream, s, h->haloIter, -1.0, h->localStats); })) return 1;
+    std::swap(h->st.ptsCur, h->st.ptsNext);
+    h->haloIter++;
+    return 0;
+}
+
+// ---- debug / parity access -------------------------------------------------------------------
+int smgpu_debug_propose(smgpu_handle* h) {
+    if (!h) return fail("null handle");
+    if (!h->prmSet) return fail("smgpu_set_params has not been called");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
+    if (runGeometry(h)) return 1;
+    if (runProposalAndConstraints(h)) return 1;
+    return checkDeviceError(h);
+}
+
+int smgpu_debug_get_field(smgpu_handle* h, const char* name, double* out, int64_t* n) {
+    if (!h || !name || !n) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    const std::string s(name);
+    const State& st = h->st;
+    const int64_t P = h->mv.nPoints, C = h->mv.nCells, F = h->mv.nFaces, E = h->mv.nEdges;
+    const double* dsrc = nullptr;
+    const uint8_t* bsrc = nullptr;
+    int64_t cnt = 0;
+    if (s == "cellCentres") { dsrc = st.cellCtr; cnt = 3 * C; }
+    else if (s == "faceCentres") { dsrc = st.fCtr; cnt = 3 * F; }
+    else if (s == "faceAreas") { dsrc = st.fArea; cnt = 3 * F; }
+    else if (s == "newPoints") { dsrc = st.prop; cnt = 3 * P; }
+    else if (s == "points") { dsrc = st.ptsCur; cnt = 3 * P; }
+    else if (s == "edgeMinAngle") { dsrc = st.edgeMin; cnt = E; }
+    else if (s == "edgeMaxAngle") { dsrc = st.edgeMax; cnt = E; }
+    else if (s == "pointMinAngle") { dsrc = st.ptMin; cnt = P; }
+    else if (s == "pointMaxAngle") { dsrc = st.ptMax; cnt = P; }
+    else if (s == "isFrozenPoint") { bsrc = st.frozen; cnt = P; }
+    else if (s == "faActive") { bsrc = st.faActive; cnt = P; }
+    else return fail("unknown field " + s);
+    *n = cnt;
+    if (!out) return 0;
+    if (dsrc) {
+        HIP_OK(hipMemcpyAsync(out, dsrc, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+    } else {
+        std::vector<uint8_t> tmp((size_t)cnt);
+        HIP_OK(hipMemcpyAsync(tmp.data(), bsrc, (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        for (int64_t i = 0; i < cnt; ++i) out[i] = tmp[(size_t)i];
+    }
+    return 0;
+}
+
+static int topoGet(const Topology& t, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
+    const std::string s(kind);
+    const std::vector<int32_t>* off = nullptr;
+    const std::vector<int32_t>* val = nullptr;
+    if (s == "pointCells") { off = &t.pointCells.off; val = &t.pointCells.val; }
+    else if (s == "pointPoints") { off = &t.pointEdges.off; val = &t.pointPoints; }
+    else if (s == "pointEdges") { off = &t.pointEdges.off; val = &t.pointEdges.val; }
+    else if (s == "pointFaces") { off = &t.pointFaces.off; val = &t.pointFaces.val; }
+    else if (s == "pointFacePrev") { off = &t.pointFaces.off; val = &t.pfPrev; }
+    else if (s == "pointFaceNext") { off = &t.pointFaces.off; val = &t.pfNext; }
+    else if (s == "edgeFaces") { off = &t.edgeFaces.off; val = &t.edgeFaces.val; }
+    else if (s == "edgeCells") { off = &t.edgeCells.off; val = &t.edgeCells.val; }
+    else if (s == "cellFacesGeom") { off = &t.cellFacesGeom.off; val = &t.cellFacesGeom.val; }
+    else if (s == "edges") { val = &t.edges; }
+    else return fail("unknown addressing " + s);
+    *nnz = (int64_t)val->size();
+    if (offsets && off) std::memcpy(offsets, off->data(), sizeof(int32_t) * off->size());
+    if (values) std::memcpy(values, val->data(), sizeof(int32_t) * val->size());
+    return 0;
+}
+
+int smgpu_debug_get_addressing(smgpu_handle* h, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
+    if (!h || !kind || !nnz) return fail("null argument");
+    return topoGet(h->topo, kind, offsets, values, nnz);
+}
+
+struct smgpu_topology { Topology t; };
+
+int smgpu_topology_create(const smgpu_mesh_desc* d, smgpu_topology** out) {
+    if (!d || !out) return fail("null argument");
+    smgpu_topology* t = new smgpu_topology();
+    const std::string terr = t->t.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints,
+                                        d->owner, d->neighbour);
+    if (!terr.empty()) { delete t; *out = nullptr; return fail("smgpu_topology_create: " + terr); }
+    *out = t;
+    return 0;
+}
+int smgpu_topology_get(smgpu_topology* t, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
+    if (!t || !kind || !nnz) return fail("null argument");
+    return topoGet(t->t, kind, offsets, values, nnz);
+}
+int smgpu_topology_num_edges(smgpu_topology* t, int32_t* nEdges) {
+    if (!t || !nEdges) return fail("null argument");
+    *nEdges = t->t.nEdges;
+    return 0;
+}
+int smgpu_topology_destroy(smgpu_topology* t) { delete t; return 0; }
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// topology.hpp -- flat CSR addressing derived from a polyMesh (faces / owner / neighbour).
+//
+// Replaces what the reference gets from OpenFOAM's demand-driven primitiveMesh addressing
+// (mesh.pointCells(), pointPoints(), pointFaces(), pointEdges(), edges(), edgeFaces(),
+// edgeCells(); call sites src/smoothMesh.C:121,328,623,850,953,1149,1207,1294,1406) plus the
+// reference's own helper lists (generateCellFaces SM.C:1575-1620, generatePointNeighPoints
+// SM.C:190-217 -- the latter is replaced by an on-the-fly pointCells intersection).
+//
+// Orderings follow OpenFOAM where results depend on them:
+//   pointCells  ascending cell id          (sum order of SM.C:127-130)
+//   edges       (min,max) pairs in upper-triangular order (calcEdges, unsorted-points branch)
+//   pointEdges  ascending edge id, pointPoints[p][i] = other end of pointEdges[p][i]
+//               (=> ascending neighbour id; stable-sort ties SM.C:345, walk order SM.C:1406)
+//   pointFaces / edgeFaces ascending face id
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace smgpu {
+
+struct Csr {
+    std::vector<int32_t> off;  // n+1
+    std::vector<int32_t> val;
+    int64_t nnz() const { return (int64_t)val.size(); }
+    int32_t rows() const { return (int32_t)off.size() - 1; }
+};
+
+struct Topology {
+    int32_t nPoints = 0, nCells = 0, nFaces = 0, nInternalFaces = 0, nEdges = 0;
+    Csr facePoints;            // copy of the input
+    std::vector<int32_t> owner, neighbour;
+
+    Csr pointCells;
+    Csr pointFaces;            // val = face id
+    std::vector<int32_t> pfPrev, pfNext;  // per pointFaces entry: previous / next vertex of the
+                                          // point in that face (getNeighbourPoints SM.C:793-831)
+    std::vector<int32_t> edges;           // 2*nEdges (start < end)
+    Csr pointEdges;            // val = edge id
+    std::vector<int32_t> pointPoints;     // same offsets as pointEdges
+    Csr edgeFaces;
+    Csr edgeCells;
+    std::vector<uint8_t> ecFace0, ecFace1;  // per edgeCells entry: the two edge faces (indices into the
+                                            // edge's edgeFaces row) that belong to the cell
+                                            // (findCellFacePair SM.C:1042-1097)
+    // cell -> faces in the accumulation order of OpenFOAM makeCellCentresAndVols: faces owned
+    // (ascending), then faces neighboured (ascending); bit 31 set = cell is the face's neighbour
+    Csr cellFacesGeom;
+    int32_t maxFaceSize = 0, maxEdgeFaces = 0, maxPointCells = 0, maxPointPoints = 0;
+
+    // returns empty string on success, else the error (reference: FatalError)
+    std::string build(int32_t nPoints, int32_t nCells, int32_t nFaces, int32_t nInternalFaces,
+                      const int32_t* faceOffsets, const int32_t* facePts, const int32_t* owner,
+                      const int32_t* neighbour);
+};
+
+}  // namespace smgpu

@@ -1,0 +1,44 @@
+// vec3.hpp -- f64 3-vector algebra with OpenFOAM Vector<double> evaluation order
+// (VectorI.H: dot = x*x' + y*y' + z*z' left to right; v/s divides component-wise; no FMA:
+// the translation units that include this are compiled with -ffp-contract=off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace smgpu {
+
+#define SMGPU_HD __host__ __device__ __forceinline__
+
+struct V3 {
+    double x, y, z;
+};
+
+SMGPU_HD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+SMGPU_HD V3 operator+(const V3& a, const V3& b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+SMGPU_HD V3 operator-(const V3& a, const V3& b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+SMGPU_HD V3 operator*(double s, const V3& a) { return v3(s * a.x, s * a.y, s * a.z); }
+SMGPU_HD V3 operator/(const V3& a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+SMGPU_HD bool operator==(const V3& a, const V3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
+SMGPU_HD bool operator!=(const V3& a, const V3& b) { return !(a == b); }
+SMGPU_HD double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SMGPU_HD V3 cross(const V3& a, const V3& b) {
+    return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+SMGPU_HD double magSqr(const V3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+SMGPU_HD double mag(const V3& a) { return sqrt(magSqr(a)); }
+
+__device__ __forceinline__ V3 ldv(const double* __restrict__ base, int i) {
+    const double* p = base + 3 * (size_t)i;
+    return v3(p[0], p[1], p[2]);
+}
+__device__ __forceinline__ void stv(double* __restrict__ base, int i, const V3& v) {
+    double* p = base + 3 * (size_t)i;
+    p[0] = v.x; p[1] = v.y; p[2] = v.z;
+}
+
+// OpenFOAM doubleScalar.H constants used on the path (SM.C:259,621,1333; COM.H:15)
+#define SMGPU_GREAT 1.0e+15
+#define SMGPU_VSMALL 1.0e-300
+#define SMGPU_ROOTVSMALL 1.0e-150
+#define SMGPU_PI 3.14159265358979323846  // M_PI
+
+}  // namespace smgpu

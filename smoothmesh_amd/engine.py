@@ -1,0 +1,216 @@
+"""Host-side mirror of the C-ABI (include/smgpu.h): one SmoothEngine = one rank's fvMesh in the
+reference's loop (src/smoothMesh.C:2257-2437).  Parameter names are the reference's command-line
+option names (SM.C:1642-1784), defaults as SM.C:1857-1918."""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _ffi
+from .mesh import PolyMesh
+
+
+class SmgpuError(RuntimeError):
+    """A non-zero status from the library (the reference would FatalError/abort here)."""
+
+
+@dataclass
+class SmoothParams:
+    maxStepLength: float
+    minEdgeLength: float
+    relStepFrac: float = 0.5
+    totalMinFreeze: bool = False
+    edgeAngleConstraint: bool = True
+    faceAngleConstraint: bool = True
+    minAngle: float = 35.0
+    maxAngle: float = 160.0
+
+
+def default_params(meshMinEdgeLength: float, **over) -> SmoothParams:
+    """SM.C:1861-1865: minEdgeLength = 0.5 * mesh min edge, maxStepLength = 0.3 * minEdgeLength."""
+    minEdge = over.pop("minEdgeLength", 0.5 * meshMinEdgeLength)
+    maxStep = over.pop("maxStepLength", 0.3 * minEdge)
+    return SmoothParams(maxStepLength=maxStep, minEdgeLength=minEdge, **over)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+def make_desc(mesh: PolyMesh, isInternalPoint, isSmoothingSurfacePoint, device=0, stream=None):
+    keep = dict(
+        pts=np.ascontiguousarray(mesh.points, dtype=np.float64),
+        fo=mesh.faceOffsets, fp=mesh.facePoints, ow=mesh.owner, ne=mesh.neighbour,
+        ip=np.ascontiguousarray(isInternalPoint, dtype=np.uint8),
+        sp=None if isSmoothingSurfacePoint is None else np.ascontiguousarray(isSmoothingSurfacePoint, dtype=np.uint8),
+    )
+    d = _ffi.MeshDesc()
+    d.nPoints, d.nCells, d.nFaces, d.nInternalFaces = mesh.nPoints, mesh.nCells, mesh.nFaces, mesh.nInternalFaces
+    d.points = _p(keep["pts"], _ffi.c_f64p)
+    d.faceOffsets = _p(keep["fo"], _ffi.c_i32p)
+    d.facePoints = _p(keep["fp"], _ffi.c_i32p)
+    d.owner = _p(keep["ow"], _ffi.c_i32p)
+    d.neighbour = _p(keep["ne"], _ffi.c_i32p)
+    d.isInternalPoint = _p(keep["ip"], _ffi.c_u8p)
+    d.isSmoothingSurfacePoint = _p(keep["sp"], _ffi.c_u8p) if keep["sp"] is not None else None
+    d.device = device
+    d.stream = stream
+    return d, keep
+
+
+class HostTopology:
+    """Host-only addressing build (no GPU): the library's derived lists, for checks and hosts."""
+
+    def __init__(self, mesh: PolyMesh):
+        self._lib = _ffi.lib()
+        d, self._keep = make_desc(mesh, np.ones(mesh.nPoints, np.uint8), None)
+        self._h = C.c_void_p()
+        if self._lib.smgpu_topology_create(C.byref(d), C.byref(self._h)):
+            raise SmgpuError(self._lib.smgpu_last_error().decode())
+
+    def addressing(self, kind):
+        nnz = C.c_int64()
+        k = kind.encode()
+        if self._lib.smgpu_topology_get(self._h, k, None, None, C.byref(nnz)):
+            raise SmgpuError(self._lib.smgpu_last_error().decode())
+        vals = np.empty(nnz.value, np.int32)
+        if kind == "edges":
+            self._lib.smgpu_topology_get(self._h, k, None, _p(vals, _ffi.c_i32p), C.byref(nnz))
+            return None, vals.reshape(-1, 2)
+        rows = {"pointCells": "P", "pointPoints": "P", "pointEdges": "P", "pointFaces": "P", "pointFacePrev": "P",
+                "pointFaceNext": "P", "edgeFaces": "E", "edgeCells": "E", "cellFacesGeom": "C"}[kind]
+        n = {"P": self._keep["pts"].shape[0], "E": self.num_edges(), "C": int(self._keep["ow"].max()) + 1}[rows]
+        off = np.empty(n + 1, np.int32)
+        self._lib.smgpu_topology_get(self._h, k, _p(off, _ffi.c_i32p), _p(vals, _ffi.c_i32p), C.byref(nnz))
+        return off, vals
+
+    def num_edges(self):
+        n = C.c_int32()
+        self._lib.smgpu_topology_num_edges(self._h, C.byref(n))
+        return n.value
+
+    def close(self):
+        if self._h:
+            self._lib.smgpu_topology_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SmoothEngine:
+    def __init__(self, mesh: PolyMesh, isInternalPoint=None, isSmoothingSurfacePoint=None, device=0, stream=None):
+        self._lib = _ffi.lib()
+        self.mesh = mesh
+        if isInternalPoint is None:
+            isInternalPoint = mesh.find_internal_points()
+        if isSmoothingSurfacePoint is None:
+            isSmoothingSurfacePoint = mesh.smoothing_surface_points()
+        self.isInternalPoint = np.ascontiguousarray(isInternalPoint, dtype=np.uint8)
+        d, keep = make_desc(mesh, self.isInternalPoint, isSmoothingSurfacePoint, device, stream)
+        self._h = C.c_void_p()
+        self._check(self._lib.smgpu_create(C.byref(d), C.byref(self._h)))
+        self.nPoints = mesh.nPoints
+        self._keepalive = []
+
+    def _check(self, rc):
+        if rc:
+            raise SmgpuError(self._lib.smgpu_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.smgpu_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- setup ---------------------------------------------------------------------------------
+    def sizes(self):
+        s = _ffi.Sizes()
+        self._check(self._lib.smgpu_get_sizes(self._h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in s._fields_}
+
+    def mesh_stats(self):
+        """getMeshStats, SM.C:1478-1541 -> (meshMinEdgeLength, meshMaxEdgeLength)."""
+        a, b = C.c_double(), C.c_double()
+        self._check(self._lib.smgpu_mesh_stats(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def set_params(self, p: SmoothParams):
+        q = _ffi.Params(p.maxStepLength, p.relStepFrac, p.minEdgeLength, int(p.totalMinFreeze),
+                        int(p.edgeAngleConstraint), int(p.faceAngleConstraint), p.minAngle, p.maxAngle)
+        self._check(self._lib.smgpu_set_params(self._h, C.byref(q)))
+        self.params = p
+
+    # -- the loop ------------------------------------------------------------------------------
+    def iterate(self, centroidalIters: int, relTol: float = 0.02):
+        """Returns (nDone, residuals[nDone], nFrozenPoints[nDone]) -- the values of the reference's
+        per-iteration log line (SM.C:2396)."""
+        stats = (_ffi.IterStats * max(centroidalIters, 1))()
+        nDone = C.c_int32()
+        self._check(self._lib.smgpu_iterate(self._h, centroidalIters, relTol, stats, C.byref(nDone)))
+        n = nDone.value
+        res = np.array([stats[i].residual for i in range(n)], dtype=np.float64)
+        frz = np.array([stats[i].nFrozenPoints for i in range(n)], dtype=np.int64)
+        return n, res, frz
+
+    def get_points(self):
+        out = np.empty((self.nPoints, 3), np.float64)
+        self._check(self._lib.smgpu_get_points(self._h, _p(out, _ffi.c_f64p)))
+        return out
+
+    def set_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        assert pts.shape == (self.nPoints, 3)
+        self._check(self._lib.smgpu_set_points(self._h, _p(pts, _ffi.c_f64p)))
+
+    # -- timing --------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._check(self._lib.smgpu_enable_timing(self._h, int(on)))
+
+    def reset_counters(self):
+        self._check(self._lib.smgpu_reset_counters(self._h))
+
+    def counters(self):
+        c = _ffi.Counters()
+        self._check(self._lib.smgpu_get_counters(self._h, C.byref(c)))
+        return [dict(name=c.name[i].decode(), ms=c.ms[i], launches=c.launches[i], algoBytesPerLaunch=c.algoBytesPerLaunch[i])
+                for i in range(c.nKernels)]
+
+    # -- multi-rank ----------------------------------------------------------------------------
+    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats):
+        """Pointers are raw device addresses (ints); see smgpu_halo_desc."""
+        keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (sharedLocal, sendShared, combOffsets, combSlots)]
+        d = _ffi.HaloDesc()
+        d.nShared = len(keep[0]); d.sharedLocal = _p(keep[0], _ffi.c_i32p)
+        d.nSend = len(keep[1]); d.sendShared = _p(keep[1], _ffi.c_i32p)
+        d.nRecv = int(nRecv); d.combOffsets = _p(keep[2], _ffi.c_i32p); d.combSlots = _p(keep[3], _ffi.c_i32p)
+        d.sendA, d.recvA, d.sendF, d.recvF, d.localStats = sendA, recvA, sendF, recvF, localStats
+        self._check(self._lib.smgpu_halo_configure(self._h, C.byref(d)))
+
+    def iter_begin(self):
+        self._check(self._lib.smgpu_iter_begin(self._h))
+
+    def iter_mid(self):
+        self._check(self._lib.smgpu_iter_mid(self._h))
+
+    def iter_end(self):
+        self._check(self._lib.smgpu_iter_end(self._h))
+
+    # -- debug / parity ------------------------------------------------------------------------
+    def debug_propose(self):
+        self._check(self._lib.smgpu_debug_propose(self._h))
+
+    def debug_field(self, name):
+        n = C.c_int64()
+        self._check(self._lib.smgpu_debug_get_field(self._h, name.encode(), None, C.byref(n)))
+        out = np.empty(n.value, np.float64)
+        self._check(self._lib.smgpu_debug_get_field(self._h, name.encode(), _p(out, _ffi.c_f64p), C.byref(n)))
+        return out
