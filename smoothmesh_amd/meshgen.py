@@ -1,32 +1,53 @@
-"""Synthetic polyMesh generators standing in for OpenFOAM's blockMesh (unavailable here).
+"""Synthetic polyMesh generators standing in for OpenFOAM's blockMesh / decomposePar (unavailable here).
 
 hex_block() reproduces blockMesh's single-block numbering: point id
 i + j(nx+1) + k(nx+1)(ny+1), cell id i + j nx + k nx ny, internal faces in upper-triangular order
-(per cell: +x, +y, +z neighbour), then the six boundary patches.  Interior points can be jittered
-with a seeded PRNG so that smoothing has work to do (a uniform block is a fixed point,
-src/smoothMesh.C:2401).
+(per cell: +x, +y, +z neighbour), then the six boundary patches.  Interior points can be jittered so
+that smoothing has work to do (a uniform block is a fixed point, src/smoothMesh.C:2401).  The jitter
+is a counter-based hash of (seed, global point id, axis), so a sub-domain generated directly by
+hex_subdomain() carries exactly the coordinates the global mesh would give it.
 """
 import numpy as np
 
 from .mesh import PolyMesh, Patch
 
 
+def _hash_uniform(seed, gid, axis):
+    """splitmix64 of (seed, 3*gid+axis) -> uniform [0,1) doubles; vectorised over gid."""
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + (gid.astype(np.uint64) * np.uint64(3) + np.uint64(axis))
+             * np.uint64(0xD1B54A32D192ED03) + np.uint64(0x9E3779B97F4A7C15))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return (x >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def _lattice_points(gi, gj, gk, GN, lengths, jitter, seed):
+    """coordinates of lattice points (global indices gi,gj,gk) of a GN=(GNX,GNY,GNZ)-cell block"""
+    GNX, GNY, GNZ = GN
+    hx, hy, hz = lengths[0] / GNX, lengths[1] / GNY, lengths[2] / GNZ
+    pts = np.stack([gi * hx, gj * hy, gk * hz], axis=1).astype(np.float64)
+    if jitter > 0.0:
+        gid = gi.astype(np.int64) + gj.astype(np.int64) * (GNX + 1) + gk.astype(np.int64) * (GNX + 1) * (GNY + 1)
+        interior = (gi > 0) & (gi < GNX) & (gj > 0) & (gj < GNY) & (gk > 0) & (gk < GNZ)
+        h = np.array([hx, hy, hz])
+        for a in range(3):
+            u = _hash_uniform(seed, gid, a)
+            pts[:, a] += np.where(interior, (2.0 * u - 1.0) * jitter * h[a], 0.0)
+    return pts
+
+
 def hex_block(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), jitter=0.0, seed=12345) -> PolyMesh:
     ny = nx if ny is None else ny
     nz = nx if nz is None else nz
     npx, npy = nx + 1, ny + 1
-    hx, hy, hz = lengths[0] / nx, lengths[1] / ny, lengths[2] / nz
 
     def pid(i, j, k):
         return (i + j * npx + k * npx * npy).astype(np.int64)
 
     K, J, I = np.meshgrid(np.arange(nz + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
-    pts = np.stack([I.ravel() * hx, J.ravel() * hy, K.ravel() * hz], axis=1).astype(np.float64)
-    if jitter > 0.0:
-        rng = np.random.default_rng(seed)
-        interior = ((I > 0) & (I < nx) & (J > 0) & (J < ny) & (K > 0) & (K < nz)).ravel()
-        d = rng.uniform(-jitter, jitter, size=(pts.shape[0], 3)) * np.array([hx, hy, hz])
-        pts[interior] += d[interior]
+    pts = _lattice_points(I.ravel(), J.ravel(), K.ravel(), (nx, ny, nz), lengths, jitter, seed)
 
     ck, cj, ci = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
     ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()

@@ -79,12 +79,20 @@ def test_relTol_stops_like_reference(oracle_lib):
 
 
 def test_uniform_block_is_fixed_point(oracle_lib):
-    mesh = _mk(6, 6, 6, 0.0, 0)
+    # h = 1/8 is exact in binary, so every cell centre / centroid is exact: residual exactly 0
+    mesh = _mk(8, 8, 8, 0.0, 0)
     o, e, p = _pair(mesh, oracle_lib)
     n, res, frz = e.iterate(10, 0.02)
-    assert n == 1 and res[0] == 0.0          # residual exactly 0 -> stops after 1 iteration (SM.C:2401)
-    assert frz[0] == mesh.nPoints - 5 ** 3   # every boundary point counts as frozen (SM.C:2387-2391)
+    assert n == 1 and res[0] == 0.0          # stops after 1 iteration (SM.C:2401)
+    assert frz[0] == mesh.nPoints - 7 ** 3   # every boundary point counts as frozen (SM.C:2387-2391)
     assert np.array_equal(e.get_points(), mesh.points)
+    # h = 1/6 is not exact: residual is rounding noise, identical to the oracle's
+    mesh = _mk(6, 6, 6, 0.0, 0)
+    o, e, p = _pair(mesh, oracle_lib)
+    n_o, res_o, frz_o = o.iterate(10, 0.02)
+    n_g, res_g, frz_g = e.iterate(10, 0.02)
+    assert n_o == n_g == 1 and res_o[0] == res_g[0] and res_g[0] < 1e-12
+    assert np.array_equal(frz_o, frz_g)
 
 
 @pytest.mark.parametrize("jit,seed", [(0.45, 7), (0.48, 11)])
