@@ -42,7 +42,10 @@ typedef struct smgpu_mesh_desc {
     const uint8_t* isInternalPoint;          /* [nPoints]  SM.C:1978-1979                    */
     const uint8_t* isSmoothingSurfacePoint;  /* [nPoints]  BPS.C:404-412; NULL = all false   */
     int32_t device;                 /* HIP device ordinal                                     */
-    void* stream;                   /* hipStream_t to run on; NULL = library creates one      */
+    void* stream;                   /* hipStream_t to run on (with useCallerStream)           */
+    int32_t useCallerStream;        /* 0: library creates its own stream and ignores `stream`;
+                                       1: run on `stream` as given -- NULL then means the HIP null
+                                       stream (what torch.cuda.current_stream() is by default)   */
 } smgpu_mesh_desc;
 
 /* Loop parameters, SM.C:1861-1890 (names as the command-line options). */

@@ -169,4 +169,64 @@ int orc_multi_iterate(void* mh, int nIters, double relTol, double* residuals, in
     return static_cast<MultiDomain*>(mh)->iterate(nIters, relTol, residuals, nFrozen);
 }
 
+// ---- one rank's side of the shared-point exchange (used by the CPU multi-process tests, where an
+// oracle Domain stands in for the HIP engine behind smoothmesh_amd.halo) -----------------------
+// record layout = include/smgpu.h exchange A: 13 doubles {sum, r1, r2, r3, (int32 count | int32 hc << 32)}
+static void packRecord(const Domain* d, int p, double* r) {
+    const Vec3 &s = d->cellSum[p], &a = d->closest1[p], &b = d->closest2[p], &c = d->closest3[p];
+    r[0] = s.x; r[1] = s.y; r[2] = s.z; r[3] = a.x; r[4] = a.y; r[5] = a.z;
+    r[6] = b.x; r[7] = b.y; r[8] = b.z; r[9] = c.x; r[10] = c.y; r[11] = c.z;
+    const long long pk = ((long long)d->hasCommonCell[p] << 32) | (long long)(unsigned int)d->cellCount[p];
+    std::memcpy(&r[12], &pk, 8);
+}
+void orc_halo_packA(void* h, int nShared, const int* sharedLocal, int nSend, const int* sendShared, double* sendA) {
+    Domain* d = static_cast<Domain*>(h);
+    (void)nShared;
+    for (int i = 0; i < nSend; ++i) packRecord(d, sharedLocal[sendShared[i]], sendA + 13 * (size_t)i);
+}
+void orc_halo_combineA(void* h, int nShared, const int* sharedLocal, const int* combOff, const int* combSlots, const double* recvA) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nShared; ++i) {
+        const int p = sharedLocal[i];
+        const int b = combOff[i], n = combOff[i + 1] - b;
+        std::vector<Vec3> r1(n), r2(n), r3(n);
+        std::vector<unsigned char> hc(n);
+        Vec3 sum{0, 0, 0};
+        int cnt = 0, self = 0;
+        double own[13];
+        packRecord(d, p, own);
+        for (int j = 0; j < n; ++j) {
+            const int sl = combSlots[b + j];
+            const double* r = (sl < 0) ? own : recvA + 13 * (size_t)sl;
+            if (sl < 0) self = j;
+            sum.x += r[0]; sum.y += r[1]; sum.z += r[2];
+            r1[j] = {r[3], r[4], r[5]}; r2[j] = {r[6], r[7], r[8]}; r3[j] = {r[9], r[10], r[11]};
+            long long pk; std::memcpy(&pk, &r[12], 8);
+            cnt += (int)(pk & 0xffffffffll);
+            hc[j] = (unsigned char)(pk >> 32);
+        }
+        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data());
+        unsigned char any = 0;
+        for (int j = 0; j < n; ++j) any |= hc[j];
+        d->cellSum[p] = sum; d->cellCount[p] = cnt;
+        d->closest1[p] = r1[self]; d->closest2[p] = r2[self]; d->closest3[p] = r3[self];
+        d->hasCommonCell[p] = any;
+    }
+}
+void orc_halo_packF(void* h, const int* sharedLocal, int nSend, const int* sendShared, int* sendF) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nSend; ++i) sendF[i] = d->isFrozenPoint[sharedLocal[sendShared[i]]];
+}
+void orc_halo_orF(void* h, int nShared, const int* sharedLocal, const int* combOff, const int* combSlots, const int* recvF) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nShared; ++i)
+        for (int k = combOff[i]; k < combOff[i + 1]; ++k)
+            if (combSlots[k] >= 0 && recvF[combSlots[k]]) d->isFrozenPoint[sharedLocal[i]] = 1;
+}
+void orc_local_stats(void* h, double* out2) {
+    Domain* d = static_cast<Domain*>(h);
+    out2[0] = d->residualLocal; out2[1] = (double)d->nFrozenLocal;
+}
+
 }  // extern "C"
+

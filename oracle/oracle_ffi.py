@@ -55,6 +55,11 @@ def lib():
         l.orc_multi_set_shared.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p]
         l.orc_multi_iterate.restype = C.c_int
         l.orc_multi_iterate.argtypes = [C.c_void_p, C.c_int, C.c_double, f64p, i32p]
+        l.orc_halo_packA.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int, i32p, f64p]
+        l.orc_halo_combineA.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, f64p]
+        l.orc_halo_packF.argtypes = [C.c_void_p, i32p, C.c_int, i32p, i32p]
+        l.orc_halo_orF.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]
+        l.orc_local_stats.argtypes = [C.c_void_p, f64p]
         _lib = l
     return _lib
 
@@ -151,6 +156,53 @@ class Oracle:
         off = np.empty(rows + 1, np.int32)
         self._lib.orc_get_addressing(self._h, kind.encode(), _p(off, i32p), _p(vals, i32p))
         return off, vals
+
+
+class OracleRankEngine:
+    """An oracle Domain behind the engine interface smoothmesh_amd.halo drives (mesh_stats, set_params,
+    halo_configure, iter_begin/mid/end, get_points) -- lets the CPU tests run the product's multi-rank
+    host logic (slot tables, torch.distributed exchange, stop rule) under gloo with the oracle standing
+    in for the HIP kernels.  Buffers arrive as raw host addresses (CPU torch tensors)."""
+
+    def __init__(self, mesh):
+        self.o = Oracle(mesh)
+        self._lib = lib()
+
+    def mesh_stats(self):
+        return self.o.mesh_stats()
+
+    def set_params(self, p):
+        self.o.set_params(p)
+
+    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats):
+        self.sharedLocal = np.ascontiguousarray(sharedLocal, np.int32)
+        self.sendShared = np.ascontiguousarray(sendShared, np.int32)
+        self.combOffsets = np.ascontiguousarray(combOffsets, np.int32)
+        self.combSlots = np.ascontiguousarray(combSlots, np.int32)
+        self.ptr = dict(sendA=C.cast(sendA, f64p), recvA=C.cast(recvA, f64p), sendF=C.cast(sendF, i32p),
+                        recvF=C.cast(recvF, i32p), localStats=C.cast(localStats, f64p))
+
+    def iter_begin(self):
+        self.o.phaseA()
+        self._lib.orc_halo_packA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), len(self.sendShared),
+                                 _p(self.sendShared, i32p), self.ptr["sendA"])
+
+    def iter_mid(self):
+        self._lib.orc_halo_combineA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
+                                    _p(self.combSlots, i32p), self.ptr["recvA"])
+        self.o.phaseB()
+        self._lib.orc_halo_packF(self.o._h, _p(self.sharedLocal, i32p), len(self.sendShared), _p(self.sendShared, i32p),
+                                 self.ptr["sendF"])
+
+    def iter_end(self):
+        self._lib.orc_halo_orF(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
+                               _p(self.combSlots, i32p), self.ptr["recvF"])
+        self.o.phaseC()
+        self._lib.orc_local_stats(self.o._h, self.ptr["localStats"])
+        self.o.commit()
+
+    def get_points(self):
+        return self.o.points()
 
 
 class MultiOracle:

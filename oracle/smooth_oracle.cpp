@@ -649,6 +649,40 @@ int Domain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) 
 //    starting from ITS OWN value, then the other sharers' values in ascending domain order
 //    (processor-patch exchange: cop(myValue, nbrValue)), so an exact tie keeps the own value;
 //  * orEqOp: logical or.
+// The three sequential closest-point syncs of findClosestPoints (SM.C:391-469) for the n ranks
+// sharing one point; arrays hold every sharer's local values on entry and its synced values on exit.
+void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc) {
+    auto fold = [&](const std::vector<Vec3>& v, int self) {
+        Vec3 x = v[self];
+        for (int k = 0; k < n; ++k) {
+            if (k == self) continue;
+            x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
+        }
+        return x;
+    };
+    {   // position 1, SM.C:397-419
+        std::vector<Vec3> sent(r1, r1 + n);
+        for (int j = 0; j < n; ++j) {
+            const Vec3 sv = fold(sent, j);
+            if (isCloserPoint(sv, r1[j])) { r3[j] = r2[j]; r2[j] = r1[j]; r1[j] = sv; hc[j] = 0; }
+        }
+    }
+    {   // position 2, SM.C:424-445
+        std::vector<Vec3> sent(r2, r2 + n);
+        for (int j = 0; j < n; ++j) {
+            const Vec3 sv = fold(sent, j);
+            if (isCloserPoint(sv, r2[j])) { r3[j] = r2[j]; r2[j] = sv; hc[j] = 0; }
+        }
+    }
+    {   // position 3, SM.C:450-469
+        std::vector<Vec3> sent(r3, r3 + n);
+        for (int j = 0; j < n; ++j) {
+            const Vec3 sv = fold(sent, j);
+            if (isCloserPoint(sv, r3[j])) { r3[j] = sv; }
+        }
+    }
+}
+
 void MultiDomain::syncA() {
     for (const SharedPoint& sp : shared) {
         const int n = int(sp.domain.size());
@@ -673,35 +707,7 @@ void MultiDomain::syncA() {
             r3[j] = d->closest3[sp.local[j]];
             hc[j] = d->hasCommonCell[sp.local[j]];
         }
-        auto fold = [&](const std::vector<Vec3>& v, int self) {
-            Vec3 x = v[self];
-            for (int k = 0; k < n; ++k) {
-                if (k == self) continue;
-                x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
-            }
-            return x;
-        };
-        {   // position 1, SM.C:397-419
-            std::vector<Vec3> sent = r1;
-            for (int j = 0; j < n; ++j) {
-                const Vec3 sv = fold(sent, j);
-                if (isCloserPoint(sv, r1[j])) { r3[j] = r2[j]; r2[j] = r1[j]; r1[j] = sv; hc[j] = 0; }
-            }
-        }
-        {   // position 2, SM.C:424-445
-            std::vector<Vec3> sent = r2;
-            for (int j = 0; j < n; ++j) {
-                const Vec3 sv = fold(sent, j);
-                if (isCloserPoint(sv, r2[j])) { r3[j] = r2[j]; r2[j] = sv; hc[j] = 0; }
-            }
-        }
-        {   // position 3, SM.C:450-469
-            std::vector<Vec3> sent = r3;
-            for (int j = 0; j < n; ++j) {
-                const Vec3 sv = fold(sent, j);
-                if (isCloserPoint(sv, r3[j])) { r3[j] = sv; }
-            }
-        }
+        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data());
         unsigned char any = 0;  // SM.C:472-478
         for (int j = 0; j < n; ++j) any |= hc[j];
         for (int j = 0; j < n; ++j) {

@@ -124,5 +124,6 @@ public:
 double edgeEdgeAngle(const Vec3& c, const Vec3& p1, const Vec3& p2);   // SM.C:766-786
 double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1);  // SM.C:980-998
 bool isCloserPoint(const Vec3& a, const Vec3& b);  // SM.C:246-272
+void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc);  // SM.C:391-469
 
 }  // namespace orc

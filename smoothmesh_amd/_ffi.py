@@ -15,7 +15,7 @@ class MeshDesc(C.Structure):
         ("nPoints", C.c_int32), ("nCells", C.c_int32), ("nFaces", C.c_int32), ("nInternalFaces", C.c_int32),
         ("points", c_f64p), ("faceOffsets", c_i32p), ("facePoints", c_i32p), ("owner", c_i32p),
         ("neighbour", c_i32p), ("isInternalPoint", c_u8p), ("isSmoothingSurfacePoint", c_u8p),
-        ("device", C.c_int32), ("stream", C.c_void_p),
+        ("device", C.c_int32), ("stream", C.c_void_p), ("useCallerStream", C.c_int32),
     ]
 
 

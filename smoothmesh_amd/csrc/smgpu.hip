@@ -170,7 +170,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (!terr.empty()) { delete h; return fail("smgpu_create: " + terr); }
     auto cleanup = [&](int rc) { smgpu_destroy(h); return rc; };
     if (hipSetDevice(h->device) != hipSuccess) return cleanup(fail("hipSetDevice failed"));
-    if (d->stream) h->stream = (hipStream_t)d->stream;
+    if (d->useCallerStream) h->stream = (hipStream_t)d->stream;
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return cleanup(fail("hipStreamCreate failed"));
         h->ownStream = true;

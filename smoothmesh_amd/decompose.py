@@ -1,0 +1,132 @@
+"""Domain decomposition in OpenFOAM decomposePar layout (processorN/constant/polyMesh).
+
+The reference runs one MPI rank per sub-domain produced by decomposePar (testcase/run_parallel,
+system/decomposeParDict); processor-patch points count as internal points (src/smoothMesh.C:49-58)
+and per-point values are combined across ranks by syncTools::syncPointList.  decomposePar is not
+available here, so this module writes the same layout:
+  * local cells / points / faces keep ascending global order (cell-, point-, faceProcAddressing);
+  * faces: internal, then every physical patch (kept even when empty), then one processor patch per
+    neighbouring rank (ascending rank; faces in ascending global face id);
+  * a processor face whose local cell is the global neighbour is reversed about its first vertex
+    (face::reverseFace), so its normal points out of the local domain.
+"""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from .mesh import PolyMesh, Patch
+
+
+@dataclass
+class SubDomain:
+    mesh: PolyMesh
+    rank: int
+    nRanks: int
+    pointProcAddressing: np.ndarray   # local point -> global point id
+    cellProcAddressing: np.ndarray = None
+    faceProcAddressing: np.ndarray = None
+
+    def processor_patch_points(self) -> np.ndarray:
+        """sorted unique GLOBAL ids of the points on this rank's processor patches"""
+        m = self.mesh
+        ids = []
+        for p in m.patches:
+            if p.type == "processor" and p.nFaces:
+                a, b = m.faceOffsets[p.startFace], m.faceOffsets[p.startFace + p.nFaces]
+                ids.append(m.facePoints[a:b])
+        if not ids:
+            return np.zeros(0, np.int64)
+        return np.unique(self.pointProcAddressing[np.concatenate(ids)])
+
+
+def grid_partition(mesh: PolyMesh, grid) -> np.ndarray:
+    """decomposePar 'simple'-like geometric partition: split the bounding box of the cell-centre
+    estimates (mean of the cell's face vertex averages) into grid[0] x grid[1] x grid[2] boxes."""
+    px, py, pz = grid
+    F = mesh.nFaces
+    sizes = np.diff(mesh.faceOffsets)
+    fsum = np.zeros((F, 3))
+    np.add.at(fsum, np.repeat(np.arange(F), sizes), mesh.points[mesh.facePoints])
+    fc = fsum / sizes[:, None]
+    cs = np.zeros((mesh.nCells, 3)); cn = np.zeros(mesh.nCells)
+    np.add.at(cs, mesh.owner, fc); np.add.at(cn, mesh.owner, 1)
+    np.add.at(cs, mesh.neighbour, fc[:mesh.nInternalFaces]); np.add.at(cn, mesh.neighbour, 1)
+    cc = cs / cn[:, None]
+    lo, hi = mesh.points.min(0), mesh.points.max(0)
+    rel = (cc - lo) / (hi - lo)
+    r = [np.minimum((rel[:, a] * g).astype(np.int64), g - 1) for a, g in enumerate((px, py, pz))]
+    return (r[0] + r[1] * px + r[2] * px * py).astype(np.int32)
+
+
+def _take_faces(mesh, fids, reverse):
+    """CSR sub-list of faces `fids`; faces with reverse[i] get reverseFace ordering"""
+    off, fp = mesh.faceOffsets, mesh.facePoints
+    b = off[fids].astype(np.int64); e = off[fids + 1].astype(np.int64)
+    n = e - b
+    newoff = np.zeros(len(fids) + 1, np.int64); np.cumsum(n, out=newoff[1:])
+    j = np.arange(newoff[-1]) - np.repeat(newoff[:-1], n)
+    bb = np.repeat(b, n); ee = np.repeat(e, n); rv = np.repeat(reverse, n)
+    src = np.where(rv & (j > 0), ee - j, bb + j)
+    return newoff, fp[src]
+
+
+def decompose(mesh: PolyMesh, cellRank: np.ndarray, nRanks: int) -> List[SubDomain]:
+    cellRank = np.asarray(cellRank)
+    nIF = mesh.nInternalFaces
+    own_r = cellRank[mesh.owner]
+    nei_r = cellRank[mesh.neighbour]
+    subs = []
+    for r in range(nRanks):
+        cells = np.flatnonzero(cellRank == r)
+        g2l_cell = np.full(mesh.nCells, -1, np.int64); g2l_cell[cells] = np.arange(len(cells))
+        intf = np.flatnonzero((own_r[:nIF] == r) & (nei_r == r))
+        groups = [(intf, np.zeros(len(intf), bool))]
+        own_l = [g2l_cell[mesh.owner[intf]]]
+        nei_l = g2l_cell[mesh.neighbour[intf]]
+        patches = []
+        start = len(intf)
+        for p in mesh.patches:
+            f = np.arange(p.startFace, p.startFace + p.nFaces)
+            f = f[own_r[f] == r]
+            groups.append((f, np.zeros(len(f), bool)))
+            own_l.append(g2l_cell[mesh.owner[f]])
+            patches.append(Patch(p.name, p.type, len(f), start))
+            start += len(f)
+        # processor faces
+        cut = np.flatnonzero(((own_r[:nIF] == r) | (nei_r == r)) & (own_r[:nIF] != nei_r))
+        mine_is_owner = own_r[cut] == r
+        other = np.where(mine_is_owner, nei_r[cut], own_r[cut])
+        for o in np.unique(other):
+            sel = other == o
+            f = cut[sel]
+            rev = ~mine_is_owner[sel]
+            groups.append((f, rev))
+            own_l.append(g2l_cell[np.where(rev, mesh.neighbour[f], mesh.owner[f])])
+            patches.append(Patch(f"procBoundary{r}to{int(o)}", "processor", len(f), start, myProcNo=r, neighbProcNo=int(o)))
+            start += len(f)
+        fids = np.concatenate([g[0] for g in groups])
+        rev = np.concatenate([g[1] for g in groups])
+        off, fpg = _take_faces(mesh, fids, rev)
+        gpts = np.unique(fpg)
+        fpl = np.searchsorted(gpts, fpg)
+        sub = PolyMesh(points=mesh.points[gpts], faceOffsets=off.astype(np.int32), facePoints=fpl.astype(np.int32),
+                       owner=np.concatenate(own_l).astype(np.int32), neighbour=nei_l.astype(np.int32), patches=patches,
+                       nCells=len(cells))
+        subs.append(SubDomain(sub, r, nRanks, gpts.astype(np.int64), cells.astype(np.int64), fids.astype(np.int64)))
+    return subs
+
+
+def shared_point_table(subs: List[SubDomain]):
+    """Global view (tests / single-process drivers): CSR over points held by >= 2 sub-domains ->
+    (offsets, domain ids ascending, local ids)."""
+    g = np.concatenate([s.pointProcAddressing for s in subs])
+    d = np.concatenate([np.full(len(s.pointProcAddressing), s.rank, np.int32) for s in subs])
+    l = np.concatenate([np.arange(len(s.pointProcAddressing), dtype=np.int32) for s in subs])
+    order = np.lexsort((d, g))
+    g, d, l = g[order], d[order], l[order]
+    uniq, first, cnt = np.unique(g, return_index=True, return_counts=True)
+    keep = cnt >= 2
+    idx = np.concatenate([np.arange(f, f + c) for f, c in zip(first[keep], cnt[keep])]) if keep.any() else np.zeros(0, np.int64)
+    off = np.zeros(keep.sum() + 1, np.int32); np.cumsum(cnt[keep], out=off[1:])
+    return off, d[idx], l[idx]

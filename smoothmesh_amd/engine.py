@@ -54,7 +54,8 @@ def make_desc(mesh: PolyMesh, isInternalPoint, isSmoothingSurfacePoint, device=0
     d.isInternalPoint = _p(keep["ip"], _ffi.c_u8p)
     d.isSmoothingSurfacePoint = _p(keep["sp"], _ffi.c_u8p) if keep["sp"] is not None else None
     d.device = device
-    d.stream = stream
+    d.stream = stream if stream else None      # stream: None = library-owned stream; an int handle
+    d.useCallerStream = 0 if stream is None else 1   # (0 = the HIP null stream) = run on the caller's
     return d, keep
 
 

@@ -1,0 +1,217 @@
+"""Multi-rank driver: one rank per GPU, OpenFOAM-style sub-domains, shared-point exchange.
+
+Replaces the reference's syncTools::syncPointList / returnReduce calls inside the loop
+(src/smoothMesh.C:134,142,402,429,455,472 -> exchange "A"; :2374 -> exchange "F"; :1567,2396 ->
+the 2-scalar reduction).  The library (include/smgpu.h, smgpu_iter_begin/mid/end) packs and
+combines on the device; this module only builds the slot tables and moves the packed buffers with
+torch.distributed (backend "nccl" = RCCL over xGMI on MI355X; "gloo" in the CPU tests).
+
+Exchange pattern: every pair of ranks that shares points exchanges, in ascending global point id,
+one record per shared point -- a single all_to_all_single per exchange (two per iteration) plus one
+all_gather of {residual, nFrozenPoints}.  No collective touches non-shared data.
+"""
+import numpy as np
+
+A_DOUBLES = 13  # SMGPU_HALO_A_DOUBLES
+
+
+class HaloTables:
+    """Slot tables of one rank from the per-rank lists of processor-patch point ids."""
+
+    def __init__(self, rank, pointProcAddressing, candidates):
+        """candidates[r] = sorted unique global ids of rank r's processor-patch points"""
+        self.rank = rank
+        n = len(candidates)
+        mine = candidates[rank]
+        shared_with = {}
+        for o in range(n):
+            if o == rank:
+                continue
+            s = np.intersect1d(mine, candidates[o], assume_unique=True)
+            if len(s):
+                shared_with[o] = s
+        allg = np.unique(np.concatenate(list(shared_with.values()))) if shared_with else np.zeros(0, np.int64)
+        # local ids of the shared points, ordered by global id
+        order = np.argsort(pointProcAddressing, kind="stable")
+        sorted_g = pointProcAddressing[order]
+        pos = np.searchsorted(sorted_g, allg)
+        assert np.array_equal(sorted_g[pos], allg), "shared point not present in pointProcAddressing"
+        self.sharedGlobal = allg
+        self.sharedLocal = order[pos].astype(np.int32)
+        self.counts = np.zeros(n, np.int64)         # send == recv counts per peer (symmetric lists)
+        send = []
+        base = {}
+        run = 0
+        for o in range(n):
+            if o in shared_with:
+                idx = np.searchsorted(allg, shared_with[o]).astype(np.int32)
+                send.append(idx)
+                self.counts[o] = len(idx)
+                base[o] = (run, idx)
+                run += len(idx)
+        self.sendShared = np.concatenate(send).astype(np.int32) if send else np.zeros(0, np.int32)
+        self.nSend = self.nRecv = int(run)
+        # combine table: sharers ascending by rank, -1 marks this rank
+        nsh = len(allg)
+        per = [[] for _ in range(nsh)]
+        for o in sorted(list(shared_with.keys()) + [rank]):
+            if o == rank:
+                for i in range(nsh):
+                    per[i].append(-1)
+            else:
+                b, idx = base[o]
+                for k, i in enumerate(idx):
+                    per[i].append(b + k)
+        self.combOffsets = np.zeros(nsh + 1, np.int32)
+        if nsh:
+            np.cumsum([len(p) for p in per], out=self.combOffsets[1:])
+        self.combSlots = np.array([s for p in per for s in p], dtype=np.int32) if nsh else np.zeros(0, np.int32)
+
+
+class _RankState:
+    """engine + exchange buffers of one rank (torch tensors on the engine's device)"""
+
+    def __init__(self, sub, tables, engine, torch, device):
+        self.sub, self.t, self.eng = sub, tables, engine
+        f64, i32 = torch.float64, torch.int32
+        self.sendA = torch.zeros((max(tables.nSend, 1), A_DOUBLES), dtype=f64, device=device)
+        self.recvA = torch.zeros((max(tables.nRecv, 1), A_DOUBLES), dtype=f64, device=device)
+        self.sendF = torch.zeros(max(tables.nSend, 1), dtype=i32, device=device)
+        self.recvF = torch.zeros(max(tables.nRecv, 1), dtype=i32, device=device)
+        self.localStats = torch.zeros(2, dtype=f64, device=device)
+        engine.halo_configure(tables.sharedLocal, tables.sendShared, tables.nRecv, tables.combOffsets, tables.combSlots,
+                              self.sendA.data_ptr(), self.recvA.data_ptr(), self.sendF.data_ptr(), self.recvF.data_ptr(),
+                              self.localStats.data_ptr())
+
+
+class DistributedSmoother:
+    """The reference's loop (SM.C:2257-2437) on this rank's sub-domain, in step with all other ranks."""
+
+    def __init__(self, sub, device=0, engine_factory=None, torch_device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.sub = sub
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert sub.rank == self.rank and sub.nRanks == self.world
+        if torch_device is None:
+            torch_device = torch.device("cuda", device)
+        self.device = torch_device
+        cands = [None] * self.world
+        dist.all_gather_object(cands, sub.processor_patch_points())
+        self.tables = HaloTables(self.rank, sub.pointProcAddressing, cands)
+        if engine_factory is None:
+            from .engine import SmoothEngine
+            stream = torch.cuda.current_stream(torch_device).cuda_stream   # collectives order against this stream
+            engine = SmoothEngine(sub.mesh, device=device, stream=stream)
+        else:
+            engine = engine_factory(sub.mesh)
+        self.engine = engine
+        self.state = _RankState(sub, self.tables, engine, torch, torch_device)
+        self.counts = [int(c) for c in self.tables.counts]
+        self.allStats = torch.zeros((self.world, 2), dtype=torch.float64, device=torch_device)
+
+    def global_min_edge(self):
+        """getMeshStats + returnReduce(minOp), SM.C:1527"""
+        t = self.torch.tensor([self.engine.mesh_stats()[0]], dtype=self.torch.float64, device=self.device)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return float(t.item())
+
+    def set_params(self, p):
+        self.engine.set_params(p)
+
+    def _a2a(self, recv, send):
+        if self.tables.nSend == 0 and self.tables.nRecv == 0 and self.world == 1:
+            return
+        n = self.tables.nSend
+        self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts)
+
+    def iterate(self, centroidalIters, relTol=0.02):
+        torch, dist, st, eng = self.torch, self.dist, self.state, self.engine
+        hist = torch.zeros((max(centroidalIters, 1), 2), dtype=torch.float64, device=self.device)
+        done = 0
+        for i in range(centroidalIters):
+            eng.iter_begin()
+            self._a2a(st.recvA, st.sendA)               # SM.C:134-148, 402-478
+            eng.iter_mid()
+            self._a2a(st.recvF, st.sendF)               # SM.C:2374
+            eng.iter_end()
+            dist.all_gather_into_tensor(self.allStats.view(-1), st.localStats)   # SM.C:1567, 2396
+            hist[i, 0] = self.allStats[:, 0].max()
+            hist[i, 1] = self.allStats[:, 1].sum()
+            done += 1
+            # residual >= 0, so relTol <= 0 can never stop the loop: skip the host read-back then
+            if relTol > 0.0 and float(hist[i, 0].item()) < relTol:       # SM.C:2401
+                break
+        h = hist[:done].cpu().numpy()
+        return done, h[:, 0].copy(), h[:, 1].astype(np.int64)
+
+    def get_points(self):
+        return self.engine.get_points()
+
+
+class LocalMultiSmoother:
+    """All sub-domains in ONE process on ONE device (engines side by side), the exchange done by
+    device-side tensor indexing instead of RCCL.  Exercises every device-side piece of the multi-rank
+    path (pack / combine / or kernels, slot tables) on a single GPU."""
+
+    def __init__(self, subs, device=0, engine_factory=None, torch_device=None):
+        import torch
+        self.torch = torch
+        self.subs = subs
+        if torch_device is None:
+            torch_device = torch.device("cuda", device)
+        self.device = torch_device
+        cands = [s.processor_patch_points() for s in subs]
+        self.states = []
+        for s in subs:
+            t = HaloTables(s.rank, s.pointProcAddressing, cands)
+            if engine_factory is None:
+                from .engine import SmoothEngine
+                eng = SmoothEngine(s.mesh, device=device, stream=torch.cuda.current_stream(torch_device).cuda_stream)
+            else:
+                eng = engine_factory(s.mesh)
+            self.states.append(_RankState(s, t, eng, torch, torch_device))
+        # (src rank, src offset, dst offset, count) copies implementing the all_to_all
+        self.copies = []
+        n = len(subs)
+        offs = [np.concatenate([[0], np.cumsum(st.t.counts)]) for st in self.states]
+        for a in range(n):
+            for b in range(n):
+                c = int(self.states[a].t.counts[b])
+                if c:
+                    self.copies.append((a, int(offs[a][b]), b, int(offs[b][a]), c))
+
+    def global_min_edge(self):
+        return min(st.eng.mesh_stats()[0] for st in self.states)
+
+    def set_params(self, p):
+        for st in self.states:
+            st.eng.set_params(p)
+
+    def _exchange(self, which):
+        for a, so, b, do, c in self.copies:
+            src = getattr(self.states[a], "send" + which)
+            dst = getattr(self.states[b], "recv" + which)
+            dst[do:do + c].copy_(src[so:so + c])
+
+    def iterate(self, centroidalIters, relTol=0.02):
+        res, frz = [], []
+        for i in range(centroidalIters):
+            for st in self.states:
+                st.eng.iter_begin()
+            self._exchange("A")
+            for st in self.states:
+                st.eng.iter_mid()
+            self._exchange("F")
+            for st in self.states:
+                st.eng.iter_end()
+            allst = self.torch.stack([st.localStats for st in self.states]).cpu().numpy()
+            res.append(float(allst[:, 0].max()))
+            frz.append(int(allst[:, 1].sum()))
+            if res[-1] < relTol:
+                break
+        return len(res), np.array(res), np.array(frz, dtype=np.int64)
+
+    def get_points(self):
+        return [st.eng.get_points() for st in self.states]

@@ -104,3 +104,86 @@ def hex_block(nx, ny=None, nz=None, lengths=(1.0, 1.0, 1.0), jitter=0.0, seed=12
     F = len(faces)
     return PolyMesh(points=pts, faceOffsets=(np.arange(F + 1) * 4).astype(np.int32), facePoints=faces.ravel(),
                     owner=owner, neighbour=int_nei.astype(np.int32), patches=patches, nCells=nx * ny * nz)
+
+
+def hex_subdomain(nLocal, grid, rank, lengths=None, jitter=0.0, seed=12345):
+    """Sub-domain `rank` of a (grid[0]*nx, grid[1]*ny, grid[2]*nz)-cell block cut into grid boxes of
+    nLocal=(nx,ny,nz) cells, generated directly (identical to decompose(hex_block(global),
+    grid_partition) -- tests/test_decompose.py checks that), so an 8-rank 8M-cell case never needs the
+    global mesh in one process.  Rank id = rx + ry*Px + rz*Px*Py."""
+    from .decompose import SubDomain
+    nx, ny, nz = nLocal
+    Px, Py, Pz = grid
+    rx, ry, rz = rank % Px, (rank // Px) % Py, rank // (Px * Py)
+    GN = (nx * Px, ny * Py, nz * Pz)
+    if lengths is None:
+        lengths = (float(Px), float(Py), float(Pz))     # unit cube per sub-domain
+    ox, oy, oz = rx * nx, ry * ny, rz * nz
+    npx, npy = nx + 1, ny + 1
+
+    def pid(i, j, k):
+        return (i + j * npx + k * npx * npy).astype(np.int64)
+
+    K, J, I = np.meshgrid(np.arange(nz + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    gi, gj, gk = I.ravel() + ox, J.ravel() + oy, K.ravel() + oz
+    pts = _lattice_points(gi, gj, gk, GN, lengths, jitter, seed)
+    gid = gi.astype(np.int64) + gj.astype(np.int64) * (GN[0] + 1) + gk.astype(np.int64) * (GN[0] + 1) * (GN[1] + 1)
+
+    ck, cj, ci = np.meshgrid(np.arange(nz), np.arange(ny), np.arange(nx), indexing="ij")
+    ci, cj, ck = ci.ravel(), cj.ravel(), ck.ravel()
+    cid = ci + cj * nx + ck * nx * ny
+
+    def quad_x(i, j, k):
+        return np.stack([pid(i, j, k), pid(i, j + 1, k), pid(i, j + 1, k + 1), pid(i, j, k + 1)], axis=1)
+
+    def quad_y(i, j, k):
+        return np.stack([pid(i, j, k), pid(i, j, k + 1), pid(i + 1, j, k + 1), pid(i + 1, j, k)], axis=1)
+
+    def quad_z(i, j, k):
+        return np.stack([pid(i, j, k), pid(i + 1, j, k), pid(i + 1, j + 1, k), pid(i, j + 1, k)], axis=1)
+
+    faces3 = np.stack([quad_x(ci + 1, cj, ck), quad_y(ci, cj + 1, ck), quad_z(ci, cj, ck + 1)], axis=1)
+    valid3 = np.stack([ci < nx - 1, cj < ny - 1, ck < nz - 1], axis=1)
+    nei3 = np.stack([cid + 1, cid + nx, cid + nx * ny], axis=1)
+    own3 = np.repeat(cid[:, None], 3, axis=1)
+    int_faces, int_own, int_nei = faces3[valid3], own3[valid3], nei3[valid3]
+
+    # the six sides: (name, cell mask, outward quad on the global-owner side, is max side, neighbour rank)
+    def rk(ax, d):
+        r3 = [rx, ry, rz]; r3[ax] += d
+        return r3[0] + r3[1] * Px + r3[2] * Px * Py
+
+    sides = [
+        ("xmin", ci == 0, lambda i, j, k: quad_x(i, j, k), False, rx == 0, rk(0, -1)),
+        ("xmax", ci == nx - 1, lambda i, j, k: quad_x(i + 1, j, k), True, rx == Px - 1, rk(0, +1)),
+        ("ymin", cj == 0, lambda i, j, k: quad_y(i, j, k), False, ry == 0, rk(1, -1)),
+        ("ymax", cj == ny - 1, lambda i, j, k: quad_y(i, j + 1, k), True, ry == Py - 1, rk(1, +1)),
+        ("zmin", ck == 0, lambda i, j, k: quad_z(i, j, k), False, rz == 0, rk(2, -1)),
+        ("zmax", ck == nz - 1, lambda i, j, k: quad_z(i, j, k + 1), True, rz == Pz - 1, rk(2, +1)),
+    ]
+    bfaces, bown, patches = [], [], []
+    start = len(int_faces)
+    for name, mask, quad, is_max, physical, _ in sides:
+        if physical:
+            q = quad(ci[mask], cj[mask], ck[mask])
+            if not is_max:
+                q = q[:, ::-1]            # same (arbitrary) outward ordering as hex_block's min patches
+            bfaces.append(q); bown.append(cid[mask])
+            patches.append(Patch(name, "patch", len(q), start)); start += len(q)
+        else:
+            patches.append(Patch(name, "patch", 0, start))
+    procs = sorted([(nbr, name, mask, quad, is_max) for name, mask, quad, is_max, physical, nbr in sides if not physical],
+                   key=lambda t: t[0])
+    for nbr, name, mask, quad, is_max in procs:
+        q = quad(ci[mask], cj[mask], ck[mask])
+        if not is_max:
+            q = q[:, [0, 3, 2, 1]]        # face::reverseFace of the global owner's face
+        bfaces.append(q); bown.append(cid[mask])
+        patches.append(Patch(f"procBoundary{rank}to{nbr}", "processor", len(q), start, myProcNo=rank, neighbProcNo=nbr))
+        start += len(q)
+    faces = np.concatenate([int_faces] + bfaces, axis=0).astype(np.int32)
+    owner = np.concatenate([int_own] + bown).astype(np.int32)
+    F = len(faces)
+    mesh = PolyMesh(points=pts, faceOffsets=(np.arange(F + 1) * 4).astype(np.int32), facePoints=faces.ravel(), owner=owner,
+                    neighbour=int_nei.astype(np.int32), patches=patches, nCells=nx * ny * nz)
+    return SubDomain(mesh, rank, Px * Py * Pz, gid)

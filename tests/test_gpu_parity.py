@@ -151,3 +151,21 @@ def test_large_mesh_properties():
     assert np.array_equal(after[~internal], before[~internal])
     assert np.max(np.linalg.norm(after - before, axis=1)) <= 10 * p.maxStepLength * (1 + 1e-12)
     assert np.all(frz >= (~internal).sum())
+
+
+def test_golden_fixture_hip():
+    """The HIP path against the committed golden vectors (tests/golden/make_golden.py; oracle-generated)."""
+    import os
+    from smoothmesh_amd import SmoothEngine, default_params
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hex6_jitter03_seed7.npz"))
+    mesh = _mk(6, 6, 6, 0.3, 7)
+    assert np.array_equal(mesh.points, g["points0"])
+    e = SmoothEngine(mesh)
+    e.set_params(default_params(e.mesh_stats()[0]))
+    frz_all, res_all = [], []
+    for tag, iters in (("1", 1), ("5", 4), ("20", 15)):
+        n, res, frz = e.iterate(iters, 0.0)
+        frz_all.append(frz); res_all.append(res)
+        assert rel_linf(e.get_points(), g["points" + tag]) <= COORD_TOL
+    assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
+    assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-10, atol=0)

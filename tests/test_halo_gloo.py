@@ -1,0 +1,78 @@
+"""world_size-2/4 CPU tests (gloo) of the product's multi-rank host logic: decomposition, slot tables,
+all_to_all exchange, 2-scalar reduction and the stop rule of smoothmesh_amd.halo.DistributedSmoother.
+The HIP engine cannot run here (no GPU), so an oracle Domain stands in for it behind the same engine
+interface; the expected result is the oracle's in-process MultiDomain (the reference under mpirun)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, grid, nLocal, jitter, seed, constraints, iters, relTol, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle_ffi import OracleRankEngine
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.halo import DistributedSmoother
+    from smoothmesh_amd.meshgen import hex_subdomain
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sub = hex_subdomain(nLocal, grid, rank, jitter=jitter, seed=seed)
+    ds = DistributedSmoother(sub, engine_factory=OracleRankEngine, torch_device=torch.device("cpu"))
+    prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ds.set_params(prm)
+    n, res, frz = ds.iterate(iters, relTol)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), n=n, res=res, frz=frz, pts=ds.get_points())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _expected(grid, nLocal, jitter, seed, constraints, iters, relTol):
+    from oracle import oracle_ffi
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.meshgen import hex_subdomain
+    world = grid[0] * grid[1] * grid[2]
+    subs = [hex_subdomain(nLocal, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+    orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_ffi.MultiOracle(orcs, off, dom, loc)
+    n, res, frz = mo.iterate(iters, relTol)
+    return n, res, frz, [o.points() for o in orcs]
+
+
+@pytest.mark.parametrize("grid,constraints,relTol", [((2, 1, 1), False, 0.0), ((2, 1, 1), True, 0.0),
+                                                      ((2, 2, 1), True, 0.0), ((2, 1, 1), False, 0.6)])
+def test_distributed_smoother_gloo(tmp_path, oracle_lib, grid, constraints, relTol):
+    import torch.multiprocessing as mp
+    world = grid[0] * grid[1] * grid[2]
+    nLocal, jitter, seed = (5, 4, 4), 0.3, 9
+    iters = 40 if relTol > 0 else 6
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, grid, nLocal, jitter, seed, constraints, iters, relTol, str(tmp_path)),
+             nprocs=world, join=True)
+    n_e, res_e, frz_e, pts_e = _expected(grid, nLocal, jitter, seed, constraints, iters, relTol)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert int(d["n"]) == n_e
+        assert np.array_equal(d["res"], res_e)          # same arithmetic on both sides: bit-exact
+        assert np.array_equal(d["frz"], frz_e)
+        assert np.array_equal(d["pts"], pts_e[r])
+    if relTol > 0:
+        assert n_e < iters
