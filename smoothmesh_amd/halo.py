@@ -113,21 +113,40 @@ class DistributedSmoother:
 
     def global_min_edge(self):
         """getMeshStats + returnReduce(minOp), SM.C:1527"""
-        t = self.torch.tensor([self.engine.mesh_stats()[0]], dtype=self.torch.float64, device=self.device)
+        dev = "cpu" if self._staged() else self.device
+        t = self.torch.tensor([self.engine.mesh_stats()[0]], dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return float(t.item())
 
     def set_params(self, p):
         self.engine.set_params(p)
 
+    def _staged(self):
+        # RCCL moves device buffers directly; gloo (CPU tests, or several debug ranks sharing one GPU)
+        # cannot, so device tensors are staged through the host for it
+        return self.dist.get_backend() == "gloo" and self.device.type != "cpu"
+
     def _a2a(self, recv, send):
-        if self.tables.nSend == 0 and self.tables.nRecv == 0 and self.world == 1:
-            return
         n = self.tables.nSend
-        self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts)
+        if self.world == 1 or (n == 0 and self.tables.nRecv == 0):
+            return
+        if self._staged():
+            r = self.torch.empty_like(recv[:n], device="cpu")
+            self.dist.all_to_all_single(r, send[:n].cpu(), self.counts, self.counts)
+            recv[:n].copy_(r)
+        else:
+            self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts)
+
+    def _gather_stats(self):
+        if self._staged():
+            out = self.torch.empty((self.world, 2), dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(out.view(-1), self.state.localStats.cpu())
+            self.allStats.copy_(out)
+        else:
+            self.dist.all_gather_into_tensor(self.allStats.view(-1), self.state.localStats)
 
     def iterate(self, centroidalIters, relTol=0.02):
-        torch, dist, st, eng = self.torch, self.dist, self.state, self.engine
+        torch, st, eng = self.torch, self.state, self.engine
         hist = torch.zeros((max(centroidalIters, 1), 2), dtype=torch.float64, device=self.device)
         done = 0
         for i in range(centroidalIters):
@@ -136,7 +155,7 @@ class DistributedSmoother:
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF)               # SM.C:2374
             eng.iter_end()
-            dist.all_gather_into_tensor(self.allStats.view(-1), st.localStats)   # SM.C:1567, 2396
+            self._gather_stats()                        # SM.C:1567, 2396
             hist[i, 0] = self.allStats[:, 0].max()
             hist[i, 1] = self.allStats[:, 1].sum()
             done += 1
