@@ -1,0 +1,51 @@
+/* smhost.h -- C-ABI of the host side either side of the smoothing loop: OpenFOAM polyMesh
+ * directory I/O (what createMesh.H does at src/smoothMesh.C:1814-1818 and mesh.write() at
+ * :2416-2431).  Plain C++ (no GPU); used by the bundled `smoothMesh` front-end and, through
+ * ctypes, by the Python tests and mesh generators.
+ *
+ * Formats: FoamFile header + ascii or binary payload (faceList / faceCompactList, labelList,
+ * vectorField, polyBoundaryMesh), label = 32 or 64 bit on read (header `arch`), label=32 /
+ * scalar=64 on write.  gz-compressed files are not read (no zlib dependency).
+ * All functions return 0 on success; message through smhost_last_error().
+ */
+#ifndef SMHOST_H
+#define SMHOST_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct smhost_mesh smhost_mesh;
+
+const char* smhost_last_error(void);
+
+/* Read <dir>/{points,faces,owner,neighbour,boundary}; pointsDir (may be NULL) overrides where
+ * `points` is read from (a later time directory's polyMesh, like OpenFOAM's pointsInstance). */
+int smhost_read_polymesh(const char* polyMeshDir, const char* pointsDir, smhost_mesh** out);
+void smhost_mesh_free(smhost_mesh* m);
+int smhost_mesh_sizes(const smhost_mesh* m, int32_t* nPoints, int32_t* nCells, int32_t* nFaces,
+                      int32_t* nInternalFaces, int32_t* nPatches, int64_t* nnzFacePoints);
+int smhost_mesh_copy(const smhost_mesh* m, double* points, int32_t* faceOffsets, int32_t* facePoints,
+                     int32_t* owner, int32_t* neighbour);
+int smhost_mesh_patch(const smhost_mesh* m, int32_t i, char* name, int32_t nameCap, char* type, int32_t typeCap,
+                      int32_t* nFaces, int32_t* startFace, int32_t* myProcNo, int32_t* neighbProcNo);
+
+/* Write a complete polyMesh directory (mesh generators, decomposition). */
+int smhost_write_polymesh(const char* polyMeshDir, const char* location, int32_t nPoints, const double* points,
+                          int32_t nFaces, const int32_t* faceOffsets, const int32_t* facePoints, const int32_t* owner,
+                          int32_t nInternalFaces, const int32_t* neighbour, int32_t nCells, int32_t nPatches,
+                          const char* const* patchNames, const char* const* patchTypes, const int32_t* patchNFaces,
+                          const int32_t* patchStart, const int32_t* patchMyProc, const int32_t* patchNbrProc,
+                          int32_t binary, int32_t precision);
+/* Write <dir>/points only (mesh.write() of a moved mesh, SM.C:2430); precision as SM.C:2425. */
+int smhost_write_points(const char* polyMeshDir, const char* location, int32_t nPoints, const double* points,
+                        int32_t binary, int32_t precision);
+/* labelList file (pointProcAddressing etc.): n = -1 on input to query the size into *n. */
+int smhost_read_label_list(const char* file, int32_t* out, int64_t* n);
+int smhost_write_label_list(const char* file, const char* location, const char* object, const char* cls,
+                            int64_t n, const int32_t* values, int32_t binary);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

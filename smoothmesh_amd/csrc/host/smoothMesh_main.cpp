@@ -1,0 +1,492 @@
+// smoothMesh_main.cpp -- the `smoothMesh` front-end: same command-line options, case-directory
+// inputs/outputs and log lines as the reference's main() (src/smoothMesh.C:1635-2445), with the
+// iteration loop (SM.C:2257-2437) executed by the MI355X engine behind include/smgpu.h.
+//
+// This host is standalone (own option parser, own polyMesh I/O) because OpenFOAM is not available
+// in the build environment; INTEGRATION.md shows the OpenFOAM-linked variant of the same calls.
+// Out of scope: boundary-layer treatment (-layerPatches ...) and
+// boundary point smoothing (constant/geometry/*.obj); asking for them is an error, not a silent skip.
+//
+//   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
+//
+// -parallel: the case holds processorN/ sub-domains (decomposePar layout, with pointProcAddressing);
+// this single process drives one engine per sub-domain, placed round-robin on the visible GPUs, and
+// moves the shared-point buffers with device-to-device copies.  (The measured multi-GPU path is the
+// one-process-per-GPU RCCL driver in smoothmesh_amd/halo.py; this one keeps the CLI usable on any
+// number of GPUs.)
+#include <dirent.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../../include/smgpu.h"
+#include "polymesh_io.hpp"
+
+using namespace smhost;
+
+namespace {
+
+const double VSMALL = 1.0e-300, SMALL = 1.0e-15;
+
+[[noreturn]] void fatal(const std::string& msg) {   // FatalError << ... << abort(FatalError)
+    std::fprintf(stdout, "\n\n--> FOAM FATAL ERROR: \n%s\n\nFOAM aborting\n\n", msg.c_str());
+    std::fflush(stdout);
+    std::exit(1);
+}
+
+struct Options {
+    std::map<std::string, std::string> kv;
+    bool parallel = false;
+    std::string caseDir = ".";
+    bool found(const std::string& k) const { return kv.count(k) != 0; }
+    double getD(const std::string& k, double def) const {
+        if (!found(k)) return def;
+        char* e = nullptr;
+        const double v = std::strtod(kv.at(k).c_str(), &e);
+        if (e == kv.at(k).c_str()) fatal("Bad value for option -" + k + ": " + kv.at(k));
+        return v;
+    }
+    long getL(const std::string& k, long def) const {
+        if (!found(k)) return def;
+        char* e = nullptr;
+        const long v = std::strtol(kv.at(k).c_str(), &e, 10);
+        if (e == kv.at(k).c_str()) fatal("Bad value for option -" + k + ": " + kv.at(k));
+        return v;
+    }
+    bool getB(const std::string& k, bool def) const {   // OpenFOAM Switch words
+        if (!found(k)) return def;
+        std::string v = kv.at(k);
+        std::transform(v.begin(), v.end(), v.begin(), ::tolower);
+        if (v == "true" || v == "on" || v == "yes" || v == "y" || v == "t" || v == "1") return true;
+        if (v == "false" || v == "off" || v == "no" || v == "n" || v == "f" || v == "0" || v == "none") return false;
+        fatal("Bad bool value for option -" + k + ": " + kv.at(k));
+    }
+};
+
+// the options main() registers with argList::addOption (SM.C:1642-1784)
+const char* kValueOptions[] = {"time", "centroidalIters", "maxStepLength", "relStepFrac", "edgeAngleConstraint",
+                               "faceAngleConstraint", "minEdgeLength", "totalMinFreeze", "minAngle", "maxAngle",
+                               "layerMaxBlendingFraction", "layerEdgeLength", "layerExpansionRatio", "minLayers",
+                               "maxLayers", "layerPatches", "smoothingPatches", "internalSmoothingBlendingFraction",
+                               "relTol", "writeInterval", "case", "writeFormat", "device"};
+
+Options parseArgs(int argc, char** argv) {
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a == "-parallel") { o.parallel = true; continue; }
+        if (a == "-help" || a == "-h") {
+            std::puts("Usage: smoothMesh [-case dir] [-parallel] [-time t] [-centroidalIters n] [-relTol x] [-minEdgeLength x]\n"
+                      "       [-maxStepLength x] [-relStepFrac x] [-totalMinFreeze b] [-edgeAngleConstraint b] [-faceAngleConstraint b]\n"
+                      "       [-minAngle deg] [-maxAngle deg] [-writeInterval n] [-writeFormat ascii|binary] [-device n]\n"
+                      "Move internal mesh points to increase mesh quality (MI355X engine)");
+            std::exit(0);
+        }
+        if (a.size() < 2 || a[0] != '-') fatal("Wrong argument " + a);
+        const std::string key = a.substr(1);
+        bool known = false;
+        for (const char* k : kValueOptions) known |= (key == k);
+        if (!known) fatal("Wrong option " + a);
+        if (i + 1 >= argc) fatal("Option " + a + " requires an argument");
+        o.kv[key] = argv[++i];
+    }
+    if (o.found("case")) o.caseDir = o.kv["case"];
+    return o;
+}
+
+// minimal system/controlDict access: "key value;" entries at top level
+std::map<std::string, std::string> readControlDict(const std::string& file) {
+    std::map<std::string, std::string> d;
+    FILE* f = std::fopen(file.c_str(), "rb");
+    if (!f) return d;
+    std::string s;
+    char buf[4096];
+    size_t n;
+    while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) s.append(buf, n);
+    std::fclose(f);
+    // strip comments
+    std::string t;
+    for (size_t i = 0; i < s.size(); ++i) {
+        if (s[i] == '/' && i + 1 < s.size() && s[i + 1] == '/') { while (i < s.size() && s[i] != '\n') ++i; t.push_back('\n'); continue; }
+        if (s[i] == '/' && i + 1 < s.size() && s[i + 1] == '*') { i += 2; while (i + 1 < s.size() && !(s[i] == '*' && s[i + 1] == '/')) ++i; ++i; continue; }
+        t.push_back(s[i]);
+    }
+    int depth = 0;
+    size_t i = 0;
+    while (i < t.size()) {
+        if (t[i] == '{') { ++depth; ++i; continue; }
+        if (t[i] == '}') { --depth; ++i; continue; }
+        if (depth == 0 && (std::isalpha((unsigned char)t[i]))) {
+            size_t j = i;
+            while (j < t.size() && !std::isspace((unsigned char)t[j]) && t[j] != ';' && t[j] != '{') ++j;
+            const std::string key = t.substr(i, j - i);
+            size_t k = j;
+            while (k < t.size() && std::isspace((unsigned char)t[k])) ++k;
+            if (k < t.size() && t[k] == '{') { i = k; continue; }
+            size_t e = t.find(';', k);
+            if (e == std::string::npos) break;
+            std::string v = t.substr(k, e - k);
+            while (!v.empty() && std::isspace((unsigned char)v.back())) v.pop_back();
+            d[key] = v;
+            i = e + 1;
+            continue;
+        }
+        ++i;
+    }
+    return d;
+}
+
+std::vector<std::pair<double, std::string>> listTimes(const std::string& dir) {
+    std::vector<std::pair<double, std::string>> t;
+    DIR* d = ::opendir(dir.c_str());
+    if (!d) return t;
+    while (dirent* e = ::readdir(d)) {
+        const std::string n = e->d_name;
+        if (n == "." || n == "..") continue;
+        char* end = nullptr;
+        const double v = std::strtod(n.c_str(), &end);
+        if (end != n.c_str() && *end == '\0' && dirExists(dir + "/" + n)) t.push_back({v, n});
+    }
+    ::closedir(d);
+    std::sort(t.begin(), t.end());
+    return t;
+}
+
+std::string timeName(double t) {   // timeFormat general; timePrecision 6 (testcase/system/controlDict:34-36)
+    char b[64];
+    std::snprintf(b, sizeof b, "%.6g", t);
+    return b;
+}
+
+// SM.C:40-91 findInternalMeshPoints
+std::vector<uint8_t> findInternalMeshPoints(const PolyMeshData& m) {
+    std::vector<uint8_t> in((size_t)m.nPoints(), 1);
+    for (const auto& p : m.patches) {
+        if (p.type == "processor") continue;
+        if (p.type == "empty") fatal("Smoothing of non-3D meshes (meshes with type empty patches) is not supported");
+        for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
+            for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) in[(size_t)m.facePoints[k]] = 0;
+    }
+    return in;
+}
+
+void check(int rc, const char* what) {
+    if (rc) fatal(std::string(what) + ": " + smgpu_last_error());
+}
+#define HIPCHK(e) do { hipError_t r__ = (e); if (r__ != hipSuccess) fatal(std::string(#e) + ": " + hipGetErrorString(r__)); } while (0)
+
+struct Rank {
+    std::string root;            // case dir (serial) or processorN dir
+    PolyMeshData mesh;
+    std::vector<uint8_t> internal;
+    std::vector<int32_t> pointProc;
+    smgpu_handle* h = nullptr;
+    int device = 0;
+    // halo
+    std::vector<int32_t> sharedLocal, sendShared, combOff, combSlots;
+    std::vector<int64_t> sharedGlobal;
+    std::vector<int> peerCount, peerSendBase;
+    double *sendA = nullptr, *recvA = nullptr, *localStats = nullptr;
+    int32_t *sendF = nullptr, *recvF = nullptr;
+    int nSend = 0;
+};
+
+std::string findInstance(const std::string& root, const std::vector<std::pair<double, std::string>>& times, double startValue,
+                         bool startIsConstant, const std::string& file) {
+    if (!startIsConstant)
+        for (auto it = times.rbegin(); it != times.rend(); ++it)
+            if (it->first <= startValue + 1e-12 && fileExists(root + "/" + it->second + "/polyMesh/" + file))
+                return root + "/" + it->second + "/polyMesh";
+    return root + "/constant/polyMesh";
+}
+
+void buildHalo(std::vector<Rank>& R) {
+    const int n = (int)R.size();
+    std::vector<std::vector<int64_t>> cand(n);
+    for (int r = 0; r < n; ++r) {
+        std::set<int64_t> s;
+        const auto& m = R[r].mesh;
+        for (const auto& p : m.patches)
+            if (p.type == "processor")
+                for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
+                    for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) s.insert(R[r].pointProc[(size_t)m.facePoints[k]]);
+        cand[r].assign(s.begin(), s.end());
+    }
+    for (int r = 0; r < n; ++r) {
+        Rank& K = R[r];
+        std::vector<std::vector<int64_t>> shared(n);
+        std::set<int64_t> all;
+        for (int o = 0; o < n; ++o) {
+            if (o == r) continue;
+            std::set_intersection(cand[r].begin(), cand[r].end(), cand[o].begin(), cand[o].end(), std::back_inserter(shared[o]));
+            all.insert(shared[o].begin(), shared[o].end());
+        }
+        K.sharedGlobal.assign(all.begin(), all.end());
+        std::map<int64_t, int32_t> g2l;
+        for (int32_t p = 0; p < K.mesh.nPoints(); ++p) g2l[K.pointProc[(size_t)p]] = p;
+        K.sharedLocal.clear();
+        for (int64_t g : K.sharedGlobal) K.sharedLocal.push_back(g2l.at(g));
+        K.peerCount.assign(n, 0);
+        K.peerSendBase.assign(n, 0);
+        K.sendShared.clear();
+        std::vector<std::vector<std::pair<int, int>>> per(K.sharedGlobal.size());   // (rank, slot)
+        for (size_t i = 0; i < per.size(); ++i) per[i].push_back({r, -1});
+        int run = 0;
+        for (int o = 0; o < n; ++o) {
+            K.peerSendBase[o] = run;
+            K.peerCount[o] = (int)shared[o].size();
+            for (size_t k = 0; k < shared[o].size(); ++k) {
+                const int32_t idx = (int32_t)(std::lower_bound(K.sharedGlobal.begin(), K.sharedGlobal.end(), shared[o][k]) - K.sharedGlobal.begin());
+                K.sendShared.push_back(idx);
+                per[(size_t)idx].push_back({o, run + (int)k});
+            }
+            run += (int)shared[o].size();
+        }
+        K.nSend = run;
+        K.combOff.assign(1, 0);
+        K.combSlots.clear();
+        for (auto& v : per) {
+            std::sort(v.begin(), v.end());
+            for (auto& pr : v) K.combSlots.push_back(pr.second);
+            K.combOff.push_back((int32_t)K.combSlots.size());
+        }
+    }
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    const auto t0 = std::chrono::steady_clock::now();
+    const Options opt = parseArgs(argc, argv);
+    const std::string& cd = opt.caseDir;
+
+    // createTime.H: deltaT sanity (SM.C:1805-1812)
+    const auto control = readControlDict(cd + "/system/controlDict");
+    const double deltaT = control.count("deltaT") ? std::atof(control.at("deltaT").c_str()) : 1.0;
+    if (deltaT < VSMALL) fatal("Time step (deltaT) value " + std::to_string(deltaT) + " specified in controlDict is too small");
+    const bool binary = opt.found("writeFormat") ? (opt.kv.at("writeFormat") == "binary")
+                                                 : (control.count("writeFormat") && control.at("writeFormat") == "binary");
+    int writePrecision = control.count("writePrecision") ? std::atoi(control.at("writePrecision").c_str()) : 6;
+    writePrecision = std::max(10, writePrecision);   // SM.C:2425
+
+    // sub-domain roots
+    std::vector<Rank> R;
+    if (opt.parallel) {
+        for (int r = 0;; ++r) {
+            const std::string root = cd + "/processor" + std::to_string(r);
+            if (!dirExists(root)) break;
+            R.emplace_back();
+            R.back().root = root;
+        }
+        if (R.empty()) fatal("-parallel: no processor0 directory in " + cd + " (run decomposePar first)");
+    } else {
+        R.emplace_back();
+        R.back().root = cd;
+    }
+    const int nRanks = (int)R.size();
+
+    // start time (SM.C:1791-1803; controlDict startFrom latestTime)
+    const auto times = listTimes(R[0].root);
+    bool startIsConstant = false;
+    double startValue = 0.0;
+    if (opt.found("time")) {
+        if (opt.kv.at("time") == "constant") startIsConstant = true;
+        else startValue = opt.getD("time", 0.0);
+    } else if (!times.empty()) startValue = times.back().first;
+    else startIsConstant = true;
+
+    std::printf("smoothMesh (MI355X engine %s)\nCase: %s%s\n", smgpu_version(), cd.c_str(), opt.parallel ? "  [parallel]" : "");
+    std::printf("Create mesh for time = %s\n\n", startIsConstant ? "constant" : timeName(startValue).c_str());
+
+    try {
+        for (Rank& K : R) {
+            const std::string meshDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "faces");
+            const std::string ptsDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "points");
+            readPolyMesh(meshDir, ptsDir == meshDir ? "" : ptsDir, K.mesh);
+            K.internal = findInternalMeshPoints(K.mesh);
+            if (opt.parallel) {
+                const std::string ppa = K.root + "/constant/polyMesh/pointProcAddressing";
+                if (!fileExists(ppa)) fatal(ppa + " not found (written by decomposePar; needed to match shared points)");
+                readLabelList(ppa, K.pointProc);
+                if ((int32_t)K.pointProc.size() != K.mesh.nPoints()) fatal(ppa + ": size does not match the number of points");
+            }
+        }
+    } catch (const std::exception& e) { fatal(e.what()); }
+
+    // out-of-scope features: refuse instead of silently ignoring (SM.C:2025, 2081-2093)
+    std::printf("Patches for boundary layer treatment: %s\n", opt.found("layerPatches") ? opt.kv.at("layerPatches").c_str() : "none");
+    const double layerMaxBlendingFraction = opt.getD("layerMaxBlendingFraction", 0.3);
+    if (opt.found("layerPatches") && layerMaxBlendingFraction > SMALL)
+        fatal("-layerPatches: boundary layer treatment (orthogonalBoundaryBlending.C) is outside the scope of this build");
+    if (fileExists(cd + "/constant/geometry/targetSurfaces.obj"))
+        fatal("constant/geometry/targetSurfaces.obj found: boundary point smoothing (boundaryPointSmoothing.C) is outside the scope of this build");
+    std::puts("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
+    std::puts("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\nconstant/geometry/targetSurfaces.obj\nconstant/geometry/initEdges.obj\n");
+
+    // engines
+    int nDev = 0;
+    if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) fatal("no HIP device available (this build has no CPU fallback)");
+    const int dev0 = (int)opt.getL("device", 0);
+    for (int r = 0; r < nRanks; ++r) {
+        Rank& K = R[r];
+        smgpu_mesh_desc d{};
+        d.nPoints = K.mesh.nPoints(); d.nCells = K.mesh.nCells; d.nFaces = K.mesh.nFaces(); d.nInternalFaces = K.mesh.nInternalFaces();
+        d.points = K.mesh.points.data(); d.faceOffsets = K.mesh.faceOffsets.data(); d.facePoints = K.mesh.facePoints.data();
+        d.owner = K.mesh.owner.data(); d.neighbour = K.mesh.neighbour.data();
+        d.isInternalPoint = K.internal.data(); d.isSmoothingSurfacePoint = nullptr;
+        K.device = (dev0 + r) % nDev;
+        d.device = K.device; d.stream = nullptr; d.useCallerStream = 0;
+        check(smgpu_create(&d, &K.h), "smgpu_create");
+    }
+
+    // getMeshStats + defaults (SM.C:1857-1918)
+    double meshMinEdgeLength = 1e300, meshMaxEdgeLength = 0.0;
+    for (Rank& K : R) {
+        double a, b;
+        check(smgpu_mesh_stats(K.h, &a, &b), "smgpu_mesh_stats");
+        meshMinEdgeLength = std::min(meshMinEdgeLength, a);
+        meshMaxEdgeLength = std::max(meshMaxEdgeLength, b);
+    }
+    smgpu_params prm{};
+    prm.minEdgeLength = opt.getD("minEdgeLength", 0.5 * meshMinEdgeLength);
+    prm.maxStepLength = opt.getD("maxStepLength", 0.3 * prm.minEdgeLength);
+    if (prm.maxStepLength > 0.5 * prm.minEdgeLength)
+        std::puts("WARNING: The maximum allowed step length is more than half of the minimum edge length! This may cause unstability in smoothing.\n");
+    prm.relStepFrac = opt.getD("relStepFrac", 0.5);
+    prm.totalMinFreeze = opt.getB("totalMinFreeze", false);
+    prm.minAngle = opt.getD("minAngle", 35.0);
+    prm.maxAngle = opt.getD("maxAngle", 160.0);
+    prm.edgeAngleConstraint = opt.getB("edgeAngleConstraint", true);
+    prm.faceAngleConstraint = opt.getB("faceAngleConstraint", true);
+    const double relTol = opt.getD("relTol", 0.02);
+    const long centroidalIters = opt.getL("centroidalIters", 1000);
+    const long writeInterval = opt.getL("writeInterval", centroidalIters);
+    if (writeInterval <= 0) fatal("writeInterval must be positive");
+
+    // parameter echo, SM.C:1933-1975
+    std::puts("Applying following parameter values in smoothing:");
+    std::printf("    centroidalIters        %ld\n    relTol                 %g\n    minEdgeLength          %g\n", centroidalIters, relTol, prm.minEdgeLength);
+    std::printf("    maxStepLength          %g\n    relStepFrac            %g\n    totalMinFreeze         %d\n", prm.maxStepLength, prm.relStepFrac, prm.totalMinFreeze);
+    if (prm.edgeAngleConstraint) std::printf("    edgeAngleConstraint    true\n    minAngle               %g\n", prm.minAngle);
+    else std::puts("    edgeAngleConstraint    false (edge min angle quality constraint is NOT applied)");
+    if (prm.faceAngleConstraint) std::printf("    faceAngleConstraint    true\n    minAngle               %g\n    maxAngle               %g\n", prm.minAngle, prm.maxAngle);
+    else std::puts("    faceAngleConstraint    false (face angle quality constraints are NOT applied)");
+    std::puts("    layerMaxBlendingFraction 0 (boundary layer treatment is NOT applied)\n");
+
+    long nPointsTot = 0, nInternalTot = 0;
+    for (Rank& K : R) {
+        nPointsTot += K.mesh.nPoints();
+        for (uint8_t v : K.internal) nInternalTot += v;
+    }
+    std::printf("Mesh includes a total of %ld points:\n  - %ld internal (non-boundary) points\n  - %ld boundary points\n", nPointsTot, nInternalTot, nPointsTot - nInternalTot);
+    std::printf("Mesh minimum edge length = %g\nMesh maximum edge length = %g\n\n", meshMinEdgeLength, meshMaxEdgeLength);
+
+    for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
+
+    if (opt.parallel) {
+        buildHalo(R);
+        for (Rank& K : R) {
+            HIPCHK(hipSetDevice(K.device));
+            const size_t ns = (size_t)std::max(K.nSend, 1);
+            HIPCHK(hipMalloc((void**)&K.sendA, ns * SMGPU_HALO_A_DOUBLES * 8));
+            HIPCHK(hipMalloc((void**)&K.recvA, ns * SMGPU_HALO_A_DOUBLES * 8));
+            HIPCHK(hipMalloc((void**)&K.sendF, ns * 4));
+            HIPCHK(hipMalloc((void**)&K.recvF, ns * 4));
+            HIPCHK(hipMalloc((void**)&K.localStats, 16));
+            smgpu_halo_desc hd{};
+            hd.nShared = (int32_t)K.sharedLocal.size(); hd.sharedLocal = K.sharedLocal.data();
+            hd.nSend = K.nSend; hd.sendShared = K.sendShared.data(); hd.nRecv = K.nSend;
+            hd.combOffsets = K.combOff.data(); hd.combSlots = K.combSlots.data();
+            hd.sendA = K.sendA; hd.recvA = K.recvA; hd.sendF = K.sendF; hd.recvF = K.recvF; hd.localStats = K.localStats;
+            check(smgpu_halo_configure(K.h, &hd), "smgpu_halo_configure");
+        }
+    }
+
+    auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
+    auto exchange = [&](bool isA) {
+        syncAll();
+        for (int a = 0; a < nRanks; ++a)
+            for (int b = 0; b < nRanks; ++b) {
+                const int c = R[a].peerCount[b];
+                if (!c) continue;
+                // slots a->b on a's send side start at peerSendBase[b]; on b's recv side at b.peerSendBase[a]
+                if (isA)
+                    HIPCHK(hipMemcpyPeer(R[b].recvA + (size_t)R[b].peerSendBase[a] * SMGPU_HALO_A_DOUBLES, R[b].device,
+                                         R[a].sendA + (size_t)R[a].peerSendBase[b] * SMGPU_HALO_A_DOUBLES, R[a].device,
+                                         (size_t)c * SMGPU_HALO_A_DOUBLES * 8));
+                else
+                    HIPCHK(hipMemcpyPeer(R[b].recvF + R[b].peerSendBase[a], R[b].device, R[a].sendF + R[a].peerSendBase[b], R[a].device, (size_t)c * 4));
+            }
+    };
+
+    auto writeMesh = [&](double timeValue) {
+        const std::string tn = timeName(timeValue);
+        std::printf("Writing new mesh to time %s\n\n", tn.c_str());
+        for (Rank& K : R) {
+            std::vector<double> pts((size_t)K.mesh.nPoints() * 3);
+            check(smgpu_get_points(K.h, pts.data()), "smgpu_get_points");
+            try { writePoints(K.root + "/" + tn + "/polyMesh", tn + "/polyMesh", K.mesh.nPoints(), pts.data(), binary, writePrecision); }
+            catch (const std::exception& e) { fatal(e.what()); }
+        }
+    };
+
+    // the loop, SM.C:2257-2437
+    bool stopIteration = false;
+    long i = 0;
+    double timeValue = startIsConstant ? 0.0 : startValue;
+    std::vector<smgpu_iter_stats> stats;
+    while (i < centroidalIters && !stopIteration) {
+        // run up to the next write point in one engine call (no host synchronisation inside)
+        long chunk = std::min(centroidalIters - i, writeInterval - (i % writeInterval));
+        int32_t done = 0;
+        stats.assign((size_t)chunk, smgpu_iter_stats{});
+        if (!opt.parallel) {
+            check(smgpu_iterate(R[0].h, (int32_t)chunk, relTol, stats.data(), &done), "smgpu_iterate");
+        } else {
+            for (long k = 0; k < chunk; ++k) {
+                for (Rank& K : R) check(smgpu_iter_begin(K.h), "smgpu_iter_begin");
+                exchange(true);
+                for (Rank& K : R) check(smgpu_iter_mid(K.h), "smgpu_iter_mid");
+                exchange(false);
+                for (Rank& K : R) check(smgpu_iter_end(K.h), "smgpu_iter_end");
+                syncAll();
+                double res = 0.0, nf = 0.0;
+                for (Rank& K : R) {
+                    double ls[2];
+                    HIPCHK(hipMemcpy(ls, K.localStats, 16, hipMemcpyDeviceToHost));
+                    res = std::max(res, ls[0]);   // returnReduce maxOp, SM.C:1567
+                    nf += ls[1];                  // returnReduce sumOp, SM.C:2396
+                }
+                stats[(size_t)k].residual = res;
+                stats[(size_t)k].nFrozenPoints = (int32_t)nf;
+                ++done;
+                if (res < relTol) break;
+            }
+        }
+        for (int32_t k = 0; k < done; ++k)
+            std::printf("Smoothing iteration=%ld nFrozenPoints=%d residual=%g\n", i + k + 1, stats[(size_t)k].nFrozenPoints, stats[(size_t)k].residual);
+        i += done;
+        timeValue += done * deltaT;   // runTime++ per iteration, SM.C:2414
+        const bool hitTol = done > 0 && stats[(size_t)done - 1].residual < relTol;
+        if (hitTol) { std::puts("Residual reached relTol, stopping."); stopIteration = true; }
+        if (i == centroidalIters) { std::puts("Maximum centroidalIters reached, stopping."); stopIteration = true; }
+        // SM.C:2416: write at stop or every writeInterval iterations (not after the very first one)
+        if (stopIteration || ((i % writeInterval) == 0 && i > 1)) writeMesh(timeValue);
+        if (done == 0) break;
+    }
+
+    for (Rank& K : R) smgpu_destroy(K.h);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("ClockTime = %d s.\n\nEnd\n", (int)secs);
+    return 0;
+}

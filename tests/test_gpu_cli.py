@@ -1,0 +1,84 @@
+"""End-to-end drop-in check of the `smoothMesh` front-end on the GPU box: case directory in,
+<time>/polyMesh/points out, log lines as the reference prints them (SM.C:2396-2409)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "smoothmesh_amd", "bin", "smoothMesh")
+LINE = re.compile(r"Smoothing iteration=(\d+) nFrozenPoints=(\d+) residual=(\S+)")
+
+
+def _run(args):
+    r = subprocess.run([BIN] + args, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("fmt", ["ascii", "binary"])
+def test_serial_case(tmp_path, oracle_lib, fmt):
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_case
+    m = hex_block(9, 8, 7, jitter=0.3, seed=4)
+    write_case(str(tmp_path), m, binary=(fmt == "binary"), writeFormat=fmt)
+    out = _run(["-case", str(tmp_path), "-centroidalIters", "12", "-relTol", "0", "-minAngle", "40", "-writeInterval", "5"])
+    o = oracle_lib.Oracle(m)
+    o.set_params(default_params(o.mesh_stats()[0], minAngle=40.0))
+    n, res, frz = o.iterate(12, 0.0)
+    lines = LINE.findall(out)
+    assert [int(a) for a, _, _ in lines] == list(range(1, 13))
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    assert np.allclose([float(c) for _, _, c in lines], res, rtol=1e-5)          # %g prints 6 digits
+    assert "Maximum centroidalIters reached, stopping." in out and "End" in out
+    # writes at 5, 10 (writeInterval) and 12 (stop), SM.C:2416
+    assert sorted(d for d in os.listdir(tmp_path) if d.isdigit()) == ["10", "12", "5"]
+    got = read_polymesh(str(tmp_path / "constant" / "polyMesh"), pointsDir=str(tmp_path / "12" / "polyMesh")).points
+    tol = 0.0 if fmt == "binary" else 2e-10           # ascii output carries 10 significant digits (SM.C:2425)
+    assert rel_linf(got, o.points()) <= max(tol, 1e-13)
+    # restart from latestTime continues the series
+    out2 = _run(["-case", str(tmp_path), "-centroidalIters", "3", "-relTol", "0", "-minAngle", "40"])
+    assert "Create mesh for time = 12" in out2 and os.path.isdir(tmp_path / "15")
+
+
+def test_relTol_stop_and_option_errors(tmp_path):
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import write_case
+    write_case(str(tmp_path), hex_block(4))
+    out = _run(["-case", str(tmp_path)])
+    assert "Smoothing iteration=1 nFrozenPoints=98 residual=0" in out and "Residual reached relTol, stopping." in out
+    assert os.path.isdir(tmp_path / "1")
+    r = subprocess.run([BIN, "-case", str(tmp_path), "-noSuchOption", "1"], capture_output=True, text=True)
+    assert r.returncode != 0 and "Wrong option" in r.stdout
+    r = subprocess.run([BIN, "-case", str(tmp_path), "-layerPatches", "(walls)"], capture_output=True, text=True)
+    assert r.returncode != 0 and "outside the scope" in r.stdout
+
+
+def test_parallel_case(tmp_path, oracle_lib):
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    grid = (2, 2, 1)
+    subs = [hex_subdomain((5, 4, 6), grid, r, jitter=0.3, seed=6) for r in range(4)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "7", "-relTol", "0"])
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs))
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    n, res, frz = mo.iterate(7, 0.0)
+    lines = LINE.findall(out)
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    for s, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "7" / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13

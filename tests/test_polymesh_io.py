@@ -1,0 +1,80 @@
+"""polyMesh directory I/O (C++ host library, include/smhost.h): round trips in both formats, format
+details OpenFOAM readers rely on, error reporting."""
+import os
+
+import numpy as np
+import pytest
+
+
+def _same(a, b, exact_points=True):
+    for f in ("faceOffsets", "facePoints", "owner", "neighbour"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.nCells == b.nCells
+    assert [(p.name, p.type, p.nFaces, p.startFace, p.myProcNo, p.neighbProcNo) for p in a.patches] == \
+           [(p.name, p.type, p.nFaces, p.startFace, p.myProcNo, p.neighbProcNo) for p in b.patches]
+    if exact_points:
+        assert np.array_equal(a.points, b.points)
+
+
+@pytest.mark.parametrize("binary", [False, True])
+def test_roundtrip(tmp_path, binary):
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_polymesh
+    m = hex_block(4, 3, 2, jitter=0.2, seed=1)
+    d = str(tmp_path / "constant" / "polyMesh")
+    write_polymesh(d, m, binary=binary, precision=17)
+    r = read_polymesh(d)
+    _same(m, r)
+    txt = open(os.path.join(d, "faces"), "rb").read()
+    assert (b"faceCompactList" in txt) == binary and (b"faceList" in txt) != binary
+    assert b"nInternalFaces:" in open(os.path.join(d, "owner"), "rb").read()
+
+
+def test_processor_patches_and_addressing(tmp_path):
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import read_label_list, read_polymesh, write_decomposed_case
+    subs = [hex_subdomain((3, 2, 2), (2, 1, 1), r, jitter=0.1) for r in range(2)]
+    write_decomposed_case(str(tmp_path), subs)
+    for s in subs:
+        d = str(tmp_path / f"processor{s.rank}" / "constant" / "polyMesh")
+        _same(s.mesh, read_polymesh(d))
+        assert np.array_equal(read_label_list(os.path.join(d, "pointProcAddressing")), s.pointProcAddressing)
+    b = open(tmp_path / "processor0" / "constant" / "polyMesh" / "boundary").read()
+    assert "procBoundary0to1" in b and "neighbProcNo    1;" in b
+
+
+def test_points_precision_and_time_instance(tmp_path):
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_points, write_polymesh
+    m = hex_block(3, jitter=0.3, seed=2)
+    d = str(tmp_path / "constant" / "polyMesh")
+    write_polymesh(d, m)
+    moved = m.points + 1e-3
+    write_points(str(tmp_path / "5" / "polyMesh"), moved, "5/polyMesh", precision=10)     # SM.C:2425
+    r = read_polymesh(d, pointsDir=str(tmp_path / "5" / "polyMesh"))
+    assert np.max(np.abs(r.points - moved)) / np.max(np.abs(moved)) < 1e-9   # 10 significant digits
+    assert 'location    "5/polyMesh"' in open(tmp_path / "5" / "polyMesh" / "points").read()
+
+
+def test_reads_handwritten_openfoam_style(tmp_path):
+    """comments, inline short lists, uniform-list shorthand, label=64 header -- as OpenFOAM writes them"""
+    from smoothmesh_amd.polymesh import read_polymesh
+    d = tmp_path / "constant" / "polyMesh"
+    os.makedirs(d)
+    hdr = 'FoamFile\n{\n version 2.0;\n format ascii;\n arch "LSB;label=32;scalar=64";\n class %s;\n location "constant/polyMesh";\n object %s;\n}\n// * * * //\n'
+    (d / "points").write_text(hdr % ("vectorField", "points") + "8\n(\n(0 0 0) (1 0 0) (1 1 0) (0 1 0)\n(0 0 1) (1 0 1) /* c */ (1 1 1) (0 1 1)\n)\n")
+    (d / "faces").write_text(hdr % ("faceList", "faces") + "6\n(\n4(0 4 7 3)\n4(1 2 6 5)\n4(0 1 5 4)\n4(3 7 6 2)\n4(0 3 2 1)\n4(4 5 6 7)\n)\n")
+    (d / "owner").write_text(hdr % ("labelList", "owner") + "6{0}\n")
+    (d / "neighbour").write_text(hdr % ("labelList", "neighbour") + "0()\n")
+    (d / "boundary").write_text(hdr % ("polyBoundaryMesh", "boundary") +
+                                "1\n(\n walls\n {\n type wall;\n inGroups 1(wall);\n nFaces 6;\n startFace 0;\n }\n)\n")
+    m = read_polymesh(str(d))
+    assert m.nPoints == 8 and m.nFaces == 6 and m.nInternalFaces == 0 and m.nCells == 1
+    assert m.patches[0].type == "wall" and m.patches[0].nFaces == 6
+    assert np.array_equal(m.owner, np.zeros(6, np.int32))
+
+
+def test_errors_name_the_file(tmp_path):
+    from smoothmesh_amd.polymesh import read_polymesh
+    with pytest.raises(RuntimeError, match="points"):
+        read_polymesh(str(tmp_path))
