@@ -427,6 +427,7 @@ int main(int argc, char** argv) {
                 else
                     HIPCHK(hipMemcpyPeer(R[b].recvF + R[b].peerSendBase[a], R[b].device, R[a].sendF + R[a].peerSendBase[b], R[a].device, (size_t)c * 4));
             }
+        syncAll();   // device-to-device copies may return before they complete; the engines' streams are non-blocking
     };
 
     auto writeMesh = [&](double timeValue) {
