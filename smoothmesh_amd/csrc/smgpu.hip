@@ -9,6 +9,8 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "kernels_tiled.hpp"
+#include "tiles.hpp"
 #include "topology.hpp"
 
 using namespace smgpu;
@@ -25,10 +27,10 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     } while (0)
 
 enum KernelId { K_FACE_GEOM = 0, K_CELL_CENTRES, K_SMOOTH_FINAL, K_SMOOTH_PROP, K_EDGE_ANGLE, K_FA_EDGES,
-                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_COUNT };
+                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_face_geom", "k_cell_centres", "k_smooth<final>", "k_smooth<proposal>",
                                             "k_edge_angle", "k_fa_edges", "k_fa_points", "k_fa_pred", "k_fa_walk",
-                                            "k_apply", "k_finish", "k_halo_*"};
+                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile"};
 
 struct smgpu_handle {
     Topology topo;
@@ -62,7 +64,21 @@ struct smgpu_handle {
     int *sendF = nullptr, *recvF = nullptr;
     double* localStats = nullptr;
     int haloIter = 0;
+    // LDS staging tiles (tiles.hpp)
+    bool useTiles = false;
+    int geomT = 128, smoothT = 256;
+    GeomTiles gt;
+    SmoothTiles stl;
+    GeomTileView gv{};
+    SmoothTileView sv{};
+    size_t geomLds = 0, smoothLds = 0;
+    bool writeFaces = false;   // debug: publish per-face centres/areas from the tiled geometry kernel
 };
+
+static int envInt(const char* name, int def) {
+    const char* v = std::getenv(name);
+    return v ? std::atoi(v) : def;
+}
 
 template <typename T>
 static int devAlloc(smgpu_handle* h, T** out, size_t n) {
@@ -150,6 +166,8 @@ static void computeAlgoBytes(smgpu_handle* h) {
     b[K_APPLY] = 24 * P + 24 * P + 2 * P + 24 * P;
     b[K_FINISH] = 64;
     b[K_HALO] = 0;
+    // fused geometry: points + face/cell index lists + cell centres (no face arrays round trip)
+    b[K_GEOM_TILE] = 24 * P + 4 * (F + 1) + 4 * nfp + 4 * (C + 1) + 4 * ncf + 24 * C + (fa ? 24 * F : 0);
 }
 
 extern "C" {
@@ -204,6 +222,53 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devUpload(h, &m.ecF1, t.ecFace1);
     rc |= devUpload(h, &m.pflags, flags);
     if (rc) return cleanup(1);
+    // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
+    h->useTiles = envInt("SMGPU_TILES", 1) != 0;
+    if (h->useTiles) {
+        h->geomT = envInt("SMGPU_GEOM_T", 128);
+        h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
+        if (h->geomT != 64 && h->geomT != 128 && h->geomT != 256) return cleanup(fail("SMGPU_GEOM_T must be 64, 128 or 256"));
+        if (h->smoothT != 64 && h->smoothT != 128 && h->smoothT != 256) return cleanup(fail("SMGPU_SMOOTH_T must be 64, 128 or 256"));
+        // capacities sized for a 160 KiB LDS: a tile must leave room for >= 2 workgroups per CU
+        const int capGP = std::min(6 * h->geomT, 1400), capGF = std::min(6 * h->geomT, 1400);
+        const std::string e1 = h->gt.build(t, h->geomT, capGP, capGF);
+        const std::string e2 = h->stl.build(t, h->smoothT, std::min(8 * h->smoothT, 1500), std::min(8 * h->smoothT, 1500));
+        if (!e1.empty() || !e2.empty()) {
+            h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
+        } else {
+            for (size_t k = 0; k < h->stl.ppLoc.size(); ++k)
+                if (flags[t.pointPoints[k]] & PF_INTERNAL) h->stl.ppLoc[k] |= 0x8000;
+            GeomTileView& g = h->gv;
+            SmoothTileView& v = h->sv;
+            rc |= devUpload(h, &g.cellBeg, h->gt.cellBeg);
+            rc |= devUpload(h, &g.tpOff, h->gt.tpOff);
+            rc |= devUpload(h, &g.tpIds, h->gt.tpIds);
+            rc |= devUpload(h, &g.tfOff, h->gt.tfOff);
+            rc |= devUpload(h, &g.tfIds, h->gt.tfIds);
+            rc |= devUpload(h, &g.tfpOff, h->gt.tfpOff);
+            rc |= devUpload(h, &g.tfpLoc, h->gt.tfpLoc);
+            rc |= devUpload(h, &g.cfLoc, h->gt.cfLoc);
+            g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
+            rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
+            rc |= devUpload(h, &v.tcOff, h->stl.tcOff);
+            rc |= devUpload(h, &v.tcIds, h->stl.tcIds);
+            rc |= devUpload(h, &v.tnOff, h->stl.tnOff);
+            rc |= devUpload(h, &v.tnIds, h->stl.tnIds);
+            rc |= devUpload(h, &v.pcLoc, h->stl.pcLoc);
+            rc |= devUpload(h, &v.ppLoc, h->stl.ppLoc);
+            rc |= devUpload(h, &v.selfLoc, h->stl.selfLoc);
+            rc |= devUpload(h, &v.pairShare, h->stl.pairShare);
+            v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
+            v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
+            if (rc) return cleanup(1);
+            h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + 6 * (size_t)g.maxFaces);
+            h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
+            if (envInt("SMGPU_VERBOSE", 0))
+                std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
+                             h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, h->smoothT, h->stl.nTiles, h->smoothLds,
+                             v.maxCells, v.maxPoints);
+        }
+    }
     State& s = h->st;
     const size_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
     rc |= devAlloc(h, &h->bufA, 3 * P);
@@ -292,11 +357,44 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
     return 0;
 }
 
+extern "C++" {
+template <int T>
+static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg) {
+    static bool attrSet = false;
+    if (!attrSet) { (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
+    hipLaunchKernelGGL(k_geom_tile<T>, dim3(h->gt.nTiles), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0);
+}
+template <bool FINAL, int T>
+static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm) {
+    static bool attrSet = false;
+    if (!attrSet) { (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
+    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(h->stl.nTiles), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv);
+}
+template <bool FINAL>
+static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm) {
+    const int kid = FINAL ? K_SMOOTH_FINAL : K_SMOOTH_PROP;
+    if (h->useTiles)
+        return launchK(h, kid, [&] {
+            if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm);
+            else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm);
+            else launchSmoothTile<FINAL, 256>(h, m, s, prm);
+        });
+    return launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); });
+}
+
+}  // extern "C++"
+
 // geometry of the current coordinates: OpenFOAM face centres/areas + cell centres
 static int runGeometry(smgpu_handle* h) {
     const MeshView& m = h->mv;
     State s = h->st;
     const int wantAvg = h->prm.faceAngleConstraint ? 1 : 0;
+    if (h->useTiles)
+        return launchK(h, K_GEOM_TILE, [&] {
+            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg);
+            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg);
+            else launchGeomTile<256>(h, m, s, wantAvg);
+        });
     if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg); })) return 1;
     if (launchK(h, K_CELL_CENTRES, [&] { hipLaunchKernelGGL(k_cell_centres, dim3(gridFor(m.nCells)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
     return 0;
@@ -308,7 +406,7 @@ static int runProposalAndConstraints(smgpu_handle* h) {
     State s = h->st;
     const Prm prm = makePrm(h->prm);
     const int gP = gridFor(m.nPoints);
-    if (launchK(h, K_SMOOTH_PROP, [&] { hipLaunchKernelGGL(k_smooth<false>, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    if (runSmooth<false>(h, m, s, prm)) return 1;
     if (h->prm.edgeAngleConstraint)
         if (launchK(h, K_EDGE_ANGLE, [&] { hipLaunchKernelGGL(k_edge_angle, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     if (h->prm.faceAngleConstraint) {
@@ -355,7 +453,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
         if (runGeometry(h)) return 1;
         State s = h->st;
         if (fused) {
-            if (launchK(h, K_SMOOTH_FINAL, [&] { hipLaunchKernelGGL(k_smooth<true>, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+            if (runSmooth<true>(h, m, s, prm)) return 1;
         } else {
             if (runProposalAndConstraints(h)) return 1;
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
@@ -527,7 +625,10 @@ int smgpu_debug_propose(smgpu_handle* h) {
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
-    if (runGeometry(h)) return 1;
+    h->writeFaces = true;
+    const int rcg = runGeometry(h);
+    h->writeFaces = false;
+    if (rcg) return 1;
     if (runProposalAndConstraints(h)) return 1;
     return checkDeviceError(h);
 }
