@@ -50,6 +50,7 @@ struct State {
     double* edgeMin; double* edgeMax; double* ptMin; double* ptMax;
     uint8_t* faActive; uint8_t* faS; uint8_t* faN; int* walkStack;
     Accum* acc;
+    double* blkMax; int* blkCnt;   // per-workgroup partials of (max step, frozen count); reduced by k_finish
     smgpu_iter_stats* stats;
     const int* sharedSlot;     // multi-rank: per point slot into combA, or -1 (NULL on one rank)
     const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
@@ -217,10 +218,13 @@ __device__ __forceinline__ double arRatio(const V3& c1, const V3& c2, const V3& 
     }
 }
 
-__device__ __forceinline__ void blockAccumulate(State& s, double dist, int frozenCount) {
-    // residual = max over points (SM.C:1556-1565), nFrozenPoints = count (SM.C:2384-2392)
-    __shared__ double shMax[kBlock / 64];
-    __shared__ int shCnt[kBlock / 64];
+// residual = max over points (SM.C:1556-1565), nFrozenPoints = count (SM.C:2384-2392): every workgroup
+// publishes one partial (no same-address atomics: thousands of workgroups on one word serialise at
+// ~90 atomics/us); k_finish reduces the partials.
+template <int T>
+__device__ __forceinline__ void blockPublish(const State& s, double dist, int frozenCount) {
+    __shared__ double shMax[T / 64];
+    __shared__ int shCnt[T / 64];
     if (!(dist > 0.0)) dist = 0.0;  // NaN never wins "distance > maxStep"
     for (int o = 32; o > 0; o >>= 1) {
         const double od = __shfl_down(dist, o, 64);
@@ -233,9 +237,9 @@ __device__ __forceinline__ void blockAccumulate(State& s, double dist, int froze
     __syncthreads();
     if (threadIdx.x == 0) {
         double d = shMax[0]; int c = shCnt[0];
-        for (int i = 1; i < kBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
-        if (d > 0.0) atomicMax(&s.acc->resBits, (unsigned long long)__double_as_longlong(d));
-        if (c) atomicAdd(&s.acc->nFrozen, c);
+        for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
+        s.blkMax[blockIdx.x] = d;
+        s.blkCnt[blockIdx.x] = c;
     }
 }
 
@@ -312,7 +316,7 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             s.frozen[p] = frozen ? 1 : 0;
         }
     }
-    if (FINAL) blockAccumulate(s, dist, fcount);
+    if (FINAL) blockPublish<kBlock>(s, dist, fcount);
 }
 
 // restrictMinEdgeAngleDecrease SM.C:900-930 (+ calc_min_edge_angles :837-894) -- one thread per point.
@@ -547,19 +551,37 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
         dist = mag(np - cur) / prm.maxStep;
         stv(s.ptsNext, p, np);
     }
-    blockAccumulate(s, dist, fcount);
+    blockPublish<kBlock>(s, dist, fcount);
 }
 
-// End of iteration: publish the log-line values (SM.C:2396), stop test (SM.C:2401), reset accumulators.
-__global__ void k_finish(State s, int iter, double relTol, double* localStats) {
+// End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test
+// (SM.C:2401), reset accumulators.  One workgroup.
+__global__ void __launch_bounds__(kBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
     Accum* a = s.acc;
     if (a->stop) return;
-    const double res = __longlong_as_double((long long)a->resBits);
-    if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = a->nFrozen; s.stats[iter].pad = 1; }
-    if (localStats) { localStats[0] = res; localStats[1] = (double)a->nFrozen; }
+    __shared__ double shMax[kBlock / 64];
+    __shared__ int shCnt[kBlock / 64];
+    double d = 0.0;
+    int c = 0;
+    for (int i = threadIdx.x; i < nPartials; i += kBlock) {
+        const double v = s.blkMax[i];
+        d = (v > d) ? v : d;
+        c += s.blkCnt[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double od = __shfl_down(d, o, 64);
+        const int oc = __shfl_down(c, o, 64);
+        d = (od > d) ? od : d;
+        c += oc;
+    }
+    if ((threadIdx.x & 63) == 0) { shMax[threadIdx.x >> 6] = d; shCnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int i = 1; i < kBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
+    const double res = d;
+    if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
+    if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
     if (res < relTol) a->stop = 1;
-    a->resBits = 0ull;
-    a->nFrozen = 0;
     a->nActive = 0;
 }
 

@@ -1,25 +1,45 @@
 // kernels_tiled.hpp -- LDS-staged forms of the two gather stages (see tiles.hpp for the idea).
 // Same arithmetic, same summation order, same results as k_face_geom + k_cell_centres and k_smooth in
-// kernels.hpp; global memory is only streamed (coalesced id-list loads), all indexed access is in LDS.
+// kernels.hpp; global memory is only streamed (coalesced id lists and sliced-ELL index tables, 8 bytes
+// per lane per load), all indexed access is in LDS.
 #pragma once
 #include "kernels.hpp"
 
 namespace smgpu {
 
+constexpr unsigned kPad = 0xFFFFu;
+
 struct GeomTileView {
     const int* cellBeg; const int* tpOff; const int* tpIds; const int* tfOff; const int* tfIds;
-    const int* tfpOff; const uint16_t* tfpLoc; const uint16_t* cfLoc;
+    const int* fvBase; const uint8_t* fvWidth; const uint16_t* faceVerts;
+    const int* cfBase; const uint8_t* cfWidth; const uint16_t* cellFaces;
     int maxPoints, maxFaces;
 };
 
 struct SmoothTileView {
     const int* ptBeg; const int* tcOff; const int* tcIds; const int* tnOff; const int* tnIds;
-    const uint16_t* pcLoc; const uint16_t* ppLoc;   // ppLoc bit 15: the neighbour is an internal point
-    const uint16_t* selfLoc; const uint16_t* pairShare;
+    const uint16_t* selfLoc;
+    const int* pcBase; const uint8_t* pcWidth; const uint16_t* pcEll;
+    const int* ppBase; const uint8_t* ppWidth; const uint16_t* ppEll;   // bit 15: the neighbour is an internal point
+    const uint16_t* pairEll;
     int maxCells, maxPoints, usePairShare;
 };
 
 __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const double* z, int i) { return v3(x[i], y[i], z[i]); }
+
+// Visit the entries of one ELL row (4 per 8-byte chunk, `w4` chunks `stride` chunks apart) in list
+// order; pads (0xFFFF) only occur at the tail and are skipped.  No early exit, so the chunk loads
+// stay independent of the entry processing.  BODY sees `j` (list position) and `e` (entry value).
+// (A macro, not a lambda: closures captured by reference ended up in scratch memory.)
+#define SMGPU_ELL_ENTRY(J, E, BODY) { const int j = (J); const unsigned e = (E); if (e != kPad) { BODY } }
+#define SMGPU_ELL_FOREACH(ROWS, W4, STRIDE, BODY)                         \
+    for (int c_ = 0; c_ < (W4); ++c_) {                                   \
+        const ushort4 q_ = (ROWS)[(size_t)c_ * (STRIDE)];                 \
+        SMGPU_ELL_ENTRY(4 * c_ + 0, q_.x, BODY)                           \
+        SMGPU_ELL_ENTRY(4 * c_ + 1, q_.y, BODY)                           \
+        SMGPU_ELL_ENTRY(4 * c_ + 2, q_.z, BODY)                           \
+        SMGPU_ELL_ENTRY(4 * c_ + 3, q_.w, BODY)                           \
+    }
 
 // Cell centres of the current coordinates for one tile of consecutive cells:
 // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols (.com v2412), staged through LDS.
@@ -45,42 +65,59 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
     // phase 1: every face of the tile once
     {
         const int b = g.tfOff[tile], nf = g.tfOff[tile + 1] - b;
+        const int fw4 = g.fvWidth[tile] >> 2;
+        const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
         for (int i = tid; i < nf; i += T) {
-            const int o = g.tfpOff[b + i], n = g.tfpOff[b + i + 1] - o;
-            const uint16_t* lp = g.tfpLoc + o;
-            V3 ctr, area;
-            V3 fCentre = ldsv(px, py, pz, lp[0]);
-            for (int j = 1; j < n; ++j) fCentre = fCentre + ldsv(px, py, pz, lp[j]);
+            const ushort4* row = fvTile + (size_t)i * fw4;
+            // vertex average (fCentre of makeFaceCentresAndAreas; calcFaceCenter SM.C:1103-1130)
+            V3 fCentre = v3(0, 0, 0);
+            int n = 0;
+            SMGPU_ELL_FOREACH(row, fw4, 1, {
+                const V3 p = ldsv(px, py, pz, e);
+                fCentre = (j == 0) ? p : fCentre + p;
+                n = j + 1;
+            })
             fCentre = fCentre / double(n);
+            V3 ctr, area;
             if (n == 3) {
-                const V3 p0 = ldsv(px, py, pz, lp[0]), p1 = ldsv(px, py, pz, lp[1]), p2 = ldsv(px, py, pz, lp[2]);
+                const ushort4 q = row[0];
+                const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z);
                 ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
                 area = 0.5 * cross(p1 - p0, p2 - p0);
             } else {
                 V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
                 double sumA = 0.0;
-                V3 thisPoint = ldsv(px, py, pz, lp[0]);
-                const V3 first = thisPoint;
-                for (int j = 0; j < n; ++j) {
-                    const V3 nextPoint = (j == n - 1) ? first : ldsv(px, py, pz, lp[j + 1]);
-                    const V3 c = (thisPoint + nextPoint) + fCentre;
-                    const V3 nn = cross(nextPoint - thisPoint, fCentre - thisPoint);
-                    const double a = mag(nn);
-                    sumN = sumN + nn;
-                    sumA += a;
-                    sumAc = sumAc + a * c;
-                    thisPoint = nextPoint;
-                }
+                V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
+#define SMGPU_FAN(NEXT)                                                        \
+    {                                                                          \
+        const V3 nextPoint = (NEXT);                                           \
+        const V3 c = (thisPoint + nextPoint) + fCentre;                        \
+        const V3 nn = cross(nextPoint - thisPoint, fCentre - thisPoint);       \
+        const double a = mag(nn);                                              \
+        sumN = sumN + nn;                                                      \
+        sumA += a;                                                             \
+        sumAc = sumAc + a * c;                                                 \
+        thisPoint = nextPoint;                                                 \
+    }
+                SMGPU_ELL_FOREACH(row, fw4, 1, {
+                    const V3 p = ldsv(px, py, pz, e);
+                    if (j == 0) { first = p; thisPoint = p; }
+                    else SMGPU_FAN(p)
+                })
+                SMGPU_FAN(first)
+#undef SMGPU_FAN
                 if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
                 else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
             }
             fcx[i] = ctr.x; fcy[i] = ctr.y; fcz[i] = ctr.z;
             fax[i] = area.x; fay[i] = area.y; faz[i] = area.z;
-            const int fid = g.tfIds[b + i];
-            if (fid < 0) {   // this tile holds the face's owner cell: it publishes the per-face values
-                const int f = fid & 0x7fffffff;
-                if (wantAvg) stv(s.fAvg, f, fCentre);
-                if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
+            if (wantAvg || writeFaces) {
+                const int fid = g.tfIds[b + i];
+                if (fid < 0) {   // this tile holds the face's owner cell: it publishes the per-face values
+                    const int f = fid & 0x7fffffff;
+                    if (wantAvg) stv(s.fAvg, f, fCentre);
+                    if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
+                }
             }
         }
     }
@@ -89,22 +126,27 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
     // phase 2: one thread per cell
     const int c = g.cellBeg[tile] + tid;
     if (c < g.cellBeg[tile + 1]) {
-        const int b = m.cfOff[c], e = m.cfOff[c + 1];
+        const int cw4 = g.cfWidth[tile] >> 2;
+        const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
         V3 cEst = v3(0, 0, 0);
-        for (int k = b; k < e; ++k) cEst = cEst + ldsv(fcx, fcy, fcz, g.cfLoc[k] & 0x7fff);
-        cEst = cEst / double(e - b);
+        int nFaces = 0;
+        SMGPU_ELL_FOREACH(row, cw4, T, {
+            cEst = cEst + ldsv(fcx, fcy, fcz, e & 0x7fff);
+            nFaces = j + 1;
+        })
+        cEst = cEst / double(nFaces);
         V3 ctr = v3(0, 0, 0);
         double vol = 0.0;
-        for (int k = b; k < e; ++k) {
-            const int v = g.cfLoc[k];
-            const int f = v & 0x7fff;
+        SMGPU_ELL_FOREACH(row, cw4, T, {
+            (void)j;
+            const int f = e & 0x7fff;
             const V3 fc = ldsv(fcx, fcy, fcz, f);
             const V3 fA = ldsv(fax, fay, faz, f);
-            const double pyr3Vol = (v & 0x8000) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
+            const double pyr3Vol = (e & 0x8000) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
             const V3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst;
             ctr = ctr + pyr3Vol * pc;
             vol += pyr3Vol;
-        }
+        })
         if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
         else ctr = cEst;
         stv(s.cellCtr, c, ctr);
@@ -141,9 +183,11 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
         const uint8_t fl = m.pflags[p];
         const bool internal = fl & PF_INTERNAL;
         const V3 cur = ldsv(nx, ny, nz, g.selfLoc[p]);
-        const int nb = m.ppOff[p], ne = m.ppOff[p + 1];
+        const int wn4 = g.ppWidth[tile] >> 2;
+        const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
         V3 sum = v3(0, 0, 0), r1, r2, r3;
         int count = 0, hc = 0;
+        double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
         const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
         if (slot >= 0) {
             const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
@@ -152,30 +196,46 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             const long long pk = __double_as_longlong(r[12]);
             count = (int)(pk & 0xffffffffll);
             hc = (int)(pk >> 32);
+            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+                (void)j;
+                const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
+                if (len < shortestCur) shortestCur = len;
+            })
         } else {
             if (internal) {   // SM.C:116-130
-                const int b = m.pcOff[p], e = m.pcOff[p + 1];
-                count = e - b;
-                for (int k = b; k < e; ++k) sum = sum + ldsv(cx, cy, cz, g.pcLoc[k]);
+                const int wc4 = g.pcWidth[tile] >> 2;
+                const ushort4* pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
+                SMGPU_ELL_FOREACH(pcRow, wc4, T, {
+                    sum = sum + ldsv(cx, cy, cz, e);
+                    count = j + 1;
+                })
             }
             // SM.C:325-387 (stable top three; boundary points look at boundary neighbours only)
             double l1 = 0, l2 = 0, l3 = 0;
             int k1 = -1, k2 = -1, k3 = -1;
-            for (int k = nb; k < ne; ++k) {
-                const int q = g.ppLoc[k];
-                if (!internal && (q & 0x8000)) continue;
-                const double len = mag(cur - ldsv(nx, ny, nz, q & 0x7fff));
-                if (k1 < 0 || len < l1) { l3 = l2; k3 = k2; l2 = l1; k2 = k1; l1 = len; k1 = k; }
-                else if (k2 < 0 || len < l2) { l3 = l2; k3 = k2; l2 = len; k2 = k; }
-                else if (k3 < 0 || len < l3) { l3 = len; k3 = k; }
-            }
+            unsigned q1 = 0, q2 = 0, q3 = 0;
+            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+                // getPointDistance(neigh, cCoords) = |cCoords - neigh|; the same value serves SM.C:626
+                const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
+                if (len < shortestCur) shortestCur = len;
+                if (internal || !(e & 0x8000)) {
+                    if (k1 < 0 || len < l1) { l3 = l2; k3 = k2; q3 = q2; l2 = l1; k2 = k1; q2 = q1; l1 = len; k1 = j; q1 = e; }
+                    else if (k2 < 0 || len < l2) { l3 = l2; k3 = k2; q3 = q2; l2 = len; k2 = j; q2 = e; }
+                    else if (k3 < 0 || len < l3) { l3 = len; k3 = j; q3 = e; }
+                }
+            })
             if (k2 < 0) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
             else {
-                r1 = ldsv(nx, ny, nz, g.ppLoc[k1] & 0x7fff) - cur;
-                r2 = ldsv(nx, ny, nz, g.ppLoc[k2] & 0x7fff) - cur;
-                r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, g.ppLoc[k3] & 0x7fff) - cur;
-                if (g.usePairShare) hc = (g.pairShare[k1] >> (k2 - nb)) & 1;
-                else hc = shareCell(m, m.ppPt[k1], m.ppPt[k2]) ? 1 : 0;
+                r1 = ldsv(nx, ny, nz, q1 & 0x7fff) - cur;
+                r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
+                r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
+                if (g.usePairShare) {
+                    const uint16_t* pe = g.pairEll + g.ppBase[tile];
+                    hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
+                } else {
+                    const int nb = m.ppOff[p];
+                    hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
+                }
             }
         }
         V3 np = cur;
@@ -193,14 +253,12 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
         }
         bool frozen = false;                                           // SM.C:611-648
         {
-            double shortestCur = SMGPU_GREAT, shortestNew = SMGPU_GREAT;
-            for (int k = nb; k < ne; ++k) {
-                const V3 q = ldsv(nx, ny, nz, g.ppLoc[k] & 0x7fff);
-                const double tc = mag(cur - q);
-                if (tc < shortestCur) shortestCur = tc;
-                const double tn = mag(np - q);
+            double shortestNew = SMGPU_GREAT;
+            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+                (void)j;
+                const double tn = mag(np - ldsv(nx, ny, nz, e & 0x7fff));
                 if (tn < shortestNew) shortestNew = tn;
-            }
+            })
             const double shortest = (shortestNew < shortestCur) ? shortestNew : shortestCur;
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
@@ -214,26 +272,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             s.frozen[p] = frozen ? 1 : 0;
         }
     }
-    if (FINAL) {
-        // block reduction as blockAccumulate, for T threads
-        __shared__ double shMax[T / 64];
-        __shared__ int shCnt[T / 64];
-        if (!(dist > 0.0)) dist = 0.0;
-        for (int o = 32; o > 0; o >>= 1) {
-            const double od = __shfl_down(dist, o, 64);
-            const int oc = __shfl_down(fcount, o, 64);
-            dist = (od > dist) ? od : dist;
-            fcount += oc;
-        }
-        if ((tid & 63) == 0) { shMax[tid >> 6] = dist; shCnt[tid >> 6] = fcount; }
-        __syncthreads();
-        if (tid == 0) {
-            double d = shMax[0]; int c = shCnt[0];
-            for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
-            if (d > 0.0) atomicMax(&s.acc->resBits, (unsigned long long)__double_as_longlong(d));
-            if (c) atomicAdd(&s.acc->nFrozen, c);
-        }
-    }
+    if (FINAL) blockPublish<T>(s, dist, fcount);
 }
 
 }  // namespace smgpu

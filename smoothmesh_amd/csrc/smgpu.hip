@@ -225,19 +225,30 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     if (h->useTiles) {
-        h->geomT = envInt("SMGPU_GEOM_T", 128);
+        h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
         if (h->geomT != 64 && h->geomT != 128 && h->geomT != 256) return cleanup(fail("SMGPU_GEOM_T must be 64, 128 or 256"));
         if (h->smoothT != 64 && h->smoothT != 128 && h->smoothT != 256) return cleanup(fail("SMGPU_SMOOTH_T must be 64, 128 or 256"));
         // capacities sized for a 160 KiB LDS: a tile must leave room for >= 2 workgroups per CU
-        const int capGP = std::min(6 * h->geomT, 1400), capGF = std::min(6 * h->geomT, 1400);
-        const std::string e1 = h->gt.build(t, h->geomT, capGP, capGF);
+        const int geomCells = envInt("SMGPU_GEOM_CELLS", h->geomT / 2);   // cells per tile (<= threads)
+        const int capGP = std::min(6 * geomCells, 1400), capGF = std::min(6 * geomCells, 1400);
+        const std::string e1 = h->gt.build(t, h->geomT, geomCells, capGP, capGF);
         const std::string e2 = h->stl.build(t, h->smoothT, std::min(8 * h->smoothT, 1500), std::min(8 * h->smoothT, 1500));
         if (!e1.empty() || !e2.empty()) {
             h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
         } else {
-            for (size_t k = 0; k < h->stl.ppLoc.size(); ++k)
-                if (flags[t.pointPoints[k]] & PF_INTERNAL) h->stl.ppLoc[k] |= 0x8000;
+            {   // mark internal neighbours (SM.C:294) in the ELL copy of pointPoints
+                const SmoothTiles& st = h->stl;
+                for (int ti = 0; ti < st.nTiles; ++ti) {
+                    const int w = st.ppWidth[ti];
+                    for (int p = st.ptBeg[ti]; p < st.ptBeg[ti + 1]; ++p) {
+                        const int tl = p - st.ptBeg[ti], nb = t.pointEdges.off[p], v = t.pointEdges.off[p + 1] - nb;
+                        for (int j = 0; j < v && j < w; ++j)
+                            if (flags[t.pointPoints[nb + j]] & PF_INTERNAL)
+                                h->stl.ppEll[(size_t)st.ppBase[ti] + ((size_t)(j / 4) * st.threads + tl) * 4 + (j % 4)] |= 0x8000;
+                    }
+                }
+            }
             GeomTileView& g = h->gv;
             SmoothTileView& v = h->sv;
             rc |= devUpload(h, &g.cellBeg, h->gt.cellBeg);
@@ -245,19 +256,26 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &g.tpIds, h->gt.tpIds);
             rc |= devUpload(h, &g.tfOff, h->gt.tfOff);
             rc |= devUpload(h, &g.tfIds, h->gt.tfIds);
-            rc |= devUpload(h, &g.tfpOff, h->gt.tfpOff);
-            rc |= devUpload(h, &g.tfpLoc, h->gt.tfpLoc);
-            rc |= devUpload(h, &g.cfLoc, h->gt.cfLoc);
+            rc |= devUpload(h, &g.fvBase, h->gt.fvBase);
+            rc |= devUpload(h, &g.fvWidth, h->gt.fvWidth);
+            rc |= devUpload(h, &g.faceVerts, h->gt.faceVerts);
+            rc |= devUpload(h, &g.cfBase, h->gt.cfBase);
+            rc |= devUpload(h, &g.cfWidth, h->gt.cfWidth);
+            rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
             g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
             rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
             rc |= devUpload(h, &v.tcOff, h->stl.tcOff);
             rc |= devUpload(h, &v.tcIds, h->stl.tcIds);
             rc |= devUpload(h, &v.tnOff, h->stl.tnOff);
             rc |= devUpload(h, &v.tnIds, h->stl.tnIds);
-            rc |= devUpload(h, &v.pcLoc, h->stl.pcLoc);
-            rc |= devUpload(h, &v.ppLoc, h->stl.ppLoc);
             rc |= devUpload(h, &v.selfLoc, h->stl.selfLoc);
-            rc |= devUpload(h, &v.pairShare, h->stl.pairShare);
+            rc |= devUpload(h, &v.pcBase, h->stl.pcBase);
+            rc |= devUpload(h, &v.pcWidth, h->stl.pcWidth);
+            rc |= devUpload(h, &v.pcEll, h->stl.pcEll);
+            rc |= devUpload(h, &v.ppBase, h->stl.ppBase);
+            rc |= devUpload(h, &v.ppWidth, h->stl.ppWidth);
+            rc |= devUpload(h, &v.ppEll, h->stl.ppEll);
+            rc |= devUpload(h, &v.pairEll, h->stl.pairEll);
             v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
             v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
             if (rc) return cleanup(1);
@@ -288,6 +306,11 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.faN, (size_t)t.pointEdges.nnz());
     rc |= devAlloc(h, &s.walkStack, P + 64);
     rc |= devAlloc(h, &s.acc, 1);
+    {
+        const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + 1;
+        rc |= devAlloc(h, &s.blkMax, nPart);
+        rc |= devAlloc(h, &s.blkCnt, nPart);
+    }
     if (rc) return cleanup(1);
     if (hipMemset(s.acc, 0, sizeof(Accum)) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemset(s.frozen, 0, P) != hipSuccess) return cleanup(fail("hipMemset failed"));
@@ -458,7 +481,8 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (runProposalAndConstraints(h)) return 1;
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
-        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, h->stream, s, i, relTol, (double*)nullptr); })) return 1;
+        const int nPart = (fused && h->useTiles) ? h->stl.nTiles : gP;
+        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
         ++launched;
         // a positive relTol can stop the loop: poll the device flag now and then so a converged run
@@ -613,7 +637,7 @@ int smgpu_iter_end(smgpu_handle* h) {
             })) return 1;
     if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
-    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(1), 0, h->stream, s, h->haloIter, -1.0, h->localStats); })) return 1;
+    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, h->stream, s, gridFor(m.nPoints), h->haloIter, -1.0, h->localStats); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     return 0;

@@ -5,7 +5,11 @@
 
 namespace smgpu {
 
-std::string GeomTiles::build(const Topology& t, int32_t capCells, int32_t capPoints, int32_t capFaces) {
+static inline int32_t roundUp4(int32_t v) { return (v + 3) & ~3; }
+
+std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCells, int32_t capPoints, int32_t capFaces) {
+    threads = nThreads;
+    if (capCells > threads) capCells = threads;
     const auto& cf = t.cellFacesGeom;
     const auto& fp = t.facePoints;
     std::vector<int32_t> stampP((size_t)t.nPoints, -1), stampF((size_t)t.nFaces, -1);
@@ -34,52 +38,69 @@ std::string GeomTiles::build(const Topology& t, int32_t capCells, int32_t capPoi
     cellBeg.push_back(t.nCells);
     nTiles = (int32_t)cellBeg.size() - 1;
 
-    // pass 2: per tile unique lists (ascending) and local indices
+    // pass 2: per tile unique lists (ascending), local indices, ELL tables
     std::fill(stampP.begin(), stampP.end(), -1);
     std::fill(stampF.begin(), stampF.end(), -1);
     std::vector<int32_t> locP((size_t)t.nPoints, -1), locF((size_t)t.nFaces, -1);
-    tpOff.assign(1, 0); tfOff.assign(1, 0); tfpOff.assign(1, 0);
-    tpIds.clear(); tfIds.clear(); tfpLoc.clear();
-    cfLoc.assign(cf.val.size(), 0);
+    tpOff.assign(1, 0); tfOff.assign(1, 0);
+    tpIds.clear(); tfIds.clear(); faceVerts.clear(); cellFaces.clear();
+    fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear();
     std::vector<int32_t> faces, points;
     for (int32_t ti = 0; ti < nTiles; ++ti) {
         faces.clear(); points.clear();
         const int32_t cb = cellBeg[ti], ce = cellBeg[ti + 1];
-        for (int32_t c = cb; c < ce; ++c)
+        int32_t cw = 0, fw = 0;
+        for (int32_t c = cb; c < ce; ++c) {
+            cw = std::max(cw, cf.off[c + 1] - cf.off[c]);
             for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
                 const int32_t f = cf.val[k] & 0x7fffffff;
                 if (stampF[f] != ti) { stampF[f] = ti; faces.push_back(f); }
             }
+        }
         std::sort(faces.begin(), faces.end());
-        for (int32_t f : faces)
+        for (int32_t f : faces) {
+            fw = std::max(fw, fp.off[f + 1] - fp.off[f]);
             for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
                 if (stampP[fp.val[j]] != ti) { stampP[fp.val[j]] = ti; points.push_back(fp.val[j]); }
+        }
         std::sort(points.begin(), points.end());
-        if ((int32_t)points.size() > 32767 || (int32_t)faces.size() > 32767) return "tile too large for 15-bit local indices";
+        cw = roundUp4(cw); fw = roundUp4(fw);
+        if ((int32_t)points.size() > 32767 || (int32_t)faces.size() > 32767 || cw > 252 || fw > 252)
+            return "tile too large for the 15-bit local index tables";
         for (size_t i = 0; i < points.size(); ++i) locP[points[i]] = (int32_t)i;
         for (size_t i = 0; i < faces.size(); ++i) locF[faces[i]] = (int32_t)i;
         tpIds.insert(tpIds.end(), points.begin(), points.end());
         tpOff.push_back((int32_t)tpIds.size());
+        fvBase.push_back((int32_t)faceVerts.size());
+        fvWidth.push_back((uint8_t)fw);
         for (int32_t f : faces) {
             const bool ownerHere = t.owner[f] >= cb && t.owner[f] < ce;
             tfIds.push_back(ownerHere ? (int32_t)(0x80000000u | (uint32_t)f) : f);
-            for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j) tfpLoc.push_back((uint16_t)locP[fp.val[j]]);
-            tfpOff.push_back((int32_t)tfpLoc.size());
+            const int32_t n = fp.off[f + 1] - fp.off[f];
+            for (int32_t j = 0; j < fw; ++j) faceVerts.push_back(j < n ? (uint16_t)locP[fp.val[fp.off[f] + j]] : kEllPad);
         }
         tfOff.push_back((int32_t)tfIds.size());
-        for (int32_t c = cb; c < ce; ++c)
-            for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
+        cfBase.push_back((int32_t)cellFaces.size());
+        cfWidth.push_back((uint8_t)cw);
+        const size_t base = cellFaces.size();
+        cellFaces.resize(base + (size_t)cw * threads, kEllPad);
+        for (int32_t c = cb; c < ce; ++c) {
+            const int32_t tl = c - cb;
+            for (int32_t k = cf.off[c], j = 0; k < cf.off[c + 1]; ++k, ++j) {
                 const int32_t v = cf.val[k];
-                cfLoc[k] = (uint16_t)(locF[v & 0x7fffffff] | (v < 0 ? 0x8000 : 0));
+                cellFaces[base + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)(locF[v & 0x7fffffff] | (v < 0 ? 0x8000 : 0));
             }
+        }
         maxPoints = std::max(maxPoints, (int32_t)points.size());
         maxFaces = std::max(maxFaces, (int32_t)faces.size());
-        maxCells = std::max(maxCells, ce - cb);
+        if (faceVerts.size() > 0x7fffffffu || cellFaces.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
     }
     return "";
 }
 
-std::string SmoothTiles::build(const Topology& t, int32_t capTile, int32_t capCells, int32_t capPoints) {
+std::string SmoothTiles::build(const Topology& t, int32_t nThreads, int32_t capCells, int32_t capPoints) {
+    threads = nThreads;
+    const int32_t capTile = threads;
     const auto& pc = t.pointCells;
     const auto& pe = t.pointEdges;   // offsets shared with pointPoints
     std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
@@ -111,14 +132,17 @@ std::string SmoothTiles::build(const Topology& t, int32_t capTile, int32_t capCe
     std::vector<int32_t> locC((size_t)t.nCells, -1), locN((size_t)t.nPoints, -1);
     tcOff.assign(1, 0); tnOff.assign(1, 0);
     tcIds.clear(); tnIds.clear();
-    pcLoc.assign(pc.val.size(), 0);
-    ppLoc.assign(t.pointPoints.size(), 0);
     selfLoc.assign((size_t)t.nPoints, 0);
+    pcBase.clear(); pcWidth.clear(); pcEll.clear(); ppBase.clear(); ppWidth.clear(); ppEll.clear(); pairEll.clear();
+    const bool pairs = t.maxPointPoints <= 16;
     std::vector<int32_t> cells, pts;
     for (int32_t ti = 0; ti < nTiles; ++ti) {
         cells.clear(); pts.clear();
         const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
+        int32_t wc = 0, wn = 0;
         for (int32_t p = pb; p < pend; ++p) {
+            wc = std::max(wc, pc.off[p + 1] - pc.off[p]);
+            wn = std::max(wn, pe.off[p + 1] - pe.off[p]);
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
                 if (stampC[pc.val[k]] != ti) { stampC[pc.val[k]] = ti; cells.push_back(pc.val[k]); }
             if (stampN[p] != ti) { stampN[p] = ti; pts.push_back(p); }
@@ -127,42 +151,50 @@ std::string SmoothTiles::build(const Topology& t, int32_t capTile, int32_t capCe
         }
         std::sort(cells.begin(), cells.end());
         std::sort(pts.begin(), pts.end());
-        if ((int32_t)cells.size() > 32767 || (int32_t)pts.size() > 32767) return "tile too large for 15-bit local indices";
+        wc = roundUp4(wc); wn = roundUp4(wn);
+        if ((int32_t)cells.size() > 32766 || (int32_t)pts.size() > 32766 || wc > 252 || wn > 252)
+            return "tile too large for the 15-bit local index tables";
         for (size_t i = 0; i < cells.size(); ++i) locC[cells[i]] = (int32_t)i;
         for (size_t i = 0; i < pts.size(); ++i) locN[pts[i]] = (int32_t)i;
         tcIds.insert(tcIds.end(), cells.begin(), cells.end());
         tcOff.push_back((int32_t)tcIds.size());
         tnIds.insert(tnIds.end(), pts.begin(), pts.end());
         tnOff.push_back((int32_t)tnIds.size());
+        pcBase.push_back((int32_t)pcEll.size()); pcWidth.push_back((uint8_t)wc);
+        ppBase.push_back((int32_t)ppEll.size()); ppWidth.push_back((uint8_t)wn);
+        const size_t cbase = pcEll.size(), nbase = ppEll.size();
+        pcEll.resize(cbase + (size_t)wc * threads, kEllPad);
+        ppEll.resize(nbase + (size_t)wn * threads, kEllPad);
+        pairEll.resize(nbase + (size_t)wn * threads, 0);
         for (int32_t p = pb; p < pend; ++p) {
+            const int32_t tl = p - pb;
             selfLoc[p] = (uint16_t)locN[p];
-            for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k) pcLoc[k] = (uint16_t)locC[pc.val[k]];
-            for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k) ppLoc[k] = (uint16_t)locN[t.pointPoints[k]];
-        }
-        maxCells = std::max(maxCells, (int32_t)cells.size());
-        maxPoints = std::max(maxPoints, (int32_t)pts.size());
-        maxTilePoints = std::max(maxTilePoints, pend - pb);
-    }
-
-    // pairShare: neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect
-    pairShare.assign(t.pointPoints.size(), 0);
-    if (t.maxPointPoints <= 16) {
-        for (int32_t p = 0; p < t.nPoints; ++p) {
+            for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
+                pcEll[cbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[pc.val[k]];
             const int32_t b = pe.off[p], v = pe.off[p + 1] - b;
-            for (int32_t i = 0; i < v; ++i) {
-                const int32_t qi = t.pointPoints[b + i];
-                for (int32_t j = i + 1; j < v; ++j) {
-                    const int32_t qj = t.pointPoints[b + j];
-                    int32_t a = pc.off[qi], ae = pc.off[qi + 1], c = pc.off[qj], ce = pc.off[qj + 1];
-                    bool share = false;
-                    while (a < ae && c < ce) {
-                        if (pc.val[a] == pc.val[c]) { share = true; break; }
-                        if (pc.val[a] < pc.val[c]) ++a; else ++c;
+            for (int32_t j = 0; j < v; ++j)
+                ppEll[nbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[t.pointPoints[b + j]];
+            if (pairs) {
+                // neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect
+                for (int32_t i = 0; i < v; ++i) {
+                    const int32_t qi = t.pointPoints[b + i];
+                    uint16_t mask = 0;
+                    for (int32_t j = 0; j < v; ++j) {
+                        if (j == i) continue;
+                        const int32_t qj = t.pointPoints[b + j];
+                        int32_t a = pc.off[qi], ae = pc.off[qi + 1], c = pc.off[qj], ce = pc.off[qj + 1];
+                        while (a < ae && c < ce) {
+                            if (pc.val[a] == pc.val[c]) { mask |= (uint16_t)(1u << j); break; }
+                            if (pc.val[a] < pc.val[c]) ++a; else ++c;
+                        }
                     }
-                    if (share) { pairShare[b + i] |= (uint16_t)(1u << j); pairShare[b + j] |= (uint16_t)(1u << i); }
+                    pairEll[nbase + ((size_t)(i / 4) * threads + tl) * 4 + (i % 4)] = mask;
                 }
             }
         }
+        maxCells = std::max(maxCells, (int32_t)cells.size());
+        maxPoints = std::max(maxPoints, (int32_t)pts.size());
+        if (pcEll.size() > 0x7fffffffu || ppEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
     }
     return "";
 }
