@@ -5,6 +5,8 @@ import sys
 
 for line in sys.stdin:
     line = line.strip()
+    if line.startswith("[smgpu]"):
+        print(line)
     if not line.startswith("{"):
         continue
     d = json.loads(line)

@@ -10,14 +10,14 @@ namespace smgpu {
 constexpr unsigned kPad = 0xFFFFu;
 
 struct GeomTileView {
-    const int* cellBeg; const int* tpOff; const int* tpIds; const int* tfOff; const int* tfIds;
+    const int* cellOrder; const int* cellBeg; const int* tpOff; const int* tpIds; const int* tfOff; const int* tfIds;
     const int* fvBase; const uint8_t* fvWidth; const uint16_t* faceVerts;
     const int* cfBase; const uint8_t* cfWidth; const uint16_t* cellFaces;
     int maxPoints, maxFaces;
 };
 
 struct SmoothTileView {
-    const int* ptBeg; const int* tcOff; const int* tcIds; const int* tnOff; const int* tnIds;
+    const int* ptOrder; const int* ptBeg; const int* tcOff; const int* tcIds; const int* tnOff; const int* tnIds;
     const uint16_t* selfLoc;
     const int* pcBase; const uint8_t* pcWidth; const uint16_t* pcEll;
     const int* ppBase; const uint8_t* ppWidth; const uint16_t* ppEll;   // bit 15: the neighbour is an internal point
@@ -124,8 +124,9 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
     __syncthreads();
 
     // phase 2: one thread per cell
-    const int c = g.cellBeg[tile] + tid;
-    if (c < g.cellBeg[tile + 1]) {
+    const int ci = g.cellBeg[tile] + tid;
+    if (ci < g.cellBeg[tile + 1]) {
+        const int c = g.cellOrder[ci];
         const int cw4 = g.cfWidth[tile] >> 2;
         const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
         V3 cEst = v3(0, 0, 0);
@@ -176,13 +177,14 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     }
     __syncthreads();
 
-    const int p = g.ptBeg[tile] + tid;
+    const int pi = g.ptBeg[tile] + tid;
     double dist = 0.0;
     int fcount = 0;
-    if (p < g.ptBeg[tile + 1]) {
+    if (pi < g.ptBeg[tile + 1]) {
+        const int p = g.ptOrder[pi];
         const uint8_t fl = m.pflags[p];
         const bool internal = fl & PF_INTERNAL;
-        const V3 cur = ldsv(nx, ny, nz, g.selfLoc[p]);
+        const V3 cur = ldsv(nx, ny, nz, g.selfLoc[pi]);
         const int wn4 = g.ppWidth[tile] >> 2;
         const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
         V3 sum = v3(0, 0, 0), r1, r2, r3;

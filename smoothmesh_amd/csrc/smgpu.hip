@@ -231,26 +231,21 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         if (h->smoothT != 64 && h->smoothT != 128 && h->smoothT != 256) return cleanup(fail("SMGPU_SMOOTH_T must be 64, 128 or 256"));
         // capacities sized for a 160 KiB LDS: a tile must leave room for >= 2 workgroups per CU
         const int geomCells = envInt("SMGPU_GEOM_CELLS", h->geomT / 2);   // cells per tile (<= threads)
-        const int capGP = std::min(6 * geomCells, 1400), capGF = std::min(6 * geomCells, 1400);
-        const std::string e1 = h->gt.build(t, h->geomT, geomCells, capGP, capGF);
-        const std::string e2 = h->stl.build(t, h->smoothT, std::min(8 * h->smoothT, 1500), std::min(8 * h->smoothT, 1500));
+        const int capGP = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells, 1400));
+        const int capGF = envInt("SMGPU_GEOM_CAPF", std::min(6 * geomCells, 1400));
+        const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(8 * h->smoothT, 1500));
+        const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(8 * h->smoothT, 1500));
+        const bool morton = envInt("SMGPU_TILE_MORTON", 1) != 0;
+        std::vector<uint8_t> internalMask((size_t)t.nPoints);
+        for (int p = 0; p < t.nPoints; ++p) internalMask[(size_t)p] = (flags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
+        const std::string e1 = h->gt.build(t, d->points, morton, h->geomT, geomCells, capGP, capGF);
+        const std::string e2 = h->stl.build(t, d->points, internalMask.data(), morton, h->smoothT, capSC, capSN);
         if (!e1.empty() || !e2.empty()) {
             h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
         } else {
-            {   // mark internal neighbours (SM.C:294) in the ELL copy of pointPoints
-                const SmoothTiles& st = h->stl;
-                for (int ti = 0; ti < st.nTiles; ++ti) {
-                    const int w = st.ppWidth[ti];
-                    for (int p = st.ptBeg[ti]; p < st.ptBeg[ti + 1]; ++p) {
-                        const int tl = p - st.ptBeg[ti], nb = t.pointEdges.off[p], v = t.pointEdges.off[p + 1] - nb;
-                        for (int j = 0; j < v && j < w; ++j)
-                            if (flags[t.pointPoints[nb + j]] & PF_INTERNAL)
-                                h->stl.ppEll[(size_t)st.ppBase[ti] + ((size_t)(j / 4) * st.threads + tl) * 4 + (j % 4)] |= 0x8000;
-                    }
-                }
-            }
             GeomTileView& g = h->gv;
             SmoothTileView& v = h->sv;
+            rc |= devUpload(h, &g.cellOrder, h->gt.order);
             rc |= devUpload(h, &g.cellBeg, h->gt.cellBeg);
             rc |= devUpload(h, &g.tpOff, h->gt.tpOff);
             rc |= devUpload(h, &g.tpIds, h->gt.tpIds);
@@ -263,6 +258,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &g.cfWidth, h->gt.cfWidth);
             rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
             g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
+            rc |= devUpload(h, &v.ptOrder, h->stl.order);
             rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
             rc |= devUpload(h, &v.tcOff, h->stl.tcOff);
             rc |= devUpload(h, &v.tcIds, h->stl.tcIds);

@@ -7,16 +7,68 @@ namespace smgpu {
 
 static inline int32_t roundUp4(int32_t v) { return (v + 3) & ~3; }
 
-std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCells, int32_t capPoints, int32_t capFaces) {
+static inline uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+
+// positions sorted along the Z-curve of the given coordinates (3 per element); ties keep id order
+static std::vector<int32_t> mortonOrder(int32_t n, const std::vector<double>& xyz) {
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int32_t i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], xyz[3 * (size_t)i + a]); hi[a] = std::max(hi[a], xyz[3 * (size_t)i + a]); }
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+    const double scale = ext > 0.0 ? 2097151.0 / ext : 0.0;   // one isotropic scale: bricks stay cubic in space
+    std::vector<std::pair<uint64_t, int32_t>> key((size_t)n);
+    for (int32_t i = 0; i < n; ++i) {
+        uint64_t k = 0;
+        for (int a = 0; a < 3; ++a) k |= spread21((uint64_t)((xyz[3 * (size_t)i + a] - lo[a]) * scale)) << a;
+        key[(size_t)i] = {k, i};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int32_t> order((size_t)n);
+    for (int32_t i = 0; i < n; ++i) order[(size_t)i] = key[(size_t)i].second;
+    return order;
+}
+
+static std::vector<int32_t> naturalOrder(int32_t n) {
+    std::vector<int32_t> o((size_t)n);
+    for (int32_t i = 0; i < n; ++i) o[(size_t)i] = i;
+    return o;
+}
+
+std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
+                             int32_t capPoints, int32_t capFaces) {
     threads = nThreads;
     if (capCells > threads) capCells = threads;
     const auto& cf = t.cellFacesGeom;
     const auto& fp = t.facePoints;
+    if (morton) {
+        std::vector<double> cc(3 * (size_t)t.nCells, 0.0);
+        for (int32_t c = 0; c < t.nCells; ++c) {
+            double s[3] = {0, 0, 0};
+            int32_t n = 0;
+            for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
+                const int32_t f = cf.val[k] & 0x7fffffff;
+                for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j, ++n)
+                    for (int a = 0; a < 3; ++a) s[a] += pts[3 * (size_t)fp.val[j] + a];
+            }
+            for (int a = 0; a < 3; ++a) cc[3 * (size_t)c + a] = n ? s[a] / n : 0.0;
+        }
+        order = mortonOrder(t.nCells, cc);
+    } else order = naturalOrder(t.nCells);
     std::vector<int32_t> stampP((size_t)t.nPoints, -1), stampF((size_t)t.nFaces, -1);
     // pass 1: greedy tile boundaries under the three capacities
     cellBeg.assign(1, 0);
     int32_t tile = 0, nP = 0, nF = 0, nC = 0;
-    for (int32_t c = 0; c < t.nCells; ++c) {
+    for (int32_t ci = 0; ci < t.nCells; ++ci) {
+        const int32_t c = order[(size_t)ci];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addF = 0, addP = 0;
             for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
@@ -26,7 +78,7 @@ std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCel
                     if (stampP[fp.val[j]] != tile) { stampP[fp.val[j]] = tile; ++addP; }
             }
             if (nC > 0 && (nC + 1 > capCells || nP + addP > capPoints || nF + addF > capFaces)) {
-                cellBeg.push_back(c);   // close the tile before this cell and re-add the cell to a fresh one
+                cellBeg.push_back(ci);  // close the tile before this cell and re-add the cell to a fresh one
                 ++tile; nP = nF = nC = 0;
                 continue;
             }
@@ -46,11 +98,15 @@ std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCel
     tpIds.clear(); tfIds.clear(); faceVerts.clear(); cellFaces.clear();
     fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear();
     std::vector<int32_t> faces, points;
+    std::vector<int32_t> cellTile((size_t)t.nCells, -1);   // which tile a cell belongs to
+    for (int32_t ti = 0; ti < nTiles; ++ti)
+        for (int32_t ci = cellBeg[ti]; ci < cellBeg[ti + 1]; ++ci) cellTile[(size_t)order[(size_t)ci]] = ti;
     for (int32_t ti = 0; ti < nTiles; ++ti) {
         faces.clear(); points.clear();
         const int32_t cb = cellBeg[ti], ce = cellBeg[ti + 1];
         int32_t cw = 0, fw = 0;
-        for (int32_t c = cb; c < ce; ++c) {
+        for (int32_t ci = cb; ci < ce; ++ci) {
+            const int32_t c = order[(size_t)ci];
             cw = std::max(cw, cf.off[c + 1] - cf.off[c]);
             for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
                 const int32_t f = cf.val[k] & 0x7fffffff;
@@ -74,7 +130,7 @@ std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCel
         fvBase.push_back((int32_t)faceVerts.size());
         fvWidth.push_back((uint8_t)fw);
         for (int32_t f : faces) {
-            const bool ownerHere = t.owner[f] >= cb && t.owner[f] < ce;
+            const bool ownerHere = cellTile[(size_t)t.owner[f]] == ti;
             tfIds.push_back(ownerHere ? (int32_t)(0x80000000u | (uint32_t)f) : f);
             const int32_t n = fp.off[f + 1] - fp.off[f];
             for (int32_t j = 0; j < fw; ++j) faceVerts.push_back(j < n ? (uint16_t)locP[fp.val[fp.off[f] + j]] : kEllPad);
@@ -84,8 +140,9 @@ std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCel
         cfWidth.push_back((uint8_t)cw);
         const size_t base = cellFaces.size();
         cellFaces.resize(base + (size_t)cw * threads, kEllPad);
-        for (int32_t c = cb; c < ce; ++c) {
-            const int32_t tl = c - cb;
+        for (int32_t ci = cb; ci < ce; ++ci) {
+            const int32_t c = order[(size_t)ci];
+            const int32_t tl = ci - cb;
             for (int32_t k = cf.off[c], j = 0; k < cf.off[c + 1]; ++k, ++j) {
                 const int32_t v = cf.val[k];
                 cellFaces[base + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)(locF[v & 0x7fffffff] | (v < 0 ? 0x8000 : 0));
@@ -98,15 +155,19 @@ std::string GeomTiles::build(const Topology& t, int32_t nThreads, int32_t capCel
     return "";
 }
 
-std::string SmoothTiles::build(const Topology& t, int32_t nThreads, int32_t capCells, int32_t capPoints) {
+std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
+                               int32_t capCells, int32_t capPoints) {
     threads = nThreads;
+    if (morton) order = mortonOrder(t.nPoints, std::vector<double>(xyz, xyz + 3 * (size_t)t.nPoints));
+    else order = naturalOrder(t.nPoints);
     const int32_t capTile = threads;
     const auto& pc = t.pointCells;
     const auto& pe = t.pointEdges;   // offsets shared with pointPoints
     std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
     ptBeg.assign(1, 0);
     int32_t tile = 0, nC = 0, nN = 0, nT = 0;
-    for (int32_t p = 0; p < t.nPoints; ++p) {
+    for (int32_t pi = 0; pi < t.nPoints; ++pi) {
+        const int32_t p = order[(size_t)pi];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addC = 0, addN = 0;
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
@@ -115,7 +176,7 @@ std::string SmoothTiles::build(const Topology& t, int32_t nThreads, int32_t capC
             for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k)
                 if (stampN[t.pointPoints[k]] != tile) { stampN[t.pointPoints[k]] = tile; ++addN; }
             if (nT > 0 && (nT + 1 > capTile || nC + addC > capCells || nN + addN > capPoints)) {
-                ptBeg.push_back(p);
+                ptBeg.push_back(pi);
                 ++tile; nC = nN = nT = 0;
                 continue;
             }
@@ -140,7 +201,8 @@ std::string SmoothTiles::build(const Topology& t, int32_t nThreads, int32_t capC
         cells.clear(); pts.clear();
         const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
         int32_t wc = 0, wn = 0;
-        for (int32_t p = pb; p < pend; ++p) {
+        for (int32_t pi = pb; pi < pend; ++pi) {
+            const int32_t p = order[(size_t)pi];
             wc = std::max(wc, pc.off[p + 1] - pc.off[p]);
             wn = std::max(wn, pe.off[p + 1] - pe.off[p]);
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
@@ -166,14 +228,17 @@ std::string SmoothTiles::build(const Topology& t, int32_t nThreads, int32_t capC
         pcEll.resize(cbase + (size_t)wc * threads, kEllPad);
         ppEll.resize(nbase + (size_t)wn * threads, kEllPad);
         pairEll.resize(nbase + (size_t)wn * threads, 0);
-        for (int32_t p = pb; p < pend; ++p) {
-            const int32_t tl = p - pb;
-            selfLoc[p] = (uint16_t)locN[p];
+        for (int32_t pi = pb; pi < pend; ++pi) {
+            const int32_t p = order[(size_t)pi];
+            const int32_t tl = pi - pb;
+            selfLoc[(size_t)pi] = (uint16_t)locN[p];
             for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
                 pcEll[cbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[pc.val[k]];
             const int32_t b = pe.off[p], v = pe.off[p + 1] - b;
-            for (int32_t j = 0; j < v; ++j)
-                ppEll[nbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[t.pointPoints[b + j]];
+            for (int32_t j = 0; j < v; ++j) {
+                const int32_t q = t.pointPoints[b + j];
+                ppEll[nbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)(locN[q] | (isInternal[q] ? 0x8000 : 0));
+            }
             if (pairs) {
                 // neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect
                 for (int32_t i = 0; i < v; ++i) {

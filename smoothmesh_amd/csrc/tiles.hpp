@@ -40,7 +40,12 @@ struct GeomTiles {
     std::vector<uint8_t> cfWidth;   // nTiles
     std::vector<uint16_t> cellFaces;
     int32_t maxPoints = 0, maxFaces = 0;
-    std::string build(const Topology& t, int32_t threads, int32_t capCells, int32_t capPoints, int32_t capFaces);
+    // tile order: position -> cell id.  Natural order, or a Morton (Z-curve) order of the cell centres so
+    // that a run of consecutive positions is a compact 3-D brick (fewer faces / points shared with other
+    // tiles => less duplicated face work, smaller LDS footprint).  Results do not depend on it.
+    std::vector<int32_t> order;
+    std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
+                      int32_t capPoints, int32_t capFaces);
 };
 
 // ---- smoothing: tile = consecutive points; LDS holds the cell centres and neighbour points -------
@@ -51,7 +56,7 @@ struct SmoothTiles {
     std::vector<int32_t> tcIds;     // unique cell ids per tile, ascending
     std::vector<int32_t> tnOff;     // nTiles+1 -> tnIds
     std::vector<int32_t> tnIds;     // unique point ids (the tile's points and their neighbours), ascending
-    std::vector<uint16_t> selfLoc;  // per point: its own LDS-local point index
+    std::vector<uint16_t> selfLoc;  // per tile position: the point's own LDS-local point index
     // sliced ELL (layout as GeomTiles::cellFaces)
     std::vector<int32_t> pcBase;    // nTiles
     std::vector<uint8_t> pcWidth;
@@ -63,7 +68,10 @@ struct SmoothTiles {
     // membership, SM.C:383); valid while valence <= 16, else the kernel intersects pointCells lists
     std::vector<uint16_t> pairEll;
     int32_t maxCells = 0, maxPoints = 0;
-    std::string build(const Topology& t, int32_t threads, int32_t capCells, int32_t capPoints);
+    std::vector<int32_t> order;     // tile order: position -> point id (see GeomTiles::order)
+    // isInternal (SM.C:40-91) marks bit 15 of the ppEll entries whose neighbour is an internal point (SM.C:294)
+    std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
+                      int32_t capCells, int32_t capPoints);
 };
 
 }  // namespace smgpu
