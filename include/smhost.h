@@ -45,6 +45,10 @@ int smhost_read_label_list(const char* file, int32_t* out, int64_t* n);
 int smhost_write_label_list(const char* file, const char* location, const char* object, const char* cls,
                             int64_t n, const int32_t* values, int32_t binary);
 
+/* Synthetic polyhedral mesh (stands in for snappyHexMesh, BASELINE configs[3-4]): castellated one-level
+ * octree mesh of the unit cube with a spherical cavity; see csrc/host/meshgen.cpp. */
+int smhost_gen_cavity_mesh(int32_t N, double radius, double shell, double jitter, uint64_t seed, smhost_mesh** out);
+
 #ifdef __cplusplus
 }
 #endif

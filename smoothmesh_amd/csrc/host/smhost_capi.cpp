@@ -7,6 +7,7 @@
 #include "polymesh_io.hpp"
 
 using namespace smhost;
+namespace smhost { void genCavityMesh(int N, double radius, double shell, double jitter, uint64_t seed, PolyMeshData& out); }
 
 static thread_local std::string g_err;
 struct smhost_mesh { PolyMeshData d; };
@@ -91,5 +92,13 @@ int smhost_read_label_list(const char* file, int32_t* out, int64_t* n) {
 int smhost_write_label_list(const char* file, const char* location, const char* object, const char* cls, int64_t n,
                             const int32_t* values, int32_t binary) {
     return guarded([&] { writeLabelList(file, location, object, cls, n, values, binary != 0); });
+}
+int smhost_gen_cavity_mesh(int32_t N, double radius, double shell, double jitter, uint64_t seed, smhost_mesh** out) {
+    return guarded([&] {
+        auto* m = new smhost_mesh();
+        try { genCavityMesh(N, radius, shell, jitter, seed, m->d); }
+        catch (...) { delete m; throw; }
+        *out = m;
+    });
 }
 }

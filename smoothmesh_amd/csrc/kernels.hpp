@@ -28,6 +28,8 @@ struct MeshView {
     const int* pcOff; const int* pcVal;          // pointCells
     const int* ppOff; const int* ppPt; const int* peEdge;  // pointPoints / pointEdges (shared offsets)
     const int* pfOff; const int* pfPrev; const int* pfNext;  // pointFaces entries -> prev/next vertex
+    const uint8_t* pfPrevSlot; const uint8_t* pfNextSlot;    // ... as slots of the point's pointPoints row
+    const int* ringFace; const int* ringCell; const uint8_t* edgeRingOk;  // ring order around each edge
     const int* edges;                             // 2 per edge
     const int* efOff; const int* efFace;          // edgeFaces
     const int* ecOff; const int* ecCell; const uint8_t* ecF0; const uint8_t* ecF1;  // edgeCells + face pair
@@ -350,6 +352,97 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle(MeshView m, State s, Prm 
     if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
 }
 
+// restrictMinEdgeAngleDecrease SM.C:900-930, wave-cooperative form: 8 lanes per point.
+//  * every incident edge (p, q) appears in several of p's faces (4 in a hex mesh), so the three unit
+//    vectors per neighbour q -- (x_q - x_p)/|.|, (x_q - n_p)/|.|, (n_q - n_p)/|.| -- are formed ONCE per
+//    neighbour (lane j takes neighbour j) and shared through LDS instead of once per (face, corner);
+//  * the lanes then take the point's faces (5 dot products each) and keep the LARGEST clamped cosine;
+//    acos is evaluated only on the two extremes: min_i acos(c_i) = acos(max_i c_i) because acos is
+//    monotone (SM.C:880-886 take minima of angles; same operations on the same operands otherwise).
+constexpr int kEaLanes = 8;
+constexpr int kEaPointsPerBlock = kBlock / kEaLanes;
+
+__device__ __forceinline__ double clampCos(double cosA) {
+    const double MAXC = 0.99999;   // SM.C:781-782, std::min/std::max comparison forms (NaN -> +MAX)
+    const double t = (cosA < MAXC) ? cosA : MAXC;
+    return (-MAXC < t) ? t : -MAXC;
+}
+
+__global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s, Prm prm, int maxEntries) {
+    if (s.acc->stop) return;
+    extern __shared__ double lds[];
+    double* U = lds;   // 9 arrays of maxEntries: ucc.xyz, uc.xyz, un.xyz
+    const int tid = threadIdx.x, g = tid & (kEaLanes - 1);
+    const int pBase = blockIdx.x * kEaPointsPerBlock;
+    const int p = pBase + (tid / kEaLanes);
+    const bool valid = p < m.nPoints;
+    const bool active = valid && !s.frozen[p];
+    const int e0 = m.ppOff[pBase];
+    int nb = 0, nv = 0;
+    V3 cp0 = v3(0, 0, 0), np0 = v3(0, 0, 0);
+    if (active) {
+        nb = m.ppOff[p]; nv = m.ppOff[p + 1] - nb;
+        cp0 = ldv(s.ptsCur, p); np0 = ldv(s.prop, p);
+        for (int j = g; j < nv; j += kEaLanes) {
+            const int q = m.ppPt[nb + j];
+            const V3 cq = ldv(s.ptsCur, q), nq = ldv(s.prop, q);
+            const V3 a = unitTo(cp0, cq), b = unitTo(np0, cq), c = unitTo(np0, nq);
+            const int i = nb + j - e0;
+            U[i] = a.x; U[maxEntries + i] = a.y; U[2 * maxEntries + i] = a.z;
+            U[3 * maxEntries + i] = b.x; U[4 * maxEntries + i] = b.y; U[5 * maxEntries + i] = b.z;
+            U[6 * maxEntries + i] = c.x; U[7 * maxEntries + i] = c.y; U[8 * maxEntries + i] = c.z;
+        }
+    }
+    __syncthreads();
+    double maxC = -2.0, maxN = -2.0;
+    int nf = 0;
+    if (active) {
+        const int fb = m.pfOff[p];
+        nf = m.pfOff[p + 1] - fb;
+        for (int k = g; k < nf; k += kEaLanes) {
+            const int sa = m.pfPrevSlot[fb + k], sb = m.pfNextSlot[fb + k];
+            V3 cca, ccb, ca, cb, na, nbv;
+            if (sa != 255 && sb != 255) {
+                const int ia = nb + sa - e0, ib = nb + sb - e0;
+                cca = v3(U[ia], U[maxEntries + ia], U[2 * maxEntries + ia]);
+                ca = v3(U[3 * maxEntries + ia], U[4 * maxEntries + ia], U[5 * maxEntries + ia]);
+                na = v3(U[6 * maxEntries + ia], U[7 * maxEntries + ia], U[8 * maxEntries + ia]);
+                ccb = v3(U[ib], U[maxEntries + ib], U[2 * maxEntries + ib]);
+                cb = v3(U[3 * maxEntries + ib], U[4 * maxEntries + ib], U[5 * maxEntries + ib]);
+                nbv = v3(U[6 * maxEntries + ib], U[7 * maxEntries + ib], U[8 * maxEntries + ib]);
+            } else {   // neighbour not in the slot table (valence > 254): form the vectors directly
+                const int a1 = m.pfPrev[fb + k], a2 = m.pfNext[fb + k];
+                const V3 cp1 = ldv(s.ptsCur, a1), cp2 = ldv(s.ptsCur, a2), np1 = ldv(s.prop, a1), np2 = ldv(s.prop, a2);
+                cca = unitTo(cp0, cp1); ccb = unitTo(cp0, cp2);
+                ca = unitTo(np0, cp1); cb = unitTo(np0, cp2);
+                na = unitTo(np0, np1); nbv = unitTo(np0, np2);
+            }
+            const double cC = clampCos(dot(cca, ccb));
+            const double c0 = clampCos(dot(ca, cb));      // nAngle0: (n0; x1, x2)
+            const double c1 = clampCos(dot(na, nbv));     // nAngle1: (n0; n1, n2)
+            const double c2 = clampCos(dot(ca, nbv));     // nAngle2: (n0; x1, n2)
+            const double c3 = clampCos(dot(na, cb));      // nAngle3: (n0; n1, x2)
+            double cN = (c0 > c1) ? c0 : c1;
+            cN = (cN > c2) ? cN : c2;
+            cN = (cN > c3) ? cN : c3;
+            if (cC > maxC) maxC = cC;
+            if (cN > maxN) maxN = cN;
+        }
+    }
+    for (int o = kEaLanes / 2; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(maxC, o, 64), on = __shfl_xor(maxN, o, 64);
+        maxC = (oc > maxC) ? oc : maxC;
+        maxN = (on > maxN) ? on : maxN;
+    }
+    // one acos evaluation per wave serves both extremes: lane 0 of each group takes maxC, lane 1 maxN
+    const double ang = acos((g == 0) ? maxC : maxN);
+    const double minN = __shfl_down(ang, 1, 64);   // lane 0 of the group reads lane 1's value
+    if (active && g == 0 && nf > 0) {
+        const double minC = ang;
+        if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // calcMinMaxFaceAngleForEdge SM.C:1135-1231 for one edge, with optional substitution of the
 // coordinates of two points (i1 -> c1, i2 -> c2; i = -1 disables).  SUBST = false is the
@@ -408,14 +501,45 @@ __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s
     }
 }
 
-// calcCurrentMinMaxFaceAnglesForEdges SM.C:1252-1270 -- one thread per edge.
+// calcCurrentMinMaxFaceAnglesForEdges SM.C:1252-1270 -- one thread per edge.  Faces and cells are
+// visited in ring order around the edge (Topology::ringFace): cell i sits between ring faces i and i+1,
+// so each projected face-centre vector is formed once and handed on (the reference forms them per
+// edge face too, SM.C:1183-1200; min/max over the cells do not depend on the visiting order).
 __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s) {
     if (s.acc->stop) return;
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= m.nEdges) return;
     double mn, mx;
-    const V3 z = v3(0, 0, 0);
-    edgeFaceAngles<false>(m, s, e, -1, z, -1, z, mn, mx);
+    if (!m.edgeRingOk[e]) {
+        const V3 z = v3(0, 0, 0);
+        edgeFaceAngles<false>(m, s, e, -1, z, -1, z, mn, mx);
+    } else {
+        const V3 e0 = ldv(s.ptsCur, m.edges[2 * e]), e1 = ldv(s.ptsCur, m.edges[2 * e + 1]);
+        const V3 cC = 0.5 * (e0 + e1);
+        const V3 d = e1 - e0;
+        const V3 eVec = d / mag(d);
+        auto project = [&](const V3& c) -> V3 {   // SM.C:1189-1196 / 1219-1223
+            const V3 cf = cC - c;
+            const double dp = dot(cf, eVec);
+            const V3 pC = c + dp * eVec;
+            const V3 w = pC - cC;
+            return w / mag(w);
+        };
+        const int fb = m.efOff[e], nf = m.efOff[e + 1] - fb;
+        const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
+        const V3 first = project(ldv(s.fAvg, m.ringFace[fb]));
+        V3 prev = first;
+        mn = 2.0 * SMGPU_PI;
+        mx = 0.0;
+        for (int i = 0; i < nc; ++i) {
+            const V3 next = (i + 1 < nf) ? project(ldv(s.fAvg, m.ringFace[fb + i + 1])) : first;
+            const V3 cV = project(ldv(s.cellCtr, m.ringCell[cb + i]));   // mesh.C()[cellI], SM.C:1218
+            const double angle = clampAcos(dot(prev, cV)) + clampAcos(dot(cV, next));   // SM.C:980-998
+            if (angle < mn) mn = angle;
+            if (angle > mx) mx = angle;
+            prev = next;
+        }
+    }
     s.edgeMin[e] = mn;
     s.edgeMax[e] = mx;
 }

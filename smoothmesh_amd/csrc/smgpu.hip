@@ -73,6 +73,8 @@ struct smgpu_handle {
     SmoothTileView sv{};
     size_t geomLds = 0, smoothLds = 0;
     bool writeFaces = false;   // debug: publish per-face centres/areas from the tiled geometry kernel
+    bool eaCoop = true;        // wave-cooperative edge-angle kernel (SMGPU_EDGE_ANGLE=faithful selects the per-angle acos form)
+    int eaMaxEntries = 0;
 };
 
 static int envInt(const char* name, int def) {
@@ -213,6 +215,11 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devUpload(h, &m.pfOff, t.pointFaces.off);
     rc |= devUpload(h, &m.pfPrev, t.pfPrev);
     rc |= devUpload(h, &m.pfNext, t.pfNext);
+    rc |= devUpload(h, &m.pfPrevSlot, t.pfPrevSlot);
+    rc |= devUpload(h, &m.pfNextSlot, t.pfNextSlot);
+    rc |= devUpload(h, &m.ringFace, t.ringFace);
+    rc |= devUpload(h, &m.ringCell, t.ringCell);
+    rc |= devUpload(h, &m.edgeRingOk, t.edgeRingOk);
     rc |= devUpload(h, &m.edges, t.edges);
     rc |= devUpload(h, &m.efOff, t.edgeFaces.off);
     rc |= devUpload(h, &m.efFace, t.edgeFaces.val);
@@ -282,6 +289,15 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                              h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, h->smoothT, h->stl.nTiles, h->smoothLds,
                              v.maxCells, v.maxPoints);
         }
+    }
+    {
+        const char* ea = std::getenv("SMGPU_EDGE_ANGLE");
+        h->eaCoop = !(ea && std::string(ea) == "faithful");
+        for (int p0 = 0; p0 < t.nPoints; p0 += kEaPointsPerBlock) {
+            const int p1 = std::min(t.nPoints, p0 + kEaPointsPerBlock);
+            h->eaMaxEntries = std::max(h->eaMaxEntries, t.pointEdges.off[p1] - t.pointEdges.off[p0]);
+        }
+        if (sizeof(double) * 9 * (size_t)h->eaMaxEntries > 60 * 1024) h->eaCoop = false;   // extreme valences: per-point form
     }
     State& s = h->st;
     const size_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
@@ -426,8 +442,14 @@ static int runProposalAndConstraints(smgpu_handle* h) {
     const Prm prm = makePrm(h->prm);
     const int gP = gridFor(m.nPoints);
     if (runSmooth<false>(h, m, s, prm)) return 1;
-    if (h->prm.edgeAngleConstraint)
-        if (launchK(h, K_EDGE_ANGLE, [&] { hipLaunchKernelGGL(k_edge_angle, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    if (h->prm.edgeAngleConstraint) {
+        if (h->eaCoop) {
+            if (launchK(h, K_EDGE_ANGLE, [&] {
+                    hipLaunchKernelGGL(k_edge_angle_coop, dim3((m.nPoints + kEaPointsPerBlock - 1) / kEaPointsPerBlock), dim3(kBlock),
+                                       sizeof(double) * 9 * (size_t)h->eaMaxEntries, h->stream, m, s, prm, h->eaMaxEntries);
+                })) return 1;
+        } else if (launchK(h, K_EDGE_ANGLE, [&] { hipLaunchKernelGGL(k_edge_angle, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    }
     if (h->prm.faceAngleConstraint) {
         if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
         if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;

@@ -152,6 +152,17 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         }
     }
     for (int32_t p = 0; p < nP; ++p) maxPointPoints = std::max(maxPointPoints, pointEdges.off[p + 1] - pointEdges.off[p]);
+    // prev/next vertex of every pointFaces entry as a slot of the point's pointPoints row
+    pfPrevSlot.assign(pfPrev.size(), 255);
+    pfNextSlot.assign(pfNext.size(), 255);
+    for (int32_t p = 0; p < nP; ++p) {
+        const int32_t nb = pointEdges.off[p], nv = pointEdges.off[p + 1] - nb;
+        for (int32_t k = pointFaces.off[p]; k < pointFaces.off[p + 1]; ++k)
+            for (int32_t j = 0; j < nv && j < 255; ++j) {
+                if (pointPoints[nb + j] == pfPrev[k]) pfPrevSlot[k] = (uint8_t)j;
+                if (pointPoints[nb + j] == pfNext[k]) pfNextSlot[k] = (uint8_t)j;
+            }
+    }
 
     // ---- edgeFaces (ascending face id) ------------------------------------------------------------
     edgeFaces.off.assign(nEdges + 1, 0);
@@ -206,6 +217,47 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
                 ecFace1.push_back((uint8_t)f1);
             }
             edgeCells.off[e + 1] = (int32_t)edgeCells.val.size();
+        }
+    }
+
+    // ---- ring order around each edge -------------------------------------------------------------
+    ringFace.assign(edgeFaces.val.size(), -1);
+    ringCell.assign(edgeCells.val.size(), -1);
+    edgeRingOk.assign((size_t)nEdges, 0);
+    {
+        std::vector<int32_t> deg, usedC;
+        for (int32_t e = 0; e < nEdges; ++e) {
+            const int32_t fb = edgeFaces.off[e], nf = edgeFaces.off[e + 1] - fb;
+            const int32_t cb = edgeCells.off[e], nc = edgeCells.off[e + 1] - cb;
+            // a chain has nc = nf - 1 cells, a closed ring nc = nf
+            if (nc < 1 || (nc != nf && nc != nf - 1)) continue;
+            deg.assign((size_t)nf, 0);
+            for (int32_t i = 0; i < nc; ++i) { deg[ecFace0[cb + i]]++; deg[ecFace1[cb + i]]++; }
+            bool ok = true;
+            int32_t start = 0, nEnds = 0;
+            for (int32_t i = 0; i < nf; ++i) {
+                if (deg[i] == 1) { if (nEnds == 0) start = i; ++nEnds; }
+                else if (deg[i] != 2) ok = false;
+            }
+            if (!ok || (nc == nf && nEnds != 0) || (nc == nf - 1 && nEnds != 2)) continue;
+            usedC.assign((size_t)nc, 0);
+            int32_t cur = start, placed = 0;
+            ringFace[fb] = edgeFaces.val[fb + cur];
+            while (placed < nc) {
+                int32_t next = -1, ci = -1;
+                for (int32_t i = 0; i < nc; ++i) {
+                    if (usedC[i]) continue;
+                    if (ecFace0[cb + i] == cur) { next = ecFace1[cb + i]; ci = i; break; }
+                    if (ecFace1[cb + i] == cur) { next = ecFace0[cb + i]; ci = i; break; }
+                }
+                if (ci < 0) break;
+                usedC[ci] = 1;
+                ringCell[cb + placed] = edgeCells.val[cb + ci];
+                ++placed;
+                if (placed < nf) ringFace[fb + placed] = edgeFaces.val[fb + next];
+                cur = next;
+            }
+            if (placed == nc && (nc == nf - 1 || cur == start)) edgeRingOk[(size_t)e] = 1;
         }
     }
     return "";

@@ -35,6 +35,8 @@ struct Topology {
     Csr pointFaces;            // val = face id
     std::vector<int32_t> pfPrev, pfNext;  // per pointFaces entry: previous / next vertex of the
                                           // point in that face (getNeighbourPoints SM.C:793-831)
+    std::vector<uint8_t> pfPrevSlot, pfNextSlot;  // the same two vertices as positions in the point's
+                                                  // pointPoints row (255 = not representable)
     std::vector<int32_t> edges;           // 2*nEdges (start < end)
     Csr pointEdges;            // val = edge id
     std::vector<int32_t> pointPoints;     // same offsets as pointEdges
@@ -43,6 +45,13 @@ struct Topology {
     std::vector<uint8_t> ecFace0, ecFace1;  // per edgeCells entry: the two edge faces (indices into the
                                             // edge's edgeFaces row) that belong to the cell
                                             // (findCellFacePair SM.C:1042-1097)
+    // Ring order of the faces / cells around each edge (same offsets as edgeFaces / edgeCells): cell i
+    // of the ring lies between ring faces i and i+1 (the last cell of a closed ring between the last and
+    // the first face).  Only min/max over the cells consume the order (SM.C:1003-1037), so any order is
+    // valid; the ring lets every face vector be formed once.  edgeRingOk[e] = 0 for edges whose cells do
+    // not form one chain (non-manifold): kernels use the generic pair form there.
+    std::vector<int32_t> ringFace, ringCell;
+    std::vector<uint8_t> edgeRingOk;
     // cell -> faces in the accumulation order of OpenFOAM makeCellCentresAndVols: faces owned
     // (ascending), then faces neighboured (ascending); bit 31 set = cell is the face's neighbour
     Csr cellFacesGeom;

@@ -32,6 +32,7 @@ def lib():
         l.smhost_write_points.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, f64p, C.c_int32, C.c_int32]
         l.smhost_read_label_list.argtypes = [C.c_char_p, i32p, C.POINTER(C.c_int64)]
         l.smhost_write_label_list.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, i32p, C.c_int32]
+        l.smhost_gen_cavity_mesh.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_void_p)]
         _lib = l
     return _lib
 
@@ -45,10 +46,8 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def read_polymesh(polyMeshDir, pointsDir=None) -> PolyMesh:
+def _take(h) -> PolyMesh:
     l = lib()
-    h = C.c_void_p()
-    _check(l.smhost_read_polymesh(polyMeshDir.encode(), pointsDir.encode() if pointsDir else None, C.byref(h)))
     try:
         n = [C.c_int32() for _ in range(5)]
         nnz = C.c_int64()
@@ -67,6 +66,23 @@ def read_polymesh(polyMeshDir, pointsDir=None) -> PolyMesh:
         return PolyMesh(pts, fo, fp, ow, ne, patches, nC)
     finally:
         l.smhost_mesh_free(h)
+
+
+def read_polymesh(polyMeshDir, pointsDir=None) -> PolyMesh:
+    h = C.c_void_p()
+    _check(lib().smhost_read_polymesh(polyMeshDir.encode(), pointsDir.encode() if pointsDir else None, C.byref(h)))
+    return _take(h)
+
+
+def cavity_mesh(N, radius=0.25, shell=None, jitter=0.2, seed=12345) -> PolyMesh:
+    """Castellated one-level octree mesh of the unit cube with a spherical cavity (polyhedral cells at the
+    refinement interface) -- stands in for snappyHexMesh, see csrc/host/meshgen.cpp.  shell = half-width of
+    the refined band around the sphere surface (default 2 coarse cells)."""
+    if shell is None:
+        shell = 2.0 / N
+    h = C.c_void_p()
+    _check(lib().smhost_gen_cavity_mesh(N, radius, shell, jitter, seed, C.byref(h)))
+    return _take(h)
 
 
 def write_polymesh(polyMeshDir, mesh: PolyMesh, location="constant/polyMesh", binary=False, precision=17):

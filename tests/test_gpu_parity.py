@@ -169,3 +169,52 @@ def test_golden_fixture_hip():
         assert rel_linf(e.get_points(), g["points" + tag]) <= COORD_TOL
     assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
     assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("jit,minAngle", [(0.3, 35.0), (0.45, 60.0), (0.48, 75.0)])
+def test_edge_angle_forms_agree(oracle_lib, monkeypatch, jit, minAngle):
+    """The wave-cooperative edge-angle kernel (acos of the extreme cosine) must freeze exactly the points the
+    per-angle form (5 acos per corner, SM.C:862-880) and the oracle freeze."""
+    from smoothmesh_amd import SmoothEngine, default_params
+    mesh = _mk(9, 8, 7, jit, 17)
+    o = oracle_lib.Oracle(mesh)
+    p = default_params(o.mesh_stats()[0], minAngle=minAngle, faceAngleConstraint=False)
+    o.set_params(p)
+    o.phaseA(); o.phaseB()
+    ref = o.field("frozenAfterEdgeAngle")
+    assert ref.sum() > o.field("frozenAfterEdgeLen").sum() or minAngle < 40     # the evaluator froze something
+    masks = []
+    for mode in ("coop", "faithful"):
+        monkeypatch.setenv("SMGPU_EDGE_ANGLE", mode)
+        e = SmoothEngine(mesh)
+        e.set_params(p)
+        e.debug_propose()
+        masks.append(e.debug_field("isFrozenPoint"))
+        e.close()
+    assert np.array_equal(masks[0], masks[1])
+    assert np.array_equal(masks[0], ref)
+
+
+@pytest.mark.parametrize("constraints", [False, True])
+def test_polyhedral_cavity_mesh(oracle_lib, constraints):
+    """Castellated octree mesh (polyhedral cells with split faces and hanging edge nodes, valence 3..6,
+    coplanar face pairs => face angles of 180 degrees => the ordered freeze walk is busy every iteration)."""
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.polymesh import cavity_mesh
+    mesh = cavity_mesh(12, jitter=0.2, seed=3)
+    assert np.bincount(np.diff(mesh.faceOffsets))[5:].sum() > 0          # genuinely polygonal faces
+    o = oracle_lib.Oracle(mesh)
+    e = SmoothEngine(mesh)
+    p = default_params(o.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    o.set_params(p); e.set_params(p)
+    if constraints:
+        o.phaseA(); o.phaseB()
+        e.debug_propose()
+        assert o.field("frozenAfterFaceAngle").sum() > o.field("frozenAfterEdgeAngle").sum()
+        assert np.array_equal(e.debug_field("isFrozenPoint"), o.field("frozenAfterFaceAngle"))
+        for name in ("edgeMinAngle", "edgeMaxAngle", "pointMinAngle", "pointMaxAngle"):
+            assert np.max(np.abs(e.debug_field(name) - o.field(name))) <= ANGLE_TOL, name
+    n_o, res_o, frz_o = o.iterate(12, 0.0)
+    n_g, res_g, frz_g = e.iterate(12, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
