@@ -25,25 +25,35 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 
 
 def parse_workload(w):
+    """hexN[c] = N^3 hex block; cavityN[c] = castellated polyhedral cube-with-sphere-cavity on an N^3 base grid;
+    trailing c = edgeAngle + faceAngle constraints on."""
     constraints = w.endswith("c")
     base = w[:-1] if constraints else w
-    if not base.startswith("hex"):
-        raise SystemExit(f"unknown workload {w}")
-    n = int(base[3:])
-    return n, constraints
+    for kind in ("hex", "cavity"):
+        if base.startswith(kind):
+            return kind, int(base[len(kind):]), constraints
+    raise SystemExit(f"unknown workload {w}")
+
+
+def make_mesh(kind, n):
+    if kind == "hex":
+        from smoothmesh_amd.meshgen import hex_block
+        return hex_block(n, jitter=0.2, seed=12345)
+    from smoothmesh_amd.polymesh import cavity_mesh
+    return cavity_mesh(n, jitter=0.2, seed=12345)
 
 
 def proc_grid(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(n_cells_side, constraints, budget_s=12.0):
+def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0):
     """Serial oracle (CPU restatement of the reference loop) on the SAME mesh for a bounded number of
     iterations.  kind = "port": the reference itself needs OpenFOAM and cannot be built here."""
     from oracle import oracle_ffi
     from smoothmesh_amd import default_params
-    from smoothmesh_amd.meshgen import hex_block
-    mesh = hex_block(n_cells_side, jitter=0.2, seed=12345)
+    sample_n = n_cells_side if kind == "hex" else min(n_cells_side, 100)   # bounded sample of the same family
+    mesh = make_mesh(kind, sample_n)
     o = oracle_ffi.Oracle(mesh)
     p = default_params(o.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     o.set_params(p)
@@ -56,7 +66,7 @@ def cpu_baseline(n_cells_side, constraints, budget_s=12.0):
     dt = time.perf_counter() - t0
     return {
         "value": mesh.nPoints * iters / dt, "unit": "points/s", "cores": 1, "kind": "port",
-        "sample": f"{iters} iterations of the same {n_cells_side}^3 mesh ({mesh.nPoints} points), serial oracle "
+        "sample": f"{iters} iterations of the {kind}{sample_n} mesh ({mesh.nPoints} points, {mesh.nCells} cells), serial oracle "
                   f"(g++ -O2 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
                   f"so it is faster than the real reference",
         "host_cpus": os.cpu_count(),
@@ -77,7 +87,7 @@ def main():
     from smoothmesh_amd import SmoothEngine, default_params
     from smoothmesh_amd.meshgen import hex_block
 
-    n_side, constraints = parse_workload(args.workload)
+    kind, n_side, constraints = parse_workload(args.workload)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -93,7 +103,7 @@ def main():
     K, W = args.steps, args.warmup
 
     if world == 1:
-        mesh = hex_block(n_side, jitter=0.2, seed=12345)
+        mesh = make_mesh(kind, n_side)
         eng = SmoothEngine(mesh, device=local_rank)
         prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         eng.set_params(prm)
@@ -125,6 +135,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        if kind != "hex":
+            raise SystemExit("multi-GPU bench uses the hexN workloads (sub-domains are generated per rank)")
         grid = proc_grid(world)
         sub = hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345)
         ds = DistributedSmoother(sub, device=local_rank)
@@ -186,9 +198,12 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"{n_side}^3-cell uniform hex block per GPU (blockMesh numbering), interior jitter 0.2h seed 12345, "
+            "workload": (f"{n_side}^3-cell uniform hex block per GPU (blockMesh numbering)" if kind == "hex" else
+                         f"castellated polyhedral cube-with-sphere-cavity, {n_side}^3 base grid + one 2:1 refinement shell "
+                         f"(own generator standing in for snappyHexMesh)") +
+                        f", interior jitter 0.2h seed 12345, "
                         f"{'edgeAngle+faceAngle constraints on (minAngle 35 / maxAngle 160)' if constraints else 'constraints off'}, "
-                        f"relTol 0, defaults otherwise (BASELINE.json configs[{2 if constraints else 1}])",
+                        f"relTol 0, defaults otherwise (BASELINE.json configs[{(2 if constraints else 1) if kind == 'hex' else 3}])",
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
             "parallelism": parallelism,
         },
@@ -198,7 +213,8 @@ def main():
             "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
             "avg_launch_us": avg_s * 1e6,
             "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
-                    "a 100^3 mesh (working set < 256 MiB) is Infinity-Cache resident, so this is not an HBM-roofline test",
+                    "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
+                    "cache-level throughput, not as an HBM-roofline test",
         },
         "kernels": [
             {"name": c["name"], "launches": int(c["launches"]), "avg_us": c["ms"] / c["launches"] * 1e3,
@@ -207,7 +223,7 @@ def main():
         "residual_last": float(res[-1]), "nFrozenPoints_last": int(frz[-1]),
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(n_side, constraints)
+        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,148 @@
+// kernels_walk.hpp -- compacted form of the face-angle freeze walk (SM.C:1347-1434) for meshes where
+// many points lie outside the good angle range (e.g. refinement interfaces: coplanar face pairs give
+// face angles of 180 degrees in every iteration).
+//
+// The walk itself is inherently sequential (LIFO stack, reads and writes isFrozenPoint as it goes), but
+// everything expensive in it is a pure function of (current coordinates, proposals).  So:
+//   1. k_walk_count / k_walk_scan / k_walk_fill : ordered compaction of the active points (ascending
+//      point id) and of their pointPoints rows into dense tables;
+//   2. k_walk_pred : one thread per table entry evaluates the geometric predicates in parallel
+//      (self-deterioration, and for every neighbour "its move hurts me" with me at my proposal / at my
+//      current position) -- the same bits as k_fa_pred;
+//   3. the host replays the reference's stack order over the bit tables (a few ns per entry; the same
+//      replay on one GPU lane costs microseconds per point), and
+//   4. k_walk_apply marks the points the replay froze.
+#pragma once
+#include "kernels.hpp"
+
+namespace smgpu {
+
+struct WalkView {
+    int* activeSlot;      // [P] slot of an active point, -1 otherwise
+    int* blkA; int* blkE; // per 256-point block: active count / entry count, then exclusive offsets
+    int* header;          // {nActive, nEntries}
+    int* actIds;          // [nActive] point ids ascending
+    int* actEntOff;       // [nActive+1]
+    uint8_t* actBits;     // bit0 self move deteriorates, bit1 moved, bit2 frozen before the walk
+    int* entOwner;        // [nEntries] slot of the point the entry belongs to
+    int* entNbr;          // neighbour point id
+    int* entSlot;         // neighbour's slot or -1
+    uint8_t* entBits;     // bit0 N(moved), bit1 N(frozen), bit2 neighbour moving, bit3 neighbour frozen before the walk
+};
+
+__global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    int a = 0, e = 0;
+    if (p < m.nPoints && s.faActive[p]) { a = 1; e = m.ppOff[p + 1] - m.ppOff[p]; }
+    __shared__ int sa[kBlock / 64], se[kBlock / 64];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); e += __shfl_down(e, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; se[threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, te = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
+        w.blkA[blockIdx.x] = ta;
+        w.blkE[blockIdx.x] = te;
+    }
+}
+
+// exclusive scan of the per-block counts (one workgroup; nBlk is at most a few 10^4)
+__global__ void __launch_bounds__(kBlock) k_walk_scan(State s, WalkView w, int nBlk) {
+    if (s.acc->stop) return;
+    __shared__ int baseA, baseE;
+    __shared__ int wa[kBlock / 64], we[kBlock / 64];
+    if (threadIdx.x == 0) { baseA = 0; baseE = 0; }
+    __syncthreads();
+    for (int b0 = 0; b0 < nBlk; b0 += kBlock) {
+        const int i = b0 + threadIdx.x;
+        const int a = (i < nBlk) ? w.blkA[i] : 0, e = (i < nBlk) ? w.blkE[i] : 0;
+        int ia = a, ie = e;   // inclusive scan inside the wave
+        const int lane = threadIdx.x & 63;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
+            if (lane >= o) { ia += ta; ie += te; }
+        }
+        if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
+        __syncthreads();
+        int offA = baseA, offE = baseE;
+        for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
+        if (i < nBlk) { w.blkA[i] = offA + ia - a; w.blkE[i] = offE + ie - e; }
+        __syncthreads();
+        if (threadIdx.x == kBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { w.header[0] = baseA; w.header[1] = baseE; }
+}
+
+__global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool act = p < m.nPoints && s.faActive[p];
+    const int a = act ? 1 : 0, e = act ? m.ppOff[p + 1] - m.ppOff[p] : 0;
+    int ia = a, ie = e;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
+        if (lane >= o) { ia += ta; ie += te; }
+    }
+    __shared__ int wa[kBlock / 64], we[kBlock / 64];
+    if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
+    __syncthreads();
+    int offA = w.blkA[blockIdx.x], offE = w.blkE[blockIdx.x];
+    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
+    if (p < m.nPoints) w.activeSlot[p] = act ? offA + ia - 1 : -1;
+    if (act) {
+        const int slot = offA + ia - 1, eo = offE + ie - e;
+        w.actIds[slot] = p;
+        w.actEntOff[slot] = eo;
+        const int nb = m.ppOff[p];
+        for (int j = 0; j < e; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
+    }
+}
+
+// predicates, one thread per (active point, neighbour) entry plus one per active point (self test)
+__global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nA + nE) return;
+    if (t == 0) w.actEntOff[nA] = nE;
+    const int slot = (t < nA) ? t : w.entOwner[t - nA];
+    const int p = w.actIds[slot];
+    const V3 cur = ldv(s.ptsCur, p);
+    const V3 np = ldv(s.prop, p);
+    const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+    const bool moved = (np != cur);
+    double mn, mx;
+    if (t < nA) {
+        uint8_t sb = (moved ? 2 : 0) | (s.frozen[p] ? 4 : 0);
+        if (moved) {   // SM.C:1385-1394
+            pointFaceAngles(m, s, p, np, -1, np, mn, mx);
+            if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+        }
+        w.actBits[slot] = sb;
+    } else {
+        const int e = t - nA;
+        const int q = w.entNbr[e];
+        const V3 nq = ldv(s.prop, q);
+        uint8_t nb = s.frozen[q] ? 8 : 0;
+        if (nq != ldv(s.ptsCur, q)) {   // SM.C:1414: the neighbour is moving
+            nb |= 4;
+            pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
+            const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+            if (badF) nb |= 2;
+            if (moved) {
+                pointFaceAngles(m, s, p, np, q, nq, mn, mx);   // this point at its proposal, SM.C:1419
+                if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
+            } else if (badF) nb |= 1;
+        }
+        w.entBits[e] = nb;
+        w.entSlot[e] = w.activeSlot[q];
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_walk_apply(State s, const int* ids, int n) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) s.frozen[ids[i]] = 1;
+}
+
+}  // namespace smgpu

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -10,6 +11,7 @@
 
 #include "kernels.hpp"
 #include "kernels_tiled.hpp"
+#include "kernels_walk.hpp"
 #include "tiles.hpp"
 #include "topology.hpp"
 
@@ -73,6 +75,15 @@ struct smgpu_handle {
     SmoothTileView sv{};
     size_t geomLds = 0, smoothLds = 0;
     bool writeFaces = false;   // debug: publish per-face centres/areas from the tiled geometry kernel
+    // face-angle walk: compacted tables + host replay (kernels_walk.hpp) when many points are active
+    int walkMode = -1;         // -1 undecided, 0 device replay (k_fa_pred + k_fa_walk), 1 host replay
+    bool walkAlloc = false;
+    WalkView wv{};
+    int walkBlocks = 0;
+    void* pinned = nullptr;
+    size_t pinnedBytes = 0;
+    std::vector<uint8_t> walkFrozen;
+    std::vector<int> walkStack, walkOut;
     bool eaCoop = true;        // wave-cooperative edge-angle kernel (SMGPU_EDGE_ANGLE=faithful selects the per-angle acos form)
     int eaMaxEntries = 0;
 };
@@ -347,6 +358,7 @@ int smgpu_destroy(smgpu_handle* h) {
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->freeEvents) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -388,6 +400,7 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
     if (!(p->maxStepLength > 0.0)) return fail("maxStepLength must be > 0");
     h->prm = *p;
     h->prmSet = true;
+    h->walkMode = -1;
     computeAlgoBytes(h);
     return 0;
 }
@@ -435,6 +448,122 @@ static int runGeometry(smgpu_handle* h) {
     return 0;
 }
 
+// ---- face-angle walk with host replay (kernels_walk.hpp) ---------------------------------------
+static int ensureWalkBuffers(smgpu_handle* h) {
+    if (h->walkAlloc) return 0;
+    const Topology& t = h->topo;
+    const size_t P = t.nPoints, E = (size_t)t.pointEdges.nnz();
+    h->walkBlocks = gridFor(t.nPoints);
+    WalkView& w = h->wv;
+    int rc = 0;
+    rc |= devAlloc(h, &w.activeSlot, P);
+    rc |= devAlloc(h, &w.blkA, (size_t)h->walkBlocks + 1);
+    rc |= devAlloc(h, &w.blkE, (size_t)h->walkBlocks + 1);
+    rc |= devAlloc(h, &w.header, 4);
+    rc |= devAlloc(h, &w.actIds, P);
+    rc |= devAlloc(h, &w.actEntOff, P + 1);
+    rc |= devAlloc(h, &w.actBits, P);
+    rc |= devAlloc(h, &w.entOwner, E + P);
+    rc |= devAlloc(h, &w.entNbr, E);
+    rc |= devAlloc(h, &w.entSlot, E);
+    rc |= devAlloc(h, &w.entBits, E);
+    if (rc) return 1;
+    h->walkAlloc = true;
+    return 0;
+}
+
+static int ensurePinned(smgpu_handle* h, size_t bytes) {
+    if (h->pinnedBytes >= bytes) return 0;
+    if (h->pinned) HIP_OK(hipHostFree(h->pinned));
+    h->pinned = nullptr;
+    h->pinnedBytes = 0;
+    const size_t want = bytes + bytes / 2 + 4096;
+    HIP_OK(hipHostMalloc(&h->pinned, want, hipHostMallocDefault));
+    h->pinnedBytes = want;
+    return 0;
+}
+
+// The reference's stack walk SM.C:1347-1434 over the predicate bit tables.  Slots ascend with the point id,
+// so the reference's pop order (highest id first) is slot nA-1 .. 0; a point frozen by a neighbour is pushed
+// and re-visited before the walk continues (SM.C:1431).  Non-active points never act (SM.C:1367-1369), so
+// only freezing them is recorded.
+static void replayWalk(int nA, const int* actIds, const int* entOff, const uint8_t* actBits, const int* entNbr,
+                       const int* entSlot, const uint8_t* entBits, std::vector<uint8_t>& frozen, std::vector<int>& stack,
+                       std::vector<int>& out) {
+    frozen.resize((size_t)nA);
+    for (int a = 0; a < nA; ++a) frozen[(size_t)a] = (actBits[a] & 4) ? 1 : 0;
+    stack.clear();
+    out.clear();
+    for (int top = nA - 1; top >= 0; --top) {
+        stack.push_back(top);
+        while (!stack.empty()) {
+            const int a = stack.back();
+            stack.pop_back();
+            const uint8_t sb = actBits[a];
+            bool useNew = !frozen[(size_t)a] && (sb & 2);                        // SM.C:1376-1385
+            if (useNew && (sb & 1)) { frozen[(size_t)a] = 1; out.push_back(actIds[a]); useNew = false; }   // SM.C:1391-1399
+            for (int k = entOff[a]; k < entOff[a + 1]; ++k) {                   // SM.C:1406-1433
+                const uint8_t nb = entBits[k];
+                if (!(nb & 4)) continue;                                         // neighbour not moving
+                const int sl = entSlot[k];
+                if (sl >= 0 ? frozen[(size_t)sl] : (nb & 8)) continue;           // neighbour already frozen
+                if (useNew ? (nb & 1) : (nb & 2)) {
+                    out.push_back(entNbr[k]);
+                    if (sl >= 0) { frozen[(size_t)sl] = 1; stack.push_back(sl); }
+                }
+            }
+        }
+    }
+}
+
+static int runHostWalk(smgpu_handle* h) {
+    if (ensureWalkBuffers(h)) return 1;
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const Prm prm = makePrm(h->prm);
+    WalkView w = h->wv;
+    if (ensurePinned(h, 64)) return 1;
+    if (launchK(h, K_FA_PRED, [&] {
+            hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks);
+        })) return 1;
+    int* hdr = (int*)h->pinned;
+    HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    const int nA = hdr[0], nE = hdr[1];
+    if (nA <= 0) return 0;
+    if (launchK(h, K_FA_PRED, [&] {
+            hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_pred, dim3(gridFor((int64_t)nA + nE)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+        })) return 1;
+    // dense tables -> pinned host memory
+    const size_t oIds = 0, oOff = oIds + 4 * (size_t)nA, oNbr = oOff + 4 * ((size_t)nA + 1), oSlot = oNbr + 4 * (size_t)nE,
+                 oABits = oSlot + 4 * (size_t)nE, oEBits = oABits + (size_t)nA, total = oEBits + (size_t)nE;
+    if (ensurePinned(h, total + 16)) return 1;
+    char* base = (char*)h->pinned;
+    HIP_OK(hipMemcpyAsync(base + oIds, w.actIds, 4 * (size_t)nA, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oOff, w.actEntOff, 4 * ((size_t)nA + 1), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oNbr, w.entNbr, 4 * (size_t)nE, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oSlot, w.entSlot, 4 * (size_t)nE, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oABits, w.actBits, (size_t)nA, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oEBits, w.entBits, (size_t)nE, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    replayWalk(nA, (const int*)(base + oIds), (const int*)(base + oOff), (const uint8_t*)(base + oABits), (const int*)(base + oNbr),
+               (const int*)(base + oSlot), (const uint8_t*)(base + oEBits), h->walkFrozen, h->walkStack, h->walkOut);
+    if (h->timing) h->ms[K_FA_WALK] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    h->launches[K_FA_WALK]++;
+    const int nOut = (int)h->walkOut.size();
+    if (nOut > 0) {
+        // the id list reuses the pinned buffer's head and the (now consumed) entOwner array on the device
+        std::memcpy(base, h->walkOut.data(), sizeof(int) * (size_t)nOut);
+        HIP_OK(hipMemcpyAsync(w.entOwner, base, sizeof(int) * (size_t)nOut, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_walk_apply, dim3(gridFor(nOut)), dim3(kBlock), 0, h->stream, s, w.entOwner, nOut);
+        HIP_OK(hipStreamSynchronize(h->stream));   // the pinned buffer is reused by the next iteration
+    }
+    return 0;
+}
+
 // proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
 static int runProposalAndConstraints(smgpu_handle* h) {
     const MeshView& m = h->mv;
@@ -453,8 +582,23 @@ static int runProposalAndConstraints(smgpu_handle* h) {
     if (h->prm.faceAngleConstraint) {
         if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
         if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
-        if (launchK(h, K_FA_PRED, [&] { hipLaunchKernelGGL(k_fa_pred, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
-        if (launchK(h, K_FA_WALK, [&] { hipLaunchKernelGGL(k_fa_walk, dim3(1), dim3(64), 0, h->stream, m, s); })) return 1;
+        if (h->walkMode < 0) {
+            // decide once per parameter set: read how many points lie outside the good range now (one sync)
+            const char* env = std::getenv("SMGPU_HOST_WALK");
+            if (env && std::string(env) != "auto") h->walkMode = std::atoi(env) ? 1 : 0;
+            else {
+                Accum a;
+                HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
+                HIP_OK(hipStreamSynchronize(h->stream));
+                h->walkMode = a.nActive > envInt("SMGPU_HOST_WALK_THRESHOLD", 256) ? 1 : 0;
+            }
+        }
+        if (h->walkMode == 1) {
+            if (runHostWalk(h)) return 1;
+        } else {
+            if (launchK(h, K_FA_PRED, [&] { hipLaunchKernelGGL(k_fa_pred, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+            if (launchK(h, K_FA_WALK, [&] { hipLaunchKernelGGL(k_fa_walk, dim3(1), dim3(64), 0, h->stream, m, s); })) return 1;
+        }
     }
     return 0;
 }
