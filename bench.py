@@ -180,10 +180,19 @@ def main():
             dist.destroy_process_group()
         return
 
+    # HBM traffic per launch, measured separately under rocprofv3 --pmc (scripts/measure_traffic.sh) and
+    # committed under profiles/; None when no measurement of this workload exists
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r1", f"traffic_{args.workload}.json")
+    tdoc = json.load(open(tpath)) if os.path.exists(tpath) else None
     ctr.sort(key=lambda c: -c["ms"])
     dom = [c for c in ctr if c["algoBytesPerLaunch"] > 1024][0]     # dominant compute kernel (not pack/finish)
     avg_s = dom["ms"] / dom["launches"] * 1e-3
     achieved = dom["algoBytesPerLaunch"] / avg_s / 1e9
+    if tdoc:
+        for kname, kv in tdoc["kernels"].items():
+            if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
+                traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
     out = {
         "metric": "mesh-points smoothed/sec/node (100 iters) + achieved HBM GB/s vs roofline",
         "value": total_points * K / dt,
@@ -209,7 +218,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
             "avg_launch_us": avg_s * 1e6,
             "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "

@@ -197,13 +197,15 @@ __device__ __forceinline__ void pointLocal(const MeshView& m, const State& s, in
     L.hc = shareCell(m, q1, q2) ? 1 : 0;
 }
 
-// SM.C:489-543
-__device__ __forceinline__ double arRatio(const V3& c1, const V3& c2, const V3& c3, bool hasCommonCell, bool internal) {
+// SM.C:489-543.  m1..m3 = mag(closestPoint1..3) (SM.C:509-510), passed in because the callers already
+// hold them: |x_q - x_p| computed as an edge length (SM.C:336) is the same value bit for bit.
+__device__ __forceinline__ double arRatioLen(const V3& c1, const V3& c2, double m1, double m2, double m3, bool hasCommonCell,
+                                             bool internal) {
     if (hasCommonCell) return 0.0;
     const V3 z = v3(0, 0, 0);
     if ((c1 == z) || (c2 == z)) return 0.0;
-    const double lengthRatio1 = mag(c2) / mag(c1);
-    const double lengthRatio2 = mag(c3) / mag(c2);
+    const double lengthRatio1 = m2 / m1;
+    const double lengthRatio2 = m3 / m2;
     if (internal) {
         const double minRatio = 1.5, maxRatio = 3.0;
         if ((lengthRatio1 < minRatio) && (lengthRatio2 > minRatio)) {
@@ -218,6 +220,16 @@ __device__ __forceinline__ double arRatio(const V3& c1, const V3& c2, const V3& 
         const double t = (0.0 > frac) ? 0.0 : frac;
         return (1.0 < t) ? 1.0 : t;
     }
+}
+__device__ __forceinline__ double arRatio(const V3& c1, const V3& c2, const V3& c3, bool hasCommonCell, bool internal) {
+    return arRatioLen(c1, c2, mag(c1), mag(c2), mag(c3), hasCommonCell, internal);
+}
+
+// v / double(n) for a small positive count: a power-of-two count is an exact scaling, so the product
+// with the exact reciprocal is the same correctly rounded value as the quotient, at a tenth of the cost
+__device__ __forceinline__ V3 divByCount(const V3& v, int n) {
+    if ((n & (n - 1)) == 0) { const double r = 1.0 / double(n); return v3(v.x * r, v.y * r, v.z * r); }
+    return v / double(n);
 }
 
 // residual = max over points (SM.C:1556-1565), nFrozenPoints = count (SM.C:2384-2392): every workgroup
@@ -679,18 +691,25 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
 }
 
 // End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test
-// (SM.C:2401), reset accumulators.  One workgroup.
-__global__ void __launch_bounds__(kBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
+// (SM.C:2401), reset accumulators.  One workgroup of 1024 threads, 4 independent loads in flight per thread.
+constexpr int kFinishBlock = 1024;
+__global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
     Accum* a = s.acc;
     if (a->stop) return;
-    __shared__ double shMax[kBlock / 64];
-    __shared__ int shCnt[kBlock / 64];
+    __shared__ double shMax[kFinishBlock / 64];
+    __shared__ int shCnt[kFinishBlock / 64];
     double d = 0.0;
     int c = 0;
-    for (int i = threadIdx.x; i < nPartials; i += kBlock) {
-        const double v = s.blkMax[i];
-        d = (v > d) ? v : d;
-        c += s.blkCnt[i];
+    for (int i0 = threadIdx.x; i0 < nPartials; i0 += 4 * kFinishBlock) {
+        double v[4]; int n[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * kFinishBlock;
+            v[u] = (i < nPartials) ? s.blkMax[i] : 0.0;
+            n[u] = (i < nPartials) ? s.blkCnt[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { d = (v[u] > d) ? v[u] : d; c += n[u]; }
     }
     for (int o = 32; o > 0; o >>= 1) {
         const double od = __shfl_down(d, o, 64);
@@ -701,7 +720,7 @@ __global__ void __launch_bounds__(kBlock) k_finish(State s, int nPartials, int i
     if ((threadIdx.x & 63) == 0) { shMax[threadIdx.x >> 6] = d; shCnt[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int i = 1; i < kBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
+    for (int i = 1; i < kFinishBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
     const double res = d;
     if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
                 fCentre = (j == 0) ? p : fCentre + p;
                 n = j + 1;
             })
-            fCentre = fCentre / double(n);
+            fCentre = divByCount(fCentre, n);
             V3 ctr, area;
             if (n == 3) {
                 const ushort4 q = row[0];
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
             cEst = cEst + ldsv(fcx, fcy, fcz, e & 0x7fff);
             nFaces = j + 1;
         })
-        cEst = cEst / double(nFaces);
+        cEst = divByCount(cEst, nFaces);
         V3 ctr = v3(0, 0, 0);
         double vol = 0.0;
         SMGPU_ELL_FOREACH(row, cw4, T, {
@@ -188,6 +188,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
         const int wn4 = g.ppWidth[tile] >> 2;
         const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
         V3 sum = v3(0, 0, 0), r1, r2, r3;
+        double m1 = 0.0, m2 = 0.0, m3 = 0.0;   // mag(closestPoint1..3), SM.C:509-510
         int count = 0, hc = 0;
         double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
         const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
@@ -198,6 +199,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             const long long pk = __double_as_longlong(r[12]);
             count = (int)(pk & 0xffffffffll);
             hc = (int)(pk >> 32);
+            m1 = mag(r1); m2 = mag(r2); m3 = mag(r3);
             SMGPU_ELL_FOREACH(ppRow, wn4, T, {
                 (void)j;
                 const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
                 r1 = ldsv(nx, ny, nz, q1 & 0x7fff) - cur;
                 r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
                 r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
+                m1 = l1; m2 = l2; m3 = (k3 < 0) ? mag(r3) : l3;
                 if (g.usePairShare) {
                     const uint16_t* pe = g.pairEll + g.ppBase[tile];
                     hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
@@ -241,10 +244,10 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             }
         }
         V3 np = cur;
-        if (count) np = sum / double(count);                          // SM.C:155-163
-        const double blendFrac = arRatio(r1, r2, r3, hc != 0, internal);
+        if (count) np = divByCount(sum, count);                        // SM.C:155-163
+        const double blendFrac = arRatioLen(r1, r2, m1, m2, m3, hc != 0, internal);
         if (blendFrac > 0.0) {                                         // SM.C:580-590
-            const V3 aCoords = cur + (r1 + r2) / 2.0;
+            const V3 aCoords = cur + 0.5 * (r1 + r2);   // (r1 + r2) / 2.0: halving is exact either way
             np = (1.0 - blendFrac) * np + blendFrac * aCoords;
         }
         {                                                              // SM.C:722-745

@@ -644,7 +644,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
         const int nPart = (fused && h->useTiles) ? h->stl.nTiles : gP;
-        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
+        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
         ++launched;
         // a positive relTol can stop the loop: poll the device flag now and then so a converged run
@@ -799,7 +799,7 @@ int smgpu_iter_end(smgpu_handle* h) {
             })) return 1;
     if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
-    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kBlock), 0, h->stream, s, gridFor(m.nPoints), h->haloIter, -1.0, h->localStats); })) return 1;
+    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, gridFor(m.nPoints), h->haloIter, -1.0, h->localStats); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     return 0;

@@ -147,23 +147,44 @@ class DistributedSmoother:
 
     def iterate(self, centroidalIters, relTol=0.02):
         torch, st, eng = self.torch, self.state, self.engine
-        hist = torch.zeros((max(centroidalIters, 1), 2), dtype=torch.float64, device=self.device)
+        n = max(centroidalIters, 1)
         done = 0
+        if relTol > 0.0:
+            hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
+            for i in range(centroidalIters):
+                eng.iter_begin()
+                self._a2a(st.recvA, st.sendA)               # SM.C:134-148, 402-478
+                eng.iter_mid()
+                self._a2a(st.recvF, st.sendF)               # SM.C:2374
+                eng.iter_end()
+                self._gather_stats()                        # SM.C:1567, 2396
+                hist[i, 0] = self.allStats[:, 0].max()
+                hist[i, 1] = self.allStats[:, 1].sum()
+                done += 1
+                if float(hist[i, 0].item()) < relTol:       # SM.C:2401
+                    break
+            h = hist[:done].cpu().numpy()
+            return done, h[:, 0].copy(), h[:, 1].astype(np.int64)
+        # residual >= 0, so relTol <= 0 can never stop the loop (SM.C:2401): no per-iteration reduction and no
+        # host read-back; every rank keeps its local {residual, nFrozenPoints} history on the device and the
+        # all-rank values of the log line (SM.C:2396) come from ONE gather after the loop
+        local = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
         for i in range(centroidalIters):
             eng.iter_begin()
-            self._a2a(st.recvA, st.sendA)               # SM.C:134-148, 402-478
+            self._a2a(st.recvA, st.sendA)
             eng.iter_mid()
-            self._a2a(st.recvF, st.sendF)               # SM.C:2374
+            self._a2a(st.recvF, st.sendF)
             eng.iter_end()
-            self._gather_stats()                        # SM.C:1567, 2396
-            hist[i, 0] = self.allStats[:, 0].max()
-            hist[i, 1] = self.allStats[:, 1].sum()
+            local[i].copy_(st.localStats)
             done += 1
-            # residual >= 0, so relTol <= 0 can never stop the loop: skip the host read-back then
-            if relTol > 0.0 and float(hist[i, 0].item()) < relTol:       # SM.C:2401
-                break
-        h = hist[:done].cpu().numpy()
-        return done, h[:, 0].copy(), h[:, 1].astype(np.int64)
+        if self._staged():
+            allh = torch.empty((self.world, n, 2), dtype=torch.float64)
+            self.dist.all_gather_into_tensor(allh.view(-1), local.cpu().view(-1))
+        else:
+            allh = torch.empty((self.world, n, 2), dtype=torch.float64, device=self.device)
+            self.dist.all_gather_into_tensor(allh.view(-1), local.view(-1))
+        allh = allh[:, :done].cpu().numpy()
+        return done, allh[:, :, 0].max(axis=0), allh[:, :, 1].sum(axis=0).astype(np.int64)
 
     def get_points(self):
         return self.engine.get_points()
