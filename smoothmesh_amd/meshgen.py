@@ -187,3 +187,78 @@ def hex_subdomain(nLocal, grid, rank, lengths=None, jitter=0.0, seed=12345):
     mesh = PolyMesh(points=pts, faceOffsets=(np.arange(F + 1) * 4).astype(np.int32), facePoints=faces.ravel(), owner=owner,
                     neighbour=int_nei.astype(np.int32), patches=patches, nCells=nx * ny * nz)
     return SubDomain(mesh, rank, Px * Py * Pz, gid)
+
+
+def read_obj_surface(path):
+    """vertices (V,3) and polygon faces (list of 0-based index lists) of a Wavefront OBJ surface"""
+    verts, faces = [], []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                verts.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                faces.append([int(tok.split("/")[0]) - 1 for tok in t[1:]])
+    return np.array(verts, dtype=np.float64), faces
+
+
+def extrude_surface(verts, faces2d, nLayers=15, thickness=1.5, direction=(0.0, 1.0, 0.0)) -> PolyMesh:
+    """Linear extrusion of a planar polygon surface into prism/hex cells -- stands in for OpenFOAM's
+    extrude2DMesh (reference testcase/run_serial:11, system/extrude2DMeshDict: nLayers 15, thickness 1.5 along
+    +y; BASELINE.json configs[0]).  Numbering: point = v + layer*nV, cell = f + layer*nF; internal faces in
+    upper-triangular order; patches back (layer 0), front (last layer), sides."""
+    d = np.asarray(direction, dtype=np.float64)
+    d = d / np.linalg.norm(d)
+    nV, nF = len(verts), len(faces2d)
+    # orient every polygon counter-clockwise about the extrusion direction
+    polys = []
+    for f in faces2d:
+        p = verts[f]
+        nrm = np.zeros(3)
+        for i in range(len(f)):
+            nrm += np.cross(p[i], p[(i + 1) % len(f)])
+        polys.append(list(f) if nrm @ d > 0 else list(f)[::-1])
+    pts = np.concatenate([verts + d * (thickness * l / nLayers) for l in range(nLayers + 1)], axis=0)
+    # lateral adjacency of the 2-D faces
+    edge_faces = {}
+    for fi, f in enumerate(polys):
+        for i in range(len(f)):
+            a, b = f[i], f[(i + 1) % len(f)]
+            edge_faces.setdefault((min(a, b), max(a, b)), []).append((fi, a, b))
+    internal = []   # (owner, neighbour, vertex list)
+    back, front, sides = [], [], []
+    for l in range(nLayers):
+        o0, o1 = l * nV, (l + 1) * nV
+        for fi, f in enumerate(polys):
+            c = fi + l * nF
+            if l + 1 < nLayers:
+                internal.append((c, c + nF, [v + o1 for v in f]))
+            else:
+                front.append((c, [v + o1 for v in f]))
+            if l == 0:
+                back.append((c, [v + o0 for v in f][::-1]))
+            for i in range(len(f)):
+                a, b = f[i], f[(i + 1) % len(f)]
+                users = edge_faces[(min(a, b), max(a, b))]
+                quad = [a + o0, b + o0, b + o1, a + o1]      # normal points out of this cell
+                if len(users) == 1:
+                    sides.append((c, quad))
+                elif len(users) == 2:
+                    other = users[0][0] if users[1][0] == fi else users[1][0]
+                    if other > fi:
+                        internal.append((c, other + l * nF, quad))
+                else:
+                    raise ValueError("non-manifold edge in the surface")
+    internal.sort(key=lambda t: (t[0], t[1]))
+    allf = [t[2] for t in internal] + [t[1] for t in back] + [t[1] for t in front] + [t[1] for t in sides]
+    owner = [t[0] for t in internal] + [t[0] for t in back] + [t[0] for t in front] + [t[0] for t in sides]
+    off = np.zeros(len(allf) + 1, np.int32)
+    np.cumsum([len(f) for f in allf], out=off[1:])
+    nI = len(internal)
+    patches = [Patch("back", "patch", len(back), nI), Patch("front", "patch", len(front), nI + len(back)),
+               Patch("sides", "patch", len(sides), nI + len(back) + len(front))]
+    return PolyMesh(points=pts, faceOffsets=off, facePoints=np.concatenate([np.asarray(f, np.int32) for f in allf]),
+                    owner=np.asarray(owner, np.int32), neighbour=np.asarray([t[1] for t in internal], np.int32), patches=patches,
+                    nCells=nF * nLayers)

@@ -1,0 +1,62 @@
+"""BASELINE.json configs[0]: the reference's bundled testcase/ -- MeshedSurface.obj (a data file of the
+reference's own test, committed as a fixture under tests/golden/) extruded 15 layers (own extruder standing
+in for extrude2DMesh), 20 centroidal iterations, constraints off: plumbing check of the oracle on a mixed
+prism/hex mesh.  The GPU variant (marked gpu) checks the HIP path on the same mesh with the reference's
+testcase options (run_serial:18 without the out-of-scope -layerPatches)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_linf
+
+OBJ = os.path.join(os.path.dirname(__file__), "golden", "MeshedSurface.obj")
+
+
+def _mesh():
+    from smoothmesh_amd.meshgen import extrude_surface, read_obj_surface
+    v, f = read_obj_surface(OBJ)
+    assert v.shape == (660, 3) and len(f) == 750
+    assert sum(len(x) == 3 for x in f) == 275 and sum(len(x) == 4 for x in f) == 475
+    return extrude_surface(v, f, nLayers=15, thickness=1.5, direction=(0, 1, 0))
+
+
+def test_extruded_mesh_is_valid(oracle_lib):
+    m = _mesh()
+    assert m.nCells == 11250 and m.nPoints == 10560
+    o = oracle_lib.Oracle(m)
+    o.phaseA()
+    fa = o.field("faceAreas").reshape(-1, 3)
+    s = np.zeros((m.nCells, 3))
+    np.add.at(s, m.owner, fa)
+    np.subtract.at(s, m.neighbour, fa[:m.nInternalFaces])
+    assert np.abs(s).max() < 1e-15                                      # every cell is closed
+    assert np.all(m.owner[:m.nInternalFaces] < m.neighbour)             # upper-triangular
+
+
+def test_config0_oracle_runs_20_iterations(oracle_lib):
+    from smoothmesh_amd import default_params
+    m = _mesh()
+    o = oracle_lib.Oracle(m)
+    o.set_params(default_params(o.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False))
+    n, res, frz = o.iterate(20, 0.0)
+    assert n == 20 and np.all(np.isfinite(res)) and np.all(res <= 1.0 + 1e-12)   # clamped steps (SM.C:732-735)
+    internal = m.find_internal_points().astype(bool)
+    assert np.array_equal(o.points()[~internal], m.points[~internal])
+    assert np.all(frz >= (~internal).sum())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("opts", [dict(edgeAngleConstraint=False, faceAngleConstraint=False),
+                                  dict(minEdgeLength=0.01, maxStepLength=0.002, minAngle=15.0, maxAngle=160.0)])
+def test_config0_gpu_matches_oracle(oracle_lib, opts):
+    from smoothmesh_amd import SmoothEngine, default_params
+    m = _mesh()
+    o = oracle_lib.Oracle(m)
+    e = SmoothEngine(m)
+    p = default_params(o.mesh_stats()[0], **opts)
+    o.set_params(p); e.set_params(p)
+    n_o, res_o, frz_o = o.iterate(20, 0.0)
+    n_g, res_g, frz_g = e.iterate(20, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= 1e-13
