@@ -130,6 +130,9 @@ typedef struct smgpu_halo_desc {
 } smgpu_halo_desc;
 int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d);
 int smgpu_iter_begin(smgpu_handle* h);   /* geometry + local partial sums / closest points -> sendA */
+int smgpu_iter_interior(smgpu_handle* h);/* optional, between begin and mid: everything that does not need
+                                            recvA (points away from the shared ones) -- lets the host overlap
+                                            exchange A with compute                                         */
 int smgpu_iter_mid(smgpu_handle* h);     /* combine recvA, proposal, constraints -> sendF           */
 int smgpu_iter_end(smgpu_handle* h);     /* or recvF, restore, residual -> localStats; movePoints   */
 

@@ -187,6 +187,9 @@ class OracleRankEngine:
         self._lib.orc_halo_packA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), len(self.sendShared),
                                  _p(self.sendShared, i32p), self.ptr["sendA"])
 
+    def iter_interior(self):
+        pass   # the oracle has no exchange-independent stage
+
     def iter_mid(self):
         self._lib.orc_halo_combineA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
                                     _p(self.combSlots, i32p), self.ptr["recvA"])

@@ -456,6 +456,7 @@ int main(int argc, char** argv) {
         } else {
             for (long k = 0; k < chunk; ++k) {
                 for (Rank& K : R) check(smgpu_iter_begin(K.h), "smgpu_iter_begin");
+                for (Rank& K : R) check(smgpu_iter_interior(K.h), "smgpu_iter_interior");
                 exchange(true);
                 for (Rank& K : R) check(smgpu_iter_mid(K.h), "smgpu_iter_mid");
                 exchange(false);

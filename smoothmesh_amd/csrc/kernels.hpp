@@ -236,7 +236,7 @@ __device__ __forceinline__ V3 divByCount(const V3& v, int n) {
 // publishes one partial (no same-address atomics: thousands of workgroups on one word serialise at
 // ~90 atomics/us); k_finish reduces the partials.
 template <int T>
-__device__ __forceinline__ void blockPublish(const State& s, double dist, int frozenCount) {
+__device__ __forceinline__ void blockPublish(const State& s, double dist, int frozenCount, int partialSlot) {
     __shared__ double shMax[T / 64];
     __shared__ int shCnt[T / 64];
     if (!(dist > 0.0)) dist = 0.0;  // NaN never wins "distance > maxStep"
@@ -252,8 +252,8 @@ __device__ __forceinline__ void blockPublish(const State& s, double dist, int fr
     if (threadIdx.x == 0) {
         double d = shMax[0]; int c = shCnt[0];
         for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
-        s.blkMax[blockIdx.x] = d;
-        s.blkCnt[blockIdx.x] = c;
+        s.blkMax[partialSlot] = d;
+        s.blkCnt[partialSlot] = c;
     }
 }
 
@@ -330,7 +330,7 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             s.frozen[p] = frozen ? 1 : 0;
         }
     }
-    if (FINAL) blockPublish<kBlock>(s, dist, fcount);
+    if (FINAL) blockPublish<kBlock>(s, dist, fcount, blockIdx.x);
 }
 
 // restrictMinEdgeAngleDecrease SM.C:900-930 (+ calc_min_edge_angles :837-894) -- one thread per point.
@@ -687,7 +687,7 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
         dist = mag(np - cur) / prm.maxStep;
         stv(s.ptsNext, p, np);
     }
-    blockPublish<kBlock>(s, dist, fcount);
+    blockPublish<kBlock>(s, dist, fcount, blockIdx.x);
 }
 
 // End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test
@@ -840,6 +840,34 @@ __global__ void __launch_bounds__(kBlock) k_halo_orF(int nShared, const int* sha
         if (sl >= 0) any |= recvF[sl];
     }
     if (any) frozen[sharedLocal[i]] = 1;
+}
+
+// Multi-rank, constraints off: the fused proposal kernel has already moved every non-shared point; for
+// the shared points it left the proposal and the local freeze flag.  After exchange F this kernel ORs the
+// flags (SM.C:2374), restores / counts (SM.C:2384-2392), writes the new coordinates and publishes the
+// residual partials of the shared points (partial slots after the tile slots).
+__global__ void __launch_bounds__(kBlock) k_shared_fix(MeshView m, State s, Prm prm, int nShared, const int* sharedLocal,
+                                                       const int* combOff, const int* combSlots, const int* recvF, int partialBase) {
+    if (s.acc->stop) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double dist = 0.0;
+    int fcount = 0;
+    if (i < nShared) {
+        const int p = sharedLocal[i];
+        int frz = s.frozen[p];
+        for (int k = combOff[i]; k < combOff[i + 1]; ++k) {
+            const int sl = combSlots[k];
+            if (sl >= 0) frz |= recvF[sl];
+        }
+        s.frozen[p] = frz ? 1 : 0;
+        const uint8_t fl = m.pflags[p];
+        const V3 cur = ldv(s.ptsCur, p);
+        V3 np = ldv(s.prop, p);
+        if (frz || (!(fl & PF_INTERNAL) && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
+        dist = mag(np - cur) / prm.maxStep;
+        stv(s.ptsNext, p, np);
+    }
+    blockPublish<kBlock>(s, dist, fcount, partialBase + blockIdx.x);
 }
 
 // getMeshStats SM.C:1495-1510: min / max edge length

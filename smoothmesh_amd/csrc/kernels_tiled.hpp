@@ -156,13 +156,15 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
 
 // The fused per-point proposal kernel of kernels.hpp (k_smooth) with the cell centres and neighbour
 // coordinates of one tile of consecutive points staged in LDS.
+// tileList (may be NULL) selects the tiles of this launch: the multi-rank driver smooths the tiles without
+// shared points while exchange A is in flight, the others after it.
 template <bool FINAL, int T>
-__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g) {
+__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList) {
     if (s.acc->stop) return;
     extern __shared__ double lds[];
     double* cx = lds;              double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
     double* nx = cz + g.maxCells;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = tileList ? tileList[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
     {
         const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
         for (int i = tid; i < n; i += T) {
@@ -268,7 +270,12 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (FINAL) {
+        if (FINAL && slot >= 0) {
+            // shared point (multi-rank): its freeze flag still has to be OR-ed over the ranks (SM.C:2374);
+            // k_shared_fix finishes it after exchange F
+            stv(s.prop, p, np);
+            s.frozen[p] = frozen ? 1 : 0;
+        } else if (FINAL) {
             if (frozen || (!internal && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
             dist = mag(np - cur) / prm.maxStep;
             stv(s.ptsNext, p, np);
@@ -277,7 +284,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             s.frozen[p] = frozen ? 1 : 0;
         }
     }
-    if (FINAL) blockPublish<T>(s, dist, fcount);
+    if (FINAL) blockPublish<T>(s, dist, fcount, tile);
 }
 
 }  // namespace smgpu

@@ -66,6 +66,9 @@ struct smgpu_handle {
     int *sendF = nullptr, *recvF = nullptr;
     double* localStats = nullptr;
     int haloIter = 0;
+    int *dInteriorTiles = nullptr, *dSharedTiles = nullptr;   // smoothing tiles without / with shared points
+    int nInteriorTiles = 0, nSharedTiles = 0;
+    bool interiorDone = false;
     // LDS staging tiles (tiles.hpp)
     bool useTiles = false;
     int geomT = 128, smoothT = 256;
@@ -141,6 +144,9 @@ static int launchK(smgpu_handle* h, int k, F&& f) {
     } else {
         f();
     }
+    // a bad launch configuration is reported through the sticky last-error, not by the launch macro
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(std::string("launch of ") + kKernelNames[k] + ": " + hipGetErrorString(le));
     h->launches[k]++;
     return 0;
 }
@@ -409,24 +415,34 @@ extern "C++" {
 template <int T>
 static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg) {
     static bool attrSet = false;
-    if (!attrSet) { (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
+    if (!attrSet) {
+        if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
+        attrSet = true;
+    }
     hipLaunchKernelGGL(k_geom_tile<T>, dim3(h->gt.nTiles), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0);
 }
 template <bool FINAL, int T>
-static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm) {
+static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
     static bool attrSet = false;
-    if (!attrSet) { (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attrSet = true; }
-    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(h->stl.nTiles), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv);
+    if (!attrSet) {
+        if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+        attrSet = true;
+    }
+    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(nTiles), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList);
 }
+// tileList == NULL: all tiles; otherwise the nTiles listed ones (multi-rank interior / shared split)
 template <bool FINAL>
-static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm) {
+static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList = nullptr, int nList = 0) {
     const int kid = FINAL ? K_SMOOTH_FINAL : K_SMOOTH_PROP;
-    if (h->useTiles)
+    if (h->useTiles) {
+        const int nT = tileList ? nList : h->stl.nTiles;
+        if (nT == 0) return 0;
         return launchK(h, kid, [&] {
-            if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm);
-            else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm);
-            else launchSmoothTile<FINAL, 256>(h, m, s, prm);
+            if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm, tileList, nT);
+            else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm, tileList, nT);
+            else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT);
         });
+    }
     return launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); });
 }
 
@@ -565,12 +581,17 @@ static int runHostWalk(smgpu_handle* h) {
 }
 
 // proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
+static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
+    if (runSmooth<false>(h, h->mv, h->st, makePrm(h->prm))) return 1;
+    return runConstraints(h);
+}
+// the constraint evaluators on the proposals left in prop / frozen (SM.C:2361-2371)
+static int runConstraints(smgpu_handle* h) {
     const MeshView& m = h->mv;
     State s = h->st;
     const Prm prm = makePrm(h->prm);
     const int gP = gridFor(m.nPoints);
-    if (runSmooth<false>(h, m, s, prm)) return 1;
     if (h->prm.edgeAngleConstraint) {
         if (h->eaCoop) {
             if (launchK(h, K_EDGE_ANGLE, [&] {
@@ -744,6 +765,22 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     h->localStats = (double*)d->localStats;
     if ((d->nSend && (!h->sendA || !h->sendF)) || (d->nRecv && (!h->recvA || !h->recvF)) || !h->localStats)
         return fail("halo: null exchange buffer");
+    if (h->useTiles) {
+        std::vector<int> inter, shr;
+        for (int ti = 0; ti < h->stl.nTiles; ++ti) {
+            bool any = false;
+            for (int pi = h->stl.ptBeg[ti]; pi < h->stl.ptBeg[ti + 1] && !any; ++pi) any = slot[(size_t)h->stl.order[(size_t)pi]] >= 0;
+            (any ? shr : inter).push_back(ti);
+        }
+        const int *pa = nullptr, *pb = nullptr;
+        if (devUpload(h, &pa, inter) || devUpload(h, &pb, shr)) return 1;
+        h->dInteriorTiles = (int*)pa; h->dSharedTiles = (int*)pb;
+        h->nInteriorTiles = (int)inter.size(); h->nSharedTiles = (int)shr.size();
+    }
+    {   // partial slots: tiles (or point blocks) + the blocks of k_shared_fix
+        const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2;
+        if (devAlloc(h, &h->st.blkMax, nPart) || devAlloc(h, &h->st.blkCnt, nPart)) return 1;
+    }
     h->st.sharedSlot = h->dSharedSlot;
     h->st.combA = h->dCombA;
     h->haloOn = true;
@@ -769,15 +806,36 @@ int smgpu_iter_begin(smgpu_handle* h) {
     return 0;
 }
 
+// Work of the iteration that does not depend on exchange A: the proposal (and, with the constraints off,
+// the final move) of every tile that holds no shared point.  Optional: smgpu_iter_mid does it when skipped.
+int smgpu_iter_interior(smgpu_handle* h) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    if (!h->useTiles || h->interiorDone) return 0;
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    const Prm prm = makePrm(h->prm);
+    if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, h->dInteriorTiles, h->nInteriorTiles)) return 1; }
+    else if (runSmooth<false>(h, h->mv, h->st, prm, h->dInteriorTiles, h->nInteriorTiles)) return 1;
+    h->interiorDone = true;
+    return 0;
+}
+
 int smgpu_iter_mid(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     HIP_OK(hipSetDevice(h->device));
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    const Prm prm = makePrm(h->prm);
+    if (h->useTiles && !h->interiorDone && smgpu_iter_interior(h)) return 1;
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_combineA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                    h->dCombSlots, h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err);
             })) return 1;
-    if (runProposalAndConstraints(h)) return 1;
+    if (h->useTiles) {
+        if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, h->dSharedTiles, h->nSharedTiles)) return 1; }
+        else if (runSmooth<false>(h, h->mv, h->st, prm, h->dSharedTiles, h->nSharedTiles)) return 1;
+        if (!fused && runConstraints(h)) return 1;
+    } else if (runProposalAndConstraints(h)) return 1;
     if (h->nSend)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
@@ -792,16 +850,31 @@ int smgpu_iter_end(smgpu_handle* h) {
     const MeshView& m = h->mv;
     State s = h->st;
     const Prm prm = makePrm(h->prm);
-    if (h->nShared && h->nRecv)
-        if (launchK(h, K_HALO, [&] {
-                hipLaunchKernelGGL(k_halo_orF, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dSharedLocal,
-                                   h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen);
-            })) return 1;
-    if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    int nPart;
+    if (fused && h->useTiles) {
+        // every non-shared point is already final; finish the shared ones (or of the freeze flags included)
+        const int gS = gridFor(h->nShared);
+        if (h->nShared)
+            if (launchK(h, K_HALO, [&] {
+                    hipLaunchKernelGGL(k_shared_fix, dim3(gS), dim3(kBlock), 0, h->stream, m, s, prm, h->nShared, h->dSharedLocal, h->dCombOff,
+                                       h->dCombSlots, h->recvF, h->stl.nTiles);
+                })) return 1;
+        nPart = h->stl.nTiles + (h->nShared ? gS : 0);
+    } else {
+        if (h->nShared && h->nRecv)
+            if (launchK(h, K_HALO, [&] {
+                    hipLaunchKernelGGL(k_halo_orF, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dSharedLocal,
+                                       h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen);
+                })) return 1;
+        if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        nPart = gridFor(m.nPoints);
+    }
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
-    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, gridFor(m.nPoints), h->haloIter, -1.0, h->localStats); })) return 1;
+    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
+    h->interiorDone = false;
     return 0;
 }
 

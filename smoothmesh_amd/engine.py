@@ -199,6 +199,9 @@ class SmoothEngine:
     def iter_begin(self):
         self._check(self._lib.smgpu_iter_begin(self._h))
 
+    def iter_interior(self):
+        self._check(self._lib.smgpu_iter_interior(self._h))
+
     def iter_mid(self):
         self._check(self._lib.smgpu_iter_mid(self._h))
 

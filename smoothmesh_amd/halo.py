@@ -126,14 +126,24 @@ class DistributedSmoother:
         # cannot, so device tensors are staged through the host for it
         return self.dist.get_backend() == "gloo" and self.device.type != "cpu"
 
-    def _a2a(self, recv, send):
+    def _a2a(self, recv, send, overlap=None):
+        """all_to_all of the packed shared-point records; `overlap` (a callable launching exchange-independent
+        kernels) runs while the collective is in flight on RCCL's stream."""
         n = self.tables.nSend
         if self.world == 1 or (n == 0 and self.tables.nRecv == 0):
+            if overlap:
+                overlap()
             return
         if self._staged():
             r = self.torch.empty_like(recv[:n], device="cpu")
             self.dist.all_to_all_single(r, send[:n].cpu(), self.counts, self.counts)
             recv[:n].copy_(r)
+            if overlap:
+                overlap()
+        elif overlap:
+            work = self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts, async_op=True)
+            overlap()
+            work.wait()      # orders the current stream after the collective; the host does not block
         else:
             self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts)
 
@@ -153,7 +163,7 @@ class DistributedSmoother:
             hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
             for i in range(centroidalIters):
                 eng.iter_begin()
-                self._a2a(st.recvA, st.sendA)               # SM.C:134-148, 402-478
+                self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
                 eng.iter_mid()
                 self._a2a(st.recvF, st.sendF)               # SM.C:2374
                 eng.iter_end()
@@ -171,7 +181,7 @@ class DistributedSmoother:
         local = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
         for i in range(centroidalIters):
             eng.iter_begin()
-            self._a2a(st.recvA, st.sendA)
+            self._a2a(st.recvA, st.sendA, eng.iter_interior)
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF)
             eng.iter_end()
@@ -240,6 +250,8 @@ class LocalMultiSmoother:
         for i in range(centroidalIters):
             for st in self.states:
                 st.eng.iter_begin()
+            for st in self.states:
+                st.eng.iter_interior()
             self._exchange("A")
             for st in self.states:
                 st.eng.iter_mid()
