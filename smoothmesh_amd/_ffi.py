@@ -96,6 +96,13 @@ def lib():
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C smoothmesh_amd/csrc` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same soname as /opt/rocm's).
+        # Whichever is loaded first serves both; if ours came first torch would later fail with "No HIP GPUs
+        # are available", so let torch (when present) load its runtime before libsmgpu.so is opened.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError = header/library mismatch

@@ -41,6 +41,49 @@ __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const doubl
         SMGPU_ELL_ENTRY(4 * c_ + 3, q_.w, BODY)                           \
     }
 
+// Same, with the first two chunks already in registers (Q0, Q1: loaded up front so that their latency
+// overlaps the LDS staging); rows wider than 8 entries fetch the remaining chunks here.
+#define SMGPU_ELL_CHUNK(C, Q, BODY)                                       \
+    {                                                                     \
+        SMGPU_ELL_ENTRY(4 * (C) + 0, (Q).x, BODY)                         \
+        SMGPU_ELL_ENTRY(4 * (C) + 1, (Q).y, BODY)                         \
+        SMGPU_ELL_ENTRY(4 * (C) + 2, (Q).z, BODY)                         \
+        SMGPU_ELL_ENTRY(4 * (C) + 3, (Q).w, BODY)                         \
+    }
+#define SMGPU_ELL_FOREACH_PRE(Q0, Q1, ROWS, W4, STRIDE, BODY)             \
+    {                                                                     \
+        if ((W4) > 0) SMGPU_ELL_CHUNK(0, Q0, BODY)                        \
+        if ((W4) > 1) SMGPU_ELL_CHUNK(1, Q1, BODY)                        \
+        for (int c_ = 2; c_ < (W4); ++c_) {                               \
+            const ushort4 q_ = (ROWS)[(size_t)c_ * (STRIDE)];             \
+            SMGPU_ELL_CHUNK(c_, q_, BODY)                                 \
+        }                                                                 \
+    }
+
+// Stage n elements (24-byte records picked by an ascending id list) into SoA LDS arrays.  All id loads
+// of a thread are issued first, then all record loads, then the LDS stores: two memory round trips per
+// tile instead of two per 256 elements.
+template <int T, int ROUNDS>
+__device__ __forceinline__ void stageRecords(const double* __restrict__ src, const int* __restrict__ ids, int n, double* x,
+                                             double* y, double* z, int tid) {
+    for (int base = 0; base < n; base += T * ROUNDS) {
+        int id[ROUNDS];
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int i = base + u * T + tid;
+            id[u] = (i < n) ? ids[i] : -1;
+        }
+        V3 v[ROUNDS];
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) v[u] = (id[u] >= 0) ? ldv(src, id[u]) : v3(0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < ROUNDS; ++u) {
+            const int i = base + u * T + tid;
+            if (id[u] >= 0) { x[i] = v[u].x; y[i] = v[u].y; z[i] = v[u].z; }
+        }
+    }
+}
+
 // Cell centres of the current coordinates for one tile of consecutive cells:
 // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols (.com v2412), staged through LDS.
 template <int T>
@@ -55,10 +98,7 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
     // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
     {
         const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
-        for (int i = tid; i < n; i += T) {
-            const V3 v = ldv(s.ptsCur, g.tpIds[b + i]);
-            px[i] = v.x; py[i] = v.y; pz[i] = v.z;
-        }
+        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, px, py, pz, tid);
     }
     __syncthreads();
 
@@ -165,30 +205,38 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     double* cx = lds;              double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
     double* nx = cz + g.maxCells;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
     const int tile = tileList ? tileList[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
+    // everything a thread needs from global memory besides the staged records is requested first, so that
+    // its latency overlaps the staging: point id, flags, own LDS slot, the first two ELL chunks of both rows
+    const int pi = g.ptBeg[tile] + tid;
+    const bool mine = pi < g.ptBeg[tile + 1];
+    const int wn4 = g.ppWidth[tile] >> 2, wc4 = g.pcWidth[tile] >> 2;
+    const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
+    const ushort4* pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
+    const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
+    int p = 0, selfL = 0;
+    ushort4 pp0 = padq, pp1 = padq, pc0 = padq, pc1 = padq;
+    if (mine) {
+        p = g.ptOrder[pi];
+        selfL = g.selfLoc[pi];
+        if (wn4 > 0) pp0 = ppRow[0];
+        if (wn4 > 1) pp1 = ppRow[T];
+        if (wc4 > 0) pc0 = pcRow[0];
+        if (wc4 > 1) pc1 = pcRow[T];
+    }
     {
         const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
-        for (int i = tid; i < n; i += T) {
-            const V3 v = ldv(s.cellCtr, g.tcIds[b + i]);
-            cx[i] = v.x; cy[i] = v.y; cz[i] = v.z;
-        }
         const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        for (int i = tid; i < n2; i += T) {
-            const V3 v = ldv(s.ptsCur, g.tnIds[b2 + i]);
-            nx[i] = v.x; ny[i] = v.y; nz[i] = v.z;
-        }
+        stageRecords<T, 3>(s.cellCtr, g.tcIds + b, n, cx, cy, cz, tid);
+        stageRecords<T, 3>(s.ptsCur, g.tnIds + b2, n2, nx, ny, nz, tid);
     }
     __syncthreads();
 
-    const int pi = g.ptBeg[tile] + tid;
     double dist = 0.0;
     int fcount = 0;
-    if (pi < g.ptBeg[tile + 1]) {
-        const int p = g.ptOrder[pi];
+    if (mine) {
         const uint8_t fl = m.pflags[p];
         const bool internal = fl & PF_INTERNAL;
-        const V3 cur = ldsv(nx, ny, nz, g.selfLoc[pi]);
-        const int wn4 = g.ppWidth[tile] >> 2;
-        const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
+        const V3 cur = ldsv(nx, ny, nz, selfL);
         V3 sum = v3(0, 0, 0), r1, r2, r3;
         double m1 = 0.0, m2 = 0.0, m3 = 0.0;   // mag(closestPoint1..3), SM.C:509-510
         int count = 0, hc = 0;
@@ -202,16 +250,14 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             count = (int)(pk & 0xffffffffll);
             hc = (int)(pk >> 32);
             m1 = mag(r1); m2 = mag(r2); m3 = mag(r3);
-            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+            SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 (void)j;
                 const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
                 if (len < shortestCur) shortestCur = len;
             })
         } else {
             if (internal) {   // SM.C:116-130
-                const int wc4 = g.pcWidth[tile] >> 2;
-                const ushort4* pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
-                SMGPU_ELL_FOREACH(pcRow, wc4, T, {
+                SMGPU_ELL_FOREACH_PRE(pc0, pc1, pcRow, wc4, T, {
                     sum = sum + ldsv(cx, cy, cz, e);
                     count = j + 1;
                 })
@@ -220,7 +266,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             double l1 = 0, l2 = 0, l3 = 0;
             int k1 = -1, k2 = -1, k3 = -1;
             unsigned q1 = 0, q2 = 0, q3 = 0;
-            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+            SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 // getPointDistance(neigh, cCoords) = |cCoords - neigh|; the same value serves SM.C:626
                 const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
                 if (len < shortestCur) shortestCur = len;
@@ -261,7 +307,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
         bool frozen = false;                                           // SM.C:611-648
         {
             double shortestNew = SMGPU_GREAT;
-            SMGPU_ELL_FOREACH(ppRow, wn4, T, {
+            SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 (void)j;
                 const double tn = mag(np - ldsv(nx, ny, nz, e & 0x7fff));
                 if (tn < shortestNew) shortestNew = tn;
