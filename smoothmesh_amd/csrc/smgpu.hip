@@ -256,9 +256,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         // capacities sized for a 160 KiB LDS: a tile must leave room for >= 2 workgroups per CU
         const int geomCells = envInt("SMGPU_GEOM_CELLS", h->geomT / 2);   // cells per tile (<= threads)
         const int capGP = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells, 1400));
-        const int capGF = envInt("SMGPU_GEOM_CAPF", std::min(6 * geomCells, 1400));
-        const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(8 * h->smoothT, 1500));
-        const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(8 * h->smoothT, 1500));
+        const int capGF = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells, 1400));   // two rounds of 256 face threads at 128 cells
+        const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500));
+        const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
         const bool morton = envInt("SMGPU_TILE_MORTON", 1) != 0;
         std::vector<uint8_t> internalMask((size_t)t.nPoints);
         for (int p = 0; p < t.nPoints; ++p) internalMask[(size_t)p] = (flags[(size_t)p] & PF_INTERNAL) ? 1 : 0;

@@ -1,0 +1,104 @@
+"""Edge cases of the HIP path: tiny and ragged meshes, high valence (wide ELL rows, pair-table fallback),
+polygon faces with many vertices, the direct-gather fallback kernels, error reporting."""
+import numpy as np
+import pytest
+
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+
+
+def _fan_mesh(nSpokes, nLayers=3, jitter=0.05, seed=1):
+    """prisms around an axis: the axis points have valence nSpokes + 2"""
+    from smoothmesh_amd.meshgen import extrude_surface
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0, 2 * np.pi, nSpokes, endpoint=False)
+    ring1 = np.stack([np.cos(ang), np.zeros(nSpokes), np.sin(ang)], axis=1)
+    ring2 = 2.0 * np.stack([np.cos(ang + 0.1), np.zeros(nSpokes), np.sin(ang + 0.1)], axis=1)
+    verts = np.concatenate([[[0.0, 0.0, 0.0]], ring1, ring2])
+    verts[1:1 + nSpokes] += jitter * rng.standard_normal((nSpokes, 3)) * [1, 0, 1]
+    faces = []
+    for i in range(nSpokes):
+        j = (i + 1) % nSpokes
+        faces.append([0, 1 + i, 1 + j])                                   # inner triangles
+        faces.append([1 + i, 1 + nSpokes + i, 1 + nSpokes + j, 1 + j])    # outer quads
+    return extrude_surface(verts, faces, nLayers=nLayers, thickness=1.0, direction=(0, 1, 0))
+
+
+def _compare(mesh, oracle_lib, iters=6, **over):
+    from smoothmesh_amd import SmoothEngine, default_params
+    o = oracle_lib.Oracle(mesh)
+    e = SmoothEngine(mesh)
+    p = default_params(o.mesh_stats()[0], **over)
+    o.set_params(p); e.set_params(p)
+    n_o, res_o, frz_o = o.iterate(iters, 0.0)
+    n_g, res_g, frz_g = e.iterate(iters, 0.0)
+    assert n_o == n_g and np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= 1e-13
+    return e
+
+
+@pytest.mark.parametrize("dims", [(1, 1, 1), (2, 1, 1), (3, 2, 1), (2, 2, 2)])
+def test_tiny_blocks(oracle_lib, dims):
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(*dims, jitter=0.2, seed=3)
+    _compare(m, oracle_lib)
+    _compare(m, oracle_lib, edgeAngleConstraint=False, faceAngleConstraint=False)
+
+
+@pytest.mark.parametrize("nSpokes", [5, 12, 20])
+def test_high_valence_fan(oracle_lib, nSpokes):
+    """valence nSpokes+2 on the axis: ELL rows wider than 8 entries; > 16 switches hasCommonCell to the
+    pointCells-intersection form (no pair table)"""
+    m = _fan_mesh(nSpokes)
+    _compare(m, oracle_lib, iters=8)
+    _compare(m, oracle_lib, iters=8, edgeAngleConstraint=False, faceAngleConstraint=False, minEdgeLength=0.3, totalMinFreeze=True)
+
+
+def test_zero_iterations_and_param_errors(oracle_lib):
+    from smoothmesh_amd import SmgpuError, SmoothEngine, SmoothParams, default_params
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(3, jitter=0.2)
+    e = SmoothEngine(m)
+    with pytest.raises(SmgpuError, match="set_params"):
+        e.iterate(1, 0.0)
+    with pytest.raises(SmgpuError, match="maxStepLength"):
+        e.set_params(SmoothParams(maxStepLength=0.0, minEdgeLength=0.1))
+    e.set_params(default_params(e.mesh_stats()[0]))
+    n, res, frz = e.iterate(0, 0.0)
+    assert n == 0 and len(res) == 0
+    assert np.array_equal(e.get_points(), m.points)
+    pts = m.points + 0.001
+    e.set_points(pts)
+    assert np.array_equal(e.get_points(), pts)
+
+
+def test_direct_gather_fallback_kernels(oracle_lib, monkeypatch):
+    """SMGPU_TILES=0: the one-thread-per-element kernels (used when a mesh does not fit the LDS tile tables)"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    monkeypatch.setenv("SMGPU_TILES", "0")
+    m = cavity_mesh(8, jitter=0.2, seed=5)
+    _compare(m, oracle_lib, iters=5)
+    _compare(m, oracle_lib, iters=5, edgeAngleConstraint=False, faceAngleConstraint=False)
+
+
+def test_natural_tile_order(oracle_lib, monkeypatch):
+    from smoothmesh_amd.meshgen import hex_block
+    monkeypatch.setenv("SMGPU_TILE_MORTON", "0")
+    _compare(hex_block(9, 7, 5, jitter=0.3, seed=2), oracle_lib)
+
+
+def test_counters_and_sizes(oracle_lib):
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(10, jitter=0.2)
+    e = SmoothEngine(m)
+    sz = e.sizes()
+    assert sz["nPoints"] == 1331 and sz["nCells"] == 1000 and sz["nEdges"] == 3 * 10 * 11 * 11
+    assert sz["nnzPointCells"] == 8 * 1000 and sz["nnzFacePoints"] == 4 * sz["nFaces"]
+    e.set_params(default_params(e.mesh_stats()[0]))
+    e.enable_timing(True)
+    e.iterate(5, 0.0)
+    c = {k["name"]: k for k in e.counters()}
+    assert c["k_geom_tile"]["launches"] == 5 and c["k_geom_tile"]["ms"] > 0
+    assert c["k_smooth<proposal>"]["algoBytesPerLaunch"] > 100 * 1331
