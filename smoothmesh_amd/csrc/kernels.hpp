@@ -364,14 +364,14 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle(MeshView m, State s, Prm 
     if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
 }
 
-// restrictMinEdgeAngleDecrease SM.C:900-930, wave-cooperative form: 8 lanes per point.
+// restrictMinEdgeAngleDecrease SM.C:900-930, wave-cooperative form: 4 lanes per point (measured best of 2, 4, 8).
 //  * every incident edge (p, q) appears in several of p's faces (4 in a hex mesh), so the three unit
 //    vectors per neighbour q -- (x_q - x_p)/|.|, (x_q - n_p)/|.|, (n_q - n_p)/|.| -- are formed ONCE per
 //    neighbour (lane j takes neighbour j) and shared through LDS instead of once per (face, corner);
 //  * the lanes then take the point's faces (5 dot products each) and keep the LARGEST clamped cosine;
 //    acos is evaluated only on the two extremes: min_i acos(c_i) = acos(max_i c_i) because acos is
 //    monotone (SM.C:880-886 take minima of angles; same operations on the same operands otherwise).
-constexpr int kEaLanes = 8;
+constexpr int kEaLanes = 4;
 constexpr int kEaPointsPerBlock = kBlock / kEaLanes;
 
 __device__ __forceinline__ double clampCos(double cosA) {
