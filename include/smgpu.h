@@ -75,7 +75,7 @@ typedef struct smgpu_sizes {
 } smgpu_sizes;
 
 /* Per-kernel accumulated device time (hipEvent, milliseconds) and launch counts. */
-#define SMGPU_MAX_KERNELS 16
+#define SMGPU_MAX_KERNELS 24
 typedef struct smgpu_counters {
     int32_t nKernels;
     const char* name[SMGPU_MAX_KERNELS];

@@ -37,7 +37,7 @@ class Sizes(C.Structure):
         "nnzPointPoints", "nnzPointFaces", "nnzEdgeFaces", "nnzEdgeCells", "nnzCellFaces", "deviceBytes")]
 
 
-MAX_KERNELS = 16
+MAX_KERNELS = 24
 
 
 class Counters(C.Structure):

@@ -380,7 +380,7 @@ __device__ __forceinline__ double clampCos(double cosA) {
     return (-MAXC < t) ? t : -MAXC;
 }
 
-__global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s, Prm prm, int maxEntries) {
+__global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s, Prm prm, int maxEntries, const uint8_t* eaMaybe) {
     if (s.acc->stop) return;
     extern __shared__ double lds[];
     double* U = lds;   // 9 arrays of maxEntries: ucc.xyz, uc.xyz, un.xyz
@@ -388,7 +388,9 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s,
     const int pBase = blockIdx.x * kEaPointsPerBlock;
     const int p = pBase + (tid / kEaLanes);
     const bool valid = p < m.nPoints;
-    const bool active = valid && !s.frozen[p];
+    // eaMaybe (may be NULL): points the f32 filter (kernels_filter.hpp) could not rule out
+    const bool active = valid && !s.frozen[p] && (!eaMaybe || eaMaybe[p]);
+    if (!__syncthreads_or(active ? 1 : 0)) return;   // nothing to decide in this workgroup
     const int e0 = m.ppOff[pBase];
     int nb = 0, nv = 0;
     V3 cp0 = v3(0, 0, 0), np0 = v3(0, 0, 0);
@@ -517,10 +519,12 @@ __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s
 // visited in ring order around the edge (Topology::ringFace): cell i sits between ring faces i and i+1,
 // so each projected face-centre vector is formed once and handed on (the reference forms them per
 // edge face too, SM.C:1183-1200; min/max over the cells do not depend on the visiting order).
-__global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s) {
+// faMaybe (may be NULL): only edges with an end point the filter could not rule out are evaluated.
+__global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const uint8_t* faMaybe) {
     if (s.acc->stop) return;
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= m.nEdges) return;
+    if (faMaybe && !(faMaybe[m.edges[2 * e]] | faMaybe[m.edges[2 * e + 1]])) return;
     double mn, mx;
     if (!m.edgeRingOk[e]) {
         const V3 z = v3(0, 0, 0);
@@ -558,10 +562,11 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s) {
 
 // mapCurrentMinMaxFaceAnglesToPoints SM.C:938-975 as a gather over pointEdges, plus the
 // good-range test SM.C:1367-1369 -- one thread per point.
-__global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm) {
+__global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm, const uint8_t* faMaybe) {
     if (s.acc->stop) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= m.nPoints) return;
+    if (faMaybe && !faMaybe[p]) return;   // k_fa_point_flags already cleared faActive: all its edges are GOOD
     double mn = 2.0 * SMGPU_PI, mx = 0.0;
     for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
         const int e = m.peEdge[k];

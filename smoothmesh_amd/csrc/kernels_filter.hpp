@@ -1,0 +1,263 @@
+// kernels_filter.hpp -- floating-point filters for the two angle evaluators.
+//
+// Both evaluators end in threshold tests (edge angle < minAngle, SM.C:923; face angles outside
+// (minAngle, maxAngle), SM.C:1367) and on a decent mesh almost every point / edge is far from the
+// thresholds, yet the exact f64 evaluation costs ~400 (edge, cell) / ~380 (point, face) FP64
+// instructions of sqrt / div / acos.  As in exact geometric predicates, a cheap conservative filter
+// runs first: the same quantity in f32 (difference vectors are formed in f64 first, so large
+// coordinates cannot cancel), with an error margin orders of magnitude above the f32 error bound.
+// Only elements the filter cannot decide are evaluated exactly, by the unchanged f64 kernels.
+// The filter never decides a borderline case, so frozen sets are identical to the unfiltered run.
+//
+// Error budget (angles in radians): unit vectors from f64 differences rounded to f32: <= 2e-7 per
+// component; a projection is trusted only if the in-plane part keeps > 1 % of the vector (else
+// UNSURE), so cancellation amplifies by < 100: < 2e-5; acos amplifies by 1/sqrt(1-x^2) <= 224 at the
+// clamp +-0.99999: < 5e-3 worst case at the clamp, < 1e-4 for |cos| < 0.999.  The margins below
+// (kFaMargin on angle sums, kEaMargin on cosines) are applied together with a guard that sends every
+// near-clamp cosine to the exact path.
+#pragma once
+#include "kernels.hpp"
+#include "kernels_tiled.hpp"
+
+namespace smgpu {
+
+constexpr float kFaMargin = 2.0e-3f;     // rad, on acos(a) + acos(b)
+constexpr float kEaMargin = 1.0e-3f;     // on a clamped cosine
+constexpr float kNearClamp = 0.999f;     // |cos| above this goes to the exact path
+
+struct F3 { float x, y, z; };
+__device__ __forceinline__ F3 f3(const V3& v) { F3 r; r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; return r; }
+__device__ __forceinline__ float fdot(const F3& a, const F3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ F3 fscale(const F3& a, float s) { F3 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
+__device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
+    const float n2 = fdot(a, a);
+    ok = ok && (n2 > 1.0e-30f) && (n2 < 1.0e30f);
+    return fscale(a, rsqrtf(n2));
+}
+
+// ---- face angles: per edge GOOD (0) / UNSURE (1) -------------------------------------------------------
+// GOOD = every cell angle of the edge lies inside (small + margin, large - margin) for sure.
+__global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s, Prm prm, uint8_t* edgeFlag) {
+    if (s.acc->stop) return;
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m.nEdges) return;
+    uint8_t flag = 1;
+    if (m.edgeRingOk[e]) {
+        const V3 e0 = ldv(s.ptsCur, m.edges[2 * e]), e1 = ldv(s.ptsCur, m.edges[2 * e + 1]);
+        const V3 cC = 0.5 * (e0 + e1);
+        bool ok = true;
+        const F3 eV = funit(f3(e1 - e0), ok);
+        // unit vector of the part of (c - cC) perpendicular to the edge (SM.C:1189-1196 up to rounding)
+        auto project = [&](const V3& c) -> F3 {
+            const F3 d = f3(c - cC);
+            const float t = fdot(d, eV);
+            F3 w; w.x = d.x - t * eV.x; w.y = d.y - t * eV.y; w.z = d.z - t * eV.z;
+            const float w2 = fdot(w, w), d2 = fdot(d, d);
+            ok = ok && (w2 > 1.0e-4f * d2);          // in-plane part keeps > 1 % of the vector
+            return funit(w, ok);
+        };
+        const int fb = m.efOff[e], nf = m.efOff[e + 1] - fb;
+        const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
+        const F3 first = project(ldv(s.fAvg, m.ringFace[fb]));
+        F3 prev = first;
+        const float lo = (float)prm.smallAngle + kFaMargin, hi = (float)prm.largeAngle - kFaMargin;
+        bool inside = true;
+        for (int i = 0; i < nc; ++i) {
+            const F3 next = (i + 1 < nf) ? project(ldv(s.fAvg, m.ringFace[fb + i + 1])) : first;
+            const F3 cV = project(ldv(s.cellCtr, m.ringCell[cb + i]));
+            const float a = fdot(prev, cV), b = fdot(cV, next);
+            ok = ok && (fabsf(a) < kNearClamp) && (fabsf(b) < kNearClamp);
+            const float ang = acosf(a) + acosf(b);
+            inside = inside && (ang > lo) && (ang < hi);     // NaN -> false -> UNSURE
+            prev = next;
+        }
+        if (ok && inside && nc > 0) flag = 0;
+    }
+    edgeFlag[e] = flag;
+}
+
+// a point may be outside the good range only if one of its edges is UNSURE
+__global__ void __launch_bounds__(kBlock) k_fa_point_flags(MeshView m, State s, const uint8_t* edgeFlag, uint8_t* faMaybe) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    uint8_t any = 0;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) any |= edgeFlag[m.peEdge[k]];
+    faMaybe[p] = any;
+    if (!any) s.faActive[p] = 0;     // every incident edge is GOOD: inside the good range for sure (SM.C:1367-1369)
+}
+
+// ---- edge angles: per point "may freeze" ----------------------------------------------------------------
+// A point is frozen iff minN < small && minN < minC (SM.C:923).  If every new-angle cosine is below
+// cos(small) - margin, minN > small for sure and the exact kernel can skip the point.
+__global__ void __launch_bounds__(kBlock) k_edge_angle_filter(MeshView m, State s, Prm prm, float cosSmall, uint8_t* eaMaybe) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    if (s.frozen[p]) { eaMaybe[p] = 0; return; }
+    const V3 np0 = ldv(s.prop, p);
+    const float thr = cosSmall - kEaMargin;
+    bool ok = true, below = true;
+    const int b = m.pfOff[p], e = m.pfOff[p + 1];
+    for (int k = b; k < e; ++k) {
+        const int a1 = m.pfPrev[k], a2 = m.pfNext[k];
+        const F3 uc1 = funit(f3(ldv(s.ptsCur, a1) - np0), ok), uc2 = funit(f3(ldv(s.ptsCur, a2) - np0), ok);
+        const F3 un1 = funit(f3(ldv(s.prop, a1) - np0), ok), un2 = funit(f3(ldv(s.prop, a2) - np0), ok);
+        const float c0 = fdot(uc1, uc2), c1 = fdot(un1, un2), c2 = fdot(uc1, un2), c3 = fdot(un1, uc2);
+        below = below && (c0 < thr) && (c1 < thr) && (c2 < thr) && (c3 < thr);   // NaN -> false -> exact path
+    }
+    eaMaybe[p] = (ok && below) ? 0 : 1;
+}
+
+// The same filter on the smoothing tiles: current and proposed coordinates of the tile's points and their
+// neighbours are staged in LDS once (the per-point form above gathers each neighbour 8 times from global
+// memory and is bound by those gathers, not by arithmetic); corner pairs come from the pfEll table.
+template <int T>
+__global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, SmoothTileView g, float cosSmall, uint8_t* eaMaybe) {
+    if (s.acc->stop) return;
+    extern __shared__ double lds[];
+    double* cx = lds;               double* cy = cx + g.maxPoints; double* cz = cy + g.maxPoints;
+    double* nx = cz + g.maxPoints;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int pi = g.ptBeg[tile] + tid;
+    const bool mine = pi < g.ptBeg[tile + 1];
+    const int wf4 = g.pfWidth[tile] >> 2;
+    const ushort4* row = reinterpret_cast<const ushort4*>(g.pfEll + g.pfBase[tile]) + tid;
+    const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
+    int p = 0, selfL = 0;
+    ushort4 q0 = padq, q1 = padq;
+    if (mine) {
+        p = g.ptOrder[pi];
+        selfL = g.selfLoc[pi];
+        if (wf4 > 0) q0 = row[0];
+        if (wf4 > 1) q1 = row[T];
+    }
+    {
+        const int b = g.tnOff[tile], n = g.tnOff[tile + 1] - b;
+        stageRecords<T, 3>(s.ptsCur, g.tnIds + b, n, cx, cy, cz, tid);
+        stageRecords<T, 3>(s.prop, g.tnIds + b, n, nx, ny, nz, tid);
+    }
+    __syncthreads();
+    if (!mine) return;
+    if (s.frozen[p]) { eaMaybe[p] = 0; return; }
+    const V3 np0 = ldsv(nx, ny, nz, selfL);
+    const float thr = cosSmall - kEaMargin;
+    bool ok = true, below = true;
+#define SMGPU_EA_CORNER(A1, A2)                                                                                   \
+    if ((A1) != kPad) {                                                                                           \
+        const F3 uc1 = funit(f3(ldsv(cx, cy, cz, (A1)) - np0), ok), uc2 = funit(f3(ldsv(cx, cy, cz, (A2)) - np0), ok); \
+        const F3 un1 = funit(f3(ldsv(nx, ny, nz, (A1)) - np0), ok), un2 = funit(f3(ldsv(nx, ny, nz, (A2)) - np0), ok); \
+        const float c0 = fdot(uc1, uc2), c1 = fdot(un1, un2), c2 = fdot(uc1, un2), c3 = fdot(un1, uc2);            \
+        below = below && (c0 < thr) && (c1 < thr) && (c2 < thr) && (c3 < thr);                                    \
+    }
+    if (wf4 > 0) { SMGPU_EA_CORNER(q0.x, q0.y) SMGPU_EA_CORNER(q0.z, q0.w) }
+    if (wf4 > 1) { SMGPU_EA_CORNER(q1.x, q1.y) SMGPU_EA_CORNER(q1.z, q1.w) }
+    for (int c = 2; c < wf4; ++c) {
+        const ushort4 q = row[(size_t)c * T];
+        SMGPU_EA_CORNER(q.x, q.y) SMGPU_EA_CORNER(q.z, q.w)
+    }
+#undef SMGPU_EA_CORNER
+    eaMaybe[p] = (ok && below) ? 0 : 1;
+}
+
+struct EdgeTileView {
+    const int* order; const int* edgeBeg;
+    const int* tpOff; const int* tpIds; const int* tfOff; const int* tfIds; const int* tcOff; const int* tcIds;
+    const uint16_t* epLoc;
+    const int* efBase; const int* ecBase; const uint8_t* efWidth; const uint8_t* ecWidth;
+    const uint16_t* efEll; const uint16_t* ecEll;
+    int maxPoints, maxFaces, maxCells;
+};
+
+// k_fa_edges_filter on edge tiles: the end points, the face vertex averages and the cell centres the tile's
+// edges need are staged in LDS (the per-edge form gathers ~10 records of 24 bytes per edge from global memory
+// and is bound by those gathers).  Ring order as in k_fa_edges: cell i lies between ring faces i and i+1.
+template <int T>
+__global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTileView g, uint8_t* edgeFlag) {
+    if (s.acc->stop) return;
+    extern __shared__ double lds[];
+    double* px = lds;                 double* py = px + g.maxPoints; double* pz = py + g.maxPoints;
+    double* fx = pz + g.maxPoints;    double* fy = fx + g.maxFaces;  double* fz = fy + g.maxFaces;
+    double* cx = fz + g.maxFaces;     double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int ei = g.edgeBeg[tile] + tid;
+    const bool mine = ei < g.edgeBeg[tile + 1];
+    const int wf4 = g.efWidth[tile] >> 2, wc4 = g.ecWidth[tile] >> 2;
+    const ushort4* fRow = reinterpret_cast<const ushort4*>(g.efEll + g.efBase[tile]) + tid;
+    const ushort4* cRow = reinterpret_cast<const ushort4*>(g.ecEll + g.ecBase[tile]) + tid;
+    const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
+    int e = 0;
+    unsigned ep = 0;
+    ushort4 f0 = padq, f1 = padq, c0 = padq, c1 = padq;
+    if (mine) {
+        e = g.order[ei];
+        ep = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
+        if (wf4 > 0) f0 = fRow[0];
+        if (wf4 > 1) f1 = fRow[T];
+        if (wc4 > 0) c0 = cRow[0];
+        if (wc4 > 1) c1 = cRow[T];
+    }
+    {
+        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
+        const int b2 = g.tfOff[tile], n2 = g.tfOff[tile + 1] - b2;
+        const int b3 = g.tcOff[tile], n3 = g.tcOff[tile + 1] - b3;
+        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, px, py, pz, tid);
+        stageRecords<T, 3>(s.fAvg, g.tfIds + b2, n2, fx, fy, fz, tid);
+        stageRecords<T, 2>(s.cellCtr, g.tcIds + b3, n3, cx, cy, cz, tid);
+    }
+    __syncthreads();
+    if (!mine) return;
+    uint8_t flag = 1;
+    if (f0.x != kPad) {
+        const V3 e0 = ldsv(px, py, pz, ep & 0xffff), e1 = ldsv(px, py, pz, ep >> 16);
+        const V3 cC = 0.5 * (e0 + e1);
+        bool ok = true, inside = true;
+        const F3 eV = funit(f3(e1 - e0), ok);
+        const float lo = (float)prm.smallAngle + kFaMargin, hi = (float)prm.largeAngle - kFaMargin;
+        F3 first = {0, 0, 0}, prev = {0, 0, 0}, cPend = {0, 0, 0};
+        bool pend = false;
+#define SMGPU_FA_PROJECT(OUT, C)                                                        \
+        {                                                                               \
+            const F3 d_ = f3((C) - cC);                                                 \
+            const float t_ = fdot(d_, eV);                                              \
+            F3 w_; w_.x = d_.x - t_ * eV.x; w_.y = d_.y - t_ * eV.y; w_.z = d_.z - t_ * eV.z; \
+            ok = ok && (fdot(w_, w_) > 1.0e-4f * fdot(d_, d_));                        \
+            OUT = funit(w_, ok);                                                        \
+        }
+#define SMGPU_FA_EVAL(NEXT)                                                             \
+        {                                                                               \
+            const float a_ = fdot(prev, cPend), b_ = fdot(cPend, (NEXT));               \
+            ok = ok && (fabsf(a_) < kNearClamp) && (fabsf(b_) < kNearClamp);            \
+            const float ang_ = acosf(a_) + acosf(b_);                                   \
+            inside = inside && (ang_ > lo) && (ang_ < hi);                              \
+        }
+#define SMGPU_FA_STEP(J, FE, CE)                                                        \
+        if ((FE) != kPad) {                                                             \
+            F3 nx_;                                                                     \
+            SMGPU_FA_PROJECT(nx_, ldsv(fx, fy, fz, (FE)))                               \
+            if ((J) == 0) { first = nx_; }                                              \
+            else if (pend) { SMGPU_FA_EVAL(nx_) pend = false; }                          \
+            prev = nx_;                                                                 \
+        }                                                                               \
+        if ((CE) != kPad) { SMGPU_FA_PROJECT(cPend, ldsv(cx, cy, cz, (CE))) pend = true; }
+#define SMGPU_FA_CHUNK(CIDX, FQ, CQ)                                                    \
+        SMGPU_FA_STEP(4 * (CIDX) + 0, (FQ).x, (CQ).x) SMGPU_FA_STEP(4 * (CIDX) + 1, (FQ).y, (CQ).y)   \
+        SMGPU_FA_STEP(4 * (CIDX) + 2, (FQ).z, (CQ).z) SMGPU_FA_STEP(4 * (CIDX) + 3, (FQ).w, (CQ).w)
+        SMGPU_FA_CHUNK(0, f0, c0)
+        if (wf4 > 1) { SMGPU_FA_CHUNK(1, f1, c1) }
+        for (int c = 2; c < wf4; ++c) {
+            const ushort4 fq = fRow[(size_t)c * T];
+            const ushort4 cq = (c < wc4) ? cRow[(size_t)c * T] : padq;
+            SMGPU_FA_CHUNK(c, fq, cq)
+        }
+        if (pend) { SMGPU_FA_EVAL(first) }   // closed ring: the last cell lies between the last and the first face
+#undef SMGPU_FA_CHUNK
+#undef SMGPU_FA_STEP
+#undef SMGPU_FA_EVAL
+#undef SMGPU_FA_PROJECT
+        if (ok && inside) flag = 0;
+    }
+    edgeFlag[e] = flag;
+}
+
+}  // namespace smgpu

@@ -22,6 +22,7 @@ struct SmoothTileView {
     const int* pcBase; const uint8_t* pcWidth; const uint16_t* pcEll;
     const int* ppBase; const uint8_t* ppWidth; const uint16_t* ppEll;   // bit 15: the neighbour is an internal point
     const uint16_t* pairEll;
+    const int* pfBase; const uint8_t* pfWidth; const uint16_t* pfEll;   // (prev, next) vertex per (point, face)
     int maxCells, maxPoints, usePairShare;
 };
 

@@ -12,6 +12,7 @@
 #include "kernels.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_walk.hpp"
+#include "kernels_filter.hpp"
 #include "tiles.hpp"
 #include "topology.hpp"
 
@@ -29,10 +30,10 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     } while (0)
 
 enum KernelId { K_FACE_GEOM = 0, K_CELL_CENTRES, K_SMOOTH_FINAL, K_SMOOTH_PROP, K_EDGE_ANGLE, K_FA_EDGES,
-                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_COUNT };
+                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_EA_FILTER, K_FA_FILTER, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_face_geom", "k_cell_centres", "k_smooth<final>", "k_smooth<proposal>",
                                             "k_edge_angle", "k_fa_edges", "k_fa_points", "k_fa_pred", "k_fa_walk",
-                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile"};
+                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile", "k_edge_angle_filter", "k_fa_edges_filter+flags"};
 
 struct smgpu_handle {
     Topology topo;
@@ -87,6 +88,13 @@ struct smgpu_handle {
     size_t pinnedBytes = 0;
     std::vector<uint8_t> walkFrozen;
     std::vector<int> walkStack, walkOut;
+    // f32 filters in front of the two angle evaluators (kernels_filter.hpp); SMGPU_FILTER=0 disables
+    bool useFilter = true, exactAll = false;
+    uint8_t *dEdgeFlag = nullptr, *dFaMaybe = nullptr, *dEaMaybe = nullptr;
+    EdgeTiles etl;
+    EdgeTileView ev{};
+    bool edgeTilesOk = false;
+    size_t edgeLds = 0;
     bool eaCoop = true;        // wave-cooperative edge-angle kernel (SMGPU_EDGE_ANGLE=faithful selects the per-angle acos form)
     int eaMaxEntries = 0;
 };
@@ -187,6 +195,8 @@ static void computeAlgoBytes(smgpu_handle* h) {
     b[K_HALO] = 0;
     // fused geometry: points + face/cell index lists + cell centres (no face arrays round trip)
     b[K_GEOM_TILE] = 24 * P + 4 * (F + 1) + 4 * nfp + 4 * (C + 1) + 4 * ncf + 24 * C + (fa ? 24 * F : 0);
+    b[K_EA_FILTER] = b[K_EDGE_ANGLE];
+    b[K_FA_FILTER] = b[K_FA_EDGES] - 16 * E + E + 4 * (P + 1) + 4 * npp + P;
 }
 
 extern "C" {
@@ -248,6 +258,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (rc) return cleanup(1);
     // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
+    h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -296,8 +307,35 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &v.ppWidth, h->stl.ppWidth);
             rc |= devUpload(h, &v.ppEll, h->stl.ppEll);
             rc |= devUpload(h, &v.pairEll, h->stl.pairEll);
+            rc |= devUpload(h, &v.pfBase, h->stl.pfBase);
+            rc |= devUpload(h, &v.pfWidth, h->stl.pfWidth);
+            rc |= devUpload(h, &v.pfEll, h->stl.pfEll);
             v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
             v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
+            if (h->useFilter) {
+                const std::string e3 = h->etl.build(t, d->points, morton, 256, 512, 768, 512);
+                if (e3.empty()) {
+                    EdgeTileView& ev = h->ev;
+                    rc |= devUpload(h, &ev.order, h->etl.order);
+                    rc |= devUpload(h, &ev.edgeBeg, h->etl.edgeBeg);
+                    rc |= devUpload(h, &ev.tpOff, h->etl.tpOff);
+                    rc |= devUpload(h, &ev.tpIds, h->etl.tpIds);
+                    rc |= devUpload(h, &ev.tfOff, h->etl.tfOff);
+                    rc |= devUpload(h, &ev.tfIds, h->etl.tfIds);
+                    rc |= devUpload(h, &ev.tcOff, h->etl.tcOff);
+                    rc |= devUpload(h, &ev.tcIds, h->etl.tcIds);
+                    rc |= devUpload(h, &ev.epLoc, h->etl.epLoc);
+                    rc |= devUpload(h, &ev.efBase, h->etl.efBase);
+                    rc |= devUpload(h, &ev.ecBase, h->etl.ecBase);
+                    rc |= devUpload(h, &ev.efWidth, h->etl.efWidth);
+                    rc |= devUpload(h, &ev.ecWidth, h->etl.ecWidth);
+                    rc |= devUpload(h, &ev.efEll, h->etl.efEll);
+                    rc |= devUpload(h, &ev.ecEll, h->etl.ecEll);
+                    ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
+                    h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
+                    h->edgeTilesOk = h->edgeLds <= 64 * 1024;
+                }
+            }
             if (rc) return cleanup(1);
             h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + 6 * (size_t)g.maxFaces);
             h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
@@ -331,6 +369,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.ptMin, P);
     rc |= devAlloc(h, &s.ptMax, P);
     rc |= devAlloc(h, &s.faActive, P);
+    rc |= devAlloc(h, &h->dEdgeFlag, E);
+    rc |= devAlloc(h, &h->dFaMaybe, P);
+    rc |= devAlloc(h, &h->dEaMaybe, P);
     rc |= devAlloc(h, &s.faS, P);
     rc |= devAlloc(h, &s.faN, (size_t)t.pointEdges.nnz());
     rc |= devAlloc(h, &s.walkStack, P + 64);
@@ -592,17 +633,40 @@ static int runConstraints(smgpu_handle* h) {
     State s = h->st;
     const Prm prm = makePrm(h->prm);
     const int gP = gridFor(m.nPoints);
+    const bool filt = h->useFilter && !h->exactAll;
     if (h->prm.edgeAngleConstraint) {
+        const uint8_t* eaMaybe = nullptr;
+        if (filt && h->eaCoop) {
+            const float cosSmall = (float)std::cos(prm.smallAngle);
+            if (h->useTiles && h->smoothT == 256) {
+                const size_t ldsB = sizeof(double) * 6 * (size_t)h->sv.maxPoints;
+                if (launchK(h, K_EA_FILTER, [&] {
+                        hipLaunchKernelGGL(k_ea_filter_tile<256>, dim3(h->stl.nTiles), dim3(256), ldsB, h->stream, m, s, h->sv, cosSmall, h->dEaMaybe);
+                    })) return 1;
+            } else if (launchK(h, K_EA_FILTER, [&] { hipLaunchKernelGGL(k_edge_angle_filter, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, cosSmall, h->dEaMaybe); })) return 1;
+            eaMaybe = h->dEaMaybe;
+        }
         if (h->eaCoop) {
             if (launchK(h, K_EDGE_ANGLE, [&] {
                     hipLaunchKernelGGL(k_edge_angle_coop, dim3((m.nPoints + kEaPointsPerBlock - 1) / kEaPointsPerBlock), dim3(kBlock),
-                                       sizeof(double) * 9 * (size_t)h->eaMaxEntries, h->stream, m, s, prm, h->eaMaxEntries);
+                                       sizeof(double) * 9 * (size_t)h->eaMaxEntries, h->stream, m, s, prm, h->eaMaxEntries, eaMaybe);
                 })) return 1;
         } else if (launchK(h, K_EDGE_ANGLE, [&] { hipLaunchKernelGGL(k_edge_angle, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     }
     if (h->prm.faceAngleConstraint) {
-        if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
-        if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        const uint8_t* faMaybe = nullptr;
+        if (filt) {
+            if (launchK(h, K_FA_FILTER, [&] {
+                    if (h->edgeTilesOk)
+                        hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(h->etl.nTiles), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, h->dEdgeFlag);
+                    else
+                        hipLaunchKernelGGL(k_fa_edges_filter, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, prm, h->dEdgeFlag);
+                    hipLaunchKernelGGL(k_fa_point_flags, dim3(gP), dim3(kBlock), 0, h->stream, m, s, h->dEdgeFlag, h->dFaMaybe);
+                })) return 1;
+            faMaybe = h->dFaMaybe;
+        }
+        if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
+        if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
         if (h->walkMode < 0) {
             // decide once per parameter set: read how many points lie outside the good range now (one sync)
             const char* env = std::getenv("SMGPU_HOST_WALK");
@@ -888,7 +952,12 @@ int smgpu_debug_propose(smgpu_handle* h) {
     const int rcg = runGeometry(h);
     h->writeFaces = false;
     if (rcg) return 1;
-    if (runProposalAndConstraints(h)) return 1;
+    // the debug fields (edge / point angles) are only complete without the filters; SMGPU_DEBUG_FILTERED=1
+    // keeps them on so tests can compare the decisions of the filtered path
+    h->exactAll = envInt("SMGPU_DEBUG_FILTERED", 0) == 0;
+    const int rcp = runProposalAndConstraints(h);
+    h->exactAll = false;
+    if (rcp) return 1;
     return checkDeviceError(h);
 }
 

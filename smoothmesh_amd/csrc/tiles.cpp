@@ -195,14 +195,16 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     tcIds.clear(); tnIds.clear();
     selfLoc.assign((size_t)t.nPoints, 0);
     pcBase.clear(); pcWidth.clear(); pcEll.clear(); ppBase.clear(); ppWidth.clear(); ppEll.clear(); pairEll.clear();
+    pfBase.clear(); pfWidth.clear(); pfEll.clear();
     const bool pairs = t.maxPointPoints <= 16;
     std::vector<int32_t> cells, pts;
     for (int32_t ti = 0; ti < nTiles; ++ti) {
         cells.clear(); pts.clear();
         const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
-        int32_t wc = 0, wn = 0;
+        int32_t wc = 0, wn = 0, wf = 0;
         for (int32_t pi = pb; pi < pend; ++pi) {
             const int32_t p = order[(size_t)pi];
+            wf = std::max(wf, 2 * (t.pointFaces.off[p + 1] - t.pointFaces.off[p]));
             wc = std::max(wc, pc.off[p + 1] - pc.off[p]);
             wn = std::max(wn, pe.off[p + 1] - pe.off[p]);
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
@@ -213,8 +215,8 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
         }
         std::sort(cells.begin(), cells.end());
         std::sort(pts.begin(), pts.end());
-        wc = roundUp4(wc); wn = roundUp4(wn);
-        if ((int32_t)cells.size() > 32766 || (int32_t)pts.size() > 32766 || wc > 252 || wn > 252)
+        wc = roundUp4(wc); wn = roundUp4(wn); wf = roundUp4(wf);
+        if ((int32_t)cells.size() > 32766 || (int32_t)pts.size() > 32766 || wc > 252 || wn > 252 || wf > 252)
             return "tile too large for the 15-bit local index tables";
         for (size_t i = 0; i < cells.size(); ++i) locC[cells[i]] = (int32_t)i;
         for (size_t i = 0; i < pts.size(); ++i) locN[pts[i]] = (int32_t)i;
@@ -228,10 +230,17 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
         pcEll.resize(cbase + (size_t)wc * threads, kEllPad);
         ppEll.resize(nbase + (size_t)wn * threads, kEllPad);
         pairEll.resize(nbase + (size_t)wn * threads, 0);
+        pfBase.push_back((int32_t)pfEll.size()); pfWidth.push_back((uint8_t)wf);
+        const size_t fbase = pfEll.size();
+        pfEll.resize(fbase + (size_t)wf * threads, kEllPad);
         for (int32_t pi = pb; pi < pend; ++pi) {
             const int32_t p = order[(size_t)pi];
             const int32_t tl = pi - pb;
             selfLoc[(size_t)pi] = (uint16_t)locN[p];
+            for (int32_t k = t.pointFaces.off[p], j = 0; k < t.pointFaces.off[p + 1]; ++k, j += 2) {
+                pfEll[fbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[t.pfPrev[k]];
+                pfEll[fbase + ((size_t)((j + 1) / 4) * threads + tl) * 4 + ((j + 1) % 4)] = (uint16_t)locN[t.pfNext[k]];
+            }
             for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
                 pcEll[cbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[pc.val[k]];
             const int32_t b = pe.off[p], v = pe.off[p + 1] - b;
@@ -259,7 +268,92 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
         }
         maxCells = std::max(maxCells, (int32_t)cells.size());
         maxPoints = std::max(maxPoints, (int32_t)pts.size());
-        if (pcEll.size() > 0x7fffffffu || ppEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
+        if (pcEll.size() > 0x7fffffffu || ppEll.size() > 0x7fffffffu || pfEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    }
+    return "";
+}
+
+std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
+                             int32_t capFaces, int32_t capCells) {
+    threads = nThreads;
+    const int32_t nE = t.nEdges;
+    if (morton) {
+        std::vector<double> mid(3 * (size_t)nE);
+        for (int32_t e = 0; e < nE; ++e)
+            for (int a = 0; a < 3; ++a) mid[3 * (size_t)e + a] = 0.5 * (xyz[3 * (size_t)t.edges[2 * e] + a] + xyz[3 * (size_t)t.edges[2 * e + 1] + a]);
+        order = mortonOrder(nE, mid);
+    } else order = naturalOrder(nE);
+    const auto& ef = t.edgeFaces;
+    const auto& ec = t.edgeCells;
+    std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
+    edgeBeg.assign(1, 0);
+    int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
+    for (int32_t ei = 0; ei < nE; ++ei) {
+        const int32_t e = order[(size_t)ei];
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int32_t aP = 0, aF = 0, aC = 0;
+            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
+            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
+            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
+            if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
+                edgeBeg.push_back(ei);
+                ++tile; nP = nF = nC = nT = 0;
+                continue;
+            }
+            if (aP > capPoints || aF > capFaces || aC > capCells) return "a single edge exceeds the LDS tile capacity";
+            nP += aP; nF += aF; nC += aC; ++nT;
+            break;
+        }
+    }
+    edgeBeg.push_back(nE);
+    nTiles = (int32_t)edgeBeg.size() - 1;
+    std::fill(stP.begin(), stP.end(), -1); std::fill(stF.begin(), stF.end(), -1); std::fill(stC.begin(), stC.end(), -1);
+    std::vector<int32_t> locP((size_t)t.nPoints, -1), locF((size_t)t.nFaces, -1), locC((size_t)t.nCells, -1);
+    tpOff.assign(1, 0); tfOff.assign(1, 0); tcOff.assign(1, 0);
+    tpIds.clear(); tfIds.clear(); tcIds.clear(); efBase.clear(); ecBase.clear(); efWidth.clear(); ecWidth.clear(); efEll.clear(); ecEll.clear();
+    epLoc.assign(2 * (size_t)nE, 0);
+    std::vector<int32_t> pts, fcs, cls;
+    for (int32_t ti = 0; ti < nTiles; ++ti) {
+        pts.clear(); fcs.clear(); cls.clear();
+        const int32_t eb = edgeBeg[ti], ee = edgeBeg[ti + 1];
+        int32_t wf = 0, wc = 0;
+        for (int32_t ei = eb; ei < ee; ++ei) {
+            const int32_t e = order[(size_t)ei];
+            wf = std::max(wf, ef.off[e + 1] - ef.off[e]);
+            wc = std::max(wc, ec.off[e + 1] - ec.off[e]);
+            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != ti) { stP[p] = ti; pts.push_back(p); } }
+            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != ti) { stF[f] = ti; fcs.push_back(f); } }
+            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != ti) { stC[cI] = ti; cls.push_back(cI); } }
+        }
+        std::sort(pts.begin(), pts.end()); std::sort(fcs.begin(), fcs.end()); std::sort(cls.begin(), cls.end());
+        wf = roundUp4(wf); wc = roundUp4(wc);
+        if (pts.size() > 32766 || fcs.size() > 32766 || cls.size() > 32766 || wf > 252 || wc > 252)
+            return "tile too large for the 15-bit local index tables";
+        for (size_t i = 0; i < pts.size(); ++i) locP[pts[i]] = (int32_t)i;
+        for (size_t i = 0; i < fcs.size(); ++i) locF[fcs[i]] = (int32_t)i;
+        for (size_t i = 0; i < cls.size(); ++i) locC[cls[i]] = (int32_t)i;
+        tpIds.insert(tpIds.end(), pts.begin(), pts.end()); tpOff.push_back((int32_t)tpIds.size());
+        tfIds.insert(tfIds.end(), fcs.begin(), fcs.end()); tfOff.push_back((int32_t)tfIds.size());
+        tcIds.insert(tcIds.end(), cls.begin(), cls.end()); tcOff.push_back((int32_t)tcIds.size());
+        efBase.push_back((int32_t)efEll.size()); efWidth.push_back((uint8_t)wf);
+        ecBase.push_back((int32_t)ecEll.size()); ecWidth.push_back((uint8_t)wc);
+        const size_t fb = efEll.size(), cb = ecEll.size();
+        efEll.resize(fb + (size_t)wf * threads, kEllPad);
+        ecEll.resize(cb + (size_t)wc * threads, kEllPad);
+        for (int32_t ei = eb; ei < ee; ++ei) {
+            const int32_t e = order[(size_t)ei], tl = ei - eb;
+            epLoc[2 * (size_t)ei] = (uint16_t)locP[t.edges[2 * e]];
+            epLoc[2 * (size_t)ei + 1] = (uint16_t)locP[t.edges[2 * e + 1]];
+            if (!t.edgeRingOk[(size_t)e]) continue;   // all-pad rows: the kernel flags the edge UNSURE
+            for (int32_t k = ef.off[e], j = 0; k < ef.off[e + 1]; ++k, ++j)
+                efEll[fb + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locF[t.ringFace[k]];
+            for (int32_t k = ec.off[e], j = 0; k < ec.off[e + 1]; ++k, ++j)
+                ecEll[cb + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[t.ringCell[k]];
+        }
+        maxPoints = std::max(maxPoints, (int32_t)pts.size());
+        maxFaces = std::max(maxFaces, (int32_t)fcs.size());
+        maxCells = std::max(maxCells, (int32_t)cls.size());
+        if (efEll.size() > 0x7fffffffu || ecEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
     }
     return "";
 }

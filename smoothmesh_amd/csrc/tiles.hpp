@@ -67,11 +67,33 @@ struct SmoothTiles {
     // pairEll entry (p, i): bit j set <=> neighbours i and j of p share a cell (pointNeighPoints
     // membership, SM.C:383); valid while valence <= 16, else the kernel intersects pointCells lists
     std::vector<uint16_t> pairEll;
+    // pfEll: per (point, face) the LDS-local indices of the previous and the next vertex of the point in the
+    // face (getNeighbourPoints SM.C:793-831), two entries per face, width pfWidth (multiple of 4)
+    std::vector<int32_t> pfBase;
+    std::vector<uint8_t> pfWidth;
+    std::vector<uint16_t> pfEll;
     int32_t maxCells = 0, maxPoints = 0;
     std::vector<int32_t> order;     // tile order: position -> point id (see GeomTiles::order)
     // isInternal (SM.C:40-91) marks bit 15 of the ppEll entries whose neighbour is an internal point (SM.C:294)
     std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
                       int32_t capCells, int32_t capPoints);
+};
+
+// ---- face-angle filter: tile = edges (Morton order of the edge midpoints); LDS holds the points, the
+// face vertex averages and the cell centres the tile's edges need ------------------------------------------
+struct EdgeTiles {
+    int32_t nTiles = 0, threads = 0;
+    std::vector<int32_t> order;     // position -> edge id
+    std::vector<int32_t> edgeBeg;   // nTiles+1
+    std::vector<int32_t> tpOff, tpIds, tfOff, tfIds, tcOff, tcIds;   // unique points / faces / cells per tile
+    std::vector<uint16_t> epLoc;    // 2 per tile position: LDS-local ids of the edge's end points
+    std::vector<int32_t> efBase, ecBase;        // nTiles
+    std::vector<uint8_t> efWidth, ecWidth;      // multiples of 4
+    std::vector<uint16_t> efEll, ecEll;         // ring faces / ring cells (Topology::ringFace/ringCell), sliced ELL;
+                                                // an edge without a ring (non-manifold) has an all-pad face row
+    int32_t maxPoints = 0, maxFaces = 0, maxCells = 0;
+    std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
+                      int32_t capFaces, int32_t capCells);
 };
 
 }  // namespace smgpu

@@ -218,3 +218,29 @@ def test_polyhedral_cavity_mesh(oracle_lib, constraints):
     n_g, res_g, frz_g = e.iterate(12, 0.0)
     assert np.array_equal(frz_o, frz_g)
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
+
+
+@pytest.mark.parametrize("kind,arg,jit", [("hex", (9, 8, 7), 0.3), ("hex", (8, 7, 6), 0.47), ("cavity", 10, 0.2)])
+def test_filtered_path_makes_the_same_decisions(oracle_lib, monkeypatch, kind, arg, jit):
+    """The f32 filters (kernels_filter.hpp) only skip elements that are certainly far from the thresholds: the
+    active set and the frozen set after the three evaluators must equal the unfiltered run's and the oracle's."""
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.polymesh import cavity_mesh
+    mesh = _mk(*arg, jit, 23) if kind == "hex" else cavity_mesh(arg, jitter=jit, seed=23)
+    o = oracle_lib.Oracle(mesh)
+    p = default_params(o.mesh_stats()[0], minAngle=45.0, maxAngle=150.0)
+    o.set_params(p)
+    o.phaseA(); o.phaseB()
+    small, large = np.pi * 45 / 180, np.pi * 150 / 180
+    act_ref = ~((o.field("pointMinAngle") > small) & (o.field("pointMaxAngle") < large))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SMGPU_DEBUG_FILTERED", mode)
+        e = SmoothEngine(mesh)
+        e.set_params(p)
+        e.debug_propose()
+        out[mode] = (e.debug_field("isFrozenPoint"), e.debug_field("faActive"))
+        e.close()
+    assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
+    assert np.array_equal(out["1"][0], o.field("frozenAfterFaceAngle"))
+    assert np.array_equal(out["1"][1].astype(bool), act_ref)
