@@ -28,6 +28,12 @@ struct WalkView {
     int* entNbr;          // neighbour point id
     int* entSlot;         // neighbour's slot or -1
     uint8_t* entBits;     // bit0 N(moved), bit1 N(frozen), bit2 neighbour moving, bit3 neighbour frozen before the walk
+    // second compaction: only points that can act (a true self bit or a true neighbour bit) and only their
+    // true entries travel to the host; every other active point is a pure sink in the walk
+    int* relSlot;         // [nActive] slot among the relevant points or -1
+    int* header2;         // {nRelevant, nBadEntries}
+    int* relIds; int* relEntOff; uint8_t* relBits;
+    int* badNbr; int* badSlot; uint8_t* badBits;
 };
 
 __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
@@ -138,6 +144,78 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
         w.entBits[e] = nb;
         w.entSlot[e] = w.activeSlot[q];
     }
+}
+
+// ---- second compaction (over active slots) ------------------------------------------------------------------
+__device__ __forceinline__ bool entryActs(uint8_t nb) { return (nb & 4) && (nb & 3); }   // moving neighbour, hurt in some state
+
+__global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
+    const int a = blockIdx.x * kBlock + threadIdx.x;
+    int r = 0, b = 0;
+    if (a < nA) {
+        for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
+        const uint8_t sb = w.actBits[a];
+        r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
+        if (!r) b = 0;
+    }
+    __shared__ int sa[kBlock / 64], se[kBlock / 64];
+    for (int o = 32; o > 0; o >>= 1) { r += __shfl_down(r, o, 64); b += __shfl_down(b, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = r; se[threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, te = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
+        w.blkA[blockIdx.x] = ta;
+        w.blkE[blockIdx.x] = te;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA) {
+    const int a = blockIdx.x * kBlock + threadIdx.x;
+    int r = 0, b = 0;
+    if (a < nA) {
+        for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
+        const uint8_t sb = w.actBits[a];
+        r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
+        if (!r) b = 0;
+    }
+    int ir = r, ib = b;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int tr = __shfl_up(ir, o, 64), tb = __shfl_up(ib, o, 64);
+        if (lane >= o) { ir += tr; ib += tb; }
+    }
+    __shared__ int wr[kBlock / 64], wb[kBlock / 64];
+    if (lane == 63) { wr[threadIdx.x >> 6] = ir; wb[threadIdx.x >> 6] = ib; }
+    __syncthreads();
+    int offR = w.blkA[blockIdx.x], offB = w.blkE[blockIdx.x];
+    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offR += wr[k]; offB += wb[k]; }
+    if (a < nA) w.relSlot[a] = r ? offR + ir - 1 : -1;
+    if (r) {
+        const int slot = offR + ir - 1;
+        int eo = offB + ib - b;
+        w.relIds[slot] = w.actIds[a];
+        w.relBits[slot] = w.actBits[a];
+        w.relEntOff[slot] = eo;
+        for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) {
+            const uint8_t nb = w.entBits[k];
+            if (!entryActs(nb)) continue;
+            w.badNbr[eo] = w.entNbr[k];
+            w.badSlot[eo] = w.entSlot[k];    // active slot for now; k_rel_link turns it into a relevant slot
+            w.badBits[eo] = nb;
+            ++eo;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_rel_link(WalkView w, int nR, int nB) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0) w.relEntOff[nR] = nB;
+    if (i >= nB) return;
+    const int sl = w.badSlot[i];
+    // a neighbour that is not active, or active but unable to act, is a sink: keep -1 / -2 apart because the
+    // replay must still honour "already frozen" for active sinks through their initial flag only
+    w.badSlot[i] = (sl >= 0) ? w.relSlot[sl] : -1;
 }
 
 __global__ void __launch_bounds__(kBlock) k_walk_apply(State s, const int* ids, int n) {

@@ -524,6 +524,14 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     rc |= devAlloc(h, &w.entNbr, E);
     rc |= devAlloc(h, &w.entSlot, E);
     rc |= devAlloc(h, &w.entBits, E);
+    rc |= devAlloc(h, &w.relSlot, P);
+    rc |= devAlloc(h, &w.header2, 4);
+    rc |= devAlloc(h, &w.relIds, P);
+    rc |= devAlloc(h, &w.relEntOff, P + 1);
+    rc |= devAlloc(h, &w.relBits, P);
+    rc |= devAlloc(h, &w.badNbr, E);
+    rc |= devAlloc(h, &w.badSlot, E);
+    rc |= devAlloc(h, &w.badBits, E);
     if (rc) return 1;
     h->walkAlloc = true;
     return 0;
@@ -593,22 +601,41 @@ static int runHostWalk(smgpu_handle* h) {
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_pred, dim3(gridFor((int64_t)nA + nE)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
         })) return 1;
-    // dense tables -> pinned host memory
-    const size_t oIds = 0, oOff = oIds + 4 * (size_t)nA, oNbr = oOff + 4 * ((size_t)nA + 1), oSlot = oNbr + 4 * (size_t)nE,
-                 oABits = oSlot + 4 * (size_t)nE, oEBits = oABits + (size_t)nA, total = oEBits + (size_t)nE;
+    // second compaction: only the points that can act and only their true entries go to the host
+    const int nSlotBlocks = gridFor(nA);
+    if (launchK(h, K_FA_PRED, [&] {
+            hipLaunchKernelGGL(k_rel_count, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, nSlotBlocks);
+        })) return 1;
+    HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    const int nR = hdr[0], nB = hdr[1];
+    if (nR <= 0) return 0;
+    if (launchK(h, K_FA_PRED, [&] {
+            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
+            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(std::max(nB, 1))), dim3(kBlock), 0, h->stream, w, nR, nB);
+        })) return 1;
+    const size_t oIds = 0, oOff = oIds + 4 * (size_t)nR, oNbr = oOff + 4 * ((size_t)nR + 1), oSlot = oNbr + 4 * (size_t)nB,
+                 oABits = oSlot + 4 * (size_t)nB, oEBits = oABits + (size_t)nR, total = oEBits + (size_t)nB;
     if (ensurePinned(h, total + 16)) return 1;
     char* base = (char*)h->pinned;
-    HIP_OK(hipMemcpyAsync(base + oIds, w.actIds, 4 * (size_t)nA, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oOff, w.actEntOff, 4 * ((size_t)nA + 1), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oNbr, w.entNbr, 4 * (size_t)nE, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oSlot, w.entSlot, 4 * (size_t)nE, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oABits, w.actBits, (size_t)nA, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oEBits, w.entBits, (size_t)nE, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oIds, w.relIds, 4 * (size_t)nR, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oOff, w.relEntOff, 4 * ((size_t)nR + 1), hipMemcpyDeviceToHost, h->stream));
+    if (nB) {
+        HIP_OK(hipMemcpyAsync(base + oNbr, w.badNbr, 4 * (size_t)nB, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(base + oSlot, w.badSlot, 4 * (size_t)nB, hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipMemcpyAsync(base + oEBits, w.badBits, (size_t)nB, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIP_OK(hipMemcpyAsync(base + oABits, w.relBits, (size_t)nR, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    replayWalk(nA, (const int*)(base + oIds), (const int*)(base + oOff), (const uint8_t*)(base + oABits), (const int*)(base + oNbr),
+    replayWalk(nR, (const int*)(base + oIds), (const int*)(base + oOff), (const uint8_t*)(base + oABits), (const int*)(base + oNbr),
                (const int*)(base + oSlot), (const uint8_t*)(base + oEBits), h->walkFrozen, h->walkStack, h->walkOut);
-    if (h->timing) h->ms[K_FA_WALK] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const double replayMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (h->timing) h->ms[K_FA_WALK] += replayMs;
+    if (envInt("SMGPU_VERBOSE", 0) > 1)
+        std::fprintf(stderr, "[smgpu] walk: active %d entries %d -> acting %d entries %d, froze %zu, replay %.3f ms\n", nA, nE, nR, nB,
+                     h->walkOut.size(), replayMs);
     h->launches[K_FA_WALK]++;
     const int nOut = (int)h->walkOut.size();
     if (nOut > 0) {
