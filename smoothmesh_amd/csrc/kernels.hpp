@@ -36,12 +36,10 @@ struct MeshView {
     const uint8_t* pflags;
 };
 
-struct Accum {                 // per-iteration device accumulators
-    unsigned long long resBits;  // max over points of |new-cur| / maxStepLength, as f64 bits (>= 0)
-    int nFrozen;
-    int nActive;               // face-angle walk: points outside the good range
+struct Accum {                 // device-side loop state
+    int nActive;               // face-angle walk: points outside the good range (this iteration)
     int stop;                  // set once residual < relTol (SM.C:2401)
-    int err;                   // 1 = fewer than two closest points (SM.C:354-362)
+    int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks
     int pad;
 };
 
