@@ -38,6 +38,7 @@ struct MeshView {
 
 struct Accum {                 // device-side loop state
     int nActive;               // face-angle walk: points outside the good range (this iteration)
+    int nEaMaybe, nFaMaybe;    // elements the f32 filters could not decide (this iteration)
     int stop;                  // set once residual < relTol (SM.C:2401)
     int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks
     int pad;
@@ -380,6 +381,7 @@ __device__ __forceinline__ double clampCos(double cosA) {
 
 __global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s, Prm prm, int maxEntries, const uint8_t* eaMaybe) {
     if (s.acc->stop) return;
+    if (eaMaybe && s.acc->nEaMaybe == 0) return;   // the filter decided every point
     extern __shared__ double lds[];
     double* U = lds;   // 9 arrays of maxEntries: ucc.xyz, uc.xyz, un.xyz
     const int tid = threadIdx.x, g = tid & (kEaLanes - 1);
@@ -520,6 +522,7 @@ __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s
 // faMaybe (may be NULL): only edges with an end point the filter could not rule out are evaluated.
 __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const uint8_t* faMaybe) {
     if (s.acc->stop) return;
+    if (faMaybe && s.acc->nFaMaybe == 0) return;   // the filter found every edge inside the good range
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= m.nEdges) return;
     if (faMaybe && !(faMaybe[m.edges[2 * e]] | faMaybe[m.edges[2 * e + 1]])) return;
@@ -562,6 +565,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const 
 // good-range test SM.C:1367-1369 -- one thread per point.
 __global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm, const uint8_t* faMaybe) {
     if (s.acc->stop) return;
+    if (faMaybe && s.acc->nFaMaybe == 0) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= m.nPoints) return;
     if (faMaybe && !faMaybe[p]) return;   // k_fa_point_flags already cleared faActive: all its edges are GOOD
@@ -729,6 +733,8 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials,
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
     if (res < relTol) a->stop = 1;
     a->nActive = 0;
+    a->nEaMaybe = 0;
+    a->nFaMaybe = 0;
 }
 
 // ---- multi-rank pack / combine -------------------------------------------------------------------

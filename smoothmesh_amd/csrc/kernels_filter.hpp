@@ -84,6 +84,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_point_flags(MeshView m, State s, 
     uint8_t any = 0;
     for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) any |= edgeFlag[m.peEdge[k]];
     faMaybe[p] = any;
+    if (any) atomicAdd(&s.acc->nFaMaybe, 1);   // rare on a decent mesh
     if (!any) s.faActive[p] = 0;     // every incident edge is GOOD: inside the good range for sure (SM.C:1367-1369)
 }
 
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_filter(MeshView m, State 
         below = below && (c0 < thr) && (c1 < thr) && (c2 < thr) && (c3 < thr);   // NaN -> false -> exact path
     }
     eaMaybe[p] = (ok && below) ? 0 : 1;
+    if (!(ok && below)) atomicAdd(&s.acc->nEaMaybe, 1);
 }
 
 // The same filter on the smoothing tiles: current and proposed coordinates of the tile's points and their
@@ -158,6 +160,7 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
     }
 #undef SMGPU_EA_CORNER
     eaMaybe[p] = (ok && below) ? 0 : 1;
+    if (!(ok && below)) atomicAdd(&s.acc->nEaMaybe, 1);
 }
 
 struct EdgeTileView {
