@@ -91,6 +91,10 @@ struct smgpu_handle {
     // f32 filters in front of the two angle evaluators (kernels_filter.hpp); SMGPU_FILTER=0 disables
     bool useFilter = true, exactAll = false;
     uint8_t *dEdgeFlag = nullptr, *dFaMaybe = nullptr, *dEaMaybe = nullptr;
+    // the face-angle filter only needs the geometry, so it runs on a side stream next to the proposal kernel
+    hipStream_t side = nullptr;
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
+    bool faFilterInFlight = false;
     EdgeTiles etl;
     EdgeTileView ev{};
     bool edgeTilesOk = false;
@@ -138,16 +142,17 @@ static inline int gridFor(int64_t n) { return (int)((n + kBlock - 1) / kBlock); 
 
 // Launch helper: optional hipEvent bracketing on the handle's stream.
 template <typename F>
-static int launchK(smgpu_handle* h, int k, F&& f) {
+static int launchK(smgpu_handle* h, int k, F&& f, hipStream_t stream = nullptr) {
+    if (!stream) stream = h->stream;
     if (h->timing) {
         hipEvent_t a, b;
         for (hipEvent_t* ev : {&a, &b}) {
             if (!h->freeEvents.empty()) { *ev = h->freeEvents.back(); h->freeEvents.pop_back(); }
             else HIP_OK(hipEventCreate(ev));
         }
-        HIP_OK(hipEventRecord(a, h->stream));
+        HIP_OK(hipEventRecord(a, stream));
         f();
-        HIP_OK(hipEventRecord(b, h->stream));
+        HIP_OK(hipEventRecord(b, stream));
         h->pending.push_back({k, a, b});
     } else {
         f();
@@ -162,6 +167,7 @@ static int launchK(smgpu_handle* h, int k, F&& f) {
 static int drainTimers(smgpu_handle* h) {
     if (h->pending.empty()) return 0;
     HIP_OK(hipStreamSynchronize(h->stream));
+    if (h->side) HIP_OK(hipStreamSynchronize(h->side));
     for (auto& p : h->pending) {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -334,6 +340,12 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
                     h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;
+                    if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", 1)) {
+                        if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
+                            hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
+                            hipEventCreateWithFlags(&h->evJoin, hipEventDisableTiming) != hipSuccess)
+                            return cleanup(fail("side stream creation failed"));
+                    }
                 }
             }
             if (rc) return cleanup(1);
@@ -406,6 +418,9 @@ int smgpu_destroy(smgpu_handle* h) {
     for (auto e : h->freeEvents) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->evFork) (void)hipEventDestroy(h->evFork);
+    if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return 0;
@@ -649,8 +664,26 @@ static int runHostWalk(smgpu_handle* h) {
 }
 
 // proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
+// launch the face-angle filter (needs only the geometry of the current coordinates) on the side stream
+static int forkFaFilter(smgpu_handle* h) {
+    if (!h->side || !h->prm.faceAngleConstraint || !h->useFilter || h->exactAll || !h->edgeTilesOk || h->faFilterInFlight) return 0;
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const Prm prm = makePrm(h->prm);
+    HIP_OK(hipEventRecord(h->evFork, h->stream));
+    HIP_OK(hipStreamWaitEvent(h->side, h->evFork, 0));
+    if (launchK(h, K_FA_FILTER, [&] {
+            hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(h->etl.nTiles), dim3(256), h->edgeLds, h->side, s, prm, h->ev, h->dEdgeFlag);
+            hipLaunchKernelGGL(k_fa_point_flags, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->side, m, s, h->dEdgeFlag, h->dFaMaybe);
+        }, h->side)) return 1;
+    HIP_OK(hipEventRecord(h->evJoin, h->side));
+    h->faFilterInFlight = true;
+    return 0;
+}
+
 static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
+    if (forkFaFilter(h)) return 1;
     if (runSmooth<false>(h, h->mv, h->st, makePrm(h->prm))) return 1;
     return runConstraints(h);
 }
@@ -682,7 +715,11 @@ static int runConstraints(smgpu_handle* h) {
     }
     if (h->prm.faceAngleConstraint) {
         const uint8_t* faMaybe = nullptr;
-        if (filt) {
+        if (filt && h->faFilterInFlight) {
+            HIP_OK(hipStreamWaitEvent(h->stream, h->evJoin, 0));   // join the side stream
+            h->faFilterInFlight = false;
+            faMaybe = h->dFaMaybe;
+        } else if (filt) {
             if (launchK(h, K_FA_FILTER, [&] {
                     if (h->edgeTilesOk)
                         hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(h->etl.nTiles), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, h->dEdgeFlag);
@@ -885,6 +922,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
     HIP_OK(hipSetDevice(h->device));
     if (runGeometry(h)) return 1;
+    if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;
     if (h->nShared)
