@@ -136,8 +136,7 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
     }
     {
         const int b = g.tnOff[tile], n = g.tnOff[tile + 1] - b;
-        stageRecords<T, 3>(s.ptsCur, g.tnIds + b, n, cx, cy, cz, tid);
-        stageRecords<T, 3>(s.prop, g.tnIds + b, n, nx, ny, nz, tid);
+        stageRecordsPair<T, 3>(s.ptsCur, s.prop, g.tnIds + b, n, cx, cy, cz, nx, ny, nz, tid);
     }
     __syncthreads();
     if (!mine) return;
@@ -204,9 +203,8 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
         const int b2 = g.tfOff[tile], n2 = g.tfOff[tile + 1] - b2;
         const int b3 = g.tcOff[tile], n3 = g.tcOff[tile + 1] - b3;
+        stageRecords2<T, 3, 2>(s.fAvg, g.tfIds + b2, n2, fx, fy, fz, s.cellCtr, g.tcIds + b3, n3, cx, cy, cz, tid);
         stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, px, py, pz, tid);
-        stageRecords<T, 3>(s.fAvg, g.tfIds + b2, n2, fx, fy, fz, tid);
-        stageRecords<T, 2>(s.cellCtr, g.tcIds + b3, n3, cx, cy, cz, tid);
     }
     __syncthreads();
     if (!mine) return;

@@ -85,6 +85,52 @@ __device__ __forceinline__ void stageRecords(const double* __restrict__ src, con
     }
 }
 
+// Two (or three) record sets in one pass: all id loads, then all record loads, then the LDS stores -- two
+// memory round trips per tile in total.  Falls back to set-by-set staging when a set exceeds its rounds.
+template <int T, int R1, int R2>
+__device__ __forceinline__ void stageRecords2(const double* __restrict__ s1, const int* __restrict__ i1, int n1, double* x1, double* y1,
+                                              double* z1, const double* __restrict__ s2, const int* __restrict__ i2, int n2, double* x2,
+                                              double* y2, double* z2, int tid) {
+    if (n1 > T * R1 || n2 > T * R2) {
+        stageRecords<T, R1>(s1, i1, n1, x1, y1, z1, tid);
+        stageRecords<T, R2>(s2, i2, n2, x2, y2, z2, tid);
+        return;
+    }
+    int a[R1], b[R2];
+#pragma unroll
+    for (int u = 0; u < R1; ++u) { const int i = u * T + tid; a[u] = (i < n1) ? i1[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < R2; ++u) { const int i = u * T + tid; b[u] = (i < n2) ? i2[i] : -1; }
+    V3 va[R1], vb[R2];
+#pragma unroll
+    for (int u = 0; u < R1; ++u) va[u] = (a[u] >= 0) ? ldv(s1, a[u]) : v3(0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < R2; ++u) vb[u] = (b[u] >= 0) ? ldv(s2, b[u]) : v3(0, 0, 0);
+#pragma unroll
+    for (int u = 0; u < R1; ++u) { const int i = u * T + tid; if (a[u] >= 0) { x1[i] = va[u].x; y1[i] = va[u].y; z1[i] = va[u].z; } }
+#pragma unroll
+    for (int u = 0; u < R2; ++u) { const int i = u * T + tid; if (b[u] >= 0) { x2[i] = vb[u].x; y2[i] = vb[u].y; z2[i] = vb[u].z; } }
+}
+
+// the same id list into two destinations from two sources (current and proposed coordinates)
+template <int T, int R>
+__device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, const double* __restrict__ s2, const int* __restrict__ ids,
+                                                 int n, double* x1, double* y1, double* z1, double* x2, double* y2, double* z2, int tid) {
+    for (int base = 0; base < n; base += T * R) {
+        int id[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) { const int i = base + u * T + tid; id[u] = (i < n) ? ids[i] : -1; }
+        V3 va[R], vb[R];
+#pragma unroll
+        for (int u = 0; u < R; ++u) { va[u] = (id[u] >= 0) ? ldv(s1, id[u]) : v3(0, 0, 0); vb[u] = (id[u] >= 0) ? ldv(s2, id[u]) : v3(0, 0, 0); }
+#pragma unroll
+        for (int u = 0; u < R; ++u) {
+            const int i = base + u * T + tid;
+            if (id[u] >= 0) { x1[i] = va[u].x; y1[i] = va[u].y; z1[i] = va[u].z; x2[i] = vb[u].x; y2[i] = vb[u].y; z2[i] = vb[u].z; }
+        }
+    }
+}
+
 // Cell centres of the current coordinates for one tile of consecutive cells:
 // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols (.com v2412), staged through LDS.
 template <int T>
@@ -227,8 +273,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     {
         const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
         const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        stageRecords<T, 3>(s.cellCtr, g.tcIds + b, n, cx, cy, cz, tid);
-        stageRecords<T, 3>(s.ptsCur, g.tnIds + b2, n2, nx, ny, nz, tid);
+        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, cx, cy, cz, s.ptsCur, g.tnIds + b2, n2, nx, ny, nz, tid);
     }
     __syncthreads();
 
