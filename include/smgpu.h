@@ -134,6 +134,8 @@ int smgpu_iter_interior(smgpu_handle* h);/* optional, between begin and mid: eve
                                             recvA (points away from the shared ones) -- lets the host overlap
                                             exchange A with compute                                         */
 int smgpu_iter_mid(smgpu_handle* h);     /* combine recvA, proposal, constraints -> sendF           */
+int smgpu_iter_ahead(smgpu_handle* h);   /* optional, between mid and end: next iteration's geometry away from
+                                            the shared points -- overlaps exchange F (constraints off)      */
 int smgpu_iter_end(smgpu_handle* h);     /* or recvF, restore, residual -> localStats; movePoints   */
 
 /* ---- debug / parity access (device -> host copy of an internal field) -----------------------

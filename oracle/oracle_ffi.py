@@ -197,6 +197,9 @@ class OracleRankEngine:
         self._lib.orc_halo_packF(self.o._h, _p(self.sharedLocal, i32p), len(self.sendShared), _p(self.sendShared, i32p),
                                  self.ptr["sendF"])
 
+    def iter_ahead(self):
+        pass
+
     def iter_end(self):
         self._lib.orc_halo_orF(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
                                _p(self.combSlots, i32p), self.ptr["recvF"])

@@ -75,6 +75,7 @@ SYMBOLS = {
     "smgpu_iter_begin": (C.c_int, [C.c_void_p]),
     "smgpu_iter_interior": (C.c_int, [C.c_void_p]),
     "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
+    "smgpu_iter_ahead": (C.c_int, [C.c_void_p]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),
     "smgpu_debug_get_field": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p, C.POINTER(C.c_int64)]),
     "smgpu_debug_get_addressing": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i32p, C.POINTER(C.c_int64)]),

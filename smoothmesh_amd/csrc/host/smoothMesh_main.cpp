@@ -459,6 +459,7 @@ int main(int argc, char** argv) {
                 for (Rank& K : R) check(smgpu_iter_interior(K.h), "smgpu_iter_interior");
                 exchange(true);
                 for (Rank& K : R) check(smgpu_iter_mid(K.h), "smgpu_iter_mid");
+                for (Rank& K : R) check(smgpu_iter_ahead(K.h), "smgpu_iter_ahead");
                 exchange(false);
                 for (Rank& K : R) check(smgpu_iter_end(K.h), "smgpu_iter_end");
                 syncAll();

@@ -133,14 +133,16 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 
 // Cell centres of the current coordinates for one tile of consecutive cells:
 // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols (.com v2412), staged through LDS.
+// tileList (may be NULL) selects the tiles of this launch (multi-rank: the tiles away from the shared points
+// are recomputed ahead, while exchange F is in flight).
 template <int T>
-__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces) {
+__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList) {
     if (s.acc->stop) return;
     extern __shared__ double lds[];
     double* px = lds;             double* py = px + g.maxPoints;  double* pz = py + g.maxPoints;
     double* fcx = pz + g.maxPoints; double* fcy = fcx + g.maxFaces; double* fcz = fcy + g.maxFaces;
     double* fax = fcz + g.maxFaces; double* fay = fax + g.maxFaces; double* faz = fay + g.maxFaces;
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = tileList ? tileList[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
 
     // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
     {

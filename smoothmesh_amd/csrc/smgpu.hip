@@ -70,6 +70,9 @@ struct smgpu_handle {
     int *dInteriorTiles = nullptr, *dSharedTiles = nullptr;   // smoothing tiles without / with shared points
     int nInteriorTiles = 0, nSharedTiles = 0;
     bool interiorDone = false;
+    int *dGeomInterior = nullptr, *dGeomShared = nullptr;     // geometry tiles without / with a shared point
+    int nGeomInterior = 0, nGeomShared = 0;
+    bool geomAheadDone = false;
     // LDS staging tiles (tiles.hpp)
     bool useTiles = false;
     int geomT = 128, smoothT = 256;
@@ -463,19 +466,20 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
     h->prm = *p;
     h->prmSet = true;
     h->walkMode = -1;
+    h->geomAheadDone = false;
     computeAlgoBytes(h);
     return 0;
 }
 
 extern "C++" {
 template <int T>
-static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg) {
+static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles) {
     static bool attrSet = false;
     if (!attrSet) {
         if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
         attrSet = true;
     }
-    hipLaunchKernelGGL(k_geom_tile<T>, dim3(h->gt.nTiles), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0);
+    hipLaunchKernelGGL(k_geom_tile<T>, dim3(nTiles), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0, tileList);
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
@@ -504,17 +508,23 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
 
 }  // extern "C++"
 
-// geometry of the current coordinates: OpenFOAM face centres/areas + cell centres
-static int runGeometry(smgpu_handle* h) {
+// geometry of the current coordinates: OpenFOAM face centres/areas + cell centres.
+// tileList != NULL restricts the tiled form to the listed tiles; fromNext reads the coordinates of the
+// iteration being finished (ptsNext) instead of ptsCur (multi-rank look-ahead, smgpu_iter_ahead).
+static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList = 0, bool fromNext = false) {
     const MeshView& m = h->mv;
     State s = h->st;
+    if (fromNext) s.ptsCur = h->st.ptsNext;
     const int wantAvg = h->prm.faceAngleConstraint ? 1 : 0;
-    if (h->useTiles)
+    if (h->useTiles) {
+        const int nT = tileList ? nList : h->gt.nTiles;
+        if (nT == 0) return 0;
         return launchK(h, K_GEOM_TILE, [&] {
-            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg);
-            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg);
-            else launchGeomTile<256>(h, m, s, wantAvg);
+            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg, tileList, nT);
+            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg, tileList, nT);
+            else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT);
         });
+    }
     if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg); })) return 1;
     if (launchK(h, K_CELL_CENTRES, [&] { hipLaunchKernelGGL(k_cell_centres, dim3(gridFor(m.nCells)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
     return 0;
@@ -832,6 +842,7 @@ int smgpu_get_points(smgpu_handle* h, double* out) {
 int smgpu_set_points(smgpu_handle* h, const double* pts) {
     if (!h || !pts) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));
+    h->geomAheadDone = false;
     HIP_OK(hipMemcpyAsync(h->st.ptsCur, pts, sizeof(double) * 3 * (size_t)h->mv.nPoints, hipMemcpyHostToDevice, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
     return 0;
@@ -904,6 +915,24 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         if (devUpload(h, &pa, inter) || devUpload(h, &pb, shr)) return 1;
         h->dInteriorTiles = (int*)pa; h->dSharedTiles = (int*)pb;
         h->nInteriorTiles = (int)inter.size(); h->nSharedTiles = (int)shr.size();
+        // geometry tiles: a tile is "shared" when one of its cells has a shared point
+        const Topology& t = h->topo;
+        std::vector<int> gi, gs;
+        for (int ti = 0; ti < h->gt.nTiles; ++ti) {
+            bool any = false;
+            for (int ci = h->gt.cellBeg[ti]; ci < h->gt.cellBeg[ti + 1] && !any; ++ci) {
+                const int c = h->gt.order[(size_t)ci];
+                for (int k = t.cellFacesGeom.off[c]; k < t.cellFacesGeom.off[c + 1] && !any; ++k) {
+                    const int f = t.cellFacesGeom.val[k] & 0x7fffffff;
+                    for (int j = t.facePoints.off[f]; j < t.facePoints.off[f + 1] && !any; ++j) any = slot[(size_t)t.facePoints.val[j]] >= 0;
+                }
+            }
+            (any ? gs : gi).push_back(ti);
+        }
+        const int *pc = nullptr, *pd = nullptr;
+        if (devUpload(h, &pc, gi) || devUpload(h, &pd, gs)) return 1;
+        h->dGeomInterior = (int*)pc; h->dGeomShared = (int*)pd;
+        h->nGeomInterior = (int)gi.size(); h->nGeomShared = (int)gs.size();
     }
     {   // partial slots: tiles (or point blocks) + the blocks of k_shared_fix
         const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2;
@@ -921,7 +950,11 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
     HIP_OK(hipSetDevice(h->device));
-    if (runGeometry(h)) return 1;
+    if (h->geomAheadDone) {
+        // the tiles away from the shared points were recomputed by smgpu_iter_ahead of the previous iteration
+        if (runGeometry(h, h->dGeomShared, h->nGeomShared)) return 1;
+        h->geomAheadDone = false;
+    } else if (runGeometry(h)) return 1;
     if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;
@@ -970,6 +1003,18 @@ int smgpu_iter_mid(smgpu_handle* h) {
                 hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
                                    h->dSharedLocal, h->st.frozen, h->sendF);
             })) return 1;
+    return 0;
+}
+
+// Optional, between smgpu_iter_mid and smgpu_iter_end (constraints off): while exchange F is in flight, start
+// the NEXT iteration's geometry for every tile whose cells hold no shared point -- their points are final.
+int smgpu_iter_ahead(smgpu_handle* h) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    if (!h->useTiles || !fused || h->geomAheadDone) return 0;
+    if (runGeometry(h, h->dGeomInterior, h->nGeomInterior, true)) return 1;
+    h->geomAheadDone = true;
     return 0;
 }
 

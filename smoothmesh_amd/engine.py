@@ -205,6 +205,9 @@ class SmoothEngine:
     def iter_mid(self):
         self._check(self._lib.smgpu_iter_mid(self._h))
 
+    def iter_ahead(self):
+        self._check(self._lib.smgpu_iter_ahead(self._h))
+
     def iter_end(self):
         self._check(self._lib.smgpu_iter_end(self._h))
 

@@ -165,7 +165,7 @@ class DistributedSmoother:
                 eng.iter_begin()
                 self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
                 eng.iter_mid()
-                self._a2a(st.recvF, st.sendF)               # SM.C:2374
+                self._a2a(st.recvF, st.sendF, eng.iter_ahead)   # SM.C:2374
                 eng.iter_end()
                 self._gather_stats()                        # SM.C:1567, 2396
                 hist[i, 0] = self.allStats[:, 0].max()
@@ -183,7 +183,7 @@ class DistributedSmoother:
             eng.iter_begin()
             self._a2a(st.recvA, st.sendA, eng.iter_interior)
             eng.iter_mid()
-            self._a2a(st.recvF, st.sendF)
+            self._a2a(st.recvF, st.sendF, eng.iter_ahead)
             eng.iter_end()
             local[i].copy_(st.localStats)
             done += 1
@@ -255,6 +255,8 @@ class LocalMultiSmoother:
             self._exchange("A")
             for st in self.states:
                 st.eng.iter_mid()
+            for st in self.states:
+                st.eng.iter_ahead()
             self._exchange("F")
             for st in self.states:
                 st.eng.iter_end()

@@ -9,14 +9,18 @@ from conftest import rel_linf
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("grid,constraints", [((2, 1, 1), False), ((2, 1, 1), True), ((2, 2, 2), True), ((3, 1, 2), True)])
-def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints):
+# the (16, 12, 12) sub-domains span several geometry/smoothing tiles, so the interior/shared tile split and the
+# look-ahead geometry (smgpu_iter_ahead) are really exercised
+@pytest.mark.parametrize("grid,constraints,sub", [((2, 1, 1), False, (5, 4, 4)), ((2, 1, 1), True, (5, 4, 4)),
+                                                  ((2, 2, 2), True, (5, 4, 4)), ((3, 1, 2), True, (5, 4, 4)),
+                                                  ((2, 2, 1), False, (16, 12, 12)), ((2, 1, 2), True, (16, 12, 12))])
+def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints, sub):
     from smoothmesh_amd import default_params
     from smoothmesh_amd.decompose import shared_point_table
     from smoothmesh_amd.halo import LocalMultiSmoother
     from smoothmesh_amd.meshgen import hex_subdomain
     world = grid[0] * grid[1] * grid[2]
-    subs = [hex_subdomain((5, 4, 4), grid, r, jitter=0.3, seed=9) for r in range(world)]
+    subs = [hex_subdomain(sub, grid, r, jitter=0.3, seed=9) for r in range(world)]
     ms = LocalMultiSmoother(subs, device=0)
     orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
     mn = min(o.mesh_stats()[0] for o in orcs)
@@ -28,7 +32,15 @@ def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints
     off, dom, loc = shared_point_table(subs)
     mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
     n_o, res_o, frz_o = mo.iterate(8, 0.0)
+    big_fused = sub[0] > 8 and not constraints
+    if big_fused:
+        ms.states[0].eng.enable_timing(True)
     n_g, res_g, frz_g = ms.iterate(8, 0.0)
+    if big_fused:
+        # look-ahead active: iteration 1 = one full geometry launch, every later one = shared tiles, and every
+        # iteration launches the look-ahead for the interior tiles -> 1 + 7 + 8 launches
+        geom = [c for c in ms.states[0].eng.counters() if c["name"] == "k_geom_tile"]
+        assert geom and geom[0]["launches"] == 16
     assert n_o == n_g
     assert np.array_equal(frz_o, frz_g)
     assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
