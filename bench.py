@@ -102,7 +102,12 @@ def main():
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
 
-    if world == 1:
+    # SMOOTHMESH_FORCE_DIST=1: run the N=1 case through the multi-rank code path (host-overhead measurements)
+    force_dist = world == 1 and bool(os.environ.get("SMOOTHMESH_FORCE_DIST"))
+    if force_dist:
+        for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
+            os.environ.setdefault(k, v)
+    if world == 1 and not force_dist:
         mesh = make_mesh(kind, n_side)
         eng = SmoothEngine(mesh, device=local_rank)
         prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
@@ -139,9 +144,14 @@ def main():
             raise SystemExit("multi-GPU bench uses the hexN workloads (sub-domains are generated per rank)")
         grid = proc_grid(world)
         sub = hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345)
-        ds = DistributedSmoother(sub, device=local_rank)
+        ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
         prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         ds.set_params(prm)
+        # exchange arrangement (in order on the engine's stream / on a communication stream next to the
+        # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
+        tune = ds.autotune(20) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None
+        if tune is None:
+            ds.set_overlap(os.environ["SMOOTHMESH_OVERLAP"] == "1")
         if W:
             ds.iterate(W, 0.0)
         torch.cuda.synchronize()
@@ -171,7 +181,9 @@ def main():
         ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
         sizes = eng.sizes()
         parallelism = (f"domain decomposition {grid[0]}x{grid[1]}x{grid[2]}, "
-                       f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo")
+                       f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, "
+                       f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
+                       + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
 
     if rank != 0:
         if world > 1:
@@ -238,11 +250,13 @@ def main():
         "ms_per_step_with_events": dt_ev / K * 1e3,
         "residual_last": float(res[-1]), "nFrozenPoints_last": int(frz[-1]),
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if force_dist:
+        out["config"]["parallelism"] += " [N=1 forced through the multi-rank path]"
+    if world == 1 and not force_dist and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -127,8 +127,17 @@ typedef struct smgpu_halo_desc {
     void* sendA; void* recvA;     /* device, nSend / nRecv records of 13 doubles              */
     void* sendF; void* recvF;     /* device, nSend / nRecv int32                              */
     void* localStats;             /* device, 2 doubles {residual, nFrozenPoints} per iteration */
+    int32_t useExchangeStream;    /* 0: the host enqueues its exchanges on the engine's stream (in order).       */
+    void* exchangeStream;         /* 1: the host enqueues them on THIS hipStream_t (NULL = the null stream); the
+                                     engine orders its own stream against it with events inside
+                                     smgpu_iter_begin/mid/end, so the exchange runs next to the kernels of
+                                     smgpu_iter_interior / smgpu_iter_ahead and the compute queue does not idle */
 } smgpu_halo_desc;
 int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d);
+/* change useExchangeStream / exchangeStream of a configured halo (e.g. to time both arrangements on the target) */
+int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, void* exchangeStream);
+/* the hipStream_t the engine launches on (its own, or the caller's when useCallerStream was set) */
+int smgpu_get_stream(smgpu_handle* h, void** stream);
 int smgpu_iter_begin(smgpu_handle* h);   /* geometry + local partial sums / closest points -> sendA */
 int smgpu_iter_interior(smgpu_handle* h);/* optional, between begin and mid: everything that does not need
                                             recvA (points away from the shared ones) -- lets the host overlap

@@ -174,7 +174,8 @@ class OracleRankEngine:
     def set_params(self, p):
         self.o.set_params(p)
 
-    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats):
+    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats,
+                       exchangeStream=None):
         self.sharedLocal = np.ascontiguousarray(sharedLocal, np.int32)
         self.sendShared = np.ascontiguousarray(sendShared, np.int32)
         self.combOffsets = np.ascontiguousarray(combOffsets, np.int32)

@@ -52,7 +52,7 @@ class HaloDesc(C.Structure):
         ("nShared", C.c_int32), ("sharedLocal", c_i32p), ("nSend", C.c_int32), ("sendShared", c_i32p),
         ("nRecv", C.c_int32), ("combOffsets", c_i32p), ("combSlots", c_i32p),
         ("sendA", C.c_void_p), ("recvA", C.c_void_p), ("sendF", C.c_void_p), ("recvF", C.c_void_p),
-        ("localStats", C.c_void_p),
+        ("localStats", C.c_void_p), ("useExchangeStream", C.c_int32), ("exchangeStream", C.c_void_p),
     ]
 
 
@@ -76,6 +76,8 @@ SYMBOLS = {
     "smgpu_iter_interior": (C.c_int, [C.c_void_p]),
     "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
     "smgpu_iter_ahead": (C.c_int, [C.c_void_p]),
+    "smgpu_halo_set_exchange_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "smgpu_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),
     "smgpu_debug_get_field": (C.c_int, [C.c_void_p, C.c_char_p, c_f64p, C.POINTER(C.c_int64)]),
     "smgpu_debug_get_addressing": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i32p, C.POINTER(C.c_int64)]),

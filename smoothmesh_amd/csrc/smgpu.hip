@@ -97,6 +97,11 @@ struct smgpu_handle {
     // the face-angle filter only needs the geometry, so it runs on a side stream next to the proposal kernel
     hipStream_t side = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
+    // that order it against the engine's stream
+    bool useExch = false;
+    hipStream_t exch = nullptr;
+    hipEvent_t evToExch = nullptr, evFromExch = nullptr;
     bool faFilterInFlight = false;
     EdgeTiles etl;
     EdgeTileView ev{};
@@ -422,6 +427,8 @@ int smgpu_destroy(smgpu_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
+    if (h->evToExch) (void)hipEventDestroy(h->evToExch);
+    if (h->evFromExch) (void)hipEventDestroy(h->evFromExch);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -876,10 +883,33 @@ int smgpu_reset_counters(smgpu_handle* h) {
 }
 
 // ---- multi-rank ----------------------------------------------------------------------------------
+int smgpu_get_stream(smgpu_handle* h, void** stream) {
+    if (!h || !stream) return fail("null argument");
+    *stream = (void*)h->stream;
+    return 0;
+}
+
+int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, void* exchangeStream) {
+    if (!h) return fail("null handle");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipDeviceSynchronize());
+    h->useExch = useExchangeStream && (hipStream_t)exchangeStream != h->stream;
+    h->exch = (hipStream_t)exchangeStream;
+    if (h->useExch && !h->evToExch) {
+        if (hipEventCreateWithFlags(&h->evToExch, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evFromExch, hipEventDisableTiming) != hipSuccess)
+            return fail("event creation failed");
+    }
+    return 0;
+}
+
 int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     if (!h || !d) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));
     h->nShared = d->nShared; h->nSend = d->nSend; h->nRecv = d->nRecv;
+    // the host's buffers may still be being initialised on the host's streams
+    HIP_OK(hipDeviceSynchronize());
+    if (smgpu_halo_set_exchange_stream(h, d->useExchangeStream, d->exchangeStream)) return 1;
     const int P = h->mv.nPoints;
     std::vector<int> sharedLocal(d->sharedLocal, d->sharedLocal + d->nShared);
     std::vector<int> sendShared(d->sendShared, d->sendShared + d->nSend);
@@ -946,6 +976,21 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     return 0;
 }
 
+// order the host's exchange stream after everything queued on the engine's stream so far / the engine's stream
+// after everything the host has queued on its exchange stream so far
+static int exchAfterCompute(smgpu_handle* h) {
+    if (!h->useExch) return 0;
+    HIP_OK(hipEventRecord(h->evToExch, h->stream));
+    HIP_OK(hipStreamWaitEvent(h->exch, h->evToExch, 0));
+    return 0;
+}
+static int computeAfterExch(smgpu_handle* h) {
+    if (!h->useExch) return 0;
+    HIP_OK(hipEventRecord(h->evFromExch, h->exch));
+    HIP_OK(hipStreamWaitEvent(h->stream, h->evFromExch, 0));
+    return 0;
+}
+
 int smgpu_iter_begin(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
@@ -965,11 +1010,12 @@ int smgpu_iter_begin(smgpu_handle* h) {
                     hipLaunchKernelGGL(k_halo_copyA, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_A_DOUBLES)), dim3(kBlock), 0, h->stream,
                                        h->nSend, h->dSendShared, h->dOwnA, h->sendA);
             })) return 1;
-    return 0;
+    return exchAfterCompute(h);             // sendA is complete: exchange A may start
 }
 
 // Work of the iteration that does not depend on exchange A: the proposal (and, with the constraints off,
 // the final move) of every tile that holds no shared point.  Optional: smgpu_iter_mid does it when skipped.
+// With an exchange stream configured its kernels run next to exchange A.
 int smgpu_iter_interior(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     HIP_OK(hipSetDevice(h->device));
@@ -988,6 +1034,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const Prm prm = makePrm(h->prm);
     if (h->useTiles && !h->interiorDone && smgpu_iter_interior(h)) return 1;
+    if (computeAfterExch(h)) return 1;      // exchange A has been enqueued by the host
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_combineA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
@@ -1003,7 +1050,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
                 hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
                                    h->dSharedLocal, h->st.frozen, h->sendF);
             })) return 1;
-    return 0;
+    return exchAfterCompute(h);             // sendF is complete: exchange F may start
 }
 
 // Optional, between smgpu_iter_mid and smgpu_iter_end (constraints off): while exchange F is in flight, start
@@ -1025,6 +1072,8 @@ int smgpu_iter_end(smgpu_handle* h) {
     State s = h->st;
     const Prm prm = makePrm(h->prm);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
+    s.stats = nullptr;                      // per-iteration results go to localStats in this mode
     int nPart;
     if (fused && h->useTiles) {
         // every non-shared point is already final; finish the shared ones (or of the freeze flags included)
@@ -1049,7 +1098,7 @@ int smgpu_iter_end(smgpu_handle* h) {
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     h->interiorDone = false;
-    return 0;
+    return exchAfterCompute(h);             // localStats is complete: the host may reduce / copy it
 }
 
 // ---- debug / parity access -------------------------------------------------------------------

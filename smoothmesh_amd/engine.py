@@ -186,15 +186,29 @@ class SmoothEngine:
                 for i in range(c.nKernels)]
 
     # -- multi-rank ----------------------------------------------------------------------------
-    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats):
-        """Pointers are raw device addresses (ints); see smgpu_halo_desc."""
+    def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats,
+                       exchangeStream=None):
+        """Pointers are raw device addresses (ints); exchangeStream: raw hipStream_t (int, 0 = null stream) the
+        caller enqueues its exchanges on, or None = the engine's own stream; see smgpu_halo_desc."""
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (sharedLocal, sendShared, combOffsets, combSlots)]
         d = _ffi.HaloDesc()
         d.nShared = len(keep[0]); d.sharedLocal = _p(keep[0], _ffi.c_i32p)
         d.nSend = len(keep[1]); d.sendShared = _p(keep[1], _ffi.c_i32p)
         d.nRecv = int(nRecv); d.combOffsets = _p(keep[2], _ffi.c_i32p); d.combSlots = _p(keep[3], _ffi.c_i32p)
         d.sendA, d.recvA, d.sendF, d.recvF, d.localStats = sendA, recvA, sendF, recvF, localStats
+        d.useExchangeStream = 0 if exchangeStream is None else 1
+        d.exchangeStream = exchangeStream or None
         self._check(self._lib.smgpu_halo_configure(self._h, C.byref(d)))
+
+    def set_exchange_stream(self, exchangeStream):
+        """None = exchanges are enqueued on the engine's stream; int = raw hipStream_t they are enqueued on"""
+        self._check(self._lib.smgpu_halo_set_exchange_stream(self._h, 0 if exchangeStream is None else 1, exchangeStream or None))
+
+    def stream(self):
+        """raw hipStream_t handle (int) of the engine's stream"""
+        out = C.c_void_p()
+        self._check(self._lib.smgpu_get_stream(self._h, C.byref(out)))
+        return out.value or 0
 
     def iter_begin(self):
         self._check(self._lib.smgpu_iter_begin(self._h))

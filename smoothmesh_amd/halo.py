@@ -71,7 +71,7 @@ class HaloTables:
 class _RankState:
     """engine + exchange buffers of one rank (torch tensors on the engine's device)"""
 
-    def __init__(self, sub, tables, engine, torch, device):
+    def __init__(self, sub, tables, engine, torch, device, exchange_stream=None):
         self.sub, self.t, self.eng = sub, tables, engine
         f64, i32 = torch.float64, torch.int32
         self.sendA = torch.zeros((max(tables.nSend, 1), A_DOUBLES), dtype=f64, device=device)
@@ -81,17 +81,19 @@ class _RankState:
         self.localStats = torch.zeros(2, dtype=f64, device=device)
         engine.halo_configure(tables.sharedLocal, tables.sendShared, tables.nRecv, tables.combOffsets, tables.combSlots,
                               self.sendA.data_ptr(), self.recvA.data_ptr(), self.sendF.data_ptr(), self.recvF.data_ptr(),
-                              self.localStats.data_ptr())
+                              self.localStats.data_ptr(), exchangeStream=exchange_stream)
 
 
 class DistributedSmoother:
     """The reference's loop (SM.C:2257-2437) on this rank's sub-domain, in step with all other ranks."""
 
-    def __init__(self, sub, device=0, engine_factory=None, torch_device=None):
+    def __init__(self, sub, device=0, engine_factory=None, torch_device=None, probe_slots=0, overlap=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.sub = sub
+        self.probe_slots = int(probe_slots)
+        self.xstream = None
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         assert sub.rank == self.rank and sub.nRanks == self.world
         if torch_device is None:
@@ -102,14 +104,21 @@ class DistributedSmoother:
         self.tables = HaloTables(self.rank, sub.pointProcAddressing, cands)
         if engine_factory is None:
             from .engine import SmoothEngine
-            stream = torch.cuda.current_stream(torch_device).cuda_stream   # collectives order against this stream
-            engine = SmoothEngine(sub.mesh, device=device, stream=stream)
+            # the engine computes on a stream of its own; torch's current stream carries the exchanges
+            engine = SmoothEngine(sub.mesh, device=device)          # computes on a stream of its own
+            self.xstream = torch.cuda.Stream(torch_device)           # communication stream
+            self.estream = torch.cuda.ExternalStream(engine.stream(), device=torch_device)
+            self.overlap = bool(overlap)
+            xs = self.xstream.cuda_stream if self.overlap else None
         else:
-            engine = engine_factory(sub.mesh)
+            engine, xs = engine_factory(sub.mesh), None
         self.engine = engine
-        self.state = _RankState(sub, self.tables, engine, torch, torch_device)
+        self.state = _RankState(sub, self.tables, engine, torch, torch_device, xs)
         self.counts = [int(c) for c in self.tables.counts]
         self.allStats = torch.zeros((self.world, 2), dtype=torch.float64, device=torch_device)
+        if self.probe_slots:
+            z = lambda shape, dt: (torch.zeros(shape, dtype=dt, device=torch_device), torch.zeros(shape, dtype=dt, device=torch_device))
+            self._probe = {torch.float64: z((self.probe_slots, A_DOUBLES), torch.float64), torch.int32: z((self.probe_slots,), torch.int32)}
 
     def global_min_edge(self):
         """getMeshStats + returnReduce(minOp), SM.C:1527"""
@@ -127,25 +136,29 @@ class DistributedSmoother:
         return self.dist.get_backend() == "gloo" and self.device.type != "cpu"
 
     def _a2a(self, recv, send, overlap=None):
-        """all_to_all of the packed shared-point records; `overlap` (a callable launching exchange-independent
-        kernels) runs while the collective is in flight on RCCL's stream."""
+        """all_to_all of the packed shared-point records on torch's current stream (= the engine's exchange
+        stream), then `overlap` (smgpu_iter_interior / smgpu_iter_ahead: the kernels that do not need the
+        exchanged data) on the engine's own stream.  The engine orders the two streams with events inside
+        smgpu_iter_begin/mid/end, so compute never leaves its queue and the host only pays for the collective
+        call (~17 us on this stack; async_op=True + wait() costs ~70 us, torch stream contexts ~40 us)."""
         n = self.tables.nSend
-        if self.world == 1 or (n == 0 and self.tables.nRecv == 0):
-            if overlap:
-                overlap()
-            return
-        if self._staged():
+        counts = self.counts
+        if self.world == 1 and self.probe_slots:
+            # measurement aid (bench.py, SMOOTHMESH_FORCE_DIST=1): a self-exchange of probe_slots dummy records
+            # drives the same stream/event/collective machinery a real N>1 run uses
+            n = self.probe_slots
+            recv, send = self._probe[recv.dtype]
+            counts = [n]
+        elif self.world == 1 or (n == 0 and self.tables.nRecv == 0):
+            n = 0
+        if n and self._staged():
             r = self.torch.empty_like(recv[:n], device="cpu")
-            self.dist.all_to_all_single(r, send[:n].cpu(), self.counts, self.counts)
+            self.dist.all_to_all_single(r, send[:n].cpu(), counts, counts)
             recv[:n].copy_(r)
-            if overlap:
-                overlap()
-        elif overlap:
-            work = self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts, async_op=True)
+        elif n:
+            self.dist.all_to_all_single(recv[:n], send[:n], counts, counts)
+        if overlap:
             overlap()
-            work.wait()      # orders the current stream after the collective; the host does not block
-        else:
-            self.dist.all_to_all_single(recv[:n], send[:n], self.counts, self.counts)
 
     def _gather_stats(self):
         if self._staged():
@@ -155,7 +168,55 @@ class DistributedSmoother:
         else:
             self.dist.all_gather_into_tensor(self.allStats.view(-1), self.state.localStats)
 
+    def set_overlap(self, overlap):
+        """overlap=True: exchanges run on a communication stream next to the engine's exchange-independent
+        kernels (ordered with events inside the engine); False: exchanges run in order on the engine's stream.
+        Which one is faster depends on the exchange latency of the machine (each cross-stream dependency costs
+        ~10 us of iteration time on MI355X, an exposed exchange its full latency): see autotune()."""
+        if self.xstream is None:
+            return
+        self.overlap = bool(overlap)
+        self.engine.set_exchange_stream(self.xstream.cuda_stream if self.overlap else None)
+
+    def autotune(self, iters=20):
+        """Time `iters` iterations in both arrangements (max over ranks), keep the faster one for all ranks and
+        restore the coordinates.  Returns {"overlap": bool, "us_per_iter": {...}}."""
+        import time
+        if self.xstream is None or self.world == 1 and not self.probe_slots:
+            return {"overlap": getattr(self, "overlap", False), "us_per_iter": {}}
+        torch = self.torch
+        pts0 = self.engine.get_points()
+        timing = {}
+        for mode in (False, True):
+            self.set_overlap(mode)
+            self.iterate(3, 0.0)
+            torch.cuda.synchronize(self.device)
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            self.iterate(iters, 0.0)
+            torch.cuda.synchronize(self.device)
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if self._staged() else self.device)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            timing[mode] = float(t.item()) / iters * 1e6
+            self.engine.set_points(pts0)
+        best = min(timing, key=timing.get)
+        self.set_overlap(best)
+        return {"overlap": best, "us_per_iter": {"inorder": timing[False], "overlap": timing[True]}}
+
     def iterate(self, centroidalIters, relTol=0.02):
+        if self.xstream is None:
+            return self._iterate(centroidalIters, relTol)
+        # torch's current stream for the loop: the communication stream (overlap) or the engine's own stream
+        # (in order).  Never the HIP null stream: operations on it synchronise with every blocking stream.
+        torch = self.torch
+        loop = self.xstream if self.overlap else self.estream
+        loop.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(loop):
+            out = self._iterate(centroidalIters, relTol)
+        torch.cuda.current_stream(self.device).wait_stream(loop)
+        return out
+
+    def _iterate(self, centroidalIters, relTol):
         torch, st, eng = self.torch, self.state, self.engine
         n = max(centroidalIters, 1)
         done = 0
@@ -205,7 +266,7 @@ class LocalMultiSmoother:
     device-side tensor indexing instead of RCCL.  Exercises every device-side piece of the multi-rank
     path (pack / combine / or kernels, slot tables) on a single GPU."""
 
-    def __init__(self, subs, device=0, engine_factory=None, torch_device=None):
+    def __init__(self, subs, device=0, engine_factory=None, torch_device=None, overlap=True):
         import torch
         self.torch = torch
         self.subs = subs
@@ -218,10 +279,12 @@ class LocalMultiSmoother:
             t = HaloTables(s.rank, s.pointProcAddressing, cands)
             if engine_factory is None:
                 from .engine import SmoothEngine
-                eng = SmoothEngine(s.mesh, device=device, stream=torch.cuda.current_stream(torch_device).cuda_stream)
+                cur = torch.cuda.current_stream(torch_device).cuda_stream
+                eng = SmoothEngine(s.mesh, device=device) if overlap else SmoothEngine(s.mesh, device=device, stream=cur)
+                xs = cur if overlap else None
             else:
-                eng = engine_factory(s.mesh)
-            self.states.append(_RankState(s, t, eng, torch, torch_device))
+                eng, xs = engine_factory(s.mesh), None
+            self.states.append(_RankState(s, t, eng, torch, torch_device, xs))
         # (src rank, src offset, dst offset, count) copies implementing the all_to_all
         self.copies = []
         n = len(subs)

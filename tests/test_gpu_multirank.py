@@ -11,17 +11,19 @@ pytestmark = pytest.mark.gpu
 
 # the (16, 12, 12) sub-domains span several geometry/smoothing tiles, so the interior/shared tile split and the
 # look-ahead geometry (smgpu_iter_ahead) are really exercised
-@pytest.mark.parametrize("grid,constraints,sub", [((2, 1, 1), False, (5, 4, 4)), ((2, 1, 1), True, (5, 4, 4)),
-                                                  ((2, 2, 2), True, (5, 4, 4)), ((3, 1, 2), True, (5, 4, 4)),
-                                                  ((2, 2, 1), False, (16, 12, 12)), ((2, 1, 2), True, (16, 12, 12))])
-def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints, sub):
+# overlap = 1: engines compute on their own streams, the exchange runs on torch's stream (smgpu_halo_desc.exchangeStream)
+@pytest.mark.parametrize("grid,constraints,sub,overlap", [
+    ((2, 1, 1), False, (5, 4, 4), 0), ((2, 1, 1), True, (5, 4, 4), 0), ((2, 2, 2), True, (5, 4, 4), 1),
+    ((3, 1, 2), True, (5, 4, 4), 0), ((2, 2, 1), False, (16, 12, 12), 0), ((2, 2, 1), False, (16, 12, 12), 1),
+    ((2, 1, 2), True, (16, 12, 12), 0), ((2, 1, 2), True, (16, 12, 12), 1)])
+def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints, sub, overlap):
     from smoothmesh_amd import default_params
     from smoothmesh_amd.decompose import shared_point_table
     from smoothmesh_amd.halo import LocalMultiSmoother
     from smoothmesh_amd.meshgen import hex_subdomain
     world = grid[0] * grid[1] * grid[2]
     subs = [hex_subdomain(sub, grid, r, jitter=0.3, seed=9) for r in range(world)]
-    ms = LocalMultiSmoother(subs, device=0)
+    ms = LocalMultiSmoother(subs, device=0, overlap=bool(overlap))
     orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
     mn = min(o.mesh_stats()[0] for o in orcs)
     assert mn == ms.global_min_edge()
