@@ -115,12 +115,15 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_filter(MeshView m, State 
 // neighbours are staged in LDS once (the per-point form above gathers each neighbour 8 times from global
 // memory and is bound by those gathers, not by arithmetic); corner pairs come from the pfEll table.
 template <int T>
-__global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, SmoothTileView g, float cosSmall, uint8_t* eaMaybe) {
+__global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, SmoothTileView g, float cosSmall, uint8_t* eaMaybe,
+                                                       int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
     extern __shared__ double lds[];
     double* cx = lds;               double* cy = cx + g.maxPoints; double* cz = cy + g.maxPoints;
     double* nx = cz + g.maxPoints;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = li, tid = threadIdx.x;
     const int pi = g.ptBeg[tile] + tid;
     const bool mine = pi < g.ptBeg[tile + 1];
     const int wf4 = g.pfWidth[tile] >> 2;
@@ -175,13 +178,15 @@ struct EdgeTileView {
 // edges need are staged in LDS (the per-edge form gathers ~10 records of 24 bytes per edge from global memory
 // and is bound by those gathers).  Ring order as in k_fa_edges: cell i lies between ring faces i and i+1.
 template <int T>
-__global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTileView g, uint8_t* edgeFlag) {
+__global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTileView g, uint8_t* edgeFlag, int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
     extern __shared__ double lds[];
     double* px = lds;                 double* py = px + g.maxPoints; double* pz = py + g.maxPoints;
     double* fx = pz + g.maxPoints;    double* fy = fx + g.maxFaces;  double* fz = fy + g.maxFaces;
     double* cx = fz + g.maxFaces;     double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tile = li, tid = threadIdx.x;
     const int ei = g.edgeBeg[tile] + tid;
     const bool mine = ei < g.edgeBeg[tile + 1];
     const int wf4 = g.efWidth[tile] >> 2, wc4 = g.ecWidth[tile] >> 2;

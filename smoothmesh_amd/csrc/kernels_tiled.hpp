@@ -26,6 +26,18 @@ struct SmoothTileView {
     int maxCells, maxPoints, usePairShare;
 };
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  With xcdMap the launch has 8*ceil(n/8)
+// workgroups and XCD x walks the contiguous range [x*ceil(n/8), ...) of the Morton-ordered tile sequence, so
+// that tiles which stage the same records share an L2.  Returns -1 for the padding workgroups.
+__device__ __forceinline__ int launchTile(int n, int xcdMap) {
+    const int b = blockIdx.x;
+    if (!xcdMap) return b;
+    const int per = (n + 7) >> 3;
+    const int i = (b & 7) * per + (b >> 3);
+    return i < n ? i : -1;
+}
+inline int tileGrid(int n, int xcdMap) { return xcdMap ? ((n + 7) >> 3) << 3 : n; }
+
 __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const double* z, int i) { return v3(x[i], y[i], z[i]); }
 
 // Visit the entries of one ELL row (4 per 8-byte chunk, `w4` chunks `stride` chunks apart) in list
@@ -136,13 +148,16 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 // tileList (may be NULL) selects the tiles of this launch (multi-rank: the tiles away from the shared points
 // are recomputed ahead, while exchange F is in flight).
 template <int T>
-__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList) {
+__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
+                                                  int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
     extern __shared__ double lds[];
     double* px = lds;             double* py = px + g.maxPoints;  double* pz = py + g.maxPoints;
     double* fcx = pz + g.maxPoints; double* fcy = fcx + g.maxFaces; double* fcz = fcy + g.maxFaces;
     double* fax = fcz + g.maxFaces; double* fay = fax + g.maxFaces; double* faz = fay + g.maxFaces;
-    const int tile = tileList ? tileList[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
+    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
 
     // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
     {
@@ -248,12 +263,15 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
 // tileList (may be NULL) selects the tiles of this launch: the multi-rank driver smooths the tiles without
 // shared points while exchange A is in flight, the others after it.
 template <bool FINAL, int T>
-__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList) {
+__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList,
+                                                    int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
     extern __shared__ double lds[];
     double* cx = lds;              double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
     double* nx = cz + g.maxCells;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
-    const int tile = tileList ? tileList[blockIdx.x] : blockIdx.x, tid = threadIdx.x;
+    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
     // everything a thread needs from global memory besides the staged records is requested first, so that
     // its latency overlaps the staging: point id, flags, own LDS slot, the first two ELL chunks of both rows
     const int pi = g.ptBeg[tile] + tid;

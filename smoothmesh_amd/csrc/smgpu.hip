@@ -99,6 +99,7 @@ struct smgpu_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
+    int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool useExch = false;
     hipStream_t exch = nullptr;
     hipEvent_t evToExch = nullptr, evFromExch = nullptr;
@@ -273,6 +274,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
+    h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -486,7 +488,8 @@ static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, i
         if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
         attrSet = true;
     }
-    hipLaunchKernelGGL(k_geom_tile<T>, dim3(nTiles), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0, tileList);
+    hipLaunchKernelGGL(k_geom_tile<T>, dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
+                       tileList, nTiles, h->xcdMap);
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
@@ -495,7 +498,8 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
         if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
         attrSet = true;
     }
-    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(nTiles), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList);
+    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
+                       nTiles, h->xcdMap);
 }
 // tileList == NULL: all tiles; otherwise the nTiles listed ones (multi-rank interior / shared split)
 template <bool FINAL>
@@ -690,7 +694,8 @@ static int forkFaFilter(smgpu_handle* h) {
     HIP_OK(hipEventRecord(h->evFork, h->stream));
     HIP_OK(hipStreamWaitEvent(h->side, h->evFork, 0));
     if (launchK(h, K_FA_FILTER, [&] {
-            hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(h->etl.nTiles), dim3(256), h->edgeLds, h->side, s, prm, h->ev, h->dEdgeFlag);
+            hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->side, s, prm, h->ev, h->dEdgeFlag,
+                               h->etl.nTiles, h->xcdMap);
             hipLaunchKernelGGL(k_fa_point_flags, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->side, m, s, h->dEdgeFlag, h->dFaMaybe);
         }, h->side)) return 1;
     HIP_OK(hipEventRecord(h->evJoin, h->side));
@@ -718,7 +723,8 @@ static int runConstraints(smgpu_handle* h) {
             if (h->useTiles && h->smoothT == 256) {
                 const size_t ldsB = sizeof(double) * 6 * (size_t)h->sv.maxPoints;
                 if (launchK(h, K_EA_FILTER, [&] {
-                        hipLaunchKernelGGL(k_ea_filter_tile<256>, dim3(h->stl.nTiles), dim3(256), ldsB, h->stream, m, s, h->sv, cosSmall, h->dEaMaybe);
+                        hipLaunchKernelGGL(k_ea_filter_tile<256>, dim3(tileGrid(h->stl.nTiles, h->xcdMap)), dim3(256), ldsB, h->stream, m, s, h->sv, cosSmall, h->dEaMaybe,
+                                           h->stl.nTiles, h->xcdMap);
                     })) return 1;
             } else if (launchK(h, K_EA_FILTER, [&] { hipLaunchKernelGGL(k_edge_angle_filter, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, cosSmall, h->dEaMaybe); })) return 1;
             eaMaybe = h->dEaMaybe;
@@ -739,7 +745,8 @@ static int runConstraints(smgpu_handle* h) {
         } else if (filt) {
             if (launchK(h, K_FA_FILTER, [&] {
                     if (h->edgeTilesOk)
-                        hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(h->etl.nTiles), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, h->dEdgeFlag);
+                        hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, h->dEdgeFlag,
+                                           h->etl.nTiles, h->xcdMap);
                     else
                         hipLaunchKernelGGL(k_fa_edges_filter, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, prm, h->dEdgeFlag);
                     hipLaunchKernelGGL(k_fa_point_flags, dim3(gP), dim3(kBlock), 0, h->stream, m, s, h->dEdgeFlag, h->dFaMaybe);
