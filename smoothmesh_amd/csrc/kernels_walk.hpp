@@ -17,6 +17,22 @@
 
 namespace smgpu {
 
+// One 16-byte record per header / entry, so that a re-visit (a jump to a random point) touches one or two
+// cache lines on the host.  The bits are laid out so that the host treats headers and entries alike:
+//   act = !frozen[slot] && (bits & sel)          sel = 1: the visiting point sits at its proposal, 2: at its current position
+//   bit0 / bit1  entry: the neighbour must freeze when the visiting point is at its proposal / current position
+//                header: both = the point freezes itself when visited unfrozen (moved && own angles deteriorate)
+//   bit4  entry: push the neighbour for a re-visit when it gets frozen (it has a slot and its re-visit can act)
+//   bit5  `slot` is a real slot (its frozen flag is updated); otherwise slot = nRelevant + (frozen before the walk)
+//   bit6  header: visited unfrozen and not freezing itself, the point acts from its proposal (sel = 1)
+//   bit7  header
+struct WalkItem {
+    int slot;             // header: the point's relevant slot;   entry: the neighbour's relevant slot, or see bit5
+    int id;               // header: the point id;                entry: the neighbour's point id
+    unsigned bits;
+    int hpos;             // position of the header item of `slot` (bit5 set)
+};
+
 struct WalkView {
     int* activeSlot;      // [P] slot of an active point, -1 otherwise
     int* blkA; int* blkE; // per 256-point block: active count / entry count, then exclusive offsets
@@ -32,8 +48,12 @@ struct WalkView {
     // true entries travel to the host; every other active point is a pure sink in the walk
     int* relSlot;         // [nActive] slot among the relevant points or -1
     int* header2;         // {nRelevant, nBadEntries}
-    int* relIds; int* relEntOff; uint8_t* relBits;
-    int* badNbr; int* badSlot; uint8_t* badBits;
+    uint8_t* relBits;     // [nRelevant] actBits | bit3: a re-visit (point held at its current position) can act
+    // The relevant points and their true entries as ONE item sequence in the order the reference's walk first
+    // visits them (points by descending id, entries by ascending list position): per point a header item
+    // followed by its entry items.  The host replays it with a flat, branch-free loop.
+    int* hdrPos;          // [nRelevant] position of the point's header item
+    WalkItem* items;      // [nRelevant + nBadEntries]
 };
 
 __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
@@ -170,7 +190,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA) {
+__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR, int nB) {
     const int a = blockIdx.x * kBlock + threadIdx.x;
     int r = 0, b = 0;
     if (a < nA) {
@@ -193,29 +213,48 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA) {
     if (a < nA) w.relSlot[a] = r ? offR + ir - 1 : -1;
     if (r) {
         const int slot = offR + ir - 1;
-        int eo = offB + ib - b;
-        w.relIds[slot] = w.actIds[a];
-        w.relBits[slot] = w.actBits[a];
-        w.relEntOff[slot] = eo;
+        const int eoEnd = offB + ib;                       // entries of slots 0..slot
+        // visiting order: slot nR-1 first; every earlier-visited point contributes its header and its entries
+        int pos = (nR - 1 - slot) + (nB - eoEnd);
+        w.hdrPos[slot] = pos;
+        const int hdr = pos++;
+        uint8_t anyOld = 0;
         for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) {
             const uint8_t nb = w.entBits[k];
             if (!entryActs(nb)) continue;
-            w.badNbr[eo] = w.entNbr[k];
-            w.badSlot[eo] = w.entSlot[k];    // active slot for now; k_rel_link turns it into a relevant slot
-            w.badBits[eo] = nb;
-            ++eo;
+            w.items[pos] = WalkItem{w.entSlot[k], w.entNbr[k], nb, 0};   // active slot for now, see k_rel_link
+            anyOld |= nb & 2;
+            ++pos;
         }
+        // bit 3: a re-visit of this point after a neighbour froze it (held at its current position, SM.C:1431)
+        // can freeze somebody; without it the replay does not need to come back
+        const uint8_t rb = w.actBits[a] | (anyOld ? 8 : 0);
+        w.relBits[slot] = rb;
+        const bool moved = rb & 2, selfBad = rb & 1;
+        w.items[hdr] = WalkItem{slot, w.actIds[a], ((moved && selfBad) ? 3u : 0u) | 32u | ((moved && !selfBad) ? 64u : 0u) | 128u, hdr};
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_rel_link(WalkView w, int nR, int nB) {
+__global__ void __launch_bounds__(kBlock) k_rel_link(WalkView w, int nItems, int nR) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i == 0) w.relEntOff[nR] = nB;
-    if (i >= nB) return;
-    const int sl = w.badSlot[i];
-    // a neighbour that is not active, or active but unable to act, is a sink: keep -1 / -2 apart because the
-    // replay must still honour "already frozen" for active sinks through their initial flag only
-    w.badSlot[i] = (sl >= 0) ? w.relSlot[sl] : -1;
+    if (i >= nItems) return;
+    WalkItem it = w.items[i];
+    if (it.bits & 0x80u) return;
+    // a neighbour that is not active, or active but unable to act, is a sink: the replay only honours its
+    // "frozen before the walk" bit (two constant pseudo slots behind the real ones)
+    const unsigned nb = it.bits;
+    const int rs = (it.slot >= 0) ? w.relSlot[it.slot] : -1;
+    unsigned bits = nb & 3u;
+    if (rs >= 0) {
+        it.slot = rs;
+        it.hpos = w.hdrPos[rs];
+        bits |= 32u;
+        if (w.relBits[rs] & 8) bits |= 16u;
+    } else {
+        it.slot = nR + ((nb >> 3) & 1u);
+    }
+    it.bits = bits;
+    w.items[i] = it;
 }
 
 __global__ void __launch_bounds__(kBlock) k_walk_apply(State s, const int* ids, int n) {

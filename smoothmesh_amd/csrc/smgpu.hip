@@ -91,6 +91,7 @@ struct smgpu_handle {
     size_t pinnedBytes = 0;
     std::vector<uint8_t> walkFrozen;
     std::vector<int> walkStack, walkOut;
+    std::vector<char> walkHost;
     // f32 filters in front of the two angle evaluators (kernels_filter.hpp); SMGPU_FILTER=0 disables
     bool useFilter = true, exactAll = false;
     uint8_t *dEdgeFlag = nullptr, *dFaMaybe = nullptr, *dEaMaybe = nullptr;
@@ -562,12 +563,9 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     rc |= devAlloc(h, &w.entBits, E);
     rc |= devAlloc(h, &w.relSlot, P);
     rc |= devAlloc(h, &w.header2, 4);
-    rc |= devAlloc(h, &w.relIds, P);
-    rc |= devAlloc(h, &w.relEntOff, P + 1);
     rc |= devAlloc(h, &w.relBits, P);
-    rc |= devAlloc(h, &w.badNbr, E);
-    rc |= devAlloc(h, &w.badSlot, E);
-    rc |= devAlloc(h, &w.badBits, E);
+    rc |= devAlloc(h, &w.hdrPos, P);
+    rc |= devAlloc(h, &w.items, E + P);
     if (rc) return 1;
     h->walkAlloc = true;
     return 0;
@@ -584,36 +582,92 @@ static int ensurePinned(smgpu_handle* h, size_t bytes) {
     return 0;
 }
 
-// The reference's stack walk SM.C:1347-1434 over the predicate bit tables.  Slots ascend with the point id,
-// so the reference's pop order (highest id first) is slot nA-1 .. 0; a point frozen by a neighbour is pushed
-// and re-visited before the walk continues (SM.C:1431).  Non-active points never act (SM.C:1367-1369), so
-// only freezing them is recorded.
-static void replayWalk(int nA, const int* actIds, const int* entOff, const uint8_t* actBits, const int* entNbr,
-                       const int* entSlot, const uint8_t* entBits, std::vector<uint8_t>& frozen, std::vector<int>& stack,
-                       std::vector<int>& out) {
-    frozen.resize((size_t)nA);
-    for (int a = 0; a < nA; ++a) frozen[(size_t)a] = (actBits[a] & 4) ? 1 : 0;
-    stack.clear();
-    out.clear();
-    for (int top = nA - 1; top >= 0; --top) {
-        stack.push_back(top);
-        while (!stack.empty()) {
-            const int a = stack.back();
-            stack.pop_back();
-            const uint8_t sb = actBits[a];
-            bool useNew = !frozen[(size_t)a] && (sb & 2);                        // SM.C:1376-1385
-            if (useNew && (sb & 1)) { frozen[(size_t)a] = 1; out.push_back(actIds[a]); useNew = false; }   // SM.C:1391-1399
-            for (int k = entOff[a]; k < entOff[a + 1]; ++k) {                   // SM.C:1406-1433
-                const uint8_t nb = entBits[k];
-                if (!(nb & 4)) continue;                                         // neighbour not moving
-                const int sl = entSlot[k];
-                if (sl >= 0 ? frozen[(size_t)sl] : (nb & 8)) continue;           // neighbour already frozen
-                if (useNew ? (nb & 1) : (nb & 2)) {
-                    out.push_back(entNbr[k]);
-                    if (sl >= 0) { frozen[(size_t)sl] = 1; stack.push_back(sl); }
-                }
-            }
+// The reference's stack walk SM.C:1347-1434 over the item sequence of k_rel_fill.  Slots ascend with the
+// point id, so the reference's pop order (highest id first) is the order of the items; a point frozen by a
+// neighbour is pushed and re-visited before the walk continues (SM.C:1431).  Non-active points never act
+// (SM.C:1367-1369), so only freezing them is recorded.
+//
+// The first visits are one flat loop over the items without data-dependent branches (the decisions are close to
+// 50/50 and the per-point entry lists are 2-3 long: the nested, branchy form spent its time in mispredictions):
+// candidates are always stored and the cursors advance by the 0/1 outcome.  Re-visits are rare and take the
+// ordinary path (drain) before the next point starts.
+static void drainWalk(const WalkItem* __restrict items, int N, uint8_t* __restrict frozen, int* __restrict stack, int* __restrict out,
+                      int* spIO, size_t* nOutIO) {
+    int sp = *spIO;
+    size_t nOut = *nOutIO;
+    while (sp) {
+        int i = stack[--sp];                                                     // header position
+        const WalkItem hd = items[i];
+        unsigned sel = 2;                                                        // SM.C:1376-1385
+        if (!frozen[hd.slot]) {
+            if (hd.bits & 3u) { frozen[hd.slot] = 1; out[nOut++] = hd.id; }      // SM.C:1391-1399
+            else if (hd.bits & 64u) sel = 1;
         }
+        for (++i; i < N && !(items[i].bits & 0x80u); ++i) {                      // SM.C:1406-1433
+            const WalkItem e = items[i];
+            if (frozen[e.slot] || !(e.bits & sel)) continue;                     // neighbour already frozen / not hurt
+            out[nOut++] = e.id;
+            if (e.bits & 32u) frozen[e.slot] = 1;
+            if (e.bits & 16u) { stack[sp++] = e.hpos; __builtin_prefetch(&items[e.hpos]); }
+        }
+    }
+    *spIO = sp;
+    *nOutIO = nOut;
+}
+
+static void replayWalk(const WalkItem* __restrict items, int N, int nA, const uint8_t* __restrict relBits, std::vector<uint8_t>& frozenV,
+                       std::vector<int>& stackV, std::vector<int>& outV) {
+    frozenV.resize((size_t)nA + 2);
+    stackV.resize((size_t)nA + 8);
+    if (outV.size() < (size_t)2 * N + 8) outV.resize((size_t)2 * N + 8);
+    uint8_t* __restrict frozen = frozenV.data();
+    int* __restrict stack = stackV.data();
+    int* __restrict out = outV.data();
+    for (int a = 0; a < nA; ++a) frozen[a] = (relBits[a] >> 2) & 1;
+    frozen[nA] = 0;                                  // pseudo slots of the sinks: not frozen / frozen before the walk
+    frozen[nA + 1] = 1;
+    size_t nOut = 0;
+    int sp = 0;
+    unsigned sel = 2;
+    // first visits: one pass over the items, no data-dependent branch besides the (rare) drain
+    for (int i = 0; i < N; ++i) {
+        const WalkItem it = items[i];
+        const unsigned bits = it.bits;
+        const unsigned isH = bits >> 7;
+        if (__builtin_expect((isH * (unsigned)sp) != 0, 0)) {   // the previous point is complete: its pushes come first
+            int spT = sp;
+            size_t nT = nOut;
+            drainWalk(items, N, frozen, stack, out, &spT, &nT);
+            sp = spT;
+            nOut = nT;
+        }
+        const unsigned nf = frozen[it.slot] ^ 1u;
+        const unsigned act = nf & (0u - (unsigned)((bits & sel) != 0));
+        out[nOut] = it.id;
+        nOut += act;
+        frozen[it.slot] |= (uint8_t)(act & (bits >> 5));
+        stack[sp] = it.hpos;
+        sp += (int)(act & (bits >> 4));
+        const unsigned selH = 2u - (nf & (bits >> 6));                           // header: SM.C:1376-1399
+        sel ^= (sel ^ selH) & (0u - isH);
+    }
+    {
+        int spT = sp;
+        size_t nT = nOut;
+        drainWalk(items, N, frozen, stack, out, &spT, &nT);
+        nOut = nT;
+    }
+    outV.resize(nOut);
+}
+
+// Busy-wait for the stream: the host replay that follows is latency critical, and a blocking wait lets the core
+// drop to a low-power state (the replay then ran ~2x slower than on a busy core).
+static int spinSync(hipStream_t stream) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) return fail(std::string("hipStreamQuery: ") + hipGetErrorString(e));
+        __builtin_ia32_pause();
     }
 }
 
@@ -630,7 +684,7 @@ static int runHostWalk(smgpu_handle* h) {
         })) return 1;
     int* hdr = (int*)h->pinned;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
+    if (spinSync(h->stream)) return 1;
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
@@ -644,34 +698,43 @@ static int runHostWalk(smgpu_handle* h) {
             hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, nSlotBlocks);
         })) return 1;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
+    if (spinSync(h->stream)) return 1;
     const int nR = hdr[0], nB = hdr[1];
     if (nR <= 0) return 0;
+    const int nItems = nR + nB;
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
-            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(std::max(nB, 1))), dim3(kBlock), 0, h->stream, w, nR, nB);
+            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA, nR, nB);
+            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(nItems)), dim3(kBlock), 0, h->stream, w, nItems, nR);
         })) return 1;
-    const size_t oIds = 0, oOff = oIds + 4 * (size_t)nR, oNbr = oOff + 4 * ((size_t)nR + 1), oSlot = oNbr + 4 * (size_t)nB,
-                 oABits = oSlot + 4 * (size_t)nB, oEBits = oABits + (size_t)nR, total = oEBits + (size_t)nB;
+    const size_t oItems = 0, oRel = oItems + sizeof(WalkItem) * (size_t)nItems, total = oRel + (size_t)nR;
     if (ensurePinned(h, total + 16)) return 1;
     char* base = (char*)h->pinned;
-    HIP_OK(hipMemcpyAsync(base + oIds, w.relIds, 4 * (size_t)nR, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipMemcpyAsync(base + oOff, w.relEntOff, 4 * ((size_t)nR + 1), hipMemcpyDeviceToHost, h->stream));
-    if (nB) {
-        HIP_OK(hipMemcpyAsync(base + oNbr, w.badNbr, 4 * (size_t)nB, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipMemcpyAsync(base + oSlot, w.badSlot, 4 * (size_t)nB, hipMemcpyDeviceToHost, h->stream));
-        HIP_OK(hipMemcpyAsync(base + oEBits, w.badBits, (size_t)nB, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oItems, w.items, sizeof(WalkItem) * (size_t)nItems, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(base + oRel, w.relBits, (size_t)nR, hipMemcpyDeviceToHost, h->stream));
+    if (spinSync(h->stream)) return 1;
+    if (const char* dump = std::getenv("SMGPU_DUMP_WALK")) {          // offline analysis of the replay input
+        static int calls = 0;
+        if (++calls == 3) {
+            if (FILE* f = std::fopen(dump, "wb")) {
+                const int64_t hdr3[3] = {nR, nB, (int64_t)total};
+                std::fwrite(hdr3, sizeof(hdr3), 1, f);
+                std::fwrite(base, 1, total, f);
+                std::fclose(f);
+            }
+        }
     }
-    HIP_OK(hipMemcpyAsync(base + oABits, w.relBits, (size_t)nR, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
     const auto t0 = std::chrono::steady_clock::now();
-    replayWalk(nR, (const int*)(base + oIds), (const int*)(base + oOff), (const uint8_t*)(base + oABits), (const int*)(base + oNbr),
-               (const int*)(base + oSlot), (const uint8_t*)(base + oEBits), h->walkFrozen, h->walkStack, h->walkOut);
+    // the walk runs on a copy in ordinary memory (a streaming copy that also warms the cache)
+    h->walkHost.resize(total);
+    std::memcpy(h->walkHost.data(), base, total);
+    const char* hb = h->walkHost.data();
+    const double copyMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    replayWalk((const WalkItem*)(hb + oItems), nItems, nR, (const uint8_t*)(hb + oRel), h->walkFrozen, h->walkStack, h->walkOut);
     const double replayMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (h->timing) h->ms[K_FA_WALK] += replayMs;
     if (envInt("SMGPU_VERBOSE", 0) > 1)
-        std::fprintf(stderr, "[smgpu] walk: active %d entries %d -> acting %d entries %d, froze %zu, replay %.3f ms\n", nA, nE, nR, nB,
-                     h->walkOut.size(), replayMs);
+        std::fprintf(stderr, "[smgpu] walk: active %d entries %d -> acting %d entries %d, froze %zu, replay %.3f ms (copy %.3f ms)\n", nA, nE, nR, nB,
+                     h->walkOut.size(), replayMs, copyMs);
     h->launches[K_FA_WALK]++;
     const int nOut = (int)h->walkOut.size();
     if (nOut > 0) {
@@ -679,7 +742,7 @@ static int runHostWalk(smgpu_handle* h) {
         std::memcpy(base, h->walkOut.data(), sizeof(int) * (size_t)nOut);
         HIP_OK(hipMemcpyAsync(w.entOwner, base, sizeof(int) * (size_t)nOut, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_walk_apply, dim3(gridFor(nOut)), dim3(kBlock), 0, h->stream, s, w.entOwner, nOut);
-        HIP_OK(hipStreamSynchronize(h->stream));   // the pinned buffer is reused by the next iteration
+        if (spinSync(h->stream)) return 1;   // the pinned buffer is reused by the next iteration
     }
     return 0;
 }
