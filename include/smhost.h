@@ -37,6 +37,9 @@ int smhost_write_polymesh(const char* polyMeshDir, const char* location, int32_t
                           const char* const* patchNames, const char* const* patchTypes, const int32_t* patchNFaces,
                           const int32_t* patchStart, const int32_t* patchMyProc, const int32_t* patchNbrProc,
                           int32_t binary, int32_t precision);
+/* controlDict's writeCompression: files written afterwards are gzip-compressed (<file>.gz).  Reading accepts a
+ * <file>.gz wherever <file> is missing, as OpenFOAM does. */
+int smhost_set_write_compression(int32_t on);
 /* Write <dir>/points only (mesh.write() of a moved mesh, SM.C:2430); precision as SM.C:2425. */
 int smhost_write_points(const char* polyMeshDir, const char* location, int32_t nPoints, const double* points,
                         int32_t binary, int32_t precision);

@@ -2,6 +2,7 @@
 #include "polymesh_io.hpp"
 
 #include <sys/stat.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -10,6 +11,7 @@
 #include <cstring>
 #include <map>
 #include <stdexcept>
+#include <vector>
 
 namespace smhost {
 
@@ -32,10 +34,29 @@ void makeDirs(const std::string& path) {
     }
 }
 
+static bool gWriteCompression = false;
+void setWriteCompression(bool on) { gWriteCompression = on; }
+
+// <file>.gz (OpenFOAM's writeCompression on) is read when <file> itself does not exist, as OpenFOAM does
+static std::string slurpGz(const std::string& file) {
+    gzFile g = gzopen(file.c_str(), "rb");
+    if (!g) throw std::runtime_error("cannot open " + file);
+    std::string s;
+    std::vector<char> buf(1 << 20);
+    for (;;) {
+        const int n = gzread(g, buf.data(), (unsigned)buf.size());
+        if (n < 0) { gzclose(g); throw std::runtime_error("gzip read error on " + file); }
+        if (n == 0) break;
+        s.append(buf.data(), (size_t)n);
+    }
+    gzclose(g);
+    return s;
+}
+
 static std::string slurp(const std::string& file) {
     FILE* f = std::fopen(file.c_str(), "rb");
     if (!f) {
-        if (fileExists(file + ".gz")) throw std::runtime_error(file + ".gz: compressed polyMesh files are not supported (gunzip first)");
+        if (fileExists(file + ".gz")) return slurpGz(file + ".gz");
         throw std::runtime_error("cannot open " + file);
     }
     std::fseek(f, 0, SEEK_END);
@@ -211,6 +232,23 @@ FILE* openOut(const std::string& file) {
     if (!f) throw std::runtime_error("cannot write " + file);
     return f;
 }
+// close; with write compression the file becomes <file>.gz.  The other variant is removed either way so that a
+// reader never finds a stale copy.
+void closeOut(FILE* f, const std::string& file) {
+    if (std::fclose(f) != 0) throw std::runtime_error("write error on " + file);
+    if (!gWriteCompression) { std::remove((file + ".gz").c_str()); return; }
+    const std::string data = slurp(file);
+    gzFile g = gzopen((file + ".gz").c_str(), "wb");
+    if (!g) throw std::runtime_error("cannot write " + file + ".gz");
+    size_t off = 0;
+    while (off < data.size()) {
+        const unsigned chunk = (unsigned)std::min<size_t>(data.size() - off, 1u << 30);
+        if (gzwrite(g, data.data() + off, chunk) != (int)chunk) { gzclose(g); throw std::runtime_error("gzip write error on " + file + ".gz"); }
+        off += chunk;
+    }
+    if (gzclose(g) != Z_OK) throw std::runtime_error("gzip write error on " + file + ".gz");
+    std::remove(file.c_str());
+}
 }  // namespace
 
 void readPoints(const std::string& file, std::vector<double>& pts) {
@@ -335,7 +373,7 @@ void writePoints(const std::string& dir, const std::string& location, int32_t nP
     }
     std::fputs(")\n", f);
     writeFooter(f);
-    std::fclose(f);
+    closeOut(f, dir + "/points");
 }
 
 void writeLabelList(const std::string& file, const std::string& location, const std::string& object, const std::string& cls,
@@ -347,7 +385,7 @@ void writeLabelList(const std::string& file, const std::string& location, const 
     else { std::fputc('\n', f); for (int64_t i = 0; i < n; ++i) std::fprintf(f, "%d\n", v[i]); }
     std::fputs(")\n", f);
     writeFooter(f);
-    std::fclose(f);
+    closeOut(f, file);
 }
 
 void writePolyMesh(const std::string& dir, const std::string& location, const PolyMeshData& m, bool binary, int precision) {
@@ -374,7 +412,7 @@ void writePolyMesh(const std::string& dir, const std::string& location, const Po
             std::fputs(")\n", f);
         }
         writeFooter(f);
-        std::fclose(f);
+        closeOut(f, dir + "/faces");
     }
     char note[256];
     std::snprintf(note, sizeof note, "nPoints:%d  nCells:%d  nFaces:%d  nInternalFaces:%d", m.nPoints(), m.nCells, nF, m.nInternalFaces());
@@ -395,7 +433,7 @@ void writePolyMesh(const std::string& dir, const std::string& location, const Po
         }
         std::fputs(")\n", f);
         writeFooter(f);
-        std::fclose(f);
+        closeOut(f, dir + "/boundary");
     }
 }
 

@@ -37,6 +37,8 @@ void writeLabelList(const std::string& file, const std::string& location, const 
                     const std::string& cls, int64_t n, const int32_t* v, bool binary, const std::string& note = "");
 void writePolyMesh(const std::string& polyMeshDir, const std::string& location, const PolyMeshData& m, bool binary,
                    int precision);
+// OpenFOAM's writeCompression: every file written afterwards becomes <file>.gz (reading accepts both always)
+void setWriteCompression(bool on);
 void makeDirs(const std::string& path);
 bool fileExists(const std::string& path);
 bool dirExists(const std::string& path);

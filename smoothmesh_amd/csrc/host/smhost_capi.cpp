@@ -78,6 +78,10 @@ int smhost_write_polymesh(const char* dir, const char* location, int32_t nPoints
         writePolyMesh(dir, location, d, binary != 0, precision);
     });
 }
+int smhost_set_write_compression(int32_t on) {
+    return guarded([&] { setWriteCompression(on != 0); });
+}
+
 int smhost_write_points(const char* dir, const char* location, int32_t nPoints, const double* points, int32_t binary, int32_t precision) {
     return guarded([&] { writePoints(dir, location, nPoints, points, binary != 0, precision); });
 }

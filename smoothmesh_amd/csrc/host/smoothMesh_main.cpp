@@ -205,7 +205,7 @@ std::string findInstance(const std::string& root, const std::vector<std::pair<do
                          bool startIsConstant, const std::string& file) {
     if (!startIsConstant)
         for (auto it = times.rbegin(); it != times.rend(); ++it)
-            if (it->first <= startValue + 1e-12 && fileExists(root + "/" + it->second + "/polyMesh/" + file))
+            if (it->first <= startValue + 1e-12 && (fileExists(root + "/" + it->second + "/polyMesh/" + file) || fileExists(root + "/" + it->second + "/polyMesh/" + file + ".gz")))
                 return root + "/" + it->second + "/polyMesh";
     return root + "/constant/polyMesh";
 }
@@ -278,6 +278,10 @@ int main(int argc, char** argv) {
                                                  : (control.count("writeFormat") && control.at("writeFormat") == "binary");
     int writePrecision = control.count("writePrecision") ? std::atoi(control.at("writePrecision").c_str()) : 6;
     writePrecision = std::max(10, writePrecision);   // SM.C:2425
+    if (control.count("writeCompression")) {          // on / true / yes / compressed
+        const std::string wc = control.at("writeCompression");
+        setWriteCompression(wc == "on" || wc == "true" || wc == "yes" || wc == "compressed");
+    }
 
     // sub-domain roots
     std::vector<Rank> R;
@@ -316,7 +320,7 @@ int main(int argc, char** argv) {
             K.internal = findInternalMeshPoints(K.mesh);
             if (opt.parallel) {
                 const std::string ppa = K.root + "/constant/polyMesh/pointProcAddressing";
-                if (!fileExists(ppa)) fatal(ppa + " not found (written by decomposePar; needed to match shared points)");
+                if (!fileExists(ppa) && !fileExists(ppa + ".gz")) fatal(ppa + " not found (written by decomposePar; needed to match shared points)");
                 readLabelList(ppa, K.pointProc);
                 if ((int32_t)K.pointProc.size() != K.mesh.nPoints()) fatal(ppa + ": size does not match the number of points");
             }

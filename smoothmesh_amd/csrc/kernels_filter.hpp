@@ -37,7 +37,15 @@ __device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
 
 // ---- face angles: per edge GOOD (0) / UNSURE (1) -------------------------------------------------------
 // GOOD = every cell angle of the edge lies inside (small + margin, large - margin) for sure.
-__global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s, Prm prm, uint8_t* edgeFlag) {
+// An UNSURE edge marks both end points in faMaybe (zeroed before the launch, like faActive): a point may be
+// outside the good range only if one of its edges is UNSURE; every other point is inside for sure (SM.C:1367-1369).
+__device__ __forceinline__ void markUnsureEdge(const State& s, const int* edges, int e, uint8_t* faMaybe) {
+    faMaybe[edges[2 * e]] = 1;          // racing writers all store 1
+    faMaybe[edges[2 * e + 1]] = 1;
+    atomicAdd(&s.acc->nFaMaybe, 1);     // rare on a decent mesh
+}
+
+__global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s, Prm prm, uint8_t* faMaybe) {
     if (s.acc->stop) return;
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= m.nEdges) return;
@@ -73,19 +81,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s,
         }
         if (ok && inside && nc > 0) flag = 0;
     }
-    edgeFlag[e] = flag;
-}
-
-// a point may be outside the good range only if one of its edges is UNSURE
-__global__ void __launch_bounds__(kBlock) k_fa_point_flags(MeshView m, State s, const uint8_t* edgeFlag, uint8_t* faMaybe) {
-    if (s.acc->stop) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= m.nPoints) return;
-    uint8_t any = 0;
-    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) any |= edgeFlag[m.peEdge[k]];
-    faMaybe[p] = any;
-    if (any) atomicAdd(&s.acc->nFaMaybe, 1);   // rare on a decent mesh
-    if (!any) s.faActive[p] = 0;     // every incident edge is GOOD: inside the good range for sure (SM.C:1367-1369)
+    if (flag) markUnsureEdge(s, m.edges, e, faMaybe);
 }
 
 // ---- edge angles: per point "may freeze" ----------------------------------------------------------------
@@ -178,7 +174,7 @@ struct EdgeTileView {
 // edges need are staged in LDS (the per-edge form gathers ~10 records of 24 bytes per edge from global memory
 // and is bound by those gathers).  Ring order as in k_fa_edges: cell i lies between ring faces i and i+1.
 template <int T>
-__global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTileView g, uint8_t* edgeFlag, int nLaunch, int xcdMap) {
+__global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTileView g, const int* edges, uint8_t* faMaybe, int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
@@ -263,7 +259,7 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
 #undef SMGPU_FA_PROJECT
         if (ok && inside) flag = 0;
     }
-    edgeFlag[e] = flag;
+    if (flag) markUnsureEdge(s, edges, e, faMaybe);
 }
 
 }  // namespace smgpu

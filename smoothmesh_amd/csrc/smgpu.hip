@@ -33,7 +33,7 @@ enum KernelId { K_FACE_GEOM = 0, K_CELL_CENTRES, K_SMOOTH_FINAL, K_SMOOTH_PROP, 
                 K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_EA_FILTER, K_FA_FILTER, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_face_geom", "k_cell_centres", "k_smooth<final>", "k_smooth<proposal>",
                                             "k_edge_angle", "k_fa_edges", "k_fa_points", "k_fa_pred", "k_fa_walk",
-                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile", "k_edge_angle_filter", "k_fa_edges_filter+flags"};
+                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile", "k_edge_angle_filter", "k_fa_edges_filter"};
 
 struct smgpu_handle {
     Topology topo;
@@ -94,7 +94,7 @@ struct smgpu_handle {
     std::vector<char> walkHost;
     // f32 filters in front of the two angle evaluators (kernels_filter.hpp); SMGPU_FILTER=0 disables
     bool useFilter = true, exactAll = false;
-    uint8_t *dEdgeFlag = nullptr, *dFaMaybe = nullptr, *dEaMaybe = nullptr;
+    uint8_t *dFaMaybe = nullptr, *dEaMaybe = nullptr;
     // the face-angle filter only needs the geometry, so it runs on a side stream next to the proposal kernel
     hipStream_t side = nullptr;
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -392,7 +392,6 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.ptMin, P);
     rc |= devAlloc(h, &s.ptMax, P);
     rc |= devAlloc(h, &s.faActive, P);
-    rc |= devAlloc(h, &h->dEdgeFlag, E);
     rc |= devAlloc(h, &h->dFaMaybe, P);
     rc |= devAlloc(h, &h->dEaMaybe, P);
     rc |= devAlloc(h, &s.faS, P);
@@ -757,9 +756,10 @@ static int forkFaFilter(smgpu_handle* h) {
     HIP_OK(hipEventRecord(h->evFork, h->stream));
     HIP_OK(hipStreamWaitEvent(h->side, h->evFork, 0));
     if (launchK(h, K_FA_FILTER, [&] {
-            hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->side, s, prm, h->ev, h->dEdgeFlag,
+            (void)hipMemsetAsync(h->dFaMaybe, 0, (size_t)m.nPoints, h->side);
+            (void)hipMemsetAsync(s.faActive, 0, (size_t)m.nPoints, h->side);
+            hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->side, s, prm, h->ev, m.edges, h->dFaMaybe,
                                h->etl.nTiles, h->xcdMap);
-            hipLaunchKernelGGL(k_fa_point_flags, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->side, m, s, h->dEdgeFlag, h->dFaMaybe);
         }, h->side)) return 1;
     HIP_OK(hipEventRecord(h->evJoin, h->side));
     h->faFilterInFlight = true;
@@ -807,12 +807,13 @@ static int runConstraints(smgpu_handle* h) {
             faMaybe = h->dFaMaybe;
         } else if (filt) {
             if (launchK(h, K_FA_FILTER, [&] {
+                    (void)hipMemsetAsync(h->dFaMaybe, 0, (size_t)m.nPoints, h->stream);
+                    (void)hipMemsetAsync(s.faActive, 0, (size_t)m.nPoints, h->stream);
                     if (h->edgeTilesOk)
-                        hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, h->dEdgeFlag,
+                        hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, m.edges, h->dFaMaybe,
                                            h->etl.nTiles, h->xcdMap);
                     else
-                        hipLaunchKernelGGL(k_fa_edges_filter, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, prm, h->dEdgeFlag);
-                    hipLaunchKernelGGL(k_fa_point_flags, dim3(gP), dim3(kBlock), 0, h->stream, m, s, h->dEdgeFlag, h->dFaMaybe);
+                        hipLaunchKernelGGL(k_fa_edges_filter, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, prm, h->dFaMaybe);
                 })) return 1;
             faMaybe = h->dFaMaybe;
         }

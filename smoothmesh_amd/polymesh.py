@@ -30,6 +30,7 @@ def lib():
                                             C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), i32p, i32p, i32p, i32p,
                                             C.c_int32, C.c_int32]
         l.smhost_write_points.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, f64p, C.c_int32, C.c_int32]
+        l.smhost_set_write_compression.argtypes = [C.c_int32]
         l.smhost_read_label_list.argtypes = [C.c_char_p, i32p, C.POINTER(C.c_int64)]
         l.smhost_write_label_list.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, i32p, C.c_int32]
         l.smhost_gen_cavity_mesh.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_void_p)]
@@ -99,6 +100,11 @@ def write_polymesh(polyMeshDir, mesh: PolyMesh, location="constant/polyMesh", bi
                                        _p(nf, i32p), _p(st, i32p), _p(my, i32p), _p(nb, i32p), int(binary), precision))
 
 
+def set_write_compression(on):
+    """controlDict writeCompression: files written afterwards become <file>.gz (reading accepts both always)"""
+    _check(lib().smhost_set_write_compression(int(bool(on))))
+
+
 def write_points(polyMeshDir, points, location, binary=False, precision=10):
     pts = np.ascontiguousarray(points, dtype=np.float64)
     _check(lib().smhost_write_points(polyMeshDir.encode(), location.encode(), pts.shape[0], _p(pts, f64p), int(binary), precision))
@@ -134,24 +140,29 @@ writeControl    timeStep;
 writeInterval   1;
 writeFormat     %s;
 writePrecision  %d;
+writeCompression %s;
 timeFormat      general;
 timePrecision   6;
 """
 
 
-def write_case(caseDir, mesh: PolyMesh, binary=False, precision=17, writeFormat="ascii", writePrecision=10):
-    """A minimal OpenFOAM case: system/controlDict + constant/polyMesh."""
+def write_case(caseDir, mesh: PolyMesh, binary=False, precision=17, writeFormat="ascii", writePrecision=10, writeCompression=False):
+    """A minimal OpenFOAM case: system/controlDict + constant/polyMesh (gzip-compressed with writeCompression)."""
     os.makedirs(os.path.join(caseDir, "system"), exist_ok=True)
     with open(os.path.join(caseDir, "system", "controlDict"), "w") as f:
-        f.write(CONTROL_DICT % (writeFormat, writePrecision))
-    write_polymesh(os.path.join(caseDir, "constant", "polyMesh"), mesh, binary=binary, precision=precision)
+        f.write(CONTROL_DICT % (writeFormat, writePrecision, "on" if writeCompression else "off"))
+    set_write_compression(writeCompression)
+    try:
+        write_polymesh(os.path.join(caseDir, "constant", "polyMesh"), mesh, binary=binary, precision=precision)
+    finally:
+        set_write_compression(False)
 
 
 def write_decomposed_case(caseDir, subs, binary=False, precision=17, **kw):
     """processorN/constant/polyMesh + pointProcAddressing, decomposePar layout."""
     os.makedirs(os.path.join(caseDir, "system"), exist_ok=True)
     with open(os.path.join(caseDir, "system", "controlDict"), "w") as f:
-        f.write(CONTROL_DICT % (kw.get("writeFormat", "ascii"), kw.get("writePrecision", 10)))
+        f.write(CONTROL_DICT % (kw.get("writeFormat", "ascii"), kw.get("writePrecision", 10), "off"))
     for s in subs:
         d = os.path.join(caseDir, f"processor{s.rank}", "constant", "polyMesh")
         write_polymesh(d, s.mesh, binary=binary, precision=precision)

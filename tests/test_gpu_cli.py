@@ -47,6 +47,23 @@ def test_serial_case(tmp_path, oracle_lib, fmt):
     assert "Create mesh for time = 12" in out2 and os.path.isdir(tmp_path / "15")
 
 
+def test_compressed_case(tmp_path, oracle_lib):
+    """writeCompression on in controlDict: the mesh is read from *.gz and points are written as points.gz"""
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_case
+    m = hex_block(7, 6, 5, jitter=0.3, seed=5)
+    write_case(str(tmp_path), m, binary=True, writeFormat="binary", writeCompression=True)
+    assert "points.gz" in os.listdir(tmp_path / "constant" / "polyMesh")
+    _run(["-case", str(tmp_path), "-centroidalIters", "4", "-relTol", "0"])
+    assert os.listdir(tmp_path / "4" / "polyMesh") == ["points.gz"]
+    o = oracle_lib.Oracle(m)
+    o.set_params(default_params(o.mesh_stats()[0]))
+    o.iterate(4, 0.0)
+    got = read_polymesh(str(tmp_path / "constant" / "polyMesh"), pointsDir=str(tmp_path / "4" / "polyMesh")).points
+    assert rel_linf(got, o.points()) <= 1e-13
+
+
 def test_relTol_stop_and_option_errors(tmp_path):
     from smoothmesh_amd.meshgen import hex_block
     from smoothmesh_amd.polymesh import write_case

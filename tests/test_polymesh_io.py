@@ -56,6 +56,38 @@ def test_points_precision_and_time_instance(tmp_path):
     assert 'location    "5/polyMesh"' in open(tmp_path / "5" / "polyMesh" / "points").read()
 
 
+@pytest.mark.parametrize("binary", [False, True])
+def test_gzip_compressed_files(tmp_path, binary):
+    """writeCompression on: every file is <file>.gz; a reader takes <file>.gz where <file> is missing -- checked
+    against files compressed by an independent writer (Python's gzip) and against our own writer"""
+    import gzip
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, set_write_compression, write_points, write_polymesh
+    m = hex_block(4, 3, 3, jitter=0.2, seed=3)
+    d = tmp_path / "constant" / "polyMesh"
+    write_polymesh(str(d), m, binary=binary, precision=17)
+    for name in ("points", "faces", "owner", "neighbour", "boundary"):
+        raw = (d / name).read_bytes()
+        with gzip.open(d / (name + ".gz"), "wb") as g:
+            g.write(raw)
+        os.remove(d / name)
+    _same(m, read_polymesh(str(d)))
+    # our writer: compressed output only, decodable by gzip, and no stale plain copy next to it
+    set_write_compression(True)
+    try:
+        moved = m.points * 2.0
+        t = tmp_path / "3" / "polyMesh"
+        write_points(str(t), moved, "3/polyMesh", binary=binary, precision=17)
+    finally:
+        set_write_compression(False)
+    assert sorted(os.listdir(t)) == ["points.gz"]
+    assert b"vectorField" in gzip.open(t / "points.gz").read()
+    assert np.array_equal(read_polymesh(str(d), pointsDir=str(t)).points, moved)
+    # switching compression off again replaces the .gz
+    write_points(str(t), moved, "3/polyMesh", binary=binary, precision=17)
+    assert sorted(os.listdir(t)) == ["points"]
+
+
 def test_reads_handwritten_openfoam_style(tmp_path):
     """comments, inline short lists, uniform-list shorthand, label=64 header -- as OpenFOAM writes them"""
     from smoothmesh_amd.polymesh import read_polymesh
