@@ -147,6 +147,26 @@ int smgpu_iter_ahead(smgpu_handle* h);   /* optional, between mid and end: next 
                                             the shared points -- overlaps exchange F (constraints off)      */
 int smgpu_iter_end(smgpu_handle* h);     /* or recvF, restore, residual -> localStats; movePoints   */
 
+/* ---- optional boundary layer treatment (prismatic layers on selected patches), serial runs ------------------
+ * Replaces SM.C:2186-2221 (set-up: point classification BPS.C:296-340,397-403; calculatePointHopsToBoundary,
+ * calculateBoundaryPointNormals, propagateOuterNeighInfo, OBB.C = src/orthogonalBoundaryBlending.C) and, inside
+ * every later iteration, SM.C:2266 + 2283-2305 (updateNeighCoords, blendWithOrthogonalPoints, second step clamp).
+ * Patches as in polyMesh/boundary: face ranges in file order.  Call after smgpu_create (the set-up uses the
+ * coordinates the engine holds) and before iterating; not available together with smgpu_halo_configure.
+ * *enabled = the reference's doLayerTreatment (a layer patch is selected and layerMaxBlendingFraction > SMALL). */
+typedef struct smgpu_layer_desc {
+    int32_t nPatches;
+    const int32_t* patchStart;     /* [nPatches] first face                                    */
+    const int32_t* patchSize;      /* [nPatches] number of faces                               */
+    const uint8_t* patchKind;      /* [nPatches] 0 ordinary, 1 processor, 2 empty (OBB.C:156-159) */
+    const uint8_t* isLayerPatch;   /* [nPatches] selected by -layerPatches (SM.C:1823)          */
+    double layerMaxBlendingFraction;   /* SM.C:1892, default 0.3                                */
+    double layerEdgeLength;            /* SM.C:1895, default minEdgeLength                      */
+    double layerExpansionRatio;        /* SM.C:1898, default 1.3                                */
+    int32_t minLayers, maxLayers;      /* SM.C:1901-1905, defaults 1 and 4                      */
+} smgpu_layer_desc;
+int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled);
+
 /* ---- debug / parity access (device -> host copy of an internal field) -----------------------
  * name: "cellCentres" [3C], "faceCentres" [3F], "faceAreas" [3F], "newPoints" [3P] (proposal of the
  * last iteration before restore), "isFrozenPoint" [P], "edgeMinAngle"/"edgeMaxAngle" [E],

@@ -228,5 +228,32 @@ void orc_local_stats(void* h, double* out2) {
     out2[0] = d->residualLocal; out2[1] = (double)d->nFrozenLocal;
 }
 
+// boundary layer treatment (serial): patches as (start, size, kind 0/1/2, isLayerPatch)
+void orc_setup_layers(void* h, int nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
+                      double layerMaxBlendingFraction, double layerEdgeLength, double layerExpansionRatio, int minLayers,
+                      int maxLayers) {
+    Domain* d = static_cast<Domain*>(h);
+    std::vector<Patch> p((size_t)nPatches);
+    for (int i = 0; i < nPatches; ++i) { p[i].start = start[i]; p[i].size = size[i]; p[i].kind = kind[i]; p[i].isLayerPatch = isLayer[i] != 0; }
+    LayerParams lp;
+    lp.layerMaxBlendingFraction = layerMaxBlendingFraction;
+    lp.layerEdgeLength = layerEdgeLength;
+    lp.layerExpansionRatio = layerExpansionRatio;
+    lp.minLayers = minLayers;
+    lp.maxLayers = maxLayers;
+    d->setupLayers(p, lp);
+}
+int orc_layers_enabled(void* h) { return static_cast<Domain*>(h)->doLayerTreatment ? 1 : 0; }
+void orc_get_layer_fields(void* h, int* hops, int* outerMap, double* normals, unsigned char* isConnected, unsigned char* isLayerSurface) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int p = 0; p < d->nPoints; ++p) {
+        hops[p] = d->pointHopsToLayerBoundary[p];
+        outerMap[p] = d->pointToOuterPointMap[p];
+        normals[3 * p] = d->pointNormals[p].x; normals[3 * p + 1] = d->pointNormals[p].y; normals[3 * p + 2] = d->pointNormals[p].z;
+        isConnected[p] = d->isConnectedToInternalPoint[p];
+        isLayerSurface[p] = d->isLayerSurfacePoint[p];
+    }
+}
+
 }  // extern "C"
 

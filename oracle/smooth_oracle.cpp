@@ -315,10 +315,135 @@ static double calcARSmoothingRatio(const Vec3& closestPoint1, const Vec3& closes
     return 0.0;
 }
 
+// ---- boundary layer treatment: setup (serial) ---------------------------------------------------------
+static inline Vec3& operator-=(Vec3& a, const Vec3& b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
+
+// OBB.C:141-233.  Note the reference never resets pointNormals: a boundary point's new normal is the
+// normalised sum of its previous (unit) normal and the inverted unit normals of its boundary faces, and every
+// non-zero normal (also the ones copied to internal points) is divided by its magnitude again on every call.
+void Domain::calculateBoundaryPointNormals() {
+    std::vector<int> nFaces(nPoints, 0);
+    for (const Patch& pp : patches) {
+        if (pp.kind == 1) continue;   // processor
+        if (pp.kind == 2) continue;   // empty
+        for (int faceI = 0; faceI < pp.size; ++faceI) {
+            const Vec3 cSf = faceAreas[pp.start + faceI];          // fvPatch::Sf
+            const Vec3 Sf = cSf / mag(cSf);                        // / magSf (= mag(Sf))
+            for (int pointI : faces[pp.start + faceI]) {
+                pointNormals[pointI] -= Sf;
+                ++nFaces[pointI];
+            }
+        }
+    }
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (nFaces[pointI] < 1) continue;
+        const double magNorm = mag(pointNormals[pointI]);
+        if (magNorm < 0.1) { pointNormals[pointI] = ZERO_VECTOR; isSharpEdgePoint[pointI] = 1; }
+        else isSharpEdgePoint[pointI] = 0;
+    }
+    for (int pointI = 0; pointI < nPoints; ++pointI)
+        if (pointNormals[pointI] != ZERO_VECTOR) pointNormals[pointI] /= mag(pointNormals[pointI]);
+}
+
+void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
+    patches = p;
+    lay = lp;
+    bool anyLayer = false;
+    for (const Patch& pp : patches) anyLayer = anyLayer || pp.isLayerPatch;
+    doLayerTreatment = anyLayer && (lay.layerMaxBlendingFraction > SMALL);   // SM.C:2024-2028
+    pointHopsToLayerBoundary.assign(nPoints, -1);      // UNDEF_LABEL, SM.C:1983
+    pointNormals.assign(nPoints, ZERO_VECTOR);         // SM.C:1987
+    outerNeighCoords.assign(nPoints, UNDEF_VECTOR);    // SM.C:1993
+    isOuterNeighInProc.assign(nPoints, 0);
+    pointToOuterPointMap.assign(nPoints, -1);
+    isConnectedToInternalPoint.assign(nPoints, 0);
+    isLayerSurfacePoint.assign(nPoints, 0);
+    isSharpEdgePoint.assign(nPoints, 0);
+    if (!doLayerTreatment) return;
+    updateGeometry();
+
+    // classifyBoundaryPoints BPS.C:296-340, 397-403: every point is classified by the first patch it is met on
+    std::vector<unsigned char> isVisitedPoint(nPoints, 0);
+    for (const Patch& pp : patches)
+        for (int faceI = pp.start; faceI < pp.start + pp.size; ++faceI)
+            for (int pointI : faces[faceI]) {
+                if (isVisitedPoint[pointI]) continue;
+                isVisitedPoint[pointI] = 1;
+                if (isInternalPoint[pointI]) continue;
+                for (int i : pointPoints[pointI])
+                    if (isInternalPoint[i]) isConnectedToInternalPoint[pointI] = 1;
+                if (pp.isLayerPatch) isLayerSurfacePoint[pointI] = 1;
+            }
+
+    // calculatePointHopsToBoundary OBB.C:52-133 with maxIter = maxLayers + 1 (SM.C:2217)
+    const int maxIter = lay.maxLayers + 1;
+    std::vector<int>& hops = pointHopsToLayerBoundary;
+    for (const Patch& pp : patches) {
+        if (!pp.isLayerPatch) continue;
+        for (int faceI = pp.start; faceI < pp.start + pp.size; ++faceI)   // getPatchPointIndices OBB.C:22-46
+            for (int patchPointI : faces[faceI])
+                if (isConnectedToInternalPoint[patchPointI]) hops[patchPointI] = 0;
+    }
+    std::vector<int> newHopCounts(nPoints, -1);
+    for (int iter = 0; iter < maxIter; ++iter) {
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            if (hops[pointI] >= 0) continue;
+            if (!isInternalPoint[pointI]) continue;
+            int maxHops = -1;
+            for (int neighI : pointPoints[pointI])
+                if (hops[neighI] > maxHops) maxHops = hops[neighI];
+            if (maxHops >= 0) newHopCounts[pointI] = maxHops + 1;
+        }
+        for (int pointI = 0; pointI < nPoints; ++pointI)
+            if (newHopCounts[pointI] > hops[pointI]) hops[pointI] = newHopCounts[pointI];
+    }
+
+    calculateBoundaryPointNormals();   // SM.C:2219
+
+    // propagateOuterNeighInfo OBB.C:244-391
+    // boundaryPointLabels[q] = outer neighbour of q (OBB.C:258); the reference looks a label up with findIndex
+    // (lowest q holding it).  All points that map to the same neighbour have the same hop count, so they are met
+    // in one sweep in ascending order and the first one recorded IS the lowest: firstMapper replaces the O(P) scan.
+    std::vector<int> firstMapper(nPoints, -1);
+    for (int iter = 1; iter < maxIter + 1; ++iter) {
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            const int nHops = hops[pointI];
+            if (nHops != iter) continue;
+            int nNeighHops = 0;
+            int neighPointI = -1;
+            for (int neighI : pointPoints[pointI])
+                if (hops[neighI] == (nHops - 1)) { ++nNeighHops; neighPointI = neighI; }
+            if (nNeighHops == 1) {
+                if ((!isInternalPoint[neighPointI]) && (!isLayerSurfacePoint[neighPointI])) continue;
+                // findIndex(boundaryPointLabels, neighPointI): the lowest point label already mapped to it
+                const int prevPointI = firstMapper[neighPointI];
+                if (prevPointI >= 0) {
+                    pointNormals[pointI] = UNDEF_VECTOR;
+                    pointNormals[prevPointI] = UNDEF_VECTOR;
+                    continue;
+                }
+                isOuterNeighInProc[pointI] = 1;
+                pointToOuterPointMap[pointI] = neighPointI;
+                pointNormals[pointI] = pointNormals[neighPointI];
+                firstMapper[neighPointI] = pointI;
+            }
+        }
+    }
+    for (int pointI = 0; pointI < nPoints; ++pointI)
+        if (pointNormals[pointI] == UNDEF_VECTOR) {
+            pointNormals[pointI] = ZERO_VECTOR;
+            isOuterNeighInProc[pointI] = 0;
+            pointToOuterPointMap[pointI] = -1;
+        }
+}
+
 void Domain::phaseA() {
     // SM.C:2262 reset frozen points
     isFrozenPoint.assign(nPoints, 0);
     updateGeometry();
+    // SM.C:2266 "Recalculate point normals" (the reference does it whether or not a treatment is enabled;
+    // the normals are only consumed by the layer treatment here)
+    if (doLayerTreatment) calculateBoundaryPointNormals();
 
     // SM.C:108-131 (doBoundarySmoothing == false: internal points only)
     cellSum.assign(nPoints, ZERO_VECTOR);
@@ -473,6 +598,50 @@ void Domain::phaseB() {
         else globalScale = 1.0;
         const Vec3 nCoords = cCoords + (prm.relStepFrac * globalScale) * stepDir;
         newPoints[pointI] = nCoords;
+    }
+
+    // SM.C:2283-2305 optional boundary layer treatment
+    if (doLayerTreatment) {
+        // updateNeighCoords OBB.C:464-500 (serial: the minMagSqr sync is the identity)
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            if (!isOuterNeighInProc[pointI]) { outerNeighCoords[pointI] = UNDEF_VECTOR; continue; }
+            const int neighI = pointToOuterPointMap[pointI];
+            if (neighI < 0) { error = "Sanity broken, neighI does not exist for pointI"; return; }
+            outerNeighCoords[pointI] = mp[neighI];
+        }
+        // blendWithOrthogonalPoints OBB.C:507-567, called with maxLayers + 1 (SM.C:2299)
+        const double layerMaxBlendingFraction = lay.layerMaxBlendingFraction;
+        const double minLayers = lay.minLayers;
+        const double maxLayers = lay.maxLayers + 1;
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            if (pointNormals[pointI] == ZERO_VECTOR) continue;
+            if (!isInternalPoint[pointI]) continue;
+            const int nHops = pointHopsToLayerBoundary[pointI];
+            if (nHops < 1) continue;
+            const Vec3 pointNormal = pointNormals[pointI];
+            const Vec3 outerNeighCoord = outerNeighCoords[pointI];
+            if (outerNeighCoord == UNDEF_VECTOR) { error = "Sanity broken, outerNeighCoord is zero for pointI"; return; }
+            const int maxHops = int(std::min(double(nHops - 1), maxLayers));   // label maxHops = min(label, double)
+            const double length = lay.layerEdgeLength * std::pow(lay.layerExpansionRatio, double(maxHops));
+            const double slope = -layerMaxBlendingFraction / (maxLayers - minLayers);
+            const double y0 = -slope * maxLayers;
+            const double y = y0 + slope * nHops;
+            const double blendFrac = std::max(0.0, std::min(y, layerMaxBlendingFraction));
+            const Vec3 newPoint = newPoints[pointI];
+            const Vec3 orthoPoint = outerNeighCoord + length * pointNormal;
+            const Vec3 blendedPoint = blendFrac * orthoPoint + (1.0 - blendFrac) * newPoint;
+            newPoints[pointI] = blendedPoint;
+        }
+        // SM.C:2304 constrainMaxStepLength once more, over all points
+        for (int pointI = 0; pointI < nPoints; ++pointI) {
+            const Vec3 cCoords = mp[pointI];
+            const Vec3 stepDir = newPoints[pointI] - cCoords;
+            double globalScale;
+            if (mag(stepDir) > prm.maxStepLength) globalScale = prm.maxStepLength / (mag(stepDir) * prm.relStepFrac);
+            else globalScale = 1.0;
+            const Vec3 nCoords = cCoords + (prm.relStepFrac * globalScale) * stepDir;
+            newPoints[pointI] = nCoords;
+        }
     }
 
     // SM.C:602-652 restrictEdgeShortening

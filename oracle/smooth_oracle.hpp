@@ -45,6 +45,21 @@ struct Params {
     double maxAngle = 160.0;      // SM.C:1883 (degrees)
 };
 
+// polyMesh boundary patch as the layer treatment needs it (OBB.C = src/orthogonalBoundaryBlending.C)
+struct Patch {
+    int start = 0, size = 0;   // face range
+    int kind = 0;              // 0 ordinary, 1 processor, 2 empty (skipped by OBB.C:156-159)
+    bool isLayerPatch = false; // selected by -layerPatches (SM.C:1823)
+};
+
+// boundary layer treatment options, defaults SM.C:1892-1905
+struct LayerParams {
+    double layerMaxBlendingFraction = 0.3;
+    double layerEdgeLength = 0.0;      // default: minEdgeLength, SM.C:1895
+    double layerExpansionRatio = 1.3;
+    int minLayers = 1, maxLayers = 4;
+};
+
 // One mesh (= one MPI rank's sub-domain in the reference).
 class Domain {
 public:
@@ -84,6 +99,17 @@ public:
     int nFrozenLocal = 0;
     double residualLocal = 0.0;
     std::string error;
+
+    // optional boundary layer treatment (serial): setup SM.C:2186-2221, per iteration SM.C:2266, 2283-2305
+    std::vector<Patch> patches;
+    LayerParams lay;
+    bool doLayerTreatment = false;     // SM.C:2024-2028
+    std::vector<unsigned char> isConnectedToInternalPoint, isLayerSurfacePoint;   // BPS.C:332-340, 397-403
+    std::vector<unsigned char> isSharpEdgePoint, isOuterNeighInProc;
+    std::vector<int> pointHopsToLayerBoundary, pointToOuterPointMap;
+    std::vector<Vec3> pointNormals, outerNeighCoords;
+    void setupLayers(const std::vector<Patch>& p, const LayerParams& lp);
+    void calculateBoundaryPointNormals();   // OBB.C:141-233 (uses the current faceAreas)
 
     void build();  // addressing from faces/owner/neighbour
     void meshStats(double& minEdge, double& maxEdge) const;  // SM.C:1478-1541

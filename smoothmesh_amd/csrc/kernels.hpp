@@ -55,12 +55,16 @@ struct State {
     smgpu_iter_stats* stats;
     const int* sharedSlot;     // multi-rank: per point slot into combA, or -1 (NULL on one rank)
     const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
+    // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
+    // outer neighbour; per hop count the target edge length and the blending fraction
+    double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
 };
 
 struct Prm {
     double maxStep, relStepFrac, minEdge;
     int totalMinFreeze;
     double smallAngle, largeAngle;   // M_PI * deg / 180.0  (SM.C:921, 1364-1365)
+    int layersOn;                    // boundary layer treatment enabled (SM.C:2024-2028)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -256,6 +260,34 @@ __device__ __forceinline__ void blockPublish(const State& s, double dist, int fr
     }
 }
 
+// Optional boundary layer treatment of one point, between the first step clamp and restrictEdgeShortening
+// (SM.C:2283-2305), serial run:
+//  * SM.C:2266 calculateBoundaryPointNormals -- of its effects only the last pass matters here (OBB.C:222-229): every
+//    non-zero normal is divided by its magnitude again, each iteration (internal points carry copies made at set-up;
+//    the normals of boundary points are not read by the treatment);
+//  * updateNeighCoords OBB.C:464-500: the outer neighbour's CURRENT coordinates;
+//  * blendWithOrthogonalPoints OBB.C:507-567, with the hop-count functions tabulated by the host (layers.cpp);
+//  * constrainMaxStepLength once more, for every point (SM.C:2304).
+__device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, bool internal, const V3& cur, V3 np) {
+    V3 n = ldv(s.layerNormal, p);
+    const V3 z = v3(0, 0, 0);
+    if (n != z) {
+        n = n / mag(n);
+        stv(s.layerNormal, p, n);
+        const int hops = s.layerHops[p];
+        if (internal && hops >= 1) {
+            const V3 outer = ldv(s.ptsCur, s.layerMap[p]);
+            const double blendFrac = s.layerBlend[hops];
+            const V3 orthoPoint = outer + s.layerLen[hops] * n;
+            np = blendFrac * orthoPoint + (1.0 - blendFrac) * np;
+        }
+    }
+    const V3 stepDir = np - cur;
+    const double len = mag(stepDir);
+    const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
+    return cur + (prm.relStepFrac * globalScale) * stepDir;
+}
+
 // The fused per-point proposal kernel: centroidalSmoothing SM.C:96-166, aspectRatioSmoothing
 // SM.C:548-593 (+ findClosestPoints/calcARSmoothingRatio), constrainMaxStepLength SM.C:684-754,
 // restrictEdgeShortening SM.C:602-652.  FINAL = true additionally does restore/count SM.C:2384-2392,
@@ -304,6 +336,7 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
             np = cur + (prm.relStepFrac * globalScale) * stepDir;
         }
+        if (prm.layersOn) np = layerTreat(s, prm, p, internal, cur, np);   // SM.C:2283-2305
         // SM.C:611-648 (isFrozenPoint is all false here: reset at SM.C:2262)
         bool frozen = false;
         {

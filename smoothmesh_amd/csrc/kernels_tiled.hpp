@@ -370,6 +370,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
             np = cur + (prm.relStepFrac * globalScale) * stepDir;
         }
+        if (prm.layersOn) np = layerTreat(s, prm, p, internal, cur, np);   // SM.C:2283-2305
         bool frozen = false;                                           // SM.C:611-648
         {
             double shortestNew = SMGPU_GREAT;

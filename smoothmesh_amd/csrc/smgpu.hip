@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "layers.hpp"
 #include "kernels_tiled.hpp"
 #include "kernels_walk.hpp"
 #include "kernels_filter.hpp"
@@ -101,6 +102,8 @@ struct smgpu_handle {
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
+    bool layersOn = false;     // smgpu_set_layers
+    std::vector<int32_t> layerHopsHost, layerMapHost;   // kept for the debug getters
     bool useExch = false;
     hipStream_t exch = nullptr;
     hipEvent_t evToExch = nullptr, evFromExch = nullptr;
@@ -137,8 +140,10 @@ static int devUpload(smgpu_handle* h, const T** out, const std::vector<T>& v) {
     return 0;
 }
 
-static Prm makePrm(const smgpu_params& p) {
+static Prm makePrm(const smgpu_handle* h) {
+    const smgpu_params& p = h->prm;
     Prm r;
+    r.layersOn = h->layersOn ? 1 : 0;
     r.maxStep = p.maxStepLength;
     r.relStepFrac = p.relStepFrac;
     r.minEdge = p.minEdgeLength;
@@ -674,7 +679,7 @@ static int runHostWalk(smgpu_handle* h) {
     if (ensureWalkBuffers(h)) return 1;
     const MeshView& m = h->mv;
     State s = h->st;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     WalkView w = h->wv;
     if (ensurePinned(h, 64)) return 1;
     if (launchK(h, K_FA_PRED, [&] {
@@ -752,7 +757,7 @@ static int forkFaFilter(smgpu_handle* h) {
     if (!h->side || !h->prm.faceAngleConstraint || !h->useFilter || h->exactAll || !h->edgeTilesOk || h->faFilterInFlight) return 0;
     const MeshView& m = h->mv;
     State s = h->st;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     HIP_OK(hipEventRecord(h->evFork, h->stream));
     HIP_OK(hipStreamWaitEvent(h->side, h->evFork, 0));
     if (launchK(h, K_FA_FILTER, [&] {
@@ -769,14 +774,14 @@ static int forkFaFilter(smgpu_handle* h) {
 static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
     if (forkFaFilter(h)) return 1;
-    if (runSmooth<false>(h, h->mv, h->st, makePrm(h->prm))) return 1;
+    if (runSmooth<false>(h, h->mv, h->st, makePrm(h))) return 1;
     return runConstraints(h);
 }
 // the constraint evaluators on the proposals left in prop / frozen (SM.C:2361-2371)
 static int runConstraints(smgpu_handle* h) {
     const MeshView& m = h->mv;
     State s = h->st;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     const int gP = gridFor(m.nPoints);
     const bool filt = h->useFilter && !h->exactAll;
     if (h->prm.edgeAngleConstraint) {
@@ -865,7 +870,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
     h->st.stats = h->dStats;
     const MeshView& m = h->mv;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const int gP = gridFor(m.nPoints);
     double* const buf0 = h->st.ptsCur;
@@ -1092,7 +1097,7 @@ int smgpu_iter_interior(smgpu_handle* h) {
     HIP_OK(hipSetDevice(h->device));
     if (!h->useTiles || h->interiorDone) return 0;
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, h->dInteriorTiles, h->nInteriorTiles)) return 1; }
     else if (runSmooth<false>(h, h->mv, h->st, prm, h->dInteriorTiles, h->nInteriorTiles)) return 1;
     h->interiorDone = true;
@@ -1103,7 +1108,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     HIP_OK(hipSetDevice(h->device));
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     if (h->useTiles && !h->interiorDone && smgpu_iter_interior(h)) return 1;
     if (computeAfterExch(h)) return 1;      // exchange A has been enqueued by the host
     if (h->nShared)
@@ -1141,7 +1146,7 @@ int smgpu_iter_end(smgpu_handle* h) {
     HIP_OK(hipSetDevice(h->device));
     const MeshView& m = h->mv;
     State s = h->st;
-    const Prm prm = makePrm(h->prm);
+    const Prm prm = makePrm(h);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
     s.stats = nullptr;                      // per-iteration results go to localStats in this mode
@@ -1170,6 +1175,47 @@ int smgpu_iter_end(smgpu_handle* h) {
     h->haloIter++;
     h->interiorDone = false;
     return exchAfterCompute(h);             // localStats is complete: the host may reduce / copy it
+}
+
+// ---- optional boundary layer treatment -------------------------------------------------------------------------
+int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled) {
+    if (!h || !d) return fail("null argument");
+    if (h->haloOn) return fail("boundary layer treatment is only available in serial runs (no halo)");
+    if (d->nPatches < 0 || (d->nPatches && (!d->patchStart || !d->patchSize || !d->patchKind || !d->isLayerPatch))) return fail("bad patch description");
+    HIP_OK(hipSetDevice(h->device));
+    bool any = false;
+    std::vector<LayerPatch> patches((size_t)d->nPatches);
+    for (int i = 0; i < d->nPatches; ++i) {
+        patches[(size_t)i] = LayerPatch{d->patchStart[i], d->patchSize[i], (int32_t)d->patchKind[i], d->isLayerPatch[i] != 0};
+        any = any || d->isLayerPatch[i];
+    }
+    const bool on = any && (d->layerMaxBlendingFraction > 1.0e-15);   // SM.C:2025, SMALL
+    if (enabled) *enabled = on ? 1 : 0;
+    h->layersOn = false;
+    if (!on) return 0;
+    // face area vectors of the current coordinates (fvPatch::Sf): the direct face kernel writes all of them
+    const MeshView& m = h->mv;
+    State s = h->st;
+    hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, 0);
+    std::vector<double> area(3 * (size_t)m.nFaces);
+    HIP_OK(hipMemcpyAsync(area.data(), s.fArea, sizeof(double) * area.size(), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    std::vector<uint8_t> internal((size_t)m.nPoints);
+    HIP_OK(hipMemcpy(internal.data(), m.pflags, (size_t)m.nPoints, hipMemcpyDeviceToHost));
+    for (auto& f : internal) f = (f & PF_INTERNAL) ? 1 : 0;
+    LayerSetup ls;
+    const std::string err = buildLayerSetup(h->topo, internal.data(), patches, area.data(), d->layerMaxBlendingFraction, d->layerEdgeLength,
+                                            d->layerExpansionRatio, d->minLayers, d->maxLayers, ls);
+    if (!err.empty()) return fail(err);
+    const double* dn = nullptr; const int *dh = nullptr, *dm = nullptr; const double *dl = nullptr, *db = nullptr;
+    if (devUpload(h, &dn, ls.normals) || devUpload(h, &dh, ls.hops) || devUpload(h, &dm, ls.outerMap) || devUpload(h, &dl, ls.lengthOfHops) ||
+        devUpload(h, &db, ls.blendOfHops)) return 1;
+    h->st.layerNormal = const_cast<double*>(dn);
+    h->st.layerHops = dh; h->st.layerMap = dm; h->st.layerLen = dl; h->st.layerBlend = db;
+    h->layerHopsHost = ls.hops;
+    h->layerMapHost = ls.outerMap;
+    h->layersOn = true;
+    return 0;
 }
 
 // ---- debug / parity access -------------------------------------------------------------------
@@ -1211,6 +1257,12 @@ int smgpu_debug_get_field(smgpu_handle* h, const char* name, double* out, int64_
     else if (s == "pointMaxAngle") { dsrc = st.ptMax; cnt = P; }
     else if (s == "isFrozenPoint") { bsrc = st.frozen; cnt = P; }
     else if (s == "faActive") { bsrc = st.faActive; cnt = P; }
+    else if (s == "layerNormals" && h->layersOn) { dsrc = st.layerNormal; cnt = 3 * P; }
+    else if ((s == "layerHops" || s == "layerOuterMap") && h->layersOn) {
+        *n = P;
+        if (out) { const std::vector<int32_t>& v = (s == "layerHops") ? h->layerHopsHost : h->layerMapHost; for (int64_t i = 0; i < P; ++i) out[i] = v[(size_t)i]; }
+        return 0;
+    }
     else return fail("unknown field " + s);
     *n = cnt;
     if (!out) return 0;
