@@ -60,6 +60,10 @@ def lib():
         l.orc_halo_packF.argtypes = [C.c_void_p, i32p, C.c_int, i32p, i32p]
         l.orc_halo_orF.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]
         l.orc_local_stats.argtypes = [C.c_void_p, f64p]
+        l.orc_setup_layers.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        l.orc_layers_enabled.restype = C.c_int
+        l.orc_layers_enabled.argtypes = [C.c_void_p]
+        l.orc_get_layer_fields.argtypes = [C.c_void_p, i32p, i32p, f64p, u8p, u8p]
         _lib = l
     return _lib
 
@@ -102,6 +106,23 @@ class Oracle:
     def set_params(self, p):
         self._lib.orc_set_params(self._h, p.maxStepLength, p.relStepFrac, p.minEdgeLength, int(p.totalMinFreeze),
                                  int(p.edgeAngleConstraint), int(p.faceAngleConstraint), p.minAngle, p.maxAngle)
+
+    def setup_layers(self, start, size, kind, isLayer, layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio,
+                     minLayers, maxLayers):
+        """boundary layer treatment set-up SM.C:2186-2221 (serial); returns doLayerTreatment"""
+        st, sz = np.ascontiguousarray(start, np.int32), np.ascontiguousarray(size, np.int32)
+        kd, il = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(isLayer, np.uint8)
+        self._lib.orc_setup_layers(self._h, len(st), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p),
+                                   layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers)
+        return bool(self._lib.orc_layers_enabled(self._h))
+
+    def layer_fields(self):
+        n = self.nPoints
+        hops, omap = np.empty(n, np.int32), np.empty(n, np.int32)
+        nrm = np.empty((n, 3), np.float64)
+        con, lsp = np.empty(n, np.uint8), np.empty(n, np.uint8)
+        self._lib.orc_get_layer_fields(self._h, _p(hops, i32p), _p(omap, i32p), _p(nrm, f64p), _p(con, u8p), _p(lsp, u8p))
+        return dict(hops=hops, outerMap=omap, normals=nrm, isConnectedToInternalPoint=con, isLayerSurfacePoint=lsp)
 
     def mesh_stats(self):
         a, b = C.c_double(), C.c_double()

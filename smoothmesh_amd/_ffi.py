@@ -56,6 +56,14 @@ class HaloDesc(C.Structure):
     ]
 
 
+class LayerDesc(C.Structure):
+    _fields_ = [
+        ("nPatches", C.c_int32), ("patchStart", c_i32p), ("patchSize", c_i32p), ("patchKind", c_u8p), ("isLayerPatch", c_u8p),
+        ("layerMaxBlendingFraction", C.c_double), ("layerEdgeLength", C.c_double), ("layerExpansionRatio", C.c_double),
+        ("minLayers", C.c_int32), ("maxLayers", C.c_int32),
+    ]
+
+
 # every symbol include/smgpu.h declares: (restype, argtypes)
 SYMBOLS = {
     "smgpu_last_error": (C.c_char_p, []),
@@ -76,6 +84,7 @@ SYMBOLS = {
     "smgpu_iter_interior": (C.c_int, [C.c_void_p]),
     "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
     "smgpu_iter_ahead": (C.c_int, [C.c_void_p]),
+    "smgpu_set_layers": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p]),
     "smgpu_halo_set_exchange_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "smgpu_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),

@@ -4,8 +4,9 @@
 //
 // This host is standalone (own option parser, own polyMesh I/O) because OpenFOAM is not available
 // in the build environment; INTEGRATION.md shows the OpenFOAM-linked variant of the same calls.
-// Out of scope: boundary-layer treatment (-layerPatches ...) and
-// boundary point smoothing (constant/geometry/*.obj); asking for them is an error, not a silent skip.
+// Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available for serial runs.
+// Out of scope: boundary point smoothing (constant/geometry/*.obj) and the layer treatment under -parallel;
+// asking for them is an error, not a silent skip.
 //
 //   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
 //
@@ -24,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <regex>
 #include <set>
 #include <stdexcept>
 #include <string>
@@ -89,6 +91,8 @@ Options parseArgs(int argc, char** argv) {
             std::puts("Usage: smoothMesh [-case dir] [-parallel] [-time t] [-centroidalIters n] [-relTol x] [-minEdgeLength x]\n"
                       "       [-maxStepLength x] [-relStepFrac x] [-totalMinFreeze b] [-edgeAngleConstraint b] [-faceAngleConstraint b]\n"
                       "       [-minAngle deg] [-maxAngle deg] [-writeInterval n] [-writeFormat ascii|binary] [-device n]\n"
+                      "       [-layerPatches '(p1 \"re.*\")' -layerMaxBlendingFraction x -layerEdgeLength x -layerExpansionRatio x\n"
+                      "        -minLayers n -maxLayers n]   (serial runs)\n"
                       "Move internal mesh points to increase mesh quality (MI355X engine)");
             std::exit(0);
         }
@@ -327,15 +331,45 @@ int main(int argc, char** argv) {
         }
     } catch (const std::exception& e) { fatal(e.what()); }
 
-    // out-of-scope features: refuse instead of silently ignoring (SM.C:2025, 2081-2093)
-    std::printf("Patches for boundary layer treatment: %s\n", opt.found("layerPatches") ? opt.kv.at("layerPatches").c_str() : "none");
+    // patches for the boundary layer treatment, getPatchIdsForOption SM.C:1442-1471 / 1823-1833: a wordRe list,
+    // "(name1 name2 \"regex.*\")" or a single word; quoted entries are regular expressions
+    std::vector<uint8_t> isLayerPatch(R[0].mesh.patches.size(), 0);
+    bool anyLayerPatch = false;
+    if (opt.found("layerPatches")) {
+        std::string v = opt.kv.at("layerPatches");
+        for (char& ch : v) if (ch == '(' || ch == ')') ch = ' ';
+        size_t i = 0;
+        while (i < v.size()) {
+            while (i < v.size() && std::isspace((unsigned char)v[i])) ++i;
+            if (i >= v.size()) break;
+            bool isRe = false;
+            std::string tok;
+            if (v[i] == '"') { isRe = true; ++i; while (i < v.size() && v[i] != '"') tok.push_back(v[i++]); ++i; }
+            else while (i < v.size() && !std::isspace((unsigned char)v[i])) tok.push_back(v[i++]);
+            for (size_t p = 0; p < R[0].mesh.patches.size(); ++p) {
+                bool hit;
+                if (isRe) {
+                    try { hit = std::regex_match(R[0].mesh.patches[p].name, std::regex(tok, std::regex::extended)); }
+                    catch (const std::regex_error&) { fatal("-layerPatches: bad regular expression \"" + tok + "\""); }
+                } else hit = (R[0].mesh.patches[p].name == tok);
+                if (hit) { isLayerPatch[p] = 1; anyLayerPatch = true; }
+            }
+        }
+    }
+    if (anyLayerPatch) std::printf("Patches for boundary layer treatment: %s\n", opt.kv.at("layerPatches").c_str());
+    else std::puts("Patches for boundary layer treatment: none");
     const double layerMaxBlendingFraction = opt.getD("layerMaxBlendingFraction", 0.3);
-    if (opt.found("layerPatches") && layerMaxBlendingFraction > SMALL)
-        fatal("-layerPatches: boundary layer treatment (orthogonalBoundaryBlending.C) is outside the scope of this build");
+    const bool doLayerTreatment = anyLayerPatch && layerMaxBlendingFraction > SMALL;   // SM.C:2024-2028
+    if (doLayerTreatment && opt.parallel)
+        fatal("-layerPatches with -parallel: the boundary layer treatment of this build is serial only");
+    // out-of-scope feature: refuse instead of silently ignoring (SM.C:2081-2093)
     if (fileExists(cd + "/constant/geometry/targetSurfaces.obj"))
         fatal("constant/geometry/targetSurfaces.obj found: boundary point smoothing (boundaryPointSmoothing.C) is outside the scope of this build");
-    std::puts("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
+    if (doLayerTreatment) std::puts("Enabled boundary layer treatment\n");
+    else std::puts("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
     std::puts("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\nconstant/geometry/targetSurfaces.obj\nconstant/geometry/initEdges.obj\n");
+    if (doLayerTreatment)   // SM.C:2095-2098
+        std::puts("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
 
     // engines
     int nDev = 0;
@@ -385,7 +419,13 @@ int main(int argc, char** argv) {
     else std::puts("    edgeAngleConstraint    false (edge min angle quality constraint is NOT applied)");
     if (prm.faceAngleConstraint) std::printf("    faceAngleConstraint    true\n    minAngle               %g\n    maxAngle               %g\n", prm.minAngle, prm.maxAngle);
     else std::puts("    faceAngleConstraint    false (face angle quality constraints are NOT applied)");
-    std::puts("    layerMaxBlendingFraction 0 (boundary layer treatment is NOT applied)\n");
+    const double layerEdgeLength = opt.getD("layerEdgeLength", prm.minEdgeLength);       // SM.C:1895-1905
+    const double layerExpansionRatio = opt.getD("layerExpansionRatio", 1.3);
+    const long minLayers = opt.getL("minLayers", 1), maxLayers = opt.getL("maxLayers", 4);
+    if (layerMaxBlendingFraction > SMALL)
+        std::printf("    layerMaxBlendingFraction %g\n    layerEdgeLength          %g\n    layerExpansionRatio      %g\n    minLayers                %ld\n"
+                    "    maxLayers                %ld\n\n", layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers);
+    else std::puts("    layerMaxBlendingFraction 0 (boundary layer treatment is NOT applied)\n");
 
     long nPointsTot = 0, nInternalTot = 0;
     for (Rank& K : R) {
@@ -396,6 +436,23 @@ int main(int argc, char** argv) {
     std::printf("Mesh minimum edge length = %g\nMesh maximum edge length = %g\n\n", meshMinEdgeLength, meshMaxEdgeLength);
 
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
+    if (doLayerTreatment) {   // set-up SM.C:2215-2221 on the engine's side
+        const PolyMeshData& pm = R[0].mesh;
+        std::vector<int32_t> pStart, pSize;
+        std::vector<uint8_t> pKind;
+        for (const PatchInfo& p : pm.patches) {
+            pStart.push_back(p.startFace);
+            pSize.push_back(p.nFaces);
+            pKind.push_back(p.type == "processor" ? 1 : (p.type == "empty" ? 2 : 0));
+        }
+        smgpu_layer_desc ld{};
+        ld.nPatches = (int32_t)pStart.size();
+        ld.patchStart = pStart.data(); ld.patchSize = pSize.data(); ld.patchKind = pKind.data(); ld.isLayerPatch = isLayerPatch.data();
+        ld.layerMaxBlendingFraction = layerMaxBlendingFraction; ld.layerEdgeLength = layerEdgeLength;
+        ld.layerExpansionRatio = layerExpansionRatio; ld.minLayers = (int32_t)minLayers; ld.maxLayers = (int32_t)maxLayers;
+        int32_t on = 0;
+        check(smgpu_set_layers(R[0].h, &ld, &on), "smgpu_set_layers");
+    }
 
     if (opt.parallel) {
         buildHalo(R);

@@ -3,6 +3,7 @@ reference's loop (src/smoothMesh.C:2257-2437).  Parameter names are the referenc
 option names (SM.C:1642-1784), defaults as SM.C:1857-1918."""
 import ctypes as C
 from dataclasses import dataclass
+from typing import Optional
 
 import numpy as np
 
@@ -24,6 +25,34 @@ class SmoothParams:
     faceAngleConstraint: bool = True
     minAngle: float = 35.0
     maxAngle: float = 160.0
+
+
+@dataclass
+class LayerParams:
+    """Boundary layer treatment options (SM.C:1749-1775), defaults SM.C:1892-1905."""
+    layerPatches: tuple = ()                  # patch names; a name in double quotes is a regular expression
+    layerMaxBlendingFraction: float = 0.3
+    layerEdgeLength: Optional[float] = None   # None = minEdgeLength
+    layerExpansionRatio: float = 1.3
+    minLayers: int = 1
+    maxLayers: int = 4
+
+
+def patch_arrays(mesh: PolyMesh, layerPatches):
+    """(start, size, kind, isLayer) of mesh.patches; kind 0 ordinary / 1 processor / 2 empty.  Selection as
+    polyBoundaryMesh::patchSet (SM.C:1442-1471): a plain word matches a patch name, a quoted string is a regex."""
+    import re
+    pats = []
+    for w in layerPatches:
+        w = str(w)
+        pats.append(re.compile(w[1:-1]) if len(w) >= 2 and w[0] == '"' and w[-1] == '"' else w)
+    kinds = {"processor": 1, "empty": 2}
+    start = np.array([p.startFace for p in mesh.patches], np.int32)
+    size = np.array([p.nFaces for p in mesh.patches], np.int32)
+    kind = np.array([kinds.get(p.type, 0) for p in mesh.patches], np.uint8)
+    sel = np.array([any((q.fullmatch(p.name) is not None) if hasattr(q, "fullmatch") else (q == p.name) for q in pats)
+                    for p in mesh.patches], np.uint8)
+    return start, size, kind, sel
 
 
 def default_params(meshMinEdgeLength: float, **over) -> SmoothParams:
@@ -151,6 +180,22 @@ class SmoothEngine:
         self.params = p
 
     # -- the loop ------------------------------------------------------------------------------
+    def set_layers(self, lp: LayerParams, minEdgeLength: float):
+        """Enable the boundary layer treatment on lp.layerPatches (serial runs); returns the reference's
+        doLayerTreatment.  Call after construction, before iterating."""
+        start, size, kind, sel = patch_arrays(self.mesh, lp.layerPatches)
+        d = _ffi.LayerDesc()
+        d.nPatches = len(start)
+        d.patchStart, d.patchSize = _p(start, _ffi.c_i32p), _p(size, _ffi.c_i32p)
+        d.patchKind, d.isLayerPatch = _p(kind, _ffi.c_u8p), _p(sel, _ffi.c_u8p)
+        d.layerMaxBlendingFraction = lp.layerMaxBlendingFraction
+        d.layerEdgeLength = minEdgeLength if lp.layerEdgeLength is None else lp.layerEdgeLength
+        d.layerExpansionRatio = lp.layerExpansionRatio
+        d.minLayers, d.maxLayers = lp.minLayers, lp.maxLayers
+        on = C.c_int32(0)
+        self._check(self._lib.smgpu_set_layers(self._h, C.byref(d), C.byref(on)))
+        return bool(on.value)
+
     def iterate(self, centroidalIters: int, relTol: float = 0.02):
         """Returns (nDone, residuals[nDone], nFrozenPoints[nDone]) -- the values of the reference's
         per-iteration log line (SM.C:2396)."""

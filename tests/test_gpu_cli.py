@@ -64,6 +64,33 @@ def test_compressed_case(tmp_path, oracle_lib):
     assert rel_linf(got, o.points()) <= 1e-13
 
 
+def test_layer_patches_case(tmp_path, oracle_lib):
+    """-layerPatches & co. (SM.C:1749-1775): the boundary layer treatment through the command line"""
+    from smoothmesh_amd import default_params, patch_arrays
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_case
+    m = hex_block(10, 8, 7, jitter=0.25, seed=6)
+    write_case(str(tmp_path), m, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-centroidalIters", "8", "-relTol", "0", "-layerPatches", '(xmin "y.*")',
+                "-layerExpansionRatio", "1.2", "-maxLayers", "3", "-faceAngleConstraint", "false"])
+    assert "Enabled boundary layer treatment" in out and "layerExpansionRatio      1.2" in out
+    assert "WARNING: Boundary layer treatment will be done without boundary point smoothing" in out
+    o = oracle_lib.Oracle(m)
+    prm = default_params(o.mesh_stats()[0], faceAngleConstraint=False)
+    o.set_params(prm)
+    st, sz, kd, sel = patch_arrays(m, ["xmin", '"y.*"'])
+    assert sel.tolist() == [1, 0, 1, 1, 0, 0]
+    assert o.setup_layers(st, sz, kd, sel, 0.3, prm.minEdgeLength, 1.2, 1, 3)
+    n, res, frz = o.iterate(8, 0.0)
+    lines = LINE.findall(out)
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    got = read_polymesh(str(tmp_path / "constant" / "polyMesh"), pointsDir=str(tmp_path / "8" / "polyMesh")).points
+    assert rel_linf(got, o.points()) <= 1e-13
+    # no such patch -> treatment disabled, as in the reference (SM.C:2025-2033)
+    out2 = _run(["-case", str(tmp_path), "-time", "constant", "-centroidalIters", "1", "-relTol", "0", "-layerPatches", "nosuch"])
+    assert "Patches for boundary layer treatment: none" in out2 and "Boundary layer treatment is disabled" in out2
+
+
 def test_relTol_stop_and_option_errors(tmp_path):
     from smoothmesh_amd.meshgen import hex_block
     from smoothmesh_amd.polymesh import write_case
@@ -73,7 +100,10 @@ def test_relTol_stop_and_option_errors(tmp_path):
     assert os.path.isdir(tmp_path / "1")
     r = subprocess.run([BIN, "-case", str(tmp_path), "-noSuchOption", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "Wrong option" in r.stdout
-    r = subprocess.run([BIN, "-case", str(tmp_path), "-layerPatches", "(walls)"], capture_output=True, text=True)
+    # boundary point smoothing is out of scope: its input file is refused, not silently ignored
+    os.makedirs(tmp_path / "constant" / "geometry")
+    (tmp_path / "constant" / "geometry" / "targetSurfaces.obj").write_text("# empty\n")
+    r = subprocess.run([BIN, "-case", str(tmp_path)], capture_output=True, text=True)
     assert r.returncode != 0 and "outside the scope" in r.stdout
 
 
@@ -86,6 +116,8 @@ def test_parallel_case(tmp_path, oracle_lib):
     subs = [hex_subdomain((5, 4, 6), grid, r, jitter=0.3, seed=6) for r in range(4)]
     write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
     out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "7", "-relTol", "0"])
+    r = subprocess.run([BIN, "-case", str(tmp_path), "-parallel", "-layerPatches", "(xmin)"], capture_output=True, text=True)
+    assert r.returncode != 0 and "serial only" in r.stdout
     orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
     prm = default_params(min(o.mesh_stats()[0] for o in orcs))
     for o in orcs:

@@ -1,0 +1,126 @@
+"""Known answers for the oracle's boundary layer treatment (OBB.C = src/orthogonalBoundaryBlending.C, set-up
+SM.C:2186-2221, per iteration SM.C:2266 + 2283-2305) on meshes where the reference's result can be written down."""
+import numpy as np
+import pytest
+
+
+def _setup(oracle_lib, mesh, layerPatches, **kw):
+    from smoothmesh_amd import default_params, patch_arrays
+    o = oracle_lib.Oracle(mesh)
+    prm = default_params(o.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False)
+    o.set_params(prm)
+    st, sz, kd, sel = patch_arrays(mesh, layerPatches)
+    on = o.setup_layers(st, sz, kd, sel, kw.get("blend", 0.3), kw.get("edge", prm.minEdgeLength), kw.get("ratio", 1.3),
+                        kw.get("minLayers", 1), kw.get("maxLayers", 4))
+    return o, prm, on
+
+
+def _ijk(n):
+    """point label -> (i, j, k) of an n^3-cell blockMesh-numbered block (x fastest)"""
+    p = np.arange((n + 1) ** 3)
+    return p % (n + 1), (p // (n + 1)) % (n + 1), p // (n + 1) ** 2
+
+
+def test_hops_normals_and_outer_map_on_a_uniform_block(oracle_lib):
+    from smoothmesh_amd.meshgen import hex_block
+    n = 8
+    m = hex_block(n, jitter=0.0)
+    o, prm, on = _setup(oracle_lib, m, ["xmin"])
+    assert on
+    f = o.layer_fields()
+    i, j, k = _ijk(n)
+    inner = (j > 0) & (j < n) & (k > 0) & (k < n)                      # columns that start inside the xmin face
+    # OBB.C:52-133: hop count = number of edges to the xmin face, up to maxLayers + 1 = 5 sweeps
+    want = np.where(inner & (i <= 5), i, -1)
+    want[inner & (i == n)] = -1                                         # xmax face points are boundary points
+    assert np.array_equal(f["hops"], want)
+    # BPS.C:332-340: boundary points with an internal neighbour; :397-403 first patch wins (xmin is listed first)
+    assert np.array_equal(f["isLayerSurfacePoint"].astype(bool), i == 0)
+    # OBB.C:244-391: every hop-h point hangs on the hop-(h-1) point of its column and carries the inward normal
+    mapped = inner & (i >= 1) & (i <= 5)
+    assert np.array_equal(f["outerMap"][mapped], np.arange(len(i))[mapped] - 1)
+    assert np.all(f["outerMap"][~mapped] == -1)
+    assert np.array_equal(f["normals"][mapped], np.tile([1.0, 0.0, 0.0], (mapped.sum(), 1)))
+    # OBB.C:141-233: the corner of three orthogonal patches gets -(sum of outward unit normals) / sqrt(3)
+    c = f["normals"][0]
+    assert np.allclose(c, np.full(3, 1 / np.sqrt(3)), rtol=0, atol=1e-15)
+
+
+def test_not_enabled_without_patch_or_fraction(oracle_lib):
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(4, jitter=0.1, seed=1)
+    assert not _setup(oracle_lib, m, [])[2]                             # SM.C:2025
+    assert not _setup(oracle_lib, m, ["xmin"], blend=0.0)[2]
+    assert _setup(oracle_lib, m, ['"x.*"'])[2]                          # quoted = regular expression (wordRe)
+
+
+def test_uniform_layers_are_a_fixed_point(oracle_lib):
+    """ratio 1, layerEdgeLength = grid spacing: the orthogonal target of every layer point is where it already is"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 8                                                               # 1/8 is exact in binary
+    m = hex_block(n, jitter=0.0)
+    o, prm, on = _setup(oracle_lib, m, ["xmin", "ymax"], edge=1.0 / n, ratio=1.0)
+    nIt, res, frz = o.iterate(3, 0.0)
+    assert np.all(res == 0.0) and np.array_equal(o.points(), m.points)
+
+
+def test_second_step_clamp_scales_every_step_again(oracle_lib):
+    """SM.C:2304: with the treatment enabled constrainMaxStepLength runs twice, also for points far from any layer"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 8
+    m = hex_block(n, jitter=0.0)
+    p = (n + 1) ** 2 * 4 + (n + 1) * 4 + 7                              # interior point at i = 7: no hop count
+    d = 1e-4                                                            # well below maxStepLength
+    m.points[p, 1] += d
+    o0, prm, _ = _setup(oracle_lib, m, [])
+    o1, _, on = _setup(oracle_lib, m, ["xmin"], edge=1.0 / n, ratio=1.0)
+    assert on and o1.layer_fields()["hops"][p] == -1
+    o0.iterate(1, 0.0); o1.iterate(1, 0.0)
+    s0 = o0.points()[p] - m.points[p]
+    s1 = o1.points()[p] - m.points[p]
+    assert np.allclose(s1, prm.relStepFrac * s0, rtol=1e-10, atol=1e-15)    # one more factor relStepFrac
+
+
+def test_layer_target_length_and_blend(oracle_lib):
+    """one iteration on a uniform block: a hop-h point moves towards outer + L*r^(h-1)*n with weight b(h)
+    (OBB.C:545-560), then the step clamp applies once more; hop 5 = maxLayers + 1 has weight 0"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 8
+    h = 1.0 / n
+    m = hex_block(n, jitter=0.0)
+    L, r, blend = 0.05, 1.3, 0.3
+    o, prm, _ = _setup(oracle_lib, m, ["xmin"], edge=L, ratio=r, blend=blend)
+    o.iterate(1, 0.0)
+    i, j, k = _ijk(n)
+    moved = o.points() - m.points
+    for hop in range(1, 6):
+        p = (n + 1) ** 2 * 4 + (n + 1) * 4 + hop
+        slope = -blend / (5 - 1)
+        b = max(0.0, min(-slope * 5 + slope * hop, blend))
+        target_dx = b * ((hop - 1) * h + L * r ** (hop - 1) - hop * h)  # centroidal proposal = current position
+        # the clamp after the blend (SM.C:2304): exactly maxStepLength when longer, else x relStepFrac
+        want = np.sign(target_dx) * prm.maxStepLength if abs(target_dx) > prm.maxStepLength else prm.relStepFrac * target_dx
+        assert moved[p, 0] == pytest.approx(want, rel=1e-12, abs=1e-18)
+        assert moved[p, 1] == 0.0 and moved[p, 2] == 0.0
+    assert moved[(n + 1) ** 2 * 4 + (n + 1) * 4 + 5, 0] == 0.0
+
+
+def test_multiply_connected_boundary_points_are_left_out(oracle_lib):
+    """OBB.C:311-320: on the castellated cavity surface a concave step makes two hop-1 points hang on one wall point;
+    both lose their normal and their map, and nothing inherits from them"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    m = cavity_mesh(12)
+    o, prm, on = _setup(oracle_lib, m, ["cavity"])
+    assert on
+    f = o.layer_fields()
+    mapped = f["outerMap"] >= 0
+    assert mapped.any()
+    assert np.all(np.abs(f["normals"][mapped]).sum(axis=1) > 0)
+    # a mapped point's target is one hop nearer and is claimed by nobody else
+    assert np.array_equal(f["hops"][f["outerMap"][mapped]], f["hops"][mapped] - 1)
+    tg, cnt = np.unique(f["outerMap"][mapped], return_counts=True)
+    assert np.all(cnt == 1)
+    # some hop >= 1 points stay unmapped (two candidates, or a disqualified chain)
+    assert ((f["hops"] >= 1) & ~mapped).any()
+    n, res, frz = o.iterate(3, 0.0)
+    assert n == 3 and np.all(np.isfinite(res))
