@@ -204,11 +204,15 @@ def read_obj_surface(path):
     return np.array(verts, dtype=np.float64), faces
 
 
-def extrude_surface(verts, faces2d, nLayers=15, thickness=1.5, direction=(0.0, 1.0, 0.0)) -> PolyMesh:
+def extrude_surface(verts, faces2d, nLayers=15, thickness=1.5, direction=(0.0, 1.0, 0.0), box_patches=False) -> PolyMesh:
     """Linear extrusion of a planar polygon surface into prism/hex cells -- stands in for OpenFOAM's
     extrude2DMesh (reference testcase/run_serial:11, system/extrude2DMeshDict: nLayers 15, thickness 1.5 along
     +y; BASELINE.json configs[0]).  Numbering: point = v + layer*nV, cell = f + layer*nF; internal faces in
-    upper-triangular order; patches back (layer 0), front (last layer), sides."""
+    upper-triangular order; patches back (layer 0), front (last layer), sides.
+    box_patches=True mimics the testcase's topoSet + createPatch step (run_serial:12-13, system/createPatchDict):
+    lateral faces on the bounding box of the surface go to side_left/right/bottom/top, back/front are called
+    side_back/side_front, and what remains (the immersed shape) stays in defaultFaces -- the patch the testcase
+    selects with -layerPatches '("def.*")'."""
     d = np.asarray(direction, dtype=np.float64)
     d = d / np.linalg.norm(d)
     nV, nF = len(verts), len(faces2d)
@@ -252,13 +256,33 @@ def extrude_surface(verts, faces2d, nLayers=15, thickness=1.5, direction=(0.0, 1
                 else:
                     raise ValueError("non-manifold edge in the surface")
     internal.sort(key=lambda t: (t[0], t[1]))
-    allf = [t[2] for t in internal] + [t[1] for t in back] + [t[1] for t in front] + [t[1] for t in sides]
-    owner = [t[0] for t in internal] + [t[0] for t in back] + [t[0] for t in front] + [t[0] for t in sides]
+    if box_patches:
+        # two in-plane axes of the surface and its bounding box
+        ax = [i for i in range(3) if abs(d[i]) < 0.5]
+        lo, hi = verts[:, ax].min(axis=0), verts[:, ax].max(axis=0)
+        tol = 1e-9 * float(np.max(hi - lo))
+        groups = {k: [] for k in ("defaultFaces", "side_left", "side_right", "side_bottom", "side_top")}
+        for c, quad in sides:
+            q = pts[quad][:, ax]
+            if np.all(np.abs(q[:, 0] - lo[0]) < tol): groups["side_left"].append((c, quad))
+            elif np.all(np.abs(q[:, 0] - hi[0]) < tol): groups["side_right"].append((c, quad))
+            elif np.all(np.abs(q[:, 1] - lo[1]) < tol): groups["side_bottom"].append((c, quad))
+            elif np.all(np.abs(q[:, 1] - hi[1]) < tol): groups["side_top"].append((c, quad))
+            else: groups["defaultFaces"].append((c, quad))
+        named = [("defaultFaces", groups["defaultFaces"]), ("side_front", front), ("side_back", back)] + \
+                [(k, groups[k]) for k in ("side_left", "side_right", "side_top", "side_bottom")]
+    else:
+        named = [("back", back), ("front", front), ("sides", sides)]
+    named = [(k, g) for k, g in named if g]
+    allf = [t[2] for t in internal] + [t[1] for _, g in named for t in g]
+    owner = [t[0] for t in internal] + [t[0] for _, g in named for t in g]
     off = np.zeros(len(allf) + 1, np.int32)
     np.cumsum([len(f) for f in allf], out=off[1:])
     nI = len(internal)
-    patches = [Patch("back", "patch", len(back), nI), Patch("front", "patch", len(front), nI + len(back)),
-               Patch("sides", "patch", len(sides), nI + len(back) + len(front))]
+    patches, startFace = [], nI
+    for k, g in named:
+        patches.append(Patch(k, "patch", len(g), startFace))
+        startFace += len(g)
     return PolyMesh(points=pts, faceOffsets=off, facePoints=np.concatenate([np.asarray(f, np.int32) for f in allf]),
                     owner=np.asarray(owner, np.int32), neighbour=np.asarray([t[1] for t in internal], np.int32), patches=patches,
                     nCells=nF * nLayers)

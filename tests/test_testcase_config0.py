@@ -13,12 +13,24 @@ from conftest import rel_linf
 OBJ = os.path.join(os.path.dirname(__file__), "golden", "MeshedSurface.obj")
 
 
-def _mesh():
+def _mesh(box_patches=False):
     from smoothmesh_amd.meshgen import extrude_surface, read_obj_surface
     v, f = read_obj_surface(OBJ)
     assert v.shape == (660, 3) and len(f) == 750
     assert sum(len(x) == 3 for x in f) == 275 and sum(len(x) == 4 for x in f) == 475
-    return extrude_surface(v, f, nLayers=15, thickness=1.5, direction=(0, 1, 0))
+    return extrude_surface(v, f, nLayers=15, thickness=1.5, direction=(0, 1, 0), box_patches=box_patches)
+
+
+def _testcase_oracle(oracle_lib, m):
+    """the options of testcase/run_serial:18"""
+    from smoothmesh_amd import default_params, patch_arrays
+    o = oracle_lib.Oracle(m)
+    prm = default_params(o.mesh_stats()[0], minEdgeLength=0.01, maxStepLength=0.002, minAngle=15.0, maxAngle=160.0)
+    o.set_params(prm)
+    st, sz, kd, sel = patch_arrays(m, ['"def.*"'])
+    assert [p.name for p, s in zip(m.patches, sel) if s] == ["defaultFaces"]
+    assert o.setup_layers(st, sz, kd, sel, 0.3, prm.minEdgeLength, 1.3, 1, 4)
+    return o, prm
 
 
 def test_extruded_mesh_is_valid(oracle_lib):
@@ -44,6 +56,34 @@ def test_config0_oracle_runs_20_iterations(oracle_lib):
     internal = m.find_internal_points().astype(bool)
     assert np.array_equal(o.points()[~internal], m.points[~internal])
     assert np.all(frz >= (~internal).sum())
+
+
+def test_testcase_command_line_in_the_oracle(oracle_lib):
+    """run_serial:18 incl. the boundary layer treatment on the immersed shape: prismatic edges exist for the first
+    hop counts around the shape, and the run stays finite"""
+    m = _mesh(box_patches=True)
+    assert [p.name for p in m.patches][0] == "defaultFaces" and m.patches[0].nFaces == 30 * 15
+    o, prm = _testcase_oracle(oracle_lib, m)
+    f = o.layer_fields()
+    assert (f["hops"] == 0).sum() > 0 and (f["outerMap"] >= 0).sum() > 0
+    n, res, frz = o.iterate(25, 0.0)
+    assert n == 25 and np.all(np.isfinite(res))
+    internal = m.find_internal_points().astype(bool)
+    assert np.array_equal(o.points()[~internal], m.points[~internal])
+
+
+@pytest.mark.gpu
+def test_testcase_command_line_gpu_matches_oracle(oracle_lib):
+    from smoothmesh_amd import LayerParams, SmoothEngine
+    m = _mesh(box_patches=True)
+    o, prm = _testcase_oracle(oracle_lib, m)
+    e = SmoothEngine(m)
+    e.set_params(prm)
+    assert e.set_layers(LayerParams(layerPatches=('"def.*"',)), prm.minEdgeLength)
+    n_o, res_o, frz_o = o.iterate(100, 0.0)                           # -centroidalIters 100
+    n_g, res_g, frz_g = e.iterate(100, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= 1e-13
 
 
 @pytest.mark.gpu
