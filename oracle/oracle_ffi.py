@@ -8,7 +8,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("SMOOTHMESH_ORACLE_LIB", os.path.join(_HERE, "liboracle.so"))   # override: sanitizer builds
 _lib = None
 f64p = C.POINTER(C.c_double)
 i32p = C.POINTER(C.c_int32)

@@ -8,7 +8,7 @@ import numpy as np
 from .mesh import PolyMesh, Patch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmhost.so")
+LIB_PATH = os.environ.get("SMOOTHMESH_SMHOST_LIB", os.path.join(_HERE, "csrc", "libsmhost.so"))   # override: sanitizer builds
 _lib = None
 i32p = C.POINTER(C.c_int32)
 f64p = C.POINTER(C.c_double)

@@ -1,0 +1,23 @@
+"""The product's host-only C++ (addressing build, tile tables, layer set-up, polyMesh I/O, mesh generator) under
+AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "smoothmesh_amd", "csrc")
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_host_code_is_clean_under_asan_ubsan(tmp_path):
+    exe = str(tmp_path / "host_sanitize")
+    src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
+          [os.path.join(CSRC, f) for f in ("topology.cpp", "tiles.cpp", "layers.cpp", "host/meshgen.cpp", "host/polymesh_io.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", exe] + src + ["-lz"])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, "14"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok points") and "ERROR" not in r.stderr and "runtime error" not in r.stderr
