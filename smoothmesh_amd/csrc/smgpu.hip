@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <future>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -233,6 +234,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (d->device < 0 || d->device >= nDev) return fail("smgpu_create: device ordinal out of range");
     smgpu_handle* h = new smgpu_handle();
     h->device = d->device;
+    const auto tCreate0 = std::chrono::steady_clock::now();
+    auto sinceCreate = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tCreate0).count(); };
     const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets,
                                            d->facePoints, d->owner, d->neighbour);
     if (!terr.empty()) { delete h; return fail("smgpu_create: " + terr); }
@@ -295,8 +298,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const bool morton = envInt("SMGPU_TILE_MORTON", 1) != 0;
         std::vector<uint8_t> internalMask((size_t)t.nPoints);
         for (int p = 0; p < t.nPoints; ++p) internalMask[(size_t)p] = (flags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
-        const std::string e1 = h->gt.build(t, d->points, morton, h->geomT, geomCells, capGP, capGF);
+        const double tTopo = sinceCreate();
+        // the three tile tables only read the addressing: built side by side on host threads
+        auto fGeom = std::async(std::launch::async, [&] { return h->gt.build(t, d->points, morton, h->geomT, geomCells, capGP, capGF); });
+        auto fEdge = std::async(std::launch::async, [&]() -> std::string {
+            return h->useFilter ? h->etl.build(t, d->points, morton, 256, 512, 768, 512) : std::string("not built");
+        });
         const std::string e2 = h->stl.build(t, d->points, internalMask.data(), morton, h->smoothT, capSC, capSN);
+        const std::string e1 = fGeom.get();
+        const std::string e3 = fEdge.get();
+        if (envInt("SMGPU_VERBOSE", 0))
+            std::fprintf(stderr, "[smgpu] set-up: addressing %.2f s, tile tables (3 host threads) %.2f s\n", tTopo, sinceCreate() - tTopo);
         if (!e1.empty() || !e2.empty()) {
             h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
         } else {
@@ -335,7 +347,6 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
             v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
             if (h->useFilter) {
-                const std::string e3 = h->etl.build(t, d->points, morton, 256, 512, 768, 512);
                 if (e3.empty()) {
                     EdgeTileView& ev = h->ev;
                     rc |= devUpload(h, &ev.order, h->etl.order);
@@ -421,6 +432,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     s.sharedSlot = nullptr;
     s.combA = nullptr;
     computeAlgoBytes(h);
+    if (envInt("SMGPU_VERBOSE", 0)) std::fprintf(stderr, "[smgpu] set-up: total %.2f s\n", sinceCreate());
     *out = h;
     return 0;
 }
