@@ -24,9 +24,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table); ~6290 achievable
 
 
+def workload_layers(w):
+    """trailing L = boundary layer treatment on (hex: all six sides, cavity: the cavity wall), one GPU only"""
+    return w.endswith("L")
+
+
 def parse_workload(w):
-    """hexN[c] = N^3 hex block; cavityN[c] = castellated polyhedral cube-with-sphere-cavity on an N^3 base grid;
-    trailing c = edgeAngle + faceAngle constraints on."""
+    """hexN[c][L] = N^3 hex block; cavityN[c][L] = castellated polyhedral cube-with-sphere-cavity on an N^3 base
+    grid; c = edgeAngle + faceAngle constraints on; L = boundary layer treatment on (see workload_layers)."""
+    if w.endswith("L"):
+        w = w[:-1]
     constraints = w.endswith("c")
     base = w[:-1] if constraints else w
     for kind in ("hex", "cavity"):
@@ -47,7 +54,12 @@ def proc_grid(n):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(n) or (n, 1, 1)
 
 
-def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0):
+def layer_params(kind):
+    from smoothmesh_amd import LayerParams
+    return LayerParams(layerPatches=('".*"',) if kind == "hex" else ("cavity",))
+
+
+def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False):
     """Serial oracle (CPU restatement of the reference loop) on the SAME mesh for a bounded number of
     iterations.  kind = "port": the reference itself needs OpenFOAM and cannot be built here."""
     from oracle import oracle_ffi
@@ -57,6 +69,11 @@ def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0):
     o = oracle_ffi.Oracle(mesh)
     p = default_params(o.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     o.set_params(p)
+    if layers:
+        from smoothmesh_amd import patch_arrays
+        lp = layer_params(kind)
+        st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches)
+        o.setup_layers(st, sz, kd, sel, lp.layerMaxBlendingFraction, p.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
     t0 = time.perf_counter()
     o.iterate(1, 0.0)
     t1 = time.perf_counter() - t0
@@ -88,6 +105,7 @@ def main():
     from smoothmesh_amd.meshgen import hex_block
 
     kind, n_side, constraints = parse_workload(args.workload)
+    layers = workload_layers(args.workload)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -112,6 +130,8 @@ def main():
         eng = SmoothEngine(mesh, device=local_rank)
         prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         eng.set_params(prm)
+        if layers and not eng.set_layers(layer_params(kind), prm.minEdgeLength):
+            raise SystemExit("boundary layer treatment could not be enabled")
         if W:
             eng.iterate(W, 0.0)
         torch.cuda.synchronize()
@@ -140,8 +160,8 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        if kind != "hex":
-            raise SystemExit("multi-GPU bench uses the hexN workloads (sub-domains are generated per rank)")
+        if kind != "hex" or layers:
+            raise SystemExit("multi-GPU bench uses the hexN[c] workloads (sub-domains are generated per rank; layers are serial)")
         grid = proc_grid(world)
         sub = hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345)
         ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
@@ -225,7 +245,10 @@ def main():
                          f"(own generator standing in for snappyHexMesh)") +
                         f", interior jitter 0.2h seed 12345, "
                         f"{'edgeAngle+faceAngle constraints on (minAngle 35 / maxAngle 160)' if constraints else 'constraints off'}, "
-                        f"relTol 0, defaults otherwise (BASELINE.json configs[{(2 if constraints else 1) if kind == 'hex' else 3}])",
+                        + ("boundary layer treatment on (" + ("all six sides" if kind == "hex" else "the cavity wall") + ", default layer options), "
+                           if layers else "") +
+                        f"relTol 0, defaults otherwise (BASELINE.json configs[{(2 if constraints else 1) if kind == 'hex' else 3}]"
+                        + (" + -layerPatches" if layers else "") + ")",
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
             "parallelism": parallelism,
         },
@@ -253,7 +276,7 @@ def main():
     if force_dist:
         out["config"]["parallelism"] += " [N=1 forced through the multi-rank path]"
     if world == 1 and not force_dist and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints)
+        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if world > 1 or force_dist:

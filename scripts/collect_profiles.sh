@@ -6,6 +6,7 @@ rm -rf $out; mkdir -p $out
 cd $root
 python bench.py > $out/bench_hex100.json 2>$out/bench_hex100.err
 python bench.py --workload hex100c > $out/bench_hex100c.json 2>>$out/bench_hex100.err
+python bench.py --workload hex100L --steps 50 --warmup 5 > $out/bench_hex100L.json 2>>$out/bench_hex100.err
 python bench.py --workload hex215 --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_hex215.json 2>>$out/bench_hex100.err
 python bench.py --workload hex300 --no-cpu-baseline --steps 20 --warmup 2 > $out/bench_hex300.json 2>>$out/bench_hex100.err
 python bench.py --workload cavity215 --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity215.json 2>>$out/bench_hex100.err
