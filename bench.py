@@ -21,6 +21,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FP64_VALU_PEAK_TOPS = 256 * 64 * 2.4e9 / 1e12   # FP64 vector instructions per second (x2 = 78.6 TFLOP/s with FMA)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level table); ~6290 achievable
 
 
@@ -257,6 +258,13 @@ def main():
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
             "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
             "avg_launch_us": avg_s * 1e6,
+            # the geometry kernel is FP64-VALU bound, not HBM bound: its rate of algorithmic FP64 instructions (per
+            # element; sqrt = 22, division = 11 as expanded; no FMA contraction, as the reference's x86-64 build)
+            # against the chip's FP64 vector instruction rate (256 CUs x 64 lanes x 2.4 GHz = 39.3 T/s = 78.6 TFLOP/s FMA)
+            **({"valu_f64": {"algorithmic_ops_per_launch": int(dom["algoF64OpsPerLaunch"]),
+                             "achieved_Tops": dom["algoF64OpsPerLaunch"] / avg_s / 1e12, "peak_Tops": FP64_VALU_PEAK_TOPS,
+                             "frac": dom["algoF64OpsPerLaunch"] / avg_s / 1e12 / FP64_VALU_PEAK_TOPS}}
+               if dom.get("algoF64OpsPerLaunch") else {}),
             "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
                     "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
                     "cache-level throughput, not as an HBM-roofline test",

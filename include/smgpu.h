@@ -82,6 +82,9 @@ typedef struct smgpu_counters {
     double ms[SMGPU_MAX_KERNELS];
     int64_t launches[SMGPU_MAX_KERNELS];
     int64_t algoBytesPerLaunch[SMGPU_MAX_KERNELS];
+    int64_t algoF64OpsPerLaunch[SMGPU_MAX_KERNELS];   /* FP64 VALU instructions (per element, not per wave) the
+                                                         reference's arithmetic needs, sqrt = 22 and div = 11 as the
+                                                         compiler expands them; 0 = not counted for this kernel    */
 } smgpu_counters;
 
 const char* smgpu_last_error(void);

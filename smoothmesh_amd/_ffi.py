@@ -44,6 +44,7 @@ class Counters(C.Structure):
     _fields_ = [
         ("nKernels", C.c_int32), ("name", C.c_char_p * MAX_KERNELS), ("ms", C.c_double * MAX_KERNELS),
         ("launches", C.c_int64 * MAX_KERNELS), ("algoBytesPerLaunch", C.c_int64 * MAX_KERNELS),
+        ("algoF64OpsPerLaunch", C.c_int64 * MAX_KERNELS),
     ]
 
 

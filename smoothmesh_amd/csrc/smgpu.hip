@@ -60,6 +60,7 @@ struct smgpu_handle {
     double ms[K_COUNT] = {0};
     int64_t launches[K_COUNT] = {0};
     int64_t algoBytes[K_COUNT] = {0};
+    int64_t algoF64[K_COUNT] = {0};
     // halo
     bool haloOn = false;
     int nShared = 0, nSend = 0, nRecv = 0;
@@ -219,6 +220,22 @@ static void computeAlgoBytes(smgpu_handle* h) {
     b[K_GEOM_TILE] = 24 * P + 4 * (F + 1) + 4 * nfp + 4 * (C + 1) + 4 * ncf + 24 * C + (fa ? 24 * F : 0);
     b[K_EA_FILTER] = b[K_EDGE_ANGLE];
     b[K_FA_FILTER] = b[K_FA_EDGES] - 16 * E + E + 4 * (P + 1) + 4 * npp + P;
+    // FP64 VALU instructions of the geometry (makeFaceCentresAndAreas + makeCellCentresAndVols, each face once):
+    // sqrt counted as 22 and a division as 11 instructions (their IEEE expansions), a 3-vector op as 3.
+    //  face, n > 3 vertices: vertex average 3(n-1) + (n power of two ? 3 : 33); per fan triangle 58 (two differences 6,
+    //    cross 9, magnitude 5 + sqrt, centre sum 6, three accumulations 3 + 1 + 6); result 3 + 33 + 3
+    //  triangle: 6 + 3 + 6 + 9 + 3;   cell with k faces: average 3(k-1) + (3 or 33); per face 24; result 33
+    int64_t ops = 0;
+    for (int32_t f = 0; f < t.nFaces; ++f) {
+        const int64_t n = t.facePoints.off[f + 1] - t.facePoints.off[f];
+        ops += (n == 3) ? 27 : 3 * (n - 1) + (((n & (n - 1)) == 0) ? 3 : 33) + 58 * n + 39;
+    }
+    for (int32_t c = 0; c < t.nCells; ++c) {
+        const int64_t k = t.cellFacesGeom.off[c + 1] - t.cellFacesGeom.off[c];
+        ops += 3 * (k - 1) + (((k & (k - 1)) == 0) ? 3 : 33) + 24 * k + 33;
+    }
+    for (int k = 0; k < K_COUNT; ++k) h->algoF64[k] = 0;
+    h->algoF64[K_GEOM_TILE] = ops;
 }
 
 extern "C" {
@@ -959,6 +976,7 @@ int smgpu_get_counters(smgpu_handle* h, smgpu_counters* o) {
         o->ms[k] = h->ms[k];
         o->launches[k] = h->launches[k];
         o->algoBytesPerLaunch[k] = h->algoBytes[k];
+        o->algoF64OpsPerLaunch[k] = h->algoF64[k];
     }
     return 0;
 }

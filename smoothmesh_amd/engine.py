@@ -227,7 +227,8 @@ class SmoothEngine:
     def counters(self):
         c = _ffi.Counters()
         self._check(self._lib.smgpu_get_counters(self._h, C.byref(c)))
-        return [dict(name=c.name[i].decode(), ms=c.ms[i], launches=c.launches[i], algoBytesPerLaunch=c.algoBytesPerLaunch[i])
+        return [dict(name=c.name[i].decode(), ms=c.ms[i], launches=c.launches[i], algoBytesPerLaunch=c.algoBytesPerLaunch[i],
+                     algoF64OpsPerLaunch=c.algoF64OpsPerLaunch[i])
                 for i in range(c.nKernels)]
 
     # -- multi-rank ----------------------------------------------------------------------------
