@@ -13,6 +13,7 @@ struct GeomTileView {
     const int* cellOrder; const int* cellBeg; const int* tpOff; const int* tpIds; const int* tfOff; const int* tfIds;
     const int* fvBase; const uint8_t* fvWidth; const uint16_t* faceVerts;
     const int* cfBase; const uint8_t* cfWidth; const uint16_t* cellFaces;
+    const uint8_t* tileFlags;    // bit0 all faces quadrilaterals, bit1 all cells six-faced: unrolled paths (same arithmetic)
     int maxPoints, maxFaces;
 };
 
@@ -171,6 +172,42 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         const int b = g.tfOff[tile], nf = g.tfOff[tile + 1] - b;
         const int fw4 = g.fvWidth[tile] >> 2;
         const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
+        const unsigned tflags = g.tileFlags[tile];
+        if (tflags & 1u) {
+            // every face is a quadrilateral: the general loop below unrolled -- same operations in the same order,
+            // the four vertices read once and no pad / position tests
+            for (int i = tid; i < nf; i += T) {
+                const ushort4 q = fvTile[i];
+                const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z), p3 = ldsv(px, py, pz, q.w);
+                const V3 fCentre = divByCount(((p0 + p1) + p2) + p3, 4);
+                V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
+                double sumA = 0.0;
+#define SMGPU_FAN4(THIS, NEXT)                                                 \
+    {                                                                          \
+        const V3 c = ((THIS) + (NEXT)) + fCentre;                              \
+        const V3 nn = cross((NEXT) - (THIS), fCentre - (THIS));                \
+        const double a = mag(nn);                                              \
+        sumN = sumN + nn;                                                      \
+        sumA += a;                                                             \
+        sumAc = sumAc + a * c;                                                 \
+    }
+                SMGPU_FAN4(p0, p1) SMGPU_FAN4(p1, p2) SMGPU_FAN4(p2, p3) SMGPU_FAN4(p3, p0)
+#undef SMGPU_FAN4
+                V3 ctr, area;
+                if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
+                else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
+                fcx[i] = ctr.x; fcy[i] = ctr.y; fcz[i] = ctr.z;
+                fax[i] = area.x; fay[i] = area.y; faz[i] = area.z;
+                if (wantAvg || writeFaces) {
+                    const int fid = g.tfIds[b + i];
+                    if (fid < 0) {
+                        const int f = fid & 0x7fffffff;
+                        if (wantAvg) stv(s.fAvg, f, fCentre);
+                        if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
+                    }
+                }
+            }
+        } else
         for (int i = tid; i < nf; i += T) {
             const ushort4* row = fvTile + (size_t)i * fw4;
             // vertex average (fCentre of makeFaceCentresAndAreas; calcFaceCenter SM.C:1103-1130)
@@ -233,6 +270,32 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         const int c = g.cellOrder[ci];
         const int cw4 = g.cfWidth[tile] >> 2;
         const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
+        if (g.tileFlags[tile] & 2u) {
+            // every cell of the tile has six faces: the loops below unrolled, each face record read once
+            const ushort4 qa = row[0], qb = row[T];
+            const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
+            const V3 c0 = ldsv(fcx, fcy, fcz, e0 & 0x7fff), c1 = ldsv(fcx, fcy, fcz, e1 & 0x7fff), c2 = ldsv(fcx, fcy, fcz, e2 & 0x7fff),
+                     c3 = ldsv(fcx, fcy, fcz, e3 & 0x7fff), c4 = ldsv(fcx, fcy, fcz, e4 & 0x7fff), c5 = ldsv(fcx, fcy, fcz, e5 & 0x7fff);
+            V3 cEst = v3(0, 0, 0);
+            cEst = cEst + c0; cEst = cEst + c1; cEst = cEst + c2; cEst = cEst + c3; cEst = cEst + c4; cEst = cEst + c5;
+            cEst = divByCount(cEst, 6);
+            V3 ctr = v3(0, 0, 0);
+            double vol = 0.0;
+#define SMGPU_PYR(E, FC)                                                                                   \
+    {                                                                                                      \
+        const V3 fA = ldsv(fax, fay, faz, (E) & 0x7fff);                                                   \
+        const double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);               \
+        const V3 pc = (3.0 / 4.0) * (FC) + (1.0 / 4.0) * cEst;                                             \
+        ctr = ctr + pyr3Vol * pc;                                                                          \
+        vol += pyr3Vol;                                                                                    \
+    }
+            SMGPU_PYR(e0, c0) SMGPU_PYR(e1, c1) SMGPU_PYR(e2, c2) SMGPU_PYR(e3, c3) SMGPU_PYR(e4, c4) SMGPU_PYR(e5, c5)
+#undef SMGPU_PYR
+            if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
+            else ctr = cEst;
+            stv(s.cellCtr, c, ctr);
+            return;
+        }
         V3 cEst = v3(0, 0, 0);
         int nFaces = 0;
         SMGPU_ELL_FOREACH(row, cw4, T, {

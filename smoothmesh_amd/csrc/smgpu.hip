@@ -343,6 +343,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &g.cfBase, h->gt.cfBase);
             rc |= devUpload(h, &g.cfWidth, h->gt.cfWidth);
             rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
+            rc |= devUpload(h, &g.tileFlags, h->gt.tileFlags);
             g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
             rc |= devUpload(h, &v.ptOrder, h->stl.order);
             rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);

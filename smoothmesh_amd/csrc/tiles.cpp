@@ -96,7 +96,7 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
     std::vector<int32_t> locP((size_t)t.nPoints, -1), locF((size_t)t.nFaces, -1);
     tpOff.assign(1, 0); tfOff.assign(1, 0);
     tpIds.clear(); tfIds.clear(); faceVerts.clear(); cellFaces.clear();
-    fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear();
+    fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear(); tileFlags.clear();
     std::vector<int32_t> faces, points;
     std::vector<int32_t> cellTile((size_t)t.nCells, -1);   // which tile a cell belongs to
     for (int32_t ti = 0; ti < nTiles; ++ti)
@@ -114,7 +114,10 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
             }
         }
         std::sort(faces.begin(), faces.end());
+        bool allQuads = true, allHex = true;
+        for (int32_t ci = cb; ci < ce; ++ci) { const int32_t c = order[(size_t)ci]; allHex = allHex && (cf.off[c + 1] - cf.off[c] == 6); }
         for (int32_t f : faces) {
+            allQuads = allQuads && (fp.off[f + 1] - fp.off[f] == 4);
             fw = std::max(fw, fp.off[f + 1] - fp.off[f]);
             for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
                 if (stampP[fp.val[j]] != ti) { stampP[fp.val[j]] = ti; points.push_back(fp.val[j]); }
@@ -138,6 +141,7 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
         tfOff.push_back((int32_t)tfIds.size());
         cfBase.push_back((int32_t)cellFaces.size());
         cfWidth.push_back((uint8_t)cw);
+        tileFlags.push_back((uint8_t)((allQuads ? 1 : 0) | (allHex ? 2 : 0)));
         const size_t base = cellFaces.size();
         cellFaces.resize(base + (size_t)cw * threads, kEllPad);
         for (int32_t ci = cb; ci < ce; ++ci) {

@@ -39,6 +39,8 @@ struct GeomTiles {
     std::vector<int32_t> cfBase;    // nTiles
     std::vector<uint8_t> cfWidth;   // nTiles
     std::vector<uint16_t> cellFaces;
+    std::vector<uint8_t> tileFlags; // nTiles: bit0 every face of the tile is a quadrilateral, bit1 every cell has 6 faces
+                                    // (wave-uniform selection of the unrolled kernel paths)
     int32_t maxPoints = 0, maxFaces = 0;
     // tile order: position -> cell id.  Natural order, or a Morton (Z-curve) order of the cell centres so
     // that a run of consecutive positions is a compact 3-D brick (fewer faces / points shared with other
