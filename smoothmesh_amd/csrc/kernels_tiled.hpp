@@ -148,40 +148,37 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols (.com v2412), staged through LDS.
 // tileList (may be NULL) selects the tiles of this launch (multi-rank: the tiles away from the shared points
 // are recomputed ahead, while exchange F is in flight).
-template <int T>
-__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
-                                                  int nLaunch, int xcdMap) {
-    if (s.acc->stop) return;
-    const int li = launchTile(nLaunch, xcdMap);
-    if (li < 0) return;
-    extern __shared__ double lds[];
-    double* px = lds;             double* py = px + g.maxPoints;  double* pz = py + g.maxPoints;
-    double* fcx = pz + g.maxPoints; double* fcy = fcx + g.maxFaces; double* fcz = fcy + g.maxFaces;
-    double* fax = fcz + g.maxFaces; double* fay = fax + g.maxFaces; double* faz = fay + g.maxFaces;
-    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
+// LDS arrays of one geometry tile
+struct GeomLds {
+    double *px, *py, *pz;        // the tile's points
+    double *fcx, *fcy, *fcz;     // face centres
+    double *fax, *fay, *faz;     // face area vectors
+};
+__device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileView& g) {
+    GeomLds L;
+    L.px = lds;                  L.py = L.px + g.maxPoints;  L.pz = L.py + g.maxPoints;
+    L.fcx = L.pz + g.maxPoints;  L.fcy = L.fcx + g.maxFaces; L.fcz = L.fcy + g.maxFaces;
+    L.fax = L.fcz + g.maxFaces;  L.fay = L.fax + g.maxFaces; L.faz = L.fay + g.maxFaces;
+    return L;
+}
 
-    // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
-    {
-        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
-        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, px, py, pz, tid);
-    }
-    __syncthreads();
-
-    // phase 1: every face of the tile once
-    {
-        const int b = g.tfOff[tile], nf = g.tfOff[tile + 1] - b;
-        const int fw4 = g.fvWidth[tile] >> 2;
-        const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
-        const unsigned tflags = g.tileFlags[tile];
-        if (tflags & 1u) {
-            // every face is a quadrilateral: the general loop below unrolled -- same operations in the same order,
-            // the four vertices read once and no pad / position tests
-            for (int i = tid; i < nf; i += T) {
-                const ushort4 q = fvTile[i];
-                const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z), p3 = ldsv(px, py, pz, q.w);
-                const V3 fCentre = divByCount(((p0 + p1) + p2) + p3, 4);
-                V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
-                double sumA = 0.0;
+// face i of the tile: OpenFOAM makeFaceCentresAndAreas (.com v2412) on the staged points -> LDS (+ the per-face
+// values the owner's tile publishes).  tflags bit0: every face of the tile is a quadrilateral.
+__device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int i, unsigned tflags,
+                                         int wantAvg, int writeFaces) {
+    const double *px = L.px, *py = L.py, *pz = L.pz;
+    const int b = g.tfOff[tile];
+    const int fw4 = g.fvWidth[tile] >> 2;
+    const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
+    V3 fCentre, ctr, area;
+    if (tflags & 1u) {
+        // the general loop below unrolled for four vertices -- same operations in the same order, every vertex read
+        // once, no pad / position tests
+        const ushort4 q = fvTile[i];
+        const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z), p3 = ldsv(px, py, pz, q.w);
+        fCentre = divByCount(((p0 + p1) + p2) + p3, 4);
+        V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
+        double sumA = 0.0;
 #define SMGPU_FAN4(THIS, NEXT)                                                 \
     {                                                                          \
         const V3 c = ((THIS) + (NEXT)) + fCentre;                              \
@@ -191,44 +188,30 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         sumA += a;                                                             \
         sumAc = sumAc + a * c;                                                 \
     }
-                SMGPU_FAN4(p0, p1) SMGPU_FAN4(p1, p2) SMGPU_FAN4(p2, p3) SMGPU_FAN4(p3, p0)
+        SMGPU_FAN4(p0, p1) SMGPU_FAN4(p1, p2) SMGPU_FAN4(p2, p3) SMGPU_FAN4(p3, p0)
 #undef SMGPU_FAN4
-                V3 ctr, area;
-                if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
-                else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
-                fcx[i] = ctr.x; fcy[i] = ctr.y; fcz[i] = ctr.z;
-                fax[i] = area.x; fay[i] = area.y; faz[i] = area.z;
-                if (wantAvg || writeFaces) {
-                    const int fid = g.tfIds[b + i];
-                    if (fid < 0) {
-                        const int f = fid & 0x7fffffff;
-                        if (wantAvg) stv(s.fAvg, f, fCentre);
-                        if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
-                    }
-                }
-            }
-        } else
-        for (int i = tid; i < nf; i += T) {
-            const ushort4* row = fvTile + (size_t)i * fw4;
-            // vertex average (fCentre of makeFaceCentresAndAreas; calcFaceCenter SM.C:1103-1130)
-            V3 fCentre = v3(0, 0, 0);
-            int n = 0;
-            SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, e);
-                fCentre = (j == 0) ? p : fCentre + p;
-                n = j + 1;
-            })
-            fCentre = divByCount(fCentre, n);
-            V3 ctr, area;
-            if (n == 3) {
-                const ushort4 q = row[0];
-                const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z);
-                ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
-                area = 0.5 * cross(p1 - p0, p2 - p0);
-            } else {
-                V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
-                double sumA = 0.0;
-                V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
+        if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
+        else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
+    } else {
+        const ushort4* row = fvTile + (size_t)i * fw4;
+        // vertex average (fCentre of makeFaceCentresAndAreas; calcFaceCenter SM.C:1103-1130)
+        fCentre = v3(0, 0, 0);
+        int n = 0;
+        SMGPU_ELL_FOREACH(row, fw4, 1, {
+            const V3 p = ldsv(px, py, pz, e);
+            fCentre = (j == 0) ? p : fCentre + p;
+            n = j + 1;
+        })
+        fCentre = divByCount(fCentre, n);
+        if (n == 3) {
+            const ushort4 q = row[0];
+            const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z);
+            ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
+            area = 0.5 * cross(p1 - p0, p2 - p0);
+        } else {
+            V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
+            double sumA = 0.0;
+            V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
 #define SMGPU_FAN(NEXT)                                                        \
     {                                                                          \
         const V3 nextPoint = (NEXT);                                           \
@@ -240,47 +223,41 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         sumAc = sumAc + a * c;                                                 \
         thisPoint = nextPoint;                                                 \
     }
-                SMGPU_ELL_FOREACH(row, fw4, 1, {
-                    const V3 p = ldsv(px, py, pz, e);
-                    if (j == 0) { first = p; thisPoint = p; }
-                    else SMGPU_FAN(p)
-                })
-                SMGPU_FAN(first)
+            SMGPU_ELL_FOREACH(row, fw4, 1, {
+                const V3 p = ldsv(px, py, pz, e);
+                if (j == 0) { first = p; thisPoint = p; }
+                else SMGPU_FAN(p)
+            })
+            SMGPU_FAN(first)
 #undef SMGPU_FAN
-                if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
-                else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
-            }
-            fcx[i] = ctr.x; fcy[i] = ctr.y; fcz[i] = ctr.z;
-            fax[i] = area.x; fay[i] = area.y; faz[i] = area.z;
-            if (wantAvg || writeFaces) {
-                const int fid = g.tfIds[b + i];
-                if (fid < 0) {   // this tile holds the face's owner cell: it publishes the per-face values
-                    const int f = fid & 0x7fffffff;
-                    if (wantAvg) stv(s.fAvg, f, fCentre);
-                    if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
-                }
-            }
+            if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
+            else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
         }
     }
-    __syncthreads();
+    L.fcx[i] = ctr.x; L.fcy[i] = ctr.y; L.fcz[i] = ctr.z;
+    L.fax[i] = area.x; L.fay[i] = area.y; L.faz[i] = area.z;
+    if (wantAvg || writeFaces) {
+        const int fid = g.tfIds[b + i];
+        if (fid < 0) {   // this tile holds the face's owner cell: it publishes the per-face values
+            const int f = fid & 0x7fffffff;
+            if (wantAvg) stv(s.fAvg, f, fCentre);
+            if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
+        }
+    }
+}
 
-    // phase 2: one thread per cell
+// the thread's cell of the tile: OpenFOAM makeCellCentresAndVols (.com v2412) on the face values in LDS.
+// tflags bit1: every cell of the tile has six faces.
+template <int T>
+__device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int tid, unsigned tflags) {
+    const double *fcx = L.fcx, *fcy = L.fcy, *fcz = L.fcz, *fax = L.fax, *fay = L.fay, *faz = L.faz;
     const int ci = g.cellBeg[tile] + tid;
-    if (ci < g.cellBeg[tile + 1]) {
-        const int c = g.cellOrder[ci];
-        const int cw4 = g.cfWidth[tile] >> 2;
-        const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
-        if (g.tileFlags[tile] & 2u) {
-            // every cell of the tile has six faces: the loops below unrolled, each face record read once
-            const ushort4 qa = row[0], qb = row[T];
-            const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
-            const V3 c0 = ldsv(fcx, fcy, fcz, e0 & 0x7fff), c1 = ldsv(fcx, fcy, fcz, e1 & 0x7fff), c2 = ldsv(fcx, fcy, fcz, e2 & 0x7fff),
-                     c3 = ldsv(fcx, fcy, fcz, e3 & 0x7fff), c4 = ldsv(fcx, fcy, fcz, e4 & 0x7fff), c5 = ldsv(fcx, fcy, fcz, e5 & 0x7fff);
-            V3 cEst = v3(0, 0, 0);
-            cEst = cEst + c0; cEst = cEst + c1; cEst = cEst + c2; cEst = cEst + c3; cEst = cEst + c4; cEst = cEst + c5;
-            cEst = divByCount(cEst, 6);
-            V3 ctr = v3(0, 0, 0);
-            double vol = 0.0;
+    if (ci >= g.cellBeg[tile + 1]) return;
+    const int c = g.cellOrder[ci];
+    const int cw4 = g.cfWidth[tile] >> 2;
+    const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
+    V3 cEst = v3(0, 0, 0), ctr = v3(0, 0, 0);
+    double vol = 0.0;
 #define SMGPU_PYR(E, FC)                                                                                   \
     {                                                                                                      \
         const V3 fA = ldsv(fax, fay, faz, (E) & 0x7fff);                                                   \
@@ -289,35 +266,124 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         ctr = ctr + pyr3Vol * pc;                                                                          \
         vol += pyr3Vol;                                                                                    \
     }
-            SMGPU_PYR(e0, c0) SMGPU_PYR(e1, c1) SMGPU_PYR(e2, c2) SMGPU_PYR(e3, c3) SMGPU_PYR(e4, c4) SMGPU_PYR(e5, c5)
-#undef SMGPU_PYR
-            if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
-            else ctr = cEst;
-            stv(s.cellCtr, c, ctr);
-            return;
-        }
-        V3 cEst = v3(0, 0, 0);
+    if (tflags & 2u) {
+        // the loops below unrolled for six faces, each face centre read once
+        const ushort4 qa = row[0], qb = row[T];
+        const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
+        const V3 c0 = ldsv(fcx, fcy, fcz, e0 & 0x7fff), c1 = ldsv(fcx, fcy, fcz, e1 & 0x7fff), c2 = ldsv(fcx, fcy, fcz, e2 & 0x7fff),
+                 c3 = ldsv(fcx, fcy, fcz, e3 & 0x7fff), c4 = ldsv(fcx, fcy, fcz, e4 & 0x7fff), c5 = ldsv(fcx, fcy, fcz, e5 & 0x7fff);
+        cEst = cEst + c0; cEst = cEst + c1; cEst = cEst + c2; cEst = cEst + c3; cEst = cEst + c4; cEst = cEst + c5;
+        cEst = divByCount(cEst, 6);
+        SMGPU_PYR(e0, c0) SMGPU_PYR(e1, c1) SMGPU_PYR(e2, c2) SMGPU_PYR(e3, c3) SMGPU_PYR(e4, c4) SMGPU_PYR(e5, c5)
+    } else {
         int nFaces = 0;
         SMGPU_ELL_FOREACH(row, cw4, T, {
             cEst = cEst + ldsv(fcx, fcy, fcz, e & 0x7fff);
             nFaces = j + 1;
         })
         cEst = divByCount(cEst, nFaces);
-        V3 ctr = v3(0, 0, 0);
-        double vol = 0.0;
         SMGPU_ELL_FOREACH(row, cw4, T, {
             (void)j;
-            const int f = e & 0x7fff;
-            const V3 fc = ldsv(fcx, fcy, fcz, f);
-            const V3 fA = ldsv(fax, fay, faz, f);
-            const double pyr3Vol = (e & 0x8000) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
-            const V3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst;
-            ctr = ctr + pyr3Vol * pc;
-            vol += pyr3Vol;
+            const V3 fc = ldsv(fcx, fcy, fcz, e & 0x7fff);
+            SMGPU_PYR(e, fc)
         })
-        if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
-        else ctr = cEst;
-        stv(s.cellCtr, c, ctr);
+    }
+#undef SMGPU_PYR
+    if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
+    else ctr = cEst;
+    stv(s.cellCtr, c, ctr);
+}
+
+template <int T>
+__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
+                                                  int nLaunch, int xcdMap) {
+    if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
+    extern __shared__ double lds[];
+    const GeomLds L = geomLds(lds, g);
+    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
+    // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
+    {
+        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
+        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, L.px, L.py, L.pz, tid);
+    }
+    __syncthreads();
+    // phase 1: every face of the tile once
+    const unsigned tflags = g.tileFlags[tile];
+    const int nf = g.tfOff[tile + 1] - g.tfOff[tile];
+    for (int i = tid; i < nf; i += T) geomFace(s, g, L, tile, i, tflags, wantAvg, writeFaces);
+    __syncthreads();
+    // phase 2: one thread per cell
+    geomCell<T>(s, g, L, tile, tid, tflags);
+}
+
+// The same work as k_geom_tile on a PERSISTENT grid: every workgroup walks a sequence of tiles and software-pipelines
+// them -- the point ids of its next tile are requested before the face phase of the current one, the point records
+// after the first round of faces, and they are stored into the LDS point arrays as soon as the faces are done (the
+// cell phase no longer reads points).  With one tile per workgroup all resident workgroups stage, then compute, in
+// step; here the loads of one tile hide behind the arithmetic of the previous one.
+// MEASURED (100^3, MI355X): slower than k_geom_tile, 80.8 vs 66.3 us -- the prefetch registers push the kernel from 117
+// to 150+ VGPRs, i.e. from 4 to 3 waves per SIMD, which costs more than the hidden staging (14.8 us if it were fully
+// exposed) gains; capping the registers spills (118 us).  Kept selectable (SMGPU_GEOM_PERSIST=1) and under test.
+// wgPerXcd: workgroups per XCD of the launch (grid = 8 * wgPerXcd with xcdMap, see launchTile).
+constexpr int kGeomPrefetchRounds = 2;
+template <int T>
+__global__ void __launch_bounds__(T) k_geom_tile_p(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
+                                                    int nLaunch, int xcdMap, int wgPerXcd) {
+    if (s.acc->stop) return;
+    int li, stride, end;
+    if (xcdMap & 1) {
+        const int per = (nLaunch + 7) >> 3, x = blockIdx.x & 7;
+        li = x * per + (blockIdx.x >> 3);
+        stride = wgPerXcd;
+        end = min((x + 1) * per, nLaunch);
+    } else { li = blockIdx.x; stride = gridDim.x; end = nLaunch; }
+    if (li >= end) return;
+    extern __shared__ double lds[];
+    const GeomLds L = geomLds(lds, g);
+    const int tid = threadIdx.x;
+    int tile = tileList ? tileList[li] : li;
+    {
+        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
+        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, L.px, L.py, L.pz, tid);
+    }
+    __syncthreads();
+    for (;;) {
+        const int liNext = li + stride;
+        const bool hasNext = liNext < end;
+        const int tileNext = hasNext ? (tileList ? tileList[liNext] : liNext) : 0;
+        const int nb = hasNext ? g.tpOff[tileNext] : 0, nn = hasNext ? g.tpOff[tileNext + 1] - nb : 0;
+        const bool pre = hasNext && nn <= T * kGeomPrefetchRounds;     // wave-uniform
+        int nid[kGeomPrefetchRounds];
+        V3 nv[kGeomPrefetchRounds];
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < kGeomPrefetchRounds; ++u) { const int i = u * T + tid; nid[u] = (i < nn) ? g.tpIds[nb + i] : -1; }
+        }
+        const unsigned tflags = g.tileFlags[tile];
+        const int nf = g.tfOff[tile + 1] - g.tfOff[tile];
+        if (tid < nf) geomFace(s, g, L, tile, tid, tflags, wantAvg, writeFaces);
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < kGeomPrefetchRounds; ++u) nv[u] = (nid[u] >= 0) ? ldv(s.ptsCur, nid[u]) : v3(0, 0, 0);
+        }
+        for (int i = tid + T; i < nf; i += T) geomFace(s, g, L, tile, i, tflags, wantAvg, writeFaces);
+        __syncthreads();                      // faces complete; the point arrays are free
+        if (pre) {
+#pragma unroll
+            for (int u = 0; u < kGeomPrefetchRounds; ++u) {
+                const int i = u * T + tid;
+                if (nid[u] >= 0) { L.px[i] = nv[u].x; L.py[i] = nv[u].y; L.pz[i] = nv[u].z; }
+            }
+        } else if (hasNext) {
+            stageRecords<T, 2>(s.ptsCur, g.tpIds + nb, nn, L.px, L.py, L.pz, tid);
+        }
+        geomCell<T>(s, g, L, tile, tid, tflags);
+        if (!hasNext) break;
+        __syncthreads();                      // next tile's points staged, this tile's face arrays consumed
+        li = liNext;
+        tile = tileNext;
     }
 }
 

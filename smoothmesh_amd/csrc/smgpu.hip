@@ -103,6 +103,7 @@ struct smgpu_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
+    bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
     std::vector<int32_t> layerHopsHost, layerMapHost;   // kept for the debug getters
@@ -301,6 +302,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
+    h->geomPersist = envInt("SMGPU_GEOM_PERSIST", 0) != 0;
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -522,6 +524,20 @@ static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, i
     if (!attrSet) {
         if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
         attrSet = true;
+    }
+    if (h->geomPersist) {
+        // persistent, software-pipelined form: as many workgroups as the chip holds at once (8 XCDs x 32 CUs)
+        static int perCu = 0;
+        if (!perCu) {
+            if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile_p<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_geom_tile_p<T>, T, h->geomLds) != hipSuccess || perCu < 1) perCu = 2;
+        }
+        const int per = (nTiles + 7) >> 3;
+        const int wgPerXcd = std::min(per, perCu * 32);
+        const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
+        hipLaunchKernelGGL(k_geom_tile_p<T>, dim3(grid), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0, tileList, nTiles,
+                           h->xcdMap, wgPerXcd);
+        return;
     }
     hipLaunchKernelGGL(k_geom_tile<T>, dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
                        tileList, nTiles, h->xcdMap);
