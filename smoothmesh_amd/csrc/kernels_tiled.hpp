@@ -391,43 +391,51 @@ __global__ void __launch_bounds__(T) k_geom_tile_p(MeshView m, State s, GeomTile
 // coordinates of one tile of consecutive points staged in LDS.
 // tileList (may be NULL) selects the tiles of this launch: the multi-rank driver smooths the tiles without
 // shared points while exchange A is in flight, the others after it.
-template <bool FINAL, int T>
-__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList,
-                                                    int nLaunch, int xcdMap) {
-    if (s.acc->stop) return;
-    const int li = launchTile(nLaunch, xcdMap);
-    if (li < 0) return;
-    extern __shared__ double lds[];
-    double* cx = lds;              double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
-    double* nx = cz + g.maxCells;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
-    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
-    // everything a thread needs from global memory besides the staged records is requested first, so that
-    // its latency overlaps the staging: point id, flags, own LDS slot, the first two ELL chunks of both rows
+// LDS arrays of one smoothing tile and the per-thread prologue (what a thread reads from global memory besides the
+// staged records: point id, own LDS slot, the first two ELL chunks of both rows)
+struct SmoothLds { double *cx, *cy, *cz, *nx, *ny, *nz; };
+__device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileView& g) {
+    SmoothLds L;
+    L.cx = lds;                 L.cy = L.cx + g.maxCells;  L.cz = L.cy + g.maxCells;
+    L.nx = L.cz + g.maxCells;   L.ny = L.nx + g.maxPoints; L.nz = L.ny + g.maxPoints;
+    return L;
+}
+struct SmoothRow {
+    bool mine; int p, selfL, wn4, wc4;
+    const ushort4 *ppRow, *pcRow;
+    ushort4 pp0, pp1, pc0, pc1;
+};
+template <int T>
+__device__ __forceinline__ SmoothRow smoothRow(const SmoothTileView& g, int tile, int tid) {
+    SmoothRow r;
     const int pi = g.ptBeg[tile] + tid;
-    const bool mine = pi < g.ptBeg[tile + 1];
-    const int wn4 = g.ppWidth[tile] >> 2, wc4 = g.pcWidth[tile] >> 2;
-    const ushort4* ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
-    const ushort4* pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
+    r.mine = pi < g.ptBeg[tile + 1];
+    r.wn4 = g.ppWidth[tile] >> 2; r.wc4 = g.pcWidth[tile] >> 2;
+    r.ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
+    r.pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
     const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
-    int p = 0, selfL = 0;
-    ushort4 pp0 = padq, pp1 = padq, pc0 = padq, pc1 = padq;
-    if (mine) {
-        p = g.ptOrder[pi];
-        selfL = g.selfLoc[pi];
-        if (wn4 > 0) pp0 = ppRow[0];
-        if (wn4 > 1) pp1 = ppRow[T];
-        if (wc4 > 0) pc0 = pcRow[0];
-        if (wc4 > 1) pc1 = pcRow[T];
+    r.p = 0; r.selfL = 0;
+    r.pp0 = padq; r.pp1 = padq; r.pc0 = padq; r.pc1 = padq;
+    if (r.mine) {
+        r.p = g.ptOrder[pi];
+        r.selfL = g.selfLoc[pi];
+        if (r.wn4 > 0) r.pp0 = r.ppRow[0];
+        if (r.wn4 > 1) r.pp1 = r.ppRow[T];
+        if (r.wc4 > 0) r.pc0 = r.pcRow[0];
+        if (r.wc4 > 1) r.pc1 = r.pcRow[T];
     }
-    {
-        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
-        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, cx, cy, cz, s.ptsCur, g.tnIds + b2, n2, nx, ny, nz, tid);
-    }
-    __syncthreads();
+    return r;
+}
 
-    double dist = 0.0;
-    int fcount = 0;
+// the thread's point of the tile, from the staged cell centres / neighbour coordinates (see k_smooth for the steps)
+template <bool FINAL, int T>
+__device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, const Prm& prm, const SmoothTileView& g, const SmoothLds& L,
+                                            const SmoothRow& R, int tile, int tid, double& dist, int& fcount) {
+    const double *cx = L.cx, *cy = L.cy, *cz = L.cz, *nx = L.nx, *ny = L.ny, *nz = L.nz;
+    const bool mine = R.mine;
+    const int p = R.p, selfL = R.selfL, wn4 = R.wn4, wc4 = R.wc4;
+    const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
+    const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
     if (mine) {
         const uint8_t fl = m.pflags[p];
         const bool internal = fl & PF_INTERNAL;
@@ -526,7 +534,130 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
             s.frozen[p] = frozen ? 1 : 0;
         }
     }
+}
+
+template <bool FINAL, int T>
+__global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList,
+                                                    int nLaunch, int xcdMap) {
+    if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
+    extern __shared__ double lds[];
+    const SmoothLds L = smoothLds(lds, g);
+    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
+    // everything a thread needs from global memory besides the staged records is requested first, so that
+    // its latency overlaps the staging
+    const SmoothRow R = smoothRow<T>(g, tile, tid);
+    {
+        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
+        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
+        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
+    }
+    __syncthreads();
+    double dist = 0.0;
+    int fcount = 0;
+    smoothPoint<FINAL, T>(m, s, prm, g, L, R, tile, tid, dist, fcount);
     if (FINAL) blockPublish<T>(s, dist, fcount, tile);
+}
+
+// k_smooth_tile on a PERSISTENT grid, software-pipelined over the tile sequence of each workgroup (tile staging takes
+// 21 us of the 45 us kernel on 100^3 and all resident workgroups stage, then compute, in step): while tile k is being
+// computed from LDS, the records of tile k+1 are in flight into registers (their ids were fetched one tile earlier) and
+// the ids of tile k+2 are requested; after the compute phase the registers are stored to LDS.
+// MEASURED (100^3, MI355X): slower than k_smooth_tile, 59.9 vs 45.8 us -- the compiler needs 132-143 VGPRs instead of
+// 64-67 (3 instead of 5 waves per SIMD).  Kept selectable (SMGPU_SMOOTH_PERSIST=1) and under test.
+// wgPerXcd: workgroups per XCD of the launch (grid = 8 * wgPerXcd with xcdMap, see launchTile).
+template <bool FINAL, int T>
+__global__ void __launch_bounds__(T) k_smooth_tile_p(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList, int nLaunch,
+                                                      int xcdMap, int wgPerXcd) {
+    if (s.acc->stop) return;
+    constexpr int RC = 2, RN = 3;        // register rounds for the cell-centre / neighbour-point records of a tile
+    int li, stride, end;
+    if (xcdMap & 1) {
+        const int per = (nLaunch + 7) >> 3, x = blockIdx.x & 7;
+        li = x * per + (blockIdx.x >> 3);
+        stride = wgPerXcd;
+        end = min((x + 1) * per, nLaunch);
+    } else { li = blockIdx.x; stride = gridDim.x; end = nLaunch; }
+    if (li >= end) return;
+    extern __shared__ double lds[];
+    const SmoothLds L = smoothLds(lds, g);
+    const int tid = threadIdx.x;
+#define SMGPU_TILE_OF(LI) (tileList ? tileList[(LI)] : (LI))
+    int tile = SMGPU_TILE_OF(li);
+    {
+        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
+        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
+        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
+    }
+    // ids of the next tile
+    int idC[RC], idN[RN];
+    bool pre1 = false;                    // tile k+1 exists and fits the register rounds (wave-uniform)
+    int li1 = li + stride;
+    {
+        const bool has1 = li1 < end;
+        const int t1 = has1 ? SMGPU_TILE_OF(li1) : 0;
+        const int bC = has1 ? g.tcOff[t1] : 0, nC = has1 ? g.tcOff[t1 + 1] - bC : 0;
+        const int bN = has1 ? g.tnOff[t1] : 0, nN = has1 ? g.tnOff[t1 + 1] - bN : 0;
+        pre1 = has1 && nC <= T * RC && nN <= T * RN;
+#pragma unroll
+        for (int u = 0; u < RC; ++u) { const int i = u * T + tid; idC[u] = (pre1 && i < nC) ? g.tcIds[bC + i] : -1; }
+#pragma unroll
+        for (int u = 0; u < RN; ++u) { const int i = u * T + tid; idN[u] = (pre1 && i < nN) ? g.tnIds[bN + i] : -1; }
+    }
+    __syncthreads();
+    for (;;) {
+        const bool has1 = li1 < end;
+        const int t1 = has1 ? SMGPU_TILE_OF(li1) : 0;
+        // records of tile k+1 (ids already here), ids of tile k+2
+        V3 vC[RC], vN[RN];
+        if (pre1) {
+#pragma unroll
+            for (int u = 0; u < RC; ++u) vC[u] = (idC[u] >= 0) ? ldv(s.cellCtr, idC[u]) : v3(0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < RN; ++u) vN[u] = (idN[u] >= 0) ? ldv(s.ptsCur, idN[u]) : v3(0, 0, 0);
+        }
+        const int li2 = li1 + stride;
+        const bool has2 = li2 < end;
+        int idC2[RC], idN2[RN];
+        bool pre2 = false;
+        {
+            const int t2 = has2 ? SMGPU_TILE_OF(li2) : 0;
+            const int bC = has2 ? g.tcOff[t2] : 0, nC = has2 ? g.tcOff[t2 + 1] - bC : 0;
+            const int bN = has2 ? g.tnOff[t2] : 0, nN = has2 ? g.tnOff[t2 + 1] - bN : 0;
+            pre2 = has2 && nC <= T * RC && nN <= T * RN;
+#pragma unroll
+            for (int u = 0; u < RC; ++u) { const int i = u * T + tid; idC2[u] = (pre2 && i < nC) ? g.tcIds[bC + i] : -1; }
+#pragma unroll
+            for (int u = 0; u < RN; ++u) { const int i = u * T + tid; idN2[u] = (pre2 && i < nN) ? g.tnIds[bN + i] : -1; }
+        }
+        // tile k from LDS
+        const SmoothRow R = smoothRow<T>(g, tile, tid);
+        double dist = 0.0;
+        int fcount = 0;
+        smoothPoint<FINAL, T>(m, s, prm, g, L, R, tile, tid, dist, fcount);
+        if (FINAL) blockPublish<T>(s, dist, fcount, tile);
+        if (!has1) break;
+        __syncthreads();                  // every thread is done reading the LDS records of tile k
+        if (pre1) {
+#pragma unroll
+            for (int u = 0; u < RC; ++u) { const int i = u * T + tid; if (idC[u] >= 0) { L.cx[i] = vC[u].x; L.cy[i] = vC[u].y; L.cz[i] = vC[u].z; } }
+#pragma unroll
+            for (int u = 0; u < RN; ++u) { const int i = u * T + tid; if (idN[u] >= 0) { L.nx[i] = vN[u].x; L.ny[i] = vN[u].y; L.nz[i] = vN[u].z; } }
+        } else {
+            const int b = g.tcOff[t1], n = g.tcOff[t1 + 1] - b;
+            const int b2 = g.tnOff[t1], n2 = g.tnOff[t1 + 1] - b2;
+            stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
+        }
+#pragma unroll
+        for (int u = 0; u < RC; ++u) idC[u] = idC2[u];
+#pragma unroll
+        for (int u = 0; u < RN; ++u) idN[u] = idN2[u];
+        pre1 = pre2;
+        li = li1; li1 = li2; tile = t1;
+        __syncthreads();
+    }
+#undef SMGPU_TILE_OF
 }
 
 }  // namespace smgpu

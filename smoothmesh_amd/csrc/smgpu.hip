@@ -103,6 +103,7 @@ struct smgpu_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
+    bool smoothPersist = false; // SMGPU_SMOOTH_PERSIST=1: persistent, software-pipelined smoothing kernel (measured slower)
     bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
@@ -303,6 +304,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->geomPersist = envInt("SMGPU_GEOM_PERSIST", 0) != 0;
+    h->smoothPersist = envInt("SMGPU_SMOOTH_PERSIST", 0) != 0;
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -548,6 +550,19 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
     if (!attrSet) {
         if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
         attrSet = true;
+    }
+    if (h->smoothPersist) {
+        static int perCu = 0;
+        if (!perCu) {
+            if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile_p<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_smooth_tile_p<FINAL, T>, T, h->smoothLds) != hipSuccess || perCu < 1) perCu = 2;
+        }
+        const int per = (nTiles + 7) >> 3;
+        const int wgPerXcd = std::min(per, perCu * 32);
+        const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
+        hipLaunchKernelGGL((k_smooth_tile_p<FINAL, T>), dim3(grid), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList, nTiles, h->xcdMap,
+                           wgPerXcd);
+        return;
     }
     hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
                        nTiles, h->xcdMap);

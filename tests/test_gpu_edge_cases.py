@@ -88,9 +88,10 @@ def test_natural_tile_order(oracle_lib, monkeypatch):
     _compare(hex_block(9, 7, 5, jitter=0.3, seed=2), oracle_lib)
 
 
-@pytest.mark.parametrize("env", [{"SMGPU_GEOM_PERSIST": "1"}, {"SMGPU_XCD_MAP": "0"}, {"SMGPU_GEOM_PERSIST": "1", "SMGPU_XCD_MAP": "0"}])
+@pytest.mark.parametrize("env", [{"SMGPU_GEOM_PERSIST": "1", "SMGPU_SMOOTH_PERSIST": "1"}, {"SMGPU_XCD_MAP": "0"},
+                                 {"SMGPU_GEOM_PERSIST": "1", "SMGPU_SMOOTH_PERSIST": "1", "SMGPU_XCD_MAP": "0"}])
 def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
-    """persistent / software-pipelined geometry kernel and round-robin tile launch: tuning knobs, same bits;
+    """persistent / software-pipelined geometry and smoothing kernels, round-robin tile launch: tuning knobs, same bits;
     meshes large enough for several tiles per workgroup sequence, with quadrilateral-only and mixed tiles"""
     from smoothmesh_amd.meshgen import hex_block
     from smoothmesh_amd.polymesh import cavity_mesh
