@@ -46,7 +46,10 @@ struct Accum {                 // device-side loop state
 
 struct State {
     double* ptsCur; double* ptsNext; double* prop;
-    double* fCtr; double* fArea; double* fAvg; double* cellCtr;
+    double* fCtr; double* fArea; double* cellCtr;
+    double* fAvg;      // face vertex averages for the f32 face-angle filter: by face id, or (avgPacked) in the order of the
+                       // geometry tiles' face lists -- contiguous stores; the exact kernels form the average themselves
+    int avgPacked;
     uint8_t* frozen;
     double* edgeMin; double* edgeMax; double* ptMin; double* ptMax;
     uint8_t* faActive; uint8_t* faS; uint8_t* faN; int* walkStack;
@@ -494,6 +497,15 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s,
 // calcMinMaxFaceAngleForEdge SM.C:1135-1231 for one edge, with optional substitution of the
 // coordinates of two points (i1 -> c1, i2 -> c2; i = -1 disables).  SUBST = false is the
 // current-mesh form (SM.C:1235-1247) and uses the per-face vertex averages from k_face_geom.
+// vertex average of a face of the current coordinates (calcFaceCenter SM.C:1103-1130; the same operations as the
+// geometry kernels' fCentre, so the same bits)
+__device__ __forceinline__ V3 faceAverage(const MeshView& m, const State& s, int f) {
+    const int b = m.faceOff[f], n = m.faceOff[f + 1] - b;
+    V3 fc = ldv(s.ptsCur, m.facePts[b]);
+    for (int i = 1; i < n; ++i) fc = fc + ldv(s.ptsCur, m.facePts[b + i]);
+    return divByCount(fc, n);
+}
+
 template <bool SUBST>
 __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s, int e, int i1, const V3& c1, int i2,
                                                const V3& c2, double& minA, double& maxA) {
@@ -521,7 +533,7 @@ __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s
             }
             fc = fc / double(n);
         } else {
-            fc = ldv(s.fAvg, f);
+            fc = faceAverage(m, s, f);
         }
         const V3 cf = cC - fc;
         const double dp = dot(cf, eVec);
@@ -577,12 +589,12 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const 
         };
         const int fb = m.efOff[e], nf = m.efOff[e + 1] - fb;
         const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
-        const V3 first = project(ldv(s.fAvg, m.ringFace[fb]));
+        const V3 first = project(faceAverage(m, s, m.ringFace[fb]));
         V3 prev = first;
         mn = 2.0 * SMGPU_PI;
         mx = 0.0;
         for (int i = 0; i < nc; ++i) {
-            const V3 next = (i + 1 < nf) ? project(ldv(s.fAvg, m.ringFace[fb + i + 1])) : first;
+            const V3 next = (i + 1 < nf) ? project(faceAverage(m, s, m.ringFace[fb + i + 1])) : first;
             const V3 cV = project(ldv(s.cellCtr, m.ringCell[cb + i]));   // mesh.C()[cellI], SM.C:1218
             const double angle = clampAcos(dot(prev, cV)) + clampAcos(dot(cV, next));   // SM.C:980-998
             if (angle < mn) mn = angle;

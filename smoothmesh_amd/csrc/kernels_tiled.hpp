@@ -236,11 +236,13 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
     }
     L.fcx[i] = ctr.x; L.fcy[i] = ctr.y; L.fcz[i] = ctr.z;
     L.fax[i] = area.x; L.fay[i] = area.y; L.faz[i] = area.z;
-    if (wantAvg || writeFaces) {
+    if (wantAvg && s.avgPacked) stv(s.fAvg, b + i, fCentre);   // tile order: contiguous stores (the face-angle filter's
+                                                                // tiles hold positions into this order)
+    if ((wantAvg && !s.avgPacked) || writeFaces) {
         const int fid = g.tfIds[b + i];
         if (fid < 0) {   // this tile holds the face's owner cell: it publishes the per-face values
             const int f = fid & 0x7fffffff;
-            if (wantAvg) stv(s.fAvg, f, fCentre);
+            if (wantAvg && !s.avgPacked) stv(s.fAvg, f, fCentre);
             if (writeFaces) { stv(s.fCtr, f, ctr); stv(s.fArea, f, area); }
         }
     }

@@ -115,6 +115,7 @@ struct smgpu_handle {
     EdgeTiles etl;
     EdgeTileView ev{};
     bool edgeTilesOk = false;
+    size_t avgPackedCount = 0;   // > 0: fAvg is stored in geometry-tile order (State::avgPacked)
     size_t edgeLds = 0;
     bool eaCoop = true;        // wave-cooperative edge-angle kernel (SMGPU_EDGE_ANGLE=faithful selects the per-angle acos form)
     int eaMaxEntries = 0;
@@ -371,6 +372,15 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             if (h->useFilter) {
                 if (e3.empty()) {
                     EdgeTileView& ev = h->ev;
+                    // the filter reads the face averages where the geometry tiles store them: position of every face
+                    // in the face list of its owner's tile
+                    {
+                        std::vector<int32_t> facePos((size_t)t.nFaces, -1);
+                        for (size_t k = 0; k < h->gt.tfIds.size(); ++k)
+                            if (h->gt.tfIds[k] < 0) facePos[(size_t)(h->gt.tfIds[k] & 0x7fffffff)] = (int32_t)k;
+                        for (int32_t& f : h->etl.tfIds) f = facePos[(size_t)f];
+                        h->avgPackedCount = h->gt.tfIds.size();
+                    }
                     rc |= devUpload(h, &ev.order, h->etl.order);
                     rc |= devUpload(h, &ev.edgeBeg, h->etl.edgeBeg);
                     rc |= devUpload(h, &ev.tpOff, h->etl.tpOff);
@@ -422,7 +432,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.prop, 3 * P);
     rc |= devAlloc(h, &s.fCtr, 3 * F);
     rc |= devAlloc(h, &s.fArea, 3 * F);
-    rc |= devAlloc(h, &s.fAvg, 3 * F);
+    s.avgPacked = (h->useTiles && h->edgeTilesOk && h->avgPackedCount) ? 1 : 0;
+    rc |= devAlloc(h, &s.fAvg, 3 * (s.avgPacked ? h->avgPackedCount : F));
     rc |= devAlloc(h, &s.cellCtr, 3 * C);
     rc |= devAlloc(h, &s.frozen, P);
     rc |= devAlloc(h, &s.edgeMin, E);
