@@ -163,3 +163,66 @@ def test_golden_fixture(oracle_lib):
     n, res, frz = o2.iterate(20, 0.0)
     assert np.array_equal(frz, g["nFrozen"])
     assert np.allclose(res, g["residual"], rtol=1e-12, atol=0)
+
+
+# ---- geometry and angle formulas against independent analytic answers on affinely mapped lattices --------------------
+def _affine_block(n, A, b):
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(n, jitter=0.0)
+    ref = m.points.copy()
+    m.points = ref @ np.asarray(A, float).T + np.asarray(b, float)
+    return m, ref
+
+
+def test_face_and_cell_centres_of_parallelepipeds(oracle_lib):
+    """An affine map sends centroids to centroids: for a sheared/stretched lattice the OpenFOAM formulas
+    (area-weighted triangle fan per face, volume-weighted pyramids per cell) must give the images of the cube
+    lattice's face and cell centres, and face area vectors must follow the cofactor rule Sf' = det(A) A^-T Sf."""
+    A = np.array([[1.3, 0.4, -0.2], [0.1, 0.9, 0.5], [-0.3, 0.2, 1.1]])
+    b = np.array([2.0, -1.0, 0.5])
+    n = 4
+    m, ref = _affine_block(n, A, b)
+    from smoothmesh_amd.meshgen import hex_block
+    o_ref = oracle_lib.Oracle(hex_block(n, jitter=0.0)); o_ref.phaseA()
+    o = oracle_lib.Oracle(m); o.phaseA()
+    fc0, fa0, cc0 = (o_ref.field(k).reshape(-1, 3) for k in ("faceCentres", "faceAreas", "cellCentres"))
+    fc, fa, cc = (o.field(k).reshape(-1, 3) for k in ("faceCentres", "faceAreas", "cellCentres"))
+    assert np.max(np.abs(fc - (fc0 @ A.T + b))) < 1e-14
+    assert np.max(np.abs(cc - (cc0 @ A.T + b))) < 1e-14
+    cof = np.linalg.det(A) * np.linalg.inv(A).T
+    assert np.max(np.abs(fa - fa0 @ cof.T)) < 1e-15
+
+
+def test_centroid_of_a_wedge_cell(oracle_lib):
+    """triangular prism (extruded right triangle): cell centre = triangle centroid at mid height; the two triangle
+    faces take the 3-point shortcut of makeFaceCentresAndAreas, the three quads the fan"""
+    from smoothmesh_amd.meshgen import extrude_surface
+    v = np.array([[0.0, 0.0, 0.0], [3.0, 0.0, 0.0], [0.0, 0.0, 1.5]])
+    m = extrude_surface(v, [[0, 1, 2]], nLayers=1, thickness=2.0, direction=(0, 1, 0))
+    o = oracle_lib.Oracle(m, isInternalPoint=np.zeros(m.nPoints, np.uint8)); o.phaseA()
+    assert np.allclose(o.field("cellCentres").reshape(-1, 3), [[1.0, 1.0, 0.5]], rtol=0, atol=1e-15)
+    areas = np.linalg.norm(o.field("faceAreas").reshape(-1, 3), axis=1)
+    assert sorted(np.round(areas, 12)) == sorted(np.round([2.25, 2.25, 6.0, 3.0, 2.0 * math.hypot(3.0, 1.5)], 12))
+
+
+def test_face_angles_of_a_sheared_lattice(oracle_lib):
+    """cells around an interior edge of a lattice sheared by angle phi in the plane normal to the edge: the four
+    cell angles (SM.C:1135-1231: projected face-centre / cell-centre directions) are phi, pi-phi, phi, pi-phi"""
+    phi = math.radians(70.0)
+    A = np.array([[1.0, math.cos(phi), 0.0], [0.0, math.sin(phi), 0.0], [0.0, 0.0, 1.0]])   # y axis tilted towards x
+    m, ref = _affine_block(4, A, [0, 0, 0])
+    o, p = _oracle(oracle_lib, m)
+    o.phaseA(); o.phaseB()
+    emin, emax = o.field("edgeMinAngle"), o.field("edgeMaxAngle")
+    # interior z-edges: both end points strictly inside in x and y
+    ed = o.addressing("edges")[1]
+    r0, r1 = ref[ed[:, 0]], ref[ed[:, 1]]
+    zdir = (np.abs(r0[:, 0] - r1[:, 0]) < 1e-12) & (np.abs(r0[:, 1] - r1[:, 1]) < 1e-12)
+    inside = (r0[:, 0] > 0.1) & (r0[:, 0] < 0.9) & (r0[:, 1] > 0.1) & (r0[:, 1] < 0.9)
+    sel = zdir & inside
+    assert sel.sum() == 3 * 3 * 4
+    assert np.allclose(emin[sel], phi, rtol=0, atol=1e-13) and np.allclose(emax[sel], math.pi - phi, rtol=0, atol=1e-13)
+    # edges along x are not sheared in their normal plane... y-z stays orthogonal only for x-edges: pi/2 there
+    xdir = (np.abs(r0[:, 1] - r1[:, 1]) < 1e-12) & (np.abs(r0[:, 2] - r1[:, 2]) < 1e-12)
+    insx = (r0[:, 1] > 0.1) & (r0[:, 1] < 0.9) & (r0[:, 2] > 0.1) & (r0[:, 2] < 0.9)
+    assert np.allclose(emin[xdir & insx], math.pi / 2, atol=1e-13) and np.allclose(emax[xdir & insx], math.pi / 2, atol=1e-13)
