@@ -101,6 +101,37 @@ def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
     _compare(cavity_mesh(16, jitter=0.2, seed=3), oracle_lib, iters=3)
 
 
+@pytest.mark.parametrize("case", ["coincident", "collapsed_cell", "inverted"])
+@pytest.mark.parametrize("constraints", [False, True])
+def test_degenerate_geometry_matches_the_oracle(oracle_lib, case, constraints):
+    """zero-length edges (NaN cosines -> clamp rule SM.C:781), a zero-volume cell (|V| <= VSMALL -> face-centre average),
+    inverted cells: the same special-case branches on both sides, the same bits out"""
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(6, 5, 4, jitter=0.2, seed=3)
+    P, n1 = m.points, 7
+    p = (n1 * 6) * 2 + n1 * 3 + 3                  # an interior point
+    if case == "coincident":
+        P[p] = P[p + 1]
+    elif case == "collapsed_cell":
+        for q in (p, p + 1, p + n1, p + n1 + 1):
+            P[q] = P[q + n1 * 6]
+    else:
+        P[p] = P[p] + (P[p + 1] - P[p]) * 1.7
+    o = oracle_lib.Oracle(m)
+    e = SmoothEngine(m)
+    mn = o.mesh_stats()[0]
+    assert mn == e.mesh_stats()[0]
+    prm = default_params(max(mn, 1e-3), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    o.set_params(prm); e.set_params(prm)
+    n_o, res_o, frz_o = o.iterate(4, 0.0)
+    n_g, res_g, frz_g = e.iterate(4, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    a, b = e.get_points(), o.points()
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    assert np.array_equal(a[~np.isnan(b)], b[~np.isnan(b)])
+
+
 def test_counters_and_sizes(oracle_lib):
     from smoothmesh_amd import SmoothEngine, default_params
     from smoothmesh_amd.meshgen import hex_block
