@@ -21,6 +21,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(l, name), f"libsmgpu.so does not export {name}"
     assert declared == set(_ffi.SYMBOLS), (declared ^ set(_ffi.SYMBOLS))
     assert b"gfx950" in _ffi.lib().smgpu_version()
+    # include/smhost.h (polyMesh I/O, mesh generator) against libsmhost.so
+    from smoothmesh_amd import polymesh
+    hdr2 = open(os.path.join(ROOT, "include", "smhost.h")).read()
+    declared2 = set(re.findall(r"\b(smhost_[a-z_]+)\s*\(", hdr2))
+    assert len(declared2) >= 10
+    l2 = ctypes.CDLL(polymesh.LIB_PATH)
+    for name in declared2:
+        assert hasattr(l2, name), f"libsmhost.so does not export {name}"
 
 
 @pytest.mark.parametrize("dims,jit", [((5, 4, 3), 0.2), ((2, 2, 2), 0.0), ((7, 1, 2), 0.1)])
