@@ -255,5 +255,26 @@ void orc_get_layer_fields(void* h, int* hops, int* outerMap, double* normals, un
     }
 }
 
+// MultiDomain variant: patches of all domains concatenated, nPatches[d] per domain
+void orc_multi_setup_layers(void* mh, const int* nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
+                            double layerMaxBlendingFraction, double layerEdgeLength, double layerExpansionRatio, int minLayers,
+                            int maxLayers) {
+    MultiDomain* m = static_cast<MultiDomain*>(mh);
+    std::vector<std::vector<Patch>> p(m->dom.size());
+    int k = 0;
+    for (size_t d = 0; d < m->dom.size(); ++d)
+        for (int i = 0; i < nPatches[d]; ++i, ++k) {
+            Patch q; q.start = start[k]; q.size = size[k]; q.kind = kind[k]; q.isLayerPatch = isLayer[k] != 0;
+            p[d].push_back(q);
+        }
+    LayerParams lp;
+    lp.layerMaxBlendingFraction = layerMaxBlendingFraction;
+    lp.layerEdgeLength = layerEdgeLength;
+    lp.layerExpansionRatio = layerExpansionRatio;
+    lp.minLayers = minLayers;
+    lp.maxLayers = maxLayers;
+    m->setupLayers(p, lp);
+}
+
 }  // extern "C"
 

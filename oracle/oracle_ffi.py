@@ -61,6 +61,7 @@ def lib():
         l.orc_halo_orF.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]
         l.orc_local_stats.argtypes = [C.c_void_p, f64p]
         l.orc_setup_layers.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        l.orc_multi_setup_layers.argtypes = [C.c_void_p, i32p, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         l.orc_layers_enabled.restype = C.c_int
         l.orc_layers_enabled.argtypes = [C.c_void_p]
         l.orc_get_layer_fields.argtypes = [C.c_void_p, i32p, i32p, f64p, u8p, u8p]
@@ -245,6 +246,17 @@ class MultiOracle:
         sd = np.ascontiguousarray(sharedDomain, np.int32)
         sl = np.ascontiguousarray(sharedLocal, np.int32)
         self._lib.orc_multi_set_shared(self._h, len(so) - 1, _p(so, i32p), _p(sd, i32p), _p(sl, i32p))
+
+    def setup_layers(self, patch_arrays_per_domain, layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers,
+                     maxLayers):
+        """boundary layer treatment under -parallel (set-up SM.C:2215-2221 with its syncPointList calls);
+        patch_arrays_per_domain[d] = (start, size, kind, isLayer) of domain d; returns doLayerTreatment"""
+        npd = np.array([len(a[0]) for a in patch_arrays_per_domain], np.int32)
+        cat = lambda k, t: np.ascontiguousarray(np.concatenate([np.asarray(a[k]) for a in patch_arrays_per_domain]), t)
+        st, sz, kd, il = cat(0, np.int32), cat(1, np.int32), cat(2, np.int32), cat(3, np.uint8)
+        self._lib.orc_multi_setup_layers(self._h, _p(npd, i32p), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p),
+                                         layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers)
+        return bool(self._lib.orc_layers_enabled(self._oracles[0]._h))
 
     def iterate(self, nIters, relTol=0.02):
         res = np.zeros(max(nIters, 1), np.float64)

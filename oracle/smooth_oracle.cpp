@@ -321,8 +321,8 @@ static inline Vec3& operator-=(Vec3& a, const Vec3& b) { a.x -= b.x; a.y -= b.y;
 // OBB.C:141-233.  Note the reference never resets pointNormals: a boundary point's new normal is the
 // normalised sum of its previous (unit) normal and the inverted unit normals of its boundary faces, and every
 // non-zero normal (also the ones copied to internal points) is divided by its magnitude again on every call.
-void Domain::calculateBoundaryPointNormals() {
-    std::vector<int> nFaces(nPoints, 0);
+void Domain::layersNormalsAccumulate() {
+    layerNFaces.assign(nPoints, 0);
     for (const Patch& pp : patches) {
         if (pp.kind == 1) continue;   // processor
         if (pp.kind == 2) continue;   // empty
@@ -331,12 +331,14 @@ void Domain::calculateBoundaryPointNormals() {
             const Vec3 Sf = cSf / mag(cSf);                        // / magSf (= mag(Sf))
             for (int pointI : faces[pp.start + faceI]) {
                 pointNormals[pointI] -= Sf;
-                ++nFaces[pointI];
+                ++layerNFaces[pointI];
             }
         }
     }
+}
+void Domain::layersNormalsFinish() {
     for (int pointI = 0; pointI < nPoints; ++pointI) {
-        if (nFaces[pointI] < 1) continue;
+        if (layerNFaces[pointI] < 1) continue;
         const double magNorm = mag(pointNormals[pointI]);
         if (magNorm < 0.1) { pointNormals[pointI] = ZERO_VECTOR; isSharpEdgePoint[pointI] = 1; }
         else isSharpEdgePoint[pointI] = 0;
@@ -344,8 +346,12 @@ void Domain::calculateBoundaryPointNormals() {
     for (int pointI = 0; pointI < nPoints; ++pointI)
         if (pointNormals[pointI] != ZERO_VECTOR) pointNormals[pointI] /= mag(pointNormals[pointI]);
 }
+void Domain::calculateBoundaryPointNormals() {
+    layersNormalsAccumulate();
+    layersNormalsFinish();
+}
 
-void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
+void Domain::layersBegin(const std::vector<Patch>& p, const LayerParams& lp) {
     patches = p;
     lay = lp;
     bool anyLayer = false;
@@ -359,7 +365,12 @@ void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
     isConnectedToInternalPoint.assign(nPoints, 0);
     isLayerSurfacePoint.assign(nPoints, 0);
     isSharpEdgePoint.assign(nPoints, 0);
-    if (!doLayerTreatment) return;
+    layerNewHopCounts.assign(nPoints, -1);
+    layerNFaces.assign(nPoints, 0);
+    // boundaryPointLabels[q] = outer neighbour of q (OBB.C:258); the reference looks a label up with findIndex
+    // (lowest q holding it).  All points that map to the same neighbour have the same hop count, so they are met
+    // in one sweep in ascending order and the first one recorded IS the lowest: firstMapper replaces the O(P) scan.
+    layerFirstMapper.assign(nPoints, -1);
     updateGeometry();
 
     // classifyBoundaryPoints BPS.C:296-340, 397-403: every point is classified by the first patch it is met on
@@ -374,61 +385,55 @@ void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
                     if (isInternalPoint[i]) isConnectedToInternalPoint[pointI] = 1;
                 if (pp.isLayerPatch) isLayerSurfacePoint[pointI] = 1;
             }
-
-    // calculatePointHopsToBoundary OBB.C:52-133 with maxIter = maxLayers + 1 (SM.C:2217)
-    const int maxIter = lay.maxLayers + 1;
-    std::vector<int>& hops = pointHopsToLayerBoundary;
+    // calculatePointHopsToBoundary OBB.C:62-79: zero hops on the layer patches
     for (const Patch& pp : patches) {
         if (!pp.isLayerPatch) continue;
         for (int faceI = pp.start; faceI < pp.start + pp.size; ++faceI)   // getPatchPointIndices OBB.C:22-46
             for (int patchPointI : faces[faceI])
-                if (isConnectedToInternalPoint[patchPointI]) hops[patchPointI] = 0;
+                if (isConnectedToInternalPoint[patchPointI]) pointHopsToLayerBoundary[patchPointI] = 0;
     }
-    std::vector<int> newHopCounts(nPoints, -1);
-    for (int iter = 0; iter < maxIter; ++iter) {
-        for (int pointI = 0; pointI < nPoints; ++pointI) {
-            if (hops[pointI] >= 0) continue;
-            if (!isInternalPoint[pointI]) continue;
-            int maxHops = -1;
-            for (int neighI : pointPoints[pointI])
-                if (hops[neighI] > maxHops) maxHops = hops[neighI];
-            if (maxHops >= 0) newHopCounts[pointI] = maxHops + 1;
-        }
-        for (int pointI = 0; pointI < nPoints; ++pointI)
-            if (newHopCounts[pointI] > hops[pointI]) hops[pointI] = newHopCounts[pointI];
+}
+
+void Domain::layersHopsSweep() {
+    std::vector<int>& hops = pointHopsToLayerBoundary;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (hops[pointI] >= 0) continue;
+        if (!isInternalPoint[pointI]) continue;
+        int maxHops = -1;
+        for (int neighI : pointPoints[pointI])
+            if (hops[neighI] > maxHops) maxHops = hops[neighI];
+        if (maxHops >= 0) layerNewHopCounts[pointI] = maxHops + 1;
     }
+    for (int pointI = 0; pointI < nPoints; ++pointI)
+        if (layerNewHopCounts[pointI] > hops[pointI]) hops[pointI] = layerNewHopCounts[pointI];
+}
 
-    calculateBoundaryPointNormals();   // SM.C:2219
-
-    // propagateOuterNeighInfo OBB.C:244-391
-    // boundaryPointLabels[q] = outer neighbour of q (OBB.C:258); the reference looks a label up with findIndex
-    // (lowest q holding it).  All points that map to the same neighbour have the same hop count, so they are met
-    // in one sweep in ascending order and the first one recorded IS the lowest: firstMapper replaces the O(P) scan.
-    std::vector<int> firstMapper(nPoints, -1);
-    for (int iter = 1; iter < maxIter + 1; ++iter) {
-        for (int pointI = 0; pointI < nPoints; ++pointI) {
-            const int nHops = hops[pointI];
-            if (nHops != iter) continue;
-            int nNeighHops = 0;
-            int neighPointI = -1;
-            for (int neighI : pointPoints[pointI])
-                if (hops[neighI] == (nHops - 1)) { ++nNeighHops; neighPointI = neighI; }
-            if (nNeighHops == 1) {
-                if ((!isInternalPoint[neighPointI]) && (!isLayerSurfacePoint[neighPointI])) continue;
-                // findIndex(boundaryPointLabels, neighPointI): the lowest point label already mapped to it
-                const int prevPointI = firstMapper[neighPointI];
-                if (prevPointI >= 0) {
-                    pointNormals[pointI] = UNDEF_VECTOR;
-                    pointNormals[prevPointI] = UNDEF_VECTOR;
-                    continue;
-                }
-                isOuterNeighInProc[pointI] = 1;
-                pointToOuterPointMap[pointI] = neighPointI;
-                pointNormals[pointI] = pointNormals[neighPointI];
-                firstMapper[neighPointI] = pointI;
+void Domain::layersPropagateSweep(int iter) {
+    const std::vector<int>& hops = pointHopsToLayerBoundary;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        const int nHops = hops[pointI];
+        if (nHops != iter) continue;
+        int nNeighHops = 0;
+        int neighPointI = -1;
+        for (int neighI : pointPoints[pointI])
+            if (hops[neighI] == (nHops - 1)) { ++nNeighHops; neighPointI = neighI; }
+        if (nNeighHops == 1) {
+            if ((!isInternalPoint[neighPointI]) && (!isLayerSurfacePoint[neighPointI])) continue;
+            const int prevPointI = layerFirstMapper[neighPointI];   // findIndex(boundaryPointLabels, neighPointI)
+            if (prevPointI >= 0) {
+                pointNormals[pointI] = UNDEF_VECTOR;
+                pointNormals[prevPointI] = UNDEF_VECTOR;
+                continue;
             }
+            isOuterNeighInProc[pointI] = 1;
+            pointToOuterPointMap[pointI] = neighPointI;
+            pointNormals[pointI] = pointNormals[neighPointI];
+            layerFirstMapper[neighPointI] = pointI;
         }
     }
+}
+
+void Domain::layersUndo() {
     for (int pointI = 0; pointI < nPoints; ++pointI)
         if (pointNormals[pointI] == UNDEF_VECTOR) {
             pointNormals[pointI] = ZERO_VECTOR;
@@ -437,13 +442,33 @@ void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
         }
 }
 
+void Domain::layersUpdateNeighCoords() {
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (!isOuterNeighInProc[pointI]) { outerNeighCoords[pointI] = UNDEF_VECTOR; continue; }
+        const int neighI = pointToOuterPointMap[pointI];
+        if (neighI < 0) { error = "Sanity broken, neighI does not exist for pointI"; return; }
+        outerNeighCoords[pointI] = points[neighI];
+    }
+}
+
+// serial set-up, SM.C:2215-2221
+void Domain::setupLayers(const std::vector<Patch>& p, const LayerParams& lp) {
+    layersBegin(p, lp);
+    if (!doLayerTreatment) return;
+    const int maxIter = lay.maxLayers + 1;                                   // SM.C:2217
+    for (int iter = 0; iter < maxIter; ++iter) layersHopsSweep();            // OBB.C:83-131
+    calculateBoundaryPointNormals();                                         // SM.C:2219
+    for (int iter = 1; iter < maxIter + 1; ++iter) layersPropagateSweep(iter);   // OBB.C:274-366
+    layersUndo();
+}
+
 void Domain::phaseA() {
     // SM.C:2262 reset frozen points
     isFrozenPoint.assign(nPoints, 0);
     updateGeometry();
     // SM.C:2266 "Recalculate point normals" (the reference does it whether or not a treatment is enabled;
     // the normals are only consumed by the layer treatment here)
-    if (doLayerTreatment) calculateBoundaryPointNormals();
+    if (doLayerTreatment) layersNormalsAccumulate();   // MultiDomain::syncLayers follows (OBB.C:184-198); finish in phaseB
 
     // SM.C:108-131 (doBoundarySmoothing == false: internal points only)
     cellSum.assign(nPoints, ZERO_VECTOR);
@@ -486,6 +511,8 @@ void Domain::phaseA() {
         else closest3[pointI] = points[pp[cLabel3]] - cCoords;
         hasCommonCell[pointI] = (findIndex(pointNeighPoints[pp[cLabel1]], pp[cLabel2]) >= 0) ? 1 : 0;
     }
+    // the rank-local part of updateNeighCoords (SM.C:2286): it only needs the current coordinates
+    if (doLayerTreatment) layersUpdateNeighCoords();
 }
 
 // SM.C:1135-1231 (with calcFaceCenter :1103-1130, findCellFacePair :1042-1097,
@@ -570,6 +597,7 @@ void Domain::calcMinMaxFaceAngleForPoint(int pointI1, const Vec3& coords1, int p
 
 void Domain::phaseB() {
     const std::vector<Vec3>& mp = points;
+    if (doLayerTreatment) layersNormalsFinish();   // OBB.C:201-230, after the plusEq syncs
 
     // SM.C:150-163
     centroidalPoints = points;
@@ -600,15 +628,9 @@ void Domain::phaseB() {
         newPoints[pointI] = nCoords;
     }
 
-    // SM.C:2283-2305 optional boundary layer treatment
+    // SM.C:2283-2305 optional boundary layer treatment (updateNeighCoords OBB.C:464-500: its local part ran at the
+    // end of phaseA, MultiDomain::syncLayers did the minMagSqr sync)
     if (doLayerTreatment) {
-        // updateNeighCoords OBB.C:464-500 (serial: the minMagSqr sync is the identity)
-        for (int pointI = 0; pointI < nPoints; ++pointI) {
-            if (!isOuterNeighInProc[pointI]) { outerNeighCoords[pointI] = UNDEF_VECTOR; continue; }
-            const int neighI = pointToOuterPointMap[pointI];
-            if (neighI < 0) { error = "Sanity broken, neighI does not exist for pointI"; return; }
-            outerNeighCoords[pointI] = mp[neighI];
-        }
         // blendWithOrthogonalPoints OBB.C:507-567, called with maxLayers + 1 (SM.C:2299)
         const double layerMaxBlendingFraction = lay.layerMaxBlendingFraction;
         const double minLayers = lay.minLayers;
@@ -897,11 +919,90 @@ void MultiDomain::syncFrozen() {  // SM.C:2374-2380
     }
 }
 
+// syncPointList(maxMagSqrEqOp / minMagSqrEqOp) for one shared point: every sharer folds the others' values onto its
+// own in ascending rank order; a tie keeps what it has (x = (magSqr(x) >= magSqr(y)) ? x : y)
+static void foldMagSqr(std::vector<Vec3>& v, bool takeMax) {
+    const int n = int(v.size());
+    const std::vector<Vec3> sent(v);
+    for (int self = 0; self < n; ++self) {
+        Vec3 x = sent[self];
+        for (int k = 0; k < n; ++k) {
+            if (k == self) continue;
+            const bool keep = takeMax ? (magSqr(x) >= magSqr(sent[k])) : (magSqr(x) <= magSqr(sent[k]));
+            x = keep ? x : sent[k];
+        }
+        v[self] = x;
+    }
+}
+
+// OBB.C:184-198 plusEq syncs of calculateBoundaryPointNormals (sums in ascending rank order, as syncA does for the
+// cell sums) and OBB.C:490-496 minMagSqr sync of updateNeighCoords
+void MultiDomain::syncLayers() {
+    if (dom.empty() || !dom[0]->doLayerTreatment) return;
+    for (const SharedPoint& sp : shared) {
+        const int n = int(sp.domain.size());
+        Vec3 s = ZERO_VECTOR;
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) {
+            s += dom[sp.domain[j]]->pointNormals[sp.local[j]];
+            cnt += dom[sp.domain[j]]->layerNFaces[sp.local[j]];
+        }
+        std::vector<Vec3> nc(n);
+        for (int j = 0; j < n; ++j) {
+            dom[sp.domain[j]]->pointNormals[sp.local[j]] = s;
+            dom[sp.domain[j]]->layerNFaces[sp.local[j]] = cnt;
+            nc[j] = dom[sp.domain[j]]->outerNeighCoords[sp.local[j]];
+        }
+        foldMagSqr(nc, false);
+        for (int j = 0; j < n; ++j) dom[sp.domain[j]]->outerNeighCoords[sp.local[j]] = nc[j];
+    }
+}
+
+// SM.C:2215-2221 with the syncPointList calls of OBB.C:124-130 (maxEq), :184-198 (plusEq), :359-365 (maxMagSqr)
+void MultiDomain::setupLayers(const std::vector<std::vector<Patch>>& p, const LayerParams& lp) {
+    for (size_t d = 0; d < dom.size(); ++d) dom[d]->layersBegin(p[d], lp);
+    if (dom.empty() || !dom[0]->doLayerTreatment) return;
+    const int maxIter = lp.maxLayers + 1;
+    for (int iter = 0; iter < maxIter; ++iter) {
+        for (Domain* d : dom) d->layersHopsSweep();
+        for (const SharedPoint& sp : shared) {
+            int m = -1;
+            for (size_t j = 0; j < sp.domain.size(); ++j) m = std::max(m, dom[sp.domain[j]]->pointHopsToLayerBoundary[sp.local[j]]);
+            for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->pointHopsToLayerBoundary[sp.local[j]] = m;
+        }
+    }
+    for (Domain* d : dom) d->layersNormalsAccumulate();
+    for (const SharedPoint& sp : shared) {
+        Vec3 s = ZERO_VECTOR;
+        int cnt = 0;
+        for (size_t j = 0; j < sp.domain.size(); ++j) {
+            s += dom[sp.domain[j]]->pointNormals[sp.local[j]];
+            cnt += dom[sp.domain[j]]->layerNFaces[sp.local[j]];
+        }
+        for (size_t j = 0; j < sp.domain.size(); ++j) {
+            dom[sp.domain[j]]->pointNormals[sp.local[j]] = s;
+            dom[sp.domain[j]]->layerNFaces[sp.local[j]] = cnt;
+        }
+    }
+    for (Domain* d : dom) d->layersNormalsFinish();
+    for (int iter = 1; iter < maxIter + 1; ++iter) {
+        for (Domain* d : dom) d->layersPropagateSweep(iter);
+        for (const SharedPoint& sp : shared) {
+            std::vector<Vec3> v(sp.domain.size());
+            for (size_t j = 0; j < sp.domain.size(); ++j) v[j] = dom[sp.domain[j]]->pointNormals[sp.local[j]];
+            foldMagSqr(v, true);
+            for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->pointNormals[sp.local[j]] = v[j];
+        }
+    }
+    for (Domain* d : dom) d->layersUndo();
+}
+
 int MultiDomain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) {
     int done = 0;
     for (int i = 0; i < nIters; ++i) {
         for (Domain* d : dom) { d->phaseA(); if (!d->error.empty()) return -1; }
         syncA();
+        syncLayers();
         for (Domain* d : dom) { d->phaseB(); if (!d->error.empty()) return -1; }
         syncFrozen();
         double res = 0.0;

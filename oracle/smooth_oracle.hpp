@@ -110,6 +110,15 @@ public:
     std::vector<Vec3> pointNormals, outerNeighCoords;
     void setupLayers(const std::vector<Patch>& p, const LayerParams& lp);
     void calculateBoundaryPointNormals();   // OBB.C:141-233 (uses the current faceAreas)
+    // the same in steps, so that MultiDomain can put the reference's syncPointList calls between them
+    std::vector<int> layerNewHopCounts, layerNFaces, layerFirstMapper;
+    void layersBegin(const std::vector<Patch>& p, const LayerParams& lp);  // SM.C:1983-2028, BPS.C:296-403, OBB.C:62-79
+    void layersHopsSweep();                 // OBB.C:85-121 (one sweep, before the maxEq sync :124-130)
+    void layersNormalsAccumulate();         // OBB.C:150-181 (before the plusEq syncs :184-198)
+    void layersNormalsFinish();             // OBB.C:201-230
+    void layersPropagateSweep(int iter);    // OBB.C:276-353 (one sweep, before the maxMagSqr sync :359-365)
+    void layersUndo();                      // OBB.C:370-379
+    void layersUpdateNeighCoords();         // OBB.C:471-486 (before the minMagSqr sync :490-496)
 
     void build();  // addressing from faces/owner/neighbour
     void meshStats(double& minEdge, double& maxEdge) const;  // SM.C:1478-1541
@@ -145,6 +154,9 @@ public:
     int iterate(int nIters, double relTol, double* residuals, int* nFrozen);
     void syncA();
     void syncFrozen();
+    // boundary layer treatment under -parallel: the set-up with its syncs, and the two per-iteration syncs
+    void setupLayers(const std::vector<std::vector<Patch>>& p, const LayerParams& lp);
+    void syncLayers();   // plusEq of normals / face counts (OBB.C:184-198), minMagSqr of neighbour coordinates (:490-496)
 };
 
 double edgeEdgeAngle(const Vec3& c, const Vec3& p1, const Vec3& p2);   // SM.C:766-786

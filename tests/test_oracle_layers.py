@@ -124,3 +124,82 @@ def test_multiply_connected_boundary_points_are_left_out(oracle_lib):
     assert ((f["hops"] >= 1) & ~mapped).any()
     n, res, frz = o.iterate(3, 0.0)
     assert n == 3 and np.all(np.isfinite(res))
+
+
+# ---- under -parallel: MultiDomain with the reference's syncPointList calls (OBB.C:124-130, 184-198, 359-365, 490-496) --------
+def _multi(oracle_lib, subs, layerPatches, **kw):
+    from smoothmesh_amd import default_params, patch_arrays
+    from smoothmesh_amd.decompose import shared_point_table
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    mn = min(o.mesh_stats()[0] for o in orcs)
+    prm = default_params(mn, edgeAngleConstraint=kw.get("constraints", False), faceAngleConstraint=kw.get("constraints", False))
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    on = mo.setup_layers([patch_arrays(s.mesh, layerPatches) for s in subs], kw.get("blend", 0.3), kw.get("edge", prm.minEdgeLength),
+                         kw.get("ratio", 1.3), 1, kw.get("maxLayers", 4))
+    return mo, orcs, prm, on
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (1, 2, 1), (2, 2, 1)])
+def test_decomposed_uniform_block_has_the_serial_layer_fields(oracle_lib, grid):
+    """hop counts cross processor boundaries through the maxEq sync, normals through the maxMagSqr sync: on a
+    uniform block every rank ends up with the values of the undecomposed mesh at its points"""
+    from smoothmesh_amd.meshgen import hex_block, hex_subdomain
+    nloc = (4, 4, 4)
+    world = grid[0] * grid[1] * grid[2]
+    subs = [hex_subdomain(nloc, grid, r, jitter=0.0) for r in range(world)]
+    mo, orcs, prm, on = _multi(oracle_lib, subs, ["xmin"], maxLayers=5)
+    assert on
+    whole = hex_block(nloc[0] * grid[0], nloc[1] * grid[1], nloc[2] * grid[2], jitter=0.0)
+    o, _, on1 = _setup(oracle_lib, whole, ["xmin"], maxLayers=5)
+    ref = o.layer_fields()
+    for s, oo in zip(subs, orcs):
+        f = oo.layer_fields()
+        g = s.pointProcAddressing
+        assert np.array_equal(f["hops"], ref["hops"][g])
+        assert np.array_equal(f["normals"], ref["normals"][g])
+        # the outer neighbour is rank-local information: where a rank has one, it is the serial one
+        has = f["outerMap"] >= 0
+        assert np.array_equal(g[f["outerMap"][has]], ref["outerMap"][g][has])
+
+
+def test_decomposed_uniform_layers_are_a_fixed_point(oracle_lib):
+    """layers of one patch crossing a processor boundary (hop 5 lies in the second rank): with ratio 1 and
+    layerEdgeLength = spacing nothing moves.  (With two interacting layer patches a point shared by four ranks can
+    hang on different neighbours on different ranks -- rank-local views, OBB.C:292-300 -- and then does move: the
+    reference's result depends on the decomposition there.)"""
+    from smoothmesh_amd.meshgen import hex_subdomain
+    subs = [hex_subdomain((4, 4, 4), (2, 2, 1), r, jitter=0.0) for r in range(4)]       # spacing 1/4: exact
+    mo, orcs, prm, on = _multi(oracle_lib, subs, ["xmin"], edge=0.25, ratio=1.0)
+    f1 = orcs[1].layer_fields()
+    assert on and f1["hops"].max() == 5 and (f1["outerMap"] >= 0).any()
+    n, res, frz = mo.iterate(3, 0.0)
+    assert np.all(res == 0.0)
+    for s, o in zip(subs, orcs):
+        assert np.array_equal(o.points(), s.mesh.points)
+
+
+def test_shared_points_stay_identical_with_layers(oracle_lib):
+    """jittered decomposed block, layers across the processor boundary: after the syncs every sharer of a point
+    holds the same coordinates, iteration after iteration; one domain alone reproduces the serial run"""
+    from smoothmesh_amd.meshgen import hex_subdomain
+    grid = (2, 2, 1)
+    subs = [hex_subdomain((5, 4, 4), grid, r, jitter=0.25, seed=4) for r in range(4)]
+    mo, orcs, prm, on = _multi(oracle_lib, subs, ["xmin", "zmax"], ratio=1.2)
+    assert on
+    n, res, frz = mo.iterate(6, 0.0)
+    g = np.concatenate([s.pointProcAddressing for s in subs])
+    allp = np.concatenate([o.points() for o in orcs])
+    order = np.argsort(g, kind="stable")
+    gs, ps = g[order], allp[order]
+    same = gs[1:] == gs[:-1]
+    assert same.any() and np.array_equal(ps[1:][same], ps[:-1][same])
+    # world size 1 == serial
+    one = [hex_subdomain((5, 4, 4), (1, 1, 1), 0, jitter=0.25, seed=4)]
+    mo1, orcs1, prm1, _ = _multi(oracle_lib, one, ["xmin", "zmax"], ratio=1.2)
+    mo1.iterate(6, 0.0)
+    o, _, _ = _setup(oracle_lib, one[0].mesh, ["xmin", "zmax"], ratio=1.2)
+    o.iterate(6, 0.0)
+    assert np.array_equal(orcs1[0].points(), o.points())
