@@ -130,6 +130,8 @@ typedef struct smgpu_halo_desc {
     void* sendA; void* recvA;     /* device, nSend / nRecv records of 13 doubles              */
     void* sendF; void* recvF;     /* device, nSend / nRecv int32                              */
     void* localStats;             /* device, 2 doubles {residual, nFrozenPoints} per iteration */
+    void* sendL; void* recvL;     /* device, nSend / nRecv records of 6 doubles; only used with the boundary layer
+                                     treatment (may be NULL otherwise), exchanged together with sendA / recvA  */
     int32_t useExchangeStream;    /* 0: the host enqueues its exchanges on the engine's stream (in order).       */
     void* exchangeStream;         /* 1: the host enqueues them on THIS hipStream_t (NULL = the null stream); the
                                      engine orders its own stream against it with events inside
@@ -169,6 +171,28 @@ typedef struct smgpu_layer_desc {
     int32_t minLayers, maxLayers;      /* SM.C:1901-1905, defaults 1 and 4                      */
 } smgpu_layer_desc;
 int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled);
+
+/* The same set-up in steps, for runs with a halo (-parallel): between the steps the host performs the reference's
+ * syncTools::syncPointList calls over the shared points (values in the order of smgpu_halo_desc.sharedLocal, exchanged
+ * and combined by the host like exchange A).  Sequence (SM.C:2215-2221):
+ *   smgpu_layers_begin                                         -> *maxIter = maxLayers + 1
+ *   maxIter x { step HOPS_SWEEP;  get HOPS, combine with max over the sharers (OBB.C:124-130), set HOPS }
+ *   step NORMALS_ACCUMULATE;  get NORMALS_COUNT, sum over the sharers in ascending rank order (OBB.C:184-198), set
+ *   step NORMALS_FINISH
+ *   for iter = 1..maxIter { step PROPAGATE_SWEEP(iter);  get NORMALS, every sharer folds the others' values onto its own
+ *                           in ascending rank order keeping the larger magnitude, ties keep (OBB.C:359-365), set }
+ *   step FINISH
+ * Every later iteration additionally exchanges 6 doubles per shared point (smgpu_halo_desc.sendL / recvL: the local
+ * normal and the outer neighbour's coordinates; plusEq OBB.C:184-198 and minMagSqr OBB.C:490-496) next to exchange A. */
+enum { SMGPU_LAYERS_HOPS_SWEEP = 0, SMGPU_LAYERS_NORMALS_ACCUMULATE = 1, SMGPU_LAYERS_NORMALS_FINISH = 2,
+       SMGPU_LAYERS_PROPAGATE_SWEEP = 3, SMGPU_LAYERS_FINISH = 4 };
+enum { SMGPU_LAYERS_F_HOPS = 0,            /* 1 double per shared point (the hop count or -1)        */
+       SMGPU_LAYERS_F_NORMALS_COUNT = 1,   /* 4 doubles: normal, number of boundary faces            */
+       SMGPU_LAYERS_F_NORMALS = 2 };       /* 3 doubles: normal                                      */
+#define SMGPU_HALO_L_DOUBLES 6
+int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled, int32_t* maxIter);
+int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg);
+int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);
 
 /* ---- debug / parity access (device -> host copy of an internal field) -----------------------
  * name: "cellCentres" [3C], "faceCentres" [3F], "faceAreas" [3F], "newPoints" [3P] (proposal of the

@@ -53,7 +53,8 @@ class HaloDesc(C.Structure):
         ("nShared", C.c_int32), ("sharedLocal", c_i32p), ("nSend", C.c_int32), ("sendShared", c_i32p),
         ("nRecv", C.c_int32), ("combOffsets", c_i32p), ("combSlots", c_i32p),
         ("sendA", C.c_void_p), ("recvA", C.c_void_p), ("sendF", C.c_void_p), ("recvF", C.c_void_p),
-        ("localStats", C.c_void_p), ("useExchangeStream", C.c_int32), ("exchangeStream", C.c_void_p),
+        ("localStats", C.c_void_p), ("sendL", C.c_void_p), ("recvL", C.c_void_p),
+        ("useExchangeStream", C.c_int32), ("exchangeStream", C.c_void_p),
     ]
 
 
@@ -86,6 +87,9 @@ SYMBOLS = {
     "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
     "smgpu_iter_ahead": (C.c_int, [C.c_void_p]),
     "smgpu_set_layers": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p]),
+    "smgpu_layers_begin": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p, c_i32p]),
+    "smgpu_layers_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "smgpu_layers_shared": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_f64p]),
     "smgpu_halo_set_exchange_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "smgpu_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),

@@ -61,6 +61,8 @@ struct State {
     // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
     // outer neighbour; per hop count the target edge length and the blending fraction
     double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
+    const double* combL;       // multi-rank + layers: per shared point the summed normals and the combined outer
+                               // neighbour coordinates (6 doubles), or NULL
 };
 
 struct Prm {
@@ -271,15 +273,18 @@ __device__ __forceinline__ void blockPublish(const State& s, double dist, int fr
 //  * updateNeighCoords OBB.C:464-500: the outer neighbour's CURRENT coordinates;
 //  * blendWithOrthogonalPoints OBB.C:507-567, with the hop-count functions tabulated by the host (layers.cpp);
 //  * constrainMaxStepLength once more, for every point (SM.C:2304).
+// Under -parallel a shared point takes the plusEq-synchronised normal (the sum over its sharers, OBB.C:184-190) and the
+// minMagSqr-synchronised neighbour coordinates (OBB.C:490-496) from combL instead of its local values.
 __device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, bool internal, const V3& cur, V3 np) {
-    V3 n = ldv(s.layerNormal, p);
+    const int slot = (s.combL && s.sharedSlot) ? s.sharedSlot[p] : -1;
+    V3 n = (slot >= 0) ? ldv(s.combL, 2 * slot) : ldv(s.layerNormal, p);
     const V3 z = v3(0, 0, 0);
     if (n != z) {
         n = n / mag(n);
         stv(s.layerNormal, p, n);
         const int hops = s.layerHops[p];
         if (internal && hops >= 1) {
-            const V3 outer = ldv(s.ptsCur, s.layerMap[p]);
+            const V3 outer = (slot >= 0) ? ldv(s.combL, 2 * slot + 1) : ldv(s.ptsCur, s.layerMap[p]);
             const double blendFrac = s.layerBlend[hops];
             const V3 orthoPoint = outer + s.layerLen[hops] * n;
             np = blendFrac * orthoPoint + (1.0 - blendFrac) * np;
@@ -807,6 +812,43 @@ __global__ void __launch_bounds__(kBlock) k_halo_copyA(int nSend, const int* sen
     if (i >= nSend * SMGPU_HALO_A_DOUBLES) return;
     const int slot = i / SMGPU_HALO_A_DOUBLES, j = i % SMGPU_HALO_A_DOUBLES;
     sendA[i] = ownA[(size_t)sendShared[slot] * SMGPU_HALO_A_DOUBLES + j];
+}
+
+// boundary layer treatment under -parallel: per shared point the local normal and the local outer neighbour's current
+// coordinates (UNDEF_VECTOR when the neighbour is not in this rank, OBB.C:474-478)
+__global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* sharedLocal, double* ownL, int nShared) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    const int p = sharedLocal[i];
+    const int q = s.layerMap[p];
+    stv(ownL, 2 * i, ldv(s.layerNormal, p));
+    stv(ownL, 2 * i + 1, q >= 0 ? ldv(s.ptsCur, q) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT));
+}
+__global__ void __launch_bounds__(kBlock) k_halo_copyL(int nSend, const int* sendShared, const double* ownL, double* sendL) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nSend * SMGPU_HALO_L_DOUBLES) return;
+    const int slot = i / SMGPU_HALO_L_DOUBLES, j = i % SMGPU_HALO_L_DOUBLES;
+    sendL[i] = ownL[(size_t)sendShared[slot] * SMGPU_HALO_L_DOUBLES + j];
+}
+// plusEqOp in ascending rank order for the normals; minMagSqrEqOp folded from the own value for the coordinates
+__global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
+                                                          const double* recvL, double* combL) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    const int b = combOff[i], n = combOff[i + 1] - b;
+    V3 sum = v3(0, 0, 0);
+    V3 x = ldv(ownL, 2 * i + 1);
+    for (int j = 0; j < n; ++j) {
+        const int sl = combSlots[b + j];
+        const double* r = (sl < 0) ? ownL + (size_t)i * SMGPU_HALO_L_DOUBLES : recvL + (size_t)sl * SMGPU_HALO_L_DOUBLES;
+        sum = sum + v3(r[0], r[1], r[2]);
+        if (sl >= 0) {
+            const V3 y = v3(r[3], r[4], r[5]);
+            x = (magSqr(x) <= magSqr(y)) ? x : y;
+        }
+    }
+    stv(combL, 2 * i, sum);
+    stv(combL, 2 * i + 1, x);
 }
 
 // SM.C:246-272 isCloserPoint

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <chrono>
 #include <future>
+#include <memory>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -67,6 +68,11 @@ struct smgpu_handle {
     int *dSharedLocal = nullptr, *dSendShared = nullptr, *dCombOff = nullptr, *dCombSlots = nullptr, *dSharedSlot = nullptr;
     double *dOwnA = nullptr, *dCombA = nullptr;
     double *sendA = nullptr, *recvA = nullptr;
+    double *dOwnL = nullptr, *dCombL = nullptr, *sendL = nullptr, *recvL = nullptr;   // boundary layer treatment under -parallel
+    std::vector<int> sharedLocalHost;
+    std::unique_ptr<LayerBuilder> lb;                                                  // set-up in progress
+    std::vector<double> lbArea;
+    std::vector<uint8_t> lbInternal;
     int *sendF = nullptr, *recvF = nullptr;
     double* localStats = nullptr;
     int haloIter = 0;
@@ -1079,6 +1085,9 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     if (devAlloc(h, &h->dOwnA, (size_t)d->nShared * SMGPU_HALO_A_DOUBLES)) return 1;
     if (devAlloc(h, &h->dCombA, (size_t)d->nShared * SMGPU_HALO_A_DOUBLES)) return 1;
     h->sendA = (double*)d->sendA; h->recvA = (double*)d->recvA;
+    h->sendL = (double*)d->sendL; h->recvL = (double*)d->recvL;
+    h->sharedLocalHost = sharedLocal;
+    if (h->layersOn) return fail("smgpu_halo_configure after the boundary layer set-up: configure the halo first");
     h->sendF = (int*)d->sendF; h->recvF = (int*)d->recvF;
     h->localStats = (double*)d->localStats;
     if ((d->nSend && (!h->sendA || !h->sendF)) || (d->nRecv && (!h->recvA || !h->recvF)) || !h->localStats)
@@ -1158,8 +1167,14 @@ int smgpu_iter_begin(smgpu_handle* h) {
                 if (h->nSend)
                     hipLaunchKernelGGL(k_halo_copyA, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_A_DOUBLES)), dim3(kBlock), 0, h->stream,
                                        h->nSend, h->dSendShared, h->dOwnA, h->sendA);
+                if (h->layersOn) {          // local normals / outer neighbour coordinates (SM.C:2266, 2286)
+                    hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared);
+                    if (h->nSend)
+                        hipLaunchKernelGGL(k_halo_copyL, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_L_DOUBLES)), dim3(kBlock), 0, h->stream,
+                                           h->nSend, h->dSendShared, h->dOwnL, h->sendL);
+                }
             })) return 1;
-    return exchAfterCompute(h);             // sendA is complete: exchange A may start
+    return exchAfterCompute(h);             // sendA (and sendL) complete: the exchange may start
 }
 
 // Work of the iteration that does not depend on exchange A: the proposal (and, with the constraints off,
@@ -1188,6 +1203,9 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_combineA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                    h->dCombSlots, h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err);
+                if (h->layersOn)
+                    hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
+                                       h->dCombSlots, h->dOwnL, h->recvL, h->dCombL);
             })) return 1;
     if (h->useTiles) {
         if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, h->dSharedTiles, h->nSharedTiles)) return 1; }
@@ -1251,9 +1269,8 @@ int smgpu_iter_end(smgpu_handle* h) {
 }
 
 // ---- optional boundary layer treatment -------------------------------------------------------------------------
-int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled) {
+int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled, int32_t* maxIter) {
     if (!h || !d) return fail("null argument");
-    if (h->haloOn) return fail("boundary layer treatment is only available in serial runs (no halo)");
     if (d->nPatches < 0 || (d->nPatches && (!d->patchStart || !d->patchSize || !d->patchKind || !d->isLayerPatch))) return fail("bad patch description");
     HIP_OK(hipSetDevice(h->device));
     bool any = false;
@@ -1264,22 +1281,42 @@ int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enable
     }
     const bool on = any && (d->layerMaxBlendingFraction > 1.0e-15);   // SM.C:2025, SMALL
     if (enabled) *enabled = on ? 1 : 0;
+    if (maxIter) *maxIter = d->maxLayers + 1;
     h->layersOn = false;
+    h->lb.reset();
     if (!on) return 0;
     // face area vectors of the current coordinates (fvPatch::Sf): the direct face kernel writes all of them
     const MeshView& m = h->mv;
     State s = h->st;
     hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, 0);
-    std::vector<double> area(3 * (size_t)m.nFaces);
-    HIP_OK(hipMemcpyAsync(area.data(), s.fArea, sizeof(double) * area.size(), hipMemcpyDeviceToHost, h->stream));
+    h->lbArea.resize(3 * (size_t)m.nFaces);
+    HIP_OK(hipMemcpyAsync(h->lbArea.data(), s.fArea, sizeof(double) * h->lbArea.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
-    std::vector<uint8_t> internal((size_t)m.nPoints);
-    HIP_OK(hipMemcpy(internal.data(), m.pflags, (size_t)m.nPoints, hipMemcpyDeviceToHost));
-    for (auto& f : internal) f = (f & PF_INTERNAL) ? 1 : 0;
-    LayerSetup ls;
-    const std::string err = buildLayerSetup(h->topo, internal.data(), patches, area.data(), d->layerMaxBlendingFraction, d->layerEdgeLength,
-                                            d->layerExpansionRatio, d->minLayers, d->maxLayers, ls);
-    if (!err.empty()) return fail(err);
+    h->lbInternal.resize((size_t)m.nPoints);
+    HIP_OK(hipMemcpy(h->lbInternal.data(), m.pflags, (size_t)m.nPoints, hipMemcpyDeviceToHost));
+    for (auto& f : h->lbInternal) f = (f & PF_INTERNAL) ? 1 : 0;
+    h->lb.reset(new LayerBuilder());
+    const std::string err = h->lb->begin(h->topo, h->lbInternal.data(), patches, h->lbArea.data(), d->layerMaxBlendingFraction, d->layerEdgeLength,
+                                         d->layerExpansionRatio, d->minLayers, d->maxLayers);
+    if (!err.empty()) { h->lb.reset(); return fail(err); }
+    return 0;
+}
+
+int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg) {
+    if (!h) return fail("null handle");
+    if (!h->lb) return fail("smgpu_layers_step: no set-up in progress (smgpu_layers_begin, enabled)");
+    LayerBuilder& b = *h->lb;
+    switch (step) {
+    case SMGPU_LAYERS_HOPS_SWEEP: b.hopsSweep(); return 0;
+    case SMGPU_LAYERS_NORMALS_ACCUMULATE: b.normalsAccumulate(); return 0;
+    case SMGPU_LAYERS_NORMALS_FINISH: b.normalsFinish(); return 0;
+    case SMGPU_LAYERS_PROPAGATE_SWEEP: b.propagateSweep(arg); return 0;
+    case SMGPU_LAYERS_FINISH: break;
+    default: return fail("smgpu_layers_step: unknown step");
+    }
+    HIP_OK(hipSetDevice(h->device));
+    b.finish();
+    const LayerSetup& ls = b.out;
     const double* dn = nullptr; const int *dh = nullptr, *dm = nullptr; const double *dl = nullptr, *db = nullptr;
     if (devUpload(h, &dn, ls.normals) || devUpload(h, &dh, ls.hops) || devUpload(h, &dm, ls.outerMap) || devUpload(h, &dl, ls.lengthOfHops) ||
         devUpload(h, &db, ls.blendOfHops)) return 1;
@@ -1287,8 +1324,51 @@ int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enable
     h->st.layerHops = dh; h->st.layerMap = dm; h->st.layerLen = dl; h->st.layerBlend = db;
     h->layerHopsHost = ls.hops;
     h->layerMapHost = ls.outerMap;
+    h->st.combL = nullptr;
+    if (h->haloOn) {
+        if (h->nSend && (!h->sendL || !h->recvL)) return fail("boundary layer treatment with a halo needs smgpu_halo_desc.sendL / recvL");
+        if (devAlloc(h, &h->dOwnL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
+        if (devAlloc(h, &h->dCombL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
+        h->st.combL = h->dCombL;
+    }
+    h->lb.reset();
+    h->lbArea.clear(); h->lbArea.shrink_to_fit();
     h->layersOn = true;
     return 0;
+}
+
+int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* v) {
+    if (!h || !v) return fail("null argument");
+    if (!h->lb) return fail("smgpu_layers_shared: no set-up in progress");
+    if (!h->haloOn) return fail("smgpu_layers_shared: halo not configured");
+    LayerSetup& o = h->lb->out;
+    const std::vector<int>& sl = h->sharedLocalHost;
+    const size_t n = sl.size();
+    for (size_t i = 0; i < n; ++i) {
+        const size_t p = (size_t)sl[i];
+        if (field == SMGPU_LAYERS_F_HOPS) {
+            if (set) o.hops[p] = (int32_t)v[i]; else v[i] = o.hops[p];
+        } else if (field == SMGPU_LAYERS_F_NORMALS_COUNT || field == SMGPU_LAYERS_F_NORMALS) {
+            const size_t w = field == SMGPU_LAYERS_F_NORMALS_COUNT ? 4 : 3;
+            for (size_t c = 0; c < 3; ++c) { if (set) o.normals[3 * p + c] = v[w * i + c]; else v[w * i + c] = o.normals[3 * p + c]; }
+            if (w == 4) { if (set) h->lb->nFaces[p] = (int32_t)v[4 * i + 3]; else v[4 * i + 3] = h->lb->nFaces[p]; }
+        } else return fail("smgpu_layers_shared: unknown field");
+    }
+    return 0;
+}
+
+int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled) {
+    if (!h || !d) return fail("null argument");
+    if (h->haloOn) return fail("smgpu_set_layers is the serial set-up; with a halo use smgpu_layers_begin / step / shared");
+    int32_t on = 0, maxIter = 0;
+    if (smgpu_layers_begin(h, d, &on, &maxIter)) return 1;
+    if (enabled) *enabled = on;
+    if (!on) return 0;
+    for (int i = 0; i < maxIter; ++i) h->lb->hopsSweep();
+    h->lb->normalsAccumulate();
+    h->lb->normalsFinish();
+    for (int i = 1; i <= maxIter; ++i) h->lb->propagateSweep(i);
+    return smgpu_layers_step(h, SMGPU_LAYERS_FINISH, 0);
 }
 
 // ---- debug / parity access -------------------------------------------------------------------

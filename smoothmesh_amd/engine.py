@@ -180,9 +180,7 @@ class SmoothEngine:
         self.params = p
 
     # -- the loop ------------------------------------------------------------------------------
-    def set_layers(self, lp: LayerParams, minEdgeLength: float):
-        """Enable the boundary layer treatment on lp.layerPatches (serial runs); returns the reference's
-        doLayerTreatment.  Call after construction, before iterating."""
+    def _layer_desc(self, lp: LayerParams, minEdgeLength: float):
         start, size, kind, sel = patch_arrays(self.mesh, lp.layerPatches)
         d = _ffi.LayerDesc()
         d.nPatches = len(start)
@@ -192,6 +190,37 @@ class SmoothEngine:
         d.layerEdgeLength = minEdgeLength if lp.layerEdgeLength is None else lp.layerEdgeLength
         d.layerExpansionRatio = lp.layerExpansionRatio
         d.minLayers, d.maxLayers = lp.minLayers, lp.maxLayers
+        return d, (start, size, kind, sel)
+
+    # step-wise set-up for runs with a halo (see include/smgpu.h, smgpu_layers_begin)
+    LAYERS_HOPS_SWEEP, LAYERS_NORMALS_ACCUMULATE, LAYERS_NORMALS_FINISH, LAYERS_PROPAGATE_SWEEP, LAYERS_FINISH = range(5)
+    LAYERS_F_HOPS, LAYERS_F_NORMALS_COUNT, LAYERS_F_NORMALS = range(3)
+    _LAYER_FIELD_WIDTH = (1, 4, 3)
+
+    def layers_begin(self, lp: LayerParams, minEdgeLength: float):
+        d, keep = self._layer_desc(lp, minEdgeLength)
+        on, it = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.smgpu_layers_begin(self._h, C.byref(d), C.byref(on), C.byref(it)))
+        return bool(on.value), it.value
+
+    def layers_step(self, step, arg=0):
+        self._check(self._lib.smgpu_layers_step(self._h, int(step), int(arg)))
+
+    def layers_shared_get(self, field):
+        v = np.zeros((self._nShared, self._LAYER_FIELD_WIDTH[field]), np.float64)
+        if self._nShared:
+            self._check(self._lib.smgpu_layers_shared(self._h, int(field), 0, _p(v, _ffi.c_f64p)))
+        return v
+
+    def layers_shared_set(self, field, values):
+        v = np.ascontiguousarray(values, np.float64).reshape(self._nShared, self._LAYER_FIELD_WIDTH[field])
+        if self._nShared:
+            self._check(self._lib.smgpu_layers_shared(self._h, int(field), 1, _p(v, _ffi.c_f64p)))
+
+    def set_layers(self, lp: LayerParams, minEdgeLength: float):
+        """Enable the boundary layer treatment on lp.layerPatches (serial runs); returns the reference's
+        doLayerTreatment.  Call after construction, before iterating."""
+        d, keep = self._layer_desc(lp, minEdgeLength)
         on = C.c_int32(0)
         self._check(self._lib.smgpu_set_layers(self._h, C.byref(d), C.byref(on)))
         return bool(on.value)
@@ -233,7 +262,7 @@ class SmoothEngine:
 
     # -- multi-rank ----------------------------------------------------------------------------
     def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats,
-                       exchangeStream=None):
+                       exchangeStream=None, sendL=None, recvL=None):
         """Pointers are raw device addresses (ints); exchangeStream: raw hipStream_t (int, 0 = null stream) the
         caller enqueues its exchanges on, or None = the engine's own stream; see smgpu_halo_desc."""
         keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (sharedLocal, sendShared, combOffsets, combSlots)]
@@ -242,6 +271,8 @@ class SmoothEngine:
         d.nSend = len(keep[1]); d.sendShared = _p(keep[1], _ffi.c_i32p)
         d.nRecv = int(nRecv); d.combOffsets = _p(keep[2], _ffi.c_i32p); d.combSlots = _p(keep[3], _ffi.c_i32p)
         d.sendA, d.recvA, d.sendF, d.recvF, d.localStats = sendA, recvA, sendF, recvF, localStats
+        d.sendL, d.recvL = sendL, recvL
+        self._nShared = len(keep[0])
         d.useExchangeStream = 0 if exchangeStream is None else 1
         d.exchangeStream = exchangeStream or None
         self._check(self._lib.smgpu_halo_configure(self._h, C.byref(d)))

@@ -13,6 +13,7 @@ all_gather of {residual, nFrozenPoints}.  No collective touches non-shared data.
 import numpy as np
 
 A_DOUBLES = 13  # SMGPU_HALO_A_DOUBLES
+L_DOUBLES = 6   # SMGPU_HALO_L_DOUBLES (boundary layer treatment: local normal + outer neighbour coordinates)
 
 
 class HaloTables:
@@ -68,6 +69,72 @@ class HaloTables:
         self.combSlots = np.array([s for p in per for s in p], dtype=np.int32) if nsh else np.zeros(0, np.int32)
 
 
+def combine_shared(tables, own, recv, op):
+    """syncTools::syncPointList for the shared points of one rank, on the host (set-up only).  own: (nShared, k) this
+    rank's values, recv: (nRecv, k) the other sharers' values in recv-slot order.  op: "max" (maxEqOp), "sum" (plusEqOp,
+    ascending rank order), "maxmag" (maxMagSqrEqOp: fold the others onto the own value in ascending rank order, the
+    larger magnitude wins, ties keep)."""
+    out = own.copy()
+    off, slots = tables.combOffsets, tables.combSlots
+    for i in range(len(own)):
+        sl = slots[off[i]:off[i + 1]]
+        if op == "max":
+            for s in sl:
+                if s >= 0:
+                    out[i] = np.maximum(out[i], recv[s])
+        elif op == "sum":
+            acc = np.zeros_like(own[i])
+            for s in sl:
+                acc = acc + (own[i] if s < 0 else recv[s])
+            out[i] = acc
+        elif op == "maxmag":
+            x = own[i]
+            for s in sl:
+                if s >= 0:
+                    y = recv[s]
+                    # magSqr left to right in plain IEEE doubles (no BLAS / FMA), as the reference evaluates it
+                    mx = float(x[0]) * float(x[0]) + float(x[1]) * float(x[1]) + float(x[2]) * float(x[2])
+                    my = float(y[0]) * float(y[0]) + float(y[1]) * float(y[1]) + float(y[2]) * float(y[2])
+                    x = x if mx >= my else y
+            out[i] = x
+        else:
+            raise ValueError(op)
+    return out
+
+
+def setup_layers_stepwise(engines, exchange, lp, minEdgeLength):
+    """The reference's layer set-up under -parallel (SM.C:2215-2221) on `engines` (this process's ranks), with its
+    syncPointList calls done by `exchange(field_index, list of own arrays, op) -> list of combined arrays`."""
+    E = type(engines[0])
+    res = [e.layers_begin(lp, minEdgeLength) for e in engines]
+    on, maxIter = res[0]
+    assert all(r == res[0] for r in res)
+    if not on:
+        return False
+
+    def sync(field, op):
+        own = [e.layers_shared_get(field) for e in engines]
+        for e, c in zip(engines, exchange(own, op)):
+            e.layers_shared_set(field, c)
+
+    for _ in range(maxIter):
+        for e in engines:
+            e.layers_step(E.LAYERS_HOPS_SWEEP)
+        sync(E.LAYERS_F_HOPS, "max")                       # OBB.C:124-130
+    for e in engines:
+        e.layers_step(E.LAYERS_NORMALS_ACCUMULATE)
+    sync(E.LAYERS_F_NORMALS_COUNT, "sum")                  # OBB.C:184-198
+    for e in engines:
+        e.layers_step(E.LAYERS_NORMALS_FINISH)
+    for it in range(1, maxIter + 1):
+        for e in engines:
+            e.layers_step(E.LAYERS_PROPAGATE_SWEEP, it)
+        sync(E.LAYERS_F_NORMALS, "maxmag")                 # OBB.C:359-365
+    for e in engines:
+        e.layers_step(E.LAYERS_FINISH)
+    return True
+
+
 class _RankState:
     """engine + exchange buffers of one rank (torch tensors on the engine's device)"""
 
@@ -79,9 +146,12 @@ class _RankState:
         self.sendF = torch.zeros(max(tables.nSend, 1), dtype=i32, device=device)
         self.recvF = torch.zeros(max(tables.nRecv, 1), dtype=i32, device=device)
         self.localStats = torch.zeros(2, dtype=f64, device=device)
+        self.sendL = torch.zeros((max(tables.nSend, 1), L_DOUBLES), dtype=f64, device=device)
+        self.recvL = torch.zeros((max(tables.nRecv, 1), L_DOUBLES), dtype=f64, device=device)
         engine.halo_configure(tables.sharedLocal, tables.sendShared, tables.nRecv, tables.combOffsets, tables.combSlots,
                               self.sendA.data_ptr(), self.recvA.data_ptr(), self.sendF.data_ptr(), self.recvF.data_ptr(),
-                              self.localStats.data_ptr(), exchangeStream=exchange_stream)
+                              self.localStats.data_ptr(), exchangeStream=exchange_stream,
+                              sendL=self.sendL.data_ptr(), recvL=self.recvL.data_ptr())
 
 
 class DistributedSmoother:
@@ -308,6 +378,17 @@ class LocalMultiSmoother:
             dst = getattr(self.states[b], "recv" + which)
             dst[do:do + c].copy_(src[so:so + c])
 
+    def set_layers(self, lp, minEdgeLength):
+        """boundary layer treatment on all sub-domains (the reference under mpirun with -layerPatches)"""
+        def exchange(own, op):
+            # recv slots of rank b from rank a = a's values at a's send slots towards b
+            recv = [np.zeros((st.t.nRecv, own[0].shape[1])) for st in self.states]
+            for a, so, b, do, c in self.copies:
+                recv[b][do:do + c] = own[a][self.states[a].t.sendShared[so:so + c]]
+            return [combine_shared(st.t, o, r, op) for st, o, r in zip(self.states, own, recv)]
+        self.layers = setup_layers_stepwise([st.eng for st in self.states], exchange, lp, minEdgeLength)
+        return self.layers
+
     def iterate(self, centroidalIters, relTol=0.02):
         res, frz = [], []
         for i in range(centroidalIters):
@@ -316,6 +397,8 @@ class LocalMultiSmoother:
             for st in self.states:
                 st.eng.iter_interior()
             self._exchange("A")
+            if getattr(self, "layers", False):
+                self._exchange("L")
             for st in self.states:
                 st.eng.iter_mid()
             for st in self.states:

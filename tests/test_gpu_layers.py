@@ -88,3 +88,40 @@ def test_disabled_and_refused_cases(oracle_lib):
     assert e.set_layers(LayerParams(layerPatches=("xmin",), layerMaxBlendingFraction=0.0), prm.minEdgeLength) is False
     with pytest.raises(SmgpuError):
         e.set_layers(LayerParams(layerPatches=("xmin",), maxLayers=-2), prm.minEdgeLength)
+
+
+@pytest.mark.parametrize("grid,patches,constraints,sub", [((2, 1, 1), ["xmin"], False, (5, 4, 4)), ((2, 2, 1), ["xmin", "zmax"], False, (5, 4, 4)),
+                                                          ((2, 2, 2), ['"x.*"', "ymin"], True, (4, 4, 3)), ((2, 2, 1), ["xmin", "ymax"], False, (14, 12, 10))])
+def test_layers_under_parallel_match_the_multi_domain_oracle(oracle_lib, grid, patches, constraints, sub):
+    """-parallel + -layerPatches: step-wise set-up with the host doing the reference's syncPointList calls, the 6-double
+    layer exchange next to exchange A; expected = the oracle's MultiDomain.  The last case spans several tiles and a
+    point shared by four ranks that hangs on different neighbours on different ranks."""
+    from smoothmesh_amd import LayerParams, default_params, patch_arrays
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    from smoothmesh_amd.meshgen import hex_subdomain
+    world = grid[0] * grid[1] * grid[2]
+    subs = [hex_subdomain(sub, grid, r, jitter=0.25, seed=13) for r in range(world)]
+    ms = LocalMultiSmoother(subs, device=0)
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    mn = min(o.mesh_stats()[0] for o in orcs)
+    prm = default_params(mn, edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ms.set_params(prm)
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    lp = LayerParams(layerPatches=tuple(patches), layerExpansionRatio=1.2)
+    assert mo.setup_layers([patch_arrays(s.mesh, patches) for s in subs], lp.layerMaxBlendingFraction, prm.minEdgeLength,
+                           lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+    assert ms.set_layers(lp, prm.minEdgeLength)
+    for st, o in zip(ms.states, orcs):
+        f = o.layer_fields()
+        assert np.array_equal(st.eng.debug_field("layerHops").astype(np.int32), f["hops"])
+        assert np.array_equal(st.eng.debug_field("layerOuterMap").astype(np.int32), f["outerMap"])
+        assert np.array_equal(st.eng.debug_field("layerNormals").reshape(-1, 3), f["normals"])
+    n_o, res_o, frz_o = mo.iterate(8, 0.0)
+    n_g, res_g, frz_g = ms.iterate(8, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    for o, pts in zip(orcs, ms.get_points()):
+        assert rel_linf(pts, o.points()) <= 1e-13
