@@ -213,6 +213,79 @@ void orc_halo_combineA(void* h, int nShared, const int* sharedLocal, const int* 
         d->hasCommonCell[p] = any;
     }
 }
+// boundary layer treatment under -parallel, rank-engine form: 6 doubles per shared point (local normal, local outer
+// neighbour coordinates), combined as MultiDomain::syncLayers does
+void orc_halo_packL(void* h, const int* sharedLocal, int nSend, const int* sendShared, double* sendL) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nSend; ++i) {
+        const int p = sharedLocal[sendShared[i]];
+        double* r = sendL + 6 * (size_t)i;
+        r[0] = d->pointNormals[p].x; r[1] = d->pointNormals[p].y; r[2] = d->pointNormals[p].z;
+        r[3] = d->outerNeighCoords[p].x; r[4] = d->outerNeighCoords[p].y; r[5] = d->outerNeighCoords[p].z;
+    }
+}
+void orc_halo_combineL(void* h, int nShared, const int* sharedLocal, const int* combOff, const int* combSlots, const double* recvL) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nShared; ++i) {
+        const int p = sharedLocal[i];
+        const int b = combOff[i], n = combOff[i + 1] - b;
+        const Vec3 ownN = d->pointNormals[p], ownC = d->outerNeighCoords[p];
+        Vec3 sum{0, 0, 0};
+        Vec3 x = ownC;
+        for (int j = 0; j < n; ++j) {
+            const int sl = combSlots[b + j];
+            const Vec3 nj = (sl < 0) ? ownN : Vec3{recvL[6 * (size_t)sl], recvL[6 * (size_t)sl + 1], recvL[6 * (size_t)sl + 2]};
+            sum.x += nj.x; sum.y += nj.y; sum.z += nj.z;
+            if (sl >= 0) {
+                const Vec3 y{recvL[6 * (size_t)sl + 3], recvL[6 * (size_t)sl + 4], recvL[6 * (size_t)sl + 5]};
+                const double mx = x.x * x.x + x.y * x.y + x.z * x.z, my = y.x * y.x + y.y * y.y + y.z * y.z;
+                x = (mx <= my) ? x : y;
+            }
+        }
+        d->pointNormals[p] = sum;
+        d->outerNeighCoords[p] = x;
+    }
+}
+// step-wise set-up (same steps / fields as include/smgpu.h smgpu_layers_*)
+int orc_layers_begin(void* h, int nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
+                     double layerMaxBlendingFraction, double layerEdgeLength, double layerExpansionRatio, int minLayers, int maxLayers) {
+    Domain* d = static_cast<Domain*>(h);
+    std::vector<Patch> p((size_t)nPatches);
+    for (int i = 0; i < nPatches; ++i) { p[i].start = start[i]; p[i].size = size[i]; p[i].kind = kind[i]; p[i].isLayerPatch = isLayer[i] != 0; }
+    LayerParams lp;
+    lp.layerMaxBlendingFraction = layerMaxBlendingFraction;
+    lp.layerEdgeLength = layerEdgeLength;
+    lp.layerExpansionRatio = layerExpansionRatio;
+    lp.minLayers = minLayers;
+    lp.maxLayers = maxLayers;
+    d->layersBegin(p, lp);
+    return d->doLayerTreatment ? 1 : 0;
+}
+void orc_layers_step(void* h, int step, int arg) {
+    Domain* d = static_cast<Domain*>(h);
+    switch (step) {
+    case 0: d->layersHopsSweep(); break;
+    case 1: d->layersNormalsAccumulate(); break;
+    case 2: d->layersNormalsFinish(); break;
+    case 3: d->layersPropagateSweep(arg); break;
+    case 4: d->layersUndo(); break;
+    }
+}
+void orc_layers_shared(void* h, int nShared, const int* sharedLocal, int field, int set, double* v) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int i = 0; i < nShared; ++i) {
+        const int p = sharedLocal[i];
+        if (field == 0) {
+            if (set) d->pointHopsToLayerBoundary[p] = (int)v[i]; else v[i] = d->pointHopsToLayerBoundary[p];
+        } else {
+            const int w = field == 1 ? 4 : 3;
+            Vec3& n = d->pointNormals[p];
+            if (set) { n.x = v[w * i]; n.y = v[w * i + 1]; n.z = v[w * i + 2]; } else { v[w * i] = n.x; v[w * i + 1] = n.y; v[w * i + 2] = n.z; }
+            if (w == 4) { if (set) d->layerNFaces[p] = (int)v[4 * i + 3]; else v[4 * i + 3] = d->layerNFaces[p]; }
+        }
+    }
+}
+
 void orc_halo_packF(void* h, const int* sharedLocal, int nSend, const int* sendShared, int* sendF) {
     Domain* d = static_cast<Domain*>(h);
     for (int i = 0; i < nSend; ++i) sendF[i] = d->isFrozenPoint[sharedLocal[sendShared[i]]];

@@ -60,6 +60,12 @@ def lib():
         l.orc_halo_packF.argtypes = [C.c_void_p, i32p, C.c_int, i32p, i32p]
         l.orc_halo_orF.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, i32p]
         l.orc_local_stats.argtypes = [C.c_void_p, f64p]
+        l.orc_halo_packL.argtypes = [C.c_void_p, i32p, C.c_int, i32p, f64p]
+        l.orc_halo_combineL.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, f64p]
+        l.orc_layers_begin.restype = C.c_int
+        l.orc_layers_begin.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+        l.orc_layers_step.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.orc_layers_shared.argtypes = [C.c_void_p, C.c_int, i32p, C.c_int, C.c_int, f64p]
         l.orc_setup_layers.argtypes = [C.c_void_p, C.c_int, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         l.orc_multi_setup_layers.argtypes = [C.c_void_p, i32p, i32p, i32p, i32p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
         l.orc_layers_enabled.restype = C.c_int
@@ -188,6 +194,7 @@ class OracleRankEngine:
 
     def __init__(self, mesh):
         self.o = Oracle(mesh)
+        self.o_mesh = mesh
         self._lib = lib()
 
     def mesh_stats(self):
@@ -197,7 +204,9 @@ class OracleRankEngine:
         self.o.set_params(p)
 
     def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats,
-                       exchangeStream=None):
+                       exchangeStream=None, sendL=None, recvL=None):
+        self.layers = False
+        self.ptrL = (C.cast(sendL, f64p), C.cast(recvL, f64p)) if sendL else None
         self.sharedLocal = np.ascontiguousarray(sharedLocal, np.int32)
         self.sendShared = np.ascontiguousarray(sendShared, np.int32)
         self.combOffsets = np.ascontiguousarray(combOffsets, np.int32)
@@ -205,10 +214,41 @@ class OracleRankEngine:
         self.ptr = dict(sendA=C.cast(sendA, f64p), recvA=C.cast(recvA, f64p), sendF=C.cast(sendF, i32p),
                         recvF=C.cast(recvF, i32p), localStats=C.cast(localStats, f64p))
 
+    # step-wise boundary layer set-up, same interface as smoothmesh_amd.engine.SmoothEngine
+    LAYERS_HOPS_SWEEP, LAYERS_NORMALS_ACCUMULATE, LAYERS_NORMALS_FINISH, LAYERS_PROPAGATE_SWEEP, LAYERS_FINISH = range(5)
+    LAYERS_F_HOPS, LAYERS_F_NORMALS_COUNT, LAYERS_F_NORMALS = range(3)
+    _LAYER_FIELD_WIDTH = (1, 4, 3)
+
+    def layers_begin(self, lp, minEdgeLength):
+        from smoothmesh_amd import patch_arrays
+        st, sz, kd, il = patch_arrays(self.o_mesh, lp.layerPatches)
+        st, sz = np.ascontiguousarray(st, np.int32), np.ascontiguousarray(sz, np.int32)
+        kd, il = np.ascontiguousarray(kd, np.int32), np.ascontiguousarray(il, np.uint8)
+        on = self._lib.orc_layers_begin(self.o._h, len(st), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p),
+                                        lp.layerMaxBlendingFraction, minEdgeLength if lp.layerEdgeLength is None else lp.layerEdgeLength,
+                                        lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        return bool(on), lp.maxLayers + 1
+
+    def layers_step(self, step, arg=0):
+        self._lib.orc_layers_step(self.o._h, int(step), int(arg))
+        if step == self.LAYERS_FINISH:
+            self.layers = True
+
+    def layers_shared_get(self, field):
+        v = np.zeros((len(self.sharedLocal), self._LAYER_FIELD_WIDTH[field]), np.float64)
+        self._lib.orc_layers_shared(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), int(field), 0, _p(v, f64p))
+        return v
+
+    def layers_shared_set(self, field, values):
+        v = np.ascontiguousarray(values, np.float64)
+        self._lib.orc_layers_shared(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), int(field), 1, _p(v, f64p))
+
     def iter_begin(self):
         self.o.phaseA()
         self._lib.orc_halo_packA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), len(self.sendShared),
                                  _p(self.sendShared, i32p), self.ptr["sendA"])
+        if self.layers:
+            self._lib.orc_halo_packL(self.o._h, _p(self.sharedLocal, i32p), len(self.sendShared), _p(self.sendShared, i32p), self.ptrL[0])
 
     def iter_interior(self):
         pass   # the oracle has no exchange-independent stage
@@ -216,6 +256,9 @@ class OracleRankEngine:
     def iter_mid(self):
         self._lib.orc_halo_combineA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
                                     _p(self.combSlots, i32p), self.ptr["recvA"])
+        if self.layers:
+            self._lib.orc_halo_combineL(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
+                                        _p(self.combSlots, i32p), self.ptrL[1])
         self.o.phaseB()
         self._lib.orc_halo_packF(self.o._h, _p(self.sharedLocal, i32p), len(self.sendShared), _p(self.sendShared, i32p),
                                  self.ptr["sendF"])

@@ -164,6 +164,7 @@ class DistributedSmoother:
         self.sub = sub
         self.probe_slots = int(probe_slots)
         self.xstream = None
+        self.layers = False
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         assert sub.rank == self.rank and sub.nRanks == self.world
         if torch_device is None:
@@ -199,6 +200,28 @@ class DistributedSmoother:
 
     def set_params(self, p):
         self.engine.set_params(p)
+
+    def set_layers(self, lp, minEdgeLength):
+        """boundary layer treatment (-layerPatches under mpirun): step-wise set-up, the reference's syncPointList calls
+        done with the same all_to_all as the per-iteration exchanges (values travel as doubles; set-up only)"""
+        torch, t = self.torch, self.tables
+        cpu = self._staged() or self.device.type == "cpu"
+
+        def exchange(own, op):
+            o = own[0]
+            k = o.shape[1]
+            send = torch.from_numpy(np.ascontiguousarray(o[t.sendShared])).reshape(-1, k) if t.nSend else torch.zeros((0, k), dtype=torch.float64)
+            recv = torch.zeros((t.nRecv, k), dtype=torch.float64)
+            if self.world > 1:
+                if cpu:
+                    self.dist.all_to_all_single(recv, send, self.counts, self.counts)
+                else:
+                    r = recv.to(self.device)
+                    self.dist.all_to_all_single(r, send.to(self.device), self.counts, self.counts)
+                    recv = r.cpu()
+            return [combine_shared(t, o, recv.numpy(), op)]
+        self.layers = setup_layers_stepwise([self.engine], exchange, lp, minEdgeLength)
+        return self.layers
 
     def _staged(self):
         # RCCL moves device buffers directly; gloo (CPU tests, or several debug ranks sharing one GPU)
@@ -294,6 +317,8 @@ class DistributedSmoother:
             hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
             for i in range(centroidalIters):
                 eng.iter_begin()
+                if self.layers:
+                    self._a2a(st.recvL, st.sendL)                  # OBB.C:184-198, 490-496
                 self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
                 eng.iter_mid()
                 self._a2a(st.recvF, st.sendF, eng.iter_ahead)   # SM.C:2374
@@ -312,6 +337,8 @@ class DistributedSmoother:
         local = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
         for i in range(centroidalIters):
             eng.iter_begin()
+            if self.layers:
+                self._a2a(st.recvL, st.sendL)
             self._a2a(st.recvA, st.sendA, eng.iter_interior)
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF, eng.iter_ahead)
