@@ -4,9 +4,8 @@
 //
 // This host is standalone (own option parser, own polyMesh I/O) because OpenFOAM is not available
 // in the build environment; INTEGRATION.md shows the OpenFOAM-linked variant of the same calls.
-// Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available for serial runs.
-// Out of scope: boundary point smoothing (constant/geometry/*.obj) and the layer treatment under -parallel;
-// asking for them is an error, not a silent skip.
+// Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available, serial and -parallel.
+// Out of scope: boundary point smoothing (constant/geometry/*.obj); asking for it is an error, not a silent skip.
 //
 //   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
 //
@@ -92,7 +91,7 @@ Options parseArgs(int argc, char** argv) {
                       "       [-maxStepLength x] [-relStepFrac x] [-totalMinFreeze b] [-edgeAngleConstraint b] [-faceAngleConstraint b]\n"
                       "       [-minAngle deg] [-maxAngle deg] [-writeInterval n] [-writeFormat ascii|binary] [-device n]\n"
                       "       [-layerPatches '(p1 \"re.*\")' -layerMaxBlendingFraction x -layerEdgeLength x -layerExpansionRatio x\n"
-                      "        -minLayers n -maxLayers n]   (serial runs)\n"
+                      "        -minLayers n -maxLayers n]\n"
                       "Move internal mesh points to increase mesh quality (MI355X engine)");
             std::exit(0);
         }
@@ -200,7 +199,7 @@ struct Rank {
     std::vector<int32_t> sharedLocal, sendShared, combOff, combSlots;
     std::vector<int64_t> sharedGlobal;
     std::vector<int> peerCount, peerSendBase;
-    double *sendA = nullptr, *recvA = nullptr, *localStats = nullptr;
+    double *sendA = nullptr, *recvA = nullptr, *localStats = nullptr, *sendL = nullptr, *recvL = nullptr;
     int32_t *sendF = nullptr, *recvF = nullptr;
     int nSend = 0;
 };
@@ -332,9 +331,9 @@ int main(int argc, char** argv) {
     } catch (const std::exception& e) { fatal(e.what()); }
 
     // patches for the boundary layer treatment, getPatchIdsForOption SM.C:1442-1471 / 1823-1833: a wordRe list,
-    // "(name1 name2 \"regex.*\")" or a single word; quoted entries are regular expressions
-    std::vector<uint8_t> isLayerPatch(R[0].mesh.patches.size(), 0);
-    bool anyLayerPatch = false;
+    // "(name1 name2 \"regex.*\")" or a single word; quoted entries are regular expressions.  Every sub-domain carries
+    // the original patches (possibly empty) plus its processor patches, so the names are matched per sub-domain.
+    std::vector<std::pair<std::string, bool>> layerWords;   // (word, is a regular expression)
     if (opt.found("layerPatches")) {
         std::string v = opt.kv.at("layerPatches");
         for (char& ch : v) if (ch == '(' || ch == ')') ch = ' ';
@@ -346,22 +345,28 @@ int main(int argc, char** argv) {
             std::string tok;
             if (v[i] == '"') { isRe = true; ++i; while (i < v.size() && v[i] != '"') tok.push_back(v[i++]); ++i; }
             else while (i < v.size() && !std::isspace((unsigned char)v[i])) tok.push_back(v[i++]);
-            for (size_t p = 0; p < R[0].mesh.patches.size(); ++p) {
-                bool hit;
-                if (isRe) {
-                    try { hit = std::regex_match(R[0].mesh.patches[p].name, std::regex(tok, std::regex::extended)); }
-                    catch (const std::regex_error&) { fatal("-layerPatches: bad regular expression \"" + tok + "\""); }
-                } else hit = (R[0].mesh.patches[p].name == tok);
-                if (hit) { isLayerPatch[p] = 1; anyLayerPatch = true; }
+            if (isRe) {
+                try { (void)std::regex(tok, std::regex::extended); }
+                catch (const std::regex_error&) { fatal("-layerPatches: bad regular expression \"" + tok + "\""); }
             }
+            layerWords.push_back({tok, isRe});
         }
+    }
+    bool anyLayerPatch = false;
+    std::vector<std::vector<uint8_t>> isLayerPatchOf(R.size());
+    for (size_t r = 0; r < R.size(); ++r) {
+        const auto& patches = R[r].mesh.patches;
+        isLayerPatchOf[r].assign(patches.size(), 0);
+        for (size_t p = 0; p < patches.size(); ++p)
+            for (const auto& w : layerWords) {
+                const bool hit = w.second ? std::regex_match(patches[p].name, std::regex(w.first, std::regex::extended)) : (patches[p].name == w.first);
+                if (hit) { isLayerPatchOf[r][p] = 1; anyLayerPatch = true; }
+            }
     }
     if (anyLayerPatch) std::printf("Patches for boundary layer treatment: %s\n", opt.kv.at("layerPatches").c_str());
     else std::puts("Patches for boundary layer treatment: none");
     const double layerMaxBlendingFraction = opt.getD("layerMaxBlendingFraction", 0.3);
     const bool doLayerTreatment = anyLayerPatch && layerMaxBlendingFraction > SMALL;   // SM.C:2024-2028
-    if (doLayerTreatment && opt.parallel)
-        fatal("-layerPatches with -parallel: the boundary layer treatment of this build is serial only");
     // out-of-scope feature: refuse instead of silently ignoring (SM.C:2081-2093)
     if (fileExists(cd + "/constant/geometry/targetSurfaces.obj"))
         fatal("constant/geometry/targetSurfaces.obj found: boundary point smoothing (boundaryPointSmoothing.C) is outside the scope of this build");
@@ -436,24 +441,6 @@ int main(int argc, char** argv) {
     std::printf("Mesh minimum edge length = %g\nMesh maximum edge length = %g\n\n", meshMinEdgeLength, meshMaxEdgeLength);
 
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
-    if (doLayerTreatment) {   // set-up SM.C:2215-2221 on the engine's side
-        const PolyMeshData& pm = R[0].mesh;
-        std::vector<int32_t> pStart, pSize;
-        std::vector<uint8_t> pKind;
-        for (const PatchInfo& p : pm.patches) {
-            pStart.push_back(p.startFace);
-            pSize.push_back(p.nFaces);
-            pKind.push_back(p.type == "processor" ? 1 : (p.type == "empty" ? 2 : 0));
-        }
-        smgpu_layer_desc ld{};
-        ld.nPatches = (int32_t)pStart.size();
-        ld.patchStart = pStart.data(); ld.patchSize = pSize.data(); ld.patchKind = pKind.data(); ld.isLayerPatch = isLayerPatch.data();
-        ld.layerMaxBlendingFraction = layerMaxBlendingFraction; ld.layerEdgeLength = layerEdgeLength;
-        ld.layerExpansionRatio = layerExpansionRatio; ld.minLayers = (int32_t)minLayers; ld.maxLayers = (int32_t)maxLayers;
-        int32_t on = 0;
-        check(smgpu_set_layers(R[0].h, &ld, &on), "smgpu_set_layers");
-    }
-
     if (opt.parallel) {
         buildHalo(R);
         for (Rank& K : R) {
@@ -464,18 +451,100 @@ int main(int argc, char** argv) {
             HIPCHK(hipMalloc((void**)&K.sendF, ns * 4));
             HIPCHK(hipMalloc((void**)&K.recvF, ns * 4));
             HIPCHK(hipMalloc((void**)&K.localStats, 16));
+            HIPCHK(hipMalloc((void**)&K.sendL, ns * SMGPU_HALO_L_DOUBLES * 8));
+            HIPCHK(hipMalloc((void**)&K.recvL, ns * SMGPU_HALO_L_DOUBLES * 8));
             smgpu_halo_desc hd{};
             hd.nShared = (int32_t)K.sharedLocal.size(); hd.sharedLocal = K.sharedLocal.data();
             hd.nSend = K.nSend; hd.sendShared = K.sendShared.data(); hd.nRecv = K.nSend;
             hd.combOffsets = K.combOff.data(); hd.combSlots = K.combSlots.data();
             hd.sendA = K.sendA; hd.recvA = K.recvA; hd.sendF = K.sendF; hd.recvF = K.recvF; hd.localStats = K.localStats;
+            hd.sendL = K.sendL; hd.recvL = K.recvL;
             check(smgpu_halo_configure(K.h, &hd), "smgpu_halo_configure");
         }
     }
 
+    if (doLayerTreatment) {   // set-up SM.C:2215-2221 on the engines' side
+        std::vector<std::vector<int32_t>> pStart(R.size()), pSize(R.size());
+        std::vector<std::vector<uint8_t>> pKind(R.size());
+        std::vector<smgpu_layer_desc> ld(R.size());
+        for (size_t r = 0; r < R.size(); ++r) {
+            for (const PatchInfo& p : R[r].mesh.patches) {
+                pStart[r].push_back(p.startFace);
+                pSize[r].push_back(p.nFaces);
+                pKind[r].push_back(p.type == "processor" ? 1 : (p.type == "empty" ? 2 : 0));
+            }
+            ld[r] = smgpu_layer_desc{};
+            ld[r].nPatches = (int32_t)pStart[r].size();
+            ld[r].patchStart = pStart[r].data(); ld[r].patchSize = pSize[r].data(); ld[r].patchKind = pKind[r].data();
+            ld[r].isLayerPatch = isLayerPatchOf[r].data();
+            ld[r].layerMaxBlendingFraction = layerMaxBlendingFraction; ld[r].layerEdgeLength = layerEdgeLength;
+            ld[r].layerExpansionRatio = layerExpansionRatio; ld[r].minLayers = (int32_t)minLayers; ld[r].maxLayers = (int32_t)maxLayers;
+        }
+        int32_t on = 0, maxIter = 0;
+        if (!opt.parallel) check(smgpu_set_layers(R[0].h, &ld[0], &on), "smgpu_set_layers");
+        else {
+            // step-wise, with the reference's syncPointList calls done here over the shared points (all sub-domains live in
+            // this process): sharers of a global point in ascending rank order
+            std::map<int64_t, std::vector<std::pair<int, int>>> sharers;   // global id -> (rank, index in the rank's shared list)
+            for (int r = 0; r < nRanks; ++r)
+                for (size_t i = 0; i < R[r].sharedGlobal.size(); ++i) sharers[R[r].sharedGlobal[i]].push_back({r, (int)i});
+            auto sync = [&](int field, int width, int op) {   // op 0 max, 1 sum (ascending rank), 2 larger magnitude folded onto own
+                std::vector<std::vector<double>> v(R.size());
+                for (int r = 0; r < nRanks; ++r) {
+                    v[r].assign(std::max<size_t>(R[r].sharedGlobal.size(), 1) * width, 0.0);
+                    if (!R[r].sharedGlobal.empty()) check(smgpu_layers_shared(R[r].h, field, 0, v[r].data()), "smgpu_layers_shared");
+                }
+                const std::vector<std::vector<double>> sent(v);
+                for (const auto& kv : sharers) {
+                    const auto& sh = kv.second;
+                    for (const auto& me : sh) {
+                        double* x = &v[me.first][(size_t)me.second * width];
+                        if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
+                        for (const auto& ot : sh) {
+                            const double* y = &sent[ot.first][(size_t)ot.second * width];
+                            if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
+                            if (ot.first == me.first) continue;
+                            if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
+                            else {
+                                const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+                                if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
+                            }
+                        }
+                    }
+                }
+                for (int r = 0; r < nRanks; ++r)
+                    if (!R[r].sharedGlobal.empty()) check(smgpu_layers_shared(R[r].h, field, 1, v[r].data()), "smgpu_layers_shared");
+            };
+            for (int r = 0; r < nRanks; ++r) check(smgpu_layers_begin(R[r].h, &ld[r], &on, &maxIter), "smgpu_layers_begin");
+            for (int it = 0; it < maxIter; ++it) {
+                for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_HOPS_SWEEP, 0), "smgpu_layers_step");
+                sync(SMGPU_LAYERS_F_HOPS, 1, 0);                          // OBB.C:124-130
+            }
+            for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_NORMALS_ACCUMULATE, 0), "smgpu_layers_step");
+            sync(SMGPU_LAYERS_F_NORMALS_COUNT, 4, 1);                     // OBB.C:184-198
+            for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_NORMALS_FINISH, 0), "smgpu_layers_step");
+            for (int it = 1; it <= maxIter; ++it) {
+                for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_PROPAGATE_SWEEP, it), "smgpu_layers_step");
+                sync(SMGPU_LAYERS_F_NORMALS, 3, 2);                       // OBB.C:359-365
+            }
+            for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_FINISH, 0), "smgpu_layers_step");
+        }
+    }
+
     auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
+    auto exchangeL = [&] {
+        for (int a = 0; a < nRanks; ++a)
+            for (int b = 0; b < nRanks; ++b) {
+                const int c = R[a].peerCount[b];
+                if (!c) continue;
+                HIPCHK(hipMemcpyPeer(R[b].recvL + (size_t)R[b].peerSendBase[a] * SMGPU_HALO_L_DOUBLES, R[b].device,
+                                     R[a].sendL + (size_t)R[a].peerSendBase[b] * SMGPU_HALO_L_DOUBLES, R[a].device,
+                                     (size_t)c * SMGPU_HALO_L_DOUBLES * 8));
+            }
+    };
     auto exchange = [&](bool isA) {
         syncAll();
+        if (isA && doLayerTreatment) exchangeL();
         for (int a = 0; a < nRanks; ++a)
             for (int b = 0; b < nRanks; ++b) {
                 const int c = R[a].peerCount[b];

@@ -116,8 +116,6 @@ def test_parallel_case(tmp_path, oracle_lib):
     subs = [hex_subdomain((5, 4, 6), grid, r, jitter=0.3, seed=6) for r in range(4)]
     write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
     out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "7", "-relTol", "0"])
-    r = subprocess.run([BIN, "-case", str(tmp_path), "-parallel", "-layerPatches", "(xmin)"], capture_output=True, text=True)
-    assert r.returncode != 0 and "serial only" in r.stdout
     orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
     prm = default_params(min(o.mesh_stats()[0] for o in orcs))
     for o in orcs:
@@ -130,4 +128,32 @@ def test_parallel_case(tmp_path, oracle_lib):
     for s, o in zip(subs, orcs):
         d = tmp_path / f"processor{s.rank}"
         got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "7" / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13
+
+
+def test_parallel_case_with_layer_patches(tmp_path, oracle_lib):
+    """the reference's own parallel test (testcase/run_parallel:18): mpirun ... -parallel ... -layerPatches"""
+    from smoothmesh_amd import default_params, patch_arrays
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    grid = (2, 2, 1)
+    subs = [hex_subdomain((6, 5, 4), grid, r, jitter=0.25, seed=7) for r in range(4)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0", "-layerPatches", '(xmin "y.*")',
+                "-layerExpansionRatio", "1.2", "-faceAngleConstraint", "false"])
+    assert "Enabled boundary layer treatment" in out
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), faceAngleConstraint=False)
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    assert mo.setup_layers([patch_arrays(s.mesh, ["xmin", '"y.*"']) for s in subs], 0.3, prm.minEdgeLength, 1.2, 1, 4)
+    n, res, frz = mo.iterate(6, 0.0)
+    lines = LINE.findall(out)
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    for s, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "6" / "polyMesh")).points
         assert rel_linf(got, o.points()) <= 1e-13
