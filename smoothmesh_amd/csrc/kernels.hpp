@@ -750,18 +750,19 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
 // End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test
 // (SM.C:2401), reset accumulators.  One workgroup of 1024 threads, 4 independent loads in flight per thread.
 constexpr int kFinishBlock = 1024;
-__global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
+// the reduction by one workgroup of T threads (all of them call it)
+template <int T>
+__device__ __forceinline__ void finishPartials(const State& s, int nPartials, int iter, double relTol, double* localStats) {
     Accum* a = s.acc;
-    if (a->stop) return;
-    __shared__ double shMax[kFinishBlock / 64];
-    __shared__ int shCnt[kFinishBlock / 64];
+    __shared__ double shMax[T / 64];
+    __shared__ int shCnt[T / 64];
     double d = 0.0;
     int c = 0;
-    for (int i0 = threadIdx.x; i0 < nPartials; i0 += 4 * kFinishBlock) {
+    for (int i0 = threadIdx.x; i0 < nPartials; i0 += 4 * T) {
         double v[4]; int n[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u * kFinishBlock;
+            const int i = i0 + u * T;
             v[u] = (i < nPartials) ? s.blkMax[i] : 0.0;
             n[u] = (i < nPartials) ? s.blkCnt[i] : 0;
         }
@@ -777,7 +778,7 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials,
     if ((threadIdx.x & 63) == 0) { shMax[threadIdx.x >> 6] = d; shCnt[threadIdx.x >> 6] = c; }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int i = 1; i < kFinishBlock / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
+    for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
     const double res = d;
     if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
@@ -785,6 +786,10 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials,
     a->nActive = 0;
     a->nEaMaybe = 0;
     a->nFaMaybe = 0;
+}
+__global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
+    if (s.acc->stop) return;
+    finishPartials<kFinishBlock>(s, nPartials, iter, relTol, localStats);
 }
 
 // ---- multi-rank pack / combine -------------------------------------------------------------------

@@ -109,6 +109,7 @@ struct smgpu_handle {
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
+    int deferN = 0, deferIter = 0;   // close the previous iteration inside the next geometry launch (k_geom_tile)
     bool smoothPersist = false; // SMGPU_SMOOTH_PERSIST=1: persistent, software-pipelined smoothing kernel (measured slower)
     bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
@@ -559,7 +560,8 @@ static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, i
         return;
     }
     hipLaunchKernelGGL(k_geom_tile<T>, dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                       tileList, nTiles, h->xcdMap);
+                       tileList, nTiles, h->xcdMap, h->deferN, h->deferIter);
+    h->deferN = 0;
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
@@ -954,6 +956,10 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     double* const buf0 = h->st.ptsCur;
     double* const buf1 = h->st.ptsNext;
     int launched = 0;
+    // relTol <= 0 cannot stop the loop (residual >= 0): the end-of-iteration reduction then rides in the next
+    // iteration's geometry launch instead of a launch of its own; the last iteration is closed by k_finish
+    const bool deferFinish = relTol <= 0.0 && h->useTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1);
+    h->deferN = 0;
     for (int i = 0; i < nIters; ++i) {
         if (runGeometry(h)) return 1;
         State s = h->st;
@@ -964,7 +970,8 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
         const int nPart = (fused && h->useTiles) ? h->stl.nTiles : gP;
-        if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
+        if (deferFinish && i + 1 < nIters) { h->deferN = nPart; h->deferIter = i; }
+        else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
         ++launched;
         // a positive relTol can stop the loop: poll the device flag now and then so a converged run
