@@ -1,0 +1,88 @@
+"""Randomised GPU-vs-oracle parity sweep (run on the GPU box): random block sizes, jitter up to near-inversion, random
+smoothing parameters, constraints, layer patches, serial and decomposed.  Prints one line per case; exit code 1 on the
+first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from oracle import oracle_ffi
+from smoothmesh_amd import LayerParams, SmoothEngine, default_params, patch_arrays
+from smoothmesh_amd.decompose import shared_point_table
+from smoothmesh_amd.halo import LocalMultiSmoother
+from smoothmesh_amd.meshgen import hex_block, hex_subdomain
+from smoothmesh_amd.polymesh import cavity_mesh
+
+n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+PATCHES = ["xmin", "xmax", "ymin", "ymax", "zmin", "zmax"]
+
+
+def params(mn):
+    over = dict(edgeAngleConstraint=bool(rng.integers(2)), faceAngleConstraint=bool(rng.integers(2)),
+                minAngle=float(rng.choice([15.0, 35.0, 50.0])), maxAngle=float(rng.choice([140.0, 160.0, 175.0])),
+                relStepFrac=float(rng.choice([0.3, 0.5, 0.9])), totalMinFreeze=bool(rng.integers(2)))
+    minEdge = float(rng.choice([0.3, 0.5, 0.9])) * mn
+    return default_params(mn, minEdgeLength=minEdge, maxStepLength=float(rng.choice([0.1, 0.3, 0.6])) * minEdge, **over)
+
+
+bad = 0
+for case in range(n_cases):
+    kind = rng.choice(["hex", "hex", "cavity", "multi", "multi"])
+    iters = int(rng.integers(2, 9))
+    layers = rng.random() < 0.5
+    lp = LayerParams(layerPatches=tuple(rng.choice(PATCHES, size=int(rng.integers(1, 4)), replace=False)),
+                     layerMaxBlendingFraction=float(rng.choice([0.2, 0.3, 0.6])), layerExpansionRatio=float(rng.choice([1.0, 1.2, 1.5])),
+                     minLayers=int(rng.integers(0, 3)), maxLayers=int(rng.integers(3, 6)))
+    jitter = float(rng.choice([0.1, 0.3, 0.45]))
+    seed = int(rng.integers(1 << 30))
+    if kind == "multi":
+        grid = tuple(int(x) for x in rng.choice([1, 2, 3], size=3))
+        if grid == (1, 1, 1):
+            grid = (2, 1, 1)
+        world = grid[0] * grid[1] * grid[2]
+        nloc = tuple(int(x) for x in rng.integers(3, 9, size=3))
+        subs = [hex_subdomain(nloc, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+        ms = LocalMultiSmoother(subs, device=0)
+        orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
+        mn = min(o.mesh_stats()[0] for o in orcs)
+        prm = params(mn)
+        ms.set_params(prm)
+        for o in orcs:
+            o.set_params(prm)
+        off, dom, loc = shared_point_table(subs)
+        mo = oracle_ffi.MultiOracle(orcs, off, dom, loc)
+        if layers:
+            on_o = mo.setup_layers([patch_arrays(s.mesh, lp.layerPatches) for s in subs], lp.layerMaxBlendingFraction, prm.minEdgeLength,
+                                   lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+            assert on_o == ms.set_layers(lp, prm.minEdgeLength)
+        n_o, res_o, frz_o = mo.iterate(iters, 0.0)
+        n_g, res_g, frz_g = ms.iterate(iters, 0.0)
+        a = np.concatenate(ms.get_points()); b = np.concatenate([o.points() for o in orcs])
+        desc = f"multi grid {grid} local {nloc}"
+    else:
+        if kind == "hex":
+            dims = tuple(int(x) for x in rng.integers(2, 14, size=3))
+            mesh = hex_block(*dims, jitter=jitter, seed=seed)
+            desc = f"hex {dims}"
+        else:
+            n = int(rng.integers(8, 15))
+            mesh = cavity_mesh(n, jitter=min(jitter, 0.3), seed=seed)
+            lp.layerPatches = ("cavity",) if rng.random() < 0.5 else lp.layerPatches
+            desc = f"cavity {n}"
+        o = oracle_ffi.Oracle(mesh); e = SmoothEngine(mesh)
+        prm = params(o.mesh_stats()[0])
+        o.set_params(prm); e.set_params(prm)
+        if layers:
+            st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches)
+            on_o = o.setup_layers(st, sz, kd, sel, lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+            assert on_o == e.set_layers(lp, prm.minEdgeLength)
+        n_o, res_o, frz_o = o.iterate(iters, 0.0)
+        n_g, res_g, frz_g = e.iterate(iters, 0.0)
+        a, b = e.get_points(), o.points()
+    fin = ~np.isnan(b)
+    ok = (n_o == n_g and np.array_equal(frz_o, frz_g) and np.array_equal(np.isnan(a), np.isnan(b)) and
+          (not fin.any() or np.max(np.abs(a[fin] - b[fin])) <= 1e-13 * max(1.0, np.max(np.abs(b[fin])))))
+    print(f"case {case:3d} {'ok ' if ok else 'BAD'} {desc} jitter {jitter} iters {iters} layers {lp.layerPatches if layers else '-'} "
+          f"ea {prm.edgeAngleConstraint} fa {prm.faceAngleConstraint} frozen {frz_o[-1]} maxdiff {np.max(np.abs(a[fin] - b[fin])) if fin.any() else 0:.2e}", flush=True)
+    bad += 0 if ok else 1
+sys.exit(1 if bad else 0)
