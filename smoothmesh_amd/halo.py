@@ -175,10 +175,11 @@ class DistributedSmoother:
         self.tables = HaloTables(self.rank, sub.pointProcAddressing, cands)
         if engine_factory is None:
             from .engine import SmoothEngine
-            # the engine computes on a stream of its own; torch's current stream carries the exchanges
-            engine = SmoothEngine(sub.mesh, device=device)          # computes on a stream of its own
-            self.xstream = torch.cuda.Stream(torch_device)           # communication stream
-            self.estream = torch.cuda.ExternalStream(engine.stream(), device=torch_device)
+            # two torch-owned streams: the engine computes on estream (handed over as its caller stream); the exchanges are
+            # enqueued on estream as well (in order) or on xstream (overlapped, ordered by the engine's events)
+            self.estream = torch.cuda.Stream(torch_device)
+            self.xstream = torch.cuda.Stream(torch_device)
+            engine = SmoothEngine(sub.mesh, device=device, stream=self.estream.cuda_stream)
             self.overlap = bool(overlap)
             xs = self.xstream.cuda_stream if self.overlap else None
         else:
