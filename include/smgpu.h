@@ -143,6 +143,10 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d);
 int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, void* exchangeStream);
 /* the hipStream_t the engine launches on (its own, or the caller's when useCallerStream was set) */
 int smgpu_get_stream(smgpu_handle* h, void** stream);
+/* optional: smgpu_iter_end additionally writes the iteration's {residual, nFrozenPoints} to record (n mod capacity) of
+ * this device array of 2*capacity doubles, n = number of smgpu_iter_end calls since this call -- a run that cannot
+ * stop early (relTol <= 0) then needs no per-iteration host action on localStats.  history = NULL switches it off. */
+int smgpu_halo_set_stats_history(smgpu_handle* h, void* history, int32_t capacity);
 int smgpu_iter_begin(smgpu_handle* h);   /* geometry + local partial sums / closest points -> sendA */
 int smgpu_iter_interior(smgpu_handle* h);/* optional, between begin and mid: everything that does not need
                                             recvA (points away from the shared ones) -- lets the host overlap

@@ -266,11 +266,18 @@ class OracleRankEngine:
     def iter_ahead(self):
         pass
 
+    def set_stats_history(self, ptr, capacity):
+        self._hist = (C.cast(ptr, f64p), int(capacity), 0) if ptr else None
+
     def iter_end(self):
         self._lib.orc_halo_orF(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), _p(self.combOffsets, i32p),
                                _p(self.combSlots, i32p), self.ptr["recvF"])
         self.o.phaseC()
         self._lib.orc_local_stats(self.o._h, self.ptr["localStats"])
+        if getattr(self, "_hist", None):
+            p, cap, n = self._hist
+            p[2 * (n % cap)], p[2 * (n % cap) + 1] = self.ptr["localStats"][0], self.ptr["localStats"][1]
+            self._hist = (p, cap, n + 1)
         self.o.commit()
 
     def get_points(self):

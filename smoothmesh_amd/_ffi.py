@@ -86,6 +86,7 @@ SYMBOLS = {
     "smgpu_iter_interior": (C.c_int, [C.c_void_p]),
     "smgpu_iter_mid": (C.c_int, [C.c_void_p]),
     "smgpu_iter_ahead": (C.c_int, [C.c_void_p]),
+    "smgpu_halo_set_stats_history": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
     "smgpu_set_layers": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p]),
     "smgpu_layers_begin": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p, c_i32p]),
     "smgpu_layers_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),

@@ -752,7 +752,8 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
 constexpr int kFinishBlock = 1024;
 // the reduction by one workgroup of T threads (all of them call it)
 template <int T>
-__device__ __forceinline__ void finishPartials(const State& s, int nPartials, int iter, double relTol, double* localStats) {
+__device__ __forceinline__ void finishPartials(const State& s, int nPartials, int iter, double relTol, double* localStats,
+                                               double* history = nullptr) {
     Accum* a = s.acc;
     __shared__ double shMax[T / 64];
     __shared__ int shCnt[T / 64];
@@ -782,14 +783,16 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     const double res = d;
     if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
+    if (history) { history[0] = res; history[1] = (double)c; }
     if (res < relTol) a->stop = 1;
     a->nActive = 0;
     a->nEaMaybe = 0;
     a->nFaMaybe = 0;
 }
-__global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats) {
+__global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats,
+                                                          double* history) {
     if (s.acc->stop) return;
-    finishPartials<kFinishBlock>(s, nPartials, iter, relTol, localStats);
+    finishPartials<kFinishBlock>(s, nPartials, iter, relTol, localStats, history);
 }
 
 // ---- multi-rank pack / combine -------------------------------------------------------------------

@@ -75,6 +75,9 @@ struct smgpu_handle {
     std::vector<uint8_t> lbInternal;
     int *sendF = nullptr, *recvF = nullptr;
     double* localStats = nullptr;
+    double* statsHistory = nullptr;      // smgpu_halo_set_stats_history: ring of {residual, nFrozenPoints} records
+    int32_t statsHistoryCap = 0;
+    int64_t statsHistoryN = 0;
     int haloIter = 0;
     int *dInteriorTiles = nullptr, *dSharedTiles = nullptr;   // smoothing tiles without / with shared points
     int nInteriorTiles = 0, nSharedTiles = 0;
@@ -971,7 +974,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
         }
         const int nPart = (fused && h->useTiles) ? h->stl.nTiles : gP;
         if (deferFinish && i + 1 < nIters) { h->deferN = nPart; h->deferIter = i; }
-        else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr); })) return 1;
+        else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
         ++launched;
         // a positive relTol can stop the loop: poll the device flag now and then so a converged run
@@ -1045,6 +1048,15 @@ int smgpu_reset_counters(smgpu_handle* h) {
 }
 
 // ---- multi-rank ----------------------------------------------------------------------------------
+int smgpu_halo_set_stats_history(smgpu_handle* h, void* history, int32_t capacity) {
+    if (!h) return fail("null handle");
+    if (history && capacity <= 0) return fail("smgpu_halo_set_stats_history: capacity must be positive");
+    h->statsHistory = (double*)history;
+    h->statsHistoryCap = history ? capacity : 0;
+    h->statsHistoryN = 0;
+    return 0;
+}
+
 int smgpu_get_stream(smgpu_handle* h, void** stream) {
     if (!h || !stream) return fail("null argument");
     *stream = (void*)h->stream;
@@ -1268,7 +1280,8 @@ int smgpu_iter_end(smgpu_handle* h) {
         nPart = gridFor(m.nPoints);
     }
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
-    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats); })) return 1;
+    double* hist = (h->statsHistory && h->statsHistoryCap > 0) ? h->statsHistory + 2 * (size_t)(h->statsHistoryN++ % h->statsHistoryCap) : nullptr;
+    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     h->interiorDone = false;

@@ -287,6 +287,10 @@ class SmoothEngine:
         self._check(self._lib.smgpu_get_stream(self._h, C.byref(out)))
         return out.value or 0
 
+    def set_stats_history(self, ptr, capacity):
+        """device array of 2*capacity doubles that iter_end fills record by record (None switches it off)"""
+        self._check(self._lib.smgpu_halo_set_stats_history(self._h, ptr, int(capacity)))
+
     def iter_begin(self):
         self._check(self._lib.smgpu_iter_begin(self._h))
 

@@ -336,6 +336,7 @@ class DistributedSmoother:
         # host read-back; every rank keeps its local {residual, nFrozenPoints} history on the device and the
         # all-rank values of the log line (SM.C:2396) come from ONE gather after the loop
         local = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
+        eng.set_stats_history(local.data_ptr(), n)      # iter_end fills record i: no per-iteration copy
         for i in range(centroidalIters):
             eng.iter_begin()
             if self.layers:
@@ -344,8 +345,8 @@ class DistributedSmoother:
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF, eng.iter_ahead)
             eng.iter_end()
-            local[i].copy_(st.localStats)
             done += 1
+        eng.set_stats_history(None, 0)
         if self._staged():
             allh = torch.empty((self.world, n, 2), dtype=torch.float64)
             self.dist.all_gather_into_tensor(allh.view(-1), local.cpu().view(-1))
