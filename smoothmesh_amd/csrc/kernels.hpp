@@ -871,12 +871,56 @@ constexpr int kMaxSharers = 16;
 
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
 // plusEqOp in ascending rank order; minMagSqrEqOp folds from the own value (ties keep own).
+// Points with more than two sharers (processor edges and corners: few) are left to k_halo_combineA_multi when skipMulti
+// is set: their per-sharer arrays live in scratch memory and a single lane walking them cost ~70 us per launch.
 __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
-                                                          const double* ownA, const double* recvA, double* combA, int* err) {
+                                                          const double* ownA, const double* recvA, double* combA, int* err,
+                                                          int skipMulti) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
     if (n > kMaxSharers) { *err = 2; return; }
+    if (n > 2 && skipMulti) return;
+    if (n == 2) {
+        // two sharers (a point inside a processor face: nearly all shared points): the same three sequential syncs with
+        // both ranks' views in scalars -- the general form below keeps per-sharer arrays, which live in scratch memory
+        const int s0 = combSlots[b], s1 = combSlots[b + 1];
+        const double* ra = ownA + (size_t)i * SMGPU_HALO_A_DOUBLES;                       // A = this rank
+        const double* rb = recvA + (size_t)(s0 < 0 ? s1 : s0) * SMGPU_HALO_A_DOUBLES;     // B = the other one
+        const bool selfFirst = s0 < 0;
+        const V3 sa = v3(ra[0], ra[1], ra[2]), sb = v3(rb[0], rb[1], rb[2]);
+        const V3 sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;    // plusEqOp, ascending rank
+        V3 a1 = v3(ra[3], ra[4], ra[5]), a2 = v3(ra[6], ra[7], ra[8]), a3 = v3(ra[9], ra[10], ra[11]);
+        V3 b1 = v3(rb[3], rb[4], rb[5]), b2 = v3(rb[6], rb[7], rb[8]), b3 = v3(rb[9], rb[10], rb[11]);
+        const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
+        const int cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
+        int hcA = (int)(pa >> 32), hcB = (int)(pb >> 32);
+        // minMagSqrEqOp folded from the own value: x = (magSqr(x) <= magSqr(y)) ? x : y
+#define SMGPU_FOLD2(X, Y) ((magSqr(X) <= magSqr(Y)) ? (X) : (Y))
+        {   // SM.C:397-419: both ranks exchange their first vectors
+            const V3 svA = SMGPU_FOLD2(a1, b1), svB = SMGPU_FOLD2(b1, a1);
+            if (isCloserPoint(svA, a1)) { a3 = a2; a2 = a1; a1 = svA; hcA = 0; }
+            if (isCloserPoint(svB, b1)) { b3 = b2; b2 = b1; b1 = svB; hcB = 0; }
+        }
+        {   // SM.C:424-445: the (updated) second vectors
+            const V3 svA = SMGPU_FOLD2(a2, b2), svB = SMGPU_FOLD2(b2, a2);
+            if (isCloserPoint(svA, a2)) { a3 = a2; a2 = svA; hcA = 0; }
+            if (isCloserPoint(svB, b2)) { b3 = b2; b2 = svB; hcB = 0; }
+        }
+        {   // SM.C:450-469: the (updated) third vectors
+            const V3 svA = SMGPU_FOLD2(a3, b3);
+            if (isCloserPoint(svA, a3)) a3 = svA;
+        }
+#undef SMGPU_FOLD2
+        double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+        const int any2 = hcA | hcB;
+        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+        o[3] = a1.x; o[4] = a1.y; o[5] = a1.z;
+        o[6] = a2.x; o[7] = a2.y; o[8] = a2.z;
+        o[9] = a3.x; o[10] = a3.y; o[11] = a3.z;
+        o[12] = __longlong_as_double(((long long)any2 << 32) | (long long)(unsigned int)cnt);
+        return;
+    }
     V3 r1[kMaxSharers], r2[kMaxSharers], r3[kMaxSharers];
     int hc[kMaxSharers];
     V3 sum = v3(0, 0, 0);
@@ -925,6 +969,66 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
     o[6] = r2[self].x; o[7] = r2[self].y; o[8] = r2[self].z;
     o[9] = r3[self].x; o[10] = r3[self].y; o[11] = r3[self].z;
     o[12] = __longlong_as_double(((long long)any << 32) | (long long)(unsigned int)cnt);
+}
+
+// The same three syncs for the shared points with 3..16 sharers, 16 lanes per point: lane j plays sharer j (ascending
+// rank), holds its three vectors in registers and reads the others' through wave shuffles.  multiIdx lists those points.
+__device__ __forceinline__ V3 shflV3(const V3& v, int src) {
+    return v3(__shfl(v.x, src, 16), __shfl(v.y, src, 16), __shfl(v.z, src, 16));
+}
+__global__ void __launch_bounds__(kBlock) k_halo_combineA_multi(int nMulti, const int* multiIdx, const int* combOff, const int* combSlots,
+                                                                const double* ownA, const double* recvA, double* combA) {
+    const int g = (blockIdx.x * kBlock + threadIdx.x) >> 4, j = threadIdx.x & 15;
+    const bool live = g < nMulti;
+    const int i = live ? multiIdx[g] : 0;
+    const int b = live ? combOff[i] : 0, n = live ? combOff[i + 1] - b : 0;
+    const bool mine = j < n;
+    const int sl = mine ? combSlots[b + j] : 0;
+    const double* r = (mine && sl < 0) ? ownA + (size_t)i * SMGPU_HALO_A_DOUBLES : recvA + (size_t)sl * SMGPU_HALO_A_DOUBLES;
+    V3 sv0 = v3(0, 0, 0), r1 = sv0, r2 = sv0, r3 = sv0;
+    int cntJ = 0, hc = 0;
+    if (mine) {
+        sv0 = v3(r[0], r[1], r[2]);
+        r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);
+        const long long pk = __double_as_longlong(r[12]);
+        cntJ = (int)(pk & 0xffffffffll);
+        hc = (int)(pk >> 32);
+    }
+    // plusEqOp in ascending rank order (every lane forms the same sum), count, or of the flags after the syncs
+    V3 sum = v3(0, 0, 0);
+    int cnt = 0;
+    for (int k = 0; k < 16; ++k) {
+        const V3 y = shflV3(sv0, k);
+        const int c = __shfl(cntJ, k, 16);
+        if (k < n) { sum = sum + y; cnt += c; }
+    }
+#define SMGPU_FOLD_ALL(SENT, OUT)                                                  \
+    {                                                                              \
+        V3 x_ = (SENT);                                                            \
+        for (int k = 0; k < 16; ++k) {                                             \
+            const V3 y_ = shflV3((SENT), k);                                       \
+            if (k < n && k != j) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;        \
+        }                                                                          \
+        (OUT) = x_;                                                                \
+    }
+    V3 sv;
+    SMGPU_FOLD_ALL(r1, sv)                       // SM.C:397-419
+    if (mine && isCloserPoint(sv, r1)) { r3 = r2; r2 = r1; r1 = sv; hc = 0; }
+    SMGPU_FOLD_ALL(r2, sv)                       // SM.C:424-445
+    if (mine && isCloserPoint(sv, r2)) { r3 = r2; r2 = sv; hc = 0; }
+    SMGPU_FOLD_ALL(r3, sv)                       // SM.C:450-469
+    if (mine && isCloserPoint(sv, r3)) r3 = sv;
+#undef SMGPU_FOLD_ALL
+    int any = 0;                                 // SM.C:472-478
+    for (int k = 0; k < 16; ++k) { const int f = __shfl(hc, k, 16); if (k < n) any |= f; }
+    if (mine && sl < 0) {
+        double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+        o[3] = r1.x; o[4] = r1.y; o[5] = r1.z;
+        o[6] = r2.x; o[7] = r2.y; o[8] = r2.z;
+        o[9] = r3.x; o[10] = r3.y; o[11] = r3.z;
+        o[12] = __longlong_as_double(((long long)any << 32) | (long long)(unsigned int)cnt);
+    }
 }
 
 // exchange F: isFrozenPoint of shared points, orEqOp (SM.C:2374-2380)
