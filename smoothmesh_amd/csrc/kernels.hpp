@@ -871,11 +871,20 @@ constexpr int kMaxSharers = 16;
 
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
 // plusEqOp in ascending rank order; minMagSqrEqOp folds from the own value (ties keep own).
-// Points with more than two sharers (processor edges and corners: few) are left to k_halo_combineA_multi when skipMulti
+// Points with more than two sharers (processor edges and corners: few) are left to combineMulti when skipMulti
 // is set: their per-sharer arrays live in scratch memory and a single lane walking them cost ~70 us per launch.
+__device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
+                                             const double* ownA, const double* recvA, double* combA);
+// The workgroups after the first nBlocksTwo handle the listed points with more than two sharers (combineMulti): one launch,
+// so that the latency of that small, dependent-load-bound part overlaps with the two-sharer part.
 __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
                                                           const double* ownA, const double* recvA, double* combA, int* err,
-                                                          int skipMulti) {
+                                                          int skipMulti, int nBlocksTwo, int nMulti, const int* multiIdx,
+                                                          const int* multiSlots) {
+    if ((int)blockIdx.x >= nBlocksTwo) {
+        combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
+        return;
+    }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
@@ -972,18 +981,23 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
 }
 
 // The same three syncs for the shared points with 3..16 sharers, 16 lanes per point: lane j plays sharer j (ascending
-// rank), holds its three vectors in registers and reads the others' through wave shuffles.  multiIdx lists those points.
-__device__ __forceinline__ V3 shflV3(const V3& v, int src) {
-    return v3(__shfl(v.x, src, 16), __shfl(v.y, src, 16), __shfl(v.z, src, 16));
-}
-__global__ void __launch_bounds__(kBlock) k_halo_combineA_multi(int nMulti, const int* multiIdx, const int* combOff, const int* combSlots,
-                                                                const double* ownA, const double* recvA, double* combA) {
-    const int g = (blockIdx.x * kBlock + threadIdx.x) >> 4, j = threadIdx.x & 15;
+// rank), holds its three vectors in registers and reads the others' values through LDS (wave shuffles of doubles were
+// measured ~4x slower here).  multiIdx lists those points.
+// multiSlots: 16 entries per listed point -- the recv slot of sharer j, -1 = this rank, -2 = no such sharer (one coalesced
+// load instead of the multiIdx -> combOff -> combSlots chain: this part is a handful of workgroups and latency bound)
+__device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
+                                             const double* ownA, const double* recvA, double* combA) {
+    __shared__ double shx[kBlock], shy[kBlock], shz[kBlock];
+    __shared__ int shi[kBlock];
+    const int t = threadIdx.x, g = (blk * kBlock + t) >> 4, j = t & 15, base = t & ~15;
     const bool live = g < nMulti;
+    const int sl = live ? multiSlots[g * 16 + j] : -2;
     const int i = live ? multiIdx[g] : 0;
-    const int b = live ? combOff[i] : 0, n = live ? combOff[i + 1] - b : 0;
-    const bool mine = j < n;
-    const int sl = mine ? combSlots[b + j] : 0;
+    const bool mine = sl > -2;
+    shi[t] = mine ? j + 1 : 0;
+    __syncthreads();
+    int n = 0;                                  // sharers occupy the first n lanes of the group
+    for (int k = 0; k < 16; ++k) n = shi[base + k] > n ? shi[base + k] : n;
     const double* r = (mine && sl < 0) ? ownA + (size_t)i * SMGPU_HALO_A_DOUBLES : recvA + (size_t)sl * SMGPU_HALO_A_DOUBLES;
     V3 sv0 = v3(0, 0, 0), r1 = sv0, r2 = sv0, r3 = sv0;
     int cntJ = 0, hc = 0;
@@ -994,22 +1008,22 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA_multi(int nMulti, cons
         cntJ = (int)(pk & 0xffffffffll);
         hc = (int)(pk >> 32);
     }
-    // plusEqOp in ascending rank order (every lane forms the same sum), count, or of the flags after the syncs
+#define SMGPU_PUBLISH(V, I) { __syncthreads(); shx[t] = (V).x; shy[t] = (V).y; shz[t] = (V).z; shi[t] = (I); __syncthreads(); }
+    // plusEqOp in ascending rank order (every lane forms the same sum), count
+    SMGPU_PUBLISH(sv0, cntJ)
     V3 sum = v3(0, 0, 0);
     int cnt = 0;
-    for (int k = 0; k < 16; ++k) {
-        const V3 y = shflV3(sv0, k);
-        const int c = __shfl(cntJ, k, 16);
-        if (k < n) { sum = sum + y; cnt += c; }
-    }
-#define SMGPU_FOLD_ALL(SENT, OUT)                                                  \
-    {                                                                              \
-        V3 x_ = (SENT);                                                            \
-        for (int k = 0; k < 16; ++k) {                                             \
-            const V3 y_ = shflV3((SENT), k);                                       \
-            if (k < n && k != j) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;        \
-        }                                                                          \
-        (OUT) = x_;                                                                \
+    for (int k = 0; k < n; ++k) { sum = sum + v3(shx[base + k], shy[base + k], shz[base + k]); cnt += shi[base + k]; }
+    // minMagSqrEqOp folded from the own value over the others in ascending rank order
+#define SMGPU_FOLD_ALL(SENT, OUT)                                                          \
+    {                                                                                      \
+        SMGPU_PUBLISH(SENT, 0)                                                             \
+        V3 x_ = (SENT);                                                                    \
+        for (int k = 0; k < n; ++k) {                                                      \
+            const V3 y_ = v3(shx[base + k], shy[base + k], shz[base + k]);                 \
+            if (k != j) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;                         \
+        }                                                                                  \
+        (OUT) = x_;                                                                        \
     }
     V3 sv;
     SMGPU_FOLD_ALL(r1, sv)                       // SM.C:397-419
@@ -1019,8 +1033,10 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA_multi(int nMulti, cons
     SMGPU_FOLD_ALL(r3, sv)                       // SM.C:450-469
     if (mine && isCloserPoint(sv, r3)) r3 = sv;
 #undef SMGPU_FOLD_ALL
-    int any = 0;                                 // SM.C:472-478
-    for (int k = 0; k < 16; ++k) { const int f = __shfl(hc, k, 16); if (k < n) any |= f; }
+    SMGPU_PUBLISH(sv0, hc)                       // SM.C:472-478
+#undef SMGPU_PUBLISH
+    int any = 0;
+    for (int k = 0; k < n; ++k) any |= shi[base + k];
     if (mine && sl < 0) {
         double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;

@@ -68,7 +68,8 @@ struct smgpu_handle {
     int *dSharedLocal = nullptr, *dSendShared = nullptr, *dCombOff = nullptr, *dCombSlots = nullptr, *dSharedSlot = nullptr;
     double *dOwnA = nullptr, *dCombA = nullptr;
     double *sendA = nullptr, *recvA = nullptr;
-    int* dMultiIdx = nullptr;            // shared points with 3..16 sharers (k_halo_combineA_multi)
+    int* dMultiSlots = nullptr;          // 16 per listed point: recv slot of each sharer, -1 this rank, -2 none
+    int* dMultiIdx = nullptr;            // shared points with 3..16 sharers (combineMulti, the trailing workgroups of k_halo_combineA)
     int nMulti = 0;
     double *dOwnL = nullptr, *dCombL = nullptr, *sendL = nullptr, *recvL = nullptr;   // boundary layer treatment under -parallel
     std::vector<int> sharedLocalHost;
@@ -1146,10 +1147,16 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         }
         h->nMulti = 0; h->dMultiIdx = nullptr;
         if (!tooMany) {      // otherwise the one-lane form handles every point (and reports > kMaxSharers)
+            std::vector<int> mslots(multi.size() * 16 + 16, -2);
+            for (size_t g = 0; g < multi.size(); ++g) {
+                const int i = multi[g];
+                for (int j = combOff[(size_t)i]; j < combOff[(size_t)i + 1]; ++j) mslots[g * 16 + (size_t)(j - combOff[(size_t)i])] = combSlots[(size_t)j];
+            }
             multi.push_back(0);   // never an empty upload; the extra entry is not counted
-            const int* pm = nullptr;
-            if (devUpload(h, &pm, multi)) return 1;
+            const int *pm = nullptr, *ps = nullptr;
+            if (devUpload(h, &pm, multi) || devUpload(h, &ps, mslots)) return 1;
             h->dMultiIdx = (int*)pm;
+            h->dMultiSlots = (int*)ps;
             h->nMulti = (int)multi.size() - 1;
         }
     }
@@ -1267,11 +1274,9 @@ int smgpu_iter_mid(smgpu_handle* h) {
     if (computeAfterExch(h)) return 1;      // exchange A has been enqueued by the host
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
-                hipLaunchKernelGGL(k_halo_combineA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
-                                   h->dCombSlots, h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0);
-                if (h->nMulti)
-                    hipLaunchKernelGGL(k_halo_combineA_multi, dim3(gridFor((int64_t)h->nMulti * 16)), dim3(kBlock), 0, h->stream, h->nMulti,
-                                       h->dMultiIdx, h->dCombOff, h->dCombSlots, h->dOwnA, h->recvA, h->dCombA);
+                const int nTwo = gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
+                hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
+                                   h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
                 if (h->layersOn)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                        h->dCombSlots, h->dOwnL, h->recvL, h->dCombL);
