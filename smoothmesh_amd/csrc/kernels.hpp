@@ -781,7 +781,7 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     if (threadIdx.x != 0) return;
     for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
     const double res = d;
-    if (s.stats) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
+    if (s.stats && iter >= 0) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
     if (history) { history[0] = res; history[1] = (double)c; }
     if (res < relTol) a->stop = 1;
@@ -797,9 +797,10 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials,
 
 // ---- multi-rank pack / combine -------------------------------------------------------------------
 // exchange A: local partial sums and closest points of the shared points (SM.C:108-131, 325-387)
-__global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, const int* sharedLocal, double* ownA, int nShared) {
+__global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, const int* sharedLocal, double* ownA, int nShared,
+                                                        const int* sendOff, const int* sendSlots, double* sendA) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    // own records first (one per shared point); k_halo_copyA then fills the send slots from them
+    // the own record (one per shared point) and its copies in the send slots of the point (one per other sharer)
     if (i < nShared) {
         const int p = sharedLocal[i];
         const V3 cur = ldv(s.ptsCur, p);
@@ -813,30 +814,30 @@ __global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, cons
         r[6] = L.r2.x; r[7] = L.r2.y; r[8] = L.r2.z;
         r[9] = L.r3.x; r[10] = L.r3.y; r[11] = L.r3.z;
         r[12] = __longlong_as_double(((long long)L.hc << 32) | (long long)(unsigned int)L.count);
+        for (int k = sendOff[i]; k < sendOff[i + 1]; ++k) {
+            double* q = sendA + (size_t)sendSlots[k] * SMGPU_HALO_A_DOUBLES;
+#pragma unroll
+            for (int j = 0; j < SMGPU_HALO_A_DOUBLES; ++j) q[j] = r[j];
+        }
     }
-}
-__global__ void __launch_bounds__(kBlock) k_halo_copyA(int nSend, const int* sendShared, const double* ownA, double* sendA) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nSend * SMGPU_HALO_A_DOUBLES) return;
-    const int slot = i / SMGPU_HALO_A_DOUBLES, j = i % SMGPU_HALO_A_DOUBLES;
-    sendA[i] = ownA[(size_t)sendShared[slot] * SMGPU_HALO_A_DOUBLES + j];
 }
 
 // boundary layer treatment under -parallel: per shared point the local normal and the local outer neighbour's current
 // coordinates (UNDEF_VECTOR when the neighbour is not in this rank, OBB.C:474-478)
-__global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* sharedLocal, double* ownL, int nShared) {
+__global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* sharedLocal, double* ownL, int nShared, const int* sendOff,
+                                                        const int* sendSlots, double* sendL) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int p = sharedLocal[i];
     const int q = s.layerMap[p];
-    stv(ownL, 2 * i, ldv(s.layerNormal, p));
-    stv(ownL, 2 * i + 1, q >= 0 ? ldv(s.ptsCur, q) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT));
-}
-__global__ void __launch_bounds__(kBlock) k_halo_copyL(int nSend, const int* sendShared, const double* ownL, double* sendL) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nSend * SMGPU_HALO_L_DOUBLES) return;
-    const int slot = i / SMGPU_HALO_L_DOUBLES, j = i % SMGPU_HALO_L_DOUBLES;
-    sendL[i] = ownL[(size_t)sendShared[slot] * SMGPU_HALO_L_DOUBLES + j];
+    const V3 nrm = ldv(s.layerNormal, p);
+    const V3 x = q >= 0 ? ldv(s.ptsCur, q) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+    stv(ownL, 2 * i, nrm);
+    stv(ownL, 2 * i + 1, x);
+    for (int k = sendOff[i]; k < sendOff[i + 1]; ++k) {
+        stv(sendL, 2 * sendSlots[k], nrm);
+        stv(sendL, 2 * sendSlots[k] + 1, x);
+    }
 }
 // plusEqOp in ascending rank order for the normals; minMagSqrEqOp folded from the own value for the coordinates
 __global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,

@@ -301,11 +301,12 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 // not need a launch of its own between the iterations (k_finish, ~6 us of launch latency per iteration).
 template <int T>
 __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
-                                                  int nLaunch, int xcdMap, int deferN, int deferIter) {
+                                                  int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
+                                                  double* deferHist) {
     if (s.acc->stop) return;
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
-    if (deferN > 0 && blockIdx.x == 0) { finishPartials<T>(s, deferN, deferIter, -1.0, nullptr); __syncthreads(); }
+    if (deferN > 0 && blockIdx.x == 0) { finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
     const GeomLds L = geomLds(lds, g);
     const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;

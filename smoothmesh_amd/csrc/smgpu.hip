@@ -66,6 +66,7 @@ struct smgpu_handle {
     bool haloOn = false;
     int nShared = 0, nSend = 0, nRecv = 0;
     int *dSharedLocal = nullptr, *dSendShared = nullptr, *dCombOff = nullptr, *dCombSlots = nullptr, *dSharedSlot = nullptr;
+    int *dSendOff = nullptr, *dSendSlots = nullptr;   // CSR: shared point -> its send slots
     double *dOwnA = nullptr, *dCombA = nullptr;
     double *sendA = nullptr, *recvA = nullptr;
     int* dMultiSlots = nullptr;          // 16 per listed point: recv slot of each sharer, -1 this rank, -2 none
@@ -122,6 +123,8 @@ struct smgpu_handle {
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
     int deferN = 0, deferIter = 0;   // close the previous iteration inside the next geometry launch (k_geom_tile)
+    double* deferLocal = nullptr;    // multi-rank: where that deferred reduction leaves {residual, nFrozenPoints}
+    double* deferHist = nullptr;
     bool smoothPersist = false; // SMGPU_SMOOTH_PERSIST=1: persistent, software-pipelined smoothing kernel (measured slower)
     bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
@@ -594,8 +597,9 @@ static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, i
         return;
     }
     hipLaunchKernelGGL(k_geom_tile<T>, dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                       tileList, nTiles, h->xcdMap, h->deferN, h->deferIter);
+                       tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     h->deferN = 0;
+    h->deferLocal = h->deferHist = nullptr;
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
@@ -967,6 +971,17 @@ static int checkDeviceError(smgpu_handle* h) {
     return 0;
 }
 
+// the end-of-iteration reduction left to the next geometry launch, when no such launch is coming
+static int flushDeferred(smgpu_handle* h) {
+    if (h->deferN <= 0) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, h->st, h->deferN, h->deferIter, -1.0, h->deferLocal, h->deferHist);
+    h->deferN = 0;
+    h->deferLocal = h->deferHist = nullptr;
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_stats* stats, int32_t* nDone) {
     if (!h) return fail("null handle");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
@@ -992,7 +1007,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     // relTol <= 0 cannot stop the loop (residual >= 0): the end-of-iteration reduction then rides in the next
     // iteration's geometry launch instead of a launch of its own; the last iteration is closed by k_finish
     const bool deferFinish = relTol <= 0.0 && h->useTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1);
-    h->deferN = 0;
+    if (flushDeferred(h)) return 1;
     for (int i = 0; i < nIters; ++i) {
         if (runGeometry(h)) return 1;
         State s = h->st;
@@ -1081,6 +1096,7 @@ int smgpu_reset_counters(smgpu_handle* h) {
 int smgpu_halo_set_stats_history(smgpu_handle* h, void* history, int32_t capacity) {
     if (!h) return fail("null handle");
     if (history && capacity <= 0) return fail("smgpu_halo_set_stats_history: capacity must be positive");
+    if (flushDeferred(h)) return 1;
     h->statsHistory = (double*)history;
     h->statsHistoryCap = history ? capacity : 0;
     h->statsHistoryN = 0;
@@ -1127,6 +1143,17 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         if (combOff[i + 1] - combOff[i] > kMaxSharers) return fail("halo: more than 16 ranks share a point");
     }
     for (int v : sendShared) if (v < 0 || v >= d->nShared) return fail("halo: sendShared out of range");
+    // send slots of each shared point (the pack kernels write the own record and its copies in one pass)
+    std::vector<int> sendOff((size_t)d->nShared + 1, 0), sendSlots((size_t)d->nSend + 1, 0);
+    for (int v : sendShared) ++sendOff[(size_t)v + 1];
+    for (int i = 0; i < d->nShared; ++i) sendOff[(size_t)i + 1] += sendOff[(size_t)i];
+    {
+        std::vector<int> fill(sendOff.begin(), sendOff.end() - 1);
+        for (int k = 0; k < d->nSend; ++k) sendSlots[(size_t)fill[(size_t)sendShared[(size_t)k]]++] = k;
+    }
+    const int *so = nullptr, *ss = nullptr;
+    if (devUpload(h, &so, sendOff) || devUpload(h, &ss, sendSlots)) return 1;
+    h->dSendOff = (int*)so; h->dSendSlots = (int*)ss;
     for (int v : combSlots) if (v < -1 || v >= d->nRecv) return fail("halo: combSlots out of range");
     const int *a = nullptr, *b = nullptr, *c = nullptr, *e = nullptr, *f = nullptr;
     if (devUpload(h, &a, sharedLocal) || devUpload(h, &b, sendShared) || devUpload(h, &c, combOff) ||
@@ -1234,16 +1261,11 @@ int smgpu_iter_begin(smgpu_handle* h) {
     const MeshView& m = h->mv;
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
-                hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared);
-                if (h->nSend)
-                    hipLaunchKernelGGL(k_halo_copyA, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_A_DOUBLES)), dim3(kBlock), 0, h->stream,
-                                       h->nSend, h->dSendShared, h->dOwnA, h->sendA);
-                if (h->layersOn) {          // local normals / outer neighbour coordinates (SM.C:2266, 2286)
-                    hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared);
-                    if (h->nSend)
-                        hipLaunchKernelGGL(k_halo_copyL, dim3(gridFor((int64_t)h->nSend * SMGPU_HALO_L_DOUBLES)), dim3(kBlock), 0, h->stream,
-                                           h->nSend, h->dSendShared, h->dOwnL, h->sendL);
-                }
+                hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
+                                   h->dSendOff, h->dSendSlots, h->sendA);
+                if (h->layersOn)            // local normals / outer neighbour coordinates (SM.C:2266, 2286)
+                    hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared,
+                                       h->dSendOff, h->dSendSlots, h->sendL);
             })) return 1;
     return exchAfterCompute(h);             // sendA (and sendL) complete: the exchange may start
 }
@@ -1317,10 +1339,11 @@ int smgpu_iter_end(smgpu_handle* h) {
     State s = h->st;
     const Prm prm = makePrm(h);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    const bool fusedTiles = fused && h->useTiles;
     if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
     s.stats = nullptr;                      // per-iteration results go to localStats in this mode
     int nPart;
-    if (fused && h->useTiles) {
+    if (fusedTiles) {
         // every non-shared point is already final; finish the shared ones (or of the freeze flags included)
         const int gS = gridFor(h->nShared);
         if (h->nShared)
@@ -1340,7 +1363,11 @@ int smgpu_iter_end(smgpu_handle* h) {
     }
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
     double* hist = (h->statsHistory && h->statsHistoryCap > 0) ? h->statsHistory + 2 * (size_t)(h->statsHistoryN++ % h->statsHistoryCap) : nullptr;
-    if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
+    // with a stats history nobody reads the record before the loop ends: the reduction then rides in the next geometry
+    // launch (first launch of smgpu_iter_begin) as in smgpu_iterate; flushDeferred closes the last iteration
+    if (hist && fusedTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
+        h->deferN = nPart; h->deferIter = -1 /* no stats[] record in this mode */; h->deferLocal = h->localStats; h->deferHist = hist;
+    } else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     h->interiorDone = false;
