@@ -198,6 +198,47 @@ int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enab
 int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg);
 int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);
 
+/* ---- optional boundary point smoothing (projection of boundary points to feature edges and target surfaces), serial --
+ * Replaces, for this feature, the set-up SM.C:2080-2253 (edge mesh sanity checks BPS.C:20-79, target edge strings
+ * BPS.C:446-587, classifyBoundaryPoints BPS.C:269-441, hop counts to the smoothing patches OBB.C:52-133, inner neighbour
+ * map OBB.C:396-459, target strings of the feature edge points SM.C:2234-2249) and, inside every later iteration,
+ * SM.C:2266 (calculateBoundaryPointNormals OBB.C:141-233), centroidalSmoothing of the boundary points too (SM.C:116),
+ * SM.C:2307-2357 (projectBoundaryPointsToEdgesAndSurfaces BPS.C:843-945, projectPrismaticInternalPointsToSurfaces
+ * OBB.C:573-631, third step clamp)  (BPS.C = src/boundaryPointSmoothing.C, OBB.C = src/orthogonalBoundaryBlending.C).
+ * Inputs are the contents of constant/geometry/{initEdges,targetEdges,targetSurfaces}.obj (SM.C:1924-1926) as flat
+ * arrays and, optionally, the isCornerPoint / isFeatureEdgePoint lists a previous run wrote (SM.C:2039-2077).
+ * OpenFOAM's octree line query is replaced by a bounding volume hierarchy; semantics in csrc/kernels_boundary.hpp.
+ * Call after smgpu_create and, when both are used, after smgpu_set_layers; before iterating.  Not available together
+ * with smgpu_halo_configure (the reference's -parallel syncs of this feature are not provided yet).
+ * info->enabled = the reference's doBoundarySmoothing (SM.C:2080-2093). */
+typedef struct smgpu_boundary_desc {
+    int32_t nPatches;
+    const int32_t* patchStart;         /* [nPatches] first face                                              */
+    const int32_t* patchSize;          /* [nPatches] number of faces                                         */
+    const uint8_t* patchKind;          /* [nPatches] 0 ordinary, 1 processor, 2 empty                        */
+    const uint8_t* isSmoothingPatch;   /* [nPatches] selected by -smoothingPatches (default all, SM.C:1837)  */
+    int32_t nInitEdgePoints;   const double* initEdgePoints;     /* [3 n] initEdges.obj                      */
+    int32_t nInitEdges;        const int32_t* initEdges;         /* [2 n]                                    */
+    int32_t nTargetEdgePoints; const double* targetEdgePoints;   /* targetEdges.obj; 0 edges = use initEdges */
+    int32_t nTargetEdges;      const int32_t* targetEdges;
+    int32_t nSurfacePoints;    const double* surfacePoints;      /* [3 n] targetSurfaces.obj                 */
+    int32_t nSurfaceTriangles; const int32_t* surfaceTriangles;  /* [3 n]                                    */
+    const int32_t* isCornerPointIO;        /* [nPoints] or NULL                                              */
+    const int32_t* isFeatureEdgePointIO;   /* [nPoints] or NULL                                              */
+    double distanceTolerance;                  /* SM.C:1921: REL_TOL * min(mesh min edge length, layerEdgeLength) */
+    double internalSmoothingBlendingFraction;  /* SM.C:1907, default 0                                       */
+} smgpu_boundary_desc;
+typedef struct smgpu_boundary_info {
+    int32_t enabled;
+    int32_t nCornerPoints, nFeatureEdgePoints, nSmoothingSurfacePoints, nFrozenSurfacePoints;   /* BPS.C:423-438 */
+    int32_t nTargetEdgeStrings;                                                                /* SM.C:2171      */
+} smgpu_boundary_info;
+int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info);
+/* the classification to persist as <time>/isCornerPoint and <time>/isFeatureEdgePoint (labelIOLists, SM.C:2039-2064) */
+int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, int32_t* isFeatureEdgePoint);
+/* parity access: nearest intersections of n segments (6 doubles each: start, end) with the target surface */
+int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit);
+
 /* ---- debug / parity access (device -> host copy of an internal field) -----------------------
  * name: "cellCentres" [3C], "faceCentres" [3F], "faceAreas" [3F], "newPoints" [3P] (proposal of the
  * last iteration before restore), "isFrozenPoint" [P], "edgeMinAngle"/"edgeMaxAngle" [E],

@@ -328,6 +328,73 @@ void orc_get_layer_fields(void* h, int* hops, int* outerMap, double* normals, un
     }
 }
 
+// boundary point smoothing (serial), SM.C:2080-2253: patches + layer options as orc_setup_layers, edge meshes and target
+// surface as flat arrays (targetEdges may be empty: the initial edges are then the target, SM.C:2154-2160), the
+// classification lists of a previous run or NULL.  Returns doBoundarySmoothing, -1 on the reference's FatalErrors.
+int orc_setup_boundary(void* h, int nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
+                       const unsigned char* isSmoothing, double layerMaxBlendingFraction, double layerEdgeLength,
+                       double layerExpansionRatio, int minLayers, int maxLayers, int nInitPts, const double* initPts, int nInitEdges,
+                       const int* initEdges, int nTgtPts, const double* tgtPts, int nTgtEdges, const int* tgtEdges, int nSurfPts,
+                       const double* surfPts, int nTris, const int* tris, const int* cornerIO, const int* featureIO,
+                       double internalSmoothingBlendingFraction) {
+    Domain* d = static_cast<Domain*>(h);
+    std::vector<Patch> p((size_t)nPatches);
+    for (int i = 0; i < nPatches; ++i) {
+        p[i].start = start[i]; p[i].size = size[i]; p[i].kind = kind[i];
+        p[i].isLayerPatch = isLayer[i] != 0; p[i].isSmoothingPatch = isSmoothing[i] != 0;
+    }
+    LayerParams lp;
+    lp.layerMaxBlendingFraction = layerMaxBlendingFraction;
+    lp.layerEdgeLength = layerEdgeLength;
+    lp.layerExpansionRatio = layerExpansionRatio;
+    lp.minLayers = minLayers;
+    lp.maxLayers = maxLayers;
+    BoundaryInput in;
+    auto fillEdges = [](EdgeMesh& em, int nP, const double* pts, int nE, const int* e) {
+        em.points.resize((size_t)nP);
+        for (int i = 0; i < nP; ++i) em.points[(size_t)i] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        em.edges.resize((size_t)nE);
+        for (int i = 0; i < nE; ++i) em.edges[(size_t)i] = {e[2 * i], e[2 * i + 1]};
+    };
+    fillEdges(in.initEdges, nInitPts, initPts, nInitEdges, initEdges);
+    fillEdges(in.targetEdges, nTgtPts, tgtPts, nTgtEdges, tgtEdges);
+    in.surf.points.resize((size_t)nSurfPts);
+    for (int i = 0; i < nSurfPts; ++i) in.surf.points[(size_t)i] = {surfPts[3 * i], surfPts[3 * i + 1], surfPts[3 * i + 2]};
+    in.surf.tris.resize((size_t)nTris);
+    for (int i = 0; i < nTris; ++i) in.surf.tris[(size_t)i] = {tris[3 * i], tris[3 * i + 1], tris[3 * i + 2]};
+    if (cornerIO) in.isCornerPointIO.assign(cornerIO, cornerIO + d->nPoints);
+    if (featureIO) in.isFeatureEdgePointIO.assign(featureIO, featureIO + d->nPoints);
+    in.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
+    d->setupBoundary(p, lp, in);
+    if (!d->error.empty()) return -1;
+    return d->doBoundarySmoothing ? 1 : 0;
+}
+void orc_get_boundary_fields(void* h, unsigned char* isCorner, unsigned char* isFeature, unsigned char* isSmoothingSurface,
+                             unsigned char* isSharp, double* cornerPoints, int* pointStrings, int* innerMap, int* hopsSmoothing,
+                             double* normals) {
+    Domain* d = static_cast<Domain*>(h);
+    for (int p = 0; p < d->nPoints; ++p) {
+        isCorner[p] = d->isCornerPoint[p]; isFeature[p] = d->isFeatureEdgePoint[p];
+        isSmoothingSurface[p] = d->isSmoothingSurfacePoint[p]; isSharp[p] = d->isSharpEdgePoint[p];
+        cornerPoints[3 * p] = d->cornerPoints[p].x; cornerPoints[3 * p + 1] = d->cornerPoints[p].y; cornerPoints[3 * p + 2] = d->cornerPoints[p].z;
+        pointStrings[p] = d->pointStrings[p]; innerMap[p] = d->pointToInnerPointMap[p]; hopsSmoothing[p] = d->pointHopsToSmoothingBoundary[p];
+        normals[3 * p] = d->pointNormals[p].x; normals[3 * p + 1] = d->pointNormals[p].y; normals[3 * p + 2] = d->pointNormals[p].z;
+    }
+}
+int orc_get_edge_strings(void* h, int* out) {
+    Domain* d = static_cast<Domain*>(h);
+    if (out) for (size_t i = 0; i < d->targetEdgeStrings.size(); ++i) out[i] = d->targetEdgeStrings[i];
+    return (int)d->targetEdgeStrings.size();
+}
+// nearest hit of a segment with the target surface (Domain::findLine); returns 1 on a hit
+int orc_find_line(void* h, const double* start, const double* end, double* hitPoint) {
+    Domain* d = static_cast<Domain*>(h);
+    bool hit;
+    const Vec3 r = d->findLine({start[0], start[1], start[2]}, {end[0], end[1], end[2]}, hit);
+    hitPoint[0] = r.x; hitPoint[1] = r.y; hitPoint[2] = r.z;
+    return hit ? 1 : 0;
+}
+
 // MultiDomain variant: patches of all domains concatenated, nPatches[d] per domain
 void orc_multi_setup_layers(void* mh, const int* nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
                             double layerMaxBlendingFraction, double layerEdgeLength, double layerExpansionRatio, int minLayers,

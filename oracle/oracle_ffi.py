@@ -71,6 +71,14 @@ def lib():
         l.orc_layers_enabled.restype = C.c_int
         l.orc_layers_enabled.argtypes = [C.c_void_p]
         l.orc_get_layer_fields.argtypes = [C.c_void_p, i32p, i32p, f64p, u8p, u8p]
+        l.orc_setup_boundary.restype = C.c_int
+        l.orc_setup_boundary.argtypes = ([C.c_void_p, C.c_int, i32p, i32p, i32p, u8p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+                                         + [C.c_int, f64p, C.c_int, i32p] * 2 + [C.c_int, f64p, C.c_int, i32p, i32p, i32p, C.c_double])
+        l.orc_get_boundary_fields.argtypes = [C.c_void_p, u8p, u8p, u8p, u8p, f64p, i32p, i32p, i32p, f64p]
+        l.orc_get_edge_strings.restype = C.c_int
+        l.orc_get_edge_strings.argtypes = [C.c_void_p, i32p]
+        l.orc_find_line.restype = C.c_int
+        l.orc_find_line.argtypes = [C.c_void_p, f64p, f64p, f64p]
         _lib = l
     return _lib
 
@@ -122,6 +130,52 @@ class Oracle:
         self._lib.orc_setup_layers(self._h, len(st), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p),
                                    layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers)
         return bool(self._lib.orc_layers_enabled(self._h))
+
+    def setup_boundary(self, start, size, kind, isLayer, isSmoothing, layer, initEdges, targetEdges, surf, cornerIO=None,
+                       featureIO=None, internalSmoothingBlendingFraction=0.0):
+        """boundary point smoothing set-up SM.C:2080-2253 (serial).  layer = (layerMaxBlendingFraction, layerEdgeLength,
+        layerExpansionRatio, minLayers, maxLayers); initEdges / targetEdges = (points (n,3), edges (m,2)) or None;
+        surf = (points (n,3), triangles (m,3)).  Returns doBoundarySmoothing."""
+        st, sz = np.ascontiguousarray(start, np.int32), np.ascontiguousarray(size, np.int32)
+        kd, il = np.ascontiguousarray(kind, np.int32), np.ascontiguousarray(isLayer, np.uint8)
+        ism = np.ascontiguousarray(isSmoothing, np.uint8)
+        def pe(m):
+            if m is None:
+                return np.zeros((0, 3), np.float64), np.zeros((0, 2), np.int32)
+            return np.ascontiguousarray(m[0], np.float64).reshape(-1, 3), np.ascontiguousarray(m[1], np.int32)
+        ip, ie = pe(initEdges); tp, te = pe(targetEdges); sp, stri = pe(surf)
+        cio = None if cornerIO is None else np.ascontiguousarray(cornerIO, np.int32)
+        fio = None if featureIO is None else np.ascontiguousarray(featureIO, np.int32)
+        rc = self._lib.orc_setup_boundary(self._h, len(st), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p), _p(ism, u8p),
+                                          float(layer[0]), float(layer[1]), float(layer[2]), int(layer[3]), int(layer[4]),
+                                          len(ip), _p(ip, f64p), len(ie), _p(ie, i32p), len(tp), _p(tp, f64p), len(te), _p(te, i32p),
+                                          len(sp), _p(sp, f64p), len(stri), _p(stri, i32p),
+                                          None if cio is None else _p(cio, i32p), None if fio is None else _p(fio, i32p),
+                                          float(internalSmoothingBlendingFraction))
+        if rc < 0:
+            raise RuntimeError(self._lib.orc_last_error(self._h).decode())
+        return bool(rc)
+
+    def boundary_fields(self):
+        n = self.nPoints
+        u8 = lambda: np.empty(n, np.uint8)
+        i32 = lambda: np.empty(n, np.int32)
+        co, fe, ss, sh = u8(), u8(), u8(), u8()
+        cp, nrm = np.empty((n, 3), np.float64), np.empty((n, 3), np.float64)
+        ps, im, hs = i32(), i32(), i32()
+        self._lib.orc_get_boundary_fields(self._h, _p(co, u8p), _p(fe, u8p), _p(ss, u8p), _p(sh, u8p), _p(cp, f64p), _p(ps, i32p),
+                                          _p(im, i32p), _p(hs, i32p), _p(nrm, f64p))
+        ne = self._lib.orc_get_edge_strings(self._h, None)
+        es = np.empty(max(ne, 1), np.int32)
+        self._lib.orc_get_edge_strings(self._h, _p(es, i32p))
+        return dict(isCornerPoint=co, isFeatureEdgePoint=fe, isSmoothingSurfacePoint=ss, isSharpEdgePoint=sh, cornerPoints=cp,
+                    pointStrings=ps, innerMap=im, hopsToSmoothingBoundary=hs, normals=nrm, targetEdgeStrings=es[:ne])
+
+    def find_line(self, start, end):
+        a, pa = _v(start); b, pb = _v(end)
+        out = np.empty(3, np.float64)
+        hit = self._lib.orc_find_line(self._h, pa, pb, _p(out, f64p))
+        return bool(hit), out
 
     def layer_fields(self):
         n = self.nPoints

@@ -6,6 +6,7 @@
 //
 // Every function cites the reference lines it follows (SM.C = src/smoothMesh.C).
 #include "smooth_oracle.hpp"
+#include "oracle_vec.hpp"
 
 #include <algorithm>
 #include <cfloat>
@@ -15,24 +16,6 @@
 #include <stack>
 
 namespace orc {
-
-// ---- OpenFOAM Vector<double> algebra (VectorI.H / VectorSpaceI.H semantics) ----------
-static inline Vec3 operator+(const Vec3& a, const Vec3& b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
-static inline Vec3 operator-(const Vec3& a, const Vec3& b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
-static inline Vec3 operator*(double s, const Vec3& a) { return {s * a.x, s * a.y, s * a.z}; }
-static inline Vec3 operator/(const Vec3& a, double s) { return {a.x / s, a.y / s, a.z / s}; }
-static inline Vec3& operator+=(Vec3& a, const Vec3& b) { a.x += b.x; a.y += b.y; a.z += b.z; return a; }
-static inline Vec3& operator/=(Vec3& a, double s) { a.x /= s; a.y /= s; a.z /= s; return a; }
-static inline bool operator==(const Vec3& a, const Vec3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
-static inline bool operator!=(const Vec3& a, const Vec3& b) { return !(a == b); }
-static inline double dot(const Vec3& a, const Vec3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // operator&
-static inline Vec3 cross(const Vec3& a, const Vec3& b) {                                              // operator^
-    return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
-}
-static inline double magSqr(const Vec3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-static inline double mag(const Vec3& a) { return std::sqrt(magSqr(a)); }
-static const Vec3 ZERO_VECTOR{0.0, 0.0, 0.0};          // COM.H:16
-static const Vec3 UNDEF_VECTOR{GREAT, GREAT, GREAT};   // COM.H:15
 
 // SM.C:172-180
 static inline double getPointDistance(const Vec3& coords1, const Vec3& coords2) {
@@ -316,7 +299,6 @@ static double calcARSmoothingRatio(const Vec3& closestPoint1, const Vec3& closes
 }
 
 // ---- boundary layer treatment: setup (serial) ---------------------------------------------------------
-static inline Vec3& operator-=(Vec3& a, const Vec3& b) { a.x -= b.x; a.y -= b.y; a.z -= b.z; return a; }
 
 // OBB.C:141-233.  Note the reference never resets pointNormals: a boundary point's new normal is the
 // normalised sum of its previous (unit) normal and the inverted unit normals of its boundary faces, and every
@@ -468,13 +450,13 @@ void Domain::phaseA() {
     updateGeometry();
     // SM.C:2266 "Recalculate point normals" (the reference does it whether or not a treatment is enabled;
     // the normals are only consumed by the layer treatment here)
-    if (doLayerTreatment) layersNormalsAccumulate();   // MultiDomain::syncLayers follows (OBB.C:184-198); finish in phaseB
+    if (doLayerTreatment || doBoundarySmoothing) layersNormalsAccumulate();   // MultiDomain::syncLayers follows (OBB.C:184-198); finish in phaseB
 
-    // SM.C:108-131 (doBoundarySmoothing == false: internal points only)
+    // SM.C:108-131 (internal points only unless doBoundarySmoothing, SM.C:116)
     cellSum.assign(nPoints, ZERO_VECTOR);
     cellCount.assign(nPoints, 0);
     for (int pointI = 0; pointI < nPoints; ++pointI) {
-        if (!isInternalPoint[pointI]) continue;
+        if ((!doBoundarySmoothing) && (!isInternalPoint[pointI])) continue;
         const std::vector<int>& pCells = pointCells[pointI];
         cellCount[pointI] = int(pCells.size());
         for (int celli : pCells) cellSum[pointI] += cellCentres[celli];
@@ -597,7 +579,7 @@ void Domain::calcMinMaxFaceAngleForPoint(int pointI1, const Vec3& coords1, int p
 
 void Domain::phaseB() {
     const std::vector<Vec3>& mp = points;
-    if (doLayerTreatment) layersNormalsFinish();   // OBB.C:201-230, after the plusEq syncs
+    if (doLayerTreatment || doBoundarySmoothing) layersNormalsFinish();   // OBB.C:201-230, after the plusEq syncs
 
     // SM.C:150-163
     centroidalPoints = points;
@@ -664,6 +646,12 @@ void Domain::phaseB() {
             const Vec3 nCoords = cCoords + (prm.relStepFrac * globalScale) * stepDir;
             newPoints[pointI] = nCoords;
         }
+    }
+
+    // SM.C:2307-2357 optional boundary point smoothing
+    if (doBoundarySmoothing) {
+        projectBoundaryPoints();
+        if (!error.empty()) return;
     }
 
     // SM.C:602-652 restrictEdgeShortening

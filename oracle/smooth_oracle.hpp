@@ -50,6 +50,27 @@ struct Patch {
     int start = 0, size = 0;   // face range
     int kind = 0;              // 0 ordinary, 1 processor, 2 empty (skipped by OBB.C:156-159)
     bool isLayerPatch = false; // selected by -layerPatches (SM.C:1823)
+    bool isSmoothingPatch = false;   // selected by -smoothingPatches (SM.C:1837-1842; default: all patches)
+};
+
+// OpenFOAM edgeMesh as the boundary point smoothing uses it: points, edges, pointEdges (ascending edge ids)
+struct EdgeMesh {
+    std::vector<Vec3> points;
+    std::vector<std::array<int, 2>> edges;
+    std::vector<std::vector<int>> pointEdges;
+    void buildPointEdges();
+};
+struct TriSurface {
+    std::vector<Vec3> points;
+    std::vector<std::array<int, 3>> tris;
+};
+// inputs of the optional boundary point smoothing: constant/geometry/{initEdges,targetEdges,targetSurfaces}.obj
+// (SM.C:1924-1926) and the classification lists a previous run left (SM.C:2039-2077; empty = no data)
+struct BoundaryInput {
+    EdgeMesh initEdges, targetEdges;
+    TriSurface surf;
+    std::vector<int> isCornerPointIO, isFeatureEdgePointIO;
+    double internalSmoothingBlendingFraction = 0.0;   // SM.C:1907
 };
 
 // boundary layer treatment options, defaults SM.C:1892-1905
@@ -119,6 +140,24 @@ public:
     void layersPropagateSweep(int iter);    // OBB.C:276-353 (one sweep, before the maxMagSqr sync :359-365)
     void layersUndo();                      // OBB.C:370-379
     void layersUpdateNeighCoords();         // OBB.C:471-486 (before the minMagSqr sync :490-496)
+
+    // optional boundary point smoothing (serial): set-up SM.C:2080-2253, per iteration SM.C:2266-2269, 2307-2357
+    // (BPS.C = src/boundaryPointSmoothing.C, OBB.C = src/orthogonalBoundaryBlending.C).  The ray query of
+    // OpenFOAM's indexedOctree (findLine) is third-party code absent from the reference tree: restated as "nearest
+    // hit along the segment" with OpenFOAM's triangle::intersection (Moller-Trumbore, HALF_RAY, tolerance
+    // indexedOctree::perturbTol = 10*SMALL), ties to the lowest triangle id.
+    bool doBoundarySmoothing = false;
+    BoundaryInput bnd;
+    double distanceTolerance = 0.0, meshMinEdgeLength = 0.0, meshPerimeter = 0.0;
+    std::vector<int> targetEdgeStrings, pointStrings;
+    std::vector<unsigned char> isFeatureEdgePoint, isCornerPoint, isFrozenSurfacePoint, isInnerNeighInProc;
+    std::vector<int> isCornerPointOut, isFeatureEdgePointOut;   // the labelIOLists written back (BPS.C:370-379)
+    std::vector<Vec3> cornerPoints, innerNeighCoords;
+    std::vector<int> pointHopsToSmoothingBoundary, pointToInnerPointMap;
+    void setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, const BoundaryInput& in);
+    Vec3 findLine(const Vec3& start, const Vec3& end, bool& hit) const;
+    Vec3 findIntersection(const Vec3& origPoint, const Vec3& pointNormal, double searchDistance) const;   // BPS.C:682-745
+    void projectBoundaryPoints();     // BPS.C:843-945 + OBB.C:573-631 + SM.C:2356
 
     void build();  // addressing from faces/owner/neighbour
     void meshStats(double& minEdge, double& maxEdge) const;  // SM.C:1478-1541

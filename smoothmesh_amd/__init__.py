@@ -7,4 +7,4 @@ path runs in csrc/libsmgpu.so (hand-written HIP); there is no CPU fallback: load
 the library has not been built.
 """
 from .mesh import PolyMesh, Patch  # noqa: F401
-from .engine import LayerParams, SmoothEngine, SmoothParams, SmgpuError, default_params, patch_arrays  # noqa: F401
+from .engine import BoundaryParams, LayerParams, SmoothEngine, SmoothParams, SmgpuError, default_params, patch_arrays  # noqa: F401

@@ -66,6 +66,22 @@ class LayerDesc(C.Structure):
     ]
 
 
+class BoundaryDesc(C.Structure):
+    _fields_ = [
+        ("nPatches", C.c_int32), ("patchStart", c_i32p), ("patchSize", c_i32p), ("patchKind", c_u8p), ("isSmoothingPatch", c_u8p),
+        ("nInitEdgePoints", C.c_int32), ("initEdgePoints", c_f64p), ("nInitEdges", C.c_int32), ("initEdges", c_i32p),
+        ("nTargetEdgePoints", C.c_int32), ("targetEdgePoints", c_f64p), ("nTargetEdges", C.c_int32), ("targetEdges", c_i32p),
+        ("nSurfacePoints", C.c_int32), ("surfacePoints", c_f64p), ("nSurfaceTriangles", C.c_int32), ("surfaceTriangles", c_i32p),
+        ("isCornerPointIO", c_i32p), ("isFeatureEdgePointIO", c_i32p),
+        ("distanceTolerance", C.c_double), ("internalSmoothingBlendingFraction", C.c_double),
+    ]
+
+
+class BoundaryInfo(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("nCornerPoints", C.c_int32), ("nFeatureEdgePoints", C.c_int32),
+                ("nSmoothingSurfacePoints", C.c_int32), ("nFrozenSurfacePoints", C.c_int32), ("nTargetEdgeStrings", C.c_int32)]
+
+
 # every symbol include/smgpu.h declares: (restype, argtypes)
 SYMBOLS = {
     "smgpu_last_error": (C.c_char_p, []),
@@ -91,6 +107,9 @@ SYMBOLS = {
     "smgpu_layers_begin": (C.c_int, [C.c_void_p, C.POINTER(LayerDesc), c_i32p, c_i32p]),
     "smgpu_layers_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "smgpu_layers_shared": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_f64p]),
+    "smgpu_set_boundary_smoothing": (C.c_int, [C.c_void_p, C.POINTER(BoundaryDesc), C.POINTER(BoundaryInfo)]),
+    "smgpu_get_boundary_classification": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
+    "smgpu_debug_find_line": (C.c_int, [C.c_void_p, C.c_int32, c_f64p, c_f64p, c_i32p]),
     "smgpu_halo_set_exchange_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "smgpu_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),

@@ -1,0 +1,71 @@
+// boundary.hpp -- one-off host set-up of the optional boundary point smoothing.
+//
+// Replaces the reference's preparation SM.C:2080-2253 for this feature: sanity checks of the feature edge meshes
+// (BPS.C:20-79), the edge strings of the target edge mesh (BPS.C:446-587), classifyBoundaryPoints with corner and
+// feature edge detection (BPS.C:269-441), the hop counts to the smoothing patches (OBB.C:52-133 with maxIter 2), the
+// inner neighbour map (OBB.C:396-459) and the target string of every feature edge point (SM.C:2234-2249)
+// (BPS.C = src/boundaryPointSmoothing.C, OBB.C = src/orthogonalBoundaryBlending.C).  The per-iteration part
+// (SM.C:2266, 2307-2357) runs in kernels_boundary.hpp.
+//
+// OpenFOAM's indexedOctree<treeDataTriSurface> (third-party, not in the reference tree) is replaced by a bounding
+// volume hierarchy over the target triangles; the query semantics are stated in kernels_boundary.hpp (findLine).
+// Serial runs only: under -parallel the reference synchronises normals, feature projections and inner neighbour
+// coordinates over the processor patches, which this round does not provide.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "topology.hpp"
+
+namespace smgpu {
+
+struct BndPatch {
+    int32_t start, size;   // face range of the patch
+    int32_t kind;          // 0 ordinary, 1 processor, 2 empty
+    bool isSmoothing;      // selected by -smoothingPatches (default: every patch, SM.C:1837-1840)
+};
+
+// OpenFOAM edgeMesh: points, edges, pointEdges (ascending edge ids per point)
+struct EdgeMeshHost {
+    std::vector<double> pts;        // 3 per point
+    std::vector<int32_t> edges;     // 2 per edge
+    std::vector<std::vector<int32_t>> pointEdges;
+    int32_t nPoints() const { return (int32_t)(pts.size() / 3); }
+    int32_t nEdges() const { return (int32_t)(edges.size() / 2); }
+    void buildPointEdges();
+};
+
+struct BoundaryInputHost {
+    EdgeMeshHost initEdges, targetEdges;   // targetEdges empty: the initial edges are the target (SM.C:2154-2160)
+    std::vector<double> surfPts;           // 3 per point
+    std::vector<int32_t> surfTris;         // 3 per triangle
+    const int32_t* isCornerPointIO = nullptr;        // per mesh point, from a previous run (SM.C:2039-2077), or NULL
+    const int32_t* isFeatureEdgePointIO = nullptr;
+    double distanceTolerance = 0.0;        // SM.C:1921
+    double meshMinEdgeLength = 0.0, meshPerimeter = 0.0;   // getMeshStats SM.C:1478-1541
+};
+
+struct Bvh {
+    std::vector<double> box;       // 6 per node: min xyz, max xyz (inflated: the traversal is conservative)
+    std::vector<int32_t> link;     // 2 per node: children (left, right), or (-(first + 1), count) for a leaf
+    std::vector<double> triVerts;  // 9 per triangle, leaf order
+    std::vector<int32_t> triId;    // original triangle id, leaf order
+    void build(const std::vector<double>& pts, const std::vector<int32_t>& tris);
+};
+
+struct BoundarySetup {
+    bool enabled = false;          // doBoundarySmoothing, SM.C:2080-2093
+    std::vector<uint8_t> isConnectedToInternalPoint, isCornerPoint, isFeatureEdgePoint, isSmoothingSurfacePoint, isFrozenSurfacePoint;
+    std::vector<int32_t> isCornerPointOut, isFeatureEdgePointOut;   // the labelIOLists to write back
+    std::vector<double> cornerPoints;              // 3 per point (GREAT = none)
+    std::vector<int32_t> pointStrings, hopsToSmoothingBoundary, innerMap, targetEdgeStrings;
+    EdgeMeshHost target;                           // the resolved target edge mesh
+    int32_t nCorner = 0, nFeature = 0, nSmoothingSurface = 0, nFrozenSurface = 0;
+};
+
+// points: the coordinates the set-up is made for (3 per mesh point).  Returns the reference's FatalError text, or "".
+std::string buildBoundarySetup(const Topology& t, const uint8_t* isInternalPoint, const double* points,
+                               const std::vector<BndPatch>& patches, const BoundaryInputHost& in, BoundarySetup& out);
+
+}  // namespace smgpu

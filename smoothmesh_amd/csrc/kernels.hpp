@@ -70,6 +70,7 @@ struct Prm {
     int totalMinFreeze;
     double smallAngle, largeAngle;   // M_PI * deg / 180.0  (SM.C:921, 1364-1365)
     int layersOn;                    // boundary layer treatment enabled (SM.C:2024-2028)
+    int bndOn;                       // boundary point smoothing enabled (SM.C:2080-2093): kernels_boundary.hpp
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -176,11 +177,11 @@ __device__ __forceinline__ bool shareCell(const MeshView& m, int q1, int q2) {
 }
 
 __device__ __forceinline__ void pointLocal(const MeshView& m, const State& s, int p, const V3& cur, bool internal,
-                                           PointLocal& L, int& err) {
-    // SM.C:116-130: only internal points gather (doBoundarySmoothing == false)
+                                           PointLocal& L, int& err, bool centroidAll = false) {
+    // SM.C:116-130: only internal points gather unless doBoundarySmoothing (centroidAll)
     L.sum = v3(0, 0, 0);
     L.count = 0;
-    if (internal) {
+    if (internal || centroidAll) {
         const int b = m.pcOff[p], e = m.pcOff[p + 1];
         L.count = e - b;
         for (int k = b; k < e; ++k) L.sum = L.sum + ldv(s.cellCtr, m.pcVal[k]);
@@ -280,8 +281,11 @@ __device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, 
     V3 n = (slot >= 0) ? ldv(s.combL, 2 * slot) : ldv(s.layerNormal, p);
     const V3 z = v3(0, 0, 0);
     if (n != z) {
-        n = n / mag(n);
-        stv(s.layerNormal, p, n);
+        // with boundary point smoothing k_bnd_normals has already recomputed the boundary points' normals this iteration
+        if (!(prm.bndOn && !internal)) {
+            n = n / mag(n);
+            stv(s.layerNormal, p, n);
+        }
         const int hops = s.layerHops[p];
         if (internal && hops >= 1) {
             const V3 outer = (slot >= 0) ? ldv(s.combL, 2 * slot + 1) : ldv(s.ptsCur, s.layerMap[p]);
@@ -325,7 +329,7 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             L.count = (int)(pk & 0xffffffffll);
             L.hc = (int)(pk >> 32);
         } else {
-            pointLocal(m, s, p, cur, internal, L, err);
+            pointLocal(m, s, p, cur, internal, L, err, prm.bndOn != 0);
             if (err) s.acc->err = 1;
         }
         // SM.C:155-163
@@ -345,6 +349,13 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             np = cur + (prm.relStepFrac * globalScale) * stepDir;
         }
         if (prm.layersOn) np = layerTreat(s, prm, p, internal, cur, np);   // SM.C:2283-2305
+        const bool deferBnd = prm.bndOn && !internal;   // k_bnd_fix finishes the boundary points (kernels_boundary.hpp)
+        if (prm.bndOn && internal) {                                       // SM.C:2356
+            const V3 stepDir = np - cur;
+            const double len = mag(stepDir);
+            const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
+            np = cur + (prm.relStepFrac * globalScale) * stepDir;
+        }
         // SM.C:611-648 (isFrozenPoint is all false here: reset at SM.C:2262)
         bool frozen = false;
         {
@@ -361,7 +372,8 @@ __global__ void __launch_bounds__(kBlock) k_smooth(MeshView m, State s, Prm prm)
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (FINAL) {
+        if (deferBnd) stv(s.prop, p, np);
+        else if (FINAL) {
             if (frozen || (!internal && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
             dist = mag(np - cur) / prm.maxStep;
             stv(s.ptsNext, p, np);

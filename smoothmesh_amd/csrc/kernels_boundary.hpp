@@ -1,0 +1,318 @@
+// kernels_boundary.hpp -- per-iteration part of the optional boundary point smoothing, serial run:
+//
+//   SM.C:2266        calculateBoundaryPointNormals OBB.C:141-233                      -> k_bnd_normals
+//   SM.C:2311-2330   calculateFeatureEdgeProjections BPS.C:623-677                    -> k_bnd_feature
+//                    projectBoundaryPointsToEdgesAndSurfaces BPS.C:843-945 (corners, feature edges, sharp edge
+//                    freeze, projection to the target surface along +-normal with findIntersection BPS.C:682-745)
+//   SM.C:2337-2351   projectPrismaticInternalPointsToSurfaces OBB.C:573-631
+//   SM.C:2356        constrainMaxStepLength once more (every point: the internal ones inside the smoothing kernels)
+//   then, for the boundary points, the rest of the iteration that the smoothing kernels do for the internal points:
+//   restrictEdgeShortening SM.C:602-652 and -- constraints off -- restore / count / residual / move    -> k_bnd_fix
+//
+// The smoothing kernels leave the boundary points' proposals (centroidal + aspect-ratio blend + step clamp [+ layer
+// treatment]) in State::prop and skip them; k_bnd_fix finishes them.  All of it is per-point work on a few per cent of
+// the points with gathers from global memory: latency-bound kernels of a few microseconds, not HBM-bound.
+//
+// findLine (OpenFOAM indexedOctree<treeDataTriSurface>::findLine, third-party code absent from the reference tree): the
+// intersection nearest to the start of a segment.  Every candidate triangle is tested with OpenFOAM's
+// triangle::intersection(orig, dir, HALF_RAY, tol = indexedOctree::perturbTol() = 10*SMALL) (Moller-Trumbore) on the full
+// segment; the smallest parameter wins, ties to the lowest triangle id -- so the result does not depend on the order
+// in which the bounding volume hierarchy presents the triangles (the oracle tests all of them in id order).
+#pragma once
+#include "kernels.hpp"
+
+namespace smgpu {
+
+// per boundary point flag bits (BndView::flags)
+constexpr uint8_t BF_CORNER = 1, BF_FEATURE = 2, BF_SMOOTHSURF = 4, BF_CONNECTED = 8, BF_SHARP = 16;
+constexpr int BND_ERR_NORMAL = 3, BND_ERR_NOHIT = 4, BND_ERR_STRING = 5;   // Accum::err codes
+
+struct BndView {
+    int nB;                     // boundary (non-internal) points, ascending point id
+    const int* pts;             // [nB] point id
+    uint8_t* flags;             // [nB] BF_*; BF_SHARP is rewritten by k_bnd_normals every iteration
+    const double* corner;       // [3 nB] cornerPoints (BPS.C:387-388)
+    const int* inner;           // [nB] pointToInnerPointMap or -1
+    const int* bfOff; const int* bfVal;   // boundary faces of the point on non-processor, non-empty patches, ascending
+    const uint8_t* ptClass;     // [nPoints] BF_CORNER | BF_FEATURE of every mesh point
+    int nFeat;                  // feature edge points
+    const int* featPts; const int* featString; const int* featOfBnd;   // featOfBnd[nB] = index into the feature list or -1
+    double* featSum; int* featCnt;        // featureEdgeProjections / nFeatureEdgeProjections of the feature points
+    int nTE;                    // target edge mesh
+    const double* tePts; const int* teEdges; const int* teString;
+    int nNodes;                 // bounding volume hierarchy over the target triangles (boundary.hpp)
+    const double* nodeBox; const int* nodeLink; const double* triVerts; const int* triId;
+    double distanceTolerance, internalBlend;
+};
+
+// OpenFOAM face area vector (primitiveMesh::makeFaceCentresAndAreas, as k_face_geom)
+__device__ __forceinline__ V3 faceAreaOf(const MeshView& m, const double* __restrict__ P, int f) {
+    const int b = m.faceOff[f];
+    const int n = m.faceOff[f + 1] - b;
+    if (n == 3) {
+        const V3 p0 = ldv(P, m.facePts[b]), p1 = ldv(P, m.facePts[b + 1]), p2 = ldv(P, m.facePts[b + 2]);
+        return 0.5 * cross(p1 - p0, p2 - p0);
+    }
+    V3 fCentre = ldv(P, m.facePts[b]);
+    for (int i = 1; i < n; ++i) fCentre = fCentre + ldv(P, m.facePts[b + i]);
+    fCentre = fCentre / double(n);
+    V3 sumN = v3(0, 0, 0);
+    double sumA = 0.0;
+    V3 thisPoint = ldv(P, m.facePts[b]);
+    const V3 first = thisPoint;
+    for (int i = 0; i < n; ++i) {
+        const V3 nextPoint = (i == n - 1) ? first : ldv(P, m.facePts[b + i + 1]);
+        const V3 nn = cross(nextPoint - thisPoint, fCentre - thisPoint);
+        sumN = sumN + nn;
+        sumA += mag(nn);
+        thisPoint = nextPoint;
+    }
+    if (sumA < SMGPU_ROOTVSMALL) return v3(0, 0, 0);
+    return 0.5 * sumN;
+}
+
+// calculateBoundaryPointNormals OBB.C:141-233 for the boundary points.  The reference never resets pointNormals: the
+// new normal is the normalised sum of the previous (unit) normal and the inverted unit normals of the point's
+// boundary faces.  (Internal points keep copies made at set-up; layerTreat re-normalises those.)
+__global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, BndView b) {
+    if (s.acc->stop) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= b.nB) return;
+    const int p = b.pts[i];
+    V3 n = ldv(s.layerNormal, p);
+    const int f0 = b.bfOff[i], f1 = b.bfOff[i + 1];
+    for (int k = f0; k < f1; ++k) {
+        const V3 cSf = faceAreaOf(m, s.ptsCur, b.bfVal[k]);
+        n = n - cSf / mag(cSf);
+    }
+    uint8_t fl = b.flags[i];
+    if (f1 > f0) {
+        if (mag(n) < 0.1) { n = v3(0, 0, 0); fl |= BF_SHARP; }
+        else fl &= (uint8_t)~BF_SHARP;
+        b.flags[i] = fl;
+    }
+    if (n != v3(0, 0, 0)) n = n / mag(n);
+    stv(s.layerNormal, p, n);
+}
+
+// projectPointToEdge BPS.C:89-145 (the edge point index it also reports is not consumed per iteration)
+__device__ __forceinline__ V3 projectToEdge(const BndView& b, const V3& pt, int e) {
+    const V3 a = ldv(b.tePts, b.teEdges[2 * e]), c = ldv(b.tePts, b.teEdges[2 * e + 1]);
+    const double edgeLength = mag(c - a);
+    const V3 c2pt = pt - a, edgeVec = c - a;
+    const double sN = dot(c2pt, edgeVec) / (edgeLength * edgeLength);
+    if (sN <= 1e-6) return a;                 // ABS_TOL, COM.H:21
+    if (sN >= (1.0 - 1e-6)) return c;
+    return a + sN * edgeVec;
+}
+
+// calculateFeatureEdgeProjections BPS.C:623-677: one wave per feature edge point; for each eligible neighbour the
+// lanes share the scan over the target edges of the point's string (findClosestEdgeInfo BPS.C:206-264: strict "<",
+// so the lowest edge id among equal distances) and lane 0 accumulates in pointPoints order.
+__global__ void __launch_bounds__(64) k_bnd_feature(MeshView m, State s, BndView b) {
+    if (s.acc->stop) return;
+    const int j = blockIdx.x, lane = threadIdx.x;
+    if (j >= b.nFeat) return;
+    const int p = b.featPts[j], str = b.featString[j];
+    V3 sum = v3(0, 0, 0);
+    int cnt = 0;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+        const int q = m.ppPt[k];
+        if (m.pflags[q] & PF_INTERNAL) continue;          // findNeighborSurfacePoints BPS.C:592-615
+        if (b.ptClass[q] & (BF_FEATURE | BF_CORNER)) continue;
+        const V3 pt = ldv(s.ptsCur, q);
+        double best = SMGPU_GREAT;
+        int bestE = 0x7fffffff;
+        V3 bestP = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+        for (int e = lane; e < b.nTE; e += 64) {
+            if (str >= 0 && b.teString[e] != str) continue;
+            const V3 pr = projectToEdge(b, pt, e);
+            const double d = mag(pr - pt);
+            if (d < best) { best = d; bestE = e; bestP = pr; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const double od = __shfl_xor(best, o, 64);
+            const int oe = __shfl_xor(bestE, o, 64);
+            const V3 op = v3(__shfl_xor(bestP.x, o, 64), __shfl_xor(bestP.y, o, 64), __shfl_xor(bestP.z, o, 64));
+            if (od < best || (od == best && oe < bestE)) { best = od; bestE = oe; bestP = op; }
+        }
+        if (bestE == 0x7fffffff) { if (lane == 0) s.acc->err = BND_ERR_STRING; continue; }   // BPS.C:258-261
+        sum = sum + bestP;
+        ++cnt;
+    }
+    if (lane == 0) { stv(b.featSum, j, sum); b.featCnt[j] = cnt; }
+}
+
+// OpenFOAM triangle::intersection(orig, dir, intersection::HALF_RAY, tol)
+__device__ __forceinline__ bool triangleIntersection(const double* __restrict__ tv, const V3& orig, const V3& dir, double tol, double& t, V3& pt) {
+    const V3 a = v3(tv[0], tv[1], tv[2]), bb = v3(tv[3], tv[4], tv[5]), c = v3(tv[6], tv[7], tv[8]);
+    const V3 edge1 = bb - a, edge2 = c - a;
+    const V3 pVec = cross(dir, edge2);
+    const double det = dot(edge1, pVec);
+    if (det > -SMGPU_ROOTVSMALL && det < SMGPU_ROOTVSMALL) return false;
+    const double inv_det = 1.0 / det;
+    const V3 tVec = orig - a;
+    const double u = dot(tVec, pVec) * inv_det;
+    if (u < -tol || u > 1.0 + tol) return false;
+    const V3 qVec = cross(tVec, edge1);
+    const double v = dot(dir, qVec) * inv_det;
+    if (v < -tol || u + v > 1.0 + tol) return false;
+    t = dot(edge2, qVec) * inv_det;
+    if (t < -tol) return false;
+    pt = a + u * edge1 + v * edge2;
+    return true;
+}
+
+// segment against an (inflated) box, with slack on the parameter range: conservative
+__device__ __forceinline__ bool segmentTouchesBox(const double* __restrict__ bx, const V3& o, const V3& d) {
+    double t0 = -1e-6, t1 = 1.0 + 1e-6;
+    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        if (dd[a] == 0.0) {
+            if (oo[a] < bx[a] || oo[a] > bx[3 + a]) return false;
+        } else {
+            double ta = (bx[a] - oo[a]) / dd[a], tb = (bx[3 + a] - oo[a]) / dd[a];
+            if (ta > tb) { const double sw = ta; ta = tb; tb = sw; }
+            const double slack = 1e-9 * (fabs(ta) + fabs(tb)) + 1e-12;
+            ta -= slack; tb += slack;
+            if (ta > t0) t0 = ta;
+            if (tb < t1) t1 = tb;
+            if (t0 > t1) return false;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ bool findLine(const BndView& b, const V3& start, const V3& end, V3& hitPoint) {
+    const V3 dir = end - start;
+    const double tol = 10.0 * 1.0e-15;   // indexedOctree::perturbTol() = 10*SMALL
+    double best = 0.0;
+    int bestId = 0x7fffffff;
+    int stack[40];
+    int sp = 0;
+    if (b.nNodes > 0) stack[sp++] = 0;
+    while (sp > 0) {
+        const int node = stack[--sp];
+        if (!segmentTouchesBox(b.nodeBox + 6 * (size_t)node, start, dir)) continue;
+        const int l0 = b.nodeLink[2 * node], l1 = b.nodeLink[2 * node + 1];
+        if (l0 >= 0) {
+            if (sp < 38) { stack[sp++] = l0; stack[sp++] = l1; }
+            continue;
+        }
+        const int first = -(l0 + 1);
+        for (int k = first; k < first + l1; ++k) {
+            double t;
+            V3 pt;
+            if (!triangleIntersection(b.triVerts + 9 * (size_t)k, start, dir, tol, t, pt)) continue;
+            if (!(t <= 1.0)) continue;   // treeDataTriSurface::findIntersectOp: inter.distance() <= 1
+            const int id = b.triId[k];
+            if (bestId == 0x7fffffff || t < best || (t == best && id < bestId)) { best = t; bestId = id; hitPoint = pt; }
+        }
+    }
+    return bestId != 0x7fffffff;
+}
+
+// findIntersection BPS.C:682-745
+__device__ __forceinline__ V3 findIntersection(const BndView& b, const V3& origPoint, const V3& pointNormal, double searchDistance) {
+    const V3 undef = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+    const V3 endPoint1 = origPoint + pointNormal * searchDistance;
+    const V3 endPoint2 = origPoint - pointNormal * searchDistance;
+    V3 hitPoint1 = undef, hitPoint2 = undef, h;
+    if (findLine(b, origPoint, endPoint1, h)) hitPoint1 = h;
+    if (findLine(b, origPoint, endPoint2, h)) hitPoint2 = h;
+    const double distance1 = mag(origPoint - hitPoint1);
+    const double distance2 = mag(origPoint - hitPoint2);
+    if (distance1 < distance2) return hitPoint1;
+    else if (distance2 < distance1) return hitPoint2;
+    if (findLine(b, endPoint1, endPoint2, h)) return h;
+    return undef;
+}
+
+// The boundary points' part of the iteration from the projection on (see the file header).
+template <bool FINAL>
+__global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm, BndView b, int partialBase) {
+    if (s.acc->stop) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    double dist = 0.0;
+    int fcount = 0;
+    if (i < b.nB) {
+        const int p = b.pts[i];
+        const uint8_t fl = b.flags[i];
+        const V3 cur = ldv(s.ptsCur, p);
+        V3 np = ldv(s.prop, p);
+        const V3 undef = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+        bool frozen = false;
+        // projectBoundaryPointsToEdgesAndSurfaces BPS.C:876-940
+        if (fl & BF_CORNER) np = ldv(b.corner, i);
+        else if (fl & BF_FEATURE) {
+            const int j = b.featOfBnd[i];
+            np = ldv(b.featSum, j) / double(b.featCnt[j]);
+        } else if (fl & BF_SHARP) frozen = true;
+        else if (fl & BF_SMOOTHSURF) {
+            const V3 pointNormal = ldv(s.layerNormal, p);
+            if (pointNormal == v3(0, 0, 0)) s.acc->err = BND_ERR_NORMAL;   // BPS.C:691-696
+            else {
+                double searchDistance = b.distanceTolerance;
+                V3 surfPoint = undef;
+                for (int it = 0; it < 4; ++it) {
+                    searchDistance *= (1.0 / 1e-4);   // 1.0 / REL_TOL
+                    surfPoint = findIntersection(b, np, pointNormal, searchDistance);
+                    if (surfPoint != undef) { np = surfPoint; break; }
+                }
+                if (surfPoint == undef) s.acc->err = BND_ERR_NOHIT;        // BPS.C:932-938
+            }
+        }
+        // projectPrismaticInternalPointsToSurfaces OBB.C:573-631
+        if ((fl & BF_SMOOTHSURF) && (fl & BF_CONNECTED) && b.inner[i] >= 0 && !(fl & (BF_FEATURE | BF_CORNER | BF_SHARP))) {
+            const V3 pointNormal = ldv(s.layerNormal, p);
+            if (pointNormal == v3(0, 0, 0)) s.acc->err = BND_ERR_NORMAL;
+            const V3 innerNeighCoord = ldv(s.ptsCur, b.inner[i]);   // updateNeighCoords OBB.C:464-500 (serial)
+            const V3 cCoords = np;
+            const V3 neighVec = cCoords - innerNeighCoord;
+            const double dotProd = dot(neighVec, pointNormal);
+            const V3 pVec = neighVec - dotProd * pointNormal;
+            const V3 newCoords = cCoords - pVec;
+            np = b.internalBlend * newCoords + (1.0 - b.internalBlend) * np;
+        }
+        {   // SM.C:2356 constrainMaxStepLength
+            const V3 stepDir = np - cur;
+            const double len = mag(stepDir);
+            const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
+            np = cur + (prm.relStepFrac * globalScale) * stepDir;
+        }
+        if (!frozen) {   // restrictEdgeShortening SM.C:611-648 (skips the points frozen above)
+            double shortestCur = SMGPU_GREAT, shortestNew = SMGPU_GREAT;
+            for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+                const V3 nb = ldv(s.ptsCur, m.ppPt[k]);
+                const double tc = mag(cur - nb);
+                if (tc < shortestCur) shortestCur = tc;
+                const double tn = mag(np - nb);
+                if (tn < shortestNew) shortestNew = tn;
+            }
+            const double shortest = (shortestNew < shortestCur) ? shortestNew : shortestCur;
+            if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
+            else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
+        }
+        if (FINAL) {
+            if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
+            dist = mag(np - cur) / prm.maxStep;
+            stv(s.ptsNext, p, np);
+        } else {
+            stv(s.prop, p, np);
+            s.frozen[p] = frozen ? 1 : 0;
+        }
+    }
+    if (FINAL) blockPublish<kBlock>(s, dist, fcount, partialBase + blockIdx.x);
+}
+
+// parity access to the segment query: one thread per segment
+__global__ void __launch_bounds__(kBlock) k_bnd_find_line(BndView b, int n, const double* seg, double* out, int* hit) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    V3 h = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+    hit[i] = findLine(b, ldv(seg, 2 * i), ldv(seg, 2 * i + 1), h) ? 1 : 0;
+    stv(out, i, h);
+}
+
+}  // namespace smgpu

@@ -466,7 +466,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
                 if (len < shortestCur) shortestCur = len;
             })
         } else {
-            if (internal) {   // SM.C:116-130
+            if (internal || prm.bndOn) {   // SM.C:116-130 (boundary points too with doBoundarySmoothing)
                 SMGPU_ELL_FOREACH_PRE(pc0, pc1, pcRow, wc4, T, {
                     sum = sum + ldsv(cx, cy, cz, e);
                     count = j + 1;
@@ -515,6 +515,13 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             np = cur + (prm.relStepFrac * globalScale) * stepDir;
         }
         if (prm.layersOn) np = layerTreat(s, prm, p, internal, cur, np);   // SM.C:2283-2305
+        const bool deferBnd = prm.bndOn && !internal;   // k_bnd_fix finishes the boundary points (kernels_boundary.hpp)
+        if (prm.bndOn && internal) {                                   // SM.C:2356
+            const V3 stepDir = np - cur;
+            const double len = mag(stepDir);
+            const double globalScale = (len > prm.maxStep) ? prm.maxStep / (len * prm.relStepFrac) : 1.0;
+            np = cur + (prm.relStepFrac * globalScale) * stepDir;
+        }
         bool frozen = false;                                           // SM.C:611-648
         {
             double shortestNew = SMGPU_GREAT;
@@ -527,7 +534,8 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (FINAL && slot >= 0) {
+        if (deferBnd) stv(s.prop, p, np);
+        else if (FINAL && slot >= 0) {
             // shared point (multi-rank): its freeze flag still has to be OR-ed over the ranks (SM.C:2374);
             // k_shared_fix finishes it after exchange F
             stv(s.prop, p, np);

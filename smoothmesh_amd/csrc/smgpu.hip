@@ -16,6 +16,8 @@
 #include "kernels_tiled.hpp"
 #include "kernels_walk.hpp"
 #include "kernels_filter.hpp"
+#include "kernels_boundary.hpp"
+#include "boundary.hpp"
 #include "tiles.hpp"
 #include "topology.hpp"
 
@@ -33,10 +35,10 @@ static int fail(const std::string& m) { g_err = m; return 1; }
     } while (0)
 
 enum KernelId { K_FACE_GEOM = 0, K_CELL_CENTRES, K_SMOOTH_FINAL, K_SMOOTH_PROP, K_EDGE_ANGLE, K_FA_EDGES,
-                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_EA_FILTER, K_FA_FILTER, K_COUNT };
+                K_FA_POINTS, K_FA_PRED, K_FA_WALK, K_APPLY, K_FINISH, K_HALO, K_GEOM_TILE, K_EA_FILTER, K_FA_FILTER, K_BND, K_COUNT };
 static const char* kKernelNames[K_COUNT] = {"k_face_geom", "k_cell_centres", "k_smooth<final>", "k_smooth<proposal>",
                                             "k_edge_angle", "k_fa_edges", "k_fa_points", "k_fa_pred", "k_fa_walk",
-                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile", "k_edge_angle_filter", "k_fa_edges_filter"};
+                                            "k_apply", "k_finish", "k_halo_*", "k_geom_tile", "k_edge_angle_filter", "k_fa_edges_filter", "k_bnd_*"};
 
 struct smgpu_handle {
     Topology topo;
@@ -129,6 +131,9 @@ struct smgpu_handle {
     bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
+    bool bndOn = false;        // smgpu_set_boundary_smoothing
+    BndView bv{};
+    BoundarySetup bs;
     std::vector<int32_t> layerHopsHost, layerMapHost;   // kept for the debug getters
     bool useExch = false;
     hipStream_t exch = nullptr;
@@ -171,6 +176,7 @@ static Prm makePrm(const smgpu_handle* h) {
     const smgpu_params& p = h->prm;
     Prm r;
     r.layersOn = h->layersOn ? 1 : 0;
+    r.bndOn = h->bndOn ? 1 : 0;
     r.maxStep = p.maxStepLength;
     r.relStepFrac = p.relStepFrac;
     r.minEdge = p.minEdgeLength;
@@ -261,6 +267,7 @@ static void computeAlgoBytes(smgpu_handle* h) {
     b[K_APPLY] = 24 * P + 24 * P + 2 * P + 24 * P;
     b[K_FINISH] = 64;
     b[K_HALO] = 0;
+    b[K_BND] = 0;
     // fused geometry: points + face/cell index lists + cell centres (no face arrays round trip)
     b[K_GEOM_TILE] = 24 * P + 4 * (F + 1) + 4 * nfp + 4 * (C + 1) + 4 * ncf + 24 * C + (fa ? 24 * F : 0);
     b[K_EA_FILTER] = b[K_EDGE_ANGLE];
@@ -491,7 +498,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.walkStack, P + 64);
     rc |= devAlloc(h, &s.acc, 1);
     {
-        const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + 1;
+        // + the boundary points' partials when k_bnd_fix finishes them (smgpu_set_boundary_smoothing)
+        const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(t.nPoints) + 1;
         rc |= devAlloc(h, &s.blkMax, nPart);
         rc |= devAlloc(h, &s.blkCnt, nPart);
     }
@@ -628,16 +636,26 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
 template <bool FINAL>
 static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList = nullptr, int nList = 0) {
     const int kid = FINAL ? K_SMOOTH_FINAL : K_SMOOTH_PROP;
+    // boundary point smoothing: normals and feature edge projections of the current coordinates first (SM.C:2266,
+    // BPS.C:866); after the smoothing kernel k_bnd_fix finishes the boundary points it skipped
+    if (h->bndOn && launchK(h, K_BND, [&] {
+            hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, h->bv);
+            if (h->bv.nFeat) hipLaunchKernelGGL(k_bnd_feature, dim3(h->bv.nFeat), dim3(64), 0, h->stream, m, s, h->bv);
+        })) return 1;
     if (h->useTiles) {
         const int nT = tileList ? nList : h->stl.nTiles;
         if (nT == 0) return 0;
-        return launchK(h, kid, [&] {
-            if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm, tileList, nT);
-            else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm, tileList, nT);
-            else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT);
-        });
+        if (launchK(h, kid, [&] {
+                if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm, tileList, nT);
+                else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm, tileList, nT);
+                else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT);
+            })) return 1;
+    } else if (launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+    if (h->bndOn) {
+        const int base = h->useTiles ? h->stl.nTiles : gridFor(m.nPoints);
+        return launchK(h, K_BND, [&] { hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, prm, h->bv, base); });
     }
-    return launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); });
+    return 0;
 }
 
 }  // extern "C++"
@@ -968,6 +986,9 @@ static int checkDeviceError(smgpu_handle* h) {
     HIP_OK(hipStreamSynchronize(h->stream));
     if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
     if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
+    if (a.err == BND_ERR_NORMAL) return fail("pointNormal is zero for a boundary point that is to be projected (BPS.C:691-696, OBB.C:609-610)");
+    if (a.err == BND_ERR_NOHIT) return fail("Did not find surface intersection for a boundary point (BPS.C:932-938)");
+    if (a.err == BND_ERR_STRING) return fail("Internal sanity check failed: Did not find any edges with the string index of a feature edge point (BPS.C:258-261)");
     return 0;
 }
 
@@ -1017,7 +1038,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (runProposalAndConstraints(h)) return 1;
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
-        const int nPart = (fused && h->useTiles) ? h->stl.nTiles : gP;
+        const int nPart = ((fused && h->useTiles) ? h->stl.nTiles : gP) + ((fused && h->bndOn) ? gridFor(h->bv.nB) : 0);
         if (deferFinish && i + 1 < nIters) { h->deferN = nPart; h->deferIter = i; }
         else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
@@ -1188,6 +1209,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         }
     }
     if (h->layersOn) return fail("smgpu_halo_configure after the boundary layer set-up: configure the halo first");
+    if (h->bndOn) return fail("smgpu_halo_configure: boundary point smoothing is a serial-run feature");
     h->sendF = (int*)d->sendF; h->recvF = (int*)d->recvF;
     h->localStats = (double*)d->localStats;
     if ((d->nSend && (!h->sendA || !h->sendF)) || (d->nRecv && (!h->recvA || !h->recvF)) || !h->localStats)
@@ -1477,6 +1499,183 @@ int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enable
     return smgpu_layers_step(h, SMGPU_LAYERS_FINISH, 0);
 }
 
+// ---- optional boundary point smoothing ---------------------------------------------------------------------------
+int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info) {
+    if (!h || !d) return fail("null argument");
+    if (h->haloOn) return fail("smgpu_set_boundary_smoothing: boundary point smoothing is a serial-run feature (no halo)");
+    if (d->nPatches < 0 || (d->nPatches && (!d->patchStart || !d->patchSize || !d->patchKind || !d->isSmoothingPatch))) return fail("bad patch description");
+    if ((d->nInitEdges && (!d->initEdges || !d->initEdgePoints)) || (d->nTargetEdges && (!d->targetEdges || !d->targetEdgePoints)) ||
+        (d->nSurfaceTriangles && (!d->surfaceTriangles || !d->surfacePoints)))
+        return fail("smgpu_set_boundary_smoothing: null geometry array");
+    HIP_OK(hipSetDevice(h->device));
+    const Topology& t = h->topo;
+    const MeshView& m = h->mv;
+    const int P = t.nPoints;
+    h->bndOn = false;
+    if (info) std::memset(info, 0, sizeof(*info));
+
+    std::vector<double> pts(3 * (size_t)P);
+    HIP_OK(hipMemcpyAsync(pts.data(), h->st.ptsCur, sizeof(double) * pts.size(), hipMemcpyDeviceToHost, h->stream));
+    std::vector<uint8_t> pflags((size_t)P), internal((size_t)P);
+    HIP_OK(hipMemcpyAsync(pflags.data(), m.pflags, (size_t)P, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    for (int p = 0; p < P; ++p) internal[(size_t)p] = (pflags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
+
+    BoundaryInputHost in;
+    auto fillEdges = [](EdgeMeshHost& em, int nP, const double* ep, int nE, const int32_t* e) {
+        if (nP > 0 && ep) em.pts.assign(ep, ep + 3 * (size_t)nP);
+        if (nE > 0 && e) em.edges.assign(e, e + 2 * (size_t)nE);
+    };
+    fillEdges(in.initEdges, d->nInitEdgePoints, d->initEdgePoints, d->nInitEdges, d->initEdges);
+    fillEdges(in.targetEdges, d->nTargetEdgePoints, d->targetEdgePoints, d->nTargetEdges, d->targetEdges);
+    if (d->nSurfaceTriangles > 0) {
+        in.surfPts.assign(d->surfacePoints, d->surfacePoints + 3 * (size_t)d->nSurfacePoints);
+        in.surfTris.assign(d->surfaceTriangles, d->surfaceTriangles + 3 * (size_t)d->nSurfaceTriangles);
+    }
+    in.isCornerPointIO = d->isCornerPointIO;
+    in.isFeatureEdgePointIO = d->isFeatureEdgePointIO;
+    in.distanceTolerance = d->distanceTolerance;
+    {   // getMeshStats SM.C:1478-1541: minimum edge length and the "perimeter" of the bounding box of the edge end points
+        double shortest = 1.0e300, lo[3] = {1.0e300, 1.0e300, 1.0e300}, hi[3] = {-1.0e300, -1.0e300, -1.0e300};
+        for (int e = 0; e < t.nEdges; ++e) {
+            const double* a = &pts[3 * (size_t)t.edges[2 * (size_t)e]];
+            const double* b = &pts[3 * (size_t)t.edges[2 * (size_t)e + 1]];
+            const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+            const double len = std::sqrt(dx * dx + dy * dy + dz * dz);
+            if (len < shortest) shortest = len;
+            for (int c = 0; c < 3; ++c) {
+                if (a[c] < lo[c]) lo[c] = a[c];
+                if (a[c] > hi[c]) hi[c] = a[c];
+                if (b[c] < lo[c]) lo[c] = b[c];
+                if (b[c] > hi[c]) hi[c] = b[c];
+            }
+        }
+        in.meshMinEdgeLength = shortest;
+        in.meshPerimeter = hi[0] - lo[0] + hi[1] - lo[1] + hi[2] + lo[2];   // SM.C:1538
+    }
+    std::vector<BndPatch> patches((size_t)d->nPatches);
+    for (int i = 0; i < d->nPatches; ++i) patches[(size_t)i] = BndPatch{d->patchStart[i], d->patchSize[i], (int32_t)d->patchKind[i], d->isSmoothingPatch[i] != 0};
+    BoundarySetup& bs = h->bs;
+    const std::string err = buildBoundarySetup(t, internal.data(), pts.data(), patches, in, bs);
+    if (!err.empty()) return fail(err);
+    if (info) {
+        info->enabled = bs.enabled ? 1 : 0;
+        info->nCornerPoints = bs.nCorner; info->nFeatureEdgePoints = bs.nFeature;
+        info->nSmoothingSurfacePoints = bs.nSmoothingSurface; info->nFrozenSurfacePoints = bs.nFrozenSurface;
+        int mx = -1;
+        for (int32_t v : bs.targetEdgeStrings) mx = std::max(mx, (int)v);
+        info->nTargetEdgeStrings = mx + 1;
+    }
+    if (!bs.enabled) return 0;
+
+    // device tables over the boundary (non-internal) points
+    std::vector<int> bpts, inner, featPts, featString, featOfBnd, bfOff(1, 0), bfVal;
+    std::vector<uint8_t> flags, ptClass((size_t)P, 0);
+    std::vector<double> corner;
+    std::vector<int> bndOf((size_t)P, -1);
+    for (int p = 0; p < P; ++p) {
+        if (internal[(size_t)p]) continue;
+        bndOf[(size_t)p] = (int)bpts.size();
+        bpts.push_back(p);
+        uint8_t f = 0;
+        if (bs.isCornerPoint[(size_t)p]) f |= BF_CORNER;
+        if (bs.isFeatureEdgePoint[(size_t)p]) f |= BF_FEATURE;
+        if (bs.isSmoothingSurfacePoint[(size_t)p]) f |= BF_SMOOTHSURF;
+        if (bs.isConnectedToInternalPoint[(size_t)p]) f |= BF_CONNECTED;
+        flags.push_back(f);
+        ptClass[(size_t)p] = f & (BF_CORNER | BF_FEATURE);
+        inner.push_back(bs.innerMap[(size_t)p]);
+        for (int c = 0; c < 3; ++c) corner.push_back(bs.cornerPoints[3 * (size_t)p + c]);
+        if (f & BF_FEATURE) { featOfBnd.push_back((int)featPts.size()); featPts.push_back(p); featString.push_back(bs.pointStrings[(size_t)p]); }
+        else featOfBnd.push_back(-1);
+    }
+    const int nB = (int)bpts.size();
+    {   // boundary faces per boundary point on ordinary patches (OBB.C:156-159), ascending face id = the reference's order
+        std::vector<std::vector<int>> bf((size_t)nB);
+        for (const BndPatch& pp : patches) {
+            if (pp.kind != 0) continue;
+            for (int f = pp.start; f < pp.start + pp.size; ++f)
+                for (int k = t.facePoints.off[f]; k < t.facePoints.off[f + 1]; ++k) {
+                    const int bi = bndOf[(size_t)t.facePoints.val[k]];
+                    if (bi >= 0) bf[(size_t)bi].push_back(f);
+                }
+        }
+        for (int i = 0; i < nB; ++i) {
+            std::sort(bf[(size_t)i].begin(), bf[(size_t)i].end());
+            bfVal.insert(bfVal.end(), bf[(size_t)i].begin(), bf[(size_t)i].end());
+            bfOff.push_back((int)bfVal.size());
+        }
+    }
+    Bvh bvh;
+    bvh.build(in.surfPts, in.surfTris);
+    BndView& v = h->bv;
+    v = BndView{};
+    v.nB = nB;
+    const int *dPts = nullptr, *dInner = nullptr, *dBfOff = nullptr, *dBfVal = nullptr, *dFeatPts = nullptr, *dFeatStr = nullptr, *dFeatOf = nullptr;
+    const int *dTeE = nullptr, *dTeS = nullptr, *dLink = nullptr, *dTriId = nullptr;
+    const uint8_t *dFlags = nullptr, *dClass = nullptr;
+    const double *dCorner = nullptr, *dTeP = nullptr, *dBox = nullptr, *dTri = nullptr;
+    if (devUpload(h, &dPts, bpts) || devUpload(h, &dInner, inner) || devUpload(h, &dBfOff, bfOff) || devUpload(h, &dBfVal, bfVal) ||
+        devUpload(h, &dFeatPts, featPts) || devUpload(h, &dFeatStr, featString) || devUpload(h, &dFeatOf, featOfBnd) ||
+        devUpload(h, &dFlags, flags) || devUpload(h, &dClass, ptClass) || devUpload(h, &dCorner, corner) ||
+        devUpload(h, &dTeP, bs.target.pts) || devUpload(h, &dTeE, bs.target.edges) || devUpload(h, &dTeS, bs.targetEdgeStrings) ||
+        devUpload(h, &dBox, bvh.box) || devUpload(h, &dLink, bvh.link) || devUpload(h, &dTri, bvh.triVerts) || devUpload(h, &dTriId, bvh.triId))
+        return 1;
+    v.pts = dPts; v.flags = const_cast<uint8_t*>(dFlags); v.corner = dCorner; v.inner = dInner; v.bfOff = dBfOff; v.bfVal = dBfVal;
+    v.ptClass = dClass;
+    v.nFeat = (int)featPts.size(); v.featPts = dFeatPts; v.featString = dFeatStr; v.featOfBnd = dFeatOf;
+    if (devAlloc(h, &v.featSum, 3 * (size_t)std::max(v.nFeat, 1)) || devAlloc(h, &v.featCnt, (size_t)std::max(v.nFeat, 1))) return 1;
+    v.nTE = bs.target.nEdges(); v.tePts = dTeP; v.teEdges = dTeE; v.teString = dTeS;
+    v.nNodes = (int)(bvh.link.size() / 2); v.nodeBox = dBox; v.nodeLink = dLink; v.triVerts = dTri; v.triId = dTriId;
+    v.distanceTolerance = d->distanceTolerance;
+    v.internalBlend = d->internalSmoothingBlendingFraction;
+    // isSmoothingSurfacePoint is this classification's from now on (BPS.C:404-412)
+    for (int p = 0; p < P; ++p) {
+        pflags[(size_t)p] &= (uint8_t)~PF_SMOOTHSURF;
+        if (bs.isSmoothingSurfacePoint[(size_t)p]) pflags[(size_t)p] |= PF_SMOOTHSURF;
+    }
+    HIP_OK(hipMemcpy(const_cast<uint8_t*>(m.pflags), pflags.data(), (size_t)P, hipMemcpyHostToDevice));
+    // SM.C:2219: the first calculateBoundaryPointNormals (done by the layer set-up when that ran)
+    if (!h->st.layerNormal) {
+        if (devAlloc(h, &h->st.layerNormal, 3 * (size_t)P)) return 1;
+        HIP_OK(hipMemsetAsync(h->st.layerNormal, 0, sizeof(double) * 3 * (size_t)P, h->stream));
+        HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
+        hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(nB)), dim3(kBlock), 0, h->stream, m, h->st, v);
+        HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    h->bndOn = true;
+    return 0;
+}
+
+int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, int32_t* isFeatureEdgePoint) {
+    if (!h || !isCornerPoint || !isFeatureEdgePoint) return fail("null argument");
+    if ((int)h->bs.isCornerPointOut.size() != h->topo.nPoints) return fail("smgpu_get_boundary_classification: no boundary set-up has been made");
+    std::copy(h->bs.isCornerPointOut.begin(), h->bs.isCornerPointOut.end(), isCornerPoint);
+    std::copy(h->bs.isFeatureEdgePointOut.begin(), h->bs.isFeatureEdgePointOut.end(), isFeatureEdgePoint);
+    return 0;
+}
+
+int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit) {
+    if (!h || !segments || !hitPoints || !hit || n < 0) return fail("bad argument");
+    if (!h->bndOn) return fail("smgpu_debug_find_line: boundary point smoothing is not enabled");
+    HIP_OK(hipSetDevice(h->device));
+    double *dSeg = nullptr, *dOut = nullptr;
+    int* dHit = nullptr;
+    HIP_OK(hipMalloc((void**)&dSeg, sizeof(double) * 6 * (size_t)std::max(n, 1)));
+    HIP_OK(hipMalloc((void**)&dOut, sizeof(double) * 3 * (size_t)std::max(n, 1)));
+    HIP_OK(hipMalloc((void**)&dHit, sizeof(int) * (size_t)std::max(n, 1)));
+    hipError_t e = hipMemcpy(dSeg, segments, sizeof(double) * 6 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(k_bnd_find_line, dim3(gridFor(n)), dim3(kBlock), 0, h->stream, h->bv, n, dSeg, dOut, dHit);
+        e = hipStreamSynchronize(h->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(hitPoints, dOut, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(hit, dHit, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(dSeg); (void)hipFree(dOut); (void)hipFree(dHit);
+    if (e != hipSuccess) return fail(std::string("smgpu_debug_find_line: ") + hipGetErrorString(e));
+    return 0;
+}
+
 // ---- debug / parity access -------------------------------------------------------------------
 int smgpu_debug_propose(smgpu_handle* h) {
     if (!h) return fail("null handle");
@@ -1516,7 +1715,7 @@ int smgpu_debug_get_field(smgpu_handle* h, const char* name, double* out, int64_
     else if (s == "pointMaxAngle") { dsrc = st.ptMax; cnt = P; }
     else if (s == "isFrozenPoint") { bsrc = st.frozen; cnt = P; }
     else if (s == "faActive") { bsrc = st.faActive; cnt = P; }
-    else if (s == "layerNormals" && h->layersOn) { dsrc = st.layerNormal; cnt = 3 * P; }
+    else if (s == "layerNormals" && (h->layersOn || h->bndOn)) { dsrc = st.layerNormal; cnt = 3 * P; }
     else if ((s == "layerHops" || s == "layerOuterMap") && h->layersOn) {
         *n = P;
         if (out) { const std::vector<int32_t>& v = (s == "layerHops") ? h->layerHopsHost : h->layerMapHost; for (int64_t i = 0; i < P; ++i) out[i] = v[(size_t)i]; }

@@ -16,6 +16,7 @@ SMGPU_HD V3 v3(double x, double y, double z) { V3 r; r.x = x; r.y = y; r.z = z; 
 SMGPU_HD V3 operator+(const V3& a, const V3& b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
 SMGPU_HD V3 operator-(const V3& a, const V3& b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 SMGPU_HD V3 operator*(double s, const V3& a) { return v3(s * a.x, s * a.y, s * a.z); }
+SMGPU_HD V3 operator*(const V3& a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
 SMGPU_HD V3 operator/(const V3& a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
 SMGPU_HD bool operator==(const V3& a, const V3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 SMGPU_HD bool operator!=(const V3& a, const V3& b) { return !(a == b); }

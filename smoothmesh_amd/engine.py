@@ -38,6 +38,19 @@ class LayerParams:
     maxLayers: int = 4
 
 
+@dataclass
+class BoundaryParams:
+    """Boundary point smoothing inputs: the contents of constant/geometry/{initEdges,targetEdges,targetSurfaces}.obj
+    (SM.C:1924-1926) and the options SM.C:1758-1770, 1907."""
+    initEdges: tuple = None                   # (points (n,3), edges (m,2))
+    targetSurfaces: tuple = None              # (points (n,3), triangles (m,3))
+    targetEdges: tuple = None                 # None = the initial edges are the target (SM.C:2154-2160)
+    smoothingPatches: tuple = ('".*"',)       # default: every patch (SM.C:1837-1840)
+    internalSmoothingBlendingFraction: float = 0.0
+    isCornerPointIO: object = None            # classification lists of a previous run (SM.C:2039-2077)
+    isFeatureEdgePointIO: object = None
+
+
 def patch_arrays(mesh: PolyMesh, layerPatches):
     """(start, size, kind, isLayer) of mesh.patches; kind 0 ordinary / 1 processor / 2 empty.  Selection as
     polyBoundaryMesh::patchSet (SM.C:1442-1471): a plain word matches a patch name, a quoted string is a regex."""
@@ -224,6 +237,51 @@ class SmoothEngine:
         on = C.c_int32(0)
         self._check(self._lib.smgpu_set_layers(self._h, C.byref(d), C.byref(on)))
         return bool(on.value)
+
+    def set_boundary_smoothing(self, bp: "BoundaryParams", minEdgeLength: float, layerEdgeLength=None):
+        """Enable the boundary point smoothing (serial runs; after set_layers when both are used).  minEdgeLength is
+        the -minEdgeLength option value (the default of layerEdgeLength, SM.C:1895).  Returns a dict with the
+        reference's doBoundarySmoothing ("enabled") and the classification summary (BPS.C:423-438)."""
+        REL_TOL = 1e-4                                                     # COM.H:20
+        lel = minEdgeLength if layerEdgeLength is None else layerEdgeLength
+        tol = REL_TOL * min(self.mesh_stats()[0], lel)                     # SM.C:1921
+        start, size, kind, sel = patch_arrays(self.mesh, bp.smoothingPatches)
+        def pe(m, w):
+            if m is None:
+                return np.zeros((0, 3), np.float64), np.zeros((0, w), np.int32)
+            return np.ascontiguousarray(m[0], np.float64).reshape(-1, 3), np.ascontiguousarray(m[1], np.int32).reshape(-1, w)
+        ip, ie = pe(bp.initEdges, 2); tp, te = pe(bp.targetEdges, 2); sp, st = pe(bp.targetSurfaces, 3)
+        cio = None if bp.isCornerPointIO is None else np.ascontiguousarray(bp.isCornerPointIO, np.int32)
+        fio = None if bp.isFeatureEdgePointIO is None else np.ascontiguousarray(bp.isFeatureEdgePointIO, np.int32)
+        d = _ffi.BoundaryDesc()
+        d.nPatches = len(start)
+        d.patchStart, d.patchSize = _p(start, _ffi.c_i32p), _p(size, _ffi.c_i32p)
+        d.patchKind, d.isSmoothingPatch = _p(kind, _ffi.c_u8p), _p(sel, _ffi.c_u8p)
+        d.nInitEdgePoints, d.initEdgePoints, d.nInitEdges, d.initEdges = len(ip), _p(ip, _ffi.c_f64p), len(ie), _p(ie, _ffi.c_i32p)
+        d.nTargetEdgePoints, d.targetEdgePoints, d.nTargetEdges, d.targetEdges = len(tp), _p(tp, _ffi.c_f64p), len(te), _p(te, _ffi.c_i32p)
+        d.nSurfacePoints, d.surfacePoints, d.nSurfaceTriangles, d.surfaceTriangles = len(sp), _p(sp, _ffi.c_f64p), len(st), _p(st, _ffi.c_i32p)
+        d.isCornerPointIO = None if cio is None else _p(cio, _ffi.c_i32p)
+        d.isFeatureEdgePointIO = None if fio is None else _p(fio, _ffi.c_i32p)
+        d.distanceTolerance = tol
+        d.internalSmoothingBlendingFraction = bp.internalSmoothingBlendingFraction
+        info = _ffi.BoundaryInfo()
+        self._check(self._lib.smgpu_set_boundary_smoothing(self._h, C.byref(d), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ffi.BoundaryInfo._fields_}
+
+    def boundary_classification(self):
+        """(isCornerPoint, isFeatureEdgePoint) as the labelIOLists the reference writes (SM.C:2039-2064)."""
+        a, b = np.zeros(self.nPoints, np.int32), np.zeros(self.nPoints, np.int32)
+        self._check(self._lib.smgpu_get_boundary_classification(self._h, _p(a, _ffi.c_i32p), _p(b, _ffi.c_i32p)))
+        return a, b
+
+    def debug_find_line(self, starts, ends):
+        """nearest intersections of the segments with the target surface: (hit mask, hit points)"""
+        seg = np.ascontiguousarray(np.concatenate([np.asarray(starts, np.float64).reshape(-1, 3),
+                                                   np.asarray(ends, np.float64).reshape(-1, 3)], axis=1))
+        n = len(seg)
+        out, hit = np.zeros((n, 3), np.float64), np.zeros(n, np.int32)
+        self._check(self._lib.smgpu_debug_find_line(self._h, n, _p(seg, _ffi.c_f64p), _p(out, _ffi.c_f64p), _p(hit, _ffi.c_i32p)))
+        return hit.astype(bool), out
 
     def iterate(self, centroidalIters: int, relTol: float = 0.02):
         """Returns (nDone, residuals[nDone], nFrozenPoints[nDone]) -- the values of the reference's

@@ -1,0 +1,141 @@
+"""GPU parity of the optional boundary point smoothing (include/smgpu.h smgpu_set_boundary_smoothing; reference set-up
+SM.C:2080-2253, per iteration SM.C:2266 + 2307-2357) against the CPU oracle, through the C-ABI."""
+import os
+
+import numpy as np
+import pytest
+
+from bnd_cases import boundary_inputs, make_pair, scale_about_centre, tangential_jitter
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_setup(o, e):
+    f = o.boundary_fields()
+    cio, fio = e.boundary_classification()
+    assert np.array_equal(cio, f["isCornerPoint"].astype(np.int32))
+    assert np.array_equal(fio, f["isFeatureEdgePoint"].astype(np.int32))
+    info = e.boundary_info
+    assert info["nCornerPoints"] == f["isCornerPoint"].sum() and info["nFeatureEdgePoints"] == f["isFeatureEdgePoint"].sum()
+    assert info["nSmoothingSurfacePoints"] == f["isSmoothingSurfacePoint"].sum()
+    assert info["nTargetEdgeStrings"] == len(np.unique(f["targetEdgeStrings"]))
+    assert np.array_equal(e.debug_field("layerNormals").reshape(-1, 3), f["normals"])     # same operations: same bits
+
+
+def _run_both(o, e, iters):
+    n_o, res_o, frz_o = o.iterate(iters, 0.0)
+    n_g, res_g, frz_g = e.iterate(iters, 0.0)
+    assert n_o == n_g and np.array_equal(frz_o, frz_g)
+    assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
+    assert rel_linf(e.get_points(), o.points()) <= 1e-13
+    return res_g, frz_g
+
+
+@pytest.mark.parametrize("constraints", [False, True])
+@pytest.mark.parametrize("warp", [None, 1.03])
+def test_hex_block_boundary_smoothing(oracle_lib, constraints, warp):
+    from smoothmesh_amd.meshgen import hex_block
+    m = tangential_jitter(hex_block(12, 10, 9, jitter=0.25, seed=11), 0.02, seed=3)
+    # non-cubic block: lengths stay 1, the generators below describe the same unit cube
+    init, target, surf = boundary_inputs(7, 5, warp=None if warp is None else scale_about_centre(warp))
+    o, e, prm, on = make_pair(m, oracle_lib, init, target, surf, constraints=constraints)
+    assert on
+    _check_setup(o, e)
+    _run_both(o, e, 12)
+    # the boundary really moves: different from a run with the boundary frozen
+    from smoothmesh_amd import SmoothEngine
+    e2 = SmoothEngine(m)
+    e2.set_params(prm)
+    e2.iterate(12, 0.0)
+    assert rel_linf(e2.get_points(), e.get_points()) > 1e-4
+
+
+def test_boundary_smoothing_with_layers_and_blending(oracle_lib):
+    """layer treatment on one patch + boundary smoothing + internalSmoothingBlendingFraction (OBB.C:573-631)"""
+    from smoothmesh_amd.meshgen import hex_block
+    m = tangential_jitter(hex_block(10, jitter=0.2, seed=7), 0.02, seed=5)
+    init, target, surf = boundary_inputs(10, 4)
+    o, e, prm, on = make_pair(m, oracle_lib, init, None, surf, layerPatches=("xmin",), blend=0.5)
+    assert on
+    _check_setup(o, e)
+    _run_both(o, e, 10)
+
+
+def test_only_some_patches_smoothed(oracle_lib):
+    """-smoothingPatches '(xmin zmax)': the other boundary points are frozen surface points (BPS.C:414-420), yet corners
+    and feature edge points among them are still projected before the restore (BPS.C:876-900, SM.C:2384-2392)"""
+    from smoothmesh_amd.meshgen import hex_block
+    m = tangential_jitter(hex_block(9, jitter=0.2, seed=8), 0.02, seed=6)
+    init, target, surf = boundary_inputs(9, 3, warp=scale_about_centre(1.02))
+    o, e, prm, on = make_pair(m, oracle_lib, init, target, surf, constraints=True, smoothingPatches=("xmin", "zmax"))
+    assert on
+    _check_setup(o, e)
+    _run_both(o, e, 8)
+
+
+def test_direct_gather_kernels(oracle_lib, monkeypatch):
+    """SMGPU_TILES=0: the non-tiled smoothing kernel leaves the boundary points to k_bnd_fix the same way"""
+    from smoothmesh_amd.meshgen import hex_block
+    monkeypatch.setenv("SMGPU_TILES", "0")
+    m = tangential_jitter(hex_block(8, jitter=0.2, seed=2), 0.02, seed=1)
+    init, target, surf = boundary_inputs(8, 3)
+    for constraints in (False, True):
+        o, e, prm, on = make_pair(m, oracle_lib, init, None, surf, constraints=constraints)
+        _run_both(o, e, 6)
+
+
+def test_find_line_matches_the_oracle(oracle_lib):
+    """the bounding volume hierarchy returns what testing every triangle returns: random segments against a finely
+    triangulated, warped surface, including segments that start on the surface and axis-parallel ones"""
+    from smoothmesh_amd.meshgen import hex_block
+    warp = lambda x: x + 0.03 * np.sin(5.0 * x[:, [1, 2, 0]])
+    m = hex_block(4)
+    init, _, _ = boundary_inputs(4, 2)
+    from smoothmesh_amd.surfgen import box_surface
+    surf = box_surface(12, warp=warp)
+    o, e, prm, on = make_pair(m, oracle_lib, init, None, surf)
+    rng = np.random.default_rng(0)
+    a = rng.uniform(-0.3, 1.3, (400, 3))
+    b = rng.uniform(-0.3, 1.3, (400, 3))
+    b[:50] = a[:50] + np.eye(3)[rng.integers(0, 3, 50)] * rng.uniform(-1.5, 1.5, (50, 1))      # axis-parallel
+    a[50:80] = surf[0][rng.integers(0, len(surf[0]), 30)]                                      # start on a surface vertex
+    hit_g, p_g = e.debug_find_line(a, b)
+    n_hit = 0
+    for s in range(len(a)):
+        hit_o, p_o = o.find_line(a[s], b[s])
+        assert hit_o == hit_g[s]
+        if hit_o:
+            n_hit += 1
+            assert np.array_equal(p_o, p_g[s])
+    assert n_hit > 100
+
+
+def test_persisted_classification_round_trip(oracle_lib):
+    """the lists smgpu_get_boundary_classification returns, fed back, reproduce the run (SM.C:2039-2077)"""
+    from smoothmesh_amd.meshgen import hex_block
+    m = tangential_jitter(hex_block(7, jitter=0.2, seed=4), 0.02, seed=2)
+    init, target, surf = boundary_inputs(7, 3)
+    o, e, prm, on = make_pair(m, oracle_lib, init, None, surf)
+    cio, fio = e.boundary_classification()
+    e.iterate(5, 0.0)
+    o2, e2, _, on2 = make_pair(m, oracle_lib, init, None, surf, cornerIO=cio, featureIO=fio)
+    assert on2
+    e2.iterate(5, 0.0)
+    assert np.array_equal(e.get_points(), e2.get_points())
+
+
+def test_not_available_with_a_halo(oracle_lib):
+    from smoothmesh_amd import SmgpuError
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(4, jitter=0.1, seed=1)
+    init, target, surf = boundary_inputs(4, 2)
+    o, e, prm, on = make_pair(m, oracle_lib, init, None, surf)
+    assert on
+    # missing surface intersections are reported, not ignored (BPS.C:932-938): a target far away from the boundary
+    far = (surf[0] * 1e-3 + 50.0, surf[1])
+    o3, e3, _, on3 = make_pair(m, oracle_lib, init, None, far)
+    with pytest.raises(SmgpuError, match="surface intersection"):
+        e3.iterate(1, 0.0)
+    with pytest.raises(RuntimeError):
+        o3.iterate(1, 0.0)

@@ -1,0 +1,139 @@
+"""Known answers for the oracle's boundary point smoothing (BPS.C = src/boundaryPointSmoothing.C, OBB.C:573-631, set-up
+SM.C:2080-2253, per iteration SM.C:2266 + 2307-2357) on cases where the reference's result can be written down."""
+import numpy as np
+import pytest
+
+from bnd_cases import boundary_inputs, make_pair, scale_about_centre, tangential_jitter
+
+
+def _ijk(n):
+    p = np.arange((n + 1) ** 3)
+    return p % (n + 1), (p // (n + 1)) % (n + 1), p // (n + 1) ** 2
+
+
+def test_classification_of_a_block(oracle_lib):
+    """BPS.C:269-441: the eight block corners sit on edge mesh points with three edges -> corner points; the other points
+    of the twelve block edges are within distanceTolerance of an initial edge -> feature edge points; every boundary point
+    is a smoothing surface point with the default -smoothingPatches '(".*")' (SM.C:1837-1840)."""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 6
+    m = hex_block(n, jitter=0.2, seed=5)
+    init, target, surf = boundary_inputs(3, 2)                 # 3 segments per block edge: mesh points between edge points
+    o, _, prm, on = make_pair(m, oracle_lib, init, target, surf, engine=False)
+    assert on
+    f = o.boundary_fields()
+    i, j, k = _ijk(n)
+    ext = lambda a: (a == 0) | (a == n)
+    n_ext = ext(i).astype(int) + ext(j) + ext(k)
+    assert np.array_equal(f["isCornerPoint"].astype(bool), n_ext == 3)
+    assert np.array_equal(f["isFeatureEdgePoint"].astype(bool), n_ext == 2)
+    assert np.array_equal(f["isSmoothingSurfacePoint"].astype(bool), n_ext >= 1)
+    # corner targets = the corners themselves (BPS.C:381-388); one string per block edge (BPS.C:557-587)
+    c = f["isCornerPoint"].astype(bool)
+    assert np.array_equal(f["cornerPoints"][c], np.array(m.points)[c])
+    assert len(np.unique(f["targetEdgeStrings"])) == 12
+    # points of one block edge share a string, different edges differ (SM.C:2234-2249)
+    e1 = (j == 0) & (k == 0) & (n_ext == 2)
+    e2 = (i == 0) & (k == n) & (n_ext == 2)
+    s1, s2 = np.unique(f["pointStrings"][e1]), np.unique(f["pointStrings"][e2])
+    assert len(s1) == 1 and len(s2) == 1 and s1[0] != s2[0] and s1[0] >= 0
+    # OBB.C:396-459: face-interior boundary points hang on the one neighbour a hop inside
+    face = (i == 0) & (n_ext == 1)
+    assert np.array_equal(f["innerMap"][face], np.arange(len(i))[face] + 1)
+    assert np.all(f["innerMap"][n_ext >= 2] == -1)             # edge / corner points have no internal neighbour
+    # OBB.C:141-233: inward unit normals
+    assert np.array_equal(f["normals"][face], np.tile([1.0, 0.0, 0.0], (face.sum(), 1)))
+
+
+def test_not_enabled_without_inputs(oracle_lib):
+    """SM.C:2080-2093: needs the target surface, the initial edges (or classification lists) and a smoothing patch"""
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(4, jitter=0.1, seed=1)
+    init, target, surf = boundary_inputs(4, 2)
+    assert not make_pair(m, oracle_lib, init, None, None, engine=False)[3]
+    assert not make_pair(m, oracle_lib, None, None, surf, engine=False)[3]
+    assert not make_pair(m, oracle_lib, init, None, surf, engine=False, smoothingPatches=())[3]
+    assert make_pair(m, oracle_lib, init, None, surf, engine=False, smoothingPatches=("xmin",))[3]
+
+
+def test_find_line_known_answers(oracle_lib):
+    """nearest hit along the segment; misses beyond the segment end and behind its start"""
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(4)
+    init, target, surf = boundary_inputs(4, 2)
+    o = make_pair(m, oracle_lib, init, None, surf, engine=False)[0]
+    hit, p = o.find_line([0.3, 0.4, 0.5], [0.3, 0.4, 2.0])            # from inside through the z = 1 side
+    assert hit and np.allclose(p, [0.3, 0.4, 1.0], rtol=0, atol=1e-15)
+    hit, p = o.find_line([0.3, 0.4, -1.0], [0.3, 0.4, 2.0])           # crosses z = 0 first, then z = 1
+    assert hit and np.allclose(p, [0.3, 0.4, 0.0], rtol=0, atol=1e-15)
+    assert not o.find_line([0.3, 0.4, 0.5], [0.3, 0.4, 0.9])[0]       # ends before the surface
+    assert not o.find_line([0.3, 0.4, 1.5], [0.3, 0.4, 2.0])[0]       # starts beyond it, pointing away
+
+
+def test_uniform_block_on_its_own_surface_is_a_fixed_point(oracle_lib):
+    """Uniform block, target = the block's own surface: the centroid of a face point's cells lies h/2 inside on the
+    point's normal, the ray along the normal brings it back (BPS.C:682-745); edge points are the mean of their two
+    surface neighbours' projections, i.e. themselves; corners are pinned -> residual exactly 0."""
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(8, jitter=0.0)                                        # 1/8 is exact in binary
+    init, target, surf = boundary_inputs(8, 2)
+    o = make_pair(m, oracle_lib, init, None, surf, engine=False)[0]
+    n, res, frz = o.iterate(3, 0.0)
+    assert n == 3 and np.all(res == 0.0) and np.all(frz == 0)
+    assert np.array_equal(o.points(), np.array(m.points))
+
+
+@pytest.mark.parametrize("constraints", [False, True])
+def test_boundary_points_slide_on_the_target(oracle_lib, constraints):
+    """jittered block: face points stay in their plane, edge points on their edge, corners fixed, and the tangential
+    jitter of the boundary decays (the boundary is smoothed, not frozen)"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 8
+    m = tangential_jitter(hex_block(n, jitter=0.2, seed=2), 0.03, seed=9)
+    p0 = np.array(m.points).copy()
+    init, target, surf = boundary_inputs(n, 3)
+    o = make_pair(m, oracle_lib, init, None, surf, constraints=constraints, engine=False)[0]
+    nd, res, frz = o.iterate(40, 0.0)
+    p = o.points()
+    i, j, k = _ijk(n)
+    for a, idx in enumerate((i, j, k)):
+        assert np.all(p[idx == 0, a] == 0.0) and np.all(p[idx == n, a] == 1.0)      # on the box, exactly
+    moved = np.abs(p - p0).max(axis=1)
+    ext = ((i == 0) | (i == n)).astype(int) + ((j == 0) | (j == n)) + ((k == 0) | (k == n))
+    assert np.all(moved[ext == 3] == 0.0) and moved[ext == 2].max() > 1e-3 and moved[ext == 1].max() > 1e-3
+    # spacing along one block edge becomes more uniform
+    e = np.where((j == 0) & (k == 0))[0]
+    assert np.std(np.diff(p[e, 0])) < 0.5 * np.std(np.diff(p0[e, 0]))
+    assert res[-1] < 0.3 * res[0]
+
+
+def test_boundary_moves_onto_a_scaled_target(oracle_lib):
+    """target surface, edges and corners = the block scaled by 1.04 about its centre: corners jump to the scaled
+    corners (then step-clamped), face points are projected along their normals, until the boundary lies on the target"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 6
+    m = hex_block(n, jitter=0.1, seed=4)
+    init, target, surf = boundary_inputs(n, 3, warp=scale_about_centre(1.04))
+    o = make_pair(m, oracle_lib, init, target, surf, engine=False)[0]
+    o.iterate(60, 0.0)
+    p = o.points()
+    i, j, k = _ijk(n)
+    lo, hi = 0.5 - 0.52, 0.5 + 0.52
+    for a, idx in enumerate((i, j, k)):
+        assert np.allclose(p[idx == 0, a], lo, rtol=0, atol=1e-9) and np.allclose(p[idx == n, a], hi, rtol=0, atol=1e-9)
+
+
+def test_classification_lists_of_a_previous_run_are_used(oracle_lib):
+    """SM.C:2066-2077 + BPS.C:344-349: with isCornerPoint / isFeatureEdgePoint data the edge meshes are not consulted"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 4
+    m = hex_block(n, jitter=0.1, seed=1)
+    init, target, surf = boundary_inputs(n, 2)
+    f0 = make_pair(m, oracle_lib, init, None, surf, engine=False)[0].boundary_fields()
+    cio = f0["isCornerPoint"].astype(np.int32).copy()
+    fio = f0["isFeatureEdgePoint"].astype(np.int32).copy()
+    victim = np.where(fio == 1)[0][0]
+    fio[victim] = 0                                             # the lists win over the geometry
+    f1 = make_pair(m, oracle_lib, init, None, surf, engine=False, cornerIO=cio, featureIO=fio)[0].boundary_fields()
+    assert f1["isFeatureEdgePoint"][victim] == 0 and f1["isFeatureEdgePoint"].sum() == f0["isFeatureEdgePoint"].sum() - 1
+    assert np.array_equal(f1["isCornerPoint"], f0["isCornerPoint"])
