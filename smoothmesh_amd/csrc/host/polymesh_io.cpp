@@ -9,7 +9,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <map>
+#include <sstream>
 #include <stdexcept>
 #include <vector>
 
@@ -386,6 +388,69 @@ void writeLabelList(const std::string& file, const std::string& location, const 
     std::fputs(")\n", f);
     writeFooter(f);
     closeOut(f, file);
+}
+
+namespace {
+// one OBJ record: keyword + whitespace-separated tokens; "12/3/4" style vertex references keep their first number,
+// negative numbers count back from the last vertex read
+template <class OnVertex, class OnRecord>
+void scanObj(const std::string& file, OnVertex onVertex, OnRecord onRecord) {
+    std::ifstream in(file);
+    if (!in) throw std::runtime_error("cannot open " + file);
+    std::string line;
+    int64_t nv = 0, lineNo = 0;
+    while (std::getline(in, line)) {
+        ++lineNo;
+        std::istringstream ls(line);
+        std::string key;
+        if (!(ls >> key) || key[0] == '#') continue;
+        if (key == "v") {
+            double x, y, z;
+            if (!(ls >> x >> y >> z)) throw std::runtime_error(file + ":" + std::to_string(lineNo) + ": bad vertex record");
+            onVertex(x, y, z);
+            ++nv;
+        } else if (key == "f" || key == "l") {
+            std::vector<int32_t> ids;
+            std::string tok;
+            while (ls >> tok) {
+                const long i = std::strtol(tok.c_str(), nullptr, 10);
+                const int64_t id = i > 0 ? i - 1 : nv + i;
+                if (i == 0 || id < 0 || id >= nv) throw std::runtime_error(file + ":" + std::to_string(lineNo) + ": vertex reference out of range");
+                ids.push_back((int32_t)id);
+            }
+            onRecord(key[0], ids);
+        }
+    }
+}
+}  // namespace
+
+void readObjSurface(const std::string& file, std::vector<double>& points, std::vector<int32_t>& triangles) {
+    points.clear(); triangles.clear();
+    scanObj(file, [&](double x, double y, double z) { points.push_back(x); points.push_back(y); points.push_back(z); },
+            [&](char kind, const std::vector<int32_t>& v) {
+                if (kind != 'f') return;
+                for (size_t k = 1; k + 1 < v.size(); ++k) { triangles.push_back(v[0]); triangles.push_back(v[k]); triangles.push_back(v[k + 1]); }
+            });
+}
+
+void readObjEdges(const std::string& file, std::vector<double>& points, std::vector<int32_t>& edges) {
+    std::vector<double> all;
+    edges.clear();
+    scanObj(file, [&](double x, double y, double z) { all.push_back(x); all.push_back(y); all.push_back(z); },
+            [&](char kind, const std::vector<int32_t>& v) {
+                if (kind != 'l') return;
+                for (size_t k = 0; k + 1 < v.size(); ++k) { edges.push_back(v[k]); edges.push_back(v[k + 1]); }
+            });
+    std::vector<int32_t> renumber(all.size() / 3, -1);
+    for (int32_t v : edges) renumber[(size_t)v] = 0;
+    points.clear();
+    int32_t next = 0;
+    for (size_t i = 0; i < renumber.size(); ++i)
+        if (renumber[i] == 0) {
+            renumber[i] = next++;
+            points.insert(points.end(), all.begin() + 3 * (std::ptrdiff_t)i, all.begin() + 3 * (std::ptrdiff_t)i + 3);
+        }
+    for (int32_t& v : edges) v = renumber[(size_t)v];
 }
 
 void writePolyMesh(const std::string& dir, const std::string& location, const PolyMeshData& m, bool binary, int precision) {

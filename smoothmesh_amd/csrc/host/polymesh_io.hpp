@@ -31,6 +31,11 @@ struct PolyMeshData {
 void readPolyMesh(const std::string& polyMeshDir, const std::string& pointsDir, PolyMeshData& out);
 void readPoints(const std::string& file, std::vector<double>& pts);
 void readLabelList(const std::string& file, std::vector<int32_t>& out);
+// Wavefront OBJ inputs of the boundary point smoothing (constant/geometry/*.obj, SM.C:1924-1926).  As OpenFOAM's readers
+// (third-party) treat them: surface polygons become triangle fans about their first vertex; an edge mesh takes the
+// consecutive pairs of every "l" record and drops the points no edge uses, keeping the order of the others.
+void readObjSurface(const std::string& file, std::vector<double>& points, std::vector<int32_t>& triangles);
+void readObjEdges(const std::string& file, std::vector<double>& points, std::vector<int32_t>& edges);
 void writePoints(const std::string& polyMeshDir, const std::string& location, int32_t nPoints, const double* pts,
                  bool binary, int precision);
 void writeLabelList(const std::string& file, const std::string& location, const std::string& object,

@@ -4,8 +4,9 @@
 //
 // This host is standalone (own option parser, own polyMesh I/O) because OpenFOAM is not available
 // in the build environment; INTEGRATION.md shows the OpenFOAM-linked variant of the same calls.
-// Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available, serial and -parallel.
-// Out of scope: boundary point smoothing (constant/geometry/*.obj); asking for it is an error, not a silent skip.
+// Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available, serial and -parallel;
+// boundary point smoothing (constant/geometry/*.obj, boundaryPointSmoothing.C) in serial runs.
+// (under -parallel asking for it is an error, not a silent skip).
 //
 //   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
 //
@@ -92,6 +93,8 @@ Options parseArgs(int argc, char** argv) {
                       "       [-minAngle deg] [-maxAngle deg] [-writeInterval n] [-writeFormat ascii|binary] [-device n]\n"
                       "       [-layerPatches '(p1 \"re.*\")' -layerMaxBlendingFraction x -layerEdgeLength x -layerExpansionRatio x\n"
                       "        -minLayers n -maxLayers n]\n"
+                      "       [-smoothingPatches '(p1 \"re.*\")' -internalSmoothingBlendingFraction x]   (boundary point smoothing, with\n"
+                      "        constant/geometry/targetSurfaces.obj + initEdges.obj [+ targetEdges.obj]; serial runs)\n"
                       "Move internal mesh points to increase mesh quality (MI355X engine)");
             std::exit(0);
         }
@@ -333,9 +336,9 @@ int main(int argc, char** argv) {
     // patches for the boundary layer treatment, getPatchIdsForOption SM.C:1442-1471 / 1823-1833: a wordRe list,
     // "(name1 name2 \"regex.*\")" or a single word; quoted entries are regular expressions.  Every sub-domain carries
     // the original patches (possibly empty) plus its processor patches, so the names are matched per sub-domain.
-    std::vector<std::pair<std::string, bool>> layerWords;   // (word, is a regular expression)
-    if (opt.found("layerPatches")) {
-        std::string v = opt.kv.at("layerPatches");
+    typedef std::vector<std::pair<std::string, bool>> WordRes;   // (word, is a regular expression)
+    auto parseWordRes = [&](const std::string& optName, std::string v) {
+        WordRes words;
         for (char& ch : v) if (ch == '(' || ch == ')') ch = ' ';
         size_t i = 0;
         while (i < v.size()) {
@@ -347,33 +350,78 @@ int main(int argc, char** argv) {
             else while (i < v.size() && !std::isspace((unsigned char)v[i])) tok.push_back(v[i++]);
             if (isRe) {
                 try { (void)std::regex(tok, std::regex::extended); }
-                catch (const std::regex_error&) { fatal("-layerPatches: bad regular expression \"" + tok + "\""); }
+                catch (const std::regex_error&) { fatal("-" + optName + ": bad regular expression \"" + tok + "\""); }
             }
-            layerWords.push_back({tok, isRe});
+            words.push_back({tok, isRe});
         }
-    }
+        return words;
+    };
+    auto matchesAny = [](const WordRes& words, const std::string& name) {
+        for (const auto& w : words)
+            if (w.second ? std::regex_match(name, std::regex(w.first, std::regex::extended)) : (name == w.first)) return true;
+        return false;
+    };
+    WordRes layerWords;
+    if (opt.found("layerPatches")) layerWords = parseWordRes("layerPatches", opt.kv.at("layerPatches"));
     bool anyLayerPatch = false;
     std::vector<std::vector<uint8_t>> isLayerPatchOf(R.size());
     for (size_t r = 0; r < R.size(); ++r) {
         const auto& patches = R[r].mesh.patches;
         isLayerPatchOf[r].assign(patches.size(), 0);
         for (size_t p = 0; p < patches.size(); ++p)
-            for (const auto& w : layerWords) {
-                const bool hit = w.second ? std::regex_match(patches[p].name, std::regex(w.first, std::regex::extended)) : (patches[p].name == w.first);
-                if (hit) { isLayerPatchOf[r][p] = 1; anyLayerPatch = true; }
-            }
+            if (matchesAny(layerWords, patches[p].name)) { isLayerPatchOf[r][p] = 1; anyLayerPatch = true; }
     }
     if (anyLayerPatch) std::printf("Patches for boundary layer treatment: %s\n", opt.kv.at("layerPatches").c_str());
     else std::puts("Patches for boundary layer treatment: none");
     const double layerMaxBlendingFraction = opt.getD("layerMaxBlendingFraction", 0.3);
     const bool doLayerTreatment = anyLayerPatch && layerMaxBlendingFraction > SMALL;   // SM.C:2024-2028
-    // out-of-scope feature: refuse instead of silently ignoring (SM.C:2081-2093)
-    if (fileExists(cd + "/constant/geometry/targetSurfaces.obj"))
-        fatal("constant/geometry/targetSurfaces.obj found: boundary point smoothing (boundaryPointSmoothing.C) is outside the scope of this build");
+    // smoothing patches: every patch unless -smoothingPatches says otherwise (SM.C:1835-1853)
+    const std::string smoothingOpt = opt.found("smoothingPatches") ? opt.kv.at("smoothingPatches") : std::string("(\".*\")");
+    const WordRes smoothingWords = parseWordRes("smoothingPatches", smoothingOpt);
+    bool anySmoothingPatch = false;
+    std::vector<std::vector<uint8_t>> isSmoothingPatchOf(R.size());
+    for (size_t r = 0; r < R.size(); ++r) {
+        const auto& patches = R[r].mesh.patches;
+        isSmoothingPatchOf[r].assign(patches.size(), 0);
+        for (size_t p = 0; p < patches.size(); ++p)
+            if (matchesAny(smoothingWords, patches[p].name)) { isSmoothingPatchOf[r][p] = 1; anySmoothingPatch = true; }
+    }
+    if (anySmoothingPatch) std::printf("Patches for boundary point smoothing: %s\n", smoothingOpt.c_str());
+    else std::puts("Patches for boundary point smoothing: none");
+    const double internalSmoothingBlendingFraction = opt.getD("internalSmoothingBlendingFraction", 0.0);   // SM.C:1907
+
     if (doLayerTreatment) std::puts("Enabled boundary layer treatment\n");
     else std::puts("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
-    std::puts("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\nconstant/geometry/targetSurfaces.obj\nconstant/geometry/initEdges.obj\n");
-    if (doLayerTreatment)   // SM.C:2095-2098
+
+    // classification lists of a previous run (labelIOLists <time>/isCornerPoint, <time>/isFeatureEdgePoint, SM.C:2039-2077)
+    const std::string startName = startIsConstant ? std::string("constant") : timeName(startValue);
+    std::vector<int32_t> isCornerPointIO, isFeatureEdgePointIO;
+    bool labelIOListsHaveData = false;
+    if (!opt.parallel) {
+        auto readIfPresent = [&](const std::string& name, std::vector<int32_t>& out) {
+            const std::string f = cd + "/" + startName + "/" + name;
+            if (!fileExists(f) && !fileExists(f + ".gz")) return;
+            try { readLabelList(f, out); } catch (const std::exception& e) { fatal(e.what()); }
+            if ((int32_t)out.size() != R[0].mesh.nPoints()) fatal(f + ": size does not match the number of points");
+            for (int32_t v : out) labelIOListsHaveData = labelIOListsHaveData || v == 1;
+        };
+        readIfPresent("isCornerPoint", isCornerPointIO);
+        readIfPresent("isFeatureEdgePoint", isFeatureEdgePointIO);
+    }
+    if (labelIOListsHaveData) std::puts("Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
+    else std::puts("Did not find corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
+
+    // prerequisites of the boundary point smoothing, SM.C:2080-2093
+    const std::string targetSurfacesFile = "constant/geometry/targetSurfaces.obj", initEdgesFile = "constant/geometry/initEdges.obj",
+                      targetEdgesFile = "constant/geometry/targetEdges.obj";
+    const bool doBoundarySmoothing = fileExists(cd + "/" + targetSurfacesFile) && (fileExists(cd + "/" + initEdgesFile) || labelIOListsHaveData) &&
+                                     anySmoothingPatch;
+    if (doBoundarySmoothing && opt.parallel)
+        fatal("boundary point smoothing (constant/geometry/targetSurfaces.obj is present) is not available under -parallel in this build: "
+              "run the case serially, or pass -smoothingPatches '()' to smooth the internal points only");
+    if (doBoundarySmoothing) std::puts("Enabled boundary point smoothing\n");
+    else std::printf("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\n%s\n%s\n\n", targetSurfacesFile.c_str(), initEdgesFile.c_str());
+    if (doLayerTreatment && !doBoundarySmoothing)   // SM.C:2095-2098
         std::puts("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
 
     // engines
@@ -531,6 +579,50 @@ int main(int argc, char** argv) {
         }
     }
 
+    if (doBoundarySmoothing) {   // SM.C:2131-2172, 2186-2253 on the engine's side
+        std::vector<double> surfPts, initPts, tgtPts;
+        std::vector<int32_t> surfTris, initE, tgtE;
+        try {
+            readObjSurface(cd + "/" + targetSurfacesFile, surfPts, surfTris);
+            std::printf("Target surfaces file \"%s\" stats:\nTriangles    : %zu\nVertices     : %zu\n\n", targetSurfacesFile.c_str(), surfTris.size() / 3, surfPts.size() / 3);
+            if (fileExists(cd + "/" + initEdgesFile)) {
+                readObjEdges(cd + "/" + initEdgesFile, initPts, initE);
+                std::printf("Initial feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n\n", initEdgesFile.c_str(), initPts.size() / 3, initE.size() / 2);
+            }
+            if (fileExists(cd + "/" + targetEdgesFile)) {
+                readObjEdges(cd + "/" + targetEdgesFile, tgtPts, tgtE);
+                std::printf("Target feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n", targetEdgesFile.c_str(), tgtPts.size() / 3, tgtE.size() / 2);
+            } else
+                std::printf("WARNING: Initial feature edges will be used also as target edges, because\ndid not find file %s.\n\n", targetEdgesFile.c_str());
+        } catch (const std::exception& e) { fatal(e.what()); }
+        const auto& patches = R[0].mesh.patches;
+        std::vector<int32_t> pStart, pSize;
+        std::vector<uint8_t> pKind;
+        for (const auto& pt : patches) {
+            pStart.push_back(pt.startFace); pSize.push_back(pt.nFaces);
+            pKind.push_back(pt.type == "processor" ? 1 : pt.type == "empty" ? 2 : 0);
+        }
+        smgpu_boundary_desc bd{};
+        bd.nPatches = (int32_t)patches.size(); bd.patchStart = pStart.data(); bd.patchSize = pSize.data(); bd.patchKind = pKind.data();
+        bd.isSmoothingPatch = isSmoothingPatchOf[0].data();
+        bd.nInitEdgePoints = (int32_t)(initPts.size() / 3); bd.initEdgePoints = initPts.data(); bd.nInitEdges = (int32_t)(initE.size() / 2); bd.initEdges = initE.data();
+        bd.nTargetEdgePoints = (int32_t)(tgtPts.size() / 3); bd.targetEdgePoints = tgtPts.data(); bd.nTargetEdges = (int32_t)(tgtE.size() / 2); bd.targetEdges = tgtE.data();
+        bd.nSurfacePoints = (int32_t)(surfPts.size() / 3); bd.surfacePoints = surfPts.data();
+        bd.nSurfaceTriangles = (int32_t)(surfTris.size() / 3); bd.surfaceTriangles = surfTris.data();
+        bd.isCornerPointIO = isCornerPointIO.empty() ? nullptr : isCornerPointIO.data();
+        bd.isFeatureEdgePointIO = isFeatureEdgePointIO.empty() ? nullptr : isFeatureEdgePointIO.data();
+        bd.distanceTolerance = 1e-4 * std::min(meshMinEdgeLength, layerEdgeLength);   // REL_TOL, SM.C:1921
+        bd.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
+        std::printf("Distance tolerance = %g\n\n", bd.distanceTolerance);
+        smgpu_boundary_info bi{};
+        check(smgpu_set_boundary_smoothing(R[0].h, &bd, &bi), "smgpu_set_boundary_smoothing");
+        if (!bi.enabled) fatal("boundary point smoothing: the engine did not enable it (empty target surface or edge mesh?)");
+        std::printf("Detected number of target edge mesh strings: %d\n\n", bi.nTargetEdgeStrings);
+        std::printf("Boundary point classification summary:\n- Detected number of corner points: %d\n- Detected number of feature edge points: %d\n"
+                    "- Detected number of smoothing surface points: %d\n- Detected number of frozen surface points: %d\n\n",
+                    bi.nCornerPoints, bi.nFeatureEdgePoints, bi.nSmoothingSurfacePoints, bi.nFrozenSurfacePoints);
+    }
+
     auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
     auto exchangeL = [&] {
         for (int a = 0; a < nRanks; ++a)
@@ -568,6 +660,14 @@ int main(int argc, char** argv) {
             check(smgpu_get_points(K.h, pts.data()), "smgpu_get_points");
             try { writePoints(K.root + "/" + tn + "/polyMesh", tn + "/polyMesh", K.mesh.nPoints(), pts.data(), binary, writePrecision); }
             catch (const std::exception& e) { fatal(e.what()); }
+        }
+        if (doBoundarySmoothing) {   // labelIOLists with AUTO_WRITE, SM.C:2039-2064
+            std::vector<int32_t> a((size_t)R[0].mesh.nPoints()), b((size_t)R[0].mesh.nPoints());
+            check(smgpu_get_boundary_classification(R[0].h, a.data(), b.data()), "smgpu_get_boundary_classification");
+            try {
+                writeLabelList(cd + "/" + tn + "/isCornerPoint", tn, "isCornerPoint", "labelList", (int64_t)a.size(), a.data(), binary, "");
+                writeLabelList(cd + "/" + tn + "/isFeatureEdgePoint", tn, "isFeatureEdgePoint", "labelList", (int64_t)b.size(), b.data(), binary, "");
+            } catch (const std::exception& e) { fatal(e.what()); }
         }
     };
 

@@ -91,6 +91,62 @@ def test_layer_patches_case(tmp_path, oracle_lib):
     assert "Patches for boundary layer treatment: none" in out2 and "Boundary layer treatment is disabled" in out2
 
 
+def test_boundary_point_smoothing_case(tmp_path, oracle_lib):
+    """constant/geometry/{targetSurfaces,initEdges,targetEdges}.obj present -> boundary points are projected to the target
+    (SM.C:2080-2093, 2307-2357); the classification lists are written with the mesh and read back on a restart"""
+    from bnd_cases import boundary_inputs, make_pair, scale_about_centre, tangential_jitter
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import read_polymesh, write_case
+    from smoothmesh_amd.surfgen import read_obj_edges, read_obj_surface, write_obj_edges, write_obj_surface
+    m = tangential_jitter(hex_block(8, jitter=0.2, seed=3), 0.02, seed=4)
+    write_case(str(tmp_path), m, binary=True, writeFormat="binary")
+    init, target, surf = boundary_inputs(8, 3, warp=scale_about_centre(1.02))
+    geo = tmp_path / "constant" / "geometry"
+    os.makedirs(geo)
+    write_obj_edges(str(geo / "initEdges.obj"), *init)
+    write_obj_edges(str(geo / "targetEdges.obj"), *target)
+    # quads in the file: the reader triangulates them as fans
+    with open(geo / "targetSurfaces.obj", "w") as f:
+        for p in surf[0]:
+            f.write("v %.17g %.17g %.17g\n" % tuple(p))
+        for k in range(0, len(surf[1]), 2):
+            a, b = surf[1][k], surf[1][k + 1]                   # (q0 q1 q2), (q0 q2 q3)
+            f.write("f %d %d %d %d\n" % (a[0] + 1, a[1] + 1, a[2] + 1, b[2] + 1))
+    out = _run(["-case", str(tmp_path), "-centroidalIters", "10", "-relTol", "0", "-internalSmoothingBlendingFraction", "0.3"])
+    assert "Enabled boundary point smoothing" in out
+    assert "- Detected number of corner points: 8" in out and "- Detected number of feature edge points: 84" in out
+    assert "Detected number of target edge mesh strings: 12" in out
+    # what the front-end read is what the Python readers read
+    init_r, target_r, surf_r = read_obj_edges(str(geo / "initEdges.obj")), read_obj_edges(str(geo / "targetEdges.obj")), read_obj_surface(str(geo / "targetSurfaces.obj"))
+    assert np.array_equal(surf_r[1], surf[1]) and np.array_equal(init_r[1], init[1])
+    o = make_pair(m, oracle_lib, init_r, target_r, surf_r, constraints=True, engine=False, blend=0.3)[0]
+    n, res, frz = o.iterate(10, 0.0)
+    lines = LINE.findall(out)
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    got = read_polymesh(str(tmp_path / "constant" / "polyMesh"), pointsDir=str(tmp_path / "10" / "polyMesh")).points
+    assert rel_linf(got, o.points()) <= 1e-13
+    assert os.path.exists(tmp_path / "10" / "isCornerPoint") and os.path.exists(tmp_path / "10" / "isFeatureEdgePoint")
+    # restart: the lists are found and used (the points have left the initial edges by now)
+    out2 = _run(["-case", str(tmp_path), "-centroidalIters", "2", "-relTol", "0", "-internalSmoothingBlendingFraction", "0.3"])
+    assert "Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files" in out2
+    assert "- Detected number of corner points: 8" in out2 and "- Detected number of feature edge points: 84" in out2
+    # -parallel with the geometry present is refused, not silently different
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import write_decomposed_case
+    par = tmp_path / "par"
+    os.makedirs(par)
+    write_decomposed_case(str(par), [hex_subdomain((4, 4, 4), (2, 1, 1), r, jitter=0.1, seed=1) for r in range(2)], binary=True,
+                          writeFormat="binary")
+    os.makedirs(par / "constant" / "geometry")
+    write_obj_edges(str(par / "constant" / "geometry" / "initEdges.obj"), *init)
+    write_obj_surface(str(par / "constant" / "geometry" / "targetSurfaces.obj"), *surf)
+    r = subprocess.run([BIN, "-case", str(par), "-parallel", "-centroidalIters", "1"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "not available under -parallel" in (r.stdout + r.stderr)
+    # ... unless no patch is to be smoothed (SM.C:2080-2093: boundary point smoothing stays disabled)
+    out3 = _run(["-case", str(par), "-parallel", "-centroidalIters", "1", "-smoothingPatches", "()"])
+    assert "Boundary point smoothing is disabled" in out3
+
+
 def test_relTol_stop_and_option_errors(tmp_path):
     from smoothmesh_amd.meshgen import hex_block
     from smoothmesh_amd.polymesh import write_case
@@ -100,11 +156,18 @@ def test_relTol_stop_and_option_errors(tmp_path):
     assert os.path.isdir(tmp_path / "1")
     r = subprocess.run([BIN, "-case", str(tmp_path), "-noSuchOption", "1"], capture_output=True, text=True)
     assert r.returncode != 0 and "Wrong option" in r.stdout
-    # boundary point smoothing is out of scope: its input file is refused, not silently ignored
+    # boundary point smoothing needs the target surface AND the initial edges (SM.C:2080-2093): one file alone leaves it off
     os.makedirs(tmp_path / "constant" / "geometry")
     (tmp_path / "constant" / "geometry" / "targetSurfaces.obj").write_text("# empty\n")
+    out = _run(["-case", str(tmp_path)])
+    assert "Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:" in out
+    # both present but unusable (no triangles): an error, not a silent skip
+    (tmp_path / "constant" / "geometry" / "initEdges.obj").write_text("v 0 0 0\nv 1 0 0\nl 1 2\n")
     r = subprocess.run([BIN, "-case", str(tmp_path)], capture_output=True, text=True)
-    assert r.returncode != 0 and "outside the scope" in r.stdout
+    assert r.returncode != 0 and "did not enable" in r.stdout
+    (tmp_path / "constant" / "geometry" / "targetSurfaces.obj").write_text("v 0 0 0\nv 1 0 0\nf 1 2 7\n")
+    r = subprocess.run([BIN, "-case", str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode != 0 and "vertex reference out of range" in r.stdout
 
 
 def test_parallel_case(tmp_path, oracle_lib):
