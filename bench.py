@@ -27,12 +27,27 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level
 
 def workload_layers(w):
     """trailing L = boundary layer treatment on (hex: all six sides, cavity: the cavity wall), one GPU only"""
-    return w.endswith("L")
+    return w.rstrip("B").endswith("L")
+
+
+def workload_boundary(w):
+    """trailing B = boundary point smoothing on (hex: every side onto the block's own surface + its twelve feature
+    edges; cavity: the cavity wall onto the sphere it was carved from), one GPU only"""
+    return w.endswith("B")
+
+
+def boundary_params(kind, n):
+    from smoothmesh_amd import BoundaryParams
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface, sphere_surface
+    if kind == "hex":
+        return BoundaryParams(initEdges=box_feature_edges(n), targetSurfaces=box_surface(max(n // 2, 1)))
+    return BoundaryParams(initEdges=box_feature_edges(n), targetSurfaces=sphere_surface(levels=6), smoothingPatches=("cavity",))
 
 
 def parse_workload(w):
     """hexN[c][L] = N^3 hex block; cavityN[c][L] = castellated polyhedral cube-with-sphere-cavity on an N^3 base
     grid; c = edgeAngle + faceAngle constraints on; L = boundary layer treatment on (see workload_layers)."""
+    w = w.rstrip("B")
     if w.endswith("L"):
         w = w[:-1]
     constraints = w.endswith("c")
@@ -60,7 +75,7 @@ def layer_params(kind):
     return LayerParams(layerPatches=('".*"',) if kind == "hex" else ("cavity",))
 
 
-def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False):
+def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False, boundary=False):
     """Serial oracle (CPU restatement of the reference loop) on the SAME mesh for a bounded number of
     iterations.  kind = "port": the reference itself needs OpenFOAM and cannot be built here."""
     from oracle import oracle_ffi
@@ -70,11 +85,16 @@ def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False):
     o = oracle_ffi.Oracle(mesh)
     p = default_params(o.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     o.set_params(p)
-    if layers:
-        from smoothmesh_amd import patch_arrays
-        lp = layer_params(kind)
+    if layers or boundary:
+        from smoothmesh_amd import LayerParams, patch_arrays
+        lp = layer_params(kind) if layers else LayerParams()
         st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches)
-        o.setup_layers(st, sz, kd, sel, lp.layerMaxBlendingFraction, p.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        lopt = (lp.layerMaxBlendingFraction, p.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        if boundary:
+            bp = boundary_params(kind, sample_n)
+            o.setup_boundary(st, sz, kd, sel, patch_arrays(mesh, bp.smoothingPatches)[3], lopt, bp.initEdges, bp.targetEdges, bp.targetSurfaces)
+        else:
+            o.setup_layers(st, sz, kd, sel, *lopt)
     t0 = time.perf_counter()
     o.iterate(1, 0.0)
     t1 = time.perf_counter() - t0
@@ -107,6 +127,7 @@ def main():
 
     kind, n_side, constraints = parse_workload(args.workload)
     layers = workload_layers(args.workload)
+    boundary = workload_boundary(args.workload)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,6 +154,8 @@ def main():
         eng.set_params(prm)
         if layers and not eng.set_layers(layer_params(kind), prm.minEdgeLength):
             raise SystemExit("boundary layer treatment could not be enabled")
+        if boundary and not eng.set_boundary_smoothing(boundary_params(kind, n_side), prm.minEdgeLength)["enabled"]:
+            raise SystemExit("boundary point smoothing could not be enabled")
         if W:
             eng.iterate(W, 0.0)
         torch.cuda.synchronize()
@@ -172,6 +195,8 @@ def main():
         ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
         prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         ds.set_params(prm)
+        if boundary:
+            raise SystemExit("boundary point smoothing (workload suffix B) is a one-GPU feature in this round")
         if layers and not ds.set_layers(layer_params(kind), prm.minEdgeLength):
             raise SystemExit("boundary layer treatment could not be enabled")
         # exchange arrangement (in order on the engine's stream / on a communication stream next to the
@@ -255,7 +280,9 @@ def main():
                         + ("boundary layer treatment on (" + ("all six sides" if kind == "hex" else "the cavity wall") + ", default layer options), "
                            if layers else "") +
                         f"relTol 0, defaults otherwise (BASELINE.json configs[{(2 if constraints else 1) if kind == 'hex' else 3}]"
-                        + (" + -layerPatches" if layers else "") + ")",
+                        + (" + -layerPatches" if layers else "") + (" + constant/geometry/*.obj" if boundary else "") + ")"
+                        + (", boundary point smoothing on (" + ("all sides onto the block's own surface and feature edges" if kind == "hex"
+                                                                 else "the cavity wall onto the triangulated sphere") + ")" if boundary else ""),
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
             "parallelism": parallelism,
         },
@@ -290,7 +317,7 @@ def main():
     if force_dist:
         out["config"]["parallelism"] += " [N=1 forced through the multi-rank path]"
     if world == 1 and not force_dist and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers)
+        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers, boundary=boundary)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if world > 1 or force_dist:

@@ -312,13 +312,14 @@ void Bvh::build(const std::vector<double>& pts, const std::vector<int32_t>& tris
         for (int d = 0; d < 3; ++d) { box[6 * (size_t)tk.node + d] = bl[d] - pad; box[6 * (size_t)tk.node + 3 + d] = bh[d] + pad; }
         int axis = 0;
         for (int d = 1; d < 3; ++d) if (ch[d] - cl[d] > ch[axis] - cl[axis]) axis = d;
-        if (tk.count <= leafSize || !(ch[axis] - cl[axis] > 0.0)) {
+        if (tk.count <= leafSize) {   // leaves hold at most four triangles (the device loads a leaf in one batch)
             link[2 * (size_t)tk.node] = -(tk.first + 1);
             link[2 * (size_t)tk.node + 1] = tk.count;
             continue;
         }
         const int half = tk.count / 2;
-        std::nth_element(order.begin() + tk.first, order.begin() + tk.first + half, order.begin() + tk.first + tk.count,
+        if (ch[axis] - cl[axis] > 0.0)   // coincident centroids: any split will do
+            std::nth_element(order.begin() + tk.first, order.begin() + tk.first + half, order.begin() + tk.first + tk.count,
                          [&](int a, int b) { return ctr[3 * (size_t)a + axis] < ctr[3 * (size_t)b + axis] || (ctr[3 * (size_t)a + axis] == ctr[3 * (size_t)b + axis] && a < b); });
         const int left = (int)(link.size() / 2), right = left + 1;
         box.resize(box.size() + 12); link.resize(link.size() + 4);
@@ -326,6 +327,62 @@ void Bvh::build(const std::vector<double>& pts, const std::vector<int32_t>& tris
         link[2 * (size_t)tk.node + 1] = right;
         todo.push_back({left, tk.first, half});
         todo.push_back({right, tk.first + half, tk.count - half});
+    }
+    // collapse into 8-wide nodes: the children of a wide node are the binary descendants reached by repeatedly opening
+    // the internal candidate with the largest box surface until eight candidates stand (or only leaves are left)
+    wideBox.clear(); wideRef.clear();
+    wideDepth = 0;
+    {
+        auto area = [&](int node) {
+            const double* b = &box[6 * (size_t)node];
+            const double dx = b[3] - b[0], dy = b[4] - b[1], dz = b[5] - b[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        struct WTask { int binNode, wide, depth; };
+        std::vector<WTask> wtodo;
+        auto newWide = [&]() {
+            const int w = (int)(wideRef.size() / 16);
+            wideBox.resize(wideBox.size() + 48, 0.0f);
+            wideRef.resize(wideRef.size() + 16, 0);
+            for (int c = 0; c < 8; ++c) wideRef[16 * (size_t)w + 8 + (size_t)c] = -1;
+            return w;
+        };
+        auto down = [](double v) { float f = (float)v; return ((double)f > v) ? std::nextafterf(f, -INFINITY) : f; };
+        auto up = [](double v) { float f = (float)v; return ((double)f < v) ? std::nextafterf(f, INFINITY) : f; };
+        wtodo.push_back({0, newWide(), 1});
+        while (!wtodo.empty()) {
+            const WTask tk = wtodo.back();
+            wtodo.pop_back();
+            wideDepth = std::max(wideDepth, tk.depth);
+            std::vector<int> cand;
+            if (link[2 * (size_t)tk.binNode] < 0) cand.push_back(tk.binNode);   // the whole (sub)tree is one leaf
+            else { cand.push_back(link[2 * (size_t)tk.binNode]); cand.push_back(link[2 * (size_t)tk.binNode + 1]); }
+            while (cand.size() < 8) {
+                int best = -1;
+                for (size_t c = 0; c < cand.size(); ++c)
+                    if (link[2 * (size_t)cand[c]] >= 0 && (best < 0 || area(cand[c]) > area(cand[(size_t)best]))) best = (int)c;
+                if (best < 0) break;
+                const int open = cand[(size_t)best];
+                cand[(size_t)best] = link[2 * (size_t)open];
+                cand.push_back(link[2 * (size_t)open + 1]);
+            }
+            for (size_t c = 0; c < cand.size(); ++c) {
+                const int bn = cand[c];
+                for (int d = 0; d < 3; ++d) {
+                    wideBox[48 * (size_t)tk.wide + 8 * (size_t)d + c] = down(box[6 * (size_t)bn + (size_t)d]);
+                    wideBox[48 * (size_t)tk.wide + 24 + 8 * (size_t)d + c] = up(box[6 * (size_t)bn + 3 + (size_t)d]);
+                }
+                if (link[2 * (size_t)bn] < 0) {
+                    wideRef[16 * (size_t)tk.wide + c] = -(link[2 * (size_t)bn] + 1);
+                    wideRef[16 * (size_t)tk.wide + 8 + c] = link[2 * (size_t)bn + 1];
+                } else {
+                    const int w = newWide();
+                    wideRef[16 * (size_t)tk.wide + c] = w;
+                    wideRef[16 * (size_t)tk.wide + 8 + c] = 0;
+                    wtodo.push_back({bn, w, tk.depth + 1});
+                }
+            }
+        }
     }
     triVerts.resize(9 * (size_t)n);
     triId.resize((size_t)n);

@@ -46,11 +46,18 @@ struct BoundaryInputHost {
     double meshMinEdgeLength = 0.0, meshPerimeter = 0.0;   // getMeshStats SM.C:1478-1541
 };
 
+// Bounding volume hierarchy over the target triangles.  build() makes a binary tree (median split on the longest
+// centroid axis, <= 4 triangles per leaf) and collapses it into 8-wide nodes: one visit tests eight boxes that lie next
+// to each other in memory, so a query costs a handful of dependent memory round trips instead of two per binary level.
 struct Bvh {
-    std::vector<double> box;       // 6 per node: min xyz, max xyz (inflated: the traversal is conservative)
-    std::vector<int32_t> link;     // 2 per node: children (left, right), or (-(first + 1), count) for a leaf
+    std::vector<double> box;       // binary tree, 6 per node: min xyz, max xyz (inflated: the traversal is conservative)
+    std::vector<int32_t> link;     // binary tree, 2 per node: children (left, right), or (-(first + 1), count) for a leaf
+    std::vector<float> wideBox;    // 48 per wide node, floats rounded outwards: lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]
+    std::vector<int32_t> wideRef;  // 16 per wide node: ref[8] = child wide node, or first triangle (leaf order) of a leaf
+                                   // child; cnt[8] = -1 unused slot, 0 child is a wide node, > 0 triangles of a leaf child
     std::vector<double> triVerts;  // 9 per triangle, leaf order
     std::vector<int32_t> triId;    // original triangle id, leaf order
+    int32_t wideDepth = 0;
     void build(const std::vector<double>& pts, const std::vector<int32_t>& tris);
 };
 

@@ -40,8 +40,11 @@ struct BndView {
     double* featSum; int* featCnt;        // featureEdgeProjections / nFeatureEdgeProjections of the feature points
     int nTE;                    // target edge mesh
     const double* tePts; const int* teEdges; const int* teString;
-    int nNodes;                 // bounding volume hierarchy over the target triangles (boundary.hpp)
-    const double* nodeBox; const int* nodeLink; const double* triVerts; const int* triId;
+    const int* strOff; const int* strEdges;   // CSR string -> its edges (ascending)
+    int nNodes;                 // 8-wide bounding volume hierarchy over the target triangles (boundary.hpp)
+    const float* wideBox;       // 48 floats per node (see findLine)
+    const int* wideRef;         // 16 ints per node: ref[8], cnt[8]
+    const double* triVerts; const int* triId;
     double distanceTolerance, internalBlend;
 };
 
@@ -124,8 +127,10 @@ __global__ void __launch_bounds__(64) k_bnd_feature(MeshView m, State s, BndView
         double best = SMGPU_GREAT;
         int bestE = 0x7fffffff;
         V3 bestP = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
-        for (int e = lane; e < b.nTE; e += 64) {
-            if (str >= 0 && b.teString[e] != str) continue;
+        // the edges of the point's string, in ascending id order (all edges when the point has no string)
+        const int e0 = (str >= 0) ? b.strOff[str] : 0, e1 = (str >= 0) ? b.strOff[str + 1] : b.nTE;
+        for (int ke = e0 + lane; ke < e1; ke += 64) {
+            const int e = (str >= 0) ? b.strEdges[ke] : ke;
             const V3 pr = projectToEdge(b, pt, e);
             const double d = mag(pr - pt);
             if (d < best) { best = d; bestE = e; bestP = pr; }
@@ -163,77 +168,114 @@ __device__ __forceinline__ bool triangleIntersection(const double* __restrict__ 
     return true;
 }
 
-// segment against an (inflated) box, with slack on the parameter range: conservative
-__device__ __forceinline__ bool segmentTouchesBox(const double* __restrict__ bx, const V3& o, const V3& d) {
-    double t0 = -1e-6, t1 = 1.0 + 1e-6;
-    const double oo[3] = {o.x, o.y, o.z}, dd[3] = {d.x, d.y, d.z};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        if (dd[a] == 0.0) {
-            if (oo[a] < bx[a] || oo[a] > bx[3 + a]) return false;
-        } else {
-            double ta = (bx[a] - oo[a]) / dd[a], tb = (bx[3 + a] - oo[a]) / dd[a];
-            if (ta > tb) { const double sw = ta; ta = tb; tb = sw; }
-            const double slack = 1e-9 * (fabs(ta) + fabs(tb)) + 1e-12;
-            ta -= slack; tb += slack;
-            if (ta > t0) t0 = ta;
-            if (tb < t1) t1 = tb;
-            if (t0 > t1) return false;
-        }
-    }
-    return true;
-}
+// One 8-wide node: the child boxes as floats rounded outwards (conservative), structure-of-arrays so that a node is
+// twelve 16-byte loads: lo.x[8], lo.y[8], lo.z[8], hi.x[8], hi.y[8], hi.z[8]  (192 bytes, 64-byte aligned rows).
+// The traversal stack lives in LDS, one column per thread ([entry][thread]: conflict-free): in private memory every
+// push / pop would be a scratch round trip in the dependent chain of the descent.  7 pending siblings per level of the
+// 8-wide tree; the host checks 7 * depth + 1 <= kBvhStack (depth 6 = a million triangles).
+constexpr int kBvhStack = 48;
 
-__device__ __forceinline__ bool findLine(const BndView& b, const V3& start, const V3& end, V3& hitPoint) {
+__device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ stack, const V3& start, const V3& end, V3& hitPoint) {
     const V3 dir = end - start;
     const double tol = 10.0 * 1.0e-15;   // indexedOctree::perturbTol() = 10*SMALL
+    // slab test per axis with the reciprocal direction; an axis the segment does not move along only checks the origin.
+    // Slack on the parameter range and on every slab keeps the test conservative (it may only accept too much).
+    const double o3[3] = {start.x, start.y, start.z}, d3[3] = {dir.x, dir.y, dir.z};
+    double inv[3];
+    bool flat[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { flat[a] = d3[a] == 0.0; inv[a] = flat[a] ? 0.0 : 1.0 / d3[a]; }
     double best = 0.0;
     int bestId = 0x7fffffff;
-    int stack[40];
+    // One kind of work per loop trip: a popped node tests its eight child boxes and pushes what the segment touches
+    // (leaves too, as -(16 * first + count) - 1); a popped leaf loads its (at most four) triangles in one batch and
+    // tests them.  Lanes of a wave that are at different places of their descents still meet at these two program
+    // points, instead of serialising leaf visits inside the child loop.
     int sp = 0;
-    if (b.nNodes > 0) stack[sp++] = 0;
+    if (b.nNodes > 0) stack[kBlock * sp++] = 0;
     while (sp > 0) {
-        const int node = stack[--sp];
-        if (!segmentTouchesBox(b.nodeBox + 6 * (size_t)node, start, dir)) continue;
-        const int l0 = b.nodeLink[2 * node], l1 = b.nodeLink[2 * node + 1];
-        if (l0 >= 0) {
-            if (sp < 38) { stack[sp++] = l0; stack[sp++] = l1; }
-            continue;
-        }
-        const int first = -(l0 + 1);
-        for (int k = first; k < first + l1; ++k) {
-            double t;
-            V3 pt;
-            if (!triangleIntersection(b.triVerts + 9 * (size_t)k, start, dir, tol, t, pt)) continue;
-            if (!(t <= 1.0)) continue;   // treeDataTriSurface::findIntersectOp: inter.distance() <= 1
-            const int id = b.triId[k];
-            if (bestId == 0x7fffffff || t < best || (t == best && id < bestId)) { best = t; bestId = id; hitPoint = pt; }
+        const int item = stack[kBlock * --sp];
+        if (item >= 0) {
+            const float4* __restrict__ nb = reinterpret_cast<const float4*>(b.wideBox) + 12 * (size_t)item;
+            float bx[48];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) { const float4 v = nb[q]; bx[4 * q] = v.x; bx[4 * q + 1] = v.y; bx[4 * q + 2] = v.z; bx[4 * q + 3] = v.w; }
+            const int4* __restrict__ rc = reinterpret_cast<const int4*>(b.wideRef) + 4 * (size_t)item;   // ref[8], cnt[8]
+            const int4 r0 = rc[0], r1 = rc[1], c0 = rc[2], c1 = rc[3];
+            const int ref[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+            const int cnt[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int n = cnt[c];
+                double t0 = -1e-6, t1 = 1.0 + 1e-6;
+                bool touch = n >= 0;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double lo = (double)bx[8 * a + c], hi = (double)bx[24 + 8 * a + c];
+                    if (flat[a]) { touch = touch && !(o3[a] < lo || o3[a] > hi); }
+                    else {
+                        double ta = (lo - o3[a]) * inv[a], tb = (hi - o3[a]) * inv[a];
+                        if (ta > tb) { const double sw = ta; ta = tb; tb = sw; }
+                        const double slack = 1e-9 * (fabs(ta) + fabs(tb)) + 1e-12;
+                        ta -= slack; tb += slack;
+                        t0 = (ta > t0) ? ta : t0;
+                        t1 = (tb < t1) ? tb : t1;
+                    }
+                }
+                if (touch && !(t0 > t1) && sp < kBvhStack) stack[kBlock * sp++] = (n == 0) ? ref[c] : -(16 * ref[c] + n) - 1;
+            }
+        } else {
+            const int code = -(item + 1), first = code >> 4, n = code & 15;
+            double tv[4][9];
+            int ids[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int kk = first + ((k < n) ? k : n - 1);
+                const double* __restrict__ src = b.triVerts + 9 * (size_t)kk;
+#pragma unroll
+                for (int q = 0; q < 9; ++q) tv[k][q] = src[q];
+                ids[k] = b.triId[kk];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                double t;
+                V3 pt;
+                if (k >= n || !triangleIntersection(tv[k], start, dir, tol, t, pt)) continue;
+                if (!(t <= 1.0)) continue;   // treeDataTriSurface::findIntersectOp: inter.distance() <= 1
+                if (bestId == 0x7fffffff || t < best || (t == best && ids[k] < bestId)) { best = t; bestId = ids[k]; hitPoint = pt; }
+            }
         }
     }
     return bestId != 0x7fffffff;
 }
 
-// findIntersection BPS.C:682-745
-__device__ __forceinline__ V3 findIntersection(const BndView& b, const V3& origPoint, const V3& pointNormal, double searchDistance) {
+// findIntersection BPS.C:682-745.  Called by BOTH lanes of a pair (role 0 / 1, lanes 2k and 2k + 1 work on the same
+// point): the two half-ray queries run side by side, one per lane, and the results are exchanged by shuffles.
+__device__ __forceinline__ V3 findIntersectionPair(const BndView& b, int* __restrict__ stack, const V3& origPoint, const V3& pointNormal, double searchDistance, int role) {
     const V3 undef = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
     const V3 endPoint1 = origPoint + pointNormal * searchDistance;
     const V3 endPoint2 = origPoint - pointNormal * searchDistance;
-    V3 hitPoint1 = undef, hitPoint2 = undef, h;
-    if (findLine(b, origPoint, endPoint1, h)) hitPoint1 = h;
-    if (findLine(b, origPoint, endPoint2, h)) hitPoint2 = h;
+    V3 mine = undef, h;
+    if (findLine(b, stack, origPoint, role ? endPoint2 : endPoint1, h)) mine = h;
+    const V3 other = v3(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64), __shfl_xor(mine.z, 1, 64));
+    const V3 hitPoint1 = role ? other : mine, hitPoint2 = role ? mine : other;
     const double distance1 = mag(origPoint - hitPoint1);
     const double distance2 = mag(origPoint - hitPoint2);
     if (distance1 < distance2) return hitPoint1;
     else if (distance2 < distance1) return hitPoint2;
-    if (findLine(b, endPoint1, endPoint2, h)) return h;
+    if (findLine(b, stack, endPoint1, endPoint2, h)) return h;
     return undef;
 }
 
 // The boundary points' part of the iteration from the projection on (see the file header).
+// Two lanes per boundary point: they differ only in which half-ray they trace (findIntersectionPair); lane "role 0"
+// writes the results.
 template <bool FINAL>
 __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm, BndView b, int partialBase) {
     if (s.acc->stop) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    __shared__ int bvhStack[kBvhStack * kBlock];
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int i = t >> 1, role = t & 1;
     double dist = 0.0;
     int fcount = 0;
     if (i < b.nB) {
@@ -257,7 +299,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
                 V3 surfPoint = undef;
                 for (int it = 0; it < 4; ++it) {
                     searchDistance *= (1.0 / 1e-4);   // 1.0 / REL_TOL
-                    surfPoint = findIntersection(b, np, pointNormal, searchDistance);
+                    surfPoint = findIntersectionPair(b, bvhStack + threadIdx.x, np, pointNormal, searchDistance, role);
                     if (surfPoint != undef) { np = surfPoint; break; }
                 }
                 if (surfPoint == undef) s.acc->err = BND_ERR_NOHIT;        // BPS.C:932-938
@@ -294,13 +336,15 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (FINAL) {
-            if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
-            dist = mag(np - cur) / prm.maxStep;
-            stv(s.ptsNext, p, np);
-        } else {
-            stv(s.prop, p, np);
-            s.frozen[p] = frozen ? 1 : 0;
+        if (role == 0) {
+            if (FINAL) {
+                if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
+                dist = mag(np - cur) / prm.maxStep;
+                stv(s.ptsNext, p, np);
+            } else {
+                stv(s.prop, p, np);
+                s.frozen[p] = frozen ? 1 : 0;
+            }
         }
     }
     if (FINAL) blockPublish<kBlock>(s, dist, fcount, partialBase + blockIdx.x);
@@ -308,10 +352,11 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
 
 // parity access to the segment query: one thread per segment
 __global__ void __launch_bounds__(kBlock) k_bnd_find_line(BndView b, int n, const double* seg, double* out, int* hit) {
+    __shared__ int bvhStack[kBvhStack * kBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     V3 h = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
-    hit[i] = findLine(b, ldv(seg, 2 * i), ldv(seg, 2 * i + 1), h) ? 1 : 0;
+    hit[i] = findLine(b, bvhStack + threadIdx.x, ldv(seg, 2 * i), ldv(seg, 2 * i + 1), h) ? 1 : 0;
     stv(out, i, h);
 }
 

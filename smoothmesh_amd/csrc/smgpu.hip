@@ -119,8 +119,8 @@ struct smgpu_handle {
     // cross-stream ordering by stream memory operations (hipStreamWriteValue32 on the producer, hipStreamWaitValue32 on the
     // consumer, one monotonically increasing word per dependency kind): measured 4.1 us per dependency against 10.1 us for
     // hipEventRecord + hipStreamWaitEvent (scripts/native/stream_dep_bench.hip).  SMGPU_STREAM_OPS=0 selects the events.
-    uint32_t* depWords = nullptr;        // 4 words, 64 bytes apart
-    uint32_t depValue[4] = {0, 0, 0, 0};
+    uint32_t* depWords = nullptr;        // one word per dependency kind, 64 bytes apart
+    uint32_t depValue[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool streamOps = false;
     // multi-rank: the stream the host enqueues its exchanges on (smgpu_halo_desc.exchangeStream) and the events
     // that order it against the engine's stream
@@ -132,6 +132,9 @@ struct smgpu_handle {
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
     bool bndOn = false;        // smgpu_set_boundary_smoothing
+    hipStream_t bndSide = nullptr;   // k_bnd_normals / k_bnd_feature run next to the geometry kernel
+    hipEvent_t evBndFork = nullptr, evBndJoin = nullptr;
+    bool bndPreInFlight = false;
     BndView bv{};
     BoundarySetup bs;
     std::vector<int32_t> layerHopsHost, layerMapHost;   // kept for the debug getters
@@ -212,11 +215,11 @@ static int launchK(smgpu_handle* h, int k, F&& f, hipStream_t stream = nullptr) 
     return 0;
 }
 
-enum { DEP_FORK = 0, DEP_JOIN = 1, DEP_TO_EXCH = 2, DEP_FROM_EXCH = 3 };
+enum { DEP_FORK = 0, DEP_JOIN = 1, DEP_TO_EXCH = 2, DEP_FROM_EXCH = 3, DEP_BND_FORK = 4, DEP_BND_JOIN = 5, DEP_COUNT = 6 };
 static int depInit(smgpu_handle* h) {
     if (h->depWords || !envInt("SMGPU_STREAM_OPS", 1)) return 0;
-    if (hipMalloc((void**)&h->depWords, 4 * 64) != hipSuccess) { (void)hipGetLastError(); h->depWords = nullptr; return 0; }
-    if (hipMemset(h->depWords, 0, 4 * 64) != hipSuccess) return fail("hipMemset failed");
+    if (hipMalloc((void**)&h->depWords, DEP_COUNT * 64) != hipSuccess) { (void)hipGetLastError(); h->depWords = nullptr; return 0; }
+    if (hipMemset(h->depWords, 0, DEP_COUNT * 64) != hipSuccess) return fail("hipMemset failed");
     h->streamOps = true;
     return 0;
 }
@@ -236,6 +239,7 @@ static int drainTimers(smgpu_handle* h) {
     if (h->pending.empty()) return 0;
     HIP_OK(hipStreamSynchronize(h->stream));
     if (h->side) HIP_OK(hipStreamSynchronize(h->side));
+    if (h->bndSide) HIP_OK(hipStreamSynchronize(h->bndSide));
     for (auto& p : h->pending) {
         float ms = 0.f;
         HIP_OK(hipEventElapsedTime(&ms, p.a, p.b));
@@ -499,7 +503,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.acc, 1);
     {
         // + the boundary points' partials when k_bnd_fix finishes them (smgpu_set_boundary_smoothing)
-        const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(t.nPoints) + 1;
+        const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + 2 * (size_t)gridFor(t.nPoints) + 1;
         rc |= devAlloc(h, &s.blkMax, nPart);
         rc |= devAlloc(h, &s.blkCnt, nPart);
     }
@@ -533,6 +537,9 @@ int smgpu_destroy(smgpu_handle* h) {
     if (h->evToExch) (void)hipEventDestroy(h->evToExch);
     if (h->evFromExch) (void)hipEventDestroy(h->evFromExch);
     if (h->depWords) (void)hipFree(h->depWords);
+    if (h->bndSide) { (void)hipStreamSynchronize(h->bndSide); (void)hipStreamDestroy(h->bndSide); }
+    if (h->evBndFork) (void)hipEventDestroy(h->evBndFork);
+    if (h->evBndJoin) (void)hipEventDestroy(h->evBndJoin);
     if (h->evFork) (void)hipEventDestroy(h->evFork);
     if (h->evJoin) (void)hipEventDestroy(h->evJoin);
     if (h->ownStream && h->stream) (void)hipStreamDestroy(h->stream);
@@ -632,16 +639,35 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
     hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
                        nTiles, h->xcdMap);
 }
+static int launchBndPre(smgpu_handle* h, const MeshView& m, const State& s, hipStream_t stream) {
+    return launchK(h, K_BND, [&] {
+        hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, stream, m, s, h->bv);
+        if (h->bv.nFeat) hipLaunchKernelGGL(k_bnd_feature, dim3(h->bv.nFeat), dim3(64), 0, stream, m, s, h->bv);
+    }, stream);
+}
+// Start of an iteration with boundary point smoothing: both kernels only read the current coordinates, so they run on
+// a side stream while the geometry kernel has the main one; runSmooth joins.
+static int runBndPre(smgpu_handle* h) {
+    if (!h->bndOn || !h->bndSide || h->bndPreInFlight) return 0;
+    if (depSignal(h, DEP_BND_FORK, h->stream, h->evBndFork) || depWait(h, DEP_BND_FORK, h->bndSide, h->evBndFork)) return 1;
+    if (launchBndPre(h, h->mv, h->st, h->bndSide)) return 1;
+    if (depSignal(h, DEP_BND_JOIN, h->bndSide, h->evBndJoin)) return 1;
+    h->bndPreInFlight = true;
+    return 0;
+}
 // tileList == NULL: all tiles; otherwise the nTiles listed ones (multi-rank interior / shared split)
 template <bool FINAL>
 static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList = nullptr, int nList = 0) {
     const int kid = FINAL ? K_SMOOTH_FINAL : K_SMOOTH_PROP;
     // boundary point smoothing: normals and feature edge projections of the current coordinates first (SM.C:2266,
-    // BPS.C:866); after the smoothing kernel k_bnd_fix finishes the boundary points it skipped
-    if (h->bndOn && launchK(h, K_BND, [&] {
-            hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, h->bv);
-            if (h->bv.nFeat) hipLaunchKernelGGL(k_bnd_feature, dim3(h->bv.nFeat), dim3(64), 0, h->stream, m, s, h->bv);
-        })) return 1;
+    // BPS.C:866) -- started next to the geometry kernel by runBndPre when there is a side stream; after the smoothing
+    // kernel k_bnd_fix finishes the boundary points it skipped
+    if (h->bndOn) {
+        if (h->bndPreInFlight) {
+            if (depWait(h, DEP_BND_JOIN, h->stream, h->evBndJoin)) return 1;
+            h->bndPreInFlight = false;
+        } else if (launchBndPre(h, m, s, h->stream)) return 1;
+    }
     if (h->useTiles) {
         const int nT = tileList ? nList : h->stl.nTiles;
         if (nT == 0) return 0;
@@ -653,7 +679,7 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
     } else if (launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     if (h->bndOn) {
         const int base = h->useTiles ? h->stl.nTiles : gridFor(m.nPoints);
-        return launchK(h, K_BND, [&] { hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, prm, h->bv, base); });
+        return launchK(h, K_BND, [&] { hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(2 * (int64_t)h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, prm, h->bv, base); });
     }
     return 0;
 }
@@ -1030,6 +1056,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     const bool deferFinish = relTol <= 0.0 && h->useTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1);
     if (flushDeferred(h)) return 1;
     for (int i = 0; i < nIters; ++i) {
+        if (runBndPre(h)) return 1;
         if (runGeometry(h)) return 1;
         State s = h->st;
         if (fused) {
@@ -1038,7 +1065,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (runProposalAndConstraints(h)) return 1;
             if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
-        const int nPart = ((fused && h->useTiles) ? h->stl.nTiles : gP) + ((fused && h->bndOn) ? gridFor(h->bv.nB) : 0);
+        const int nPart = ((fused && h->useTiles) ? h->stl.nTiles : gP) + ((fused && h->bndOn) ? gridFor(2 * (int64_t)h->bv.nB) : 0);
         if (deferFinish && i + 1 < nIters) { h->deferN = nPart; h->deferIter = i; }
         else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr, (double*)nullptr); })) return 1;
         std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
@@ -1608,25 +1635,40 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
     }
     Bvh bvh;
     bvh.build(in.surfPts, in.surfTris);
+    if (7 * bvh.wideDepth + 1 > kBvhStack) return fail("boundary set-up: the target surface's hierarchy is deeper than the traversal stack");
     BndView& v = h->bv;
     v = BndView{};
     v.nB = nB;
     const int *dPts = nullptr, *dInner = nullptr, *dBfOff = nullptr, *dBfVal = nullptr, *dFeatPts = nullptr, *dFeatStr = nullptr, *dFeatOf = nullptr;
-    const int *dTeE = nullptr, *dTeS = nullptr, *dLink = nullptr, *dTriId = nullptr;
+    const int *dTeE = nullptr, *dTeS = nullptr, *dRef = nullptr, *dTriId = nullptr;
+    const float* dBox = nullptr;
     const uint8_t *dFlags = nullptr, *dClass = nullptr;
-    const double *dCorner = nullptr, *dTeP = nullptr, *dBox = nullptr, *dTri = nullptr;
+    const double *dCorner = nullptr, *dTeP = nullptr, *dTri = nullptr;
     if (devUpload(h, &dPts, bpts) || devUpload(h, &dInner, inner) || devUpload(h, &dBfOff, bfOff) || devUpload(h, &dBfVal, bfVal) ||
         devUpload(h, &dFeatPts, featPts) || devUpload(h, &dFeatStr, featString) || devUpload(h, &dFeatOf, featOfBnd) ||
         devUpload(h, &dFlags, flags) || devUpload(h, &dClass, ptClass) || devUpload(h, &dCorner, corner) ||
         devUpload(h, &dTeP, bs.target.pts) || devUpload(h, &dTeE, bs.target.edges) || devUpload(h, &dTeS, bs.targetEdgeStrings) ||
-        devUpload(h, &dBox, bvh.box) || devUpload(h, &dLink, bvh.link) || devUpload(h, &dTri, bvh.triVerts) || devUpload(h, &dTriId, bvh.triId))
+        devUpload(h, &dBox, bvh.wideBox) || devUpload(h, &dRef, bvh.wideRef) || devUpload(h, &dTri, bvh.triVerts) || devUpload(h, &dTriId, bvh.triId))
         return 1;
     v.pts = dPts; v.flags = const_cast<uint8_t*>(dFlags); v.corner = dCorner; v.inner = dInner; v.bfOff = dBfOff; v.bfVal = dBfVal;
     v.ptClass = dClass;
     v.nFeat = (int)featPts.size(); v.featPts = dFeatPts; v.featString = dFeatStr; v.featOfBnd = dFeatOf;
     if (devAlloc(h, &v.featSum, 3 * (size_t)std::max(v.nFeat, 1)) || devAlloc(h, &v.featCnt, (size_t)std::max(v.nFeat, 1))) return 1;
     v.nTE = bs.target.nEdges(); v.tePts = dTeP; v.teEdges = dTeE; v.teString = dTeS;
-    v.nNodes = (int)(bvh.link.size() / 2); v.nodeBox = dBox; v.nodeLink = dLink; v.triVerts = dTri; v.triId = dTriId;
+    {   // string -> edges
+        int nStr = 0;
+        for (int32_t sid : bs.targetEdgeStrings) nStr = std::max(nStr, (int)sid + 1);
+        std::vector<int> strOff((size_t)nStr + 1, 0), strEdges(bs.targetEdgeStrings.size());
+        for (int32_t sid : bs.targetEdgeStrings) if (sid >= 0) ++strOff[(size_t)sid + 1];
+        for (int i = 0; i < nStr; ++i) strOff[(size_t)i + 1] += strOff[(size_t)i];
+        std::vector<int> fill(strOff.begin(), strOff.end() - 1);
+        for (size_t e = 0; e < bs.targetEdgeStrings.size(); ++e)
+            if (bs.targetEdgeStrings[e] >= 0) strEdges[(size_t)fill[(size_t)bs.targetEdgeStrings[e]]++] = (int)e;
+        const int *dSo = nullptr, *dSe = nullptr;
+        if (devUpload(h, &dSo, strOff) || devUpload(h, &dSe, strEdges)) return 1;
+        v.strOff = dSo; v.strEdges = dSe;
+    }
+    v.nNodes = (int)(bvh.wideRef.size() / 16); v.wideBox = dBox; v.wideRef = dRef; v.triVerts = dTri; v.triId = dTriId;
     v.distanceTolerance = d->distanceTolerance;
     v.internalBlend = d->internalSmoothingBlendingFraction;
     // isSmoothingSurfacePoint is this classification's from now on (BPS.C:404-412)
@@ -1642,6 +1684,13 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
         hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(nB)), dim3(kBlock), 0, h->stream, m, h->st, v);
         HIP_OK(hipStreamSynchronize(h->stream));
+    }
+    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", 1)) {
+        if (depInit(h)) return 1;
+        if (hipStreamCreateWithFlags(&h->bndSide, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evBndFork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->evBndJoin, hipEventDisableTiming) != hipSuccess)
+            return fail("side stream creation failed");
     }
     h->bndOn = true;
     return 0;
@@ -1683,6 +1732,7 @@ int smgpu_debug_propose(smgpu_handle* h) {
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
     h->writeFaces = true;
+    if (runBndPre(h)) return 1;
     const int rcg = runGeometry(h);
     h->writeFaces = false;
     if (rcg) return 1;

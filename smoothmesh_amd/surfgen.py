@@ -134,3 +134,27 @@ def box_feature_edges(m, lo=(0, 0, 0), hi=(1, 1, 1), warp=None):
     if warp is not None:
         xyz = warp(xyz)
     return np.ascontiguousarray(xyz, np.float64), np.array(edges, np.int32)
+
+
+def sphere_surface(centre=(0.5, 0.5, 0.5), radius=0.25, levels=3):
+    """Triangulated sphere: an octahedron subdivided `levels` times (4^levels * 8 triangles), vertices on the sphere."""
+    pts = [(1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1)]
+    tris = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    pts = [np.array(p, np.float64) for p in pts]
+    for _ in range(levels):
+        mid, out = {}, []
+
+        def midpoint(a, b):
+            key = (min(a, b), max(a, b))
+            if key not in mid:
+                m = pts[a] + pts[b]
+                pts.append(m / np.linalg.norm(m))
+                mid[key] = len(pts) - 1
+            return mid[key]
+
+        for a, b, c in tris:
+            ab, bc, ca = midpoint(a, b), midpoint(b, c), midpoint(c, a)
+            out += [(a, ab, ca), (ab, b, bc), (ca, bc, c), (ab, bc, ca)]
+        tris = out
+    xyz = np.asarray(centre, np.float64) + radius * np.array(pts)
+    return np.ascontiguousarray(xyz), np.array(tris, np.int32)

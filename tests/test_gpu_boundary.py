@@ -74,6 +74,24 @@ def test_only_some_patches_smoothed(oracle_lib):
     _run_both(o, e, 8)
 
 
+@pytest.mark.parametrize("constraints", [False, True])
+def test_polyhedral_cavity_snapped_to_a_sphere(oracle_lib, constraints):
+    """castellated cavity wall projected to the sphere: most first searches miss (the wall is farther from the target
+    than minEdgeLength) and the search radius grows (BPS.C:919-930); rays hit a curved, finely triangulated surface"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    from smoothmesh_amd.surfgen import box_feature_edges, sphere_surface
+    m = cavity_mesh(12)
+    o, e, prm, on = make_pair(m, oracle_lib, box_feature_edges(12), None, sphere_surface(levels=4), constraints=constraints,
+                              smoothingPatches=("cavity",))
+    assert on
+    _check_setup(o, e)
+    _run_both(o, e, 15)
+    wall = o.boundary_fields()["isSmoothingSurfacePoint"].astype(bool)
+    r = np.linalg.norm(e.get_points()[wall] - 0.5, axis=1)
+    if not constraints:               # with the angle constraints some wall points are frozen on their way
+        assert r.min() > 0.23 and r.max() <= 0.25 + 1e-12
+
+
 def test_direct_gather_kernels(oracle_lib, monkeypatch):
     """SMGPU_TILES=0: the non-tiled smoothing kernel leaves the boundary points to k_bnd_fix the same way"""
     from smoothmesh_amd.meshgen import hex_block

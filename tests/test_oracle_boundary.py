@@ -137,3 +137,24 @@ def test_classification_lists_of_a_previous_run_are_used(oracle_lib):
     f1 = make_pair(m, oracle_lib, init, None, surf, engine=False, cornerIO=cio, featureIO=fio)[0].boundary_fields()
     assert f1["isFeatureEdgePoint"][victim] == 0 and f1["isFeatureEdgePoint"].sum() == f0["isFeatureEdgePoint"].sum() - 1
     assert np.array_equal(f1["isCornerPoint"], f0["isCornerPoint"])
+
+
+def test_castellated_cavity_snaps_to_the_sphere(oracle_lib):
+    """polyhedral mesh with a staircase cavity wall, target surface = the sphere the cavity was carved from, only the
+    cavity patch smoothed: the wall points end on the (inscribed) triangulated sphere; the outer box stays where it is"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    from smoothmesh_amd.surfgen import box_feature_edges, sphere_surface
+    m = cavity_mesh(10)
+    p0 = np.array(m.points).copy()
+    o = make_pair(m, oracle_lib, box_feature_edges(10), None, sphere_surface(levels=3), engine=False, smoothingPatches=("cavity",))[0]
+    f = o.boundary_fields()
+    wall = f["isSmoothingSurfacePoint"].astype(bool)
+    assert wall.sum() > 400 and f["isCornerPoint"].sum() == 8
+    r0 = np.linalg.norm(p0[wall] - 0.5, axis=1)
+    assert r0.min() < 0.22 and r0.max() > 0.29                        # the staircase
+    o.iterate(30, 0.0)
+    p = o.points()
+    r = np.linalg.norm(p[wall] - 0.5, axis=1)
+    assert r.min() > 0.245 and r.max() <= 0.25 + 1e-12                # between the inscribed facets and the sphere
+    box = (~wall) & ((p0 == 0.0) | (p0 == 1.0)).any(axis=1)
+    assert np.array_equal(p[box], p0[box])                            # frozen surface points are restored (SM.C:2384-2392)
