@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace smgpu {
@@ -384,13 +385,15 @@ void Bvh::build(const std::vector<double>& pts, const std::vector<int32_t>& tris
             }
         }
     }
-    triVerts.resize(9 * (size_t)n);
+    triVerts.assign(10 * (size_t)n, 0.0);
     triId.resize((size_t)n);
     for (int k = 0; k < n; ++k) {
         const int i = order[(size_t)k];
         triId[(size_t)k] = i;
         for (int v = 0; v < 3; ++v)
-            for (int d = 0; d < 3; ++d) triVerts[9 * (size_t)k + 3 * (size_t)v + d] = pts[3 * (size_t)tris[3 * (size_t)i + v] + d];
+            for (int d = 0; d < 3; ++d) triVerts[10 * (size_t)k + 3 * (size_t)v + d] = pts[3 * (size_t)tris[3 * (size_t)i + v] + d];
+        const int64_t idBits = i;
+        std::memcpy(&triVerts[10 * (size_t)k + 9], &idBits, sizeof(double));
     }
 }
 

@@ -55,7 +55,7 @@ struct Bvh {
     std::vector<float> wideBox;    // 48 per wide node, floats rounded outwards: lo.x[8] lo.y[8] lo.z[8] hi.x[8] hi.y[8] hi.z[8]
     std::vector<int32_t> wideRef;  // 16 per wide node: ref[8] = child wide node, or first triangle (leaf order) of a leaf
                                    // child; cnt[8] = -1 unused slot, 0 child is a wide node, > 0 triangles of a leaf child
-    std::vector<double> triVerts;  // 9 per triangle, leaf order
+    std::vector<double> triVerts;  // 10 per triangle, leaf order: nine coordinates + the original id (bit pattern)
     std::vector<int32_t> triId;    // original triangle id, leaf order
     int32_t wideDepth = 0;
     void build(const std::vector<double>& pts, const std::vector<int32_t>& tris);

@@ -44,7 +44,7 @@ struct BndView {
     int nNodes;                 // 8-wide bounding volume hierarchy over the target triangles (boundary.hpp)
     const float* wideBox;       // 48 floats per node (see findLine)
     const int* wideRef;         // 16 ints per node: ref[8], cnt[8]
-    const double* triVerts; const int* triId;
+    const double* triVerts;     // 10 doubles per triangle in leaf order: nine coordinates + the original id (as bits)
     double distanceTolerance, internalBlend;
 };
 
@@ -178,13 +178,20 @@ constexpr int kBvhStack = 48;
 __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ stack, const V3& start, const V3& end, V3& hitPoint) {
     const V3 dir = end - start;
     const double tol = 10.0 * 1.0e-15;   // indexedOctree::perturbTol() = 10*SMALL
-    // slab test per axis with the reciprocal direction; an axis the segment does not move along only checks the origin.
-    // Slack on the parameter range and on every slab keeps the test conservative (it may only accept too much).
+    // Slab test per axis, t = box * (1/d) - o * (1/d) as one fused multiply-add (this is culling, not reference
+    // arithmetic), near / far plane picked by the sign of the direction.  The parameter range carries the slack
+    // (rounding here is ~1e-16 |o/d|, the boxes are inflated besides); an axis the segment does not move along only
+    // checks the origin.  The test may accept too much, never too little.
     const double o3[3] = {start.x, start.y, start.z}, d3[3] = {dir.x, dir.y, dir.z};
-    double inv[3];
-    bool flat[3];
+    double inv[3], oinv[3];
+    bool flat[3], neg[3];
 #pragma unroll
-    for (int a = 0; a < 3; ++a) { flat[a] = d3[a] == 0.0; inv[a] = flat[a] ? 0.0 : 1.0 / d3[a]; }
+    for (int a = 0; a < 3; ++a) {
+        flat[a] = d3[a] == 0.0;
+        neg[a] = d3[a] < 0.0;
+        inv[a] = flat[a] ? 0.0 : 1.0 / d3[a];
+        oinv[a] = -(o3[a] * inv[a]);
+    }
     double best = 0.0;
     int bestId = 0x7fffffff;
     // One kind of work per loop trip: a popped node tests its eight child boxes and pushes what the segment touches
@@ -214,10 +221,7 @@ __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ sta
                     const double lo = (double)bx[8 * a + c], hi = (double)bx[24 + 8 * a + c];
                     if (flat[a]) { touch = touch && !(o3[a] < lo || o3[a] > hi); }
                     else {
-                        double ta = (lo - o3[a]) * inv[a], tb = (hi - o3[a]) * inv[a];
-                        if (ta > tb) { const double sw = ta; ta = tb; tb = sw; }
-                        const double slack = 1e-9 * (fabs(ta) + fabs(tb)) + 1e-12;
-                        ta -= slack; tb += slack;
+                        const double ta = fma(neg[a] ? hi : lo, inv[a], oinv[a]), tb = fma(neg[a] ? lo : hi, inv[a], oinv[a]);
                         t0 = (ta > t0) ? ta : t0;
                         t1 = (tb < t1) ? tb : t1;
                     }
@@ -226,15 +230,19 @@ __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ sta
             }
         } else {
             const int code = -(item + 1), first = code >> 4, n = code & 15;
+            // a triangle record is 80 bytes = five 16-byte loads: nine coordinates and the triangle id (the memory
+            // pipeline's cost here is the number of load instructions per lane, not the bytes)
             double tv[4][9];
             int ids[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int kk = first + ((k < n) ? k : n - 1);
-                const double* __restrict__ src = b.triVerts + 9 * (size_t)kk;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) tv[k][q] = src[q];
-                ids[k] = b.triId[kk];
+                if (k < n) {
+                    const double2* __restrict__ src = reinterpret_cast<const double2*>(b.triVerts) + 5 * (size_t)(first + k);
+                    const double2 q0 = src[0], q1 = src[1], q2 = src[2], q3 = src[3], q4 = src[4];
+                    tv[k][0] = q0.x; tv[k][1] = q0.y; tv[k][2] = q1.x; tv[k][3] = q1.y; tv[k][4] = q2.x; tv[k][5] = q2.y;
+                    tv[k][6] = q3.x; tv[k][7] = q3.y; tv[k][8] = q4.x;
+                    ids[k] = (int)__double_as_longlong(q4.y);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {

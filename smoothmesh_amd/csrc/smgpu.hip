@@ -1640,7 +1640,7 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
     v = BndView{};
     v.nB = nB;
     const int *dPts = nullptr, *dInner = nullptr, *dBfOff = nullptr, *dBfVal = nullptr, *dFeatPts = nullptr, *dFeatStr = nullptr, *dFeatOf = nullptr;
-    const int *dTeE = nullptr, *dTeS = nullptr, *dRef = nullptr, *dTriId = nullptr;
+    const int *dTeE = nullptr, *dTeS = nullptr, *dRef = nullptr;
     const float* dBox = nullptr;
     const uint8_t *dFlags = nullptr, *dClass = nullptr;
     const double *dCorner = nullptr, *dTeP = nullptr, *dTri = nullptr;
@@ -1648,7 +1648,7 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         devUpload(h, &dFeatPts, featPts) || devUpload(h, &dFeatStr, featString) || devUpload(h, &dFeatOf, featOfBnd) ||
         devUpload(h, &dFlags, flags) || devUpload(h, &dClass, ptClass) || devUpload(h, &dCorner, corner) ||
         devUpload(h, &dTeP, bs.target.pts) || devUpload(h, &dTeE, bs.target.edges) || devUpload(h, &dTeS, bs.targetEdgeStrings) ||
-        devUpload(h, &dBox, bvh.wideBox) || devUpload(h, &dRef, bvh.wideRef) || devUpload(h, &dTri, bvh.triVerts) || devUpload(h, &dTriId, bvh.triId))
+        devUpload(h, &dBox, bvh.wideBox) || devUpload(h, &dRef, bvh.wideRef) || devUpload(h, &dTri, bvh.triVerts))
         return 1;
     v.pts = dPts; v.flags = const_cast<uint8_t*>(dFlags); v.corner = dCorner; v.inner = dInner; v.bfOff = dBfOff; v.bfVal = dBfVal;
     v.ptClass = dClass;
@@ -1668,7 +1668,7 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         if (devUpload(h, &dSo, strOff) || devUpload(h, &dSe, strEdges)) return 1;
         v.strOff = dSo; v.strEdges = dSe;
     }
-    v.nNodes = (int)(bvh.wideRef.size() / 16); v.wideBox = dBox; v.wideRef = dRef; v.triVerts = dTri; v.triId = dTriId;
+    v.nNodes = (int)(bvh.wideRef.size() / 16); v.wideBox = dBox; v.wideRef = dRef; v.triVerts = dTri;
     v.distanceTolerance = d->distanceTolerance;
     v.internalBlend = d->internalSmoothingBlendingFraction;
     // isSmoothingSurfacePoint is this classification's from now on (BPS.C:404-412)

@@ -6,6 +6,7 @@
 
 #include "../../smoothmesh_amd/csrc/host/polymesh_io.hpp"
 #include "../../smoothmesh_amd/csrc/layers.hpp"
+#include "../../smoothmesh_amd/csrc/boundary.hpp"
 #include "../../smoothmesh_amd/csrc/tiles.hpp"
 #include "../../smoothmesh_amd/csrc/topology.hpp"
 
@@ -44,6 +45,55 @@ int main(int argc, char** argv) {
     if (!err.empty()) { std::fprintf(stderr, "layers: %s\n", err.c_str()); return 1; }
     long mapped = 0;
     for (int v : ls.outerMap) mapped += v >= 0;
+    // boundary point smoothing set-up: the unit cube's twelve edges (4 segments each, built by hand), a two-triangle
+    // "surface" per cube side, every patch smoothed; then the hierarchy over a larger strip of triangles
+    {
+        smgpu::BoundaryInputHost in;
+        auto addPoint = [&](double x, double y, double z) { in.initEdges.pts.insert(in.initEdges.pts.end(), {x, y, z}); return in.initEdges.nPoints() - 1; };
+        for (int axis = 0; axis < 3; ++axis)
+            for (int u = 0; u < 2; ++u)
+                for (int v = 0; v < 2; ++v) {
+                    int prev = -1;
+                    for (int a = 0; a <= 4; ++a) {
+                        double c[3];
+                        c[axis] = a / 4.0; c[(axis + 1) % 3] = u; c[(axis + 2) % 3] = v;
+                        const int id = addPoint(c[0], c[1], c[2]);   // corners duplicated: three open strings meet nowhere -- fine here
+                        if (prev >= 0) { in.initEdges.edges.push_back(prev); in.initEdges.edges.push_back(id); }
+                        prev = id;
+                    }
+                }
+        const double q[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+        for (auto& c : q) in.surfPts.insert(in.surfPts.end(), {c[0], c[1], c[2]});
+        const int quads[6][4] = {{0, 3, 2, 1}, {4, 5, 6, 7}, {0, 1, 5, 4}, {2, 3, 7, 6}, {1, 2, 6, 5}, {0, 4, 7, 3}};
+        for (auto& f : quads) in.surfTris.insert(in.surfTris.end(), {f[0], f[1], f[2], f[0], f[2], f[3]});
+        in.distanceTolerance = 1e-6;
+        in.meshMinEdgeLength = 0.01;
+        in.meshPerimeter = 3.0;
+        std::vector<smgpu::BndPatch> bp;
+        for (const smhost::PatchInfo& p : m.patches) bp.push_back({p.startFace, p.nFaces, 0, true});
+        smgpu::BoundarySetup bs;
+        err = smgpu::buildBoundarySetup(t, internal.data(), m.points.data(), bp, in, bs);
+        if (!err.empty()) { std::fprintf(stderr, "boundary: %s\n", err.c_str()); return 1; }
+        if (!bs.enabled || bs.nSmoothingSurface == 0) { std::fprintf(stderr, "boundary: not enabled\n"); return 1; }
+        std::vector<double> sp;
+        std::vector<int32_t> st;
+        for (int i = 0; i < 300; ++i) {   // a strip, with repeated (coincident-centroid) triangles at the end
+            const double x = (i < 280) ? i * 0.01 : 1.0;
+            sp.insert(sp.end(), {x, 0, 0, x + 0.01, 0, 0, x, 1, 0.001 * (i % 7)});
+            st.insert(st.end(), {3 * i, 3 * i + 1, 3 * i + 2});
+        }
+        smgpu::Bvh bvh;
+        bvh.build(sp, st);
+        if (bvh.triId.size() != 300 || bvh.wideRef.empty() || bvh.wideDepth < 1) { std::fprintf(stderr, "bvh: bad build\n"); return 1; }
+        long leafTris = 0;
+        for (size_t w = 0; w < bvh.wideRef.size() / 16; ++w)
+            for (int c = 0; c < 8; ++c) {
+                const int n = bvh.wideRef[16 * w + 8 + (size_t)c];
+                if (n > 4) { std::fprintf(stderr, "bvh: leaf of %d triangles\n", n); return 1; }
+                if (n > 0) leafTris += n;
+            }
+        if (leafTris != 300) { std::fprintf(stderr, "bvh: %ld triangles in leaves\n", leafTris); return 1; }
+    }
     std::printf("ok points %d cells %d edges %d mapped %ld\n", m.nPoints(), m.nCells, t.nEdges, mapped);
     return 0;
 }

@@ -1,4 +1,4 @@
-"""The product's host-only C++ (addressing build, tile tables, layer set-up, polyMesh I/O, mesh generator) under
+"""The product's host-only C++ (addressing build, tile tables, layer and boundary smoothing set-up incl. the triangle hierarchy, polyMesh I/O, mesh generator) under
 AddressSanitizer + UndefinedBehaviorSanitizer on the CPU (GPU sanitizers are not available on the pool)."""
 import os
 import shutil
@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "smoothmesh_amd", "csrc")
 def test_host_code_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_sanitize")
     src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
-          [os.path.join(CSRC, f) for f in ("topology.cpp", "tiles.cpp", "layers.cpp", "host/meshgen.cpp", "host/polymesh_io.cpp")]
+          [os.path.join(CSRC, f) for f in ("topology.cpp", "tiles.cpp", "layers.cpp", "boundary.cpp", "host/meshgen.cpp", "host/polymesh_io.cpp")]
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", exe] + src + ["-lz"])
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
