@@ -1,12 +1,13 @@
 """Randomised GPU-vs-oracle parity sweep (run on the GPU box): random block sizes, jitter up to near-inversion, random
-smoothing parameters, constraints, layer patches, serial and decomposed.  Prints one line per case; exit code 1 on the
+smoothing parameters, constraints, layer patches, boundary point smoothing (box and sphere targets), serial and decomposed.  Prints one line per case; exit code 1 on the
 first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 from oracle import oracle_ffi
-from smoothmesh_amd import LayerParams, SmoothEngine, default_params, patch_arrays
+from smoothmesh_amd import BoundaryParams, LayerParams, SmoothEngine, SmgpuError, default_params, patch_arrays
+from smoothmesh_amd.surfgen import box_feature_edges, box_surface, sphere_surface
 from smoothmesh_amd.decompose import shared_point_table
 from smoothmesh_amd.halo import LocalMultiSmoother
 from smoothmesh_amd.meshgen import hex_block, hex_subdomain
@@ -72,12 +73,44 @@ for case in range(n_cases):
         o = oracle_ffi.Oracle(mesh); e = SmoothEngine(mesh)
         prm = params(o.mesh_stats()[0])
         o.set_params(prm); e.set_params(prm)
-        if layers:
-            st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches)
-            on_o = o.setup_layers(st, sz, kd, sel, lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        boundary = rng.random() < 0.5
+        st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches if layers else ())
+        lopt = (lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        if boundary:
+            f = float(rng.choice([1.0, 1.0, 1.02]))
+            warp = (lambda x: 0.5 + (x - 0.5) * f) if f != 1.0 else None
+            m_e, m_s = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+            if kind == "hex":
+                pats = tuple(rng.choice(PATCHES, size=int(rng.integers(1, 7)), replace=False)) if rng.random() < 0.5 else ('".*"',)
+                bp = BoundaryParams(initEdges=box_feature_edges(m_e), targetEdges=box_feature_edges(m_e, warp=warp) if warp else None,
+                                    targetSurfaces=box_surface(m_s, warp=warp), smoothingPatches=pats,
+                                    internalSmoothingBlendingFraction=float(rng.choice([0.0, 0.3, 1.0])))
+            else:
+                bp = BoundaryParams(initEdges=box_feature_edges(m_e), targetSurfaces=sphere_surface(levels=int(rng.integers(1, 5))),
+                                    smoothingPatches=("cavity",), internalSmoothingBlendingFraction=float(rng.choice([0.0, 0.5])))
+            desc += f" boundary->{'sphere' if kind != 'hex' else 'box*%g' % f} {bp.smoothingPatches}"
+            if layers:
+                e.set_layers(lp, prm.minEdgeLength)
+            on_o = o.setup_boundary(st, sz, kd, sel, patch_arrays(mesh, bp.smoothingPatches)[3], lopt, bp.initEdges, bp.targetEdges,
+                                    bp.targetSurfaces, None, None, bp.internalSmoothingBlendingFraction)
+            assert on_o == bool(e.set_boundary_smoothing(bp, prm.minEdgeLength)["enabled"])
+        elif layers:
+            on_o = o.setup_layers(st, sz, kd, sel, *lopt)
             assert on_o == e.set_layers(lp, prm.minEdgeLength)
-        n_o, res_o, frz_o = o.iterate(iters, 0.0)
-        n_g, res_g, frz_g = e.iterate(iters, 0.0)
+        err_o = err_g = None
+        try:
+            n_o, res_o, frz_o = o.iterate(iters, 0.0)
+        except RuntimeError as ex:
+            err_o = str(ex)
+        try:
+            n_g, res_g, frz_g = e.iterate(iters, 0.0)
+        except SmgpuError as ex:
+            err_g = str(ex)
+        if err_o or err_g:      # the reference's FatalErrors (e.g. no surface intersection): both sides must report one
+            ok = bool(err_o) and bool(err_g)
+            print(f"case {case:3d} {'ok ' if ok else 'BAD'} {desc} jitter {jitter} iters {iters}: oracle error [{err_o}] engine error [{err_g}]", flush=True)
+            bad += 0 if ok else 1
+            continue
         a, b = e.get_points(), o.points()
     fin = ~np.isnan(b)
     ok = (n_o == n_g and np.array_equal(frz_o, frz_g) and np.array_equal(np.isnan(a), np.isnan(b)) and
