@@ -106,7 +106,9 @@ def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False, b
         "value": mesh.nPoints * iters / dt, "unit": "points/s", "cores": 1, "kind": "port",
         "sample": f"{iters} iterations of the {kind}{sample_n} mesh ({mesh.nPoints} points, {mesh.nCells} cells), serial oracle "
                   f"(g++ -O2 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
-                  f"so it is faster than the real reference",
+                  f"so it is faster than the real reference"
+                  + ("; with boundary point smoothing the oracle tests every target triangle per ray where OpenFOAM walks an "
+                     "octree, so THIS number is slower than the real reference and no fair baseline" if boundary else ""),
         "host_cpus": os.cpu_count(),
     }
 

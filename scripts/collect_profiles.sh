@@ -12,8 +12,10 @@ python bench.py --workload hex300 --no-cpu-baseline --steps 20 --warmup 2 > $out
 python bench.py --workload cavity215 --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity215.json 2>>$out/bench_hex100.err
 python bench.py --workload cavity215c --no-cpu-baseline --steps 20 --warmup 2 > $out/bench_cavity215c.json 2>>$out/bench_hex100.err
 python bench.py --workload cavity100c --steps 20 --warmup 2 > $out/bench_cavity100c.json 2>>$out/bench_hex100.err
+python bench.py --workload hex100B --steps 50 --warmup 5 > $out/bench_hex100B.json 2>>$out/bench_hex100.err
+python bench.py --workload cavity100B --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity100B.json 2>>$out/bench_hex100.err
 cd /tmp && export TMPDIR=/tmp
-for wl in hex100 hex100c; do
+for wl in hex100 hex100c hex100B; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_$wl -- python3 $root/bench.py --no-cpu-baseline --workload $wl > /dev/null 2>&1
   cp $out/rocprof_$wl/*/*kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv
   rm -rf $out/rocprof_$wl
