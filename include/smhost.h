@@ -45,6 +45,11 @@ int smhost_write_points(const char* polyMeshDir, const char* location, int32_t n
                         int32_t binary, int32_t precision);
 /* labelList file (pointProcAddressing etc.): n = -1 on input to query the size into *n. */
 int smhost_read_label_list(const char* file, int32_t* out, int64_t* n);
+/* Wavefront OBJ inputs of the boundary point smoothing (constant/geometry/ .obj files, SM.C:1924-1926), read the way
+ * OpenFOAM's readers do: kind 0 = surface (triSurface: polygons as triangle fans about their first vertex; 3 ids per
+ * element), kind 1 = edge mesh (edgeMesh: consecutive pairs of every "l" record, unused points dropped; 2 ids per
+ * element).  Two calls: with points == NULL only the counts are returned. */
+int smhost_read_obj(const char* file, int32_t kind, double* points, int64_t* nPoints, int32_t* elements, int64_t* nElements);
 int smhost_write_label_list(const char* file, const char* location, const char* object, const char* cls,
                             int64_t n, const int32_t* values, int32_t binary);
 

@@ -93,6 +93,22 @@ int smhost_read_label_list(const char* file, int32_t* out, int64_t* n) {
         *n = (int64_t)v.size();
     });
 }
+int smhost_read_obj(const char* file, int32_t kind, double* points, int64_t* nPoints, int32_t* elements, int64_t* nElements) {
+    return guarded([&] {
+        std::vector<double> p;
+        std::vector<int32_t> e;
+        if (kind == 0) readObjSurface(file, p, e);
+        else if (kind == 1) readObjEdges(file, p, e);
+        else throw std::runtime_error("smhost_read_obj: kind must be 0 (surface) or 1 (edge mesh)");
+        const int64_t w = kind == 0 ? 3 : 2;
+        if (points && elements && *nPoints >= (int64_t)p.size() / 3 && *nElements >= (int64_t)e.size() / w) {
+            std::memcpy(points, p.data(), p.size() * sizeof(double));
+            std::memcpy(elements, e.data(), e.size() * sizeof(int32_t));
+        }
+        *nPoints = (int64_t)p.size() / 3;
+        *nElements = (int64_t)e.size() / w;
+    });
+}
 int smhost_write_label_list(const char* file, const char* location, const char* object, const char* cls, int64_t n,
                             const int32_t* values, int32_t binary) {
     return guarded([&] { writeLabelList(file, location, object, cls, n, values, binary != 0); });

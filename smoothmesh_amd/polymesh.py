@@ -32,6 +32,7 @@ def lib():
         l.smhost_write_points.argtypes = [C.c_char_p, C.c_char_p, C.c_int32, f64p, C.c_int32, C.c_int32]
         l.smhost_set_write_compression.argtypes = [C.c_int32]
         l.smhost_read_label_list.argtypes = [C.c_char_p, i32p, C.POINTER(C.c_int64)]
+        l.smhost_read_obj.argtypes = [C.c_char_p, C.c_int32, f64p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]
         l.smhost_write_label_list.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, i32p, C.c_int32]
         l.smhost_gen_cavity_mesh.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_void_p)]
         _lib = l
@@ -116,6 +117,16 @@ def read_label_list(path):
     out = np.empty(n.value, np.int32)
     _check(lib().smhost_read_label_list(path.encode(), _p(out, i32p), C.byref(n)))
     return out
+
+
+def read_obj(path, kind):
+    """the front-end's OBJ reader (csrc/host/polymesh_io.cpp): kind "surface" -> (points, triangles), "edges" -> (points, edges)"""
+    k = {"surface": 0, "edges": 1}[kind]
+    nP, nE = C.c_int64(0), C.c_int64(0)
+    _check(lib().smhost_read_obj(path.encode(), k, None, C.byref(nP), None, C.byref(nE)))
+    pts, el = np.empty((nP.value, 3), np.float64), np.empty((nE.value, 3 if k == 0 else 2), np.int32)
+    _check(lib().smhost_read_obj(path.encode(), k, _p(pts, f64p), C.byref(nP), _p(el, i32p), C.byref(nE)))
+    return pts, el
 
 
 def write_label_list(path, values, location, obj, cls="labelList", binary=False):

@@ -157,3 +157,26 @@ def test_not_available_with_a_halo(oracle_lib):
         e3.iterate(1, 0.0)
     with pytest.raises(RuntimeError):
         o3.iterate(1, 0.0)
+
+
+def test_tiny_scale_cube_like_reference_testcase8(oracle_lib):
+    """the reference's testcase8: a 3x3x3 block of 2e-8 m with its surface and twelve edges as targets, default options
+    (`smoothMesh -centroidalIters 50`): every tolerance of the path is relative to the mesh size, nothing may depend on
+    coordinates being O(1)"""
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface
+    L = 2e-8
+    m = hex_block(3, lengths=(L, L, L), jitter=0.25, seed=8)
+    m.points[:] = np.array(m.points) - 0.5 * L
+    lo, hi = (-0.5 * L,) * 3, (0.5 * L,) * 3
+    init, surf = box_feature_edges(1, lo, hi), box_surface(1, lo, hi)           # one quad per side, as the reference's file
+    o, e, prm, on = make_pair(m, oracle_lib, init, None, surf, constraints=True)
+    assert on
+    _check_setup(o, e)
+    f = o.boundary_fields()
+    assert f["isCornerPoint"].sum() == 8 and f["isFeatureEdgePoint"].sum() == 24
+    res, frz = _run_both(o, e, 50)
+    p = e.get_points()
+    bnd = ~np.array(m.isInternalPoint, bool) if hasattr(m, "isInternalPoint") else (np.abs(np.abs(np.array(m.points)) - 0.5 * L).min(axis=1) == 0)
+    assert np.all(np.abs(np.abs(p[bnd]) - 0.5 * L).min(axis=1) <= 1e-22)       # boundary points are still on the cube
+    assert np.isfinite(res).all() and res[-1] < res[0]

@@ -110,3 +110,44 @@ def test_errors_name_the_file(tmp_path):
     from smoothmesh_amd.polymesh import read_polymesh
     with pytest.raises(RuntimeError, match="points"):
         read_polymesh(str(tmp_path))
+
+
+def test_obj_readers_agree_and_follow_openfoam_conventions(tmp_path):
+    """constant/geometry/*.obj (SM.C:1924-1926): polygons become triangle fans about their first vertex, `l` records
+    become consecutive pairs, unused points of an edge mesh are dropped, v/vt/vn references and negative indices work;
+    the front-end's C++ reader and the Python reader return the same arrays"""
+    from smoothmesh_amd.polymesh import read_obj
+    from smoothmesh_amd.surfgen import read_obj_edges, read_obj_surface
+    f = tmp_path / "s.obj"
+    f.write_text("# comment\nmtllib x.mtl\no Cube\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 0.5 0.5 1\nvn 0 0 1\nusemtl m\ns 0\n"
+                 "f 1//1 2//1 3//1 4//1\nf 1/1/1 2/2/1 5/3/1\nf -1 -2 -3\n")
+    p, t = read_obj_surface(str(f))
+    assert p.shape == (5, 3) and t.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4], [4, 3, 2]]
+    p2, t2 = read_obj(str(f), "surface")
+    assert np.array_equal(p, p2) and np.array_equal(t, t2)
+    g = tmp_path / "e.obj"
+    g.write_text("v 9 9 9\nv 0 0 0\nv 1 0 0\nv 2 0 0\nv 7 7 7\nv 2 1 0\nl 2 3 4\nl 4 6\n")
+    p, e = read_obj_edges(str(g))
+    assert p.tolist() == [[0, 0, 0], [1, 0, 0], [2, 0, 0], [2, 1, 0]] and e.tolist() == [[0, 1], [1, 2], [2, 3]]
+    p2, e2 = read_obj(str(g), "edges")
+    assert np.array_equal(p, p2) and np.array_equal(e, e2)
+    bad = tmp_path / "bad.obj"
+    bad.write_text("v 0 0 0\nf 1 2 3\n")
+    with pytest.raises(Exception, match="out of range"):
+        read_obj(str(bad), "surface")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/testcase3/constant/geometry"), reason="reference tree not present")
+def test_obj_readers_on_the_reference_test_cases():
+    """the geometry files of the reference's own test cases (Blender / VTK exports with mtllib, o, vn, s records and quads)"""
+    import glob
+    from smoothmesh_amd.polymesh import read_obj
+    from smoothmesh_amd.surfgen import read_obj_edges, read_obj_surface
+    files = sorted(glob.glob("/root/reference/testcase*/constant/geometry/*.obj"))
+    assert len(files) >= 10
+    for f in files:
+        kind = "surface" if f.endswith("targetSurfaces.obj") else "edges"
+        a = (read_obj_surface if kind == "surface" else read_obj_edges)(f)
+        b = read_obj(f, kind)
+        assert len(a[1]) > 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f
+        assert a[1].min() == 0 and a[1].max() == len(a[0]) - 1 if kind == "edges" else a[1].max() < len(a[0])
