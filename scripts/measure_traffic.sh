@@ -8,8 +8,9 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/traffic_$wl
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/fetch.err
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/write.err
+export SMGPU_SIDE_STREAM=0   # counter collection serialises kernels: no cross-stream waits (see scripts/pmc_kernels.sh)
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/write.err
 cd $root
 python3 - "$out" "$wl" <<'PY'
 import csv, glob, json, sys
