@@ -143,12 +143,20 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
     const V3 np0 = ldsv(nx, ny, nz, selfL);
     const float thr = cosSmall - kEaMargin;
     bool ok = true, below = true;
+    // The corner list of a point is ordered as chains (tiles.cpp, chainCorners): a corner usually starts at the vertex
+    // the previous one ended at, whose two unit vectors are still at hand.
+    int heldId = -1;
+    F3 huc = {0.f, 0.f, 0.f}, hun = {0.f, 0.f, 0.f};
 #define SMGPU_EA_CORNER(A1, A2)                                                                                   \
     if ((A1) != kPad) {                                                                                           \
-        const F3 uc1 = funit(f3(ldsv(cx, cy, cz, (A1)) - np0), ok), uc2 = funit(f3(ldsv(cx, cy, cz, (A2)) - np0), ok); \
-        const F3 un1 = funit(f3(ldsv(nx, ny, nz, (A1)) - np0), ok), un2 = funit(f3(ldsv(nx, ny, nz, (A2)) - np0), ok); \
-        const float c0 = fdot(uc1, uc2), c1 = fdot(un1, un2), c2 = fdot(uc1, un2), c3 = fdot(un1, uc2);            \
+        if ((int)(A1) != heldId) {                                                                                \
+            huc = funit(f3(ldsv(cx, cy, cz, (A1)) - np0), ok);                                                    \
+            hun = funit(f3(ldsv(nx, ny, nz, (A1)) - np0), ok);                                                    \
+        }                                                                                                         \
+        const F3 uc2 = funit(f3(ldsv(cx, cy, cz, (A2)) - np0), ok), un2 = funit(f3(ldsv(nx, ny, nz, (A2)) - np0), ok); \
+        const float c0 = fdot(huc, uc2), c1 = fdot(hun, un2), c2 = fdot(huc, un2), c3 = fdot(hun, uc2);            \
         below = below && (c0 < thr) && (c1 < thr) && (c2 < thr) && (c3 < thr);                                    \
+        huc = uc2; hun = un2; heldId = (int)(A2);                                                                 \
     }
     if (wf4 > 0) { SMGPU_EA_CORNER(q0.x, q0.y) SMGPU_EA_CORNER(q0.z, q0.w) }
     if (wf4 > 1) { SMGPU_EA_CORNER(q1.x, q1.y) SMGPU_EA_CORNER(q1.z, q1.w) }

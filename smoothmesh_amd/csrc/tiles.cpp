@@ -159,6 +159,84 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
     return "";
 }
 
+// The face corners of a point, (previous vertex, next vertex) per incident face, are the edges of a small graph on the
+// point's neighbours (an octahedron for an interior hex point).  The edge-angle filter evaluates a pair of unit vectors
+// per neighbour and corner; ordered as Euler trails (each corner starts where the previous one ended, corners flipped as
+// needed -- the filter's four cosines are symmetric in the pair) it can carry one neighbour's vectors over from corner to
+// corner and evaluates about half of them.  Hierholzer on the graph with the odd-degree vertices paired by virtual edges;
+// the virtual edges are dropped from the output, where a new trail starts.  The set of corners is unchanged.
+namespace {
+struct ChainScratch {
+    std::vector<int32_t> verts, deg, adjOff, adjEdge, ea, eb, stackV, stackE, next;
+    std::vector<uint8_t> used;
+    std::vector<std::pair<int32_t, int32_t>> comp, out;
+};
+void chainCorners(std::vector<std::pair<int32_t, int32_t>>& corners, ChainScratch& w) {
+    const int n = (int)corners.size();
+    if (n < 2) return;
+    w.verts.clear();
+    for (const auto& c : corners) { w.verts.push_back(c.first); w.verts.push_back(c.second); }
+    std::sort(w.verts.begin(), w.verts.end());
+    w.verts.erase(std::unique(w.verts.begin(), w.verts.end()), w.verts.end());
+    const int nv = (int)w.verts.size();
+    auto vid = [&](int32_t v) { return (int)(std::lower_bound(w.verts.begin(), w.verts.end(), v) - w.verts.begin()); };
+    w.ea.clear(); w.eb.clear();
+    for (const auto& c : corners) { w.ea.push_back(vid(c.first)); w.eb.push_back(vid(c.second)); }
+    w.deg.assign((size_t)nv, 0);
+    for (int e = 0; e < n; ++e) { ++w.deg[(size_t)w.ea[(size_t)e]]; ++w.deg[(size_t)w.eb[(size_t)e]]; }
+    int pending = -1;
+    for (int v = 0; v < nv; ++v)
+        if (w.deg[(size_t)v] & 1) {
+            if (pending < 0) pending = v;
+            else { w.ea.push_back(pending); w.eb.push_back(v); ++w.deg[(size_t)pending]; ++w.deg[(size_t)v]; pending = -1; }
+        }
+    const int ne = (int)w.ea.size();
+    w.adjOff.assign((size_t)nv + 1, 0);
+    for (int e = 0; e < ne; ++e) { ++w.adjOff[(size_t)w.ea[(size_t)e] + 1]; ++w.adjOff[(size_t)w.eb[(size_t)e] + 1]; }
+    for (int v = 0; v < nv; ++v) w.adjOff[(size_t)v + 1] += w.adjOff[(size_t)v];
+    w.adjEdge.assign((size_t)w.adjOff[(size_t)nv], 0);
+    w.next.assign(w.adjOff.begin(), w.adjOff.end() - 1);
+    for (int e = 0; e < ne; ++e) { w.adjEdge[(size_t)w.next[(size_t)w.ea[(size_t)e]]++] = e; w.adjEdge[(size_t)w.next[(size_t)w.eb[(size_t)e]]++] = e; }
+    w.used.assign((size_t)ne, 0);
+    std::vector<int32_t>& next = w.next;   // per vertex: first adjacency entry not yet looked at
+    next.assign(w.adjOff.begin(), w.adjOff.end() - 1);
+    std::vector<std::pair<int32_t, int32_t>>& out = w.out;
+    out.clear();
+    for (int start = 0; start < nv; ++start) {
+        if (next[(size_t)start] >= w.adjOff[(size_t)start + 1]) continue;
+        // Hierholzer: walk until stuck, back up emitting edges; the emitted sequence reversed is a circuit of the component
+        w.stackV.assign(1, start); w.stackE.assign(1, -1);
+        std::vector<std::pair<int32_t, int32_t>>& comp = w.comp;   // (edge, vertex the edge is entered from) in emission order
+        comp.clear();
+        while (!w.stackV.empty()) {
+            const int v = w.stackV.back();
+            int e = -1;
+            while (next[(size_t)v] < w.adjOff[(size_t)v + 1]) {
+                const int cand = w.adjEdge[(size_t)next[(size_t)v]++];
+                if (!w.used[(size_t)cand]) { e = cand; break; }
+            }
+            if (e >= 0) {
+                w.used[(size_t)e] = 1;
+                const int to = (w.ea[(size_t)e] == v) ? w.eb[(size_t)e] : w.ea[(size_t)e];
+                w.stackV.push_back(to); w.stackE.push_back(e);
+            } else {
+                const int eIn = w.stackE.back();
+                w.stackV.pop_back(); w.stackE.pop_back();
+                if (eIn >= 0) comp.push_back({eIn, w.stackV.back()});   // traversed from stackV.back() to v
+            }
+        }
+        // reversed emission order: consecutive edges share a vertex; edge (e, from) runs from `from` to its other end
+        for (size_t i = comp.size(); i-- > 0;) {
+            const int e = comp[i].first, from = comp[i].second;
+            if (e >= n) continue;   // virtual edge: a new trail starts after it
+            const int to = (w.ea[(size_t)e] == from) ? w.eb[(size_t)e] : w.ea[(size_t)e];
+            out.push_back({w.verts[(size_t)from], w.verts[(size_t)to]});
+        }
+    }
+    if ((int)out.size() == n) corners.swap(out);   // (always; kept as a guard)
+}
+}  // namespace
+
 std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
                                int32_t capCells, int32_t capPoints) {
     threads = nThreads;
@@ -202,6 +280,8 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     pfBase.clear(); pfWidth.clear(); pfEll.clear();
     const bool pairs = t.maxPointPoints <= 16;
     std::vector<int32_t> cells, pts;
+    std::vector<std::pair<int32_t, int32_t>> corners;
+    ChainScratch chainScratch;
     for (int32_t ti = 0; ti < nTiles; ++ti) {
         cells.clear(); pts.clear();
         const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
@@ -241,9 +321,12 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
             const int32_t p = order[(size_t)pi];
             const int32_t tl = pi - pb;
             selfLoc[(size_t)pi] = (uint16_t)locN[p];
-            for (int32_t k = t.pointFaces.off[p], j = 0; k < t.pointFaces.off[p + 1]; ++k, j += 2) {
-                pfEll[fbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[t.pfPrev[k]];
-                pfEll[fbase + ((size_t)((j + 1) / 4) * threads + tl) * 4 + ((j + 1) % 4)] = (uint16_t)locN[t.pfNext[k]];
+            corners.clear();
+            for (int32_t k = t.pointFaces.off[p]; k < t.pointFaces.off[p + 1]; ++k) corners.push_back({t.pfPrev[k], t.pfNext[k]});
+            chainCorners(corners, chainScratch);
+            for (int32_t j = 0; j < 2 * (int32_t)corners.size(); j += 2) {
+                pfEll[fbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[corners[(size_t)j / 2].first];
+                pfEll[fbase + ((size_t)((j + 1) / 4) * threads + tl) * 4 + ((j + 1) % 4)] = (uint16_t)locN[corners[(size_t)j / 2].second];
             }
             for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
                 pcEll[cbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[pc.val[k]];
