@@ -236,6 +236,8 @@ typedef struct smgpu_boundary_info {
 int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info);
 /* the classification to persist as <time>/isCornerPoint and <time>/isFeatureEdgePoint (labelIOLists, SM.C:2039-2064) */
 int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, int32_t* isFeatureEdgePoint);
+/* parity access, host only: the string index of every edge of an edge mesh (findEdgeMeshStrings BPS.C:557-587) */
+int smgpu_debug_edge_strings(int32_t nPoints, int32_t nEdges, const int32_t* edges, int32_t* strings, int32_t* nStrings);
 /* parity access: nearest intersections of n segments (6 doubles each: start, end) with the target surface */
 int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit);
 

@@ -386,6 +386,18 @@ int orc_get_edge_strings(void* h, int* out) {
     if (out) for (size_t i = 0; i < d->targetEdgeStrings.size(); ++i) out[i] = d->targetEdgeStrings[i];
     return (int)d->targetEdgeStrings.size();
 }
+// findEdgeMeshStrings BPS.C:557-587 on a bare edge mesh; returns the number of strings
+int orc_edge_strings(int nPts, int nEdges, const int* edges, int* out) {
+    EdgeMesh em;
+    em.points.assign((size_t)nPts, Vec3{0, 0, 0});
+    em.edges.resize((size_t)nEdges);
+    for (int i = 0; i < nEdges; ++i) em.edges[(size_t)i] = {edges[2 * i], edges[2 * i + 1]};
+    em.buildPointEdges();
+    std::vector<int> strings;
+    const int last = findEdgeMeshStrings(strings, em);
+    for (int i = 0; i < nEdges; ++i) out[i] = strings[(size_t)i];
+    return last + 1;
+}
 // nearest hit of a segment with the target surface (Domain::findLine); returns 1 on a hit
 int orc_find_line(void* h, const double* start, const double* end, double* hitPoint) {
     Domain* d = static_cast<Domain*>(h);

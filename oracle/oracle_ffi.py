@@ -77,6 +77,8 @@ def lib():
         l.orc_get_boundary_fields.argtypes = [C.c_void_p, u8p, u8p, u8p, u8p, f64p, i32p, i32p, i32p, f64p]
         l.orc_get_edge_strings.restype = C.c_int
         l.orc_get_edge_strings.argtypes = [C.c_void_p, i32p]
+        l.orc_edge_strings.restype = C.c_int
+        l.orc_edge_strings.argtypes = [C.c_int, C.c_int, i32p, i32p]
         l.orc_find_line.restype = C.c_int
         l.orc_find_line.argtypes = [C.c_void_p, f64p, f64p, f64p]
         _lib = l
@@ -374,6 +376,14 @@ class MultiOracle:
         if getattr(self, "_h", None):
             self._lib.orc_multi_destroy(self._h)
             self._h = None
+
+
+def edge_strings(nPoints, edges):
+    """findEdgeMeshStrings BPS.C:557-587 -> (string index per edge, number of strings)"""
+    e = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
+    out = np.empty(len(e), np.int32)
+    n = lib().orc_edge_strings(int(nPoints), len(e), _p(e, i32p), _p(out, i32p))
+    return out, n
 
 
 def edgeEdgeAngle(c, p1, p2):

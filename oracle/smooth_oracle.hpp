@@ -198,6 +198,7 @@ public:
     void syncLayers();   // plusEq of normals / face counts (OBB.C:184-198), minMagSqr of neighbour coordinates (:490-496)
 };
 
+int findEdgeMeshStrings(std::vector<int>& targetEdgeStrings, const EdgeMesh& em);   // BPS.C:557-587 (pointEdges must be built)
 double edgeEdgeAngle(const Vec3& c, const Vec3& p1, const Vec3& p2);   // SM.C:766-786
 double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1);  // SM.C:980-998
 bool isCloserPoint(const Vec3& a, const Vec3& b);  // SM.C:246-272

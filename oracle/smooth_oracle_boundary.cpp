@@ -155,7 +155,7 @@ static void stringifyEdgeMeshEdges(const EdgeMesh& em, std::vector<int>& targetE
 }
 
 // BPS.C:557-587
-static int findEdgeMeshStrings(std::vector<int>& targetEdgeStrings, const EdgeMesh& em) {
+int findEdgeMeshStrings(std::vector<int>& targetEdgeStrings, const EdgeMesh& em) {
     int nStrings = UNDEF_LABEL;
     targetEdgeStrings.assign(em.edges.size(), UNDEF_LABEL);
     for (size_t edgeI = 0; edgeI < em.edges.size(); ++edgeI) {

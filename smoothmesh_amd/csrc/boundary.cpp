@@ -129,6 +129,13 @@ void edgeStrings(const EdgeMeshHost& em, std::vector<int32_t>& strings) {
 }
 }  // namespace
 
+int32_t edgeMeshStrings(const EdgeMeshHost& em, std::vector<int32_t>& strings) {
+    edgeStrings(em, strings);
+    int32_t mx = -1;
+    for (int32_t v : strings) mx = std::max(mx, v);
+    return mx + 1;
+}
+
 void EdgeMeshHost::buildPointEdges() {
     pointEdges.assign((size_t)nPoints(), {});
     for (int e = 0; e < nEdges(); ++e) {

@@ -71,6 +71,9 @@ struct BoundarySetup {
     int32_t nCorner = 0, nFeature = 0, nSmoothingSurface = 0, nFrozenSurface = 0;
 };
 
+// findEdgeMeshStrings BPS.C:557-587 alone (pointEdges must be built); returns the number of strings
+int32_t edgeMeshStrings(const EdgeMeshHost& em, std::vector<int32_t>& strings);
+
 // points: the coordinates the set-up is made for (3 per mesh point).  Returns the reference's FatalError text, or "".
 std::string buildBoundarySetup(const Topology& t, const uint8_t* isInternalPoint, const double* points,
                                const std::vector<BndPatch>& patches, const BoundaryInputHost& in, BoundarySetup& out);

@@ -1704,6 +1704,20 @@ int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, i
     return 0;
 }
 
+int smgpu_debug_edge_strings(int32_t nPoints, int32_t nEdges, const int32_t* edges, int32_t* strings, int32_t* nStrings) {
+    if (nPoints < 0 || nEdges < 0 || (nEdges && (!edges || !strings))) return fail("bad argument");
+    EdgeMeshHost em;
+    em.pts.assign(3 * (size_t)nPoints, 0.0);
+    em.edges.assign(edges, edges + 2 * (size_t)nEdges);
+    for (int32_t v : em.edges) if (v < 0 || v >= nPoints) return fail("smgpu_debug_edge_strings: point id out of range");
+    em.buildPointEdges();
+    std::vector<int32_t> s;
+    const int32_t n = edgeMeshStrings(em, s);
+    std::copy(s.begin(), s.end(), strings);
+    if (nStrings) *nStrings = n;
+    return 0;
+}
+
 int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit) {
     if (!h || !segments || !hitPoints || !hit || n < 0) return fail("bad argument");
     if (!h->bndOn) return fail("smgpu_debug_find_line: boundary point smoothing is not enabled");
