@@ -172,8 +172,8 @@ __device__ __forceinline__ bool triangleIntersection(const double* __restrict__ 
 // twelve 16-byte loads: lo.x[8], lo.y[8], lo.z[8], hi.x[8], hi.y[8], hi.z[8]  (192 bytes, 64-byte aligned rows).
 // The traversal stack lives in LDS, one column per thread ([entry][thread]: conflict-free): in private memory every
 // push / pop would be a scratch round trip in the dependent chain of the descent.  7 pending siblings per level of the
-// 8-wide tree; the host checks 7 * depth + 1 <= kBvhStack (depth 6 = a million triangles).
-constexpr int kBvhStack = 48;
+// 8-wide tree; the host checks 7 * depth + 1 <= kBvhStack (depth 9: far beyond any surface that fits the device).
+constexpr int kBvhStack = 64;
 
 __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ stack, const V3& start, const V3& end, V3& hitPoint) {
     const V3 dir = end - start;
@@ -198,6 +198,8 @@ __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ sta
     // (leaves too, as -(16 * first + count) - 1); a popped leaf loads its (at most four) triangles in one batch and
     // tests them.  Lanes of a wave that are at different places of their descents still meet at these two program
     // points, instead of serialising leaf visits inside the child loop.
+    // boxes entered beyond the best hit so far cannot hold a nearer (or equal, lower-id) one: the limit follows the hits
+    double tLimit = 1.0 + 1e-6;
     int sp = 0;
     if (b.nNodes > 0) stack[kBlock * sp++] = 0;
     while (sp > 0) {
@@ -214,7 +216,7 @@ __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ sta
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int n = cnt[c];
-                double t0 = -1e-6, t1 = 1.0 + 1e-6;
+                double t0 = -1e-6, t1 = tLimit;
                 bool touch = n >= 0;
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
@@ -252,6 +254,7 @@ __device__ __forceinline__ bool findLine(const BndView& b, int* __restrict__ sta
                 if (!(t <= 1.0)) continue;   // treeDataTriSurface::findIntersectOp: inter.distance() <= 1
                 if (bestId == 0x7fffffff || t < best || (t == best && ids[k] < bestId)) { best = t; bestId = ids[k]; hitPoint = pt; }
             }
+            if (bestId != 0x7fffffff) tLimit = fmin(tLimit, best + 1e-6 * (1.0 + fabs(best)));
         }
     }
     return bestId != 0x7fffffff;
