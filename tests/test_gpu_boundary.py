@@ -180,3 +180,24 @@ def test_tiny_scale_cube_like_reference_testcase8(oracle_lib):
     bnd = ~np.array(m.isInternalPoint, bool) if hasattr(m, "isInternalPoint") else (np.abs(np.abs(np.array(m.points)) - 0.5 * L).min(axis=1) == 0)
     assert np.all(np.abs(np.abs(p[bnd]) - 0.5 * L).min(axis=1) <= 1e-22)       # boundary points are still on the cube
     assert np.isfinite(res).all() and res[-1] < res[0]
+
+
+def test_golden_fixture_boundary_hip(oracle_lib):
+    """The HIP path against the committed golden vectors (tests/golden/make_golden_boundary.py; oracle-generated)."""
+    import importlib.util
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_golden_boundary", os.path.join(here, "golden", "make_golden_boundary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(here, "golden", "hex6_boundary_seed5.npz"))
+    m, init, target, surf = mod.case()
+    o, e, prm, on = make_pair(m, oracle_lib, init, target, surf, constraints=True, blend=0.4)
+    cio, fio = e.boundary_classification()
+    assert np.array_equal(cio, g["isCornerPoint"]) and np.array_equal(fio, g["isFeatureEdgePoint"])
+    frz_all, res_all = [], []
+    for tag, iters in (("1", 1), ("5", 4), ("15", 10)):
+        n, res, frz = e.iterate(iters, 0.0)
+        frz_all.append(frz); res_all.append(res)
+        assert rel_linf(e.get_points(), g["points" + tag]) <= 1e-13
+    assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
+    assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-10, atol=0)

@@ -232,3 +232,27 @@ def test_edge_strings_on_the_reference_test_cases(oracle_lib):
         n, ideal, same = seen[case]
         assert same and n == ideal, (case, n, ideal)
     assert seen["testcase3/constant/geometry/initEdges.obj"][:2] == (17, 15)
+
+
+def test_golden_fixture_boundary(oracle_lib):
+    """Regression fixture written by tests/golden/make_golden_boundary.py (oracle output; see that script)."""
+    import importlib.util
+    import os
+    here = os.path.dirname(__file__)
+    spec = importlib.util.spec_from_file_location("make_golden_boundary", os.path.join(here, "golden", "make_golden_boundary.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    g = np.load(os.path.join(here, "golden", "hex6_boundary_seed5.npz"))
+    m, init, target, surf = mod.case()
+    assert np.array_equal(np.array(m.points), g["points0"])
+    o = make_pair(m, oracle_lib, init, target, surf, constraints=True, engine=False, blend=0.4)[0]
+    f = o.boundary_fields()
+    for k in ("isCornerPoint", "isFeatureEdgePoint", "pointStrings", "innerMap"):
+        assert np.array_equal(f[k], g[k]), k
+    frz_all, res_all = [], []
+    for tag, iters in (("1", 1), ("5", 4), ("15", 10)):
+        n, res, frz = o.iterate(iters, 0.0)
+        frz_all.append(frz); res_all.append(res)
+        assert np.max(np.abs(o.points() - g["points" + tag])) <= 1e-14
+    assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
+    assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-12, atol=0)
