@@ -316,6 +316,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
                 if (surfPoint == undef) s.acc->err = BND_ERR_NOHIT;        // BPS.C:932-938
             }
         }
+        if (role == 0) {   // the second lane of the pair was only needed for its half-ray
         // projectPrismaticInternalPointsToSurfaces OBB.C:573-631
         if ((fl & BF_SMOOTHSURF) && (fl & BF_CONNECTED) && b.inner[i] >= 0 && !(fl & (BF_FEATURE | BF_CORNER | BF_SHARP))) {
             const V3 pointNormal = ldv(s.layerNormal, p);
@@ -347,15 +348,14 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (role == 0) {
-            if (FINAL) {
-                if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
-                dist = mag(np - cur) / prm.maxStep;
-                stv(s.ptsNext, p, np);
-            } else {
-                stv(s.prop, p, np);
-                s.frozen[p] = frozen ? 1 : 0;
-            }
+        if (FINAL) {
+            if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
+            dist = mag(np - cur) / prm.maxStep;
+            stv(s.ptsNext, p, np);
+        } else {
+            stv(s.prop, p, np);
+            s.frozen[p] = frozen ? 1 : 0;
+        }
         }
     }
     if (FINAL) blockPublish<kBlock>(s, dist, fcount, partialBase + blockIdx.x);
