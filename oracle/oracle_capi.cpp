@@ -428,5 +428,46 @@ void orc_multi_setup_layers(void* mh, const int* nPatches, const int* start, con
     m->setupLayers(p, lp);
 }
 
+// boundary point smoothing of a MultiDomain (-parallel): patches of all domains concatenated, nPatches[d] per domain; the
+// geometry inputs are the same for every domain (each rank reads the same constant/geometry files).  Returns
+// doBoundarySmoothing, -1 on the reference's FatalErrors.
+int orc_multi_setup_boundary(void* mh, const int* nPatches, const int* start, const int* size, const int* kind, const unsigned char* isLayer,
+                             const unsigned char* isSmoothing, double layerMaxBlendingFraction, double layerEdgeLength,
+                             double layerExpansionRatio, int minLayers, int maxLayers, int nInitPts, const double* initPts, int nInitEdges,
+                             const int* initEdges, int nTgtPts, const double* tgtPts, int nTgtEdges, const int* tgtEdges, int nSurfPts,
+                             const double* surfPts, int nTris, const int* tris, double internalSmoothingBlendingFraction) {
+    MultiDomain* m = static_cast<MultiDomain*>(mh);
+    std::vector<std::vector<Patch>> p(m->dom.size());
+    int k = 0;
+    for (size_t d = 0; d < m->dom.size(); ++d)
+        for (int i = 0; i < nPatches[d]; ++i, ++k) {
+            Patch q; q.start = start[k]; q.size = size[k]; q.kind = kind[k]; q.isLayerPatch = isLayer[k] != 0; q.isSmoothingPatch = isSmoothing[k] != 0;
+            p[d].push_back(q);
+        }
+    LayerParams lp;
+    lp.layerMaxBlendingFraction = layerMaxBlendingFraction;
+    lp.layerEdgeLength = layerEdgeLength;
+    lp.layerExpansionRatio = layerExpansionRatio;
+    lp.minLayers = minLayers;
+    lp.maxLayers = maxLayers;
+    BoundaryInput in;
+    auto fillEdges = [](EdgeMesh& em, int nP, const double* pts, int nE, const int* e) {
+        em.points.resize((size_t)nP);
+        for (int i = 0; i < nP; ++i) em.points[(size_t)i] = {pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]};
+        em.edges.resize((size_t)nE);
+        for (int i = 0; i < nE; ++i) em.edges[(size_t)i] = {e[2 * i], e[2 * i + 1]};
+    };
+    fillEdges(in.initEdges, nInitPts, initPts, nInitEdges, initEdges);
+    fillEdges(in.targetEdges, nTgtPts, tgtPts, nTgtEdges, tgtEdges);
+    in.surf.points.resize((size_t)nSurfPts);
+    for (int i = 0; i < nSurfPts; ++i) in.surf.points[(size_t)i] = {surfPts[3 * i], surfPts[3 * i + 1], surfPts[3 * i + 2]};
+    in.surf.tris.resize((size_t)nTris);
+    for (int i = 0; i < nTris; ++i) in.surf.tris[(size_t)i] = {tris[3 * i], tris[3 * i + 1], tris[3 * i + 2]};
+    in.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
+    m->setupBoundary(p, lp, in);
+    for (Domain* d : m->dom) if (!d->error.empty()) return -1;
+    return (!m->dom.empty() && m->dom[0]->doBoundarySmoothing) ? 1 : 0;
+}
+
 }  // extern "C"
 

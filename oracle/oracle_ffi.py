@@ -77,6 +77,9 @@ def lib():
         l.orc_get_boundary_fields.argtypes = [C.c_void_p, u8p, u8p, u8p, u8p, f64p, i32p, i32p, i32p, f64p]
         l.orc_get_edge_strings.restype = C.c_int
         l.orc_get_edge_strings.argtypes = [C.c_void_p, i32p]
+        l.orc_multi_setup_boundary.restype = C.c_int
+        l.orc_multi_setup_boundary.argtypes = ([C.c_void_p, i32p, i32p, i32p, i32p, u8p, u8p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int]
+                                               + [C.c_int, f64p, C.c_int, i32p] * 3 + [C.c_double])
         l.orc_edge_strings.restype = C.c_int
         l.orc_edge_strings.argtypes = [C.c_int, C.c_int, i32p, i32p]
         l.orc_find_line.restype = C.c_int
@@ -363,6 +366,25 @@ class MultiOracle:
         self._lib.orc_multi_setup_layers(self._h, _p(npd, i32p), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p),
                                          layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers)
         return bool(self._lib.orc_layers_enabled(self._oracles[0]._h))
+
+    def setup_boundary(self, patch_arrays_per_domain, layer, initEdges, targetEdges, surf, internalSmoothingBlendingFraction=0.0):
+        """boundary point smoothing under -parallel (set-up SM.C:2080-2253 with its reductions and syncPointList calls);
+        patch_arrays_per_domain[d] = (start, size, kind, isLayer, isSmoothing) of domain d; layer as Oracle.setup_boundary"""
+        npd = np.array([len(a[0]) for a in patch_arrays_per_domain], np.int32)
+        cat = lambda k, t: np.ascontiguousarray(np.concatenate([np.asarray(a[k]) for a in patch_arrays_per_domain]), t)
+        st, sz, kd, il, ism = cat(0, np.int32), cat(1, np.int32), cat(2, np.int32), cat(3, np.uint8), cat(4, np.uint8)
+        def pe(m):
+            if m is None:
+                return np.zeros((0, 3), np.float64), np.zeros((0, 2), np.int32)
+            return np.ascontiguousarray(m[0], np.float64).reshape(-1, 3), np.ascontiguousarray(m[1], np.int32)
+        ip, ie = pe(initEdges); tp, te = pe(targetEdges); sp, stri = pe(surf)
+        rc = self._lib.orc_multi_setup_boundary(self._h, _p(npd, i32p), _p(st, i32p), _p(sz, i32p), _p(kd, i32p), _p(il, u8p), _p(ism, u8p),
+                                                float(layer[0]), float(layer[1]), float(layer[2]), int(layer[3]), int(layer[4]),
+                                                len(ip), _p(ip, f64p), len(ie), _p(ie, i32p), len(tp), _p(tp, f64p), len(te), _p(te, i32p),
+                                                len(sp), _p(sp, f64p), len(stri), _p(stri, i32p), float(internalSmoothingBlendingFraction))
+        if rc < 0:
+            raise RuntimeError("; ".join(o.error() for o in self._oracles if o.error()))
+        return bool(rc)
 
     def iterate(self, nIters, relTol=0.02):
         res = np.zeros(max(nIters, 1), np.float64)

@@ -495,6 +495,7 @@ void Domain::phaseA() {
     }
     // the rank-local part of updateNeighCoords (SM.C:2286): it only needs the current coordinates
     if (doLayerTreatment) layersUpdateNeighCoords();
+    if (doBoundarySmoothing) { boundaryLocalPre(); if (!error.empty()) return; }   // SM.C:2310, BPS.C:866 local halves
 }
 
 // SM.C:1135-1231 (with calcFaceCenter :1103-1130, findCellFacePair :1042-1097,
@@ -926,7 +927,7 @@ static void foldMagSqr(std::vector<Vec3>& v, bool takeMax) {
 // OBB.C:184-198 plusEq syncs of calculateBoundaryPointNormals (sums in ascending rank order, as syncA does for the
 // cell sums) and OBB.C:490-496 minMagSqr sync of updateNeighCoords
 void MultiDomain::syncLayers() {
-    if (dom.empty() || !dom[0]->doLayerTreatment) return;
+    if (dom.empty() || !(dom[0]->doLayerTreatment || dom[0]->doBoundarySmoothing)) return;
     for (const SharedPoint& sp : shared) {
         const int n = int(sp.domain.size());
         Vec3 s = ZERO_VECTOR;
@@ -985,12 +986,95 @@ void MultiDomain::setupLayers(const std::vector<std::vector<Patch>>& p, const La
     for (Domain* d : dom) d->layersUndo();
 }
 
+// Boundary point smoothing under -parallel.  What is rank-local in the reference stays rank-local here (classification by
+// the rank's own patches and neighbours, inner neighbour map, feature projections of the rank's own neighbour points -- a
+// neighbour that is itself shared is projected, and counted, by every rank that holds it); what the reference reduces or
+// synchronises is combined over the ranks in ascending rank order.
+void MultiDomain::setupBoundary(const std::vector<std::vector<Patch>>& p, const LayerParams& lp, const BoundaryInput& in) {
+    if (dom.empty()) return;
+    // getMeshStats reductions SM.C:1528-1538
+    double minLen = VGREAT, bb[6] = {VGREAT, -VGREAT, VGREAT, -VGREAT, VGREAT, -VGREAT};
+    for (Domain* d : dom) {
+        double m, b[6];
+        d->boundaryStatsLocal(m, b);
+        if (m < minLen) minLen = m;
+        for (int k = 0; k < 6; k += 2) { if (b[k] < bb[k]) bb[k] = b[k]; if (b[k + 1] > bb[k + 1]) bb[k + 1] = b[k + 1]; }
+    }
+    const double perimeter = bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4];
+    for (size_t d = 0; d < dom.size(); ++d) {
+        dom[d]->boundaryBegin(p[d], lp, in, minLen, perimeter);
+        if (!dom[d]->error.empty()) return;
+    }
+    auto syncMax = [&](std::vector<int> Domain::*field) {   // maxEqOp, OBB.C:124-130
+        for (const SharedPoint& sp : shared) {
+            int m = -1;
+            for (size_t j = 0; j < sp.domain.size(); ++j) m = std::max(m, (dom[sp.domain[j]]->*field)[sp.local[j]]);
+            for (size_t j = 0; j < sp.domain.size(); ++j) (dom[sp.domain[j]]->*field)[sp.local[j]] = m;
+        }
+    };
+    const int maxIter = lp.maxLayers + 1;
+    for (int iter = 0; iter < maxIter; ++iter) {
+        for (Domain* d : dom) d->layersHopsSweep();
+        syncMax(&Domain::pointHopsToLayerBoundary);
+    }
+    for (int iter = 0; iter < 2; ++iter) {
+        for (Domain* d : dom) d->boundaryHopsSweep();
+        syncMax(&Domain::pointHopsToSmoothingBoundary);
+    }
+    for (Domain* d : dom) d->layersNormalsAccumulate();
+    for (const SharedPoint& sp : shared) {   // plusEq of normals and face counts, OBB.C:184-198
+        Vec3 s = ZERO_VECTOR;
+        int cnt = 0;
+        for (size_t j = 0; j < sp.domain.size(); ++j) {
+            s += dom[sp.domain[j]]->pointNormals[sp.local[j]];
+            cnt += dom[sp.domain[j]]->layerNFaces[sp.local[j]];
+        }
+        for (size_t j = 0; j < sp.domain.size(); ++j) {
+            dom[sp.domain[j]]->pointNormals[sp.local[j]] = s;
+            dom[sp.domain[j]]->layerNFaces[sp.local[j]] = cnt;
+        }
+    }
+    for (Domain* d : dom) d->layersNormalsFinish();
+    for (int iter = 1; iter < maxIter + 1; ++iter) {
+        for (Domain* d : dom) d->layersPropagateSweep(iter);
+        for (const SharedPoint& sp : shared) {   // maxMagSqr, OBB.C:359-365
+            std::vector<Vec3> v(sp.domain.size());
+            for (size_t j = 0; j < sp.domain.size(); ++j) v[j] = dom[sp.domain[j]]->pointNormals[sp.local[j]];
+            foldMagSqr(v, true);
+            for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->pointNormals[sp.local[j]] = v[j];
+        }
+    }
+    for (Domain* d : dom) { d->layersUndo(); d->boundaryFinish(); }
+}
+
+void MultiDomain::syncBoundary() {
+    if (dom.empty() || !dom[0]->doBoundarySmoothing) return;
+    for (const SharedPoint& sp : shared) {
+        const int n = int(sp.domain.size());
+        Vec3 s = ZERO_VECTOR;
+        int cnt = 0;
+        std::vector<Vec3> nc(n);
+        for (int j = 0; j < n; ++j) {
+            s += dom[sp.domain[j]]->featureEdgeProjections[sp.local[j]];       // plusEqOp, BPS.C:659-674
+            cnt += dom[sp.domain[j]]->nFeatureEdgeProjections[sp.local[j]];
+            nc[j] = dom[sp.domain[j]]->innerNeighCoords[sp.local[j]];
+        }
+        foldMagSqr(nc, false);                                                 // minMagSqrEqOp, OBB.C:490-496
+        for (int j = 0; j < n; ++j) {
+            dom[sp.domain[j]]->featureEdgeProjections[sp.local[j]] = s;
+            dom[sp.domain[j]]->nFeatureEdgeProjections[sp.local[j]] = cnt;
+            dom[sp.domain[j]]->innerNeighCoords[sp.local[j]] = nc[j];
+        }
+    }
+}
+
 int MultiDomain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) {
     int done = 0;
     for (int i = 0; i < nIters; ++i) {
         for (Domain* d : dom) { d->phaseA(); if (!d->error.empty()) return -1; }
         syncA();
         syncLayers();
+        syncBoundary();
         for (Domain* d : dom) { d->phaseB(); if (!d->error.empty()) return -1; }
         syncFrozen();
         double res = 0.0;

@@ -155,6 +155,14 @@ public:
     std::vector<Vec3> cornerPoints, innerNeighCoords;
     std::vector<int> pointHopsToSmoothingBoundary, pointToInnerPointMap;
     void setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, const BoundaryInput& in);
+    // the same in steps, so that MultiDomain can put the reference's reductions / syncPointList calls between them
+    std::vector<int> smoothingNewHopCounts, nFeatureEdgeProjections;
+    std::vector<Vec3> featureEdgeProjections;
+    void boundaryStatsLocal(double& minLength, double bb[6]) const;   // getMeshStats SM.C:1478-1526 before the reductions
+    void boundaryBegin(const std::vector<Patch>& p, const LayerParams& lp, const BoundaryInput& in, double minEdgeGlobal, double perimeterGlobal);
+    void boundaryHopsSweep();     // OBB.C:85-121 for the smoothing patches (before the maxEq sync :124-130)
+    void boundaryFinish();        // OBB.C:396-459, SM.C:2234-2249
+    void boundaryLocalPre();      // per iteration, before the syncs: OBB.C:471-486 (inner maps), BPS.C:637-656
     Vec3 findLine(const Vec3& start, const Vec3& end, bool& hit) const;
     Vec3 findIntersection(const Vec3& origPoint, const Vec3& pointNormal, double searchDistance) const;   // BPS.C:682-745
     void projectBoundaryPoints();     // BPS.C:843-945 + OBB.C:573-631 + SM.C:2356
@@ -195,6 +203,10 @@ public:
     void syncFrozen();
     // boundary layer treatment under -parallel: the set-up with its syncs, and the two per-iteration syncs
     void setupLayers(const std::vector<std::vector<Patch>>& p, const LayerParams& lp);
+    // boundary point smoothing under -parallel: the set-up with its reductions and syncs (SM.C:2080-2253), and the per-iteration
+    // syncs of the inner neighbour coordinates (minMagSqr, OBB.C:490-496) and the feature edge projections (plusEq, BPS.C:659-674)
+    void setupBoundary(const std::vector<std::vector<Patch>>& p, const LayerParams& lp, const BoundaryInput& in);
+    void syncBoundary();
     void syncLayers();   // plusEq of normals / face counts (OBB.C:184-198), minMagSqr of neighbour coordinates (:490-496)
 };
 

@@ -167,31 +167,53 @@ int findEdgeMeshStrings(std::vector<int>& targetEdgeStrings, const EdgeMesh& em)
     return nStrings;
 }
 
+// getMeshStats SM.C:1478-1541, the rank-local part: minimum edge length and bounding box of the edge end points
+// (bb = min x, max x, min y, max y, min z, max z); the reference reduces them over the ranks (returnReduce :1528-1535)
+void Domain::boundaryStatsLocal(double& minLength, double bb[6]) const {
+    minLength = VGREAT;
+    bb[0] = bb[2] = bb[4] = VGREAT;
+    bb[1] = bb[3] = bb[5] = -VGREAT;
+    for (const auto& e : edges) {
+        const Vec3 startCoords = points[(size_t)e[0]], endCoords = points[(size_t)e[1]];
+        const double length = mag(endCoords - startCoords);
+        if (length < minLength) minLength = length;
+        for (const Vec3& q : {startCoords, endCoords}) {
+            if (q.x < bb[0]) bb[0] = q.x;
+            if (q.y < bb[2]) bb[2] = q.y;
+            if (q.z < bb[4]) bb[4] = q.z;
+            if (q.x > bb[1]) bb[1] = q.x;
+            if (q.y > bb[3]) bb[3] = q.y;
+            if (q.z > bb[5]) bb[5] = q.z;
+        }
+    }
+}
+
+// serial set-up SM.C:2080-2253
 void Domain::setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, const BoundaryInput& in) {
+    double minLength, bb[6];
+    boundaryStatsLocal(minLength, bb);
+    boundaryBegin(p, lp, in, minLength, bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4]);   // perimeter as SM.C:1538 ("+ bbMinZ")
+    if (!error.empty()) return;
+    const int maxIter = lay.maxLayers + 1;                                   // SM.C:2217
+    for (int iter = 0; iter < maxIter; ++iter) layersHopsSweep();            // layer patches, OBB.C:83-131
+    for (int iter = 0; iter < 2; ++iter) boundaryHopsSweep();                // smoothing patches, SM.C:2218
+    calculateBoundaryPointNormals();                                         // SM.C:2219
+    for (int iter = 1; iter < maxIter + 1; ++iter) layersPropagateSweep(iter);   // OBB.C:274-366
+    layersUndo();
+    boundaryFinish();
+}
+
+// Everything of the set-up that precedes the first synchronised step: storage, mesh statistics (already reduced over the
+// ranks by the caller), prerequisites SM.C:2080-2093, edge mesh checks and strings SM.C:2131-2172, classifyBoundaryPoints
+// BPS.C:269-441, zero hop counts on the layer and smoothing patches OBB.C:62-79.
+void Domain::boundaryBegin(const std::vector<Patch>& p, const LayerParams& lp, const BoundaryInput& in, double minEdgeGlobal,
+                           double perimeterGlobal) {
     layersBegin(p, lp);   // SM.C:1983-2028 storage, the layer part of classifyBoundaryPoints, zero hops of the layer patches
     if (!error.empty()) return;
     bnd = in;
-    // getMeshStats SM.C:1478-1541 (serial), distanceTolerance SM.C:1921
-    {
-        double minLength = VGREAT;
-        double bbMinX = VGREAT, bbMaxX = -VGREAT, bbMinY = VGREAT, bbMaxY = -VGREAT, bbMinZ = VGREAT, bbMaxZ = -VGREAT;
-        for (const auto& e : edges) {
-            const Vec3 startCoords = points[(size_t)e[0]], endCoords = points[(size_t)e[1]];
-            const double length = mag(endCoords - startCoords);
-            if (length < minLength) minLength = length;
-            for (const Vec3& q : {startCoords, endCoords}) {
-                if (q.x < bbMinX) bbMinX = q.x;
-                if (q.y < bbMinY) bbMinY = q.y;
-                if (q.z < bbMinZ) bbMinZ = q.z;
-                if (q.x > bbMaxX) bbMaxX = q.x;
-                if (q.y > bbMaxY) bbMaxY = q.y;
-                if (q.z > bbMaxZ) bbMaxZ = q.z;
-            }
-        }
-        meshMinEdgeLength = minLength;
-        meshPerimeter = bbMaxX - bbMinX + bbMaxY - bbMinY + bbMaxZ + bbMinZ;   // SM.C:1538
-    }
-    distanceTolerance = REL_TOL * std::min(meshMinEdgeLength, lay.layerEdgeLength);
+    meshMinEdgeLength = minEdgeGlobal;
+    meshPerimeter = perimeterGlobal;
+    distanceTolerance = REL_TOL * std::min(meshMinEdgeLength, lay.layerEdgeLength);   // SM.C:1921
 
     bool labelIOListsHaveData = false;   // SM.C:2066-2077
     for (int v : bnd.isCornerPointIO) labelIOListsHaveData = labelIOListsHaveData || v == 1;
@@ -263,10 +285,7 @@ void Domain::setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, c
                 else isFrozenSurfacePoint[pointI] = 1;
             }
 
-    // SM.C:2215-2221
-    const int maxIter = lay.maxLayers + 1;
-    for (int iter = 0; iter < maxIter; ++iter) layersHopsSweep();            // layer patches, OBB.C:83-131
-    // calculatePointHopsToBoundary(smoothingPatchIds, ..., 2) OBB.C:52-133
+    // calculatePointHopsToBoundary(smoothingPatchIds, ..., 2) OBB.C:52-133: the zero hops; the two sweeps follow
     pointHopsToSmoothingBoundary.assign(nPoints, UNDEF_LABEL);
     for (const Patch& pp : patches) {
         if (!pp.isSmoothingPatch) continue;
@@ -274,26 +293,28 @@ void Domain::setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, c
             for (int patchPointI : faces[faceI])
                 if (isConnectedToInternalPoint[patchPointI]) pointHopsToSmoothingBoundary[patchPointI] = 0;
     }
-    {
-        std::vector<int>& hops = pointHopsToSmoothingBoundary;
-        std::vector<int> newHopCounts(nPoints, -1);
-        for (int iter = 0; iter < 2; ++iter) {
-            for (int pointI = 0; pointI < nPoints; ++pointI) {
-                if (hops[pointI] >= 0) continue;
-                if (!isInternalPoint[pointI]) continue;
-                int maxHops = -1;
-                for (int neighI : pointPoints[pointI])
-                    if (hops[neighI] > maxHops) maxHops = hops[neighI];
-                if (maxHops >= 0) newHopCounts[pointI] = maxHops + 1;
-            }
-            for (int pointI = 0; pointI < nPoints; ++pointI)
-                if (newHopCounts[pointI] > hops[pointI]) hops[pointI] = newHopCounts[pointI];
-        }
+    smoothingNewHopCounts.assign(nPoints, -1);
+}
+
+// one sweep of calculatePointHopsToBoundary for the smoothing patches (OBB.C:85-121; the maxEq sync :124-130 follows)
+void Domain::boundaryHopsSweep() {
+    std::vector<int>& hops = pointHopsToSmoothingBoundary;
+    std::vector<int>& newHopCounts = smoothingNewHopCounts;
+    for (int pointI = 0; pointI < nPoints; ++pointI) {
+        if (hops[pointI] >= 0) continue;
+        if (!isInternalPoint[pointI]) continue;
+        int maxHops = -1;
+        for (int neighI : pointPoints[pointI])
+            if (hops[neighI] > maxHops) maxHops = hops[neighI];
+        if (maxHops >= 0) newHopCounts[pointI] = maxHops + 1;
     }
-    calculateBoundaryPointNormals();                                         // SM.C:2219
-    for (int iter = 1; iter < maxIter + 1; ++iter) layersPropagateSweep(iter);   // OBB.C:274-366
-    layersUndo();
-    // propagateInnerNeighInfo OBB.C:396-459
+    for (int pointI = 0; pointI < nPoints; ++pointI)
+        if (newHopCounts[pointI] > hops[pointI]) hops[pointI] = newHopCounts[pointI];
+}
+
+// propagateInnerNeighInfo OBB.C:396-459 and the target edge string of every feature edge point SM.C:2234-2249 (rank-local)
+void Domain::boundaryFinish() {
+    const EdgeMesh& targetEdges = bnd.targetEdges;
     isInnerNeighInProc.assign(nPoints, 0);
     pointToInnerPointMap.assign(nPoints, UNDEF_LABEL);
     innerNeighCoords.assign(nPoints, UNDEF_VECTOR);
@@ -307,7 +328,6 @@ void Domain::setupBoundary(const std::vector<Patch>& p, const LayerParams& lp, c
             if (pointHopsToSmoothingBoundary[neighI] == (nHops + 1)) { ++nNeighHops; neighPointI = neighI; }
         if (nNeighHops == 1) { isInnerNeighInProc[pointI] = 1; pointToInnerPointMap[pointI] = neighPointI; }
     }
-    // SM.C:2234-2249 target edge string of every feature edge point
     if (doBoundarySmoothing)
         for (int pointI = 0; pointI < nPoints; ++pointI) {
             if (!isFeatureEdgePoint[pointI]) continue;
@@ -384,18 +404,17 @@ Vec3 Domain::findIntersection(const Vec3& origPoint, const Vec3& pointNormal, do
     return UNDEF_VECTOR;
 }
 
-// SM.C:2307-2357: updateNeighCoords (inner), projectBoundaryPointsToEdgesAndSurfaces BPS.C:843-945,
-// projectPrismaticInternalPointsToSurfaces OBB.C:573-631, constrainMaxStepLength over all points
-void Domain::projectBoundaryPoints() {
+// The parts of SM.C:2307-2330 that only read the current coordinates, before their syncPointList calls: the local half of
+// updateNeighCoords with the inner maps (OBB.C:471-486; minMagSqr sync :490-496) and of calculateFeatureEdgeProjections
+// (BPS.C:637-656; plusEq syncs :659-674).
+void Domain::boundaryLocalPre() {
     const EdgeMesh& targetEdges = bnd.targetEdges;
-    // updateNeighCoords OBB.C:464-500 with the inner maps
     for (int pointI = 0; pointI < nPoints; ++pointI) {
         if (!isInnerNeighInProc[pointI]) { innerNeighCoords[pointI] = UNDEF_VECTOR; continue; }
         innerNeighCoords[pointI] = points[(size_t)pointToInnerPointMap[pointI]];
     }
-    // calculateFeatureEdgeProjections BPS.C:623-677
-    std::vector<Vec3> featureEdgeProjections(nPoints, ZERO_VECTOR);
-    std::vector<int> nFeatureEdgeProjections(nPoints, 0);
+    featureEdgeProjections.assign(nPoints, ZERO_VECTOR);
+    nFeatureEdgeProjections.assign(nPoints, 0);
     for (int pointI = 0; pointI < nPoints; ++pointI) {
         if (!isFeatureEdgePoint[pointI]) continue;
         for (int neighI : pointPoints[pointI]) {   // findNeighborSurfacePoints BPS.C:592-615
@@ -412,6 +431,11 @@ void Domain::projectBoundaryPoints() {
             ++nFeatureEdgeProjections[pointI];
         }
     }
+}
+
+// SM.C:2307-2357 after the synchronised inputs are in place: projectBoundaryPointsToEdgesAndSurfaces BPS.C:843-945,
+// projectPrismaticInternalPointsToSurfaces OBB.C:573-631, constrainMaxStepLength over all points
+void Domain::projectBoundaryPoints() {
     // calculateSurfaceCentroids BPS.C:781-839: the centroids are blended with faceCentroidBlendingFraction = 0.0
     // (BPS.C:872): the term is 0 * centroid, which changes no finite value; not restated
     for (int pointI = 0; pointI < nPoints; ++pointI) {

@@ -256,3 +256,45 @@ def test_golden_fixture_boundary(oracle_lib):
         assert np.max(np.abs(o.points() - g["points" + tag])) <= 1e-14
     assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
     assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-12, atol=0)
+
+
+def _multi_boundary_case(oracle_lib, grid, nloc, jitter, constraints, blend=0.3, seed=3):
+    from smoothmesh_amd import default_params, patch_arrays
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface
+    world = grid[0] * grid[1] * grid[2]
+    subs = [hex_subdomain(nloc, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+    hi = tuple(float(g) for g in grid)                      # every sub-domain is a unit cube
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    pa = [patch_arrays(s.mesh, ()) + (patch_arrays(s.mesh, ('".*"',))[3],) for s in subs]
+    on = mo.setup_boundary(pa, (0.3, prm.minEdgeLength, 1.3, 1, 4), box_feature_edges(8, hi=hi), None, box_surface(4, hi=hi), blend)
+    assert on
+    return mo, orcs, subs, (off, dom, loc), hi
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 1), (2, 2, 2)])
+def test_decomposed_boundary_smoothing_keeps_the_ranks_consistent(oracle_lib, grid):
+    """Under -parallel every rank projects its copy of a shared boundary point itself; the reference's syncs (normals
+    OBB.C:184-198, inner neighbour coordinates OBB.C:490-496, feature projections BPS.C:659-674, centroid sums SM.C:134-148)
+    give all sharers the same inputs, so the copies must stay identical; the boundary stays on the block"""
+    mo, orcs, subs, (off, dom, loc), hi = _multi_boundary_case(oracle_lib, grid, (4, 5, 6), 0.25, True)
+    n, res, frz = mo.iterate(10, 0.0)
+    assert n == 10 and np.isfinite(res).all() and res[-1] < 0.5 * res[0]
+    P = [o.points() for o in orcs]
+    for i in range(len(off) - 1):
+        c = [P[dom[k]][loc[k]] for k in range(off[i], off[i + 1])]
+        assert all(np.array_equal(c[0], x) for x in c[1:])
+    allp = np.concatenate(P)
+    assert np.array_equal(allp.min(axis=0), [0.0, 0.0, 0.0]) and np.array_equal(allp.max(axis=0), hi)
+    # a uniform decomposed block on its own surface is a fixed point, as in the serial run
+    mo2, orcs2, subs2, _, _ = _multi_boundary_case(oracle_lib, grid, (4, 4, 4), 0.0, False)      # 1/4 is exact in binary
+    n, res, frz = mo2.iterate(3, 0.0)
+    assert np.all(res == 0.0) and np.all(frz == 0)
+    for o, s in zip(orcs2, subs2):
+        assert np.array_equal(o.points(), np.array(s.mesh.points))
