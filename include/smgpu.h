@@ -193,7 +193,10 @@ enum { SMGPU_LAYERS_HOPS_SWEEP = 0, SMGPU_LAYERS_NORMALS_ACCUMULATE = 1, SMGPU_L
 enum { SMGPU_LAYERS_F_HOPS = 0,            /* 1 double per shared point (the hop count or -1)        */
        SMGPU_LAYERS_F_NORMALS_COUNT = 1,   /* 4 doubles: normal, number of boundary faces            */
        SMGPU_LAYERS_F_NORMALS = 2 };       /* 3 doubles: normal                                      */
-#define SMGPU_HALO_L_DOUBLES 6
+/* One record per shared point: [0:3] local normal, [3:6] outer neighbour coordinates (layers), [6] local number of boundary
+ * faces, [7:10] inner neighbour coordinates, [10:13] local feature edge projection sum, [13] its count (boundary point
+ * smoothing; zero / UNDEF when that is off).  Exchanged whenever the layer treatment or the boundary point smoothing is on. */
+#define SMGPU_HALO_L_DOUBLES 14
 int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled, int32_t* maxIter);
 int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg);
 int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);
@@ -208,8 +211,8 @@ int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* val
  * Inputs are the contents of constant/geometry/{initEdges,targetEdges,targetSurfaces}.obj (SM.C:1924-1926) as flat
  * arrays and, optionally, the isCornerPoint / isFeatureEdgePoint lists a previous run wrote (SM.C:2039-2077).
  * OpenFOAM's octree line query is replaced by a bounding volume hierarchy; semantics in csrc/kernels_boundary.hpp.
- * Call after smgpu_create and, when both are used, after smgpu_set_layers; before iterating.  Not available together
- * with smgpu_halo_configure (the reference's -parallel syncs of this feature are not provided yet).
+ * Call after smgpu_create and, when both are used, after smgpu_set_layers; before iterating.  With a halo use the
+ * step-wise form below.
  * info->enabled = the reference's doBoundarySmoothing (SM.C:2080-2093). */
 typedef struct smgpu_boundary_desc {
     int32_t nPatches;
@@ -234,6 +237,24 @@ typedef struct smgpu_boundary_info {
     int32_t nTargetEdgeStrings;                                                                /* SM.C:2171      */
 } smgpu_boundary_info;
 int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info);
+/* The same set-up in steps, for runs with a halo (-parallel; configure the halo and, if used, the layers first).  The host
+ * performs the reference's reductions and syncTools::syncPointList calls between the steps (SM.C:1528-1538, 2218-2219):
+ *   smgpu_boundary_stats on every rank; minimum of the edge lengths, bounding box over the ranks,
+ *                                       perimeter = (max x - min x) + (max y - min y) + (max z + min z)   [SM.C:1538 as written]
+ *   smgpu_boundary_begin(reduced values) on every rank
+ *   2 x { step HOPS_SWEEP;  get F_HOPS, combine with max over the sharers (OBB.C:124-130), set F_HOPS }
+ *   step TABLES
+ *   step NORMALS_ACCUMULATE;  get F_NORMALS_COUNT, sum over the sharers in ascending rank order (OBB.C:184-198), set;
+ *   step NORMALS_FINISH                      (both are no-ops when the layer set-up has produced the normals already)
+ * Every later iteration the boundary point smoothing fields travel in the sendL / recvL records (SMGPU_HALO_L_DOUBLES). */
+enum { SMGPU_BOUNDARY_HOPS_SWEEP = 0, SMGPU_BOUNDARY_TABLES = 1, SMGPU_BOUNDARY_NORMALS_ACCUMULATE = 2, SMGPU_BOUNDARY_NORMALS_FINISH = 3 };
+enum { SMGPU_BOUNDARY_F_HOPS = 0,            /* 1 double per shared point (the hop count or -1)         */
+       SMGPU_BOUNDARY_F_NORMALS_COUNT = 1 }; /* 4 doubles: local normal sum, local number of boundary faces */
+int smgpu_boundary_stats(smgpu_handle* h, double* minEdgeLength, double* boundingBox /* [6]: min x, max x, min y, ... */);
+int smgpu_boundary_begin(smgpu_handle* h, const smgpu_boundary_desc* d, double minEdgeLengthGlobal, double perimeterGlobal,
+                         smgpu_boundary_info* info);
+int smgpu_boundary_step(smgpu_handle* h, int32_t step);
+int smgpu_boundary_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);
 /* the classification to persist as <time>/isCornerPoint and <time>/isFeatureEdgePoint (labelIOLists, SM.C:2039-2064) */
 int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, int32_t* isFeatureEdgePoint);
 /* parity access, host only: the string index of every edge of an edge mesh (findEdgeMeshStrings BPS.C:557-587) */

@@ -215,35 +215,62 @@ void orc_halo_combineA(void* h, int nShared, const int* sharedLocal, const int* 
 }
 // boundary layer treatment under -parallel, rank-engine form: 6 doubles per shared point (local normal, local outer
 // neighbour coordinates), combined as MultiDomain::syncLayers does
+// the exchange-L record of include/smgpu.h (SMGPU_HALO_L_DOUBLES = 14): normal, outer neighbour coordinates, local face
+// count, inner neighbour coordinates, local feature edge projection sum and count
+static const int kL = 14;
 void orc_halo_packL(void* h, const int* sharedLocal, int nSend, const int* sendShared, double* sendL) {
     Domain* d = static_cast<Domain*>(h);
+    const bool bnd = d->doBoundarySmoothing;
     for (int i = 0; i < nSend; ++i) {
         const int p = sharedLocal[sendShared[i]];
-        double* r = sendL + 6 * (size_t)i;
+        double* r = sendL + (size_t)kL * (size_t)i;
         r[0] = d->pointNormals[p].x; r[1] = d->pointNormals[p].y; r[2] = d->pointNormals[p].z;
         r[3] = d->outerNeighCoords[p].x; r[4] = d->outerNeighCoords[p].y; r[5] = d->outerNeighCoords[p].z;
+        r[6] = d->layerNFaces.empty() ? 0.0 : (double)d->layerNFaces[p];
+        r[7] = r[8] = r[9] = GREAT;
+        r[10] = r[11] = r[12] = r[13] = 0.0;
+        if (bnd) {
+            r[7] = d->innerNeighCoords[p].x; r[8] = d->innerNeighCoords[p].y; r[9] = d->innerNeighCoords[p].z;
+            r[10] = d->featureEdgeProjections[p].x; r[11] = d->featureEdgeProjections[p].y; r[12] = d->featureEdgeProjections[p].z;
+            r[13] = (double)d->nFeatureEdgeProjections[p];
+        }
     }
 }
 void orc_halo_combineL(void* h, int nShared, const int* sharedLocal, const int* combOff, const int* combSlots, const double* recvL) {
     Domain* d = static_cast<Domain*>(h);
+    const bool bnd = d->doBoundarySmoothing;
+    auto fold = [](const Vec3& x, const Vec3& y) {
+        const double mx = x.x * x.x + x.y * x.y + x.z * x.z, my = y.x * y.x + y.y * y.y + y.z * y.z;
+        return (mx <= my) ? x : y;
+    };
     for (int i = 0; i < nShared; ++i) {
         const int p = sharedLocal[i];
         const int b = combOff[i], n = combOff[i + 1] - b;
-        const Vec3 ownN = d->pointNormals[p], ownC = d->outerNeighCoords[p];
-        Vec3 sum{0, 0, 0};
-        Vec3 x = ownC;
+        const Vec3 ownN = d->pointNormals[p];
+        Vec3 sum{0, 0, 0}, fsum{0, 0, 0};
+        Vec3 x = d->outerNeighCoords[p];
+        Vec3 y = bnd ? d->innerNeighCoords[p] : Vec3{GREAT, GREAT, GREAT};
+        int faces = 0, fcnt = 0;
         for (int j = 0; j < n; ++j) {
             const int sl = combSlots[b + j];
-            const Vec3 nj = (sl < 0) ? ownN : Vec3{recvL[6 * (size_t)sl], recvL[6 * (size_t)sl + 1], recvL[6 * (size_t)sl + 2]};
+            const double* r = (sl < 0) ? nullptr : recvL + (size_t)kL * (size_t)sl;
+            const Vec3 nj = r ? Vec3{r[0], r[1], r[2]} : ownN;
             sum.x += nj.x; sum.y += nj.y; sum.z += nj.z;
-            if (sl >= 0) {
-                const Vec3 y{recvL[6 * (size_t)sl + 3], recvL[6 * (size_t)sl + 4], recvL[6 * (size_t)sl + 5]};
-                const double mx = x.x * x.x + x.y * x.y + x.z * x.z, my = y.x * y.x + y.y * y.y + y.z * y.z;
-                x = (mx <= my) ? x : y;
+            faces += r ? (int)r[6] : (d->layerNFaces.empty() ? 0 : d->layerNFaces[p]);
+            if (bnd) {
+                const Vec3 fj = r ? Vec3{r[10], r[11], r[12]} : d->featureEdgeProjections[p];
+                fsum.x += fj.x; fsum.y += fj.y; fsum.z += fj.z;
+                fcnt += r ? (int)r[13] : d->nFeatureEdgeProjections[p];
+            }
+            if (r) {
+                x = fold(x, Vec3{r[3], r[4], r[5]});
+                if (bnd) y = fold(y, Vec3{r[7], r[8], r[9]});
             }
         }
         d->pointNormals[p] = sum;
         d->outerNeighCoords[p] = x;
+        if (!d->layerNFaces.empty()) d->layerNFaces[p] = faces;
+        if (bnd) { d->innerNeighCoords[p] = y; d->featureEdgeProjections[p] = fsum; d->nFeatureEdgeProjections[p] = fcnt; }
     }
 }
 // step-wise set-up (same steps / fields as include/smgpu.h smgpu_layers_*)

@@ -108,6 +108,10 @@ SYMBOLS = {
     "smgpu_layers_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "smgpu_layers_shared": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_f64p]),
     "smgpu_set_boundary_smoothing": (C.c_int, [C.c_void_p, C.POINTER(BoundaryDesc), C.POINTER(BoundaryInfo)]),
+    "smgpu_boundary_stats": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
+    "smgpu_boundary_begin": (C.c_int, [C.c_void_p, C.POINTER(BoundaryDesc), C.c_double, C.c_double, C.POINTER(BoundaryInfo)]),
+    "smgpu_boundary_step": (C.c_int, [C.c_void_p, C.c_int32]),
+    "smgpu_boundary_shared": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, c_f64p]),
     "smgpu_get_boundary_classification": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
     "smgpu_debug_edge_strings": (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p]),
     "smgpu_debug_find_line": (C.c_int, [C.c_void_p, C.c_int32, c_f64p, c_f64p, c_i32p]),

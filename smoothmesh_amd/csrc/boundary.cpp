@@ -248,19 +248,31 @@ std::string buildBoundarySetup(const Topology& t, const uint8_t* internal, const
             for (int k = fp.off[f]; k < fp.off[f + 1]; ++k)
                 if (o.isConnectedToInternalPoint[fp.val[k]]) hops[fp.val[k]] = 0;
     }
-    {
-        std::vector<int32_t> fresh((size_t)P, -1);
-        for (int iter = 0; iter < 2; ++iter) {
-            for (int p = 0; p < P; ++p) {
-                if (hops[p] >= 0 || !internal[p]) continue;
-                int mx = -1;
-                for (int j = pe.off[p]; j < pe.off[p + 1]; ++j) mx = std::max(mx, hops[t.pointPoints[j]]);
-                if (mx >= 0) fresh[p] = mx + 1;
-            }
-            for (int p = 0; p < P; ++p) if (fresh[p] > hops[p]) hops[p] = fresh[p];
-        }
+    o.hopsFresh.assign((size_t)P, -1);
+    o.distanceTolerance = tol;
+    return "";
+}
+
+// one sweep of calculatePointHopsToBoundary for the smoothing patches (OBB.C:85-121; under -parallel the host applies the
+// maxEq sync :124-130 to the shared points between the sweeps)
+void boundarySetupHopsSweep(const Topology& t, const uint8_t* internal, BoundarySetup& o) {
+    const int P = t.nPoints;
+    const Csr& pe = t.pointEdges;
+    std::vector<int32_t>& hops = o.hopsToSmoothingBoundary;
+    for (int p = 0; p < P; ++p) {
+        if (hops[p] >= 0 || !internal[p]) continue;
+        int mx = -1;
+        for (int j = pe.off[p]; j < pe.off[p + 1]; ++j) mx = std::max(mx, hops[t.pointPoints[j]]);
+        if (mx >= 0) o.hopsFresh[p] = mx + 1;
     }
-    // propagateInnerNeighInfo OBB.C:396-459
+    for (int p = 0; p < P; ++p) if (o.hopsFresh[p] > hops[p]) hops[p] = o.hopsFresh[p];
+}
+
+// propagateInnerNeighInfo OBB.C:396-459 and the target edge string of every feature edge point SM.C:2234-2249 (rank-local)
+std::string boundarySetupFinish(const Topology& t, const double* points, BoundarySetup& o) {
+    const int P = t.nPoints;
+    const Csr& pe = t.pointEdges;
+    const std::vector<int32_t>& hops = o.hopsToSmoothingBoundary;
     o.innerMap.assign((size_t)P, -1);
     for (int p = 0; p < P; ++p) {
         if (!o.isSmoothingSurfacePoint[p] || !o.isConnectedToInternalPoint[p]) continue;
@@ -270,11 +282,18 @@ std::string buildBoundarySetup(const Topology& t, const uint8_t* internal, const
             if (hops[t.pointPoints[j]] == 1) { ++n; q = t.pointPoints[j]; }
         if (n == 1) o.innerMap[p] = q;
     }
-    // SM.C:2234-2249: the target edge string of every feature edge point
     if (o.enabled)
         for (int p = 0; p < P; ++p)
-            if (o.isFeatureEdgePoint[p]) o.pointStrings[p] = closestEdge(ld(points, p), o.target, o.targetEdgeStrings, tol).string;
+            if (o.isFeatureEdgePoint[p]) o.pointStrings[p] = closestEdge(ld(points, p), o.target, o.targetEdgeStrings, o.distanceTolerance).string;
     return "";
+}
+
+std::string buildBoundarySetupSerial(const Topology& t, const uint8_t* internal, const double* points, const std::vector<BndPatch>& patches,
+                                     const BoundaryInputHost& in, BoundarySetup& o) {
+    const std::string err = buildBoundarySetup(t, internal, points, patches, in, o);
+    if (!err.empty()) return err;
+    for (int iter = 0; iter < 2; ++iter) boundarySetupHopsSweep(t, internal, o);   // SM.C:2218
+    return boundarySetupFinish(t, points, o);
 }
 
 // ---- bounding volume hierarchy over the target triangles -------------------------------------------------------------

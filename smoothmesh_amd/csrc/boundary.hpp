@@ -69,13 +69,25 @@ struct BoundarySetup {
     std::vector<int32_t> pointStrings, hopsToSmoothingBoundary, innerMap, targetEdgeStrings;
     EdgeMeshHost target;                           // the resolved target edge mesh
     int32_t nCorner = 0, nFeature = 0, nSmoothingSurface = 0, nFrozenSurface = 0;
+    std::vector<int32_t> hopsFresh;                // newHopCounts of the sweeps (OBB.C:82)
+    double distanceTolerance = 0.0;
 };
 
 // findEdgeMeshStrings BPS.C:557-587 alone (pointEdges must be built); returns the number of strings
 int32_t edgeMeshStrings(const EdgeMeshHost& em, std::vector<int32_t>& strings);
 
 // points: the coordinates the set-up is made for (3 per mesh point).  Returns the reference's FatalError text, or "".
+// The set-up in steps (under -parallel the host synchronises the hop counts of the shared points between the sweeps):
+//   buildBoundarySetup    everything up to the zero hop counts on the smoothing patches (in.meshMinEdgeLength / meshPerimeter
+//                         already reduced over the ranks)
+//   boundarySetupHopsSweep x 2
+//   boundarySetupFinish   inner neighbour map, target strings of the feature edge points
 std::string buildBoundarySetup(const Topology& t, const uint8_t* isInternalPoint, const double* points,
                                const std::vector<BndPatch>& patches, const BoundaryInputHost& in, BoundarySetup& out);
+void boundarySetupHopsSweep(const Topology& t, const uint8_t* isInternalPoint, BoundarySetup& out);
+std::string boundarySetupFinish(const Topology& t, const double* points, BoundarySetup& out);
+// all of it back to back (serial run)
+std::string buildBoundarySetupSerial(const Topology& t, const uint8_t* isInternalPoint, const double* points,
+                                     const std::vector<BndPatch>& patches, const BoundaryInputHost& in, BoundarySetup& out);
 
 }  // namespace smgpu

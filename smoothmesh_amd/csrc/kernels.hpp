@@ -61,6 +61,7 @@ struct State {
     // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
     // outer neighbour; per hop count the target edge length and the blending fraction
     double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
+    const int* bndOfShared;    // multi-rank + boundary point smoothing: per shared point its index in the boundary tables or -1
     const double* combL;       // multi-rank + layers: per shared point the summed normals and the combined outer
                                // neighbour coordinates (6 doubles), or NULL
 };
@@ -278,7 +279,8 @@ __device__ __forceinline__ void blockPublish(const State& s, double dist, int fr
 // minMagSqr-synchronised neighbour coordinates (OBB.C:490-496) from combL instead of its local values.
 __device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, bool internal, const V3& cur, V3 np) {
     const int slot = (s.combL && s.sharedSlot) ? s.sharedSlot[p] : -1;
-    V3 n = (slot >= 0) ? ldv(s.combL, 2 * slot) : ldv(s.layerNormal, p);
+    const double* cl = (slot >= 0) ? s.combL + (size_t)slot * SMGPU_HALO_L_DOUBLES : nullptr;
+    V3 n = cl ? v3(cl[0], cl[1], cl[2]) : ldv(s.layerNormal, p);
     const V3 z = v3(0, 0, 0);
     if (n != z) {
         // with boundary point smoothing k_bnd_normals has already recomputed the boundary points' normals this iteration
@@ -288,7 +290,7 @@ __device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, 
         }
         const int hops = s.layerHops[p];
         if (internal && hops >= 1) {
-            const V3 outer = (slot >= 0) ? ldv(s.combL, 2 * slot + 1) : ldv(s.ptsCur, s.layerMap[p]);
+            const V3 outer = cl ? v3(cl[3], cl[4], cl[5]) : ldv(s.ptsCur, s.layerMap[p]);
             const double blendFrac = s.layerBlend[hops];
             const V3 orthoPoint = outer + s.layerLen[hops] * n;
             np = blendFrac * orthoPoint + (1.0 - blendFrac) * np;
@@ -810,7 +812,7 @@ __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials,
 // ---- multi-rank pack / combine -------------------------------------------------------------------
 // exchange A: local partial sums and closest points of the shared points (SM.C:108-131, 325-387)
 __global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, const int* sharedLocal, double* ownA, int nShared,
-                                                        const int* sendOff, const int* sendSlots, double* sendA) {
+                                                        const int* sendOff, const int* sendSlots, double* sendA, int centroidAll) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     // the own record (one per shared point) and its copies in the send slots of the point (one per other sharer)
     if (i < nShared) {
@@ -818,7 +820,7 @@ __global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, cons
         const V3 cur = ldv(s.ptsCur, p);
         PointLocal L;
         int err = 0;
-        pointLocal(m, s, p, cur, m.pflags[p] & PF_INTERNAL, L, err);
+        pointLocal(m, s, p, cur, m.pflags[p] & PF_INTERNAL, L, err, centroidAll != 0);
         if (err) s.acc->err = 1;
         double* r = ownA + (size_t)i * SMGPU_HALO_A_DOUBLES;
         r[0] = L.sum.x; r[1] = L.sum.y; r[2] = L.sum.z;
@@ -834,42 +836,65 @@ __global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, cons
     }
 }
 
-// boundary layer treatment under -parallel: per shared point the local normal and the local outer neighbour's current
-// coordinates (UNDEF_VECTOR when the neighbour is not in this rank, OBB.C:474-478)
+// boundary layer treatment / boundary point smoothing under -parallel: the record of SMGPU_HALO_L_DOUBLES per shared point
+// (layout in include/smgpu.h): local normal and outer neighbour coordinates (UNDEF_VECTOR when the neighbour is not in this
+// rank, OBB.C:474-478); with boundary point smoothing also the local face count, the inner neighbour's coordinates and the
+// local feature edge projections (bf* / inner / feat* = the boundary tables of kernels_boundary.hpp, or null).
 __global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* sharedLocal, double* ownL, int nShared, const int* sendOff,
-                                                        const int* sendSlots, double* sendL) {
+                                                        const int* sendSlots, double* sendL, const int* bfOff, const int* inner,
+                                                        const int* featOfBnd, const double* featSum, const int* featCnt) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int p = sharedLocal[i];
-    const int q = s.layerMap[p];
+    const int q = s.layerMap ? s.layerMap[p] : -1;
+    double rec[SMGPU_HALO_L_DOUBLES];
     const V3 nrm = ldv(s.layerNormal, p);
     const V3 x = q >= 0 ? ldv(s.ptsCur, q) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
-    stv(ownL, 2 * i, nrm);
-    stv(ownL, 2 * i + 1, x);
+    rec[0] = nrm.x; rec[1] = nrm.y; rec[2] = nrm.z; rec[3] = x.x; rec[4] = x.y; rec[5] = x.z;
+    rec[6] = 0.0; rec[7] = rec[8] = rec[9] = SMGPU_GREAT; rec[10] = rec[11] = rec[12] = 0.0; rec[13] = 0.0;
+    const int bi = s.bndOfShared ? s.bndOfShared[i] : -1;
+    if (bi >= 0) {
+        rec[6] = (double)(bfOff[bi + 1] - bfOff[bi]);
+        if (inner[bi] >= 0) { const V3 y = ldv(s.ptsCur, inner[bi]); rec[7] = y.x; rec[8] = y.y; rec[9] = y.z; }   // OBB.C:471-486
+        const int f = featOfBnd[bi];
+        if (f >= 0) { const V3 fs = ldv(featSum, f); rec[10] = fs.x; rec[11] = fs.y; rec[12] = fs.z; rec[13] = (double)featCnt[f]; }
+    }
+    double* o = ownL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+#pragma unroll
+    for (int j = 0; j < SMGPU_HALO_L_DOUBLES; ++j) o[j] = rec[j];
     for (int k = sendOff[i]; k < sendOff[i + 1]; ++k) {
-        stv(sendL, 2 * sendSlots[k], nrm);
-        stv(sendL, 2 * sendSlots[k] + 1, x);
+        double* d = sendL + (size_t)sendSlots[k] * SMGPU_HALO_L_DOUBLES;
+#pragma unroll
+        for (int j = 0; j < SMGPU_HALO_L_DOUBLES; ++j) d[j] = rec[j];
     }
 }
-// plusEqOp in ascending rank order for the normals; minMagSqrEqOp folded from the own value for the coordinates
+// plusEq in ascending rank order for the normals, face counts and feature projections (OBB.C:184-198, BPS.C:659-674);
+// minMagSqrEqOp folded from the own value for the outer and inner neighbour coordinates (OBB.C:490-496)
 __global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
                                                           const double* recvL, double* combL) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
-    V3 sum = v3(0, 0, 0);
-    V3 x = ldv(ownL, 2 * i + 1);
+    const double* own = ownL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+    V3 sum = v3(0, 0, 0), fsum = v3(0, 0, 0);
+    double faces = 0.0, fcnt = 0.0;
+    V3 x = v3(own[3], own[4], own[5]), y = v3(own[7], own[8], own[9]);
     for (int j = 0; j < n; ++j) {
         const int sl = combSlots[b + j];
-        const double* r = (sl < 0) ? ownL + (size_t)i * SMGPU_HALO_L_DOUBLES : recvL + (size_t)sl * SMGPU_HALO_L_DOUBLES;
+        const double* r = (sl < 0) ? own : recvL + (size_t)sl * SMGPU_HALO_L_DOUBLES;
         sum = sum + v3(r[0], r[1], r[2]);
+        faces += r[6];
+        fsum = fsum + v3(r[10], r[11], r[12]);
+        fcnt += r[13];
         if (sl >= 0) {
-            const V3 y = v3(r[3], r[4], r[5]);
-            x = (magSqr(x) <= magSqr(y)) ? x : y;
+            const V3 x2 = v3(r[3], r[4], r[5]), y2 = v3(r[7], r[8], r[9]);
+            x = (magSqr(x) <= magSqr(x2)) ? x : x2;
+            y = (magSqr(y) <= magSqr(y2)) ? y : y2;
         }
     }
-    stv(combL, 2 * i, sum);
-    stv(combL, 2 * i + 1, x);
+    double* o = combL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+    o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = x.x; o[4] = x.y; o[5] = x.z; o[6] = faces;
+    o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt;
 }
 
 // SM.C:246-272 isCloserPoint

@@ -88,6 +88,9 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, Bnd
         const V3 cSf = faceAreaOf(m, s.ptsCur, b.bfVal[k]);
         n = n - cSf / mag(cSf);
     }
+    // multi-rank: a shared point's local sum goes to the other sharers first (plusEq, OBB.C:184-198); k_bnd_normals_shared
+    // classifies and normalises it after the exchange
+    if (s.sharedSlot && s.sharedSlot[p] >= 0) { stv(s.layerNormal, p, n); return; }
     uint8_t fl = b.flags[i];
     if (f1 > f0) {
         if (mag(n) < 0.1) { n = v3(0, 0, 0); fl |= BF_SHARP; }
@@ -96,6 +99,25 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, Bnd
     }
     if (n != v3(0, 0, 0)) n = n / mag(n);
     stv(s.layerNormal, p, n);
+}
+
+// OBB.C:201-230 for the shared boundary points, on the sums over the sharers (combL: normal [0:3], face count [6])
+__global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView b, int nShared, const int* sharedLocal) {
+    if (s.acc->stop) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    const int bi = s.bndOfShared[i];
+    if (bi < 0) return;
+    const double* r = s.combL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+    V3 n = v3(r[0], r[1], r[2]);
+    uint8_t fl = b.flags[bi];
+    if (r[6] >= 1.0) {
+        if (mag(n) < 0.1) { n = v3(0, 0, 0); fl |= BF_SHARP; }
+        else fl &= (uint8_t)~BF_SHARP;
+        b.flags[bi] = fl;
+    }
+    if (n != v3(0, 0, 0)) n = n / mag(n);
+    stv(s.layerNormal, sharedLocal[i], n);
 }
 
 // projectPointToEdge BPS.C:89-145 (the edge point index it also reports is not consumed per iteration)
@@ -296,11 +318,15 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
         V3 np = ldv(s.prop, p);
         const V3 undef = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
         bool frozen = false;
+        // multi-rank: a shared point takes the values combined over its sharers (BPS.C:659-674, OBB.C:490-496)
+        const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
+        const double* cl = (slot >= 0) ? s.combL + (size_t)slot * SMGPU_HALO_L_DOUBLES : nullptr;
         // projectBoundaryPointsToEdgesAndSurfaces BPS.C:876-940
         if (fl & BF_CORNER) np = ldv(b.corner, i);
         else if (fl & BF_FEATURE) {
             const int j = b.featOfBnd[i];
-            np = ldv(b.featSum, j) / double(b.featCnt[j]);
+            if (cl) np = v3(cl[10], cl[11], cl[12]) / cl[13];
+            else np = ldv(b.featSum, j) / double(b.featCnt[j]);
         } else if (fl & BF_SHARP) frozen = true;
         else if (fl & BF_SMOOTHSURF) {
             const V3 pointNormal = ldv(s.layerNormal, p);
@@ -321,7 +347,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
         if ((fl & BF_SMOOTHSURF) && (fl & BF_CONNECTED) && b.inner[i] >= 0 && !(fl & (BF_FEATURE | BF_CORNER | BF_SHARP))) {
             const V3 pointNormal = ldv(s.layerNormal, p);
             if (pointNormal == v3(0, 0, 0)) s.acc->err = BND_ERR_NORMAL;
-            const V3 innerNeighCoord = ldv(s.ptsCur, b.inner[i]);   // updateNeighCoords OBB.C:464-500 (serial)
+            const V3 innerNeighCoord = cl ? v3(cl[7], cl[8], cl[9]) : ldv(s.ptsCur, b.inner[i]);   // updateNeighCoords OBB.C:464-500
             const V3 cCoords = np;
             const V3 neighVec = cCoords - innerNeighCoord;
             const double dotProd = dot(neighVec, pointNormal);
@@ -348,7 +374,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
         }
-        if (FINAL) {
+        if (FINAL && slot < 0) {
             if (frozen || !(m.pflags[p] & PF_SMOOTHSURF)) { np = cur; fcount = 1; }   // SM.C:2384-2392
             dist = mag(np - cur) / prm.maxStep;
             stv(s.ptsNext, p, np);

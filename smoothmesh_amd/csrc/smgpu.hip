@@ -135,6 +135,12 @@ struct smgpu_handle {
     hipStream_t bndSide = nullptr;   // k_bnd_normals / k_bnd_feature run next to the geometry kernel
     hipEvent_t evBndFork = nullptr, evBndJoin = nullptr;
     bool bndPreInFlight = false;
+    bool bndPending = false, bndNormalsFromLayers = false;   // step-wise set-up state
+    std::vector<double> bndPts, bndSurfPts;
+    std::vector<int32_t> bndSurfTris;
+    std::vector<uint8_t> bndFlags, bndInternal;
+    std::vector<BndPatch> bndPatches;
+    double bndBlend = 0.0;
     BndView bv{};
     BoundarySetup bs;
     std::vector<int32_t> layerHopsHost, layerMapHost;   // kept for the debug getters
@@ -639,6 +645,12 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
     hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
                        nTiles, h->xcdMap);
 }
+template <bool FINAL>
+static int launchBndFix(smgpu_handle* h, int partialBase) {
+    return launchK(h, K_BND, [&] {
+        hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(2 * (int64_t)h->bv.nB)), dim3(kBlock), 0, h->stream, h->mv, h->st, makePrm(h), h->bv, partialBase);
+    });
+}
 static int launchBndPre(smgpu_handle* h, const MeshView& m, const State& s, hipStream_t stream) {
     return launchK(h, K_BND, [&] {
         hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, stream, m, s, h->bv);
@@ -662,7 +674,8 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
     // boundary point smoothing: normals and feature edge projections of the current coordinates first (SM.C:2266,
     // BPS.C:866) -- started next to the geometry kernel by runBndPre when there is a side stream; after the smoothing
     // kernel k_bnd_fix finishes the boundary points it skipped
-    if (h->bndOn) {
+    const bool withBnd = h->bndOn && !h->haloOn;   // with a halo smgpu_iter_begin / smgpu_iter_mid place the boundary kernels
+    if (withBnd) {
         if (h->bndPreInFlight) {
             if (depWait(h, DEP_BND_JOIN, h->stream, h->evBndJoin)) return 1;
             h->bndPreInFlight = false;
@@ -677,7 +690,7 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
                 else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT);
             })) return 1;
     } else if (launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
-    if (h->bndOn) {
+    if (withBnd) {
         const int base = h->useTiles ? h->stl.nTiles : gridFor(m.nPoints);
         return launchK(h, K_BND, [&] { hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(2 * (int64_t)h->bv.nB)), dim3(kBlock), 0, h->stream, m, s, prm, h->bv, base); });
     }
@@ -936,6 +949,7 @@ static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
     if (forkFaFilter(h)) return 1;
     if (runSmooth<false>(h, h->mv, h->st, makePrm(h))) return 1;
+    if (h->bndOn && h->haloOn && launchBndFix<false>(h, 0)) return 1;
     return runConstraints(h);
 }
 // the constraint evaluators on the proposals left in prop / frozen (SM.C:2361-2371)
@@ -1272,7 +1286,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         h->nGeomInterior = (int)gi.size(); h->nGeomShared = (int)gs.size();
     }
     {   // partial slots: tiles (or point blocks) + the blocks of k_shared_fix
-        const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2;
+        const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2 * (size_t)gridFor(P) + 2;
         if (devAlloc(h, &h->st.blkMax, nPart) || devAlloc(h, &h->st.blkCnt, nPart)) return 1;
     }
     h->st.sharedSlot = h->dSharedSlot;
@@ -1308,13 +1322,15 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;
+    // boundary point smoothing: local normal sums and feature edge projections of the current coordinates (SM.C:2266, BPS.C:866)
+    if (h->bndOn && launchBndPre(h, m, s, h->stream)) return 1;
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
-                                   h->dSendOff, h->dSendSlots, h->sendA);
-                if (h->layersOn)            // local normals / outer neighbour coordinates (SM.C:2266, 2286)
+                                   h->dSendOff, h->dSendSlots, h->sendA, h->bndOn ? 1 : 0);
+                if (h->layersOn || h->bndOn)   // local normals / neighbour coordinates / feature projections (SM.C:2266, 2286, 2310-2330)
                     hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared,
-                                       h->dSendOff, h->dSendSlots, h->sendL);
+                                       h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
             })) return 1;
     return exchAfterCompute(h);             // sendA (and sendL) complete: the exchange may start
 }
@@ -1348,9 +1364,11 @@ int smgpu_iter_mid(smgpu_handle* h) {
                 const int nTwo = gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
                 hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
                                    h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
-                if (h->layersOn)
+                if (h->layersOn || h->bndOn)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                        h->dCombSlots, h->dOwnL, h->recvL, h->dCombL);
+                if (h->bndOn)   // OBB.C:201-230 for the shared boundary points, on the sums
+                    hipLaunchKernelGGL(k_bnd_normals_shared, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->bv, h->nShared, h->dSharedLocal);
             })) return 1;
     if (h->useTiles) {
         // the tiles with shared points only when the others have been done next to the exchange, otherwise all of them
@@ -1359,6 +1377,8 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (h->interiorDone && nList == 0) { /* every tile has been done */ }
         else if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, list, nList)) return 1; }
         else if (runSmooth<false>(h, h->mv, h->st, prm, list, nList)) return 1;
+        // the boundary points the smoothing kernels skipped; their partials follow the tiles' and the shared points' (k_shared_fix)
+        if (h->bndOn) { if (fused ? launchBndFix<true>(h, h->stl.nTiles + gridFor(h->nShared)) : launchBndFix<false>(h, 0)) return 1; }
         if (!fused && runConstraints(h)) return 1;
     } else if (runProposalAndConstraints(h)) return 1;
     if (h->nSend)
@@ -1400,7 +1420,7 @@ int smgpu_iter_end(smgpu_handle* h) {
                     hipLaunchKernelGGL(k_shared_fix, dim3(gS), dim3(kBlock), 0, h->stream, m, s, prm, h->nShared, h->dSharedLocal, h->dCombOff,
                                        h->dCombSlots, h->recvF, h->stl.nTiles);
                 })) return 1;
-        nPart = h->stl.nTiles + (h->nShared ? gS : 0);
+        nPart = h->stl.nTiles + (h->bndOn ? gridFor(h->nShared) + gridFor(2 * (int64_t)h->bv.nB) : (h->nShared ? gS : 0));
     } else {
         if (h->nShared && h->nRecv)
             if (launchK(h, K_HALO, [&] {
@@ -1527,26 +1547,59 @@ int smgpu_set_layers(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enable
 }
 
 // ---- optional boundary point smoothing ---------------------------------------------------------------------------
-int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info) {
+// ---- the set-up in steps (serial: smgpu_set_boundary_smoothing runs them back to back) ------------------------------
+// host copies the set-up works on
+static int bndFetchHost(smgpu_handle* h) {
+    const int P = h->topo.nPoints;
+    h->bndPts.resize(3 * (size_t)P);
+    HIP_OK(hipMemcpyAsync(h->bndPts.data(), h->st.ptsCur, sizeof(double) * h->bndPts.size(), hipMemcpyDeviceToHost, h->stream));
+    h->bndFlags.resize((size_t)P);
+    h->bndInternal.resize((size_t)P);
+    HIP_OK(hipMemcpyAsync(h->bndFlags.data(), h->mv.pflags, (size_t)P, hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    for (int p = 0; p < P; ++p) h->bndInternal[(size_t)p] = (h->bndFlags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
+    return 0;
+}
+
+int smgpu_boundary_stats(smgpu_handle* h, double* minEdgeLength, double* bb) {
+    if (!h || !minEdgeLength || !bb) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    if (bndFetchHost(h)) return 1;
+    const Topology& t = h->topo;
+    const std::vector<double>& pts = h->bndPts;
+    // getMeshStats SM.C:1478-1526: minimum edge length and the bounding box of the edge end points (min x, max x, min y, ...)
+    double shortest = 1.0e300;
+    for (int c = 0; c < 3; ++c) { bb[2 * c] = 1.0e300; bb[2 * c + 1] = -1.0e300; }
+    for (int e = 0; e < t.nEdges; ++e) {
+        const double* a = &pts[3 * (size_t)t.edges[2 * (size_t)e]];
+        const double* b = &pts[3 * (size_t)t.edges[2 * (size_t)e + 1]];
+        const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
+        const double len = std::sqrt(dx * dx + dy * dy + dz * dz);
+        if (len < shortest) shortest = len;
+        for (int c = 0; c < 3; ++c) {
+            if (a[c] < bb[2 * c]) bb[2 * c] = a[c];
+            if (a[c] > bb[2 * c + 1]) bb[2 * c + 1] = a[c];
+            if (b[c] < bb[2 * c]) bb[2 * c] = b[c];
+            if (b[c] > bb[2 * c + 1]) bb[2 * c + 1] = b[c];
+        }
+    }
+    *minEdgeLength = shortest;
+    return 0;
+}
+
+int smgpu_boundary_begin(smgpu_handle* h, const smgpu_boundary_desc* d, double minEdgeLengthGlobal, double perimeterGlobal,
+                         smgpu_boundary_info* info) {
     if (!h || !d) return fail("null argument");
-    if (h->haloOn) return fail("smgpu_set_boundary_smoothing: boundary point smoothing is a serial-run feature (no halo)");
     if (d->nPatches < 0 || (d->nPatches && (!d->patchStart || !d->patchSize || !d->patchKind || !d->isSmoothingPatch))) return fail("bad patch description");
     if ((d->nInitEdges && (!d->initEdges || !d->initEdgePoints)) || (d->nTargetEdges && (!d->targetEdges || !d->targetEdgePoints)) ||
         (d->nSurfaceTriangles && (!d->surfaceTriangles || !d->surfacePoints)))
-        return fail("smgpu_set_boundary_smoothing: null geometry array");
+        return fail("smgpu_boundary_begin: null geometry array");
     HIP_OK(hipSetDevice(h->device));
     const Topology& t = h->topo;
-    const MeshView& m = h->mv;
-    const int P = t.nPoints;
     h->bndOn = false;
+    h->bndPending = false;
     if (info) std::memset(info, 0, sizeof(*info));
-
-    std::vector<double> pts(3 * (size_t)P);
-    HIP_OK(hipMemcpyAsync(pts.data(), h->st.ptsCur, sizeof(double) * pts.size(), hipMemcpyDeviceToHost, h->stream));
-    std::vector<uint8_t> pflags((size_t)P), internal((size_t)P);
-    HIP_OK(hipMemcpyAsync(pflags.data(), m.pflags, (size_t)P, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-    for (int p = 0; p < P; ++p) internal[(size_t)p] = (pflags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
+    if (bndFetchHost(h)) return 1;
 
     BoundaryInputHost in;
     auto fillEdges = [](EdgeMeshHost& em, int nP, const double* ep, int nE, const int32_t* e) {
@@ -1555,35 +1608,23 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
     };
     fillEdges(in.initEdges, d->nInitEdgePoints, d->initEdgePoints, d->nInitEdges, d->initEdges);
     fillEdges(in.targetEdges, d->nTargetEdgePoints, d->targetEdgePoints, d->nTargetEdges, d->targetEdges);
+    h->bndSurfPts.clear(); h->bndSurfTris.clear();
     if (d->nSurfaceTriangles > 0) {
-        in.surfPts.assign(d->surfacePoints, d->surfacePoints + 3 * (size_t)d->nSurfacePoints);
-        in.surfTris.assign(d->surfaceTriangles, d->surfaceTriangles + 3 * (size_t)d->nSurfaceTriangles);
+        h->bndSurfPts.assign(d->surfacePoints, d->surfacePoints + 3 * (size_t)d->nSurfacePoints);
+        h->bndSurfTris.assign(d->surfaceTriangles, d->surfaceTriangles + 3 * (size_t)d->nSurfaceTriangles);
     }
+    in.surfPts = h->bndSurfPts;
+    in.surfTris = h->bndSurfTris;
     in.isCornerPointIO = d->isCornerPointIO;
     in.isFeatureEdgePointIO = d->isFeatureEdgePointIO;
     in.distanceTolerance = d->distanceTolerance;
-    {   // getMeshStats SM.C:1478-1541: minimum edge length and the "perimeter" of the bounding box of the edge end points
-        double shortest = 1.0e300, lo[3] = {1.0e300, 1.0e300, 1.0e300}, hi[3] = {-1.0e300, -1.0e300, -1.0e300};
-        for (int e = 0; e < t.nEdges; ++e) {
-            const double* a = &pts[3 * (size_t)t.edges[2 * (size_t)e]];
-            const double* b = &pts[3 * (size_t)t.edges[2 * (size_t)e + 1]];
-            const double dx = b[0] - a[0], dy = b[1] - a[1], dz = b[2] - a[2];
-            const double len = std::sqrt(dx * dx + dy * dy + dz * dz);
-            if (len < shortest) shortest = len;
-            for (int c = 0; c < 3; ++c) {
-                if (a[c] < lo[c]) lo[c] = a[c];
-                if (a[c] > hi[c]) hi[c] = a[c];
-                if (b[c] < lo[c]) lo[c] = b[c];
-                if (b[c] > hi[c]) hi[c] = b[c];
-            }
-        }
-        in.meshMinEdgeLength = shortest;
-        in.meshPerimeter = hi[0] - lo[0] + hi[1] - lo[1] + hi[2] + lo[2];   // SM.C:1538
-    }
-    std::vector<BndPatch> patches((size_t)d->nPatches);
-    for (int i = 0; i < d->nPatches; ++i) patches[(size_t)i] = BndPatch{d->patchStart[i], d->patchSize[i], (int32_t)d->patchKind[i], d->isSmoothingPatch[i] != 0};
+    in.meshMinEdgeLength = minEdgeLengthGlobal;
+    in.meshPerimeter = perimeterGlobal;
+    h->bndPatches.assign((size_t)d->nPatches, BndPatch{});
+    for (int i = 0; i < d->nPatches; ++i) h->bndPatches[(size_t)i] = BndPatch{d->patchStart[i], d->patchSize[i], (int32_t)d->patchKind[i], d->isSmoothingPatch[i] != 0};
+    h->bndBlend = d->internalSmoothingBlendingFraction;
     BoundarySetup& bs = h->bs;
-    const std::string err = buildBoundarySetup(t, internal.data(), pts.data(), patches, in, bs);
+    const std::string err = buildBoundarySetup(t, h->bndInternal.data(), h->bndPts.data(), h->bndPatches, in, bs);
     if (!err.empty()) return fail(err);
     if (info) {
         info->enabled = bs.enabled ? 1 : 0;
@@ -1593,9 +1634,19 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         for (int32_t v : bs.targetEdgeStrings) mx = std::max(mx, (int)v);
         info->nTargetEdgeStrings = mx + 1;
     }
-    if (!bs.enabled) return 0;
+    h->bndPending = bs.enabled;
+    return 0;
+}
 
-    // device tables over the boundary (non-internal) points
+// device tables over the boundary (non-internal) points; needs the final hop counts
+static int bndTables(smgpu_handle* h) {
+    const Topology& t = h->topo;
+    const MeshView& m = h->mv;
+    const int P = t.nPoints;
+    BoundarySetup& bs = h->bs;
+    const std::string err = boundarySetupFinish(t, h->bndPts.data(), bs);
+    if (!err.empty()) return fail(err);
+    const std::vector<uint8_t>& internal = h->bndInternal;
     std::vector<int> bpts, inner, featPts, featString, featOfBnd, bfOff(1, 0), bfVal;
     std::vector<uint8_t> flags, ptClass((size_t)P, 0);
     std::vector<double> corner;
@@ -1619,7 +1670,7 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
     const int nB = (int)bpts.size();
     {   // boundary faces per boundary point on ordinary patches (OBB.C:156-159), ascending face id = the reference's order
         std::vector<std::vector<int>> bf((size_t)nB);
-        for (const BndPatch& pp : patches) {
+        for (const BndPatch& pp : h->bndPatches) {
             if (pp.kind != 0) continue;
             for (int f = pp.start; f < pp.start + pp.size; ++f)
                 for (int k = t.facePoints.off[f]; k < t.facePoints.off[f + 1]; ++k) {
@@ -1634,7 +1685,7 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         }
     }
     Bvh bvh;
-    bvh.build(in.surfPts, in.surfTris);
+    bvh.build(h->bndSurfPts, h->bndSurfTris);
     if (7 * bvh.wideDepth + 1 > kBvhStack) return fail("boundary set-up: the target surface's hierarchy is deeper than the traversal stack");
     BndView& v = h->bv;
     v = BndView{};
@@ -1669,23 +1720,31 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
         v.strOff = dSo; v.strEdges = dSe;
     }
     v.nNodes = (int)(bvh.wideRef.size() / 16); v.wideBox = dBox; v.wideRef = dRef; v.triVerts = dTri;
-    v.distanceTolerance = d->distanceTolerance;
-    v.internalBlend = d->internalSmoothingBlendingFraction;
+    v.distanceTolerance = bs.distanceTolerance;
+    v.internalBlend = h->bndBlend;
     // isSmoothingSurfacePoint is this classification's from now on (BPS.C:404-412)
     for (int p = 0; p < P; ++p) {
-        pflags[(size_t)p] &= (uint8_t)~PF_SMOOTHSURF;
-        if (bs.isSmoothingSurfacePoint[(size_t)p]) pflags[(size_t)p] |= PF_SMOOTHSURF;
+        h->bndFlags[(size_t)p] &= (uint8_t)~PF_SMOOTHSURF;
+        if (bs.isSmoothingSurfacePoint[(size_t)p]) h->bndFlags[(size_t)p] |= PF_SMOOTHSURF;
     }
-    HIP_OK(hipMemcpy(const_cast<uint8_t*>(m.pflags), pflags.data(), (size_t)P, hipMemcpyHostToDevice));
-    // SM.C:2219: the first calculateBoundaryPointNormals (done by the layer set-up when that ran)
+    HIP_OK(hipMemcpy(const_cast<uint8_t*>(m.pflags), h->bndFlags.data(), (size_t)P, hipMemcpyHostToDevice));
+    if (h->haloOn) {   // shared points: their place in the boundary tables, and the exchange-L staging buffers
+        std::vector<int> bos(h->sharedLocalHost.size() + 1, -1);
+        for (size_t i = 0; i < h->sharedLocalHost.size(); ++i) bos[i] = bndOf[(size_t)h->sharedLocalHost[i]];
+        const int* dBos = nullptr;
+        if (devUpload(h, &dBos, bos)) return 1;
+        h->st.bndOfShared = dBos;
+        if (h->nSend && (!h->sendL || !h->recvL)) return fail("boundary point smoothing with a halo needs smgpu_halo_desc.sendL / recvL");
+        if (!h->dOwnL && devAlloc(h, &h->dOwnL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
+        if (!h->dCombL && devAlloc(h, &h->dCombL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
+        h->st.combL = h->dCombL;
+    }
+    h->bndNormalsFromLayers = h->st.layerNormal != nullptr;   // SM.C:2219 is done by the layer set-up when that ran
     if (!h->st.layerNormal) {
         if (devAlloc(h, &h->st.layerNormal, 3 * (size_t)P)) return 1;
         HIP_OK(hipMemsetAsync(h->st.layerNormal, 0, sizeof(double) * 3 * (size_t)P, h->stream));
-        HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
-        hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(nB)), dim3(kBlock), 0, h->stream, m, h->st, v);
-        HIP_OK(hipStreamSynchronize(h->stream));
     }
-    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", 1)) {
+    if (!h->bndSide && !h->haloOn && envInt("SMGPU_SIDE_STREAM", 1)) {
         if (depInit(h)) return 1;
         if (hipStreamCreateWithFlags(&h->bndSide, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->evBndFork, hipEventDisableTiming) != hipSuccess ||
@@ -1693,7 +1752,87 @@ int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, 
             return fail("side stream creation failed");
     }
     h->bndOn = true;
+    h->bndPending = false;
+    h->bndPts.clear(); h->bndPts.shrink_to_fit();
+    h->bndSurfPts.clear(); h->bndSurfPts.shrink_to_fit();
+    h->bndSurfTris.clear(); h->bndSurfTris.shrink_to_fit();
     return 0;
+}
+
+int smgpu_boundary_step(smgpu_handle* h, int32_t step) {
+    if (!h) return fail("null handle");
+    HIP_OK(hipSetDevice(h->device));
+    const MeshView& m = h->mv;
+    switch (step) {
+    case SMGPU_BOUNDARY_HOPS_SWEEP:
+        if (!h->bndPending) return fail("smgpu_boundary_step: no set-up in progress (smgpu_boundary_begin, enabled)");
+        boundarySetupHopsSweep(h->topo, h->bndInternal.data(), h->bs);
+        return 0;
+    case SMGPU_BOUNDARY_TABLES:
+        if (!h->bndPending) return fail("smgpu_boundary_step: no set-up in progress (smgpu_boundary_begin, enabled)");
+        return bndTables(h);
+    case SMGPU_BOUNDARY_NORMALS_ACCUMULATE:   // SM.C:2219 (first calculateBoundaryPointNormals), local part
+        if (!h->bndOn) return fail("smgpu_boundary_step: the tables step comes first");
+        if (h->bndNormalsFromLayers) return 0;
+        HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
+        hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, h->st, h->bv);
+        HIP_OK(hipStreamSynchronize(h->stream));
+        return 0;
+    case SMGPU_BOUNDARY_NORMALS_FINISH:       // shared points, after the host has set the sums
+        if (!h->bndOn) return fail("smgpu_boundary_step: the tables step comes first");
+        if (h->bndNormalsFromLayers || !h->haloOn || !h->nShared) return 0;
+        hipLaunchKernelGGL(k_bnd_normals_shared, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->bv, h->nShared, h->dSharedLocal);
+        HIP_OK(hipStreamSynchronize(h->stream));
+        return 0;
+    default: return fail("smgpu_boundary_step: unknown step");
+    }
+}
+
+int smgpu_boundary_shared(smgpu_handle* h, int32_t field, int32_t set, double* v) {
+    if (!h || !v) return fail("null argument");
+    if (!h->haloOn) return fail("smgpu_boundary_shared: halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    const std::vector<int>& sl = h->sharedLocalHost;
+    const size_t n = sl.size();
+    if (field == SMGPU_BOUNDARY_F_HOPS) {
+        if (!h->bndPending) return fail("smgpu_boundary_shared: no set-up in progress");
+        std::vector<int32_t>& hops = h->bs.hopsToSmoothingBoundary;
+        for (size_t i = 0; i < n; ++i) { if (set) hops[(size_t)sl[i]] = (int32_t)v[i]; else v[i] = hops[(size_t)sl[i]]; }
+        return 0;
+    }
+    if (field == SMGPU_BOUNDARY_F_NORMALS_COUNT) {   // 4 doubles: the local normal sum and the local boundary face count
+        if (!h->bndOn) return fail("smgpu_boundary_shared: the tables step comes first");
+        if (n == 0) return 0;
+        std::vector<double> rec(n * SMGPU_HALO_L_DOUBLES, 0.0);
+        if (!set) {
+            // pack through the exchange kernel: the same values an iteration would send
+            hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->dSharedLocal, h->dOwnL, h->nShared,
+                               h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
+            HIP_OK(hipMemcpyAsync(rec.data(), h->dOwnL, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) v[4 * i + c] = rec[i * SMGPU_HALO_L_DOUBLES + c]; v[4 * i + 3] = rec[i * SMGPU_HALO_L_DOUBLES + 6]; }
+        } else {
+            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) rec[i * SMGPU_HALO_L_DOUBLES + c] = v[4 * i + c]; rec[i * SMGPU_HALO_L_DOUBLES + 6] = v[4 * i + 3]; }
+            HIP_OK(hipMemcpyAsync(h->dCombL, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, h->stream));
+            HIP_OK(hipStreamSynchronize(h->stream));
+        }
+        return 0;
+    }
+    return fail("smgpu_boundary_shared: unknown field");
+}
+
+int smgpu_set_boundary_smoothing(smgpu_handle* h, const smgpu_boundary_desc* d, smgpu_boundary_info* info) {
+    if (!h || !d) return fail("null argument");
+    if (h->haloOn) return fail("smgpu_set_boundary_smoothing is the serial set-up; with a halo use smgpu_boundary_stats / begin / step / shared");
+    double minEdge = 0.0, bb[6];
+    if (smgpu_boundary_stats(h, &minEdge, bb)) return 1;
+    smgpu_boundary_info bi{};
+    if (smgpu_boundary_begin(h, d, minEdge, bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4] /* SM.C:1538 */, &bi)) return 1;
+    if (info) *info = bi;
+    if (!bi.enabled) return 0;
+    for (int i = 0; i < 2; ++i) if (smgpu_boundary_step(h, SMGPU_BOUNDARY_HOPS_SWEEP)) return 1;   // SM.C:2218
+    if (smgpu_boundary_step(h, SMGPU_BOUNDARY_TABLES)) return 1;
+    return smgpu_boundary_step(h, SMGPU_BOUNDARY_NORMALS_ACCUMULATE);
 }
 
 int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, int32_t* isFeatureEdgePoint) {

@@ -238,13 +238,11 @@ class SmoothEngine:
         self._check(self._lib.smgpu_set_layers(self._h, C.byref(d), C.byref(on)))
         return bool(on.value)
 
-    def set_boundary_smoothing(self, bp: "BoundaryParams", minEdgeLength: float, layerEdgeLength=None):
-        """Enable the boundary point smoothing (serial runs; after set_layers when both are used).  minEdgeLength is
-        the -minEdgeLength option value (the default of layerEdgeLength, SM.C:1895).  Returns a dict with the
-        reference's doBoundarySmoothing ("enabled") and the classification summary (BPS.C:423-438)."""
+    def _boundary_desc(self, bp: "BoundaryParams", minEdgeLength: float, layerEdgeLength=None, meshMinEdgeLength=None):
         REL_TOL = 1e-4                                                     # COM.H:20
         lel = minEdgeLength if layerEdgeLength is None else layerEdgeLength
-        tol = REL_TOL * min(self.mesh_stats()[0], lel)                     # SM.C:1921
+        mn = self.mesh_stats()[0] if meshMinEdgeLength is None else meshMinEdgeLength
+        tol = REL_TOL * min(mn, lel)                                       # SM.C:1921
         start, size, kind, sel = patch_arrays(self.mesh, bp.smoothingPatches)
         def pe(m, w):
             if m is None:
@@ -264,9 +262,47 @@ class SmoothEngine:
         d.isFeatureEdgePointIO = None if fio is None else _p(fio, _ffi.c_i32p)
         d.distanceTolerance = tol
         d.internalSmoothingBlendingFraction = bp.internalSmoothingBlendingFraction
+        return d, (start, size, kind, sel, ip, ie, tp, te, sp, st, cio, fio)
+
+    def set_boundary_smoothing(self, bp: "BoundaryParams", minEdgeLength: float, layerEdgeLength=None):
+        """Enable the boundary point smoothing (serial runs; after set_layers when both are used).  minEdgeLength is
+        the -minEdgeLength option value (the default of layerEdgeLength, SM.C:1895).  Returns a dict with the
+        reference's doBoundarySmoothing ("enabled") and the classification summary (BPS.C:423-438)."""
+        d, keep = self._boundary_desc(bp, minEdgeLength, layerEdgeLength)
         info = _ffi.BoundaryInfo()
         self._check(self._lib.smgpu_set_boundary_smoothing(self._h, C.byref(d), C.byref(info)))
         return {k: getattr(info, k) for k, _ in _ffi.BoundaryInfo._fields_}
+
+    # step-wise set-up for runs with a halo (see include/smgpu.h, smgpu_boundary_begin)
+    BOUNDARY_HOPS_SWEEP, BOUNDARY_TABLES, BOUNDARY_NORMALS_ACCUMULATE, BOUNDARY_NORMALS_FINISH = range(4)
+    BOUNDARY_F_HOPS, BOUNDARY_F_NORMALS_COUNT = range(2)
+    _BOUNDARY_FIELD_WIDTH = (1, 4)
+
+    def boundary_stats(self):
+        """(minimum edge length, bounding box [min x, max x, min y, max y, min z, max z]) of this rank (SM.C:1478-1526)"""
+        mn, bb = C.c_double(0), np.zeros(6, np.float64)
+        self._check(self._lib.smgpu_boundary_stats(self._h, C.byref(mn), _p(bb, _ffi.c_f64p)))
+        return mn.value, bb
+
+    def boundary_begin(self, bp, minEdgeLength, minEdgeGlobal, perimeterGlobal, layerEdgeLength=None):
+        d, keep = self._boundary_desc(bp, minEdgeLength, layerEdgeLength, meshMinEdgeLength=minEdgeGlobal)
+        info = _ffi.BoundaryInfo()
+        self._check(self._lib.smgpu_boundary_begin(self._h, C.byref(d), float(minEdgeGlobal), float(perimeterGlobal), C.byref(info)))
+        return {k: getattr(info, k) for k, _ in _ffi.BoundaryInfo._fields_}
+
+    def boundary_step(self, step):
+        self._check(self._lib.smgpu_boundary_step(self._h, int(step)))
+
+    def boundary_shared_get(self, field):
+        v = np.zeros((self._nShared, self._BOUNDARY_FIELD_WIDTH[field]), np.float64)
+        if self._nShared:
+            self._check(self._lib.smgpu_boundary_shared(self._h, int(field), 0, _p(v, _ffi.c_f64p)))
+        return v
+
+    def boundary_shared_set(self, field, values):
+        v = np.ascontiguousarray(values, np.float64).reshape(self._nShared, self._BOUNDARY_FIELD_WIDTH[field])
+        if self._nShared:
+            self._check(self._lib.smgpu_boundary_shared(self._h, int(field), 1, _p(v, _ffi.c_f64p)))
 
     def boundary_classification(self):
         """(isCornerPoint, isFeatureEdgePoint) as the labelIOLists the reference writes (SM.C:2039-2064)."""

@@ -13,7 +13,7 @@ all_gather of {residual, nFrozenPoints}.  No collective touches non-shared data.
 import numpy as np
 
 A_DOUBLES = 13  # SMGPU_HALO_A_DOUBLES
-L_DOUBLES = 6   # SMGPU_HALO_L_DOUBLES (boundary layer treatment: local normal + outer neighbour coordinates)
+L_DOUBLES = 14  # SMGPU_HALO_L_DOUBLES (layer treatment / boundary point smoothing record, layout in include/smgpu.h)
 
 
 class HaloTables:
@@ -133,6 +133,37 @@ def setup_layers_stepwise(engines, exchange, lp, minEdgeLength):
     for e in engines:
         e.layers_step(E.LAYERS_FINISH)
     return True
+
+
+def setup_boundary_stepwise(engines, exchange, reduce_stats, bp, minEdgeLength, layerEdgeLength=None):
+    """The reference's boundary point smoothing set-up under -parallel (SM.C:2080-2253) on `engines` (this process's ranks):
+    `reduce_stats(list of (minEdge, bb)) -> (minEdge, bb)` over ALL ranks (returnReduce, SM.C:1528-1535), `exchange` as in
+    setup_layers_stepwise.  Returns the list of classification summaries (one per engine)."""
+    E = type(engines[0])
+    mn, bb = reduce_stats([e.boundary_stats() for e in engines])
+    perimeter = bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4]              # SM.C:1538, "+ bbMinZ" as written
+    infos = [e.boundary_begin(bp, minEdgeLength, mn, perimeter, layerEdgeLength) for e in engines]
+    assert all(i["enabled"] == infos[0]["enabled"] for i in infos)
+    if not infos[0]["enabled"]:
+        return infos
+
+    def sync(field, op):
+        own = [e.boundary_shared_get(field) for e in engines]
+        for e, c in zip(engines, exchange(own, op)):
+            e.boundary_shared_set(field, c)
+
+    for _ in range(2):                                                      # SM.C:2218
+        for e in engines:
+            e.boundary_step(E.BOUNDARY_HOPS_SWEEP)
+        sync(E.BOUNDARY_F_HOPS, "max")                                      # OBB.C:124-130
+    for e in engines:
+        e.boundary_step(E.BOUNDARY_TABLES)
+    for e in engines:
+        e.boundary_step(E.BOUNDARY_NORMALS_ACCUMULATE)
+    sync(E.BOUNDARY_F_NORMALS_COUNT, "sum")                                 # OBB.C:184-198
+    for e in engines:
+        e.boundary_step(E.BOUNDARY_NORMALS_FINISH)
+    return infos
 
 
 class _RankState:
@@ -418,6 +449,21 @@ class LocalMultiSmoother:
         self.layers = setup_layers_stepwise([st.eng for st in self.states], exchange, lp, minEdgeLength)
         return self.layers
 
+    def set_boundary_smoothing(self, bp, minEdgeLength, layerEdgeLength=None):
+        """boundary point smoothing on all sub-domains (the reference under mpirun with constant/geometry/*.obj); after
+        set_layers when both are used"""
+        def exchange(own, op):
+            recv = [np.zeros((st.t.nRecv, own[0].shape[1])) for st in self.states]
+            for a, so, b, do, c in self.copies:
+                recv[b][do:do + c] = own[a][self.states[a].t.sendShared[so:so + c]]
+            return [combine_shared(st.t, o, r, op) for st, o, r in zip(self.states, own, recv)]
+        def reduce_stats(stats):
+            bb = np.array([s[1] for s in stats])
+            return min(s[0] for s in stats), np.array([bb[:, 0].min(), bb[:, 1].max(), bb[:, 2].min(), bb[:, 3].max(), bb[:, 4].min(), bb[:, 5].max()])
+        infos = setup_boundary_stepwise([st.eng for st in self.states], exchange, reduce_stats, bp, minEdgeLength, layerEdgeLength)
+        self.boundary = bool(infos[0]["enabled"])
+        return infos
+
     def iterate(self, centroidalIters, relTol=0.02):
         res, frz = [], []
         for i in range(centroidalIters):
@@ -426,7 +472,7 @@ class LocalMultiSmoother:
             for st in self.states:
                 st.eng.iter_interior()
             self._exchange("A")
-            if getattr(self, "layers", False):
+            if getattr(self, "layers", False) or getattr(self, "boundary", False):
                 self._exchange("L")
             for st in self.states:
                 st.eng.iter_mid()

@@ -72,7 +72,7 @@ int main(int argc, char** argv) {
         std::vector<smgpu::BndPatch> bp;
         for (const smhost::PatchInfo& p : m.patches) bp.push_back({p.startFace, p.nFaces, 0, true});
         smgpu::BoundarySetup bs;
-        err = smgpu::buildBoundarySetup(t, internal.data(), m.points.data(), bp, in, bs);
+        err = smgpu::buildBoundarySetupSerial(t, internal.data(), m.points.data(), bp, in, bs);
         if (!err.empty()) { std::fprintf(stderr, "boundary: %s\n", err.c_str()); return 1; }
         if (!bs.enabled || bs.nSmoothingSurface == 0) { std::fprintf(stderr, "boundary: not enabled\n"); return 1; }
         std::vector<double> sp;

@@ -201,3 +201,34 @@ def test_golden_fixture_boundary_hip(oracle_lib):
         assert rel_linf(e.get_points(), g["points" + tag]) <= 1e-13
     assert np.array_equal(np.concatenate(frz_all), g["nFrozen"])
     assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-10, atol=0)
+
+
+@pytest.mark.parametrize("grid,constraints,layers", [((2, 1, 1), False, False), ((2, 2, 1), True, False), ((2, 2, 2), False, True),
+                                                      ((1, 2, 2), True, True)])
+def test_decomposed_boundary_smoothing(oracle_lib, grid, constraints, layers):
+    """-parallel: every engine holds one sub-domain; the set-up runs in steps with the reference's reductions and syncs
+    between them, the per-iteration fields travel in the L records.  Bit-equal to the oracle's MultiDomain."""
+    from smoothmesh_amd import BoundaryParams, LayerParams, patch_arrays
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface
+    from test_oracle_boundary import _multi_boundary_case
+    lpatches = ("xmin", "zmax") if layers else ()
+    mo, orcs, subs, (off, dom, loc), hi = _multi_boundary_case(oracle_lib, grid, (5, 4, 6), 0.25, constraints, blend=0.4, layerPatches=lpatches)
+    prm = mo.params
+    ms = LocalMultiSmoother(subs, device=0)
+    ms.set_params(prm)
+    if layers:
+        assert ms.set_layers(LayerParams(layerPatches=lpatches), prm.minEdgeLength)
+    bp = BoundaryParams(initEdges=box_feature_edges(8, hi=hi), targetSurfaces=box_surface(4, hi=hi), internalSmoothingBlendingFraction=0.4)
+    infos = ms.set_boundary_smoothing(bp, prm.minEdgeLength)
+    assert all(i["enabled"] for i in infos)
+    for o, i in zip(orcs, infos):
+        f = o.boundary_fields()
+        assert i["nCornerPoints"] == f["isCornerPoint"].sum() and i["nFeatureEdgePoints"] == f["isFeatureEdgePoint"].sum()
+        assert i["nSmoothingSurfacePoints"] == f["isSmoothingSurfacePoint"].sum()
+    n_o, res_o, frz_o = mo.iterate(8, 0.0)
+    n_g, res_g, frz_g = ms.iterate(8, 0.0)
+    assert n_o == n_g and np.array_equal(frz_o, frz_g)
+    assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
+    for o, p in zip(orcs, ms.get_points()):
+        assert rel_linf(p, o.points()) <= 1e-13

@@ -258,7 +258,7 @@ def test_golden_fixture_boundary(oracle_lib):
     assert np.allclose(np.concatenate(res_all), g["residual"], rtol=1e-12, atol=0)
 
 
-def _multi_boundary_case(oracle_lib, grid, nloc, jitter, constraints, blend=0.3, seed=3):
+def _multi_boundary_case(oracle_lib, grid, nloc, jitter, constraints, blend=0.3, seed=3, layerPatches=()):
     from smoothmesh_amd import default_params, patch_arrays
     from smoothmesh_amd.decompose import shared_point_table
     from smoothmesh_amd.meshgen import hex_subdomain
@@ -272,9 +272,10 @@ def _multi_boundary_case(oracle_lib, grid, nloc, jitter, constraints, blend=0.3,
         o.set_params(prm)
     off, dom, loc = shared_point_table(subs)
     mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
-    pa = [patch_arrays(s.mesh, ()) + (patch_arrays(s.mesh, ('".*"',))[3],) for s in subs]
+    pa = [patch_arrays(s.mesh, layerPatches) + (patch_arrays(s.mesh, ('".*"',))[3],) for s in subs]
     on = mo.setup_boundary(pa, (0.3, prm.minEdgeLength, 1.3, 1, 4), box_feature_edges(8, hi=hi), None, box_surface(4, hi=hi), blend)
     assert on
+    mo.params = prm
     return mo, orcs, subs, (off, dom, loc), hi
 
 
