@@ -5,8 +5,7 @@
 // This host is standalone (own option parser, own polyMesh I/O) because OpenFOAM is not available
 // in the build environment; INTEGRATION.md shows the OpenFOAM-linked variant of the same calls.
 // Boundary layer treatment (-layerPatches ..., orthogonalBoundaryBlending.C) is available, serial and -parallel;
-// boundary point smoothing (constant/geometry/*.obj, boundaryPointSmoothing.C) in serial runs.
-// (under -parallel asking for it is an error, not a silent skip).
+// boundary point smoothing (constant/geometry/*.obj, boundaryPointSmoothing.C), both serial and -parallel.
 //
 //   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
 //
@@ -94,7 +93,7 @@ Options parseArgs(int argc, char** argv) {
                       "       [-layerPatches '(p1 \"re.*\")' -layerMaxBlendingFraction x -layerEdgeLength x -layerExpansionRatio x\n"
                       "        -minLayers n -maxLayers n]\n"
                       "       [-smoothingPatches '(p1 \"re.*\")' -internalSmoothingBlendingFraction x]   (boundary point smoothing, with\n"
-                      "        constant/geometry/targetSurfaces.obj + initEdges.obj [+ targetEdges.obj]; serial runs)\n"
+                      "        constant/geometry/targetSurfaces.obj + initEdges.obj [+ targetEdges.obj])\n"
                       "Move internal mesh points to increase mesh quality (MI355X engine)");
             std::exit(0);
         }
@@ -395,18 +394,18 @@ int main(int argc, char** argv) {
 
     // classification lists of a previous run (labelIOLists <time>/isCornerPoint, <time>/isFeatureEdgePoint, SM.C:2039-2077)
     const std::string startName = startIsConstant ? std::string("constant") : timeName(startValue);
-    std::vector<int32_t> isCornerPointIO, isFeatureEdgePointIO;
+    std::vector<std::vector<int32_t>> isCornerPointIO(R.size()), isFeatureEdgePointIO(R.size());   // per sub-domain
     bool labelIOListsHaveData = false;
-    if (!opt.parallel) {
+    for (size_t r = 0; r < R.size(); ++r) {
         auto readIfPresent = [&](const std::string& name, std::vector<int32_t>& out) {
-            const std::string f = cd + "/" + startName + "/" + name;
+            const std::string f = R[r].root + "/" + startName + "/" + name;
             if (!fileExists(f) && !fileExists(f + ".gz")) return;
             try { readLabelList(f, out); } catch (const std::exception& e) { fatal(e.what()); }
-            if ((int32_t)out.size() != R[0].mesh.nPoints()) fatal(f + ": size does not match the number of points");
+            if ((int32_t)out.size() != R[r].mesh.nPoints()) fatal(f + ": size does not match the number of points");
             for (int32_t v : out) labelIOListsHaveData = labelIOListsHaveData || v == 1;
         };
-        readIfPresent("isCornerPoint", isCornerPointIO);
-        readIfPresent("isFeatureEdgePoint", isFeatureEdgePointIO);
+        readIfPresent("isCornerPoint", isCornerPointIO[r]);
+        readIfPresent("isFeatureEdgePoint", isFeatureEdgePointIO[r]);
     }
     if (labelIOListsHaveData) std::puts("Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
     else std::puts("Did not find corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
@@ -416,9 +415,6 @@ int main(int argc, char** argv) {
                       targetEdgesFile = "constant/geometry/targetEdges.obj";
     const bool doBoundarySmoothing = fileExists(cd + "/" + targetSurfacesFile) && (fileExists(cd + "/" + initEdgesFile) || labelIOListsHaveData) &&
                                      anySmoothingPatch;
-    if (doBoundarySmoothing && opt.parallel)
-        fatal("boundary point smoothing (constant/geometry/targetSurfaces.obj is present) is not available under -parallel in this build: "
-              "run the case serially, or pass -smoothingPatches '()' to smooth the internal points only");
     if (doBoundarySmoothing) std::puts("Enabled boundary point smoothing\n");
     else std::printf("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\n%s\n%s\n\n", targetSurfacesFile.c_str(), initEdgesFile.c_str());
     if (doLayerTreatment && !doBoundarySmoothing)   // SM.C:2095-2098
@@ -511,6 +507,41 @@ int main(int argc, char** argv) {
         }
     }
 
+    // -parallel: the reference's syncPointList calls of the set-ups are done here over the shared points (all sub-domains live
+    // in this process); sharers of a global point in ascending rank order
+    std::map<int64_t, std::vector<std::pair<int, int>>> sharers;   // global id -> (rank, index in the rank's shared list)
+    if (opt.parallel)
+        for (int r = 0; r < nRanks; ++r)
+            for (size_t i = 0; i < R[r].sharedGlobal.size(); ++i) sharers[R[r].sharedGlobal[i]].push_back({r, (int)i});
+    typedef int (*SharedFn)(smgpu_handle*, int32_t, int32_t, double*);
+    auto syncShared = [&](SharedFn fn, const char* what, int field, int width, int op) {   // op 0 max, 1 sum (ascending rank), 2 larger magnitude folded onto own
+        std::vector<std::vector<double>> v(R.size());
+        for (int r = 0; r < nRanks; ++r) {
+            v[r].assign(std::max<size_t>(R[r].sharedGlobal.size(), 1) * width, 0.0);
+            if (!R[r].sharedGlobal.empty()) check(fn(R[r].h, field, 0, v[r].data()), what);
+        }
+        const std::vector<std::vector<double>> sent(v);
+        for (const auto& kv : sharers) {
+            const auto& sh = kv.second;
+            for (const auto& me : sh) {
+                double* x = &v[me.first][(size_t)me.second * width];
+                if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
+                for (const auto& ot : sh) {
+                    const double* y = &sent[ot.first][(size_t)ot.second * width];
+                    if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
+                    if (ot.first == me.first) continue;
+                    if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
+                    else {
+                        const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+                        if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
+                    }
+                }
+            }
+        }
+        for (int r = 0; r < nRanks; ++r)
+            if (!R[r].sharedGlobal.empty()) check(fn(R[r].h, field, 1, v[r].data()), what);
+    };
+
     if (doLayerTreatment) {   // set-up SM.C:2215-2221 on the engines' side
         std::vector<std::vector<int32_t>> pStart(R.size()), pSize(R.size());
         std::vector<std::vector<uint8_t>> pKind(R.size());
@@ -531,38 +562,7 @@ int main(int argc, char** argv) {
         int32_t on = 0, maxIter = 0;
         if (!opt.parallel) check(smgpu_set_layers(R[0].h, &ld[0], &on), "smgpu_set_layers");
         else {
-            // step-wise, with the reference's syncPointList calls done here over the shared points (all sub-domains live in
-            // this process): sharers of a global point in ascending rank order
-            std::map<int64_t, std::vector<std::pair<int, int>>> sharers;   // global id -> (rank, index in the rank's shared list)
-            for (int r = 0; r < nRanks; ++r)
-                for (size_t i = 0; i < R[r].sharedGlobal.size(); ++i) sharers[R[r].sharedGlobal[i]].push_back({r, (int)i});
-            auto sync = [&](int field, int width, int op) {   // op 0 max, 1 sum (ascending rank), 2 larger magnitude folded onto own
-                std::vector<std::vector<double>> v(R.size());
-                for (int r = 0; r < nRanks; ++r) {
-                    v[r].assign(std::max<size_t>(R[r].sharedGlobal.size(), 1) * width, 0.0);
-                    if (!R[r].sharedGlobal.empty()) check(smgpu_layers_shared(R[r].h, field, 0, v[r].data()), "smgpu_layers_shared");
-                }
-                const std::vector<std::vector<double>> sent(v);
-                for (const auto& kv : sharers) {
-                    const auto& sh = kv.second;
-                    for (const auto& me : sh) {
-                        double* x = &v[me.first][(size_t)me.second * width];
-                        if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
-                        for (const auto& ot : sh) {
-                            const double* y = &sent[ot.first][(size_t)ot.second * width];
-                            if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
-                            if (ot.first == me.first) continue;
-                            if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
-                            else {
-                                const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
-                                if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
-                            }
-                        }
-                    }
-                }
-                for (int r = 0; r < nRanks; ++r)
-                    if (!R[r].sharedGlobal.empty()) check(smgpu_layers_shared(R[r].h, field, 1, v[r].data()), "smgpu_layers_shared");
-            };
+            auto sync = [&](int field, int width, int op) { syncShared(smgpu_layers_shared, "smgpu_layers_shared", field, width, op); };
             for (int r = 0; r < nRanks; ++r) check(smgpu_layers_begin(R[r].h, &ld[r], &on, &maxIter), "smgpu_layers_begin");
             for (int it = 0; it < maxIter; ++it) {
                 for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_HOPS_SWEEP, 0), "smgpu_layers_step");
@@ -595,32 +595,67 @@ int main(int argc, char** argv) {
             } else
                 std::printf("WARNING: Initial feature edges will be used also as target edges, because\ndid not find file %s.\n\n", targetEdgesFile.c_str());
         } catch (const std::exception& e) { fatal(e.what()); }
-        const auto& patches = R[0].mesh.patches;
-        std::vector<int32_t> pStart, pSize;
-        std::vector<uint8_t> pKind;
-        for (const auto& pt : patches) {
-            pStart.push_back(pt.startFace); pSize.push_back(pt.nFaces);
-            pKind.push_back(pt.type == "processor" ? 1 : pt.type == "empty" ? 2 : 0);
+        std::vector<std::vector<int32_t>> pStart(R.size()), pSize(R.size());
+        std::vector<std::vector<uint8_t>> pKind(R.size());
+        std::vector<smgpu_boundary_desc> bd(R.size());
+        for (size_t r = 0; r < R.size(); ++r) {
+            for (const auto& pt : R[r].mesh.patches) {
+                pStart[r].push_back(pt.startFace); pSize[r].push_back(pt.nFaces);
+                pKind[r].push_back(pt.type == "processor" ? 1 : pt.type == "empty" ? 2 : 0);
+            }
+            smgpu_boundary_desc& d = bd[r];
+            d = smgpu_boundary_desc{};
+            d.nPatches = (int32_t)R[r].mesh.patches.size(); d.patchStart = pStart[r].data(); d.patchSize = pSize[r].data(); d.patchKind = pKind[r].data();
+            d.isSmoothingPatch = isSmoothingPatchOf[r].data();
+            d.nInitEdgePoints = (int32_t)(initPts.size() / 3); d.initEdgePoints = initPts.data(); d.nInitEdges = (int32_t)(initE.size() / 2); d.initEdges = initE.data();
+            d.nTargetEdgePoints = (int32_t)(tgtPts.size() / 3); d.targetEdgePoints = tgtPts.data(); d.nTargetEdges = (int32_t)(tgtE.size() / 2); d.targetEdges = tgtE.data();
+            d.nSurfacePoints = (int32_t)(surfPts.size() / 3); d.surfacePoints = surfPts.data();
+            d.nSurfaceTriangles = (int32_t)(surfTris.size() / 3); d.surfaceTriangles = surfTris.data();
+            d.isCornerPointIO = isCornerPointIO[r].empty() ? nullptr : isCornerPointIO[r].data();
+            d.isFeatureEdgePointIO = isFeatureEdgePointIO[r].empty() ? nullptr : isFeatureEdgePointIO[r].data();
+            d.distanceTolerance = 1e-4 * std::min(meshMinEdgeLength, layerEdgeLength);   // REL_TOL, SM.C:1921
+            d.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
         }
-        smgpu_boundary_desc bd{};
-        bd.nPatches = (int32_t)patches.size(); bd.patchStart = pStart.data(); bd.patchSize = pSize.data(); bd.patchKind = pKind.data();
-        bd.isSmoothingPatch = isSmoothingPatchOf[0].data();
-        bd.nInitEdgePoints = (int32_t)(initPts.size() / 3); bd.initEdgePoints = initPts.data(); bd.nInitEdges = (int32_t)(initE.size() / 2); bd.initEdges = initE.data();
-        bd.nTargetEdgePoints = (int32_t)(tgtPts.size() / 3); bd.targetEdgePoints = tgtPts.data(); bd.nTargetEdges = (int32_t)(tgtE.size() / 2); bd.targetEdges = tgtE.data();
-        bd.nSurfacePoints = (int32_t)(surfPts.size() / 3); bd.surfacePoints = surfPts.data();
-        bd.nSurfaceTriangles = (int32_t)(surfTris.size() / 3); bd.surfaceTriangles = surfTris.data();
-        bd.isCornerPointIO = isCornerPointIO.empty() ? nullptr : isCornerPointIO.data();
-        bd.isFeatureEdgePointIO = isFeatureEdgePointIO.empty() ? nullptr : isFeatureEdgePointIO.data();
-        bd.distanceTolerance = 1e-4 * std::min(meshMinEdgeLength, layerEdgeLength);   // REL_TOL, SM.C:1921
-        bd.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
-        std::printf("Distance tolerance = %g\n\n", bd.distanceTolerance);
-        smgpu_boundary_info bi{};
-        check(smgpu_set_boundary_smoothing(R[0].h, &bd, &bi), "smgpu_set_boundary_smoothing");
-        if (!bi.enabled) fatal("boundary point smoothing: the engine did not enable it (empty target surface or edge mesh?)");
-        std::printf("Detected number of target edge mesh strings: %d\n\n", bi.nTargetEdgeStrings);
+        std::printf("Distance tolerance = %g\n\n", bd[0].distanceTolerance);
+        smgpu_boundary_info tot{};
+        if (!opt.parallel) {
+            check(smgpu_set_boundary_smoothing(R[0].h, &bd[0], &tot), "smgpu_set_boundary_smoothing");
+        } else {
+            // the reductions of getMeshStats (SM.C:1528-1538), then the set-up in steps with its syncPointList calls
+            double mn = 1e300, bb[6] = {1e300, -1e300, 1e300, -1e300, 1e300, -1e300};
+            for (Rank& K : R) {
+                double m1, b1[6];
+                check(smgpu_boundary_stats(K.h, &m1, b1), "smgpu_boundary_stats");
+                mn = std::min(mn, m1);
+                for (int c = 0; c < 6; c += 2) { bb[c] = std::min(bb[c], b1[c]); bb[c + 1] = std::max(bb[c + 1], b1[c + 1]); }
+            }
+            const double perimeter = bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4];
+            for (size_t r = 0; r < R.size(); ++r) {
+                smgpu_boundary_info bi{};
+                check(smgpu_boundary_begin(R[r].h, &bd[r], mn, perimeter, &bi), "smgpu_boundary_begin");
+                if (r == 0) tot = bi;
+                else {   // returnReduce sumOp, BPS.C:423-427
+                    tot.enabled = tot.enabled && bi.enabled;
+                    tot.nCornerPoints += bi.nCornerPoints; tot.nFeatureEdgePoints += bi.nFeatureEdgePoints;
+                    tot.nSmoothingSurfacePoints += bi.nSmoothingSurfacePoints; tot.nFrozenSurfacePoints += bi.nFrozenSurfacePoints;
+                }
+            }
+            if (tot.enabled) {
+                for (int it = 0; it < 2; ++it) {   // SM.C:2218
+                    for (Rank& K : R) check(smgpu_boundary_step(K.h, SMGPU_BOUNDARY_HOPS_SWEEP), "smgpu_boundary_step");
+                    syncShared(smgpu_boundary_shared, "smgpu_boundary_shared", SMGPU_BOUNDARY_F_HOPS, 1, 0);   // OBB.C:124-130
+                }
+                for (Rank& K : R) check(smgpu_boundary_step(K.h, SMGPU_BOUNDARY_TABLES), "smgpu_boundary_step");
+                for (Rank& K : R) check(smgpu_boundary_step(K.h, SMGPU_BOUNDARY_NORMALS_ACCUMULATE), "smgpu_boundary_step");
+                syncShared(smgpu_boundary_shared, "smgpu_boundary_shared", SMGPU_BOUNDARY_F_NORMALS_COUNT, 4, 1);   // OBB.C:184-198
+                for (Rank& K : R) check(smgpu_boundary_step(K.h, SMGPU_BOUNDARY_NORMALS_FINISH), "smgpu_boundary_step");
+            }
+        }
+        if (!tot.enabled) fatal("boundary point smoothing: the engine did not enable it (empty target surface or edge mesh?)");
+        std::printf("Detected number of target edge mesh strings: %d\n\n", tot.nTargetEdgeStrings);
         std::printf("Boundary point classification summary:\n- Detected number of corner points: %d\n- Detected number of feature edge points: %d\n"
                     "- Detected number of smoothing surface points: %d\n- Detected number of frozen surface points: %d\n\n",
-                    bi.nCornerPoints, bi.nFeatureEdgePoints, bi.nSmoothingSurfacePoints, bi.nFrozenSurfacePoints);
+                    tot.nCornerPoints, tot.nFeatureEdgePoints, tot.nSmoothingSurfacePoints, tot.nFrozenSurfacePoints);
     }
 
     auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
@@ -636,7 +671,7 @@ int main(int argc, char** argv) {
     };
     auto exchange = [&](bool isA) {
         syncAll();
-        if (isA && doLayerTreatment) exchangeL();
+        if (isA && (doLayerTreatment || doBoundarySmoothing)) exchangeL();
         for (int a = 0; a < nRanks; ++a)
             for (int b = 0; b < nRanks; ++b) {
                 const int c = R[a].peerCount[b];
@@ -661,14 +696,15 @@ int main(int argc, char** argv) {
             try { writePoints(K.root + "/" + tn + "/polyMesh", tn + "/polyMesh", K.mesh.nPoints(), pts.data(), binary, writePrecision); }
             catch (const std::exception& e) { fatal(e.what()); }
         }
-        if (doBoundarySmoothing) {   // labelIOLists with AUTO_WRITE, SM.C:2039-2064
-            std::vector<int32_t> a((size_t)R[0].mesh.nPoints()), b((size_t)R[0].mesh.nPoints());
-            check(smgpu_get_boundary_classification(R[0].h, a.data(), b.data()), "smgpu_get_boundary_classification");
-            try {
-                writeLabelList(cd + "/" + tn + "/isCornerPoint", tn, "isCornerPoint", "labelList", (int64_t)a.size(), a.data(), binary, "");
-                writeLabelList(cd + "/" + tn + "/isFeatureEdgePoint", tn, "isFeatureEdgePoint", "labelList", (int64_t)b.size(), b.data(), binary, "");
-            } catch (const std::exception& e) { fatal(e.what()); }
-        }
+        if (doBoundarySmoothing)   // labelIOLists with AUTO_WRITE, SM.C:2039-2064 (per sub-domain under -parallel)
+            for (Rank& K : R) {
+                std::vector<int32_t> a((size_t)K.mesh.nPoints()), b((size_t)K.mesh.nPoints());
+                check(smgpu_get_boundary_classification(K.h, a.data(), b.data()), "smgpu_get_boundary_classification");
+                try {
+                    writeLabelList(K.root + "/" + tn + "/isCornerPoint", tn, "isCornerPoint", "labelList", (int64_t)a.size(), a.data(), binary, "");
+                    writeLabelList(K.root + "/" + tn + "/isFeatureEdgePoint", tn, "isFeatureEdgePoint", "labelList", (int64_t)b.size(), b.data(), binary, "");
+                } catch (const std::exception& e) { fatal(e.what()); }
+            }
     };
 
     // the loop, SM.C:2257-2437

@@ -130,20 +130,34 @@ def test_boundary_point_smoothing_case(tmp_path, oracle_lib):
     out2 = _run(["-case", str(tmp_path), "-centroidalIters", "2", "-relTol", "0", "-internalSmoothingBlendingFraction", "0.3"])
     assert "Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files" in out2
     assert "- Detected number of corner points: 8" in out2 and "- Detected number of feature edge points: 84" in out2
-    # -parallel with the geometry present is refused, not silently different
-    from smoothmesh_amd.meshgen import hex_subdomain
-    from smoothmesh_amd.polymesh import write_decomposed_case
-    par = tmp_path / "par"
-    os.makedirs(par)
-    write_decomposed_case(str(par), [hex_subdomain((4, 4, 4), (2, 1, 1), r, jitter=0.1, seed=1) for r in range(2)], binary=True,
-                          writeFormat="binary")
-    os.makedirs(par / "constant" / "geometry")
-    write_obj_edges(str(par / "constant" / "geometry" / "initEdges.obj"), *init)
-    write_obj_surface(str(par / "constant" / "geometry" / "targetSurfaces.obj"), *surf)
-    r = subprocess.run([BIN, "-case", str(par), "-parallel", "-centroidalIters", "1"], capture_output=True, text=True, timeout=120)
-    assert r.returncode != 0 and "not available under -parallel" in (r.stdout + r.stderr)
-    # ... unless no patch is to be smoothed (SM.C:2080-2093: boundary point smoothing stays disabled)
-    out3 = _run(["-case", str(par), "-parallel", "-centroidalIters", "1", "-smoothingPatches", "()"])
+
+
+def test_parallel_boundary_point_smoothing_case(tmp_path, oracle_lib):
+    """mpirun ... smoothMesh -parallel with constant/geometry/*.obj (the reference's run_parallel of testcase2-8): every
+    sub-domain projects its boundary points, the shared ones from synchronised inputs; per-processor results equal the oracle's
+    MultiDomain; the classification lists are written per processor"""
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface, write_obj_edges, write_obj_surface
+    from test_oracle_boundary import _multi_boundary_case
+    grid = (2, 2, 1)
+    mo, orcs, subs, _, hi = _multi_boundary_case(oracle_lib, grid, (4, 5, 4), 0.25, True, blend=0.3)
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    geo = tmp_path / "constant" / "geometry"
+    os.makedirs(geo)
+    write_obj_edges(str(geo / "initEdges.obj"), *box_feature_edges(8, hi=hi))
+    write_obj_surface(str(geo / "targetSurfaces.obj"), *box_surface(4, hi=hi))
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0", "-internalSmoothingBlendingFraction", "0.3"])
+    assert "Enabled boundary point smoothing" in out
+    n, res, frz = mo.iterate(6, 0.0)
+    lines = LINE.findall(out)
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    for s_, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s_.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "6" / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13
+        assert os.path.exists(d / "6" / "isCornerPoint") and os.path.exists(d / "6" / "isFeatureEdgePoint")
+    # boundary point smoothing stays off when no patch is to be smoothed (SM.C:2080-2093)
+    out3 = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "1", "-smoothingPatches", "()"])
     assert "Boundary point smoothing is disabled" in out3
 
 
