@@ -32,15 +32,15 @@ def workload_layers(w):
 
 def workload_boundary(w):
     """trailing B = boundary point smoothing on (hex: every side onto the block's own surface + its twelve feature
-    edges; cavity: the cavity wall onto the sphere it was carved from), one GPU only"""
+    edges; cavity: the cavity wall onto the sphere it was carved from)"""
     return w.endswith("B")
 
 
-def boundary_params(kind, n):
+def boundary_params(kind, n, hi=(1.0, 1.0, 1.0)):
     from smoothmesh_amd import BoundaryParams
     from smoothmesh_amd.surfgen import box_feature_edges, box_surface, sphere_surface
     if kind == "hex":
-        return BoundaryParams(initEdges=box_feature_edges(n), targetSurfaces=box_surface(max(n // 2, 1)))
+        return BoundaryParams(initEdges=box_feature_edges(n, hi=hi), targetSurfaces=box_surface(max(n // 2, 1), hi=hi))
     return BoundaryParams(initEdges=box_feature_edges(n), targetSurfaces=sphere_surface(levels=6), smoothingPatches=("cavity",))
 
 
@@ -197,10 +197,12 @@ def main():
         ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
         prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         ds.set_params(prm)
-        if boundary:
-            raise SystemExit("boundary point smoothing (workload suffix B) is a one-GPU feature in this round")
         if layers and not ds.set_layers(layer_params(kind), prm.minEdgeLength):
             raise SystemExit("boundary layer treatment could not be enabled")
+        if boundary:   # hex: every rank is a unit cube of the global block [0, grid]; cavity: the global unit cube
+            hi = tuple(float(g) for g in grid) if kind == "hex" else (1.0, 1.0, 1.0)
+            if not ds.set_boundary_smoothing(boundary_params(kind, n_side, hi), prm.minEdgeLength)["enabled"]:
+                raise SystemExit("boundary point smoothing could not be enabled")
         # exchange arrangement (in order on the engine's stream / on a communication stream next to the
         # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
         tune = ds.autotune(20) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None

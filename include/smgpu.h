@@ -201,7 +201,7 @@ int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enab
 int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg);
 int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);
 
-/* ---- optional boundary point smoothing (projection of boundary points to feature edges and target surfaces), serial --
+/* ---- optional boundary point smoothing (projection of boundary points to feature edges and target surfaces) --------
  * Replaces, for this feature, the set-up SM.C:2080-2253 (edge mesh sanity checks BPS.C:20-79, target edge strings
  * BPS.C:446-587, classifyBoundaryPoints BPS.C:269-441, hop counts to the smoothing patches OBB.C:52-133, inner neighbour
  * map OBB.C:396-459, target strings of the feature edge points SM.C:2234-2249) and, inside every later iteration,

@@ -9,8 +9,8 @@
 //
 // OpenFOAM's indexedOctree<treeDataTriSurface> (third-party, not in the reference tree) is replaced by a bounding
 // volume hierarchy over the target triangles; the query semantics are stated in kernels_boundary.hpp (findLine).
-// Serial runs only: under -parallel the reference synchronises normals, feature projections and inner neighbour
-// coordinates over the processor patches, which this round does not provide.
+// Under -parallel the reference synchronises hop counts, normals, feature projections and inner neighbour coordinates over
+// the processor patches: the set-up below comes in steps so that the host can do that between them (smgpu_boundary_*).
 #pragma once
 #include <cstdint>
 #include <string>

@@ -1,4 +1,4 @@
-// kernels_boundary.hpp -- per-iteration part of the optional boundary point smoothing, serial run:
+// kernels_boundary.hpp -- per-iteration part of the optional boundary point smoothing:
 //
 //   SM.C:2266        calculateBoundaryPointNormals OBB.C:141-233                      -> k_bnd_normals
 //   SM.C:2311-2330   calculateFeatureEdgeProjections BPS.C:623-677                    -> k_bnd_feature

@@ -196,6 +196,7 @@ class DistributedSmoother:
         self.probe_slots = int(probe_slots)
         self.xstream = None
         self.layers = False
+        self.boundary = False
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         assert sub.rank == self.rank and sub.nRanks == self.world
         if torch_device is None:
@@ -254,6 +255,37 @@ class DistributedSmoother:
             return [combine_shared(t, o, recv.numpy(), op)]
         self.layers = setup_layers_stepwise([self.engine], exchange, lp, minEdgeLength)
         return self.layers
+
+    def set_boundary_smoothing(self, bp, minEdgeLength, layerEdgeLength=None):
+        """boundary point smoothing (constant/geometry/*.obj under mpirun): step-wise set-up; the reductions of getMeshStats
+        (SM.C:1528-1538) with all_gather_object, the syncPointList calls with the all_to_all of the exchanges.  After
+        set_layers when both are used.  Returns this rank's classification summary."""
+        torch, t = self.torch, self.tables
+        cpu = self._staged() or self.device.type == "cpu"
+
+        def exchange(own, op):
+            o = own[0]
+            k = o.shape[1]
+            send = torch.from_numpy(np.ascontiguousarray(o[t.sendShared])).reshape(-1, k) if t.nSend else torch.zeros((0, k), dtype=torch.float64)
+            recv = torch.zeros((t.nRecv, k), dtype=torch.float64)
+            if self.world > 1:
+                if cpu:
+                    self.dist.all_to_all_single(recv, send, self.counts, self.counts)
+                else:
+                    r = recv.to(self.device)
+                    self.dist.all_to_all_single(r, send.to(self.device), self.counts, self.counts)
+                    recv = r.cpu()
+            return [combine_shared(t, o, recv.numpy(), op)]
+
+        def reduce_stats(stats):
+            mn, bb = stats[0]
+            allv = [None] * self.world
+            self.dist.all_gather_object(allv, (float(mn), [float(x) for x in bb]))
+            b = np.array([v[1] for v in allv])
+            return min(v[0] for v in allv), np.array([b[:, 0].min(), b[:, 1].max(), b[:, 2].min(), b[:, 3].max(), b[:, 4].min(), b[:, 5].max()])
+        info = setup_boundary_stepwise([self.engine], exchange, reduce_stats, bp, minEdgeLength, layerEdgeLength)[0]
+        self.boundary = bool(info["enabled"])
+        return info
 
     def _staged(self):
         # RCCL moves device buffers directly; gloo (CPU tests, or several debug ranks sharing one GPU)
@@ -349,7 +381,7 @@ class DistributedSmoother:
             hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
             for i in range(centroidalIters):
                 eng.iter_begin()
-                if self.layers:
+                if self.layers or self.boundary:
                     self._a2a(st.recvL, st.sendL)                  # OBB.C:184-198, 490-496
                 self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
                 eng.iter_mid()
@@ -370,7 +402,7 @@ class DistributedSmoother:
         eng.set_stats_history(local.data_ptr(), n)      # iter_end fills record i: no per-iteration copy
         for i in range(centroidalIters):
             eng.iter_begin()
-            if self.layers:
+            if self.layers or self.boundary:
                 self._a2a(st.recvL, st.sendL)
             self._a2a(st.recvA, st.sendA, eng.iter_interior)
             eng.iter_mid()

@@ -232,3 +232,18 @@ def test_decomposed_boundary_smoothing(oracle_lib, grid, constraints, layers):
     assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
     for o, p in zip(orcs, ms.get_points()):
         assert rel_linf(p, o.points()) <= 1e-13
+
+
+def test_distributed_smoother_with_boundary_smoothing_two_ranks():
+    """One process per rank (torch.distributed.run), real engines, two ranks sharing this box's GPU through the gloo debug
+    transport: DistributedSmoother with boundary point smoothing (and layers, constraints) equals the oracle's MultiDomain
+    bit for bit (scripts/check_dist_boundary.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMOOTHMESH_SHARE_GPU="1", SMOOTHMESH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29519", os.path.join(root, "scripts", "check_dist_boundary.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": ok ") == 4 and "BAD" not in r.stdout
