@@ -52,14 +52,42 @@ for case in range(n_cases):
             o.set_params(prm)
         off, dom, loc = shared_point_table(subs)
         mo = oracle_ffi.MultiOracle(orcs, off, dom, loc)
-        if layers:
+        desc = f"multi grid {grid} local {nloc}"
+        boundary = rng.random() < 0.5
+        if boundary:      # every sub-domain is a unit cube of the block [0, grid]
+            hi = tuple(float(g) for g in grid)
+            f = float(rng.choice([1.0, 1.0, 1.02]))
+            c = 0.5 * np.array(hi)
+            warp = (lambda x: c + (x - c) * f) if f != 1.0 else None
+            m_e, m_s = int(rng.integers(1, 9)), int(rng.integers(1, 7))
+            bp = BoundaryParams(initEdges=box_feature_edges(m_e, hi=hi), targetEdges=box_feature_edges(m_e, hi=hi, warp=warp) if warp else None,
+                                targetSurfaces=box_surface(m_s, hi=hi, warp=warp), internalSmoothingBlendingFraction=float(rng.choice([0.0, 0.3, 1.0])))
+            lopt = (lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+            pa = [patch_arrays(s.mesh, lp.layerPatches if layers else ()) + (patch_arrays(s.mesh, bp.smoothingPatches)[3],) for s in subs]
+            if layers:
+                ms.set_layers(lp, prm.minEdgeLength)
+            on_o = mo.setup_boundary(pa, lopt, bp.initEdges, bp.targetEdges, bp.targetSurfaces, bp.internalSmoothingBlendingFraction)
+            assert on_o == bool(ms.set_boundary_smoothing(bp, prm.minEdgeLength)[0]["enabled"])
+            desc += f" boundary->box*{f:g}"
+        elif layers:
             on_o = mo.setup_layers([patch_arrays(s.mesh, lp.layerPatches) for s in subs], lp.layerMaxBlendingFraction, prm.minEdgeLength,
                                    lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
             assert on_o == ms.set_layers(lp, prm.minEdgeLength)
-        n_o, res_o, frz_o = mo.iterate(iters, 0.0)
-        n_g, res_g, frz_g = ms.iterate(iters, 0.0)
+        err_o = err_g = None
+        try:
+            n_o, res_o, frz_o = mo.iterate(iters, 0.0)
+        except RuntimeError as ex:
+            err_o = str(ex)
+        try:
+            n_g, res_g, frz_g = ms.iterate(iters, 0.0)
+        except SmgpuError as ex:
+            err_g = str(ex)
+        if err_o or err_g:
+            ok = bool(err_o) and bool(err_g)
+            print(f"case {case:3d} {'ok ' if ok else 'BAD'} {desc} jitter {jitter} iters {iters}: oracle error [{err_o}] engine error [{err_g}]", flush=True)
+            bad += 0 if ok else 1
+            continue
         a = np.concatenate(ms.get_points()); b = np.concatenate([o.points() for o in orcs])
-        desc = f"multi grid {grid} local {nloc}"
     else:
         if kind == "hex":
             dims = tuple(int(x) for x in rng.integers(2, 14, size=3))
