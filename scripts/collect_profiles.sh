@@ -14,6 +14,8 @@ python bench.py --workload cavity215c --no-cpu-baseline --steps 20 --warmup 2 > 
 python bench.py --workload cavity100c --steps 20 --warmup 2 > $out/bench_cavity100c.json 2>>$out/bench_hex100.err
 python bench.py --workload hex100B --steps 50 --warmup 5 > $out/bench_hex100B.json 2>>$out/bench_hex100.err
 python bench.py --workload cavity100B --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity100B.json 2>>$out/bench_hex100.err
+python bench.py --workload hex215B --no-cpu-baseline --steps 30 --warmup 3 > $out/bench_hex215B.json 2>>$out/bench_hex100.err
+python bench.py --workload hex100cB --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_hex100cB.json 2>>$out/bench_hex100.err
 cd /tmp && export TMPDIR=/tmp
 for wl in hex100 hex100c hex100B; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_$wl -- python3 $root/bench.py --no-cpu-baseline --workload $wl > /dev/null 2>&1
