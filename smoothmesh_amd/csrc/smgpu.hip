@@ -647,11 +647,13 @@ static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s,
 }
 template <bool FINAL>
 static int launchBndFix(smgpu_handle* h, int partialBase) {
+    if (h->bv.nB == 0) return 0;   // a sub-domain without boundary points (interior rank of a decomposition)
     return launchK(h, K_BND, [&] {
         hipLaunchKernelGGL(k_bnd_fix<FINAL>, dim3(gridFor(2 * (int64_t)h->bv.nB)), dim3(kBlock), 0, h->stream, h->mv, h->st, makePrm(h), h->bv, partialBase);
     });
 }
 static int launchBndPre(smgpu_handle* h, const MeshView& m, const State& s, hipStream_t stream) {
+    if (h->bv.nB == 0) return 0;
     return launchK(h, K_BND, [&] {
         hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, stream, m, s, h->bv);
         if (h->bv.nFeat) hipLaunchKernelGGL(k_bnd_feature, dim3(h->bv.nFeat), dim3(64), 0, stream, m, s, h->bv);
@@ -1775,8 +1777,9 @@ int smgpu_boundary_step(smgpu_handle* h, int32_t step) {
         if (!h->bndOn) return fail("smgpu_boundary_step: the tables step comes first");
         if (h->bndNormalsFromLayers) return 0;
         HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
-        hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, h->st, h->bv);
+        if (h->bv.nB > 0) hipLaunchKernelGGL(k_bnd_normals, dim3(gridFor(h->bv.nB)), dim3(kBlock), 0, h->stream, m, h->st, h->bv);
         HIP_OK(hipStreamSynchronize(h->stream));
+        HIP_OK(hipGetLastError());
         return 0;
     case SMGPU_BOUNDARY_NORMALS_FINISH:       // shared points, after the host has set the sums
         if (!h->bndOn) return fail("smgpu_boundary_step: the tables step comes first");
