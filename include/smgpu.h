@@ -197,6 +197,11 @@ enum { SMGPU_LAYERS_F_HOPS = 0,            /* 1 double per shared point (the hop
  * faces, [7:10] inner neighbour coordinates, [10:13] local feature edge projection sum, [13] its count (boundary point
  * smoothing; zero / UNDEF when that is off).  Exchanged whenever the layer treatment or the boundary point smoothing is on. */
 #define SMGPU_HALO_L_DOUBLES 14
+/* The record in use is shorter while only the layer treatment needs it: the first SMGPU_HALO_L_LAYERS doubles, records packed
+ * back to back from the start of sendL / recvL (which are sized for SMGPU_HALO_L_DOUBLES per slot).  smgpu_halo_l_doubles tells
+ * the host how many doubles per slot to exchange; it changes when the boundary point smoothing is set up. */
+#define SMGPU_HALO_L_LAYERS 6
+int smgpu_halo_l_doubles(smgpu_handle* h, int32_t* doublesPerSlot);
 int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enabled, int32_t* maxIter);
 int smgpu_layers_step(smgpu_handle* h, int32_t step, int32_t arg);
 int smgpu_layers_shared(smgpu_handle* h, int32_t field, int32_t set, double* values);

@@ -302,6 +302,9 @@ class OracleRankEngine:
         v = np.ascontiguousarray(values, np.float64)
         self._lib.orc_layers_shared(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), int(field), 1, _p(v, f64p))
 
+    def l_doubles(self):
+        return 14          # the rank engine always packs the full record (oracle_capi.cpp: kL)
+
     def iter_begin(self):
         self.o.phaseA()
         self._lib.orc_halo_packA(self.o._h, len(self.sharedLocal), _p(self.sharedLocal, i32p), len(self.sendShared),

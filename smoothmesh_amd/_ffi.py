@@ -115,6 +115,7 @@ SYMBOLS = {
     "smgpu_get_boundary_classification": (C.c_int, [C.c_void_p, c_i32p, c_i32p]),
     "smgpu_debug_edge_strings": (C.c_int, [C.c_int32, C.c_int32, c_i32p, c_i32p, c_i32p]),
     "smgpu_debug_find_line": (C.c_int, [C.c_void_p, C.c_int32, c_f64p, c_f64p, c_i32p]),
+    "smgpu_halo_l_doubles": (C.c_int, [C.c_void_p, c_i32p]),
     "smgpu_halo_set_exchange_stream": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "smgpu_get_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "smgpu_iter_end": (C.c_int, [C.c_void_p]),

@@ -659,14 +659,15 @@ int main(int argc, char** argv) {
     }
 
     auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
+    int32_t lDoubles = SMGPU_HALO_L_LAYERS;   // doubles per slot of the L records in use (all engines agree)
+    if (opt.parallel) check(smgpu_halo_l_doubles(R[0].h, &lDoubles), "smgpu_halo_l_doubles");
     auto exchangeL = [&] {
         for (int a = 0; a < nRanks; ++a)
             for (int b = 0; b < nRanks; ++b) {
                 const int c = R[a].peerCount[b];
                 if (!c) continue;
-                HIPCHK(hipMemcpyPeer(R[b].recvL + (size_t)R[b].peerSendBase[a] * SMGPU_HALO_L_DOUBLES, R[b].device,
-                                     R[a].sendL + (size_t)R[a].peerSendBase[b] * SMGPU_HALO_L_DOUBLES, R[a].device,
-                                     (size_t)c * SMGPU_HALO_L_DOUBLES * 8));
+                HIPCHK(hipMemcpyPeer(R[b].recvL + (size_t)R[b].peerSendBase[a] * lDoubles, R[b].device,
+                                     R[a].sendL + (size_t)R[a].peerSendBase[b] * lDoubles, R[a].device, (size_t)c * lDoubles * 8));
             }
     };
     auto exchange = [&](bool isA) {

@@ -61,6 +61,7 @@ struct State {
     // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
     // outer neighbour; per hop count the target edge length and the blending fraction
     double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
+    int lStride;               // multi-rank: doubles per exchange-L record in use (SMGPU_HALO_L_LAYERS or SMGPU_HALO_L_DOUBLES)
     const int* bndOfShared;    // multi-rank + boundary point smoothing: per shared point its index in the boundary tables or -1
     const double* combL;       // multi-rank + layers: per shared point the summed normals and the combined outer
                                // neighbour coordinates (6 doubles), or NULL
@@ -279,7 +280,7 @@ __device__ __forceinline__ void blockPublish(const State& s, double dist, int fr
 // minMagSqr-synchronised neighbour coordinates (OBB.C:490-496) from combL instead of its local values.
 __device__ __forceinline__ V3 layerTreat(const State& s, const Prm& prm, int p, bool internal, const V3& cur, V3 np) {
     const int slot = (s.combL && s.sharedSlot) ? s.sharedSlot[p] : -1;
-    const double* cl = (slot >= 0) ? s.combL + (size_t)slot * SMGPU_HALO_L_DOUBLES : nullptr;
+    const double* cl = (slot >= 0) ? s.combL + (size_t)slot * s.lStride : nullptr;
     V3 n = cl ? v3(cl[0], cl[1], cl[2]) : ldv(s.layerNormal, p);
     const V3 z = v3(0, 0, 0);
     if (n != z) {
@@ -859,42 +860,44 @@ __global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* share
         const int f = featOfBnd[bi];
         if (f >= 0) { const V3 fs = ldv(featSum, f); rec[10] = fs.x; rec[11] = fs.y; rec[12] = fs.z; rec[13] = (double)featCnt[f]; }
     }
-    double* o = ownL + (size_t)i * SMGPU_HALO_L_DOUBLES;
-#pragma unroll
-    for (int j = 0; j < SMGPU_HALO_L_DOUBLES; ++j) o[j] = rec[j];
+    const int w = s.lStride;
+    double* o = ownL + (size_t)i * w;
+    for (int j = 0; j < w; ++j) o[j] = rec[j];
     for (int k = sendOff[i]; k < sendOff[i + 1]; ++k) {
-        double* d = sendL + (size_t)sendSlots[k] * SMGPU_HALO_L_DOUBLES;
-#pragma unroll
-        for (int j = 0; j < SMGPU_HALO_L_DOUBLES; ++j) d[j] = rec[j];
+        double* d = sendL + (size_t)sendSlots[k] * w;
+        for (int j = 0; j < w; ++j) d[j] = rec[j];
     }
 }
 // plusEq in ascending rank order for the normals, face counts and feature projections (OBB.C:184-198, BPS.C:659-674);
 // minMagSqrEqOp folded from the own value for the outer and inner neighbour coordinates (OBB.C:490-496)
 __global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
-                                                          const double* recvL, double* combL) {
+                                                          const double* recvL, double* combL, int w) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
-    const double* own = ownL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+    const double* own = ownL + (size_t)i * w;
+    const bool wide = w > SMGPU_HALO_L_LAYERS;   // the boundary point smoothing fields travel too
     V3 sum = v3(0, 0, 0), fsum = v3(0, 0, 0);
     double faces = 0.0, fcnt = 0.0;
-    V3 x = v3(own[3], own[4], own[5]), y = v3(own[7], own[8], own[9]);
+    V3 x = v3(own[3], own[4], own[5]), y = wide ? v3(own[7], own[8], own[9]) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
     for (int j = 0; j < n; ++j) {
         const int sl = combSlots[b + j];
-        const double* r = (sl < 0) ? own : recvL + (size_t)sl * SMGPU_HALO_L_DOUBLES;
+        const double* r = (sl < 0) ? own : recvL + (size_t)sl * w;
         sum = sum + v3(r[0], r[1], r[2]);
-        faces += r[6];
-        fsum = fsum + v3(r[10], r[11], r[12]);
-        fcnt += r[13];
+        if (wide) {
+            faces += r[6];
+            fsum = fsum + v3(r[10], r[11], r[12]);
+            fcnt += r[13];
+        }
         if (sl >= 0) {
-            const V3 x2 = v3(r[3], r[4], r[5]), y2 = v3(r[7], r[8], r[9]);
+            const V3 x2 = v3(r[3], r[4], r[5]);
             x = (magSqr(x) <= magSqr(x2)) ? x : x2;
-            y = (magSqr(y) <= magSqr(y2)) ? y : y2;
+            if (wide) { const V3 y2 = v3(r[7], r[8], r[9]); y = (magSqr(y) <= magSqr(y2)) ? y : y2; }
         }
     }
-    double* o = combL + (size_t)i * SMGPU_HALO_L_DOUBLES;
-    o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = x.x; o[4] = x.y; o[5] = x.z; o[6] = faces;
-    o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt;
+    double* o = combL + (size_t)i * w;
+    o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = x.x; o[4] = x.y; o[5] = x.z;
+    if (wide) { o[6] = faces; o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt; }
 }
 
 // SM.C:246-272 isCloserPoint

@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView 
     if (i >= nShared) return;
     const int bi = s.bndOfShared[i];
     if (bi < 0) return;
-    const double* r = s.combL + (size_t)i * SMGPU_HALO_L_DOUBLES;
+    const double* r = s.combL + (size_t)i * s.lStride;
     V3 n = v3(r[0], r[1], r[2]);
     uint8_t fl = b.flags[bi];
     if (r[6] >= 1.0) {
@@ -320,7 +320,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_fix(MeshView m, State s, Prm prm
         bool frozen = false;
         // multi-rank: a shared point takes the values combined over its sharers (BPS.C:659-674, OBB.C:490-496)
         const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
-        const double* cl = (slot >= 0) ? s.combL + (size_t)slot * SMGPU_HALO_L_DOUBLES : nullptr;
+        const double* cl = (slot >= 0) ? s.combL + (size_t)slot * s.lStride : nullptr;
         // projectBoundaryPointsToEdgesAndSurfaces BPS.C:876-940
         if (fl & BF_CORNER) np = ldv(b.corner, i);
         else if (fl & BF_FEATURE) {

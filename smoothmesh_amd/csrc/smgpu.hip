@@ -1167,6 +1167,12 @@ int smgpu_halo_set_stats_history(smgpu_handle* h, void* history, int32_t capacit
     return 0;
 }
 
+int smgpu_halo_l_doubles(smgpu_handle* h, int32_t* doublesPerSlot) {
+    if (!h || !doublesPerSlot) return fail("null argument");
+    *doublesPerSlot = h->st.lStride > 0 ? h->st.lStride : SMGPU_HALO_L_LAYERS;
+    return 0;
+}
+
 int smgpu_get_stream(smgpu_handle* h, void** stream) {
     if (!h || !stream) return fail("null argument");
     *stream = (void*)h->stream;
@@ -1293,6 +1299,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     }
     h->st.sharedSlot = h->dSharedSlot;
     h->st.combA = h->dCombA;
+    h->st.lStride = SMGPU_HALO_L_LAYERS;
     h->haloOn = true;
     h->haloIter = 0;
     HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
@@ -1368,7 +1375,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
                                    h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
                 if (h->layersOn || h->bndOn)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
-                                       h->dCombSlots, h->dOwnL, h->recvL, h->dCombL);
+                                       h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride);
                 if (h->bndOn)   // OBB.C:201-230 for the shared boundary points, on the sums
                     hipLaunchKernelGGL(k_bnd_normals_shared, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->bv, h->nShared, h->dSharedLocal);
             })) return 1;
@@ -1740,6 +1747,7 @@ static int bndTables(smgpu_handle* h) {
         if (!h->dOwnL && devAlloc(h, &h->dOwnL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
         if (!h->dCombL && devAlloc(h, &h->dCombL, (size_t)std::max(h->nShared, 1) * SMGPU_HALO_L_DOUBLES)) return 1;
         h->st.combL = h->dCombL;
+        h->st.lStride = SMGPU_HALO_L_DOUBLES;   // from now on the boundary point smoothing fields travel too
     }
     h->bndNormalsFromLayers = h->st.layerNormal != nullptr;   // SM.C:2219 is done by the layer set-up when that ran
     if (!h->st.layerNormal) {
@@ -1806,16 +1814,17 @@ int smgpu_boundary_shared(smgpu_handle* h, int32_t field, int32_t set, double* v
     if (field == SMGPU_BOUNDARY_F_NORMALS_COUNT) {   // 4 doubles: the local normal sum and the local boundary face count
         if (!h->bndOn) return fail("smgpu_boundary_shared: the tables step comes first");
         if (n == 0) return 0;
-        std::vector<double> rec(n * SMGPU_HALO_L_DOUBLES, 0.0);
+        const size_t W = (size_t)h->st.lStride;
+        std::vector<double> rec(n * W, 0.0);
         if (!set) {
             // pack through the exchange kernel: the same values an iteration would send
             hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->dSharedLocal, h->dOwnL, h->nShared,
                                h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
             HIP_OK(hipMemcpyAsync(rec.data(), h->dOwnL, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipStreamSynchronize(h->stream));
-            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) v[4 * i + c] = rec[i * SMGPU_HALO_L_DOUBLES + c]; v[4 * i + 3] = rec[i * SMGPU_HALO_L_DOUBLES + 6]; }
+            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) v[4 * i + c] = rec[i * W + c]; v[4 * i + 3] = rec[i * W + 6]; }
         } else {
-            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) rec[i * SMGPU_HALO_L_DOUBLES + c] = v[4 * i + c]; rec[i * SMGPU_HALO_L_DOUBLES + 6] = v[4 * i + 3]; }
+            for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) rec[i * W + c] = v[4 * i + c]; rec[i * W + 6] = v[4 * i + 3]; }
             HIP_OK(hipMemcpyAsync(h->dCombL, rec.data(), sizeof(double) * rec.size(), hipMemcpyHostToDevice, h->stream));
             HIP_OK(hipStreamSynchronize(h->stream));
         }

@@ -230,6 +230,12 @@ class SmoothEngine:
         if self._nShared:
             self._check(self._lib.smgpu_layers_shared(self._h, int(field), 1, _p(v, _ffi.c_f64p)))
 
+    def l_doubles(self):
+        """doubles per slot of the exchange-L records in use (6 with the layer treatment only, 14 with boundary smoothing)"""
+        n = C.c_int32(0)
+        self._check(self._lib.smgpu_halo_l_doubles(self._h, C.byref(n)))
+        return n.value
+
     def set_layers(self, lp: LayerParams, minEdgeLength: float):
         """Enable the boundary layer treatment on lp.layerPatches (serial runs); returns the reference's
         doLayerTreatment.  Call after construction, before iterating."""

@@ -166,6 +166,12 @@ def setup_boundary_stepwise(engines, exchange, reduce_stats, bp, minEdgeLength, 
     return infos
 
 
+def l_view(t, width):
+    """the exchange-L records in use: `width` doubles per slot, packed from the start of the (slots, L_DOUBLES) buffer"""
+    n = t.shape[0]
+    return t.view(-1)[: n * width].view(n, width)
+
+
 class _RankState:
     """engine + exchange buffers of one rank (torch tensors on the engine's device)"""
 
@@ -382,7 +388,7 @@ class DistributedSmoother:
             for i in range(centroidalIters):
                 eng.iter_begin()
                 if self.layers or self.boundary:
-                    self._a2a(st.recvL, st.sendL)                  # OBB.C:184-198, 490-496
+                    self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))   # OBB.C:184-198, 490-496
                 self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
                 eng.iter_mid()
                 self._a2a(st.recvF, st.sendF, eng.iter_ahead)   # SM.C:2374
@@ -403,7 +409,7 @@ class DistributedSmoother:
         for i in range(centroidalIters):
             eng.iter_begin()
             if self.layers or self.boundary:
-                self._a2a(st.recvL, st.sendL)
+                self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))
             self._a2a(st.recvA, st.sendA, eng.iter_interior)
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF, eng.iter_ahead)
@@ -468,6 +474,9 @@ class LocalMultiSmoother:
         for a, so, b, do, c in self.copies:
             src = getattr(self.states[a], "send" + which)
             dst = getattr(self.states[b], "recv" + which)
+            if which == "L":     # records of the width in use, packed from the start of the buffers
+                w = self.states[a].eng.l_doubles()
+                src, dst = l_view(src, w), l_view(dst, w)
             dst[do:do + c].copy_(src[so:so + c])
 
     def set_layers(self, lp, minEdgeLength):
