@@ -1323,6 +1323,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
     HIP_OK(hipSetDevice(h->device));
+    if (runBndPre(h)) return 1;
     if (h->geomAheadDone) {
         // the tiles away from the shared points were recomputed by smgpu_iter_ahead of the previous iteration
         if (runGeometry(h, h->dGeomShared, h->nGeomShared)) return 1;
@@ -1331,8 +1332,14 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;
-    // boundary point smoothing: local normal sums and feature edge projections of the current coordinates (SM.C:2266, BPS.C:866)
-    if (h->bndOn && launchBndPre(h, m, s, h->stream)) return 1;
+    // boundary point smoothing: local normal sums and feature edge projections of the current coordinates (SM.C:2266, BPS.C:866),
+    // started next to the geometry kernel above when there is a side stream
+    if (h->bndOn) {
+        if (h->bndPreInFlight) {
+            if (depWait(h, DEP_BND_JOIN, h->stream, h->evBndJoin)) return 1;
+            h->bndPreInFlight = false;
+        } else if (launchBndPre(h, m, s, h->stream)) return 1;
+    }
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
@@ -1754,7 +1761,7 @@ static int bndTables(smgpu_handle* h) {
         if (devAlloc(h, &h->st.layerNormal, 3 * (size_t)P)) return 1;
         HIP_OK(hipMemsetAsync(h->st.layerNormal, 0, sizeof(double) * 3 * (size_t)P, h->stream));
     }
-    if (!h->bndSide && !h->haloOn && envInt("SMGPU_SIDE_STREAM", 1)) {
+    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", 1)) {
         if (depInit(h)) return 1;
         if (hipStreamCreateWithFlags(&h->bndSide, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->evBndFork, hipEventDisableTiming) != hipSuccess ||
