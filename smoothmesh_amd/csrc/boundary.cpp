@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 namespace smgpu {
 namespace {
@@ -195,7 +196,10 @@ std::string buildBoundarySetup(const Topology& t, const uint8_t* internal, const
 
     // classifyBoundaryPoints BPS.C:296-420: every boundary point is classified on the first patch that holds it
     const bool haveEdges = init.nPoints() > 0 && o.target.nPoints() > 0;
+    // pass 1 (visiting order): the boundary points in the order the reference meets them, each with its first patch
     std::vector<uint8_t> visited((size_t)P, 0);
+    std::vector<int32_t> met;
+    std::vector<uint8_t> metSmoothing;
     for (const BndPatch& pp : patches)
         for (int f = pp.start; f < pp.start + pp.size; ++f)
             for (int k = fp.off[f]; k < fp.off[f + 1]; ++k) {
@@ -203,41 +207,69 @@ std::string buildBoundarySetup(const Topology& t, const uint8_t* internal, const
                 if (visited[p]) continue;
                 visited[p] = 1;
                 if (internal[p]) continue;
+                met.push_back(p);
+                metSmoothing.push_back(pp.isSmoothing ? 1 : 0);
+            }
+    // pass 2 (independent per point, on the host's threads): neighbours, closest initial edge, closest target corner
+    std::vector<int32_t> cornerOf(met.size(), -2);   // -2 not a corner, -1 no eligible corner point, else the target point
+    {
+        auto work = [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const int p = met[i];
                 for (int j = pe.off[p]; j < pe.off[p + 1]; ++j)
                     if (internal[t.pointPoints[j]]) { o.isConnectedToInternalPoint[p] = 1; break; }
-                if (haveEdges) {
-                    const N3 pt = ld(points, p);
-                    if (ioHaveData) {
-                        o.isCornerPoint[p] = o.isCornerPointOut[p] == 1;
-                        o.isFeatureEdgePoint[p] = o.isFeatureEdgePointOut[p] == 1;
-                    } else {
-                        const ClosestEdge ce = closestEdge(pt, init, o.targetEdgeStrings, tol);
-                        if (ce.edgePoint >= 0 && init.pointEdges[(size_t)ce.edgePoint].size() != 2) {
-                            o.isCornerPoint[p] = 1;
-                            o.isCornerPointOut[p] = 1;
-                        } else if (magOf(sub(pt, ce.proj)) < tol) {
-                            o.isFeatureEdgePoint[p] = 1;
-                            o.isFeatureEdgePointOut[p] = 1;
-                        }
+                if (!haveEdges) continue;
+                const N3 pt = ld(points, p);
+                if (ioHaveData) {
+                    o.isCornerPoint[p] = o.isCornerPointOut[p] == 1;
+                    o.isFeatureEdgePoint[p] = o.isFeatureEdgePointOut[p] == 1;
+                } else {
+                    const ClosestEdge ce = closestEdge(pt, init, o.targetEdgeStrings, tol);
+                    if (ce.edgePoint >= 0 && init.pointEdges[(size_t)ce.edgePoint].size() != 2) {
+                        o.isCornerPoint[p] = 1;
+                        o.isCornerPointOut[p] = 1;
+                    } else if (magOf(sub(pt, ce.proj)) < tol) {
+                        o.isFeatureEdgePoint[p] = 1;
+                        o.isFeatureEdgePointOut[p] = 1;
                     }
-                    if (o.isCornerPoint[p]) {
-                        // findClosestEdgeMeshCornerPointIndex BPS.C:151-183 on the target edge mesh
-                        double best = kGreat;
-                        int bestPoint = -1;
-                        for (int q = 0; q < o.target.nPoints(); ++q) {
-                            if (o.target.pointEdges[(size_t)q].size() == 2) continue;
-                            const double d = magOf(sub(pt, ld(o.target.pts.data(), q)));
-                            if (d < best) { best = d; bestPoint = q; }
-                        }
-                        if (bestPoint < 0) return "Did not find any eligible corner points in edge mesh";
-                        for (int d = 0; d < 3; ++d) o.cornerPoints[3 * (size_t)p + d] = o.target.pts[3 * (size_t)bestPoint + d];
-                        ++o.nCorner;
-                    }
-                    if (o.isFeatureEdgePoint[p]) ++o.nFeature;
                 }
-                if (o.enabled && pp.isSmoothing) { o.isSmoothingSurfacePoint[p] = 1; ++o.nSmoothingSurface; }
-                else { o.isFrozenSurfacePoint[p] = 1; ++o.nFrozenSurface; }
+                if (o.isCornerPoint[p]) {
+                    // findClosestEdgeMeshCornerPointIndex BPS.C:151-183 on the target edge mesh
+                    double best = kGreat;
+                    int bestPoint = -1;
+                    for (int q = 0; q < o.target.nPoints(); ++q) {
+                        if (o.target.pointEdges[(size_t)q].size() == 2) continue;
+                        const double d = magOf(sub(pt, ld(o.target.pts.data(), q)));
+                        if (d < best) { best = d; bestPoint = q; }
+                    }
+                    cornerOf[i] = bestPoint;
+                }
             }
+        };
+        const size_t n = met.size();
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        const size_t nThreads = (n * (size_t)std::max(1, init.nEdges()) < 2000000) ? 1 : hw;
+        if (nThreads <= 1) work(0, n);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t k = 0; k < nThreads; ++k) pool.emplace_back(work, n * k / nThreads, n * (k + 1) / nThreads);
+            for (auto& th : pool) th.join();
+        }
+    }
+    // pass 3: counts and corner targets
+    for (size_t i = 0; i < met.size(); ++i) {
+        const int p = met[i];
+        if (haveEdges) {
+            if (o.isCornerPoint[p]) {
+                if (cornerOf[i] < 0) return "Did not find any eligible corner points in edge mesh";
+                for (int d = 0; d < 3; ++d) o.cornerPoints[3 * (size_t)p + d] = o.target.pts[3 * (size_t)cornerOf[i] + d];
+                ++o.nCorner;
+            }
+            if (o.isFeatureEdgePoint[p]) ++o.nFeature;
+        }
+        if (o.enabled && metSmoothing[i]) { o.isSmoothingSurfacePoint[p] = 1; ++o.nSmoothingSurface; }
+        else { o.isFrozenSurfacePoint[p] = 1; ++o.nFrozenSurface; }
+    }
 
     // calculatePointHopsToBoundary(smoothingPatchIds, ..., maxIter = 2) OBB.C:52-133, SM.C:2218
     std::vector<int32_t>& hops = o.hopsToSmoothingBoundary;
