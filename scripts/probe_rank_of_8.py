@@ -12,7 +12,7 @@ dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 from smoothmesh_amd import SmoothEngine, default_params
 from smoothmesh_amd import halo
 from smoothmesh_amd.meshgen import hex_subdomain
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
 grid = (2, 2, 2)
 subs = [hex_subdomain((n, n, n), grid, r, jitter=0.2, seed=12345) for r in range(8)]
 cands = [s.processor_patch_points() for s in subs]
@@ -41,6 +41,22 @@ for mode in ("inorder", "overlap"):
             if c["launches"]:
                 print(f"      {c['name']:24s} launches/iter {c['launches']/50:.1f}  avg {1e3*c['ms']/c['launches']:.1f} us  per iter {1e3*c['ms']/50:.1f} us")
     del ds
+if "--boundary" in sys.argv:
+    # the same rank with boundary point smoothing: its three real sides onto the unit cube's surface (the other three sides are
+    # processor patches); the L records (14 doubles per slot) travel through the same self-exchange
+    from smoothmesh_amd import BoundaryParams
+    from smoothmesh_amd.surfgen import box_feature_edges, box_surface
+    dist.all_gather_object = real_gather
+    for mode in ("inorder", "overlap"):
+        ds = halo.DistributedSmoother(sub, device=0, probe_slots=t.nSend, overlap=(mode == "overlap"))
+        prm = default_params(ds.global_min_edge(), edgeAngleConstraint=False, faceAngleConstraint=False)
+        ds.set_params(prm)
+        info = ds.set_boundary_smoothing(BoundaryParams(initEdges=box_feature_edges(n), targetSurfaces=box_surface(n // 2)), prm.minEdgeLength)
+        ds.iterate(10, 0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); ds.iterate(100, 0.0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        print(f"  boundary smoothing, {mode}: {1e4*dt:.1f} us/iter  ({info['nSmoothingSurfacePoints']} smoothing surface points)")
+        del ds
 e = SmoothEngine(sub.mesh, device=0)
 e.set_params(default_params(e.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False))
 e.iterate(10, 0.0)
