@@ -299,3 +299,41 @@ def test_decomposed_boundary_smoothing_keeps_the_ranks_consistent(oracle_lib, gr
     assert np.all(res == 0.0) and np.all(frz == 0)
     for o, s in zip(orcs2, subs2):
         assert np.array_equal(o.points(), np.array(s.mesh.points))
+
+
+def test_find_line_on_a_tilted_triangle(oracle_lib):
+    """analytic hit: the plane x + y + z = 1 cut by the segment from the origin towards (1, 1, 1) at t = 1/3; a segment
+    that stops short misses, one that passes outside the triangle misses"""
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.surfgen import box_feature_edges
+    m = hex_block(2)
+    tri = (np.array([[1.0, 0, 0], [0, 1.0, 0], [0, 0, 1.0]]), np.array([[0, 1, 2]], np.int32))
+    o = make_pair(m, oracle_lib, box_feature_edges(2), None, tri, engine=False)[0]
+    hit, p = o.find_line([0, 0, 0], [1, 1, 1])
+    assert hit and np.allclose(p, [1 / 3, 1 / 3, 1 / 3], rtol=0, atol=1e-15)
+    assert not o.find_line([0, 0, 0], [0.3, 0.3, 0.3])[0]
+    assert not o.find_line([2, 2, -1], [2, 2, 3])[0]
+    hit, p = o.find_line([0.2, 0.2, -1], [0.2, 0.2, 2])                   # vertical through (0.2, 0.2, 0.6)
+    assert hit and np.allclose(p, [0.2, 0.2, 0.6], rtol=0, atol=1e-15)
+
+
+def test_feature_edge_point_moves_to_the_mean_projection_of_its_surface_neighbours(oracle_lib):
+    """BPS.C:623-677 + 883-893 + SM.C:2356: a point on a block edge has two surface neighbours (one on each adjacent side);
+    its target is the mean of their projections onto the edge, and the step clamp (relStepFrac 0.5, step below maxStepLength)
+    takes it half of the way"""
+    from smoothmesh_amd.meshgen import hex_block
+    n = 6
+    m = hex_block(n, jitter=0.0)
+    p0 = np.array(m.points).copy()
+    i, j, k = _ijk(n)
+    idx = lambda a, b, c: a + (n + 1) * (b + (n + 1) * c)
+    e, q1, q2 = idx(3, 0, 0), idx(3, 1, 0), idx(3, 0, 1)                  # edge point on the x axis and its two surface neighbours
+    p0[q1, 0] += 0.02
+    p0[q2, 0] += 0.05
+    m.points[:] = p0
+    init, target, surf = boundary_inputs(n, 2)
+    o = make_pair(m, oracle_lib, init, None, surf, engine=False, maxStepLength=10.0)[0]
+    o.iterate(1, 0.0)
+    p = o.points()
+    want = p0[e, 0] + 0.5 * (0.5 * (p0[q1, 0] + p0[q2, 0]) - p0[e, 0])
+    assert abs(p[e, 0] - want) <= 1e-15 and p[e, 1] == 0.0 and p[e, 2] == 0.0
