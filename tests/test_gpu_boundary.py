@@ -248,3 +248,18 @@ def test_distributed_smoother_with_boundary_smoothing_two_ranks():
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(": ok ") == 4 and "BAD" not in r.stdout
+
+
+@pytest.mark.parametrize("env", [{"SMGPU_HOST_WALK": "1"}, {"SMGPU_HOST_WALK": "0"}, {"SMGPU_FILTER": "0"},
+                                 {"SMGPU_SIDE_STREAM": "0"}, {"SMGPU_STREAM_OPS": "0"}, {"SMGPU_XCD_MAP": "0"}])
+def test_boundary_smoothing_under_engine_knobs(oracle_lib, monkeypatch, env):
+    """results never depend on the launch arrangement: walk replay place, filters, side streams, dependency mechanism"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    from smoothmesh_amd.surfgen import box_feature_edges, sphere_surface
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = cavity_mesh(10)
+    o, e, prm, on = make_pair(m, oracle_lib, box_feature_edges(10), None, sphere_surface(levels=3), constraints=True,
+                              smoothingPatches=("cavity",))
+    assert on
+    _run_both(o, e, 6)
