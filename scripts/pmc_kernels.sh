@@ -3,7 +3,7 @@
 # Counter collection serialises kernels: a stream that waits for a value written behind a kernel of ANOTHER stream never
 # wakes up (observed: 25 minutes until the outer limit), so the side streams are switched off for these passes and every
 # pass has its own time limit.
-export SMGPU_SIDE_STREAM=0
+export SMGPU_SIDE_STREAM=0   # (the engine also does this by itself when it sees ROCPROF_COUNTER_COLLECTION=1)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 wl=${1:-hex100B}
 out=$root/gpurun_out/pmc_$wl

@@ -162,6 +162,14 @@ static int envInt(const char* name, int def) {
     return v ? std::atoi(v) : def;
 }
 
+// rocprofv3 --pmc serialises kernels: a stream that waits for a value written behind a kernel of another stream would never
+// wake up (observed as a hang until the outer time limit).  Under counter collection the side streams stay off by default.
+static int sideStreamDefault() {
+    const char* v = std::getenv("ROCPROF_COUNTER_COLLECTION");
+    return (v && std::atoi(v) != 0) ? 0 : 1;
+}
+
+
 template <typename T>
 static int devAlloc(smgpu_handle* h, T** out, size_t n) {
     void* p = nullptr;
@@ -458,7 +466,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
                     h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;
-                    if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", 1)) {
+                    if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", sideStreamDefault())) {
                         if (depInit(h)) return cleanup(1);
                         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
                             hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
@@ -1761,7 +1769,7 @@ static int bndTables(smgpu_handle* h) {
         if (devAlloc(h, &h->st.layerNormal, 3 * (size_t)P)) return 1;
         HIP_OK(hipMemsetAsync(h->st.layerNormal, 0, sizeof(double) * 3 * (size_t)P, h->stream));
     }
-    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", 1)) {
+    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", sideStreamDefault())) {
         if (depInit(h)) return 1;
         if (hipStreamCreateWithFlags(&h->bndSide, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->evBndFork, hipEventDisableTiming) != hipSuccess ||
