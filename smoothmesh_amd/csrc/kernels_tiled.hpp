@@ -575,6 +575,88 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     if (FINAL) blockPublish<T>(s, dist, fcount, tile);
 }
 
+// Exchange A of the multi-rank path (local partial sums and closest points of the shared points, SM.C:108-131, 325-387) on the
+// smoothing tiles that hold shared points: the same staged gather as k_smooth_tile instead of k_halo_packA's per-point
+// gathers from global memory (a chain of dependent loads per point).  Writes the own record and its copies in the send slots.
+struct PackView {
+    double* ownA; double* sendA;
+    const int* sendOff; const int* sendSlots;
+    int centroidAll;            // boundary point smoothing: boundary points gather cell centres too (SM.C:116)
+};
+template <int T>
+__global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTileView g, PackView pk, const int* tileList, int nLaunch,
+                                                  int xcdMap) {
+    if (s.acc->stop) return;
+    const int li = launchTile(nLaunch, xcdMap);
+    if (li < 0) return;
+    extern __shared__ double lds[];
+    const SmoothLds L = smoothLds(lds, g);
+    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
+    const SmoothRow R = smoothRow<T>(g, tile, tid);
+    {
+        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
+        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
+        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
+    }
+    __syncthreads();
+    if (!R.mine) return;
+    const int p = R.p;
+    const int slot = s.sharedSlot[p];
+    if (slot < 0) return;
+    const double *cx = L.cx, *cy = L.cy, *cz = L.cz, *nx = L.nx, *ny = L.ny, *nz = L.nz;
+    const int wn4 = R.wn4, wc4 = R.wc4;
+    const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
+    const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
+    const bool internal = m.pflags[p] & PF_INTERNAL;
+    const V3 cur = ldsv(nx, ny, nz, R.selfL);
+    V3 sum = v3(0, 0, 0), r1, r2, r3;
+    int count = 0, hc = 0;
+    if (internal || pk.centroidAll) {
+        SMGPU_ELL_FOREACH_PRE(pc0, pc1, pcRow, wc4, T, {
+            sum = sum + ldsv(cx, cy, cz, e);
+            count = j + 1;
+        })
+    }
+    double l1 = 0, l2 = 0, l3 = 0;
+    int k1 = -1, k2 = -1, k3 = -1;
+    unsigned q1 = 0, q2 = 0, q3 = 0;
+    SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
+        const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
+        if (internal || !(e & 0x8000)) {
+            if (k1 < 0 || len < l1) { l3 = l2; k3 = k2; q3 = q2; l2 = l1; k2 = k1; q2 = q1; l1 = len; k1 = j; q1 = e; }
+            else if (k2 < 0 || len < l2) { l3 = l2; k3 = k2; q3 = q2; l2 = len; k2 = j; q2 = e; }
+            else if (k3 < 0 || len < l3) { l3 = len; k3 = j; q3 = e; }
+        }
+    })
+    if (k2 < 0) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
+    else {
+        r1 = ldsv(nx, ny, nz, q1 & 0x7fff) - cur;
+        r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
+        r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
+        if (g.usePairShare) {
+            const uint16_t* pe = g.pairEll + g.ppBase[tile];
+            hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
+        } else {
+            const int nb = m.ppOff[p];
+            hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
+        }
+    }
+    double rec[SMGPU_HALO_A_DOUBLES];
+    rec[0] = sum.x; rec[1] = sum.y; rec[2] = sum.z;
+    rec[3] = r1.x; rec[4] = r1.y; rec[5] = r1.z;
+    rec[6] = r2.x; rec[7] = r2.y; rec[8] = r2.z;
+    rec[9] = r3.x; rec[10] = r3.y; rec[11] = r3.z;
+    rec[12] = __longlong_as_double(((long long)hc << 32) | (long long)(unsigned int)count);
+    double* o = pk.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
+#pragma unroll
+    for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) o[q] = rec[q];
+    for (int k = pk.sendOff[slot]; k < pk.sendOff[slot + 1]; ++k) {
+        double* d = pk.sendA + (size_t)pk.sendSlots[k] * SMGPU_HALO_A_DOUBLES;
+#pragma unroll
+        for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) d[q] = rec[q];
+    }
+}
+
 // k_smooth_tile on a PERSISTENT grid, software-pipelined over the tile sequence of each workgroup (tile staging takes
 // 21 us of the 45 us kernel on 100^3 and all resident workgroups stage, then compute, in step): while tile k is being
 // computed from LDS, the records of tile k+1 are in flight into registers (their ids were fetched one tile earlier) and

@@ -131,6 +131,7 @@ struct smgpu_handle {
     bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
+    bool packTiles = true;     // SMGPU_PACK_TILES=0: exchange A packed by the per-point kernel (k_halo_packA)
     bool bndOn = false;        // smgpu_set_boundary_smoothing
     hipStream_t bndSide = nullptr;   // k_bnd_normals / k_bnd_feature run next to the geometry kernel
     hipEvent_t evBndFork = nullptr, evBndJoin = nullptr;
@@ -1307,6 +1308,12 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     }
     h->st.sharedSlot = h->dSharedSlot;
     h->st.combA = h->dCombA;
+    h->packTiles = envInt("SMGPU_PACK_TILES", 1) != 0;
+    if (h->useTiles && h->smoothLds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)k_pack_tile<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+        (void)hipFuncSetAttribute((const void*)k_pack_tile<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+        (void)hipFuncSetAttribute((const void*)k_pack_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+    }
     h->st.lStride = SMGPU_HALO_L_LAYERS;
     h->haloOn = true;
     h->haloIter = 0;
@@ -1350,8 +1357,15 @@ int smgpu_iter_begin(smgpu_handle* h) {
     }
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
-                hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
-                                   h->dSendOff, h->dSendSlots, h->sendA, h->bndOn ? 1 : 0);
+                if (h->useTiles && h->nSharedTiles > 0 && h->packTiles) {   // the staged gather of the smoothing tiles
+                    const PackView pk{h->dOwnA, h->sendA, h->dSendOff, h->dSendSlots, h->bndOn ? 1 : 0};
+                    const dim3 grid(tileGrid(h->nSharedTiles, h->xcdMap));
+                    if (h->smoothT == 64) hipLaunchKernelGGL(k_pack_tile<64>, grid, dim3(64), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
+                    else if (h->smoothT == 128) hipLaunchKernelGGL(k_pack_tile<128>, grid, dim3(128), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
+                    else hipLaunchKernelGGL(k_pack_tile<256>, grid, dim3(256), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
+                } else
+                    hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
+                                       h->dSendOff, h->dSendSlots, h->sendA, h->bndOn ? 1 : 0);
                 if (h->layersOn || h->bndOn)   // local normals / neighbour coordinates / feature projections (SM.C:2266, 2286, 2310-2330)
                     hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared,
                                        h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
