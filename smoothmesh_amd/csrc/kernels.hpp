@@ -1135,19 +1135,26 @@ __global__ void __launch_bounds__(kBlock) k_shared_fix(MeshView m, State s, Prm 
     blockPublish<kBlock>(s, dist, fcount, partialBase + blockIdx.x);
 }
 
-// getMeshStats SM.C:1495-1510: min / max edge length
+// getMeshStats SM.C:1495-1510: min / max edge length.  Grid-stride loop, one pair of atomics per workgroup (a few thousand
+// atomics on one word serialise at ~90 per microsecond).
 __global__ void __launch_bounds__(kBlock) k_edge_stats(MeshView m, const double* pts, unsigned long long* minBits,
                                                        unsigned long long* maxBits) {
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    double len = -1.0;
-    if (e < m.nEdges) len = mag(ldv(pts, m.edges[2 * e + 1]) - ldv(pts, m.edges[2 * e]));
-    double mn = (len >= 0.0) ? len : 1.0e300, mx = (len >= 0.0) ? len : 0.0;
+    __shared__ double shMin[kBlock / 64], shMax[kBlock / 64];
+    double mn = 1.0e300, mx = 0.0;
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < m.nEdges; e += gridDim.x * kBlock) {
+        const double len = mag(ldv(pts, m.edges[2 * e + 1]) - ldv(pts, m.edges[2 * e]));
+        mn = (len < mn) ? len : mn;
+        mx = (len > mx) ? len : mx;
+    }
     for (int o = 32; o > 0; o >>= 1) {
         const double a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
         mn = (a < mn) ? a : mn;
         mx = (b > mx) ? b : mx;
     }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0) { shMin[threadIdx.x >> 6] = mn; shMax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) { mn = (shMin[w] < mn) ? shMin[w] : mn; mx = (shMax[w] > mx) ? shMax[w] : mx; }
         atomicMin(minBits, (unsigned long long)__double_as_longlong(mn));
         atomicMax(maxBits, (unsigned long long)__double_as_longlong(mx));
     }

@@ -583,7 +583,7 @@ int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
     std::memcpy(&init[0], &big, 8);
     std::memcpy(&init[1], &zero, 8);
     HIP_OK(hipMemcpyAsync(d, init, 16, hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_edge_stats, dim3(gridFor(h->mv.nEdges)), dim3(kBlock), 0, h->stream, h->mv, h->st.ptsCur, d, d + 1);
+    hipLaunchKernelGGL(k_edge_stats, dim3(std::max(1, std::min(gridFor(h->mv.nEdges), 1024))), dim3(kBlock), 0, h->stream, h->mv, h->st.ptsCur, d, d + 1);
     unsigned long long out[2];
     HIP_OK(hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
