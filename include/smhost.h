@@ -5,7 +5,7 @@
  *
  * Formats: FoamFile header + ascii or binary payload (faceList / faceCompactList, labelList,
  * vectorField, polyBoundaryMesh), label = 32 or 64 bit on read (header `arch`), label=32 /
- * scalar=64 on write.  gz-compressed files are not read (no zlib dependency).
+ * scalar=64 on write.  <file>.gz is read wherever <file> is missing (zlib), as OpenFOAM does.
  * All functions return 0 on success; message through smhost_last_error().
  */
 #ifndef SMHOST_H
@@ -56,6 +56,16 @@ int smhost_write_label_list(const char* file, const char* location, const char* 
 /* Synthetic polyhedral mesh (stands in for snappyHexMesh, BASELINE configs[3-4]): castellated one-level
  * octree mesh of the unit cube with a spherical cavity; see csrc/host/meshgen.cpp. */
 int smhost_gen_cavity_mesh(int32_t N, double radius, double shell, double jitter, uint64_t seed, smhost_mesh** out);
+/* Sub-domain `rank` of the (px, py, pz) box decomposition of that mesh, generated directly in decomposePar layout
+ * (processor patches, local numbering in ascending global order: what processorN/constant/polyMesh would hold; the
+ * reference reads exactly that per rank, testcase/run_parallel:11-19).  Only the box is visited, so no process ever
+ * holds the global mesh.  Coarse cell i of an axis goes to box b with floor(b N / P) <= i < floor((b+1) N / P). */
+int smhost_gen_cavity_subdomain(int32_t N, double radius, double shell, double jitter, uint64_t seed, int32_t px, int32_t py,
+                                int32_t pz, int32_t rank, smhost_mesh** out);
+/* Global ids of a smhost_gen_cavity_subdomain mesh (either pointer may be NULL): per point its index in the global
+ * (2N+1)^3 lattice (unique per global point and ascending with the global point id: a pointProcAddressing for the
+ * shared-point tables), per cell 8 * coarse cell index + child (ascending with the global cell id). */
+int smhost_mesh_global_ids(const smhost_mesh* m, int64_t* pointGlobal, int64_t* cellGlobal);
 
 #ifdef __cplusplus
 }

@@ -7,10 +7,14 @@
 #include "polymesh_io.hpp"
 
 using namespace smhost;
-namespace smhost { void genCavityMesh(int N, double radius, double shell, double jitter, uint64_t seed, PolyMeshData& out); }
+namespace smhost {
+void genCavityMesh(int N, double radius, double shell, double jitter, uint64_t seed, PolyMeshData& out);
+void genCavitySubdomain(int N, double radius, double shell, double jitter, uint64_t seed, const int grid[3], int rank, PolyMeshData& out,
+                        std::vector<int64_t>* pointGlobal, std::vector<int64_t>* cellGlobal);
+}
 
 static thread_local std::string g_err;
-struct smhost_mesh { PolyMeshData d; };
+struct smhost_mesh { PolyMeshData d; std::vector<int64_t> pointGlobal, cellGlobal; };
 
 template <typename F>
 static int guarded(F&& f) {
@@ -120,5 +124,24 @@ int smhost_gen_cavity_mesh(int32_t N, double radius, double shell, double jitter
         catch (...) { delete m; throw; }
         *out = m;
     });
+}
+int smhost_gen_cavity_subdomain(int32_t N, double radius, double shell, double jitter, uint64_t seed, int32_t px, int32_t py, int32_t pz,
+                                int32_t rank, smhost_mesh** out) {
+    return guarded([&] {
+        auto* m = new smhost_mesh();
+        const int grid[3] = {px, py, pz};
+        try { genCavitySubdomain(N, radius, shell, jitter, seed, grid, rank, m->d, &m->pointGlobal, &m->cellGlobal); }
+        catch (...) { delete m; throw; }
+        *out = m;
+    });
+}
+int smhost_mesh_global_ids(const smhost_mesh* m, int64_t* pointGlobal, int64_t* cellGlobal) {
+    if ((int64_t)m->pointGlobal.size() != m->d.nPoints() || (int64_t)m->cellGlobal.size() != m->d.nCells) {
+        g_err = "smhost_mesh_global_ids: this mesh carries no global ids (only smhost_gen_cavity_subdomain meshes do)";
+        return 1;
+    }
+    if (pointGlobal) std::memcpy(pointGlobal, m->pointGlobal.data(), m->pointGlobal.size() * sizeof(int64_t));
+    if (cellGlobal) std::memcpy(cellGlobal, m->cellGlobal.data(), m->cellGlobal.size() * sizeof(int64_t));
+    return 0;
 }
 }

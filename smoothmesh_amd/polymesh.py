@@ -35,6 +35,9 @@ def lib():
         l.smhost_read_obj.argtypes = [C.c_char_p, C.c_int32, f64p, C.POINTER(C.c_int64), i32p, C.POINTER(C.c_int64)]
         l.smhost_write_label_list.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int64, i32p, C.c_int32]
         l.smhost_gen_cavity_mesh.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.POINTER(C.c_void_p)]
+        l.smhost_gen_cavity_subdomain.argtypes = [C.c_int32, C.c_double, C.c_double, C.c_double, C.c_uint64, C.c_int32, C.c_int32, C.c_int32,
+                                                  C.c_int32, C.POINTER(C.c_void_p)]
+        l.smhost_mesh_global_ids.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         _lib = l
     return _lib
 
@@ -48,7 +51,8 @@ def _p(a, t):
     return a.ctypes.data_as(t)
 
 
-def _take(h) -> PolyMesh:
+def _take(h, global_ids=None) -> PolyMesh:
+    """copy a smhost_mesh out and free it; global_ids: a list that receives (pointGlobal, cellGlobal)"""
     l = lib()
     try:
         n = [C.c_int32() for _ in range(5)]
@@ -65,6 +69,10 @@ def _take(h) -> PolyMesh:
             _check(l.smhost_mesh_patch(h, i, name, 256, typ, 64, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
             patches.append(Patch(name.value.decode(), typ.value.decode(), a.value, b.value,
                                  c.value if c.value >= 0 else None, d.value if d.value >= 0 else None))
+        if global_ids is not None:
+            pg, cg = np.empty(nP, np.int64), np.empty(nC, np.int64)
+            _check(l.smhost_mesh_global_ids(h, _p(pg, C.POINTER(C.c_int64)), _p(cg, C.POINTER(C.c_int64))))
+            global_ids.extend([pg, cg])
         return PolyMesh(pts, fo, fp, ow, ne, patches, nC)
     finally:
         l.smhost_mesh_free(h)
@@ -85,6 +93,43 @@ def cavity_mesh(N, radius=0.25, shell=None, jitter=0.2, seed=12345) -> PolyMesh:
     h = C.c_void_p()
     _check(lib().smhost_gen_cavity_mesh(N, radius, shell, jitter, seed, C.byref(h)))
     return _take(h)
+
+
+def cavity_box_of(N, P, i):
+    """box of coarse cell index i along an axis cut into P boxes: floor(b N / P) <= i < floor((b + 1) N / P)"""
+    i = np.asarray(i, np.int64)
+    lo = (np.arange(P + 1, dtype=np.int64) * N) // P
+    return (np.searchsorted(lo, i, side="right") - 1).astype(np.int64)
+
+
+def cavity_subdomain(N, grid, rank, radius=0.25, shell=None, jitter=0.2, seed=12345, with_cells=False):
+    """Sub-domain `rank` of cavity_mesh(N, ...) cut into grid[0] x grid[1] x grid[2] boxes of coarse cells, generated
+    directly in decomposePar layout (csrc/host/meshgen.cpp): identical to decompose(cavity_mesh(N), cavity_partition)[rank]
+    (tests/test_host_logic.py), but no process ever holds the global mesh -- the analogue of meshgen.hex_subdomain for
+    BASELINE configs[4].  pointProcAddressing holds global LATTICE indices (unique per global point, ascending with the
+    global point id), which is all the shared-point tables need."""
+    from .decompose import SubDomain
+    if shell is None:
+        shell = 2.0 / N
+    h = C.c_void_p()
+    _check(lib().smhost_gen_cavity_subdomain(N, radius, shell, jitter, seed, grid[0], grid[1], grid[2], rank, C.byref(h)))
+    ids = []
+    mesh = _take(h, ids)
+    return SubDomain(mesh, rank, grid[0] * grid[1] * grid[2], ids[0], ids[1] if with_cells else None)
+
+
+def cavity_partition(N, grid, radius=0.25, shell=None):
+    """(cellRank of every cell of cavity_mesh(N), global lattice index of every point) under cavity_subdomain's box rule"""
+    if shell is None:
+        shell = 2.0 / N
+    h = C.c_void_p()
+    _check(lib().smhost_gen_cavity_subdomain(N, radius, shell, 0.0, 0, 1, 1, 1, 0, C.byref(h)))
+    ids = []
+    _take(h, ids)
+    coarse = ids[1] // 8
+    ci, cj, ck = coarse % N, (coarse // N) % N, coarse // (N * N)
+    r = cavity_box_of(N, grid[0], ci) + grid[0] * (cavity_box_of(N, grid[1], cj) + grid[1] * cavity_box_of(N, grid[2], ck))
+    return r.astype(np.int32), ids[0]
 
 
 def write_polymesh(polyMeshDir, mesh: PolyMesh, location="constant/polyMesh", binary=False, precision=17):

@@ -115,6 +115,34 @@ def test_decompose_matches_direct_subdomains(grid, nLocal):
     assert np.all(np.diff(off) >= 2)
 
 
+@pytest.mark.parametrize("N,grid", [(8, (2, 1, 1)), (9, (2, 2, 1)), (12, (2, 2, 2)), (11, (3, 2, 1)), (13, (3, 3, 3))])
+def test_cavity_subdomain_matches_decompose_of_the_global_mesh(N, grid):
+    """BASELINE configs[4]: the rank-local polyhedral generator (no global mesh in any process) gives, array for array,
+    what cutting the global castellated mesh in decomposePar layout gives -- hanging-node faces on processor patches,
+    reversed processor faces, points on the cavity wall that only another rank's cell touches (not jittered)"""
+    from smoothmesh_amd.decompose import decompose, shared_point_table
+    from smoothmesh_amd.polymesh import cavity_mesh, cavity_partition, cavity_subdomain
+    g = cavity_mesh(N, jitter=0.2, seed=7)
+    cellRank, lattice = cavity_partition(N, grid)
+    world = grid[0] * grid[1] * grid[2]
+    ref = decompose(g, cellRank, world)
+    subs = [cavity_subdomain(N, grid, r, jitter=0.2, seed=7) for r in range(world)]
+    for r, (a, b) in enumerate(zip(ref, subs)):
+        for f in ("points", "faceOffsets", "facePoints", "owner", "neighbour"):
+            assert np.array_equal(getattr(a.mesh, f), getattr(b.mesh, f)), (r, f)
+        assert a.mesh.nCells == b.mesh.nCells
+        key = lambda m: [(p.name, p.type, p.nFaces, p.startFace, p.myProcNo, p.neighbProcNo) for p in m.patches]
+        assert key(a.mesh) == key(b.mesh)
+        assert np.array_equal(lattice[a.pointProcAddressing], b.pointProcAddressing)
+    # polygonal faces (hanging mid-edge points) do lie on processor patches, and some points have >= 3 sharers
+    if world >= 4:
+        off, dom, loc = shared_point_table(subs)
+        assert np.diff(off).max() >= 3
+    sizes = np.concatenate([np.diff(s.mesh.faceOffsets)[p.startFace:p.startFace + p.nFaces] for s in subs for p in s.mesh.patches
+                            if p.type == "processor"])
+    assert sizes.max() > 4
+
+
 def test_halo_tables_are_symmetric():
     from smoothmesh_amd.halo import HaloTables
     from smoothmesh_amd.meshgen import hex_subdomain
