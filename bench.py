@@ -8,9 +8,16 @@ relTol 0 (exactly K iterations run).  Inputs are device-resident when the timed 
 
   python bench.py --gpus N --steps K --warmup W [--workload hex100|hex100c|hexN[c]]
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): weak scaling -- every rank owns a
-100^3 sub-block of a (Px*100, Py*100, Pz*100) block, shared-point values are exchanged per iteration
-with RCCL all_to_all (smoothmesh_amd/halo.py); value = all ranks' points * K / max-over-ranks time.
+N > 1, one rank per GPU (started by torch.distributed.run, or by this script itself when WORLD_SIZE is unset): weak
+scaling -- hexN: every rank owns an N^3 sub-block of a (Px*N, Py*N, Pz*N) block; cavityN: the castellated polyhedral
+cavity mesh on a round(N * world^(1/3))^3 base grid cut into Px x Py x Pz boxes (BASELINE configs[4]: cavity215 on 8
+GPUs = the 430^3-base, ~80 M-cell mesh), every rank generating ITS box only (polymesh.cavity_subdomain).  Shared-point
+values are exchanged per iteration with RCCL all_to_all (smoothmesh_amd/halo.py); value = all ranks' points * K /
+max-over-ranks time.
+
+The default N = 1 run also measures BASELINE.json's other single-GPU configurations (configs[2] hex100c, configs[3]
+cavity215c and its constraints-off twin) with a bounded number of steps and reports them under "configs" in the same
+JSON line (--no-configs skips that, --configs a,b,c selects).
 """
 import argparse
 import json
@@ -105,12 +112,140 @@ def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False, b
     return {
         "value": mesh.nPoints * iters / dt, "unit": "points/s", "cores": 1, "kind": "port",
         "sample": f"{iters} iterations of the {kind}{sample_n} mesh ({mesh.nPoints} points, {mesh.nCells} cells), serial oracle "
-                  f"(g++ -O2 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
+                  f"(g++ -O3 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
                   f"so it is faster than the real reference"
                   + ("; with boundary point smoothing the oracle tests every target triangle per ray where OpenFOAM walks an "
                      "octree, so THIS number is slower than the real reference and no fair baseline" if boundary else ""),
         "host_cpus": os.cpu_count(),
     }
+
+
+def workload_text(kind, n_side, constraints, layers, boundary, world=1, n_global=None):
+    if kind == "hex":
+        w = f"{n_side}^3-cell uniform hex block per GPU (blockMesh numbering)"
+    elif world == 1:
+        w = (f"castellated polyhedral cube-with-sphere-cavity, {n_side}^3 base grid + one 2:1 refinement shell "
+             f"(own generator standing in for snappyHexMesh)")
+    else:
+        w = (f"castellated polyhedral cube-with-sphere-cavity, {n_global}^3 base grid + one 2:1 refinement shell (own generator "
+             f"standing in for snappyHexMesh + decomposePar), cut into {world} boxes, one per GPU, each rank generating its own")
+    cfg = (2 if constraints else 1) if kind == "hex" else (3 if world == 1 else 4)
+    return (w + f", interior jitter 0.2h seed 12345, "
+            f"{'edgeAngle+faceAngle constraints on (minAngle 35 / maxAngle 160)' if constraints else 'constraints off'}, "
+            + ("boundary layer treatment on (" + ("all six sides" if kind == "hex" else "the cavity wall") + ", default layer options), "
+               if layers else "") +
+            f"relTol 0, defaults otherwise (BASELINE.json configs[{cfg}]"
+            + (" + -layerPatches" if layers else "") + (" + constant/geometry/*.obj" if boundary else "") + ")"
+            + (", boundary point smoothing on (" + ("all sides onto the block's own surface and feature edges" if kind == "hex"
+                                                     else "the cavity wall onto the triangulated sphere") + ")" if boundary else ""))
+
+
+def kernel_report(workload, ctr, K, dt, dt_ev):
+    """roofline objects + per-kernel table from the hipEvent counters of the second pass"""
+    # HBM traffic per launch, measured separately under rocprofv3 --pmc (scripts/measure_traffic.sh) and
+    # committed under profiles/; None when no measurement of this workload exists
+    traffic = None
+    tdoc = None
+    for rnd in ("r2", "r1"):
+        tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{workload}.json")
+        if os.path.exists(tpath):
+            tdoc = json.load(open(tpath))
+            break
+    ctr = sorted(ctr, key=lambda c: -c["ms"])
+    # dominant device kernel (not pack/finish, not the walk stages whose cost is latency)
+    dom = [c for c in ctr if c["algoBytesPerLaunch"] > 1024 and c["name"] not in ("k_fa_walk", "k_fa_pred")][0]
+    avg_s = dom["ms"] / dom["launches"] * 1e-3
+    achieved = dom["algoBytesPerLaunch"] / avg_s / 1e9
+    if tdoc:
+        for kname, kv in tdoc["kernels"].items():
+            if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
+                traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
+    gather = next((c for c in ctr if c["name"].startswith("k_smooth")), None)
+    return {
+        "roofline": {
+            "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
+            "avg_launch_us": avg_s * 1e6,
+            # the geometry kernel is FP64-VALU bound, not HBM bound: its rate of algorithmic FP64 instructions (per
+            # element; sqrt = 22, division = 11 as expanded; no FMA contraction, as the reference's x86-64 build)
+            # against the chip's FP64 vector instruction rate (256 CUs x 64 lanes x 2.4 GHz = 39.3 T/s = 78.6 TFLOP/s FMA)
+            **({"valu_f64": {"algorithmic_ops_per_launch": int(dom["algoF64OpsPerLaunch"]),
+                             "achieved_Tops": dom["algoF64OpsPerLaunch"] / avg_s / 1e12, "peak_Tops": FP64_VALU_PEAK_TOPS,
+                             "frac": dom["algoF64OpsPerLaunch"] / avg_s / 1e12 / FP64_VALU_PEAK_TOPS}}
+               if dom.get("algoF64OpsPerLaunch") else {}),
+            "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
+                    "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
+                    "cache-level throughput, not as an HBM-roofline test",
+        },
+        "roofline_centroid_gather": None if gather is None else {
+            "bound": "hbm", "kernel": gather["name"], "achieved": gather["algoBytesPerLaunch"] / (gather["ms"] / gather["launches"] * 1e-3) / 1e9,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gather["algoBytesPerLaunch"] / (gather["ms"] / gather["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names)"},
+        "kernels": [
+            {"name": c["name"], "launches": int(c["launches"]), "avg_us": c["ms"] / c["launches"] * 1e3,
+             "algo_GBps": c["algoBytesPerLaunch"] / (c["ms"] / c["launches"] * 1e-3) / 1e9} for c in ctr],
+        "ms_per_step_with_events": dt_ev / K * 1e3,
+    }
+
+
+def run_single(workload, K, W, device):
+    """one GPU, one workload: K timed steps (inputs resident), then the same K steps again with per-kernel hipEvents"""
+    import torch
+    from smoothmesh_amd import SmoothEngine, default_params
+    kind, n_side, constraints = parse_workload(workload)
+    layers, boundary = workload_layers(workload), workload_boundary(workload)
+    mesh = make_mesh(kind, n_side)
+    eng = SmoothEngine(mesh, device=device)
+    prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    eng.set_params(prm)
+    if layers and not eng.set_layers(layer_params(kind), prm.minEdgeLength):
+        raise SystemExit("boundary layer treatment could not be enabled")
+    if boundary and not eng.set_boundary_smoothing(boundary_params(kind, n_side), prm.minEdgeLength)["enabled"]:
+        raise SystemExit("boundary point smoothing could not be enabled")
+    if W:
+        eng.iterate(W, 0.0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n, res, frz = eng.iterate(K, 0.0)          # returns after the stream has drained
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert n == K
+    # second pass over the same K steps with per-kernel hipEvent brackets (on the engine's stream)
+    eng.reset_counters()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    eng.iterate(K, 0.0)
+    dt_ev = time.perf_counter() - t0
+    eng.enable_timing(False)
+    ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
+    sizes = eng.sizes()
+    nPoints = mesh.nPoints
+    eng.close()
+    del eng, mesh
+    return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_ev=dt_ev, ctr=ctr,
+                sizes=sizes, total_points=nPoints, res=res, frz=frz)
+
+
+def self_launch(args):
+    """--gpus N > 1 without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run) BEFORE
+    anything in this process touches the GPU, relay rank 0's JSON line and exit with the launcher's code"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for line in r.stdout.splitlines():
+        if line.startswith("{"):
+            print(line, flush=True)
+    raise SystemExit(r.returncode)
 
 
 def main():
@@ -120,29 +255,33 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="hex100")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--configs", default=None, help="comma-separated workloads reported under \"configs\" (N = 1); "
+                    "default with the default workload: hex100c,cavity215,cavity215c")
+    ap.add_argument("--no-configs", action="store_true")
+    ap.add_argument("--config-steps", type=int, default=30)
     args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)            # does not return
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
 
     import numpy as np
     import torch
-    from smoothmesh_amd import SmoothEngine, default_params
-    from smoothmesh_amd.meshgen import hex_block
 
     kind, n_side, constraints = parse_workload(args.workload)
     layers = workload_layers(args.workload)
     boundary = workload_boundary(args.workload)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch with python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no GPU visible); there is no CPU fallback")
     if os.environ.get("SMOOTHMESH_SHARE_GPU"):      # debugging aid: several ranks on one GPU
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
+    n_global = None
 
     # SMOOTHMESH_FORCE_DIST=1: run the N=1 case through the multi-rank code path (host-overhead measurements)
     force_dist = world == 1 and bool(os.environ.get("SMOOTHMESH_FORCE_DIST"))
@@ -150,35 +289,12 @@ def main():
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
             os.environ.setdefault(k, v)
     if world == 1 and not force_dist:
-        mesh = make_mesh(kind, n_side)
-        eng = SmoothEngine(mesh, device=local_rank)
-        prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
-        eng.set_params(prm)
-        if layers and not eng.set_layers(layer_params(kind), prm.minEdgeLength):
-            raise SystemExit("boundary layer treatment could not be enabled")
-        if boundary and not eng.set_boundary_smoothing(boundary_params(kind, n_side), prm.minEdgeLength)["enabled"]:
-            raise SystemExit("boundary point smoothing could not be enabled")
-        if W:
-            eng.iterate(W, 0.0)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n, res, frz = eng.iterate(K, 0.0)          # returns after the stream has drained
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        assert n == K
-        total_points = mesh.nPoints
-        # second pass over the same K steps with per-kernel hipEvent brackets (on the engine's stream)
-        eng.reset_counters()
-        eng.enable_timing(True)
-        t0 = time.perf_counter()
-        eng.iterate(K, 0.0)
-        dt_ev = time.perf_counter() - t0
-        eng.enable_timing(False)
-        ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
-        sizes = eng.sizes()
+        r = run_single(args.workload, K, W, local_rank)
+        dt, dt_ev, ctr, sizes, total_points, res, frz = r["dt"], r["dt_ev"], r["ctr"], r["sizes"], r["total_points"], r["res"], r["frz"]
         parallelism = "1 GPU"
     else:
         import torch.distributed as dist
+        from smoothmesh_amd import default_params
         from smoothmesh_amd.halo import DistributedSmoother
         from smoothmesh_amd.meshgen import hex_subdomain
         backend = os.environ.get("SMOOTHMESH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" = debug only
@@ -189,11 +305,10 @@ def main():
         grid = proc_grid(world)
         if kind == "hex":      # weak scaling: every rank generates its own n^3 sub-domain of the global block
             sub = hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345)
-        else:                  # polyhedral: the GLOBAL mesh of the workload, cut geometrically (strong scaling in N)
-            from smoothmesh_amd.decompose import decompose, grid_partition
-            gmesh = make_mesh(kind, n_side)
-            sub = decompose(gmesh, grid_partition(gmesh, grid), world)[rank]
-            del gmesh
+        else:                  # polyhedral, weak scaling: base grid grown with the rank count, every rank generates ITS box only
+            from smoothmesh_amd.polymesh import cavity_subdomain
+            n_global = int(round(n_side * world ** (1.0 / 3.0)))
+            sub = cavity_subdomain(n_global, grid, rank, jitter=0.2, seed=12345)
         ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
         prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         ds.set_params(prm)
@@ -248,20 +363,6 @@ def main():
             dist.destroy_process_group()
         return
 
-    # HBM traffic per launch, measured separately under rocprofv3 --pmc (scripts/measure_traffic.sh) and
-    # committed under profiles/; None when no measurement of this workload exists
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r1", f"traffic_{args.workload}.json")
-    tdoc = json.load(open(tpath)) if os.path.exists(tpath) else None
-    ctr.sort(key=lambda c: -c["ms"])
-    # dominant device kernel (not pack/finish, not the walk stages whose cost is latency / the host replay)
-    dom = [c for c in ctr if c["algoBytesPerLaunch"] > 1024 and c["name"] not in ("k_fa_walk", "k_fa_pred")][0]
-    avg_s = dom["ms"] / dom["launches"] * 1e-3
-    achieved = dom["algoBytesPerLaunch"] / avg_s / 1e9
-    if tdoc:
-        for kname, kv in tdoc["kernels"].items():
-            if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
-                traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
     out = {
         "metric": "mesh-points smoothed/sec/node (100 iters) + achieved HBM GB/s vs roofline",
         "value": total_points * K / dt,
@@ -271,58 +372,43 @@ def main():
         "warmup": W,
         "ms_per_step": dt / K * 1e3,
         "higher_is_better": True,
-        "scaling": "weak" if (world == 1 or kind == "hex") else "strong",
+        "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": (f"{n_side}^3-cell uniform hex block per GPU (blockMesh numbering)" if kind == "hex" else
-                         f"castellated polyhedral cube-with-sphere-cavity, {n_side}^3 base grid + one 2:1 refinement shell "
-                         f"(own generator standing in for snappyHexMesh)") +
-                        f", interior jitter 0.2h seed 12345, "
-                        f"{'edgeAngle+faceAngle constraints on (minAngle 35 / maxAngle 160)' if constraints else 'constraints off'}, "
-                        + ("boundary layer treatment on (" + ("all six sides" if kind == "hex" else "the cavity wall") + ", default layer options), "
-                           if layers else "") +
-                        f"relTol 0, defaults otherwise (BASELINE.json configs[{(2 if constraints else 1) if kind == 'hex' else 3}]"
-                        + (" + -layerPatches" if layers else "") + (" + constant/geometry/*.obj" if boundary else "") + ")"
-                        + (", boundary point smoothing on (" + ("all sides onto the block's own surface and feature edges" if kind == "hex"
-                                                                 else "the cavity wall onto the triangulated sphere") + ")" if boundary else ""),
+            "workload": workload_text(kind, n_side, constraints, layers, boundary, world, n_global),
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
             "parallelism": parallelism,
         },
-        "roofline": {
-            "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
-            "avg_launch_us": avg_s * 1e6,
-            # the geometry kernel is FP64-VALU bound, not HBM bound: its rate of algorithmic FP64 instructions (per
-            # element; sqrt = 22, division = 11 as expanded; no FMA contraction, as the reference's x86-64 build)
-            # against the chip's FP64 vector instruction rate (256 CUs x 64 lanes x 2.4 GHz = 39.3 T/s = 78.6 TFLOP/s FMA)
-            **({"valu_f64": {"algorithmic_ops_per_launch": int(dom["algoF64OpsPerLaunch"]),
-                             "achieved_Tops": dom["algoF64OpsPerLaunch"] / avg_s / 1e12, "peak_Tops": FP64_VALU_PEAK_TOPS,
-                             "frac": dom["algoF64OpsPerLaunch"] / avg_s / 1e12 / FP64_VALU_PEAK_TOPS}}
-               if dom.get("algoF64OpsPerLaunch") else {}),
-            "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
-                    "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
-                    "cache-level throughput, not as an HBM-roofline test",
-        },
-        "roofline_centroid_gather": (lambda g: None if g is None else {
-            "bound": "hbm", "kernel": g["name"], "achieved": g["algoBytesPerLaunch"] / (g["ms"] / g["launches"] * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": g["algoBytesPerLaunch"] / (g["ms"] / g["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names)"})(
-                next((c for c in ctr if c["name"].startswith("k_smooth")), None)),
-        "kernels": [
-            {"name": c["name"], "launches": int(c["launches"]), "avg_us": c["ms"] / c["launches"] * 1e3,
-             "algo_GBps": c["algoBytesPerLaunch"] / (c["ms"] / c["launches"] * 1e-3) / 1e9} for c in ctr],
-        "ms_per_step_with_events": dt_ev / K * 1e3,
+        **kernel_report(args.workload, ctr, K, dt, dt_ev),
         "residual_last": float(res[-1]), "nFrozenPoints_last": int(frz[-1]),
+        "parity": "HIP == CPU oracle (tests/); the oracle restates the reference and is unpinned against a real OpenFOAM build",
     }
     if force_dist:
         out["config"]["parallelism"] += " [N=1 forced through the multi-rank path]"
-    if world == 1 and not force_dist and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers, boundary=boundary)
-        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    if world == 1 and not force_dist:
+        # BASELINE.json's other single-GPU configurations, measured by this same run (bounded steps)
+        names = [] if args.no_configs else (args.configs.split(",") if args.configs is not None else
+                                            (["hex100c", "cavity215", "cavity215c"] if args.workload == "hex100" else []))
+        subs = []
+        for wl in [w for w in names if w]:
+            t0 = time.perf_counter()
+            Kc = args.config_steps
+            r = run_single(wl, Kc, min(W, 5), local_rank)
+            subs.append({
+                "workload": wl, "config": workload_text(r["kind"], r["n_side"], r["constraints"], r["layers"], r["boundary"]),
+                "points": int(r["total_points"]), "cells": int(r["sizes"]["nCells"]), "steps": Kc,
+                "ms_per_step": r["dt"] / Kc * 1e3, "value": r["total_points"] * Kc / r["dt"], "unit": "points/s",
+                **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"]),
+                "residual_last": float(r["res"][-1]), "nFrozenPoints_last": int(r["frz"][-1]),
+                "wall_s_including_setup": time.perf_counter() - t0,
+            })
+        if subs:
+            out["configs"] = subs
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers, boundary=boundary)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out))
     if world > 1 or force_dist:
         import torch.distributed as dist

@@ -6,6 +6,7 @@
 #include <chrono>
 #include <future>
 #include <memory>
+#include <mutex>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -233,15 +234,23 @@ static int launchK(smgpu_handle* h, int k, F&& f, hipStream_t stream = nullptr) 
 enum { DEP_FORK = 0, DEP_JOIN = 1, DEP_TO_EXCH = 2, DEP_FROM_EXCH = 3, DEP_BND_FORK = 4, DEP_BND_JOIN = 5, DEP_COUNT = 6 };
 static int depInit(smgpu_handle* h) {
     if (h->depWords || !envInt("SMGPU_STREAM_OPS", 1)) return 0;
+    int can = 0;
+    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can) { (void)hipGetLastError(); return 0; }
     if (hipMalloc((void**)&h->depWords, DEP_COUNT * 64) != hipSuccess) { (void)hipGetLastError(); h->depWords = nullptr; return 0; }
     if (hipMemset(h->depWords, 0, DEP_COUNT * 64) != hipSuccess) return fail("hipMemset failed");
     h->streamOps = true;
     return 0;
 }
-// `from` has reached this point  ==>  everything enqueued on `to` afterwards may start
+// `from` has reached this point  ==>  everything enqueued on `to` afterwards may start.
+// A failing stream memory operation switches the handle to events for good: the pair (signal, wait) of one dependency
+// always uses the same mechanism because the switch happens inside depSignal, before its wait is enqueued.
 static int depSignal(smgpu_handle* h, int kind, hipStream_t from, hipEvent_t ev) {
-    if (h->streamOps) { HIP_OK(hipStreamWriteValue32(from, h->depWords + 16 * kind, ++h->depValue[kind], 0)); }
-    else HIP_OK(hipEventRecord(ev, from));
+    if (h->streamOps) {
+        if (hipStreamWriteValue32(from, h->depWords + 16 * kind, ++h->depValue[kind], 0) == hipSuccess) return 0;
+        (void)hipGetLastError();
+        h->streamOps = false;
+    }
+    HIP_OK(hipEventRecord(ev, from));
     return 0;
 }
 static int depWait(smgpu_handle* h, int kind, hipStream_t to, hipEvent_t ev) {
@@ -578,6 +587,7 @@ int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
     HIP_OK(hipSetDevice(h->device));
     unsigned long long* d = nullptr;
     HIP_OK(hipMalloc((void**)&d, 16));
+    struct Release { void* p; ~Release() { if (p) (void)hipFree(p); } } release{d};
     const double big = 1.0e300, zero = 0.0;
     unsigned long long init[2];
     std::memcpy(&init[0], &big, 8);
@@ -587,7 +597,6 @@ int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
     unsigned long long out[2];
     HIP_OK(hipMemcpyAsync(out, d, 16, hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
-    HIP_OK(hipFree(d));
     std::memcpy(minEdge, &out[0], 8);
     std::memcpy(maxEdge, &out[1], 8);
     return 0;
@@ -605,20 +614,26 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
 }
 
 extern "C++" {
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (kernel, device), not of a handle: several handles with
+// different tile capacities (SMGPU_*_CAP*), or on several devices, share it.  Raise it to the largest request seen so far.
+template <typename K>
+static void ensureDynLds(K kernel, int device, size_t bytes) {
+    static std::mutex mu;
+    static size_t have[64] = {0};
+    if (bytes <= 64 * 1024 || device < 0 || device >= 64) return;
+    std::lock_guard<std::mutex> lock(mu);
+    if (have[device] >= bytes) return;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) have[device] = bytes;
+    else (void)hipGetLastError();
+}
 template <int T>
 static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles) {
-    static bool attrSet = false;
-    if (!attrSet) {
-        if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
-        attrSet = true;
-    }
+    ensureDynLds(k_geom_tile<T>, h->device, h->geomLds);
     if (h->geomPersist) {
         // persistent, software-pipelined form: as many workgroups as the chip holds at once (8 XCDs x 32 CUs)
-        static int perCu = 0;
-        if (!perCu) {
-            if (h->geomLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_geom_tile_p<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geomLds);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_geom_tile_p<T>, T, h->geomLds) != hipSuccess || perCu < 1) perCu = 2;
-        }
+        ensureDynLds(k_geom_tile_p<T>, h->device, h->geomLds);
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_geom_tile_p<T>, T, h->geomLds) != hipSuccess || perCu < 1) perCu = 2;
         const int per = (nTiles + 7) >> 3;
         const int wgPerXcd = std::min(per, perCu * 32);
         const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
@@ -633,17 +648,11 @@ static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, i
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
-    static bool attrSet = false;
-    if (!attrSet) {
-        if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
-        attrSet = true;
-    }
+    ensureDynLds(k_smooth_tile<FINAL, T>, h->device, h->smoothLds);
     if (h->smoothPersist) {
-        static int perCu = 0;
-        if (!perCu) {
-            if (h->smoothLds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_smooth_tile_p<FINAL, T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_smooth_tile_p<FINAL, T>, T, h->smoothLds) != hipSuccess || perCu < 1) perCu = 2;
-        }
+        ensureDynLds(k_smooth_tile_p<FINAL, T>, h->device, h->smoothLds);
+        int perCu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_smooth_tile_p<FINAL, T>, T, h->smoothLds) != hipSuccess || perCu < 1) perCu = 2;
         const int per = (nTiles + 7) >> 3;
         const int wgPerXcd = std::min(per, perCu * 32);
         const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
@@ -1063,6 +1072,14 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     if (nIters == 0) return 0;
     HIP_OK(hipSetDevice(h->device));
     if (h->statsCap < nIters) {
+        if (h->dStats) {   // outgrown: release it (nothing is in flight between two smgpu_iterate calls)
+            HIP_OK(hipStreamSynchronize(h->stream));
+            h->allocs.erase(std::remove(h->allocs.begin(), h->allocs.end(), (void*)h->dStats), h->allocs.end());
+            h->deviceBytes -= (int64_t)(sizeof(smgpu_iter_stats) * (size_t)h->statsCap);
+            (void)hipFree(h->dStats);
+            h->dStats = nullptr;
+            h->statsCap = 0;
+        }
         if (devAlloc(h, &h->dStats, (size_t)nIters)) return 1;
         h->statsCap = nIters;
     }
@@ -1166,10 +1183,14 @@ int smgpu_reset_counters(smgpu_handle* h) {
 }
 
 // ---- multi-rank ----------------------------------------------------------------------------------
+static int exchAfterCompute(smgpu_handle* h);
 int smgpu_halo_set_stats_history(smgpu_handle* h, void* history, int32_t capacity) {
     if (!h) return fail("null handle");
     if (history && capacity <= 0) return fail("smgpu_halo_set_stats_history: capacity must be positive");
+    // closes the last iteration of a loop; the host reads the history on its exchange stream next
+    const bool pendingRecord = h->deferN > 0;
     if (flushDeferred(h)) return 1;
+    if (pendingRecord && h->haloOn && exchAfterCompute(h)) return 1;
     h->statsHistory = (double*)history;
     h->statsHistoryCap = history ? capacity : 0;
     h->statsHistoryN = 0;
@@ -1309,10 +1330,10 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     h->st.sharedSlot = h->dSharedSlot;
     h->st.combA = h->dCombA;
     h->packTiles = envInt("SMGPU_PACK_TILES", 1) != 0;
-    if (h->useTiles && h->smoothLds > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)k_pack_tile<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
-        (void)hipFuncSetAttribute((const void*)k_pack_tile<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
-        (void)hipFuncSetAttribute((const void*)k_pack_tile<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->smoothLds);
+    if (h->useTiles) {
+        ensureDynLds(k_pack_tile<64>, h->device, h->smoothLds);
+        ensureDynLds(k_pack_tile<128>, h->device, h->smoothLds);
+        ensureDynLds(k_pack_tile<256>, h->device, h->smoothLds);
     }
     h->st.lStride = SMGPU_HALO_L_LAYERS;
     h->haloOn = true;
@@ -1344,6 +1365,9 @@ int smgpu_iter_begin(smgpu_handle* h) {
         if (runGeometry(h, h->dGeomShared, h->nGeomShared)) return 1;
         h->geomAheadDone = false;
     } else if (runGeometry(h)) return 1;
+    // a rank without shared geometry tiles launched nothing above: the previous iteration's reduction, parked for that
+    // launch by smgpu_iter_end, must not wait for the next one (smgpu_iter_mid overwrites the partials before it)
+    if (flushDeferred(h)) return 1;
     if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;

@@ -56,3 +56,104 @@ def test_local_multi_smoother_matches_multi_oracle(oracle_lib, grid, constraints
     gs, ps = g[order], allp[order]
     same = gs[1:] == gs[:-1]
     assert np.array_equal(ps[1:][same], ps[:-1][same])
+
+
+def _poly_case(oracle_lib, N, grid, constraints, jitter=0.2, seed=4):
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.polymesh import cavity_subdomain
+    world = grid[0] * grid[1] * grid[2]
+    subs = [cavity_subdomain(N, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    for o in orcs:
+        o.set_params(prm)
+    table = shared_point_table(subs)
+    return subs, orcs, prm, table, oracle_lib.MultiOracle(orcs, *table)
+
+
+# BASELINE configs[4]'s workload in small: the castellated POLYHEDRAL cavity mesh cut into boxes by planes that pass through the
+# refinement shell -- irregular shared sets, hanging-node (5..8-vertex) faces on processor patches, reversed processor
+# faces, refinement-interface points shared by four ranks (the centre line).  N = 20: the sub-domains span several tiles.
+@pytest.mark.parametrize("N,grid,constraints,overlap", [
+    (10, (2, 1, 1), False, 0), (10, (2, 1, 1), True, 0), (12, (2, 2, 1), False, 1), (12, (2, 2, 1), True, 0),
+    (12, (2, 2, 2), False, 0), (12, (2, 2, 2), True, 1), (11, (3, 1, 2), True, 0), (20, (2, 2, 2), False, 1), (20, (2, 1, 2), True, 0)])
+def test_polyhedral_decomposition_matches_multi_oracle(oracle_lib, N, grid, constraints, overlap):
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    subs, orcs, prm, (off, dom, loc), mo = _poly_case(oracle_lib, N, grid, constraints)
+    world = len(subs)
+    if world >= 4:
+        # a point with >= 3 sharers that lies on a polygonal (hanging-node) face: a refinement-interface point on a processor patch
+        found = False
+        for i in np.flatnonzero(np.diff(off) >= 3):
+            d, l = int(dom[off[i]]), int(loc[off[i]])
+            m = subs[d].mesh
+            faces = np.searchsorted(m.faceOffsets, np.flatnonzero(m.facePoints == l), side="right") - 1
+            if np.any(np.diff(m.faceOffsets)[faces] > 4):
+                found = True
+                break
+        assert found
+    ms = LocalMultiSmoother(subs, device=0, overlap=bool(overlap))
+    assert ms.global_min_edge() == min(o.mesh_stats()[0] for o in orcs)
+    ms.set_params(prm)
+    n_o, res_o, frz_o = mo.iterate(7, 0.0)
+    n_g, res_g, frz_g = ms.iterate(7, 0.0)
+    assert n_o == n_g
+    assert np.array_equal(frz_o, frz_g)
+    assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
+    for o, pts in zip(orcs, ms.get_points()):
+        assert rel_linf(pts, o.points()) <= 1e-13
+    if constraints:
+        assert frz_g[-1] > sum(int((~s.mesh.find_internal_points().astype(bool)).sum()) for s in subs)   # the constraints did freeze points
+    # duplicated (shared) points stay bit-identical across the engines that hold them
+    g = np.concatenate([s.pointProcAddressing for s in subs])
+    allp = np.concatenate(ms.get_points())
+    order = np.argsort(g, kind="stable")
+    gs, ps = g[order], allp[order]
+    same = gs[1:] == gs[:-1]
+    assert same.any() and np.array_equal(ps[1:][same], ps[:-1][same])
+
+
+def test_distributed_smoother_polyhedral_two_processes():
+    """One process per rank (torch.distributed.run) with the real engines, two ranks sharing this box's GPU through the gloo
+    debug transport: DistributedSmoother on the two halves of the polyhedral cavity mesh (each rank generates its own)
+    equals the oracle's MultiDomain bit for bit, constraints off and on, in order and overlapped (scripts/check_dist_poly.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMOOTHMESH_SHARE_GPU="1", SMOOTHMESH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29523", os.path.join(root, "scripts", "check_dist_poly.py")],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": ok ") == 8 and "BAD" not in r.stdout
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_single_rank_distributed_history_equals_serial(oracle_lib, overlap):
+    """A rank without shared points launches no geometry in smgpu_iter_begin once the look-ahead has done every tile: the
+    end-of-iteration reduction parked for that launch must still close ITS iteration (the per-iteration residual /
+    nFrozenPoints records used to slip by one iteration).  world = 1 through the multi-rank path against the serial loop."""
+    import socket
+    import torch.distributed as dist
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.halo import DistributedSmoother
+    from smoothmesh_amd.meshgen import hex_block, hex_subdomain
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        sub = hex_subdomain((14, 12, 10), (1, 1, 1), 0, jitter=0.3, seed=5)
+        ds = DistributedSmoother(sub, device=0, overlap=overlap)
+        prm = default_params(ds.global_min_edge(), edgeAngleConstraint=False, faceAngleConstraint=False)
+        ds.set_params(prm)
+        n_d, res_d, frz_d = ds.iterate(9, 0.0)
+        eng = SmoothEngine(hex_block(14, 12, 10, lengths=(1.0, 1.0, 1.0), jitter=0.3, seed=5), device=0)
+        eng.set_params(prm)
+        n_s, res_s, frz_s = eng.iterate(9, 0.0)
+        assert n_d == n_s == 9
+        assert np.array_equal(frz_d, frz_s)
+        assert np.array_equal(res_d, res_s)
+        assert np.array_equal(ds.get_points(), eng.get_points())
+    finally:
+        dist.destroy_process_group()

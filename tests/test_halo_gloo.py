@@ -20,6 +20,16 @@ def _free_port():
     return p
 
 
+def _subdomain(nLocal, grid, rank, jitter, seed):
+    """nLocal = (nx, ny, nz): structured hex block per rank; nLocal = N: box `rank` of the castellated polyhedral cavity mesh
+    on an N^3 base grid (BASELINE configs[4]'s family: irregular shared sets, hanging-node faces on processor patches)"""
+    if isinstance(nLocal, int):
+        from smoothmesh_amd.polymesh import cavity_subdomain
+        return cavity_subdomain(nLocal, grid, rank, jitter=jitter, seed=seed)
+    from smoothmesh_amd.meshgen import hex_subdomain
+    return hex_subdomain(nLocal, grid, rank, jitter=jitter, seed=seed)
+
+
 def _worker(rank, world, port, grid, nLocal, jitter, seed, constraints, iters, relTol, out_dir, layerPatches=()):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -30,7 +40,7 @@ def _worker(rank, world, port, grid, nLocal, jitter, seed, constraints, iters, r
     from smoothmesh_amd.halo import DistributedSmoother
     from smoothmesh_amd.meshgen import hex_subdomain
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    sub = hex_subdomain(nLocal, grid, rank, jitter=jitter, seed=seed)
+    sub = _subdomain(nLocal, grid, rank, jitter, seed)
     ds = DistributedSmoother(sub, engine_factory=OracleRankEngine, torch_device=torch.device("cpu"))
     prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     ds.set_params(prm)
@@ -49,7 +59,7 @@ def _expected(grid, nLocal, jitter, seed, constraints, iters, relTol, layerPatch
     from smoothmesh_amd.decompose import shared_point_table
     from smoothmesh_amd.meshgen import hex_subdomain
     world = grid[0] * grid[1] * grid[2]
-    subs = [hex_subdomain(nLocal, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+    subs = [_subdomain(nLocal, grid, r, jitter, seed) for r in range(world)]
     orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
     prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     for o in orcs:
@@ -82,6 +92,26 @@ def test_distributed_smoother_gloo(tmp_path, oracle_lib, grid, constraints, relT
         assert np.array_equal(d["pts"], pts_e[r])
     if relTol > 0:
         assert n_e < iters
+
+
+@pytest.mark.parametrize("grid,constraints", [((2, 1, 1), True), ((2, 2, 1), False), ((1, 2, 2), True)])
+def test_distributed_smoother_gloo_polyhedral(tmp_path, oracle_lib, grid, constraints):
+    """BASELINE configs[4]'s workload in small: the polyhedral cavity mesh cut into boxes, every rank generating its own
+    sub-domain; the cuts pass through the refinement shell, so hanging-node faces lie on the processor patches and the
+    centre line is shared by four ranks"""
+    import torch.multiprocessing as mp
+    world = grid[0] * grid[1] * grid[2]
+    N, jitter, seed, iters = 10, 0.2, 4, 5
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, grid, N, jitter, seed, constraints, iters, 0.0, str(tmp_path)), nprocs=world, join=True)
+    n_e, res_e, frz_e, pts_e = _expected(grid, N, jitter, seed, constraints, iters, 0.0)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert int(d["n"]) == n_e
+        assert np.array_equal(d["res"], res_e)
+        assert np.array_equal(d["frz"], frz_e)
+        assert np.array_equal(d["pts"], pts_e[r])
+    assert frz_e[-1] > 0
 
 
 @pytest.mark.parametrize("grid,patches", [((2, 1, 1), ("xmin",)), ((2, 2, 1), ("xmin", "ymax"))])
