@@ -40,7 +40,7 @@ struct Accum {                 // device-side loop state
     int nActive;               // face-angle walk: points outside the good range (this iteration)
     int nEaMaybe, nFaMaybe;    // elements the f32 filters could not decide (this iteration)
     int stop;                  // set once residual < relTol (SM.C:2401)
-    int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks
+    int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks, 3 = walk barrier timed out
     int pad;
 };
 

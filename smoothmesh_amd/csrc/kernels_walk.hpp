@@ -9,9 +9,26 @@
 //   2. k_walk_pred : one thread per table entry evaluates the geometric predicates in parallel
 //      (self-deterioration, and for every neighbour "its move hurts me" with me at my proposal / at my
 //      current position) -- the same bits as k_fa_pred;
-//   3. the host replays the reference's stack order over the bit tables (a few ns per entry; the same
-//      replay on one GPU lane costs microseconds per point), and
-//   4. k_walk_apply marks the points the replay froze.
+//   3. the stack order is replayed over the bit tables.  Only points that can act (a true self bit or a true
+//      neighbour bit) take part.  Early in a run the interaction graph falls into thousands of tiny components, but on
+//      a refinement interface they percolate within ~10 iterations (10 M-cell cavity mesh, iteration 40: one component
+//      with 116 k of the 136 k acting points), so "one lane per component" is no way out.  What makes the walk
+//      parallel is its causal structure.  Number the first visits t = 0, 1, ... (descending point id) and let T(p) be
+//      the step at which p gets frozen.  A visit at step t only acts on what earlier steps left behind, re-visits happen
+//      within the step that caused them (LIFO), and the flags only ever go from 0 to 1, so (SM.C:1376-1433)
+//        T(p) = min( -1 if frozen before the walk,
+//                    t_p if p moves and its own move deteriorates its angles,                        (self freeze, :1391)
+//                    T(q)  over entries q -> p that hold with q at its CURRENT position,               (re-visit of q, :1431)
+//                    t_q   over such entries of a q that never moves or was frozen before the walk,    (first visit of q)
+//                    t_q   over entries q -> p that hold with q at its PROPOSAL, if T(q) >= t_q )       (q still free at its visit)
+//      Only the last rule is not monotone, and it looks strictly into the past.  So: fix the set A of points whose
+//      proposal-state entries fire, solve the (monotone) rest by min-propagation, re-derive A from the T found, and
+//      repeat until A stands.  Each round gets the earliest wrong decision -- and everything before it -- right, so
+//      it terminates with exactly the sequential result (3 rounds of 5-19 propagation sweeps on the cavity meshes).
+//      k_walk_fix runs all of it in ONE persistent launch with its own grid barrier; no copy, no host synchronisation.
+//      The host replay of round 1 (one core, three stream synchronisations and two copies per iteration) stays
+//      selectable as the A/B reference (SMGPU_WALK=host);
+//   4. k_walk_apply marks the points the host replay froze (k_walk_fix writes the flags itself).
 #pragma once
 #include "kernels.hpp"
 
@@ -56,6 +73,14 @@ struct WalkView {
     WalkItem* items;      // [nRelevant + nBadEntries]
 };
 
+// device replay (k_walk_fix): state over the relevant slots
+struct FixView {
+    int* T;               // [nRelevant] freeze step (header position of the visit that froze the point), -1 before the walk, INT_MAX never
+    int* act;             // [nRelevant] 1: the point is still free at its first visit and acts from its proposal
+    unsigned* bar;        // grid barrier counter
+    int* flags;           // [3] rotating "something changed" words
+};
+
 __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
     if (s.acc->stop) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
@@ -74,8 +99,10 @@ __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, Walk
 }
 
 // exclusive scan of the per-block counts (one workgroup; nBlk is at most a few 10^4)
-__global__ void __launch_bounds__(kBlock) k_walk_scan(State s, WalkView w, int nBlk) {
+// nElemDev != NULL: the counts cover ceil(*nElemDev / kBlock) blocks (a count the host never sees)
+__global__ void __launch_bounds__(kBlock) k_walk_scan(State s, WalkView w, int nBlk, const int* nElemDev, int* hdrOut) {
     if (s.acc->stop) return;
+    if (nElemDev) nBlk = (*nElemDev + kBlock - 1) / kBlock;
     __shared__ int baseA, baseE;
     __shared__ int wa[kBlock / 64], we[kBlock / 64];
     if (threadIdx.x == 0) { baseA = 0; baseE = 0; }
@@ -98,7 +125,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_scan(State s, WalkView w, int n
         if (threadIdx.x == kBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { w.header[0] = baseA; w.header[1] = baseE; }
+    if (threadIdx.x == 0) { hdrOut[0] = baseA; hdrOut[1] = baseE; }
 }
 
 __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
@@ -127,49 +154,56 @@ __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkV
     }
 }
 
-// predicates, one thread per (active point, neighbour) entry plus one per active point (self test)
+// predicates, one thread per (active point, neighbour) entry plus one per active point (self test).
+// nA < 0: the counts are read from the device header (no host read-back) and the threads stride over them.
 __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
-    const int t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= nA + nE) return;
-    if (t == 0) w.actEntOff[nA] = nE;
-    const int slot = (t < nA) ? t : w.entOwner[t - nA];
-    const int p = w.actIds[slot];
-    const V3 cur = ldv(s.ptsCur, p);
-    const V3 np = ldv(s.prop, p);
-    const double curMin = s.ptMin[p], curMax = s.ptMax[p];
-    const bool moved = (np != cur);
-    double mn, mx;
-    if (t < nA) {
-        uint8_t sb = (moved ? 2 : 0) | (s.frozen[p] ? 4 : 0);
-        if (moved) {   // SM.C:1385-1394
-            pointFaceAngles(m, s, p, np, -1, np, mn, mx);
-            if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+    if (s.acc->stop) return;
+    if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nA + nE; t += gridDim.x * kBlock) {
+        if (t == 0) w.actEntOff[nA] = nE;
+        const int slot = (t < nA) ? t : w.entOwner[t - nA];
+        const int p = w.actIds[slot];
+        const V3 cur = ldv(s.ptsCur, p);
+        const V3 np = ldv(s.prop, p);
+        const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+        const bool moved = (np != cur);
+        double mn, mx;
+        if (t < nA) {
+            uint8_t sb = (moved ? 2 : 0) | (s.frozen[p] ? 4 : 0);
+            if (moved) {   // SM.C:1385-1394
+                pointFaceAngles(m, s, p, np, -1, np, mn, mx);
+                if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+            }
+            w.actBits[slot] = sb;
+        } else {
+            const int e = t - nA;
+            const int q = w.entNbr[e];
+            const V3 nq = ldv(s.prop, q);
+            uint8_t nb = s.frozen[q] ? 8 : 0;
+            if (nq != ldv(s.ptsCur, q)) {   // SM.C:1414: the neighbour is moving
+                nb |= 4;
+                pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
+                const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+                if (badF) nb |= 2;
+                if (moved) {
+                    pointFaceAngles(m, s, p, np, q, nq, mn, mx);   // this point at its proposal, SM.C:1419
+                    if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
+                } else if (badF) nb |= 1;
+            }
+            w.entBits[e] = nb;
+            w.entSlot[e] = w.activeSlot[q];
         }
-        w.actBits[slot] = sb;
-    } else {
-        const int e = t - nA;
-        const int q = w.entNbr[e];
-        const V3 nq = ldv(s.prop, q);
-        uint8_t nb = s.frozen[q] ? 8 : 0;
-        if (nq != ldv(s.ptsCur, q)) {   // SM.C:1414: the neighbour is moving
-            nb |= 4;
-            pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
-            const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
-            if (badF) nb |= 2;
-            if (moved) {
-                pointFaceAngles(m, s, p, np, q, nq, mn, mx);   // this point at its proposal, SM.C:1419
-                if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
-            } else if (badF) nb |= 1;
-        }
-        w.entBits[e] = nb;
-        w.entSlot[e] = w.activeSlot[q];
     }
 }
 
 // ---- second compaction (over active slots) ------------------------------------------------------------------
 __device__ __forceinline__ bool entryActs(uint8_t nb) { return (nb & 4) && (nb & 3); }   // moving neighbour, hurt in some state
 
+// nA < 0 (here and below): counts from the device headers; the launch covers every possible slot and the blocks
+// beyond the count leave at once
 __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
+    if (nA < 0) nA = w.header[0];
+    if ((int)(blockIdx.x * kBlock) >= nA) return;
     const int a = blockIdx.x * kBlock + threadIdx.x;
     int r = 0, b = 0;
     if (a < nA) {
@@ -190,7 +224,12 @@ __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR, int nB) {
+// fx.T != NULL (device replay): an entry item keeps its owner's slot in `hpos` (k_rel_link leaves it there: nothing is
+// pushed in that mode) and the barrier words of k_walk_fix are reset
+__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR, int nB, FixView fx) {
+    if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { *fx.bar = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = 0; }
+    if (nA < 0) { nA = w.header[0]; nR = w.header2[0]; nB = w.header2[1]; }
+    if ((int)(blockIdx.x * kBlock) >= nA) return;
     const int a = blockIdx.x * kBlock + threadIdx.x;
     int r = 0, b = 0;
     if (a < nA) {
@@ -222,7 +261,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR,
         for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) {
             const uint8_t nb = w.entBits[k];
             if (!entryActs(nb)) continue;
-            w.items[pos] = WalkItem{w.entSlot[k], w.entNbr[k], nb, 0};   // active slot for now, see k_rel_link
+            w.items[pos] = WalkItem{w.entSlot[k], w.entNbr[k], nb, slot};   // active slot for now, see k_rel_link
             anyOld |= nb & 2;
             ++pos;
         }
@@ -235,26 +274,139 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR,
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_rel_link(WalkView w, int nItems, int nR) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nItems) return;
-    WalkItem it = w.items[i];
-    if (it.bits & 0x80u) return;
-    // a neighbour that is not active, or active but unable to act, is a sink: the replay only honours its
-    // "frozen before the walk" bit (two constant pseudo slots behind the real ones)
-    const unsigned nb = it.bits;
-    const int rs = (it.slot >= 0) ? w.relSlot[it.slot] : -1;
-    unsigned bits = nb & 3u;
-    if (rs >= 0) {
-        it.slot = rs;
-        it.hpos = w.hdrPos[rs];
-        bits |= 32u;
-        if (w.relBits[rs] & 8) bits |= 16u;
-    } else {
-        it.slot = nR + ((nb >> 3) & 1u);
+__global__ void __launch_bounds__(kBlock) k_rel_link(WalkView w, int nItems, int nR, int keepOwner) {
+    if (nItems < 0) { nR = w.header2[0]; nItems = nR + w.header2[1]; }
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < nItems; i += gridDim.x * kBlock) {
+        WalkItem it = w.items[i];
+        if (it.bits & 0x80u) continue;
+        // a neighbour that is not active, or active but unable to act, is a sink: the replay only honours its
+        // "frozen before the walk" bit (two constant pseudo slots behind the real ones)
+        const unsigned nb = it.bits;
+        const int rs = (it.slot >= 0) ? w.relSlot[it.slot] : -1;
+        const int owner = it.hpos;
+        unsigned bits = nb & 3u;
+        it.hpos = 0;
+        if (rs >= 0) {
+            it.slot = rs;
+            it.hpos = w.hdrPos[rs];
+            bits |= 32u;
+            if (w.relBits[rs] & 8) bits |= 16u;
+        } else {
+            it.slot = nR + ((nb >> 3) & 1u);
+        }
+        if (keepOwner) it.hpos = owner;
+        it.bits = bits;
+        w.items[i] = it;
     }
-    it.bits = bits;
-    w.items[i] = it;
+}
+
+// ---- device replay: the walk as a causal fixed point (see the head of this file) ---------------------------------------
+constexpr int kFixBlock = 1024;
+constexpr int kNever = 0x7fffffff;
+__device__ __forceinline__ int ldAgent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stAgent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Grid barrier of the persistent launch.  Everything the workgroups hand each other (T, act, flags, the items' last-sent
+// words) is written and read with agent-scope atomics / sc1 accesses, which are served by L2, so the barrier only has to
+// make sure that every wave's operations have completed before its workgroup arrives (MI355X_MICROARCH.md, "Valid forms":
+// agent atomics on both sides).  A wait that takes absurdly long (workgroups that never became resident) raises acc->err
+// instead of hanging the stream.
+__device__ __forceinline__ void fixBarrier(unsigned* ctr, unsigned& target, Accum* acc) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        target += gridDim.x;
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        long long spins = 0;
+        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1ll << 26)) { acc->err = 3; break; }
+        }
+    }
+    __syncthreads();
+}
+
+// a round's "did anything change" vote: flags[fi] collects it, the word after next is cleared for its next use (every
+// workgroup has read it two barriers ago)
+__device__ __forceinline__ bool fixVote(FixView fx, int& fi, bool mine, unsigned& target, Accum* acc) {
+    const int any = __syncthreads_or(mine ? 1 : 0);
+    if (threadIdx.x == 0) {
+        if (any) __hip_atomic_fetch_or(&fx.flags[fi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (blockIdx.x == 0) stAgent(&fx.flags[(fi + 1) % 3], 0);
+    }
+    fixBarrier(fx.bar, target, acc);
+    const bool changed = ldAgent(&fx.flags[fi]) != 0;
+    fi = (fi + 1) % 3;
+    return changed;
+}
+
+__global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, State s) {
+    if (s.acc->stop) return;
+    const int nR = w.header2[0], nItems = nR + w.header2[1];
+    if (nR <= 0) return;
+    const int gtid = blockIdx.x * kFixBlock + threadIdx.x, gstride = gridDim.x * kFixBlock;
+    unsigned target = 0;
+    int fi = 0;
+    for (int x = gtid; x < nR; x += gstride) stAgent(&fx.act[x], 0);   // round 1: no proposal-state entry fires (an upper bound of T)
+    for (int outer = 0;; ++outer) {
+        // the seeds that do not depend on anybody else
+        for (int x = gtid; x < nR; x += gstride) {
+            const unsigned rb = w.relBits[x];   // bit0 own move deteriorates, bit1 moved, bit2 frozen before the walk
+            stAgent(&fx.T[x], (rb & 4u) ? -1 : (((rb & 3u) == 3u) ? w.hdrPos[x] : kNever));
+        }
+        fixBarrier(fx.bar, target, s.acc);
+        // entries that fire at their owner's first visit: proposal-state entries of the owners in A; current-state entries
+        // of owners that never move or were frozen before the walk (they are never re-visited)
+        for (int i = gtid; i < nItems; i += gstride) {
+            const WalkItem it = w.items[i];
+            if ((it.bits & 0x80u) || !(it.bits & 32u)) continue;          // header / sink (sinks: at the end)
+            const int o = it.hpos;
+            const unsigned rbo = w.relBits[o];
+            const bool atVisitOnly = (rbo & 4u) || !(rbo & 2u);
+            if ((it.bits & 1u) && ldAgent(&fx.act[o])) atomicMin(&fx.T[it.slot], w.hdrPos[o]);
+            if (it.bits & 2u) {
+                if (atVisitOnly) atomicMin(&fx.T[it.slot], w.hdrPos[o]);
+                else stAgent(&w.items[i].id, kNever);                      // real target: `id` is free, it holds the last T sent
+            }
+        }
+        fixBarrier(fx.bar, target, s.acc);
+        // frozen => re-visited at once, held at its current position: T flows along the current-state entries
+        for (;;) {
+            bool ch = false;
+            for (int i = gtid; i < nItems; i += gstride) {
+                const WalkItem it = w.items[i];
+                if ((it.bits & 0x80u) || (it.bits & 34u) != 34u) continue;
+                const int o = it.hpos;
+                const unsigned rbo = w.relBits[o];
+                if ((rbo & 4u) || !(rbo & 2u)) continue;
+                const int t = ldAgent(&fx.T[o]);
+                if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
+            }
+            if (!fixVote(fx, fi, ch, target, s.acc)) break;
+        }
+        // who was still free at its own first visit?
+        bool ch = false;
+        for (int x = gtid; x < nR; x += gstride) {
+            const unsigned rb = w.relBits[x];
+            if ((rb & 7u) != 2u) continue;                                  // moved, own move fine, not frozen before
+            const int a = ldAgent(&fx.T[x]) >= w.hdrPos[x] ? 1 : 0;
+            if (a != ldAgent(&fx.act[x])) { stAgent(&fx.act[x], a); ch = true; }
+        }
+        if (!fixVote(fx, fi, ch, target, s.acc)) break;
+        if (outer > 4096) { if (gtid == 0) s.acc->err = 3; break; }       // cannot happen: every round fixes a longer prefix
+    }
+    // results: every point that got a freeze step, and every sink an entry fired at
+    for (int x = gtid; x < nR; x += gstride)
+        if (!(w.relBits[x] & 4u) && ldAgent(&fx.T[x]) != kNever) s.frozen[w.items[w.hdrPos[x]].id] = 1;
+    for (int i = gtid; i < nItems; i += gstride) {
+        const WalkItem it = w.items[i];
+        if ((it.bits & 0x80u) || (it.bits & 32u) || it.slot != nR) continue;   // sinks not frozen before the walk
+        const int o = it.hpos;
+        const unsigned rbo = w.relBits[o];
+        const bool atVisitOnly = (rbo & 4u) || !(rbo & 2u);
+        const bool fired = ((it.bits & 1u) && ldAgent(&fx.act[o])) || ((it.bits & 2u) && (atVisitOnly || ldAgent(&fx.T[o]) != kNever));
+        if (fired) s.frozen[it.id] = 1;
+    }
 }
 
 __global__ void __launch_bounds__(kBlock) k_walk_apply(State s, const int* ids, int n) {

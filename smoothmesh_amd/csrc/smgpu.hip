@@ -102,9 +102,13 @@ struct smgpu_handle {
     size_t geomLds = 0, smoothLds = 0;
     bool writeFaces = false;   // debug: publish per-face centres/areas from the tiled geometry kernel
     // face-angle walk: compacted tables + host replay (kernels_walk.hpp) when many points are active
-    int walkMode = -1;         // -1 undecided, 0 device replay (k_fa_pred + k_fa_walk), 1 host replay
+    int walkMode = -1;         // -1 undecided, 0 one-wave device replay (k_fa_pred + k_fa_walk: few active points), 1 host replay,
+                               // 2 device replay as a causal fixed point (k_walk_fix: many active points)
     bool walkAlloc = false;
     WalkView wv{};
+    FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
+    bool fixAlloc = false;
+    int walkFixBlocks = 64;    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
     void* pinned = nullptr;
     size_t pinnedBytes = 0;
@@ -879,7 +883,7 @@ static int runHostWalk(smgpu_handle* h) {
     if (ensurePinned(h, 64)) return 1;
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
         })) return 1;
     int* hdr = (int*)h->pinned;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -894,16 +898,16 @@ static int runHostWalk(smgpu_handle* h) {
     const int nSlotBlocks = gridFor(nA);
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_rel_count, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, nSlotBlocks);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, nSlotBlocks, (const int*)nullptr, w.header2);
         })) return 1;
-    HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipMemcpyAsync(hdr, w.header2, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (spinSync(h->stream)) return 1;
     const int nR = hdr[0], nB = hdr[1];
     if (nR <= 0) return 0;
     const int nItems = nR + nB;
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA, nR, nB);
-            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(nItems)), dim3(kBlock), 0, h->stream, w, nItems, nR);
+            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA, nR, nB, FixView{});
+            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(nItems)), dim3(kBlock), 0, h->stream, w, nItems, nR, 0);
         })) return 1;
     const size_t oItems = 0, oRel = oItems + sizeof(WalkItem) * (size_t)nItems, total = oRel + (size_t)nR;
     if (ensurePinned(h, total + 16)) return 1;
@@ -913,7 +917,7 @@ static int runHostWalk(smgpu_handle* h) {
     if (spinSync(h->stream)) return 1;
     if (const char* dump = std::getenv("SMGPU_DUMP_WALK")) {          // offline analysis of the replay input
         static int calls = 0;
-        if (++calls == 3) {
+        if (++calls == envInt("SMGPU_DUMP_WALK_CALL", 3)) {
             if (FILE* f = std::fopen(dump, "wb")) {
                 const int64_t hdr3[3] = {nR, nB, (int64_t)total};
                 std::fwrite(hdr3, sizeof(hdr3), 1, f);
@@ -943,6 +947,45 @@ static int runHostWalk(smgpu_handle* h) {
         hipLaunchKernelGGL(k_walk_apply, dim3(gridFor(nOut)), dim3(kBlock), 0, h->stream, s, w.entOwner, nOut);
         if (spinSync(h->stream)) return 1;   // the pinned buffer is reused by the next iteration
     }
+    return 0;
+}
+
+// The same walk without the host: compaction and predicates as above with every count left on the device (the
+// launches cover the largest possible count or stride over it), then k_walk_fix solves the walk as a causal fixed point
+// in one persistent launch (kernels_walk.hpp).  No copy, no synchronisation.
+static int runFixWalk(smgpu_handle* h) {
+    if (ensureWalkBuffers(h)) return 1;
+    if (!h->fixAlloc) {
+        const size_t P = (size_t)h->topo.nPoints;
+        FixView& f = h->fxw;
+        if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
+        // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
+        h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", 64), 256));
+        h->fixAlloc = true;
+    }
+    const MeshView& m = h->mv;
+    State s = h->st;
+    const Prm prm = makePrm(h);
+    WalkView w = h->wv;
+    const FixView fx = h->fxw;
+    const int P = m.nPoints;
+    const int64_t maxEntries = (int64_t)h->topo.pointEdges.nnz();
+    // grids: enough workgroups to fill the chip several times over; the kernels stride over the device-side counts
+    const int gPred = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 64);
+    const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
+    if (launchK(h, K_FA_PRED, [&] {
+            hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
+            hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_pred, dim3(gPred), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+        })) return 1;
+    if (launchK(h, K_FA_WALK, [&] {
+            hipLaunchKernelGGL(k_rel_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, 0, (const int*)w.header, w.header2);
+            hipLaunchKernelGGL(k_rel_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1, -1, -1, fx);
+            hipLaunchKernelGGL(k_rel_link, dim3(gItems), dim3(kBlock), 0, h->stream, w, -1, -1, 1);
+            hipLaunchKernelGGL(k_walk_fix, dim3(h->walkFixBlocks), dim3(kFixBlock), 0, h->stream, w, fx, s);
+        })) return 1;
     return 0;
 }
 
@@ -1020,18 +1063,26 @@ static int runConstraints(smgpu_handle* h) {
         if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
         if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
         if (h->walkMode < 0) {
-            // decide once per parameter set: read how many points lie outside the good range now (one sync)
-            const char* env = std::getenv("SMGPU_HOST_WALK");
-            if (env && std::string(env) != "auto") h->walkMode = std::atoi(env) ? 1 : 0;
+            // decide once per parameter set: read how many points lie outside the good range now (one sync).  Few: the
+            // one-wave replay over the full flag array (two launches); many: the fixed-point replay.  SMGPU_WALK = wave | host |
+            // fix forces one (SMGPU_HOST_WALK = 0 | 1: the first two, as in round 1).
+            const char* env = std::getenv("SMGPU_WALK");
+            const char* envHost = std::getenv("SMGPU_HOST_WALK");
+            if (env && std::string(env) == "wave") h->walkMode = 0;
+            else if (env && std::string(env) == "host") h->walkMode = 1;
+            else if (env && std::string(env) == "fix") h->walkMode = 2;
+            else if (envHost && std::string(envHost) != "auto") h->walkMode = std::atoi(envHost) ? 1 : 0;
             else {
                 Accum a;
                 HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
                 HIP_OK(hipStreamSynchronize(h->stream));
-                h->walkMode = a.nActive > envInt("SMGPU_HOST_WALK_THRESHOLD", 256) ? 1 : 0;
+                h->walkMode = a.nActive > envInt("SMGPU_HOST_WALK_THRESHOLD", 256) ? 2 : 0;
             }
         }
         if (h->walkMode == 1) {
             if (runHostWalk(h)) return 1;
+        } else if (h->walkMode == 2) {
+            if (runFixWalk(h)) return 1;
         } else {
             if (launchK(h, K_FA_PRED, [&] { hipLaunchKernelGGL(k_fa_pred, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
             if (launchK(h, K_FA_WALK, [&] { hipLaunchKernelGGL(k_fa_walk, dim3(1), dim3(64), 0, h->stream, m, s); })) return 1;
@@ -1044,6 +1095,7 @@ static int checkDeviceError(smgpu_handle* h) {
     Accum a;
     HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
+    if (a.err == 3) return fail("face-angle walk: the workgroups of the device replay did not all become resident (grid barrier timed out); set SMGPU_WALK=host or lower SMGPU_WALK_BLOCKS");
     if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
     if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
     if (a.err == BND_ERR_NORMAL) return fail("pointNormal is zero for a boundary point that is to be projected (BPS.C:691-696, OBB.C:609-610)");

@@ -95,10 +95,14 @@ def test_uniform_block_is_fixed_point(oracle_lib):
     assert np.array_equal(frz_o, frz_g)
 
 
+@pytest.mark.parametrize("walk", ["auto", "wave", "host", "fix"])
 @pytest.mark.parametrize("jit,seed", [(0.45, 7), (0.48, 11)])
-def test_bad_mesh_face_angle_walk(oracle_lib, jit, seed):
+def test_bad_mesh_face_angle_walk(oracle_lib, monkeypatch, jit, seed, walk):
     """Heavy jitter pushes face angles outside [35, 160] degrees: the ordered freeze walk
-    (SM.C:1347-1434) is exercised, self- and neighbour-freezes included."""
+    (SM.C:1347-1434) is exercised, self- and neighbour-freezes included -- in every place the replay can run
+    (one wave over the flag array, the host, the causal fixed point in one persistent launch)."""
+    if walk != "auto":
+        monkeypatch.setenv("SMGPU_WALK", walk)
     mesh = _mk(8, 7, 6, jit, seed)
     o, e, p = _pair(mesh, oracle_lib)
     o.phaseA(); o.phaseB()
@@ -108,6 +112,19 @@ def test_bad_mesh_face_angle_walk(oracle_lib, jit, seed):
     assert np.array_equal(e.debug_field("isFrozenPoint"), fo)
     n_o, res_o, frz_o = o.iterate(10, 0.0)
     n_g, res_g, frz_g = e.iterate(10, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
+
+
+@pytest.mark.parametrize("dims,jit,seed", [((14, 12, 10), 0.47, 3), ((20, 6, 5), 0.49, 8)])
+def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed):
+    """a badly distorted block: the interaction graph has components of hundreds of points with long re-visit chains;
+    the fixed-point device replay must still reproduce the reference's order"""
+    monkeypatch.setenv("SMGPU_WALK", "fix")
+    mesh = _mk(*dims, jit, seed)
+    o, e, p = _pair(mesh, oracle_lib)
+    n_o, res_o, frz_o = o.iterate(6, 0.0)
+    n_g, res_g, frz_g = e.iterate(6, 0.0)
     assert np.array_equal(frz_o, frz_g)
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
@@ -195,12 +212,38 @@ def test_edge_angle_forms_agree(oracle_lib, monkeypatch, jit, minAngle):
     assert np.array_equal(masks[0], ref)
 
 
+def test_walk_replay_places_agree_at_scale(monkeypatch):
+    """cavity100c (1 M cells, ~25 k acting points in ~10 k components per iteration): the fixed-point device replay, the
+    host replay and nothing else changed -- identical nFrozenPoints series and coordinates after 12 iterations, and the
+    frozen set only ever contains points the walk or the other evaluators may freeze (never a non-moving one wrongly freed)"""
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.polymesh import cavity_mesh
+    mesh = cavity_mesh(100, jitter=0.2, seed=12345)
+    outs = {}
+    for walk in ("fix", "host"):
+        monkeypatch.setenv("SMGPU_WALK", walk)
+        e = SmoothEngine(mesh)
+        e.set_params(default_params(e.mesh_stats()[0]))
+        n, res, frz = e.iterate(12, 0.0)
+        outs[walk] = (res, frz, e.get_points())
+        e.close()
+    assert np.array_equal(outs["fix"][1], outs["host"][1])
+    assert np.array_equal(outs["fix"][0], outs["host"][0])
+    assert np.array_equal(outs["fix"][2], outs["host"][2])
+    assert outs["fix"][1][-1] > outs["fix"][1][0] > (~mesh.find_internal_points().astype(bool)).sum()   # the walk freezes more and more
+
+
+@pytest.mark.parametrize("walk", ["auto", "fix"])
 @pytest.mark.parametrize("constraints", [False, True])
-def test_polyhedral_cavity_mesh(oracle_lib, constraints):
+def test_polyhedral_cavity_mesh(oracle_lib, monkeypatch, constraints, walk):
     """Castellated octree mesh (polyhedral cells with split faces and hanging edge nodes, valence 3..6,
     coplanar face pairs => face angles of 180 degrees => the ordered freeze walk is busy every iteration)."""
     from smoothmesh_amd import SmoothEngine, default_params
     from smoothmesh_amd.polymesh import cavity_mesh
+    if walk != "auto":
+        if not constraints:
+            pytest.skip("no walk without the constraints")
+        monkeypatch.setenv("SMGPU_WALK", walk)
     mesh = cavity_mesh(12, jitter=0.2, seed=3)
     assert np.bincount(np.diff(mesh.faceOffsets))[5:].sum() > 0          # genuinely polygonal faces
     o = oracle_lib.Oracle(mesh)
