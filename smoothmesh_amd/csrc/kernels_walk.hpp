@@ -98,31 +98,40 @@ __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, Walk
     }
 }
 
-// exclusive scan of the per-block counts (one workgroup; nBlk is at most a few 10^4)
-// nElemDev != NULL: the counts cover ceil(*nElemDev / kBlock) blocks (a count the host never sees)
-__global__ void __launch_bounds__(kBlock) k_walk_scan(State s, WalkView w, int nBlk, const int* nElemDev, int* hdrOut) {
+// exclusive scan of the per-block counts by one workgroup of kScanBlock threads, four counts per thread and round (a 10 M-point
+// mesh has 40 k blocks).  nElemDev != NULL: the counts cover ceil(*nElemDev / kBlock) blocks (a count the host never sees)
+constexpr int kScanBlock = 1024;
+__global__ void __launch_bounds__(kScanBlock) k_walk_scan(State s, WalkView w, int nBlk, const int* nElemDev, int* hdrOut) {
     if (s.acc->stop) return;
     if (nElemDev) nBlk = (*nElemDev + kBlock - 1) / kBlock;
     __shared__ int baseA, baseE;
-    __shared__ int wa[kBlock / 64], we[kBlock / 64];
+    __shared__ int wa[kScanBlock / 64], we[kScanBlock / 64];
     if (threadIdx.x == 0) { baseA = 0; baseE = 0; }
     __syncthreads();
-    for (int b0 = 0; b0 < nBlk; b0 += kBlock) {
-        const int i = b0 + threadIdx.x;
-        const int a = (i < nBlk) ? w.blkA[i] : 0, e = (i < nBlk) ? w.blkE[i] : 0;
-        int ia = a, ie = e;   // inclusive scan inside the wave
-        const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < nBlk; b0 += 4 * kScanBlock) {
+        const int i0 = b0 + 4 * threadIdx.x;
+        int a[4], e[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = (i0 + u < nBlk) ? w.blkA[i0 + u] : 0; e[u] = (i0 + u < nBlk) ? w.blkE[i0 + u] : 0; }
+        const int sa = a[0] + a[1] + a[2] + a[3], se = e[0] + e[1] + e[2] + e[3];
+        int ia = sa, ie = se;   // inclusive scan of the threads' sums inside the wave
         for (int o = 1; o < 64; o <<= 1) {
             const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
             if (lane >= o) { ia += ta; ie += te; }
         }
-        if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
+        if (lane == 63) { wa[wv] = ia; we[wv] = ie; }
         __syncthreads();
         int offA = baseA, offE = baseE;
-        for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
-        if (i < nBlk) { w.blkA[i] = offA + ia - a; w.blkE[i] = offE + ie - e; }
+        for (int k = 0; k < wv; ++k) { offA += wa[k]; offE += we[k]; }
+        int ra = offA + ia - sa, re = offE + ie - se;   // exclusive prefix of this thread's first count
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (i0 + u < nBlk) { w.blkA[i0 + u] = ra; w.blkE[i0 + u] = re; }
+            ra += a[u]; re += e[u];
+        }
         __syncthreads();
-        if (threadIdx.x == kBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
+        if (threadIdx.x == kScanBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
         __syncthreads();
     }
     if (threadIdx.x == 0) { hdrOut[0] = baseA; hdrOut[1] = baseE; }
@@ -154,45 +163,62 @@ __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkV
     }
 }
 
-// predicates, one thread per (active point, neighbour) entry plus one per active point (self test).
-// nA < 0: the counts are read from the device header (no host read-back) and the threads stride over them.
+// predicates: k_walk_pred_self, one thread per active point (self test), then k_walk_pred, one thread per (active point,
+// neighbour) entry.  nA < 0: the counts are read from the device header (no host read-back) and the threads stride over them.
+// What no replay can ever consult is not evaluated (the decisions are the reference's, bit for bit):
+//   * a neighbour frozen before the walk is skipped by every visit (SM.C:1411), so its entry needs no angles;
+//   * "the neighbour's move hurts me at my PROPOSAL" (bit0) is only read when the point acts from its proposal, i.e. when it is
+//     visited unfrozen and does not freeze itself (SM.C:1376-1399): never for a point whose own move deteriorates its angles
+//     (it is frozen by its first visit at the latest) nor for one frozen before the walk -- on a refinement interface that is
+//     ~88 % of the acting points, and half of each of their entries' work.
+__global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+    if (s.acc->stop) return;
+    if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nA; t += gridDim.x * kBlock) {
+        if (t == 0) w.actEntOff[nA] = nE;
+        const int p = w.actIds[t];
+        const V3 cur = ldv(s.ptsCur, p);
+        const V3 np = ldv(s.prop, p);
+        const bool moved = (np != cur);
+        const bool frozenBefore = s.frozen[p] != 0;
+        uint8_t sb = (moved ? 2 : 0) | (frozenBefore ? 4 : 0);
+        if (moved && !frozenBefore) {   // SM.C:1385-1394 (a frozen point is held at its current position: no self test)
+            double mn, mx;
+            pointFaceAngles(m, s, p, np, -1, np, mn, mx);
+            const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+            if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+        }
+        w.actBits[t] = sb;
+    }
+}
 __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nA + nE; t += gridDim.x * kBlock) {
-        if (t == 0) w.actEntOff[nA] = nE;
-        const int slot = (t < nA) ? t : w.entOwner[t - nA];
+    for (int e = blockIdx.x * kBlock + threadIdx.x; e < nE; e += gridDim.x * kBlock) {
+        const int slot = w.entOwner[e];
         const int p = w.actIds[slot];
-        const V3 cur = ldv(s.ptsCur, p);
-        const V3 np = ldv(s.prop, p);
-        const double curMin = s.ptMin[p], curMax = s.ptMax[p];
-        const bool moved = (np != cur);
-        double mn, mx;
-        if (t < nA) {
-            uint8_t sb = (moved ? 2 : 0) | (s.frozen[p] ? 4 : 0);
-            if (moved) {   // SM.C:1385-1394
-                pointFaceAngles(m, s, p, np, -1, np, mn, mx);
-                if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+        const int q = w.entNbr[e];
+        const V3 nq = ldv(s.prop, q);
+        const bool qFrozen = s.frozen[q] != 0;
+        uint8_t nb = qFrozen ? 8 : 0;
+        if (!qFrozen && nq != ldv(s.ptsCur, q)) {   // SM.C:1411-1414: the neighbour is free and moving
+            nb |= 4;
+            const V3 cur = ldv(s.ptsCur, p);
+            const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+            const uint8_t sb = w.actBits[slot];
+            double mn, mx;
+            pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
+            const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+            if (badF) nb |= 2;
+            if (!(sb & 2)) { if (badF) nb |= 1; }           // not moved: proposal = current position
+            else if (!(sb & 5)) {                           // acts from its proposal if it is still free at its first visit, SM.C:1419
+                const V3 np = ldv(s.prop, p);
+                pointFaceAngles(m, s, p, np, q, nq, mn, mx);
+                if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
             }
-            w.actBits[slot] = sb;
-        } else {
-            const int e = t - nA;
-            const int q = w.entNbr[e];
-            const V3 nq = ldv(s.prop, q);
-            uint8_t nb = s.frozen[q] ? 8 : 0;
-            if (nq != ldv(s.ptsCur, q)) {   // SM.C:1414: the neighbour is moving
-                nb |= 4;
-                pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
-                const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
-                if (badF) nb |= 2;
-                if (moved) {
-                    pointFaceAngles(m, s, p, np, q, nq, mn, mx);   // this point at its proposal, SM.C:1419
-                    if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
-                } else if (badF) nb |= 1;
-            }
-            w.entBits[e] = nb;
-            w.entSlot[e] = w.activeSlot[q];
         }
+        w.entBits[e] = nb;
+        w.entSlot[e] = w.activeSlot[q];
     }
 }
 
@@ -370,19 +396,31 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
             }
         }
         fixBarrier(fx.bar, target, s.acc);
-        // frozen => re-visited at once, held at its current position: T flows along the current-state entries
-        for (;;) {
-            bool ch = false;
-            for (int i = gtid; i < nItems; i += gstride) {
-                const WalkItem it = w.items[i];
-                if ((it.bits & 0x80u) || (it.bits & 34u) != 34u) continue;
-                const int o = it.hpos;
-                const unsigned rbo = w.relBits[o];
-                if ((rbo & 4u) || !(rbo & 2u)) continue;
-                const int t = ldAgent(&fx.T[o]);
-                if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
+        // frozen => re-visited at once, held at its current position: T flows along the current-state entries.  Every workgroup
+        // owns a contiguous stretch of the item sequence (= a slab of the mesh: the items follow the point ids) and sweeps
+        // it a few times between two grid barriers, so chains that stay inside a slab do not cost a barrier per link
+        {
+            const int chunk = (nItems + gridDim.x - 1) / gridDim.x;
+            const int i0 = blockIdx.x * chunk, i1 = min(nItems, i0 + chunk);
+            for (;;) {
+                bool chAny = false;
+                for (int sweep = 0; sweep < 6; ++sweep) {
+                    bool ch = false;
+                    for (int i = i0 + threadIdx.x; i < i1; i += kFixBlock) {
+                        const WalkItem it = w.items[i];
+                        if ((it.bits & 0x80u) || (it.bits & 34u) != 34u) continue;
+                        const int o = it.hpos;
+                        const unsigned rbo = w.relBits[o];
+                        if ((rbo & 4u) || !(rbo & 2u)) continue;
+                        const int t = ldAgent(&fx.T[o]);
+                        if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (!__syncthreads_or(ch ? 1 : 0)) break;
+                    chAny = true;
+                }
+                if (!fixVote(fx, fi, chAny, target, s.acc)) break;
             }
-            if (!fixVote(fx, fi, ch, target, s.acc)) break;
         }
         // who was still free at its own first visit?
         bool ch = false;

@@ -108,7 +108,7 @@ struct smgpu_handle {
     WalkView wv{};
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
-    int walkFixBlocks = 64;    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
+    int walkFixBlocks = 128;    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
     void* pinned = nullptr;
     size_t pinnedBytes = 0;
@@ -883,7 +883,7 @@ static int runHostWalk(smgpu_handle* h) {
     if (ensurePinned(h, 64)) return 1;
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
         })) return 1;
     int* hdr = (int*)h->pinned;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -892,13 +892,14 @@ static int runHostWalk(smgpu_handle* h) {
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_pred, dim3(gridFor((int64_t)nA + nE)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
         })) return 1;
     // second compaction: only the points that can act and only their true entries go to the host
     const int nSlotBlocks = gridFor(nA);
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_rel_count, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, nSlotBlocks, (const int*)nullptr, w.header2);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, nSlotBlocks, (const int*)nullptr, w.header2);
         })) return 1;
     HIP_OK(hipMemcpyAsync(hdr, w.header2, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (spinSync(h->stream)) return 1;
@@ -960,7 +961,7 @@ static int runFixWalk(smgpu_handle* h) {
         FixView& f = h->fxw;
         if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
         // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
-        h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", 64), 256));
+        h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", 128), 256));
         h->fixAlloc = true;
     }
     const MeshView& m = h->mv;
@@ -975,13 +976,14 @@ static int runFixWalk(smgpu_handle* h) {
     const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_pred_self, dim3(std::min(gridFor(P), 256 * 16)), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
             hipLaunchKernelGGL(k_walk_pred, dim3(gPred), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
         })) return 1;
     if (launchK(h, K_FA_WALK, [&] {
             hipLaunchKernelGGL(k_rel_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kBlock), 0, h->stream, s, w, 0, (const int*)w.header, w.header2);
+            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, 0, (const int*)w.header, w.header2);
             hipLaunchKernelGGL(k_rel_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1, -1, -1, fx);
             hipLaunchKernelGGL(k_rel_link, dim3(gItems), dim3(kBlock), 0, h->stream, w, -1, -1, 1);
             hipLaunchKernelGGL(k_walk_fix, dim3(h->walkFixBlocks), dim3(kFixBlock), 0, h->stream, w, fx, s);
