@@ -98,6 +98,13 @@ int smgpu_get_sizes(smgpu_handle* h, smgpu_sizes* out);
 /* getMeshStats (SM.C:1478-1541): min / max edge length of the current coordinates. */
 int smgpu_mesh_stats(smgpu_handle* h, double* minEdgeLength, double* maxEdgeLength);
 int smgpu_set_params(smgpu_handle* h, const smgpu_params* p);
+/* Which OpenFOAM's primitiveMesh geometry the cell centres follow (row a3 of the scope table; the reference is built against
+ * either line, Allwmake:47 / README.md:30, and inherits its makeFaceCentresAndAreas / makeCellCentresAndVols):
+ * COM = OpenFOAM.com v2312-v2506 (default; fan triangles of a face weighted by their area magnitude), ORG = OpenFOAM.org 12
+ * (weighted by the area projected on the face normal; pyramid volumes clamped at vSmall).  The environment variable
+ * SMGPU_FOAM_VARIANT=org selects ORG at smgpu_create.  Call before iterating. */
+enum { SMGPU_FOAM_COM = 0, SMGPU_FOAM_ORG = 1 };
+int smgpu_set_foam_variant(smgpu_handle* h, int32_t variant);
 
 /* The loop SM.C:2257-2437 on one rank: up to nIters iterations, stops after the first iteration
  * whose residual < relTol (SM.C:2401).  stats (host, [nIters], may be NULL) receives one entry

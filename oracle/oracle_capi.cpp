@@ -30,6 +30,7 @@ void* orc_create(int nPoints, int nCells, int nFaces, int nInternalFaces, const 
 
 void orc_destroy(void* h) { delete static_cast<Domain*>(h); }
 
+void orc_set_foam_variant(void* h, int variant) { static_cast<Domain*>(h)->foamVariant = variant; }
 void orc_set_params(void* h, double maxStepLength, double relStepFrac, double minEdgeLength, int totalMinFreeze,
                     int edgeAngleConstraint, int faceAngleConstraint, double minAngle, double maxAngle) {
     Domain* d = static_cast<Domain*>(h);

@@ -28,6 +28,7 @@ def lib():
         l.orc_create.restype = C.c_void_p
         l.orc_create.argtypes = [C.c_int] * 4 + [f64p, i32p, i32p, i32p, i32p, u8p, u8p]
         l.orc_destroy.argtypes = [C.c_void_p]
+        l.orc_set_foam_variant.argtypes = [C.c_void_p, C.c_int]
         l.orc_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         l.orc_mesh_stats.argtypes = [C.c_void_p, f64p, f64p]
         l.orc_iterate.restype = C.c_int
@@ -122,6 +123,10 @@ class Oracle:
             self.close()
         except Exception:
             pass
+
+    def set_foam_variant(self, variant):
+        """"com" (default) / "org": OpenFOAM line whose primitiveMesh geometry formulas are used (smooth_oracle.hpp)"""
+        self._lib.orc_set_foam_variant(self._h, {"com": 0, "org": 1}[variant])
 
     def set_params(self, p):
         self._lib.orc_set_params(self._h, p.maxStepLength, p.relStepFrac, p.minEdgeLength, int(p.totalMinFreeze),

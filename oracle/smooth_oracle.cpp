@@ -195,6 +195,31 @@ void Domain::updateGeometry() {
         if (nP == 3) {
             faceCentres[facei] = (1.0 / 3.0) * (p[f[0]] + p[f[1]] + p[f[2]]);
             faceAreas[facei] = 0.5 * cross(p[f[1]] - p[f[0]], p[f[2]] - p[f[0]]);
+        } else if (foamVariant == 1) {
+            // OpenFOAM.org 12, primitiveMeshFaceCentresAndAreas.C (face::centre / face::area): the triangle areas are
+            // projected on the face normal, so that the centre does not depend on the point average it is built around
+            Vec3 pAvg = p[f[0]];
+            for (int pi = 1; pi < nP; ++pi) pAvg += p[f[pi]];
+            pAvg /= double(nP);
+            Vec3 sumA = ZERO_VECTOR;
+            for (int pi = 0; pi < nP; ++pi) {
+                const Vec3 thisPoint = p[f[pi]], nextPoint = p[f[pi == nP - 1 ? 0 : pi + 1]];
+                sumA += cross(nextPoint - thisPoint, pAvg - thisPoint);
+            }
+            const Vec3 sumAHat = sumA / mag(sumA);   // normalised(sumA)
+            double sumAn = 0.0;
+            Vec3 sumAnc = ZERO_VECTOR;
+            for (int pi = 0; pi < nP; ++pi) {
+                const Vec3 thisPoint = p[f[pi]], nextPoint = p[f[pi == nP - 1 ? 0 : pi + 1]];
+                const Vec3 a = cross(nextPoint - thisPoint, pAvg - thisPoint);
+                const Vec3 c = thisPoint + nextPoint + pAvg;
+                const double an = dot(a, sumAHat);
+                sumAn += an;
+                sumAnc += an * c;
+            }
+            if (sumAn > VSMALL) faceCentres[facei] = ((1.0 / 3.0) * sumAnc) / sumAn;
+            else faceCentres[facei] = pAvg;
+            faceAreas[facei] = 0.5 * sumA;
         } else {
             Vec3 sumN = ZERO_VECTOR;
             double sumA = 0.0;
@@ -239,7 +264,8 @@ void Domain::updateGeometry() {
     for (int facei = 0; facei < nFaces; ++facei) {
         const Vec3 fc = faceCentres[facei];
         const Vec3 fA = faceAreas[facei];
-        const double pyr3Vol = dot(fA, fc - cEst[owner[facei]]);
+        double pyr3Vol = dot(fA, fc - cEst[owner[facei]]);
+        if (foamVariant == 1) pyr3Vol = (pyr3Vol > VSMALL) ? pyr3Vol : VSMALL;   // OpenFOAM.org: max(Sf & (Cf - cEst), vSmall), Foam::max(a, b) = (a > b) ? a : b
         const Vec3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst[owner[facei]];
         cellCentres[owner[facei]] += pyr3Vol * pc;
         cellVols[owner[facei]] += pyr3Vol;
@@ -247,7 +273,8 @@ void Domain::updateGeometry() {
     for (int facei = 0; facei < nInternalFaces; ++facei) {
         const Vec3 fc = faceCentres[facei];
         const Vec3 fA = faceAreas[facei];
-        const double pyr3Vol = dot(fA, cEst[neighbour[facei]] - fc);
+        double pyr3Vol = dot(fA, cEst[neighbour[facei]] - fc);
+        if (foamVariant == 1) pyr3Vol = (pyr3Vol > VSMALL) ? pyr3Vol : VSMALL;
         const Vec3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst[neighbour[facei]];
         cellCentres[neighbour[facei]] += pyr3Vol * pc;
         cellVols[neighbour[facei]] += pyr3Vol;

@@ -171,6 +171,11 @@ public:
     void meshStats(double& minEdge, double& maxEdge) const;  // SM.C:1478-1541
 
     void updateGeometry();           // OpenFOAM makeFaceCentresAndAreas + makeCellCentresAndVols
+    // Which OpenFOAM's geometry: 0 = OpenFOAM.com v2312-v2506 (fan triangles weighted by their area magnitude), 1 = OpenFOAM.org 12
+    // (fan triangles weighted by their area projected on the face normal; pyramid volumes clamped at vSmall).  The reference
+    // builds against either (Allwmake:47, README.md:30); both formulas are restated from OpenFOAM sources that are not under
+    // /root/reference.
+    int foamVariant = 0;
     void phaseA();                   // geometry, SM.C:108-131 partial sums, SM.C:325-387 local closest
     void phaseB();                   // SM.C:155-163, 580-590, 684-754, 602-652, 900-930, 1320-1437
     void phaseC();                   // SM.C:2384-2392 restore+count, SM.C:1556-1565 residual

@@ -28,6 +28,7 @@ struct MeshView {
     const int* pcOff; const int* pcVal;          // pointCells
     const int* ppOff; const int* ppPt; const int* peEdge;  // pointPoints / pointEdges (shared offsets)
     const int* pfOff; const int* pfPrev; const int* pfNext;  // pointFaces entries -> prev/next vertex
+    const int* pfFace;                                        // pointFaces (face ids, ascending)
     const uint8_t* pfPrevSlot; const uint8_t* pfNextSlot;    // ... as slots of the point's pointPoints row
     const int* ringFace; const int* ringCell; const uint8_t* edgeRingOk;  // ring order around each edge
     const int* edges;                             // 2 per edge
@@ -93,7 +94,8 @@ __device__ __forceinline__ V3 unitTo(const V3& from, const V3& to) {
 // OpenFOAM primitiveMesh::makeFaceCentresAndAreas (.com v2412) -- one thread per face.
 // Also emits the plain vertex average (calcFaceCenter SM.C:1103-1130 on current coordinates),
 // which the face-angle pass reuses.
-__global__ void __launch_bounds__(kBlock) k_face_geom(MeshView m, State s, int wantAvg) {
+// foamOrg: OpenFOAM.org 12's formulas instead of OpenFOAM.com's (see geomFace in kernels_tiled.hpp)
+__global__ void __launch_bounds__(kBlock) k_face_geom(MeshView m, State s, int wantAvg, int foamOrg) {
     if (s.acc->stop) return;
     const int f = blockIdx.x * kBlock + threadIdx.x;
     if (f >= m.nFaces) return;
@@ -108,6 +110,30 @@ __global__ void __launch_bounds__(kBlock) k_face_geom(MeshView m, State s, int w
         const V3 p0 = ldv(P, m.facePts[b]), p1 = ldv(P, m.facePts[b + 1]), p2 = ldv(P, m.facePts[b + 2]);
         ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
         area = 0.5 * cross(p1 - p0, p2 - p0);
+    } else if (foamOrg) {
+        V3 sumA = v3(0, 0, 0);
+        const V3 first = ldv(P, m.facePts[b]);
+        V3 thisPoint = first;
+        for (int i = 0; i < n; ++i) {
+            const V3 nextPoint = (i == n - 1) ? first : ldv(P, m.facePts[b + i + 1]);
+            sumA = sumA + cross(nextPoint - thisPoint, fCentre - thisPoint);
+            thisPoint = nextPoint;
+        }
+        const V3 sumAHat = sumA / mag(sumA);
+        double sumAn = 0.0;
+        V3 sumAnc = v3(0, 0, 0);
+        thisPoint = first;
+        for (int i = 0; i < n; ++i) {
+            const V3 nextPoint = (i == n - 1) ? first : ldv(P, m.facePts[b + i + 1]);
+            const V3 a = cross(nextPoint - thisPoint, fCentre - thisPoint);
+            const V3 c = (thisPoint + nextPoint) + fCentre;
+            const double an = dot(a, sumAHat);
+            sumAn += an;
+            sumAnc = sumAnc + an * c;
+            thisPoint = nextPoint;
+        }
+        ctr = (sumAn > SMGPU_VSMALL) ? ((1.0 / 3.0) * sumAnc) / sumAn : fCentre;
+        area = 0.5 * sumA;
     } else {
         V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
         double sumA = 0.0;
@@ -133,7 +159,7 @@ __global__ void __launch_bounds__(kBlock) k_face_geom(MeshView m, State s, int w
 
 // OpenFOAM primitiveMesh::makeCellCentresAndVols (.com v2412) -- one thread per cell, faces in
 // the accumulation order of the two forAll loops (owned ascending, then neighboured ascending).
-__global__ void __launch_bounds__(kBlock) k_cell_centres(MeshView m, State s) {
+__global__ void __launch_bounds__(kBlock) k_cell_centres(MeshView m, State s, int foamOrg) {
     if (s.acc->stop) return;
     const int c = blockIdx.x * kBlock + threadIdx.x;
     if (c >= m.nCells) return;
@@ -148,7 +174,8 @@ __global__ void __launch_bounds__(kBlock) k_cell_centres(MeshView m, State s) {
         const int f = v & 0x7fffffff;
         const V3 fc = ldv(s.fCtr, f);
         const V3 fA = ldv(s.fArea, f);
-        const double pyr3Vol = (v < 0) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
+        double pyr3Vol = (v < 0) ? dot(fA, cEst - fc) : dot(fA, fc - cEst);
+        if (foamOrg) pyr3Vol = (pyr3Vol > SMGPU_VSMALL) ? pyr3Vol : SMGPU_VSMALL;
         const V3 pc = (3.0 / 4.0) * fc + (1.0 / 4.0) * cEst;
         ctr = ctr + pyr3Vol * pc;
         vol += pyr3Vol;

@@ -162,8 +162,12 @@ __device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileView& g) {
     return L;
 }
 
-// face i of the tile: OpenFOAM makeFaceCentresAndAreas (.com v2412) on the staged points -> LDS (+ the per-face
-// values the owner's tile publishes).  tflags bit0: every face of the tile is a quadrilateral.
+// face i of the tile: OpenFOAM makeFaceCentresAndAreas on the staged points -> LDS (+ the per-face values the owner's
+// tile publishes).  tflags bit0: every face of the tile is a quadrilateral.
+// ORG = false: OpenFOAM.com v2312-v2506 (fan triangles weighted by |n|); ORG = true: OpenFOAM.org 12 (fan triangles weighted
+// by n . nHat with nHat the normalised sum of the n, centre = point average when the weights sum to <= vSmall) -- the two
+// OpenFOAM lines the reference builds against (Allwmake:47); the area vector 0.5 * sum(n) is the same in both.
+template <bool ORG>
 __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int i, unsigned tflags,
                                          int wantAvg, int writeFaces) {
     const double *px = L.px, *py = L.py, *pz = L.pz;
@@ -171,7 +175,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
     const int fw4 = g.fvWidth[tile] >> 2;
     const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
     V3 fCentre, ctr, area;
-    if (tflags & 1u) {
+    if (!ORG && (tflags & 1u)) {
         // the general loop below unrolled for four vertices -- same operations in the same order, every vertex read
         // once, no pad / position tests
         const ushort4 q = fvTile[i];
@@ -208,6 +212,38 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
             const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z);
             ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
             area = 0.5 * cross(p1 - p0, p2 - p0);
+        } else if (ORG) {
+            V3 sumA = v3(0, 0, 0);
+            V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
+            SMGPU_ELL_FOREACH(row, fw4, 1, {
+                const V3 p = ldsv(px, py, pz, e);
+                if (j == 0) { first = p; thisPoint = p; }
+                else { sumA = sumA + cross(p - thisPoint, fCentre - thisPoint); thisPoint = p; }
+            })
+            sumA = sumA + cross(first - thisPoint, fCentre - thisPoint);
+            const V3 sumAHat = sumA / mag(sumA);   // normalised(sumA)
+            double sumAn = 0.0;
+            V3 sumAnc = v3(0, 0, 0);
+#define SMGPU_FAN_ORG(NEXT)                                                    \
+    {                                                                          \
+        const V3 nextPoint = (NEXT);                                           \
+        const V3 a = cross(nextPoint - thisPoint, fCentre - thisPoint);        \
+        const V3 c = (thisPoint + nextPoint) + fCentre;                        \
+        const double an = dot(a, sumAHat);                                     \
+        sumAn += an;                                                           \
+        sumAnc = sumAnc + an * c;                                              \
+        thisPoint = nextPoint;                                                 \
+    }
+            SMGPU_ELL_FOREACH(row, fw4, 1, {
+                const V3 p = ldsv(px, py, pz, e);
+                if (j == 0) { first = p; thisPoint = p; }
+                else SMGPU_FAN_ORG(p)
+            })
+            SMGPU_FAN_ORG(first)
+#undef SMGPU_FAN_ORG
+            if (sumAn > SMGPU_VSMALL) ctr = ((1.0 / 3.0) * sumAnc) / sumAn;
+            else ctr = fCentre;
+            area = 0.5 * sumA;
         } else {
             V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
             double sumA = 0.0;
@@ -250,7 +286,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
 
 // the thread's cell of the tile: OpenFOAM makeCellCentresAndVols (.com v2412) on the face values in LDS.
 // tflags bit1: every cell of the tile has six faces.
-template <int T>
+template <int T, bool ORG>
 __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int tid, unsigned tflags) {
     const double *fcx = L.fcx, *fcy = L.fcy, *fcz = L.fcz, *fax = L.fax, *fay = L.fay, *faz = L.faz;
     const int ci = g.cellBeg[tile] + tid;
@@ -263,7 +299,8 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 #define SMGPU_PYR(E, FC)                                                                                   \
     {                                                                                                      \
         const V3 fA = ldsv(fax, fay, faz, (E) & 0x7fff);                                                   \
-        const double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);               \
+        double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);                     \
+        if (ORG) pyr3Vol = (pyr3Vol > SMGPU_VSMALL) ? pyr3Vol : SMGPU_VSMALL;   /* OpenFOAM.org: max(.., vSmall) */ \
         const V3 pc = (3.0 / 4.0) * (FC) + (1.0 / 4.0) * cEst;                                             \
         ctr = ctr + pyr3Vol * pc;                                                                          \
         vol += pyr3Vol;                                                                                    \
@@ -299,7 +336,7 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 // deferN > 0: the first workgroup also closes the PREVIOUS iteration (reduction of its deferN workgroup partials into
 // stats[deferIter], reset of the per-iteration counters) -- with relTol <= 0 nothing can stop the loop, so that work does
 // not need a launch of its own between the iterations (k_finish, ~6 us of launch latency per iteration).
-template <int T>
+template <int T, bool ORG>
 __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
                                                   int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
                                                   double* deferHist) {
@@ -319,79 +356,10 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
     // phase 1: every face of the tile once
     const unsigned tflags = g.tileFlags[tile];
     const int nf = g.tfOff[tile + 1] - g.tfOff[tile];
-    for (int i = tid; i < nf; i += T) geomFace(s, g, L, tile, i, tflags, wantAvg, writeFaces);
+    for (int i = tid; i < nf; i += T) geomFace<ORG>(s, g, L, tile, i, tflags, wantAvg, writeFaces);
     __syncthreads();
     // phase 2: one thread per cell
-    geomCell<T>(s, g, L, tile, tid, tflags);
-}
-
-// The same work as k_geom_tile on a PERSISTENT grid: every workgroup walks a sequence of tiles and software-pipelines
-// them -- the point ids of its next tile are requested before the face phase of the current one, the point records
-// after the first round of faces, and they are stored into the LDS point arrays as soon as the faces are done (the
-// cell phase no longer reads points).  With one tile per workgroup all resident workgroups stage, then compute, in
-// step; here the loads of one tile hide behind the arithmetic of the previous one.
-// MEASURED (100^3, MI355X): slower than k_geom_tile, 80.8 vs 66.3 us -- the prefetch registers push the kernel from 117
-// to 150+ VGPRs, i.e. from 4 to 3 waves per SIMD, which costs more than the hidden staging (14.8 us if it were fully
-// exposed) gains; capping the registers spills (118 us).  Kept selectable (SMGPU_GEOM_PERSIST=1) and under test.
-// wgPerXcd: workgroups per XCD of the launch (grid = 8 * wgPerXcd with xcdMap, see launchTile).
-constexpr int kGeomPrefetchRounds = 2;
-template <int T>
-__global__ void __launch_bounds__(T) k_geom_tile_p(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
-                                                    int nLaunch, int xcdMap, int wgPerXcd) {
-    if (s.acc->stop) return;
-    int li, stride, end;
-    if (xcdMap & 1) {
-        const int per = (nLaunch + 7) >> 3, x = blockIdx.x & 7;
-        li = x * per + (blockIdx.x >> 3);
-        stride = wgPerXcd;
-        end = min((x + 1) * per, nLaunch);
-    } else { li = blockIdx.x; stride = gridDim.x; end = nLaunch; }
-    if (li >= end) return;
-    extern __shared__ double lds[];
-    const GeomLds L = geomLds(lds, g);
-    const int tid = threadIdx.x;
-    int tile = tileList ? tileList[li] : li;
-    {
-        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
-        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, L.px, L.py, L.pz, tid);
-    }
-    __syncthreads();
-    for (;;) {
-        const int liNext = li + stride;
-        const bool hasNext = liNext < end;
-        const int tileNext = hasNext ? (tileList ? tileList[liNext] : liNext) : 0;
-        const int nb = hasNext ? g.tpOff[tileNext] : 0, nn = hasNext ? g.tpOff[tileNext + 1] - nb : 0;
-        const bool pre = hasNext && nn <= T * kGeomPrefetchRounds;     // wave-uniform
-        int nid[kGeomPrefetchRounds];
-        V3 nv[kGeomPrefetchRounds];
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < kGeomPrefetchRounds; ++u) { const int i = u * T + tid; nid[u] = (i < nn) ? g.tpIds[nb + i] : -1; }
-        }
-        const unsigned tflags = g.tileFlags[tile];
-        const int nf = g.tfOff[tile + 1] - g.tfOff[tile];
-        if (tid < nf) geomFace(s, g, L, tile, tid, tflags, wantAvg, writeFaces);
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < kGeomPrefetchRounds; ++u) nv[u] = (nid[u] >= 0) ? ldv(s.ptsCur, nid[u]) : v3(0, 0, 0);
-        }
-        for (int i = tid + T; i < nf; i += T) geomFace(s, g, L, tile, i, tflags, wantAvg, writeFaces);
-        __syncthreads();                      // faces complete; the point arrays are free
-        if (pre) {
-#pragma unroll
-            for (int u = 0; u < kGeomPrefetchRounds; ++u) {
-                const int i = u * T + tid;
-                if (nid[u] >= 0) { L.px[i] = nv[u].x; L.py[i] = nv[u].y; L.pz[i] = nv[u].z; }
-            }
-        } else if (hasNext) {
-            stageRecords<T, 2>(s.ptsCur, g.tpIds + nb, nn, L.px, L.py, L.pz, tid);
-        }
-        geomCell<T>(s, g, L, tile, tid, tflags);
-        if (!hasNext) break;
-        __syncthreads();                      // next tile's points staged, this tile's face arrays consumed
-        li = liNext;
-        tile = tileNext;
-    }
+    geomCell<T, ORG>(s, g, L, tile, tid, tflags);
 }
 
 // The fused per-point proposal kernel of kernels.hpp (k_smooth) with the cell centres and neighbour
@@ -655,106 +623,6 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
 #pragma unroll
         for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) d[q] = rec[q];
     }
-}
-
-// k_smooth_tile on a PERSISTENT grid, software-pipelined over the tile sequence of each workgroup (tile staging takes
-// 21 us of the 45 us kernel on 100^3 and all resident workgroups stage, then compute, in step): while tile k is being
-// computed from LDS, the records of tile k+1 are in flight into registers (their ids were fetched one tile earlier) and
-// the ids of tile k+2 are requested; after the compute phase the registers are stored to LDS.
-// MEASURED (100^3, MI355X): slower than k_smooth_tile, 59.9 vs 45.8 us -- the compiler needs 132-143 VGPRs instead of
-// 64-67 (3 instead of 5 waves per SIMD).  Kept selectable (SMGPU_SMOOTH_PERSIST=1) and under test.
-// wgPerXcd: workgroups per XCD of the launch (grid = 8 * wgPerXcd with xcdMap, see launchTile).
-template <bool FINAL, int T>
-__global__ void __launch_bounds__(T) k_smooth_tile_p(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList, int nLaunch,
-                                                      int xcdMap, int wgPerXcd) {
-    if (s.acc->stop) return;
-    constexpr int RC = 2, RN = 3;        // register rounds for the cell-centre / neighbour-point records of a tile
-    int li, stride, end;
-    if (xcdMap & 1) {
-        const int per = (nLaunch + 7) >> 3, x = blockIdx.x & 7;
-        li = x * per + (blockIdx.x >> 3);
-        stride = wgPerXcd;
-        end = min((x + 1) * per, nLaunch);
-    } else { li = blockIdx.x; stride = gridDim.x; end = nLaunch; }
-    if (li >= end) return;
-    extern __shared__ double lds[];
-    const SmoothLds L = smoothLds(lds, g);
-    const int tid = threadIdx.x;
-#define SMGPU_TILE_OF(LI) (tileList ? tileList[(LI)] : (LI))
-    int tile = SMGPU_TILE_OF(li);
-    {
-        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
-        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
-    }
-    // ids of the next tile
-    int idC[RC], idN[RN];
-    bool pre1 = false;                    // tile k+1 exists and fits the register rounds (wave-uniform)
-    int li1 = li + stride;
-    {
-        const bool has1 = li1 < end;
-        const int t1 = has1 ? SMGPU_TILE_OF(li1) : 0;
-        const int bC = has1 ? g.tcOff[t1] : 0, nC = has1 ? g.tcOff[t1 + 1] - bC : 0;
-        const int bN = has1 ? g.tnOff[t1] : 0, nN = has1 ? g.tnOff[t1 + 1] - bN : 0;
-        pre1 = has1 && nC <= T * RC && nN <= T * RN;
-#pragma unroll
-        for (int u = 0; u < RC; ++u) { const int i = u * T + tid; idC[u] = (pre1 && i < nC) ? g.tcIds[bC + i] : -1; }
-#pragma unroll
-        for (int u = 0; u < RN; ++u) { const int i = u * T + tid; idN[u] = (pre1 && i < nN) ? g.tnIds[bN + i] : -1; }
-    }
-    __syncthreads();
-    for (;;) {
-        const bool has1 = li1 < end;
-        const int t1 = has1 ? SMGPU_TILE_OF(li1) : 0;
-        // records of tile k+1 (ids already here), ids of tile k+2
-        V3 vC[RC], vN[RN];
-        if (pre1) {
-#pragma unroll
-            for (int u = 0; u < RC; ++u) vC[u] = (idC[u] >= 0) ? ldv(s.cellCtr, idC[u]) : v3(0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < RN; ++u) vN[u] = (idN[u] >= 0) ? ldv(s.ptsCur, idN[u]) : v3(0, 0, 0);
-        }
-        const int li2 = li1 + stride;
-        const bool has2 = li2 < end;
-        int idC2[RC], idN2[RN];
-        bool pre2 = false;
-        {
-            const int t2 = has2 ? SMGPU_TILE_OF(li2) : 0;
-            const int bC = has2 ? g.tcOff[t2] : 0, nC = has2 ? g.tcOff[t2 + 1] - bC : 0;
-            const int bN = has2 ? g.tnOff[t2] : 0, nN = has2 ? g.tnOff[t2 + 1] - bN : 0;
-            pre2 = has2 && nC <= T * RC && nN <= T * RN;
-#pragma unroll
-            for (int u = 0; u < RC; ++u) { const int i = u * T + tid; idC2[u] = (pre2 && i < nC) ? g.tcIds[bC + i] : -1; }
-#pragma unroll
-            for (int u = 0; u < RN; ++u) { const int i = u * T + tid; idN2[u] = (pre2 && i < nN) ? g.tnIds[bN + i] : -1; }
-        }
-        // tile k from LDS
-        const SmoothRow R = smoothRow<T>(g, tile, tid);
-        double dist = 0.0;
-        int fcount = 0;
-        smoothPoint<FINAL, T>(m, s, prm, g, L, R, tile, tid, dist, fcount);
-        if (FINAL) blockPublish<T>(s, dist, fcount, tile);
-        if (!has1) break;
-        __syncthreads();                  // every thread is done reading the LDS records of tile k
-        if (pre1) {
-#pragma unroll
-            for (int u = 0; u < RC; ++u) { const int i = u * T + tid; if (idC[u] >= 0) { L.cx[i] = vC[u].x; L.cy[i] = vC[u].y; L.cz[i] = vC[u].z; } }
-#pragma unroll
-            for (int u = 0; u < RN; ++u) { const int i = u * T + tid; if (idN[u] >= 0) { L.nx[i] = vN[u].x; L.ny[i] = vN[u].y; L.nz[i] = vN[u].z; } }
-        } else {
-            const int b = g.tcOff[t1], n = g.tcOff[t1 + 1] - b;
-            const int b2 = g.tnOff[t1], n2 = g.tnOff[t1 + 1] - b2;
-            stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
-        }
-#pragma unroll
-        for (int u = 0; u < RC; ++u) idC[u] = idC2[u];
-#pragma unroll
-        for (int u = 0; u < RN; ++u) idN[u] = idN2[u];
-        pre1 = pre2;
-        li = li1; li1 = li2; tile = t1;
-        __syncthreads();
-    }
-#undef SMGPU_TILE_OF
 }
 
 }  // namespace smgpu

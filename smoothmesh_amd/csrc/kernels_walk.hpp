@@ -163,8 +163,86 @@ __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkV
     }
 }
 
-// predicates: k_walk_pred_self, one thread per active point (self test), then k_walk_pred, one thread per (active point,
-// neighbour) entry.  nA < 0: the counts are read from the device header (no host read-back) and the threads stride over them.
+// calcMinMaxFaceAngleForPoint (SM.C:1276-1308; pointFaceAngles in kernels.hpp) spread over the 32 lanes of a half wave:
+// the (edge of p, cell around that edge) pairs -- 24 for an interior hex point -- are dealt to the lanes, each lane forms
+// its cell's angle exactly as edgeFaceAngles<true> does (two projected face-centre vectors with the substituted
+// coordinates, the projected cell centre, two acos), and min / max are reduced over the lanes (order-free).  One thread
+// walking all of them was a chain of ~200 dependent gathers; a lane's chain is ~10.  All 32 lanes must call it with the
+// same arguments.
+__device__ __forceinline__ void groupPointFaceAngles(const MeshView& m, const State& s, int p, const V3& c1, int i2, const V3& c2,
+                                                     int lane, double& mn, double& mx) {
+    const int eb = m.ppOff[p], nEdgesP = m.ppOff[p + 1] - eb;
+    if (nEdgesP > 32) {   // extreme valence: one lane does it the plain way
+        if (lane == 0) pointFaceAngles(m, s, p, c1, i2, c2, mn, mx);
+        mn = __shfl(mn, 0, 32);
+        mx = __shfl(mx, 0, 32);
+        return;
+    }
+    const int myE = (lane < nEdgesP) ? m.peEdge[eb + lane] : -1;
+    const int myN = (myE >= 0) ? m.ecOff[myE + 1] - m.ecOff[myE] : 0;
+    int incl = myN;
+    for (int o = 1; o < 32; o <<= 1) {
+        const int t = __shfl_up(incl, o, 32);
+        if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 31, 32);
+    mn = 2.0 * SMGPU_PI;
+    mx = 0.0;
+    for (int base = 0; base < total; base += 32) {
+        const int idx = base + lane;
+        int e = -1, first = 0;
+        for (int j = 0; j < nEdgesP; ++j) {      // the edge whose cells include pair idx
+            const int hi = __shfl(incl, j, 32), ej = __shfl(myE, j, 32), nj = __shfl(myN, j, 32);
+            if (e < 0 && idx < hi) { e = ej; first = hi - nj; }
+        }
+        if (idx >= total) continue;
+        const int k = m.ecOff[e] + (idx - first);
+        // edgeFaceAngles<true> for the one cell k of edge e
+        const int e0I = m.edges[2 * e], e1I = m.edges[2 * e + 1];
+        V3 e0 = ldv(s.ptsCur, e0I), e1 = ldv(s.ptsCur, e1I);
+        if (e0I == p) e0 = c1; else if (i2 >= 0 && e0I == i2) e0 = c2;
+        if (e1I == p) e1 = c1; else if (i2 >= 0 && e1I == i2) e1 = c2;
+        const V3 cC = 0.5 * (e0 + e1);
+        const V3 d = e1 - e0;
+        const V3 eVec = d / mag(d);
+        const int fb = m.efOff[e];
+        auto faceVec = [&](int f) -> V3 {
+            V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
+            const int b = m.faceOff[f], n = m.faceOff[f + 1] - b;
+            for (int i = 0; i < n; ++i) {
+                const int q = m.facePts[b + i];
+                if (q == p) fc = fc + c1;
+                else if (i2 >= 0 && q == i2) fc = fc + c2;
+                else fc = fc + ldv(s.ptsCur, q);
+            }
+            fc = divByCount(fc, n);   // = fc / double(n), bit for bit
+            const V3 cf = cC - fc;
+            const double dp = dot(cf, eVec);
+            const V3 pC = fc + dp * eVec;
+            const V3 w = pC - cC;
+            return w / mag(w);
+        };
+        const V3 p0 = faceVec(m.efFace[fb + m.ecF0[k]]);
+        const V3 p1 = faceVec(m.efFace[fb + m.ecF1[k]]);
+        const V3 cc = ldv(s.cellCtr, m.ecCell[k]);  // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+        const V3 cf = cC - cc;
+        const double dp = dot(cf, eVec);
+        const V3 pC = cc + dp * eVec;
+        const V3 w = pC - cC;
+        const V3 cV = w / mag(w);
+        const double angle = clampAcos(dot(p0, cV)) + clampAcos(dot(cV, p1));   // calcEdgeCenterEdgeAngle SM.C:980-998
+        if (angle < mn) mn = angle;
+        if (angle > mx) mx = angle;
+    }
+    for (int o = 16; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mn, o, 32), b = __shfl_xor(mx, o, 32);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+}
+
+// predicates: k_walk_pred_self, one half wave per active point (self test), then k_walk_pred, one half wave per (active point,
+// neighbour) entry.  nA < 0: the counts are read from the device header (no host read-back) and the groups stride over them.
 // What no replay can ever consult is not evaluated (the decisions are the reference's, bit for bit):
 //   * a neighbour frozen before the walk is skipped by every visit (SM.C:1411), so its entry needs no angles;
 //   * "the neighbour's move hurts me at my PROPOSAL" (bit0) is only read when the point acts from its proposal, i.e. when it is
@@ -174,8 +252,9 @@ __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkV
 __global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
-    for (int t = blockIdx.x * kBlock + threadIdx.x; t < nA; t += gridDim.x * kBlock) {
-        if (t == 0) w.actEntOff[nA] = nE;
+    const int lane = threadIdx.x & 31;
+    for (int t = (blockIdx.x * kBlock + threadIdx.x) >> 5; t < nA; t += (gridDim.x * kBlock) >> 5) {
+        if (t == 0 && lane == 0) w.actEntOff[nA] = nE;
         const int p = w.actIds[t];
         const V3 cur = ldv(s.ptsCur, p);
         const V3 np = ldv(s.prop, p);
@@ -184,17 +263,18 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, 
         uint8_t sb = (moved ? 2 : 0) | (frozenBefore ? 4 : 0);
         if (moved && !frozenBefore) {   // SM.C:1385-1394 (a frozen point is held at its current position: no self test)
             double mn, mx;
-            pointFaceAngles(m, s, p, np, -1, np, mn, mx);
+            groupPointFaceAngles(m, s, p, np, -1, np, lane, mn, mx);
             const double curMin = s.ptMin[p], curMax = s.ptMax[p];
             if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
         }
-        w.actBits[t] = sb;
+        if (lane == 0) w.actBits[t] = sb;
     }
 }
 __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
-    for (int e = blockIdx.x * kBlock + threadIdx.x; e < nE; e += gridDim.x * kBlock) {
+    const int lane = threadIdx.x & 31;
+    for (int e = (blockIdx.x * kBlock + threadIdx.x) >> 5; e < nE; e += (gridDim.x * kBlock) >> 5) {
         const int slot = w.entOwner[e];
         const int p = w.actIds[slot];
         const int q = w.entNbr[e];
@@ -207,18 +287,248 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
             const double curMin = s.ptMin[p], curMax = s.ptMax[p];
             const uint8_t sb = w.actBits[slot];
             double mn, mx;
-            pointFaceAngles(m, s, p, cur, q, nq, mn, mx);   // this point held at its current position
+            groupPointFaceAngles(m, s, p, cur, q, nq, lane, mn, mx);   // this point held at its current position
             const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
             if (badF) nb |= 2;
             if (!(sb & 2)) { if (badF) nb |= 1; }           // not moved: proposal = current position
             else if (!(sb & 5)) {                           // acts from its proposal if it is still free at its first visit, SM.C:1419
                 const V3 np = ldv(s.prop, p);
-                pointFaceAngles(m, s, p, np, q, nq, mn, mx);
+                groupPointFaceAngles(m, s, p, np, q, nq, lane, mn, mx);
                 if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
             }
         }
-        w.entBits[e] = nb;
-        w.entSlot[e] = w.activeSlot[q];
+        if (lane == 0) { w.entBits[e] = nb; w.entSlot[e] = w.activeSlot[q]; }
+    }
+}
+
+// ---- the predicates of one active point by one wave, from its "star" staged in LDS ----------------------------------------
+// Every angle the walk can ask about point p involves only the faces that contain p (the rings of p's edges), their vertices
+// and the centres of p's cells.  The per-entry kernels above fetch that neighbourhood again for every (entry, state, edge, cell)
+// -- ~2 000 gathers of 24 bytes per active point, and the L1 / address path, not arithmetic, bounds them.  Here a wave
+// stages the star once (faces of p with their vertex ids and current coordinates: ~48 vertex slots for an interior hex
+// point), every lane keeps ITS (edge, cell) pair (same for all jobs of the point: the edge's other end, the two ring faces
+// as local ids, the cell centre), and a job -- self test, or one entry in one state -- is the pair's angle with the
+// substituted coordinates, read from LDS, reduced over a half wave.  Two jobs run side by side on the two halves.
+// Arithmetic per angle is edgeFaceAngles<true>'s, operation for operation.  Points whose star exceeds the caps take the
+// gather form (groupPointFaceAngles).
+constexpr int kStarFaces = 32, kStarVerts = 160, kStarEnts = 64;
+struct StarLds {
+    int fid[kStarFaces];
+    int voff[kStarFaces + 1];
+    int vid[kStarVerts];
+    double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
+    unsigned char nb[kStarEnts];
+};
+struct StarPair {          // a lane's (edge, cell) pair
+    bool valid;
+    int xI;                // the edge's other end point
+    bool pFirst;           // p is the edge's first end point (edges[2e])
+    V3 xc, cc;             // current coordinates of xI, centre of the cell
+    int l0, l1;            // the two ring faces as star-local ids
+};
+__device__ __forceinline__ double starPairAngle(const StarLds& L, const StarPair& P, int p, const V3& c1, int i2, const V3& c2) {
+    const V3 xs = (i2 >= 0 && P.xI == i2) ? c2 : P.xc;
+    const V3 e0 = P.pFirst ? c1 : xs, e1 = P.pFirst ? xs : c1;
+    const V3 cC = 0.5 * (e0 + e1);
+    const V3 d = e1 - e0;
+    const V3 eVec = d / mag(d);
+    auto faceVec = [&](int l) -> V3 {
+        V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
+        const int b = L.voff[l], n = L.voff[l + 1] - b;
+        for (int i = 0; i < n; ++i) {
+            const int q = L.vid[b + i];
+            if (q == p) fc = fc + c1;
+            else if (i2 >= 0 && q == i2) fc = fc + c2;
+            else fc = fc + v3(L.vx[b + i], L.vy[b + i], L.vz[b + i]);
+        }
+        fc = divByCount(fc, n);   // = fc / double(n), bit for bit
+        const V3 cf = cC - fc;
+        const double dp = dot(cf, eVec);
+        const V3 pC = fc + dp * eVec;
+        const V3 w = pC - cC;
+        return w / mag(w);
+    };
+    const V3 p0 = faceVec(P.l0);
+    const V3 p1 = faceVec(P.l1);
+    const V3 cf = cC - P.cc;
+    const double dp = dot(cf, eVec);
+    const V3 pC = P.cc + dp * eVec;
+    const V3 w = pC - cC;
+    const V3 cV = w / mag(w);
+    return clampAcos(dot(p0, cV)) + clampAcos(dot(cV, p1));   // calcEdgeCenterEdgeAngle SM.C:980-998
+}
+// min / max of the pairs' angles over a half wave; invalid lanes contribute the neutral values
+__device__ __forceinline__ void starReduce(bool valid, double angle, double& mn, double& mx) {
+    mn = valid ? angle : 2.0 * SMGPU_PI;   // every angle is < 2 pi and > 0: the reference's start values never win
+    mx = valid ? angle : 0.0;
+    for (int o = 16; o > 0; o >>= 1) {
+        const double a = __shfl_xor(mn, o, 32), b = __shfl_xor(mx, o, 32);
+        if (a < mn) mn = a;
+        if (b > mx) mx = b;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+    if (s.acc->stop) return;
+    if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    __shared__ StarLds lds[kBlock / 64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    StarLds& L = lds[wave];
+    for (int a = blockIdx.x * (kBlock / 64) + wave; a < nA; a += gridDim.x * (kBlock / 64)) {
+        if (a == 0 && lane == 0) w.actEntOff[nA] = nE;
+        const int p = w.actIds[a];
+        const V3 cur = ldv(s.ptsCur, p);
+        const V3 np = ldv(s.prop, p);
+        const bool moved = (np != cur);
+        const bool frozenBefore = s.frozen[p] != 0;
+        const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+        const int eBeg = w.actEntOff[a], eEnd = (a + 1 < nA) ? w.actEntOff[a + 1] : nE, nEnt = eEnd - eBeg;
+        auto bad = [&](double mn, double mx) { return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax)); };
+        // the point's edges with their cell counts, its faces with their vertex counts
+        const int eb = m.ppOff[p], nEdgesP = m.ppOff[p + 1] - eb;
+        const int fb = m.pfOff[p], nF = m.pfOff[p + 1] - fb;
+        const int myE = (lane < nEdgesP) ? m.peEdge[eb + lane] : -1;
+        const int myN = (myE >= 0) ? m.ecOff[myE + 1] - m.ecOff[myE] : 0;
+        const int myF = (lane < nF) ? m.pfFace[fb + lane] : -1;
+        const int myFb = (myF >= 0) ? m.faceOff[myF] : 0;
+        const int myV = (myF >= 0) ? m.faceOff[myF + 1] - myFb : 0;
+        int inclN = myN, inclV = myV;
+        for (int o = 1; o < 64; o <<= 1) {
+            const int tn = __shfl_up(inclN, o, 64), tv = __shfl_up(inclV, o, 64);
+            if (lane >= o) { inclN += tn; inclV += tv; }
+        }
+        const int totalPairs = __shfl(inclN, 63, 64), totalV = __shfl(inclV, 63, 64);
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalPairs <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts;
+        // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
+        int q = -1;
+        V3 nq = v3(0, 0, 0);
+        bool eligible = false;
+        unsigned char nb0 = 0;
+        if (fits && lane < nEnt) {
+            q = w.entNbr[eBeg + lane];
+            nq = ldv(s.prop, q);
+            const bool qFrozen = s.frozen[q] != 0;
+            nb0 = qFrozen ? 8 : 0;
+            eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
+            if (eligible) nb0 |= 4;
+        }
+        if (!fits) {
+            // gather form, one half wave per job (the same decisions)
+            unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+            if (moved && !frozenBefore) {
+                double mn, mx;
+                groupPointFaceAngles(m, s, p, np, -1, np, hl, mn, mx);
+                if (bad(mn, mx)) sbits |= 1u;
+            }
+            if (lane == 0) w.actBits[a] = (uint8_t)sbits;
+            for (int e0 = eBeg; e0 < eEnd; e0 += 2) {
+                const int e = e0 + half;
+                if (e >= eEnd) continue;
+                const int qq = w.entNbr[e];
+                const V3 nqq = ldv(s.prop, qq);
+                const bool qFrozen = s.frozen[qq] != 0;
+                unsigned nbb = qFrozen ? 8u : 0u;
+                if (!qFrozen && nqq != ldv(s.ptsCur, qq)) {
+                    nbb |= 4u;
+                    double mn, mx;
+                    groupPointFaceAngles(m, s, p, cur, qq, nqq, hl, mn, mx);
+                    const bool badF = bad(mn, mx);
+                    if (badF) nbb |= 2u;
+                    if (!(sbits & 2u)) { if (badF) nbb |= 1u; }
+                    else if (!(sbits & 5u)) {
+                        groupPointFaceAngles(m, s, p, np, qq, nqq, hl, mn, mx);
+                        if (bad(mn, mx)) nbb |= 1u;
+                    }
+                }
+                if (hl == 0) { w.entBits[e] = (uint8_t)nbb; w.entSlot[e] = w.activeSlot[qq]; }
+            }
+            continue;
+        }
+        // stage the star: face ids, vertex offsets, vertex ids and current coordinates
+        if (lane < nF) {
+            const int o = inclV - myV;
+            L.fid[lane] = myF;
+            L.voff[lane] = o;
+            for (int v = 0; v < myV; ++v) {
+                const int g = m.facePts[myFb + v];
+                const V3 c = ldv(s.ptsCur, g);
+                L.vid[o + v] = g; L.vx[o + v] = c.x; L.vy[o + v] = c.y; L.vz[o + v] = c.z;
+            }
+        }
+        if (lane == 0) L.voff[nF] = totalV;
+        if (lane < nEnt) L.nb[lane] = nb0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // this lane's (edge, cell) pair -- the same on both halves
+        StarPair P;
+        P.valid = hl < totalPairs;
+        P.xI = -1; P.pFirst = true; P.xc = v3(0, 0, 0); P.cc = v3(0, 0, 0); P.l0 = 0; P.l1 = 0;
+        {
+            int e = -1, first = 0;
+            for (int j = 0; j < nEdgesP; ++j) {
+                const int hi = __shfl(inclN, j, 64), ej = __shfl(myE, j, 64), nj = __shfl(myN, j, 64);
+                if (e < 0 && hl < hi) { e = ej; first = hi - nj; }
+            }
+            if (P.valid) {
+                const int k = m.ecOff[e] + (hl - first);
+                const int e0I = m.edges[2 * e], e1I = m.edges[2 * e + 1];
+                P.pFirst = (e0I == p);
+                P.xI = P.pFirst ? e1I : e0I;
+                P.xc = ldv(s.ptsCur, P.xI);
+                P.cc = ldv(s.cellCtr, m.ecCell[k]);   // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+                const int efb = m.efOff[e];
+                const int f0 = m.efFace[efb + m.ecF0[k]], f1 = m.efFace[efb + m.ecF1[k]];
+                for (int l = 0; l < nF; ++l) { const int g = L.fid[l]; if (g == f0) P.l0 = l; if (g == f1) P.l1 = l; }
+            }
+        }
+        // jobs, two at a time (one per half wave).  Round 1: job 0 = the self test, job 1 + i = entry i with p at its current position
+        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+        const bool selfNeeded = moved && !frozenBefore;
+        for (int j0 = 0; j0 < 1 + nEnt; j0 += 2) {
+            const int j = j0 + half;
+            const int ei = j - 1;                                    // entry of this half's job (-1: self)
+            const int src = ei < 0 ? 0 : ei;
+            const int jq = __shfl(q, src, 64);
+            const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
+            const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
+            const bool run = (j < 1 + nEnt) && (ei < 0 ? selfNeeded : jEl);
+            double angle = 0.0;
+            if (run && P.valid) angle = (ei < 0) ? starPairAngle(L, P, p, np, -1, np) : starPairAngle(L, P, p, cur, jq, jnq);
+            double mn, mx;
+            starReduce(run && P.valid, angle, mn, mx);
+            const bool isBad = run && bad(mn, mx);
+            // the self result is known to the whole wave after the first step
+            const int selfBad = __shfl((j == 0 && isBad) ? 1 : 0, 0, 64);
+            if (j0 == 0 && selfBad) sbits |= 1u;
+            if (run && ei >= 0 && hl == 0) {
+                unsigned char v = L.nb[ei];
+                if (isBad) v |= 2;
+                if (isBad && !moved) v |= 1;                         // not moved: proposal = current position
+                L.nb[ei] = v;
+            }
+        }
+        if (lane == 0) w.actBits[a] = (uint8_t)sbits;
+        // round 2: entry i with p at its proposal -- only read if p is still free at its first visit and does not freeze itself
+        if (moved && !(sbits & 5u)) {
+            for (int j0 = 0; j0 < nEnt; j0 += 2) {
+                const int ei = j0 + half;
+                const int src = ei < nEnt ? ei : 0;
+                const int jq = __shfl(q, src, 64);
+                const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
+                const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
+                const bool run = ei < nEnt && jEl;
+                double angle = 0.0;
+                if (run && P.valid) angle = starPairAngle(L, P, p, np, jq, jnq);
+                double mn, mx;
+                starReduce(run && P.valid, angle, mn, mx);
+                if (run && hl == 0 && bad(mn, mx)) L.nb[ei] |= 1;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nEnt) { w.entBits[eBeg + lane] = L.nb[lane]; w.entSlot[eBeg + lane] = w.activeSlot[q]; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -108,7 +108,8 @@ struct smgpu_handle {
     WalkView wv{};
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
-    int walkFixBlocks = 128;    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
+    int walkFixBlocks = 128;
+    bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
     void* pinned = nullptr;
     size_t pinnedBytes = 0;
@@ -132,8 +133,7 @@ struct smgpu_handle {
     int deferN = 0, deferIter = 0;   // close the previous iteration inside the next geometry launch (k_geom_tile)
     double* deferLocal = nullptr;    // multi-rank: where that deferred reduction leaves {residual, nFrozenPoints}
     double* deferHist = nullptr;
-    bool smoothPersist = false; // SMGPU_SMOOTH_PERSIST=1: persistent, software-pipelined smoothing kernel (measured slower)
-    bool geomPersist = false;  // SMGPU_GEOM_PERSIST=1: persistent, software-pipelined geometry kernel (measured slower)
+    bool foamOrg = false;      // OpenFOAM.org 12's face / cell geometry formulas instead of OpenFOAM.com's (smgpu_set_foam_variant)
     int xcdMap = 1;            // SMGPU_XCD_MAP: contiguous tile range per XCD (L2 sharing between neighbouring tiles)
     bool layersOn = false;     // smgpu_set_layers
     bool packTiles = true;     // SMGPU_PACK_TILES=0: exchange A packed by the per-point kernel (k_halo_packA)
@@ -365,6 +365,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devUpload(h, &m.ppPt, t.pointPoints);
     rc |= devUpload(h, &m.peEdge, t.pointEdges.val);
     rc |= devUpload(h, &m.pfOff, t.pointFaces.off);
+    rc |= devUpload(h, &m.pfFace, t.pointFaces.val);
     rc |= devUpload(h, &m.pfPrev, t.pfPrev);
     rc |= devUpload(h, &m.pfNext, t.pfNext);
     rc |= devUpload(h, &m.pfPrevSlot, t.pfPrevSlot);
@@ -385,8 +386,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
-    h->geomPersist = envInt("SMGPU_GEOM_PERSIST", 0) != 0;
-    h->smoothPersist = envInt("SMGPU_SMOOTH_PERSIST", 0) != 0;
+    h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
+    { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -606,6 +607,14 @@ int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
     return 0;
 }
 
+int smgpu_set_foam_variant(smgpu_handle* h, int32_t variant) {
+    if (!h) return fail("null handle");
+    if (variant != SMGPU_FOAM_COM && variant != SMGPU_FOAM_ORG) return fail("smgpu_set_foam_variant: unknown variant");
+    h->foamOrg = variant == SMGPU_FOAM_ORG;
+    h->geomAheadDone = false;
+    return 0;
+}
+
 int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
     if (!h || !p) return fail("null argument");
     if (!(p->maxStepLength > 0.0)) return fail("maxStepLength must be > 0");
@@ -632,38 +641,21 @@ static void ensureDynLds(K kernel, int device, size_t bytes) {
 }
 template <int T>
 static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles) {
-    ensureDynLds(k_geom_tile<T>, h->device, h->geomLds);
-    if (h->geomPersist) {
-        // persistent, software-pipelined form: as many workgroups as the chip holds at once (8 XCDs x 32 CUs)
-        ensureDynLds(k_geom_tile_p<T>, h->device, h->geomLds);
-        int perCu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_geom_tile_p<T>, T, h->geomLds) != hipSuccess || perCu < 1) perCu = 2;
-        const int per = (nTiles + 7) >> 3;
-        const int wgPerXcd = std::min(per, perCu * 32);
-        const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
-        hipLaunchKernelGGL(k_geom_tile_p<T>, dim3(grid), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0, tileList, nTiles,
-                           h->xcdMap, wgPerXcd);
-        return;
+    if (h->foamOrg) {
+        ensureDynLds(k_geom_tile<T, true>, h->device, h->geomLds);
+        hipLaunchKernelGGL((k_geom_tile<T, true>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
+                           tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
+    } else {
+        ensureDynLds(k_geom_tile<T, false>, h->device, h->geomLds);
+        hipLaunchKernelGGL((k_geom_tile<T, false>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
+                           tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     }
-    hipLaunchKernelGGL(k_geom_tile<T>, dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                       tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     h->deferN = 0;
     h->deferLocal = h->deferHist = nullptr;
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
     ensureDynLds(k_smooth_tile<FINAL, T>, h->device, h->smoothLds);
-    if (h->smoothPersist) {
-        ensureDynLds(k_smooth_tile_p<FINAL, T>, h->device, h->smoothLds);
-        int perCu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, k_smooth_tile_p<FINAL, T>, T, h->smoothLds) != hipSuccess || perCu < 1) perCu = 2;
-        const int per = (nTiles + 7) >> 3;
-        const int wgPerXcd = std::min(per, perCu * 32);
-        const int grid = (h->xcdMap & 1) ? 8 * wgPerXcd : std::min(nTiles, perCu * 256);
-        hipLaunchKernelGGL((k_smooth_tile_p<FINAL, T>), dim3(grid), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList, nTiles, h->xcdMap,
-                           wgPerXcd);
-        return;
-    }
     hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
                        nTiles, h->xcdMap);
 }
@@ -740,8 +732,8 @@ static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList
             else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT);
         });
     }
-    if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg); })) return 1;
-    if (launchK(h, K_CELL_CENTRES, [&] { hipLaunchKernelGGL(k_cell_centres, dim3(gridFor(m.nCells)), dim3(kBlock), 0, h->stream, m, s); })) return 1;
+    if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg, h->foamOrg ? 1 : 0); })) return 1;
+    if (launchK(h, K_CELL_CENTRES, [&] { hipLaunchKernelGGL(k_cell_centres, dim3(gridFor(m.nCells)), dim3(kBlock), 0, h->stream, m, s, h->foamOrg ? 1 : 0); })) return 1;
     return 0;
 }
 
@@ -892,8 +884,11 @@ static int runHostWalk(smgpu_handle* h) {
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
-            hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 3) / 4), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            else {
+                hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+                hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            }
         })) return 1;
     // second compaction: only the points that can act and only their true entries go to the host
     const int nSlotBlocks = gridFor(nA);
@@ -972,14 +967,16 @@ static int runFixWalk(smgpu_handle* h) {
     const int P = m.nPoints;
     const int64_t maxEntries = (int64_t)h->topo.pointEdges.nnz();
     // grids: enough workgroups to fill the chip several times over; the kernels stride over the device-side counts
-    const int gPred = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 64);
     const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_pred_self, dim3(std::min(gridFor(P), 256 * 16)), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
-            hipLaunchKernelGGL(k_walk_pred, dim3(gPred), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+            else {
+                hipLaunchKernelGGL(k_walk_pred_self, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+                hipLaunchKernelGGL(k_walk_pred, dim3(256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+            }
         })) return 1;
     if (launchK(h, K_FA_WALK, [&] {
             hipLaunchKernelGGL(k_rel_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1);
@@ -1149,7 +1146,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     int launched = 0;
     // relTol <= 0 cannot stop the loop (residual >= 0): the end-of-iteration reduction then rides in the next
     // iteration's geometry launch instead of a launch of its own; the last iteration is closed by k_finish
-    const bool deferFinish = relTol <= 0.0 && h->useTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1);
+    const bool deferFinish = relTol <= 0.0 && h->useTiles && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1);
     if (flushDeferred(h)) return 1;
     for (int i = 0; i < nIters; ++i) {
         if (runBndPre(h)) return 1;
@@ -1550,7 +1547,7 @@ int smgpu_iter_end(smgpu_handle* h) {
     double* hist = (h->statsHistory && h->statsHistoryCap > 0) ? h->statsHistory + 2 * (size_t)(h->statsHistoryN++ % h->statsHistoryCap) : nullptr;
     // with a stats history nobody reads the record before the loop ends: the reduction then rides in the next geometry
     // launch (first launch of smgpu_iter_begin) as in smgpu_iterate; flushDeferred closes the last iteration
-    if (hist && fusedTiles && !h->geomPersist && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
+    if (hist && fusedTiles && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
         h->deferN = nPart; h->deferIter = -1 /* no stats[] record in this mode */; h->deferLocal = h->localStats; h->deferHist = hist;
     } else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
     std::swap(h->st.ptsCur, h->st.ptsNext);
@@ -1579,7 +1576,7 @@ int smgpu_layers_begin(smgpu_handle* h, const smgpu_layer_desc* d, int32_t* enab
     // face area vectors of the current coordinates (fvPatch::Sf): the direct face kernel writes all of them
     const MeshView& m = h->mv;
     State s = h->st;
-    hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, 0);
+    hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, 0, h->foamOrg ? 1 : 0);
     h->lbArea.resize(3 * (size_t)m.nFaces);
     HIP_OK(hipMemcpyAsync(h->lbArea.data(), s.fArea, sizeof(double) * h->lbArea.size(), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));

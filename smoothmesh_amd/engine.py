@@ -192,6 +192,11 @@ class SmoothEngine:
         self._check(self._lib.smgpu_set_params(self._h, C.byref(q)))
         self.params = p
 
+    def set_foam_variant(self, variant):
+        """"com" (OpenFOAM.com v2312-v2506, default) or "org" (OpenFOAM.org 12): whose face / cell geometry formulas the
+        cell centres follow (the reference builds against either, Allwmake:47)"""
+        self._check(self._lib.smgpu_set_foam_variant(self._h, {"com": 0, "org": 1}[variant]))
+
     # -- the loop ------------------------------------------------------------------------------
     def _layer_desc(self, lp: LayerParams, minEdgeLength: float):
         start, size, kind, sel = patch_arrays(self.mesh, lp.layerPatches)

@@ -88,8 +88,7 @@ def test_natural_tile_order(oracle_lib, monkeypatch):
     _compare(hex_block(9, 7, 5, jitter=0.3, seed=2), oracle_lib)
 
 
-@pytest.mark.parametrize("env", [{"SMGPU_GEOM_PERSIST": "1", "SMGPU_SMOOTH_PERSIST": "1"}, {"SMGPU_XCD_MAP": "0"},
-                                 {"SMGPU_GEOM_PERSIST": "1", "SMGPU_SMOOTH_PERSIST": "1", "SMGPU_XCD_MAP": "0"}])
+@pytest.mark.parametrize("env", [{"SMGPU_XCD_MAP": "0"}, {"SMGPU_WALK_STAR": "0"}, {"SMGPU_TILE_MORTON": "0"}])
 def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
     """persistent / software-pipelined geometry and smoothing kernels, round-robin tile launch: tuning knobs, same bits;
     meshes large enough for several tiles per workgroup sequence, with quadrilateral-only and mixed tiles"""
@@ -146,3 +145,47 @@ def test_counters_and_sizes(oracle_lib):
     c = {k["name"]: k for k in e.counters()}
     assert c["k_geom_tile"]["launches"] == 5 and c["k_geom_tile"]["ms"] > 0
     assert c["k_smooth<proposal>"]["algoBytesPerLaunch"] > 100 * 1331
+
+
+@pytest.mark.parametrize("mesh_kind", ["hex", "cavity", "nonconvex", "degenerate"])
+@pytest.mark.parametrize("tiles", ["1", "0"])
+def test_openfoam_org_geometry_variant(oracle_lib, monkeypatch, mesh_kind, tiles):
+    """OpenFOAM.org 12's makeFaceCentresAndAreas / makeCellCentresAndVols (fan triangles weighted by the projected area,
+    pyramids clamped at vSmall) as a run-time switch: tiled and direct kernels against the oracle's restatement; geometry
+    fields to rounding, coordinates bit for bit; and the results do differ from the OpenFOAM.com default"""
+    from smoothmesh_amd import SmoothEngine, default_params
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import cavity_mesh
+    monkeypatch.setenv("SMGPU_TILES", tiles)
+    if mesh_kind == "hex":
+        mesh = hex_block(11, 9, 8, jitter=0.3, seed=4)
+    elif mesh_kind == "cavity":
+        mesh = cavity_mesh(12, jitter=0.25, seed=6)
+    elif mesh_kind == "nonconvex":
+        mesh = cavity_mesh(8, jitter=0.45, seed=2)          # heavy jitter on 5..8-vertex faces: non-convex, strongly warped polygons
+    else:
+        mesh = hex_block(4, 4, 3, jitter=0.2, seed=1)
+        mesh.points[mesh.facePoints[mesh.faceOffsets[40]:mesh.faceOffsets[41]]] = mesh.points[mesh.facePoints[mesh.faceOffsets[40]]]   # a face collapsed to a point
+    o = oracle_lib.Oracle(mesh)
+    o.set_foam_variant("org")
+    e = SmoothEngine(mesh)
+    e.set_foam_variant("org")
+    p = default_params(o.mesh_stats()[0], minEdgeLength=1e-3 if mesh_kind == "degenerate" else 0.5 * o.mesh_stats()[0])
+    o.set_params(p); e.set_params(p)
+    o.phaseA(); o.phaseB()
+    e.debug_propose()
+    for name in ("faceCentres", "faceAreas", "cellCentres"):
+        a, b = e.debug_field(name), o.field(name)
+        ok = np.isfinite(b)
+        assert np.array_equal(np.isfinite(a), ok)
+        assert np.max(np.abs(a[ok] - b[ok])) <= 1e-15 * max(1.0, np.max(np.abs(b[ok]))), name
+    n_o, res_o, frz_o = o.iterate(5, 0.0)
+    n_g, res_g, frz_g = e.iterate(5, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    ok = np.isfinite(o.points())
+    assert np.array_equal(e.get_points()[ok], o.points()[ok])
+    if mesh_kind in ("hex", "cavity"):
+        e2 = SmoothEngine(mesh)                             # default variant: OpenFOAM.com
+        e2.set_params(p)
+        e2.iterate(5, 0.0)
+        assert not np.array_equal(e2.get_points(), e.get_points())

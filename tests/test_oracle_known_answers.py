@@ -226,3 +226,86 @@ def test_face_angles_of_a_sheared_lattice(oracle_lib):
     xdir = (np.abs(r0[:, 1] - r1[:, 1]) < 1e-12) & (np.abs(r0[:, 2] - r1[:, 2]) < 1e-12)
     insx = (r0[:, 1] > 0.1) & (r0[:, 1] < 0.9) & (r0[:, 2] > 0.1) & (r0[:, 2] < 0.9)
     assert np.allclose(emin[xdir & insx], math.pi / 2, atol=1e-13) and np.allclose(emax[xdir & insx], math.pi / 2, atol=1e-13)
+
+
+# ---- OpenFOAM.org 12 geometry variant (the reference builds against .org 12 as well as .com, Allwmake:47) ----------------
+def _prism_over_polygon(poly, height=1.0):
+    """one prismatic cell over a planar polygon (z = 0 .. height): faces bottom, top, sides; all boundary"""
+    from smoothmesh_amd.mesh import PolyMesh, Patch
+    n = len(poly)
+    pts = np.array([[x, y, 0.0] for x, y in poly] + [[x, y, height] for x, y in poly])
+    faces = [list(range(n))[::-1], [n + i for i in range(n)]] + [[i, (i + 1) % n, n + (i + 1) % n, n + i] for i in range(n)]
+    off = np.zeros(len(faces) + 1, np.int32); np.cumsum([len(f) for f in faces], out=off[1:])
+    return PolyMesh(points=pts, faceOffsets=off, facePoints=np.concatenate([np.asarray(f, np.int32) for f in faces]),
+                    owner=np.zeros(len(faces), np.int32), neighbour=np.zeros(0, np.int32),
+                    patches=[Patch("walls", "patch", len(faces), 0)], nCells=1)
+
+
+def _polygon_centroid(poly):
+    x, y = np.array(poly).T
+    xn, yn = np.roll(x, -1), np.roll(y, -1)
+    cr = x * yn - xn * y
+    a = cr.sum() / 2
+    return np.array([((x + xn) * cr).sum() / (6 * a), ((y + yn) * cr).sum() / (6 * a)]), a
+
+
+def test_org_variant_face_centre_is_the_true_centroid_of_a_nonconvex_polygon(oracle_lib):
+    """OpenFOAM.org weights the fan triangles by their area PROJECTED on the face normal, which makes the centre independent
+    of the point average the fan is built around: for a planar L-shaped hexagon -- whose fan has a triangle of opposite
+    orientation -- it is the exact area centroid, while OpenFOAM.com's magnitude weights miss it; areas agree"""
+    L = [(0.0, 0.0), (4.0, 0.0), (4.0, 0.5), (0.5, 0.5), (0.5, 4.0), (0.0, 4.0)]
+    mesh = _prism_over_polygon(L)
+    c2, a2 = _polygon_centroid(L)
+    out = {}
+    for variant in ("com", "org"):
+        o = oracle_lib.Oracle(mesh)
+        o.set_foam_variant(variant)
+        o.phaseA()
+        out[variant] = (o.field("faceCentres").reshape(-1, 3), o.field("faceAreas").reshape(-1, 3), o.field("cellCentres").reshape(-1, 3))
+    top_org, top_com = out["org"][0][1], out["com"][0][1]
+    assert np.max(np.abs(top_org - [c2[0], c2[1], 1.0])) < 1e-15
+    assert np.max(np.abs(top_com[:2] - c2)) > 1e-3                      # the .com formula is off for this face
+    assert np.array_equal(out["org"][1], out["com"][1])                 # area vectors: 0.5 * sum(n) in both
+    assert abs(out["org"][1][1][2] - a2) < 1e-15
+    # (the cell centre is NOT the centroid here: the mean of the face centres lies in the notch of the L, two pyramids are
+    # negative and .org clamps them -- test_org_variant_clamps_negative_pyramids pins that rule)
+
+
+def test_org_variant_equals_com_on_planar_convex_faces(oracle_lib):
+    """all fan triangles of a planar convex face point the same way: |n| = n . nHat, so the two variants agree to rounding
+    (a cube lattice is exact in both) -- and on warped faces they differ"""
+    from smoothmesh_amd.meshgen import hex_block
+    for jitter, same in ((0.0, True), (0.3, False)):
+        mesh = hex_block(5, 4, 3, jitter=jitter, seed=3)
+        cc = {}
+        for variant in ("com", "org"):
+            o = oracle_lib.Oracle(mesh); o.set_foam_variant(variant); o.phaseA()
+            cc[variant] = o.field("cellCentres")
+        if same:
+            assert np.array_equal(cc["com"], cc["org"])
+        else:
+            d = np.max(np.abs(cc["com"] - cc["org"]))
+            assert 1e-9 < d < 1e-2                                       # warped quads: the weights differ, slightly
+
+
+def test_org_variant_clamps_negative_pyramids(oracle_lib):
+    """makeCellCentresAndVols of OpenFOAM.org: pyr3Vol = max(Sf . (Cf - cEst), vSmall).  A cell with one face turned inside
+    out has a negative pyramid there: .org drops it (weight vSmall), .com subtracts it"""
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(1)
+    f = 2                                                               # reverse one face: its area vector now points inwards
+    b, e = mesh.faceOffsets[f], mesh.faceOffsets[f + 1]
+    mesh.facePoints[b:e] = mesh.facePoints[b:e][::-1].copy()
+    res = {}
+    for variant in ("com", "org"):
+        o = oracle_lib.Oracle(mesh); o.set_foam_variant(variant); o.phaseA()
+        fc, fa = o.field("faceCentres").reshape(-1, 3), o.field("faceAreas").reshape(-1, 3)
+        cest = fc.mean(axis=0)
+        pyr = np.einsum("ij,ij->i", fa, fc - cest)
+        assert (pyr < 0).sum() == 1
+        w = np.where(pyr > 1e-300, pyr, 1e-300) if variant == "org" else pyr
+        pc = 0.75 * fc + 0.25 * cest
+        expect = (w[:, None] * pc).sum(axis=0) / w.sum()
+        res[variant] = o.field("cellCentres").reshape(-1, 3)[0]
+        assert np.max(np.abs(res[variant] - expect)) < 1e-14
+    assert np.max(np.abs(res["com"] - res["org"])) > 1e-3
