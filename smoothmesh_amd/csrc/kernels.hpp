@@ -54,6 +54,8 @@ struct State {
     uint8_t* frozen;
     double* edgeMin; double* edgeMax; double* ptMin; double* ptMax;
     uint8_t* faActive; uint8_t* faS; uint8_t* faN; int* walkStack;
+    uint8_t faGen;     // generation tag of this iteration's faActive / faMaybe marks (a mark counts only if it equals the tag: no
+                       // per-iteration clearing of the two P-byte arrays; they are zeroed when the tag wraps)
     Accum* acc;
     double* blkMax; int* blkCnt;   // per-workgroup partials of (max step, frozen count); reduced by k_finish
     smgpu_iter_stats* stats;
@@ -617,7 +619,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const 
     if (faMaybe && s.acc->nFaMaybe == 0) return;   // the filter found every edge inside the good range
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= m.nEdges) return;
-    if (faMaybe && !(faMaybe[m.edges[2 * e]] | faMaybe[m.edges[2 * e + 1]])) return;
+    if (faMaybe && faMaybe[m.edges[2 * e]] != s.faGen && faMaybe[m.edges[2 * e + 1]] != s.faGen) return;
     double mn, mx;
     if (!m.edgeRingOk[e]) {
         const V3 z = v3(0, 0, 0);
@@ -660,7 +662,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm p
     if (faMaybe && s.acc->nFaMaybe == 0) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= m.nPoints) return;
-    if (faMaybe && !faMaybe[p]) return;   // k_fa_point_flags already cleared faActive: all its edges are GOOD
+    if (faMaybe && faMaybe[p] != s.faGen) return;   // all its edges are GOOD; its faActive mark is stale, i.e. clear
     double mn = 2.0 * SMGPU_PI, mx = 0.0;
     for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
         const int e = m.peEdge[k];
@@ -671,7 +673,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm p
     s.ptMin[p] = mn;
     s.ptMax[p] = mx;
     const bool good = (mn > prm.smallAngle) && (mx < prm.largeAngle);
-    s.faActive[p] = good ? 0 : 1;
+    s.faActive[p] = good ? 0 : s.faGen;
     if (!good) atomicAdd(&s.acc->nActive, 1);
 }
 
@@ -699,7 +701,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_pred(MeshView m, State s, Prm prm
     if (s.acc->nActive == 0) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     if (p >= m.nPoints) return;
-    if (!s.faActive[p]) return;
+    if (s.faActive[p] != s.faGen) return;
     const V3 cur = ldv(s.ptsCur, p);
     const V3 np = ldv(s.prop, p);
     const double curMin = s.ptMin[p], curMax = s.ptMax[p];
@@ -744,7 +746,7 @@ __global__ void __launch_bounds__(64) k_fa_walk(MeshView m, State s) {
     const int nChunks = (m.nPoints + 63) / 64;
     for (int c = nChunks - 1; c >= 0; --c) {
         const int idx = c * 64 + lane;
-        const bool act = (idx < m.nPoints) && s.faActive[idx];
+        const bool act = (idx < m.nPoints) && s.faActive[idx] == s.faGen;
         unsigned long long mask = __ballot(act);
         if (mask == 0ull) continue;
         if (lane == 0) {
@@ -755,7 +757,7 @@ __global__ void __launch_bounds__(64) k_fa_walk(MeshView m, State s) {
                 s.walkStack[sp++] = c * 64 + bit;
                 while (sp > 0) {
                     const int p = s.walkStack[--sp];
-                    if (!s.faActive[p]) continue;                  // SM.C:1367-1369
+                    if (s.faActive[p] != s.faGen) continue;        // SM.C:1367-1369
                     const uint8_t sb = s.faS[p];
                     bool useNew = (!s.frozen[p]) && (sb & 2);      // SM.C:1376-1385
                     if (useNew && (sb & 1)) { s.frozen[p] = 1; useNew = false; }  // SM.C:1391-1399

@@ -37,11 +37,11 @@ __device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
 
 // ---- face angles: per edge GOOD (0) / UNSURE (1) -------------------------------------------------------
 // GOOD = every cell angle of the edge lies inside (small + margin, large - margin) for sure.
-// An UNSURE edge marks both end points in faMaybe (zeroed before the launch, like faActive): a point may be
+// An UNSURE edge marks both end points in faMaybe with the iteration's tag (State::faGen; like faActive): a point may be
 // outside the good range only if one of its edges is UNSURE; every other point is inside for sure (SM.C:1367-1369).
 __device__ __forceinline__ void markUnsureEdge(const State& s, const int* edges, int e, uint8_t* faMaybe) {
-    faMaybe[edges[2 * e]] = 1;          // racing writers all store 1
-    faMaybe[edges[2 * e + 1]] = 1;
+    faMaybe[edges[2 * e]] = s.faGen;    // racing writers all store this iteration's tag
+    faMaybe[edges[2 * e + 1]] = s.faGen;
     atomicAdd(&s.acc->nFaMaybe, 1);     // rare on a decent mesh
 }
 

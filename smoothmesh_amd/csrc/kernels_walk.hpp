@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, Walk
     if (s.acc->stop) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
     int a = 0, e = 0;
-    if (p < m.nPoints && s.faActive[p]) { a = 1; e = m.ppOff[p + 1] - m.ppOff[p]; }
+    if (p < m.nPoints && s.faActive[p] == s.faGen) { a = 1; e = m.ppOff[p + 1] - m.ppOff[p]; }
     __shared__ int sa[kBlock / 64], se[kBlock / 64];
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); e += __shfl_down(e, o, 64); }
     if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; se[threadIdx.x >> 6] = e; }
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(kScanBlock) k_walk_scan(State s, WalkView w, i
 __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
     if (s.acc->stop) return;
     const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool act = p < m.nPoints && s.faActive[p];
+    const bool act = p < m.nPoints && s.faActive[p] == s.faGen;
     const int a = act ? 1 : 0, e = act ? m.ppOff[p + 1] - m.ppOff[p] : 0;
     int ia = a, ie = e;
     const int lane = threadIdx.x & 63;

@@ -988,17 +988,28 @@ static int runFixWalk(smgpu_handle* h) {
     return 0;
 }
 
+// New tag for this iteration's faMaybe / faActive marks; the arrays are cleared only when the 8-bit tag wraps (every 255
+// iterations) instead of by two P-byte fills per iteration.
+static int nextFaGen(smgpu_handle* h, hipStream_t stream) {
+    if (h->st.faGen == 255 || h->st.faGen == 0) {
+        HIP_OK(hipMemsetAsync(h->dFaMaybe, 0, (size_t)h->mv.nPoints, stream));
+        HIP_OK(hipMemsetAsync(h->st.faActive, 0, (size_t)h->mv.nPoints, stream));
+        h->st.faGen = 0;
+    }
+    ++h->st.faGen;
+    return 0;
+}
+
 // proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
 // launch the face-angle filter (needs only the geometry of the current coordinates) on the side stream
 static int forkFaFilter(smgpu_handle* h) {
     if (!h->side || !h->prm.faceAngleConstraint || !h->useFilter || h->exactAll || !h->edgeTilesOk || h->faFilterInFlight) return 0;
     const MeshView& m = h->mv;
-    State s = h->st;
     const Prm prm = makePrm(h);
     if (depSignal(h, DEP_FORK, h->stream, h->evFork) || depWait(h, DEP_FORK, h->side, h->evFork)) return 1;
+    if (nextFaGen(h, h->side)) return 1;
+    State s = h->st;
     if (launchK(h, K_FA_FILTER, [&] {
-            (void)hipMemsetAsync(h->dFaMaybe, 0, (size_t)m.nPoints, h->side);
-            (void)hipMemsetAsync(s.faActive, 0, (size_t)m.nPoints, h->side);
             hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->side, s, prm, h->ev, m.edges, h->dFaMaybe,
                                h->etl.nTiles, h->xcdMap);
         }, h->side)) return 1;
@@ -1048,9 +1059,9 @@ static int runConstraints(smgpu_handle* h) {
             h->faFilterInFlight = false;
             faMaybe = h->dFaMaybe;
         } else if (filt) {
+            if (nextFaGen(h, h->stream)) return 1;
+            s.faGen = h->st.faGen;
             if (launchK(h, K_FA_FILTER, [&] {
-                    (void)hipMemsetAsync(h->dFaMaybe, 0, (size_t)m.nPoints, h->stream);
-                    (void)hipMemsetAsync(s.faActive, 0, (size_t)m.nPoints, h->stream);
                     if (h->edgeTilesOk)
                         hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->stream, s, prm, h->ev, m.edges, h->dFaMaybe,
                                            h->etl.nTiles, h->xcdMap);
@@ -1058,6 +1069,9 @@ static int runConstraints(smgpu_handle* h) {
                         hipLaunchKernelGGL(k_fa_edges_filter, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, prm, h->dFaMaybe);
                 })) return 1;
             faMaybe = h->dFaMaybe;
+        } else {   // no filter: every point gets a fresh mark from k_fa_points
+            if (nextFaGen(h, h->stream)) return 1;
+            s.faGen = h->st.faGen;
         }
         if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
         if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
@@ -2050,7 +2064,8 @@ int smgpu_debug_get_field(smgpu_handle* h, const char* name, double* out, int64_
         std::vector<uint8_t> tmp((size_t)cnt);
         HIP_OK(hipMemcpyAsync(tmp.data(), bsrc, (size_t)cnt, hipMemcpyDeviceToHost, h->stream));
         HIP_OK(hipStreamSynchronize(h->stream));
-        for (int64_t i = 0; i < cnt; ++i) out[i] = tmp[(size_t)i];
+        const bool tagged = (bsrc == st.faActive);   // marks carry the iteration's tag
+        for (int64_t i = 0; i < cnt; ++i) out[i] = tagged ? (tmp[(size_t)i] == st.faGen ? 1.0 : 0.0) : (double)tmp[(size_t)i];
     }
     return 0;
 }
