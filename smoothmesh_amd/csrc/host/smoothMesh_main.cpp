@@ -9,13 +9,19 @@
 //
 //   smoothMesh [-case <dir>] [-parallel] [-time <t|constant>] [-centroidalIters n] [-relTol x] ...
 //
-// -parallel: the case holds processorN/ sub-domains (decomposePar layout, with pointProcAddressing);
-// this single process drives one engine per sub-domain, placed round-robin on the visible GPUs, and
-// moves the shared-point buffers with device-to-device copies.  (The measured multi-GPU path is the
-// one-process-per-GPU RCCL driver in smoothmesh_amd/halo.py; this one keeps the CLI usable on any
-// number of GPUs.)
+// -parallel: the case holds processorN/ sub-domains (decomposePar layout, with pointProcAddressing) and the run is what
+// `mpirun -np N smoothMesh -parallel` is for the reference (testcase/run_parallel:19): ONE PROCESS PER SUB-DOMAIN, one GPU
+// each.  There is no MPI in this image, so the front-end forks its N ranks itself before anything touches HIP
+// (node_comm.hpp); rank r takes processor<r>/ and device (r + -device) mod #devices.  Per iteration the shared-point records
+// (exchange A + the layer / boundary record L in ONE group, then exchange F; syncTools::syncPointList at SM.C:134-148,
+// 402-478, 2374) travel as grouped ncclSend / ncclRecv between the ranks that share points, straight from and into the
+// engines' device buffers on the engine's stream -- RCCL over xGMI, no host copy, no host synchronisation while relTol <= 0
+// (the per-iteration {residual, nFrozenPoints} are then gathered once per chunk).  The small collectives of the set-up go
+// through the ranks' shared mapping.  SMOOTHMESH_TRANSPORT=shm (chosen by itself when the node has fewer GPUs than ranks:
+// RCCL refuses two ranks on one device) stages the same records through that mapping instead -- a debug transport.
 #include <dirent.h>
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
 
 #include <algorithm>
 #include <chrono>
@@ -31,6 +37,7 @@
 #include <vector>
 
 #include "../../../include/smgpu.h"
+#include "node_comm.hpp"
 #include "polymesh_io.hpp"
 
 using namespace smhost;
@@ -39,10 +46,16 @@ namespace {
 
 const double VSMALL = 1.0e-300, SMALL = 1.0e-15;
 
+NodeComm g_comm;            // the ranks of a -parallel run (size 1 otherwise)
+bool g_master = true;       // Info: only the master rank prints (Pstream::master())
+#define OUT(...) do { if (g_master) std::printf(__VA_ARGS__); } while (0)
+#define OUTS(text) do { if (g_master) std::puts(text); } while (0)
+
 [[noreturn]] void fatal(const std::string& msg) {   // FatalError << ... << abort(FatalError)
-    std::fprintf(stdout, "\n\n--> FOAM FATAL ERROR: \n%s\n\nFOAM aborting\n\n", msg.c_str());
+    if (g_comm.size > 1) std::fprintf(stdout, "\n\n[%d] --> FOAM FATAL ERROR: \n%s\n\nFOAM aborting\n\n", g_comm.rank, msg.c_str());
+    else std::fprintf(stdout, "\n\n--> FOAM FATAL ERROR: \n%s\n\nFOAM aborting\n\n", msg.c_str());
     std::fflush(stdout);
-    std::exit(1);
+    std::_Exit(1);          // the parent of a -parallel run stops the other ranks
 }
 
 struct Options {
@@ -189,6 +202,7 @@ void check(int rc, const char* what) {
     if (rc) fatal(std::string(what) + ": " + smgpu_last_error());
 }
 #define HIPCHK(e) do { hipError_t r__ = (e); if (r__ != hipSuccess) fatal(std::string(#e) + ": " + hipGetErrorString(r__)); } while (0)
+#define NCCLCHK(e) do { ncclResult_t r__ = (e); if (r__ != ncclSuccess) fatal(std::string(#e) + ": " + ncclGetErrorString(r__)); } while (0)
 
 struct Rank {
     std::string root;            // case dir (serial) or processorN dir
@@ -215,57 +229,54 @@ std::string findInstance(const std::string& root, const std::vector<std::pair<do
     return root + "/constant/polyMesh";
 }
 
-void buildHalo(std::vector<Rank>& R) {
-    const int n = (int)R.size();
-    std::vector<std::vector<int64_t>> cand(n);
-    for (int r = 0; r < n; ++r) {
-        std::set<int64_t> s;
-        const auto& m = R[r].mesh;
-        for (const auto& p : m.patches)
-            if (p.type == "processor")
-                for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
-                    for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) s.insert(R[r].pointProc[(size_t)m.facePoints[k]]);
-        cand[r].assign(s.begin(), s.end());
+// the shared-point tables of this rank from every rank's processor-patch points (what smoothmesh_amd/halo.py:HaloTables builds)
+void buildHalo(Rank& K, int r, int n, const std::vector<std::vector<int64_t>>& cand) {
+    std::vector<std::vector<int64_t>> shared(n);
+    std::set<int64_t> all;
+    for (int o = 0; o < n; ++o) {
+        if (o == r) continue;
+        std::set_intersection(cand[r].begin(), cand[r].end(), cand[o].begin(), cand[o].end(), std::back_inserter(shared[o]));
+        all.insert(shared[o].begin(), shared[o].end());
     }
-    for (int r = 0; r < n; ++r) {
-        Rank& K = R[r];
-        std::vector<std::vector<int64_t>> shared(n);
-        std::set<int64_t> all;
-        for (int o = 0; o < n; ++o) {
-            if (o == r) continue;
-            std::set_intersection(cand[r].begin(), cand[r].end(), cand[o].begin(), cand[o].end(), std::back_inserter(shared[o]));
-            all.insert(shared[o].begin(), shared[o].end());
+    K.sharedGlobal.assign(all.begin(), all.end());
+    std::map<int64_t, int32_t> g2l;
+    for (int32_t p = 0; p < K.mesh.nPoints(); ++p) g2l[K.pointProc[(size_t)p]] = p;
+    K.sharedLocal.clear();
+    for (int64_t g : K.sharedGlobal) K.sharedLocal.push_back(g2l.at(g));
+    K.peerCount.assign(n, 0);
+    K.peerSendBase.assign(n, 0);
+    K.sendShared.clear();
+    std::vector<std::vector<std::pair<int, int>>> per(K.sharedGlobal.size());   // (rank, slot)
+    for (size_t i = 0; i < per.size(); ++i) per[i].push_back({r, -1});
+    int run = 0;
+    for (int o = 0; o < n; ++o) {
+        K.peerSendBase[o] = run;
+        K.peerCount[o] = (int)shared[o].size();
+        for (size_t k = 0; k < shared[o].size(); ++k) {
+            const int32_t idx = (int32_t)(std::lower_bound(K.sharedGlobal.begin(), K.sharedGlobal.end(), shared[o][k]) - K.sharedGlobal.begin());
+            K.sendShared.push_back(idx);
+            per[(size_t)idx].push_back({o, run + (int)k});
         }
-        K.sharedGlobal.assign(all.begin(), all.end());
-        std::map<int64_t, int32_t> g2l;
-        for (int32_t p = 0; p < K.mesh.nPoints(); ++p) g2l[K.pointProc[(size_t)p]] = p;
-        K.sharedLocal.clear();
-        for (int64_t g : K.sharedGlobal) K.sharedLocal.push_back(g2l.at(g));
-        K.peerCount.assign(n, 0);
-        K.peerSendBase.assign(n, 0);
-        K.sendShared.clear();
-        std::vector<std::vector<std::pair<int, int>>> per(K.sharedGlobal.size());   // (rank, slot)
-        for (size_t i = 0; i < per.size(); ++i) per[i].push_back({r, -1});
-        int run = 0;
-        for (int o = 0; o < n; ++o) {
-            K.peerSendBase[o] = run;
-            K.peerCount[o] = (int)shared[o].size();
-            for (size_t k = 0; k < shared[o].size(); ++k) {
-                const int32_t idx = (int32_t)(std::lower_bound(K.sharedGlobal.begin(), K.sharedGlobal.end(), shared[o][k]) - K.sharedGlobal.begin());
-                K.sendShared.push_back(idx);
-                per[(size_t)idx].push_back({o, run + (int)k});
-            }
-            run += (int)shared[o].size();
-        }
-        K.nSend = run;
-        K.combOff.assign(1, 0);
-        K.combSlots.clear();
-        for (auto& v : per) {
-            std::sort(v.begin(), v.end());
-            for (auto& pr : v) K.combSlots.push_back(pr.second);
-            K.combOff.push_back((int32_t)K.combSlots.size());
-        }
+        run += (int)shared[o].size();
     }
+    K.nSend = run;
+    K.combOff.assign(1, 0);
+    K.combSlots.clear();
+    for (auto& v : per) {
+        std::sort(v.begin(), v.end());
+        for (auto& pr : v) K.combSlots.push_back(pr.second);
+        K.combOff.push_back((int32_t)K.combSlots.size());
+    }
+}
+
+std::vector<int64_t> processorPatchPoints(const Rank& K) {
+    std::set<int64_t> s;
+    const auto& m = K.mesh;
+    for (const auto& p : m.patches)
+        if (p.type == "processor")
+            for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
+                for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) s.insert(K.pointProc[(size_t)m.facePoints[k]]);
+    return std::vector<int64_t>(s.begin(), s.end());
 }
 
 }  // namespace
@@ -288,21 +299,21 @@ int main(int argc, char** argv) {
         setWriteCompression(wc == "on" || wc == "true" || wc == "yes" || wc == "compressed");
     }
 
-    // sub-domain roots
-    std::vector<Rank> R;
+    // sub-domain roots.  -parallel: one process per processorN/ directory, started here, before anything touches HIP
+    std::vector<Rank> R(1);
+    int nRanks = 1;
     if (opt.parallel) {
-        for (int r = 0;; ++r) {
-            const std::string root = cd + "/processor" + std::to_string(r);
-            if (!dirExists(root)) break;
-            R.emplace_back();
-            R.back().root = root;
-        }
-        if (R.empty()) fatal("-parallel: no processor0 directory in " + cd + " (run decomposePar first)");
+        nRanks = 0;
+        while (dirExists(cd + "/processor" + std::to_string(nRanks))) ++nRanks;
+        if (nRanks == 0) fatal("-parallel: no processor0 directory in " + cd + " (run decomposePar first)");
+        g_comm.launch(nRanks);                 // returns in the ranks only
+        g_master = g_comm.master();
+        R[0].root = cd + "/processor" + std::to_string(g_comm.rank);
     } else {
-        R.emplace_back();
-        R.back().root = cd;
+        R[0].root = cd;
     }
-    const int nRanks = (int)R.size();
+    const int myRank = g_comm.rank;
+    Rank& K0 = R[0];
 
     // start time (SM.C:1791-1803; controlDict startFrom latestTime)
     const auto times = listTimes(R[0].root);
@@ -314,8 +325,9 @@ int main(int argc, char** argv) {
     } else if (!times.empty()) startValue = times.back().first;
     else startIsConstant = true;
 
-    std::printf("smoothMesh (MI355X engine %s)\nCase: %s%s\n", smgpu_version(), cd.c_str(), opt.parallel ? "  [parallel]" : "");
-    std::printf("Create mesh for time = %s\n\n", startIsConstant ? "constant" : timeName(startValue).c_str());
+    OUT("smoothMesh (MI355X engine %s)\nCase: %s%s\n", smgpu_version(), cd.c_str(), opt.parallel ? "  [parallel]" : "");
+    if (opt.parallel) OUT("nProcs : %d   (one process per sub-domain, pid of the master %d)\n", nRanks, (int)getpid());
+    OUT("Create mesh for time = %s\n\n", startIsConstant ? "constant" : timeName(startValue).c_str());
 
     try {
         for (Rank& K : R) {
@@ -370,8 +382,9 @@ int main(int argc, char** argv) {
         for (size_t p = 0; p < patches.size(); ++p)
             if (matchesAny(layerWords, patches[p].name)) { isLayerPatchOf[r][p] = 1; anyLayerPatch = true; }
     }
-    if (anyLayerPatch) std::printf("Patches for boundary layer treatment: %s\n", opt.kv.at("layerPatches").c_str());
-    else std::puts("Patches for boundary layer treatment: none");
+    anyLayerPatch = g_comm.reduceOr(anyLayerPatch);
+    if (anyLayerPatch) OUT("Patches for boundary layer treatment: %s\n", opt.kv.at("layerPatches").c_str());
+    else OUTS("Patches for boundary layer treatment: none");
     const double layerMaxBlendingFraction = opt.getD("layerMaxBlendingFraction", 0.3);
     const bool doLayerTreatment = anyLayerPatch && layerMaxBlendingFraction > SMALL;   // SM.C:2024-2028
     // smoothing patches: every patch unless -smoothingPatches says otherwise (SM.C:1835-1853)
@@ -385,12 +398,13 @@ int main(int argc, char** argv) {
         for (size_t p = 0; p < patches.size(); ++p)
             if (matchesAny(smoothingWords, patches[p].name)) { isSmoothingPatchOf[r][p] = 1; anySmoothingPatch = true; }
     }
-    if (anySmoothingPatch) std::printf("Patches for boundary point smoothing: %s\n", smoothingOpt.c_str());
-    else std::puts("Patches for boundary point smoothing: none");
+    anySmoothingPatch = g_comm.reduceOr(anySmoothingPatch);
+    if (anySmoothingPatch) OUT("Patches for boundary point smoothing: %s\n", smoothingOpt.c_str());
+    else OUTS("Patches for boundary point smoothing: none");
     const double internalSmoothingBlendingFraction = opt.getD("internalSmoothingBlendingFraction", 0.0);   // SM.C:1907
 
-    if (doLayerTreatment) std::puts("Enabled boundary layer treatment\n");
-    else std::puts("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
+    if (doLayerTreatment) OUTS("Enabled boundary layer treatment\n");
+    else OUTS("Boundary layer treatment is disabled. Either no layerPatches were specified or boundaryMaxBlendingFraction is zero\n");
 
     // classification lists of a previous run (labelIOLists <time>/isCornerPoint, <time>/isFeatureEdgePoint, SM.C:2039-2077)
     const std::string startName = startIsConstant ? std::string("constant") : timeName(startValue);
@@ -407,33 +421,58 @@ int main(int argc, char** argv) {
         readIfPresent("isCornerPoint", isCornerPointIO[r]);
         readIfPresent("isFeatureEdgePoint", isFeatureEdgePointIO[r]);
     }
-    if (labelIOListsHaveData) std::puts("Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
-    else std::puts("Did not find corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
+    labelIOListsHaveData = g_comm.reduceOr(labelIOListsHaveData);
+    if (labelIOListsHaveData) OUTS("Found corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
+    else OUTS("Did not find corners and feature edges in isCornerPoint and isFeatureEdgePoint files\n");
 
     // prerequisites of the boundary point smoothing, SM.C:2080-2093
     const std::string targetSurfacesFile = "constant/geometry/targetSurfaces.obj", initEdgesFile = "constant/geometry/initEdges.obj",
                       targetEdgesFile = "constant/geometry/targetEdges.obj";
     const bool doBoundarySmoothing = fileExists(cd + "/" + targetSurfacesFile) && (fileExists(cd + "/" + initEdgesFile) || labelIOListsHaveData) &&
                                      anySmoothingPatch;
-    if (doBoundarySmoothing) std::puts("Enabled boundary point smoothing\n");
-    else std::printf("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\n%s\n%s\n\n", targetSurfacesFile.c_str(), initEdgesFile.c_str());
+    if (doBoundarySmoothing) OUTS("Enabled boundary point smoothing\n");
+    else OUT("Boundary point smoothing is disabled. Missing smoothingPatches, or one or both of files:\n%s\n%s\n\n", targetSurfacesFile.c_str(), initEdgesFile.c_str());
     if (doLayerTreatment && !doBoundarySmoothing)   // SM.C:2095-2098
-        std::puts("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
+        OUTS("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
 
-    // engines
+    // engine: this rank's sub-domain on its device
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) fatal("no HIP device available (this build has no CPU fallback)");
     const int dev0 = (int)opt.getL("device", 0);
-    for (int r = 0; r < nRanks; ++r) {
-        Rank& K = R[r];
+    {
+        Rank& K = K0;
         smgpu_mesh_desc d{};
         d.nPoints = K.mesh.nPoints(); d.nCells = K.mesh.nCells; d.nFaces = K.mesh.nFaces(); d.nInternalFaces = K.mesh.nInternalFaces();
         d.points = K.mesh.points.data(); d.faceOffsets = K.mesh.faceOffsets.data(); d.facePoints = K.mesh.facePoints.data();
         d.owner = K.mesh.owner.data(); d.neighbour = K.mesh.neighbour.data();
         d.isInternalPoint = K.internal.data(); d.isSmoothingSurfacePoint = nullptr;
-        K.device = (dev0 + r) % nDev;
+        K.device = (dev0 + myRank) % nDev;
         d.device = K.device; d.stream = nullptr; d.useCallerStream = 0;
         check(smgpu_create(&d, &K.h), "smgpu_create");
+    }
+    // transport of the per-iteration records between the ranks
+    enum { TRANSPORT_RCCL, TRANSPORT_SHM } transport = TRANSPORT_RCCL;
+    ncclComm_t nccl = nullptr;
+    hipStream_t engineStream = nullptr;
+    if (opt.parallel) {
+        const char* tv = std::getenv("SMOOTHMESH_TRANSPORT");
+        if (tv && std::string(tv) == "shm") transport = TRANSPORT_SHM;
+        else if (tv && std::string(tv) == "rccl") transport = TRANSPORT_RCCL;
+        else if (nDev < nRanks) {
+            transport = TRANSPORT_SHM;
+            OUT("WARNING: %d ranks on %d GPU(s): RCCL needs one device per rank; staging the shared-point records through host memory (debug transport)\n\n", nRanks, nDev);
+        }
+        void* vs = nullptr;
+        check(smgpu_get_stream(K0.h, &vs), "smgpu_get_stream");
+        engineStream = (hipStream_t)vs;
+        HIPCHK(hipSetDevice(K0.device));
+        if (transport == TRANSPORT_RCCL) {
+            ncclUniqueId id;
+            std::memset(&id, 0, sizeof id);
+            if (g_master) NCCLCHK(ncclGetUniqueId(&id));
+            id = g_comm.broadcast(id, 0);
+            NCCLCHK(ncclCommInitRank(&nccl, nRanks, id, myRank));
+        }
     }
 
     // getMeshStats + defaults (SM.C:1857-1918)
@@ -444,11 +483,13 @@ int main(int argc, char** argv) {
         meshMinEdgeLength = std::min(meshMinEdgeLength, a);
         meshMaxEdgeLength = std::max(meshMaxEdgeLength, b);
     }
+    meshMinEdgeLength = g_comm.reduceMin(meshMinEdgeLength);   // returnReduce, SM.C:1527-1535
+    meshMaxEdgeLength = g_comm.reduceMax(meshMaxEdgeLength);
     smgpu_params prm{};
     prm.minEdgeLength = opt.getD("minEdgeLength", 0.5 * meshMinEdgeLength);
     prm.maxStepLength = opt.getD("maxStepLength", 0.3 * prm.minEdgeLength);
     if (prm.maxStepLength > 0.5 * prm.minEdgeLength)
-        std::puts("WARNING: The maximum allowed step length is more than half of the minimum edge length! This may cause unstability in smoothing.\n");
+        OUTS("WARNING: The maximum allowed step length is more than half of the minimum edge length! This may cause unstability in smoothing.\n");
     prm.relStepFrac = opt.getD("relStepFrac", 0.5);
     prm.totalMinFreeze = opt.getB("totalMinFreeze", false);
     prm.minAngle = opt.getD("minAngle", 35.0);
@@ -461,32 +502,36 @@ int main(int argc, char** argv) {
     if (writeInterval <= 0) fatal("writeInterval must be positive");
 
     // parameter echo, SM.C:1933-1975
-    std::puts("Applying following parameter values in smoothing:");
-    std::printf("    centroidalIters        %ld\n    relTol                 %g\n    minEdgeLength          %g\n", centroidalIters, relTol, prm.minEdgeLength);
-    std::printf("    maxStepLength          %g\n    relStepFrac            %g\n    totalMinFreeze         %d\n", prm.maxStepLength, prm.relStepFrac, prm.totalMinFreeze);
-    if (prm.edgeAngleConstraint) std::printf("    edgeAngleConstraint    true\n    minAngle               %g\n", prm.minAngle);
-    else std::puts("    edgeAngleConstraint    false (edge min angle quality constraint is NOT applied)");
-    if (prm.faceAngleConstraint) std::printf("    faceAngleConstraint    true\n    minAngle               %g\n    maxAngle               %g\n", prm.minAngle, prm.maxAngle);
-    else std::puts("    faceAngleConstraint    false (face angle quality constraints are NOT applied)");
+    OUTS("Applying following parameter values in smoothing:");
+    OUT("    centroidalIters        %ld\n    relTol                 %g\n    minEdgeLength          %g\n", centroidalIters, relTol, prm.minEdgeLength);
+    OUT("    maxStepLength          %g\n    relStepFrac            %g\n    totalMinFreeze         %d\n", prm.maxStepLength, prm.relStepFrac, prm.totalMinFreeze);
+    if (prm.edgeAngleConstraint) OUT("    edgeAngleConstraint    true\n    minAngle               %g\n", prm.minAngle);
+    else OUTS("    edgeAngleConstraint    false (edge min angle quality constraint is NOT applied)");
+    if (prm.faceAngleConstraint) OUT("    faceAngleConstraint    true\n    minAngle               %g\n    maxAngle               %g\n", prm.minAngle, prm.maxAngle);
+    else OUTS("    faceAngleConstraint    false (face angle quality constraints are NOT applied)");
     const double layerEdgeLength = opt.getD("layerEdgeLength", prm.minEdgeLength);       // SM.C:1895-1905
     const double layerExpansionRatio = opt.getD("layerExpansionRatio", 1.3);
     const long minLayers = opt.getL("minLayers", 1), maxLayers = opt.getL("maxLayers", 4);
     if (layerMaxBlendingFraction > SMALL)
-        std::printf("    layerMaxBlendingFraction %g\n    layerEdgeLength          %g\n    layerExpansionRatio      %g\n    minLayers                %ld\n"
+        OUT("    layerMaxBlendingFraction %g\n    layerEdgeLength          %g\n    layerExpansionRatio      %g\n    minLayers                %ld\n"
                     "    maxLayers                %ld\n\n", layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers, maxLayers);
-    else std::puts("    layerMaxBlendingFraction 0 (boundary layer treatment is NOT applied)\n");
+    else OUTS("    layerMaxBlendingFraction 0 (boundary layer treatment is NOT applied)\n");
 
     long nPointsTot = 0, nInternalTot = 0;
     for (Rank& K : R) {
         nPointsTot += K.mesh.nPoints();
         for (uint8_t v : K.internal) nInternalTot += v;
     }
-    std::printf("Mesh includes a total of %ld points:\n  - %ld internal (non-boundary) points\n  - %ld boundary points\n", nPointsTot, nInternalTot, nPointsTot - nInternalTot);
-    std::printf("Mesh minimum edge length = %g\nMesh maximum edge length = %g\n\n", meshMinEdgeLength, meshMaxEdgeLength);
+    nPointsTot = g_comm.reduceSum(nPointsTot);
+    nInternalTot = g_comm.reduceSum(nInternalTot);
+    OUT("Mesh includes a total of %ld points:\n  - %ld internal (non-boundary) points\n  - %ld boundary points\n", nPointsTot, nInternalTot, nPointsTot - nInternalTot);
+    OUT("Mesh minimum edge length = %g\nMesh maximum edge length = %g\n\n", meshMinEdgeLength, meshMaxEdgeLength);
 
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
+    std::vector<std::vector<int64_t>> sharedGlobalOf;   // every rank's shared points (global ids, ascending): the set-up syncs
     if (opt.parallel) {
-        buildHalo(R);
+        buildHalo(K0, myRank, nRanks, g_comm.allgatherVec(processorPatchPoints(K0)));
+        sharedGlobalOf = g_comm.allgatherVec(K0.sharedGlobal);
         for (Rank& K : R) {
             HIPCHK(hipSetDevice(K.device));
             const size_t ns = (size_t)std::max(K.nSend, 1);
@@ -507,39 +552,38 @@ int main(int argc, char** argv) {
         }
     }
 
-    // -parallel: the reference's syncPointList calls of the set-ups are done here over the shared points (all sub-domains live
-    // in this process); sharers of a global point in ascending rank order
-    std::map<int64_t, std::vector<std::pair<int, int>>> sharers;   // global id -> (rank, index in the rank's shared list)
-    if (opt.parallel)
-        for (int r = 0; r < nRanks; ++r)
-            for (size_t i = 0; i < R[r].sharedGlobal.size(); ++i) sharers[R[r].sharedGlobal[i]].push_back({r, (int)i});
+    // -parallel: the reference's syncPointList calls of the set-ups: every rank publishes its values at its shared points and
+    // combines, for each of its points, the values of the sharers in ascending rank order
     typedef int (*SharedFn)(smgpu_handle*, int32_t, int32_t, double*);
     auto syncShared = [&](SharedFn fn, const char* what, int field, int width, int op) {   // op 0 max, 1 sum (ascending rank), 2 larger magnitude folded onto own
-        std::vector<std::vector<double>> v(R.size());
-        for (int r = 0; r < nRanks; ++r) {
-            v[r].assign(std::max<size_t>(R[r].sharedGlobal.size(), 1) * width, 0.0);
-            if (!R[r].sharedGlobal.empty()) check(fn(R[r].h, field, 0, v[r].data()), what);
-        }
-        const std::vector<std::vector<double>> sent(v);
-        for (const auto& kv : sharers) {
-            const auto& sh = kv.second;
-            for (const auto& me : sh) {
-                double* x = &v[me.first][(size_t)me.second * width];
-                if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
-                for (const auto& ot : sh) {
-                    const double* y = &sent[ot.first][(size_t)ot.second * width];
-                    if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
-                    if (ot.first == me.first) continue;
-                    if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
-                    else {
-                        const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
-                        if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
-                    }
+        const size_t nS = K0.sharedGlobal.size();
+        std::vector<double> mine(std::max<size_t>(nS, 1) * width, 0.0);
+        if (nS) check(fn(K0.h, field, 0, mine.data()), what);
+        const std::vector<std::vector<double>> sent = g_comm.allgatherVec(mine);
+        std::vector<double> v(mine);
+        for (size_t i = 0; i < nS; ++i) {
+            const int64_t g = K0.sharedGlobal[i];
+            double* x = &v[i * width];
+            if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
+            for (int o = 0; o < nRanks; ++o) {
+                const double* y = nullptr;
+                if (o == myRank) y = &mine[i * width];
+                else {
+                    const auto& sg = sharedGlobalOf[(size_t)o];
+                    const auto it = std::lower_bound(sg.begin(), sg.end(), g);
+                    if (it == sg.end() || *it != g) continue;           // rank o does not hold this point
+                    y = &sent[(size_t)o][(size_t)(it - sg.begin()) * width];
+                }
+                if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
+                if (o == myRank) continue;
+                if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
+                else {
+                    const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+                    if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
                 }
             }
         }
-        for (int r = 0; r < nRanks; ++r)
-            if (!R[r].sharedGlobal.empty()) check(fn(R[r].h, field, 1, v[r].data()), what);
+        if (nS) check(fn(K0.h, field, 1, v.data()), what);
     };
 
     if (doLayerTreatment) {   // set-up SM.C:2215-2221 on the engines' side
@@ -563,7 +607,7 @@ int main(int argc, char** argv) {
         if (!opt.parallel) check(smgpu_set_layers(R[0].h, &ld[0], &on), "smgpu_set_layers");
         else {
             auto sync = [&](int field, int width, int op) { syncShared(smgpu_layers_shared, "smgpu_layers_shared", field, width, op); };
-            for (int r = 0; r < nRanks; ++r) check(smgpu_layers_begin(R[r].h, &ld[r], &on, &maxIter), "smgpu_layers_begin");
+            check(smgpu_layers_begin(K0.h, &ld[0], &on, &maxIter), "smgpu_layers_begin");
             for (int it = 0; it < maxIter; ++it) {
                 for (Rank& K : R) check(smgpu_layers_step(K.h, SMGPU_LAYERS_HOPS_SWEEP, 0), "smgpu_layers_step");
                 sync(SMGPU_LAYERS_F_HOPS, 1, 0);                          // OBB.C:124-130
@@ -584,16 +628,16 @@ int main(int argc, char** argv) {
         std::vector<int32_t> surfTris, initE, tgtE;
         try {
             readObjSurface(cd + "/" + targetSurfacesFile, surfPts, surfTris);
-            std::printf("Target surfaces file \"%s\" stats:\nTriangles    : %zu\nVertices     : %zu\n\n", targetSurfacesFile.c_str(), surfTris.size() / 3, surfPts.size() / 3);
+            OUT("Target surfaces file \"%s\" stats:\nTriangles    : %zu\nVertices     : %zu\n\n", targetSurfacesFile.c_str(), surfTris.size() / 3, surfPts.size() / 3);
             if (fileExists(cd + "/" + initEdgesFile)) {
                 readObjEdges(cd + "/" + initEdgesFile, initPts, initE);
-                std::printf("Initial feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n\n", initEdgesFile.c_str(), initPts.size() / 3, initE.size() / 2);
+                OUT("Initial feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n\n", initEdgesFile.c_str(), initPts.size() / 3, initE.size() / 2);
             }
             if (fileExists(cd + "/" + targetEdgesFile)) {
                 readObjEdges(cd + "/" + targetEdgesFile, tgtPts, tgtE);
-                std::printf("Target feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n", targetEdgesFile.c_str(), tgtPts.size() / 3, tgtE.size() / 2);
+                OUT("Target feature edges file \"%s\" stats:\n  points : %zu\n  edges  : %zu\n", targetEdgesFile.c_str(), tgtPts.size() / 3, tgtE.size() / 2);
             } else
-                std::printf("WARNING: Initial feature edges will be used also as target edges, because\ndid not find file %s.\n\n", targetEdgesFile.c_str());
+                OUT("WARNING: Initial feature edges will be used also as target edges, because\ndid not find file %s.\n\n", targetEdgesFile.c_str());
         } catch (const std::exception& e) { fatal(e.what()); }
         std::vector<std::vector<int32_t>> pStart(R.size()), pSize(R.size());
         std::vector<std::vector<uint8_t>> pKind(R.size());
@@ -616,7 +660,7 @@ int main(int argc, char** argv) {
             d.distanceTolerance = 1e-4 * std::min(meshMinEdgeLength, layerEdgeLength);   // REL_TOL, SM.C:1921
             d.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
         }
-        std::printf("Distance tolerance = %g\n\n", bd[0].distanceTolerance);
+        OUT("Distance tolerance = %g\n\n", bd[0].distanceTolerance);
         smgpu_boundary_info tot{};
         if (!opt.parallel) {
             check(smgpu_set_boundary_smoothing(R[0].h, &bd[0], &tot), "smgpu_set_boundary_smoothing");
@@ -629,16 +673,17 @@ int main(int argc, char** argv) {
                 mn = std::min(mn, m1);
                 for (int c = 0; c < 6; c += 2) { bb[c] = std::min(bb[c], b1[c]); bb[c + 1] = std::max(bb[c + 1], b1[c + 1]); }
             }
+            mn = g_comm.reduceMin(mn);                                         // returnReduce, SM.C:1528-1535
+            for (int c = 0; c < 6; c += 2) { bb[c] = g_comm.reduceMin(bb[c]); bb[c + 1] = g_comm.reduceMax(bb[c + 1]); }
             const double perimeter = bb[1] - bb[0] + bb[3] - bb[2] + bb[5] + bb[4];
-            for (size_t r = 0; r < R.size(); ++r) {
+            {
                 smgpu_boundary_info bi{};
-                check(smgpu_boundary_begin(R[r].h, &bd[r], mn, perimeter, &bi), "smgpu_boundary_begin");
-                if (r == 0) tot = bi;
-                else {   // returnReduce sumOp, BPS.C:423-427
-                    tot.enabled = tot.enabled && bi.enabled;
-                    tot.nCornerPoints += bi.nCornerPoints; tot.nFeatureEdgePoints += bi.nFeatureEdgePoints;
-                    tot.nSmoothingSurfacePoints += bi.nSmoothingSurfacePoints; tot.nFrozenSurfacePoints += bi.nFrozenSurfacePoints;
-                }
+                check(smgpu_boundary_begin(K0.h, &bd[0], mn, perimeter, &bi), "smgpu_boundary_begin");
+                tot = bi;   // returnReduce sumOp, BPS.C:423-427
+                tot.enabled = g_comm.reduceAnd(bi.enabled != 0) ? 1 : 0;
+                tot.nCornerPoints = (int32_t)g_comm.reduceSum(bi.nCornerPoints); tot.nFeatureEdgePoints = (int32_t)g_comm.reduceSum(bi.nFeatureEdgePoints);
+                tot.nSmoothingSurfacePoints = (int32_t)g_comm.reduceSum(bi.nSmoothingSurfacePoints);
+                tot.nFrozenSurfacePoints = (int32_t)g_comm.reduceSum(bi.nFrozenSurfacePoints);
             }
             if (tot.enabled) {
                 for (int it = 0; it < 2; ++it) {   // SM.C:2218
@@ -652,45 +697,73 @@ int main(int argc, char** argv) {
             }
         }
         if (!tot.enabled) fatal("boundary point smoothing: the engine did not enable it (empty target surface or edge mesh?)");
-        std::printf("Detected number of target edge mesh strings: %d\n\n", tot.nTargetEdgeStrings);
-        std::printf("Boundary point classification summary:\n- Detected number of corner points: %d\n- Detected number of feature edge points: %d\n"
+        OUT("Detected number of target edge mesh strings: %d\n\n", tot.nTargetEdgeStrings);
+        OUT("Boundary point classification summary:\n- Detected number of corner points: %d\n- Detected number of feature edge points: %d\n"
                     "- Detected number of smoothing surface points: %d\n- Detected number of frozen surface points: %d\n\n",
                     tot.nCornerPoints, tot.nFeatureEdgePoints, tot.nSmoothingSurfacePoints, tot.nFrozenSurfacePoints);
     }
 
-    auto syncAll = [&] { for (Rank& K : R) { HIPCHK(hipSetDevice(K.device)); HIPCHK(hipDeviceSynchronize()); } };
     int32_t lDoubles = SMGPU_HALO_L_LAYERS;   // doubles per slot of the L records in use (all engines agree)
-    if (opt.parallel) check(smgpu_halo_l_doubles(R[0].h, &lDoubles), "smgpu_halo_l_doubles");
-    auto exchangeL = [&] {
-        for (int a = 0; a < nRanks; ++a)
-            for (int b = 0; b < nRanks; ++b) {
-                const int c = R[a].peerCount[b];
+    if (opt.parallel) check(smgpu_halo_l_doubles(K0.h, &lDoubles), "smgpu_halo_l_doubles");
+    std::vector<int> peerBaseOf((size_t)nRanks, 0);   // first slot rank o keeps towards me
+    std::vector<int> nSendOf((size_t)nRanks, 0);      // every rank's number of send slots (the part bases in its slot of the mapping)
+    if (opt.parallel) {
+        const std::vector<std::vector<int>> allBase = g_comm.allgatherVec(K0.peerSendBase);
+        for (int o = 0; o < nRanks; ++o) peerBaseOf[(size_t)o] = allBase[(size_t)o][(size_t)myRank];
+        nSendOf = g_comm.allgather(K0.nSend);
+    }
+    const bool withL = doLayerTreatment || doBoundarySmoothing;
+    // One exchange = for every rank that shares points with this one, its slots of the send buffer against the matching slots of
+    // the receive buffer.  RCCL: one group of ncclSend / ncclRecv pairs on the engine's stream (exchange A carries the L records
+    // in the same group: one collective kernel); nothing waits on the host.  shm: the same records staged through the ranks'
+    // mapping (D2H, barrier, H2D, barrier).
+    struct Part { const void* send; void* recv; size_t bytesPerSlot; };
+    auto exchange = [&](std::initializer_list<Part> parts) {
+        if (transport == TRANSPORT_RCCL) {
+            NCCLCHK(ncclGroupStart());
+            for (const Part& pt : parts)
+                for (int o = 0; o < nRanks; ++o) {
+                    const size_t c = (size_t)K0.peerCount[o];
+                    if (!c) continue;
+                    const size_t off = (size_t)K0.peerSendBase[o] * pt.bytesPerSlot;
+                    NCCLCHK(ncclSend((const char*)pt.send + off, c * pt.bytesPerSlot, ncclChar, o, nccl, engineStream));
+                    NCCLCHK(ncclRecv((char*)pt.recv + off, c * pt.bytesPerSlot, ncclChar, o, nccl, engineStream));
+                }
+            NCCLCHK(ncclGroupEnd());
+            return;
+        }
+        // debug transport: my slot of the mapping = [part 0 send buffer | part 1 send buffer | ...]
+        size_t off = 0;
+        std::vector<size_t> base;
+        for (const Part& pt : parts) {
+            base.push_back(off);
+            const size_t bytes = (size_t)K0.nSend * pt.bytesPerSlot;
+            if (off + bytes > g_comm.slotBytes()) fatal("shm transport: send buffers exceed the mapping");
+            if (bytes) HIPCHK(hipMemcpyAsync(g_comm.slot(myRank) + off, pt.send, bytes, hipMemcpyDeviceToHost, engineStream));
+            off += (bytes + 63) & ~(size_t)63;
+        }
+        HIPCHK(hipStreamSynchronize(engineStream));
+        g_comm.barrier();                                                 // every rank's records are in its slot
+        size_t pi = 0;
+        for (const Part& pt : parts) {
+            for (int o = 0; o < nRanks; ++o) {
+                const size_t c = (size_t)K0.peerCount[o];
                 if (!c) continue;
-                HIPCHK(hipMemcpyPeer(R[b].recvL + (size_t)R[b].peerSendBase[a] * lDoubles, R[b].device,
-                                     R[a].sendL + (size_t)R[a].peerSendBase[b] * lDoubles, R[a].device, (size_t)c * lDoubles * 8));
+                size_t obase = 0;                                         // start of this part in rank o's slot
+                { size_t q = 0; for (const Part& pp : parts) { if (q == pi) break; obase += (((size_t)nSendOf[(size_t)o] * pp.bytesPerSlot) + 63) & ~(size_t)63; ++q; } }
+                const size_t theirOff = (size_t)peerBaseOf[(size_t)o] * pt.bytesPerSlot;   // where rank o keeps its slots towards me
+                HIPCHK(hipMemcpyAsync((char*)pt.recv + (size_t)K0.peerSendBase[o] * pt.bytesPerSlot, g_comm.slot(o) + obase + theirOff, c * pt.bytesPerSlot,
+                                      hipMemcpyHostToDevice, engineStream));
             }
-    };
-    auto exchange = [&](bool isA) {
-        syncAll();
-        if (isA && (doLayerTreatment || doBoundarySmoothing)) exchangeL();
-        for (int a = 0; a < nRanks; ++a)
-            for (int b = 0; b < nRanks; ++b) {
-                const int c = R[a].peerCount[b];
-                if (!c) continue;
-                // slots a->b on a's send side start at peerSendBase[b]; on b's recv side at b.peerSendBase[a]
-                if (isA)
-                    HIPCHK(hipMemcpyPeer(R[b].recvA + (size_t)R[b].peerSendBase[a] * SMGPU_HALO_A_DOUBLES, R[b].device,
-                                         R[a].sendA + (size_t)R[a].peerSendBase[b] * SMGPU_HALO_A_DOUBLES, R[a].device,
-                                         (size_t)c * SMGPU_HALO_A_DOUBLES * 8));
-                else
-                    HIPCHK(hipMemcpyPeer(R[b].recvF + R[b].peerSendBase[a], R[b].device, R[a].sendF + R[a].peerSendBase[b], R[a].device, (size_t)c * 4));
-            }
-        syncAll();   // device-to-device copies may return before they complete; the engines' streams are non-blocking
+            ++pi;
+        }
+        HIPCHK(hipStreamSynchronize(engineStream));
+        g_comm.barrier();                                                 // nobody overwrites its slot before everyone has read it
     };
 
     auto writeMesh = [&](double timeValue) {
         const std::string tn = timeName(timeValue);
-        std::printf("Writing new mesh to time %s\n\n", tn.c_str());
+        OUT("Writing new mesh to time %s\n\n", tn.c_str());
         for (Rank& K : R) {
             std::vector<double> pts((size_t)K.mesh.nPoints() * 3);
             check(smgpu_get_points(K.h, pts.data()), "smgpu_get_points");
@@ -713,6 +786,8 @@ int main(int argc, char** argv) {
     long i = 0;
     double timeValue = startIsConstant ? 0.0 : startValue;
     std::vector<smgpu_iter_stats> stats;
+    double* dHist = nullptr;       // -parallel, relTol <= 0: the chunk's {residual, nFrozenPoints} records on the device
+    size_t histCap = 0;
     while (i < centroidalIters && !stopIteration) {
         // run up to the next write point in one engine call (no host synchronisation inside)
         long chunk = std::min(centroidalIters - i, writeInterval - (i % writeInterval));
@@ -721,42 +796,65 @@ int main(int argc, char** argv) {
         if (!opt.parallel) {
             check(smgpu_iterate(R[0].h, (int32_t)chunk, relTol, stats.data(), &done), "smgpu_iterate");
         } else {
-            for (long k = 0; k < chunk; ++k) {
-                for (Rank& K : R) check(smgpu_iter_begin(K.h), "smgpu_iter_begin");
-                for (Rank& K : R) check(smgpu_iter_interior(K.h), "smgpu_iter_interior");
-                exchange(true);
-                for (Rank& K : R) check(smgpu_iter_mid(K.h), "smgpu_iter_mid");
-                for (Rank& K : R) check(smgpu_iter_ahead(K.h), "smgpu_iter_ahead");
-                exchange(false);
-                for (Rank& K : R) check(smgpu_iter_end(K.h), "smgpu_iter_end");
-                syncAll();
-                double res = 0.0, nf = 0.0;
-                for (Rank& K : R) {
-                    double ls[2];
-                    HIPCHK(hipMemcpy(ls, K.localStats, 16, hipMemcpyDeviceToHost));
-                    res = std::max(res, ls[0]);   // returnReduce maxOp, SM.C:1567
-                    nf += ls[1];                  // returnReduce sumOp, SM.C:2396
+            // relTol <= 0 cannot stop the loop (residual >= 0, SM.C:2401): the engine then keeps the chunk's per-iteration
+            // {residual, nFrozenPoints} on the device and the host reads nothing until the chunk is over
+            const bool noStop = !(relTol > 0.0);
+            if (noStop) {
+                if ((long)histCap < chunk) {
+                    if (dHist) HIPCHK(hipFree(dHist));
+                    HIPCHK(hipMalloc((void**)&dHist, (size_t)chunk * 16));
+                    histCap = (size_t)chunk;
                 }
+                check(smgpu_halo_set_stats_history(K0.h, dHist, (int32_t)chunk), "smgpu_halo_set_stats_history");
+            }
+            for (long k = 0; k < chunk; ++k) {
+                check(smgpu_iter_begin(K0.h), "smgpu_iter_begin");
+                if (withL) exchange({Part{K0.sendA, K0.recvA, SMGPU_HALO_A_DOUBLES * 8}, Part{K0.sendL, K0.recvL, (size_t)lDoubles * 8}});   // SM.C:134-148, 402-478; OBB.C:184-198, 490-496
+                else exchange({Part{K0.sendA, K0.recvA, SMGPU_HALO_A_DOUBLES * 8}});
+                check(smgpu_iter_mid(K0.h), "smgpu_iter_mid");
+                exchange({Part{K0.sendF, K0.recvF, 4}});                                                   // SM.C:2374
+                check(smgpu_iter_end(K0.h), "smgpu_iter_end");
+                ++done;
+                if (noStop) continue;
+                double ls[2];
+                HIPCHK(hipMemcpyAsync(ls, K0.localStats, 16, hipMemcpyDeviceToHost, engineStream));
+                HIPCHK(hipStreamSynchronize(engineStream));
+                const double res = g_comm.reduceMax(ls[0]);                      // returnReduce maxOp, SM.C:1567
+                const long nf = g_comm.reduceSum((long)ls[1]);                   // returnReduce sumOp, SM.C:2396
                 stats[(size_t)k].residual = res;
                 stats[(size_t)k].nFrozenPoints = (int32_t)nf;
-                ++done;
                 if (res < relTol) break;
+            }
+            if (noStop) {
+                check(smgpu_halo_set_stats_history(K0.h, nullptr, 0), "smgpu_halo_set_stats_history");   // closes the last iteration
+                std::vector<double> hist((size_t)chunk * 2);
+                HIPCHK(hipMemcpyAsync(hist.data(), dHist, hist.size() * 8, hipMemcpyDeviceToHost, engineStream));
+                HIPCHK(hipStreamSynchronize(engineStream));
+                const std::vector<std::vector<double>> all = g_comm.allgatherVec(hist);
+                for (long k = 0; k < chunk; ++k) {
+                    double res = 0.0, nf = 0.0;
+                    for (const auto& hh : all) { res = std::max(res, hh[(size_t)2 * k]); nf += hh[(size_t)2 * k + 1]; }
+                    stats[(size_t)k].residual = res;
+                    stats[(size_t)k].nFrozenPoints = (int32_t)nf;
+                }
             }
         }
         for (int32_t k = 0; k < done; ++k)
-            std::printf("Smoothing iteration=%ld nFrozenPoints=%d residual=%g\n", i + k + 1, stats[(size_t)k].nFrozenPoints, stats[(size_t)k].residual);
+            OUT("Smoothing iteration=%ld nFrozenPoints=%d residual=%g\n", i + k + 1, stats[(size_t)k].nFrozenPoints, stats[(size_t)k].residual);
         i += done;
         timeValue += done * deltaT;   // runTime++ per iteration, SM.C:2414
         const bool hitTol = done > 0 && stats[(size_t)done - 1].residual < relTol;
-        if (hitTol) { std::puts("Residual reached relTol, stopping."); stopIteration = true; }
-        if (i == centroidalIters) { std::puts("Maximum centroidalIters reached, stopping."); stopIteration = true; }
+        if (hitTol) { OUTS("Residual reached relTol, stopping."); stopIteration = true; }
+        if (i == centroidalIters) { OUTS("Maximum centroidalIters reached, stopping."); stopIteration = true; }
         // SM.C:2416: write at stop or every writeInterval iterations (not after the very first one)
         if (stopIteration || ((i % writeInterval) == 0 && i > 1)) writeMesh(timeValue);
         if (done == 0) break;
     }
 
+    if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); NCCLCHK(ncclCommDestroy(nccl)); }
     for (Rank& K : R) smgpu_destroy(K.h);
+    g_comm.barrier();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("ClockTime = %d s.\n\nEnd\n", (int)secs);
+    OUT("ClockTime = %d s.\n\nEnd\n", (int)secs);
     return 0;
 }

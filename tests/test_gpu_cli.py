@@ -234,3 +234,51 @@ def test_parallel_case_with_layer_patches(tmp_path, oracle_lib):
         d = tmp_path / f"processor{s.rank}"
         got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "6" / "polyMesh")).points
         assert rel_linf(got, o.points()) <= 1e-13
+
+
+@pytest.mark.parametrize("relTol", ["0", "1.5"])
+def test_parallel_polyhedral_case_one_process_per_rank(tmp_path, oracle_lib, relTol):
+    """`smoothMesh -parallel` = one process per processorN/ (the reference's `mpirun -np 4 smoothMesh -parallel`,
+    testcase/run_parallel:19) on a decomposed POLYHEDRAL case; on this one-GPU box the ranks share the device and the records
+    travel through the debug transport (RCCL needs a device per rank).  relTol 0: no host synchronisation inside a chunk, the
+    per-iteration values are gathered afterwards; relTol > 0: reduced every iteration, the loop stops like the reference's."""
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.polymesh import cavity_subdomain, read_polymesh, write_decomposed_case
+    grid = (2, 2, 1)
+    subs = [cavity_subdomain(12, grid, r, jitter=0.2, seed=4) for r in range(4)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "9", "-relTol", relTol, "-writeInterval", "4"])
+    assert "nProcs : 4" in out and "debug transport" in out
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs))
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_lib.MultiOracle(orcs, *shared_point_table(subs))
+    n, res, frz = mo.iterate(9, float(relTol))
+    lines = LINE.findall(out)
+    assert len(lines) == n and (n < 9) == (relTol != "0")
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    assert np.allclose([float(c) for _, _, c in lines], res, rtol=1e-5)
+    for s, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / str(n) / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13
+
+
+def test_parallel_single_rank_initialises_rccl(tmp_path, oracle_lib):
+    """one processor0/ directory: the rank is its own process and, having a device of its own, brings up RCCL
+    (ncclCommInitRank with one rank); results equal the serial run's"""
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    subs = [hex_subdomain((7, 6, 5), (1, 1, 1), 0, jitter=0.3, seed=2)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "5", "-relTol", "0"])
+    assert "nProcs : 1" in out and "debug transport" not in out
+    o = oracle_lib.Oracle(subs[0].mesh)
+    o.set_params(default_params(o.mesh_stats()[0]))
+    n, res, frz = o.iterate(5, 0.0)
+    assert [int(b) for _, b, _ in LINE.findall(out)] == frz.tolist()
+    got = read_polymesh(str(tmp_path / "processor0" / "constant" / "polyMesh"), pointsDir=str(tmp_path / "processor0" / "5" / "polyMesh")).points
+    assert rel_linf(got, o.points()) <= 1e-13
