@@ -137,8 +137,9 @@ typedef struct smgpu_halo_desc {
     void* sendA; void* recvA;     /* device, nSend / nRecv records of 13 doubles              */
     void* sendF; void* recvF;     /* device, nSend / nRecv int32                              */
     void* localStats;             /* device, 2 doubles {residual, nFrozenPoints} per iteration */
-    void* sendL; void* recvL;     /* device, nSend / nRecv records of 6 doubles; only used with the boundary layer
-                                     treatment (may be NULL otherwise), exchanged together with sendA / recvA  */
+    void* sendL; void* recvL;     /* device, nSend / nRecv records sized for SMGPU_HALO_L_DOUBLES doubles; only used with the
+                                     boundary layer treatment / boundary point smoothing (may be NULL otherwise),
+                                     exchanged together with sendA / recvA (smgpu_halo_l_doubles per slot in use)  */
     int32_t useExchangeStream;    /* 0: the host enqueues its exchanges on the engine's stream (in order).       */
     void* exchangeStream;         /* 1: the host enqueues them on THIS hipStream_t (NULL = the null stream); the
                                      engine orders its own stream against it with events inside
@@ -163,12 +164,12 @@ int smgpu_iter_ahead(smgpu_handle* h);   /* optional, between mid and end: next 
                                             the shared points -- overlaps exchange F (constraints off)      */
 int smgpu_iter_end(smgpu_handle* h);     /* or recvF, restore, residual -> localStats; movePoints   */
 
-/* ---- optional boundary layer treatment (prismatic layers on selected patches), serial runs ------------------
+/* ---- optional boundary layer treatment (prismatic layers on selected patches) -------------------------------
  * Replaces SM.C:2186-2221 (set-up: point classification BPS.C:296-340,397-403; calculatePointHopsToBoundary,
  * calculateBoundaryPointNormals, propagateOuterNeighInfo, OBB.C = src/orthogonalBoundaryBlending.C) and, inside
  * every later iteration, SM.C:2266 + 2283-2305 (updateNeighCoords, blendWithOrthogonalPoints, second step clamp).
  * Patches as in polyMesh/boundary: face ranges in file order.  Call after smgpu_create (the set-up uses the
- * coordinates the engine holds) and before iterating; not available together with smgpu_halo_configure.
+ * coordinates the engine holds) and before iterating.  With a halo (smgpu_halo_configure) use the step-wise form below.
  * *enabled = the reference's doLayerTreatment (a layer patch is selected and layerMaxBlendingFraction > SMALL). */
 typedef struct smgpu_layer_desc {
     int32_t nPatches;
