@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmgpu.so")
+LIB_PATH = os.environ.get("SMOOTHMESH_SMGPU_LIB", os.path.join(_HERE, "csrc", "libsmgpu.so"))   # override: experimental builds
 
 c_i32p = C.POINTER(C.c_int32)
 c_f64p = C.POINTER(C.c_double)

@@ -336,14 +336,19 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 // deferN > 0: the first workgroup also closes the PREVIOUS iteration (reduction of its deferN workgroup partials into
 // stats[deferIter], reset of the per-iteration counters) -- with relTol <= 0 nothing can stop the loop, so that work does
 // not need a launch of its own between the iterations (k_finish, ~6 us of launch latency per iteration).
+#ifndef SMGPU_GEOM_WAVES
+#define SMGPU_GEOM_WAVES 4
+#endif
 template <int T, bool ORG>
-__global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
+__global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
                                                   int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
                                                   double* deferHist) {
-    if (s.acc->stop) return;
+    // the "loop has stopped" flag (relTol reached, SM.C:2401) is tested after the staging: a dependent global load in front of
+    // everything else put its latency on every workgroup's critical path; a stopped run stages one tile in vain
+    const int stopped = s.acc->stop;
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
-    if (deferN > 0 && blockIdx.x == 0) { finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
+    if (deferN > 0 && blockIdx.x == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
     const GeomLds L = geomLds(lds, g);
     const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
@@ -352,6 +357,7 @@ __global__ void __launch_bounds__(T) k_geom_tile(MeshView m, State s, GeomTileVi
         const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
         stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, L.px, L.py, L.pz, tid);
     }
+    if (stopped) return;
     __syncthreads();
     // phase 1: every face of the tile once
     const unsigned tflags = g.tileFlags[tile];
@@ -522,7 +528,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
 template <bool FINAL, int T>
 __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm, SmoothTileView g, const int* tileList,
                                                     int nLaunch, int xcdMap) {
-    if (s.acc->stop) return;
+    const int stopped = s.acc->stop;   // tested after the staging, see k_geom_tile
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
     extern __shared__ double lds[];
@@ -536,6 +542,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
         const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
         stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
     }
+    if (stopped) return;
     __syncthreads();
     double dist = 0.0;
     int fcount = 0;

@@ -1,6 +1,7 @@
 // smgpu.hip -- C-ABI implementation (see include/smgpu.h): host-side addressing build, device
 // residency, kernel sequencing of one smoothing iteration (src/smoothMesh.C:2257-2437).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <chrono>
@@ -229,6 +230,28 @@ static int launchK(smgpu_handle* h, int k, F&& f, hipStream_t stream = nullptr) 
         f();
     }
     // a bad launch configuration is reported through the sticky last-error, not by the launch macro
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) return fail(std::string("launch of ") + kKernelNames[k] + ": " + hipGetErrorString(le));
+    h->launches[k]++;
+    return 0;
+}
+
+// The same for ONE kernel launched through hipExtLaunchKernelGGL: the two events are attached to the dispatch itself, so
+// their difference is the kernel's own start-to-end time (what rocprofv3 reports) -- an event pair recorded around a launch
+// adds the handling of two marker packets (~5 us) to it.  f(start, stop) launches; both are NULL when timing is off.
+template <typename F>
+static int launchKDispatch(smgpu_handle* h, int k, F&& f) {
+    if (h->timing) {
+        hipEvent_t a, b;
+        for (hipEvent_t* ev : {&a, &b}) {
+            if (!h->freeEvents.empty()) { *ev = h->freeEvents.back(); h->freeEvents.pop_back(); }
+            else HIP_OK(hipEventCreate(ev));
+        }
+        f(a, b);
+        h->pending.push_back({k, a, b});
+    } else {
+        f((hipEvent_t) nullptr, (hipEvent_t) nullptr);
+    }
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) return fail(std::string("launch of ") + kKernelNames[k] + ": " + hipGetErrorString(le));
     h->launches[k]++;
@@ -640,24 +663,24 @@ static void ensureDynLds(K kernel, int device, size_t bytes) {
     else (void)hipGetLastError();
 }
 template <int T>
-static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles) {
+static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB) {
     if (h->foamOrg) {
         ensureDynLds(k_geom_tile<T, true>, h->device, h->geomLds);
-        hipLaunchKernelGGL((k_geom_tile<T, true>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                           tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
+        hipExtLaunchKernelGGL((k_geom_tile<T, true>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
+                              h->writeFaces ? 1 : 0, tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     } else {
         ensureDynLds(k_geom_tile<T, false>, h->device, h->geomLds);
-        hipLaunchKernelGGL((k_geom_tile<T, false>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->geomLds, h->stream, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                           tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
+        hipExtLaunchKernelGGL((k_geom_tile<T, false>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
+                              h->writeFaces ? 1 : 0, tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     }
     h->deferN = 0;
     h->deferLocal = h->deferHist = nullptr;
 }
 template <bool FINAL, int T>
-static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles) {
+static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB) {
     ensureDynLds(k_smooth_tile<FINAL, T>, h->device, h->smoothLds);
-    hipLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), h->smoothLds, h->stream, m, s, prm, h->sv, tileList,
-                       nTiles, h->xcdMap);
+    hipExtLaunchKernelGGL((k_smooth_tile<FINAL, T>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->smoothLds, h->stream, evA, evB, 0, m, s, prm, h->sv,
+                          tileList, nTiles, h->xcdMap);
 }
 template <bool FINAL>
 static int launchBndFix(smgpu_handle* h, int partialBase) {
@@ -700,10 +723,10 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
     if (h->useTiles) {
         const int nT = tileList ? nList : h->stl.nTiles;
         if (nT == 0) return 0;
-        if (launchK(h, kid, [&] {
-                if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm, tileList, nT);
-                else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm, tileList, nT);
-                else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT);
+        if (launchKDispatch(h, kid, [&](hipEvent_t evA, hipEvent_t evB) {
+                if (h->smoothT == 64) launchSmoothTile<FINAL, 64>(h, m, s, prm, tileList, nT, evA, evB);
+                else if (h->smoothT == 128) launchSmoothTile<FINAL, 128>(h, m, s, prm, tileList, nT, evA, evB);
+                else launchSmoothTile<FINAL, 256>(h, m, s, prm, tileList, nT, evA, evB);
             })) return 1;
     } else if (launchK(h, kid, [&] { hipLaunchKernelGGL(k_smooth<FINAL>, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
     if (withBnd) {
@@ -726,10 +749,10 @@ static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList
     if (h->useTiles) {
         const int nT = tileList ? nList : h->gt.nTiles;
         if (nT == 0) return 0;
-        return launchK(h, K_GEOM_TILE, [&] {
-            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg, tileList, nT);
-            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg, tileList, nT);
-            else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT);
+        return launchKDispatch(h, K_GEOM_TILE, [&](hipEvent_t evA, hipEvent_t evB) {
+            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg, tileList, nT, evA, evB);
+            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg, tileList, nT, evA, evB);
+            else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT, evA, evB);
         });
     }
     if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg, h->foamOrg ? 1 : 0); })) return 1;
