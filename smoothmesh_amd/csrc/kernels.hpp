@@ -42,7 +42,7 @@ struct Accum {                 // device-side loop state
     int nEaMaybe, nFaMaybe;    // elements the f32 filters could not decide (this iteration)
     int stop;                  // set once residual < relTol (SM.C:2401)
     int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks, 3 = walk barrier timed out
-    int pad;
+    int nFaPts, nFaEdges;      // face-angle pass: points / edges listed for the exact evaluation (this iteration; adjacent: one scan writes both)
 };
 
 struct State {
@@ -54,6 +54,7 @@ struct State {
     uint8_t* frozen;
     double* edgeMin; double* edgeMax; double* ptMin; double* ptMax;
     uint8_t* faActive; uint8_t* faS; uint8_t* faN; int* walkStack;
+    int* faEdgeList; int* faPointList;   // exact face-angle pass on lists (k_fa_collect)
     uint8_t faGen;     // generation tag of this iteration's faActive / faMaybe marks (a mark counts only if it equals the tag: no
                        // per-iteration clearing of the two P-byte arrays; they are zeroed when the tag wraps)
     Accum* acc;
@@ -614,12 +615,7 @@ __device__ __forceinline__ void edgeFaceAngles(const MeshView& m, const State& s
 // so each projected face-centre vector is formed once and handed on (the reference forms them per
 // edge face too, SM.C:1183-1200; min/max over the cells do not depend on the visiting order).
 // faMaybe (may be NULL): only edges with an end point the filter could not rule out are evaluated.
-__global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const uint8_t* faMaybe) {
-    if (s.acc->stop) return;
-    if (faMaybe && s.acc->nFaMaybe == 0) return;   // the filter found every edge inside the good range
-    const int e = blockIdx.x * kBlock + threadIdx.x;
-    if (e >= m.nEdges) return;
-    if (faMaybe && faMaybe[m.edges[2 * e]] != s.faGen && faMaybe[m.edges[2 * e + 1]] != s.faGen) return;
+__device__ __forceinline__ void faEdgeExact(const MeshView& m, const State& s, int e) {
     double mn, mx;
     if (!m.edgeRingOk[e]) {
         const V3 z = v3(0, 0, 0);
@@ -654,15 +650,79 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const 
     s.edgeMin[e] = mn;
     s.edgeMax[e] = mx;
 }
+__global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const uint8_t* faMaybe) {
+    if (s.acc->stop) return;
+    if (faMaybe && s.acc->nFaMaybe == 0) return;   // the filter found every edge inside the good range
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= m.nEdges) return;
+    if (faMaybe && faMaybe[m.edges[2 * e]] != s.faGen && faMaybe[m.edges[2 * e + 1]] != s.faGen) return;
+    faEdgeExact(m, s, e);
+}
+
+// With the filter on, what needs the exact evaluation is sparse (the end points of the UNSURE edges and all their edges:
+// 2 % of a 10 M-cell refinement-interface mesh, nothing on a good hex block), but one thread per edge asking "is one of my
+// end points marked?" costs two random byte gathers for each of the 30 M edges (0.56 ms).  So the marked points list
+// themselves and their edges (every edge once: by its lower marked end point), and the exact kernels run on the lists.
+// Listing without atomics (a returning atomic on one counter word runs at ~90 per microsecond chip-wide, wave-aggregated or
+// not: 2 ms for this mesh): per 256-point block the numbers of marked points and of the edges they list (k_fa_list_count),
+// one exclusive scan over the blocks (k_walk_scan of kernels_walk.hpp, which leaves the totals in acc->nFaPts / nFaEdges),
+// then every block writes its ids at its offsets (k_fa_list_fill).  An edge is listed by its marked end point -- the lower
+// one when both are; the lists come out in point order, so the exact kernel's gathers stay local.
+__device__ __forceinline__ int faListedEdges(const MeshView& m, const State& s, const uint8_t* faMaybe, int p, int* out) {
+    int n = 0;
+    for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
+        const int q = m.ppPt[k];
+        if ((faMaybe[q] != s.faGen) || (p < q)) { if (out) out[n] = m.peEdge[k]; ++n; }
+    }
+    return n;
+}
+__global__ void __launch_bounds__(kBlock) k_fa_list_count(MeshView m, State s, const uint8_t* faMaybe, int* blkA, int* blkE) {
+    if (s.acc->stop) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    int a = 0, e = 0;
+    if (s.acc->nFaMaybe != 0 && p < m.nPoints && faMaybe[p] == s.faGen) { a = 1; e = faListedEdges(m, s, faMaybe, p, nullptr); }
+    __shared__ int sa[kBlock / 64], se[kBlock / 64];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); e += __shfl_down(e, o, 64); }
+    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; se[threadIdx.x >> 6] = e; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int ta = 0, te = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
+        blkA[blockIdx.x] = ta;
+        blkE[blockIdx.x] = te;
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_fa_list_fill(MeshView m, State s, const uint8_t* faMaybe, const int* blkA, const int* blkE) {
+    if (s.acc->stop) return;
+    if (s.acc->nFaPts == 0) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const bool marked = p < m.nPoints && faMaybe[p] == s.faGen;
+    const int a = marked ? 1 : 0, e = marked ? faListedEdges(m, s, faMaybe, p, nullptr) : 0;
+    int ia = a, ie = e;
+    const int lane = threadIdx.x & 63;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
+        if (lane >= o) { ia += ta; ie += te; }
+    }
+    __shared__ int wa[kBlock / 64], we[kBlock / 64];
+    if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
+    __syncthreads();
+    int offA = blkA[blockIdx.x], offE = blkE[blockIdx.x];
+    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
+    if (marked) {
+        s.faPointList[offA + ia - 1] = p;
+        (void)faListedEdges(m, s, faMaybe, p, s.faEdgeList + (offE + ie - e));
+    }
+}
+__global__ void __launch_bounds__(kBlock) k_fa_edges_list(MeshView m, State s) {
+    if (s.acc->stop) return;
+    const int n = s.acc->nFaEdges;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) faEdgeExact(m, s, s.faEdgeList[i]);
+}
 
 // mapCurrentMinMaxFaceAnglesToPoints SM.C:938-975 as a gather over pointEdges, plus the
 // good-range test SM.C:1367-1369 -- one thread per point.
-__global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm, const uint8_t* faMaybe) {
-    if (s.acc->stop) return;
-    if (faMaybe && s.acc->nFaMaybe == 0) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    if (p >= m.nPoints) return;
-    if (faMaybe && faMaybe[p] != s.faGen) return;   // all its edges are GOOD; its faActive mark is stale, i.e. clear
+__device__ __forceinline__ void faPointMinMax(const MeshView& m, const State& s, const Prm& prm, int p) {
     double mn = 2.0 * SMGPU_PI, mx = 0.0;
     for (int k = m.ppOff[p]; k < m.ppOff[p + 1]; ++k) {
         const int e = m.peEdge[k];
@@ -675,6 +735,19 @@ __global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm p
     const bool good = (mn > prm.smallAngle) && (mx < prm.largeAngle);
     s.faActive[p] = good ? 0 : s.faGen;
     if (!good) atomicAdd(&s.acc->nActive, 1);
+}
+__global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm, const uint8_t* faMaybe) {
+    if (s.acc->stop) return;
+    if (faMaybe && s.acc->nFaMaybe == 0) return;
+    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (p >= m.nPoints) return;
+    if (faMaybe && faMaybe[p] != s.faGen) return;   // all its edges are GOOD; its faActive mark is stale, i.e. clear
+    faPointMinMax(m, s, prm, p);
+}
+__global__ void __launch_bounds__(kBlock) k_fa_points_list(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int n = s.acc->nFaPts;
+    for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) faPointMinMax(m, s, prm, s.faPointList[i]);
 }
 
 // calcMinMaxFaceAngleForPoint SM.C:1276-1308
@@ -832,6 +905,8 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     a->nActive = 0;
     a->nEaMaybe = 0;
     a->nFaMaybe = 0;
+    a->nFaEdges = 0;
+    a->nFaPts = 0;
 }
 __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats,
                                                           double* history) {

@@ -110,15 +110,40 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_filter(MeshView m, State 
 // The same filter on the smoothing tiles: current and proposed coordinates of the tile's points and their
 // neighbours are staged in LDS once (the per-point form above gathers each neighbour 8 times from global
 // memory and is bound by those gathers, not by arithmetic); corner pairs come from the pfEll table.
+//
+// The staged coordinates are f32 offsets from a tile origin O (the tile's first staged point, subtracted in f64): a tile
+// spans ~10 edge lengths, so an offset carries an absolute error <= 2^-24 R (R = largest offset of the tile) and a difference
+// of two of them <= 1.2e-7 R.  A vector shorter than sqrt(kRelGuard) R = 1.4e-3 R sends the point to the exact kernel;
+// every other unit vector is good to 8.5e-5 and a cosine to 1.7e-4, a sixth of kEaMargin.  (R is the whole tile's: a tile
+// whose points straddle a jump of the Morton order has a large R, and a tighter guard sent many of its points to the exact kernel.)  With the offsets in f32 the (current,
+// proposed) pair of each neighbour goes through packed two-wide f32 instructions (v_pk_mul_f32 / v_pk_add_f32): the kernel is
+// bound by VALU issue, and the f64 subtract + convert of every vector was a quarter of it.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr float kRelGuard = 2.0e-6f;
+
+// block-wide maximum of a non-negative float (all T threads call it); red: T/64 floats of LDS
+template <int T>
+__device__ __forceinline__ float blockMaxF(float v, float* red) {
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float m = red[0];
+#pragma unroll
+    for (int i = 1; i < T / 64; ++i) m = red[i] > m ? red[i] : m;
+    return m;
+}
+
 template <int T>
 __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, SmoothTileView g, float cosSmall, uint8_t* eaMaybe,
                                                        int nLaunch, int xcdMap) {
     if (s.acc->stop) return;
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
-    extern __shared__ double lds[];
-    double* cx = lds;               double* cy = cx + g.maxPoints; double* cz = cy + g.maxPoints;
-    double* nx = cz + g.maxPoints;  double* ny = nx + g.maxPoints; double* nz = ny + g.maxPoints;
+    extern __shared__ double ldsRaw[];
+    float* lds = reinterpret_cast<float*>(ldsRaw);
+    float* cx = lds;                float* cy = cx + g.maxPoints; float* cz = cy + g.maxPoints;
+    float* nx = cz + g.maxPoints;   float* ny = nx + g.maxPoints; float* nz = ny + g.maxPoints;
+    float* red = nz + g.maxPoints;
     const int tile = li, tid = threadIdx.x;
     const int pi = g.ptBeg[tile] + tid;
     const bool mine = pi < g.ptBeg[tile + 1];
@@ -133,30 +158,61 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
         if (wf4 > 0) q0 = row[0];
         if (wf4 > 1) q1 = row[T];
     }
+    float r2 = 0.f;
     {
         const int b = g.tnOff[tile], n = g.tnOff[tile + 1] - b;
-        stageRecordsPair<T, 3>(s.ptsCur, s.prop, g.tnIds + b, n, cx, cy, cz, nx, ny, nz, tid);
+        const int* ids = g.tnIds + b;
+        const V3 O = (n > 0) ? ldv(s.ptsCur, ids[0]) : v3(0, 0, 0);
+        constexpr int R = 3;
+        for (int base = 0; base < n; base += T * R) {
+            int id[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) { const int i = base + u * T + tid; id[u] = (i < n) ? ids[i] : -1; }
+            V3 va[R], vb[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) { va[u] = (id[u] >= 0) ? ldv(s.ptsCur, id[u]) : O; vb[u] = (id[u] >= 0) ? ldv(s.prop, id[u]) : O; }
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                const int i = base + u * T + tid;
+                if (id[u] >= 0) {
+                    const F3 a = f3(va[u] - O), c = f3(vb[u] - O);
+                    cx[i] = a.x; cy[i] = a.y; cz[i] = a.z; nx[i] = c.x; ny[i] = c.y; nz[i] = c.z;
+                    const float aa = fdot(a, a), cc = fdot(c, c);
+                    r2 = aa > r2 ? aa : r2;
+                    r2 = cc > r2 ? cc : r2;
+                }
+            }
+        }
     }
-    __syncthreads();
+    r2 = blockMaxF<T>(r2, red);        // (also the barrier behind the staging)
     if (!mine) return;
     if (s.frozen[p]) { eaMaybe[p] = 0; return; }
-    const V3 np0 = ldsv(nx, ny, nz, selfL);
+    const float p0x = nx[selfL], p0y = ny[selfL], p0z = nz[selfL];
     const float thr = cosSmall - kEaMargin;
-    bool ok = true, below = true;
+    const float minN2 = kRelGuard * r2;
+    bool ok = r2 < 1.0e30f, below = true;
     // The corner list of a point is ordered as chains (tiles.cpp, chainCorners): a corner usually starts at the vertex
-    // the previous one ended at, whose two unit vectors are still at hand.
+    // the previous one ended at, whose unit vectors are still at hand.  A unit-vector pair = (towards the neighbour's current
+    // position, towards its proposal), both from this point's PROPOSAL (SM.C:868-885), as the two halves of f2 registers.
     int heldId = -1;
-    F3 huc = {0.f, 0.f, 0.f}, hun = {0.f, 0.f, 0.f};
+    f2 hx = {0.f, 0.f}, hy = {0.f, 0.f}, hz = {0.f, 0.f};
+#define SMGPU_EA_UNIT(UX, UY, UZ, A)                                                                              \
+    {                                                                                                             \
+        const f2 vx_ = {cx[(A)] - p0x, nx[(A)] - p0x}, vy_ = {cy[(A)] - p0y, ny[(A)] - p0y}, vz_ = {cz[(A)] - p0z, nz[(A)] - p0z}; \
+        const f2 n2_ = vx_ * vx_ + vy_ * vy_ + vz_ * vz_;                                                         \
+        ok = ok && (n2_.x > minN2) && (n2_.y > minN2);            /* NaN -> false -> exact path */                 \
+        const f2 rs_ = {__builtin_amdgcn_rsqf(n2_.x), __builtin_amdgcn_rsqf(n2_.y)};                               \
+        UX = vx_ * rs_; UY = vy_ * rs_; UZ = vz_ * rs_;                                                           \
+    }
 #define SMGPU_EA_CORNER(A1, A2)                                                                                   \
     if ((A1) != kPad) {                                                                                           \
-        if ((int)(A1) != heldId) {                                                                                \
-            huc = funit(f3(ldsv(cx, cy, cz, (A1)) - np0), ok);                                                    \
-            hun = funit(f3(ldsv(nx, ny, nz, (A1)) - np0), ok);                                                    \
-        }                                                                                                         \
-        const F3 uc2 = funit(f3(ldsv(cx, cy, cz, (A2)) - np0), ok), un2 = funit(f3(ldsv(nx, ny, nz, (A2)) - np0), ok); \
-        const float c0 = fdot(huc, uc2), c1 = fdot(hun, un2), c2 = fdot(huc, un2), c3 = fdot(hun, uc2);            \
-        below = below && (c0 < thr) && (c1 < thr) && (c2 < thr) && (c3 < thr);                                    \
-        huc = uc2; hun = un2; heldId = (int)(A2);                                                                 \
+        if ((int)(A1) != heldId) SMGPU_EA_UNIT(hx, hy, hz, (A1))                                                  \
+        f2 ux, uy, uz;                                                                                            \
+        SMGPU_EA_UNIT(ux, uy, uz, (A2))                                                                           \
+        const f2 d0 = hx * ux + hy * uy + hz * uz;               /* (x1 . x2, n1 . n2): nAngle0, nAngle1 */        \
+        const f2 d1 = hx * ux.yx + hy * uy.yx + hz * uz.yx;      /* (x1 . n2, n1 . x2): nAngle2, nAngle3 */        \
+        below = below && (d0.x < thr) && (d0.y < thr) && (d1.x < thr) && (d1.y < thr);                            \
+        hx = ux; hy = uy; hz = uz; heldId = (int)(A2);                                                            \
     }
     if (wf4 > 0) { SMGPU_EA_CORNER(q0.x, q0.y) SMGPU_EA_CORNER(q0.z, q0.w) }
     if (wf4 > 1) { SMGPU_EA_CORNER(q1.x, q1.y) SMGPU_EA_CORNER(q1.z, q1.w) }
@@ -165,6 +221,7 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
         SMGPU_EA_CORNER(q.x, q.y) SMGPU_EA_CORNER(q.z, q.w)
     }
 #undef SMGPU_EA_CORNER
+#undef SMGPU_EA_UNIT
     eaMaybe[p] = (ok && below) ? 0 : 1;
     if (!(ok && below)) atomicAdd(&s.acc->nEaMaybe, 1);
 }

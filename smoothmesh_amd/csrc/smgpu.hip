@@ -110,6 +110,7 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
     void* pinned = nullptr;
@@ -410,6 +411,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
+    h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
@@ -548,6 +550,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.ptMax, P);
     rc |= devAlloc(h, &s.faActive, P);
     rc |= devAlloc(h, &h->dFaMaybe, P);
+    rc |= devAlloc(h, &s.faEdgeList, E);
+    rc |= devAlloc(h, &s.faPointList, P);
     rc |= devAlloc(h, &h->dEaMaybe, P);
     rc |= devAlloc(h, &s.faS, P);
     rc |= devAlloc(h, &s.faN, (size_t)t.pointEdges.nnz());
@@ -1060,7 +1064,7 @@ static int runConstraints(smgpu_handle* h) {
         if (filt && h->eaCoop) {
             const float cosSmall = (float)std::cos(prm.smallAngle);
             if (h->useTiles && h->smoothT == 256) {
-                const size_t ldsB = sizeof(double) * 6 * (size_t)h->sv.maxPoints;
+                const size_t ldsB = sizeof(float) * (6 * (size_t)h->sv.maxPoints + 16);
                 if (launchK(h, K_EA_FILTER, [&] {
                         hipLaunchKernelGGL(k_ea_filter_tile<256>, dim3(tileGrid(h->stl.nTiles, h->xcdMap)), dim3(256), ldsB, h->stream, m, s, h->sv, cosSmall, h->dEaMaybe,
                                            h->stl.nTiles, h->xcdMap);
@@ -1096,8 +1100,22 @@ static int runConstraints(smgpu_handle* h) {
             if (nextFaGen(h, h->stream)) return 1;
             s.faGen = h->st.faGen;
         }
-        if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
-        if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
+        // lists pay when many points are outside the good range (the choice the walk makes once per parameter set: walkMode 0 =
+        // few); on a good mesh the filter leaves nothing open and two early-exit launches are cheaper than four
+        if (faMaybe && h->faLists && h->walkMode > 0) {
+            // exact evaluation on the lists of what the filter left open (kernels.hpp, k_fa_collect)
+            if (ensureWalkBuffers(h)) return 1;    // the block-count scratch of the walk compaction serves the listing first
+            if (launchK(h, K_FA_EDGES, [&] {
+                    hipLaunchKernelGGL(k_fa_list_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                    hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, h->wv, h->walkBlocks, (const int*)nullptr, &h->st.acc->nFaPts);
+                    hipLaunchKernelGGL(k_fa_list_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                    hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, h->stream, m, s);
+                })) return 1;
+            if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+        } else {
+            if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
+            if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
+        }
         if (h->walkMode < 0) {
             // decide once per parameter set: read how many points lie outside the good range now (one sync).  Few: the
             // one-wave replay over the full flag array (two launches); many: the fixed-point replay.  SMGPU_WALK = wave | host |
