@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(kScanBlock) k_walk_scan(State s, WalkView w, i
         if (threadIdx.x == kScanBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { hdrOut[0] = baseA; hdrOut[1] = baseE; }
+    if (threadIdx.x == 0) { hdrOut[0] = baseA; hdrOut[1] = baseE; if (hdrOut == w.header) w.header[2] = 0; }   // [2]: slots left by k_walk_pred_star
 }
 
 __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
@@ -249,12 +249,16 @@ __device__ __forceinline__ void groupPointFaceAngles(const MeshView& m, const St
 //     visited unfrozen and does not freeze itself (SM.C:1376-1399): never for a point whose own move deteriorates its angles
 //     (it is frozen by its first visit at the latest) nor for one frozen before the walk -- on a refinement interface that is
 //     ~88 % of the acting points, and half of each of their entries' work.
-__global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+// onlyLeft: only the slots k_walk_pred_star could not take (their actBits carry kStarLeft) are evaluated
+constexpr uint8_t kStarLeft = 0x80;
+__global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, int onlyLeft) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    if (onlyLeft && w.header[2] == 0) return;
     const int lane = threadIdx.x & 31;
     for (int t = (blockIdx.x * kBlock + threadIdx.x) >> 5; t < nA; t += (gridDim.x * kBlock) >> 5) {
         if (t == 0 && lane == 0) w.actEntOff[nA] = nE;
+        if (onlyLeft && !(w.actBits[t] & kStarLeft)) continue;
         const int p = w.actIds[t];
         const V3 cur = ldv(s.ptsCur, p);
         const V3 np = ldv(s.prop, p);
@@ -267,15 +271,17 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, 
             const double curMin = s.ptMin[p], curMax = s.ptMax[p];
             if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
         }
-        if (lane == 0) w.actBits[t] = sb;
+        if (lane == 0) w.actBits[t] = sb | (onlyLeft ? kStarLeft : 0);
     }
 }
-__global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+__global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, int onlyLeft) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    if (onlyLeft && w.header[2] == 0) return;
     const int lane = threadIdx.x & 31;
     for (int e = (blockIdx.x * kBlock + threadIdx.x) >> 5; e < nE; e += (gridDim.x * kBlock) >> 5) {
         const int slot = w.entOwner[e];
+        if (onlyLeft && !(w.actBits[slot] & kStarLeft)) continue;
         const int p = w.actIds[slot];
         const int q = w.entNbr[e];
         const V3 nq = ldv(s.prop, q);
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
             nb |= 4;
             const V3 cur = ldv(s.ptsCur, p);
             const double curMin = s.ptMin[p], curMax = s.ptMax[p];
-            const uint8_t sb = w.actBits[slot];
+            const uint8_t sb = w.actBits[slot] & 0x7f;
             double mn, mx;
             groupPointFaceAngles(m, s, p, cur, q, nq, lane, mn, mx);   // this point held at its current position
             const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
@@ -304,13 +310,15 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
 // ---- the predicates of one active point by one wave, from its "star" staged in LDS ----------------------------------------
 // Every angle the walk can ask about point p involves only the faces that contain p (the rings of p's edges), their vertices
 // and the centres of p's cells.  The per-entry kernels above fetch that neighbourhood again for every (entry, state, edge, cell)
-// -- ~2 000 gathers of 24 bytes per active point, and the L1 / address path, not arithmetic, bounds them.  Here a wave
-// stages the star once (faces of p with their vertex ids and current coordinates: ~48 vertex slots for an interior hex
-// point), every lane keeps ITS (edge, cell) pair (same for all jobs of the point: the edge's other end, the two ring faces
-// as local ids, the cell centre), and a job -- self test, or one entry in one state -- is the pair's angle with the
-// substituted coordinates, read from LDS, reduced over a half wave.  Two jobs run side by side on the two halves.
-// Arithmetic per angle is edgeFaceAngles<true>'s, operation for operation.  Points whose star exceeds the caps take the
-// gather form (groupPointFaceAngles).
+// -- ~2 000 gathers of 24 bytes per active point.  Here a wave stages the star once (faces of p with their vertex ids and
+// current coordinates: ~48 vertex slots for an interior hex point) and every lane keeps ITS place in the ring of one of p's
+// edges for all jobs of the point: ring face i (as a star-local id) and the cell between ring faces i and i + 1 (its centre).
+// A job -- self test, or one entry in one state -- is: every lane forms the projected centre vector of its face and of its
+// cell with the substituted coordinates read from LDS (edgeFaceAngles<true>'s arithmetic, operation for operation), takes the
+// next ring face's vector from its neighbour lane, adds the two acos (SM.C:980-998; the sum does not depend on which of the
+// cell's two faces comes first), and min / max are reduced over the half wave.  Each face vector is thus formed once per
+// job, not once per adjacent cell.  Two jobs run side by side on the two halves.  Points whose star exceeds the caps, or
+// with a non-manifold edge ring, are left (kStarLeft) to the gather form above.
 constexpr int kStarFaces = 32, kStarVerts = 160, kStarEnts = 64;
 struct StarLds {
     int fid[kStarFaces];
@@ -319,45 +327,51 @@ struct StarLds {
     double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
     unsigned char nb[kStarEnts];
 };
-struct StarPair {          // a lane's (edge, cell) pair
-    bool valid;
+struct StarLane {          // a lane's place: ring position i of edge (p, xI)
+    bool valid, hasCell;
     int xI;                // the edge's other end point
     bool pFirst;           // p is the edge's first end point (edges[2e])
-    V3 xc, cc;             // current coordinates of xI, centre of the cell
-    int l0, l1;            // the two ring faces as star-local ids
+    V3 xc, cc;             // current coordinates of xI, centre of the cell between ring faces i and i + 1
+    int l;                 // ring face i as a star-local id
+    int nextLane;          // (within the half wave) the lane of ring face i + 1
 };
-__device__ __forceinline__ double starPairAngle(const StarLds& L, const StarPair& P, int p, const V3& c1, int i2, const V3& c2) {
-    const V3 xs = (i2 >= 0 && P.xI == i2) ? c2 : P.xc;
-    const V3 e0 = P.pFirst ? c1 : xs, e1 = P.pFirst ? xs : c1;
-    const V3 cC = 0.5 * (e0 + e1);
-    const V3 d = e1 - e0;
-    const V3 eVec = d / mag(d);
-    auto faceVec = [&](int l) -> V3 {
-        V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
-        const int b = L.voff[l], n = L.voff[l + 1] - b;
-        for (int i = 0; i < n; ++i) {
-            const int q = L.vid[b + i];
-            if (q == p) fc = fc + c1;
-            else if (i2 >= 0 && q == i2) fc = fc + c2;
-            else fc = fc + v3(L.vx[b + i], L.vy[b + i], L.vz[b + i]);
+// the pair's angle for the lanes with a cell (valid && hasCell), anything for the others; all 32 lanes of the half call it
+__device__ __forceinline__ double starLaneAngle(const StarLds& L, const StarLane& P, int p, const V3& c1, int i2, const V3& c2) {
+    V3 fv = v3(0, 0, 0), cV = v3(0, 0, 0);
+    if (P.valid) {
+        const V3 xs = (i2 >= 0 && P.xI == i2) ? c2 : P.xc;
+        const V3 e0 = P.pFirst ? c1 : xs, e1 = P.pFirst ? xs : c1;
+        const V3 cC = 0.5 * (e0 + e1);
+        const V3 d = e1 - e0;
+        const V3 eVec = d / mag(d);
+        {
+            V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
+            const int b = L.voff[P.l], n = L.voff[P.l + 1] - b;
+            for (int i = 0; i < n; ++i) {
+                const int q = L.vid[b + i];
+                if (q == p) fc = fc + c1;
+                else if (i2 >= 0 && q == i2) fc = fc + c2;
+                else fc = fc + v3(L.vx[b + i], L.vy[b + i], L.vz[b + i]);
+            }
+            fc = divByCount(fc, n);   // = fc / double(n), bit for bit
+            const V3 cf = cC - fc;
+            const double dp = dot(cf, eVec);
+            const V3 pC = fc + dp * eVec;
+            const V3 w = pC - cC;
+            fv = w / mag(w);
         }
-        fc = divByCount(fc, n);   // = fc / double(n), bit for bit
-        const V3 cf = cC - fc;
-        const double dp = dot(cf, eVec);
-        const V3 pC = fc + dp * eVec;
-        const V3 w = pC - cC;
-        return w / mag(w);
-    };
-    const V3 p0 = faceVec(P.l0);
-    const V3 p1 = faceVec(P.l1);
-    const V3 cf = cC - P.cc;
-    const double dp = dot(cf, eVec);
-    const V3 pC = P.cc + dp * eVec;
-    const V3 w = pC - cC;
-    const V3 cV = w / mag(w);
-    return clampAcos(dot(p0, cV)) + clampAcos(dot(cV, p1));   // calcEdgeCenterEdgeAngle SM.C:980-998
+        if (P.hasCell) {
+            const V3 cf = cC - P.cc;
+            const double dp = dot(cf, eVec);
+            const V3 pC = P.cc + dp * eVec;
+            const V3 w = pC - cC;
+            cV = w / mag(w);
+        }
+    }
+    const V3 fn = v3(__shfl(fv.x, P.nextLane, 32), __shfl(fv.y, P.nextLane, 32), __shfl(fv.z, P.nextLane, 32));
+    return clampAcos(dot(fv, cV)) + clampAcos(dot(cV, fn));   // calcEdgeCenterEdgeAngle SM.C:980-998
 }
-// min / max of the pairs' angles over a half wave; invalid lanes contribute the neutral values
+// min / max of the lanes' angles over a half wave; lanes without a cell contribute the neutral values
 __device__ __forceinline__ void starReduce(bool valid, double angle, double& mn, double& mx) {
     mn = valid ? angle : 2.0 * SMGPU_PI;   // every angle is < 2 pi and > 0: the reference's start values never win
     mx = valid ? angle : 0.0;
@@ -368,7 +382,10 @@ __device__ __forceinline__ void starReduce(bool valid, double angle, double& mn,
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+#ifndef SMGPU_STAR_WAVES
+#define SMGPU_STAR_WAVES 3
+#endif
+__global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
     __shared__ StarLds lds[kBlock / 64];
@@ -384,65 +401,39 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_star(MeshView m, State s, 
         const double curMin = s.ptMin[p], curMax = s.ptMax[p];
         const int eBeg = w.actEntOff[a], eEnd = (a + 1 < nA) ? w.actEntOff[a + 1] : nE, nEnt = eEnd - eBeg;
         auto bad = [&](double mn, double mx) { return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax)); };
-        // the point's edges with their cell counts, its faces with their vertex counts
+        // the point's edges with the lengths of their face rings, its faces with their vertex counts
         const int eb = m.ppOff[p], nEdgesP = m.ppOff[p + 1] - eb;
         const int fb = m.pfOff[p], nF = m.pfOff[p + 1] - fb;
         const int myE = (lane < nEdgesP) ? m.peEdge[eb + lane] : -1;
-        const int myN = (myE >= 0) ? m.ecOff[myE + 1] - m.ecOff[myE] : 0;
+        const int myNf = (myE >= 0) ? m.efOff[myE + 1] - m.efOff[myE] : 0;
+        const bool myRingBad = (myE >= 0) && !m.edgeRingOk[myE];
         const int myF = (lane < nF) ? m.pfFace[fb + lane] : -1;
         const int myFb = (myF >= 0) ? m.faceOff[myF] : 0;
         const int myV = (myF >= 0) ? m.faceOff[myF + 1] - myFb : 0;
-        int inclN = myN, inclV = myV;
+        int inclN = myNf, inclV = myV;
         for (int o = 1; o < 64; o <<= 1) {
             const int tn = __shfl_up(inclN, o, 64), tv = __shfl_up(inclV, o, 64);
             if (lane >= o) { inclN += tn; inclV += tv; }
         }
-        const int totalPairs = __shfl(inclN, 63, 64), totalV = __shfl(inclV, 63, 64);
-        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalPairs <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts;
+        const int totalLanes = __shfl(inclN, 63, 64), totalV = __shfl(inclV, 63, 64);
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts &&
+                          __ballot(myRingBad) == 0ull;
+        if (!fits) {   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
+            if (lane == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }
+            continue;
+        }
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
         int q = -1;
         V3 nq = v3(0, 0, 0);
         bool eligible = false;
         unsigned char nb0 = 0;
-        if (fits && lane < nEnt) {
+        if (lane < nEnt) {
             q = w.entNbr[eBeg + lane];
             nq = ldv(s.prop, q);
             const bool qFrozen = s.frozen[q] != 0;
             nb0 = qFrozen ? 8 : 0;
             eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
             if (eligible) nb0 |= 4;
-        }
-        if (!fits) {
-            // gather form, one half wave per job (the same decisions)
-            unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
-            if (moved && !frozenBefore) {
-                double mn, mx;
-                groupPointFaceAngles(m, s, p, np, -1, np, hl, mn, mx);
-                if (bad(mn, mx)) sbits |= 1u;
-            }
-            if (lane == 0) w.actBits[a] = (uint8_t)sbits;
-            for (int e0 = eBeg; e0 < eEnd; e0 += 2) {
-                const int e = e0 + half;
-                if (e >= eEnd) continue;
-                const int qq = w.entNbr[e];
-                const V3 nqq = ldv(s.prop, qq);
-                const bool qFrozen = s.frozen[qq] != 0;
-                unsigned nbb = qFrozen ? 8u : 0u;
-                if (!qFrozen && nqq != ldv(s.ptsCur, qq)) {
-                    nbb |= 4u;
-                    double mn, mx;
-                    groupPointFaceAngles(m, s, p, cur, qq, nqq, hl, mn, mx);
-                    const bool badF = bad(mn, mx);
-                    if (badF) nbb |= 2u;
-                    if (!(sbits & 2u)) { if (badF) nbb |= 1u; }
-                    else if (!(sbits & 5u)) {
-                        groupPointFaceAngles(m, s, p, np, qq, nqq, hl, mn, mx);
-                        if (bad(mn, mx)) nbb |= 1u;
-                    }
-                }
-                if (hl == 0) { w.entBits[e] = (uint8_t)nbb; w.entSlot[e] = w.activeSlot[qq]; }
-            }
-            continue;
         }
         // stage the star: face ids, vertex offsets, vertex ids and current coordinates
         if (lane < nF) {
@@ -459,43 +450,45 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_star(MeshView m, State s, 
         if (lane < nEnt) L.nb[lane] = nb0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        // this lane's (edge, cell) pair -- the same on both halves
-        StarPair P;
-        P.valid = hl < totalPairs;
-        P.xI = -1; P.pFirst = true; P.xc = v3(0, 0, 0); P.cc = v3(0, 0, 0); P.l0 = 0; P.l1 = 0;
+        // this lane's ring place -- the same on both halves
+        StarLane P;
+        P.valid = hl < totalLanes;
+        P.hasCell = false; P.xI = -1; P.pFirst = true; P.xc = v3(0, 0, 0); P.cc = v3(0, 0, 0); P.l = 0; P.nextLane = hl;
         {
-            int e = -1, first = 0;
+            int e = -1, first = 0, nfj = 0;
             for (int j = 0; j < nEdgesP; ++j) {
-                const int hi = __shfl(inclN, j, 64), ej = __shfl(myE, j, 64), nj = __shfl(myN, j, 64);
-                if (e < 0 && hl < hi) { e = ej; first = hi - nj; }
+                const int hi = __shfl(inclN, j, 64), ej = __shfl(myE, j, 64), nj = __shfl(myNf, j, 64);
+                if (e < 0 && hl < hi) { e = ej; first = hi - nj; nfj = nj; }
             }
             if (P.valid) {
-                const int k = m.ecOff[e] + (hl - first);
+                const int i = hl - first;
+                const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
+                P.hasCell = i < nc;
+                P.nextLane = (i + 1 < nfj) ? hl + 1 : first;          // closed ring: the last cell ends at face 0
                 const int e0I = m.edges[2 * e], e1I = m.edges[2 * e + 1];
                 P.pFirst = (e0I == p);
                 P.xI = P.pFirst ? e1I : e0I;
                 P.xc = ldv(s.ptsCur, P.xI);
-                P.cc = ldv(s.cellCtr, m.ecCell[k]);   // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
-                const int efb = m.efOff[e];
-                const int f0 = m.efFace[efb + m.ecF0[k]], f1 = m.efFace[efb + m.ecF1[k]];
-                for (int l = 0; l < nF; ++l) { const int g = L.fid[l]; if (g == f0) P.l0 = l; if (g == f1) P.l1 = l; }
+                if (P.hasCell) P.cc = ldv(s.cellCtr, m.ringCell[cb + i]);   // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+                const int f = m.ringFace[m.efOff[e] + i];
+                for (int l = 0; l < nF; ++l) if (L.fid[l] == f) P.l = l;
             }
         }
+        const bool counts = P.valid && P.hasCell;
         // jobs, two at a time (one per half wave).  Round 1: job 0 = the self test, job 1 + i = entry i with p at its current position
         unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
         const bool selfNeeded = moved && !frozenBefore;
         for (int j0 = 0; j0 < 1 + nEnt; j0 += 2) {
             const int j = j0 + half;
             const int ei = j - 1;                                    // entry of this half's job (-1: self)
-            const int src = ei < 0 ? 0 : ei;
+            const int src = ei < 0 ? 0 : (ei < nEnt ? ei : 0);
             const int jq = __shfl(q, src, 64);
             const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
             const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
             const bool run = (j < 1 + nEnt) && (ei < 0 ? selfNeeded : jEl);
-            double angle = 0.0;
-            if (run && P.valid) angle = (ei < 0) ? starPairAngle(L, P, p, np, -1, np) : starPairAngle(L, P, p, cur, jq, jnq);
+            const double angle = (ei < 0) ? starLaneAngle(L, P, p, np, -1, np) : starLaneAngle(L, P, p, cur, jq, jnq);
             double mn, mx;
-            starReduce(run && P.valid, angle, mn, mx);
+            starReduce(run && counts, angle, mn, mx);
             const bool isBad = run && bad(mn, mx);
             // the self result is known to the whole wave after the first step
             const int selfBad = __shfl((j == 0 && isBad) ? 1 : 0, 0, 64);
@@ -517,10 +510,9 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_star(MeshView m, State s, 
                 const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
                 const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
                 const bool run = ei < nEnt && jEl;
-                double angle = 0.0;
-                if (run && P.valid) angle = starPairAngle(L, P, p, np, jq, jnq);
+                const double angle = starLaneAngle(L, P, p, np, jq, jnq);
                 double mn, mx;
-                starReduce(run && P.valid, angle, mn, mx);
+                starReduce(run && counts, angle, mn, mx);
                 if (run && hl == 0 && bad(mn, mx)) L.nb[ei] |= 1;
             }
         }
@@ -544,7 +536,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
     int r = 0, b = 0;
     if (a < nA) {
         for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
-        const uint8_t sb = w.actBits[a];
+        const uint8_t sb = w.actBits[a] & 0x7f;
         r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
         if (!r) b = 0;
     }
@@ -570,7 +562,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR,
     int r = 0, b = 0;
     if (a < nA) {
         for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
-        const uint8_t sb = w.actBits[a];
+        const uint8_t sb = w.actBits[a] & 0x7f;
         r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
         if (!r) b = 0;
     }
@@ -603,7 +595,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR,
         }
         // bit 3: a re-visit of this point after a neighbour froze it (held at its current position, SM.C:1431)
         // can freeze somebody; without it the replay does not need to come back
-        const uint8_t rb = w.actBits[a] | (anyOld ? 8 : 0);
+        const uint8_t rb = (w.actBits[a] & 0x7f) | (anyOld ? 8 : 0);
         w.relBits[slot] = rb;
         const bool moved = rb & 2, selfBad = rb & 1;
         w.items[hdr] = WalkItem{slot, w.actIds[a], ((moved && selfBad) ? 3u : 0u) | 32u | ((moved && !selfBad) ? 64u : 0u) | 128u, hdr};

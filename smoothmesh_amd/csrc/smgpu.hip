@@ -912,10 +912,8 @@ static int runHostWalk(smgpu_handle* h) {
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
             if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 3) / 4), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
-            else {
-                hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
-                hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
-            }
+            hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
+            hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
         })) return 1;
     // second compaction: only the points that can act and only their true entries go to the host
     const int nSlotBlocks = gridFor(nA);
@@ -1000,10 +998,8 @@ static int runFixWalk(smgpu_handle* h) {
             hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
             hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
             if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
-            else {
-                hipLaunchKernelGGL(k_walk_pred_self, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
-                hipLaunchKernelGGL(k_walk_pred, dim3(256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
-            }
+            hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
+            hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
         })) return 1;
     if (launchK(h, K_FA_WALK, [&] {
             hipLaunchKernelGGL(k_rel_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1);
