@@ -1,29 +1,41 @@
 #!/bin/bash
-# run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic for the round's profiles/
+# run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
+# usage: scripts/collect_profiles.sh [round tag, default r2]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+tag=${1:-r2}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
-out=$root/gpurun_out/profiles
+out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
 cd $root
-python bench.py > $out/bench_hex100.json 2>$out/bench_hex100.err
-python bench.py --workload hex100c > $out/bench_hex100c.json 2>>$out/bench_hex100.err
-python bench.py --workload hex100L --steps 50 --warmup 5 > $out/bench_hex100L.json 2>>$out/bench_hex100.err
-python bench.py --workload hex215 --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_hex215.json 2>>$out/bench_hex100.err
-python bench.py --workload hex300 --no-cpu-baseline --steps 20 --warmup 2 > $out/bench_hex300.json 2>>$out/bench_hex100.err
-python bench.py --workload cavity215 --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity215.json 2>>$out/bench_hex100.err
-python bench.py --workload cavity215c --no-cpu-baseline --steps 20 --warmup 2 > $out/bench_cavity215c.json 2>>$out/bench_hex100.err
-python bench.py --workload cavity100c --steps 20 --warmup 2 > $out/bench_cavity100c.json 2>>$out/bench_hex100.err
-python bench.py --workload hex100B --steps 50 --warmup 5 > $out/bench_hex100B.json 2>>$out/bench_hex100.err
-python bench.py --workload cavity100B --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_cavity100B.json 2>>$out/bench_hex100.err
-python bench.py --workload hex215B --no-cpu-baseline --steps 30 --warmup 3 > $out/bench_hex215B.json 2>>$out/bench_hex100.err
-python bench.py --workload hex100cB --no-cpu-baseline --steps 50 --warmup 5 > $out/bench_hex100cB.json 2>>$out/bench_hex100.err
+B="timeout 300 python bench.py"
+$B > $out/bench_default.json 2>$out/bench.err                                   # hex100 + configs[] (hex100c, cavity215, cavity215c) + cpu_baseline
+$B --workload hex100c --no-configs > $out/bench_hex100c.json 2>>$out/bench.err
+$B --workload hex215 --no-cpu-baseline --no-configs --steps 50 --warmup 5 > $out/bench_hex215.json 2>>$out/bench.err
+$B --workload hex300 --no-cpu-baseline --no-configs --steps 20 --warmup 2 > $out/bench_hex300.json 2>>$out/bench.err
+$B --workload cavity215 --no-cpu-baseline --no-configs --steps 50 --warmup 5 > $out/bench_cavity215.json 2>>$out/bench.err
+$B --workload cavity215c --no-cpu-baseline --no-configs --steps 200 --warmup 5 > $out/bench_cavity215c.json 2>>$out/bench.err   # configs[3] as written: 200 iterations
+$B --workload cavity100c --no-configs --steps 40 --warmup 5 > $out/bench_cavity100c.json 2>>$out/bench.err
+$B --workload hex100L --no-configs --steps 50 --warmup 5 > $out/bench_hex100L.json 2>>$out/bench.err
+$B --workload hex100B --no-configs --steps 50 --warmup 5 > $out/bench_hex100B.json 2>>$out/bench.err
+SMGPU_WALK=host $B --workload cavity215c --no-cpu-baseline --no-configs --steps 30 --warmup 5 > $out/bench_cavity215c_hostwalk.json 2>>$out/bench.err  # round-1 replay place, A/B
 cd /tmp && export TMPDIR=/tmp
-for wl in hex100 hex100c hex100B; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_$wl -- python3 $root/bench.py --no-cpu-baseline --workload $wl > /dev/null 2>&1
-  cp $out/rocprof_$wl/*/*kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv
+for wl in hex100 hex100c cavity215c; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_$wl -o p -- python3 $root/bench.py --no-cpu-baseline --no-configs --workload $wl --steps 50 --warmup 5 > /dev/null 2>&1
+  cp $out/rocprof_$wl/p_kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv
   rm -rf $out/rocprof_$wl
 done
 cd $root
-bash scripts/measure_traffic.sh hex100 10 > /dev/null
-bash scripts/measure_traffic.sh hex215 5 > /dev/null
-cp gpurun_out/traffic_hex100.json gpurun_out/traffic_hex215.json $out/
+export SMGPU_SIDE_STREAM=0   # counter collection serialises kernels: no cross-stream waits
+for wl in hex100 hex215; do
+  BENCH_EXTRA="--no-configs" timeout 600 bash scripts/measure_traffic.sh $wl 10 > /dev/null 2>&1
+  cp gpurun_out/traffic_$wl.json $out/ 2>/dev/null
+done
+cd /tmp
+i=0
+for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT"; do
+  i=$((i+1))
+  timeout 240 rocprofv3 --pmc $grp --output-format csv -d $out/sq$i -- python3 $root/bench.py --workload hex100 --steps 20 --warmup 2 --no-cpu-baseline --no-configs > /dev/null 2>&1
+done
+cd $root
+python3 scripts/pmc_summary.py $out > $out/pmc_sq_hex100.txt 2>/dev/null
+rm -rf $out/sq1 $out/sq2 $out/sq3
 ls -la $out

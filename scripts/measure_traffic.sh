@@ -9,8 +9,8 @@ out=$root/gpurun_out/traffic_$wl
 rm -rf $out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 export SMGPU_SIDE_STREAM=0   # counter collection serialises kernels: no cross-stream waits (see scripts/pmc_kernels.sh)
-timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/fetch.err
-timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu-baseline --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/write.err
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 $root/bench.py --no-cpu-baseline --no-configs --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/fetch.err
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 $root/bench.py --no-cpu-baseline --no-configs --workload $wl --steps $steps --warmup 1 > /dev/null 2>$out/write.err
 cd $root
 python3 - "$out" "$wl" <<'PY'
 import csv, glob, json, sys
@@ -34,7 +34,7 @@ doc = {"workload": wl, "units": "FETCH_SIZE/WRITE_SIZE as reported by rocprofv3 
                      "hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024; an upper bound for kernels whose misses are 64-B requests",
        "kernels": res}
 import os
-os.makedirs("profiles/r1", exist_ok=True)
+
 json.dump(doc, open(f"gpurun_out/traffic_{wl}.json", "w"), indent=1)
 print(json.dumps(doc)[:600])
 PY
