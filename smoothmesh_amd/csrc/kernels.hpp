@@ -62,6 +62,12 @@ struct State {
     smgpu_iter_stats* stats;
     const int* sharedSlot;     // multi-rank: per point slot into combA, or -1 (NULL on one rank)
     const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
+    // multi-rank, tiled kernels: a point with TWO sharers (nearly all shared points) is combined by the smoothing kernel
+    // itself from the own and the received record (inlineCombine), and its freeze flag goes straight to its send slots
+    // (inlinePackF): k_halo_combineA then only serves the few points with more sharers, k_halo_packF is not launched
+    const int* combOff; const int* combSlots; const double* ownA; const double* recvA;
+    const int* sendOff; const int* sendSlots; int* sendF;
+    int inlineCombine, inlinePackF;
     // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
     // outer neighbour; per hop count the target edge length and the blending fraction
     double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
@@ -1012,6 +1018,37 @@ __device__ __forceinline__ bool isCloserPoint(const V3& a, const V3& b) {
     return false;  // the |delta| < VSMALL branch (SM.C:266) cannot be reached once the test above failed
 }
 
+// The three sequential syncs (SM.C:391-478) for a point with TWO sharers, both ranks' views in scalars: ra = this rank's
+// record, rb = the other rank's, selfFirst = this rank is the lower one (plusEqOp sums in ascending rank order).
+__device__ __forceinline__ void combineTwoSharers(const double* ra, const double* rb, bool selfFirst, V3& sum, V3& a1, V3& a2, V3& a3,
+                                                  int& cnt, int& anyCommon) {
+    const V3 sa = v3(ra[0], ra[1], ra[2]), sb = v3(rb[0], rb[1], rb[2]);
+    sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;    // plusEqOp, ascending rank
+    a1 = v3(ra[3], ra[4], ra[5]); a2 = v3(ra[6], ra[7], ra[8]); a3 = v3(ra[9], ra[10], ra[11]);
+    V3 b1 = v3(rb[3], rb[4], rb[5]), b2 = v3(rb[6], rb[7], rb[8]), b3 = v3(rb[9], rb[10], rb[11]);
+    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
+    cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
+    int hcA = (int)(pa >> 32), hcB = (int)(pb >> 32);
+    // minMagSqrEqOp folded from the own value: x = (magSqr(x) <= magSqr(y)) ? x : y
+#define SMGPU_FOLD2(X, Y) ((magSqr(X) <= magSqr(Y)) ? (X) : (Y))
+    {   // SM.C:397-419: both ranks exchange their first vectors
+        const V3 svA = SMGPU_FOLD2(a1, b1), svB = SMGPU_FOLD2(b1, a1);
+        if (isCloserPoint(svA, a1)) { a3 = a2; a2 = a1; a1 = svA; hcA = 0; }
+        if (isCloserPoint(svB, b1)) { b3 = b2; b2 = b1; b1 = svB; hcB = 0; }
+    }
+    {   // SM.C:424-445: the (updated) second vectors
+        const V3 svA = SMGPU_FOLD2(a2, b2), svB = SMGPU_FOLD2(b2, a2);
+        if (isCloserPoint(svA, a2)) { a3 = a2; a2 = svA; hcA = 0; }
+        if (isCloserPoint(svB, b2)) { b3 = b2; b2 = svB; hcB = 0; }
+    }
+    {   // SM.C:450-469: the (updated) third vectors
+        const V3 svA = SMGPU_FOLD2(a3, b3);
+        if (isCloserPoint(svA, a3)) a3 = svA;
+    }
+#undef SMGPU_FOLD2
+    anyCommon = hcA | hcB;
+}
+
 constexpr int kMaxSharers = 16;
 
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
@@ -1042,32 +1079,10 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
         const double* ra = ownA + (size_t)i * SMGPU_HALO_A_DOUBLES;                       // A = this rank
         const double* rb = recvA + (size_t)(s0 < 0 ? s1 : s0) * SMGPU_HALO_A_DOUBLES;     // B = the other one
         const bool selfFirst = s0 < 0;
-        const V3 sa = v3(ra[0], ra[1], ra[2]), sb = v3(rb[0], rb[1], rb[2]);
-        const V3 sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;    // plusEqOp, ascending rank
-        V3 a1 = v3(ra[3], ra[4], ra[5]), a2 = v3(ra[6], ra[7], ra[8]), a3 = v3(ra[9], ra[10], ra[11]);
-        V3 b1 = v3(rb[3], rb[4], rb[5]), b2 = v3(rb[6], rb[7], rb[8]), b3 = v3(rb[9], rb[10], rb[11]);
-        const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
-        const int cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
-        int hcA = (int)(pa >> 32), hcB = (int)(pb >> 32);
-        // minMagSqrEqOp folded from the own value: x = (magSqr(x) <= magSqr(y)) ? x : y
-#define SMGPU_FOLD2(X, Y) ((magSqr(X) <= magSqr(Y)) ? (X) : (Y))
-        {   // SM.C:397-419: both ranks exchange their first vectors
-            const V3 svA = SMGPU_FOLD2(a1, b1), svB = SMGPU_FOLD2(b1, a1);
-            if (isCloserPoint(svA, a1)) { a3 = a2; a2 = a1; a1 = svA; hcA = 0; }
-            if (isCloserPoint(svB, b1)) { b3 = b2; b2 = b1; b1 = svB; hcB = 0; }
-        }
-        {   // SM.C:424-445: the (updated) second vectors
-            const V3 svA = SMGPU_FOLD2(a2, b2), svB = SMGPU_FOLD2(b2, a2);
-            if (isCloserPoint(svA, a2)) { a3 = a2; a2 = svA; hcA = 0; }
-            if (isCloserPoint(svB, b2)) { b3 = b2; b2 = svB; hcB = 0; }
-        }
-        {   // SM.C:450-469: the (updated) third vectors
-            const V3 svA = SMGPU_FOLD2(a3, b3);
-            if (isCloserPoint(svA, a3)) a3 = svA;
-        }
-#undef SMGPU_FOLD2
+        V3 sum, a1, a2, a3;
+        int cnt, any2;
+        combineTwoSharers(ra, rb, selfFirst, sum, a1, a2, a3, cnt, any2);
         double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
-        const int any2 = hcA | hcB;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
         o[3] = a1.x; o[4] = a1.y; o[5] = a1.z;
         o[6] = a2.x; o[7] = a2.y; o[8] = a2.z;

@@ -427,12 +427,19 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
         const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
         if (slot >= 0) {
-            const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
-            sum = v3(r[0], r[1], r[2]);
-            r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);
-            const long long pk = __double_as_longlong(r[12]);
-            count = (int)(pk & 0xffffffffll);
-            hc = (int)(pk >> 32);
+            const int cb = s.inlineCombine ? s.combOff[slot] : 0;
+            if (s.inlineCombine && s.combOff[slot + 1] - cb == 2) {
+                const int s0 = s.combSlots[cb], s1 = s.combSlots[cb + 1];
+                combineTwoSharers(s.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES, s.recvA + (size_t)(s0 < 0 ? s1 : s0) * SMGPU_HALO_A_DOUBLES,
+                                  s0 < 0, sum, r1, r2, r3, count, hc);
+            } else {
+                const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
+                sum = v3(r[0], r[1], r[2]);
+                r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);
+                const long long pk = __double_as_longlong(r[12]);
+                count = (int)(pk & 0xffffffffll);
+                hc = (int)(pk >> 32);
+            }
             m1 = mag(r1); m2 = mag(r2); m3 = mag(r3);
             SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 (void)j;
@@ -514,6 +521,8 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             // k_shared_fix finishes it after exchange F
             stv(s.prop, p, np);
             s.frozen[p] = frozen ? 1 : 0;
+            if (s.inlinePackF)
+                for (int k = s.sendOff[slot]; k < s.sendOff[slot + 1]; ++k) s.sendF[s.sendSlots[k]] = frozen ? 1 : 0;   // exchange F, SM.C:2374
         } else if (FINAL) {
             if (frozen || (!internal && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
             dist = mag(np - cur) / prm.maxStep;

@@ -1431,6 +1431,14 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     }
     h->st.sharedSlot = h->dSharedSlot;
     h->st.combA = h->dCombA;
+    h->st.combOff = h->dCombOff; h->st.combSlots = h->dCombSlots; h->st.ownA = h->dOwnA; h->st.recvA = h->recvA;
+    h->st.sendOff = h->dSendOff; h->st.sendSlots = h->dSendSlots; h->st.sendF = h->sendF;
+    // two-sharer points combined inside the smoothing kernel (needs the tiled kernels and the table of the multi-sharer points).
+    // MEASURED (one rank of eight, 30 k shared points): slower, 211 against 199 us per iteration -- the combine is a chain of
+    // dependent loads (offset -> slot -> record) and stalls whole waves of the smoothing kernel (47 -> 59 us), which costs more
+    // than the two small launches it removes.  Off by default (SMGPU_HALO_INLINE=1 selects it; results are the same).
+    h->st.inlineCombine = (h->useTiles && h->dMultiIdx && envInt("SMGPU_HALO_INLINE", 0)) ? 1 : 0;
+    h->st.inlinePackF = h->st.inlineCombine;
     h->packTiles = envInt("SMGPU_PACK_TILES", 1) != 0;
     if (h->useTiles) {
         ensureDynLds(k_pack_tile<64>, h->device, h->smoothLds);
@@ -1525,9 +1533,11 @@ int smgpu_iter_mid(smgpu_handle* h) {
     if (computeAfterExch(h)) return 1;      // exchange A has been enqueued by the host
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
-                const int nTwo = gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
-                hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
-                                   h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
+                // (with inlineCombine only the workgroups of the points with more than two sharers: the others are the smoothing kernel's)
+                const int nTwo = h->st.inlineCombine ? 0 : gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
+                if (nTwo + nMultiBlocks > 0)
+                    hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
+                                       h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
                 if (h->layersOn || h->bndOn)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                        h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride);
@@ -1545,7 +1555,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (h->bndOn) { if (fused ? launchBndFix<true>(h, h->stl.nTiles + gridFor(h->nShared)) : launchBndFix<false>(h, 0)) return 1; }
         if (!fused && runConstraints(h)) return 1;
     } else if (runProposalAndConstraints(h)) return 1;
-    if (h->nSend)
+    if (h->nSend && !(fused && h->st.inlinePackF && !h->bndOn && h->useTiles))   // (fused: the smoothing kernel wrote the flags into the send slots)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
                                    h->dSharedLocal, h->st.frozen, h->sendF);

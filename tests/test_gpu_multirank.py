@@ -114,6 +114,20 @@ def test_polyhedral_decomposition_matches_multi_oracle(oracle_lib, N, grid, cons
     assert same.any() and np.array_equal(ps[1:][same], ps[:-1][same])
 
 
+def test_inline_combine_knob_gives_the_same_result(oracle_lib, monkeypatch):
+    """SMGPU_HALO_INLINE=1: two-sharer points combined, and their freeze flags packed, inside the smoothing kernel"""
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    monkeypatch.setenv("SMGPU_HALO_INLINE", "1")
+    subs, orcs, prm, table, mo = _poly_case(oracle_lib, 12, (2, 2, 2), False)
+    ms = LocalMultiSmoother(subs, device=0, overlap=False)
+    ms.set_params(prm)
+    n_o, res_o, frz_o = mo.iterate(6, 0.0)
+    n_g, res_g, frz_g = ms.iterate(6, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    for o, pts in zip(orcs, ms.get_points()):
+        assert rel_linf(pts, o.points()) <= 1e-13
+
+
 def test_distributed_smoother_polyhedral_two_processes():
     """One process per rank (torch.distributed.run) with the real engines, two ranks sharing this box's GPU through the gloo
     debug transport: DistributedSmoother on the two halves of the polyhedral cavity mesh (each rank generates its own)
