@@ -170,6 +170,36 @@ def test_large_mesh_properties():
     assert np.all(frz >= (~internal).sum())
 
 
+@pytest.mark.parametrize("jitter,minAngle", [(0.2, 35.0), (0.42, 60.0)])
+def test_large_mesh_with_constraints_filters_are_conservative(monkeypatch, jitter, minAngle):
+    """Full-size config (100^3 with the edge- and face-angle constraints on, BASELINE configs[2]; the second case with heavier
+    jitter and a larger minAngle so that the evaluators do freeze thousands of points): the f32 filters, the list-based exact
+    pass and the walk mode chosen at this size decide exactly what the unfiltered exact kernels decide -- identical
+    nFrozenPoints / residual series and coordinates; boundary points never move; steps stay within maxStepLength."""
+    from smoothmesh_amd import SmoothEngine, default_params
+    mesh = _mk(100, 100, 100, jitter, 12345)
+    internal = mesh.find_internal_points().astype(bool)
+    outs = []
+    for filt in ("1", "0"):
+        monkeypatch.setenv("SMGPU_FILTER", filt)
+        e = SmoothEngine(mesh)
+        p = default_params(e.mesh_stats()[0], minAngle=minAngle)
+        e.set_params(p)
+        n, res, frz = e.iterate(12, 0.0)
+        outs.append((res, frz, e.get_points()))
+        e.close()
+    assert np.array_equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][0], outs[1][0])
+    assert np.array_equal(outs[0][2], outs[1][2])
+    res, frz, after = outs[0]
+    assert np.all(np.isfinite(res)) and np.all(res >= 0) and np.all(res <= 1.0 + 1e-12)
+    assert np.array_equal(after[~internal], mesh.points[~internal])
+    assert np.max(np.linalg.norm(after - mesh.points, axis=1)) <= 12 * p.maxStepLength * (1 + 1e-12)
+    assert np.all(frz >= (~internal).sum())
+    if jitter > 0.4:
+        assert frz[0] > (~internal).sum() + 1000       # the constraints are busy
+
+
 def test_golden_fixture_hip():
     """The HIP path against the committed golden vectors (tests/golden/make_golden.py; oracle-generated)."""
     import os
