@@ -506,6 +506,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
                     h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;
+                    if (envInt("SMGPU_VERBOSE", 0))
+                        std::fprintf(stderr, "[smgpu] edge tiles: n=%d LDS=%zu B (maxP %d maxF %d maxC %d)\n", h->etl.nTiles, h->edgeLds, ev.maxPoints, ev.maxFaces, ev.maxCells);
                     if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", sideStreamDefault())) {
                         if (depInit(h)) return cleanup(1);
                         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
