@@ -275,6 +275,11 @@ int smgpu_debug_edge_strings(int32_t nPoints, int32_t nEdges, const int32_t* edg
 /* parity access: nearest intersections of n segments (6 doubles each: start, end) with the target surface */
 int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit);
 
+/* self-test of the geometry kernel's range-tested square root / division fast paths (csrc/fpexact.hpp) against the plain
+ * IEEE operators on n generated arguments (random, zeros, denormals, inf / nan, both ends of the exponent range) on the
+ * given device; *mismatches = number of results whose bits differ (nan == nan).  0 is the only acceptable count. */
+int smgpu_debug_selftest_fpexact(int32_t device, uint64_t seed, int64_t n, int64_t* mismatches);
+
 /* ---- debug / parity access (device -> host copy of an internal field) -----------------------
  * name: "cellCentres" [3C], "faceCentres" [3F], "faceAreas" [3F], "newPoints" [3P] (proposal of the
  * last iteration before restore), "isFrozenPoint" [P], "edgeMinAngle"/"edgeMaxAngle" [E],

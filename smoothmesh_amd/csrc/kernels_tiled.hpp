@@ -4,6 +4,7 @@
 // per lane per load), all indexed access is in LDS.
 #pragma once
 #include "kernels.hpp"
+#include "fpexact.hpp"
 
 namespace smgpu {
 
@@ -14,8 +15,22 @@ struct GeomTileView {
     const int* fvBase; const uint8_t* fvWidth; const uint16_t* faceVerts;
     const int* cfBase; const uint8_t* cfWidth; const uint16_t* cellFaces;
     const uint8_t* tileFlags;    // bit0 all faces quadrilaterals, bit1 all cells six-faced: unrolled paths (same arithmetic)
+    const int* meta;             // the per-tile scalars of the arrays above in one record per tile (GeomTileMeta)
     int maxPoints, maxFaces;
 };
+// One tile's scalars, fetched with scalar loads through the constant address space (the tables are written by the host
+// before the first launch).  Read from the separate arrays with ordinary loads -- the compiler cannot prove them
+// invariant -- they were a chain of dependent vector-memory round trips in front of the staging.
+struct GeomTileMeta { int tpOff, nPts, tfOff, nFaces, fvBase, fvWidth, cellBeg, nCells, cfBase, cfWidth, flags, pad; };
+constexpr int kGeomMetaInts = 12;
+typedef const __attribute__((address_space(4))) int* const_int_ptr;
+__device__ __forceinline__ GeomTileMeta loadTileMeta(const GeomTileView& g, int tile) {
+    const_int_ptr p = (const_int_ptr)(g.meta + (size_t)kGeomMetaInts * tile);
+    GeomTileMeta t;
+    t.tpOff = p[0]; t.nPts = p[1]; t.tfOff = p[2]; t.nFaces = p[3]; t.fvBase = p[4]; t.fvWidth = p[5];
+    t.cellBeg = p[6]; t.nCells = p[7]; t.cfBase = p[8]; t.cfWidth = p[9]; t.flags = p[10]; t.pad = 0;
+    return t;
+}
 
 struct SmoothTileView {
     const int* ptOrder; const int* ptBeg; const int* tcOff; const int* tcIds; const int* tnOff; const int* tnIds;
@@ -40,6 +55,30 @@ __device__ __forceinline__ int launchTile(int n, int xcdMap) {
 inline int tileGrid(int n, int xcdMap) { return xcdMap ? ((n + 7) >> 3) << 3 : n; }
 
 __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const double* z, int i) { return v3(x[i], y[i], z[i]); }
+
+// v / s (three IEEE divisions by one denominator) with the reciprocal's Newton iteration shared (fpexact.hpp); the plain
+// operator when an exponent is near the ends of the range or a numerator is zero / denormal
+__device__ __forceinline__ V3 divExact(const V3& v, double s) {
+    const unsigned hx = (unsigned)__double2hiint(v.x) & 0x7fffffffu, hy = (unsigned)__double2hiint(v.y) & 0x7fffffffu,
+                   hz = (unsigned)__double2hiint(v.z) & 0x7fffffffu, hs = (unsigned)__double2hiint(s) & 0x7fffffffu;
+    const unsigned lo = min(min(hx, hy), min(hz, hs)), hi = max(max(hx, hy), max(hz, hs));
+    if (SMGPU_FPEXACT_FAST && __builtin_expect(lo >= ((1023u - 250u) << 20) && hi < ((1023u + 250u) << 20), 1)) {
+        const Recip d = recipCore(s);
+        return v3(divCore(v.x, d), divCore(v.y, d), divCore(v.z, d));
+    }
+    return v / s;
+}
+// four square roots behind one range test
+__device__ __forceinline__ void sqrtExact4(double m0, double m1, double m2, double m3, double& a0, double& a1, double& a2, double& a3) {
+    const unsigned h0 = (unsigned)__double2hiint(m0), h1 = (unsigned)__double2hiint(m1), h2 = (unsigned)__double2hiint(m2),
+                   h3 = (unsigned)__double2hiint(m3);
+    const unsigned lo = min(min(h0, h1), min(h2, h3)), hi = max(max(h0, h1), max(h2, h3));
+    if (SMGPU_FPEXACT_FAST && __builtin_expect(lo >= ((1023u - 767u) << 20) && hi < (2047u << 20), 1)) {
+        a0 = sqrtCore(m0); a1 = sqrtCore(m1); a2 = sqrtCore(m2); a3 = sqrtCore(m3);
+    } else {
+        a0 = sqrt(m0); a1 = sqrt(m1); a2 = sqrt(m2); a3 = sqrt(m3);
+    }
+}
 
 // Visit the entries of one ELL row (4 per 8-byte chunk, `w4` chunks `stride` chunks apart) in list
 // order; pads (0xFFFF) only occur at the tail and are skipped.  No early exit, so the chunk loads
@@ -77,7 +116,7 @@ __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const doubl
 // Stage n elements (24-byte records picked by an ascending id list) into SoA LDS arrays.  All id loads
 // of a thread are issued first, then all record loads, then the LDS stores: two memory round trips per
 // tile instead of two per 256 elements.
-template <int T, int ROUNDS>
+template <int T, int ROUNDS, int STRIDE = 1>
 __device__ __forceinline__ void stageRecords(const double* __restrict__ src, const int* __restrict__ ids, int n, double* x,
                                              double* y, double* z, int tid) {
     for (int base = 0; base < n; base += T * ROUNDS) {
@@ -93,7 +132,7 @@ __device__ __forceinline__ void stageRecords(const double* __restrict__ src, con
 #pragma unroll
         for (int u = 0; u < ROUNDS; ++u) {
             const int i = base + u * T + tid;
-            if (id[u] >= 0) { x[i] = v[u].x; y[i] = v[u].y; z[i] = v[u].z; }
+            if (id[u] >= 0) { x[STRIDE * i] = v[u].x; y[STRIDE * i] = v[u].y; z[STRIDE * i] = v[u].z; }
         }
     }
 }
@@ -149,6 +188,15 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 // tileList (may be NULL) selects the tiles of this launch (multi-rank: the tiles away from the shared points
 // are recomputed ahead, while exchange F is in flight).
 // LDS arrays of one geometry tile
+// Records, not component arrays: a point is 3 consecutive doubles, a face 6 (centre, area vector), so that one address
+// (index * stride, one v_mad) serves all components through the instruction's offset field -- with nine component arrays
+// every LDS access carried its own shift-and-add (the kernel is bound by vector instruction issue).  The
+// nine pointers stay (x[kGP * i] is component x of point i), set one element apart.  SMGPU_GEOM_AOS=0: component arrays.
+#ifndef SMGPU_GEOM_AOS
+#define SMGPU_GEOM_AOS 1
+#endif
+constexpr int kGP = SMGPU_GEOM_AOS ? 3 : 1;   // index stride of a point in px / py / pz
+constexpr int kGF = SMGPU_GEOM_AOS ? 6 : 1;   // index stride of a face in fcx .. faz
 struct GeomLds {
     double *px, *py, *pz;        // the tile's points
     double *fcx, *fcy, *fcz;     // face centres
@@ -156,6 +204,12 @@ struct GeomLds {
 };
 __device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileView& g) {
     GeomLds L;
+    if (SMGPU_GEOM_AOS) {
+        L.px = lds;                      L.py = L.px + 1;  L.pz = L.px + 2;
+        L.fcx = L.px + 3 * g.maxPoints;  L.fcy = L.fcx + 1; L.fcz = L.fcx + 2;
+        L.fax = L.fcx + 3;               L.fay = L.fcx + 4; L.faz = L.fcx + 5;
+        return L;
+    }
     L.px = lds;                  L.py = L.px + g.maxPoints;  L.pz = L.py + g.maxPoints;
     L.fcx = L.pz + g.maxPoints;  L.fcy = L.fcx + g.maxFaces; L.fcz = L.fcy + g.maxFaces;
     L.fax = L.fcz + g.maxFaces;  L.fay = L.fax + g.maxFaces; L.faz = L.fay + g.maxFaces;
@@ -167,56 +221,61 @@ __device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileView& g) {
 // ORG = false: OpenFOAM.com v2312-v2506 (fan triangles weighted by |n|); ORG = true: OpenFOAM.org 12 (fan triangles weighted
 // by n . nHat with nHat the normalised sum of the n, centre = point average when the weights sum to <= vSmall) -- the two
 // OpenFOAM lines the reference builds against (Allwmake:47); the area vector 0.5 * sum(n) is the same in both.
+// pre / preQ: the face's vertex row was read by the kernel's prologue (quadrilateral tiles, first two rounds)
 template <bool ORG>
-__device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int i, unsigned tflags,
-                                         int wantAvg, int writeFaces) {
+__device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, const GeomLds& L, const GeomTileMeta& tm, int i, unsigned tflags,
+                                         int wantAvg, int writeFaces, bool pre = false, ushort4 preQ = make_ushort4(0, 0, 0, 0)) {
     const double *px = L.px, *py = L.py, *pz = L.pz;
-    const int b = g.tfOff[tile];
-    const int fw4 = g.fvWidth[tile] >> 2;
-    const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + g.fvBase[tile]);
+    const int b = tm.tfOff;
+    const int fw4 = tm.fvWidth >> 2;
+    const ushort4* fvTile = reinterpret_cast<const ushort4*>(g.faceVerts + tm.fvBase);
     V3 fCentre, ctr, area;
     if (!ORG && (tflags & 1u)) {
         // the general loop below unrolled for four vertices -- same operations in the same order, every vertex read
         // once, no pad / position tests
-        const ushort4 q = fvTile[i];
-        const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z), p3 = ldsv(px, py, pz, q.w);
+        const ushort4 q = pre ? preQ : fvTile[i];
+        const V3 p0 = ldsv(px, py, pz, kGP * (q.x)), p1 = ldsv(px, py, pz, kGP * (q.y)), p2 = ldsv(px, py, pz, kGP * (q.z)), p3 = ldsv(px, py, pz, kGP * (q.w));
         fCentre = divByCount(((p0 + p1) + p2) + p3, 4);
         V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
         double sumA = 0.0;
-#define SMGPU_FAN4(THIS, NEXT)                                                 \
+        // the four fan triangles: normals first, their four lengths behind one range test (sqrtExact4), then the sums in
+        // the order of the general loop
+        const V3 n0 = cross(p1 - p0, fCentre - p0), n1 = cross(p2 - p1, fCentre - p1), n2 = cross(p3 - p2, fCentre - p2),
+                 n3 = cross(p0 - p3, fCentre - p3);
+        double a0, a1, a2, a3;
+        sqrtExact4(magSqr(n0), magSqr(n1), magSqr(n2), magSqr(n3), a0, a1, a2, a3);
+#define SMGPU_FAN4(THIS, NEXT, NN, A)                                          \
     {                                                                          \
         const V3 c = ((THIS) + (NEXT)) + fCentre;                              \
-        const V3 nn = cross((NEXT) - (THIS), fCentre - (THIS));                \
-        const double a = mag(nn);                                              \
-        sumN = sumN + nn;                                                      \
-        sumA += a;                                                             \
-        sumAc = sumAc + a * c;                                                 \
+        sumN = sumN + (NN);                                                    \
+        sumA += (A);                                                           \
+        sumAc = sumAc + (A) * c;                                               \
     }
-        SMGPU_FAN4(p0, p1) SMGPU_FAN4(p1, p2) SMGPU_FAN4(p2, p3) SMGPU_FAN4(p3, p0)
+        SMGPU_FAN4(p0, p1, n0, a0) SMGPU_FAN4(p1, p2, n1, a1) SMGPU_FAN4(p2, p3, n2, a2) SMGPU_FAN4(p3, p0, n3, a3)
 #undef SMGPU_FAN4
         if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
-        else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
+        else { ctr = divExact((1.0 / 3.0) * sumAc, sumA); area = 0.5 * sumN; }
     } else {
         const ushort4* row = fvTile + (size_t)i * fw4;
         // vertex average (fCentre of makeFaceCentresAndAreas; calcFaceCenter SM.C:1103-1130)
         fCentre = v3(0, 0, 0);
         int n = 0;
         SMGPU_ELL_FOREACH(row, fw4, 1, {
-            const V3 p = ldsv(px, py, pz, e);
+            const V3 p = ldsv(px, py, pz, kGP * (e));
             fCentre = (j == 0) ? p : fCentre + p;
             n = j + 1;
         })
         fCentre = divByCount(fCentre, n);
         if (n == 3) {
             const ushort4 q = row[0];
-            const V3 p0 = ldsv(px, py, pz, q.x), p1 = ldsv(px, py, pz, q.y), p2 = ldsv(px, py, pz, q.z);
+            const V3 p0 = ldsv(px, py, pz, kGP * (q.x)), p1 = ldsv(px, py, pz, kGP * (q.y)), p2 = ldsv(px, py, pz, kGP * (q.z));
             ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
             area = 0.5 * cross(p1 - p0, p2 - p0);
         } else if (ORG) {
             V3 sumA = v3(0, 0, 0);
             V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, e);
+                const V3 p = ldsv(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else { sumA = sumA + cross(p - thisPoint, fCentre - thisPoint); thisPoint = p; }
             })
@@ -235,7 +294,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         thisPoint = nextPoint;                                                 \
     }
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, e);
+                const V3 p = ldsv(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else SMGPU_FAN_ORG(p)
             })
@@ -253,25 +312,25 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         const V3 nextPoint = (NEXT);                                           \
         const V3 c = (thisPoint + nextPoint) + fCentre;                        \
         const V3 nn = cross(nextPoint - thisPoint, fCentre - thisPoint);       \
-        const double a = mag(nn);                                              \
+        const double a = sqrtExact(magSqr(nn));                                \
         sumN = sumN + nn;                                                      \
         sumA += a;                                                             \
         sumAc = sumAc + a * c;                                                 \
         thisPoint = nextPoint;                                                 \
     }
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, e);
+                const V3 p = ldsv(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else SMGPU_FAN(p)
             })
             SMGPU_FAN(first)
 #undef SMGPU_FAN
             if (sumA < SMGPU_ROOTVSMALL) { ctr = fCentre; area = v3(0, 0, 0); }
-            else { ctr = ((1.0 / 3.0) * sumAc) / sumA; area = 0.5 * sumN; }
+            else { ctr = divExact((1.0 / 3.0) * sumAc, sumA); area = 0.5 * sumN; }
         }
     }
-    L.fcx[i] = ctr.x; L.fcy[i] = ctr.y; L.fcz[i] = ctr.z;
-    L.fax[i] = area.x; L.fay[i] = area.y; L.faz[i] = area.z;
+    L.fcx[kGF * i] = ctr.x; L.fcy[kGF * i] = ctr.y; L.fcz[kGF * i] = ctr.z;
+    L.fax[kGF * i] = area.x; L.fay[kGF * i] = area.y; L.faz[kGF * i] = area.z;
     if (wantAvg && s.avgPacked) stv(s.fAvg, b + i, fCentre);   // tile order: contiguous stores (the face-angle filter's
                                                                 // tiles hold positions into this order)
     if ((wantAvg && !s.avgPacked) || writeFaces) {
@@ -286,19 +345,37 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
 
 // the thread's cell of the tile: OpenFOAM makeCellCentresAndVols (.com v2412) on the face values in LDS.
 // tflags bit1: every cell of the tile has six faces.
+// what a cell thread reads from global memory: its cell id and (tiles of six-faced cells) its face row; read by the kernel's
+// prologue so that the latency runs beside the staging of the points instead of in front of the cell phase
+struct GeomCellIn { bool mine; int c; ushort4 qa, qb; };
+template <int T>
+__device__ __forceinline__ GeomCellIn geomCellLoad(const GeomTileView& g, const GeomTileMeta& tm, int tid, unsigned tflags) {
+    GeomCellIn in;
+    const int ci = tm.cellBeg + tid;
+    in.mine = tid < tm.nCells;
+    in.c = 0;
+    in.qa = in.qb = make_ushort4(0, 0, 0, 0);
+    if (in.mine) {
+        in.c = g.cellOrder[ci];
+        if (tflags & 2u) {
+            const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + tm.cfBase) + tid;
+            in.qa = row[0]; in.qb = row[T];
+        }
+    }
+    return in;
+}
 template <int T, bool ORG>
-__device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, int tile, int tid, unsigned tflags) {
+__device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, const GeomTileMeta& tm, int tid, unsigned tflags, const GeomCellIn& in) {
     const double *fcx = L.fcx, *fcy = L.fcy, *fcz = L.fcz, *fax = L.fax, *fay = L.fay, *faz = L.faz;
-    const int ci = g.cellBeg[tile] + tid;
-    if (ci >= g.cellBeg[tile + 1]) return;
-    const int c = g.cellOrder[ci];
-    const int cw4 = g.cfWidth[tile] >> 2;
-    const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + g.cfBase[tile]) + tid;
+    if (!in.mine) return;
+    const int c = in.c;
+    const int cw4 = tm.cfWidth >> 2;
+    const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + tm.cfBase) + tid;
     V3 cEst = v3(0, 0, 0), ctr = v3(0, 0, 0);
     double vol = 0.0;
 #define SMGPU_PYR(E, FC)                                                                                   \
     {                                                                                                      \
-        const V3 fA = ldsv(fax, fay, faz, (E) & 0x7fff);                                                   \
+        const V3 fA = ldsv(fax, fay, faz, kGF * ((E) & 0x7fff));                                                   \
         double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);                     \
         if (ORG) pyr3Vol = (pyr3Vol > SMGPU_VSMALL) ? pyr3Vol : SMGPU_VSMALL;   /* OpenFOAM.org: max(.., vSmall) */ \
         const V3 pc = (3.0 / 4.0) * (FC) + (1.0 / 4.0) * cEst;                                             \
@@ -307,28 +384,28 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
     }
     if (tflags & 2u) {
         // the loops below unrolled for six faces, each face centre read once
-        const ushort4 qa = row[0], qb = row[T];
+        const ushort4 qa = in.qa, qb = in.qb;
         const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
-        const V3 c0 = ldsv(fcx, fcy, fcz, e0 & 0x7fff), c1 = ldsv(fcx, fcy, fcz, e1 & 0x7fff), c2 = ldsv(fcx, fcy, fcz, e2 & 0x7fff),
-                 c3 = ldsv(fcx, fcy, fcz, e3 & 0x7fff), c4 = ldsv(fcx, fcy, fcz, e4 & 0x7fff), c5 = ldsv(fcx, fcy, fcz, e5 & 0x7fff);
+        const V3 c0 = ldsv(fcx, fcy, fcz, kGF * (e0 & 0x7fff)), c1 = ldsv(fcx, fcy, fcz, kGF * (e1 & 0x7fff)), c2 = ldsv(fcx, fcy, fcz, kGF * (e2 & 0x7fff)),
+                 c3 = ldsv(fcx, fcy, fcz, kGF * (e3 & 0x7fff)), c4 = ldsv(fcx, fcy, fcz, kGF * (e4 & 0x7fff)), c5 = ldsv(fcx, fcy, fcz, kGF * (e5 & 0x7fff));
         cEst = cEst + c0; cEst = cEst + c1; cEst = cEst + c2; cEst = cEst + c3; cEst = cEst + c4; cEst = cEst + c5;
-        cEst = divByCount(cEst, 6);
+        cEst = divExact(cEst, 6.0);
         SMGPU_PYR(e0, c0) SMGPU_PYR(e1, c1) SMGPU_PYR(e2, c2) SMGPU_PYR(e3, c3) SMGPU_PYR(e4, c4) SMGPU_PYR(e5, c5)
     } else {
         int nFaces = 0;
         SMGPU_ELL_FOREACH(row, cw4, T, {
-            cEst = cEst + ldsv(fcx, fcy, fcz, e & 0x7fff);
+            cEst = cEst + ldsv(fcx, fcy, fcz, kGF * (e & 0x7fff));
             nFaces = j + 1;
         })
         cEst = divByCount(cEst, nFaces);
         SMGPU_ELL_FOREACH(row, cw4, T, {
             (void)j;
-            const V3 fc = ldsv(fcx, fcy, fcz, e & 0x7fff);
+            const V3 fc = ldsv(fcx, fcy, fcz, kGF * (e & 0x7fff));
             SMGPU_PYR(e, fc)
         })
     }
 #undef SMGPU_PYR
-    if (fabs(vol) > SMGPU_VSMALL) ctr = ctr / vol;
+    if (fabs(vol) > SMGPU_VSMALL) ctr = divExact(ctr, vol);
     else ctr = cEst;
     stv(s.cellCtr, c, ctr);
 }
@@ -351,21 +428,50 @@ __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(M
     if (deferN > 0 && blockIdx.x == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
     const GeomLds L = geomLds(lds, g);
-    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
+    const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
+    const GeomTileMeta tm = loadTileMeta(g, tile);
+    const unsigned tflags = (unsigned)tm.flags;
+    const int nf = tm.nFaces;
+    // prologue: what the face and cell phases read from global memory per thread (vertex rows of the first two face rounds of a
+    // quadrilateral tile, the cell's id and face row) is requested here, in flight together with the point id list -- read
+    // where it is used, each of them put a memory latency in front of its phase (five dependent round trips per tile, now two)
+    // (the id list first: the point records depend on it, everything else only has to be there after the staging)
+    const int* ids = g.tpIds + tm.tpOff;
+    int id[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int i = u * T + tid; id[u] = (i < tm.nPts) ? ids[i] : -1; }
+    const bool preFaces = !ORG && (tflags & 1u);
+    ushort4 fq[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = u * T + tid;
+        fq[u] = (preFaces && i < nf) ? reinterpret_cast<const ushort4*>(g.faceVerts + tm.fvBase)[i] : make_ushort4(0, 0, 0, 0);
+    }
+    const GeomCellIn cin = geomCellLoad<T>(g, tm, tid, tflags);
     // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
     {
-        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
-        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, L.px, L.py, L.pz, tid);
+        V3 v[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) v[u] = (id[u] >= 0) ? ldv(s.ptsCur, id[u]) : v3(0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = u * T + tid;
+            if (id[u] >= 0) { L.px[kGP * i] = v[u].x; L.py[kGP * i] = v[u].y; L.pz[kGP * i] = v[u].z; }
+        }
+        if (tm.nPts > 2 * T) stageRecords<T, 2, kGP>(s.ptsCur, ids + 2 * T, tm.nPts - 2 * T, L.px + kGP * 2 * T, L.py + kGP * 2 * T, L.pz + kGP * 2 * T, tid);
     }
     if (stopped) return;
     __syncthreads();
     // phase 1: every face of the tile once
-    const unsigned tflags = g.tileFlags[tile];
-    const int nf = g.tfOff[tile + 1] - g.tfOff[tile];
-    for (int i = tid; i < nf; i += T) geomFace<ORG>(s, g, L, tile, i, tflags, wantAvg, writeFaces);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = u * T + tid;
+        if (i < nf) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces, preFaces, fq[u]);
+    }
+    for (int i = 2 * T + tid; i < nf; i += T) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces);
     __syncthreads();
     // phase 2: one thread per cell
-    geomCell<T, ORG>(s, g, L, tile, tid, tflags);
+    geomCell<T, ORG>(s, g, L, tm, tid, tflags, cin);
 }
 
 // The fused per-point proposal kernel of kernels.hpp (k_smooth) with the cell centres and neighbour

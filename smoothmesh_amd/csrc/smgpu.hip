@@ -456,6 +456,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &g.cfWidth, h->gt.cfWidth);
             rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
             rc |= devUpload(h, &g.tileFlags, h->gt.tileFlags);
+            {   // the per-tile scalars once more, one record per tile (GeomTileMeta: scalar loads in the kernel)
+                const auto& gt = h->gt;
+                std::vector<int> meta((size_t)kGeomMetaInts * (size_t)gt.nTiles, 0);
+                for (int t = 0; t < gt.nTiles; ++t) {
+                    int* r = meta.data() + (size_t)kGeomMetaInts * t;
+                    r[0] = gt.tpOff[t]; r[1] = gt.tpOff[t + 1] - gt.tpOff[t]; r[2] = gt.tfOff[t]; r[3] = gt.tfOff[t + 1] - gt.tfOff[t];
+                    r[4] = gt.fvBase[t]; r[5] = gt.fvWidth[t]; r[6] = gt.cellBeg[t]; r[7] = gt.cellBeg[t + 1] - gt.cellBeg[t];
+                    r[8] = gt.cfBase[t]; r[9] = gt.cfWidth[t]; r[10] = gt.tileFlags[t];
+                }
+                rc |= devUpload(h, &g.meta, meta);
+            }
             g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
             rc |= devUpload(h, &v.ptOrder, h->stl.order);
             rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
@@ -633,6 +644,76 @@ int smgpu_mesh_stats(smgpu_handle* h, double* minEdge, double* maxEdge) {
     HIP_OK(hipStreamSynchronize(h->stream));
     std::memcpy(minEdge, &out[0], 8);
     std::memcpy(maxEdge, &out[1], 8);
+    return 0;
+}
+
+namespace smgpu {
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// argument j of case i: by case class random moderate values, raw bit patterns, specials, values at the range tests' edges
+__device__ __forceinline__ double selftestArg(uint64_t seed, long i, int j) {
+    const uint64_t r = mix64(seed + 8ull * (uint64_t)i + (uint64_t)j);
+    const uint64_t mant = r & 0xFFFFFFFFFFFFFull, sign = r >> 63;
+    const unsigned pick = (unsigned)((r >> 52) & 0x7ff);
+    uint64_t expo;
+    switch ((i + (j == 3 ? 0 : 0)) & 7) {
+        case 0: case 1: case 2: expo = 1023 - 40 + pick % 80; break;                     // moderate
+        case 3: return __longlong_as_double((long long)r);                                // any bit pattern
+        case 4: {                                                                          // zeros, denormals, inf, nan, tiny
+            const unsigned k = pick % 6;
+            if (k == 0) return sign ? -0.0 : 0.0;
+            if (k == 1) return __longlong_as_double((long long)((sign << 63) | mant));    // denormal
+            if (k == 2) return __longlong_as_double((long long)((sign << 63) | (0x7ffull << 52)));
+            if (k == 3) return __longlong_as_double((long long)((0x7ffull << 52) | mant | 1));
+            expo = 1 + pick % 60; break;
+        }
+        case 5: {                                                                          // the edges of the range tests
+            const unsigned edges[6] = {1023 - 767, 1023 - 250, 1023 + 250, 2046, 1, 1023 - 969};
+            expo = edges[pick % 6] + (pick / 6) % 5 - 2;
+            if ((long long)expo < 1) expo = 1;
+            if (expo > 2046) expo = 2046;
+            break;
+        }
+        case 6: expo = 1 + pick % 2046; break;                                             // any exponent
+        default: expo = 1023 - 300 + pick % 600; break;
+    }
+    const uint64_t sgn = (j == 0 && (i & 8)) ? 0 : sign;                                   // the sqrt argument: mostly positive
+    return __longlong_as_double((long long)((sgn << 63) | (expo << 52) | mant));
+}
+__device__ __forceinline__ bool sameBits(double a, double b) { return (a != a && b != b) || __double_as_longlong(a) == __double_as_longlong(b); }
+__global__ void k_selftest_fpexact(uint64_t seed, long n, unsigned long long* bad) {
+    unsigned long long mine = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const double x = selftestArg(seed, i, 0), y = selftestArg(seed, i, 1), z = selftestArg(seed, i, 2), w = selftestArg(seed, i, 3);
+        if (!sameBits(sqrtExact(x), sqrt(x))) ++mine;
+        double a0, a1, a2, a3;
+        sqrtExact4(fabs(x), fabs(y), z, fabs(w), a0, a1, a2, a3);
+        if (!sameBits(a0, sqrt(fabs(x))) || !sameBits(a1, sqrt(fabs(y))) || !sameBits(a2, sqrt(z)) || !sameBits(a3, sqrt(fabs(w)))) ++mine;
+        const V3 q = divExact(v3(x, y, z), w);
+        if (!sameBits(q.x, x / w) || !sameBits(q.y, y / w) || !sameBits(q.z, z / w)) ++mine;
+        const V3 q6 = divExact(v3(x, y, z), 6.0);
+        if (!sameBits(q6.x, x / 6.0) || !sameBits(q6.y, y / 6.0) || !sameBits(q6.z, z / 6.0)) ++mine;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+}  // namespace smgpu
+
+int smgpu_debug_selftest_fpexact(int32_t device, uint64_t seed, int64_t n, int64_t* mismatches) {
+    if (!mismatches || n < 0) return fail("smgpu_debug_selftest_fpexact: bad arguments");
+    if (hipSetDevice(device) != hipSuccess) return fail("smgpu_debug_selftest_fpexact: hipSetDevice failed");
+    unsigned long long* d = nullptr;
+    if (hipMalloc(&d, sizeof(*d)) != hipSuccess) return fail("smgpu_debug_selftest_fpexact: hipMalloc failed");
+    unsigned long long host = 0;
+    bool ok = hipMemset(d, 0, sizeof(*d)) == hipSuccess;
+    if (ok) {
+        hipLaunchKernelGGL(smgpu::k_selftest_fpexact, dim3(2048), dim3(256), 0, 0, seed, (long)n, d);
+        ok = hipGetLastError() == hipSuccess && hipMemcpy(&host, d, sizeof(host), hipMemcpyDeviceToHost) == hipSuccess;
+    }
+    (void)hipFree(d);
+    if (!ok) return fail("smgpu_debug_selftest_fpexact: launch failed");
+    *mismatches = (int64_t)host;
     return 0;
 }
 
