@@ -39,8 +39,19 @@ struct SmoothTileView {
     const int* ppBase; const uint8_t* ppWidth; const uint16_t* ppEll;   // bit 15: the neighbour is an internal point
     const uint16_t* pairEll;
     const int* pfBase; const uint8_t* pfWidth; const uint16_t* pfEll;   // (prev, next) vertex per (point, face)
+    const int* meta;             // the per-tile scalars of the arrays above, one record per tile (SmoothTileMeta)
     int maxCells, maxPoints, usePairShare;
 };
+
+struct SmoothTileMeta { int ptBeg, nPts, tcOff, nCells, tnOff, nNbrs, pcBase, pcWidth, ppBase, ppWidth, pfBase, pfWidth; };
+constexpr int kSmoothMetaInts = 12;
+__device__ __forceinline__ SmoothTileMeta loadTileMeta(const SmoothTileView& g, int tile) {
+    const_int_ptr p = (const_int_ptr)(g.meta + (size_t)kSmoothMetaInts * tile);
+    SmoothTileMeta t;
+    t.ptBeg = p[0]; t.nPts = p[1]; t.tcOff = p[2]; t.nCells = p[3]; t.tnOff = p[4]; t.nNbrs = p[5];
+    t.pcBase = p[6]; t.pcWidth = p[7]; t.ppBase = p[8]; t.ppWidth = p[9]; t.pfBase = p[10]; t.pfWidth = p[11];
+    return t;
+}
 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  With xcdMap the launch has 8*ceil(n/8)
 // workgroups and XCD x walks the contiguous range [x*ceil(n/8), ...) of the Morton-ordered tile sequence, so
@@ -488,50 +499,96 @@ __device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileView
     return L;
 }
 struct SmoothRow {
-    bool mine; int p, selfL, wn4, wc4;
+    bool mine; int p, selfL, wn4, wc4, slot;
+    unsigned fl;
     const ushort4 *ppRow, *pcRow;
     ushort4 pp0, pp1, pc0, pc1;
 };
+// Prologue of the kernels on smoothing tiles: the tile's cell centres and neighbour coordinates into LDS and the thread's own
+// inputs into registers, in TWO dependent memory round trips: (1) the id lists of both record sets, the thread's point id,
+// LDS slot and first two chunks of both ELL rows; (2) the records, the point's flags and its shared-point slot.  No branch
+// between the loads of a round (lanes without a point read the row of lane 0): conditional loads made the compiler wait for
+// each of them separately -- eight round trips per tile before.
 template <int T>
-__device__ __forceinline__ SmoothRow smoothRow(const SmoothTileView& g, int tile, int tid) {
+__device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State& s, const SmoothTileView& g, const SmoothTileMeta& tm,
+                                                 const SmoothLds& L, int tid) {
     SmoothRow r;
-    const int pi = g.ptBeg[tile] + tid;
-    r.mine = pi < g.ptBeg[tile + 1];
-    r.wn4 = g.ppWidth[tile] >> 2; r.wc4 = g.pcWidth[tile] >> 2;
-    r.ppRow = reinterpret_cast<const ushort4*>(g.ppEll + g.ppBase[tile]) + tid;
-    r.pcRow = reinterpret_cast<const ushort4*>(g.pcEll + g.pcBase[tile]) + tid;
+    r.mine = tid < tm.nPts;
+    r.wn4 = tm.ppWidth >> 2; r.wc4 = tm.pcWidth >> 2;
+    const int lane = r.mine ? tid : 0;
+    r.ppRow = reinterpret_cast<const ushort4*>(g.ppEll + tm.ppBase) + tid;
+    r.pcRow = reinterpret_cast<const ushort4*>(g.pcEll + tm.pcBase) + tid;
+    const bool fast = tm.nCells <= 2 * T && tm.nNbrs <= 3 * T && r.wn4 > 0 && r.wc4 > 0;
     const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
-    r.p = 0; r.selfL = 0;
+    if (fast) {
+        const int* ic = g.tcIds + tm.tcOff;
+        const int* in = g.tnIds + tm.tnOff;
+        int a[2], b[3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; a[u] = (i < tm.nCells) ? ic[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = u * T + tid; b[u] = (i < tm.nNbrs) ? in[i] : -1; }
+        const int pi = tm.ptBeg + lane;
+        const int p = g.ptOrder[pi];
+        const int selfL = g.selfLoc[pi];
+        const ushort4* ppl = reinterpret_cast<const ushort4*>(g.ppEll + tm.ppBase) + lane;
+        const ushort4* pcl = reinterpret_cast<const ushort4*>(g.pcEll + tm.pcBase) + lane;
+        const ushort4 pp0 = ppl[0], pp1 = ppl[r.wn4 > 1 ? T : 0], pc0 = pcl[0], pc1 = pcl[r.wc4 > 1 ? T : 0];
+        // round 2
+        V3 va[2], vb[3];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) va[u] = (a[u] >= 0) ? ldv(s.cellCtr, a[u]) : v3(0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) vb[u] = (b[u] >= 0) ? ldv(s.ptsCur, b[u]) : v3(0, 0, 0);
+        const unsigned fl = m.pflags[p];
+        const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; if (a[u] >= 0) { L.cx[i] = va[u].x; L.cy[i] = va[u].y; L.cz[i] = va[u].z; } }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = u * T + tid; if (b[u] >= 0) { L.nx[i] = vb[u].x; L.ny[i] = vb[u].y; L.nz[i] = vb[u].z; } }
+        r.p = r.mine ? p : 0; r.selfL = r.mine ? selfL : 0;
+        r.fl = fl; r.slot = r.mine ? slot : -1;
+        r.pp0 = r.mine ? pp0 : padq; r.pp1 = (r.mine && r.wn4 > 1) ? pp1 : padq;
+        r.pc0 = r.mine ? pc0 : padq; r.pc1 = (r.mine && r.wc4 > 1) ? pc1 : padq;
+        return r;
+    }
+    // tiles beyond the fixed number of staging rounds (or with empty rows): set by set
+    r.p = 0; r.selfL = 0; r.fl = 0; r.slot = -1;
     r.pp0 = padq; r.pp1 = padq; r.pc0 = padq; r.pc1 = padq;
     if (r.mine) {
+        const int pi = tm.ptBeg + tid;
         r.p = g.ptOrder[pi];
         r.selfL = g.selfLoc[pi];
         if (r.wn4 > 0) r.pp0 = r.ppRow[0];
         if (r.wn4 > 1) r.pp1 = r.ppRow[T];
         if (r.wc4 > 0) r.pc0 = r.pcRow[0];
         if (r.wc4 > 1) r.pc1 = r.pcRow[T];
+        r.fl = m.pflags[r.p];
+        r.slot = s.sharedSlot ? s.sharedSlot[r.p] : -1;
     }
+    stageRecords<T, 2>(s.cellCtr, g.tcIds + tm.tcOff, tm.nCells, L.cx, L.cy, L.cz, tid);
+    stageRecords<T, 3>(s.ptsCur, g.tnIds + tm.tnOff, tm.nNbrs, L.nx, L.ny, L.nz, tid);
     return r;
 }
 
 // the thread's point of the tile, from the staged cell centres / neighbour coordinates (see k_smooth for the steps)
 template <bool FINAL, int T>
 __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, const Prm& prm, const SmoothTileView& g, const SmoothLds& L,
-                                            const SmoothRow& R, int tile, int tid, double& dist, int& fcount) {
+                                            const SmoothRow& R, const SmoothTileMeta& tm, int tid, double& dist, int& fcount) {
     const double *cx = L.cx, *cy = L.cy, *cz = L.cz, *nx = L.nx, *ny = L.ny, *nz = L.nz;
     const bool mine = R.mine;
     const int p = R.p, selfL = R.selfL, wn4 = R.wn4, wc4 = R.wc4;
     const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
     const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
     if (mine) {
-        const uint8_t fl = m.pflags[p];
+        const unsigned fl = R.fl;
         const bool internal = fl & PF_INTERNAL;
         const V3 cur = ldsv(nx, ny, nz, selfL);
         V3 sum = v3(0, 0, 0), r1, r2, r3;
         double m1 = 0.0, m2 = 0.0, m3 = 0.0;   // mag(closestPoint1..3), SM.C:509-510
         int count = 0, hc = 0;
         double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
-        const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
+        const int slot = R.slot;
         if (slot >= 0) {
             const int cb = s.inlineCombine ? s.combOff[slot] : 0;
             if (s.inlineCombine && s.combOff[slot + 1] - cb == 2) {
@@ -580,7 +637,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
                 r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
                 m1 = l1; m2 = l2; m3 = (k3 < 0) ? mag(r3) : l3;
                 if (g.usePairShare) {
-                    const uint16_t* pe = g.pairEll + g.ppBase[tile];
+                    const uint16_t* pe = g.pairEll + tm.ppBase;
                     hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
                 } else {
                     const int nb = m.ppOff[p];
@@ -648,20 +705,14 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     if (li < 0) return;
     extern __shared__ double lds[];
     const SmoothLds L = smoothLds(lds, g);
-    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
-    // everything a thread needs from global memory besides the staged records is requested first, so that
-    // its latency overlaps the staging
-    const SmoothRow R = smoothRow<T>(g, tile, tid);
-    {
-        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
-        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
-    }
+    const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
+    const SmoothTileMeta tm = loadTileMeta(g, tile);
+    const SmoothRow R = smoothStage<T>(m, s, g, tm, L, tid);
     if (stopped) return;
     __syncthreads();
     double dist = 0.0;
     int fcount = 0;
-    smoothPoint<FINAL, T>(m, s, prm, g, L, R, tile, tid, dist, fcount);
+    smoothPoint<FINAL, T>(m, s, prm, g, L, R, tm, tid, dist, fcount);
     if (FINAL) blockPublish<T>(s, dist, fcount, tile);
 }
 
@@ -681,23 +732,19 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
     if (li < 0) return;
     extern __shared__ double lds[];
     const SmoothLds L = smoothLds(lds, g);
-    const int tile = tileList ? tileList[li] : li, tid = threadIdx.x;
-    const SmoothRow R = smoothRow<T>(g, tile, tid);
-    {
-        const int b = g.tcOff[tile], n = g.tcOff[tile + 1] - b;
-        const int b2 = g.tnOff[tile], n2 = g.tnOff[tile + 1] - b2;
-        stageRecords2<T, 2, 3>(s.cellCtr, g.tcIds + b, n, L.cx, L.cy, L.cz, s.ptsCur, g.tnIds + b2, n2, L.nx, L.ny, L.nz, tid);
-    }
+    const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
+    const SmoothTileMeta tm = loadTileMeta(g, tile);
+    const SmoothRow R = smoothStage<T>(m, s, g, tm, L, tid);
     __syncthreads();
     if (!R.mine) return;
     const int p = R.p;
-    const int slot = s.sharedSlot[p];
+    const int slot = R.slot;
     if (slot < 0) return;
     const double *cx = L.cx, *cy = L.cy, *cz = L.cz, *nx = L.nx, *ny = L.ny, *nz = L.nz;
     const int wn4 = R.wn4, wc4 = R.wc4;
     const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
     const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
-    const bool internal = m.pflags[p] & PF_INTERNAL;
+    const bool internal = R.fl & PF_INTERNAL;
     const V3 cur = ldsv(nx, ny, nz, R.selfL);
     V3 sum = v3(0, 0, 0), r1, r2, r3;
     int count = 0, hc = 0;
@@ -724,7 +771,7 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
         r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
         r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
         if (g.usePairShare) {
-            const uint16_t* pe = g.pairEll + g.ppBase[tile];
+            const uint16_t* pe = g.pairEll + tm.ppBase;
             hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
         } else {
             const int nb = m.ppOff[p];

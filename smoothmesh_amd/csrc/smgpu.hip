@@ -484,6 +484,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             rc |= devUpload(h, &v.pairEll, h->stl.pairEll);
             rc |= devUpload(h, &v.pfBase, h->stl.pfBase);
             rc |= devUpload(h, &v.pfWidth, h->stl.pfWidth);
+            {   // SmoothTileMeta records
+                const auto& st = h->stl;
+                std::vector<int> meta((size_t)kSmoothMetaInts * (size_t)st.nTiles, 0);
+                for (int t = 0; t < st.nTiles; ++t) {
+                    int* r = meta.data() + (size_t)kSmoothMetaInts * t;
+                    r[0] = st.ptBeg[t]; r[1] = st.ptBeg[t + 1] - st.ptBeg[t]; r[2] = st.tcOff[t]; r[3] = st.tcOff[t + 1] - st.tcOff[t];
+                    r[4] = st.tnOff[t]; r[5] = st.tnOff[t + 1] - st.tnOff[t]; r[6] = st.pcBase[t]; r[7] = st.pcWidth[t];
+                    r[8] = st.ppBase[t]; r[9] = st.ppWidth[t]; r[10] = st.pfBase[t]; r[11] = st.pfWidth[t];
+                }
+                rc |= devUpload(h, &v.meta, meta);
+            }
             rc |= devUpload(h, &v.pfEll, h->stl.pfEll);
             v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
             v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
