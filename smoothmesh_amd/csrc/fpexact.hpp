@@ -12,6 +12,7 @@
 // arguments in tests/test_gpu_fpexact.py through smgpu_selftest_fpexact.
 #pragma once
 #include <hip/hip_runtime.h>
+#if defined(__HIP__)   // (the host-only translation units include vec3.hpp as plain C++)
 
 // 0: every call takes the plain operator (A/B builds)
 #ifndef SMGPU_FPEXACT_FAST
@@ -65,3 +66,4 @@ __device__ __forceinline__ double divCore(double a, const Recip& d) {
 }
 
 }  // namespace smgpu
+#endif  // __HIP__

@@ -145,37 +145,62 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
     float* nx = cz + g.maxPoints;   float* ny = nx + g.maxPoints; float* nz = ny + g.maxPoints;
     float* red = nz + g.maxPoints;
     const int tile = li, tid = threadIdx.x;
-    const int pi = g.ptBeg[tile] + tid;
-    const bool mine = pi < g.ptBeg[tile + 1];
-    const int wf4 = g.pfWidth[tile] >> 2;
-    const ushort4* row = reinterpret_cast<const ushort4*>(g.pfEll + g.pfBase[tile]) + tid;
-    const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
-    int p = 0, selfL = 0;
-    ushort4 q0 = padq, q1 = padq;
-    if (mine) {
-        p = g.ptOrder[pi];
-        selfL = g.selfLoc[pi];
-        if (wf4 > 0) q0 = row[0];
-        if (wf4 > 1) q1 = row[T];
+    // prologue in two dependent round trips, as in smoothStage: (1) id list, point id / slot, the first kEaPre chunks of the
+    // corner row (lanes without a point read lane 0's; chunks past the row's width read chunk 0); (2) current and proposed
+    // coordinates, the point's frozen flag.  The tile's origin (first point of its list) comes through scalar loads.
+    constexpr int kEaPre = 6;          // 12 faces per point (hexahedral meshes) = 24 entries
+    const SmoothTileMeta tm = loadTileMeta(g, tile);
+    const bool mine = tid < tm.nPts;
+    const int wf4 = tm.pfWidth >> 2;
+    const ushort4* row = reinterpret_cast<const ushort4*>(g.pfEll + tm.pfBase) + tid;
+    const int n = tm.nNbrs;
+    const int* ids = g.tnIds + tm.tnOff;
+    typedef const __attribute__((address_space(4))) double* const_dbl_ptr;
+    V3 O = v3(0, 0, 0);
+    if (n > 0) {
+        const int id0 = ((const_int_ptr)ids)[0];
+        const_dbl_ptr o = (const_dbl_ptr)(s.ptsCur + 3 * (size_t)id0);
+        O = v3(o[0], o[1], o[2]);
+    }
+    constexpr int R = 3;
+    int id[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) { const int i = u * T + tid; id[u] = (i < n) ? ids[i] : -1; }
+    const int lane = mine ? tid : 0;
+    const int pi = tm.ptBeg + lane;
+    int p = g.ptOrder[pi], selfL = g.selfLoc[pi];
+    ushort4 qs[kEaPre];
+    {
+        const ushort4* rl = reinterpret_cast<const ushort4*>(g.pfEll + tm.pfBase) + lane;
+#pragma unroll
+        for (int c = 0; c < kEaPre; ++c) qs[c] = rl[(size_t)(c < wf4 ? c : 0) * T];     // (rows have at least one chunk: tiles.cpp)
     }
     float r2 = 0.f;
     {
-        const int b = g.tnOff[tile], n = g.tnOff[tile + 1] - b;
-        const int* ids = g.tnIds + b;
-        const V3 O = (n > 0) ? ldv(s.ptsCur, ids[0]) : v3(0, 0, 0);
-        constexpr int R = 3;
-        for (int base = 0; base < n; base += T * R) {
-            int id[R];
+        V3 va[R], vb[R];
 #pragma unroll
-            for (int u = 0; u < R; ++u) { const int i = base + u * T + tid; id[u] = (i < n) ? ids[i] : -1; }
-            V3 va[R], vb[R];
+        for (int u = 0; u < R; ++u) { const int j = (id[u] >= 0) ? id[u] : p; va[u] = ldv(s.ptsCur, j); vb[u] = ldv(s.prop, j); }   // (no branch)
+        const uint8_t fz = s.frozen[p];
 #pragma unroll
-            for (int u = 0; u < R; ++u) { va[u] = (id[u] >= 0) ? ldv(s.ptsCur, id[u]) : O; vb[u] = (id[u] >= 0) ? ldv(s.prop, id[u]) : O; }
+        for (int u = 0; u < R; ++u) {
+            const int i = u * T + tid;
+            if (id[u] >= 0) {
+                const F3 a = f3(va[u] - O), c = f3(vb[u] - O);
+                cx[i] = a.x; cy[i] = a.y; cz[i] = a.z; nx[i] = c.x; ny[i] = c.y; nz[i] = c.z;
+                const float aa = fdot(a, a), cc = fdot(c, c);
+                r2 = aa > r2 ? aa : r2;
+                r2 = cc > r2 ? cc : r2;
+            }
+        }
+        for (int base = T * R; base < n; base += T * R) {        // tiles beyond the fixed number of rounds
+            int jd[R];
+#pragma unroll
+            for (int u = 0; u < R; ++u) { const int i = base + u * T + tid; jd[u] = (i < n) ? ids[i] : -1; }
 #pragma unroll
             for (int u = 0; u < R; ++u) {
                 const int i = base + u * T + tid;
-                if (id[u] >= 0) {
-                    const F3 a = f3(va[u] - O), c = f3(vb[u] - O);
+                if (jd[u] >= 0) {
+                    const F3 a = f3(ldv(s.ptsCur, jd[u]) - O), c = f3(ldv(s.prop, jd[u]) - O);
                     cx[i] = a.x; cy[i] = a.y; cz[i] = a.z; nx[i] = c.x; ny[i] = c.y; nz[i] = c.z;
                     const float aa = fdot(a, a), cc = fdot(c, c);
                     r2 = aa > r2 ? aa : r2;
@@ -183,10 +208,13 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
                 }
             }
         }
+        if (!mine) { p = 0; selfL = 0; }
+        selfL |= (int)fz << 16;                                   // carried across the barrier with the slot
     }
     r2 = blockMaxF<T>(r2, red);        // (also the barrier behind the staging)
     if (!mine) return;
-    if (s.frozen[p]) { eaMaybe[p] = 0; return; }
+    if (selfL >> 16) { eaMaybe[p] = 0; return; }
+    selfL &= 0xffff;
     const float p0x = nx[selfL], p0y = ny[selfL], p0z = nz[selfL];
     const float thr = cosSmall - kEaMargin;
     const float minN2 = kRelGuard * r2;
@@ -214,9 +242,10 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
         below = below && (d0.x < thr) && (d0.y < thr) && (d1.x < thr) && (d1.y < thr);                            \
         hx = ux; hy = uy; hz = uz; heldId = (int)(A2);                                                            \
     }
-    if (wf4 > 0) { SMGPU_EA_CORNER(q0.x, q0.y) SMGPU_EA_CORNER(q0.z, q0.w) }
-    if (wf4 > 1) { SMGPU_EA_CORNER(q1.x, q1.y) SMGPU_EA_CORNER(q1.z, q1.w) }
-    for (int c = 2; c < wf4; ++c) {
+#pragma unroll
+    for (int c = 0; c < kEaPre; ++c)
+        if (c < wf4) { SMGPU_EA_CORNER(qs[c].x, qs[c].y) SMGPU_EA_CORNER(qs[c].z, qs[c].w) }
+    for (int c = kEaPre; c < wf4; ++c) {
         const ushort4 q = row[(size_t)c * T];
         SMGPU_EA_CORNER(q.x, q.y) SMGPU_EA_CORNER(q.z, q.w)
     }
@@ -232,8 +261,18 @@ struct EdgeTileView {
     const uint16_t* epLoc;
     const int* efBase; const int* ecBase; const uint8_t* efWidth; const uint8_t* ecWidth;
     const uint16_t* efEll; const uint16_t* ecEll;
+    const int* meta;             // per-tile scalars, one record per tile (EdgeTileMeta)
     int maxPoints, maxFaces, maxCells;
 };
+struct EdgeTileMeta { int edgeBeg, nEdges, tpOff, nPts, tfOff, nFaces, tcOff, nCells, efBase, efWidth, ecBase, ecWidth; };
+constexpr int kEdgeMetaInts = 12;
+__device__ __forceinline__ EdgeTileMeta loadTileMeta(const EdgeTileView& g, int tile) {
+    const_int_ptr p = (const_int_ptr)(g.meta + (size_t)kEdgeMetaInts * tile);
+    EdgeTileMeta t;
+    t.edgeBeg = p[0]; t.nEdges = p[1]; t.tpOff = p[2]; t.nPts = p[3]; t.tfOff = p[4]; t.nFaces = p[5];
+    t.tcOff = p[6]; t.nCells = p[7]; t.efBase = p[8]; t.efWidth = p[9]; t.ecBase = p[10]; t.ecWidth = p[11];
+    return t;
+}
 
 // k_fa_edges_filter on edge tiles: the end points, the face vertex averages and the cell centres the tile's
 // edges need are staged in LDS (the per-edge form gathers ~10 records of 24 bytes per edge from global memory
@@ -248,29 +287,65 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
     double* fx = pz + g.maxPoints;    double* fy = fx + g.maxFaces;  double* fz = fy + g.maxFaces;
     double* cx = fz + g.maxFaces;     double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
     const int tile = li, tid = threadIdx.x;
-    const int ei = g.edgeBeg[tile] + tid;
-    const bool mine = ei < g.edgeBeg[tile + 1];
-    const int wf4 = g.efWidth[tile] >> 2, wc4 = g.ecWidth[tile] >> 2;
-    const ushort4* fRow = reinterpret_cast<const ushort4*>(g.efEll + g.efBase[tile]) + tid;
-    const ushort4* cRow = reinterpret_cast<const ushort4*>(g.ecEll + g.ecBase[tile]) + tid;
+    // prologue in two dependent round trips (see smoothStage): (1) the three id lists, the edge's id, end-point slots and the
+    // first two chunks of its face and cell rows; (2) the records
+    const EdgeTileMeta tm = loadTileMeta(g, tile);
+    const bool mine = tid < tm.nEdges;
+    const int wf4 = tm.efWidth >> 2, wc4 = tm.ecWidth >> 2;
+    const ushort4* fRow = reinterpret_cast<const ushort4*>(g.efEll + tm.efBase) + tid;
+    const ushort4* cRow = reinterpret_cast<const ushort4*>(g.ecEll + tm.ecBase) + tid;
     const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
     int e = 0;
     unsigned ep = 0;
     ushort4 f0 = padq, f1 = padq, c0 = padq, c1 = padq;
-    if (mine) {
-        e = g.order[ei];
-        ep = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
-        if (wf4 > 0) f0 = fRow[0];
-        if (wf4 > 1) f1 = fRow[T];
-        if (wc4 > 0) c0 = cRow[0];
-        if (wc4 > 1) c1 = cRow[T];
-    }
-    {
-        const int b = g.tpOff[tile], n = g.tpOff[tile + 1] - b;
-        const int b2 = g.tfOff[tile], n2 = g.tfOff[tile + 1] - b2;
-        const int b3 = g.tcOff[tile], n3 = g.tcOff[tile + 1] - b3;
-        stageRecords2<T, 3, 2>(s.fAvg, g.tfIds + b2, n2, fx, fy, fz, s.cellCtr, g.tcIds + b3, n3, cx, cy, cz, tid);
-        stageRecords<T, 2>(s.ptsCur, g.tpIds + b, n, px, py, pz, tid);
+    if (tm.nFaces <= 3 * T && tm.nCells <= 2 * T && tm.nPts <= 2 * T) {
+        const int *idF = g.tfIds + tm.tfOff, *idC = g.tcIds + tm.tcOff, *idP = g.tpIds + tm.tpOff;
+        int a[3], b[2], c[2];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = u * T + tid; a[u] = (i < tm.nFaces) ? idF[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; b[u] = (i < tm.nCells) ? idC[i] : -1; }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; c[u] = (i < tm.nPts) ? idP[i] : -1; }
+        const int lane = mine ? tid : 0;
+        const int ei = tm.edgeBeg + lane;
+        const int e1 = g.order[ei];
+        const unsigned ep1 = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
+        const ushort4* fl = reinterpret_cast<const ushort4*>(g.efEll + tm.efBase) + lane;
+        const ushort4* cl = reinterpret_cast<const ushort4*>(g.ecEll + tm.ecBase) + lane;
+        const ushort4 g0 = fl[0], g1 = fl[wf4 > 1 ? T : 0], h0 = cl[0], h1 = cl[wc4 > 1 ? T : 0];
+        V3 va[3], vb[2], vc[2];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) va[u] = ldv(s.fAvg, a[u] >= 0 ? a[u] : 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) vb[u] = ldv(s.cellCtr, b[u] >= 0 ? b[u] : 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) vc[u] = ldv(s.ptsCur, c[u] >= 0 ? c[u] : 0);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) { const int i = u * T + tid; if (a[u] >= 0) { fx[i] = va[u].x; fy[i] = va[u].y; fz[i] = va[u].z; } }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; if (b[u] >= 0) { cx[i] = vb[u].x; cy[i] = vb[u].y; cz[i] = vb[u].z; } }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const int i = u * T + tid; if (c[u] >= 0) { px[i] = vc[u].x; py[i] = vc[u].y; pz[i] = vc[u].z; } }
+        if (mine) {
+            e = e1; ep = ep1;
+            f0 = g0; c0 = h0;
+            if (wf4 > 1) f1 = g1;
+            if (wc4 > 1) c1 = h1;
+        }
+    } else {
+        if (mine) {
+            const int ei = tm.edgeBeg + tid;
+            e = g.order[ei];
+            ep = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
+            if (wf4 > 0) f0 = fRow[0];
+            if (wf4 > 1) f1 = fRow[T];
+            if (wc4 > 0) c0 = cRow[0];
+            if (wc4 > 1) c1 = cRow[T];
+        }
+        stageRecords<T, 3>(s.fAvg, g.tfIds + tm.tfOff, tm.nFaces, fx, fy, fz, tid);
+        stageRecords<T, 2>(s.cellCtr, g.tcIds + tm.tcOff, tm.nCells, cx, cy, cz, tid);
+        stageRecords<T, 2>(s.ptsCur, g.tpIds + tm.tpOff, tm.nPts, px, py, pz, tid);
     }
     __syncthreads();
     if (!mine) return;
@@ -314,7 +389,8 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         if (wf4 > 1) { SMGPU_FA_CHUNK(1, f1, c1) }
         for (int c = 2; c < wf4; ++c) {
             const ushort4 fq = fRow[(size_t)c * T];
-            const ushort4 cq = (c < wc4) ? cRow[(size_t)c * T] : padq;
+            const ushort4 cl_ = cRow[(size_t)(c < wc4 ? c : 0) * T];   // (a select between a global and a private address would become a flat load)
+            const ushort4 cq = (c < wc4) ? cl_ : padq;
             SMGPU_FA_CHUNK(c, fq, cq)
         }
         if (pend) { SMGPU_FA_EVAL(first) }   // closed ring: the last cell lies between the last and the first face

@@ -4,7 +4,6 @@
 // per lane per load), all indexed access is in LDS.
 #pragma once
 #include "kernels.hpp"
-#include "fpexact.hpp"
 
 namespace smgpu {
 
@@ -67,18 +66,6 @@ inline int tileGrid(int n, int xcdMap) { return xcdMap ? ((n + 7) >> 3) << 3 : n
 
 __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const double* z, int i) { return v3(x[i], y[i], z[i]); }
 
-// v / s (three IEEE divisions by one denominator) with the reciprocal's Newton iteration shared (fpexact.hpp); the plain
-// operator when an exponent is near the ends of the range or a numerator is zero / denormal
-__device__ __forceinline__ V3 divExact(const V3& v, double s) {
-    const unsigned hx = (unsigned)__double2hiint(v.x) & 0x7fffffffu, hy = (unsigned)__double2hiint(v.y) & 0x7fffffffu,
-                   hz = (unsigned)__double2hiint(v.z) & 0x7fffffffu, hs = (unsigned)__double2hiint(s) & 0x7fffffffu;
-    const unsigned lo = min(min(hx, hy), min(hz, hs)), hi = max(max(hx, hy), max(hz, hs));
-    if (SMGPU_FPEXACT_FAST && __builtin_expect(lo >= ((1023u - 250u) << 20) && hi < ((1023u + 250u) << 20), 1)) {
-        const Recip d = recipCore(s);
-        return v3(divCore(v.x, d), divCore(v.y, d), divCore(v.z, d));
-    }
-    return v / s;
-}
 // four square roots behind one range test
 __device__ __forceinline__ void sqrtExact4(double m0, double m1, double m2, double m3, double& a0, double& a1, double& a2, double& a3) {
     const unsigned h0 = (unsigned)__double2hiint(m0), h1 = (unsigned)__double2hiint(m1), h2 = (unsigned)__double2hiint(m2),

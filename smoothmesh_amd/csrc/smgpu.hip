@@ -525,6 +525,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     rc |= devUpload(h, &ev.ecWidth, h->etl.ecWidth);
                     rc |= devUpload(h, &ev.efEll, h->etl.efEll);
                     rc |= devUpload(h, &ev.ecEll, h->etl.ecEll);
+                    {   // EdgeTileMeta records
+                        const auto& et = h->etl;
+                        std::vector<int> meta((size_t)kEdgeMetaInts * (size_t)et.nTiles, 0);
+                        for (int ti = 0; ti < et.nTiles; ++ti) {
+                            int* r = meta.data() + (size_t)kEdgeMetaInts * ti;
+                            r[0] = et.edgeBeg[ti]; r[1] = et.edgeBeg[ti + 1] - et.edgeBeg[ti]; r[2] = et.tpOff[ti]; r[3] = et.tpOff[ti + 1] - et.tpOff[ti];
+                            r[4] = et.tfOff[ti]; r[5] = et.tfOff[ti + 1] - et.tfOff[ti]; r[6] = et.tcOff[ti]; r[7] = et.tcOff[ti + 1] - et.tcOff[ti];
+                            r[8] = et.efBase[ti]; r[9] = et.efWidth[ti]; r[10] = et.ecBase[ti]; r[11] = et.ecWidth[ti];
+                        }
+                        rc |= devUpload(h, &ev.meta, meta);
+                    }
                     ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
                     h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;

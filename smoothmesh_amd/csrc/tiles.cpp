@@ -5,7 +5,8 @@
 
 namespace smgpu {
 
-static inline int32_t roundUp4(int32_t v) { return (v + 3) & ~3; }
+// ELL row widths: multiples of 4 entries (one ushort4 chunk), at least one chunk so that kernels may read chunk 0 unconditionally
+static inline int32_t roundUp4(int32_t v) { return v <= 4 ? 4 : (v + 3) & ~3; }
 
 static inline uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
     v &= 0x1fffff;

@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "fpexact.hpp"
+
 namespace smgpu {
 
 #define SMGPU_HD __host__ __device__ __forceinline__
@@ -17,7 +19,27 @@ SMGPU_HD V3 operator+(const V3& a, const V3& b) { return v3(a.x + b.x, a.y + b.y
 SMGPU_HD V3 operator-(const V3& a, const V3& b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
 SMGPU_HD V3 operator*(double s, const V3& a) { return v3(s * a.x, s * a.y, s * a.z); }
 SMGPU_HD V3 operator*(const V3& a, double s) { return v3(a.x * s, a.y * s, a.z * s); }
-SMGPU_HD V3 operator/(const V3& a, double s) { return v3(a.x / s, a.y / s, a.z / s); }
+#if defined(__HIP__)
+// v / s on the device: three IEEE divisions by one denominator with the reciprocal's Newton iteration shared (fpexact.hpp),
+// the plain quotients when an exponent is near the ends of the range or a numerator is zero / denormal -- the same bits
+__device__ __forceinline__ V3 divExact(const V3& v, double s) {
+    const unsigned hx = (unsigned)__double2hiint(v.x) & 0x7fffffffu, hy = (unsigned)__double2hiint(v.y) & 0x7fffffffu,
+                   hz = (unsigned)__double2hiint(v.z) & 0x7fffffffu, hs = (unsigned)__double2hiint(s) & 0x7fffffffu;
+    const unsigned lo = min(min(hx, hy), min(hz, hs)), hi = max(max(hx, hy), max(hz, hs));
+    if (SMGPU_FPEXACT_FAST && __builtin_expect(lo >= ((1023u - 250u) << 20) && hi < ((1023u + 250u) << 20), 1)) {
+        const Recip d = recipCore(s);
+        return v3(divCore(v.x, d), divCore(v.y, d), divCore(v.z, d));
+    }
+    return v3(v.x / s, v.y / s, v.z / s);
+}
+#endif
+SMGPU_HD V3 operator/(const V3& a, double s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return divExact(a, s);
+#else
+    return v3(a.x / s, a.y / s, a.z / s);
+#endif
+}
 SMGPU_HD bool operator==(const V3& a, const V3& b) { return a.x == b.x && a.y == b.y && a.z == b.z; }
 SMGPU_HD bool operator!=(const V3& a, const V3& b) { return !(a == b); }
 SMGPU_HD double dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
@@ -25,7 +47,13 @@ SMGPU_HD V3 cross(const V3& a, const V3& b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 SMGPU_HD double magSqr(const V3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
-SMGPU_HD double mag(const V3& a) { return sqrt(magSqr(a)); }
+SMGPU_HD double mag(const V3& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return sqrtExact(magSqr(a));   // sqrt's bits, fpexact.hpp
+#else
+    return sqrt(magSqr(a));
+#endif
+}
 
 __device__ __forceinline__ V3 ldv(const double* __restrict__ base, int i) {
     const double* p = base + 3 * (size_t)i;
