@@ -110,6 +110,8 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
+    bool faExactOnSide = false;
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
@@ -412,6 +414,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
+    h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
@@ -1128,6 +1131,31 @@ static int nextFaGen(smgpu_handle* h, hipStream_t stream) {
     return 0;
 }
 
+static int ensureWalkBuffers(smgpu_handle* h);
+// The exact face angles of the CURRENT coordinates on what the filter left open (or on everything: faMaybe == NULL) and the
+// per-point minima / maxima with the good-range test (SM.C:938-975, 1367-1369).  Needs the current geometry only -- not the
+// proposals, not the edge-angle results -- so it follows the filter on the side stream when there is one.
+static int runFaExactPass(smgpu_handle* h, const State& s, const uint8_t* faMaybe, hipStream_t stream) {
+    const MeshView& m = h->mv;
+    const Prm prm = makePrm(h);
+    const int gP = gridFor(m.nPoints);
+    // lists pay when many points are outside the good range (the choice the walk makes once per parameter set: walkMode 0 =
+    // few); on a good mesh the filter leaves nothing open and two early-exit launches are cheaper than four
+    if (faMaybe && h->faLists && h->walkMode > 0) {
+        // exact evaluation on the lists of what the filter left open (kernels.hpp, k_fa_collect)
+        if (ensureWalkBuffers(h)) return 1;    // the block-count scratch of the walk compaction serves the listing first
+        if (launchK(h, K_FA_EDGES, [&] {
+                hipLaunchKernelGGL(k_fa_list_count, dim3(h->walkBlocks), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, stream, s, h->wv, h->walkBlocks, (const int*)nullptr, &h->st.acc->nFaPts);
+                hipLaunchKernelGGL(k_fa_list_fill, dim3(h->walkBlocks), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
+            }, stream)) return 1;
+        return launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, stream, m, s, prm); }, stream);
+    }
+    if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, stream, m, s, faMaybe); }, stream)) return 1;
+    return launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, stream, m, s, prm, faMaybe); }, stream);
+}
+
 // proposal (non-final) + constraint evaluators; leaves prop / frozen on the device
 // launch the face-angle filter (needs only the geometry of the current coordinates) on the side stream
 static int forkFaFilter(smgpu_handle* h) {
@@ -1141,6 +1169,8 @@ static int forkFaFilter(smgpu_handle* h) {
             hipLaunchKernelGGL(k_fa_filter_tile<256>, dim3(tileGrid(h->etl.nTiles, h->xcdMap)), dim3(256), h->edgeLds, h->side, s, prm, h->ev, m.edges, h->dFaMaybe,
                                h->etl.nTiles, h->xcdMap);
         }, h->side)) return 1;
+    h->faExactOnSide = h->faSideExact && h->walkMode >= 0;     // (the first pass of a parameter set decides walkMode after a sync: in order)
+    if (h->faExactOnSide && runFaExactPass(h, s, h->dFaMaybe, h->side)) return 1;
     if (depSignal(h, DEP_JOIN, h->side, h->evJoin)) return 1;
     h->faFilterInFlight = true;
     return 0;
@@ -1187,6 +1217,7 @@ static int runConstraints(smgpu_handle* h) {
             h->faFilterInFlight = false;
             faMaybe = h->dFaMaybe;
         } else if (filt) {
+            h->faExactOnSide = false;
             if (nextFaGen(h, h->stream)) return 1;
             s.faGen = h->st.faGen;
             if (launchK(h, K_FA_FILTER, [&] {
@@ -1198,25 +1229,12 @@ static int runConstraints(smgpu_handle* h) {
                 })) return 1;
             faMaybe = h->dFaMaybe;
         } else {   // no filter: every point gets a fresh mark from k_fa_points
+            h->faExactOnSide = false;
             if (nextFaGen(h, h->stream)) return 1;
             s.faGen = h->st.faGen;
         }
-        // lists pay when many points are outside the good range (the choice the walk makes once per parameter set: walkMode 0 =
-        // few); on a good mesh the filter leaves nothing open and two early-exit launches are cheaper than four
-        if (faMaybe && h->faLists && h->walkMode > 0) {
-            // exact evaluation on the lists of what the filter left open (kernels.hpp, k_fa_collect)
-            if (ensureWalkBuffers(h)) return 1;    // the block-count scratch of the walk compaction serves the listing first
-            if (launchK(h, K_FA_EDGES, [&] {
-                    hipLaunchKernelGGL(k_fa_list_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
-                    hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, h->wv, h->walkBlocks, (const int*)nullptr, &h->st.acc->nFaPts);
-                    hipLaunchKernelGGL(k_fa_list_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
-                    hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, h->stream, m, s);
-                })) return 1;
-            if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
-        } else {
-            if (launchK(h, K_FA_EDGES, [&] { hipLaunchKernelGGL(k_fa_edges, dim3(gridFor(m.nEdges)), dim3(kBlock), 0, h->stream, m, s, faMaybe); })) return 1;
-            if (launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm, faMaybe); })) return 1;
-        }
+        if (h->faExactOnSide) h->faExactOnSide = false;          // done behind the filter on the side stream
+        else if (runFaExactPass(h, s, faMaybe, h->stream)) return 1;
         if (h->walkMode < 0) {
             // decide once per parameter set: read how many points lie outside the good range now (one sync).  Few: the
             // one-wave replay over the full flag array (two launches); many: the fixed-point replay.  SMGPU_WALK = wave | host |

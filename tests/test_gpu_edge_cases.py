@@ -88,7 +88,8 @@ def test_natural_tile_order(oracle_lib, monkeypatch):
     _compare(hex_block(9, 7, 5, jitter=0.3, seed=2), oracle_lib)
 
 
-@pytest.mark.parametrize("env", [{"SMGPU_XCD_MAP": "0"}, {"SMGPU_WALK_STAR": "0"}, {"SMGPU_TILE_MORTON": "0"}])
+@pytest.mark.parametrize("env", [{"SMGPU_XCD_MAP": "0"}, {"SMGPU_WALK_STAR": "0"}, {"SMGPU_TILE_MORTON": "0"}, {"SMGPU_FA_SIDE_EXACT": "0"},
+                                 {"SMGPU_SIDE_STREAM": "0"}])
 def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
     """persistent / software-pipelined geometry and smoothing kernels, round-robin tile launch: tuning knobs, same bits;
     meshes large enough for several tiles per workgroup sequence, with quadrilateral-only and mixed tiles"""

@@ -19,7 +19,7 @@ def test_random_cases(seed):
 
 
 @pytest.mark.parametrize("env", [{"SMGPU_WALK": "fix"}, {"SMGPU_WALK": "fix", "SMGPU_WALK_STAR": "0", "SMGPU_WALK_BLOCKS": "7"},
-                                 {"SMGPU_WALK": "host"}, {"SMGPU_FA_LISTS": "0", "SMGPU_FILTER": "0"}])
+                                 {"SMGPU_WALK": "host"}, {"SMGPU_FA_LISTS": "0", "SMGPU_FILTER": "0"}, {"SMGPU_WALK": "fix", "SMGPU_FA_SIDE_EXACT": "0"}])
 def test_random_cases_under_walk_knobs(env):
     """the same sweep with the face-angle walk forced to the fixed-point device replay (also with the gather-form predicates and
     an odd number of workgroups in the persistent launch), to the host replay, and without filters / lists"""
