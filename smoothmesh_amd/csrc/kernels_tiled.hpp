@@ -490,7 +490,19 @@ struct SmoothRow {
     unsigned fl;
     const ushort4 *ppRow, *pcRow;
     ushort4 pp0, pp1, pc0, pc1;
+    ushort4 pe0, pe1;      // first two chunks of the common-cell bit row (pairEll), when usePairShare
 };
+// the common-cell bits of neighbour k (one bit per other neighbour), from the prologue's registers for the first 8 neighbours
+template <int T>
+__device__ __forceinline__ unsigned pairBits(const SmoothTileView& g, const SmoothTileMeta& tm, const SmoothRow& R, int tid, int k) {
+    if (k < 8) {
+        const ushort4 q = (k & 4) ? R.pe1 : R.pe0;
+        const unsigned lo = (k & 1) ? q.y : q.x, hi = (k & 1) ? q.w : q.z;
+        return (k & 2) ? hi : lo;
+    }
+    const uint16_t* pe = g.pairEll + tm.ppBase;
+    return pe[((size_t)(k >> 2) * T + tid) * 4 + (k & 3)];
+}
 // Prologue of the kernels on smoothing tiles: the tile's cell centres and neighbour coordinates into LDS and the thread's own
 // inputs into registers, in TWO dependent memory round trips: (1) the id lists of both record sets, the thread's point id,
 // LDS slot and first two chunks of both ELL rows; (2) the records, the point's flags and its shared-point slot.  No branch
@@ -521,6 +533,8 @@ __device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State&
         const ushort4* ppl = reinterpret_cast<const ushort4*>(g.ppEll + tm.ppBase) + lane;
         const ushort4* pcl = reinterpret_cast<const ushort4*>(g.pcEll + tm.pcBase) + lane;
         const ushort4 pp0 = ppl[0], pp1 = ppl[r.wn4 > 1 ? T : 0], pc0 = pcl[0], pc1 = pcl[r.wc4 > 1 ? T : 0];
+        const ushort4* pel = reinterpret_cast<const ushort4*>((g.usePairShare ? g.pairEll : g.ppEll) + tm.ppBase) + lane;
+        r.pe0 = pel[0]; r.pe1 = pel[r.wn4 > 1 ? T : 0];
         // round 2
         V3 va[2], vb[3];
 #pragma unroll
@@ -541,8 +555,13 @@ __device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State&
     }
     // tiles beyond the fixed number of staging rounds (or with empty rows): set by set
     r.p = 0; r.selfL = 0; r.fl = 0; r.slot = -1;
-    r.pp0 = padq; r.pp1 = padq; r.pc0 = padq; r.pc1 = padq;
+    r.pp0 = padq; r.pp1 = padq; r.pc0 = padq; r.pc1 = padq; r.pe0 = padq; r.pe1 = padq;
     if (r.mine) {
+        if (g.usePairShare) {
+            const ushort4* peRow = reinterpret_cast<const ushort4*>(g.pairEll + tm.ppBase) + tid;
+            if (r.wn4 > 0) r.pe0 = peRow[0];
+            if (r.wn4 > 1) r.pe1 = peRow[T];
+        }
         const int pi = tm.ptBeg + tid;
         r.p = g.ptOrder[pi];
         r.selfL = g.selfLoc[pi];
@@ -624,8 +643,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
                 r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
                 m1 = l1; m2 = l2; m3 = (k3 < 0) ? mag(r3) : l3;
                 if (g.usePairShare) {
-                    const uint16_t* pe = g.pairEll + tm.ppBase;
-                    hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
+                    hc = (pairBits<T>(g, tm, R, tid, k1) >> k2) & 1;
                 } else {
                     const int nb = m.ppOff[p];
                     hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
@@ -758,8 +776,7 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
         r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
         r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
         if (g.usePairShare) {
-            const uint16_t* pe = g.pairEll + tm.ppBase;
-            hc = (pe[((size_t)(k1 >> 2) * T + tid) * 4 + (k1 & 3)] >> k2) & 1;
+            hc = (pairBits<T>(g, tm, R, tid, k1) >> k2) & 1;
         } else {
             const int nb = m.ppOff[p];
             hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
