@@ -1051,6 +1051,36 @@ __device__ __forceinline__ void combineTwoSharers(const double* ra, const double
 
 constexpr int kMaxSharers = 16;
 
+// k_halo_combineA for the usual case (no point with more than 16 sharers): the two-sharer points from a per-point table of
+// the other rank's receive slot (bit 30: this rank is the lower one; -1: not a two-sharer point) -- offset -> slot -> record
+// was three dependent loads, this is two -- and the points with more sharers in the trailing workgroups.  No per-sharer
+// arrays here, so the kernel needs no scratch memory.
+__device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
+                                             const double* ownA, const double* recvA, double* combA);
+__global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+                                                           const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
+                                                           const int* multiIdx, const int* multiSlots) {
+    if ((int)blockIdx.x >= nBlocksTwo) {
+        combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
+        return;
+    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= nShared) return;
+    const int pr = peer[i];
+    if (pr < 0) return;
+    const double* ra = ownA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+    const double* rb = recvA + (size_t)(pr & 0x3fffffff) * SMGPU_HALO_A_DOUBLES;
+    V3 sum, a1, a2, a3;
+    int cnt, any2;
+    combineTwoSharers(ra, rb, (pr & 0x40000000) != 0, sum, a1, a2, a3, cnt, any2);
+    double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
+    o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+    o[3] = a1.x; o[4] = a1.y; o[5] = a1.z;
+    o[6] = a2.x; o[7] = a2.y; o[8] = a2.z;
+    o[9] = a3.x; o[10] = a3.y; o[11] = a3.z;
+    o[12] = __longlong_as_double(((long long)any2 << 32) | (long long)(unsigned int)cnt);
+}
+
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
 // plusEqOp in ascending rank order; minMagSqrEqOp folds from the own value (ties keep own).
 // Points with more than two sharers (processor edges and corners: few) are left to combineMulti when skipMulti
@@ -1147,18 +1177,16 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
 // load instead of the multiIdx -> combOff -> combSlots chain: this part is a handful of workgroups and latency bound)
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
                                              const double* ownA, const double* recvA, double* combA) {
-    __shared__ double shx[kBlock], shy[kBlock], shz[kBlock];
-    __shared__ int shi[kBlock];
-    const int t = threadIdx.x, g = (blk * kBlock + t) >> 4, j = t & 15, base = t & ~15;
+    // 16 lanes per point, lane j = sharer j (ascending rank); the sharers' values travel by shuffles within the group -- no
+    // LDS, no workgroup barriers (the LDS form spent most of the launch in its ten barriers)
+    const int t = threadIdx.x, g = (blk * kBlock + t) >> 4, j = t & 15, base = t & 48;      // base: the group's first lane in the wave
     const bool live = g < nMulti;
     const int sl = live ? multiSlots[g * 16 + j] : -2;
     const int i = live ? multiIdx[g] : 0;
     const bool mine = sl > -2;
-    shi[t] = mine ? j + 1 : 0;
-    __syncthreads();
-    int n = 0;                                  // sharers occupy the first n lanes of the group
-    for (int k = 0; k < 16; ++k) n = shi[base + k] > n ? shi[base + k] : n;
-    const double* r = (mine && sl < 0) ? ownA + (size_t)i * SMGPU_HALO_A_DOUBLES : recvA + (size_t)sl * SMGPU_HALO_A_DOUBLES;
+    const unsigned long long bal = __ballot(mine);
+    const int n = __popcll((bal >> base) & 0xffffull);      // sharers occupy the first n lanes of the group
+    const double* r = (mine && sl < 0) ? ownA + (size_t)i * SMGPU_HALO_A_DOUBLES : recvA + (size_t)(mine ? sl : 0) * SMGPU_HALO_A_DOUBLES;
     V3 sv0 = v3(0, 0, 0), r1 = sv0, r2 = sv0, r3 = sv0;
     int cntJ = 0, hc = 0;
     if (mine) {
@@ -1168,19 +1196,18 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
         cntJ = (int)(pk & 0xffffffffll);
         hc = (int)(pk >> 32);
     }
-#define SMGPU_PUBLISH(V, I) { __syncthreads(); shx[t] = (V).x; shy[t] = (V).y; shz[t] = (V).z; shi[t] = (I); __syncthreads(); }
+#define SMGPU_FROM(V, K) v3(__shfl((V).x, base + (K), 64), __shfl((V).y, base + (K), 64), __shfl((V).z, base + (K), 64))
     // plusEqOp in ascending rank order (every lane forms the same sum), count
-    SMGPU_PUBLISH(sv0, cntJ)
     V3 sum = v3(0, 0, 0);
     int cnt = 0;
-    for (int k = 0; k < n; ++k) { sum = sum + v3(shx[base + k], shy[base + k], shz[base + k]); cnt += shi[base + k]; }
+    for (int k = 0; k < n; ++k) { sum = sum + SMGPU_FROM(sv0, k); cnt += __shfl(cntJ, base + k, 64); }
     // minMagSqrEqOp folded from the own value over the others in ascending rank order
 #define SMGPU_FOLD_ALL(SENT, OUT)                                                          \
     {                                                                                      \
-        SMGPU_PUBLISH(SENT, 0)                                                             \
-        V3 x_ = (SENT);                                                                    \
+        const V3 sent_ = (SENT);                                                           \
+        V3 x_ = sent_;                                                                     \
         for (int k = 0; k < n; ++k) {                                                      \
-            const V3 y_ = v3(shx[base + k], shy[base + k], shz[base + k]);                 \
+            const V3 y_ = SMGPU_FROM(sent_, k);                                            \
             if (k != j) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;                         \
         }                                                                                  \
         (OUT) = x_;                                                                        \
@@ -1193,10 +1220,9 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
     SMGPU_FOLD_ALL(r3, sv)                       // SM.C:450-469
     if (mine && isCloserPoint(sv, r3)) r3 = sv;
 #undef SMGPU_FOLD_ALL
-    SMGPU_PUBLISH(sv0, hc)                       // SM.C:472-478
-#undef SMGPU_PUBLISH
-    int any = 0;
-    for (int k = 0; k < n; ++k) any |= shi[base + k];
+#undef SMGPU_FROM
+    int any = 0;                                 // SM.C:472-478
+    for (int k = 0; k < n; ++k) any |= __shfl(hc, base + k, 64);
     if (mine && sl < 0) {
         double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;

@@ -74,6 +74,7 @@ struct smgpu_handle {
     double *dOwnA = nullptr, *dCombA = nullptr;
     double *sendA = nullptr, *recvA = nullptr;
     int* dMultiSlots = nullptr;          // 16 per listed point: recv slot of each sharer, -1 this rank, -2 none
+    int* dPeer = nullptr;                // two-sharer points: the other rank's receive slot | selfFirst << 30 (k_halo_combineA2)
     int* dMultiIdx = nullptr;            // shared points with 3..16 sharers (combineMulti, the trailing workgroups of k_halo_combineA)
     int nMulti = 0;
     double *dOwnL = nullptr, *dCombL = nullptr, *sendL = nullptr, *recvL = nullptr;   // boundary layer treatment under -parallel
@@ -1510,6 +1511,19 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             h->dMultiIdx = (int*)pm;
             h->dMultiSlots = (int*)ps;
             h->nMulti = (int)multi.size() - 1;
+            // two-sharer points: the other rank's receive slot (k_halo_combineA2)
+            std::vector<int> peer((size_t)d->nShared + 1, -1);
+            for (int i = 0; i < d->nShared; ++i) {
+                const int b = combOff[(size_t)i];
+                if (combOff[(size_t)i + 1] - b != 2) continue;
+                const int s0 = combSlots[(size_t)b], s1 = combSlots[(size_t)b + 1];
+                const int other = s0 < 0 ? s1 : s0;
+                if (other >= 0 && other < 0x40000000) peer[(size_t)i] = other | (s0 < 0 ? 0x40000000 : 0);
+                else { h->dMultiIdx = nullptr; break; }      // (cannot happen: a two-sharer point has exactly one own entry)
+            }
+            const int* pp = nullptr;
+            if (devUpload(h, &pp, peer)) return 1;
+            h->dPeer = (int*)pp;
         }
     }
     if (h->layersOn) return fail("smgpu_halo_configure after the boundary layer set-up: configure the halo first");
@@ -1561,7 +1575,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     // dependent loads (offset -> slot -> record) and stalls whole waves of the smoothing kernel (47 -> 59 us), which costs more
     // than the two small launches it removes.  Off by default (SMGPU_HALO_INLINE=1 selects it; results are the same).
     h->st.inlineCombine = (h->useTiles && h->dMultiIdx && envInt("SMGPU_HALO_INLINE", 0)) ? 1 : 0;
-    h->st.inlinePackF = h->st.inlineCombine;
+    h->st.inlinePackF = (h->st.inlineCombine || (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0))) ? 1 : 0;
     h->packTiles = envInt("SMGPU_PACK_TILES", 1) != 0;
     if (h->useTiles) {
         ensureDynLds(k_pack_tile<64>, h->device, h->smoothLds);
@@ -1658,7 +1672,10 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (launchK(h, K_HALO, [&] {
                 // (with inlineCombine only the workgroups of the points with more than two sharers: the others are the smoothing kernel's)
                 const int nTwo = h->st.inlineCombine ? 0 : gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
-                if (nTwo + nMultiBlocks > 0)
+                if (nTwo + nMultiBlocks > 0 && h->dMultiIdx && h->dPeer)
+                    hipLaunchKernelGGL(k_halo_combineA2, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA, h->recvA, h->dCombA,
+                                       nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
+                else if (nTwo + nMultiBlocks > 0)
                     hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
                                        h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
                 if (h->layersOn || h->bndOn)

@@ -229,6 +229,33 @@ class DistributedSmoother:
         if self.probe_slots:
             z = lambda shape, dt: (torch.zeros(shape, dtype=dt, device=torch_device), torch.zeros(shape, dtype=dt, device=torch_device))
             self._probe = {torch.float64: z((self.probe_slots, A_DOUBLES), torch.float64), torch.int32: z((self.probe_slots,), torch.int32)}
+        self.direct = self._open_direct(engine_factory is None)
+
+    def _open_direct(self, own_engine):
+        """grouped ncclSend / ncclRecv on the engine's stream for the per-iteration exchanges (rccl_direct.py) when the process
+        group is RCCL and every rank's self-check against all_to_all_single passes; None = the torch collective"""
+        import os
+        torch, dist = self.torch, self.dist
+        if not own_engine or dist.get_backend() != "nccl" or self.device.type != "cuda" or os.environ.get("SMOOTHMESH_EXCHANGE", "rccl") == "torch":
+            return None
+        if self.world == 1 and not self.probe_slots:
+            return None
+        from . import rccl_direct
+        try:
+            rccl_direct._find_library(torch)
+            have = 1
+        except OSError:
+            have = 0
+        flag = torch.tensor([have], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if not int(flag.item()):
+            return None
+        d = rccl_direct.RcclDirect(torch, dist, self.device)
+        counts = [self.probe_slots] if self.world == 1 else self.counts
+        if not d.self_check(counts, self.device):
+            d.close()
+            return None
+        return d
 
     def global_min_edge(self):
         """getMeshStats + returnReduce(minOp), SM.C:1527"""
@@ -318,6 +345,9 @@ class DistributedSmoother:
             r = self.torch.empty_like(recv[:n], device="cpu")
             self.dist.all_to_all_single(r, send[:n].cpu(), counts, counts)
             recv[:n].copy_(r)
+        elif n and self.direct is not None:
+            self.direct.exchange(recv.data_ptr(), send.data_ptr(), counts, (recv.numel() // recv.shape[0]) * recv.element_size(),
+                                 self.torch.cuda.current_stream(self.device).cuda_stream)
         elif n:
             self.dist.all_to_all_single(recv[:n], send[:n], counts, counts)
         if overlap:
