@@ -171,3 +171,16 @@ def test_single_rank_distributed_history_equals_serial(oracle_lib, overlap):
         assert np.array_equal(ds.get_points(), eng.get_points())
     finally:
         dist.destroy_process_group()
+
+
+def test_direct_rccl_exchange_of_the_python_driver():
+    """grouped ncclSend / ncclRecv on the engine's stream (rccl_direct.py): communicator beside torch's, start-up self-check,
+    same results as the serial loop (scripts/check_direct_exchange.py; one rank -- the box has one GPU)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_direct_exchange.py")], capture_output=True, text=True,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "direct exchange: ok" in r.stdout
