@@ -951,10 +951,14 @@ __global__ void __launch_bounds__(kBlock) k_halo_packA(MeshView m, State s, cons
 // (layout in include/smgpu.h): local normal and outer neighbour coordinates (UNDEF_VECTOR when the neighbour is not in this
 // rank, OBB.C:474-478); with boundary point smoothing also the local face count, the inner neighbour's coordinates and the
 // local feature edge projections (bf* / inner / feat* = the boundary tables of kernels_boundary.hpp, or null).
-__global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* sharedLocal, double* ownL, int nShared, const int* sendOff,
-                                                        const int* sendSlots, double* sendL, const int* bfOff, const int* inner,
-                                                        const int* featOfBnd, const double* featSum, const int* featCnt) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+struct PackLArgs {
+    const int* sharedLocal; double* ownL; int nShared; const int* sendOff; const int* sendSlots; double* sendL;
+    const int* bfOff; const int* inner; const int* featOfBnd; const double* featSum; const int* featCnt;
+};
+__device__ __forceinline__ void haloPackLOf(const State& s, const PackLArgs& a, int i) {
+    const int* sharedLocal = a.sharedLocal; double* ownL = a.ownL; const int nShared = a.nShared;
+    const int *sendOff = a.sendOff, *sendSlots = a.sendSlots; double* sendL = a.sendL;
+    const int *bfOff = a.bfOff, *inner = a.inner, *featOfBnd = a.featOfBnd; const double* featSum = a.featSum; const int* featCnt = a.featCnt;
     if (i >= nShared) return;
     const int p = sharedLocal[i];
     const int q = s.layerMap ? s.layerMap[p] : -1;
@@ -978,11 +982,11 @@ __global__ void __launch_bounds__(kBlock) k_halo_packL(State s, const int* share
         for (int j = 0; j < w; ++j) d[j] = rec[j];
     }
 }
+__global__ void __launch_bounds__(kBlock) k_halo_packL(State s, PackLArgs a) { haloPackLOf(s, a, blockIdx.x * kBlock + threadIdx.x); }
 // plusEq in ascending rank order for the normals, face counts and feature projections (OBB.C:184-198, BPS.C:659-674);
 // minMagSqrEqOp folded from the own value for the outer and inner neighbour coordinates (OBB.C:490-496)
-__global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
-                                                          const double* recvL, double* combL, int w) {
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* combOff, const int* combSlots, const double* ownL,
+                                               const double* recvL, double* combL, int w) {
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
     const double* own = ownL + (size_t)i * w;
@@ -1008,6 +1012,10 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int
     double* o = combL + (size_t)i * w;
     o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = x.x; o[4] = x.y; o[5] = x.z;
     if (wide) { o[6] = faces; o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt; }
+}
+__global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
+                                                          const double* recvL, double* combL, int w) {
+    haloCombineLOf(blockIdx.x * kBlock + threadIdx.x, nShared, combOff, combSlots, ownL, recvL, combL, w);
 }
 
 // SM.C:246-272 isCloserPoint
@@ -1057,14 +1065,14 @@ constexpr int kMaxSharers = 16;
 // arrays here, so the kernel needs no scratch memory.
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
                                              const double* ownA, const double* recvA, double* combA);
-__global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
-                                                           const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
-                                                           const int* multiIdx, const int* multiSlots) {
-    if ((int)blockIdx.x >= nBlocksTwo) {
-        combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
+__device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+                                                const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
+                                                const int* multiIdx, const int* multiSlots) {
+    if (bx >= nBlocksTwo) {
+        combineMulti(bx - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
         return;
     }
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    const int i = bx * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int pr = peer[i];
     if (pr < 0) return;
@@ -1079,6 +1087,11 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const in
     o[6] = a2.x; o[7] = a2.y; o[8] = a2.z;
     o[9] = a3.x; o[10] = a3.y; o[11] = a3.z;
     o[12] = __longlong_as_double(((long long)any2 << 32) | (long long)(unsigned int)cnt);
+}
+__global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+                                                           const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
+                                                           const int* multiIdx, const int* multiSlots) {
+    haloCombineA2Of((int)blockIdx.x, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots);
 }
 
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):

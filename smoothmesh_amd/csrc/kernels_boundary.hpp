@@ -77,9 +77,8 @@ __device__ __forceinline__ V3 faceAreaOf(const MeshView& m, const double* __rest
 // calculateBoundaryPointNormals OBB.C:141-233 for the boundary points.  The reference never resets pointNormals: the
 // new normal is the normalised sum of the previous (unit) normal and the inverted unit normals of the point's
 // boundary faces.  (Internal points keep copies made at set-up; layerTreat re-normalises those.)
-__global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, BndView b) {
+__device__ __forceinline__ void bndNormalsOf(const MeshView& m, const State& s, const BndView& b, int i) {
     if (s.acc->stop) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= b.nB) return;
     const int p = b.pts[i];
     V3 n = ldv(s.layerNormal, p);
@@ -100,11 +99,11 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, Bnd
     if (n != v3(0, 0, 0)) n = n / mag(n);
     stv(s.layerNormal, p, n);
 }
+__global__ void __launch_bounds__(kBlock) k_bnd_normals(MeshView m, State s, BndView b) { bndNormalsOf(m, s, b, blockIdx.x * kBlock + threadIdx.x); }
 
 // OBB.C:201-230 for the shared boundary points, on the sums over the sharers (combL: normal [0:3], face count [6])
-__global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView b, int nShared, const int* sharedLocal) {
+__device__ __forceinline__ void bndNormalsSharedOf(const State& s, const BndView& b, int nShared, const int* sharedLocal, int i) {
     if (s.acc->stop) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     const int bi = s.bndOfShared[i];
     if (bi < 0) return;
@@ -118,6 +117,22 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView 
     }
     if (n != v3(0, 0, 0)) n = n / mag(n);
     stv(s.layerNormal, sharedLocal[i], n);
+}
+__global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView b, int nShared, const int* sharedLocal) {
+    bndNormalsSharedOf(s, b, nShared, sharedLocal, blockIdx.x * kBlock + threadIdx.x);
+}
+// exchange A's combine (k_halo_combineA2) and, in the workgroups after its nA, exchange L's (k_halo_combineL) followed for the
+// same point by OBB.C:201-230 (k_bnd_normals_shared) -- three launch-latency-bound launches in one
+__global__ void __launch_bounds__(kBlock) k_halo_combineAL(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+                                                           const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
+                                                           const int* multiIdx, const int* multiSlots, int nA, State s, BndView b, int bndOn,
+                                                           const int* combOff, const int* combSlots, const double* ownL, const double* recvL,
+                                                           double* combL, const int* sharedLocal) {
+    const int bx = (int)blockIdx.x;
+    if (bx < nA) { haloCombineA2Of(bx, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots); return; }
+    const int i = (bx - nA) * kBlock + (int)threadIdx.x;
+    haloCombineLOf(i, nShared, combOff, combSlots, ownL, recvL, combL, s.lStride);
+    if (bndOn) bndNormalsSharedOf(s, b, nShared, sharedLocal, i);     // reads the record this thread has just written
 }
 
 // projectPointToEdge BPS.C:89-145 (the edge point index it also reports is not consumed per iteration)
@@ -134,9 +149,8 @@ __device__ __forceinline__ V3 projectToEdge(const BndView& b, const V3& pt, int 
 // calculateFeatureEdgeProjections BPS.C:623-677: one wave per feature edge point; for each eligible neighbour the
 // lanes share the scan over the target edges of the point's string (findClosestEdgeInfo BPS.C:206-264: strict "<",
 // so the lowest edge id among equal distances) and lane 0 accumulates in pointPoints order.
-__global__ void __launch_bounds__(64) k_bnd_feature(MeshView m, State s, BndView b) {
+__device__ __forceinline__ void bndFeatureOf(const MeshView& m, const State& s, const BndView& b, int j, int lane) {
     if (s.acc->stop) return;
-    const int j = blockIdx.x, lane = threadIdx.x;
     if (j >= b.nFeat) return;
     const int p = b.featPts[j], str = b.featString[j];
     V3 sum = v3(0, 0, 0);
@@ -168,6 +182,25 @@ __global__ void __launch_bounds__(64) k_bnd_feature(MeshView m, State s, BndView
         ++cnt;
     }
     if (lane == 0) { stv(b.featSum, j, sum); b.featCnt[j] = cnt; }
+}
+__global__ void __launch_bounds__(64) k_bnd_feature(MeshView m, State s, BndView b) { bndFeatureOf(m, s, b, (int)blockIdx.x, (int)threadIdx.x); }
+
+// The geometry launch with the two kernels above riding in its FIRST workgroups (they only read the current coordinates, as
+// the geometry does, and are latency-bound chains over a few ten thousand boundary points): a side stream for them cost
+// ~38 us of fork / join idle time per iteration around 23 + 14 us of kernels (rocprofv3 trace of the multi-rank probe with
+// boundary point smoothing); here they cost no launch at all.  nBndBlocks (a multiple of 8, so that the XCD mapping of the
+// geometry workgroups is unchanged) = normals blocks, then feature blocks (T / 64 feature points each).
+template <int T, bool ORG>
+__global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile_bnd(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces,
+                                                  const int* tileList, int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
+                                                  double* deferHist, BndView b, int nBndBlocks, int nNormalBlocks) {
+    const int bx = (int)blockIdx.x;
+    if (bx < nBndBlocks) {
+        if (bx < nNormalBlocks) bndNormalsOf(m, s, b, bx * T + (int)threadIdx.x);
+        else bndFeatureOf(m, s, b, (bx - nNormalBlocks) * (T / 64) + ((int)threadIdx.x >> 6), (int)threadIdx.x & 63);
+        return;
+    }
+    geomTileBody<T, ORG>(m, s, g, wantAvg, writeFaces, tileList, nLaunch, xcdMap, deferN, deferIter, deferLocal, deferHist, bx - nBndBlocks);
 }
 
 // OpenFOAM triangle::intersection(orig, dir, intersection::HALF_RAY, tol)

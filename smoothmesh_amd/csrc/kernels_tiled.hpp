@@ -55,8 +55,7 @@ __device__ __forceinline__ SmoothTileMeta loadTileMeta(const SmoothTileView& g, 
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  With xcdMap the launch has 8*ceil(n/8)
 // workgroups and XCD x walks the contiguous range [x*ceil(n/8), ...) of the Morton-ordered tile sequence, so
 // that tiles which stage the same records share an L2.  Returns -1 for the padding workgroups.
-__device__ __forceinline__ int launchTile(int n, int xcdMap) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ int launchTile(int n, int xcdMap, int b = (int)blockIdx.x) {
     if (!xcdMap) return b;
     const int per = (n + 7) >> 3;
     const int i = (b & 7) * per + (b >> 3);
@@ -414,16 +413,16 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 #ifndef SMGPU_GEOM_WAVES
 #define SMGPU_GEOM_WAVES 4
 #endif
+// the workgroup's work; bid = its index among the geometry workgroups of the launch
 template <int T, bool ORG>
-__global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
-                                                  int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
-                                                  double* deferHist) {
+__device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, const GeomTileView& g, int wantAvg, int writeFaces, const int* tileList,
+                                             int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal, double* deferHist, int bid) {
     // the "loop has stopped" flag (relTol reached, SM.C:2401) is tested after the staging: a dependent global load in front of
     // everything else put its latency on every workgroup's critical path; a stopped run stages one tile in vain
     const int stopped = s.acc->stop;
-    const int li = launchTile(nLaunch, xcdMap);
+    const int li = launchTile(nLaunch, xcdMap, bid);
     if (li < 0) return;
-    if (deferN > 0 && blockIdx.x == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
+    if (deferN > 0 && bid == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
     const GeomLds L = geomLds(lds, g);
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
@@ -470,6 +469,12 @@ __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(M
     __syncthreads();
     // phase 2: one thread per cell
     geomCell<T, ORG>(s, g, L, tm, tid, tflags, cin);
+}
+template <int T, bool ORG>
+__global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
+                                                  int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal,
+                                                  double* deferHist) {
+    geomTileBody<T, ORG>(m, s, g, wantAvg, writeFaces, tileList, nLaunch, xcdMap, deferN, deferIter, deferLocal, deferHist, (int)blockIdx.x);
 }
 
 // The fused per-point proposal kernel of kernels.hpp (k_smooth) with the cell centres and neighbour
@@ -729,11 +734,13 @@ struct PackView {
     const int* sendOff; const int* sendSlots;
     int centroidAll;            // boundary point smoothing: boundary points gather cell centres too (SM.C:116)
 };
+// (the first nLBlocks workgroups, a multiple of 8, pack exchange L's records instead -- k_halo_packL's work without its launch)
 template <int T>
 __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTileView g, PackView pk, const int* tileList, int nLaunch,
-                                                  int xcdMap) {
+                                                  int xcdMap, PackLArgs la, int nLBlocks) {
     if (s.acc->stop) return;
-    const int li = launchTile(nLaunch, xcdMap);
+    if ((int)blockIdx.x < nLBlocks) { haloPackLOf(s, la, (int)blockIdx.x * T + (int)threadIdx.x); return; }
+    const int li = launchTile(nLaunch, xcdMap, (int)blockIdx.x - nLBlocks);
     if (li < 0) return;
     extern __shared__ double lds[];
     const SmoothLds L = smoothLds(lds, g);

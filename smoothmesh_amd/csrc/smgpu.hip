@@ -111,6 +111,8 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    bool bndInGeom = true;     // SMGPU_BND_IN_GEOM=0: boundary pre-kernels on a side stream / in order instead of inside the geometry launch
+    bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
@@ -416,6 +418,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
+    h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
@@ -776,7 +779,25 @@ static void ensureDynLds(K kernel, int device, size_t bytes) {
     else (void)hipGetLastError();
 }
 template <int T>
-static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB) {
+static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB,
+                           bool withBndPre) {
+    if (withBndPre) {   // the boundary pre-kernels in the first workgroups of this launch (k_geom_tile_bnd)
+        const int nNormal = (h->bv.nB + T - 1) / T, nFeat = (h->bv.nFeat + (T / 64) - 1) / (T / 64);
+        const int nBnd = ((nNormal + nFeat + 7) / 8) * 8;
+        const dim3 grid(nBnd + tileGrid(nTiles, h->xcdMap));
+        if (h->foamOrg) {
+            ensureDynLds(k_geom_tile_bnd<T, true>, h->device, h->geomLds);
+            hipExtLaunchKernelGGL((k_geom_tile_bnd<T, true>), grid, dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
+                                  tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->bv, nBnd, nNormal);
+        } else {
+            ensureDynLds(k_geom_tile_bnd<T, false>, h->device, h->geomLds);
+            hipExtLaunchKernelGGL((k_geom_tile_bnd<T, false>), grid, dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
+                                  tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->bv, nBnd, nNormal);
+        }
+        h->deferN = 0;
+        h->deferLocal = h->deferHist = nullptr;
+        return;
+    }
     if (h->foamOrg) {
         ensureDynLds(k_geom_tile<T, true>, h->device, h->geomLds);
         hipExtLaunchKernelGGL((k_geom_tile<T, true>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
@@ -812,6 +833,7 @@ static int launchBndPre(smgpu_handle* h, const MeshView& m, const State& s, hipS
 // Start of an iteration with boundary point smoothing: both kernels only read the current coordinates, so they run on
 // a side stream while the geometry kernel has the main one; runSmooth joins.
 static int runBndPre(smgpu_handle* h) {
+    if (h->bndOn && h->bndInGeom && h->useTiles && h->bv.nB > 0) return 0;   // they ride in the geometry launch (k_geom_tile_bnd)
     if (!h->bndOn || !h->bndSide || h->bndPreInFlight) return 0;
     if (depSignal(h, DEP_BND_FORK, h->stream, h->evBndFork) || depWait(h, DEP_BND_FORK, h->bndSide, h->evBndFork)) return 1;
     if (launchBndPre(h, h->mv, h->st, h->bndSide)) return 1;
@@ -828,7 +850,8 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
     // kernel k_bnd_fix finishes the boundary points it skipped
     const bool withBnd = h->bndOn && !h->haloOn;   // with a halo smgpu_iter_begin / smgpu_iter_mid place the boundary kernels
     if (withBnd) {
-        if (h->bndPreInFlight) {
+        if (h->bndPreDone) h->bndPreDone = false;
+        else if (h->bndPreInFlight) {
             if (depWait(h, DEP_BND_JOIN, h->stream, h->evBndJoin)) return 1;
             h->bndPreInFlight = false;
         } else if (launchBndPre(h, m, s, h->stream)) return 1;
@@ -854,7 +877,9 @@ static int runSmooth(smgpu_handle* h, const MeshView& m, const State& s, const P
 // geometry of the current coordinates: OpenFOAM face centres/areas + cell centres.
 // tileList != NULL restricts the tiled form to the listed tiles; fromNext reads the coordinates of the
 // iteration being finished (ptsNext) instead of ptsCur (multi-rank look-ahead, smgpu_iter_ahead).
-static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList = 0, bool fromNext = false) {
+// withBndPre: this is the geometry launch at the start of an iteration with boundary point smoothing -- the normals / feature
+// projection kernels of the current coordinates ride in it (bndPreDone tells runSmooth / smgpu_iter_begin)
+static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList = 0, bool fromNext = false, bool withBndPre = false) {
     const MeshView& m = h->mv;
     State s = h->st;
     if (fromNext) s.ptsCur = h->st.ptsNext;
@@ -862,10 +887,12 @@ static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList
     if (h->useTiles) {
         const int nT = tileList ? nList : h->gt.nTiles;
         if (nT == 0) return 0;
+        const bool bnd = withBndPre && h->bndOn && h->bndInGeom && !fromNext && h->bv.nB > 0 && !h->bndPreInFlight && !h->bndPreDone;
+        if (bnd) h->bndPreDone = true;
         return launchKDispatch(h, K_GEOM_TILE, [&](hipEvent_t evA, hipEvent_t evB) {
-            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg, tileList, nT, evA, evB);
-            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg, tileList, nT, evA, evB);
-            else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT, evA, evB);
+            if (h->geomT == 64) launchGeomTile<64>(h, m, s, wantAvg, tileList, nT, evA, evB, bnd);
+            else if (h->geomT == 128) launchGeomTile<128>(h, m, s, wantAvg, tileList, nT, evA, evB, bnd);
+            else launchGeomTile<256>(h, m, s, wantAvg, tileList, nT, evA, evB, bnd);
         });
     }
     if (launchK(h, K_FACE_GEOM, [&] { hipLaunchKernelGGL(k_face_geom, dim3(gridFor(m.nFaces)), dim3(kBlock), 0, h->stream, m, s, wantAvg, h->foamOrg ? 1 : 0); })) return 1;
@@ -1325,7 +1352,7 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     if (flushDeferred(h)) return 1;
     for (int i = 0; i < nIters; ++i) {
         if (runBndPre(h)) return 1;
-        if (runGeometry(h)) return 1;
+        if (runGeometry(h, nullptr, 0, false, true)) return 1;
         State s = h->st;
         if (fused) {
             if (runSmooth<true>(h, m, s, prm)) return 1;
@@ -1609,9 +1636,9 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (runBndPre(h)) return 1;
     if (h->geomAheadDone) {
         // the tiles away from the shared points were recomputed by smgpu_iter_ahead of the previous iteration
-        if (runGeometry(h, h->dGeomShared, h->nGeomShared)) return 1;
+        if (runGeometry(h, h->dGeomShared, h->nGeomShared, false, true)) return 1;
         h->geomAheadDone = false;
-    } else if (runGeometry(h)) return 1;
+    } else if (runGeometry(h, nullptr, 0, false, true)) return 1;
     // a rank without shared geometry tiles launched nothing above: the previous iteration's reduction, parked for that
     // launch by smgpu_iter_end, must not wait for the next one (smgpu_iter_mid overwrites the partials before it)
     if (flushDeferred(h)) return 1;
@@ -1621,25 +1648,30 @@ int smgpu_iter_begin(smgpu_handle* h) {
     // boundary point smoothing: local normal sums and feature edge projections of the current coordinates (SM.C:2266, BPS.C:866),
     // started next to the geometry kernel above when there is a side stream
     if (h->bndOn) {
-        if (h->bndPreInFlight) {
+        if (h->bndPreDone) h->bndPreDone = false;
+        else if (h->bndPreInFlight) {
             if (depWait(h, DEP_BND_JOIN, h->stream, h->evBndJoin)) return 1;
             h->bndPreInFlight = false;
         } else if (launchBndPre(h, m, s, h->stream)) return 1;
     }
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
+                const bool withL = h->layersOn || h->bndOn;   // local normals / neighbour coordinates / feature projections (SM.C:2266, 2286, 2310-2330)
+                const PackLArgs la{h->dSharedLocal, h->dOwnL, h->nShared, h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd,
+                                   h->bv.featSum, h->bv.featCnt};
                 if (h->useTiles && h->nSharedTiles > 0 && h->packTiles) {   // the staged gather of the smoothing tiles
                     const PackView pk{h->dOwnA, h->sendA, h->dSendOff, h->dSendSlots, h->bndOn ? 1 : 0};
-                    const dim3 grid(tileGrid(h->nSharedTiles, h->xcdMap));
-                    if (h->smoothT == 64) hipLaunchKernelGGL(k_pack_tile<64>, grid, dim3(64), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
-                    else if (h->smoothT == 128) hipLaunchKernelGGL(k_pack_tile<128>, grid, dim3(128), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
-                    else hipLaunchKernelGGL(k_pack_tile<256>, grid, dim3(256), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap);
-                } else
+                    // exchange L's records are packed by the first workgroups of the same launch
+                    const int T = h->smoothT, nL = withL ? (((h->nShared + T - 1) / T + 7) / 8) * 8 : 0;
+                    const dim3 grid(nL + tileGrid(h->nSharedTiles, h->xcdMap));
+                    if (T == 64) hipLaunchKernelGGL(k_pack_tile<64>, grid, dim3(64), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
+                    else if (T == 128) hipLaunchKernelGGL(k_pack_tile<128>, grid, dim3(128), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
+                    else hipLaunchKernelGGL(k_pack_tile<256>, grid, dim3(256), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
+                } else {
                     hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
                                        h->dSendOff, h->dSendSlots, h->sendA, h->bndOn ? 1 : 0);
-                if (h->layersOn || h->bndOn)   // local normals / neighbour coordinates / feature projections (SM.C:2266, 2286, 2310-2330)
-                    hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, h->dSharedLocal, h->dOwnL, h->nShared,
-                                       h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
+                    if (withL) hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, s, la);
+                }
             })) return 1;
     return exchAfterCompute(h);             // sendA (and sendL) complete: the exchange may start
 }
@@ -1672,13 +1704,21 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (launchK(h, K_HALO, [&] {
                 // (with inlineCombine only the workgroups of the points with more than two sharers: the others are the smoothing kernel's)
                 const int nTwo = h->st.inlineCombine ? 0 : gridFor(h->nShared), nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
+                const bool withL = h->layersOn || h->bndOn;
+                if (withL && h->dMultiIdx && h->dPeer) {
+                    // exchange A's and exchange L's combines and the shared boundary normals (OBB.C:201-230) in one launch
+                    hipLaunchKernelGGL(k_halo_combineAL, dim3(nTwo + nMultiBlocks + gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA,
+                                       h->recvA, h->dCombA, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots, nTwo + nMultiBlocks, h->st, h->bv, h->bndOn ? 1 : 0,
+                                       h->dCombOff, h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->dSharedLocal);
+                    return;
+                }
                 if (nTwo + nMultiBlocks > 0 && h->dMultiIdx && h->dPeer)
                     hipLaunchKernelGGL(k_halo_combineA2, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA, h->recvA, h->dCombA,
                                        nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
                 else if (nTwo + nMultiBlocks > 0)
                     hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
                                        h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
-                if (h->layersOn || h->bndOn)
+                if (withL)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                        h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride);
                 if (h->bndOn)   // OBB.C:201-230 for the shared boundary points, on the sums
@@ -2123,8 +2163,9 @@ int smgpu_boundary_shared(smgpu_handle* h, int32_t field, int32_t set, double* v
         std::vector<double> rec(n * W, 0.0);
         if (!set) {
             // pack through the exchange kernel: the same values an iteration would send
-            hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->dSharedLocal, h->dOwnL, h->nShared,
-                               h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd, h->bv.featSum, h->bv.featCnt);
+            hipLaunchKernelGGL(k_halo_packL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st,
+                               PackLArgs{h->dSharedLocal, h->dOwnL, h->nShared, h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd,
+                                         h->bv.featSum, h->bv.featCnt});
             HIP_OK(hipMemcpyAsync(rec.data(), h->dOwnL, sizeof(double) * rec.size(), hipMemcpyDeviceToHost, h->stream));
             HIP_OK(hipStreamSynchronize(h->stream));
             for (size_t i = 0; i < n; ++i) { for (int c = 0; c < 3; ++c) v[4 * i + c] = rec[i * W + c]; v[4 * i + 3] = rec[i * W + 6]; }
@@ -2203,7 +2244,7 @@ int smgpu_debug_propose(smgpu_handle* h) {
     HIP_OK(hipMemsetAsync(h->st.acc, 0, sizeof(Accum), h->stream));
     h->writeFaces = true;
     if (runBndPre(h)) return 1;
-    const int rcg = runGeometry(h);
+    const int rcg = runGeometry(h, nullptr, 0, false, true);
     h->writeFaces = false;
     if (rcg) return 1;
     // the debug fields (edge / point angles) are only complete without the filters; SMGPU_DEBUG_FILTERED=1

@@ -228,7 +228,8 @@ class DistributedSmoother:
         self.allStats = torch.zeros((self.world, 2), dtype=torch.float64, device=torch_device)
         if self.probe_slots:
             z = lambda shape, dt: (torch.zeros(shape, dtype=dt, device=torch_device), torch.zeros(shape, dtype=dt, device=torch_device))
-            self._probe = {torch.float64: z((self.probe_slots, A_DOUBLES), torch.float64), torch.int32: z((self.probe_slots,), torch.int32)}
+            self._probe = {torch.float64: z((self.probe_slots, A_DOUBLES), torch.float64), torch.int32: z((self.probe_slots,), torch.int32),
+                           "L": z((self.probe_slots, L_DOUBLES), torch.float64)}
         self.direct = self._open_direct(engine_factory is None)
 
     def _open_direct(self, own_engine):
@@ -353,6 +354,31 @@ class DistributedSmoother:
         if overlap:
             overlap()
 
+    def _a2a_LA(self, overlap=None):
+        """exchange L (when the layer treatment or the boundary point smoothing is on) and exchange A: one send / recv group
+        with the direct exchange, two collectives otherwise"""
+        st, eng = self.state, self.engine
+        withL = self.layers or self.boundary
+        if withL and self.direct is not None:
+            probe = self.world == 1 and self.probe_slots
+            n = self.probe_slots if probe else self.tables.nSend
+            if n or self.tables.nRecv:
+                if probe:      # measurement aid: a self-exchange of dummy records of the same sizes
+                    (ra, sa), (rl, sl) = self._probe[self.torch.float64], self._probe["L"]
+                    rl, sl = l_view(rl, eng.l_doubles()), l_view(sl, eng.l_doubles())
+                else:
+                    ra, sa = st.recvA, st.sendA
+                    rl, sl = l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles())
+                self.direct.exchange_many([(rl.data_ptr(), sl.data_ptr(), (rl.numel() // rl.shape[0]) * rl.element_size()),
+                                           (ra.data_ptr(), sa.data_ptr(), (ra.numel() // ra.shape[0]) * ra.element_size())],
+                                          [n] if probe else self.counts, self.torch.cuda.current_stream(self.device).cuda_stream)
+            if overlap:
+                overlap()
+            return
+        if withL:
+            self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))   # OBB.C:184-198, 490-496
+        self._a2a(st.recvA, st.sendA, overlap)   # SM.C:134-148, 402-478
+
     def _gather_stats(self):
         if self._staged():
             out = self.torch.empty((self.world, 2), dtype=self.torch.float64)
@@ -417,9 +443,7 @@ class DistributedSmoother:
             hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
             for i in range(centroidalIters):
                 eng.iter_begin()
-                if self.layers or self.boundary:
-                    self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))   # OBB.C:184-198, 490-496
-                self._a2a(st.recvA, st.sendA, eng.iter_interior)   # SM.C:134-148, 402-478
+                self._a2a_LA(eng.iter_interior)
                 eng.iter_mid()
                 self._a2a(st.recvF, st.sendF, eng.iter_ahead)   # SM.C:2374
                 eng.iter_end()
@@ -438,9 +462,7 @@ class DistributedSmoother:
         eng.set_stats_history(local.data_ptr(), n)      # iter_end fills record i: no per-iteration copy
         for i in range(centroidalIters):
             eng.iter_begin()
-            if self.layers or self.boundary:
-                self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))
-            self._a2a(st.recvA, st.sendA, eng.iter_interior)
+            self._a2a_LA(eng.iter_interior)
             eng.iter_mid()
             self._a2a(st.recvF, st.sendF, eng.iter_ahead)
             eng.iter_end()

@@ -62,15 +62,21 @@ class RcclDirect:
 
     def exchange(self, recv_ptr, send_ptr, counts, elem_bytes, stream):
         """records of elem_bytes each, counts[r] of them to and from rank r, packed in rank order in both buffers"""
+        self.exchange_many([(recv_ptr, send_ptr, elem_bytes)], counts, stream)
+
+    def exchange_many(self, buffers, counts, stream):
+        """several record sets (recv_ptr, send_ptr, elem_bytes) with the same per-rank counts in ONE send / recv group
+        (exchange L and exchange A leave at the same point of the iteration: one collective kernel instead of two)"""
         lib = self.lib
         self._ok(lib.ncclGroupStart(), "ncclGroupStart")
-        off = 0
-        for r, c in enumerate(counts):
-            if c:
-                nb = c * elem_bytes
-                self._ok(lib.ncclSend(send_ptr + off, nb, NCCL_INT8, r, self.comm, stream), "ncclSend")
-                self._ok(lib.ncclRecv(recv_ptr + off, nb, NCCL_INT8, r, self.comm, stream), "ncclRecv")
-                off += nb
+        for recv_ptr, send_ptr, elem_bytes in buffers:
+            off = 0
+            for r, c in enumerate(counts):
+                if c:
+                    nb = c * elem_bytes
+                    self._ok(lib.ncclSend(send_ptr + off, nb, NCCL_INT8, r, self.comm, stream), "ncclSend")
+                    self._ok(lib.ncclRecv(recv_ptr + off, nb, NCCL_INT8, r, self.comm, stream), "ncclRecv")
+                    off += nb
         self._ok(lib.ncclGroupEnd(), "ncclGroupEnd")
 
     def self_check(self, counts, device):

@@ -251,7 +251,8 @@ def test_distributed_smoother_with_boundary_smoothing_two_ranks():
 
 
 @pytest.mark.parametrize("env", [{"SMGPU_HOST_WALK": "1"}, {"SMGPU_HOST_WALK": "0"}, {"SMGPU_WALK": "fix"}, {"SMGPU_FILTER": "0"},
-                                 {"SMGPU_SIDE_STREAM": "0"}, {"SMGPU_STREAM_OPS": "0"}, {"SMGPU_XCD_MAP": "0"}])
+                                 {"SMGPU_SIDE_STREAM": "0"}, {"SMGPU_STREAM_OPS": "0"}, {"SMGPU_XCD_MAP": "0"}, {"SMGPU_BND_IN_GEOM": "0"},
+                                 {"SMGPU_BND_IN_GEOM": "0", "SMGPU_SIDE_STREAM": "0"}])
 def test_boundary_smoothing_under_engine_knobs(oracle_lib, monkeypatch, env):
     """results never depend on the launch arrangement: walk replay place, filters, side streams, dependency mechanism"""
     from smoothmesh_amd.polymesh import cavity_mesh
