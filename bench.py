@@ -352,7 +352,8 @@ def main():
         ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
         sizes = eng.sizes()
         parallelism = (f"domain decomposition {grid[0]}x{grid[1]}x{grid[2]}, "
-                       f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, "
+                       + ("RCCL send/recv groups on the engine's stream, " if getattr(ds, "direct", None) is not None else
+                          f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, ") +
                        f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
                        + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
 

@@ -413,7 +413,62 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 #ifndef SMGPU_GEOM_WAVES
 #define SMGPU_GEOM_WAVES 4
 #endif
-// the workgroup's work; bid = its index among the geometry workgroups of the launch
+// ---- the workgroup's work ---------------------------------------------------------------------------------------------------
+// round 1 of the prologue for one tile: the point id list (first two rounds of T)
+template <int T>
+__device__ __forceinline__ void geomLoadIds(const GeomTileView& g, const GeomTileMeta& tm, int tid, int (&id)[2]) {
+    const int* ids = g.tpIds + tm.tpOff;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const int i = u * T + tid; id[u] = (i < tm.nPts) ? ids[i] : -1; }
+}
+// ... and what the face and cell phases read from global memory per thread: the vertex rows of the first two face rounds of a
+// quadrilateral tile, the cell's id and face row
+struct GeomRows { ushort4 fq[2]; GeomCellIn cin; bool preFaces; };
+template <int T, bool ORG>
+__device__ __forceinline__ GeomRows geomLoadRows(const GeomTileView& g, const GeomTileMeta& tm, int tid) {
+    GeomRows r;
+    const unsigned tflags = (unsigned)tm.flags;
+    r.preFaces = !ORG && (tflags & 1u);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = u * T + tid;
+        r.fq[u] = (r.preFaces && i < tm.nFaces) ? reinterpret_cast<const ushort4*>(g.faceVerts + tm.fvBase)[i] : make_ushort4(0, 0, 0, 0);
+    }
+    r.cin = geomCellLoad<T>(g, tm, tid, tflags);
+    return r;
+}
+// round 2: the point records of the ids -> registers
+__device__ __forceinline__ void geomLoadPoints(const State& s, const int (&id)[2], V3 (&v)[2]) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) v[u] = (id[u] >= 0) ? ldv(s.ptsCur, id[u]) : v3(0, 0, 0);
+}
+template <int T>
+__device__ __forceinline__ void geomStorePoints(const State& s, const GeomTileView& g, const GeomTileMeta& tm, const GeomLds& L, const int (&id)[2],
+                                                const V3 (&v)[2], int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = u * T + tid;
+        if (id[u] >= 0) { L.px[kGP * i] = v[u].x; L.py[kGP * i] = v[u].y; L.pz[kGP * i] = v[u].z; }
+    }
+    if (tm.nPts > 2 * T)      // tiles beyond the fixed number of rounds
+        stageRecords<T, 2, kGP>(s.ptsCur, g.tpIds + tm.tpOff + 2 * T, tm.nPts - 2 * T, L.px + kGP * 2 * T, L.py + kGP * 2 * T, L.pz + kGP * 2 * T, tid);
+}
+// phase 1: every face of the tile once -> LDS
+template <int T, bool ORG>
+__device__ __forceinline__ void geomFaces(const State& s, const GeomTileView& g, const GeomLds& L, const GeomTileMeta& tm, const GeomRows& r, int tid,
+                                          int wantAvg, int writeFaces) {
+    const unsigned tflags = (unsigned)tm.flags;
+    const int nf = tm.nFaces;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = u * T + tid;
+        if (i < nf) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces, r.preFaces, r.fq[u]);
+    }
+    for (int i = 2 * T + tid; i < nf; i += T) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces);
+}
+
+// bid = the workgroup's index among the geometry workgroups of the launch.  (Two tiles per workgroup with both prologues in
+// flight at once was built and measured: no gain on hex meshes, 17 % slower on the polyhedral one -- DESIGN 9.)
 template <int T, bool ORG>
 __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, const GeomTileView& g, int wantAvg, int writeFaces, const int* tileList,
                                              int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal, double* deferHist, int bid) {
@@ -424,51 +479,21 @@ __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, 
     if (li < 0) return;
     if (deferN > 0 && bid == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
-    const GeomLds L = geomLds(lds, g);
-    const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const int tile = tileList ? ((const_int_ptr)tileList)[li] : li;
     const GeomTileMeta tm = loadTileMeta(g, tile);
-    const unsigned tflags = (unsigned)tm.flags;
-    const int nf = tm.nFaces;
-    // prologue: what the face and cell phases read from global memory per thread (vertex rows of the first two face rounds of a
-    // quadrilateral tile, the cell's id and face row) is requested here, in flight together with the point id list -- read
-    // where it is used, each of them put a memory latency in front of its phase (five dependent round trips per tile, now two)
-    // (the id list first: the point records depend on it, everything else only has to be there after the staging)
-    const int* ids = g.tpIds + tm.tpOff;
+    const GeomLds L = geomLds(lds, g);
     int id[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) { const int i = u * T + tid; id[u] = (i < tm.nPts) ? ids[i] : -1; }
-    const bool preFaces = !ORG && (tflags & 1u);
-    ushort4 fq[2];
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = u * T + tid;
-        fq[u] = (preFaces && i < nf) ? reinterpret_cast<const ushort4*>(g.faceVerts + tm.fvBase)[i] : make_ushort4(0, 0, 0, 0);
-    }
-    const GeomCellIn cin = geomCellLoad<T>(g, tm, tid, tflags);
-    // phase 0: the tile's points (ascending ids: near-contiguous 24-byte records)
-    {
-        V3 v[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) v[u] = (id[u] >= 0) ? ldv(s.ptsCur, id[u]) : v3(0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int i = u * T + tid;
-            if (id[u] >= 0) { L.px[kGP * i] = v[u].x; L.py[kGP * i] = v[u].y; L.pz[kGP * i] = v[u].z; }
-        }
-        if (tm.nPts > 2 * T) stageRecords<T, 2, kGP>(s.ptsCur, ids + 2 * T, tm.nPts - 2 * T, L.px + kGP * 2 * T, L.py + kGP * 2 * T, L.pz + kGP * 2 * T, tid);
-    }
+    geomLoadIds<T>(g, tm, tid, id);                               // round 1 (the id list first: the point records depend on it)
+    const GeomRows r = geomLoadRows<T, ORG>(g, tm, tid);
+    V3 v[2];
+    geomLoadPoints(s, id, v);                                     // round 2
+    geomStorePoints<T>(s, g, tm, L, id, v, tid);
     if (stopped) return;
     __syncthreads();
-    // phase 1: every face of the tile once
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = u * T + tid;
-        if (i < nf) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces, preFaces, fq[u]);
-    }
-    for (int i = 2 * T + tid; i < nf; i += T) geomFace<ORG>(s, g, L, tm, i, tflags, wantAvg, writeFaces);
+    geomFaces<T, ORG>(s, g, L, tm, r, tid, wantAvg, writeFaces);  // phase 1: every face of the tile once
     __syncthreads();
-    // phase 2: one thread per cell
-    geomCell<T, ORG>(s, g, L, tm, tid, tflags, cin);
+    geomCell<T, ORG>(s, g, L, tm, tid, (unsigned)tm.flags, r.cin);   // phase 2: one thread per cell
 }
 template <int T, bool ORG>
 __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,

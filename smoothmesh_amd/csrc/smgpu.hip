@@ -778,37 +778,28 @@ static void ensureDynLds(K kernel, int device, size_t bytes) {
     if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess) have[device] = bytes;
     else (void)hipGetLastError();
 }
-template <int T>
-static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB,
-                           bool withBndPre) {
+template <int T, bool ORG>
+static void launchGeomTileAs(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB,
+                             bool withBndPre) {
     if (withBndPre) {   // the boundary pre-kernels in the first workgroups of this launch (k_geom_tile_bnd)
         const int nNormal = (h->bv.nB + T - 1) / T, nFeat = (h->bv.nFeat + (T / 64) - 1) / (T / 64);
         const int nBnd = ((nNormal + nFeat + 7) / 8) * 8;
-        const dim3 grid(nBnd + tileGrid(nTiles, h->xcdMap));
-        if (h->foamOrg) {
-            ensureDynLds(k_geom_tile_bnd<T, true>, h->device, h->geomLds);
-            hipExtLaunchKernelGGL((k_geom_tile_bnd<T, true>), grid, dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                                  tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->bv, nBnd, nNormal);
-        } else {
-            ensureDynLds(k_geom_tile_bnd<T, false>, h->device, h->geomLds);
-            hipExtLaunchKernelGGL((k_geom_tile_bnd<T, false>), grid, dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg, h->writeFaces ? 1 : 0,
-                                  tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->bv, nBnd, nNormal);
-        }
-        h->deferN = 0;
-        h->deferLocal = h->deferHist = nullptr;
-        return;
-    }
-    if (h->foamOrg) {
-        ensureDynLds(k_geom_tile<T, true>, h->device, h->geomLds);
-        hipExtLaunchKernelGGL((k_geom_tile<T, true>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
-                              h->writeFaces ? 1 : 0, tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
+        ensureDynLds(k_geom_tile_bnd<T, ORG>, h->device, h->geomLds);
+        hipExtLaunchKernelGGL((k_geom_tile_bnd<T, ORG>), dim3(nBnd + tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv,
+                              wantAvg, h->writeFaces ? 1 : 0, tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->bv, nBnd, nNormal);
     } else {
-        ensureDynLds(k_geom_tile<T, false>, h->device, h->geomLds);
-        hipExtLaunchKernelGGL((k_geom_tile<T, false>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
+        ensureDynLds(k_geom_tile<T, ORG>, h->device, h->geomLds);
+        hipExtLaunchKernelGGL((k_geom_tile<T, ORG>), dim3(tileGrid(nTiles, h->xcdMap)), dim3(T), (uint32_t)h->geomLds, h->stream, evA, evB, 0, m, s, h->gv, wantAvg,
                               h->writeFaces ? 1 : 0, tileList, nTiles, h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist);
     }
     h->deferN = 0;
     h->deferLocal = h->deferHist = nullptr;
+}
+template <int T>
+static void launchGeomTile(smgpu_handle* h, const MeshView& m, const State& s, int wantAvg, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB,
+                           bool withBndPre) {
+    if (h->foamOrg) launchGeomTileAs<T, true>(h, m, s, wantAvg, tileList, nTiles, evA, evB, withBndPre);
+    else launchGeomTileAs<T, false>(h, m, s, wantAvg, tileList, nTiles, evA, evB, withBndPre);
 }
 template <bool FINAL, int T>
 static void launchSmoothTile(smgpu_handle* h, const MeshView& m, const State& s, const Prm& prm, const int* tileList, int nTiles, hipEvent_t evA, hipEvent_t evB) {
