@@ -193,7 +193,12 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 #define SMGPU_GEOM_AOS 1
 #endif
 constexpr int kGP = SMGPU_GEOM_AOS ? 3 : 1;   // index stride of a point in px / py / pz
-constexpr int kGF = SMGPU_GEOM_AOS ? 6 : 1;   // index stride of a face in fcx .. faz
+// (a face record is padded to an odd number of doubles: with 6 the records of consecutive faces -- what a wave writes in the
+// face phase -- fall on 8 of the 16 bank pairs, a two-way conflict on every access; SMGPU_GEOM_FACE_STRIDE=6 restores that)
+#ifndef SMGPU_GEOM_FACE_STRIDE
+#define SMGPU_GEOM_FACE_STRIDE 7
+#endif
+constexpr int kGF = SMGPU_GEOM_AOS ? SMGPU_GEOM_FACE_STRIDE : 1;   // index stride of a face in fcx .. faz
 struct GeomLds {
     double *px, *py, *pz;        // the tile's points
     double *fcx, *fcy, *fcz;     // face centres

@@ -558,7 +558,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 }
             }
             if (rc) return cleanup(1);
-            h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + 6 * (size_t)g.maxFaces);
+            h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + (size_t)(SMGPU_GEOM_AOS ? kGF : 6) * (size_t)g.maxFaces);
             h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
             if (envInt("SMGPU_VERBOSE", 0))
                 std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
