@@ -708,12 +708,17 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         }
         bool frozen = false;                                           // SM.C:611-648
         {
-            double shortestNew = SMGPU_GREAT;
+            // min over the neighbours of |np - x_q|: the correctly rounded square root is monotone, so the minimum of the roots
+            // IS the root of the minimum of the squares -- one sqrt instead of one per neighbour, the same bits
+            // (NaN squares are skipped as NaN lengths were; lengths not below the loop's start value GREAT never won)
+            double minSqr = __builtin_inf();
             SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 (void)j;
-                const double tn = mag(np - ldsv(nx, ny, nz, e & 0x7fff));
-                if (tn < shortestNew) shortestNew = tn;
+                const double t2 = magSqr(np - ldsv(nx, ny, nz, e & 0x7fff));
+                if (t2 < minSqr) minSqr = t2;
             })
+            const double rootMin = sqrtExact(minSqr);
+            const double shortestNew = (rootMin < SMGPU_GREAT) ? rootMin : SMGPU_GREAT;
             const double shortest = (shortestNew < shortestCur) ? shortestNew : shortestCur;
             if (prm.totalMinFreeze && (shortest < prm.minEdge)) frozen = true;
             else if ((shortestNew < prm.minEdge) && (shortestNew < shortestCur)) frozen = true;
