@@ -88,7 +88,7 @@ class RcclDirect:
             send = (torch.arange(max(n, 1) * 3, dtype=torch.float64, device=device) * (self.rank + 1) + 0.25 * self.rank).reshape(-1, 3)[:n]
             ref = torch.zeros_like(send)
             got = torch.full_like(send, -1.0)
-            if n:
+            if n or self.world > 1:      # (a collective: ranks without shared points take part with zero counts)
                 dist.all_to_all_single(ref, send.contiguous(), counts, counts)
             s = torch.cuda.current_stream(device)
             self.exchange(got.data_ptr(), send.data_ptr(), counts, 24, s.cuda_stream)

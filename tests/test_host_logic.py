@@ -172,3 +172,19 @@ def test_multi_domain_oracle_one_domain_equals_single(oracle_lib):
     ra = a.iterate(5, 0.0); rb = mo.iterate(5, 0.0)
     assert np.array_equal(ra[1], rb[1]) and np.array_equal(ra[2], rb[2])
     assert np.array_equal(a.points(), b.points())
+
+
+def test_rccl_unique_id_marshalling_keeps_all_128_bytes():
+    """the ncclUniqueId travels through the process group as bytes: NUL bytes inside it must survive (a c_char array field
+    reads back truncated at the first NUL -- the bootstrap address then points nowhere)"""
+    import ctypes as C
+    from smoothmesh_amd.rccl_direct import _UniqueId
+    assert C.sizeof(_UniqueId) == 128
+    u = _UniqueId()
+    raw = bytes((7 * i + 3) % 256 if i % 5 else 0 for i in range(128))
+    C.memmove(C.byref(u), raw, 128)
+    blob = C.string_at(C.byref(u), 128)
+    assert blob == raw
+    v = _UniqueId()
+    C.memmove(C.byref(v), blob, 128)
+    assert bytes(v.internal) == raw
