@@ -105,3 +105,9 @@ class RcclDirect:
         if getattr(self, "comm", None):
             self.lib.ncclCommDestroy(self.comm)
             self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001 -- interpreter shutdown
+            pass

@@ -184,3 +184,24 @@ def test_direct_rccl_exchange_of_the_python_driver():
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "direct exchange: ok" in r.stdout
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_distributed_smoother_polyhedral_over_rccl(world):
+    """The production transport: one process per GPU, RCCL (send / recv groups on the engines' streams, torch's collectives
+    for the set-up), decomposed polyhedral mesh against the oracle's MultiDomain.  Needs `world` GPUs: skipped on the 1-GPU
+    development box (where RCCL refuses two ranks on one device) -- it is here for any node that has them."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SMOOTHMESH_SHARE_GPU", None); env.pop("SMOOTHMESH_BACKEND", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+                        "--master-port", "29527", os.path.join(root, "scripts", "check_dist_poly.py")],
+                       capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.stdout.count(": ok ") == 4 * world and "BAD" not in r.stdout
