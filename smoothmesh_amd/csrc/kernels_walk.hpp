@@ -326,6 +326,7 @@ struct StarLds {
     int vid[kStarVerts];
     double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
     unsigned char nb[kStarEnts];
+    signed char job[kStarEnts + 2];      // the jobs that are needed: -1 = the self test, i = entry i (compacted, in that order)
 };
 struct StarLane {          // a lane's place: ring position i of edge (p, xI)
     bool valid, hasCell;
@@ -475,23 +476,32 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
             }
         }
         const bool counts = P.valid && P.hasCell;
-        // jobs, two at a time (one per half wave).  Round 1: job 0 = the self test, job 1 + i = entry i with p at its current position
+        // jobs, two at a time (one per half wave).  Round 1: the self test, then entry i with p at its current position -- only
+        // the jobs whose result can be consulted: the self test of a point that moves and is still free, the entries of the
+        // neighbours that are free and moving (a job that is not needed would still cost its half wave the full arithmetic:
+        // the needed ones are listed first, two list places per step)
         unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
         const bool selfNeeded = moved && !frozenBefore;
-        for (int j0 = 0; j0 < 1 + nEnt; j0 += 2) {
+        const unsigned long long elig = __ballot(eligible);
+        const int nEl = __popcll(elig), first = selfNeeded ? 1 : 0;
+        if (eligible) L.job[first + __popcll(elig & ((1ull << lane) - 1ull))] = (signed char)lane;
+        if (lane == 0 && selfNeeded) L.job[0] = -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const int nJobs = first + nEl;
+        for (int j0 = 0; j0 < nJobs; j0 += 2) {
             const int j = j0 + half;
-            const int ei = j - 1;                                    // entry of this half's job (-1: self)
-            const int src = ei < 0 ? 0 : (ei < nEnt ? ei : 0);
+            const bool run = j < nJobs;
+            const int ei = run ? (int)L.job[j] : 0;                  // entry of this half's job (-1: self)
+            const int src = ei < 0 ? 0 : ei;
             const int jq = __shfl(q, src, 64);
             const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
-            const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
-            const bool run = (j < 1 + nEnt) && (ei < 0 ? selfNeeded : jEl);
             const double angle = (ei < 0) ? starLaneAngle(L, P, p, np, -1, np) : starLaneAngle(L, P, p, cur, jq, jnq);
             double mn, mx;
             starReduce(run && counts, angle, mn, mx);
             const bool isBad = run && bad(mn, mx);
             // the self result is known to the whole wave after the first step
-            const int selfBad = __shfl((j == 0 && isBad) ? 1 : 0, 0, 64);
+            const int selfBad = __shfl((j == 0 && selfNeeded && isBad) ? 1 : 0, 0, 64);
             if (j0 == 0 && selfBad) sbits |= 1u;
             if (run && ei >= 0 && hl == 0) {
                 unsigned char v = L.nb[ei];
@@ -503,13 +513,12 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         if (lane == 0) w.actBits[a] = (uint8_t)sbits;
         // round 2: entry i with p at its proposal -- only read if p is still free at its first visit and does not freeze itself
         if (moved && !(sbits & 5u)) {
-            for (int j0 = 0; j0 < nEnt; j0 += 2) {
-                const int ei = j0 + half;
-                const int src = ei < nEnt ? ei : 0;
-                const int jq = __shfl(q, src, 64);
-                const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
-                const bool jEl = __shfl(eligible ? 1 : 0, src, 64) != 0;
-                const bool run = ei < nEnt && jEl;
+            for (int j0 = first; j0 < nJobs; j0 += 2) {
+                const int j = j0 + half;
+                const bool run = j < nJobs;
+                const int ei = run ? (int)L.job[j] : 0;
+                const int jq = __shfl(q, ei, 64);
+                const V3 jnq = v3(__shfl(nq.x, ei, 64), __shfl(nq.y, ei, 64), __shfl(nq.z, ei, 64));
                 const double angle = starLaneAngle(L, P, p, np, jq, jnq);
                 double mn, mx;
                 starReduce(run && counts, angle, mn, mx);
