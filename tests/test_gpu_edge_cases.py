@@ -91,8 +91,8 @@ def test_natural_tile_order(oracle_lib, monkeypatch):
 @pytest.mark.parametrize("env", [{"SMGPU_XCD_MAP": "0"}, {"SMGPU_WALK_STAR": "0"}, {"SMGPU_TILE_MORTON": "0"}, {"SMGPU_FA_SIDE_EXACT": "0"},
                                  {"SMGPU_SIDE_STREAM": "0"}])
 def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
-    """persistent / software-pipelined geometry and smoothing kernels, round-robin tile launch: tuning knobs, same bits;
-    meshes large enough for several tiles per workgroup sequence, with quadrilateral-only and mixed tiles"""
+    """launch arrangements (round-robin tile launch, natural tile order, gather-form walk predicates, exact face-angle pass on
+    the main stream, no side streams): tuning knobs, same bits; meshes with quadrilateral-only and mixed tiles"""
     from smoothmesh_amd.meshgen import hex_block
     from smoothmesh_amd.polymesh import cavity_mesh
     for k, v in env.items():
