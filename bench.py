@@ -16,8 +16,13 @@ values are exchanged per iteration with RCCL all_to_all (smoothmesh_amd/halo.py)
 max-over-ranks time.
 
 The default N = 1 run also measures BASELINE.json's other single-GPU configurations (configs[2] hex100c, configs[3]
-cavity215c and its constraints-off twin) with a bounded number of steps and reports them under "configs" in the same
-JSON line (--no-configs skips that, --configs a,b,c selects).
+cavity215c and its constraints-off twin) with BASELINE's iteration counts (100 / 200) and reports them under "configs" in the
+same JSON line (--no-configs skips that, --configs a,b,c selects).  The headline and every configs[] entry carry
+  ms_per_step_cold  the same W + K steps timed before the clock pre-run,
+  parity_check      the engine against the CPU oracle on THIS workload's own mesh (same start, same n iterations),
+  cpu_baseline      the serial oracle's rate on that mesh (bounded number of iterations),
+none of which touches a timed region (--no-parity skips the oracle legs of the sub-runs: the 10 M-cell oracle costs a few
+minutes of host time).
 """
 import argparse
 import json
@@ -82,42 +87,88 @@ def layer_params(kind):
     return LayerParams(layerPatches=('".*"',) if kind == "hex" else ("cavity",))
 
 
-def cpu_baseline(kind, n_cells_side, constraints, budget_s=12.0, layers=False, boundary=False):
-    """Serial oracle (CPU restatement of the reference loop) on the SAME mesh for a bounded number of
-    iterations.  kind = "port": the reference itself needs OpenFOAM and cannot be built here."""
+_MESHES = {}    # (kind, n) -> mesh: a workload and its constraints-on twin share one mesh ...
+_ORACLES = {}   # ... and one oracle (its set-up is minutes of host time on the 10 M-cell mesh)
+
+
+def get_mesh(kind, n):
+    key = (kind, n)
+    if key not in _MESHES:
+        for k in [k for k in _MESHES if k != key]:      # one large mesh (and its oracle) at a time
+            _MESHES.pop(k)
+            o = _ORACLES.pop(k, None)
+            if o is not None:
+                o.close()
+        _MESHES[key] = make_mesh(kind, n)
+    return _MESHES[key]
+
+
+def oracle_leg(kind, n_side, constraints, eng, prm, budget_s=12.0, layers=False, boundary=False, max_iters=40):
+    """The checker and the reported CPU baseline in one pass: the serial oracle (CPU restatement of the reference loop;
+    kind = "port": the reference itself needs OpenFOAM and cannot be built here) runs n iterations of THIS workload's own
+    mesh from the initial coordinates -- n bounded by budget_s of CPU time -- and the engine `eng` runs the same n iterations
+    from the same start; returns (cpu_baseline, parity_check).  Neither is part of any timed region."""
+    import numpy as np
     from oracle import oracle_ffi
-    from smoothmesh_amd import default_params
-    sample_n = n_cells_side if kind == "hex" else min(n_cells_side, 100)   # bounded sample of the same family
-    mesh = make_mesh(kind, sample_n)
-    o = oracle_ffi.Oracle(mesh)
-    p = default_params(o.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
-    o.set_params(p)
+    mesh = get_mesh(kind, n_side)
+    key = (kind, n_side)
+    plain = not (layers or boundary)
+    t0 = time.perf_counter()
+    o = _ORACLES.get(key) if plain else None
+    if o is None:
+        o = oracle_ffi.Oracle(mesh)
+        if plain:
+            _ORACLES[key] = o
+    setup_s = time.perf_counter() - t0
+    o.set_points(mesh.points)
+    o.set_params(prm)
     if layers or boundary:
         from smoothmesh_amd import LayerParams, patch_arrays
         lp = layer_params(kind) if layers else LayerParams()
         st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches)
-        lopt = (lp.layerMaxBlendingFraction, p.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
+        lopt = (lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
         if boundary:
-            bp = boundary_params(kind, sample_n)
+            bp = boundary_params(kind, n_side)
             o.setup_boundary(st, sz, kd, sel, patch_arrays(mesh, bp.smoothingPatches)[3], lopt, bp.initEdges, bp.targetEdges, bp.targetSurfaces)
         else:
             o.setup_layers(st, sz, kd, sel, *lopt)
     t0 = time.perf_counter()
-    o.iterate(1, 0.0)
+    _, res1, frz1 = o.iterate(1, 0.0)            # first iteration untimed: it also first-touches the oracle's work arrays
     t1 = time.perf_counter() - t0
-    iters = max(2, min(40, int(budget_s / max(t1, 1e-3))))
+    iters = max(1, min(max_iters - 1, int(budget_s / max(t1, 1e-3))))
     t0 = time.perf_counter()
-    o.iterate(iters, 0.0)
+    _, res2, frz2 = o.iterate(iters, 0.0)
     dt = time.perf_counter() - t0
-    return {
+    n = 1 + iters
+    res_o, frz_o = np.concatenate([res1, res2]), np.concatenate([frz1, frz2])
+    pts_o = o.points()
+    if not plain:
+        o.close()
+    base = {
         "value": mesh.nPoints * iters / dt, "unit": "points/s", "cores": 1, "kind": "port",
-        "sample": f"{iters} iterations of the {kind}{sample_n} mesh ({mesh.nPoints} points, {mesh.nCells} cells), serial oracle "
-                  f"(g++ -O3 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
+        "sample": f"{iters} iterations (after one untimed) of this workload's own mesh ({mesh.nPoints} points, {mesh.nCells} cells), "
+                  f"serial oracle (g++ -O3 -ffp-contract=off), {dt:.1f} s; omits OpenFOAM overheads (movePoints, field rebuilds), "
                   f"so it is faster than the real reference"
                   + ("; with boundary point smoothing the oracle tests every target triangle per ray where OpenFOAM walks an "
                      "octree, so THIS number is slower than the real reference and no fair baseline" if boundary else ""),
-        "host_cpus": os.cpu_count(),
+        "host_cpus": os.cpu_count(), "oracle_setup_s": setup_s,
     }
+    # the engine: the same n iterations from the same coordinates
+    eng.set_points(mesh.points)
+    n_g, res_g, frz_g = eng.iterate(n, 0.0)
+    pts_g = eng.get_points()
+    denom = float(np.max(np.abs(pts_o)))
+    par = {
+        "iters": int(n), "against": "CPU oracle (oracle/), same mesh, same initial coordinates, same parameters",
+        "rel_linf": float(np.max(np.abs(pts_g - pts_o)) / (denom if denom > 0 else 1.0)),
+        "bitwise_equal": bool(np.array_equal(pts_g, pts_o)),
+        "nFrozen_equal": bool(n_g == n and np.array_equal(frz_g, frz_o)),
+        "residual_max_rel_diff": float(np.max(np.abs(res_g - res_o) / np.maximum(np.abs(res_o), 1e-300))) if n_g == n else None,
+        "nFrozenPoints": [int(x) for x in frz_g[:4]],
+        "tolerance": 1e-10,
+    }
+    par["ok"] = bool(par["rel_linf"] <= par["tolerance"] and par["nFrozen_equal"])
+    return base, par
 
 
 def workload_text(kind, n_side, constraints, layers, boundary, world=1, n_global=None):
@@ -140,52 +191,95 @@ def workload_text(kind, n_side, constraints, layers, boundary, world=1, n_global
                                                      else "the cavity wall onto the triangulated sphere") + ")" if boundary else ""))
 
 
+# The constraint evaluators run as a conservative f32 filter followed by the exact kernels on what the filter left open.
+# One pass of the evaluator over the mesh is the unit: its algorithmic bytes (every array element the exact algorithm touches
+# once) against the summed time of its kernels.  (Charging the post-filter exact kernels the full-array bytes -- as round 2's
+# table did -- printed bandwidths above the HBM peak for kernels that touch 2 % of the elements.)
+KERNEL_UNITS = [
+    ("edge_angle (filter + exact)", ["k_edge_angle_filter", "k_edge_angle"], ["k_edge_angle"]),
+    ("face_angles_current (filter + list compaction + exact edges + points)", ["k_fa_edges_filter", "k_fa_edges", "k_fa_points"],
+     ["k_fa_edges", "k_fa_points"]),
+]
+
+
 def kernel_report(workload, ctr, K, dt, dt_ev):
     """roofline objects + per-kernel table from the hipEvent counters of the second pass"""
     # HBM traffic per launch, measured separately under rocprofv3 --pmc (scripts/measure_traffic.sh) and
     # committed under profiles/; None when no measurement of this workload exists
     traffic = None
     tdoc = None
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{workload}.json")
         if os.path.exists(tpath):
             tdoc = json.load(open(tpath))
+            tdoc["_round"] = rnd
             break
+    by_name = {c["name"]: c for c in ctr}
     ctr = sorted(ctr, key=lambda c: -c["ms"])
-    # dominant device kernel (not pack/finish, not the walk stages whose cost is latency)
-    dom = [c for c in ctr if c["algoBytesPerLaunch"] > 1024 and c["name"] not in ("k_fa_walk", "k_fa_pred")][0]
-    avg_s = dom["ms"] / dom["launches"] * 1e-3
-    achieved = dom["algoBytesPerLaunch"] / avg_s / 1e9
-    if tdoc:
-        for kname, kv in tdoc["kernels"].items():
-            if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
-                traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
+
+    def us(c):
+        return c["ms"] / c["launches"] * 1e3
+
+    def roof(c):
+        """roofline object of one counter: HBM bytes when the kernel has an algorithmic byte count, else FP64 instructions"""
+        avg_s = us(c) * 1e-6
+        r = {"kernel": c["name"], "avg_launch_us": us(c)}
+        if c["algoBytesPerLaunch"] > 1024:
+            ach = c["algoBytesPerLaunch"] / avg_s / 1e9
+            r.update({"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                      "algorithmic_bytes_per_launch": int(c["algoBytesPerLaunch"])})
+        if c.get("algoF64OpsPerLaunch"):
+            v = {"algorithmic_ops_per_launch": int(c["algoF64OpsPerLaunch"]),
+                 "achieved_Tops": c["algoF64OpsPerLaunch"] / avg_s / 1e12, "peak_Tops": FP64_VALU_PEAK_TOPS,
+                 "frac": c["algoF64OpsPerLaunch"] / avg_s / 1e12 / FP64_VALU_PEAK_TOPS}
+            if "bound" in r:
+                r["valu_f64"] = v
+            else:   # no streaming byte count: priced against the FP64 vector instruction rate only
+                r.update({"bound": "valu_f64", "achieved": v["achieved_Tops"], "peak": FP64_VALU_PEAK_TOPS, "unit": "T FP64 instr/s",
+                          "frac": v["frac"], "algorithmic_ops_per_launch": v["algorithmic_ops_per_launch"]})
+        return r
+
+    # dominant device kernel = the largest total time among the kernels that carry an algorithmic count (no name is excluded)
+    cand = [c for c in ctr if c["algoBytesPerLaunch"] > 1024 or c.get("algoF64OpsPerLaunch")]
+    roofline = None
+    if cand:
+        dom = cand[0]
+        roofline = roof(dom)
+        if tdoc:
+            for kname, kv in tdoc["kernels"].items():
+                if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
+                    traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
+                    roofline["traffic_source"] = f"profiles/{tdoc['_round']}/traffic_{workload}.json"
+        roofline["traffic"] = traffic
+        roofline["note"] = ("per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
+                            "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
+                            "cache-level throughput, not as an HBM-roofline test; valu_f64 = the rate of ALGORITHMIC FP64 instructions "
+                            "(sqrt = 22, division = 11 as expanded, no FMA contraction) against 256 CUs x 64 lanes x 2.4 GHz")
     gather = next((c for c in ctr if c["name"].startswith("k_smooth")), None)
+    rows = []
+    grouped = set()
+    for label, members, byte_src in KERNEL_UNITS:
+        mem = [by_name[m] for m in members if m in by_name]
+        if not mem:
+            continue
+        grouped.update(c["name"] for c in mem)
+        t_us = sum(us(c) for c in mem)
+        nbytes = sum(by_name[m]["algoBytesPerLaunch"] for m in byte_src if m in by_name)
+        rows.append({"name": label, "kernels": {c["name"]: us(c) for c in mem}, "launches": int(max(c["launches"] for c in mem)),
+                     "avg_us": t_us, "algo_GBps": nbytes / (t_us * 1e-6) / 1e9 if nbytes else None, "_ms": sum(c["ms"] for c in mem)})
+    for c in ctr:
+        if c["name"] in grouped:
+            continue
+        rows.append({"name": c["name"], "launches": int(c["launches"]), "avg_us": us(c),
+                     "algo_GBps": c["algoBytesPerLaunch"] / (us(c) * 1e-6) / 1e9 if c["algoBytesPerLaunch"] > 1024 else None,
+                     **({"algo_f64_Tops": c["algoF64OpsPerLaunch"] / (us(c) * 1e-6) / 1e12} if c.get("algoF64OpsPerLaunch") else {}),
+                     "_ms": c["ms"]})
+    rows.sort(key=lambda r: -r.pop("_ms"))
     return {
-        "roofline": {
-            "bound": "hbm", "kernel": dom["name"], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-            "algorithmic_bytes_per_launch": int(dom["algoBytesPerLaunch"]),
-            "avg_launch_us": avg_s * 1e6,
-            # the geometry kernel is FP64-VALU bound, not HBM bound: its rate of algorithmic FP64 instructions (per
-            # element; sqrt = 22, division = 11 as expanded; no FMA contraction, as the reference's x86-64 build)
-            # against the chip's FP64 vector instruction rate (256 CUs x 64 lanes x 2.4 GHz = 39.3 T/s = 78.6 TFLOP/s FMA)
-            **({"valu_f64": {"algorithmic_ops_per_launch": int(dom["algoF64OpsPerLaunch"]),
-                             "achieved_Tops": dom["algoF64OpsPerLaunch"] / avg_s / 1e12, "peak_Tops": FP64_VALU_PEAK_TOPS,
-                             "frac": dom["algoF64OpsPerLaunch"] / avg_s / 1e12 / FP64_VALU_PEAK_TOPS}}
-               if dom.get("algoF64OpsPerLaunch") else {}),
-            "note": "per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
-                    "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
-                    "cache-level throughput, not as an HBM-roofline test",
-        },
+        "roofline": roofline,
         "roofline_centroid_gather": None if gather is None else {
-            "bound": "hbm", "kernel": gather["name"], "achieved": gather["algoBytesPerLaunch"] / (gather["ms"] / gather["launches"] * 1e-3) / 1e9,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": gather["algoBytesPerLaunch"] / (gather["ms"] / gather["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names)"},
-        "kernels": [
-            {"name": c["name"], "launches": int(c["launches"]), "avg_us": c["ms"] / c["launches"] * 1e3,
-             "algo_GBps": c["algoBytesPerLaunch"] / (c["ms"] / c["launches"] * 1e-3) / 1e9} for c in ctr],
+            **roof(gather), "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names)"},
+        "kernels": rows,
         "ms_per_step_with_events": dt_ev / K * 1e3,
     }
 
@@ -220,13 +314,18 @@ def clock_warm(iterate, engine, sync, fixed=0):
     return done
 
 
-def run_single(workload, K, W, device):
-    """one GPU, one workload: K timed steps (inputs resident), then the same K steps again with per-kernel hipEvents"""
+def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
+    """one GPU, one workload: W warm-up + K timed steps on a cold GPU (ms_per_step_cold), the clock pre-run, W + K again (the
+    reported value; inputs resident), the same K steps with per-kernel hipEvents, and -- outside every timed region -- the
+    oracle leg (parity_check + cpu_baseline on this workload's own mesh)"""
     import torch
     from smoothmesh_amd import SmoothEngine, default_params
     kind, n_side, constraints = parse_workload(workload)
     layers, boundary = workload_layers(workload), workload_boundary(workload)
-    mesh = make_mesh(kind, n_side)
+    t_setup = time.perf_counter()
+    mesh = get_mesh(kind, n_side)
+    t_mesh = time.perf_counter() - t_setup
+    t0 = time.perf_counter()
     eng = SmoothEngine(mesh, device=device)
     prm = default_params(eng.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     eng.set_params(prm)
@@ -234,15 +333,23 @@ def run_single(workload, K, W, device):
         raise SystemExit("boundary layer treatment could not be enabled")
     if boundary and not eng.set_boundary_smoothing(boundary_params(kind, n_side), prm.minEdgeLength)["enabled"]:
         raise SystemExit("boundary point smoothing could not be enabled")
+    t_create = time.perf_counter() - t0
+
+    def timed():
+        if W:
+            eng.iterate(W, 0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n, res, frz = eng.iterate(K, 0.0)          # returns after the stream has drained
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert n == K
+        return dt, res, frz
+
+    dt_cold, _, _ = timed()                        # exactly the contract's W + K on a GPU that has just left its idle clocks
+    eng.set_points(mesh.points)
     pre = clock_warm(lambda k: eng.iterate(k, 0.0), eng, torch.cuda.synchronize)
-    if W:
-        eng.iterate(W, 0.0)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    n, res, frz = eng.iterate(K, 0.0)          # returns after the stream has drained
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert n == K
+    dt, res, frz = timed()
     # second pass over the same K steps with per-kernel hipEvent brackets (on the engine's stream)
     eng.reset_counters()
     eng.enable_timing(True)
@@ -253,10 +360,16 @@ def run_single(workload, K, W, device):
     ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
     sizes = eng.sizes()
     nPoints = mesh.nPoints
+    base = par = None
+    t0 = time.perf_counter()
+    if oracle:
+        base, par = oracle_leg(kind, n_side, constraints, eng, prm, budget_s=oracle_budget_s, layers=layers, boundary=boundary)
+    t_oracle = time.perf_counter() - t0
     eng.close()
-    del eng, mesh
-    return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_ev=dt_ev, ctr=ctr,
-                sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre)
+    del eng
+    return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_cold=dt_cold, dt_ev=dt_ev,
+                ctr=ctr, sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par,
+                phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
 
 
 def self_launch(args):
@@ -289,7 +402,10 @@ def main():
     ap.add_argument("--configs", default=None, help="comma-separated workloads reported under \"configs\" (N = 1); "
                     "default with the default workload: hex100c,cavity215,cavity215c")
     ap.add_argument("--no-configs", action="store_true")
-    ap.add_argument("--config-steps", type=int, default=30)
+    ap.add_argument("--config-steps", type=int, default=0, help="steps of the configs[] sub-runs; 0 = BASELINE.json's counts "
+                    "(100 on the hex block, 200 on the polyhedral mesh)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the oracle legs of the configs[] sub-runs (the 10 M-cell "
+                    "oracle costs minutes of host time)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -313,6 +429,7 @@ def main():
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
     n_global = None
+    single = None
 
     # SMOOTHMESH_FORCE_DIST=1: run the N=1 case through the multi-rank code path (host-overhead measurements)
     force_dist = world == 1 and bool(os.environ.get("SMOOTHMESH_FORCE_DIST"))
@@ -320,9 +437,10 @@ def main():
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
             os.environ.setdefault(k, v)
     if world == 1 and not force_dist:
-        r = run_single(args.workload, K, W, local_rank)
+        r = run_single(args.workload, K, W, local_rank, oracle=not args.no_cpu_baseline)
         dt, dt_ev, ctr, sizes, total_points, res, frz = r["dt"], r["dt_ev"], r["ctr"], r["sizes"], r["total_points"], r["res"], r["frz"]
         pre = r["pre"]
+        single = r
         parallelism = "1 GPU"
     else:
         import torch.distributed as dist
@@ -405,13 +523,15 @@ def main():
         "steps": K,
         "warmup": W,
         "ms_per_step": dt / K * 1e3,
+        **({"ms_per_step_cold": single["dt_cold"] / K * 1e3} if single else {}),
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "pre_run": {"iterations": int(pre), "note": "the workload itself, untimed, before the W warm-up steps (GPU clocks up); "
-                    "coordinates reset to the initial ones afterwards"},
+                    "coordinates reset to the initial ones afterwards; ms_per_step_cold = the same W + K steps timed BEFORE it "
+                    "(first launches after set-up, GPU leaving its idle clocks)"},
         "config": {
             "workload": workload_text(kind, n_side, constraints, layers, boundary, world, n_global),
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
@@ -430,21 +550,38 @@ def main():
         subs = []
         for wl in [w for w in names if w]:
             t0 = time.perf_counter()
-            Kc = args.config_steps
-            r = run_single(wl, Kc, min(W, 5), local_rank)
-            subs.append({
-                "workload": wl, "config": workload_text(r["kind"], r["n_side"], r["constraints"], r["layers"], r["boundary"]),
-                "points": int(r["total_points"]), "cells": int(r["sizes"]["nCells"]), "steps": Kc,
-                "ms_per_step": r["dt"] / Kc * 1e3, "value": r["total_points"] * Kc / r["dt"], "unit": "points/s",
-                **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"]),
-                "residual_last": float(r["res"][-1]), "nFrozenPoints_last": int(r["frz"][-1]),
-                "wall_s_including_setup": time.perf_counter() - t0,
-            })
+            try:
+                k_, _, _ = parse_workload(wl)
+                Kc = args.config_steps or (100 if k_ == "hex" else 200)
+                r = run_single(wl, Kc, min(W, 5), local_rank, oracle=not (args.no_parity or args.no_cpu_baseline),
+                               oracle_budget_s=10.0 if k_ == "hex" else 30.0)
+                sub = {
+                    "workload": wl, "config": workload_text(r["kind"], r["n_side"], r["constraints"], r["layers"], r["boundary"]),
+                    "points": int(r["total_points"]), "cells": int(r["sizes"]["nCells"]), "steps": Kc,
+                    "ms_per_step": r["dt"] / Kc * 1e3, "ms_per_step_cold": r["dt_cold"] / Kc * 1e3,
+                    "value": r["total_points"] * Kc / r["dt"], "unit": "points/s",
+                    **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"]),
+                    "residual_last": float(r["res"][-1]), "nFrozenPoints_last": int(r["frz"][-1]),
+                    "phases": r["phases"],
+                }
+                if r["cpu_baseline"]:
+                    sub["cpu_baseline"] = r["cpu_baseline"]
+                    sub["speedup_vs_cpu_baseline"] = sub["value"] / r["cpu_baseline"]["value"]
+                    sub["parity_check"] = r["parity_check"]
+            except Exception as ex:          # a failing sub-run must not take the headline line with it
+                sub = {"workload": wl, "error": f"{type(ex).__name__}: {ex}"}
+            sub["wall_s_including_setup"] = time.perf_counter() - t0
+            subs.append(sub)
         if subs:
             out["configs"] = subs
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(kind, n_side, constraints, layers=layers, boundary=boundary)
+        if single and single["cpu_baseline"]:
+            out["cpu_baseline"] = single["cpu_baseline"]
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            out["parity_check"] = single["parity_check"]
+            out["parity"] = ("HIP == CPU oracle: parity_check (this run, this mesh) + tests/; the oracle restates the reference and is "
+                             "unpinned against a real OpenFOAM build")
+        if single:
+            out["phases"] = single["phases"]
     print(json.dumps(out))
     if world > 1 or force_dist:
         import torch.distributed as dist

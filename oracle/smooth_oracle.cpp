@@ -10,7 +10,11 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
+#include <future>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <numeric>
 #include <stack>
@@ -76,96 +80,131 @@ static int findIndex(const std::vector<int>& l, int v) {
 
 void Domain::build() {
     error.clear();
+    const bool verbose = std::getenv("ORACLE_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (verbose) std::fprintf(stderr, "[oracle] build: %-18s done at %.2f s\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     nFaces = int(faces.size());
     nInternalFaces = int(neighbour.size());
 
-    // OpenFOAM primitiveMesh::calcCells: owned faces ascending, then neighboured faces ascending
-    std::vector<std::vector<int>> cells(nCells);
-    for (int f = 0; f < nFaces; ++f) cells[owner[f]].push_back(f);
-    for (int f = 0; f < nInternalFaces; ++f) cells[neighbour[f]].push_back(f);
-
-    // cellPoints: cell::labels(faces) = first-appearance order walking the cell's faces
-    cellPoints.assign(nCells, {});
-    for (int c = 0; c < nCells; ++c)
-        for (int f : cells[c])
-            for (int p : faces[f])
-                if (findIndex(cellPoints[c], p) < 0) cellPoints[c].push_back(p);
-
-    // pointCells: OpenFOAM calcPointCells walks cells ascending -> ascending cell id
-    pointCells.assign(nPoints, {});
-    for (int c = 0; c < nCells; ++c)
-        for (int p : cellPoints[c]) pointCells[p].push_back(c);
-
-    // pointFaces: invertManyToMany(nPoints, faces) -> ascending face id
-    pointFaces.assign(nPoints, {});
-    for (int f = 0; f < nFaces; ++f)
-        for (int p : faces[f]) pointFaces[p].push_back(f);
-
-    // edges: OpenFOAM primitiveMesh::calcEdges, unsorted-points branch (nInternalPoints_ == -1):
-    // edges stored (min,max) and renumbered into upper-triangular order (start ascending,
-    // then end ascending); pointEdges sorted ascending; pointPoints[p][i] = other end of
-    // pointEdges[p][i]  (=> ascending neighbour point id).
-    std::map<std::pair<int, int>, int> edgeMap;
-    for (int f = 0; f < nFaces; ++f) {
-        const auto& fp = faces[f];
-        const int n = int(fp.size());
-        for (int i = 0; i < n; ++i) {
-            const int a = fp[i], b = fp[(i + 1) % n];
-            edgeMap.emplace(std::make_pair(std::min(a, b), std::max(a, b)), 0);
+    // The tables below are three independent chains over (faces, owner, neighbour); each is built exactly as before,
+    // sequentially in itself, on a host thread of its own (set-up time only: 10 M-cell meshes took minutes).
+    auto chainCells = [&] {
+        // OpenFOAM primitiveMesh::calcCells: owned faces ascending, then neighboured faces ascending
+        std::vector<std::vector<int>> cells(nCells);
+        for (int f = 0; f < nFaces; ++f) cells[owner[f]].push_back(f);
+        for (int f = 0; f < nInternalFaces; ++f) cells[neighbour[f]].push_back(f);
+        // cellPoints: cell::labels(faces) = first-appearance order walking the cell's faces
+        cellPoints.assign(nCells, {});
+        for (int c = 0; c < nCells; ++c)
+            for (int f : cells[c])
+                for (int p : faces[f])
+                    if (findIndex(cellPoints[c], p) < 0) cellPoints[c].push_back(p);
+        lap("cellPoints");
+        // pointCells: OpenFOAM calcPointCells walks cells ascending -> ascending cell id
+        pointCells.assign(nPoints, {});
+        for (int c = 0; c < nCells; ++c)
+            for (int p : cellPoints[c]) pointCells[p].push_back(c);
+        lap("pointCells");
+        // SM.C:190-217 generatePointNeighPoints
+        pointNeighPoints.assign(nPoints, {});
+        for (int p = 0; p < nPoints; ++p)
+            for (int c : pointCells[p])
+                for (int q : cellPoints[c]) {
+                    if (p == q) continue;
+                    if (findIndex(pointNeighPoints[p], q) == -1) pointNeighPoints[p].push_back(q);
+                }
+        lap("pointNeighPoints");
+    };
+    auto chainFaces = [&] {
+        // pointFaces: invertManyToMany(nPoints, faces) -> ascending face id
+        pointFaces.assign(nPoints, {});
+        for (int f = 0; f < nFaces; ++f)
+            for (int p : faces[f]) pointFaces[p].push_back(f);
+        lap("pointFaces");
+        // SM.C:1575-1620 generateCellFaces: internal faces by owner, internal faces by neighbour,
+        // then boundary faces patch by patch (= ascending face id)
+        cellFaces.assign(nCells, {});
+        for (int f = 0; f < nInternalFaces; ++f) cellFaces[owner[f]].push_back(f);
+        for (int f = 0; f < nInternalFaces; ++f) cellFaces[neighbour[f]].push_back(f);
+        for (int f = nInternalFaces; f < nFaces; ++f) cellFaces[owner[f]].push_back(f);
+        lap("cellFaces");
+    };
+    auto chainEdges = [&] {
+        // edges: OpenFOAM primitiveMesh::calcEdges, unsorted-points branch (nInternalPoints_ == -1):
+        // edges stored (min,max) and renumbered into upper-triangular order (start ascending,
+        // then end ascending); pointEdges sorted ascending; pointPoints[p][i] = other end of
+        // pointEdges[p][i]  (=> ascending neighbour point id).
+        // (built as a sorted list of (min, max) keys rather than an ordered map: the same order -- lexicographic in
+        // (start, end) -- at a fraction of the set-up time; edgeStart[a] = first edge starting at a)
+        std::vector<uint64_t> keys;
+        {
+            size_t nnz = 0;
+            for (int f = 0; f < nFaces; ++f) nnz += faces[f].size();
+            keys.reserve(nnz);
         }
-    }
-    edges.clear();
-    edges.reserve(edgeMap.size());
-    for (auto& kv : edgeMap) {
-        kv.second = int(edges.size());
-        edges.push_back({kv.first.first, kv.first.second});
-    }
-    const int nEdges = int(edges.size());
-    pointEdges.assign(nPoints, {});
-    for (int e = 0; e < nEdges; ++e) {
-        pointEdges[edges[e][0]].push_back(e);
-        pointEdges[edges[e][1]].push_back(e);
-    }
-    pointPoints.assign(nPoints, {});
-    for (int p = 0; p < nPoints; ++p)
-        for (int e : pointEdges[p]) pointPoints[p].push_back(edges[e][0] == p ? edges[e][1] : edges[e][0]);
-
-    // edgeFaces: ascending face id
-    edgeFaces.assign(nEdges, {});
-    for (int f = 0; f < nFaces; ++f) {
-        const auto& fp = faces[f];
-        const int n = int(fp.size());
-        for (int i = 0; i < n; ++i) {
-            const int a = fp[i], b = fp[(i + 1) % n];
-            const int e = edgeMap[std::make_pair(std::min(a, b), std::max(a, b))];
-            edgeFaces[e].push_back(f);
-        }
-    }
-    // edgeCells: primitiveMesh::edgeCells(edgeI, storage) on-the-fly form = first appearance
-    // walking edgeFaces (owner then neighbour).  Only min/max reductions consume it.
-    edgeCells.assign(nEdges, {});
-    for (int e = 0; e < nEdges; ++e)
-        for (int f : edgeFaces[e]) {
-            if (findIndex(edgeCells[e], owner[f]) < 0) edgeCells[e].push_back(owner[f]);
-            if (f < nInternalFaces && findIndex(edgeCells[e], neighbour[f]) < 0) edgeCells[e].push_back(neighbour[f]);
-        }
-
-    // SM.C:1575-1620 generateCellFaces: internal faces by owner, internal faces by neighbour,
-    // then boundary faces patch by patch (= ascending face id)
-    cellFaces.assign(nCells, {});
-    for (int f = 0; f < nInternalFaces; ++f) cellFaces[owner[f]].push_back(f);
-    for (int f = 0; f < nInternalFaces; ++f) cellFaces[neighbour[f]].push_back(f);
-    for (int f = nInternalFaces; f < nFaces; ++f) cellFaces[owner[f]].push_back(f);
-
-    // SM.C:190-217 generatePointNeighPoints
-    pointNeighPoints.assign(nPoints, {});
-    for (int p = 0; p < nPoints; ++p)
-        for (int c : pointCells[p])
-            for (int q : cellPoints[c]) {
-                if (p == q) continue;
-                if (findIndex(pointNeighPoints[p], q) == -1) pointNeighPoints[p].push_back(q);
+        for (int f = 0; f < nFaces; ++f) {
+            const auto& fp = faces[f];
+            const int n = int(fp.size());
+            for (int i = 0; i < n; ++i) {
+                const int a = fp[i], b = fp[(i + 1) % n];
+                keys.push_back((uint64_t(uint32_t(std::min(a, b))) << 32) | uint32_t(std::max(a, b)));
             }
-
+        }
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        edges.clear();
+        edges.reserve(keys.size());
+        std::vector<int> edgeStart(size_t(nPoints) + 1, 0);
+        for (uint64_t k : keys) {
+            edges.push_back({int(k >> 32), int(k & 0xffffffffu)});
+            ++edgeStart[size_t(k >> 32) + 1];
+        }
+        for (int p = 0; p < nPoints; ++p) edgeStart[size_t(p) + 1] += edgeStart[size_t(p)];
+        { std::vector<uint64_t>().swap(keys); }
+        auto findEdge = [&](int a, int b) -> int {
+            const int lo = std::min(a, b), hi = std::max(a, b);
+            for (int e = edgeStart[size_t(lo)]; e < edgeStart[size_t(lo) + 1]; ++e)
+                if (edges[e][1] == hi) return e;
+            return -1;
+        };
+        const int nEdges = int(edges.size());
+        pointEdges.assign(nPoints, {});
+        for (int e = 0; e < nEdges; ++e) {
+            pointEdges[edges[e][0]].push_back(e);
+            pointEdges[edges[e][1]].push_back(e);
+        }
+        pointPoints.assign(nPoints, {});
+        for (int p = 0; p < nPoints; ++p)
+            for (int e : pointEdges[p]) pointPoints[p].push_back(edges[e][0] == p ? edges[e][1] : edges[e][0]);
+        lap("edges/pointEdges");
+        // edgeFaces: ascending face id
+        edgeFaces.assign(nEdges, {});
+        for (int f = 0; f < nFaces; ++f) {
+            const auto& fp = faces[f];
+            const int n = int(fp.size());
+            for (int i = 0; i < n; ++i) edgeFaces[findEdge(fp[i], fp[(i + 1) % n])].push_back(f);
+        }
+        lap("edgeFaces");
+        // edgeCells: primitiveMesh::edgeCells(edgeI, storage) on-the-fly form = first appearance
+        // walking edgeFaces (owner then neighbour).  Only min/max reductions consume it.
+        edgeCells.assign(nEdges, {});
+        for (int e = 0; e < nEdges; ++e)
+            for (int f : edgeFaces[e]) {
+                if (findIndex(edgeCells[e], owner[f]) < 0) edgeCells[e].push_back(owner[f]);
+                if (f < nInternalFaces && findIndex(edgeCells[e], neighbour[f]) < 0) edgeCells[e].push_back(neighbour[f]);
+            }
+        lap("edgeCells");
+    };
+    if (nFaces < 200000 || std::getenv("ORACLE_SERIAL_BUILD")) {
+        chainCells(); chainFaces(); chainEdges();
+    } else {
+        auto f1 = std::async(std::launch::async, chainCells);
+        auto f2 = std::async(std::launch::async, chainFaces);
+        chainEdges();
+        f1.get(); f2.get();
+    }
     isFrozenPoint.assign(nPoints, 0);
 }
 

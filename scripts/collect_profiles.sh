@@ -1,13 +1,13 @@
 #!/bin/bash
 # run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
-# usage: scripts/collect_profiles.sh [round tag, default r2]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
-tag=${1:-r2}
+# usage: scripts/collect_profiles.sh [round tag, default r3]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+tag=${1:-r3}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
 cd $root
 B="timeout 300 python bench.py"
-$B > $out/bench_default.json 2>$out/bench.err                                   # hex100 + configs[] (hex100c, cavity215, cavity215c) + cpu_baseline
+timeout 1500 python bench.py > $out/bench_default.json 2>$out/bench.err                                   # hex100 + configs[] (hex100c, cavity215, cavity215c) + cpu_baseline
 $B --workload hex100c --no-configs > $out/bench_hex100c.json 2>>$out/bench.err
 $B --workload hex215 --no-cpu-baseline --no-configs --steps 50 --warmup 5 > $out/bench_hex215.json 2>>$out/bench.err
 $B --workload hex300 --no-cpu-baseline --no-configs --steps 20 --warmup 2 > $out/bench_hex300.json 2>>$out/bench.err
@@ -18,14 +18,15 @@ $B --workload hex100L --no-configs --steps 50 --warmup 5 > $out/bench_hex100L.js
 $B --workload hex100B --no-configs --steps 50 --warmup 5 > $out/bench_hex100B.json 2>>$out/bench.err
 SMGPU_WALK=host $B --workload cavity215c --no-cpu-baseline --no-configs --steps 30 --warmup 5 > $out/bench_cavity215c_hostwalk.json 2>>$out/bench.err  # round-1 replay place, A/B
 cd /tmp && export TMPDIR=/tmp
-for wl in hex100 hex100c cavity215c; do
+for wl in hex100 hex100c cavity215 cavity215c; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/rocprof_$wl -o p -- python3 $root/bench.py --no-cpu-baseline --no-configs --workload $wl --steps 50 --warmup 5 > /dev/null 2>&1
-  cp $out/rocprof_$wl/p_kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv
+  cp $out/rocprof_$wl/*/p_kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv 2>/dev/null
+  cp $out/rocprof_$wl/p_kernel_stats.csv $out/rocprof_${wl}_kernel_stats.csv 2>/dev/null
   rm -rf $out/rocprof_$wl
 done
 cd $root
 export SMGPU_SIDE_STREAM=0   # counter collection serialises kernels: no cross-stream waits
-for wl in hex100 hex215; do
+for wl in hex100 hex215 cavity215 cavity215c; do
   BENCH_EXTRA="--no-configs" timeout 600 bash scripts/measure_traffic.sh $wl 10 > /dev/null 2>&1
   cp gpurun_out/traffic_$wl.json $out/ 2>/dev/null
 done

@@ -665,14 +665,70 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges(MeshView m, State s, const 
     faEdgeExact(m, s, e);
 }
 
+// ---- ordered compaction of marked points without a scan launch ------------------------------------------------------------
+// A workgroup owns a chunk of kChunk = 4096 consecutive points, 16 per thread: the thread's mark bytes are ONE 16-byte load
+// (round 2 used one thread per point: 10 M threads each loading a byte, shuffling and synchronising -- 146 + 255 us for
+// k_fa_list_count / fill on the 10 M-point mesh, plus a single-workgroup scan launch over 40 k block counts, 76 us).  A count
+// launch leaves two numbers per chunk (marked points, entries they list); the fill launch computes its own offsets: every
+// workgroup sums the counts of the chunks before it (2 479 of them on a 10 M-point mesh: ten loads per thread) -- what a scan
+// launch in between would deliver, without the launch and without any cross-workgroup hand-off inside a kernel.  The last
+// workgroup leaves the totals.  Lists come out in ascending point order.
+constexpr int kChunkPer = 16;
+constexpr int kChunk = kBlock * kChunkPer;
+inline int chunkGrid(int64_t n) { return (int)((n + kChunk - 1) / kChunk); }
+// the 16 mark bytes of this thread's points (zeros beyond the end; the mark arrays are allocated with 16 spare bytes)
+__device__ __forceinline__ uint4 chunkMarks(const uint8_t* marks, int base, int n) {
+    return (base < n) ? *reinterpret_cast<const uint4*>(marks + base) : make_uint4(0u, 0u, 0u, 0u);
+}
+__device__ __forceinline__ unsigned chunkByte(const uint4& q, int i) {
+    const unsigned wsel = (i >> 2) == 0 ? q.x : (i >> 2) == 1 ? q.y : (i >> 2) == 2 ? q.z : q.w;
+    return (wsel >> (8 * (i & 3))) & 0xffu;
+}
+// sums over the workgroup; every thread gets them
+__device__ __forceinline__ void chunkReduce2(int& a, int& e) {
+    __shared__ int sh[2 * (kBlock / 64)];
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); e += __shfl_xor(e, o, 64); }
+    __syncthreads();   // (a previous use of sh has been read)
+    if ((threadIdx.x & 63) == 0) { sh[threadIdx.x >> 6] = a; sh[kBlock / 64 + (threadIdx.x >> 6)] = e; }
+    __syncthreads();
+    a = e = 0;
+    for (int i = 0; i < kBlock / 64; ++i) { a += sh[i]; e += sh[kBlock / 64 + i]; }
+}
+// sums of the chunk counts of the workgroups [0, b) and -- all != 0 -- of all nBlk workgroups
+__device__ __forceinline__ void chunkPrefix2(const int* blkA, const int* blkE, int b, int nBlk, bool all, int& pa, int& pe, int& ta, int& te) {
+    int a = 0, e = 0, a2 = 0, e2 = 0;
+    for (int i = threadIdx.x; i < (all ? nBlk : b); i += kBlock) {
+        const int va = blkA[i], ve = blkE[i];
+        if (i < b) { a += va; e += ve; }
+        a2 += va; e2 += ve;
+    }
+    chunkReduce2(a, e);
+    pa = a; pe = e;
+    if (all) { chunkReduce2(a2, e2); ta = a2; te = e2; }
+}
+// exclusive scan of (a, e) over the workgroup's threads in thread order
+__device__ __forceinline__ void chunkScan2(int a, int e, int& xa, int& xe) {
+    __shared__ int sw[2 * (kBlock / 64)];
+    int ia = a, ie = e;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
+        if (lane >= o) { ia += ta; ie += te; }
+    }
+    __syncthreads();
+    if (lane == 63) { sw[wv] = ia; sw[kBlock / 64 + wv] = ie; }
+    __syncthreads();
+    xa = ia - a; xe = ie - e;
+    for (int k = 0; k < wv; ++k) { xa += sw[k]; xe += sw[kBlock / 64 + k]; }
+}
+
 // With the filter on, what needs the exact evaluation is sparse (the end points of the UNSURE edges and all their edges:
 // 2 % of a 10 M-cell refinement-interface mesh, nothing on a good hex block), but one thread per edge asking "is one of my
 // end points marked?" costs two random byte gathers for each of the 30 M edges (0.56 ms).  So the marked points list
 // themselves and their edges (every edge once: by its lower marked end point), and the exact kernels run on the lists.
 // Listing without atomics (a returning atomic on one counter word runs at ~90 per microsecond chip-wide, wave-aggregated or
-// not: 2 ms for this mesh): per 256-point block the numbers of marked points and of the edges they list (k_fa_list_count),
-// one exclusive scan over the blocks (k_walk_scan of kernels_walk.hpp, which leaves the totals in acc->nFaPts / nFaEdges),
-// then every block writes its ids at its offsets (k_fa_list_fill).  An edge is listed by its marked end point -- the lower
+// not: 2 ms for this mesh): count per chunk (k_fa_list_count), then every chunk writes its ids at its offsets
+// (k_fa_list_fill, which leaves the totals in acc->nFaPts / nFaEdges).  An edge is listed by its marked end point -- the lower
 // one when both are; the lists come out in point order, so the exact kernel's gathers stay local.
 __device__ __forceinline__ int faListedEdges(const MeshView& m, const State& s, const uint8_t* faMaybe, int p, int* out) {
     int n = 0;
@@ -684,41 +740,45 @@ __device__ __forceinline__ int faListedEdges(const MeshView& m, const State& s, 
 }
 __global__ void __launch_bounds__(kBlock) k_fa_list_count(MeshView m, State s, const uint8_t* faMaybe, int* blkA, int* blkE) {
     if (s.acc->stop) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    if (s.acc->nFaMaybe == 0) return;                  // the filter found every edge inside the good range: no lists
+    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
+    const uint4 q = chunkMarks(faMaybe, base, m.nPoints);
     int a = 0, e = 0;
-    if (s.acc->nFaMaybe != 0 && p < m.nPoints && faMaybe[p] == s.faGen) { a = 1; e = faListedEdges(m, s, faMaybe, p, nullptr); }
-    __shared__ int sa[kBlock / 64], se[kBlock / 64];
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); e += __shfl_down(e, o, 64); }
-    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; se[threadIdx.x >> 6] = e; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ta = 0, te = 0;
-        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
-        blkA[blockIdx.x] = ta;
-        blkE[blockIdx.x] = te;
+    if (q.x | q.y | q.z | q.w) {
+        for (int i = 0; i < kChunkPer; ++i)
+            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ++a; e += faListedEdges(m, s, faMaybe, base + i, nullptr); }
     }
+    chunkReduce2(a, e);
+    if (threadIdx.x == 0) { blkA[blockIdx.x] = a; blkE[blockIdx.x] = e; }
 }
 __global__ void __launch_bounds__(kBlock) k_fa_list_fill(MeshView m, State s, const uint8_t* faMaybe, const int* blkA, const int* blkE) {
     if (s.acc->stop) return;
-    if (s.acc->nFaPts == 0) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool marked = p < m.nPoints && faMaybe[p] == s.faGen;
-    const int a = marked ? 1 : 0, e = marked ? faListedEdges(m, s, faMaybe, p, nullptr) : 0;
-    int ia = a, ie = e;
-    const int lane = threadIdx.x & 63;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
-        if (lane >= o) { ia += ta; ie += te; }
+    if (s.acc->nFaMaybe == 0) return;                  // nFaPts / nFaEdges stay 0 (reset at the end of every iteration)
+    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
+    const uint4 q = chunkMarks(faMaybe, base, m.nPoints);
+    int a = 0, e = 0;
+    int ne[kChunkPer];
+    if (q.x | q.y | q.z | q.w) {
+#pragma unroll
+        for (int i = 0; i < kChunkPer; ++i) {
+            ne[i] = -1;
+            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ne[i] = faListedEdges(m, s, faMaybe, base + i, nullptr); ++a; e += ne[i]; }
+        }
     }
-    __shared__ int wa[kBlock / 64], we[kBlock / 64];
-    if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
-    __syncthreads();
-    int offA = blkA[blockIdx.x], offE = blkE[blockIdx.x];
-    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
-    if (marked) {
-        s.faPointList[offA + ia - 1] = p;
-        (void)faListedEdges(m, s, faMaybe, p, s.faEdgeList + (offE + ie - e));
+    int xa, xe, pa, pe, ta, te;
+    chunkScan2(a, e, xa, xe);
+    chunkPrefix2(blkA, blkE, (int)blockIdx.x, (int)gridDim.x, false, pa, pe, ta, te);
+    if (a) {
+        int oa = pa + xa, oe = pe + xe;
+#pragma unroll
+        for (int i = 0; i < kChunkPer; ++i) {
+            if (ne[i] < 0) continue;
+            s.faPointList[oa++] = base + i;
+            (void)faListedEdges(m, s, faMaybe, base + i, s.faEdgeList + oe);
+            oe += ne[i];
+        }
     }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { s.acc->nFaPts = pa + xa + a; s.acc->nFaEdges = pe + xe + e; }
 }
 __global__ void __launch_bounds__(kBlock) k_fa_edges_list(MeshView m, State s) {
     if (s.acc->stop) return;
@@ -740,7 +800,10 @@ __device__ __forceinline__ void faPointMinMax(const MeshView& m, const State& s,
     s.ptMax[p] = mx;
     const bool good = (mn > prm.smallAngle) && (mx < prm.largeAngle);
     s.faActive[p] = good ? 0 : s.faGen;
-    if (!good) atomicAdd(&s.acc->nActive, 1);
+    // one add per wave (the lanes that are here together), not one per point: 136 k same-address atomics per iteration on the
+    // 10 M-cell cavity mesh otherwise
+    const unsigned long long bad = __ballot(!good);
+    if (bad && (int)(threadIdx.x & 63) == __ffsll((long long)bad) - 1) atomicAdd(&s.acc->nActive, __popcll(bad));
 }
 __global__ void __launch_bounds__(kBlock) k_fa_points(MeshView m, State s, Prm prm, const uint8_t* faMaybe) {
     if (s.acc->stop) return;

@@ -4,7 +4,7 @@
 //
 // The walk itself is inherently sequential (LIFO stack, reads and writes isFrozenPoint as it goes), but
 // everything expensive in it is a pure function of (current coordinates, proposals).  So:
-//   1. k_walk_count / k_walk_scan / k_walk_fill : ordered compaction of the active points (ascending
+//   1. k_walk_count / k_walk_fill : ordered compaction of the active points (ascending
 //      point id) and of their pointPoints rows into dense tables;
 //   2. k_walk_pred : one thread per table entry evaluates the geometric predicates in parallel
 //      (self-deterioration, and for every neighbour "its move hurts me" with me at my proposal / at my
@@ -81,85 +81,52 @@ struct FixView {
     int* flags;           // [3] rotating "something changed" words
 };
 
+// Ordered compaction of the active points and of their pointPoints rows: chunks of 4 096 points per workgroup, count launch +
+// fill launch, no scan launch in between (the chunk* helpers of kernels.hpp).  k_walk_fill leaves {nActive, nEntries, 0} in
+// w.header.  activeSlot[p] is only written for active points: it is valid iff faActive[p] carries this iteration's tag
+// (activeSlotOf) -- no 4-byte store per mesh point and iteration.
 __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
     if (s.acc->stop) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
+    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
+    const uint4 q = chunkMarks(s.faActive, base, m.nPoints);
     int a = 0, e = 0;
-    if (p < m.nPoints && s.faActive[p] == s.faGen) { a = 1; e = m.ppOff[p + 1] - m.ppOff[p]; }
-    __shared__ int sa[kBlock / 64], se[kBlock / 64];
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); e += __shfl_down(e, o, 64); }
-    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = a; se[threadIdx.x >> 6] = e; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ta = 0, te = 0;
-        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
-        w.blkA[blockIdx.x] = ta;
-        w.blkE[blockIdx.x] = te;
+    if (q.x | q.y | q.z | q.w) {
+        for (int i = 0; i < kChunkPer; ++i)
+            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ++a; e += m.ppOff[base + i + 1] - m.ppOff[base + i]; }
     }
+    chunkReduce2(a, e);
+    if (threadIdx.x == 0) { w.blkA[blockIdx.x] = a; w.blkE[blockIdx.x] = e; }
 }
-
-// exclusive scan of the per-block counts by one workgroup of kScanBlock threads, four counts per thread and round (a 10 M-point
-// mesh has 40 k blocks).  nElemDev != NULL: the counts cover ceil(*nElemDev / kBlock) blocks (a count the host never sees)
-constexpr int kScanBlock = 1024;
-__global__ void __launch_bounds__(kScanBlock) k_walk_scan(State s, WalkView w, int nBlk, const int* nElemDev, int* hdrOut) {
-    if (s.acc->stop) return;
-    if (nElemDev) nBlk = (*nElemDev + kBlock - 1) / kBlock;
-    __shared__ int baseA, baseE;
-    __shared__ int wa[kScanBlock / 64], we[kScanBlock / 64];
-    if (threadIdx.x == 0) { baseA = 0; baseE = 0; }
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int b0 = 0; b0 < nBlk; b0 += 4 * kScanBlock) {
-        const int i0 = b0 + 4 * threadIdx.x;
-        int a[4], e[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { a[u] = (i0 + u < nBlk) ? w.blkA[i0 + u] : 0; e[u] = (i0 + u < nBlk) ? w.blkE[i0 + u] : 0; }
-        const int sa = a[0] + a[1] + a[2] + a[3], se = e[0] + e[1] + e[2] + e[3];
-        int ia = sa, ie = se;   // inclusive scan of the threads' sums inside the wave
-        for (int o = 1; o < 64; o <<= 1) {
-            const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
-            if (lane >= o) { ia += ta; ie += te; }
-        }
-        if (lane == 63) { wa[wv] = ia; we[wv] = ie; }
-        __syncthreads();
-        int offA = baseA, offE = baseE;
-        for (int k = 0; k < wv; ++k) { offA += wa[k]; offE += we[k]; }
-        int ra = offA + ia - sa, re = offE + ie - se;   // exclusive prefix of this thread's first count
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (i0 + u < nBlk) { w.blkA[i0 + u] = ra; w.blkE[i0 + u] = re; }
-            ra += a[u]; re += e[u];
-        }
-        __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) { baseA = offA + ia; baseE = offE + ie; }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { hdrOut[0] = baseA; hdrOut[1] = baseE; if (hdrOut == w.header) w.header[2] = 0; }   // [2]: slots left by k_walk_pred_star
-}
+__device__ __forceinline__ int activeSlotOf(const State& s, const WalkView& w, int q) { return (s.faActive[q] == s.faGen) ? w.activeSlot[q] : -1; }
 
 __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
     if (s.acc->stop) return;
-    const int p = blockIdx.x * kBlock + threadIdx.x;
-    const bool act = p < m.nPoints && s.faActive[p] == s.faGen;
-    const int a = act ? 1 : 0, e = act ? m.ppOff[p + 1] - m.ppOff[p] : 0;
-    int ia = a, ie = e;
-    const int lane = threadIdx.x & 63;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int ta = __shfl_up(ia, o, 64), te = __shfl_up(ie, o, 64);
-        if (lane >= o) { ia += ta; ie += te; }
+    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
+    const uint4 q = chunkMarks(s.faActive, base, m.nPoints);
+    int a = 0, e = 0;
+    if (q.x | q.y | q.z | q.w) {
+        for (int i = 0; i < kChunkPer; ++i)
+            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ++a; e += m.ppOff[base + i + 1] - m.ppOff[base + i]; }
     }
-    __shared__ int wa[kBlock / 64], we[kBlock / 64];
-    if (lane == 63) { wa[threadIdx.x >> 6] = ia; we[threadIdx.x >> 6] = ie; }
-    __syncthreads();
-    int offA = w.blkA[blockIdx.x], offE = w.blkE[blockIdx.x];
-    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offA += wa[k]; offE += we[k]; }
-    if (p < m.nPoints) w.activeSlot[p] = act ? offA + ia - 1 : -1;
-    if (act) {
-        const int slot = offA + ia - 1, eo = offE + ie - e;
-        w.actIds[slot] = p;
-        w.actEntOff[slot] = eo;
-        const int nb = m.ppOff[p];
-        for (int j = 0; j < e; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
+    int xa, xe, pa, pe, ta, te;
+    chunkScan2(a, e, xa, xe);
+    chunkPrefix2(w.blkA, w.blkE, (int)blockIdx.x, (int)gridDim.x, false, pa, pe, ta, te);
+    if (a) {
+        int slot = pa + xa, eo = pe + xe;
+        for (int i = 0; i < kChunkPer; ++i) {
+            if (chunkByte(q, i) != s.faGen || base + i >= m.nPoints) continue;
+            const int p = base + i;
+            w.activeSlot[p] = slot;
+            w.actIds[slot] = p;
+            w.actEntOff[slot] = eo;
+            const int nb = m.ppOff[p], n = m.ppOff[p + 1] - nb;
+            for (int j = 0; j < n; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
+            ++slot;
+            eo += n;
+        }
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) {
+        w.header[0] = pa + xa + a; w.header[1] = pe + xe + e; w.header[2] = 0;   // [2]: slots left by k_walk_pred_star
     }
 }
 
@@ -303,7 +270,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
                 if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
             }
         }
-        if (lane == 0) { w.entBits[e] = nb; w.entSlot[e] = w.activeSlot[q]; }
+        if (lane == 0) { w.entBits[e] = nb; w.entSlot[e] = activeSlotOf(s, w, q); }
     }
 }
 
@@ -527,7 +494,7 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (lane < nEnt) { w.entBits[eBeg + lane] = L.nb[lane]; w.entSlot[eBeg + lane] = w.activeSlot[q]; }
+        if (lane < nEnt) { w.entBits[eBeg + lane] = L.nb[lane]; w.entSlot[eBeg + lane] = activeSlotOf(s, w, q); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }
@@ -536,60 +503,58 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
 // ---- second compaction (over active slots) ------------------------------------------------------------------
 __device__ __forceinline__ bool entryActs(uint8_t nb) { return (nb & 4) && (nb & 3); }   // moving neighbour, hurt in some state
 
-// nA < 0 (here and below): counts from the device headers; the launch covers every possible slot and the blocks
-// beyond the count leave at once
-__global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w, int nA) {
-    if (nA < 0) nA = w.header[0];
-    if ((int)(blockIdx.x * kBlock) >= nA) return;
-    const int a = blockIdx.x * kBlock + threadIdx.x;
+// The counts come from the device header (no host read-back); the launch covers every possible slot (kRelPer consecutive slots
+// per thread) and the workgroups beyond the count leave at once.  No scan launch between count and fill: k_rel_fill sums the
+// per-workgroup counts itself (chunkPrefix2) -- all of them, because the item positions count from the END of the sequence --
+// and leaves {nRelevant, nBadEntries} in w.header2.
+constexpr int kRelPer = 4;
+constexpr int kRelChunk = kBlock * kRelPer;
+inline int relGrid(int64_t n) { return (int)std::max<int64_t>(1, (n + kRelChunk - 1) / kRelChunk); }
+__device__ __forceinline__ void relOf(const WalkView& w, int a, int& r, int& b) {
+    b = 0;
+    for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
+    const uint8_t sb = w.actBits[a] & 0x7f;
+    r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
+    if (!r) b = 0;
+}
+__global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w) {
+    const int nA = w.header[0];
+    if ((int)(blockIdx.x * kRelChunk) >= nA) return;
+    const int a0 = blockIdx.x * kRelChunk + threadIdx.x * kRelPer;
     int r = 0, b = 0;
-    if (a < nA) {
-        for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
-        const uint8_t sb = w.actBits[a] & 0x7f;
-        r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
-        if (!r) b = 0;
-    }
-    __shared__ int sa[kBlock / 64], se[kBlock / 64];
-    for (int o = 32; o > 0; o >>= 1) { r += __shfl_down(r, o, 64); b += __shfl_down(b, o, 64); }
-    if ((threadIdx.x & 63) == 0) { sa[threadIdx.x >> 6] = r; se[threadIdx.x >> 6] = b; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int ta = 0, te = 0;
-        for (int i = 0; i < kBlock / 64; ++i) { ta += sa[i]; te += se[i]; }
-        w.blkA[blockIdx.x] = ta;
-        w.blkE[blockIdx.x] = te;
-    }
+    for (int i = 0; i < kRelPer; ++i)
+        if (a0 + i < nA) { int ri, bi; relOf(w, a0 + i, ri, bi); r += ri; b += bi; }
+    chunkReduce2(r, b);
+    if (threadIdx.x == 0) { w.blkA[blockIdx.x] = r; w.blkE[blockIdx.x] = b; }
 }
 
 // fx.T != NULL (device replay): an entry item keeps its owner's slot in `hpos` (k_rel_link leaves it there: nothing is
 // pushed in that mode) and the barrier words of k_walk_fix are reset
-__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR, int nB, FixView fx) {
+__global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, FixView fx) {
     if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { *fx.bar = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = 0; }
-    if (nA < 0) { nA = w.header[0]; nR = w.header2[0]; nB = w.header2[1]; }
-    if ((int)(blockIdx.x * kBlock) >= nA) return;
-    const int a = blockIdx.x * kBlock + threadIdx.x;
+    const int nA = w.header[0];
+    if (nA <= 0) { if (blockIdx.x == 0 && threadIdx.x == 0) { w.header2[0] = 0; w.header2[1] = 0; } return; }
+    if ((int)(blockIdx.x * kRelChunk) >= nA) return;
+    const int a0 = blockIdx.x * kRelChunk + threadIdx.x * kRelPer;
+    int rr[kRelPer], bb[kRelPer];
     int r = 0, b = 0;
-    if (a < nA) {
-        for (int k = w.actEntOff[a]; k < w.actEntOff[a + 1]; ++k) b += entryActs(w.entBits[k]) ? 1 : 0;
-        const uint8_t sb = w.actBits[a] & 0x7f;
-        r = (b > 0 || ((sb & 1) && (sb & 2))) ? 1 : 0;
-        if (!r) b = 0;
+#pragma unroll
+    for (int i = 0; i < kRelPer; ++i) {
+        rr[i] = bb[i] = 0;
+        if (a0 + i < nA) { relOf(w, a0 + i, rr[i], bb[i]); r += rr[i]; b += bb[i]; }
     }
-    int ir = r, ib = b;
-    const int lane = threadIdx.x & 63;
-    for (int o = 1; o < 64; o <<= 1) {
-        const int tr = __shfl_up(ir, o, 64), tb = __shfl_up(ib, o, 64);
-        if (lane >= o) { ir += tr; ib += tb; }
-    }
-    __shared__ int wr[kBlock / 64], wb[kBlock / 64];
-    if (lane == 63) { wr[threadIdx.x >> 6] = ir; wb[threadIdx.x >> 6] = ib; }
-    __syncthreads();
-    int offR = w.blkA[blockIdx.x], offB = w.blkE[blockIdx.x];
-    for (int k = 0; k < (threadIdx.x >> 6); ++k) { offR += wr[k]; offB += wb[k]; }
-    if (a < nA) w.relSlot[a] = r ? offR + ir - 1 : -1;
-    if (r) {
-        const int slot = offR + ir - 1;
-        const int eoEnd = offB + ib;                       // entries of slots 0..slot
+    int xr, xb, pr, pb, nR, nB;
+    chunkScan2(r, b, xr, xb);
+    chunkPrefix2(w.blkA, w.blkE, (int)blockIdx.x, (nA + kRelChunk - 1) / kRelChunk, true, pr, pb, nR, nB);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { w.header2[0] = nR; w.header2[1] = nB; }
+    int slot = pr + xr, eoEnd = pb + xb;
+#pragma unroll
+    for (int i = 0; i < kRelPer; ++i) {
+        const int a = a0 + i;
+        if (a >= nA) break;
+        w.relSlot[a] = rr[i] ? slot : -1;
+        if (!rr[i]) continue;
+        eoEnd += bb[i];                                    // entries of slots 0..slot
         // visiting order: slot nR-1 first; every earlier-visited point contributes its header and its entries
         int pos = (nR - 1 - slot) + (nB - eoEnd);
         w.hdrPos[slot] = pos;
@@ -608,6 +573,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, int nA, int nR,
         w.relBits[slot] = rb;
         const bool moved = rb & 2, selfBad = rb & 1;
         w.items[hdr] = WalkItem{slot, w.actIds[a], ((moved && selfBad) ? 3u : 0u) | 32u | ((moved && !selfBad) ? 64u : 0u) | 128u, hdr};
+        ++slot;
     }
 }
 

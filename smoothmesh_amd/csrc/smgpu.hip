@@ -590,8 +590,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.edgeMax, E);
     rc |= devAlloc(h, &s.ptMin, P);
     rc |= devAlloc(h, &s.ptMax, P);
-    rc |= devAlloc(h, &s.faActive, P);
-    rc |= devAlloc(h, &h->dFaMaybe, P);
+    rc |= devAlloc(h, &s.faActive, P + 16);    // + 16: the compaction kernels read the marks 16 bytes at a time (chunkMarks)
+    rc |= devAlloc(h, &h->dFaMaybe, P + 16);
     rc |= devAlloc(h, &s.faEdgeList, E);
     rc |= devAlloc(h, &s.faPointList, P);
     rc |= devAlloc(h, &h->dEaMaybe, P);
@@ -1027,9 +1027,10 @@ static int runHostWalk(smgpu_handle* h) {
     const Prm prm = makePrm(h);
     WalkView w = h->wv;
     if (ensurePinned(h, 64)) return 1;
+    const int gChunks = chunkGrid(m.nPoints);
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
+            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
         })) return 1;
     int* hdr = (int*)h->pinned;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1037,26 +1038,21 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
             if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 3) / 4), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
         })) return 1;
     // second compaction: only the points that can act and only their true entries go to the host
-    const int nSlotBlocks = gridFor(nA);
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_rel_count, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, nSlotBlocks, (const int*)nullptr, w.header2);
+            hipLaunchKernelGGL(k_rel_count, dim3(relGrid(nA)), dim3(kBlock), 0, h->stream, w);
+            hipLaunchKernelGGL(k_rel_fill, dim3(relGrid(nA)), dim3(kBlock), 0, h->stream, w, FixView{});
         })) return 1;
     HIP_OK(hipMemcpyAsync(hdr, w.header2, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     if (spinSync(h->stream)) return 1;
     const int nR = hdr[0], nB = hdr[1];
     if (nR <= 0) return 0;
     const int nItems = nR + nB;
-    if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_rel_fill, dim3(nSlotBlocks), dim3(kBlock), 0, h->stream, w, nA, nR, nB, FixView{});
-            hipLaunchKernelGGL(k_rel_link, dim3(gridFor(nItems)), dim3(kBlock), 0, h->stream, w, nItems, nR, 0);
-        })) return 1;
+    if (launchK(h, K_FA_PRED, [&] { hipLaunchKernelGGL(k_rel_link, dim3(gridFor(nItems)), dim3(kBlock), 0, h->stream, w, nItems, nR, 0); })) return 1;
     const size_t oItems = 0, oRel = oItems + sizeof(WalkItem) * (size_t)nItems, total = oRel + (size_t)nR;
     if (ensurePinned(h, total + 16)) return 1;
     char* base = (char*)h->pinned;
@@ -1120,18 +1116,17 @@ static int runFixWalk(smgpu_handle* h) {
     const int64_t maxEntries = (int64_t)h->topo.pointEdges.nnz();
     // grids: enough workgroups to fill the chip several times over; the kernels stride over the device-side counts
     const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
+    const int gChunks = chunkGrid(P), gRel = relGrid(P);
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_walk_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, h->walkBlocks, (const int*)nullptr, w.header);
-            hipLaunchKernelGGL(k_walk_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
             if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
         })) return 1;
     if (launchK(h, K_FA_WALK, [&] {
-            hipLaunchKernelGGL(k_rel_count, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1);
-            hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, h->stream, s, w, 0, (const int*)w.header, w.header2);
-            hipLaunchKernelGGL(k_rel_fill, dim3(h->walkBlocks), dim3(kBlock), 0, h->stream, w, -1, -1, -1, fx);
+            hipLaunchKernelGGL(k_rel_count, dim3(gRel), dim3(kBlock), 0, h->stream, w);
+            hipLaunchKernelGGL(k_rel_fill, dim3(gRel), dim3(kBlock), 0, h->stream, w, fx);
             hipLaunchKernelGGL(k_rel_link, dim3(gItems), dim3(kBlock), 0, h->stream, w, -1, -1, 1);
             hipLaunchKernelGGL(k_walk_fix, dim3(h->walkFixBlocks), dim3(kFixBlock), 0, h->stream, w, fx, s);
         })) return 1;
@@ -1164,9 +1159,8 @@ static int runFaExactPass(smgpu_handle* h, const State& s, const uint8_t* faMayb
         // exact evaluation on the lists of what the filter left open (kernels.hpp, k_fa_collect)
         if (ensureWalkBuffers(h)) return 1;    // the block-count scratch of the walk compaction serves the listing first
         if (launchK(h, K_FA_EDGES, [&] {
-                hipLaunchKernelGGL(k_fa_list_count, dim3(h->walkBlocks), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
-                hipLaunchKernelGGL(k_walk_scan, dim3(1), dim3(kScanBlock), 0, stream, s, h->wv, h->walkBlocks, (const int*)nullptr, &h->st.acc->nFaPts);
-                hipLaunchKernelGGL(k_fa_list_fill, dim3(h->walkBlocks), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                hipLaunchKernelGGL(k_fa_list_count, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
+                hipLaunchKernelGGL(k_fa_list_fill, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
                 hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
             }, stream)) return 1;
         return launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, stream, m, s, prm); }, stream);

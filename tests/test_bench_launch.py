@@ -51,5 +51,12 @@ def test_bench_single_gpu_line_carries_the_other_configs():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["frac"] > 0
     assert [c["workload"] for c in d["configs"]] == ["hex12c", "cavity10c"]
+    assert d["parity_check"]["ok"] and d["parity_check"]["rel_linf"] <= 1e-10 and d["ms_per_step_cold"] > 0
     for c in d["configs"]:
+        assert "error" not in c, c
         assert c["ms_per_step"] > 0 and c["roofline"]["frac"] > 0 and c["kernels"]
+        # every configuration is compared with the oracle on its own mesh by the same run and carries its own CPU baseline
+        assert c["parity_check"]["ok"] and c["parity_check"]["nFrozen_equal"] and c["parity_check"]["rel_linf"] <= 1e-10
+        assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["value"] > 0
+        # no impossible bandwidths in the per-kernel table (filter + exact kernels are accounted as one unit)
+        assert all(k["algo_GBps"] is None or k["algo_GBps"] < 8000 for k in c["kernels"])

@@ -1,0 +1,139 @@
+"""The HIP path against the CPU oracle ON THE BASELINE MESHES THEMSELVES (BASELINE.json configs[1..3]).
+
+The small-mesh parity tests cannot reach the code that only runs big: tile tables with thousands of tiles, the XCD-contiguous
+launch with a tile count that is no multiple of 8, ELL rows past the two pre-loaded chunks, the scans over 40 k block counts,
+the list compaction of the exact face-angle pass, the fixed-point walk on percolated components.  Here `iterate(k)` runs on both
+sides from the same coordinates (the loop body SM.C:2257-2437) and the nFrozenPoints series must be identical and the
+coordinates within 1e-13 relative L-inf (north star: 1e-10; measured: bit-equal).
+
+Cost: the serial oracle takes ~0.25 / 1.3 / 1.7 s per iteration on the 1 M-cell meshes and ~50 s of set-up plus ~30 s per
+constrained iteration on the 10 M-cell mesh -- k is sized accordingly.
+"""
+import numpy as np
+import pytest
+
+from conftest import rel_linf
+
+pytestmark = pytest.mark.gpu
+
+COORD_TOL = 1e-13
+
+
+@pytest.fixture(scope="module")
+def cavity215():
+    from smoothmesh_amd.polymesh import cavity_mesh
+    return cavity_mesh(215, jitter=0.2, seed=12345)
+
+
+def _compare(mesh, oracle_lib, k, check_every=None, **over):
+    from smoothmesh_amd import SmoothEngine, default_params
+    o = oracle_lib.Oracle(mesh)
+    e = SmoothEngine(mesh)
+    mn_o, mx_o = o.mesh_stats()
+    assert (mn_o, mx_o) == e.mesh_stats()
+    p = default_params(mn_o, **over)
+    o.set_params(p)
+    e.set_params(p)
+    try:
+        done = 0
+        frz_o_all, frz_g_all = [], []
+        for chunk in (check_every or [k]):
+            n_o, res_o, frz_o = o.iterate(chunk, 0.0)
+            n_g, res_g, frz_g = e.iterate(chunk, 0.0)
+            done += chunk
+            assert n_o == n_g == chunk
+            assert np.array_equal(frz_o, frz_g), (done, frz_o, frz_g)
+            assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
+            err = rel_linf(e.get_points(), o.points())
+            assert err <= COORD_TOL, (done, err)
+            frz_o_all.append(frz_o); frz_g_all.append(frz_g)
+        assert done == k
+        return np.concatenate(frz_g_all), bool(np.array_equal(e.get_points(), o.points()))
+    finally:
+        e.close()
+        o.close()
+
+
+def test_hex100_constraints_off_matches_oracle(oracle_lib):
+    """configs[1]: 100^3 hex block, constraints off -- 5 iterations, compared after 2 and after 5"""
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(100, jitter=0.2, seed=12345)
+    frz, bitwise = _compare(mesh, oracle_lib, 5, check_every=[2, 3], edgeAngleConstraint=False, faceAngleConstraint=False)
+    assert np.all(frz == mesh.nPoints - 99 ** 3)      # only the boundary points count as frozen
+    assert bitwise
+
+
+def test_hex100c_constraints_on_matches_oracle(oracle_lib):
+    """configs[2]: the same block with the edge- and face-angle constraints on (minAngle 35 / maxAngle 160)"""
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(100, jitter=0.2, seed=12345)
+    frz, bitwise = _compare(mesh, oracle_lib, 5, check_every=[1, 4])
+    assert bitwise
+
+
+def test_hex100c_busy_constraints_match_oracle(oracle_lib):
+    """the same size with heavier jitter and minAngle 60: thousands of points are frozen by the evaluators and the walk, so
+    the filters' UNSURE lists, the list-based exact pass and the walk replay are busy at a size with ~4 000 tiles"""
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(100, jitter=0.42, seed=12345)
+    frz, _ = _compare(mesh, oracle_lib, 4, check_every=[1, 3], minAngle=60.0)
+    assert frz[0] > mesh.nPoints - 99 ** 3 + 1000
+
+
+@pytest.mark.parametrize("constraints", [False, True])
+def test_cavity100_matches_oracle(oracle_lib, constraints):
+    """1 M-cell castellated polyhedral cavity mesh (the 10 M-cell configs[3] family at a size the oracle runs in seconds):
+    mixed tiles (general ELL loops next to the unrolled hex paths), the refinement interface keeps the walk busy"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    mesh = cavity_mesh(100, jitter=0.2, seed=12345)
+    frz, bitwise = _compare(mesh, oracle_lib, 4, check_every=[1, 3], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    if constraints:
+        assert frz[-1] > frz[0]          # the walk freezes more and more points along the interface
+    assert bitwise
+
+
+def test_cavity215c_matches_oracle(oracle_lib, cavity215):
+    """configs[3] itself: the 10 M-cell polyhedral mesh, constraints on -- two iterations on both sides (the second one starts
+    from coordinates, frozen marks and generation tags the first one left), then one more with the constraints off on the
+    same engine / oracle pair (parameters changed mid-run: the fused kernel path at 40 k tiles)."""
+    from smoothmesh_amd import SmoothEngine, default_params
+    mesh = cavity215
+    assert mesh.nCells > 9_500_000
+    o = oracle_lib.Oracle(mesh)
+    e = SmoothEngine(mesh)
+    try:
+        p = default_params(o.mesh_stats()[0])
+        o.set_params(p); e.set_params(p)
+        for it in range(2):
+            n_o, res_o, frz_o = o.iterate(1, 0.0)
+            n_g, res_g, frz_g = e.iterate(1, 0.0)
+            assert np.array_equal(frz_o, frz_g), (it, frz_o, frz_g)
+            assert rel_linf(e.get_points(), o.points()) <= COORD_TOL, it
+        assert frz_g[0] > 500_000
+        p2 = default_params(o.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False)
+        o.set_params(p2); e.set_params(p2)
+        n_o, res_o, frz_o = o.iterate(1, 0.0)
+        n_g, res_g, frz_g = e.iterate(1, 0.0)
+        assert np.array_equal(frz_o, frz_g)
+        assert np.array_equal(e.get_points(), o.points())
+    finally:
+        e.close()
+        o.close()
+
+
+def test_walk_replay_places_agree_on_the_10M_cell_mesh(monkeypatch, cavity215):
+    """cavity215c: the fixed-point device replay against the host replay (SMGPU_WALK=host) at the size of configs[3] --
+    identical nFrozenPoints series, residuals and coordinates after 6 iterations (the components start to merge)"""
+    from smoothmesh_amd import SmoothEngine, default_params
+    mesh = cavity215
+    outs = {}
+    for walk in ("fix", "host"):
+        monkeypatch.setenv("SMGPU_WALK", walk)
+        e = SmoothEngine(mesh)
+        e.set_params(default_params(e.mesh_stats()[0]))
+        n, res, frz = e.iterate(6, 0.0)
+        outs[walk] = (res, frz, e.get_points())
+        e.close()
+    assert np.array_equal(outs["fix"][1], outs["host"][1])
+    assert np.array_equal(outs["fix"][0], outs["host"][0])
+    assert np.array_equal(outs["fix"][2], outs["host"][2])
