@@ -275,6 +275,12 @@ int smgpu_debug_edge_strings(int32_t nPoints, int32_t nEdges, const int32_t* edg
 /* parity access: nearest intersections of n segments (6 doubles each: start, end) with the target surface */
 int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit);
 
+/* The replay form of the face-angle freeze walk (SM.C:1347-1434) in use: -1 not decided yet, 0 one wave over the flag array
+ * (few points outside the good angle range), 1 host replay (SMGPU_WALK=host), 2 compaction + causal fixed point (many); and how
+ * often the automatic choice has changed since smgpu_set_params -- it follows the number of points outside the good range as
+ * the run goes (results never depend on it); *lastCount = that number for the last iteration the GPU has closed (-1: none). */
+int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int32_t* lastCount);
+
 /* self-test of the geometry kernel's range-tested square root / division fast paths (csrc/fpexact.hpp) against the plain
  * IEEE operators on n generated arguments (random, zeros, denormals, inf / nan, both ends of the exponent range) on the
  * given device; *mismatches = number of results whose bits differ (nan == nan).  0 is the only acceptable count. */

@@ -92,6 +92,7 @@ SYMBOLS = {
     "smgpu_mesh_stats": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
     "smgpu_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "smgpu_set_foam_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "smgpu_debug_walk_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "smgpu_debug_selftest_fpexact": (C.c_int, [C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
     "smgpu_iterate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(IterStats), c_i32p]),
     "smgpu_get_points": (C.c_int, [C.c_void_p, c_f64p]),

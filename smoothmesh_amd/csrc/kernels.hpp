@@ -75,6 +75,8 @@ struct State {
     const int* bndOfShared;    // multi-rank + boundary point smoothing: per shared point its index in the boundary tables or -1
     const double* combL;       // multi-rank + layers: per shared point the summed normals and the combined outer
                                // neighbour coordinates (6 doubles), or NULL
+    int* nActiveHost;          // pinned host word (or NULL): the end-of-iteration reduction leaves the iteration's nActive there,
+                               // from which the host re-decides the walk's replay form (smgpu.hip:updateWalkMode)
 };
 
 struct Prm {
@@ -722,6 +724,39 @@ __device__ __forceinline__ void chunkScan2(int a, int e, int& xa, int& xe) {
     for (int k = 0; k < wv; ++k) { xa += sw[k]; xe += sw[kBlock / 64 + k]; }
 }
 
+// exclusive scan of one value over the workgroup's threads in thread order, and the workgroup's total
+__device__ __forceinline__ void chunkScan1(int v, int& x, int& total) {
+    __shared__ int sw1[kBlock / 64];
+    int iv = v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(iv, o, 64);
+        if (lane >= o) iv += t;
+    }
+    __syncthreads();
+    if (lane == 63) sw1[wv] = iv;
+    __syncthreads();
+    x = iv - v;
+    total = 0;
+    for (int k = 0; k < kBlock / 64; ++k) { if (k < wv) x += sw1[k]; total += sw1[k]; }
+}
+// The chunk's marked points in ascending order as chunk-local offsets in LDS: list[0 .. n); returns n to every thread.  The
+// work per marked point (gathers over its neighbours) is then dealt one point per thread -- marked points come in clusters
+// (a refinement interface), and a thread walking its own 16 points one after the other was a chain of up to 16 dependent
+// gather loops while the other lanes of its wave waited.
+__device__ __forceinline__ int chunkCompact(const uint4& q, unsigned gen, int base, int nPoints, uint16_t* list) {
+    int a = 0;
+    if (q.x | q.y | q.z | q.w)
+        for (int i = 0; i < kChunkPer; ++i) a += (chunkByte(q, i) == gen && base + i < nPoints) ? 1 : 0;
+    int x, n;
+    chunkScan1(a, x, n);
+    if (a)
+        for (int i = 0; i < kChunkPer; ++i)
+            if (chunkByte(q, i) == gen && base + i < nPoints) list[x++] = (uint16_t)(threadIdx.x * kChunkPer + i);
+    __syncthreads();
+    return n;
+}
+
 // With the filter on, what needs the exact evaluation is sparse (the end points of the UNSURE edges and all their edges:
 // 2 % of a 10 M-cell refinement-interface mesh, nothing on a good hex block), but one thread per edge asking "is one of my
 // end points marked?" costs two random byte gathers for each of the 30 M edges (0.56 ms).  So the marked points list
@@ -741,44 +776,36 @@ __device__ __forceinline__ int faListedEdges(const MeshView& m, const State& s, 
 __global__ void __launch_bounds__(kBlock) k_fa_list_count(MeshView m, State s, const uint8_t* faMaybe, int* blkA, int* blkE) {
     if (s.acc->stop) return;
     if (s.acc->nFaMaybe == 0) return;                  // the filter found every edge inside the good range: no lists
-    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
-    const uint4 q = chunkMarks(faMaybe, base, m.nPoints);
+    __shared__ uint16_t list[kChunk];
+    const int cb = blockIdx.x * kChunk, base = cb + threadIdx.x * kChunkPer;
+    const int n = chunkCompact(chunkMarks(faMaybe, base, m.nPoints), s.faGen, base, m.nPoints, list);
     int a = 0, e = 0;
-    if (q.x | q.y | q.z | q.w) {
-        for (int i = 0; i < kChunkPer; ++i)
-            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ++a; e += faListedEdges(m, s, faMaybe, base + i, nullptr); }
-    }
-    chunkReduce2(a, e);
-    if (threadIdx.x == 0) { blkA[blockIdx.x] = a; blkE[blockIdx.x] = e; }
+    for (int i = threadIdx.x; i < n; i += kBlock) e += faListedEdges(m, s, faMaybe, cb + list[i], nullptr);
+    if (n > 0) chunkReduce2(a, e);
+    if (threadIdx.x == 0) { blkA[blockIdx.x] = n; blkE[blockIdx.x] = e; }
 }
 __global__ void __launch_bounds__(kBlock) k_fa_list_fill(MeshView m, State s, const uint8_t* faMaybe, const int* blkA, const int* blkE) {
     if (s.acc->stop) return;
     if (s.acc->nFaMaybe == 0) return;                  // nFaPts / nFaEdges stay 0 (reset at the end of every iteration)
-    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
-    const uint4 q = chunkMarks(faMaybe, base, m.nPoints);
-    int a = 0, e = 0;
-    int ne[kChunkPer];
-    if (q.x | q.y | q.z | q.w) {
-#pragma unroll
-        for (int i = 0; i < kChunkPer; ++i) {
-            ne[i] = -1;
-            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ne[i] = faListedEdges(m, s, faMaybe, base + i, nullptr); ++a; e += ne[i]; }
-        }
-    }
-    int xa, xe, pa, pe, ta, te;
-    chunkScan2(a, e, xa, xe);
+    __shared__ uint16_t list[kChunk];
+    const int cb = blockIdx.x * kChunk, base = cb + threadIdx.x * kChunkPer;
+    const int n = chunkCompact(chunkMarks(faMaybe, base, m.nPoints), s.faGen, base, m.nPoints, list);
+    int pa, pe, ta, te;
     chunkPrefix2(blkA, blkE, (int)blockIdx.x, (int)gridDim.x, false, pa, pe, ta, te);
-    if (a) {
-        int oa = pa + xa, oe = pe + xe;
-#pragma unroll
-        for (int i = 0; i < kChunkPer; ++i) {
-            if (ne[i] < 0) continue;
-            s.faPointList[oa++] = base + i;
-            (void)faListedEdges(m, s, faMaybe, base + i, s.faEdgeList + oe);
-            oe += ne[i];
+    int running = 0;
+    for (int r = 0; r < n; r += kBlock) {              // (n is the same for every thread)
+        const int i = r + threadIdx.x;
+        const int p = (i < n) ? cb + list[i] : -1;
+        const int ne = (p >= 0) ? faListedEdges(m, s, faMaybe, p, nullptr) : 0;
+        int xe, tot;
+        chunkScan1(ne, xe, tot);
+        if (p >= 0) {
+            s.faPointList[pa + i] = p;
+            (void)faListedEdges(m, s, faMaybe, p, s.faEdgeList + (pe + running + xe));
         }
+        running += tot;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { s.acc->nFaPts = pa + xa + a; s.acc->nFaEdges = pe + xe + e; }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { s.acc->nFaPts = pa + n; s.acc->nFaEdges = pe + running; }
 }
 __global__ void __launch_bounds__(kBlock) k_fa_edges_list(MeshView m, State s) {
     if (s.acc->stop) return;
@@ -971,6 +998,7 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
     if (history) { history[0] = res; history[1] = (double)c; }
     if (res < relTol) a->stop = 1;
+    if (s.nActiveHost) __hip_atomic_store(s.nActiveHost, a->nActive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     a->nActive = 0;
     a->nEaMaybe = 0;
     a->nFaMaybe = 0;

@@ -101,32 +101,29 @@ __device__ __forceinline__ int activeSlotOf(const State& s, const WalkView& w, i
 
 __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
     if (s.acc->stop) return;
-    const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
-    const uint4 q = chunkMarks(s.faActive, base, m.nPoints);
-    int a = 0, e = 0;
-    if (q.x | q.y | q.z | q.w) {
-        for (int i = 0; i < kChunkPer; ++i)
-            if (chunkByte(q, i) == s.faGen && base + i < m.nPoints) { ++a; e += m.ppOff[base + i + 1] - m.ppOff[base + i]; }
-    }
-    int xa, xe, pa, pe, ta, te;
-    chunkScan2(a, e, xa, xe);
+    __shared__ uint16_t list[kChunk];
+    const int cb = blockIdx.x * kChunk, base = cb + threadIdx.x * kChunkPer;
+    const int n = chunkCompact(chunkMarks(s.faActive, base, m.nPoints), s.faGen, base, m.nPoints, list);
+    int pa, pe, ta, te;
     chunkPrefix2(w.blkA, w.blkE, (int)blockIdx.x, (int)gridDim.x, false, pa, pe, ta, te);
-    if (a) {
-        int slot = pa + xa, eo = pe + xe;
-        for (int i = 0; i < kChunkPer; ++i) {
-            if (chunkByte(q, i) != s.faGen || base + i >= m.nPoints) continue;
-            const int p = base + i;
+    int running = 0;
+    for (int r = 0; r < n; r += kBlock) {              // one active point per thread
+        const int i = r + threadIdx.x;
+        const int p = (i < n) ? cb + list[i] : -1;
+        const int nb = (p >= 0) ? m.ppOff[p] : 0, deg = (p >= 0) ? m.ppOff[p + 1] - nb : 0;
+        int xe, tot;
+        chunkScan1(deg, xe, tot);
+        if (p >= 0) {
+            const int slot = pa + i, eo = pe + running + xe;
             w.activeSlot[p] = slot;
             w.actIds[slot] = p;
             w.actEntOff[slot] = eo;
-            const int nb = m.ppOff[p], n = m.ppOff[p + 1] - nb;
-            for (int j = 0; j < n; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
-            ++slot;
-            eo += n;
+            for (int j = 0; j < deg; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
         }
+        running += tot;
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) {
-        w.header[0] = pa + xa + a; w.header[1] = pe + xe + e; w.header[2] = 0;   // [2]: slots left by k_walk_pred_star
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        w.header[0] = pa + n; w.header[1] = pe + running; w.header[2] = 0;   // [2]: slots left by k_walk_pred_star
     }
 }
 
@@ -286,14 +283,17 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
 // cell's two faces comes first), and min / max are reduced over the half wave.  Each face vector is thus formed once per
 // job, not once per adjacent cell.  Two jobs run side by side on the two halves.  Points whose star exceeds the caps, or
 // with a non-manifold edge ring, are left (kStarLeft) to the gather form above.
-constexpr int kStarFaces = 32, kStarVerts = 160, kStarEnts = 64;
+constexpr int kStarFaces = 32, kStarVerts = 128, kStarEnts = 32;
 struct StarLds {
     int fid[kStarFaces];
     int voff[kStarFaces + 1];
     int vid[kStarVerts];
     double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
     unsigned char nb[kStarEnts];
-    signed char job[kStarEnts + 2];      // the jobs that are needed: -1 = the self test, i = entry i (compacted, in that order)
+    signed char job[2 * kStarEnts + 2];  // the jobs that are needed, in order: -1 = the self test, e = entry e with p at its current
+                                         // position, 64 + e = entry e with p at its proposal
+    int fbeg[kStarFaces];                // staging: first entry of the face in facePts
+    unsigned char vface[kStarVerts];     // staging: the star-local face of every vertex slot
 };
 struct StarLane {          // a lane's place: ring position i of edge (p, xI)
     bool valid, hasCell;
@@ -351,150 +351,184 @@ __device__ __forceinline__ void starReduce(bool valid, double angle, double& mn,
 }
 
 #ifndef SMGPU_STAR_WAVES
-#define SMGPU_STAR_WAVES 3
+#define SMGPU_STAR_WAVES 4   // waves per SIMD the register allocation aims at (measured on the 10 M-cell cavity mesh: 3 -> 945 us, 4 -> 833 us)
 #endif
+// TWO active points per wave, one per half wave (round 3).  A point's star needs <= 32 lanes for everything (edges, faces,
+// ring places, entries), and what bounds the kernel besides FP64 issue is the chain of dependent gathers in front of the
+// arithmetic (slot -> point -> rows -> faces -> vertices -> coordinates; edges -> ring -> cells -> centres: nine round trips
+// at three waves per SIMD): with a point per half every load instruction of that chain serves two points.  The halves then
+// run their own jobs, one per step (before: two jobs of ONE point side by side, the second half idle on the odd job).  All
+// cross-lane traffic is 32 wide.
 __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
-    __shared__ StarLds lds[kBlock / 64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-    StarLds& L = lds[wave];
-    for (int a = blockIdx.x * (kBlock / 64) + wave; a < nA; a += gridDim.x * (kBlock / 64)) {
-        if (a == 0 && lane == 0) w.actEntOff[nA] = nE;
-        const int p = w.actIds[a];
+    __shared__ StarLds lds[kBlock / 32];
+    const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    StarLds& L = lds[threadIdx.x >> 5];
+    const int groups = gridDim.x * (kBlock / 32);
+    // the loop is wave-uniform (half 0 decides; half 1 of the last round may be without a point: live = false)
+    for (int a0 = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 2; a0 < nA; a0 += groups) {
+        const int a = a0 + half;
+        bool live = a < nA;
+        if (a == 0 && hl == 0) w.actEntOff[nA] = nE;
+        const int p = live ? w.actIds[a] : 0;
         const V3 cur = ldv(s.ptsCur, p);
         const V3 np = ldv(s.prop, p);
         const bool moved = (np != cur);
         const bool frozenBefore = s.frozen[p] != 0;
         const double curMin = s.ptMin[p], curMax = s.ptMax[p];
-        const int eBeg = w.actEntOff[a], eEnd = (a + 1 < nA) ? w.actEntOff[a + 1] : nE, nEnt = eEnd - eBeg;
+        const int eBeg = live ? w.actEntOff[a] : 0, eEnd = live ? ((a + 1 < nA) ? w.actEntOff[a + 1] : nE) : 0, nEnt = eEnd - eBeg;
         auto bad = [&](double mn, double mx) { return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax)); };
         // the point's edges with the lengths of their face rings, its faces with their vertex counts
-        const int eb = m.ppOff[p], nEdgesP = m.ppOff[p + 1] - eb;
-        const int fb = m.pfOff[p], nF = m.pfOff[p + 1] - fb;
-        const int myE = (lane < nEdgesP) ? m.peEdge[eb + lane] : -1;
+        const int eb = m.ppOff[p], nEdgesP = live ? m.ppOff[p + 1] - eb : 0;
+        const int fb = m.pfOff[p], nF = live ? m.pfOff[p + 1] - fb : 0;
+        const int myE = (hl < nEdgesP) ? m.peEdge[eb + hl] : -1;
         const int myNf = (myE >= 0) ? m.efOff[myE + 1] - m.efOff[myE] : 0;
         const bool myRingBad = (myE >= 0) && !m.edgeRingOk[myE];
-        const int myF = (lane < nF) ? m.pfFace[fb + lane] : -1;
+        const int myF = (hl < nF) ? m.pfFace[fb + hl] : -1;
         const int myFb = (myF >= 0) ? m.faceOff[myF] : 0;
         const int myV = (myF >= 0) ? m.faceOff[myF + 1] - myFb : 0;
         int inclN = myNf, inclV = myV;
-        for (int o = 1; o < 64; o <<= 1) {
-            const int tn = __shfl_up(inclN, o, 64), tv = __shfl_up(inclV, o, 64);
-            if (lane >= o) { inclN += tn; inclV += tv; }
+        for (int o = 1; o < 32; o <<= 1) {
+            const int tn = __shfl_up(inclN, o, 32), tv = __shfl_up(inclV, o, 32);
+            if (hl >= o) { inclN += tn; inclV += tv; }
         }
-        const int totalLanes = __shfl(inclN, 63, 64), totalV = __shfl(inclV, 63, 64);
-        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts &&
-                          __ballot(myRingBad) == 0ull;
-        if (!fits) {   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
-            if (lane == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }
-            continue;
-        }
+        const int totalLanes = __shfl(inclN, 31, 32), totalV = __shfl(inclV, 31, 32);
+        const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts && ringBad == 0u;
+        if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
+        live = live && fits;
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
         int q = -1;
         V3 nq = v3(0, 0, 0);
         bool eligible = false;
         unsigned char nb0 = 0;
-        if (lane < nEnt) {
-            q = w.entNbr[eBeg + lane];
+        if (live && hl < nEnt) {
+            q = w.entNbr[eBeg + hl];
             nq = ldv(s.prop, q);
             const bool qFrozen = s.frozen[q] != 0;
             nb0 = qFrozen ? 8 : 0;
             eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
             if (eligible) nb0 |= 4;
         }
-        // stage the star: face ids, vertex offsets, vertex ids and current coordinates
-        if (lane < nF) {
+        // Stage the star.  The loads are arranged in LEVELS of independent requests (what bounds this kernel besides FP64 issue
+        // is the chain of dependent gathers, not their number): the edge lanes fetch their edge's cell range and end points
+        // here, next to the faces' vertex ranges (the ring places below get them by shuffle instead of loading them one level
+        // later), and the vertices are fetched by SLOT (four slots per lane: two round trips for the whole star) instead of by
+        // a loop over each face's vertices (two dependent round trips per vertex).
+        const int myCb = (myE >= 0) ? m.ecOff[myE] : 0, myNc = (myE >= 0) ? m.ecOff[myE + 1] - myCb : 0;
+        const int myEfb = (myE >= 0) ? m.efOff[myE] : 0;
+        const int myE0 = (myE >= 0) ? m.edges[2 * myE] : -1, myE1 = (myE >= 0) ? m.edges[2 * myE + 1] : -1;
+        if (live && hl < nF) {
             const int o = inclV - myV;
-            L.fid[lane] = myF;
-            L.voff[lane] = o;
-            for (int v = 0; v < myV; ++v) {
-                const int g = m.facePts[myFb + v];
-                const V3 c = ldv(s.ptsCur, g);
-                L.vid[o + v] = g; L.vx[o + v] = c.x; L.vy[o + v] = c.y; L.vz[o + v] = c.z;
-            }
+            L.fid[hl] = myF;
+            L.voff[hl] = o;
+            L.fbeg[hl] = myFb;
+            for (int v = 0; v < myV; ++v) L.vface[o + v] = (unsigned char)hl;
         }
-        if (lane == 0) L.voff[nF] = totalV;
-        if (lane < nEnt) L.nb[lane] = nb0;
+        if (live && hl == 0) L.voff[nF] = totalV;
+        if (live && hl < nEnt) L.nb[hl] = nb0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        // this lane's ring place -- the same on both halves
+        // this lane's ring place
         StarLane P;
-        P.valid = hl < totalLanes;
+        P.valid = live && hl < totalLanes;
         P.hasCell = false; P.xI = -1; P.pFirst = true; P.xc = v3(0, 0, 0); P.cc = v3(0, 0, 0); P.l = 0; P.nextLane = hl;
+        int ringFaceId = -1, ringCellAt = -1;
         {
-            int e = -1, first = 0, nfj = 0;
+            int first = 0, nfj = 0, cb = 0, nc = 0, efb = 0, e0I = -1, e1I = -1;
+            bool found = false;
             for (int j = 0; j < nEdgesP; ++j) {
-                const int hi = __shfl(inclN, j, 64), ej = __shfl(myE, j, 64), nj = __shfl(myNf, j, 64);
-                if (e < 0 && hl < hi) { e = ej; first = hi - nj; nfj = nj; }
+                const int hi = __shfl(inclN, j, 32), nj = __shfl(myNf, j, 32);
+                const int cbj = __shfl(myCb, j, 32), ncj = __shfl(myNc, j, 32), efbj = __shfl(myEfb, j, 32);
+                const int e0j = __shfl(myE0, j, 32), e1j = __shfl(myE1, j, 32);
+                if (!found && hl < hi) { found = true; first = hi - nj; nfj = nj; cb = cbj; nc = ncj; efb = efbj; e0I = e0j; e1I = e1j; }
             }
             if (P.valid) {
                 const int i = hl - first;
-                const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
                 P.hasCell = i < nc;
                 P.nextLane = (i + 1 < nfj) ? hl + 1 : first;          // closed ring: the last cell ends at face 0
-                const int e0I = m.edges[2 * e], e1I = m.edges[2 * e + 1];
                 P.pFirst = (e0I == p);
                 P.xI = P.pFirst ? e1I : e0I;
-                P.xc = ldv(s.ptsCur, P.xI);
-                if (P.hasCell) P.cc = ldv(s.cellCtr, m.ringCell[cb + i]);   // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
-                const int f = m.ringFace[m.efOff[e] + i];
-                for (int l = 0; l < nF; ++l) if (L.fid[l] == f) P.l = l;
+                ringFaceId = efb + i;
+                if (P.hasCell) ringCellAt = cb + i;
             }
         }
-        const bool counts = P.valid && P.hasCell;
-        // jobs, two at a time (one per half wave).  Round 1: the self test, then entry i with p at its current position -- only
-        // the jobs whose result can be consulted: the self test of a point that moves and is still free, the entries of the
-        // neighbours that are free and moving (a job that is not needed would still cost its half wave the full arithmetic:
-        // the needed ones are listed first, two list places per step)
-        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
-        const bool selfNeeded = moved && !frozenBefore;
-        const unsigned long long elig = __ballot(eligible);
-        const int nEl = __popcll(elig), first = selfNeeded ? 1 : 0;
-        if (eligible) L.job[first + __popcll(elig & ((1ull << lane) - 1ull))] = (signed char)lane;
-        if (lane == 0 && selfNeeded) L.job[0] = -1;
+        // level: vertex ids by slot, the ring's face and cell, the coordinates of the edge's other end
+        int vg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = hl + 32 * u;
+            vg[u] = -1;
+            if (live && k < totalV) { const int l = L.vface[k]; vg[u] = m.facePts[L.fbeg[l] + (k - L.voff[l])]; }
+        }
+        const int rf = (ringFaceId >= 0) ? m.ringFace[ringFaceId] : -1;
+        const int rc = (ringCellAt >= 0) ? m.ringCell[ringCellAt] : -1;
+        if (P.valid) P.xc = ldv(s.ptsCur, P.xI);
+        // level: the coordinates
+        V3 vc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0);
+        if (rc >= 0) P.cc = ldv(s.cellCtr, rc);                      // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = hl + 32 * u;
+            if (vg[u] >= 0) { L.vid[k] = vg[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
+        }
+        if (P.valid) for (int l = 0; l < nF; ++l) if (L.fid[l] == rf) P.l = l;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const int nJobs = first + nEl;
-        for (int j0 = 0; j0 < nJobs; j0 += 2) {
-            const int j = j0 + half;
-            const bool run = j < nJobs;
-            const int ei = run ? (int)L.job[j] : 0;                  // entry of this half's job (-1: self)
-            const int src = ei < 0 ? 0 : ei;
-            const int jq = __shfl(q, src, 64);
-            const V3 jnq = v3(__shfl(nq.x, src, 64), __shfl(nq.y, src, 64), __shfl(nq.z, src, 64));
-            const double angle = (ei < 0) ? starLaneAngle(L, P, p, np, -1, np) : starLaneAngle(L, P, p, cur, jq, jnq);
+        const bool counts = P.valid && P.hasCell;
+        // Jobs, one per step and half wave, ONE call site for all of them (a job's state is data, not control flow).  Job codes:
+        // -1 the self test (p at its proposal), e = entry e with p at its current position, 64 + e = entry e with p at its
+        // proposal.  Only jobs whose result can be consulted are listed: the self test of a point that moves and is still free,
+        // the entries of the neighbours that are free and moving; the proposal-state jobs are appended after the first step,
+        // once the self test has told whether p can act from its proposal at all (it is only read if p is still free at its
+        // first visit and does not freeze itself, SM.C:1376-1399).
+        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+        const bool selfNeeded = live && moved && !frozenBefore;
+        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
+        const int nEl = __popc(elig), first = selfNeeded ? 1 : 0;
+        const int myRank = __popc(elig & ((1u << hl) - 1u));
+        if (eligible) L.job[first + myRank] = (signed char)hl;
+        if (hl == 0 && selfNeeded) L.job[0] = -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int nJobs = live ? first + nEl : 0;
+        for (int j = 0; j < nJobs; ++j) {
+            const int code = (int)L.job[j];
+            const bool isSelf = code < 0, atProp = code >= 64;
+            const int ei = isSelf ? 0 : (code & 63);                 // entry of this job
+            const int jq = __shfl(q, ei, 32);
+            const V3 jnq = v3(__shfl(nq.x, ei, 32), __shfl(nq.y, ei, 32), __shfl(nq.z, ei, 32));
+            const V3 c1 = (isSelf || atProp) ? np : cur;
+            const double angle = starLaneAngle(L, P, p, c1, isSelf ? -1 : jq, isSelf ? np : jnq);
             double mn, mx;
-            starReduce(run && counts, angle, mn, mx);
-            const bool isBad = run && bad(mn, mx);
-            // the self result is known to the whole wave after the first step
-            const int selfBad = __shfl((j == 0 && selfNeeded && isBad) ? 1 : 0, 0, 64);
-            if (j0 == 0 && selfBad) sbits |= 1u;
-            if (run && ei >= 0 && hl == 0) {
+            starReduce(counts, angle, mn, mx);
+            const bool isBad = bad(mn, mx);
+            if (j == 0) {
+                if (selfNeeded && isBad) sbits |= 1u;                // (the reduction leaves mn / mx in every lane of the half)
+                if (moved && !(sbits & 5u) && nEl > 0) {             // p can act from its proposal: the proposal-state jobs
+                    if (eligible) L.job[nJobs + myRank] = (signed char)(64 + hl);
+                    nJobs += nEl;
+                }
+            }
+            if (!isSelf && hl == 0) {
                 unsigned char v = L.nb[ei];
-                if (isBad) v |= 2;
-                if (isBad && !moved) v |= 1;                         // not moved: proposal = current position
+                if (atProp) { if (isBad) v |= 1; }
+                else {
+                    if (isBad) v |= 2;
+                    if (isBad && !moved) v |= 1;                     // not moved: proposal = current position
+                }
                 L.nb[ei] = v;
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
         }
-        if (lane == 0) w.actBits[a] = (uint8_t)sbits;
-        // round 2: entry i with p at its proposal -- only read if p is still free at its first visit and does not freeze itself
-        if (moved && !(sbits & 5u)) {
-            for (int j0 = first; j0 < nJobs; j0 += 2) {
-                const int j = j0 + half;
-                const bool run = j < nJobs;
-                const int ei = run ? (int)L.job[j] : 0;
-                const int jq = __shfl(q, ei, 64);
-                const V3 jnq = v3(__shfl(nq.x, ei, 64), __shfl(nq.y, ei, 64), __shfl(nq.z, ei, 64));
-                const double angle = starLaneAngle(L, P, p, np, jq, jnq);
-                double mn, mx;
-                starReduce(run && counts, angle, mn, mx);
-                if (run && hl == 0 && bad(mn, mx)) L.nb[ei] |= 1;
-            }
-        }
+        if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (lane < nEnt) { w.entBits[eBeg + lane] = L.nb[lane]; w.entSlot[eBeg + lane] = activeSlotOf(s, w, q); }
+        if (live && hl < nEnt) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }

@@ -106,6 +106,11 @@ struct smgpu_handle {
     // face-angle walk: compacted tables + host replay (kernels_walk.hpp) when many points are active
     int walkMode = -1;         // -1 undecided, 0 one-wave device replay (k_fa_pred + k_fa_walk: few active points), 1 host replay,
                                // 2 device replay as a causal fixed point (k_walk_fix: many active points)
+    bool walkForced = false;   // SMGPU_WALK / SMGPU_HOST_WALK name the replay form: no re-decision
+    int walkSwitches = 0;      // how often the automatic choice changed since the parameters were set (smgpu_debug_walk_mode)
+    int* nActiveHost = nullptr;   // pinned, device-visible: nActive of the last iteration the GPU has finished (-1: none yet)
+    long walkDecisions = 0;
+    hipEvent_t evWalkLag[2] = {nullptr, nullptr};
     bool walkAlloc = false;
     WalkView wv{};
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
@@ -617,6 +622,19 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     s.stats = nullptr;
     s.sharedSlot = nullptr;
     s.combA = nullptr;
+    {   // the word through which the GPU tells the host how busy the face-angle walk is (updateWalkMode)
+        void* dp = nullptr;
+        if (hipHostMalloc((void**)&h->nActiveHost, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer(&dp, h->nActiveHost, 0) == hipSuccess) {
+            *(volatile int*)h->nActiveHost = -1;
+            s.nActiveHost = (int*)dp;
+        } else {
+            (void)hipGetLastError();
+            if (h->nActiveHost) (void)hipHostFree(h->nActiveHost);
+            h->nActiveHost = nullptr;
+            s.nActiveHost = nullptr;      // the replay form then stays as first decided
+        }
+    }
     computeAlgoBytes(h);
     if (envInt("SMGPU_VERBOSE", 0)) std::fprintf(stderr, "[smgpu] set-up: total %.2f s\n", sinceCreate());
     *out = h;
@@ -631,6 +649,8 @@ int smgpu_destroy(smgpu_handle* h) {
     for (auto e : h->freeEvents) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->pinned) (void)hipHostFree(h->pinned);
+    if (h->nActiveHost) (void)hipHostFree(h->nActiveHost);
+    for (hipEvent_t e : h->evWalkLag) if (e) (void)hipEventDestroy(e);
     if (h->side) { (void)hipStreamSynchronize(h->side); (void)hipStreamDestroy(h->side); }
     if (h->evToExch) (void)hipEventDestroy(h->evToExch);
     if (h->evFromExch) (void)hipEventDestroy(h->evFromExch);
@@ -760,6 +780,9 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p) {
     h->prm = *p;
     h->prmSet = true;
     h->walkMode = -1;
+    h->walkSwitches = 0;
+    h->walkDecisions = 0;
+    if (h->nActiveHost) *(volatile int*)h->nActiveHost = -1;
     h->geomAheadDone = false;
     computeAlgoBytes(h);
     return 0;
@@ -1038,7 +1061,7 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 3) / 4), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
         })) return 1;
@@ -1189,8 +1212,58 @@ static int forkFaFilter(smgpu_handle* h) {
     return 0;
 }
 
+// The replay form of the face-angle walk (and with it the list form of the exact face-angle pass).  Few points outside the
+// good range: the one-wave replay over the full flag array (two launches); many: compaction + predicates per active point +
+// the fixed-point replay (nine launches that would be pure overhead on a good mesh).  SMGPU_WALK = wave | host | fix forces
+// one (SMGPU_HOST_WALK = 0 | 1: the first two, as in round 1).  Otherwise the first constrained iteration of a parameter set
+// reads the count once (one synchronisation, decideWalkMode), and from then on the choice follows the mesh: the
+// end-of-iteration reduction leaves nActive in a pinned host word (State::nActiveHost) and every iteration is enqueued with
+// the form that fits the LATEST count the GPU has published -- a mesh that starts good and degrades (or the reverse) changes
+// form mid-run.  Both forms give the same result, so a stale count only costs time; the staleness is bounded by waiting, every
+// 8th decision, for the iteration enqueued 8 decisions earlier (the GPU still has those 8 iterations queued: it never idles).
+static int walkThreshold() { return envInt("SMGPU_HOST_WALK_THRESHOLD", 256); }
+static int decideWalkMode(smgpu_handle* h) {
+    const char* env = std::getenv("SMGPU_WALK");
+    const char* envHost = std::getenv("SMGPU_HOST_WALK");
+    h->walkForced = true;
+    if (env && std::string(env) == "wave") h->walkMode = 0;
+    else if (env && std::string(env) == "host") h->walkMode = 1;
+    else if (env && std::string(env) == "fix") h->walkMode = 2;
+    else if (envHost && std::string(envHost) != "auto") h->walkMode = std::atoi(envHost) ? 1 : 0;
+    else {
+        h->walkForced = false;
+        Accum a;
+        HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
+        HIP_OK(hipStreamSynchronize(h->stream));
+        h->walkMode = a.nActive > walkThreshold() ? 2 : 0;
+    }
+    return 0;
+}
+static int updateWalkMode(smgpu_handle* h) {
+    if (!h->prm.faceAngleConstraint || h->walkMode < 0 || h->walkForced || !h->nActiveHost) return 0;
+    const long n = ++h->walkDecisions;
+    if ((n & 7) == 0) {
+        const int cur = (int)((n >> 3) & 1);
+        for (hipEvent_t& e : h->evWalkLag) if (!e) HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        if (n >= 16) HIP_OK(hipEventSynchronize(h->evWalkLag[cur ^ 1]));   // the iteration enqueued 8 decisions ago has finished
+        HIP_OK(hipEventRecord(h->evWalkLag[cur], h->stream));
+    }
+    const int v = *(volatile int*)h->nActiveHost;
+    if (v < 0) return 0;
+    // hysteresis: up above the threshold, down below half of it
+    const int thr = walkThreshold();
+    const int want = (h->walkMode == 2) ? (v < thr / 2 ? 0 : 2) : (v > thr ? 2 : 0);
+    if (want != h->walkMode) {
+        h->walkMode = want;
+        ++h->walkSwitches;
+        if (envInt("SMGPU_VERBOSE", 0)) std::fprintf(stderr, "[smgpu] walk: %d points outside the good range -> replay form %s\n", v, want ? "fix" : "wave");
+    }
+    return 0;
+}
+
 static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
+    if (updateWalkMode(h)) return 1;
     if (forkFaFilter(h)) return 1;
     if (runSmooth<false>(h, h->mv, h->st, makePrm(h))) return 1;
     if (h->bndOn && h->haloOn && launchBndFix<false>(h, 0)) return 1;
@@ -1248,23 +1321,7 @@ static int runConstraints(smgpu_handle* h) {
         }
         if (h->faExactOnSide) h->faExactOnSide = false;          // done behind the filter on the side stream
         else if (runFaExactPass(h, s, faMaybe, h->stream)) return 1;
-        if (h->walkMode < 0) {
-            // decide once per parameter set: read how many points lie outside the good range now (one sync).  Few: the
-            // one-wave replay over the full flag array (two launches); many: the fixed-point replay.  SMGPU_WALK = wave | host |
-            // fix forces one (SMGPU_HOST_WALK = 0 | 1: the first two, as in round 1).
-            const char* env = std::getenv("SMGPU_WALK");
-            const char* envHost = std::getenv("SMGPU_HOST_WALK");
-            if (env && std::string(env) == "wave") h->walkMode = 0;
-            else if (env && std::string(env) == "host") h->walkMode = 1;
-            else if (env && std::string(env) == "fix") h->walkMode = 2;
-            else if (envHost && std::string(envHost) != "auto") h->walkMode = std::atoi(envHost) ? 1 : 0;
-            else {
-                Accum a;
-                HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
-                HIP_OK(hipStreamSynchronize(h->stream));
-                h->walkMode = a.nActive > envInt("SMGPU_HOST_WALK_THRESHOLD", 256) ? 2 : 0;
-            }
-        }
+        if (h->walkMode < 0 && decideWalkMode(h)) return 1;
         if (h->walkMode == 1) {
             if (runHostWalk(h)) return 1;
         } else if (h->walkMode == 2) {
@@ -1372,6 +1429,14 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     h->st.ptsNext = (done & 1) ? buf0 : buf1;
     h->st.stats = nullptr;
     if (drainTimers(h)) return 1;
+    return 0;
+}
+
+int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int32_t* lastCount) {
+    if (!h || !mode || !switches || !lastCount) return fail("null argument");
+    *mode = h->walkMode;
+    *switches = h->walkSwitches;
+    *lastCount = h->nActiveHost ? *(volatile int*)h->nActiveHost : -1;
     return 0;
 }
 
@@ -1627,6 +1692,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
     // a rank without shared geometry tiles launched nothing above: the previous iteration's reduction, parked for that
     // launch by smgpu_iter_end, must not wait for the next one (smgpu_iter_mid overwrites the partials before it)
     if (flushDeferred(h)) return 1;
+    if (updateWalkMode(h)) return 1;
     if (forkFaFilter(h)) return 1;
     State s = h->st;
     const MeshView& m = h->mv;

@@ -412,6 +412,13 @@ class SmoothEngine:
         self._check(self._lib.smgpu_iter_end(self._h))
 
     # -- debug / parity ------------------------------------------------------------------------
+    def debug_walk_mode(self):
+        """(replay form of the face-angle walk in use, number of automatic changes since set_params)"""
+        mode, sw, cnt = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.smgpu_debug_walk_mode(self._h, C.byref(mode), C.byref(sw), C.byref(cnt)))
+        self.last_active_count = cnt.value
+        return mode.value, sw.value
+
     def debug_propose(self):
         self._check(self._lib.smgpu_debug_propose(self._h))
 

@@ -129,6 +129,39 @@ def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
 
+def test_walk_replay_form_follows_the_mesh_mid_run(oracle_lib, monkeypatch):
+    """The replay form of the walk is re-decided while the run goes (smgpu.hip:updateWalkMode), from the count of points outside
+    the good range that the GPU publishes at the end of every iteration.  (a) A distorted block heals: 3 040 such points at the
+    start, < 500 after six iterations -- with the threshold at 1 000 the run starts on the fixed-point replay and must come
+    down to the one-wave replay.  (b) A good block is overwritten with the distorted coordinates mid-run (smgpu_set_points, no
+    new parameters): the one-wave replay must hand over to the fixed-point replay.  Results equal the oracle's either way."""
+    monkeypatch.setenv("SMGPU_HOST_WALK_THRESHOLD", "1000")
+    bad = _mk(24, 24, 24, 0.45, 5)
+    o, e, p = _pair(bad, oracle_lib)
+    n_o, res_o, frz_o = o.iterate(40, 0.0)
+    n_g, res_g, frz_g = e.iterate(40, 0.0)
+    mode, switches = e.debug_walk_mode()
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
+    assert mode == 0 and switches >= 1, (mode, switches)
+    e.close()
+    # (b): with this block's own step lengths the distorted coordinates heal within a few iterations (3 040, 660, 223, 155, ...
+    # points), and the host sees the counts with a lag of up to 16 iterations: threshold 100, so that the count stays above it
+    # long enough to be seen
+    monkeypatch.setenv("SMGPU_HOST_WALK_THRESHOLD", "100")
+    good = _mk(24, 24, 24, 0.2, 5)
+    o, e, p = _pair(good, oracle_lib)
+    o.iterate(3, 0.0); e.iterate(3, 0.0)
+    assert e.debug_walk_mode() == (0, 0)
+    o.set_points(bad.points); e.set_points(bad.points)
+    n_o, res_o, frz_o = o.iterate(24, 0.0)
+    n_g, res_g, frz_g = e.iterate(24, 0.0)
+    mode, switches = e.debug_walk_mode()
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
+    assert switches >= 1, (mode, switches)      # went up to the fixed-point replay (and possibly down again)
+
+
 def test_totalMinFreeze_and_explicit_lengths(oracle_lib):
     mesh = _mk(7, 7, 7, 0.3, 13)
     o, e, p = _pair(mesh, oracle_lib, totalMinFreeze=True, minEdgeLength=0.11, maxStepLength=0.004, minAngle=50.0, maxAngle=130.0)
