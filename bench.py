@@ -508,6 +508,9 @@ def main():
                        f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
                        + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
 
+    if world > 1 or force_dist:
+        sizes = dict(sizes)      # (read before the engine goes)
+        ds.close()               # streams drained, second communicator destroyed -- on every rank, before the group goes
     if rank != 0:
         if world > 1:
             import torch.distributed as dist

@@ -10,10 +10,12 @@
 #include <sched.h>
 #include <signal.h>
 #include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -22,6 +24,23 @@
 #include <vector>
 
 namespace smhost {
+
+// what the front-end's signal handler needs: the ranks' pids and the blackboard's abort word (async-signal-safe access only)
+struct NodeSignalState {
+    pid_t pids[64];
+    volatile sig_atomic_t nPids;
+    std::atomic<uint32_t>* abortFlag;
+    volatile sig_atomic_t got;
+};
+inline NodeSignalState& nodeSignalState() { static NodeSignalState st{}; return st; }
+// SIGTERM / SIGINT / SIGHUP at the front-end (a scheduler, `timeout`, ^C): the ranks must not outlive it holding their GPUs
+// and RCCL communicators.  Raise the abort word (ranks spinning in a barrier leave) and pass the signal on to every rank.
+inline void nodeForwardSignal(int sig) {
+    NodeSignalState& st = nodeSignalState();
+    st.got = sig;
+    if (st.abortFlag) st.abortFlag->store(1, std::memory_order_relaxed);
+    for (int i = 0; i < st.nPids; ++i) ::kill(st.pids[i], sig == SIGINT ? SIGINT : SIGTERM);
+}
 
 struct NodeShm {
     std::atomic<uint32_t> arrived;     // barrier: arrivals of the current generation
@@ -49,17 +68,36 @@ public:
         shm_->arrived = 0; shm_->generation = 0; shm_->abortFlag = 0; shm_->nRanks = (uint32_t)n; shm_->slotBytes = slot_;
         std::fflush(stdout);
         std::vector<pid_t> pids;
+        const pid_t parent = ::getpid();
+        NodeSignalState& sg = nodeSignalState();
+        sg.nPids = 0; sg.abortFlag = &shm_->abortFlag; sg.got = 0;
         for (int r = 0; r < n; ++r) {
             const pid_t pid = ::fork();
             if (pid < 0) { std::perror("smoothMesh: fork"); for (pid_t q : pids) ::kill(q, SIGTERM); std::exit(1); }
-            if (pid == 0) { rank = r; return; }
+            if (pid == 0) {
+                // a rank dies with the front-end, however that one is killed (kill -9 included); the re-check closes the
+                // window in which the parent died between fork() and prctl()
+                ::prctl(PR_SET_PDEATHSIG, SIGTERM);
+                if (::getppid() != parent) std::_Exit(1);
+                rank = r;
+                return;
+            }
             pids.push_back(pid);
+            sg.pids[r] = pid;
+            sg.nPids = r + 1;
+        }
+        {
+            struct sigaction sa;
+            std::memset(&sa, 0, sizeof(sa));
+            sa.sa_handler = nodeForwardSignal;
+            sigemptyset(&sa.sa_mask);
+            for (int sig : {SIGTERM, SIGINT, SIGHUP}) ::sigaction(sig, &sa, nullptr);
         }
         int worst = 0, left = n;
         while (left > 0) {
             int st = 0;
             const pid_t pid = ::wait(&st);
-            if (pid < 0) break;
+            if (pid < 0) { if (errno == EINTR) continue; break; }   // (a forwarded signal interrupts the wait)
             --left;
             const int code = WIFEXITED(st) ? WEXITSTATUS(st) : 128 + (WIFSIGNALED(st) ? WTERMSIG(st) : 0);
             if (code != 0) {
@@ -68,6 +106,7 @@ public:
                 for (pid_t q : pids) if (q != pid) ::kill(q, SIGTERM);
             }
         }
+        if (worst == 0 && sg.got) worst = 128 + (int)sg.got;
         std::exit(worst);
     }
 

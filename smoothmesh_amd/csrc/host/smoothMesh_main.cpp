@@ -761,6 +761,29 @@ int main(int argc, char** argv) {
         g_comm.barrier();                                                 // nobody overwrites its slot before everyone has read it
     };
 
+    // One-shot check of the RCCL transport before the first iteration (the Python driver has the same, rccl_direct.py): every
+    // rank sends a rank-specific pattern through the very exchange the loop uses and compares what arrived with what the peers
+    // must have sent (peer o keeps its slots towards this rank from peerBaseOf[o] on).  A layout or ordering mistake in the
+    // send / recv groups would otherwise produce wrong meshes silently on the first real multi-GPU run.
+    if (opt.parallel && transport == TRANSPORT_RCCL && nRanks > 1) {
+        const int32_t kMul = 1000003;
+        std::vector<int32_t> pat((size_t)std::max(K0.nSend, 1)), got((size_t)std::max(K0.nSend, 1), -1);
+        for (int k = 0; k < K0.nSend; ++k) pat[(size_t)k] = myRank * kMul + k;
+        if (K0.nSend) {
+            HIPCHK(hipMemcpyAsync(K0.sendF, pat.data(), (size_t)K0.nSend * 4, hipMemcpyHostToDevice, engineStream));
+            HIPCHK(hipMemsetAsync(K0.recvF, 0xff, (size_t)K0.nSend * 4, engineStream));
+        }
+        exchange({Part{K0.sendF, K0.recvF, 4}});
+        if (K0.nSend) HIPCHK(hipMemcpyAsync(got.data(), K0.recvF, (size_t)K0.nSend * 4, hipMemcpyDeviceToHost, engineStream));
+        HIPCHK(hipStreamSynchronize(engineStream));
+        bool good = true;
+        for (int o = 0; o < nRanks; ++o)
+            for (int j = 0; j < K0.peerCount[o]; ++j)
+                good = good && got[(size_t)(K0.peerSendBase[o] + j)] == o * kMul + peerBaseOf[(size_t)o] + j;
+        if (!g_comm.reduceAnd(good))
+            fatal("RCCL exchange self-check failed: the records that arrived are not the ones the peers sent (set SMOOTHMESH_TRANSPORT=shm to run on the host-staged transport)");
+    }
+
     auto writeMesh = [&](double timeValue) {
         const std::string tn = timeName(timeValue);
         OUT("Writing new mesh to time %s\n\n", tn.c_str());

@@ -78,7 +78,7 @@ struct FixView {
     int* T;               // [nRelevant] freeze step (header position of the visit that froze the point), -1 before the walk, INT_MAX never
     int* act;             // [nRelevant] 1: the point is still free at its first visit and acts from its proposal
     unsigned* bar;        // grid barrier counter
-    int* flags;           // [3] rotating "something changed" words
+    int* flags;           // [3] rotating "something changed" words, [3] the abort word of a barrier that timed out
 };
 
 // Ordered compaction of the active points and of their pointPoints rows: chunks of 4 096 points per workgroup, count launch +
@@ -359,7 +359,7 @@ __device__ __forceinline__ void starReduce(bool valid, double angle, double& mn,
 // at three waves per SIMD): with a point per half every load instruction of that chain serves two points.  The halves then
 // run their own jobs, one per step (before: two jobs of ONE point side by side, the second half idle on the odd job).  All
 // cross-lane traffic is 32 wide.
-__global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE) {
+__global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
     __shared__ StarLds lds[kBlock / 32];
@@ -526,6 +526,17 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
             __builtin_amdgcn_wave_barrier();
         }
         if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
+        if (opCount) {
+            // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs, by the reference's arithmetic
+            // (SM.C:1135-1231 per (edge, cell) pair: two projected face-centre vectors 77 + 3 (n - 1) + (3 | 33) each for a face
+            // of n vertices, the projected cell centre 77, two clamped acos and their sum 95 -- sqrt = 22, division = 11 per
+            // component, acos = 40; per edge of the point 69 for the edge vector) times the jobs that were needed.  One add per
+            // point, spread over 64 words.
+            const int nv = counts ? L.voff[P.l + 1] - L.voff[P.l] : 0;
+            int ops = counts ? 2 * (77 + 3 * (nv - 1) + (((nv & (nv - 1)) == 0) ? 3 : 33)) + 77 + 95 : 0;
+            for (int o = 16; o > 0; o >>= 1) ops += __shfl_xor(ops, o, 32);
+            if (live && hl == 0) atomicAdd(&opCount[a & 63], (unsigned long long)nJobs * (unsigned long long)(ops + 69 * nEdgesP));
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         if (live && hl < nEnt) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
@@ -565,7 +576,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w) {
 // fx.T != NULL (device replay): an entry item keeps its owner's slot in `hpos` (k_rel_link leaves it there: nothing is
 // pushed in that mode) and the barrier words of k_walk_fix are reset
 __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, FixView fx) {
-    if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { *fx.bar = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = 0; }
+    if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { *fx.bar = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = fx.flags[3] = 0; }
     const int nA = w.header[0];
     if (nA <= 0) { if (blockIdx.x == 0 && threadIdx.x == 0) { w.header2[0] = 0; w.header2[1] = 0; } return; }
     if ((int)(blockIdx.x * kRelChunk) >= nA) return;
@@ -646,32 +657,50 @@ __device__ __forceinline__ void stAgent(int* p, int v) { __hip_atomic_store(p, v
 // Grid barrier of the persistent launch.  Everything the workgroups hand each other (T, act, flags, the items' last-sent
 // words) is written and read with agent-scope atomics / sc1 accesses, which are served by L2, so the barrier only has to
 // make sure that every wave's operations have completed before its workgroup arrives (MI355X_MICROARCH.md, "Valid forms":
-// agent atomics on both sides).  A wait that takes absurdly long (workgroups that never became resident) raises acc->err
-// instead of hanging the stream.
-__device__ __forceinline__ void fixBarrier(unsigned* ctr, unsigned& target, Accum* acc) {
+// agent atomics on both sides).  A barrier that cannot complete (workgroups that never became resident: several engines or
+// a foreign process on the device) must not hang the stream: the first workgroup whose wait exceeds the wall-clock limit
+// raises acc->err AND an abort word (flags[3]) that every spin loop tests, so all workgroups leave within microseconds of
+// each other; k_walk_fix returns as soon as a barrier reports it.  Returns false when the launch is being abandoned.
+constexpr unsigned long long kFixTimeoutTicks = 200000000ull;   // s_memrealtime runs at 100 MHz: two seconds
+__device__ __forceinline__ bool fixBarrier(FixView fx, unsigned& target, Accum* acc) {
+    unsigned* ctr = fx.bar;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    __shared__ int aborted;
     if (threadIdx.x == 0) {
         target += gridDim.x;
+        int ab = 0;
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        long long spins = 0;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
         while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1ll << 26)) { acc->err = 3; break; }
+            if ((++spins & 63u) == 0u) {
+                if (ldAgent(&fx.flags[3]) != 0) { ab = 1; break; }
+                if (__builtin_amdgcn_s_memrealtime() - t0 > kFixTimeoutTicks) {
+                    acc->err = 3;
+                    stAgent(&fx.flags[3], 1);
+                    ab = 1;
+                    break;
+                }
+            }
         }
+        if (!ab && ldAgent(&fx.flags[3]) != 0) ab = 1;
+        aborted = ab;
     }
     __syncthreads();
+    return aborted == 0;
 }
 
 // a round's "did anything change" vote: flags[fi] collects it, the word after next is cleared for its next use (every
-// workgroup has read it two barriers ago)
-__device__ __forceinline__ bool fixVote(FixView fx, int& fi, bool mine, unsigned& target, Accum* acc) {
+// workgroup has read it two barriers ago).  *ok = false when the launch is being abandoned (see fixBarrier).
+__device__ __forceinline__ bool fixVote(FixView fx, int& fi, bool mine, unsigned& target, Accum* acc, bool* ok) {
     const int any = __syncthreads_or(mine ? 1 : 0);
     if (threadIdx.x == 0) {
         if (any) __hip_atomic_fetch_or(&fx.flags[fi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (blockIdx.x == 0) stAgent(&fx.flags[(fi + 1) % 3], 0);
     }
-    fixBarrier(fx.bar, target, acc);
+    if (!fixBarrier(fx, target, acc)) { *ok = false; return false; }
     const bool changed = ldAgent(&fx.flags[fi]) != 0;
     fi = (fi + 1) % 3;
     return changed;
@@ -684,6 +713,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
     const int gtid = blockIdx.x * kFixBlock + threadIdx.x, gstride = gridDim.x * kFixBlock;
     unsigned target = 0;
     int fi = 0;
+    bool ok = true;
     for (int x = gtid; x < nR; x += gstride) stAgent(&fx.act[x], 0);   // round 1: no proposal-state entry fires (an upper bound of T)
     for (int outer = 0;; ++outer) {
         // the seeds that do not depend on anybody else
@@ -691,7 +721,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
             const unsigned rb = w.relBits[x];   // bit0 own move deteriorates, bit1 moved, bit2 frozen before the walk
             stAgent(&fx.T[x], (rb & 4u) ? -1 : (((rb & 3u) == 3u) ? w.hdrPos[x] : kNever));
         }
-        fixBarrier(fx.bar, target, s.acc);
+        if (!fixBarrier(fx, target, s.acc)) return;
         // entries that fire at their owner's first visit: proposal-state entries of the owners in A; current-state entries
         // of owners that never move or were frozen before the walk (they are never re-visited)
         for (int i = gtid; i < nItems; i += gstride) {
@@ -706,7 +736,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                 else stAgent(&w.items[i].id, kNever);                      // real target: `id` is free, it holds the last T sent
             }
         }
-        fixBarrier(fx.bar, target, s.acc);
+        if (!fixBarrier(fx, target, s.acc)) return;
         // frozen => re-visited at once, held at its current position: T flows along the current-state entries.  Every workgroup
         // owns a contiguous stretch of the item sequence (= a slab of the mesh: the items follow the point ids) and sweeps
         // it a few times between two grid barriers, so chains that stay inside a slab do not cost a barrier per link
@@ -730,7 +760,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                     if (!__syncthreads_or(ch ? 1 : 0)) break;
                     chAny = true;
                 }
-                if (!fixVote(fx, fi, chAny, target, s.acc)) break;
+                if (!fixVote(fx, fi, chAny, target, s.acc, &ok)) break;
             }
         }
         // who was still free at its own first visit?
@@ -741,9 +771,11 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
             const int a = ldAgent(&fx.T[x]) >= w.hdrPos[x] ? 1 : 0;
             if (a != ldAgent(&fx.act[x])) { stAgent(&fx.act[x], a); ch = true; }
         }
-        if (!fixVote(fx, fi, ch, target, s.acc)) break;
+        if (!ok) return;
+        if (!fixVote(fx, fi, ch, target, s.acc, &ok)) break;
         if (outer > 4096) { if (gtid == 0) s.acc->err = 3; break; }       // cannot happen: every round fixes a longer prefix
     }
+    if (!ok) return;
     // results: every point that got a freeze step, and every sink an entry fired at
     for (int x = gtid; x < nR; x += gstride)
         if (!(w.relBits[x] & 4u) && ldAgent(&fx.T[x]) != kNever) s.frozen[w.items[w.hdrPos[x]].id] = 1;

@@ -111,6 +111,7 @@ struct smgpu_handle {
     int* nActiveHost = nullptr;   // pinned, device-visible: nActive of the last iteration the GPU has finished (-1: none yet)
     long walkDecisions = 0;
     hipEvent_t evWalkLag[2] = {nullptr, nullptr};
+    unsigned long long* dWalkOps = nullptr;   // [64] algorithmic FP64 instructions of the walk predicates, counted in timing passes
     bool walkAlloc = false;
     WalkView wv{};
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
@@ -938,7 +939,9 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     rc |= devAlloc(h, &w.relBits, P);
     rc |= devAlloc(h, &w.hdrPos, P);
     rc |= devAlloc(h, &w.items, E + P);
+    rc |= devAlloc(h, &h->dWalkOps, 64);
     if (rc) return 1;
+    HIP_OK(hipMemset(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
     h->walkAlloc = true;
     return 0;
 }
@@ -1061,7 +1064,7 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE);
+            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
         })) return 1;
@@ -1143,7 +1146,7 @@ static int runFixWalk(smgpu_handle* h) {
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1);
+            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
         })) return 1;
@@ -1467,6 +1470,14 @@ int smgpu_enable_timing(smgpu_handle* h, int32_t on) {
 int smgpu_get_counters(smgpu_handle* h, smgpu_counters* o) {
     if (!h || !o) return fail("null argument");
     if (drainTimers(h)) return 1;
+    if (h->dWalkOps && h->launches[K_FA_PRED] > 0) {   // the walk predicates' algorithmic FP64 instructions, counted by the timed launches
+        unsigned long long ops[64];
+        HIP_OK(hipMemcpy(ops, h->dWalkOps, sizeof(ops), hipMemcpyDeviceToHost));
+        unsigned long long tot = 0;
+        for (unsigned long long v : ops) tot += v;
+        if (tot > 0) { h->algoF64[K_FA_PRED] = (int64_t)(tot / (unsigned long long)h->launches[K_FA_PRED]); h->algoBytes[K_FA_PRED] = 0; }
+    }
+    if (h->walkMode > 0) h->algoBytes[K_FA_WALK] = 0;   // the compacted replay is latency work: no streaming byte count to price it against
     o->nKernels = K_COUNT;
     for (int k = 0; k < K_COUNT; ++k) {
         o->name[k] = kKernelNames[k];
@@ -1481,6 +1492,7 @@ int smgpu_get_counters(smgpu_handle* h, smgpu_counters* o) {
 int smgpu_reset_counters(smgpu_handle* h) {
     if (!h) return fail("null handle");
     if (drainTimers(h)) return 1;
+    if (h->dWalkOps) HIP_OK(hipMemset(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
     for (int k = 0; k < K_COUNT; ++k) { h->ms[k] = 0; h->launches[k] = 0; }
     return 0;
 }

@@ -258,6 +258,21 @@ class DistributedSmoother:
             return None
         return d
 
+    def close(self):
+        """Orderly shutdown, to be called on every rank BEFORE dist.barrier() / destroy_process_group(): drain the engine's and
+        the exchange stream (nothing may still be using the second communicator), destroy that communicator, release the
+        engine.  Leaving this to __del__ would destroy the communicator after the process group is gone, with work possibly
+        still in flight -- an exit-time hang or abort inside ncclCommDestroy on a real multi-GPU run."""
+        for st in (getattr(self, "estream", None), getattr(self, "xstream", None)):
+            if st is not None:
+                st.synchronize()
+        d, self.direct = getattr(self, "direct", None), None
+        if d is not None:
+            d.close()
+        eng = getattr(self, "engine", None)
+        if eng is not None and hasattr(eng, "close"):
+            eng.close()
+
     def global_min_edge(self):
         """getMeshStats + returnReduce(minOp), SM.C:1527"""
         dev = "cpu" if self._staged() else self.device

@@ -282,3 +282,32 @@ def test_parallel_single_rank_initialises_rccl(tmp_path, oracle_lib):
     assert [int(b) for _, b, _ in LINE.findall(out)] == frz.tolist()
     got = read_polymesh(str(tmp_path / "processor0" / "constant" / "polyMesh"), pointsDir=str(tmp_path / "processor0" / "5" / "polyMesh")).points
     assert rel_linf(got, o.points()) <= 1e-13
+
+
+def test_parallel_case_over_rccl_when_the_box_has_two_gpus(tmp_path, oracle_lib, monkeypatch):
+    """two ranks, two devices, SMOOTHMESH_TRANSPORT=rccl: the grouped ncclSend / ncclRecv exchange between DIFFERENT ranks (and
+    its one-shot self-check against the slot layout) -- the path a 1-GPU box can never reach.  Skipped there."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs: RCCL refuses two ranks on one device")
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.meshgen import hex_subdomain
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    monkeypatch.setenv("SMOOTHMESH_TRANSPORT", "rccl")
+    subs = [hex_subdomain((6, 5, 4), (2, 1, 1), r, jitter=0.3, seed=9) for r in range(2)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0"])
+    assert "debug transport" not in out and "self-check failed" not in out
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs))
+    for o in orcs:
+        o.set_params(prm)
+    off, dom, loc = shared_point_table(subs)
+    mo = oracle_lib.MultiOracle(orcs, off, dom, loc)
+    n, res, frz = mo.iterate(6, 0.0)
+    assert [int(b) for _, b, _ in LINE.findall(out)] == frz.tolist()
+    for s, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "6" / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13
