@@ -372,10 +372,35 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->device = d->device;
     const auto tCreate0 = std::chrono::steady_clock::now();
     auto sinceCreate = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tCreate0).count(); };
-    const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets,
-                                           d->facePoints, d->owner, d->neighbour);
-    if (!terr.empty()) { delete h; return fail("smgpu_create: " + terr); }
-    auto cleanup = [&](int rc) { smgpu_destroy(h); return rc; };
+    // The one-off host work is pipelined: the Z-curve of the points (needs the coordinates only) starts at once; the geometry
+    // tile tables start as soon as the cell -> face lists stand (Topology::build's afterCells hook) and are built next to the
+    // rest of the addressing; the smoothing and edge tile tables follow the addressing, side by side.
+    const bool wantTiles = envInt("SMGPU_TILES", 1) != 0;
+    const bool mortonTiles = envInt("SMGPU_TILE_MORTON", 1) != 0;
+    std::future<std::vector<int32_t>> fPointOrder;
+    if (wantTiles && mortonTiles) fPointOrder = std::async(std::launch::async, [&] { return mortonOrderOf(d->nPoints, d->points); });
+    std::future<std::string> fGeom;
+    {
+        const int geomT0 = envInt("SMGPU_GEOM_T", 256);
+        const int geomCells0 = envInt("SMGPU_GEOM_CELLS", geomT0 / 2);
+        const int capGP0 = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells0, 1400)), capGF0 = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells0, 1400));
+        const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256;
+        const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour,
+            [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0] {
+                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); });
+        if (!terr.empty()) {
+            if (fGeom.valid()) fGeom.wait();
+            if (fPointOrder.valid()) fPointOrder.wait();
+            delete h;
+            return fail("smgpu_create: " + terr);
+        }
+    }
+    auto cleanup = [&](int rc) {   // (the host threads still read the handle's tables)
+        if (fGeom.valid()) fGeom.wait();
+        if (fPointOrder.valid()) fPointOrder.wait();
+        smgpu_destroy(h);
+        return rc;
+    };
     if (hipSetDevice(h->device) != hipSuccess) return cleanup(fail("hipSetDevice failed"));
     if (d->useCallerStream) h->stream = (hipStream_t)d->stream;
     else {
@@ -437,17 +462,20 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const int capGF = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells, 1400));   // two rounds of 256 face threads at 128 cells
         const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500));
         const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
-        const bool morton = envInt("SMGPU_TILE_MORTON", 1) != 0;
+        const bool morton = mortonTiles;
         std::vector<uint8_t> internalMask((size_t)t.nPoints);
         for (int p = 0; p < t.nPoints; ++p) internalMask[(size_t)p] = (flags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
         const double tTopo = sinceCreate();
-        // the three tile tables only read the addressing: built side by side on host threads
-        auto fGeom = std::async(std::launch::async, [&] { return h->gt.build(t, d->points, morton, h->geomT, geomCells, capGP, capGF); });
+        std::vector<int32_t> pointOrder;
+        if (fPointOrder.valid()) pointOrder = fPointOrder.get();
+        const std::vector<int32_t>* po = (morton && !pointOrder.empty()) ? &pointOrder : nullptr;
+        // (the geometry tables were started by Topology::build's hook; SMGPU_GEOM_T etc. were read there)
+        (void)geomCells; (void)capGP; (void)capGF;
         auto fEdge = std::async(std::launch::async, [&]() -> std::string {
-            return h->useFilter ? h->etl.build(t, d->points, morton, 256, 512, 768, 512) : std::string("not built");
+            return h->useFilter ? h->etl.build(t, d->points, morton, 256, 512, 768, 512, po) : std::string("not built");
         });
-        const std::string e2 = h->stl.build(t, d->points, internalMask.data(), morton, h->smoothT, capSC, capSN);
-        const std::string e1 = fGeom.get();
+        const std::string e2 = h->stl.build(t, d->points, internalMask.data(), morton, h->smoothT, capSC, capSN, po);
+        const std::string e1 = fGeom.valid() ? fGeom.get() : std::string("not built");
         const std::string e3 = fEdge.get();
         if (envInt("SMGPU_VERBOSE", 0))
             std::fprintf(stderr, "[smgpu] set-up: addressing %.2f s, tile tables (3 host threads) %.2f s\n", tTopo, sinceCreate() - tTopo);

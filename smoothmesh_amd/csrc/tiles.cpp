@@ -1,9 +1,28 @@
 // tiles.cpp -- see tiles.hpp.
 #include "tiles.hpp"
+#include "parallel.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace smgpu {
+
+namespace {
+struct PhaseTimer {
+    const char* who;
+    bool on;
+    std::chrono::steady_clock::time_point t;
+    explicit PhaseTimer(const char* w) : who(w), on(std::getenv("SMGPU_VERBOSE") && std::atoi(std::getenv("SMGPU_VERBOSE")) >= 2), t(std::chrono::steady_clock::now()) {}
+    void lap(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "[smgpu] %s tiles: %-18s %.2f s\n", who, what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 
 // ELL row widths: multiples of 4 entries (one ushort4 chunk), at least one chunk so that kernels may read chunk 0 unconditionally
 static inline int32_t roundUp4(int32_t v) { return v <= 4 ? 4 : (v + 3) & ~3; }
@@ -19,24 +38,90 @@ static inline uint64_t spread21(uint64_t v) {   // 21 bits -> every third bit
 }
 
 // positions sorted along the Z-curve of the given coordinates (3 per element); ties keep id order
-static std::vector<int32_t> mortonOrder(int32_t n, const std::vector<double>& xyz) {
+static std::vector<int32_t> mortonOrder(int32_t n, const double* xyz) {
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int32_t i = 0; i < n; ++i)
-        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], xyz[3 * (size_t)i + a]); hi[a] = std::max(hi[a], xyz[3 * (size_t)i + a]); }
+    {
+        const int parts = rangeParts(n);
+        std::vector<double> plo(3 * (size_t)parts, 1e300), phi(3 * (size_t)parts, -1e300);
+        parallelRanges(n, parts, [&](int part, int64_t b, int64_t e) {
+            double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+            for (int64_t i = b; i < e; ++i)
+                for (int a = 0; a < 3; ++a) { l[a] = std::min(l[a], xyz[3 * (size_t)i + a]); h[a] = std::max(h[a], xyz[3 * (size_t)i + a]); }
+            for (int a = 0; a < 3; ++a) { plo[3 * (size_t)part + a] = l[a]; phi[3 * (size_t)part + a] = h[a]; }
+        });
+        for (int part = 0; part < parts; ++part)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], plo[3 * (size_t)part + a]); hi[a] = std::max(hi[a], phi[3 * (size_t)part + a]); }
+    }
     double ext = 0.0;
     for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
     const double scale = ext > 0.0 ? 2097151.0 / ext : 0.0;   // one isotropic scale: bricks stay cubic in space
     std::vector<std::pair<uint64_t, int32_t>> key((size_t)n);
-    for (int32_t i = 0; i < n; ++i) {
-        uint64_t k = 0;
-        for (int a = 0; a < 3; ++a) k |= spread21((uint64_t)((xyz[3 * (size_t)i + a] - lo[a]) * scale)) << a;
-        key[(size_t)i] = {k, i};
-    }
-    std::sort(key.begin(), key.end());
+    parallelRanges(n, rangeParts(n), [&](int, int64_t b, int64_t e) {
+        for (int64_t i = b; i < e; ++i) {
+            uint64_t k = 0;
+            for (int a = 0; a < 3; ++a) k |= spread21((uint64_t)((xyz[3 * (size_t)i + a] - lo[a]) * scale)) << a;
+            key[(size_t)i] = {k, (int32_t)i};
+        }
+    });
+    // sort by (key, id): the keys' top byte cuts the sequence into 256 buckets (an octant subdivision of the curve) that are
+    // sorted side by side -- the same order as one std::sort over all pairs
+    if (rangeParts(n) > 1) {
+        const int shift = 55;   // keys have 63 bits
+        std::vector<size_t> cnt(257, 0);
+        for (int32_t i = 0; i < n; ++i) ++cnt[(size_t)(key[(size_t)i].first >> shift) + 1];
+        for (int bkt = 0; bkt < 256; ++bkt) cnt[(size_t)bkt + 1] += cnt[(size_t)bkt];
+        std::vector<std::pair<uint64_t, int32_t>> tmp((size_t)n);
+        {
+            std::vector<size_t> cur(cnt.begin(), cnt.end() - 1);
+            for (int32_t i = 0; i < n; ++i) tmp[cur[(size_t)(key[(size_t)i].first >> shift)]++] = key[(size_t)i];
+        }
+        key.swap(tmp);
+        std::vector<std::pair<uint64_t, int32_t>>().swap(tmp);
+        parallelRanges(256, (int)std::min<unsigned>(hostThreads(), 256u), [&](int, int64_t b, int64_t e) {
+            for (int64_t bkt = b; bkt < e; ++bkt) std::sort(key.begin() + (ptrdiff_t)cnt[(size_t)bkt], key.begin() + (ptrdiff_t)cnt[(size_t)bkt + 1]);
+        });
+    } else std::sort(key.begin(), key.end());
     std::vector<int32_t> order((size_t)n);
     for (int32_t i = 0; i < n; ++i) order[(size_t)i] = key[(size_t)i].second;
     return order;
 }
+
+std::vector<int32_t> mortonOrderOf(int32_t n, const double* xyz) { return mortonOrder(n, xyz); }
+
+// "has the open tile got this element already?" for the greedy boundary passes.  A tile holds a few hundred elements, so a
+// small open-addressing table that lives in L1 answers it; mesh-sized stamp arrays (one random access into 40 - 120 MB per
+// query) made these serial passes the longest part of the set-up on a 10 M-cell mesh.
+namespace {
+class SmallSet {
+public:
+    explicit SmallSet(int32_t expected) { int32_t n = 64; while (n < 4 * expected) n <<= 1; slot_.assign((size_t)n, -1); mask_ = (uint32_t)n - 1; }
+    bool insert(int32_t x) {   // true if x was not in the set
+        if (4 * (touched_.size() + 1) > slot_.size()) grow();
+        uint32_t h = ((uint32_t)x * 2654435761u) & mask_;
+        while (slot_[h] != -1) {
+            if (slot_[h] == x) return false;
+            h = (h + 1) & mask_;
+        }
+        slot_[h] = x;
+        touched_.push_back(h);
+        return true;
+    }
+    void clear() { for (uint32_t h : touched_) slot_[h] = -1; touched_.clear(); }
+private:
+    void grow() {
+        std::vector<int32_t> keys;
+        keys.reserve(touched_.size());
+        for (uint32_t h : touched_) keys.push_back(slot_[h]);
+        slot_.assign(slot_.size() * 2, -1);
+        mask_ = (uint32_t)slot_.size() - 1;
+        touched_.clear();
+        for (int32_t k : keys) insert(k);
+    }
+    std::vector<int32_t> slot_;
+    std::vector<uint32_t> touched_;
+    uint32_t mask_ = 0;
+};
+}  // namespace
 
 static std::vector<int32_t> naturalOrder(int32_t n) {
     std::vector<int32_t> o((size_t)n);
@@ -47,40 +132,45 @@ static std::vector<int32_t> naturalOrder(int32_t n) {
 std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
                              int32_t capPoints, int32_t capFaces) {
     threads = nThreads;
+    PhaseTimer tm("geometry");
     if (capCells > threads) capCells = threads;
     const auto& cf = t.cellFacesGeom;
     const auto& fp = t.facePoints;
     if (morton) {
         std::vector<double> cc(3 * (size_t)t.nCells, 0.0);
-        for (int32_t c = 0; c < t.nCells; ++c) {
-            double s[3] = {0, 0, 0};
-            int32_t n = 0;
-            for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
-                const int32_t f = cf.val[k] & 0x7fffffff;
-                for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j, ++n)
-                    for (int a = 0; a < 3; ++a) s[a] += pts[3 * (size_t)fp.val[j] + a];
+        parallelRanges(t.nCells, rangeParts(t.nCells), [&](int, int64_t cb0, int64_t ce0) {
+            for (int32_t c = (int32_t)cb0; c < (int32_t)ce0; ++c) {
+                double s[3] = {0, 0, 0};
+                int32_t n = 0;
+                for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
+                    const int32_t f = cf.val[k] & 0x7fffffff;
+                    for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j, ++n)
+                        for (int a = 0; a < 3; ++a) s[a] += pts[3 * (size_t)fp.val[j] + a];
+                }
+                for (int a = 0; a < 3; ++a) cc[3 * (size_t)c + a] = n ? s[a] / n : 0.0;
             }
-            for (int a = 0; a < 3; ++a) cc[3 * (size_t)c + a] = n ? s[a] / n : 0.0;
-        }
-        order = mortonOrder(t.nCells, cc);
+        });
+        order = mortonOrder(t.nCells, cc.data());
     } else order = naturalOrder(t.nCells);
-    std::vector<int32_t> stampP((size_t)t.nPoints, -1), stampF((size_t)t.nFaces, -1);
+    tm.lap("order");
     // pass 1: greedy tile boundaries under the three capacities
+    SmallSet setP(capPoints), setF(capFaces);
     cellBeg.assign(1, 0);
-    int32_t tile = 0, nP = 0, nF = 0, nC = 0;
+    int32_t nP = 0, nF = 0, nC = 0;
     for (int32_t ci = 0; ci < t.nCells; ++ci) {
         const int32_t c = order[(size_t)ci];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addF = 0, addP = 0;
             for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
                 const int32_t f = cf.val[k] & 0x7fffffff;
-                if (stampF[f] != tile) { stampF[f] = tile; ++addF; }
+                if (setF.insert(f)) ++addF;
                 for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
-                    if (stampP[fp.val[j]] != tile) { stampP[fp.val[j]] = tile; ++addP; }
+                    if (setP.insert(fp.val[j])) ++addP;
             }
             if (nC > 0 && (nC + 1 > capCells || nP + addP > capPoints || nF + addF > capFaces)) {
                 cellBeg.push_back(ci);  // close the tile before this cell and re-add the cell to a fresh one
-                ++tile; nP = nF = nC = 0;
+                setP.clear(); setF.clear();
+                nP = nF = nC = 0;
                 continue;
             }
             if (addP > capPoints || addF > capFaces) return "a single cell exceeds the LDS tile capacity";
@@ -90,73 +180,106 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
     }
     cellBeg.push_back(t.nCells);
     nTiles = (int32_t)cellBeg.size() - 1;
+    tm.lap("boundaries");
 
-    // pass 2: per tile unique lists (ascending), local indices, ELL tables
-    std::fill(stampP.begin(), stampP.end(), -1);
-    std::fill(stampF.begin(), stampF.end(), -1);
-    std::vector<int32_t> locP((size_t)t.nPoints, -1), locF((size_t)t.nFaces, -1);
-    tpOff.assign(1, 0); tfOff.assign(1, 0);
-    tpIds.clear(); tfIds.clear(); faceVerts.clear(); cellFaces.clear();
-    fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear(); tileFlags.clear();
-    std::vector<int32_t> faces, points;
+    // pass 2: per tile unique lists (ascending), local indices, ELL tables -- tile ranges on host threads, every range
+    // builds its share of the tables, the shares are concatenated in tile order (local indices by binary search in the
+    // tile's sorted lists: no mesh-sized scratch per thread)
     std::vector<int32_t> cellTile((size_t)t.nCells, -1);   // which tile a cell belongs to
     for (int32_t ti = 0; ti < nTiles; ++ti)
         for (int32_t ci = cellBeg[ti]; ci < cellBeg[ti + 1]; ++ci) cellTile[(size_t)order[(size_t)ci]] = ti;
-    for (int32_t ti = 0; ti < nTiles; ++ti) {
-        faces.clear(); points.clear();
-        const int32_t cb = cellBeg[ti], ce = cellBeg[ti + 1];
-        int32_t cw = 0, fw = 0;
-        for (int32_t ci = cb; ci < ce; ++ci) {
-            const int32_t c = order[(size_t)ci];
-            cw = std::max(cw, cf.off[c + 1] - cf.off[c]);
-            for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
-                const int32_t f = cf.val[k] & 0x7fffffff;
-                if (stampF[f] != ti) { stampF[f] = ti; faces.push_back(f); }
+    struct Part {
+        std::vector<int32_t> tpIds, tfIds, nPts, nFcs, fvBase, cfBase;
+        std::vector<uint8_t> fvWidth, cfWidth, tileFlags;
+        std::vector<uint16_t> faceVerts, cellFaces;
+        int32_t maxPoints = 0, maxFaces = 0;
+        std::string err;
+    };
+    const int parts = rangeParts(nTiles, 64);
+    std::vector<Part> P((size_t)parts);
+    const int32_t threadsL = threads;
+    parallelRanges(nTiles, parts, [&](int part, int64_t tb, int64_t te) {
+        Part& o = P[(size_t)part];
+        std::vector<int32_t> faces, points;
+        for (int32_t ti = (int32_t)tb; ti < (int32_t)te; ++ti) {
+            faces.clear(); points.clear();
+            const int32_t cb = cellBeg[ti], ce = cellBeg[ti + 1];
+            int32_t cw = 0, fw = 0;
+            bool allQuads = true, allHex = true;
+            for (int32_t ci = cb; ci < ce; ++ci) {
+                const int32_t c = order[(size_t)ci];
+                cw = std::max(cw, cf.off[c + 1] - cf.off[c]);
+                allHex = allHex && (cf.off[c + 1] - cf.off[c] == 6);
+                for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) faces.push_back(cf.val[k] & 0x7fffffff);
             }
-        }
-        std::sort(faces.begin(), faces.end());
-        bool allQuads = true, allHex = true;
-        for (int32_t ci = cb; ci < ce; ++ci) { const int32_t c = order[(size_t)ci]; allHex = allHex && (cf.off[c + 1] - cf.off[c] == 6); }
-        for (int32_t f : faces) {
-            allQuads = allQuads && (fp.off[f + 1] - fp.off[f] == 4);
-            fw = std::max(fw, fp.off[f + 1] - fp.off[f]);
-            for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
-                if (stampP[fp.val[j]] != ti) { stampP[fp.val[j]] = ti; points.push_back(fp.val[j]); }
-        }
-        std::sort(points.begin(), points.end());
-        cw = roundUp4(cw); fw = roundUp4(fw);
-        if ((int32_t)points.size() > 32767 || (int32_t)faces.size() > 32767 || cw > 252 || fw > 252)
-            return "tile too large for the 15-bit local index tables";
-        for (size_t i = 0; i < points.size(); ++i) locP[points[i]] = (int32_t)i;
-        for (size_t i = 0; i < faces.size(); ++i) locF[faces[i]] = (int32_t)i;
-        tpIds.insert(tpIds.end(), points.begin(), points.end());
-        tpOff.push_back((int32_t)tpIds.size());
-        fvBase.push_back((int32_t)faceVerts.size());
-        fvWidth.push_back((uint8_t)fw);
-        for (int32_t f : faces) {
-            const bool ownerHere = cellTile[(size_t)t.owner[f]] == ti;
-            tfIds.push_back(ownerHere ? (int32_t)(0x80000000u | (uint32_t)f) : f);
-            const int32_t n = fp.off[f + 1] - fp.off[f];
-            for (int32_t j = 0; j < fw; ++j) faceVerts.push_back(j < n ? (uint16_t)locP[fp.val[fp.off[f] + j]] : kEllPad);
-        }
-        tfOff.push_back((int32_t)tfIds.size());
-        cfBase.push_back((int32_t)cellFaces.size());
-        cfWidth.push_back((uint8_t)cw);
-        tileFlags.push_back((uint8_t)((allQuads ? 1 : 0) | (allHex ? 2 : 0)));
-        const size_t base = cellFaces.size();
-        cellFaces.resize(base + (size_t)cw * threads, kEllPad);
-        for (int32_t ci = cb; ci < ce; ++ci) {
-            const int32_t c = order[(size_t)ci];
-            const int32_t tl = ci - cb;
-            for (int32_t k = cf.off[c], j = 0; k < cf.off[c + 1]; ++k, ++j) {
-                const int32_t v = cf.val[k];
-                cellFaces[base + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)(locF[v & 0x7fffffff] | (v < 0 ? 0x8000 : 0));
+            std::sort(faces.begin(), faces.end());
+            faces.erase(std::unique(faces.begin(), faces.end()), faces.end());
+            for (int32_t f : faces) {
+                allQuads = allQuads && (fp.off[f + 1] - fp.off[f] == 4);
+                fw = std::max(fw, fp.off[f + 1] - fp.off[f]);
+                for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j) points.push_back(fp.val[j]);
             }
+            std::sort(points.begin(), points.end());
+            points.erase(std::unique(points.begin(), points.end()), points.end());
+            cw = roundUp4(cw); fw = roundUp4(fw);
+            if ((int32_t)points.size() > 32767 || (int32_t)faces.size() > 32767 || cw > 252 || fw > 252) {
+                o.err = "tile too large for the 15-bit local index tables";
+                return;
+            }
+            auto locP = [&](int32_t p) { return (int32_t)(std::lower_bound(points.begin(), points.end(), p) - points.begin()); };
+            auto locF = [&](int32_t f) { return (int32_t)(std::lower_bound(faces.begin(), faces.end(), f) - faces.begin()); };
+            o.tpIds.insert(o.tpIds.end(), points.begin(), points.end());
+            o.nPts.push_back((int32_t)points.size());
+            o.fvBase.push_back((int32_t)o.faceVerts.size());
+            o.fvWidth.push_back((uint8_t)fw);
+            for (int32_t f : faces) {
+                const bool ownerHere = cellTile[(size_t)t.owner[f]] == ti;
+                o.tfIds.push_back(ownerHere ? (int32_t)(0x80000000u | (uint32_t)f) : f);
+                const int32_t n = fp.off[f + 1] - fp.off[f];
+                for (int32_t j = 0; j < fw; ++j) o.faceVerts.push_back(j < n ? (uint16_t)locP(fp.val[fp.off[f] + j]) : kEllPad);
+            }
+            o.nFcs.push_back((int32_t)faces.size());
+            o.cfBase.push_back((int32_t)o.cellFaces.size());
+            o.cfWidth.push_back((uint8_t)cw);
+            o.tileFlags.push_back((uint8_t)((allQuads ? 1 : 0) | (allHex ? 2 : 0)));
+            const size_t base = o.cellFaces.size();
+            o.cellFaces.resize(base + (size_t)cw * threadsL, kEllPad);
+            for (int32_t ci = cb; ci < ce; ++ci) {
+                const int32_t c = order[(size_t)ci];
+                const int32_t tl = ci - cb;
+                for (int32_t k = cf.off[c], j = 0; k < cf.off[c + 1]; ++k, ++j) {
+                    const int32_t v = cf.val[k];
+                    o.cellFaces[base + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)(locF(v & 0x7fffffff) | (v < 0 ? 0x8000 : 0));
+                }
+            }
+            o.maxPoints = std::max(o.maxPoints, (int32_t)points.size());
+            o.maxFaces = std::max(o.maxFaces, (int32_t)faces.size());
         }
-        maxPoints = std::max(maxPoints, (int32_t)points.size());
-        maxFaces = std::max(maxFaces, (int32_t)faces.size());
-        if (faceVerts.size() > 0x7fffffffu || cellFaces.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    });
+    tpOff.assign(1, 0); tfOff.assign(1, 0);
+    fvBase.clear(); fvWidth.clear(); cfBase.clear(); cfWidth.clear(); tileFlags.clear();
+    size_t fvTotal = 0, cfTotal = 0;
+    for (Part& o : P) {
+        if (!o.err.empty()) return o.err;
+        for (int32_t n : o.nPts) tpOff.push_back(tpOff.back() + n);
+        for (int32_t n : o.nFcs) tfOff.push_back(tfOff.back() + n);
+        for (int32_t b : o.fvBase) fvBase.push_back((int32_t)(fvTotal + (size_t)b));
+        for (int32_t b : o.cfBase) cfBase.push_back((int32_t)(cfTotal + (size_t)b));
+        fvWidth.insert(fvWidth.end(), o.fvWidth.begin(), o.fvWidth.end());
+        cfWidth.insert(cfWidth.end(), o.cfWidth.begin(), o.cfWidth.end());
+        tileFlags.insert(tileFlags.end(), o.tileFlags.begin(), o.tileFlags.end());
+        fvTotal += o.faceVerts.size(); cfTotal += o.cellFaces.size();
+        maxPoints = std::max(maxPoints, o.maxPoints);
+        maxFaces = std::max(maxFaces, o.maxFaces);
     }
+    if (fvTotal > 0x7fffffffu || cfTotal > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    {
+        std::vector<std::vector<int32_t>> a, b;
+        std::vector<std::vector<uint16_t>> c, d;
+        for (Part& o : P) { a.push_back(std::move(o.tpIds)); b.push_back(std::move(o.tfIds)); c.push_back(std::move(o.faceVerts)); d.push_back(std::move(o.cellFaces)); }
+        concatParts(tpIds, a); concatParts(tfIds, b); concatParts(faceVerts, c); concatParts(cellFaces, d);
+    }
+    tm.lap("tables");
     return "";
 }
 
@@ -239,28 +362,31 @@ void chainCorners(std::vector<std::pair<int32_t, int32_t>>& corners, ChainScratc
 }  // namespace
 
 std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
-                               int32_t capCells, int32_t capPoints) {
+                               int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder) {
     threads = nThreads;
-    if (morton) order = mortonOrder(t.nPoints, std::vector<double>(xyz, xyz + 3 * (size_t)t.nPoints));
+    PhaseTimer tm("smoothing");
+    if (morton) order = pointOrder ? *pointOrder : mortonOrder(t.nPoints, xyz);
     else order = naturalOrder(t.nPoints);
+    tm.lap("order");
     const int32_t capTile = threads;
     const auto& pc = t.pointCells;
     const auto& pe = t.pointEdges;   // offsets shared with pointPoints
-    std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
+    SmallSet setC(capCells), setN(capPoints);
     ptBeg.assign(1, 0);
-    int32_t tile = 0, nC = 0, nN = 0, nT = 0;
+    int32_t nC = 0, nN = 0, nT = 0;
     for (int32_t pi = 0; pi < t.nPoints; ++pi) {
         const int32_t p = order[(size_t)pi];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addC = 0, addN = 0;
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
-                if (stampC[pc.val[k]] != tile) { stampC[pc.val[k]] = tile; ++addC; }
-            if (stampN[p] != tile) { stampN[p] = tile; ++addN; }
+                if (setC.insert(pc.val[k])) ++addC;
+            if (setN.insert(p)) ++addN;
             for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k)
-                if (stampN[t.pointPoints[k]] != tile) { stampN[t.pointPoints[k]] = tile; ++addN; }
+                if (setN.insert(t.pointPoints[k])) ++addN;
             if (nT > 0 && (nT + 1 > capTile || nC + addC > capCells || nN + addN > capPoints)) {
                 ptBeg.push_back(pi);
-                ++tile; nC = nN = nT = 0;
+                setC.clear(); setN.clear();
+                nC = nN = nT = 0;
                 continue;
             }
             if (addC > capCells || addN > capPoints) return "a single point exceeds the LDS tile capacity";
@@ -270,122 +396,172 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     }
     ptBeg.push_back(t.nPoints);
     nTiles = (int32_t)ptBeg.size() - 1;
+    tm.lap("boundaries");
 
-    std::fill(stampC.begin(), stampC.end(), -1);
-    std::fill(stampN.begin(), stampN.end(), -1);
-    std::vector<int32_t> locC((size_t)t.nCells, -1), locN((size_t)t.nPoints, -1);
-    tcOff.assign(1, 0); tnOff.assign(1, 0);
-    tcIds.clear(); tnIds.clear();
     selfLoc.assign((size_t)t.nPoints, 0);
-    pcBase.clear(); pcWidth.clear(); pcEll.clear(); ppBase.clear(); ppWidth.clear(); ppEll.clear(); pairEll.clear();
-    pfBase.clear(); pfWidth.clear(); pfEll.clear();
     const bool pairs = t.maxPointPoints <= 16;
-    std::vector<int32_t> cells, pts;
-    std::vector<std::pair<int32_t, int32_t>> corners;
-    ChainScratch chainScratch;
-    for (int32_t ti = 0; ti < nTiles; ++ti) {
-        cells.clear(); pts.clear();
-        const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
-        int32_t wc = 0, wn = 0, wf = 0;
-        for (int32_t pi = pb; pi < pend; ++pi) {
-            const int32_t p = order[(size_t)pi];
-            wf = std::max(wf, 2 * (t.pointFaces.off[p + 1] - t.pointFaces.off[p]));
-            wc = std::max(wc, pc.off[p + 1] - pc.off[p]);
-            wn = std::max(wn, pe.off[p + 1] - pe.off[p]);
-            for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
-                if (stampC[pc.val[k]] != ti) { stampC[pc.val[k]] = ti; cells.push_back(pc.val[k]); }
-            if (stampN[p] != ti) { stampN[p] = ti; pts.push_back(p); }
-            for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k)
-                if (stampN[t.pointPoints[k]] != ti) { stampN[t.pointPoints[k]] = ti; pts.push_back(t.pointPoints[k]); }
-        }
-        std::sort(cells.begin(), cells.end());
-        std::sort(pts.begin(), pts.end());
-        wc = roundUp4(wc); wn = roundUp4(wn); wf = roundUp4(wf);
-        if ((int32_t)cells.size() > 32766 || (int32_t)pts.size() > 32766 || wc > 252 || wn > 252 || wf > 252)
-            return "tile too large for the 15-bit local index tables";
-        for (size_t i = 0; i < cells.size(); ++i) locC[cells[i]] = (int32_t)i;
-        for (size_t i = 0; i < pts.size(); ++i) locN[pts[i]] = (int32_t)i;
-        tcIds.insert(tcIds.end(), cells.begin(), cells.end());
-        tcOff.push_back((int32_t)tcIds.size());
-        tnIds.insert(tnIds.end(), pts.begin(), pts.end());
-        tnOff.push_back((int32_t)tnIds.size());
-        pcBase.push_back((int32_t)pcEll.size()); pcWidth.push_back((uint8_t)wc);
-        ppBase.push_back((int32_t)ppEll.size()); ppWidth.push_back((uint8_t)wn);
-        const size_t cbase = pcEll.size(), nbase = ppEll.size();
-        pcEll.resize(cbase + (size_t)wc * threads, kEllPad);
-        ppEll.resize(nbase + (size_t)wn * threads, kEllPad);
-        pairEll.resize(nbase + (size_t)wn * threads, 0);
-        pfBase.push_back((int32_t)pfEll.size()); pfWidth.push_back((uint8_t)wf);
-        const size_t fbase = pfEll.size();
-        pfEll.resize(fbase + (size_t)wf * threads, kEllPad);
-        for (int32_t pi = pb; pi < pend; ++pi) {
-            const int32_t p = order[(size_t)pi];
-            const int32_t tl = pi - pb;
-            selfLoc[(size_t)pi] = (uint16_t)locN[p];
-            corners.clear();
-            for (int32_t k = t.pointFaces.off[p]; k < t.pointFaces.off[p + 1]; ++k) corners.push_back({t.pfPrev[k], t.pfNext[k]});
-            chainCorners(corners, chainScratch);
-            for (int32_t j = 0; j < 2 * (int32_t)corners.size(); j += 2) {
-                pfEll[fbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locN[corners[(size_t)j / 2].first];
-                pfEll[fbase + ((size_t)((j + 1) / 4) * threads + tl) * 4 + ((j + 1) % 4)] = (uint16_t)locN[corners[(size_t)j / 2].second];
+    struct Part {
+        std::vector<int32_t> tcIds, tnIds, nCl, nPt, pcBase, ppBase, pfBase;
+        std::vector<uint8_t> pcWidth, ppWidth, pfWidth;
+        std::vector<uint16_t> pcEll, ppEll, pairEll, pfEll;
+        int32_t maxCells = 0, maxPoints = 0;
+        std::string err;
+    };
+    const int parts = rangeParts(nTiles, 64);
+    std::vector<Part> P((size_t)parts);
+    const int32_t threadsL = threads;
+    parallelRanges(nTiles, parts, [&](int part, int64_t tb, int64_t te) {
+        Part& o = P[(size_t)part];
+        std::vector<int32_t> cells, pts;
+        std::vector<std::pair<int32_t, int32_t>> corners;
+        ChainScratch chainScratch;
+        for (int32_t ti = (int32_t)tb; ti < (int32_t)te; ++ti) {
+            cells.clear(); pts.clear();
+            const int32_t pb = ptBeg[ti], pend = ptBeg[ti + 1];
+            int32_t wc = 0, wn = 0, wf = 0;
+            for (int32_t pi = pb; pi < pend; ++pi) {
+                const int32_t p = order[(size_t)pi];
+                wf = std::max(wf, 2 * (t.pointFaces.off[p + 1] - t.pointFaces.off[p]));
+                wc = std::max(wc, pc.off[p + 1] - pc.off[p]);
+                wn = std::max(wn, pe.off[p + 1] - pe.off[p]);
+                for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k) cells.push_back(pc.val[k]);
+                pts.push_back(p);
+                for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k) pts.push_back(t.pointPoints[k]);
             }
-            for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
-                pcEll[cbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[pc.val[k]];
-            const int32_t b = pe.off[p], v = pe.off[p + 1] - b;
-            for (int32_t j = 0; j < v; ++j) {
-                const int32_t q = t.pointPoints[b + j];
-                ppEll[nbase + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)(locN[q] | (isInternal[q] ? 0x8000 : 0));
+            std::sort(cells.begin(), cells.end());
+            cells.erase(std::unique(cells.begin(), cells.end()), cells.end());
+            std::sort(pts.begin(), pts.end());
+            pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+            wc = roundUp4(wc); wn = roundUp4(wn); wf = roundUp4(wf);
+            if ((int32_t)cells.size() > 32766 || (int32_t)pts.size() > 32766 || wc > 252 || wn > 252 || wf > 252) {
+                o.err = "tile too large for the 15-bit local index tables";
+                return;
             }
-            if (pairs) {
-                // neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect
-                for (int32_t i = 0; i < v; ++i) {
-                    const int32_t qi = t.pointPoints[b + i];
-                    uint16_t mask = 0;
-                    for (int32_t j = 0; j < v; ++j) {
-                        if (j == i) continue;
-                        const int32_t qj = t.pointPoints[b + j];
-                        int32_t a = pc.off[qi], ae = pc.off[qi + 1], c = pc.off[qj], ce = pc.off[qj + 1];
-                        while (a < ae && c < ce) {
-                            if (pc.val[a] == pc.val[c]) { mask |= (uint16_t)(1u << j); break; }
-                            if (pc.val[a] < pc.val[c]) ++a; else ++c;
+            auto locC = [&](int32_t c) { return (int32_t)(std::lower_bound(cells.begin(), cells.end(), c) - cells.begin()); };
+            auto locN = [&](int32_t q) { return (int32_t)(std::lower_bound(pts.begin(), pts.end(), q) - pts.begin()); };
+            o.tcIds.insert(o.tcIds.end(), cells.begin(), cells.end());
+            o.nCl.push_back((int32_t)cells.size());
+            o.tnIds.insert(o.tnIds.end(), pts.begin(), pts.end());
+            o.nPt.push_back((int32_t)pts.size());
+            o.pcBase.push_back((int32_t)o.pcEll.size()); o.pcWidth.push_back((uint8_t)wc);
+            o.ppBase.push_back((int32_t)o.ppEll.size()); o.ppWidth.push_back((uint8_t)wn);
+            const size_t cbase = o.pcEll.size(), nbase = o.ppEll.size();
+            o.pcEll.resize(cbase + (size_t)wc * threadsL, kEllPad);
+            o.ppEll.resize(nbase + (size_t)wn * threadsL, kEllPad);
+            o.pairEll.resize(nbase + (size_t)wn * threadsL, 0);
+            o.pfBase.push_back((int32_t)o.pfEll.size()); o.pfWidth.push_back((uint8_t)wf);
+            const size_t fbase = o.pfEll.size();
+            o.pfEll.resize(fbase + (size_t)wf * threadsL, kEllPad);
+            for (int32_t pi = pb; pi < pend; ++pi) {
+                const int32_t p = order[(size_t)pi];
+                const int32_t tl = pi - pb;
+                selfLoc[(size_t)pi] = (uint16_t)locN(p);
+                corners.clear();
+                for (int32_t k = t.pointFaces.off[p]; k < t.pointFaces.off[p + 1]; ++k) corners.push_back({t.pfPrev[k], t.pfNext[k]});
+                chainCorners(corners, chainScratch);
+                for (int32_t j = 0; j < 2 * (int32_t)corners.size(); j += 2) {
+                    o.pfEll[fbase + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)locN(corners[(size_t)j / 2].first);
+                    o.pfEll[fbase + ((size_t)((j + 1) / 4) * threadsL + tl) * 4 + ((j + 1) % 4)] = (uint16_t)locN(corners[(size_t)j / 2].second);
+                }
+                for (int32_t k = pc.off[p], j = 0; k < pc.off[p + 1]; ++k, ++j)
+                    o.pcEll[cbase + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)locC(pc.val[k]);
+                const int32_t b = pe.off[p], v = pe.off[p + 1] - b;
+                for (int32_t j = 0; j < v; ++j) {
+                    const int32_t q = t.pointPoints[b + j];
+                    o.ppEll[nbase + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)(locN(q) | (isInternal[q] ? 0x8000 : 0));
+                }
+                if (pairs) {
+                    // neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect
+                    for (int32_t i = 0; i < v; ++i) {
+                        const int32_t qi = t.pointPoints[b + i];
+                        uint16_t mask = 0;
+                        for (int32_t j = 0; j < v; ++j) {
+                            if (j == i) continue;
+                            const int32_t qj = t.pointPoints[b + j];
+                            int32_t a = pc.off[qi], ae = pc.off[qi + 1], c = pc.off[qj], ce = pc.off[qj + 1];
+                            while (a < ae && c < ce) {
+                                if (pc.val[a] == pc.val[c]) { mask |= (uint16_t)(1u << j); break; }
+                                if (pc.val[a] < pc.val[c]) ++a; else ++c;
+                            }
                         }
+                        o.pairEll[nbase + ((size_t)(i / 4) * threadsL + tl) * 4 + (i % 4)] = mask;
                     }
-                    pairEll[nbase + ((size_t)(i / 4) * threads + tl) * 4 + (i % 4)] = mask;
                 }
             }
+            o.maxCells = std::max(o.maxCells, (int32_t)cells.size());
+            o.maxPoints = std::max(o.maxPoints, (int32_t)pts.size());
         }
-        maxCells = std::max(maxCells, (int32_t)cells.size());
-        maxPoints = std::max(maxPoints, (int32_t)pts.size());
-        if (pcEll.size() > 0x7fffffffu || ppEll.size() > 0x7fffffffu || pfEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    });
+    tcOff.assign(1, 0); tnOff.assign(1, 0);
+    pcBase.clear(); pcWidth.clear(); ppBase.clear(); ppWidth.clear(); pfBase.clear(); pfWidth.clear();
+    size_t pcTotal = 0, ppTotal = 0, pfTotal = 0;
+    for (Part& o : P) {
+        if (!o.err.empty()) return o.err;
+        for (int32_t n : o.nCl) tcOff.push_back(tcOff.back() + n);
+        for (int32_t n : o.nPt) tnOff.push_back(tnOff.back() + n);
+        for (int32_t b : o.pcBase) pcBase.push_back((int32_t)(pcTotal + (size_t)b));
+        for (int32_t b : o.ppBase) ppBase.push_back((int32_t)(ppTotal + (size_t)b));
+        for (int32_t b : o.pfBase) pfBase.push_back((int32_t)(pfTotal + (size_t)b));
+        pcWidth.insert(pcWidth.end(), o.pcWidth.begin(), o.pcWidth.end());
+        ppWidth.insert(ppWidth.end(), o.ppWidth.begin(), o.ppWidth.end());
+        pfWidth.insert(pfWidth.end(), o.pfWidth.begin(), o.pfWidth.end());
+        pcTotal += o.pcEll.size(); ppTotal += o.ppEll.size(); pfTotal += o.pfEll.size();
+        maxCells = std::max(maxCells, o.maxCells);
+        maxPoints = std::max(maxPoints, o.maxPoints);
     }
+    if (pcTotal > 0x7fffffffu || ppTotal > 0x7fffffffu || pfTotal > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    {
+        std::vector<std::vector<int32_t>> a, b;
+        std::vector<std::vector<uint16_t>> c, d, e, f;
+        for (Part& o : P) {
+            a.push_back(std::move(o.tcIds)); b.push_back(std::move(o.tnIds)); c.push_back(std::move(o.pcEll)); d.push_back(std::move(o.ppEll));
+            e.push_back(std::move(o.pairEll)); f.push_back(std::move(o.pfEll));
+        }
+        concatParts(tcIds, a); concatParts(tnIds, b); concatParts(pcEll, c); concatParts(ppEll, d); concatParts(pairEll, e); concatParts(pfEll, f);
+    }
+    tm.lap("tables");
     return "";
 }
 
 std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
-                             int32_t capFaces, int32_t capCells) {
+                             int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder) {
     threads = nThreads;
+    PhaseTimer tm("edge");
     const int32_t nE = t.nEdges;
-    if (morton) {
+    if (morton && pointOrder) {
+        // edges are stored in upper-triangular order, i.e. grouped by their start point: walk the points along their Z-curve
+        std::vector<int32_t> startOff((size_t)t.nPoints + 1, 0);
+        for (int32_t e = 0; e < nE; ++e) ++startOff[(size_t)t.edges[2 * e] + 1];
+        for (int32_t p = 0; p < t.nPoints; ++p) startOff[(size_t)p + 1] += startOff[(size_t)p];
+        order.clear();
+        order.reserve((size_t)nE);
+        for (int32_t p : *pointOrder)
+            for (int32_t e = startOff[(size_t)p]; e < startOff[(size_t)p + 1]; ++e) order.push_back(e);
+    } else if (morton) {
         std::vector<double> mid(3 * (size_t)nE);
-        for (int32_t e = 0; e < nE; ++e)
-            for (int a = 0; a < 3; ++a) mid[3 * (size_t)e + a] = 0.5 * (xyz[3 * (size_t)t.edges[2 * e] + a] + xyz[3 * (size_t)t.edges[2 * e + 1] + a]);
-        order = mortonOrder(nE, mid);
+        parallelRanges(nE, rangeParts(nE), [&](int, int64_t b, int64_t e1) {
+            for (int64_t e = b; e < e1; ++e)
+                for (int a = 0; a < 3; ++a) mid[3 * (size_t)e + a] = 0.5 * (xyz[3 * (size_t)t.edges[2 * e] + a] + xyz[3 * (size_t)t.edges[2 * e + 1] + a]);
+        });
+        order = mortonOrder(nE, mid.data());
     } else order = naturalOrder(nE);
+    tm.lap("order");
     const auto& ef = t.edgeFaces;
     const auto& ec = t.edgeCells;
-    std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
+    SmallSet setP(capPoints), setF(capFaces), setC(capCells);
     edgeBeg.assign(1, 0);
-    int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
+    int32_t nP = 0, nF = 0, nC = 0, nT = 0;
     for (int32_t ei = 0; ei < nE; ++ei) {
         const int32_t e = order[(size_t)ei];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t aP = 0, aF = 0, aC = 0;
-            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
-            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
-            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
+            for (int k = 0; k < 2; ++k) if (setP.insert(t.edges[2 * e + k])) ++aP;
+            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) if (setF.insert(ef.val[k])) ++aF;
+            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) if (setC.insert(ec.val[k])) ++aC;
             if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
                 edgeBeg.push_back(ei);
-                ++tile; nP = nF = nC = nT = 0;
+                setP.clear(); setF.clear(); setC.clear();
+                nP = nF = nC = nT = 0;
                 continue;
             }
             if (aP > capPoints || aF > capFaces || aC > capCells) return "a single edge exceeds the LDS tile capacity";
@@ -395,54 +571,93 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     }
     edgeBeg.push_back(nE);
     nTiles = (int32_t)edgeBeg.size() - 1;
-    std::fill(stP.begin(), stP.end(), -1); std::fill(stF.begin(), stF.end(), -1); std::fill(stC.begin(), stC.end(), -1);
-    std::vector<int32_t> locP((size_t)t.nPoints, -1), locF((size_t)t.nFaces, -1), locC((size_t)t.nCells, -1);
-    tpOff.assign(1, 0); tfOff.assign(1, 0); tcOff.assign(1, 0);
-    tpIds.clear(); tfIds.clear(); tcIds.clear(); efBase.clear(); ecBase.clear(); efWidth.clear(); ecWidth.clear(); efEll.clear(); ecEll.clear();
+    tm.lap("boundaries");
     epLoc.assign(2 * (size_t)nE, 0);
-    std::vector<int32_t> pts, fcs, cls;
-    for (int32_t ti = 0; ti < nTiles; ++ti) {
-        pts.clear(); fcs.clear(); cls.clear();
-        const int32_t eb = edgeBeg[ti], ee = edgeBeg[ti + 1];
-        int32_t wf = 0, wc = 0;
-        for (int32_t ei = eb; ei < ee; ++ei) {
-            const int32_t e = order[(size_t)ei];
-            wf = std::max(wf, ef.off[e + 1] - ef.off[e]);
-            wc = std::max(wc, ec.off[e + 1] - ec.off[e]);
-            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != ti) { stP[p] = ti; pts.push_back(p); } }
-            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != ti) { stF[f] = ti; fcs.push_back(f); } }
-            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != ti) { stC[cI] = ti; cls.push_back(cI); } }
+    struct Part {
+        std::vector<int32_t> tpIds, tfIds, tcIds, nP, nF, nC, efBase, ecBase;
+        std::vector<uint8_t> efWidth, ecWidth;
+        std::vector<uint16_t> efEll, ecEll;
+        int32_t maxPoints = 0, maxFaces = 0, maxCells = 0;
+        std::string err;
+    };
+    const int parts = rangeParts(nTiles, 64);
+    std::vector<Part> P((size_t)parts);
+    const int32_t threadsL = threads;
+    parallelRanges(nTiles, parts, [&](int part, int64_t tb, int64_t te) {
+        Part& o = P[(size_t)part];
+        std::vector<int32_t> pts, fcs, cls;
+        for (int32_t ti = (int32_t)tb; ti < (int32_t)te; ++ti) {
+            pts.clear(); fcs.clear(); cls.clear();
+            const int32_t eb = edgeBeg[ti], ee = edgeBeg[ti + 1];
+            int32_t wf = 0, wc = 0;
+            for (int32_t ei = eb; ei < ee; ++ei) {
+                const int32_t e = order[(size_t)ei];
+                wf = std::max(wf, ef.off[e + 1] - ef.off[e]);
+                wc = std::max(wc, ec.off[e + 1] - ec.off[e]);
+                pts.push_back(t.edges[2 * e]); pts.push_back(t.edges[2 * e + 1]);
+                for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) fcs.push_back(ef.val[k]);
+                for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) cls.push_back(ec.val[k]);
+            }
+            std::sort(pts.begin(), pts.end()); pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+            std::sort(fcs.begin(), fcs.end()); fcs.erase(std::unique(fcs.begin(), fcs.end()), fcs.end());
+            std::sort(cls.begin(), cls.end()); cls.erase(std::unique(cls.begin(), cls.end()), cls.end());
+            wf = roundUp4(wf); wc = roundUp4(wc);
+            if (pts.size() > 32766 || fcs.size() > 32766 || cls.size() > 32766 || wf > 252 || wc > 252) {
+                o.err = "tile too large for the 15-bit local index tables";
+                return;
+            }
+            auto loc = [](const std::vector<int32_t>& v, int32_t x) { return (int32_t)(std::lower_bound(v.begin(), v.end(), x) - v.begin()); };
+            o.tpIds.insert(o.tpIds.end(), pts.begin(), pts.end()); o.nP.push_back((int32_t)pts.size());
+            o.tfIds.insert(o.tfIds.end(), fcs.begin(), fcs.end()); o.nF.push_back((int32_t)fcs.size());
+            o.tcIds.insert(o.tcIds.end(), cls.begin(), cls.end()); o.nC.push_back((int32_t)cls.size());
+            o.efBase.push_back((int32_t)o.efEll.size()); o.efWidth.push_back((uint8_t)wf);
+            o.ecBase.push_back((int32_t)o.ecEll.size()); o.ecWidth.push_back((uint8_t)wc);
+            const size_t fb = o.efEll.size(), cb = o.ecEll.size();
+            o.efEll.resize(fb + (size_t)wf * threadsL, kEllPad);
+            o.ecEll.resize(cb + (size_t)wc * threadsL, kEllPad);
+            for (int32_t ei = eb; ei < ee; ++ei) {
+                const int32_t e = order[(size_t)ei], tl = ei - eb;
+                epLoc[2 * (size_t)ei] = (uint16_t)loc(pts, t.edges[2 * e]);
+                epLoc[2 * (size_t)ei + 1] = (uint16_t)loc(pts, t.edges[2 * e + 1]);
+                if (!t.edgeRingOk[(size_t)e]) continue;   // all-pad rows: the kernel flags the edge UNSURE
+                for (int32_t k = ef.off[e], j = 0; k < ef.off[e + 1]; ++k, ++j)
+                    o.efEll[fb + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)loc(fcs, t.ringFace[k]);
+                for (int32_t k = ec.off[e], j = 0; k < ec.off[e + 1]; ++k, ++j)
+                    o.ecEll[cb + ((size_t)(j / 4) * threadsL + tl) * 4 + (j % 4)] = (uint16_t)loc(cls, t.ringCell[k]);
+            }
+            o.maxPoints = std::max(o.maxPoints, (int32_t)pts.size());
+            o.maxFaces = std::max(o.maxFaces, (int32_t)fcs.size());
+            o.maxCells = std::max(o.maxCells, (int32_t)cls.size());
         }
-        std::sort(pts.begin(), pts.end()); std::sort(fcs.begin(), fcs.end()); std::sort(cls.begin(), cls.end());
-        wf = roundUp4(wf); wc = roundUp4(wc);
-        if (pts.size() > 32766 || fcs.size() > 32766 || cls.size() > 32766 || wf > 252 || wc > 252)
-            return "tile too large for the 15-bit local index tables";
-        for (size_t i = 0; i < pts.size(); ++i) locP[pts[i]] = (int32_t)i;
-        for (size_t i = 0; i < fcs.size(); ++i) locF[fcs[i]] = (int32_t)i;
-        for (size_t i = 0; i < cls.size(); ++i) locC[cls[i]] = (int32_t)i;
-        tpIds.insert(tpIds.end(), pts.begin(), pts.end()); tpOff.push_back((int32_t)tpIds.size());
-        tfIds.insert(tfIds.end(), fcs.begin(), fcs.end()); tfOff.push_back((int32_t)tfIds.size());
-        tcIds.insert(tcIds.end(), cls.begin(), cls.end()); tcOff.push_back((int32_t)tcIds.size());
-        efBase.push_back((int32_t)efEll.size()); efWidth.push_back((uint8_t)wf);
-        ecBase.push_back((int32_t)ecEll.size()); ecWidth.push_back((uint8_t)wc);
-        const size_t fb = efEll.size(), cb = ecEll.size();
-        efEll.resize(fb + (size_t)wf * threads, kEllPad);
-        ecEll.resize(cb + (size_t)wc * threads, kEllPad);
-        for (int32_t ei = eb; ei < ee; ++ei) {
-            const int32_t e = order[(size_t)ei], tl = ei - eb;
-            epLoc[2 * (size_t)ei] = (uint16_t)locP[t.edges[2 * e]];
-            epLoc[2 * (size_t)ei + 1] = (uint16_t)locP[t.edges[2 * e + 1]];
-            if (!t.edgeRingOk[(size_t)e]) continue;   // all-pad rows: the kernel flags the edge UNSURE
-            for (int32_t k = ef.off[e], j = 0; k < ef.off[e + 1]; ++k, ++j)
-                efEll[fb + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locF[t.ringFace[k]];
-            for (int32_t k = ec.off[e], j = 0; k < ec.off[e + 1]; ++k, ++j)
-                ecEll[cb + ((size_t)(j / 4) * threads + tl) * 4 + (j % 4)] = (uint16_t)locC[t.ringCell[k]];
-        }
-        maxPoints = std::max(maxPoints, (int32_t)pts.size());
-        maxFaces = std::max(maxFaces, (int32_t)fcs.size());
-        maxCells = std::max(maxCells, (int32_t)cls.size());
-        if (efEll.size() > 0x7fffffffu || ecEll.size() > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    });
+    tpOff.assign(1, 0); tfOff.assign(1, 0); tcOff.assign(1, 0);
+    efBase.clear(); ecBase.clear(); efWidth.clear(); ecWidth.clear();
+    size_t efTotal = 0, ecTotal = 0;
+    for (Part& o : P) {
+        if (!o.err.empty()) return o.err;
+        for (int32_t n : o.nP) tpOff.push_back(tpOff.back() + n);
+        for (int32_t n : o.nF) tfOff.push_back(tfOff.back() + n);
+        for (int32_t n : o.nC) tcOff.push_back(tcOff.back() + n);
+        for (int32_t b : o.efBase) efBase.push_back((int32_t)(efTotal + (size_t)b));
+        for (int32_t b : o.ecBase) ecBase.push_back((int32_t)(ecTotal + (size_t)b));
+        efWidth.insert(efWidth.end(), o.efWidth.begin(), o.efWidth.end());
+        ecWidth.insert(ecWidth.end(), o.ecWidth.begin(), o.ecWidth.end());
+        efTotal += o.efEll.size(); ecTotal += o.ecEll.size();
+        maxPoints = std::max(maxPoints, o.maxPoints);
+        maxFaces = std::max(maxFaces, o.maxFaces);
+        maxCells = std::max(maxCells, o.maxCells);
     }
+    if (efTotal > 0x7fffffffu || ecTotal > 0x7fffffffu) return "tile tables exceed int32 addressing";
+    {
+        std::vector<std::vector<int32_t>> a, b, c;
+        std::vector<std::vector<uint16_t>> d, e;
+        for (Part& o : P) {
+            a.push_back(std::move(o.tpIds)); b.push_back(std::move(o.tfIds)); c.push_back(std::move(o.tcIds));
+            d.push_back(std::move(o.efEll)); e.push_back(std::move(o.ecEll));
+        }
+        concatParts(tpIds, a); concatParts(tfIds, b); concatParts(tcIds, c); concatParts(efEll, d); concatParts(ecEll, e);
+    }
+    tm.lap("tables");
     return "";
 }
 

@@ -22,6 +22,9 @@ namespace smgpu {
 
 constexpr uint16_t kEllPad = 0xFFFF;
 
+// Z-curve (Morton) order of n elements given by 3 coordinates each: position -> element id, ties in id order
+std::vector<int32_t> mortonOrderOf(int32_t n, const double* xyz);
+
 // ---- geometry: tile = consecutive cells; LDS holds the tile's points and faces --------------------
 struct GeomTiles {
     int32_t nTiles = 0, threads = 0;
@@ -77,8 +80,9 @@ struct SmoothTiles {
     int32_t maxCells = 0, maxPoints = 0;
     std::vector<int32_t> order;     // tile order: position -> point id (see GeomTiles::order)
     // isInternal (SM.C:40-91) marks bit 15 of the ppEll entries whose neighbour is an internal point (SM.C:294)
+    // pointOrder (optional): mortonOrderOf(nPoints, points), computed by the caller (it also serves the edge tiles)
     std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
-                      int32_t capCells, int32_t capPoints);
+                      int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder = nullptr);
 };
 
 // ---- face-angle filter: tile = edges (Morton order of the edge midpoints); LDS holds the points, the
@@ -94,8 +98,10 @@ struct EdgeTiles {
     std::vector<uint16_t> efEll, ecEll;         // ring faces / ring cells (Topology::ringFace/ringCell), sliced ELL;
                                                 // an edge without a ring (non-manifold) has an all-pad face row
     int32_t maxPoints = 0, maxFaces = 0, maxCells = 0;
+    // pointOrder (optional, with morton): the edges follow the Z-curve of their START points (edges are stored grouped by start
+    // point) instead of a sort of their own over the 3x as many edge midpoints -- a tile is still a compact cluster of edges
     std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
-                      int32_t capFaces, int32_t capCells);
+                      int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr);
 };
 
 }  // namespace smgpu

@@ -1,7 +1,11 @@
 // topology.cpp -- see topology.hpp.  Count / scan / fill CSR construction, O(nnz).
 #include "topology.hpp"
+#include "parallel.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 
 namespace smgpu {
@@ -17,8 +21,15 @@ static void scanCounts(std::vector<int32_t>& off) {
 }
 
 std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, const int32_t* faceOffsets,
-                            const int32_t* facePts, const int32_t* own, const int32_t* nei) {
+                            const int32_t* facePts, const int32_t* own, const int32_t* nei, const std::function<void()>& afterCells) {
     nPoints = nP; nCells = nC; nFaces = nF; nInternalFaces = nIF;
+    const bool verbose = std::getenv("SMGPU_VERBOSE") && std::atoi(std::getenv("SMGPU_VERBOSE")) >= 2;
+    auto tLap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (verbose) std::fprintf(stderr, "[smgpu] addressing: %-24s %.2f s\n", what, std::chrono::duration<double>(now - tLap).count());
+        tLap = now;
+    };
     if (nP <= 0 || nC <= 0 || nF <= 0 || nIF < 0 || nIF > nF) return "invalid mesh sizes";
     const int64_t nnzFP = faceOffsets[nF];
     if (nnzFP >= (int64_t)1 << 31) return "face-point list exceeds int32 addressing";
@@ -36,6 +47,7 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
     for (int64_t i = 0; i < nnzFP; ++i)
         if (facePts[i] < 0 || facePts[i] >= nP) return "face point label out of range";
 
+    lap("copy + checks");
     // ---- cell -> faces (geometry accumulation order) -------------------------------------
     cellFacesGeom.off.assign(nC + 1, 0);
     for (int32_t f = 0; f < nF; ++f) cellFacesGeom.off[own[f] + 1]++;
@@ -48,6 +60,8 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         for (int32_t f = 0; f < nIF; ++f) cellFacesGeom.val[cur[nei[f]]++] = (int32_t)(0x80000000u | (uint32_t)f);
     }
 
+    lap("cellFaces");
+    if (afterCells) afterCells();
     // ---- pointFaces with prev/next vertex -------------------------------------------------
     pointFaces.off.assign(nP + 1, 0);
     for (int64_t i = 0; i < nnzFP; ++i) pointFaces.off[facePts[i] + 1]++;
@@ -71,28 +85,41 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         }
     }
 
+    lap("pointFaces");
     // ---- pointCells: cells of the point's faces, ascending, unique --------------------------
+    // (point ranges on host threads: every range builds its rows as the serial loop would, the ranges are concatenated in order)
     pointCells.off.assign(nP + 1, 0);
     {
-        std::vector<int32_t> tmp;
-        std::vector<int32_t> vals;
-        vals.reserve((size_t)nnzFP);
-        for (int32_t p = 0; p < nP; ++p) {
-            tmp.clear();
-            for (int32_t k = pointFaces.off[p]; k < pointFaces.off[p + 1]; ++k) {
-                const int32_t f = pointFaces.val[k];
-                tmp.push_back(own[f]);
-                if (f < nIF) tmp.push_back(nei[f]);
+        const int parts = rangeParts(nP);
+        std::vector<std::vector<int32_t>> pv((size_t)parts);
+        std::vector<int32_t> pmax((size_t)parts, 0);
+        parallelRanges(nP, parts, [&](int part, int64_t pb, int64_t pe) {
+            std::vector<int32_t> tmp;
+            std::vector<int32_t> vals;                                  // (thread-local until the end: no shared cache lines in the loop)
+            vals.reserve((size_t)(pointFaces.off[pe] - pointFaces.off[pb]));
+            int32_t localMax = 0;
+            for (int32_t p = (int32_t)pb; p < (int32_t)pe; ++p) {
+                tmp.clear();
+                for (int32_t k = pointFaces.off[p]; k < pointFaces.off[p + 1]; ++k) {
+                    const int32_t f = pointFaces.val[k];
+                    tmp.push_back(own[f]);
+                    if (f < nIF) tmp.push_back(nei[f]);
+                }
+                std::sort(tmp.begin(), tmp.end());
+                tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+                localMax = std::max(localMax, (int32_t)tmp.size());
+                vals.insert(vals.end(), tmp.begin(), tmp.end());
+                pointCells.off[p + 1] = (int32_t)tmp.size();
             }
-            std::sort(tmp.begin(), tmp.end());
-            tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
-            maxPointCells = std::max(maxPointCells, (int32_t)tmp.size());
-            vals.insert(vals.end(), tmp.begin(), tmp.end());
-            pointCells.off[p + 1] = (int32_t)vals.size();
-        }
-        pointCells.val.swap(vals);
+            pmax[(size_t)part] = localMax;
+            pv[(size_t)part].swap(vals);
+        });
+        for (int32_t v : pmax) maxPointCells = std::max(maxPointCells, v);
+        scanCounts(pointCells.off);
+        concatParts(pointCells.val, pv);
     }
 
+    lap("pointCells");
     // ---- edges: bucket (lo -> hi list), sort + unique per bucket => upper-triangular order ----
     std::vector<int32_t> loOff(nP + 1, 0);
     for (int32_t f = 0; f < nF; ++f) {
@@ -116,19 +143,32 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         }
     }
     std::vector<int32_t> edgeStart(nP + 1, 0);  // first edge id with start == p
-    edges.clear();
-    edges.reserve((size_t)nnzFP);
-    for (int32_t p = 0; p < nP; ++p) {
-        edgeStart[p] = (int32_t)(edges.size() / 2);
-        int32_t* b = his.data() + loOff[p];
-        int32_t* e = his.data() + loOff[p + 1];
-        std::sort(b, e);
-        e = std::unique(b, e);
-        for (int32_t* it = b; it != e; ++it) { edges.push_back(p); edges.push_back(*it); }
+    {
+        const int parts = rangeParts(nP);
+        std::vector<std::vector<int32_t>> pe2((size_t)parts);
+        parallelRanges(nP, parts, [&](int part, int64_t pb, int64_t pe) {
+            std::vector<int32_t> loc;
+            loc.reserve(2 * (size_t)(loOff[pe] - loOff[pb]));
+            for (int32_t p = (int32_t)pb; p < (int32_t)pe; ++p) {
+                edgeStart[p] = (int32_t)(loc.size() / 2);          // within the range; the range's base is added below
+                int32_t* b = his.data() + loOff[p];
+                int32_t* e = his.data() + loOff[p + 1];
+                std::sort(b, e);
+                e = std::unique(b, e);
+                for (int32_t* it = b; it != e; ++it) { loc.push_back(p); loc.push_back(*it); }
+            }
+            pe2[(size_t)part].swap(loc);
+        });
+        int32_t base = 0;
+        for (int part = 0; part < parts; ++part) {
+            const int64_t pb = (int64_t)nP * part / parts, pe = (int64_t)nP * (part + 1) / parts;
+            if (base) for (int64_t p = pb; p < pe; ++p) edgeStart[(size_t)p] += base;
+            base += (int32_t)(pe2[(size_t)part].size() / 2);
+        }
+        concatParts(edges, pe2);
     }
     nEdges = (int32_t)(edges.size() / 2);
     edgeStart[nP] = nEdges;
-    edges.shrink_to_fit();
     { std::vector<int32_t>().swap(his); }
     auto edgeId = [&](int32_t a, int32_t c) -> int32_t {
         const int32_t lo = std::min(a, c), hi = std::max(a, c);
@@ -137,6 +177,7 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         return -1;
     };
 
+    lap("edges");
     // ---- pointEdges / pointPoints ----------------------------------------------------------------
     pointEdges.off.assign(nP + 1, 0);
     for (int32_t e = 0; e < nEdges; ++e) { pointEdges.off[edges[2 * e] + 1]++; pointEdges.off[edges[2 * e + 1] + 1]++; }
@@ -152,29 +193,32 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
         }
     }
     for (int32_t p = 0; p < nP; ++p) maxPointPoints = std::max(maxPointPoints, pointEdges.off[p + 1] - pointEdges.off[p]);
+    lap("pointEdges");
     // prev/next vertex of every pointFaces entry as a slot of the point's pointPoints row
     pfPrevSlot.assign(pfPrev.size(), 255);
     pfNextSlot.assign(pfNext.size(), 255);
-    for (int32_t p = 0; p < nP; ++p) {
-        const int32_t nb = pointEdges.off[p], nv = pointEdges.off[p + 1] - nb;
-        for (int32_t k = pointFaces.off[p]; k < pointFaces.off[p + 1]; ++k)
-            for (int32_t j = 0; j < nv && j < 255; ++j) {
-                if (pointPoints[nb + j] == pfPrev[k]) pfPrevSlot[k] = (uint8_t)j;
-                if (pointPoints[nb + j] == pfNext[k]) pfNextSlot[k] = (uint8_t)j;
-            }
-    }
+    parallelRanges(nP, rangeParts(nP), [&](int, int64_t pb, int64_t pe) {
+        for (int32_t p = (int32_t)pb; p < (int32_t)pe; ++p) {
+            const int32_t nb = pointEdges.off[p], nv = pointEdges.off[p + 1] - nb;
+            for (int32_t k = pointFaces.off[p]; k < pointFaces.off[p + 1]; ++k)
+                for (int32_t j = 0; j < nv && j < 255; ++j) {
+                    if (pointPoints[nb + j] == pfPrev[k]) pfPrevSlot[k] = (uint8_t)j;
+                    if (pointPoints[nb + j] == pfNext[k]) pfNextSlot[k] = (uint8_t)j;
+                }
+        }
+    });
 
+    lap("pfPrev/NextSlot");
     // ---- edgeFaces (ascending face id) ------------------------------------------------------------
     edgeFaces.off.assign(nEdges + 1, 0);
     std::vector<int32_t> faceEdge(nnzFP);
-    for (int32_t f = 0; f < nF; ++f) {
-        const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
-        for (int32_t i = 0; i < n; ++i) {
-            const int32_t e = edgeId(facePts[b + i], facePts[b + (i == n - 1 ? 0 : i + 1)]);
-            faceEdge[b + i] = e;
-            edgeFaces.off[e + 1]++;
+    parallelRanges(nF, rangeParts(nF), [&](int, int64_t fb0, int64_t fe0) {
+        for (int32_t f = (int32_t)fb0; f < (int32_t)fe0; ++f) {
+            const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
+            for (int32_t i = 0; i < n; ++i) faceEdge[b + i] = edgeId(facePts[b + i], facePts[b + (i == n - 1 ? 0 : i + 1)]);
         }
-    }
+    });
+    for (int64_t k = 0; k < nnzFP; ++k) edgeFaces.off[faceEdge[(size_t)k] + 1]++;
     scanCounts(edgeFaces.off);
     edgeFaces.val.resize(edgeFaces.off[nEdges]);
     {
@@ -184,49 +228,68 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
     }
     { std::vector<int32_t>().swap(faceEdge); }
 
+    lap("edgeFaces");
     // ---- edgeCells (first appearance through edgeFaces, owner then neighbour) + face pairs ----
     edgeCells.off.assign(nEdges + 1, 0);
-    edgeCells.val.reserve(edgeFaces.val.size());
-    ecFace0.reserve(edgeFaces.val.size());
-    ecFace1.reserve(edgeFaces.val.size());
     {
-        std::vector<int32_t> cells;
-        for (int32_t e = 0; e < nEdges; ++e) {
-            const int32_t b = edgeFaces.off[e], n = edgeFaces.off[e + 1] - b;
-            maxEdgeFaces = std::max(maxEdgeFaces, n);
-            if (n > 255) return "edge with more than 255 faces";
-            cells.clear();
-            for (int32_t i = 0; i < n; ++i) {
-                const int32_t f = edgeFaces.val[b + i];
-                if (std::find(cells.begin(), cells.end(), own[f]) == cells.end()) cells.push_back(own[f]);
-                if (f < nIF && std::find(cells.begin(), cells.end(), nei[f]) == cells.end()) cells.push_back(nei[f]);
-            }
-            for (int32_t c : cells) {
-                int32_t f0 = -1, f1 = -1, hits = 0;
+        const int parts = rangeParts(nEdges);
+        std::vector<std::vector<int32_t>> pc((size_t)parts);
+        std::vector<std::vector<uint8_t>> p0((size_t)parts), p1((size_t)parts);
+        std::vector<std::string> perr((size_t)parts);
+        std::vector<int32_t> pmax((size_t)parts, 0);
+        parallelRanges(nEdges, parts, [&](int part, int64_t eb0, int64_t ee0) {
+            std::vector<int32_t> cells;
+            std::vector<int32_t> vals;                                  // (thread-local until the end: no shared cache lines in the loop)
+            std::vector<uint8_t> v0, v1;
+            const size_t guess = (size_t)(edgeFaces.off[ee0] - edgeFaces.off[eb0]);
+            vals.reserve(guess); v0.reserve(guess); v1.reserve(guess);
+            int32_t localMax = 0;
+            for (int32_t e = (int32_t)eb0; e < (int32_t)ee0; ++e) {
+                const int32_t b = edgeFaces.off[e], n = edgeFaces.off[e + 1] - b;
+                localMax = std::max(localMax, n);
+                if (n > 255) { perr[(size_t)part] = "edge with more than 255 faces"; return; }
+                cells.clear();
                 for (int32_t i = 0; i < n; ++i) {
                     const int32_t f = edgeFaces.val[b + i];
-                    if (own[f] == c || (f < nIF && nei[f] == c)) {
-                        if (hits == 0) f0 = i; else if (hits == 1) f1 = i;
-                        ++hits;
-                    }
+                    if (std::find(cells.begin(), cells.end(), own[f]) == cells.end()) cells.push_back(own[f]);
+                    if (f < nIF && std::find(cells.begin(), cells.end(), nei[f]) == cells.end()) cells.push_back(nei[f]);
                 }
-                if (hits > 2) return "Sanity broken, more than two edge faces belong to same cell";  // SM.C:1073
-                if (hits < 2) return "Sanity broken, didn't find face pairs for cell " + std::to_string(c);  // SM.C:1087
-                edgeCells.val.push_back(c);
-                ecFace0.push_back((uint8_t)f0);
-                ecFace1.push_back((uint8_t)f1);
+                for (int32_t c : cells) {
+                    int32_t f0 = -1, f1 = -1, hits = 0;
+                    for (int32_t i = 0; i < n; ++i) {
+                        const int32_t f = edgeFaces.val[b + i];
+                        if (own[f] == c || (f < nIF && nei[f] == c)) {
+                            if (hits == 0) f0 = i; else if (hits == 1) f1 = i;
+                            ++hits;
+                        }
+                    }
+                    if (hits > 2) { perr[(size_t)part] = "Sanity broken, more than two edge faces belong to same cell"; return; }  // SM.C:1073
+                    if (hits < 2) { perr[(size_t)part] = "Sanity broken, didn't find face pairs for cell " + std::to_string(c); return; }  // SM.C:1087
+                    vals.push_back(c);
+                    v0.push_back((uint8_t)f0);
+                    v1.push_back((uint8_t)f1);
+                }
+                edgeCells.off[e + 1] = (int32_t)cells.size();
             }
-            edgeCells.off[e + 1] = (int32_t)edgeCells.val.size();
-        }
+            pmax[(size_t)part] = localMax;
+            pc[(size_t)part].swap(vals); p0[(size_t)part].swap(v0); p1[(size_t)part].swap(v1);
+        });
+        for (const std::string& pe : perr) if (!pe.empty()) return pe;   // (the first range in edge order that failed)
+        for (int32_t v : pmax) maxEdgeFaces = std::max(maxEdgeFaces, v);
+        scanCounts(edgeCells.off);
+        concatParts(edgeCells.val, pc);
+        concatParts(ecFace0, p0);
+        concatParts(ecFace1, p1);
     }
 
+    lap("edgeCells");
     // ---- ring order around each edge -------------------------------------------------------------
     ringFace.assign(edgeFaces.val.size(), -1);
     ringCell.assign(edgeCells.val.size(), -1);
     edgeRingOk.assign((size_t)nEdges, 0);
-    {
+    parallelRanges(nEdges, rangeParts(nEdges), [&](int, int64_t eb0, int64_t ee0) {
         std::vector<int32_t> deg, usedC;
-        for (int32_t e = 0; e < nEdges; ++e) {
+        for (int32_t e = (int32_t)eb0; e < (int32_t)ee0; ++e) {
             const int32_t fb = edgeFaces.off[e], nf = edgeFaces.off[e + 1] - fb;
             const int32_t cb = edgeCells.off[e], nc = edgeCells.off[e + 1] - cb;
             // a chain has nc = nf - 1 cells, a closed ring nc = nf
@@ -259,7 +322,8 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
             }
             if (placed == nc && (nc == nf - 1 || cur == start)) edgeRingOk[(size_t)e] = 1;
         }
-    }
+    });
+    lap("rings");
     return "";
 }
 

@@ -14,6 +14,7 @@
 //   pointFaces / edgeFaces ascending face id
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -58,9 +59,11 @@ struct Topology {
     int32_t maxFaceSize = 0, maxEdgeFaces = 0, maxPointCells = 0, maxPointPoints = 0;
 
     // returns empty string on success, else the error (reference: FatalError)
+    // afterCells (optional) is called once facePoints, owner / neighbour and cellFacesGeom stand (they are not touched again):
+    // the geometry tile tables only need those and can be built next to the rest of the addressing (smgpu_create)
     std::string build(int32_t nPoints, int32_t nCells, int32_t nFaces, int32_t nInternalFaces,
                       const int32_t* faceOffsets, const int32_t* facePts, const int32_t* owner,
-                      const int32_t* neighbour);
+                      const int32_t* neighbour, const std::function<void()>& afterCells = nullptr);
 };
 
 }  // namespace smgpu
