@@ -147,6 +147,36 @@ typedef struct smgpu_halo_desc {
                                      smgpu_iter_interior / smgpu_iter_ahead and the compute queue does not idle */
 } smgpu_halo_desc;
 int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d);
+/* ---- peer-store transport: the ranks of one node move the shared-point records THEMSELVES -------------------------------
+ * Instead of the host enqueuing an exchange between smgpu_iter_begin / mid / end (MPI, RCCL send / recv groups), the kernels
+ * that pack exchange A / L / F store every record straight into the peer's receive slot over xGMI (the peers' receive
+ * buffers are mapped into this process: hipIpc) and raise a flag word at the peer; the first kernel that consumes the records
+ * waits for its peers' flags.  pack = send, no collective kernel, no host call.  The host
+ *   1. allocates recvA / recvL / recvF and one flag array (uint32[2 * 64], zero) with smgpu_push_alloc and passes the
+ *      receive buffers to smgpu_halo_configure as usual (useExchangeStream = 0);
+ *   2. hands the 64-byte handles to its peers (any channel) and maps theirs with smgpu_push_open;
+ *   3. calls smgpu_halo_set_push on every rank, then iterates WITHOUT moving anything between the smgpu_iter_* calls.
+ * peers = the ranks this rank shares points with, ascending (the order of the send slot groups); remoteBase[o] = first slot,
+ * in peer o's receive numbering, of this rank's records; myIndexAtPeer[o] = this rank's position among peer o's peers.
+ * All ranks must use the same transport.  A record that does not arrive within two seconds raises an error at the next
+ * host read-back (smgpu_last_error).  d = NULL switches back to host-driven exchanges. */
+typedef struct smgpu_push_desc {
+    int32_t nPeers;
+    const int32_t* peerCount;       /* [nPeers] slots per peer (sum = nSend)                              */
+    const int32_t* remoteBase;      /* [nPeers]                                                           */
+    const int32_t* myIndexAtPeer;   /* [nPeers]                                                           */
+    void* const* peerRecvA;         /* [nPeers] the peers' buffers, mapped                                */
+    void* const* peerRecvL;         /* [nPeers] (entries may be NULL while neither layers nor boundary smoothing is on) */
+    void* const* peerRecvF;         /* [nPeers]                                                           */
+    void* const* peerFlags;         /* [nPeers] the peers' flag arrays, mapped                            */
+    void* localFlags;               /* this rank's flag array                                             */
+} smgpu_push_desc;
+int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d);
+int smgpu_push_alloc(int32_t device, size_t bytes, void** ptr, void* ipcHandle64);   /* uncached device memory + its IPC handle */
+int smgpu_push_open(int32_t device, const void* ipcHandle64, void** ptr);            /* map a peer's allocation               */
+int smgpu_push_close(void* ptr);
+int smgpu_push_free(void* ptr);
+
 /* change useExchangeStream / exchangeStream of a configured halo (e.g. to time both arrangements on the target) */
 int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, void* exchangeStream);
 /* the hipStream_t the engine launches on (its own, or the caller's when useCallerStream was set) */

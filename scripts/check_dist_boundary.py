@@ -37,6 +37,7 @@ for constraints, layers in ((False, False), (True, True)):
     ok = n_o == n_g and np.array_equal(np.asarray(frz_o), np.asarray(frz_g)) and diff <= 1e-13
     print(f"rank {rank} constraints {constraints} layers {layers}: {'ok' if ok else 'BAD'} max diff {diff:.2e} frozen {list(frz_g)[-1]}", flush=True)
     bad += 0 if ok else 1
+    ds.close()
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(1 if bad else 0)

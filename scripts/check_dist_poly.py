@@ -38,8 +38,10 @@ for constraints in (False, True):
         n_g, res_g, frz_g = ds.iterate(7, 0.0)
         diff = float(np.max(np.abs(ds.engine.get_points() - orcs[rank].points())))
         ok = n_o == n_g and np.array_equal(np.asarray(frz_o), np.asarray(frz_g)) and diff <= 1e-13
-        print(f"rank {rank} constraints {constraints} overlap {overlap}: {'ok' if ok else 'BAD'} max diff {diff:.2e} frozen {list(frz_g)[-1]}", flush=True)
+        transport = "peer stores" if ds.pushbuf is not None else ("send/recv groups" if ds.direct is not None else backend)
+        print(f"rank {rank} constraints {constraints} overlap {overlap} [{transport}]: {'ok' if ok else 'BAD'} max diff {diff:.2e} frozen {list(frz_g)[-1]}", flush=True)
         bad += 0 if ok else 1
+        ds.close()
         del ds
 dist.barrier()
 dist.destroy_process_group()

@@ -26,7 +26,10 @@ t = halo.HaloTables(0, sub.pointProcAddressing, cands)
 print(f"rank 0 of 8: {sub.mesh.nPoints} points, {len(t.sharedLocal)} shared, {t.nSend} send slots to {int((t.counts > 0).sum())} peers")
 orig = halo.HaloTables
 halo.HaloTables = lambda rank, ppa, c: t
-for mode in ("inorder", "overlap"):
+modes = ("inorder", "overlap") if os.environ.get("SMOOTHMESH_EXCHANGE", "") != "push" else ("inorder",)
+print("transport:", "peer stores (self-mapping: the rank's own receive slots and flag words stand in for its seven peers')"
+      if len(modes) == 1 else "RCCL send / recv groups (self-exchange)")
+for mode in modes:
     ds = halo.DistributedSmoother(sub, device=0, probe_slots=t.nSend, overlap=(mode == "overlap"))
     ds.set_params(default_params(ds.global_min_edge(), edgeAngleConstraint=False, faceAngleConstraint=False))
     ds.iterate(10, 0.0)
@@ -47,7 +50,7 @@ if "--boundary" in sys.argv:
     from smoothmesh_amd import BoundaryParams
     from smoothmesh_amd.surfgen import box_feature_edges, box_surface
     dist.all_gather_object = real_gather
-    for mode in ("inorder", "overlap"):
+    for mode in modes:
         ds = halo.DistributedSmoother(sub, device=0, probe_slots=t.nSend, overlap=(mode == "overlap"))
         prm = default_params(ds.global_min_edge(), edgeAngleConstraint=False, faceAngleConstraint=False)
         ds.set_params(prm)

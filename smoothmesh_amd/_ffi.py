@@ -58,6 +58,14 @@ class HaloDesc(C.Structure):
     ]
 
 
+class PushDesc(C.Structure):
+    _fields_ = [
+        ("nPeers", C.c_int32), ("peerCount", c_i32p), ("remoteBase", c_i32p), ("myIndexAtPeer", c_i32p),
+        ("peerRecvA", C.POINTER(C.c_void_p)), ("peerRecvL", C.POINTER(C.c_void_p)), ("peerRecvF", C.POINTER(C.c_void_p)),
+        ("peerFlags", C.POINTER(C.c_void_p)), ("localFlags", C.c_void_p),
+    ]
+
+
 class LayerDesc(C.Structure):
     _fields_ = [
         ("nPatches", C.c_int32), ("patchStart", c_i32p), ("patchSize", c_i32p), ("patchKind", c_u8p), ("isLayerPatch", c_u8p),
@@ -92,6 +100,11 @@ SYMBOLS = {
     "smgpu_mesh_stats": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
     "smgpu_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "smgpu_set_foam_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "smgpu_halo_set_push": (C.c_int, [C.c_void_p, C.POINTER(PushDesc)]),
+    "smgpu_push_alloc": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]),
+    "smgpu_push_open": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "smgpu_push_close": (C.c_int, [C.c_void_p]),
+    "smgpu_push_free": (C.c_int, [C.c_void_p]),
     "smgpu_debug_walk_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "smgpu_debug_selftest_fpexact": (C.c_int, [C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
     "smgpu_iterate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(IterStats), c_i32p]),

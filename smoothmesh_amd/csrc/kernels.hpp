@@ -45,6 +45,86 @@ struct Accum {                 // device-side loop state
     int nFaPts, nFaEdges;      // face-angle pass: points / edges listed for the exact evaluation (this iteration; adjacent: one scan writes both)
 };
 
+// Peer-store transport of the shared-point records (multi-rank; smgpu_halo_set_push).  Every rank maps its peers' receive
+// buffers and flag words (hipIpc).  The kernels that produce exchange A / L / F then store each record where it is consumed --
+// the slot of the PEER's receive buffer (slotA / slotL / slotF: one address per send slot) -- and the last workgroup of the
+// producing launch to finish raises this rank's flag at every peer (pushSignal); the first kernel that consumes the records
+// waits for its peers' flags (pushWait).  pack = send: no collective kernel, no host call, nothing between pack and combine
+// but the wire.  Flags carry the iteration number (monotone), one word per (peer, exchange kind).
+struct PushView {
+    double* const* slotA; double* const* slotL; int* const* slotF;   // [nSend] destinations; NULL = the local send buffers
+    unsigned* ticket;              // [2] arrivals of the producing launch's workgroups (kind 0 = A + L, 1 = F)
+    unsigned* const* peerFlag;     // [nPeers] this rank's pair of flag words in peer o's flag array
+    const unsigned* localFlag;     // [2 * nPeers] the flag words the peers write here: [2 * o + kind]
+    int nPeers;
+    int fence;                     // SMGPU_PUSH_FENCE=1: full system-scope release / acquire fences around the hand-off (A/B; see pushSignal)
+};
+// A record word on its way to a peer: a system-scope store (sc0 sc1: written through to the peer's memory, nothing left dirty in
+// this GPU's L2).  The receive buffers are uncached allocations (smgpu_push_alloc), so neither side needs a cache write-back
+// or invalidate for the records -- a system-scope release fence here is a write-back of EVERYTHING dirty in the L2 (the cell
+// centres the geometry kernel has just written: ~10 us on the critical path), an acquire on the consuming side an invalidate
+// of everything the next kernels are about to re-read.
+__device__ __forceinline__ void stPeer(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void stPeer(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+// two record words in ONE 16-byte system-scope store (p 16-byte aligned): a write-through store is one fabric write whatever its
+// width, so 8-byte stores cost 2.7x the time per byte of 16-byte ones (MI355X_MICROARCH.md, "stores of each flavour").  The
+// waves drain them with s_waitcnt vmcnt(0) in pushSignal (the compiler does not count inline-assembly stores).
+__device__ __forceinline__ void stPeer2(double* p, double a, double b) {
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned long long ba = (unsigned long long)__double_as_longlong(a), bb = (unsigned long long)__double_as_longlong(b);
+    u32x4 v;
+    v.x = (unsigned)ba; v.y = (unsigned)(ba >> 32); v.z = (unsigned)bb; v.w = (unsigned)(bb >> 32);
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+constexpr int PUSH_ERR_TIMEOUT = 6;   // Accum::err: a peer's records did not arrive (pushWait)
+// what a consuming kernel needs to wait for the records of this iteration (localFlag == NULL: nothing to wait for)
+struct PushWait { const unsigned* localFlag; int nPeers; int kind; unsigned tag; int* err; int fence; };
+
+// End of a producing kernel, called by EVERY thread of EVERY workgroup of the launch: when the last workgroup has stored its
+// records, this rank's flag goes up at every peer.  Order: every wave drains its (write-through) stores, the workgroup meets,
+// one lane takes a ticket; the workgroup that draws the last ticket resets the counter for the next launch and stores the
+// flags (system scope).
+__device__ __forceinline__ void pushSignal(const PushView& pv, int kind, unsigned tag) {
+    if (!pv.ticket) return;
+    __shared__ int lastWg;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (pv.fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        const unsigned t = __hip_atomic_fetch_add(&pv.ticket[kind], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lastWg = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!lastWg) return;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(&pv.ticket[kind], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < pv.nPeers) {
+        if (pv.fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        __hip_atomic_store(pv.peerFlag[threadIdx.x] + kind, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+// Start of the first consuming kernel, called by every thread: lane o waits for peer o's flag (a bounded wait: two seconds of
+// wall clock, then Accum::err), acquires at system scope, the workgroup meets; plain loads of the records follow.
+__device__ __forceinline__ void pushWait(const PushWait& pw) {
+    if (!pw.localFlag) return;
+    if ((int)threadIdx.x < pw.nPeers) {
+        const unsigned* f = pw.localFlag + 2 * threadIdx.x + pw.kind;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - pw.tag) < 0) {
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { *pw.err = PUSH_ERR_TIMEOUT; break; }
+        }
+        if (pw.fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
+    __syncthreads();
+}
+
 struct State {
     double* ptsCur; double* ptsNext; double* prop;
     double* fCtr; double* fArea; double* cellCtr;
@@ -75,6 +155,7 @@ struct State {
     const int* bndOfShared;    // multi-rank + boundary point smoothing: per shared point its index in the boundary tables or -1
     const double* combL;       // multi-rank + layers: per shared point the summed normals and the combined outer
                                // neighbour coordinates (6 doubles), or NULL
+    PushView push;             // multi-rank, peer-store transport (smgpu_halo_set_push): all NULL = the host moves the records
     int* nActiveHost;          // pinned host word (or NULL): the end-of-iteration reduction leaves the iteration's nActive there,
                                // from which the host re-decides the walk's replay form (smgpu.hip:updateWalkMode)
 };
@@ -1069,6 +1150,15 @@ __device__ __forceinline__ void haloPackLOf(const State& s, const PackLArgs& a, 
     double* o = ownL + (size_t)i * w;
     for (int j = 0; j < w; ++j) o[j] = rec[j];
     for (int k = sendOff[i]; k < sendOff[i + 1]; ++k) {
+        if (s.push.slotL) {   // (records of 6 or 14 doubles: 16-byte aligned)
+            double* d = s.push.slotL[sendSlots[k]];
+            if (w == SMGPU_HALO_L_LAYERS) { stPeer2(d, rec[0], rec[1]); stPeer2(d + 2, rec[2], rec[3]); stPeer2(d + 4, rec[4], rec[5]); }
+            else {
+#pragma unroll
+                for (int j = 0; j < SMGPU_HALO_L_DOUBLES; j += 2) stPeer2(d + j, rec[j], rec[j + 1]);
+            }
+            continue;
+        }
         double* d = sendL + (size_t)sendSlots[k] * w;
         for (int j = 0; j < w; ++j) d[j] = rec[j];
     }
@@ -1181,7 +1271,8 @@ __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* 
 }
 __global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
                                                            const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
-                                                           const int* multiIdx, const int* multiSlots) {
+                                                           const int* multiIdx, const int* multiSlots, PushWait pw) {
+    pushWait(pw);
     haloCombineA2Of((int)blockIdx.x, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots);
 }
 
@@ -1196,7 +1287,8 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
 __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
                                                           const double* ownA, const double* recvA, double* combA, int* err,
                                                           int skipMulti, int nBlocksTwo, int nMulti, const int* multiIdx,
-                                                          const int* multiSlots) {
+                                                          const int* multiSlots, PushWait pw) {
+    pushWait(pw);
     if ((int)blockIdx.x >= nBlocksTwo) {
         combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
         return;
@@ -1339,13 +1431,17 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
 
 // exchange F: isFrozenPoint of shared points, orEqOp (SM.C:2374-2380)
 __global__ void __launch_bounds__(kBlock) k_halo_packF(int nSend, const int* sendShared, const int* sharedLocal,
-                                                       const uint8_t* frozen, int* sendF) {
+                                                       const uint8_t* frozen, int* sendF, PushView pv, unsigned tag) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= nSend) return;
-    sendF[i] = frozen[sharedLocal[sendShared[i]]];
+    if (i < nSend) {
+        const int v = frozen[sharedLocal[sendShared[i]]];
+        if (pv.slotF) stPeer(pv.slotF[i], v); else sendF[i] = v;
+    }
+    pushSignal(pv, 1, tag);
 }
 __global__ void __launch_bounds__(kBlock) k_halo_orF(int nShared, const int* sharedLocal, const int* combOff,
-                                                     const int* combSlots, const int* recvF, uint8_t* frozen) {
+                                                     const int* combSlots, const int* recvF, uint8_t* frozen, PushWait pw) {
+    pushWait(pw);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= nShared) return;
     int any = 0;
@@ -1361,8 +1457,9 @@ __global__ void __launch_bounds__(kBlock) k_halo_orF(int nShared, const int* sha
 // flags (SM.C:2374), restores / counts (SM.C:2384-2392), writes the new coordinates and publishes the
 // residual partials of the shared points (partial slots after the tile slots).
 __global__ void __launch_bounds__(kBlock) k_shared_fix(MeshView m, State s, Prm prm, int nShared, const int* sharedLocal,
-                                                       const int* combOff, const int* combSlots, const int* recvF, int partialBase) {
+                                                       const int* combOff, const int* combSlots, const int* recvF, int partialBase, PushWait pw) {
     if (s.acc->stop) return;
+    pushWait(pw);
     const int i = blockIdx.x * kBlock + threadIdx.x;
     double dist = 0.0;
     int fcount = 0;

@@ -127,7 +127,8 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineAL(int nShared, const in
                                                            const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
                                                            const int* multiIdx, const int* multiSlots, int nA, State s, BndView b, int bndOn,
                                                            const int* combOff, const int* combSlots, const double* ownL, const double* recvL,
-                                                           double* combL, const int* sharedLocal) {
+                                                           double* combL, const int* sharedLocal, PushWait pw) {
+    pushWait(pw);
     const int bx = (int)blockIdx.x;
     if (bx < nA) { haloCombineA2Of(bx, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots); return; }
     const int i = (bx - nA) * kBlock + (int)threadIdx.x;

@@ -771,10 +771,8 @@ struct PackView {
 };
 // (the first nLBlocks workgroups, a multiple of 8, pack exchange L's records instead -- k_halo_packL's work without its launch)
 template <int T>
-__global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTileView g, PackView pk, const int* tileList, int nLaunch,
-                                                  int xcdMap, PackLArgs la, int nLBlocks) {
-    if (s.acc->stop) return;
-    if ((int)blockIdx.x < nLBlocks) { haloPackLOf(s, la, (int)blockIdx.x * T + (int)threadIdx.x); return; }
+__device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, const SmoothTileView& g, const PackView& pk, const int* tileList, int nLaunch,
+                                             int xcdMap, int nLBlocks) {
     const int li = launchTile(nLaunch, xcdMap, (int)blockIdx.x - nLBlocks);
     if (li < 0) return;
     extern __shared__ double lds[];
@@ -834,10 +832,34 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
 #pragma unroll
     for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) o[q] = rec[q];
     for (int k = pk.sendOff[slot]; k < pk.sendOff[slot + 1]; ++k) {
+        // the record goes where it is consumed: the peer's receive slot with the peer-store transport, else the send buffer
+        if (s.push.slotA) {
+            // 13 doubles = 104 bytes: every other slot starts 8 bytes off a 16-byte boundary -- six 16-byte stores and one
+            // 8-byte store either way
+            double* d = s.push.slotA[pk.sendSlots[k]];
+            if (((size_t)d & 8u) == 0) {
+#pragma unroll
+                for (int q = 0; q < 12; q += 2) stPeer2(d + q, rec[q], rec[q + 1]);
+                stPeer(d + 12, rec[12]);
+            } else {
+                stPeer(d, rec[0]);
+#pragma unroll
+                for (int q = 1; q < 13; q += 2) stPeer2(d + q, rec[q], rec[q + 1]);
+            }
+            continue;
+        }
         double* d = pk.sendA + (size_t)pk.sendSlots[k] * SMGPU_HALO_A_DOUBLES;
 #pragma unroll
         for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) d[q] = rec[q];
     }
+}
+template <int T>
+__global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTileView g, PackView pk, const int* tileList, int nLaunch,
+                                                  int xcdMap, PackLArgs la, int nLBlocks, unsigned tag) {
+    if (s.acc->stop) return;
+    if ((int)blockIdx.x < nLBlocks) haloPackLOf(s, la, (int)blockIdx.x * T + (int)threadIdx.x);
+    else packTileBody<T>(m, s, g, pk, tileList, nLaunch, xcdMap, nLBlocks);
+    pushSignal(s.push, 0, tag);      // exchange A and L leave together (no-op without the peer-store transport)
 }
 
 }  // namespace smgpu

@@ -88,6 +88,14 @@ struct smgpu_handle {
     int32_t statsHistoryCap = 0;
     int64_t statsHistoryN = 0;
     int haloIter = 0;
+    // peer-store transport (smgpu_halo_set_push): the peers' mapped receive buffers and flag words, this rank's tables
+    bool pushOn = false;
+    int pushPeers = 0, pushStride = 0;
+    std::vector<int32_t> pushCount, pushRemoteBase, pushMyIndex;
+    std::vector<void*> pushRecvA, pushRecvL, pushRecvF, pushFlags;
+    void* pushLocalFlags = nullptr;
+    void *dSlotA = nullptr, *dSlotL = nullptr, *dSlotF = nullptr, *dPeerFlag = nullptr;
+    unsigned* dPushTicket = nullptr;
     int *dInteriorTiles = nullptr, *dSharedTiles = nullptr;   // smoothing tiles without / with shared points
     int nInteriorTiles = 0, nSharedTiles = 0;
     bool interiorDone = false;
@@ -1372,6 +1380,7 @@ static int checkDeviceError(smgpu_handle* h) {
     if (a.err == 3) return fail("face-angle walk: the workgroups of the device replay did not all become resident (grid barrier timed out); set SMGPU_WALK=host or lower SMGPU_WALK_BLOCKS");
     if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
     if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
+    if (a.err == PUSH_ERR_TIMEOUT) return fail("peer-store transport: a peer's records did not arrive within two seconds (a rank is behind, gone, or not using the same transport)");
     if (a.err == BND_ERR_NORMAL) return fail("pointNormal is zero for a boundary point that is to be projected (BPS.C:691-696, OBB.C:609-610)");
     if (a.err == BND_ERR_NOHIT) return fail("Did not find surface intersection for a boundary point (BPS.C:932-938)");
     if (a.err == BND_ERR_STRING) return fail("Internal sanity check failed: Did not find any edges with the string index of a feature edge point (BPS.C:258-261)");
@@ -1719,10 +1728,112 @@ static int computeAfterExch(smgpu_handle* h) {
     return 0;
 }
 
+// what the first kernel that consumes exchange `kind` (0 = A + L, 1 = F) of this iteration waits for
+static PushWait pushWaitOf(const smgpu_handle* h, int kind) {
+    PushWait pw;
+    pw.localFlag = h->pushOn ? h->st.push.localFlag : nullptr;
+    pw.nPeers = h->pushPeers; pw.kind = kind; pw.tag = (unsigned)(h->haloIter + 1); pw.err = &h->st.acc->err; pw.fence = h->st.push.fence;
+    return pw;
+}
+
+// (re)build the per-slot destination tables of the peer-store transport; the L records' stride follows smgpu_halo_l_doubles
+static int pushBuildTables(smgpu_handle* h) {
+    const int w = h->st.lStride > 0 ? h->st.lStride : SMGPU_HALO_L_LAYERS;
+    std::vector<void*> a((size_t)std::max(h->nSend, 1), nullptr), l(a.size(), nullptr), f(a.size(), nullptr), flags((size_t)std::max(h->pushPeers, 1), nullptr);
+    int k = 0;
+    for (int o = 0; o < h->pushPeers; ++o) {
+        for (int j = 0; j < h->pushCount[(size_t)o]; ++j, ++k) {
+            const size_t rs = (size_t)h->pushRemoteBase[(size_t)o] + (size_t)j;
+            a[(size_t)k] = (double*)h->pushRecvA[(size_t)o] + rs * SMGPU_HALO_A_DOUBLES;
+            l[(size_t)k] = h->pushRecvL[(size_t)o] ? (void*)((double*)h->pushRecvL[(size_t)o] + rs * (size_t)w) : nullptr;
+            f[(size_t)k] = (int32_t*)h->pushRecvF[(size_t)o] + rs;
+        }
+        flags[(size_t)o] = (unsigned*)h->pushFlags[(size_t)o] + 2 * (size_t)h->pushMyIndex[(size_t)o];
+    }
+    if (k != h->nSend) return fail("smgpu_halo_set_push: the peers' slot counts do not add up to nSend");
+    HIP_OK(hipMemcpy(h->dSlotA, a.data(), a.size() * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->dSlotL, l.data(), l.size() * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->dSlotF, f.data(), f.size() * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->dPeerFlag, flags.data(), flags.size() * sizeof(void*), hipMemcpyHostToDevice));
+    h->pushStride = w;
+    return 0;
+}
+
+int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d) {
+    if (!h || !h->haloOn) return fail("halo not configured");
+    HIP_OK(hipSetDevice(h->device));
+    HIP_OK(hipDeviceSynchronize());
+    if (!d) { h->pushOn = false; h->st.push = PushView{}; return 0; }
+    if (d->nPeers < 0 || d->nPeers > 64) return fail("smgpu_halo_set_push: at most 64 peers");
+    if (h->nShared && !(h->useTiles && h->nSharedTiles > 0 && h->packTiles)) return fail("smgpu_halo_set_push: needs the tiled pack kernel (SMGPU_TILES / SMGPU_PACK_TILES)");
+    if (h->useExch) return fail("smgpu_halo_set_push: the exchange stream arrangement does not apply (nothing is enqueued by the host)");
+    h->pushPeers = d->nPeers;
+    h->pushCount.assign(d->peerCount, d->peerCount + d->nPeers);
+    h->pushRemoteBase.assign(d->remoteBase, d->remoteBase + d->nPeers);
+    h->pushMyIndex.assign(d->myIndexAtPeer, d->myIndexAtPeer + d->nPeers);
+    h->pushRecvA.assign(d->peerRecvA, d->peerRecvA + d->nPeers);
+    h->pushRecvL.assign(d->peerRecvL, d->peerRecvL + d->nPeers);
+    h->pushRecvF.assign(d->peerRecvF, d->peerRecvF + d->nPeers);
+    h->pushFlags.assign(d->peerFlags, d->peerFlags + d->nPeers);
+    h->pushLocalFlags = d->localFlags;
+    for (int o = 0; o < d->nPeers; ++o)
+        if (!h->pushRecvA[(size_t)o] || !h->pushRecvF[(size_t)o] || !h->pushFlags[(size_t)o] || h->pushMyIndex[(size_t)o] < 0 || h->pushMyIndex[(size_t)o] >= 64)
+            return fail("smgpu_halo_set_push: incomplete peer description");
+    if (!h->dSlotA) {
+        const size_t n = (size_t)std::max(h->nSend, 1);
+        void **a = nullptr, **l = nullptr, **f = nullptr, **pf = nullptr;
+        if (devAlloc(h, &a, n) || devAlloc(h, &l, n) || devAlloc(h, &f, n) || devAlloc(h, &pf, 64) || devAlloc(h, &h->dPushTicket, 2)) return 1;
+        h->dSlotA = a; h->dSlotL = l; h->dSlotF = f; h->dPeerFlag = pf;
+        HIP_OK(hipMemset(h->dPushTicket, 0, 2 * sizeof(unsigned)));
+    }
+    if (pushBuildTables(h)) return 1;
+    PushView pv;
+    pv.slotA = (double* const*)h->dSlotA; pv.slotL = (double* const*)h->dSlotL; pv.slotF = (int* const*)h->dSlotF;
+    pv.ticket = h->dPushTicket; pv.peerFlag = (unsigned* const*)h->dPeerFlag; pv.localFlag = (const unsigned*)h->pushLocalFlags; pv.nPeers = d->nPeers;
+    pv.fence = envInt("SMGPU_PUSH_FENCE", 0) ? 1 : 0;
+    h->st.push = pv;
+    h->st.inlineCombine = 0;     // the records are consumed by the combine kernel (it carries the wait) ...
+    h->st.inlinePackF = 0;       // ... and the flags leave through k_halo_packF (it carries the signal)
+    h->pushOn = true;
+    return 0;
+}
+
+// device memory another process can map (the receive buffers and the flag words of the peer-store transport): uncached, so that
+// what a peer stores is what the next load returns -- no stale line in this GPU's L2
+int smgpu_push_alloc(int32_t device, size_t bytes, void** ptr, void* ipcHandle64) {
+    if (!ptr || !ipcHandle64 || bytes == 0) return fail("smgpu_push_alloc: bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    HIP_OK(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_OK(hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+    HIP_OK(hipMemset(p, 0, bytes));
+    HIP_OK(hipDeviceSynchronize());
+    hipIpcMemHandle_t hd;
+    const hipError_t e = hipIpcGetMemHandle(&hd, p);
+    if (e != hipSuccess) { (void)hipFree(p); return fail(std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e)); }
+    std::memcpy(ipcHandle64, &hd, 64);
+    *ptr = p;
+    return 0;
+}
+int smgpu_push_open(int32_t device, const void* ipcHandle64, void** ptr) {
+    if (!ptr || !ipcHandle64) return fail("smgpu_push_open: bad argument");
+    HIP_OK(hipSetDevice(device));
+    hipIpcMemHandle_t hd;
+    std::memcpy(&hd, ipcHandle64, 64);
+    HIP_OK(hipIpcOpenMemHandle(ptr, hd, hipIpcMemLazyEnablePeerAccess));
+    return 0;
+}
+int smgpu_push_close(void* ptr) { if (ptr) HIP_OK(hipIpcCloseMemHandle(ptr)); return 0; }
+int smgpu_push_free(void* ptr) { if (ptr) HIP_OK(hipFree(ptr)); return 0; }
+
 int smgpu_iter_begin(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
     HIP_OK(hipSetDevice(h->device));
+    if (h->pushOn && h->pushStride != (h->st.lStride > 0 ? h->st.lStride : SMGPU_HALO_L_LAYERS)) {   // the L records grew (boundary set-up)
+        HIP_OK(hipStreamSynchronize(h->stream));
+        if (pushBuildTables(h)) return 1;
+    }
     if (runBndPre(h)) return 1;
     if (h->geomAheadDone) {
         // the tiles away from the shared points were recomputed by smgpu_iter_ahead of the previous iteration
@@ -1748,6 +1859,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (h->nShared)
         if (launchK(h, K_HALO, [&] {
                 const bool withL = h->layersOn || h->bndOn;   // local normals / neighbour coordinates / feature projections (SM.C:2266, 2286, 2310-2330)
+                const unsigned tag = (unsigned)(h->haloIter + 1);   // the peer-store transport's flag value for this iteration
                 const PackLArgs la{h->dSharedLocal, h->dOwnL, h->nShared, h->dSendOff, h->dSendSlots, h->sendL, h->bv.bfOff, h->bv.inner, h->bv.featOfBnd,
                                    h->bv.featSum, h->bv.featCnt};
                 if (h->useTiles && h->nSharedTiles > 0 && h->packTiles) {   // the staged gather of the smoothing tiles
@@ -1755,9 +1867,9 @@ int smgpu_iter_begin(smgpu_handle* h) {
                     // exchange L's records are packed by the first workgroups of the same launch
                     const int T = h->smoothT, nL = withL ? (((h->nShared + T - 1) / T + 7) / 8) * 8 : 0;
                     const dim3 grid(nL + tileGrid(h->nSharedTiles, h->xcdMap));
-                    if (T == 64) hipLaunchKernelGGL(k_pack_tile<64>, grid, dim3(64), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
-                    else if (T == 128) hipLaunchKernelGGL(k_pack_tile<128>, grid, dim3(128), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
-                    else hipLaunchKernelGGL(k_pack_tile<256>, grid, dim3(256), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL);
+                    if (T == 64) hipLaunchKernelGGL(k_pack_tile<64>, grid, dim3(64), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL, tag);
+                    else if (T == 128) hipLaunchKernelGGL(k_pack_tile<128>, grid, dim3(128), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL, tag);
+                    else hipLaunchKernelGGL(k_pack_tile<256>, grid, dim3(256), h->smoothLds, h->stream, m, s, h->sv, pk, h->dSharedTiles, h->nSharedTiles, h->xcdMap, la, nL, tag);
                 } else {
                     hipLaunchKernelGGL(k_halo_packA, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, m, s, h->dSharedLocal, h->dOwnA, h->nShared,
                                        h->dSendOff, h->dSendSlots, h->sendA, h->bndOn ? 1 : 0);
@@ -1800,15 +1912,16 @@ int smgpu_iter_mid(smgpu_handle* h) {
                     // exchange A's and exchange L's combines and the shared boundary normals (OBB.C:201-230) in one launch
                     hipLaunchKernelGGL(k_halo_combineAL, dim3(nTwo + nMultiBlocks + gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA,
                                        h->recvA, h->dCombA, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots, nTwo + nMultiBlocks, h->st, h->bv, h->bndOn ? 1 : 0,
-                                       h->dCombOff, h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->dSharedLocal);
+                                       h->dCombOff, h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->dSharedLocal, pushWaitOf(h, 0));
                     return;
                 }
                 if (nTwo + nMultiBlocks > 0 && h->dMultiIdx && h->dPeer)
                     hipLaunchKernelGGL(k_halo_combineA2, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA, h->recvA, h->dCombA,
-                                       nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
+                                       nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots, pushWaitOf(h, 0));
                 else if (nTwo + nMultiBlocks > 0)
                     hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
-                                       h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots);
+                                       h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots,
+                                       pushWaitOf(h, 0));
                 if (withL)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
                                        h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride);
@@ -1829,7 +1942,7 @@ int smgpu_iter_mid(smgpu_handle* h) {
     if (h->nSend && !(fused && h->st.inlinePackF && !h->bndOn && h->useTiles))   // (fused: the smoothing kernel wrote the flags into the send slots)
         if (launchK(h, K_HALO, [&] {
                 hipLaunchKernelGGL(k_halo_packF, dim3(gridFor(h->nSend)), dim3(kBlock), 0, h->stream, h->nSend, h->dSendShared,
-                                   h->dSharedLocal, h->st.frozen, h->sendF);
+                                   h->dSharedLocal, h->st.frozen, h->sendF, h->st.push, (unsigned)(h->haloIter + 1));
             })) return 1;
     return exchAfterCompute(h);             // sendF is complete: exchange F may start
 }
@@ -1863,14 +1976,14 @@ int smgpu_iter_end(smgpu_handle* h) {
         if (h->nShared)
             if (launchK(h, K_HALO, [&] {
                     hipLaunchKernelGGL(k_shared_fix, dim3(gS), dim3(kBlock), 0, h->stream, m, s, prm, h->nShared, h->dSharedLocal, h->dCombOff,
-                                       h->dCombSlots, h->recvF, h->stl.nTiles);
+                                       h->dCombSlots, h->recvF, h->stl.nTiles, pushWaitOf(h, 1));
                 })) return 1;
         nPart = h->stl.nTiles + (h->bndOn ? gridFor(h->nShared) + gridFor(2 * (int64_t)h->bv.nB) : (h->nShared ? gS : 0));
     } else {
         if (h->nShared && h->nRecv)
             if (launchK(h, K_HALO, [&] {
                     hipLaunchKernelGGL(k_halo_orF, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dSharedLocal,
-                                       h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen);
+                                       h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen, pushWaitOf(h, 1));
                 })) return 1;
         if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         nPart = gridFor(m.nPoints);

@@ -88,41 +88,6 @@ static std::vector<int32_t> mortonOrder(int32_t n, const double* xyz) {
 
 std::vector<int32_t> mortonOrderOf(int32_t n, const double* xyz) { return mortonOrder(n, xyz); }
 
-// "has the open tile got this element already?" for the greedy boundary passes.  A tile holds a few hundred elements, so a
-// small open-addressing table that lives in L1 answers it; mesh-sized stamp arrays (one random access into 40 - 120 MB per
-// query) made these serial passes the longest part of the set-up on a 10 M-cell mesh.
-namespace {
-class SmallSet {
-public:
-    explicit SmallSet(int32_t expected) { int32_t n = 64; while (n < 4 * expected) n <<= 1; slot_.assign((size_t)n, -1); mask_ = (uint32_t)n - 1; }
-    bool insert(int32_t x) {   // true if x was not in the set
-        if (4 * (touched_.size() + 1) > slot_.size()) grow();
-        uint32_t h = ((uint32_t)x * 2654435761u) & mask_;
-        while (slot_[h] != -1) {
-            if (slot_[h] == x) return false;
-            h = (h + 1) & mask_;
-        }
-        slot_[h] = x;
-        touched_.push_back(h);
-        return true;
-    }
-    void clear() { for (uint32_t h : touched_) slot_[h] = -1; touched_.clear(); }
-private:
-    void grow() {
-        std::vector<int32_t> keys;
-        keys.reserve(touched_.size());
-        for (uint32_t h : touched_) keys.push_back(slot_[h]);
-        slot_.assign(slot_.size() * 2, -1);
-        mask_ = (uint32_t)slot_.size() - 1;
-        touched_.clear();
-        for (int32_t k : keys) insert(k);
-    }
-    std::vector<int32_t> slot_;
-    std::vector<uint32_t> touched_;
-    uint32_t mask_ = 0;
-};
-}  // namespace
-
 static std::vector<int32_t> naturalOrder(int32_t n) {
     std::vector<int32_t> o((size_t)n);
     for (int32_t i = 0; i < n; ++i) o[(size_t)i] = i;
@@ -153,24 +118,24 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
         order = mortonOrder(t.nCells, cc.data());
     } else order = naturalOrder(t.nCells);
     tm.lap("order");
-    // pass 1: greedy tile boundaries under the three capacities
-    SmallSet setP(capPoints), setF(capFaces);
+    // pass 1: greedy tile boundaries under the three capacities (mesh-sized stamp arrays: an L1-resident hash set per open tile
+    // was tried in their place and is slower on the hosts of the GPU boxes -- 1.36 s against 0.69 s for 10 M cells)
+    std::vector<int32_t> stampP((size_t)t.nPoints, -1), stampF((size_t)t.nFaces, -1);
     cellBeg.assign(1, 0);
-    int32_t nP = 0, nF = 0, nC = 0;
+    int32_t tile = 0, nP = 0, nF = 0, nC = 0;
     for (int32_t ci = 0; ci < t.nCells; ++ci) {
         const int32_t c = order[(size_t)ci];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addF = 0, addP = 0;
             for (int32_t k = cf.off[c]; k < cf.off[c + 1]; ++k) {
                 const int32_t f = cf.val[k] & 0x7fffffff;
-                if (setF.insert(f)) ++addF;
+                if (stampF[f] != tile) { stampF[f] = tile; ++addF; }
                 for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
-                    if (setP.insert(fp.val[j])) ++addP;
+                    if (stampP[fp.val[j]] != tile) { stampP[fp.val[j]] = tile; ++addP; }
             }
             if (nC > 0 && (nC + 1 > capCells || nP + addP > capPoints || nF + addF > capFaces)) {
                 cellBeg.push_back(ci);  // close the tile before this cell and re-add the cell to a fresh one
-                setP.clear(); setF.clear();
-                nP = nF = nC = 0;
+                ++tile; nP = nF = nC = 0;
                 continue;
             }
             if (addP > capPoints || addF > capFaces) return "a single cell exceeds the LDS tile capacity";
@@ -180,6 +145,7 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
     }
     cellBeg.push_back(t.nCells);
     nTiles = (int32_t)cellBeg.size() - 1;
+    { std::vector<int32_t>().swap(stampP); std::vector<int32_t>().swap(stampF); }
     tm.lap("boundaries");
 
     // pass 2: per tile unique lists (ascending), local indices, ELL tables -- tile ranges on host threads, every range
@@ -371,22 +337,21 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     const int32_t capTile = threads;
     const auto& pc = t.pointCells;
     const auto& pe = t.pointEdges;   // offsets shared with pointPoints
-    SmallSet setC(capCells), setN(capPoints);
+    std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
     ptBeg.assign(1, 0);
-    int32_t nC = 0, nN = 0, nT = 0;
+    int32_t tile = 0, nC = 0, nN = 0, nT = 0;
     for (int32_t pi = 0; pi < t.nPoints; ++pi) {
         const int32_t p = order[(size_t)pi];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addC = 0, addN = 0;
             for (int32_t k = pc.off[p]; k < pc.off[p + 1]; ++k)
-                if (setC.insert(pc.val[k])) ++addC;
-            if (setN.insert(p)) ++addN;
+                if (stampC[pc.val[k]] != tile) { stampC[pc.val[k]] = tile; ++addC; }
+            if (stampN[p] != tile) { stampN[p] = tile; ++addN; }
             for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k)
-                if (setN.insert(t.pointPoints[k])) ++addN;
+                if (stampN[t.pointPoints[k]] != tile) { stampN[t.pointPoints[k]] = tile; ++addN; }
             if (nT > 0 && (nT + 1 > capTile || nC + addC > capCells || nN + addN > capPoints)) {
                 ptBeg.push_back(pi);
-                setC.clear(); setN.clear();
-                nC = nN = nT = 0;
+                ++tile; nC = nN = nT = 0;
                 continue;
             }
             if (addC > capCells || addN > capPoints) return "a single point exceeds the LDS tile capacity";
@@ -396,6 +361,7 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     }
     ptBeg.push_back(t.nPoints);
     nTiles = (int32_t)ptBeg.size() - 1;
+    { std::vector<int32_t>().swap(stampC); std::vector<int32_t>().swap(stampN); }
     tm.lap("boundaries");
 
     selfLoc.assign((size_t)t.nPoints, 0);
@@ -548,20 +514,19 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     tm.lap("order");
     const auto& ef = t.edgeFaces;
     const auto& ec = t.edgeCells;
-    SmallSet setP(capPoints), setF(capFaces), setC(capCells);
+    std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
     edgeBeg.assign(1, 0);
-    int32_t nP = 0, nF = 0, nC = 0, nT = 0;
+    int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
     for (int32_t ei = 0; ei < nE; ++ei) {
         const int32_t e = order[(size_t)ei];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t aP = 0, aF = 0, aC = 0;
-            for (int k = 0; k < 2; ++k) if (setP.insert(t.edges[2 * e + k])) ++aP;
-            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) if (setF.insert(ef.val[k])) ++aF;
-            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) if (setC.insert(ec.val[k])) ++aC;
+            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
+            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
+            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
             if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
                 edgeBeg.push_back(ei);
-                setP.clear(); setF.clear(); setC.clear();
-                nP = nF = nC = nT = 0;
+                ++tile; nP = nF = nC = nT = 0;
                 continue;
             }
             if (aP > capPoints || aF > capFaces || aC > capCells) return "a single edge exceeds the LDS tile capacity";
@@ -571,6 +536,7 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     }
     edgeBeg.push_back(nE);
     nTiles = (int32_t)edgeBeg.size() - 1;
+    { std::vector<int32_t>().swap(stP); std::vector<int32_t>().swap(stF); std::vector<int32_t>().swap(stC); }
     tm.lap("boundaries");
     epLoc.assign(2 * (size_t)nE, 0);
     struct Part {

@@ -382,6 +382,22 @@ class SmoothEngine:
         d.exchangeStream = exchangeStream or None
         self._check(self._lib.smgpu_halo_configure(self._h, C.byref(d)))
 
+    def set_push(self, peerCount, remoteBase, myIndexAtPeer, peerRecvA, peerRecvL, peerRecvF, peerFlags, localFlags):
+        """peer-store transport (smgpu_halo_set_push): arrays per peer in ascending rank order; pointers = raw device addresses"""
+        n = len(peerCount)
+        keep = [np.ascontiguousarray(a, dtype=np.int32) for a in (peerCount, remoteBase, myIndexAtPeer)]
+        arr = lambda v: (C.c_void_p * max(n, 1))(*[C.c_void_p(int(x) if x else None) for x in v])
+        ptrs = [arr(v) for v in (peerRecvA, peerRecvL, peerRecvF, peerFlags)]
+        d = _ffi.PushDesc()
+        d.nPeers = n
+        d.peerCount, d.remoteBase, d.myIndexAtPeer = (_p(k, _ffi.c_i32p) for k in keep)
+        d.peerRecvA, d.peerRecvL, d.peerRecvF, d.peerFlags = (C.cast(a, C.POINTER(C.c_void_p)) for a in ptrs)
+        d.localFlags = localFlags
+        self._check(self._lib.smgpu_halo_set_push(self._h, C.byref(d)))
+
+    def clear_push(self):
+        self._check(self._lib.smgpu_halo_set_push(self._h, None))
+
     def set_exchange_stream(self, exchangeStream):
         """None = exchanges are enqueued on the engine's stream; int = raw hipStream_t they are enqueued on"""
         self._check(self._lib.smgpu_halo_set_exchange_stream(self._h, 0 if exchangeStream is None else 1, exchangeStream or None))

@@ -172,11 +172,52 @@ def l_view(t, width):
     return t.view(-1)[: n * width].view(n, width)
 
 
+class PushBuffers:
+    """Receive buffers and flag words of the peer-store transport (include/smgpu.h, smgpu_push_desc): device memory other
+    processes can map.  Allocated through the engine's library (uncached device memory + hipIpc handle); `handles` is what
+    travels to the peers, `open_peer` maps theirs."""
+
+    FLAG_BYTES = 4 * 2 * 64
+
+    def __init__(self, device_index, nRecv):
+        import ctypes as C
+        from . import _ffi
+        self._C, self._lib, self._dev = C, _ffi.lib(), int(device_index)
+        self._opened = []
+        n = max(int(nRecv), 1)
+        self.ptr, self.handles = {}, {}
+        for name, nbytes in (("recvA", n * A_DOUBLES * 8), ("recvL", n * L_DOUBLES * 8), ("recvF", n * 4), ("flags", self.FLAG_BYTES)):
+            p, h = C.c_void_p(), (C.c_char * 64)()
+            if self._lib.smgpu_push_alloc(self._dev, nbytes, C.byref(p), h):
+                raise RuntimeError(self._lib.smgpu_last_error().decode())
+            self.ptr[name], self.handles[name] = p.value, bytes(h)
+
+    def open_peer(self, handles):
+        C = self._C
+        out = {}
+        for name, raw in handles.items():
+            p = C.c_void_p()
+            if self._lib.smgpu_push_open(self._dev, C.create_string_buffer(raw, 64), C.byref(p)):
+                raise RuntimeError(self._lib.smgpu_last_error().decode())
+            out[name] = p.value
+            self._opened.append(p.value)
+        return out
+
+    def close(self):
+        for p in self._opened:
+            self._lib.smgpu_push_close(self._C.c_void_p(p))
+        self._opened = []
+        for p in self.ptr.values():
+            self._lib.smgpu_push_free(self._C.c_void_p(p))
+        self.ptr = {}
+
+
 class _RankState:
     """engine + exchange buffers of one rank (torch tensors on the engine's device)"""
 
-    def __init__(self, sub, tables, engine, torch, device, exchange_stream=None):
+    def __init__(self, sub, tables, engine, torch, device, exchange_stream=None, push=None):
         self.sub, self.t, self.eng = sub, tables, engine
+        self.push = push     # PushBuffers: the receive side lives in IPC-mappable memory instead of torch tensors
         f64, i32 = torch.float64, torch.int32
         self.sendA = torch.zeros((max(tables.nSend, 1), A_DOUBLES), dtype=f64, device=device)
         self.recvA = torch.zeros((max(tables.nRecv, 1), A_DOUBLES), dtype=f64, device=device)
@@ -185,10 +226,12 @@ class _RankState:
         self.localStats = torch.zeros(2, dtype=f64, device=device)
         self.sendL = torch.zeros((max(tables.nSend, 1), L_DOUBLES), dtype=f64, device=device)
         self.recvL = torch.zeros((max(tables.nRecv, 1), L_DOUBLES), dtype=f64, device=device)
+        rA, rF, rL = ((push.ptr["recvA"], push.ptr["recvF"], push.ptr["recvL"]) if push is not None
+                      else (self.recvA.data_ptr(), self.recvF.data_ptr(), self.recvL.data_ptr()))
         engine.halo_configure(tables.sharedLocal, tables.sendShared, tables.nRecv, tables.combOffsets, tables.combSlots,
-                              self.sendA.data_ptr(), self.recvA.data_ptr(), self.sendF.data_ptr(), self.recvF.data_ptr(),
+                              self.sendA.data_ptr(), rA, self.sendF.data_ptr(), rF,
                               self.localStats.data_ptr(), exchangeStream=exchange_stream,
-                              sendL=self.sendL.data_ptr(), recvL=self.recvL.data_ptr())
+                              sendL=self.sendL.data_ptr(), recvL=rL)
 
 
 class DistributedSmoother:
@@ -223,8 +266,18 @@ class DistributedSmoother:
         else:
             engine, xs = engine_factory(sub.mesh), None
         self.engine = engine
-        self.state = _RankState(sub, self.tables, engine, torch, torch_device, xs)
+        # SMOOTHMESH_EXCHANGE=push: the peer-store transport (the ranks' kernels store the records into each other's receive
+        # slots; nothing is exchanged by the host).  Needs the real engine, one node, in-order arrangement.
+        import os
+        self.pushbuf = None
+        want_push = os.environ.get("SMOOTHMESH_EXCHANGE", "") == "push" and engine_factory is None and torch_device.type == "cuda"
+        if want_push:
+            self.overlap, xs = False, None
+            self.pushbuf = PushBuffers(device, self.tables.nRecv)
+        self.state = _RankState(sub, self.tables, engine, torch, torch_device, xs, push=self.pushbuf)
         self.counts = [int(c) for c in self.tables.counts]
+        if want_push:
+            self._open_push()
         self.allStats = torch.zeros((self.world, 2), dtype=torch.float64, device=torch_device)
         if self.probe_slots:
             z = lambda shape, dt: (torch.zeros(shape, dtype=dt, device=torch_device), torch.zeros(shape, dtype=dt, device=torch_device))
@@ -232,11 +285,43 @@ class DistributedSmoother:
                            "L": z((self.probe_slots, L_DOUBLES), torch.float64)}
         self.direct = self._open_direct(engine_factory is None)
 
+    def _open_push(self):
+        """exchange the IPC handles and slot counts, map the peers' buffers, describe them to the engine"""
+        dist, t = self.dist, self.tables
+        if self.world == 1:
+            if not self.probe_slots:
+                return
+            # measurement aid (scripts/probe_rank_of_8.py): the tables are those of one rank among several, the "peers" are this
+            # rank itself -- send slot k lands in the own receive slot k, every peer's flag words are the own ones
+            peers = [o for o in range(len(t.counts)) if t.counts[o] > 0]
+            cnt = [int(t.counts[o]) for o in peers]
+            base = np.concatenate([[0], np.cumsum(cnt)[:-1]]).astype(np.int32) if cnt else np.zeros(0, np.int32)
+            mine = self.pushbuf.ptr
+            self.engine.set_push(cnt, base, list(range(len(peers))), [mine["recvA"]] * len(peers), [mine["recvL"]] * len(peers),
+                                 [mine["recvF"]] * len(peers), [mine["flags"]] * len(peers), mine["flags"])
+            return
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, {"handles": self.pushbuf.handles, "counts": [int(c) for c in t.counts]})
+        peers = [o for o in range(self.world) if t.counts[o] > 0]
+        cnt, base, my_index, rA, rL, rF, fl = [], [], [], [], [], [], []
+        for o in peers:
+            theirs = everyone[o]["counts"]                      # rank o's slots per rank (its receive numbering: ascending rank)
+            assert theirs[self.rank] == t.counts[o], "asymmetric shared-point lists"
+            cnt.append(int(t.counts[o]))
+            base.append(int(sum(theirs[:self.rank])))           # my records follow those of the lower ranks at peer o
+            my_index.append(sum(1 for r in range(self.rank) if theirs[r] > 0))
+            m = self.pushbuf.open_peer(everyone[o]["handles"])
+            rA.append(m["recvA"]); rL.append(m["recvL"]); rF.append(m["recvF"]); fl.append(m["flags"])
+        self.engine.set_push(cnt, base, my_index, rA, rL, rF, fl, self.pushbuf.ptr["flags"])
+        dist.barrier()                                          # nobody stores into a buffer its owner has not finished setting up
+
     def _open_direct(self, own_engine):
         """grouped ncclSend / ncclRecv on the engine's stream for the per-iteration exchanges (rccl_direct.py) when the process
         group is RCCL and every rank's self-check against all_to_all_single passes; None = the torch collective"""
         import os
         torch, dist = self.torch, self.dist
+        if self.pushbuf is not None:
+            return None
         if not own_engine or dist.get_backend() != "nccl" or self.device.type != "cuda" or os.environ.get("SMOOTHMESH_EXCHANGE", "rccl") == "torch":
             return None
         if self.world == 1 and not self.probe_slots:
@@ -269,6 +354,15 @@ class DistributedSmoother:
         d, self.direct = getattr(self, "direct", None), None
         if d is not None:
             d.close()
+        pb, self.pushbuf = getattr(self, "pushbuf", None), None
+        if pb is not None:
+            if self.world > 1:
+                self.dist.barrier()       # every rank has stopped storing into its peers' buffers
+            try:
+                self.engine.clear_push()
+            except Exception:             # noqa: BLE001 -- engine already closed
+                pass
+            pb.close()
         eng = getattr(self, "engine", None)
         if eng is not None and hasattr(eng, "close"):
             eng.close()
@@ -347,6 +441,10 @@ class DistributedSmoother:
         exchanged data) on the engine's own stream.  The engine orders the two streams with events inside
         smgpu_iter_begin/mid/end, so compute never leaves its queue and the host only pays for the collective
         call (~17 us on this stack; async_op=True + wait() costs ~70 us, torch stream contexts ~40 us)."""
+        if self.pushbuf is not None:      # peer-store transport: the kernels have moved the records themselves
+            if overlap:
+                overlap()
+            return
         n = self.tables.nSend
         counts = self.counts
         if self.world == 1 and self.probe_slots:
@@ -373,6 +471,10 @@ class DistributedSmoother:
         """exchange L (when the layer treatment or the boundary point smoothing is on) and exchange A: one send / recv group
         with the direct exchange, two collectives otherwise"""
         st, eng = self.state, self.engine
+        if self.pushbuf is not None:
+            if overlap:
+                overlap()
+            return
         withL = self.layers or self.boundary
         if withL and self.direct is not None:
             probe = self.world == 1 and self.probe_slots

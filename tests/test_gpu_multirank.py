@@ -144,6 +144,26 @@ def test_distributed_smoother_polyhedral_two_processes():
     assert r.stdout.count(": ok ") == 8 and "BAD" not in r.stdout
 
 
+def test_peer_store_transport_two_processes():
+    """SMOOTHMESH_EXCHANGE=push: the ranks' kernels store the shared-point records into each other's receive slots (buffers
+    mapped across the two PROCESSES with hipIpc; here both live on this box's one GPU) and signal with flag words; the host
+    exchanges nothing per iteration.  Polyhedral two-way decomposition against the oracle's MultiDomain, constraints off and on
+    (exchange A and F), and the boundary smoothing + layer case (exchange L rides with A; the L records grow from 6 to 14
+    doubles when the boundary set-up follows the layer set-up, so the destination tables are rebuilt)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMOOTHMESH_SHARE_GPU="1", SMOOTHMESH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", SMOOTHMESH_EXCHANGE="push")
+    for script, port, marks in (("check_dist_poly.py", "29531", 8), ("check_dist_boundary.py", "29533", None)):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", port, os.path.join(root, "scripts", script)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, script + r.stdout[-3000:] + r.stderr[-3000:]
+        assert "BAD" not in r.stdout
+        if marks:
+            assert r.stdout.count(": ok ") == marks and r.stdout.count("[peer stores]") == marks
+
+
 @pytest.mark.parametrize("overlap", [False, True])
 def test_single_rank_distributed_history_equals_serial(oracle_lib, overlap):
     """A rank without shared points launches no geometry in smgpu_iter_begin once the look-ahead has done every tile: the
