@@ -39,4 +39,11 @@ done
 cd $root
 python3 scripts/pmc_summary.py $out > $out/pmc_sq_hex100.txt 2>/dev/null
 rm -rf $out/sq1 $out/sq2 $out/sq3
+# one rank of eight: both transports (RCCL send / recv groups; peer stores with a self-mapping), with kernel timelines
+timeout 900 bash scripts/probe_timeline.sh > /dev/null 2>&1
+cp gpurun_out/probe_timeline/probe.txt $out/probe_rank_of_8_rccl.txt; cp gpurun_out/probe_timeline/timeline.txt $out/probe_rank_of_8_timeline_rccl.txt
+cp gpurun_out/probe_timeline/timeline_boundary.txt $out/probe_rank_of_8_timeline_boundary_rccl.txt
+SMOOTHMESH_EXCHANGE=push timeout 900 bash scripts/probe_timeline.sh > /dev/null 2>&1
+cp gpurun_out/probe_timeline/probe.txt $out/probe_rank_of_8_push.txt; cp gpurun_out/probe_timeline/timeline.txt $out/probe_rank_of_8_timeline_push.txt
+cp gpurun_out/probe_timeline/timeline_boundary.txt $out/probe_rank_of_8_timeline_boundary_push.txt
 ls -la $out
