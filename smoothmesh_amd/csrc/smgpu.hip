@@ -387,17 +387,30 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     const bool mortonTiles = envInt("SMGPU_TILE_MORTON", 1) != 0;
     std::future<std::vector<int32_t>> fPointOrder;
     if (wantTiles && mortonTiles) fPointOrder = std::async(std::launch::async, [&] { return mortonOrderOf(d->nPoints, d->points); });
-    std::future<std::string> fGeom;
+    std::future<std::string> fGeom, fSmooth;
+    std::vector<int32_t> pointOrder;
+    std::vector<uint8_t> internalMask;
     {
-        const int geomT0 = envInt("SMGPU_GEOM_T", 256);
+        const int geomT0 = envInt("SMGPU_GEOM_T", 256), smoothT0 = envInt("SMGPU_SMOOTH_T", 256);
         const int geomCells0 = envInt("SMGPU_GEOM_CELLS", geomT0 / 2);
         const int capGP0 = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells0, 1400)), capGF0 = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells0, 1400));
-        const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256;
+        const int capSC0 = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * smoothT0, 1500)), capSN0 = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * smoothT0, 1500));
+        const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256, smoothOk = smoothT0 == 64 || smoothT0 == 128 || smoothT0 == 256;
         const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour,
             [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0] {
-                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); });
+                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); },
+            [&] {
+                if (!(wantTiles && geomOk && smoothOk)) return;
+                if (fPointOrder.valid()) pointOrder = fPointOrder.get();
+                internalMask.resize((size_t)d->nPoints);
+                for (int p = 0; p < d->nPoints; ++p) internalMask[(size_t)p] = d->isInternalPoint[p] ? 1 : 0;
+                fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0] {
+                    return h->stl.build(h->topo, d->points, internalMask.data(), mortonTiles, smoothT0, capSC0, capSN0,
+                                        (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr); });
+            });
         if (!terr.empty()) {
             if (fGeom.valid()) fGeom.wait();
+            if (fSmooth.valid()) fSmooth.wait();
             if (fPointOrder.valid()) fPointOrder.wait();
             delete h;
             return fail("smgpu_create: " + terr);
@@ -405,6 +418,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     }
     auto cleanup = [&](int rc) {   // (the host threads still read the handle's tables)
         if (fGeom.valid()) fGeom.wait();
+        if (fSmooth.valid()) fSmooth.wait();
         if (fPointOrder.valid()) fPointOrder.wait();
         smgpu_destroy(h);
         return rc;
@@ -471,18 +485,15 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500));
         const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
         const bool morton = mortonTiles;
-        std::vector<uint8_t> internalMask((size_t)t.nPoints);
-        for (int p = 0; p < t.nPoints; ++p) internalMask[(size_t)p] = (flags[(size_t)p] & PF_INTERNAL) ? 1 : 0;
         const double tTopo = sinceCreate();
-        std::vector<int32_t> pointOrder;
         if (fPointOrder.valid()) pointOrder = fPointOrder.get();
         const std::vector<int32_t>* po = (morton && !pointOrder.empty()) ? &pointOrder : nullptr;
-        // (the geometry tables were started by Topology::build's hook; SMGPU_GEOM_T etc. were read there)
-        (void)geomCells; (void)capGP; (void)capGF;
+        // (the geometry and smoothing tables were started by Topology::build's hooks; SMGPU_GEOM_T etc. were read there)
+        (void)geomCells; (void)capGP; (void)capGF; (void)capSC; (void)capSN;
         auto fEdge = std::async(std::launch::async, [&]() -> std::string {
             return h->useFilter ? h->etl.build(t, d->points, morton, 256, 512, 768, 512, po) : std::string("not built");
         });
-        const std::string e2 = h->stl.build(t, d->points, internalMask.data(), morton, h->smoothT, capSC, capSN, po);
+        const std::string e2 = fSmooth.valid() ? fSmooth.get() : std::string("not built");
         const std::string e1 = fGeom.valid() ? fGeom.get() : std::string("not built");
         const std::string e3 = fEdge.get();
         if (envInt("SMGPU_VERBOSE", 0))

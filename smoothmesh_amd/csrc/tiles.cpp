@@ -514,29 +514,42 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     tm.lap("order");
     const auto& ef = t.edgeFaces;
     const auto& ec = t.edgeCells;
-    std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
-    edgeBeg.assign(1, 0);
-    int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
-    for (int32_t ei = 0; ei < nE; ++ei) {
-        const int32_t e = order[(size_t)ei];
-        for (int attempt = 0; attempt < 2; ++attempt) {
-            int32_t aP = 0, aF = 0, aC = 0;
-            for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
-            for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
-            for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
-            if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
-                edgeBeg.push_back(ei);
-                ++tile; nP = nF = nC = nT = 0;
-                continue;
+    // pass 1: greedy tile boundaries.  On large meshes the edge sequence is cut into a few segments that are tiled side by side
+    // (each with stamp arrays of its own); a segment starts a fresh tile, so the tiling differs from the one-segment tiling by
+    // at most one partial tile per cut -- any tiling is as good as any other for the results.
+    const int segs = (nE >= (4 << 20)) ? (int)std::min<unsigned>(hostThreads(), 4u) : 1;
+    std::vector<std::vector<int32_t>> segBeg((size_t)segs);
+    std::vector<std::string> segErr((size_t)segs);
+    parallelRanges(nE, segs, [&](int sg, int64_t e0, int64_t e1) {
+        std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
+        std::vector<int32_t>& beg = segBeg[(size_t)sg];
+        int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
+        for (int32_t ei = (int32_t)e0; ei < (int32_t)e1; ++ei) {
+            const int32_t e = order[(size_t)ei];
+            for (int attempt = 0; attempt < 2; ++attempt) {
+                int32_t aP = 0, aF = 0, aC = 0;
+                for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
+                for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
+                for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
+                if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
+                    beg.push_back(ei);
+                    ++tile; nP = nF = nC = nT = 0;
+                    continue;
+                }
+                if (aP > capPoints || aF > capFaces || aC > capCells) { segErr[(size_t)sg] = "a single edge exceeds the LDS tile capacity"; return; }
+                nP += aP; nF += aF; nC += aC; ++nT;
+                break;
             }
-            if (aP > capPoints || aF > capFaces || aC > capCells) return "a single edge exceeds the LDS tile capacity";
-            nP += aP; nF += aF; nC += aC; ++nT;
-            break;
         }
+    });
+    edgeBeg.assign(1, 0);
+    for (int sg = 0; sg < segs; ++sg) {
+        if (!segErr[(size_t)sg].empty()) return segErr[(size_t)sg];
+        if (sg > 0) edgeBeg.push_back((int32_t)((int64_t)nE * sg / segs));     // the cut itself
+        edgeBeg.insert(edgeBeg.end(), segBeg[(size_t)sg].begin(), segBeg[(size_t)sg].end());
     }
     edgeBeg.push_back(nE);
     nTiles = (int32_t)edgeBeg.size() - 1;
-    { std::vector<int32_t>().swap(stP); std::vector<int32_t>().swap(stF); std::vector<int32_t>().swap(stC); }
     tm.lap("boundaries");
     epLoc.assign(2 * (size_t)nE, 0);
     struct Part {

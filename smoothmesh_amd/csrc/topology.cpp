@@ -21,7 +21,8 @@ static void scanCounts(std::vector<int32_t>& off) {
 }
 
 std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, const int32_t* faceOffsets,
-                            const int32_t* facePts, const int32_t* own, const int32_t* nei, const std::function<void()>& afterCells) {
+                            const int32_t* facePts, const int32_t* own, const int32_t* nei, const std::function<void()>& afterCells,
+                            const std::function<void()>& afterPoints) {
     nPoints = nP; nCells = nC; nFaces = nF; nInternalFaces = nIF;
     const bool verbose = std::getenv("SMGPU_VERBOSE") && std::atoi(std::getenv("SMGPU_VERBOSE")) >= 2;
     auto tLap = std::chrono::steady_clock::now();
@@ -37,15 +38,29 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
     facePoints.val.assign(facePts, facePts + nnzFP);
     owner.assign(own, own + nF);
     neighbour.assign(nei, nei + nIF);
-    for (int32_t f = 0; f < nF; ++f) {
-        const int32_t n = faceOffsets[f + 1] - faceOffsets[f];
-        if (n < 3) return "face " + std::to_string(f) + " has fewer than 3 points";
-        maxFaceSize = std::max(maxFaceSize, n);
-        if (own[f] < 0 || own[f] >= nC) return "owner out of range at face " + std::to_string(f);
-        if (f < nIF && (nei[f] < 0 || nei[f] >= nC)) return "neighbour out of range at face " + std::to_string(f);
+    {
+        const int parts = rangeParts(nF);
+        std::vector<std::string> perr((size_t)parts);
+        std::vector<int32_t> pmax((size_t)parts, 0);
+        parallelRanges(nF, parts, [&](int part, int64_t fb0, int64_t fe0) {
+            int32_t localMax = 0;
+            for (int32_t f = (int32_t)fb0; f < (int32_t)fe0; ++f) {
+                const int32_t n = faceOffsets[f + 1] - faceOffsets[f];
+                std::string e;
+                if (n < 3) e = "face " + std::to_string(f) + " has fewer than 3 points";
+                else if (own[f] < 0 || own[f] >= nC) e = "owner out of range at face " + std::to_string(f);
+                else if (f < nIF && (nei[f] < 0 || nei[f] >= nC)) e = "neighbour out of range at face " + std::to_string(f);
+                else
+                    for (int32_t k = faceOffsets[f]; k < faceOffsets[f + 1]; ++k)
+                        if (facePts[k] < 0 || facePts[k] >= nP) { e = "face point label out of range"; break; }
+                if (!e.empty()) { perr[(size_t)part] = e; return; }
+                localMax = std::max(localMax, n);
+            }
+            pmax[(size_t)part] = localMax;
+        });
+        for (const std::string& e : perr) if (!e.empty()) return e;     // (the first failing face in face order)
+        for (int32_t v : pmax) maxFaceSize = std::max(maxFaceSize, v);
     }
-    for (int64_t i = 0; i < nnzFP; ++i)
-        if (facePts[i] < 0 || facePts[i] >= nP) return "face point label out of range";
 
     lap("copy + checks");
     // ---- cell -> faces (geometry accumulation order) -------------------------------------
@@ -121,26 +136,36 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
 
     lap("pointCells");
     // ---- edges: bucket (lo -> hi list), sort + unique per bucket => upper-triangular order ----
+    // (bucket counts and fills with relaxed atomics on face ranges: the order inside a bucket does not matter, it is sorted next)
     std::vector<int32_t> loOff(nP + 1, 0);
-    for (int32_t f = 0; f < nF; ++f) {
-        const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
-        for (int32_t i = 0; i < n; ++i) {
-            const int32_t a = facePts[b + i], c = facePts[b + (i == n - 1 ? 0 : i + 1)];
-            if (a == c) return "degenerate edge in face " + std::to_string(f);
-            loOff[std::min(a, c) + 1]++;
-        }
+    {
+        const int parts = rangeParts(nF);
+        std::vector<std::string> perr((size_t)parts);
+        parallelRanges(nF, parts, [&](int part, int64_t fb0, int64_t fe0) {
+            for (int32_t f = (int32_t)fb0; f < (int32_t)fe0; ++f) {
+                const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
+                for (int32_t i = 0; i < n; ++i) {
+                    const int32_t a = facePts[b + i], c = facePts[b + (i == n - 1 ? 0 : i + 1)];
+                    if (a == c) { perr[(size_t)part] = "degenerate edge in face " + std::to_string(f); return; }
+                    __atomic_fetch_add(&loOff[(size_t)std::min(a, c) + 1], 1, __ATOMIC_RELAXED);
+                }
+            }
+        });
+        for (const std::string& e : perr) if (!e.empty()) return e;
     }
     scanCounts(loOff);
     std::vector<int32_t> his(nnzFP);
     {
         std::vector<int32_t> cur(loOff.begin(), loOff.end() - 1);
-        for (int32_t f = 0; f < nF; ++f) {
-            const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
-            for (int32_t i = 0; i < n; ++i) {
-                const int32_t a = facePts[b + i], c = facePts[b + (i == n - 1 ? 0 : i + 1)];
-                his[cur[std::min(a, c)]++] = std::max(a, c);
+        parallelRanges(nF, rangeParts(nF), [&](int, int64_t fb0, int64_t fe0) {
+            for (int32_t f = (int32_t)fb0; f < (int32_t)fe0; ++f) {
+                const int32_t b = faceOffsets[f], n = faceOffsets[f + 1] - b;
+                for (int32_t i = 0; i < n; ++i) {
+                    const int32_t a = facePts[b + i], c = facePts[b + (i == n - 1 ? 0 : i + 1)];
+                    his[(size_t)__atomic_fetch_add(&cur[(size_t)std::min(a, c)], 1, __ATOMIC_RELAXED)] = std::max(a, c);
+                }
             }
-        }
+        });
     }
     std::vector<int32_t> edgeStart(nP + 1, 0);  // first edge id with start == p
     {
@@ -194,6 +219,7 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
     }
     for (int32_t p = 0; p < nP; ++p) maxPointPoints = std::max(maxPointPoints, pointEdges.off[p + 1] - pointEdges.off[p]);
     lap("pointEdges");
+    if (afterPoints) afterPoints();
     // prev/next vertex of every pointFaces entry as a slot of the point's pointPoints row
     pfPrevSlot.assign(pfPrev.size(), 255);
     pfNextSlot.assign(pfNext.size(), 255);
@@ -218,13 +244,22 @@ std::string Topology::build(int32_t nP, int32_t nC, int32_t nF, int32_t nIF, con
             for (int32_t i = 0; i < n; ++i) faceEdge[b + i] = edgeId(facePts[b + i], facePts[b + (i == n - 1 ? 0 : i + 1)]);
         }
     });
-    for (int64_t k = 0; k < nnzFP; ++k) edgeFaces.off[faceEdge[(size_t)k] + 1]++;
+    parallelRanges(nnzFP, rangeParts(nnzFP), [&](int, int64_t k0, int64_t k1) {
+        for (int64_t k = k0; k < k1; ++k) __atomic_fetch_add(&edgeFaces.off[(size_t)faceEdge[(size_t)k] + 1], 1, __ATOMIC_RELAXED);
+    });
     scanCounts(edgeFaces.off);
     edgeFaces.val.resize(edgeFaces.off[nEdges]);
     {
+        // filled from face ranges in any order, then every row sorted: ascending face id, as the serial fill leaves it
         std::vector<int32_t> cur(edgeFaces.off.begin(), edgeFaces.off.end() - 1);
-        for (int32_t f = 0; f < nF; ++f)
-            for (int32_t k = faceOffsets[f]; k < faceOffsets[f + 1]; ++k) edgeFaces.val[cur[faceEdge[k]]++] = f;
+        parallelRanges(nF, rangeParts(nF), [&](int, int64_t fb0, int64_t fe0) {
+            for (int32_t f = (int32_t)fb0; f < (int32_t)fe0; ++f)
+                for (int32_t k = faceOffsets[f]; k < faceOffsets[f + 1]; ++k)
+                    edgeFaces.val[(size_t)__atomic_fetch_add(&cur[(size_t)faceEdge[(size_t)k]], 1, __ATOMIC_RELAXED)] = f;
+        });
+        parallelRanges(nEdges, rangeParts(nEdges), [&](int, int64_t e0, int64_t e1) {
+            for (int64_t e = e0; e < e1; ++e) std::sort(edgeFaces.val.begin() + edgeFaces.off[(size_t)e], edgeFaces.val.begin() + edgeFaces.off[(size_t)e + 1]);
+        });
     }
     { std::vector<int32_t>().swap(faceEdge); }
 

@@ -60,10 +60,13 @@ struct Topology {
 
     // returns empty string on success, else the error (reference: FatalError)
     // afterCells (optional) is called once facePoints, owner / neighbour and cellFacesGeom stand (they are not touched again):
-    // the geometry tile tables only need those and can be built next to the rest of the addressing (smgpu_create)
+    // the geometry tile tables only need those and can be built next to the rest of the addressing (smgpu_create);
+    // afterPoints likewise once the point-based lists stand (pointFaces with prev / next, pointCells, edges, pointEdges /
+    // pointPoints, maxPointPoints): all the smoothing tile tables read
     std::string build(int32_t nPoints, int32_t nCells, int32_t nFaces, int32_t nInternalFaces,
                       const int32_t* faceOffsets, const int32_t* facePts, const int32_t* owner,
-                      const int32_t* neighbour, const std::function<void()>& afterCells = nullptr);
+                      const int32_t* neighbour, const std::function<void()>& afterCells = nullptr,
+                      const std::function<void()>& afterPoints = nullptr);
 };
 
 }  // namespace smgpu
