@@ -172,6 +172,23 @@ def l_view(t, width):
     return t.view(-1)[: n * width].view(n, width)
 
 
+def push_layout(rank, counts_of):
+    """Slot layout of the peer-store transport for `rank`, from every rank's slot counts per rank (counts_of[r][o] = slots of rank r
+    towards rank o; symmetric).  Returns (peers, count, remoteBase, myIndexAtPeer): the ranks `rank` shares points with
+    (ascending), the slots per peer, the first slot -- in the PEER's receive numbering, which groups its slots by source rank in
+    ascending order -- of this rank's records, and this rank's position among the peer's peers (its flag word there)."""
+    mine = counts_of[rank]
+    peers = [o for o in range(len(mine)) if mine[o] > 0]
+    cnt, base, my_index = [], [], []
+    for o in peers:
+        theirs = counts_of[o]
+        assert theirs[rank] == mine[o], "asymmetric shared-point lists"
+        cnt.append(int(mine[o]))
+        base.append(int(sum(theirs[:rank])))
+        my_index.append(sum(1 for r in range(rank) if theirs[r] > 0))
+    return peers, cnt, base, my_index
+
+
 class PushBuffers:
     """Receive buffers and flag words of the peer-store transport (include/smgpu.h, smgpu_push_desc): device memory other
     processes can map.  Allocated through the engine's library (uncached device memory + hipIpc handle); `handles` is what
@@ -302,14 +319,9 @@ class DistributedSmoother:
             return
         everyone = [None] * self.world
         dist.all_gather_object(everyone, {"handles": self.pushbuf.handles, "counts": [int(c) for c in t.counts]})
-        peers = [o for o in range(self.world) if t.counts[o] > 0]
-        cnt, base, my_index, rA, rL, rF, fl = [], [], [], [], [], [], []
+        peers, cnt, base, my_index = push_layout(self.rank, [e["counts"] for e in everyone])
+        rA, rL, rF, fl = [], [], [], []
         for o in peers:
-            theirs = everyone[o]["counts"]                      # rank o's slots per rank (its receive numbering: ascending rank)
-            assert theirs[self.rank] == t.counts[o], "asymmetric shared-point lists"
-            cnt.append(int(t.counts[o]))
-            base.append(int(sum(theirs[:self.rank])))           # my records follow those of the lower ranks at peer o
-            my_index.append(sum(1 for r in range(self.rank) if theirs[r] > 0))
             m = self.pushbuf.open_peer(everyone[o]["handles"])
             rA.append(m["recvA"]); rL.append(m["recvL"]); rF.append(m["recvF"]); fl.append(m["flags"])
         self.engine.set_push(cnt, base, my_index, rA, rL, rF, fl, self.pushbuf.ptr["flags"])

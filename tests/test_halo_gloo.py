@@ -130,3 +130,24 @@ def test_distributed_smoother_gloo_with_layers(tmp_path, oracle_lib, grid, patch
         assert np.array_equal(d["res"], res_e)
         assert np.array_equal(d["frz"], frz_e)
         assert np.array_equal(d["pts"], pts_e[r])
+
+
+def test_push_layout_is_consistent_between_the_two_ends():
+    """peer-store transport (halo.push_layout): where rank a stores its records at rank b must be exactly the slots rank b's combine
+    tables read rank a from -- b's receive slots are grouped by source rank in ascending order, the same grouping as its send slots
+    (HaloTables: base of the group of rank o = sum of the counts towards the ranks below o); flag positions are distinct per peer."""
+    import numpy as np
+    from smoothmesh_amd.halo import push_layout
+    rng = np.random.default_rng(3)
+    for world in (2, 3, 8):
+        c = rng.integers(0, 4, size=(world, world)) * rng.integers(0, 2, size=(world, world))
+        c = np.triu(c, 1); c = c + c.T                       # symmetric, zero diagonal
+        counts_of = [list(map(int, row)) for row in c]
+        lay = [push_layout(r, counts_of) for r in range(world)]
+        for a in range(world):
+            peers, cnt, base, my_index = lay[a]
+            assert peers == [o for o in range(world) if c[a, o] > 0] and cnt == [int(c[a, o]) for o in peers]
+            for o, n, b, mi in zip(peers, cnt, base, my_index):
+                recv_base_at_o = int(sum(c[o, :a]))          # HaloTables of rank o: its slots from rank a start here
+                assert b == recv_base_at_o and b + n <= int(c[o].sum())
+                assert lay[o][0][mi] == a                    # rank a's flag word at o is the one o polls for its peer a
