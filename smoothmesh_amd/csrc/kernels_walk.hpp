@@ -77,7 +77,7 @@ struct WalkView {
 struct FixView {
     int* T;               // [nRelevant] freeze step (header position of the visit that froze the point), -1 before the walk, INT_MAX never
     int* act;             // [nRelevant] 1: the point is still free at its first visit and acts from its proposal
-    unsigned* bar;        // grid barrier counter
+    unsigned* bar;        // grid barrier: two 64-bit counters used alternately (fixSync)
     int* flags;           // [3] rotating "something changed" words, [3] the abort word of a barrier that timed out
 };
 
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(kBlock) k_rel_count(WalkView w) {
 // fx.T != NULL (device replay): an entry item keeps its owner's slot in `hpos` (k_rel_link leaves it there: nothing is
 // pushed in that mode) and the barrier words of k_walk_fix are reset
 __global__ void __launch_bounds__(kBlock) k_rel_fill(WalkView w, FixView fx) {
-    if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { *fx.bar = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = fx.flags[3] = 0; }
+    if (fx.T && blockIdx.x == 0 && threadIdx.x == 0) { fx.bar[0] = fx.bar[1] = fx.bar[2] = fx.bar[3] = 0u; fx.flags[0] = fx.flags[1] = fx.flags[2] = fx.flags[3] = 0; }
     const int nA = w.header[0];
     if (nA <= 0) { if (blockIdx.x == 0 && threadIdx.x == 0) { w.header2[0] = 0; w.header2[1] = 0; } return; }
     if ((int)(blockIdx.x * kRelChunk) >= nA) return;
@@ -662,18 +662,26 @@ __device__ __forceinline__ void stAgent(int* p, int v) { __hip_atomic_store(p, v
 // raises acc->err AND an abort word (flags[3]) that every spin loop tests, so all workgroups leave within microseconds of
 // each other; k_walk_fix returns as soon as a barrier reports it.  Returns false when the launch is being abandoned.
 constexpr unsigned long long kFixTimeoutTicks = 200000000ull;   // s_memrealtime runs at 100 MHz: two seconds
-__device__ __forceinline__ bool fixBarrier(FixView fx, unsigned& target, Accum* acc) {
-    unsigned* ctr = fx.bar;
+// One 64-bit atomic per workgroup and barrier: the low word counts arrivals, the high word the workgroups that report a change
+// (the vote rides in the arrival: a separate flag word cost a second device-scope atomic round trip, ~2 us of the ~7 us a
+// barrier took).  Two counters are used alternately: a workgroup that runs ahead into the next barrier adds to the other
+// counter and cannot come back to this one before everybody has read it.  Returns false when the launch is being abandoned;
+// *changed = some workgroup reported a change in THIS barrier.
+struct FixSync { unsigned tgt[2]; unsigned seen[2]; unsigned n; };
+__device__ __forceinline__ bool fixSync(FixView fx, FixSync& fs, bool mine, Accum* acc, bool* changed) {
+    unsigned long long* ctr = reinterpret_cast<unsigned long long*>(fx.bar);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int aborted;
+    const int any = __syncthreads_or(mine ? 1 : 0);
+    __shared__ int shAbort, shChanged;
     if (threadIdx.x == 0) {
-        target += gridDim.x;
+        const unsigned c = fs.n & 1u;
+        fs.tgt[c] += gridDim.x;
         int ab = 0;
-        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(&ctr[c], 1ull | (any ? (1ull << 32) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
-        while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        unsigned long long v = __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)((unsigned)v - fs.tgt[c]) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0u) {
                 if (ldAgent(&fx.flags[3]) != 0) { ab = 1; break; }
@@ -684,44 +692,69 @@ __device__ __forceinline__ bool fixBarrier(FixView fx, unsigned& target, Accum* 
                     break;
                 }
             }
+            v = __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (!ab && ldAgent(&fx.flags[3]) != 0) ab = 1;
-        aborted = ab;
+        const unsigned high = (unsigned)(v >> 32);
+        shChanged = (high != fs.seen[c]) ? 1 : 0;
+        fs.seen[c] = high;
+        shAbort = ab;
     }
+    ++fs.n;
     __syncthreads();
-    return aborted == 0;
+    if (changed) *changed = shChanged != 0;
+    return shAbort == 0;
 }
 
-// a round's "did anything change" vote: flags[fi] collects it, the word after next is cleared for its next use (every
-// workgroup has read it two barriers ago).  *ok = false when the launch is being abandoned (see fixBarrier).
-__device__ __forceinline__ bool fixVote(FixView fx, int& fi, bool mine, unsigned& target, Accum* acc, bool* ok) {
-    const int any = __syncthreads_or(mine ? 1 : 0);
-    if (threadIdx.x == 0) {
-        if (any) __hip_atomic_fetch_or(&fx.flags[fi], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (blockIdx.x == 0) stAgent(&fx.flags[(fi + 1) % 3], 0);
-    }
-    if (!fixBarrier(fx, target, acc)) { *ok = false; return false; }
-    const bool changed = ldAgent(&fx.flags[fi]) != 0;
-    fi = (fi + 1) % 3;
-    return changed;
-}
-
-__global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, State s) {
+constexpr int kFixPer = 4, kFixLoc = 6144;   // items per thread in registers; owners' T values per workgroup in LDS (2 x 24 KB)
+__global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, State s, int maxSweeps, int useLocalArg) {
     if (s.acc->stop) return;
     const int nR = w.header2[0], nItems = nR + w.header2[1];
     if (nR <= 0) return;
     const int gtid = blockIdx.x * kFixBlock + threadIdx.x, gstride = gridDim.x * kFixBlock;
-    unsigned target = 0;
-    int fi = 0;
+    FixSync fs = {{0u, 0u}, {0u, 0u}, 0u};
     bool ok = true;
     for (int x = gtid; x < nR; x += gstride) stAgent(&fx.act[x], 0);   // round 1: no proposal-state entry fires (an upper bound of T)
+    // this workgroup's slab of the item sequence; its propagating items (current-state entries with a real target whose owner
+    // moves and was not frozen before the walk) in registers, the slot range of its owners for the LDS copy of T
+    const int chunk = (nItems + gridDim.x - 1) / gridDim.x;
+    const int i0 = blockIdx.x * chunk, i1 = min(nItems, i0 + chunk);
+    __shared__ int Tloc[kFixLoc], Tin[kFixLoc];
+    __shared__ int shLo, shHi;
+    int myO[kFixPer], myT[kFixPer], myLast[kFixPer];
+    if (threadIdx.x == 0) { shLo = 0x7fffffff; shHi = -1; }
+    __syncthreads();
+    {
+        int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+        for (int k = 0; k < kFixPer; ++k) {
+            myO[k] = -1; myT[k] = 0; myLast[k] = kNever;
+            const int i = i0 + threadIdx.x + k * kFixBlock;
+            if (i < i1) {
+                const WalkItem it = w.items[i];
+                if (!(it.bits & 0x80u) && (it.bits & 34u) == 34u) {
+                    const unsigned rbo = w.relBits[it.hpos];
+                    if (!(rbo & 4u) && (rbo & 2u)) { myO[k] = it.hpos; myT[k] = it.slot; lo = min(lo, it.hpos); hi = max(hi, it.hpos); }
+                }
+            }
+        }
+        if (hi >= 0) { atomicMin(&shLo, lo); atomicMax(&shHi, hi); }
+    }
+    __syncthreads();
+    const int oLo = shLo, oHi = shHi, oN = (oHi >= oLo) ? oHi - oLo + 1 : 0;
+    // (wave-uniform per workgroup; a slab too long for the registers or too wide for the LDS copy keeps the global form)
+    const bool useLocal = useLocalArg && chunk <= kFixPer * kFixBlock && oN <= kFixLoc;
+    const unsigned long long tStart = __builtin_amdgcn_s_memrealtime();
+    unsigned long long tSweeps = 0;
+    int nVotes = 0, nOuter = 0;
     for (int outer = 0;; ++outer) {
+        ++nOuter;
         // the seeds that do not depend on anybody else
         for (int x = gtid; x < nR; x += gstride) {
             const unsigned rb = w.relBits[x];   // bit0 own move deteriorates, bit1 moved, bit2 frozen before the walk
             stAgent(&fx.T[x], (rb & 4u) ? -1 : (((rb & 3u) == 3u) ? w.hdrPos[x] : kNever));
         }
-        if (!fixBarrier(fx, target, s.acc)) return;
+        if (!fixSync(fx, fs, false, s.acc, nullptr)) return;
         // entries that fire at their owner's first visit: proposal-state entries of the owners in A; current-state entries
         // of owners that never move or were frozen before the walk (they are never re-visited)
         for (int i = gtid; i < nItems; i += gstride) {
@@ -736,32 +769,82 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                 else stAgent(&w.items[i].id, kNever);                      // real target: `id` is free, it holds the last T sent
             }
         }
-        if (!fixBarrier(fx, target, s.acc)) return;
+        if (!fixSync(fx, fs, false, s.acc, nullptr)) return;
         // frozen => re-visited at once, held at its current position: T flows along the current-state entries.  Every workgroup
         // owns a contiguous stretch of the item sequence (= a slab of the mesh: the items follow the point ids) and sweeps
-        // it a few times between two grid barriers, so chains that stay inside a slab do not cost a barrier per link
+        // it several times between two grid barriers, so chains that stay inside a slab do not cost a barrier per link.
+        // Round 3: the sweeps run out of registers and LDS.  A thread keeps its (<= kFixPer) propagating items -- owner slot,
+        // target slot, last value sent -- in registers for the whole launch, and the T values of the slab's owners (a contiguous
+        // slot range: the items are grouped by owner, owners descend) live in LDS between two barriers: a sweep is an LDS
+        // read, a compare and an LDS or global atomicMin instead of four dependent agent-scope round trips (2.0 us per sweep
+        // -> 0.3).  The slab's values are loaded from / folded back into the global array around every barrier; values that
+        // leave the slab go out with global atomics at once.  The fixed point is the same (min-propagation is order-free).
         {
-            const int chunk = (nItems + gridDim.x - 1) / gridDim.x;
-            const int i0 = blockIdx.x * chunk, i1 = min(nItems, i0 + chunk);
-            for (;;) {
-                bool chAny = false;
-                for (int sweep = 0; sweep < 6; ++sweep) {
-                    bool ch = false;
-                    for (int i = i0 + threadIdx.x; i < i1; i += kFixBlock) {
-                        const WalkItem it = w.items[i];
-                        if ((it.bits & 0x80u) || (it.bits & 34u) != 34u) continue;
-                        const int o = it.hpos;
-                        const unsigned rbo = w.relBits[o];
-                        if ((rbo & 4u) || !(rbo & 2u)) continue;
-                        const int t = ldAgent(&fx.T[o]);
-                        if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
+            const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
+            if (useLocal) {
+#pragma unroll
+                for (int k = 0; k < kFixPer; ++k) myLast[k] = kNever;
+                for (;;) {
+                    ++nVotes;
+                    bool chAny = false;
+                    for (int sweep = 0; sweep < maxSweeps; ++sweep) {
+                        // the slab's owners as the other workgroups see them right now (they fold their findings in with global
+                        // atomics sweep by sweep, as this one does below): independent loads, not a chain
+                        for (int x = threadIdx.x; x < oN; x += kFixBlock) { const int v = ldAgent(&fx.T[oLo + x]); Tloc[x] = v; Tin[x] = v; }
+                        __syncthreads();
+                        bool ch = false;
+                        for (int pass = 0; pass < 4; ++pass) {           // a few LDS-only passes: chains inside the slab
+                            bool chp = false;
+#pragma unroll
+                            for (int k = 0; k < kFixPer; ++k) {
+                                if (myO[k] < 0) continue;
+                                const int t = Tloc[myO[k] - oLo];
+                                if (t < myLast[k]) {
+                                    const int tg = myT[k];
+                                    if (tg >= oLo && tg <= oHi) atomicMin(&Tloc[tg - oLo], t);
+                                    else atomicMin(&fx.T[tg], t);
+                                    myLast[k] = t;
+                                    chp = true;
+                                }
+                            }
+                            if (!__syncthreads_or(chp ? 1 : 0)) break;
+                            ch = true;
+                        }
+                        // what the slab learned about its own owners goes back to the global array
+                        for (int x = threadIdx.x; x < oN; x += kFixBlock) { const int v = Tloc[x]; if (v < Tin[x]) atomicMin(&fx.T[oLo + x], v); }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (!__syncthreads_or(ch ? 1 : 0)) break;
+                        chAny = true;
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    if (!__syncthreads_or(ch ? 1 : 0)) break;
-                    chAny = true;
+                    bool changed = false;
+                    if (!fixSync(fx, fs, chAny, s.acc, &changed)) { ok = false; break; }
+                    if (!changed) break;
                 }
-                if (!fixVote(fx, fi, chAny, target, s.acc, &ok)) break;
+            } else {
+                for (;;) {
+                    ++nVotes;
+                    bool chAny = false;
+                    for (int sweep = 0; sweep < maxSweeps; ++sweep) {
+                        bool ch = false;
+                        for (int i = i0 + threadIdx.x; i < i1; i += kFixBlock) {
+                            const WalkItem it = w.items[i];
+                            if ((it.bits & 0x80u) || (it.bits & 34u) != 34u) continue;
+                            const int o = it.hpos;
+                            const unsigned rbo = w.relBits[o];
+                            if ((rbo & 4u) || !(rbo & 2u)) continue;
+                            const int t = ldAgent(&fx.T[o]);
+                            if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        if (!__syncthreads_or(ch ? 1 : 0)) break;
+                        chAny = true;
+                    }
+                    bool changed = false;
+                    if (!fixSync(fx, fs, chAny, s.acc, &changed)) { ok = false; break; }
+                    if (!changed) break;
+                }
             }
+            tSweeps += __builtin_amdgcn_s_memrealtime() - ts0;
         }
         // who was still free at its own first visit?
         bool ch = false;
@@ -772,10 +855,17 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
             if (a != ldAgent(&fx.act[x])) { stAgent(&fx.act[x], a); ch = true; }
         }
         if (!ok) return;
-        if (!fixVote(fx, fi, ch, target, s.acc, &ok)) break;
+        {
+            bool changed = false;
+            if (!fixSync(fx, fs, ch, s.acc, &changed)) return;
+            if (!changed) break;
+        }
         if (outer > 4096) { if (gtid == 0) s.acc->err = 3; break; }       // cannot happen: every round fixes a longer prefix
     }
     if (!ok) return;
+    if (gtid == 0 && fx.flags[15] == 12345) {   // (debug statistics, SMGPU_WALK_STATS)
+        fx.flags[8] += nOuter; fx.flags[9] += nVotes; fx.flags[10] += (int)(__builtin_amdgcn_s_memrealtime() - tStart); fx.flags[11] += (int)tSweeps; fx.flags[12] += 1;
+    }
     // results: every point that got a freeze step, and every sink an entry fired at
     for (int x = gtid; x < nR; x += gstride)
         if (!(w.relBits[x] & 4u) && ldAgent(&fx.T[x]) != kNever) s.frozen[w.items[w.hdrPos[x]].id] = 1;

@@ -125,6 +125,7 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    int walkSweeps = 8;        // SMGPU_WALK_SWEEPS: sweeps of a workgroup over its slab of the item sequence between two grid barriers
     bool bndInGeom = true;     // SMGPU_BND_IN_GEOM=0: boundary pre-kernels on a side stream / in order instead of inside the geometry launch
     bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
@@ -1178,7 +1179,9 @@ static int runFixWalk(smgpu_handle* h) {
         if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
         // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
         h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", 128), 256));
+        h->walkSweeps = std::max(1, envInt("SMGPU_WALK_SWEEPS", 8));
         h->fixAlloc = true;
+        if (envInt("SMGPU_WALK_STATS", 0)) { const int v[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,12345}; HIP_OK(hipMemcpy(f.flags, v, sizeof(v), hipMemcpyHostToDevice)); }
     }
     const MeshView& m = h->mv;
     State s = h->st;
@@ -1201,7 +1204,7 @@ static int runFixWalk(smgpu_handle* h) {
             hipLaunchKernelGGL(k_rel_count, dim3(gRel), dim3(kBlock), 0, h->stream, w);
             hipLaunchKernelGGL(k_rel_fill, dim3(gRel), dim3(kBlock), 0, h->stream, w, fx);
             hipLaunchKernelGGL(k_rel_link, dim3(gItems), dim3(kBlock), 0, h->stream, w, -1, -1, 1);
-            hipLaunchKernelGGL(k_walk_fix, dim3(h->walkFixBlocks), dim3(kFixBlock), 0, h->stream, w, fx, s);
+            hipLaunchKernelGGL(k_walk_fix, dim3(h->walkFixBlocks), dim3(kFixBlock), 0, h->stream, w, fx, s, h->walkSweeps, envInt("SMGPU_WALK_LOCAL", 1));
         })) return 1;
     return 0;
 }
@@ -1480,6 +1483,12 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     h->st.ptsNext = (done & 1) ? buf0 : buf1;
     h->st.stats = nullptr;
     if (drainTimers(h)) return 1;
+    if (h->fixAlloc && envInt("SMGPU_WALK_STATS", 0)) {
+        int v[16];
+        HIP_OK(hipMemcpy(v, h->fxw.flags, sizeof(v), hipMemcpyDeviceToHost));
+        if (v[12] > 0) std::fprintf(stderr, "[smgpu] walk replay: %d launches, per launch %.1f outer rounds, %.1f sweep votes, %.1f us in the kernel's loop, %.1f us of it in sweeps\n",
+                                    v[12], (double)v[8] / v[12], (double)v[9] / v[12], 0.01 * v[10] / v[12], 0.01 * v[11] / v[12]);
+    }
     return 0;
 }
 
