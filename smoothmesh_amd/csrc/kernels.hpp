@@ -127,6 +127,7 @@ __device__ __forceinline__ void pushWait(const PushWait& pw) {
 
 struct State {
     double* ptsCur; double* ptsNext; double* prop;
+    double* stepSqr;   // != NULL: the proposal kernel leaves |proposal - current|^2 per point for k_apply_swap
     double* fCtr; double* fArea; double* cellCtr;
     double* fAvg;      // face vertex averages for the f32 face-angle filter: by face id, or (avgPacked) in the order of the
                        // geometry tiles' face lists -- contiguous stores; the exact kernels form the average themselves
@@ -1039,6 +1040,43 @@ __global__ void __launch_bounds__(kBlock) k_apply(MeshView m, State s, Prm prm) 
         stv(s.ptsNext, p, np);
     }
     blockPublish<kBlock>(s, dist, fcount, blockIdx.x);
+}
+
+// The same step when the proposal kernel has left |proposal - current|^2 per point (State::stepSqr): the proposal array BECOMES
+// the next coordinates (the host swaps the two pointers after this launch), so only the points that do not move are written --
+// 10 bytes per point read instead of k_apply's 50 read + 24 written.  Same values: the proposal kernel forms the square from
+// the registers it stores the proposal from; sqrt and the division by maxStep are monotone, so the largest step is the root of
+// the largest square over maxStep, bit for bit (one sqrt per thread instead of one per point); a restored point contributes 0
+// here as mag(cur - cur) / maxStep does there; NaN never wins on either side.  Four consecutive points per thread.
+constexpr int kApplyPer = 4;
+__global__ void __launch_bounds__(kBlock) k_apply_swap(MeshView m, State s, Prm prm) {
+    if (s.acc->stop) return;
+    const int p0 = (blockIdx.x * kBlock + threadIdx.x) * kApplyPer;
+    double sq[kApplyPer];
+    unsigned fl[kApplyPer], fr[kApplyPer];
+    const int n = min(kApplyPer, m.nPoints - p0);
+    if (n == kApplyPer) {
+        const unsigned f4 = *reinterpret_cast<const unsigned*>(m.pflags + p0), z4 = *reinterpret_cast<const unsigned*>(s.frozen + p0);
+        const double2 a = *reinterpret_cast<const double2*>(s.stepSqr + p0), b = *reinterpret_cast<const double2*>(s.stepSqr + p0 + 2);
+        sq[0] = a.x; sq[1] = a.y; sq[2] = b.x; sq[3] = b.y;
+#pragma unroll
+        for (int k = 0; k < kApplyPer; ++k) { fl[k] = (f4 >> (8 * k)) & 0xffu; fr[k] = (z4 >> (8 * k)) & 0xffu; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kApplyPer; ++k) {
+            const bool in = k < n;
+            fl[k] = in ? m.pflags[p0 + k] : 0u; fr[k] = in ? s.frozen[p0 + k] : 0u; sq[k] = in ? s.stepSqr[p0 + k] : 0.0;
+        }
+    }
+    double mx = 0.0;
+    int fcount = 0;
+#pragma unroll
+    for (int k = 0; k < kApplyPer; ++k) {
+        if (k >= n) break;
+        if (fr[k] || (!(fl[k] & PF_INTERNAL) && !(fl[k] & PF_SMOOTHSURF))) { stv(s.prop, p0 + k, ldv(s.ptsCur, p0 + k)); ++fcount; }
+        else if (sq[k] > mx) mx = sq[k];
+    }
+    blockPublish<kBlock>(s, sqrtExact(mx) / prm.maxStep, fcount, blockIdx.x);
 }
 
 // End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test

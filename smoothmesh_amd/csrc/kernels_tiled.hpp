@@ -193,6 +193,22 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 #define SMGPU_GEOM_AOS 1
 #endif
 constexpr int kGP = SMGPU_GEOM_AOS ? 3 : 1;   // index stride of a point in px / py / pz
+// How the geometry kernel reads a 24-byte record from LDS.  The compiler pairs the x and y reads of a record into one
+// ds_read2_b64: 8 LDS cycles per wave at the 32-bank modulus, where three plain ds_read_b64 cost 2 cycles each at the 64-bank
+// modulus (MI355X_MICROARCH.md, LDS table).  SMGPU_GEOM_LDS_B64=1 keeps the three reads apart (a volatile access is never
+// merged; the waits stay the compiler's).
+#ifndef SMGPU_GEOM_LDS_B64
+#define SMGPU_GEOM_LDS_B64 0
+#endif
+__device__ __forceinline__ V3 ldsg(const double* x, const double* y, const double* z, int i) {
+#if SMGPU_GEOM_LDS_B64
+    typedef const volatile __attribute__((address_space(3))) double* LdsPtr;   // (a volatile access through a generic pointer would become a flat load)
+    const LdsPtr vx = (LdsPtr)x, vy = (LdsPtr)y, vz = (LdsPtr)z;
+    return v3(vx[i], vy[i], vz[i]);
+#else
+    return v3(x[i], y[i], z[i]);
+#endif
+}
 // (a face record is padded to an odd number of doubles: with 6 the records of consecutive faces -- what a wave writes in the
 // face phase -- fall on 8 of the 16 bank pairs, a two-way conflict on every access; SMGPU_GEOM_FACE_STRIDE=6 restores that)
 #ifndef SMGPU_GEOM_FACE_STRIDE
@@ -236,7 +252,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         // the general loop below unrolled for four vertices -- same operations in the same order, every vertex read
         // once, no pad / position tests
         const ushort4 q = pre ? preQ : fvTile[i];
-        const V3 p0 = ldsv(px, py, pz, kGP * (q.x)), p1 = ldsv(px, py, pz, kGP * (q.y)), p2 = ldsv(px, py, pz, kGP * (q.z)), p3 = ldsv(px, py, pz, kGP * (q.w));
+        const V3 p0 = ldsg(px, py, pz, kGP * (q.x)), p1 = ldsg(px, py, pz, kGP * (q.y)), p2 = ldsg(px, py, pz, kGP * (q.z)), p3 = ldsg(px, py, pz, kGP * (q.w));
         fCentre = divByCount(((p0 + p1) + p2) + p3, 4);
         V3 sumN = v3(0, 0, 0), sumAc = v3(0, 0, 0);
         double sumA = 0.0;
@@ -263,21 +279,21 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         fCentre = v3(0, 0, 0);
         int n = 0;
         SMGPU_ELL_FOREACH(row, fw4, 1, {
-            const V3 p = ldsv(px, py, pz, kGP * (e));
+            const V3 p = ldsg(px, py, pz, kGP * (e));
             fCentre = (j == 0) ? p : fCentre + p;
             n = j + 1;
         })
         fCentre = divByCount(fCentre, n);
         if (n == 3) {
             const ushort4 q = row[0];
-            const V3 p0 = ldsv(px, py, pz, kGP * (q.x)), p1 = ldsv(px, py, pz, kGP * (q.y)), p2 = ldsv(px, py, pz, kGP * (q.z));
+            const V3 p0 = ldsg(px, py, pz, kGP * (q.x)), p1 = ldsg(px, py, pz, kGP * (q.y)), p2 = ldsg(px, py, pz, kGP * (q.z));
             ctr = (1.0 / 3.0) * ((p0 + p1) + p2);
             area = 0.5 * cross(p1 - p0, p2 - p0);
         } else if (ORG) {
             V3 sumA = v3(0, 0, 0);
             V3 first = v3(0, 0, 0), thisPoint = v3(0, 0, 0);
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, kGP * (e));
+                const V3 p = ldsg(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else { sumA = sumA + cross(p - thisPoint, fCentre - thisPoint); thisPoint = p; }
             })
@@ -296,7 +312,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         thisPoint = nextPoint;                                                 \
     }
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, kGP * (e));
+                const V3 p = ldsg(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else SMGPU_FAN_ORG(p)
             })
@@ -321,7 +337,7 @@ __device__ __forceinline__ void geomFace(const State& s, const GeomTileView& g, 
         thisPoint = nextPoint;                                                 \
     }
             SMGPU_ELL_FOREACH(row, fw4, 1, {
-                const V3 p = ldsv(px, py, pz, kGP * (e));
+                const V3 p = ldsg(px, py, pz, kGP * (e));
                 if (j == 0) { first = p; thisPoint = p; }
                 else SMGPU_FAN(p)
             })
@@ -377,7 +393,7 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
     double vol = 0.0;
 #define SMGPU_PYR(E, FC)                                                                                   \
     {                                                                                                      \
-        const V3 fA = ldsv(fax, fay, faz, kGF * ((E) & 0x7fff));                                                   \
+        const V3 fA = ldsg(fax, fay, faz, kGF * ((E) & 0x7fff));                                                   \
         double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);                     \
         if (ORG) pyr3Vol = (pyr3Vol > SMGPU_VSMALL) ? pyr3Vol : SMGPU_VSMALL;   /* OpenFOAM.org: max(.., vSmall) */ \
         const V3 pc = (3.0 / 4.0) * (FC) + (1.0 / 4.0) * cEst;                                             \
@@ -388,21 +404,21 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
         // the loops below unrolled for six faces, each face centre read once
         const ushort4 qa = in.qa, qb = in.qb;
         const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
-        const V3 c0 = ldsv(fcx, fcy, fcz, kGF * (e0 & 0x7fff)), c1 = ldsv(fcx, fcy, fcz, kGF * (e1 & 0x7fff)), c2 = ldsv(fcx, fcy, fcz, kGF * (e2 & 0x7fff)),
-                 c3 = ldsv(fcx, fcy, fcz, kGF * (e3 & 0x7fff)), c4 = ldsv(fcx, fcy, fcz, kGF * (e4 & 0x7fff)), c5 = ldsv(fcx, fcy, fcz, kGF * (e5 & 0x7fff));
+        const V3 c0 = ldsg(fcx, fcy, fcz, kGF * (e0 & 0x7fff)), c1 = ldsg(fcx, fcy, fcz, kGF * (e1 & 0x7fff)), c2 = ldsg(fcx, fcy, fcz, kGF * (e2 & 0x7fff)),
+                 c3 = ldsg(fcx, fcy, fcz, kGF * (e3 & 0x7fff)), c4 = ldsg(fcx, fcy, fcz, kGF * (e4 & 0x7fff)), c5 = ldsg(fcx, fcy, fcz, kGF * (e5 & 0x7fff));
         cEst = cEst + c0; cEst = cEst + c1; cEst = cEst + c2; cEst = cEst + c3; cEst = cEst + c4; cEst = cEst + c5;
         cEst = divExact(cEst, 6.0);
         SMGPU_PYR(e0, c0) SMGPU_PYR(e1, c1) SMGPU_PYR(e2, c2) SMGPU_PYR(e3, c3) SMGPU_PYR(e4, c4) SMGPU_PYR(e5, c5)
     } else {
         int nFaces = 0;
         SMGPU_ELL_FOREACH(row, cw4, T, {
-            cEst = cEst + ldsv(fcx, fcy, fcz, kGF * (e & 0x7fff));
+            cEst = cEst + ldsg(fcx, fcy, fcz, kGF * (e & 0x7fff));
             nFaces = j + 1;
         })
         cEst = divByCount(cEst, nFaces);
         SMGPU_ELL_FOREACH(row, cw4, T, {
             (void)j;
-            const V3 fc = ldsv(fcx, fcy, fcz, kGF * (e & 0x7fff));
+            const V3 fc = ldsg(fcx, fcy, fcz, kGF * (e & 0x7fff));
             SMGPU_PYR(e, fc)
         })
     }
@@ -738,6 +754,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         } else {
             stv(s.prop, p, np);
             s.frozen[p] = frozen ? 1 : 0;
+            if (s.stepSqr) s.stepSqr[p] = magSqr(np - cur);   // (k_apply_swap: the residual's term, SM.C:1546-1565)
         }
     }
 }

@@ -125,6 +125,7 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    double* dStepSqr = nullptr;   // |proposal - current|^2 per point (k_apply_swap)
     int walkSweeps = 8;        // SMGPU_WALK_SWEEPS: sweeps of a workgroup over its slab of the item sequence between two grid barriers
     bool bndInGeom = true;     // SMGPU_BND_IN_GEOM=0: boundary pre-kernels on a side stream / in order instead of inside the geometry launch
     bool bndPreDone = false;
@@ -323,6 +324,12 @@ static int drainTimers(smgpu_handle* h) {
     return 0;
 }
 
+// the single-rank loop's restore step as a pointer swap + k_apply_swap (see smgpu_iterate)
+static bool swapApplyOn(const smgpu_handle* h) {
+    return (h->prm.edgeAngleConstraint || h->prm.faceAngleConstraint) && h->useTiles && !h->bndOn && !h->haloOn && h->dStepSqr &&
+           envInt("SMGPU_APPLY_SWAP", 1);
+}
+
 static void computeAlgoBytes(smgpu_handle* h) {
     const Topology& t = h->topo;
     const int64_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
@@ -334,13 +341,13 @@ static void computeAlgoBytes(smgpu_handle* h) {
     b[K_CELL_CENTRES] = 4 * (C + 1) + 4 * ncf + 48 * F + 24 * C;
     const int64_t smooth = 4 * (P + 1) + 4 * npc + 24 * C + 4 * (P + 1) + 4 * npp + 24 * P + P + 24 * P;
     b[K_SMOOTH_FINAL] = smooth;
-    b[K_SMOOTH_PROP] = smooth + P;
+    b[K_SMOOTH_PROP] = smooth + P + (swapApplyOn(h) ? 8 * P : 0);
     b[K_EDGE_ANGLE] = 4 * (P + 1) + 8 * npf + 24 * P + 24 * P + 2 * P;
     b[K_FA_EDGES] = 8 * E + 4 * (E + 1) + 4 * nef + 4 * (E + 1) + 6 * nec + 24 * P + 24 * F + 24 * C + 16 * E;
     b[K_FA_POINTS] = 4 * (P + 1) + 4 * npp + 16 * E + 16 * P + P;
     b[K_FA_PRED] = P;   // good meshes: the flag scan only
     b[K_FA_WALK] = P;
-    b[K_APPLY] = 24 * P + 24 * P + 2 * P + 24 * P;
+    b[K_APPLY] = swapApplyOn(h) ? 8 * P + 2 * P : 24 * P + 24 * P + 2 * P + 24 * P;   // (+ 48 bytes per restored point, not counted)
     b[K_FINISH] = 64;
     b[K_HALO] = 0;
     b[K_BND] = 0;
@@ -634,6 +641,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &h->bufA, 3 * P);
     rc |= devAlloc(h, &h->bufB, 3 * P);
     rc |= devAlloc(h, &s.prop, 3 * P);
+    rc |= devAlloc(h, &h->dStepSqr, P + 4);
     rc |= devAlloc(h, &s.fCtr, 3 * F);
     rc |= devAlloc(h, &s.fArea, 3 * F);
     s.avgPacked = (h->useTiles && h->edgeTilesOk && h->avgPackedCount) ? 1 : 0;
@@ -1439,8 +1447,15 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     const Prm prm = makePrm(h);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const int gP = gridFor(m.nPoints);
+    // constraints on: the proposal array becomes the next coordinates (pointer swap) and k_apply_swap only restores the points
+    // that do not move, instead of k_apply's copy of everything into a third array (SMGPU_APPLY_SWAP=0: that form).  Not with
+    // boundary point smoothing: k_bnd_fix rewrites proposals behind the proposal kernel.
+    const bool swapApply = swapApplyOn(h);
+    const int gSwap = (int)((m.nPoints + (int64_t)kApplyPer * kBlock - 1) / ((int64_t)kApplyPer * kBlock));
+    h->st.stepSqr = swapApply ? h->dStepSqr : nullptr;
+    double*& other = swapApply ? h->st.prop : h->st.ptsNext;
     double* const buf0 = h->st.ptsCur;
-    double* const buf1 = h->st.ptsNext;
+    double* const buf1 = other;
     int launched = 0;
     // relTol <= 0 cannot stop the loop (residual >= 0): the end-of-iteration reduction then rides in the next
     // iteration's geometry launch instead of a launch of its own; the last iteration is closed by k_finish
@@ -1454,12 +1469,13 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
             if (runSmooth<true>(h, m, s, prm)) return 1;
         } else {
             if (runProposalAndConstraints(h)) return 1;
-            if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+            if (swapApply) { if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply_swap, dim3(gSwap), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1; }
+            else if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gP), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
         }
-        const int nPart = ((fused && h->useTiles) ? h->stl.nTiles : gP) + ((fused && h->bndOn) ? gridFor(2 * (int64_t)h->bv.nB) : 0);
+        const int nPart = ((fused && h->useTiles) ? h->stl.nTiles : (swapApply ? gSwap : gP)) + ((fused && h->bndOn) ? gridFor(2 * (int64_t)h->bv.nB) : 0);
         if (deferFinish && i + 1 < nIters) { h->deferN = nPart; h->deferIter = i; }
         else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, i, relTol, (double*)nullptr, (double*)nullptr); })) return 1;
-        std::swap(h->st.ptsCur, h->st.ptsNext);  // mesh.movePoints, SM.C:2399
+        std::swap(h->st.ptsCur, other);  // mesh.movePoints, SM.C:2399
         ++launched;
         // a positive relTol can stop the loop: poll the device flag now and then so a converged run
         // does not queue thousands of no-op launches (relTol <= 0 can never stop: residual >= 0)
@@ -1480,7 +1496,8 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     if (nDone) *nDone = done;
     // the coordinates of iteration `done` live in buf1 when done is odd, buf0 when even
     h->st.ptsCur = (done & 1) ? buf1 : buf0;
-    h->st.ptsNext = (done & 1) ? buf0 : buf1;
+    other = (done & 1) ? buf0 : buf1;
+    h->st.stepSqr = nullptr;
     h->st.stats = nullptr;
     if (drainTimers(h)) return 1;
     if (h->fixAlloc && envInt("SMGPU_WALK_STATS", 0)) {

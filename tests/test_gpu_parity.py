@@ -78,6 +78,38 @@ def test_relTol_stops_like_reference(oracle_lib):
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
 
+@pytest.mark.parametrize("swap", ["1", "0"])
+def test_restore_step_forms_agree(oracle_lib, monkeypatch, swap):
+    """constraints on, single rank: the proposal array becomes the next coordinates by a pointer swap and k_apply_swap only
+    restores the points that do not move (SM.C:2384-2399; SMGPU_APPLY_SWAP=0: k_apply copies everything into a third array).
+    Odd and even iteration counts per call, a relTol stop in the middle of a call, coordinates read and written between calls --
+    the residual series, the frozen counts and the coordinates are the oracle's in both forms."""
+    monkeypatch.setenv("SMGPU_APPLY_SWAP", swap)
+    mesh = _mk(9, 8, 7, 0.47, 21)     # (the constraints freeze ~20 interior points per iteration)
+    o, e, p = _pair(mesh, oracle_lib, edgeAngleConstraint=True, faceAngleConstraint=True)
+    for k in (3, 1, 4):
+        n_o, res_o, frz_o = o.iterate(k, 0.0)
+        n_g, res_g, frz_g = e.iterate(k, 0.0)
+        assert n_o == n_g == k
+        assert np.array_equal(frz_o, frz_g) and np.array_equal(res_o, res_g)
+        assert np.array_equal(e.get_points(), o.points())
+        assert np.array_equal(e.debug_field("points").reshape(-1, 3), o.points())
+    # a stop inside the call: the launches behind it must leave both arrays alone
+    n_o, res_o, frz_o = o.iterate(60, 0.2)
+    n_g, res_g, frz_g = e.iterate(60, 0.2)
+    assert n_o == n_g and 1 <= n_o < 60, n_o
+    assert np.array_equal(res_o, res_g) and np.array_equal(frz_o, frz_g)
+    assert np.array_equal(e.get_points(), o.points())
+    # new coordinates from the host, then on
+    pts = o.points().copy()
+    pts[mesh.nPoints // 2] += 1e-3
+    o.set_points(pts); e.set_points(pts)
+    n_o, res_o, frz_o = o.iterate(5, 0.0)
+    n_g, res_g, frz_g = e.iterate(5, 0.0)
+    assert np.array_equal(res_o, res_g) and np.array_equal(frz_o, frz_g)
+    assert np.array_equal(e.get_points(), o.points())
+
+
 def test_uniform_block_is_fixed_point(oracle_lib):
     # h = 1/8 is exact in binary, so every cell centre / centroid is exact: residual exactly 0
     mesh = _mk(8, 8, 8, 0.0, 0)
