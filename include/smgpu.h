@@ -111,6 +111,8 @@ int smgpu_set_foam_variant(smgpu_handle* h, int32_t variant);
  * per iteration done.  No host synchronisation happens inside the loop. */
 int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_stats* stats, int32_t* nDone);
 
+/* smgpu_get_points also reports an error word a kernel raised since the last check (the step-wise loop below never
+ * synchronises on its own): a non-zero return with smgpu_last_error() set. */
 int smgpu_get_points(smgpu_handle* h, double* outPoints /* [3*nPoints] */);
 int smgpu_set_points(smgpu_handle* h, const double* points /* [3*nPoints] */);
 
@@ -304,6 +306,12 @@ int smgpu_get_boundary_classification(smgpu_handle* h, int32_t* isCornerPoint, i
 int smgpu_debug_edge_strings(int32_t nPoints, int32_t nEdges, const int32_t* edges, int32_t* strings, int32_t* nStrings);
 /* parity access: nearest intersections of n segments (6 doubles each: start, end) with the target surface */
 int smgpu_debug_find_line(smgpu_handle* h, int32_t n, const double* segments, double* hitPoints, int32_t* hit);
+
+/* nEngines engines compute on this handle's device at the same time (ranks sharing a GPU in a debugging run, the sub-domains of
+ * one process): the persistent launch of the face-angle walk replay, whose workgroups all have to be resident at once, takes
+ * 1/nEngines of its default size.  No reference counterpart (the reference runs one MPI rank per core).  Results do not
+ * depend on it. */
+int smgpu_set_device_share(smgpu_handle* h, int32_t nEngines);
 
 /* The replay form of the face-angle freeze walk (SM.C:1347-1434) in use: -1 not decided yet, 0 one wave over the flag array
  * (few points outside the good angle range), 1 host replay (SMGPU_WALK=host), 2 compaction + causal fixed point (many); and how

@@ -449,6 +449,9 @@ int main(int argc, char** argv) {
         K.device = (dev0 + myRank) % nDev;
         d.device = K.device; d.stream = nullptr; d.useCallerStream = 0;
         check(smgpu_create(&d, &K.h), "smgpu_create");
+        // several ranks on one device (a debugging arrangement): every rank's persistent walk replay needs all of its workgroups
+        // resident at once, so each takes its share of the chip (the engine's default is sized for a device of its own)
+        if (nRanks > nDev) check(smgpu_set_device_share(K.h, (nRanks + nDev - 1) / nDev), "smgpu_set_device_share");
     }
     // transport of the per-iteration records between the ranks
     enum { TRANSPORT_RCCL, TRANSPORT_SHM } transport = TRANSPORT_RCCL;

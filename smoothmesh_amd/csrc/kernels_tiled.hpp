@@ -195,10 +195,11 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
 constexpr int kGP = SMGPU_GEOM_AOS ? 3 : 1;   // index stride of a point in px / py / pz
 // How the geometry kernel reads a 24-byte record from LDS.  The compiler pairs the x and y reads of a record into one
 // ds_read2_b64: 8 LDS cycles per wave at the 32-bank modulus, where three plain ds_read_b64 cost 2 cycles each at the 64-bank
-// modulus (MI355X_MICROARCH.md, LDS table).  SMGPU_GEOM_LDS_B64=1 keeps the three reads apart (a volatile access is never
-// merged; the waits stay the compiler's).
+// modulus (MI355X_MICROARCH.md, LDS table).  SMGPU_GEOM_LDS_B64=1 (default) keeps the three reads apart (a volatile access is
+// never merged; the waits stay the compiler's): k_geom_tile 50.4 -> 49.1 us on 100^3, unchanged on the 10 M-cell cavity mesh --
+// the LDS pipeline is not what the kernel waits for.
 #ifndef SMGPU_GEOM_LDS_B64
-#define SMGPU_GEOM_LDS_B64 0
+#define SMGPU_GEOM_LDS_B64 1
 #endif
 __device__ __forceinline__ V3 ldsg(const double* x, const double* y, const double* z, int i) {
 #if SMGPU_GEOM_LDS_B64

@@ -667,21 +667,35 @@ constexpr unsigned long long kFixTimeoutTicks = 200000000ull;   // s_memrealtime
 // barrier took).  Two counters are used alternately: a workgroup that runs ahead into the next barrier adds to the other
 // counter and cannot come back to this one before everybody has read it.  Returns false when the launch is being abandoned;
 // *changed = some workgroup reported a change in THIS barrier.
-struct FixSync { unsigned tgt[2]; unsigned seen[2]; unsigned n; };
-__device__ __forceinline__ bool fixSync(FixView fx, FixSync& fs, bool mine, Accum* acc, bool* changed) {
+// (plain words, no arrays: a dynamically indexed private array is promoted to LDS, 4 bytes x 1024 threads per element)
+struct FixSync { unsigned tgt0, tgt1, seen0, seen1, n, nAny; };
+// "does any thread of the workgroup say yes" through three rotating LDS words (the library's __syncthreads_or carries its own
+// 20 KB of LDS per kernel): word u is written before the barrier of use u and read after it; thread 0 clears it during use
+// u + 2, i.e. behind barrier u + 1, which no thread passes before its read of use u, and in front of barrier u + 2, behind
+// which the word is written again (use u + 3).
+__device__ __forceinline__ bool fixAny(int* anyWords, FixSync& fs, bool mine) {
+    const unsigned u = fs.nAny % 3u;
+    ++fs.nAny;
+    if (threadIdx.x == 0) anyWords[(u + 1u) % 3u] = 0;
+    if (mine) anyWords[u] = 1;
+    __syncthreads();
+    return anyWords[u] != 0;
+}
+__device__ __forceinline__ bool fixSync(FixView fx, FixSync& fs, int* anyWords, bool mine, Accum* acc, bool* changed) {
     unsigned long long* ctr = reinterpret_cast<unsigned long long*>(fx.bar);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int any = __syncthreads_or(mine ? 1 : 0);
+    const bool any = fixAny(anyWords, fs, mine);
     __shared__ int shAbort, shChanged;
     if (threadIdx.x == 0) {
         const unsigned c = fs.n & 1u;
-        fs.tgt[c] += gridDim.x;
+        if (c) fs.tgt1 += gridDim.x; else fs.tgt0 += gridDim.x;
+        const unsigned tgt = c ? fs.tgt1 : fs.tgt0;
         int ab = 0;
         __hip_atomic_fetch_add(&ctr[c], 1ull | (any ? (1ull << 32) : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
         unsigned long long v = __hip_atomic_load(&ctr[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)((unsigned)v - fs.tgt[c]) < 0) {
+        while ((int)((unsigned)v - tgt) < 0) {
             __builtin_amdgcn_s_sleep(1);
             if ((++spins & 63u) == 0u) {
                 if (ldAgent(&fx.flags[3]) != 0) { ab = 1; break; }
@@ -696,8 +710,8 @@ __device__ __forceinline__ bool fixSync(FixView fx, FixSync& fs, bool mine, Accu
         }
         if (!ab && ldAgent(&fx.flags[3]) != 0) ab = 1;
         const unsigned high = (unsigned)(v >> 32);
-        shChanged = (high != fs.seen[c]) ? 1 : 0;
-        fs.seen[c] = high;
+        shChanged = (high != (c ? fs.seen1 : fs.seen0)) ? 1 : 0;
+        if (c) fs.seen1 = high; else fs.seen0 = high;
         shAbort = ab;
     }
     ++fs.n;
@@ -706,20 +720,27 @@ __device__ __forceinline__ bool fixSync(FixView fx, FixSync& fs, bool mine, Accu
     return shAbort == 0;
 }
 
-constexpr int kFixPer = 4, kFixLoc = 6144;   // items per thread in registers; owners' T values per workgroup in LDS (2 x 24 KB)
-__global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, State s, int maxSweeps, int useLocalArg) {
+constexpr int kFixPer = 4, kFixLoc = 2048;   // (small on purpose: several engines can share a device, and every workgroup of
+                                              // every persistent launch has to be resident at once)   // items per thread in registers; owners' T values per workgroup in LDS (2 x 24 KB)
+// (two workgroups per CU = 8 waves per SIMD = at most 64 VGPRs: several engines on one device -- ranks sharing a GPU in tests,
+// the sub-domains of LocalMultiSmoother -- need their persistent launches resident side by side)
+__global__ void __launch_bounds__(kFixBlock, 8) k_walk_fix(WalkView w, FixView fx, State s, int maxSweeps, int useLocalArg) {
     if (s.acc->stop) return;
     const int nR = w.header2[0], nItems = nR + w.header2[1];
     if (nR <= 0) return;
     const int gtid = blockIdx.x * kFixBlock + threadIdx.x, gstride = gridDim.x * kFixBlock;
-    FixSync fs = {{0u, 0u}, {0u, 0u}, 0u};
+    FixSync fs = {0u, 0u, 0u, 0u, 0u, 0u};
+    __shared__ int anyWords[3];
+    if (threadIdx.x < 3) anyWords[threadIdx.x] = 0;
+    __syncthreads();
     bool ok = true;
     for (int x = gtid; x < nR; x += gstride) stAgent(&fx.act[x], 0);   // round 1: no proposal-state entry fires (an upper bound of T)
     // this workgroup's slab of the item sequence; its propagating items (current-state entries with a real target whose owner
     // moves and was not frozen before the walk) in registers, the slot range of its owners for the LDS copy of T
     const int chunk = (nItems + gridDim.x - 1) / gridDim.x;
     const int i0 = blockIdx.x * chunk, i1 = min(nItems, i0 + chunk);
-    __shared__ int Tloc[kFixLoc], Tin[kFixLoc];
+    __shared__ int Tloc[kFixLoc];
+    __shared__ unsigned dirty[kFixLoc / 32];   // slots the slab lowered itself since the last reload
     __shared__ int shLo, shHi;
     int myO[kFixPer], myT[kFixPer], myLast[kFixPer];
     if (threadIdx.x == 0) { shLo = 0x7fffffff; shHi = -1; }
@@ -754,7 +775,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
             const unsigned rb = w.relBits[x];   // bit0 own move deteriorates, bit1 moved, bit2 frozen before the walk
             stAgent(&fx.T[x], (rb & 4u) ? -1 : (((rb & 3u) == 3u) ? w.hdrPos[x] : kNever));
         }
-        if (!fixSync(fx, fs, false, s.acc, nullptr)) return;
+        if (!fixSync(fx, fs, anyWords, false, s.acc, nullptr)) return;
         // entries that fire at their owner's first visit: proposal-state entries of the owners in A; current-state entries
         // of owners that never move or were frozen before the walk (they are never re-visited)
         for (int i = gtid; i < nItems; i += gstride) {
@@ -769,7 +790,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                 else stAgent(&w.items[i].id, kNever);                      // real target: `id` is free, it holds the last T sent
             }
         }
-        if (!fixSync(fx, fs, false, s.acc, nullptr)) return;
+        if (!fixSync(fx, fs, anyWords, false, s.acc, nullptr)) return;
         // frozen => re-visited at once, held at its current position: T flows along the current-state entries.  Every workgroup
         // owns a contiguous stretch of the item sequence (= a slab of the mesh: the items follow the point ids) and sweeps
         // it several times between two grid barriers, so chains that stay inside a slab do not cost a barrier per link.
@@ -790,7 +811,8 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                     for (int sweep = 0; sweep < maxSweeps; ++sweep) {
                         // the slab's owners as the other workgroups see them right now (they fold their findings in with global
                         // atomics sweep by sweep, as this one does below): independent loads, not a chain
-                        for (int x = threadIdx.x; x < oN; x += kFixBlock) { const int v = ldAgent(&fx.T[oLo + x]); Tloc[x] = v; Tin[x] = v; }
+                        for (int x = threadIdx.x; x < oN; x += kFixBlock) Tloc[x] = ldAgent(&fx.T[oLo + x]);
+                        for (int x = threadIdx.x; x < (oN + 31) / 32; x += kFixBlock) dirty[x] = 0u;
                         __syncthreads();
                         bool ch = false;
                         for (int pass = 0; pass < 4; ++pass) {           // a few LDS-only passes: chains inside the slab
@@ -801,23 +823,23 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                                 const int t = Tloc[myO[k] - oLo];
                                 if (t < myLast[k]) {
                                     const int tg = myT[k];
-                                    if (tg >= oLo && tg <= oHi) atomicMin(&Tloc[tg - oLo], t);
+                                    if (tg >= oLo && tg <= oHi) { if (atomicMin(&Tloc[tg - oLo], t) > t) atomicOr(&dirty[(tg - oLo) >> 5], 1u << ((tg - oLo) & 31)); }
                                     else atomicMin(&fx.T[tg], t);
                                     myLast[k] = t;
                                     chp = true;
                                 }
                             }
-                            if (!__syncthreads_or(chp ? 1 : 0)) break;
+                            if (!fixAny(anyWords, fs, chp)) break;
                             ch = true;
                         }
                         // what the slab learned about its own owners goes back to the global array
-                        for (int x = threadIdx.x; x < oN; x += kFixBlock) { const int v = Tloc[x]; if (v < Tin[x]) atomicMin(&fx.T[oLo + x], v); }
+                        for (int x = threadIdx.x; x < oN; x += kFixBlock) if ((dirty[x >> 5] >> (x & 31)) & 1u) atomicMin(&fx.T[oLo + x], Tloc[x]);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (!__syncthreads_or(ch ? 1 : 0)) break;
+                        if (!fixAny(anyWords, fs, ch)) break;
                         chAny = true;
                     }
                     bool changed = false;
-                    if (!fixSync(fx, fs, chAny, s.acc, &changed)) { ok = false; break; }
+                    if (!fixSync(fx, fs, anyWords, chAny, s.acc, &changed)) { ok = false; break; }
                     if (!changed) break;
                 }
             } else {
@@ -836,11 +858,11 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
                             if (t < ldAgent(&w.items[i].id)) { atomicMin(&fx.T[it.slot], t); stAgent(&w.items[i].id, t); ch = true; }
                         }
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        if (!__syncthreads_or(ch ? 1 : 0)) break;
+                        if (!fixAny(anyWords, fs, ch)) break;
                         chAny = true;
                     }
                     bool changed = false;
-                    if (!fixSync(fx, fs, chAny, s.acc, &changed)) { ok = false; break; }
+                    if (!fixSync(fx, fs, anyWords, chAny, s.acc, &changed)) { ok = false; break; }
                     if (!changed) break;
                 }
             }
@@ -857,7 +879,7 @@ __global__ void __launch_bounds__(kFixBlock) k_walk_fix(WalkView w, FixView fx, 
         if (!ok) return;
         {
             bool changed = false;
-            if (!fixSync(fx, fs, ch, s.acc, &changed)) return;
+            if (!fixSync(fx, fs, anyWords, ch, s.acc, &changed)) return;
             if (!changed) break;
         }
         if (outer > 4096) { if (gtid == 0) s.acc->err = 3; break; }       // cannot happen: every round fixes a longer prefix

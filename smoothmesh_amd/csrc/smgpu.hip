@@ -125,6 +125,7 @@ struct smgpu_handle {
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
     bool fixAlloc = false;
     int walkFixBlocks = 128;
+    int deviceShare = 1;          // engines computing on this device at the same time (smgpu_set_device_share)
     double* dStepSqr = nullptr;   // |proposal - current|^2 per point (k_apply_swap)
     int walkSweeps = 8;        // SMGPU_WALK_SWEEPS: sweeps of a workgroup over its slab of the item sequence between two grid barriers
     bool bndInGeom = true;     // SMGPU_BND_IN_GEOM=0: boundary pre-kernels on a side stream / in order instead of inside the geometry launch
@@ -1186,7 +1187,7 @@ static int runFixWalk(smgpu_handle* h) {
         FixView& f = h->fxw;
         if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
         // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
-        h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", 128), 256));
+        h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", std::max(8, 128 / std::max(1, h->deviceShare))), 256));
         h->walkSweeps = std::max(1, envInt("SMGPU_WALK_SWEEPS", 8));
         h->fixAlloc = true;
         if (envInt("SMGPU_WALK_STATS", 0)) { const int v[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,12345}; HIP_OK(hipMemcpy(f.flags, v, sizeof(v), hipMemcpyHostToDevice)); }
@@ -1509,6 +1510,13 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     return 0;
 }
 
+int smgpu_set_device_share(smgpu_handle* h, int32_t nEngines) {
+    if (!h || nEngines < 1) return fail("smgpu_set_device_share: bad argument");
+    h->deviceShare = nEngines;
+    if (h->fixAlloc) h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", std::max(8, 128 / nEngines)), 256));
+    return 0;
+}
+
 int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int32_t* lastCount) {
     if (!h || !mode || !switches || !lastCount) return fail("null argument");
     *mode = h->walkMode;
@@ -1521,8 +1529,10 @@ int smgpu_get_points(smgpu_handle* h, double* out) {
     if (!h || !out) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipMemcpyAsync(out, h->st.ptsCur, sizeof(double) * 3 * (size_t)h->mv.nPoints, hipMemcpyDeviceToHost, h->stream));
-    HIP_OK(hipStreamSynchronize(h->stream));
-    return 0;
+    // the step-wise loop (smgpu_iter_begin / mid / end) never synchronises on its own: an error word raised by a kernel (a grid
+    // barrier or peer-store wait that timed out, a point without usable neighbours ...) surfaces here at the latest, with the
+    // coordinates it spoiled
+    return checkDeviceError(h);
 }
 
 int smgpu_set_points(smgpu_handle* h, const double* pts) {

@@ -435,6 +435,10 @@ class SmoothEngine:
         self.last_active_count = cnt.value
         return mode.value, sw.value
 
+    def set_device_share(self, n_engines):
+        """n_engines engines compute on this device at the same time: the persistent walk replay takes its share of the chip"""
+        self._check(self._lib.smgpu_set_device_share(self._h, int(n_engines)))
+
     def debug_propose(self):
         self._check(self._lib.smgpu_debug_propose(self._h))
 

@@ -10,6 +10,8 @@ Exchange pattern: every pair of ranks that shares points exchanges, in ascending
 one record per shared point -- a single all_to_all_single per exchange (two per iteration) plus one
 all_gather of {residual, nFrozenPoints}.  No collective touches non-shared data.
 """
+import os
+
 import numpy as np
 
 A_DOUBLES = 13  # SMGPU_HALO_A_DOUBLES
@@ -278,6 +280,10 @@ class DistributedSmoother:
             self.estream = torch.cuda.Stream(torch_device)
             self.xstream = torch.cuda.Stream(torch_device)
             engine = SmoothEngine(sub.mesh, device=device, stream=self.estream.cuda_stream)
+            if os.environ.get("SMOOTHMESH_SHARE_GPU") and self.world > 1:
+                # several ranks on one device (a debugging arrangement): every rank's persistent walk replay needs all of its
+                # workgroups resident at once, so each takes its share of the chip
+                engine.set_device_share(-(-self.world // max(1, torch.cuda.device_count())))
             self.overlap = bool(overlap)
             xs = self.xstream.cuda_stream if self.overlap else None
         else:
@@ -285,7 +291,6 @@ class DistributedSmoother:
         self.engine = engine
         # SMOOTHMESH_EXCHANGE=push: the peer-store transport (the ranks' kernels store the records into each other's receive
         # slots; nothing is exchanged by the host).  Needs the real engine, one node, in-order arrangement.
-        import os
         self.pushbuf = None
         want_push = os.environ.get("SMOOTHMESH_EXCHANGE", "") == "push" and engine_factory is None and torch_device.type == "cuda"
         if want_push:
@@ -330,7 +335,6 @@ class DistributedSmoother:
     def _open_direct(self, own_engine):
         """grouped ncclSend / ncclRecv on the engine's stream for the per-iteration exchanges (rccl_direct.py) when the process
         group is RCCL and every rank's self-check against all_to_all_single passes; None = the torch collective"""
-        import os
         torch, dist = self.torch, self.dist
         if self.pushbuf is not None:
             return None
@@ -630,6 +634,8 @@ class LocalMultiSmoother:
                 from .engine import SmoothEngine
                 cur = torch.cuda.current_stream(torch_device).cuda_stream
                 eng = SmoothEngine(s.mesh, device=device) if overlap else SmoothEngine(s.mesh, device=device, stream=cur)
+                if overlap:      # the sub-domains' persistent walk replays run side by side on one device: each takes its share
+                    eng.set_device_share(len(subs))
                 xs = cur if overlap else None
             else:
                 eng, xs = engine_factory(s.mesh), None
