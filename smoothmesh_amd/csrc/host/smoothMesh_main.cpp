@@ -454,17 +454,23 @@ int main(int argc, char** argv) {
         if (nRanks > nDev) check(smgpu_set_device_share(K.h, (nRanks + nDev - 1) / nDev), "smgpu_set_device_share");
     }
     // transport of the per-iteration records between the ranks
-    enum { TRANSPORT_RCCL, TRANSPORT_SHM } transport = TRANSPORT_RCCL;
+    enum { TRANSPORT_RCCL, TRANSPORT_SHM, TRANSPORT_PUSH } transport = TRANSPORT_RCCL;
     ncclComm_t nccl = nullptr;
     hipStream_t engineStream = nullptr;
+    struct PushHandles { char h[4][64]; } pushHandles{};   // recvA, recvL, recvF, flags
+    void* pushFlags = nullptr;
+    std::vector<void*> pushMapped, pushA, pushL, pushF, pushFl;
+    std::vector<int32_t> pushCount, pushBase, pushIndex;
     if (opt.parallel) {
         const char* tv = std::getenv("SMOOTHMESH_TRANSPORT");
         if (tv && std::string(tv) == "shm") transport = TRANSPORT_SHM;
         else if (tv && std::string(tv) == "rccl") transport = TRANSPORT_RCCL;
+        else if (tv && std::string(tv) == "push") transport = TRANSPORT_PUSH;   // peer stores (include/smgpu.h, smgpu_push_desc)
         else if (nDev < nRanks) {
             transport = TRANSPORT_SHM;
             OUT("WARNING: %d ranks on %d GPU(s): RCCL needs one device per rank; staging the shared-point records through host memory (debug transport)\n\n", nRanks, nDev);
         }
+        if (transport == TRANSPORT_PUSH) OUTS("Shared-point records: peer stores into the ranks' mapped receive buffers (SMOOTHMESH_TRANSPORT=push)\n");
         void* vs = nullptr;
         check(smgpu_get_stream(K0.h, &vs), "smgpu_get_stream");
         engineStream = (hipStream_t)vs;
@@ -539,12 +545,20 @@ int main(int argc, char** argv) {
             HIPCHK(hipSetDevice(K.device));
             const size_t ns = (size_t)std::max(K.nSend, 1);
             HIPCHK(hipMalloc((void**)&K.sendA, ns * SMGPU_HALO_A_DOUBLES * 8));
-            HIPCHK(hipMalloc((void**)&K.recvA, ns * SMGPU_HALO_A_DOUBLES * 8));
             HIPCHK(hipMalloc((void**)&K.sendF, ns * 4));
-            HIPCHK(hipMalloc((void**)&K.recvF, ns * 4));
             HIPCHK(hipMalloc((void**)&K.localStats, 16));
             HIPCHK(hipMalloc((void**)&K.sendL, ns * SMGPU_HALO_L_DOUBLES * 8));
-            HIPCHK(hipMalloc((void**)&K.recvL, ns * SMGPU_HALO_L_DOUBLES * 8));
+            if (transport == TRANSPORT_PUSH) {
+                // receive buffers + flag words the peers can map (uncached device memory with an IPC handle each)
+                const size_t bytes[4] = {ns * SMGPU_HALO_A_DOUBLES * 8, ns * SMGPU_HALO_L_DOUBLES * 8, ns * 4, 4 * 2 * 64};
+                void* ptr[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int b = 0; b < 4; ++b) check(smgpu_push_alloc(K.device, bytes[b], &ptr[b], pushHandles.h[b]), "smgpu_push_alloc");
+                K.recvA = (double*)ptr[0]; K.recvL = (double*)ptr[1]; K.recvF = (int32_t*)ptr[2]; pushFlags = ptr[3];
+            } else {
+                HIPCHK(hipMalloc((void**)&K.recvA, ns * SMGPU_HALO_A_DOUBLES * 8));
+                HIPCHK(hipMalloc((void**)&K.recvF, ns * 4));
+                HIPCHK(hipMalloc((void**)&K.recvL, ns * SMGPU_HALO_L_DOUBLES * 8));
+            }
             smgpu_halo_desc hd{};
             hd.nShared = (int32_t)K.sharedLocal.size(); hd.sharedLocal = K.sharedLocal.data();
             hd.nSend = K.nSend; hd.sendShared = K.sendShared.data(); hd.nRecv = K.nSend;
@@ -552,6 +566,30 @@ int main(int argc, char** argv) {
             hd.sendA = K.sendA; hd.recvA = K.recvA; hd.sendF = K.sendF; hd.recvF = K.recvF; hd.localStats = K.localStats;
             hd.sendL = K.sendL; hd.recvL = K.recvL;
             check(smgpu_halo_configure(K.h, &hd), "smgpu_halo_configure");
+        }
+        if (transport == TRANSPORT_PUSH) {
+            // every rank's handles and slot counts; the peers' buffers mapped; the layout of smoothmesh_amd/halo.py:push_layout
+            // (a peer groups its receive slots by source rank, ascending: this rank's records start behind those of the
+            // lower ranks; its flag word at the peer is its position among the peer's peers)
+            const auto allHandles = g_comm.allgather(pushHandles);
+            const auto countsOf = g_comm.allgatherVec(K0.peerCount);
+            for (int o = 0; o < nRanks; ++o) {
+                if (o == myRank || K0.peerCount[o] == 0) continue;
+                if (countsOf[(size_t)o][(size_t)myRank] != K0.peerCount[o]) fatal("asymmetric shared-point lists");
+                void* m[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int b = 0; b < 4; ++b) { check(smgpu_push_open(K0.device, allHandles[(size_t)o].h[b], &m[b]), "smgpu_push_open"); pushMapped.push_back(m[b]); }
+                int32_t base = 0, idx = 0;
+                for (int r2 = 0; r2 < myRank; ++r2) { base += countsOf[(size_t)o][(size_t)r2]; idx += countsOf[(size_t)o][(size_t)r2] > 0 ? 1 : 0; }
+                pushCount.push_back(K0.peerCount[o]); pushBase.push_back(base); pushIndex.push_back(idx);
+                pushA.push_back(m[0]); pushL.push_back(m[1]); pushF.push_back(m[2]); pushFl.push_back(m[3]);
+            }
+            smgpu_push_desc pd{};
+            pd.nPeers = (int32_t)pushCount.size();
+            pd.peerCount = pushCount.data(); pd.remoteBase = pushBase.data(); pd.myIndexAtPeer = pushIndex.data();
+            pd.peerRecvA = pushA.data(); pd.peerRecvL = pushL.data(); pd.peerRecvF = pushF.data(); pd.peerFlags = pushFl.data();
+            pd.localFlags = pushFlags;
+            g_comm.barrier();                      // every rank's flag words are zero before anybody's first store
+            check(smgpu_halo_set_push(K0.h, &pd), "smgpu_halo_set_push");
         }
     }
 
@@ -722,6 +760,7 @@ int main(int argc, char** argv) {
     // mapping (D2H, barrier, H2D, barrier).
     struct Part { const void* send; void* recv; size_t bytesPerSlot; };
     auto exchange = [&](std::initializer_list<Part> parts) {
+        if (transport == TRANSPORT_PUSH) return;   // the pack kernels have stored the records at the peers themselves
         if (transport == TRANSPORT_RCCL) {
             NCCLCHK(ncclGroupStart());
             for (const Part& pt : parts)
@@ -878,6 +917,13 @@ int main(int argc, char** argv) {
     }
 
     if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); NCCLCHK(ncclCommDestroy(nccl)); }
+    if (transport == TRANSPORT_PUSH && opt.parallel) {
+        HIPCHK(hipStreamSynchronize(engineStream));
+        g_comm.barrier();                          // nobody unmaps a buffer a peer may still store into
+        check(smgpu_halo_set_push(K0.h, nullptr), "smgpu_halo_set_push");
+        for (void* m : pushMapped) check(smgpu_push_close(m), "smgpu_push_close");
+        g_comm.barrier();
+    }
     for (Rank& K : R) smgpu_destroy(K.h);
     g_comm.barrier();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

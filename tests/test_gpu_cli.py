@@ -266,6 +266,39 @@ def test_parallel_polyhedral_case_one_process_per_rank(tmp_path, oracle_lib, rel
         assert rel_linf(got, o.points()) <= 1e-13
 
 
+@pytest.mark.parametrize("constraints", [False, True])
+def test_parallel_case_over_peer_stores(tmp_path, oracle_lib, monkeypatch, constraints):
+    """SMOOTHMESH_TRANSPORT=push: the ranks of `smoothMesh -parallel` map each other's receive buffers (hipIpc) and the pack
+    kernels store the records there themselves (include/smgpu.h, smgpu_push_desc); the front-end moves nothing between the
+    smgpu_iter_* calls.  Four ranks on this box's one device (IPC between processes works on one device too), a polyhedral
+    case, against the oracle's MultiDomain."""
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.polymesh import cavity_subdomain, read_polymesh, write_decomposed_case
+    monkeypatch.setenv("SMOOTHMESH_TRANSPORT", "push")
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    grid = (2, 2, 1)
+    subs = [cavity_subdomain(10, grid, r, jitter=0.2, seed=9) for r in range(4)]
+    write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    flag = "true" if constraints else "false"
+    out = _run(["-case", str(tmp_path), "-parallel", "-centroidalIters", "7", "-relTol", "0", "-edgeAngleConstraint", flag,
+                "-faceAngleConstraint", flag])
+    assert "nProcs : 4" in out and "peer stores" in out and "debug transport" not in out
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_lib.MultiOracle(orcs, *shared_point_table(subs))
+    n, res, frz = mo.iterate(7, 0.0)
+    lines = LINE.findall(out)
+    assert len(lines) == n == 7
+    assert [int(b) for _, b, _ in lines] == frz.tolist()
+    for s, o in zip(subs, orcs):
+        d = tmp_path / f"processor{s.rank}"
+        got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "7" / "polyMesh")).points
+        assert rel_linf(got, o.points()) <= 1e-13
+
+
 def test_parallel_single_rank_initialises_rccl(tmp_path, oracle_lib):
     """one processor0/ directory: the rank is its own process and, having a device of its own, brings up RCCL
     (ncclCommInitRank with one rank); results equal the serial run's"""
