@@ -78,7 +78,8 @@ struct FixView {
     int* T;               // [nRelevant] freeze step (header position of the visit that froze the point), -1 before the walk, INT_MAX never
     int* act;             // [nRelevant] 1: the point is still free at its first visit and acts from its proposal
     unsigned* bar;        // grid barrier: two 64-bit counters used alternately (fixSync)
-    int* flags;           // [3] rotating "something changed" words, [3] the abort word of a barrier that timed out
+    int* flags;           // [3] the abort word of a barrier that timed out, [8..15] debug statistics
+    uint8_t* actPrev;     // [nPoints] `act` of the point in the last walk it took part in: the first guess of the next one
 };
 
 // Ordered compaction of the active points and of their pointPoints rows: chunks of 4 096 points per workgroup, count launch +
@@ -734,7 +735,15 @@ __global__ void __launch_bounds__(kFixBlock, 8) k_walk_fix(WalkView w, FixView f
     if (threadIdx.x < 3) anyWords[threadIdx.x] = 0;
     __syncthreads();
     bool ok = true;
-    for (int x = gtid; x < nR; x += gstride) stAgent(&fx.act[x], 0);   // round 1: no proposal-state entry fires (an upper bound of T)
+    // First guess of the set A (points that act from their proposal): what the same point did in the previous iteration's walk.
+    // Any start converges to the one fixed point (every round gets the earliest wrong decision and everything before it
+    // right); consecutive smoothing iterations differ little, so the guess is mostly right and the loop below ends after one
+    // or two rounds instead of three (fx.actPrev == NULL: the empty set, round 2's start).
+    for (int x = gtid; x < nR; x += gstride) {
+        int g = 0;
+        if (fx.actPrev && (w.relBits[x] & 7u) == 2u) g = fx.actPrev[w.items[w.hdrPos[x]].id] ? 1 : 0;
+        stAgent(&fx.act[x], g);
+    }
     // this workgroup's slab of the item sequence; its propagating items (current-state entries with a real target whose owner
     // moves and was not frozen before the walk) in registers, the slot range of its owners for the LDS copy of T
     const int chunk = (nItems + gridDim.x - 1) / gridDim.x;
@@ -888,6 +897,9 @@ __global__ void __launch_bounds__(kFixBlock, 8) k_walk_fix(WalkView w, FixView f
     if (gtid == 0 && fx.flags[15] == 12345) {   // (debug statistics, SMGPU_WALK_STATS)
         fx.flags[8] += nOuter; fx.flags[9] += nVotes; fx.flags[10] += (int)(__builtin_amdgcn_s_memrealtime() - tStart); fx.flags[11] += (int)tSweeps; fx.flags[12] += 1;
     }
+    if (fx.actPrev)
+        for (int x = gtid; x < nR; x += gstride)
+            if ((w.relBits[x] & 7u) == 2u) fx.actPrev[w.items[w.hdrPos[x]].id] = (uint8_t)ldAgent(&fx.act[x]);
     // results: every point that got a freeze step, and every sink an entry fired at
     for (int x = gtid; x < nR; x += gstride)
         if (!(w.relBits[x] & 4u) && ldAgent(&fx.T[x]) != kNever) s.frozen[w.items[w.hdrPos[x]].id] = 1;

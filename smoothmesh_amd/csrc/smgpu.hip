@@ -1186,6 +1186,7 @@ static int runFixWalk(smgpu_handle* h) {
         const size_t P = (size_t)h->topo.nPoints;
         FixView& f = h->fxw;
         if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
+        if (envInt("SMGPU_WALK_WARM", 1)) { if (devAlloc(h, &f.actPrev, P)) return 1; HIP_OK(hipMemset(f.actPrev, 0, P)); }
         // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
         h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", std::max(8, 128 / std::max(1, h->deviceShare))), 256));
         h->walkSweeps = std::max(1, envInt("SMGPU_WALK_SWEEPS", 8));
