@@ -148,15 +148,29 @@ def test_bad_mesh_face_angle_walk(oracle_lib, monkeypatch, jit, seed, walk):
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
 
+@pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4}])
 @pytest.mark.parametrize("dims,jit,seed", [((14, 12, 10), 0.47, 3), ((20, 6, 5), 0.49, 8)])
-def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed):
+def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed, knobs):
     """a badly distorted block: the interaction graph has components of hundreds of points with long re-visit chains;
-    the fixed-point device replay must still reproduce the reference's order"""
+    the fixed-point device replay must still reproduce the reference's order -- from the previous iteration's set or from the
+    empty one, with the sweeps in LDS or in global memory, one or several sweeps between two grid barriers, with the full
+    persistent launch or a quarter of it (smgpu_set_device_share).  Coordinates are written from the host in the middle (the
+    warm start then begins from a set that belongs to other coordinates)."""
     monkeypatch.setenv("SMGPU_WALK", "fix")
+    for k, v in knobs.items():
+        if k.startswith("SMGPU_"):
+            monkeypatch.setenv(k, v)
     mesh = _mk(*dims, jit, seed)
     o, e, p = _pair(mesh, oracle_lib)
+    if "share" in knobs:
+        e.set_device_share(knobs["share"])
     n_o, res_o, frz_o = o.iterate(6, 0.0)
     n_g, res_g, frz_g = e.iterate(6, 0.0)
+    assert np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
+    o.set_points(mesh.points); e.set_points(mesh.points)
+    n_o, res_o, frz_o = o.iterate(3, 0.0)
+    n_g, res_g, frz_g = e.iterate(3, 0.0)
     assert np.array_equal(frz_o, frz_g)
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
