@@ -352,12 +352,26 @@ class DistributedSmoother:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
             return None
-        d = rccl_direct.RcclDirect(torch, dist, self.device)
+        # (the first real multi-GPU run of this path happens outside the builder's reach: a rank on which the second communicator
+        # cannot be brought up, or whose self-check raises, must not take the job down -- every rank then agrees on the torch
+        # collective instead)
+        d, ok = None, 1
+        try:
+            d = rccl_direct.RcclDirect(torch, dist, self.device)
+        except Exception as ex:  # noqa: BLE001
+            print(f"[smoothmesh_amd] rank {self.rank}: direct RCCL exchange unavailable ({type(ex).__name__}: {ex}); using all_to_all_single", flush=True)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank has its communicator, or nobody uses one
         counts = [self.probe_slots] if self.world == 1 else self.counts
-        if not d.self_check(counts, self.device):
-            d.close()
-            return None
-        return d
+        if int(flag.item()) and d.self_check(counts, self.device):   # (self_check agrees on its result across the ranks itself)
+            return d
+        if d is not None:
+            try:
+                d.close()
+            except Exception:  # noqa: BLE001
+                pass
+        return None
 
     def close(self):
         """Orderly shutdown, to be called on every rank BEFORE dist.barrier() / destroy_process_group(): drain the engine's and
