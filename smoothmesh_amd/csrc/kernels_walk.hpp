@@ -807,8 +807,9 @@ __global__ void __launch_bounds__(kFixBlock, 8) k_walk_fix(WalkView w, FixView f
         // target slot, last value sent -- in registers for the whole launch, and the T values of the slab's owners (a contiguous
         // slot range: the items are grouped by owner, owners descend) live in LDS between two barriers: a sweep is an LDS
         // read, a compare and an LDS or global atomicMin instead of four dependent agent-scope round trips (2.0 us per sweep
-        // -> 0.3).  The slab's values are loaded from / folded back into the global array around every barrier; values that
-        // leave the slab go out with global atomics at once.  The fixed point is the same (min-propagation is order-free).
+        // -> 0.3).  The slab's values are re-read from the global array at the start of every sweep (independent loads) and
+        // what the slab lowered itself -- a dirty bit per slot -- is folded back at its end; values that leave the slab go out
+        // with global atomics at once.  The fixed point is the same (min-propagation is order-free).
         {
             const unsigned long long ts0 = __builtin_amdgcn_s_memrealtime();
             if (useLocal) {
