@@ -105,6 +105,18 @@ int smgpu_set_params(smgpu_handle* h, const smgpu_params* p);
  * SMGPU_FOAM_VARIANT=org selects ORG at smgpu_create.  Call before iterating. */
 enum { SMGPU_FOAM_COM = 0, SMGPU_FOAM_ORG = 1 };
 int smgpu_set_foam_variant(smgpu_handle* h, int32_t variant);
+/* Multi-rank runs: which syncTools::syncPointList the shared-point combines of minMagSqrEqOp / maxMagSqrEqOp follow (SM.C:402-469
+ * with isCloserPoint :246-272, OBB.C:359-365, :490-496).  MASTER (default) = globalMeshData::syncData, the form of every OpenFOAM
+ * the reference builds against (Allwmake:47): the values of a point's sharers are folded ONCE, starting from the lowest rank's
+ * value, in ascending rank order, and every sharer receives that result -- an exact tie hands the lower rank's vector to all, so a
+ * rank can receive another rank's equal-length vector (the case isCloserPoint exists for) and a run cut through an exactly graded
+ * mesh reproduces the serial aspect-ratio blend.  OWN = every sharer folds the others' values onto its own (a tie keeps the own
+ * vector; the sharers may end with different vectors): the model of rounds 1-3 of this library, kept as the A/B.  The
+ * environment variable SMGPU_SYNC_VARIANT=own selects OWN at smgpu_create.  The host-side combines of the step-wise set-ups
+ * (smgpu_layers_shared / smgpu_boundary_shared) are the host's: smoothmesh_amd/halo.py and the smoothMesh front-end follow the
+ * same switch.  Call before iterating. */
+enum { SMGPU_SYNC_MASTER = 0, SMGPU_SYNC_OWN = 1 };
+int smgpu_set_sync_variant(smgpu_handle* h, int32_t variant);
 
 /* The loop SM.C:2257-2437 on one rank: up to nIters iterations, stops after the first iteration
  * whose residual < relTol (SM.C:2401).  stats (host, [nIters], may be NULL) receives one entry

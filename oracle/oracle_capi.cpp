@@ -31,6 +31,8 @@ void* orc_create(int nPoints, int nCells, int nFaces, int nInternalFaces, const 
 void orc_destroy(void* h) { delete static_cast<Domain*>(h); }
 
 void orc_set_foam_variant(void* h, int variant) { static_cast<Domain*>(h)->foamVariant = variant; }
+// syncPointList model of the rank-engine combines below: 0 = master fold (globalMeshData::syncData), 1 = own-value fold
+void orc_set_sync_variant(void* h, int variant) { static_cast<Domain*>(h)->syncVariant = variant; }
 void orc_set_params(void* h, double maxStepLength, double relStepFrac, double minEdgeLength, int totalMinFreeze,
                     int edgeAngleConstraint, int faceAngleConstraint, double minAngle, double maxAngle) {
     Domain* d = static_cast<Domain*>(h);
@@ -156,6 +158,7 @@ void* orc_multi_create(int nDomains, void** handles) {
     return m;
 }
 void orc_multi_destroy(void* m) { delete static_cast<MultiDomain*>(m); }
+void orc_multi_set_sync_variant(void* m, int variant) { static_cast<MultiDomain*>(m)->syncVariant = variant; }
 // shared points as CSR: for shared point s, entries [off[s], off[s+1]) give (domain, local) pairs,
 // ascending domain id
 void orc_multi_set_shared(void* mh, int nShared, const int* off, const int* domain, const int* local) {
@@ -206,7 +209,7 @@ void orc_halo_combineA(void* h, int nShared, const int* sharedLocal, const int* 
             cnt += (int)(pk & 0xffffffffll);
             hc[j] = (unsigned char)(pk >> 32);
         }
-        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data());
+        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data(), d->syncVariant);
         unsigned char any = 0;
         for (int j = 0; j < n; ++j) any |= hc[j];
         d->cellSum[p] = sum; d->cellCount[p] = cnt;
@@ -249,8 +252,11 @@ void orc_halo_combineL(void* h, int nShared, const int* sharedLocal, const int* 
         const int b = combOff[i], n = combOff[i + 1] - b;
         const Vec3 ownN = d->pointNormals[p];
         Vec3 sum{0, 0, 0}, fsum{0, 0, 0};
-        Vec3 x = d->outerNeighCoords[p];
-        Vec3 y = bnd ? d->innerNeighCoords[p] : Vec3{GREAT, GREAT, GREAT};
+        // minMagSqrEqOp: master fold (the first sharer's value, the others folded onto it in ascending rank order; every sharer
+        // gets the same result) or, syncVariant 1, folded onto the own value
+        const bool ownFold = d->syncVariant == 1;
+        const Vec3 ownX = d->outerNeighCoords[p], ownY = bnd ? d->innerNeighCoords[p] : Vec3{GREAT, GREAT, GREAT};
+        Vec3 x = ownX, y = ownY;
         int faces = 0, fcnt = 0;
         for (int j = 0; j < n; ++j) {
             const int sl = combSlots[b + j];
@@ -263,10 +269,12 @@ void orc_halo_combineL(void* h, int nShared, const int* sharedLocal, const int* 
                 fsum.x += fj.x; fsum.y += fj.y; fsum.z += fj.z;
                 fcnt += r ? (int)r[13] : d->nFeatureEdgeProjections[p];
             }
-            if (r) {
-                x = fold(x, Vec3{r[3], r[4], r[5]});
-                if (bnd) y = fold(y, Vec3{r[7], r[8], r[9]});
-            }
+            const Vec3 xj = r ? Vec3{r[3], r[4], r[5]} : ownX;
+            const Vec3 yj = r ? (bnd ? Vec3{r[7], r[8], r[9]} : Vec3{GREAT, GREAT, GREAT}) : ownY;
+            if (ownFold) {
+                if (r) { x = fold(x, xj); if (bnd) y = fold(y, yj); }
+            } else if (j == 0) { x = xj; y = yj; }
+            else { x = fold(x, xj); if (bnd) y = fold(y, yj); }
         }
         d->pointNormals[p] = sum;
         d->outerNeighCoords[p] = x;

@@ -19,6 +19,9 @@ def build():
     subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
 
 
+SYNC_VARIANTS = {"master": 0, "own": 1}
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -29,6 +32,8 @@ def lib():
         l.orc_create.argtypes = [C.c_int] * 4 + [f64p, i32p, i32p, i32p, i32p, u8p, u8p]
         l.orc_destroy.argtypes = [C.c_void_p]
         l.orc_set_foam_variant.argtypes = [C.c_void_p, C.c_int]
+        l.orc_set_sync_variant.argtypes = [C.c_void_p, C.c_int]
+        l.orc_multi_set_sync_variant.argtypes = [C.c_void_p, C.c_int]
         l.orc_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double]
         l.orc_mesh_stats.argtypes = [C.c_void_p, f64p, f64p]
         l.orc_iterate.restype = C.c_int
@@ -127,6 +132,11 @@ class Oracle:
     def set_foam_variant(self, variant):
         """"com" (default) / "org": OpenFOAM line whose primitiveMesh geometry formulas are used (smooth_oracle.hpp)"""
         self._lib.orc_set_foam_variant(self._h, {"com": 0, "org": 1}[variant])
+
+    def set_sync_variant(self, variant):
+        """"master" (default: globalMeshData::syncData, every sharer receives the master's fold) / "own" (every sharer folds the
+        others' values onto its own): syncPointList model of the rank-engine combines (smooth_oracle.cpp)"""
+        self._lib.orc_set_sync_variant(self._h, SYNC_VARIANTS[variant])
 
     def set_params(self, p):
         self._lib.orc_set_params(self._h, p.maxStepLength, p.relStepFrac, p.minEdgeLength, int(p.totalMinFreeze),
@@ -260,12 +270,17 @@ class OracleRankEngine:
         self.o = Oracle(mesh)
         self.o_mesh = mesh
         self._lib = lib()
+        if os.environ.get("SMGPU_SYNC_VARIANT", "") == "own":      # the variable the product's engine reads
+            self.o.set_sync_variant("own")
 
     def mesh_stats(self):
         return self.o.mesh_stats()
 
     def set_params(self, p):
         self.o.set_params(p)
+
+    def set_sync_variant(self, variant):
+        self.o.set_sync_variant(variant)
 
     def halo_configure(self, sharedLocal, sendShared, nRecv, combOffsets, combSlots, sendA, recvA, sendF, recvF, localStats,
                        exchangeStream=None, sendL=None, recvL=None):
@@ -363,6 +378,10 @@ class MultiOracle:
         sd = np.ascontiguousarray(sharedDomain, np.int32)
         sl = np.ascontiguousarray(sharedLocal, np.int32)
         self._lib.orc_multi_set_shared(self._h, len(so) - 1, _p(so, i32p), _p(sd, i32p), _p(sl, i32p))
+
+    def set_sync_variant(self, variant):
+        """"master" (default) / "own": the syncTools::syncPointList model (smooth_oracle.cpp, MultiDomain::syncVariant)"""
+        self._lib.orc_multi_set_sync_variant(self._h, SYNC_VARIANTS[variant])
 
     def setup_layers(self, patch_arrays_per_domain, layerMaxBlendingFraction, layerEdgeLength, layerExpansionRatio, minLayers,
                      maxLayers):

@@ -888,24 +888,41 @@ int Domain::iterate(int nIters, double relTol, double* residuals, int* nFrozen) 
 }
 
 // ---- multi-domain (MPI ranks of the reference, emulated in one process) ---------------
-// syncTools::syncPointList model used here (OpenFOAM is not in the reference tree):
-//  * plusEqOp: all partial values are summed in ascending domain order, same result on
-//    every sharer;
-//  * minMagSqrEqOp (ops.H: x = (magSqr(x) <= magSqr(y) ? x : y)): every sharer folds
-//    starting from ITS OWN value, then the other sharers' values in ascending domain order
-//    (processor-patch exchange: cop(myValue, nbrValue)), so an exact tie keeps the own value;
-//  * orEqOp: logical or.
-// The three sequential closest-point syncs of findClosestPoints (SM.C:391-469) for the n ranks
-// sharing one point; arrays hold every sharer's local values on entry and its synced values on exit.
-void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc) {
-    auto fold = [&](const std::vector<Vec3>& v, int self) {
+// syncTools::syncPointList model (OpenFOAM is not in the reference tree; restated from OpenFOAM's
+// syncTools::syncPointList -> globalMeshData::syncPointData -> globalMeshData::syncData, the form of every version the
+// reference builds against: OpenFOAM.org 12, OpenFOAM.com v2312-v2506, Allwmake:47):
+//  * the sharers of a point form one group; the MASTER is the sharer with the lowest processor number
+//    (globalPoints sorts a point's (processor, index) pairs, the first is the master), the slaves follow in
+//    ascending processor order;
+//  * syncData pulls the slaves' values to the master, folds  x = master;  for slaves ascending: cop(x, slave),
+//    and hands every sharer THE SAME x;
+//  * plusEqOp: the sum in ascending processor order; orEqOp / maxEqOp: order free;
+//  * minMagSqrEqOp (ops.H: x = (magSqr(x) <= magSqr(y) ? x : y)) and maxMagSqrEqOp (>=): an exact tie keeps
+//    the LOWER processor's value -- on every sharer.  This is what lets isCloserPoint's "same distance,
+//    different coordinates" case (SM.C:242-244) fire: a rank can receive another rank's equal-length vector.
+// syncVariant 1 (kept as an A/B switch; rounds 1-3 of this repository used it) is the processor-patch form of
+// OpenFOAM < 2.0: every sharer folds the others' values onto ITS OWN (cop(mine, nbr)), so a tie keeps the own value
+// and the sharers can end with different vectors.
+static Vec3 foldMagSqrOf(const Vec3* v, int n, int self, bool takeMax, int syncVariant) {
+    auto keepX = [&](const Vec3& x, const Vec3& y) { return takeMax ? (magSqr(x) >= magSqr(y)) : (magSqr(x) <= magSqr(y)); };
+    if (syncVariant == 1) {
         Vec3 x = v[self];
         for (int k = 0; k < n; ++k) {
             if (k == self) continue;
-            x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
+            x = keepX(x, v[k]) ? x : v[k];
         }
         return x;
-    };
+    }
+    Vec3 x = v[0];                                        // the master's value
+    for (int k = 1; k < n; ++k) x = keepX(x, v[k]) ? x : v[k];   // slaves in ascending processor order
+    return x;
+}
+
+// The three sequential closest-point syncs of findClosestPoints (SM.C:391-469) for the n ranks
+// sharing one point (ascending processor order); arrays hold every sharer's local values on entry and its synced
+// values on exit.
+void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc, int syncVariant) {
+    auto fold = [&](const std::vector<Vec3>& v, int self) { return foldMagSqrOf(v.data(), n, self, false, syncVariant); };
     {   // position 1, SM.C:397-419
         std::vector<Vec3> sent(r1, r1 + n);
         for (int j = 0; j < n; ++j) {
@@ -953,7 +970,7 @@ void MultiDomain::syncA() {
             r3[j] = d->closest3[sp.local[j]];
             hc[j] = d->hasCommonCell[sp.local[j]];
         }
-        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data());
+        combineClosest(n, r1.data(), r2.data(), r3.data(), hc.data(), syncVariant);
         unsigned char any = 0;  // SM.C:472-478
         for (int j = 0; j < n; ++j) any |= hc[j];
         for (int j = 0; j < n; ++j) {
@@ -974,20 +991,12 @@ void MultiDomain::syncFrozen() {  // SM.C:2374-2380
     }
 }
 
-// syncPointList(maxMagSqrEqOp / minMagSqrEqOp) for one shared point: every sharer folds the others' values onto its
-// own in ascending rank order; a tie keeps what it has (x = (magSqr(x) >= magSqr(y)) ? x : y)
-static void foldMagSqr(std::vector<Vec3>& v, bool takeMax) {
+// syncPointList(maxMagSqrEqOp / minMagSqrEqOp) for one shared point (sharers in ascending processor order): the
+// master fold by default, every sharer's own fold with syncVariant 1 (see above)
+static void foldMagSqr(std::vector<Vec3>& v, bool takeMax, int syncVariant) {
     const int n = int(v.size());
     const std::vector<Vec3> sent(v);
-    for (int self = 0; self < n; ++self) {
-        Vec3 x = sent[self];
-        for (int k = 0; k < n; ++k) {
-            if (k == self) continue;
-            const bool keep = takeMax ? (magSqr(x) >= magSqr(sent[k])) : (magSqr(x) <= magSqr(sent[k]));
-            x = keep ? x : sent[k];
-        }
-        v[self] = x;
-    }
+    for (int self = 0; self < n; ++self) v[self] = foldMagSqrOf(sent.data(), n, self, takeMax, syncVariant);
 }
 
 // OBB.C:184-198 plusEq syncs of calculateBoundaryPointNormals (sums in ascending rank order, as syncA does for the
@@ -1008,7 +1017,7 @@ void MultiDomain::syncLayers() {
             dom[sp.domain[j]]->layerNFaces[sp.local[j]] = cnt;
             nc[j] = dom[sp.domain[j]]->outerNeighCoords[sp.local[j]];
         }
-        foldMagSqr(nc, false);
+        foldMagSqr(nc, false, syncVariant);
         for (int j = 0; j < n; ++j) dom[sp.domain[j]]->outerNeighCoords[sp.local[j]] = nc[j];
     }
 }
@@ -1045,7 +1054,7 @@ void MultiDomain::setupLayers(const std::vector<std::vector<Patch>>& p, const La
         for (const SharedPoint& sp : shared) {
             std::vector<Vec3> v(sp.domain.size());
             for (size_t j = 0; j < sp.domain.size(); ++j) v[j] = dom[sp.domain[j]]->pointNormals[sp.local[j]];
-            foldMagSqr(v, true);
+            foldMagSqr(v, true, syncVariant);
             for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->pointNormals[sp.local[j]] = v[j];
         }
     }
@@ -1106,7 +1115,7 @@ void MultiDomain::setupBoundary(const std::vector<std::vector<Patch>>& p, const 
         for (const SharedPoint& sp : shared) {   // maxMagSqr, OBB.C:359-365
             std::vector<Vec3> v(sp.domain.size());
             for (size_t j = 0; j < sp.domain.size(); ++j) v[j] = dom[sp.domain[j]]->pointNormals[sp.local[j]];
-            foldMagSqr(v, true);
+            foldMagSqr(v, true, syncVariant);
             for (size_t j = 0; j < sp.domain.size(); ++j) dom[sp.domain[j]]->pointNormals[sp.local[j]] = v[j];
         }
     }
@@ -1125,7 +1134,7 @@ void MultiDomain::syncBoundary() {
             cnt += dom[sp.domain[j]]->nFeatureEdgeProjections[sp.local[j]];
             nc[j] = dom[sp.domain[j]]->innerNeighCoords[sp.local[j]];
         }
-        foldMagSqr(nc, false);                                                 // minMagSqrEqOp, OBB.C:490-496
+        foldMagSqr(nc, false, syncVariant);                                                 // minMagSqrEqOp, OBB.C:490-496
         for (int j = 0; j < n; ++j) {
             dom[sp.domain[j]]->featureEdgeProjections[sp.local[j]] = s;
             dom[sp.domain[j]]->nFeatureEdgeProjections[sp.local[j]] = cnt;

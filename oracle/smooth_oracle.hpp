@@ -176,6 +176,8 @@ public:
     // builds against either (Allwmake:47, README.md:30); both formulas are restated from OpenFOAM sources that are not under
     // /root/reference.
     int foamVariant = 0;
+    // rank-engine form of the shared-point combines (oracle_capi.cpp orc_halo_combine*): the syncPointList model, as MultiDomain::syncVariant
+    int syncVariant = 0;
     void phaseA();                   // geometry, SM.C:108-131 partial sums, SM.C:325-387 local closest
     void phaseB();                   // SM.C:155-163, 580-590, 684-754, 602-652, 900-930, 1320-1437
     void phaseC();                   // SM.C:2384-2392 restore+count, SM.C:1556-1565 residual
@@ -203,6 +205,9 @@ class MultiDomain {
 public:
     std::vector<Domain*> dom;
     std::vector<SharedPoint> shared;
+    // syncTools::syncPointList model: 0 = globalMeshData::syncData (master fold, every sharer receives the same value; OpenFOAM
+    // >= 2.0, i.e. every version the reference builds against), 1 = every sharer folds onto its own value (see smooth_oracle.cpp)
+    int syncVariant = 0;
     int iterate(int nIters, double relTol, double* residuals, int* nFrozen);
     void syncA();
     void syncFrozen();
@@ -219,6 +224,6 @@ int findEdgeMeshStrings(std::vector<int>& targetEdgeStrings, const EdgeMesh& em)
 double edgeEdgeAngle(const Vec3& c, const Vec3& p1, const Vec3& p2);   // SM.C:766-786
 double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1);  // SM.C:980-998
 bool isCloserPoint(const Vec3& a, const Vec3& b);  // SM.C:246-272
-void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc);  // SM.C:391-469
+void combineClosest(int n, Vec3* r1, Vec3* r2, Vec3* r3, unsigned char* hc, int syncVariant = 0);  // SM.C:391-469
 
 }  // namespace orc

@@ -1,7 +1,9 @@
 """DistributedSmoother on a decomposed POLYHEDRAL mesh (BASELINE configs[4]'s family) against the oracle's MultiDomain, on N
 ranks (torch.distributed.run); every rank generates its own sub-domain (polymesh.cavity_subdomain).
 On a 1-GPU box: SMOOTHMESH_SHARE_GPU=1 SMOOTHMESH_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 ... (the
-engines are the real ones; only the transport is gloo).  Exit code 1 on a mismatch."""
+engines are the real ones; only the transport is gloo).  CHECK_IRREGULAR=<kind>:<seed> takes the sub-domains from an IRREGULAR
+cellRank instead (tests/test_irregular_partitions.build_case: ragged interfaces, a disconnected sub-domain, a rank without shared
+points; any world size).  Exit code 1 on a mismatch."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,12 +22,26 @@ if os.environ.get("SMOOTHMESH_SHARE_GPU"):
 torch.cuda.set_device(local)
 backend = os.environ.get("SMOOTHMESH_BACKEND", "nccl")
 dist.init_process_group(backend, **({"device_id": torch.device("cuda", local)} if backend == "nccl" else {}))
-grid = {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
+irregular = os.environ.get("CHECK_IRREGULAR", "")
+grid = None if irregular else {2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}[world]
 N = int(os.environ.get("CHECK_POLY_N", "14"))
+
+
+def make_subs():
+    if irregular:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_irregular_partitions import build_case
+        from smoothmesh_amd.decompose import decompose
+        kind, seed = irregular.split(":")
+        mesh, cr = build_case(kind, world, int(seed))
+        return decompose(mesh, cr, world)
+    return [cavity_subdomain(N, grid, r, jitter=0.2, seed=4) for r in range(world)]
+
+
 bad = 0
 for constraints in (False, True):
     for overlap in (False, True):
-        subs = [cavity_subdomain(N, grid, r, jitter=0.2, seed=4) for r in range(world)]   # all of them only for the expected values
+        subs = make_subs()   # all of them only for the expected values
         orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
         prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
         for o in orcs:

@@ -1,6 +1,8 @@
 """Randomised GPU-vs-oracle parity sweep (run on the GPU box): random block sizes, jitter up to near-inversion, random
-smoothing parameters, constraints, layer patches, boundary point smoothing (box and sphere targets), serial and decomposed.  Prints one line per case; exit code 1 on the
-first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
+smoothing parameters, constraints, layer patches, boundary point smoothing (box and sphere targets), serial and decomposed -- into
+boxes, into IRREGULAR sub-domains (breadth-first grown or random cellRank maps, 2..8 ranks, disconnected pieces), and on
+UNJITTERED / exactly graded blocks whose points sit on binary fractions, where the edge-length comparisons of the closest-point
+syncs (SM.C:388-478) tie exactly.  Prints one line per case; exit code 1 on the first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,13 +10,14 @@ import numpy as np
 from oracle import oracle_ffi
 from smoothmesh_amd import BoundaryParams, LayerParams, SmoothEngine, SmgpuError, default_params, patch_arrays
 from smoothmesh_amd.surfgen import box_feature_edges, box_surface, sphere_surface
-from smoothmesh_amd.decompose import shared_point_table
+from smoothmesh_amd.decompose import bfs_partition, decompose, grid_partition, random_partition, shared_point_table
 from smoothmesh_amd.halo import LocalMultiSmoother
 from smoothmesh_amd.meshgen import hex_block, hex_subdomain
 from smoothmesh_amd.polymesh import cavity_mesh
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+KINDS = os.environ.get("FUZZ_KINDS", "hex,hex,cavity,multi,multi,irregular,tied").split(",")   # FUZZ_KINDS=irregular,tied: only those
 PATCHES = ["xmin", "xmax", "ymin", "ymax", "zmin", "zmax"]
 
 
@@ -28,7 +31,7 @@ def params(mn):
 
 bad = 0
 for case in range(n_cases):
-    kind = rng.choice(["hex", "hex", "cavity", "multi", "multi"])
+    kind = rng.choice(KINDS)
     iters = int(rng.integers(2, 9))
     layers = rng.random() < 0.5
     lp = LayerParams(layerPatches=tuple(rng.choice(PATCHES, size=int(rng.integers(1, 4)), replace=False)),
@@ -36,13 +39,46 @@ for case in range(n_cases):
                      minLayers=int(rng.integers(0, 3)), maxLayers=int(rng.integers(3, 6)))
     jitter = float(rng.choice([0.1, 0.3, 0.45]))
     seed = int(rng.integers(1 << 30))
-    if kind == "multi":
-        grid = tuple(int(x) for x in rng.choice([1, 2, 3], size=3))
-        if grid == (1, 1, 1):
-            grid = (2, 1, 1)
-        world = grid[0] * grid[1] * grid[2]
-        nloc = tuple(int(x) for x in rng.integers(3, 9, size=3))
-        subs = [hex_subdomain(nloc, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+    if kind in ("multi", "irregular", "tied"):
+        if kind == "multi":
+            grid = tuple(int(x) for x in rng.choice([1, 2, 3], size=3))
+            if grid == (1, 1, 1):
+                grid = (2, 1, 1)
+            world = grid[0] * grid[1] * grid[2]
+            nloc = tuple(int(x) for x in rng.integers(3, 9, size=3))
+            subs = [hex_subdomain(nloc, grid, r, jitter=jitter, seed=seed) for r in range(world)]
+            desc = f"multi grid {grid} local {nloc}"
+        elif kind == "irregular":
+            world = int(rng.integers(2, 9))
+            if rng.random() < 0.5:
+                gm = hex_block(*(int(x) for x in rng.integers(5, 11, size=3)), jitter=jitter, seed=seed)
+            else:
+                gm = cavity_mesh(int(rng.integers(8, 13)), jitter=min(jitter, 0.3), seed=seed)
+            how = rng.choice(["bfs", "island", "random"])
+            cr = random_partition(gm, world, seed=seed) if how == "random" else bfs_partition(gm, world, seed=seed, island=(how == "island"))
+            subs = decompose(gm, cr, world)
+            desc = f"irregular {how} x{world} cells {gm.nCells}"
+        else:
+            # points on binary fractions: spacing 2^-4 (x possibly 2^-5: an exactly graded block), a tenth of the interior points moved
+            # by multiples of 2^-10 -- equal lengths stay bit-equal, so the closest-point syncs see exact ties at the processor cuts
+            nx, ny, nz = (int(x) for x in rng.integers(4, 9, size=3))
+            graded = rng.random() < 0.6
+            if graded:
+                nx *= 2
+            gm = hex_block(nx, ny, nz, lengths=(nx / (32.0 if graded else 16.0), ny / 16.0, nz / 16.0), jitter=0.0)
+            P = gm.points.reshape(-1, 3)
+            inner = np.flatnonzero(gm.find_internal_points())
+            mv = rng.choice(inner, size=max(1, len(inner) // 10), replace=False)
+            P[mv] += rng.integers(-6, 7, size=(len(mv), 3)) / 1024.0
+            grid = tuple(int(x) for x in rng.choice([1, 2], size=3))
+            if grid == (1, 1, 1):
+                grid = (2, 1, 1)
+            world = grid[0] * grid[1] * grid[2]
+            how = rng.choice(["boxes", "bfs"])
+            cr = grid_partition(gm, grid) if how == "boxes" else bfs_partition(gm, world, seed=seed)
+            subs = decompose(gm, cr, world)
+            desc = f"tied {'graded ' if graded else ''}({nx},{ny},{nz}) {how} x{world}"
+            jitter = 0.0
         ms = LocalMultiSmoother(subs, device=0)
         orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
         mn = min(o.mesh_stats()[0] for o in orcs)
@@ -52,8 +88,8 @@ for case in range(n_cases):
             o.set_params(prm)
         off, dom, loc = shared_point_table(subs)
         mo = oracle_ffi.MultiOracle(orcs, off, dom, loc)
-        desc = f"multi grid {grid} local {nloc}"
-        boundary = rng.random() < 0.5
+        boundary = kind == "multi" and rng.random() < 0.5
+        layers = layers and (kind != "irregular" or "cavity" not in {p.name for p in subs[0].mesh.patches})
         if boundary:      # every sub-domain is a unit cube of the block [0, grid]
             hi = tuple(float(g) for g in grid)
             f = float(rng.choice([1.0, 1.0, 1.02]))

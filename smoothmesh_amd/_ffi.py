@@ -100,6 +100,7 @@ SYMBOLS = {
     "smgpu_mesh_stats": (C.c_int, [C.c_void_p, c_f64p, c_f64p]),
     "smgpu_set_params": (C.c_int, [C.c_void_p, C.POINTER(Params)]),
     "smgpu_set_foam_variant": (C.c_int, [C.c_void_p, C.c_int32]),
+    "smgpu_set_sync_variant": (C.c_int, [C.c_void_p, C.c_int32]),
     "smgpu_halo_set_push": (C.c_int, [C.c_void_p, C.POINTER(PushDesc)]),
     "smgpu_push_alloc": (C.c_int, [C.c_int32, C.c_size_t, C.POINTER(C.c_void_p), C.c_void_p]),
     "smgpu_push_open": (C.c_int, [C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]),

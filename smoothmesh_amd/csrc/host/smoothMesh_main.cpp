@@ -596,7 +596,11 @@ int main(int argc, char** argv) {
     // -parallel: the reference's syncPointList calls of the set-ups: every rank publishes its values at its shared points and
     // combines, for each of its points, the values of the sharers in ascending rank order
     typedef int (*SharedFn)(smgpu_handle*, int32_t, int32_t, double*);
-    auto syncShared = [&](SharedFn fn, const char* what, int field, int width, int op) {   // op 0 max, 1 sum (ascending rank), 2 larger magnitude folded onto own
+    // op 0 max, 1 sum (ascending rank), 2 larger magnitude (maxMagSqrEqOp).  The magnitude fold follows globalMeshData::syncData:
+    // started from the lowest rank's value, the others folded onto it in ascending rank order, every sharer ends with that value (a
+    // tie keeps the lower rank's); SMGPU_SYNC_VARIANT=own: folded onto the own value instead (include/smgpu.h smgpu_set_sync_variant)
+    const bool ownFold = [] { const char* sv = std::getenv("SMGPU_SYNC_VARIANT"); return sv && std::string(sv) == "own"; }();
+    auto syncShared = [&](SharedFn fn, const char* what, int field, int width, int op) {
         const size_t nS = K0.sharedGlobal.size();
         std::vector<double> mine(std::max<size_t>(nS, 1) * width, 0.0);
         if (nS) check(fn(K0.h, field, 0, mine.data()), what);
@@ -606,6 +610,7 @@ int main(int argc, char** argv) {
             const int64_t g = K0.sharedGlobal[i];
             double* x = &v[i * width];
             if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
+            bool first = true;
             for (int o = 0; o < nRanks; ++o) {
                 const double* y = nullptr;
                 if (o == myRank) y = &mine[i * width];
@@ -616,12 +621,11 @@ int main(int argc, char** argv) {
                     y = &sent[(size_t)o][(size_t)(it - sg.begin()) * width];
                 }
                 if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }
-                if (o == myRank) continue;
-                if (op == 0) { if (y[0] > x[0]) x[0] = y[0]; }
-                else {
-                    const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
-                    if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
-                }
+                if (op == 0) { if (o != myRank && y[0] > x[0]) x[0] = y[0]; continue; }
+                if (ownFold) { if (o == myRank) continue; }
+                else if (first) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; first = false; continue; }   // the master's value
+                const double mx = x[0] * x[0] + x[1] * x[1] + x[2] * x[2], my = y[0] * y[0] + y[1] * y[1] + y[2] * y[2];
+                if (!(mx >= my)) { x[0] = y[0]; x[1] = y[1]; x[2] = y[2]; }
             }
         }
         if (nS) check(fn(K0.h, field, 1, v.data()), what);

@@ -149,6 +149,9 @@ struct State {
     const int* combOff; const int* combSlots; const double* ownA; const double* recvA;
     const int* sendOff; const int* sendSlots; int* sendF;
     int inlineCombine, inlinePackF;
+    // syncTools::syncPointList model of the minMagSqr / maxMagSqr folds (smgpu_set_sync_variant): 0 = the master's fold handed to
+    // every sharer (globalMeshData::syncData), 1 = every sharer folds the others onto its own value
+    int ownFold;
     // optional boundary layer treatment (layers.hpp): per point normal (re-normalised every iteration), hop count,
     // outer neighbour; per hop count the target edge length and the blending fraction
     double* layerNormal; const int* layerHops; const int* layerMap; const double* layerLen; const double* layerBlend;
@@ -1203,16 +1206,19 @@ __device__ __forceinline__ void haloPackLOf(const State& s, const PackLArgs& a, 
 }
 __global__ void __launch_bounds__(kBlock) k_halo_packL(State s, PackLArgs a) { haloPackLOf(s, a, blockIdx.x * kBlock + threadIdx.x); }
 // plusEq in ascending rank order for the normals, face counts and feature projections (OBB.C:184-198, BPS.C:659-674);
-// minMagSqrEqOp folded from the own value for the outer and inner neighbour coordinates (OBB.C:490-496)
+// minMagSqrEqOp for the outer and inner neighbour coordinates (OBB.C:490-496): the master's fold -- the lowest rank's value, the
+// others folded onto it in ascending rank order, the same result on every sharer (globalMeshData::syncData) -- or, ownFold, the
+// others folded onto the own value
 __device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* combOff, const int* combSlots, const double* ownL,
-                                               const double* recvL, double* combL, int w) {
+                                               const double* recvL, double* combL, int w, int ownFold) {
     if (i >= nShared) return;
     const int b = combOff[i], n = combOff[i + 1] - b;
     const double* own = ownL + (size_t)i * w;
     const bool wide = w > SMGPU_HALO_L_LAYERS;   // the boundary point smoothing fields travel too
     V3 sum = v3(0, 0, 0), fsum = v3(0, 0, 0);
     double faces = 0.0, fcnt = 0.0;
-    V3 x = v3(own[3], own[4], own[5]), y = wide ? v3(own[7], own[8], own[9]) : v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+    const V3 great = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
+    V3 x = v3(own[3], own[4], own[5]), y = wide ? v3(own[7], own[8], own[9]) : great;
     for (int j = 0; j < n; ++j) {
         const int sl = combSlots[b + j];
         const double* r = (sl < 0) ? own : recvL + (size_t)sl * w;
@@ -1222,10 +1228,11 @@ __device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* co
             fsum = fsum + v3(r[10], r[11], r[12]);
             fcnt += r[13];
         }
-        if (sl >= 0) {
-            const V3 x2 = v3(r[3], r[4], r[5]);
+        const V3 x2 = v3(r[3], r[4], r[5]), y2 = wide ? v3(r[7], r[8], r[9]) : great;
+        if (!ownFold && j == 0) { x = x2; y = y2; }        // the master's value starts the fold
+        else if (!ownFold || sl >= 0) {
             x = (magSqr(x) <= magSqr(x2)) ? x : x2;
-            if (wide) { const V3 y2 = v3(r[7], r[8], r[9]); y = (magSqr(y) <= magSqr(y2)) ? y : y2; }
+            if (wide) y = (magSqr(y) <= magSqr(y2)) ? y : y2;
         }
     }
     double* o = combL + (size_t)i * w;
@@ -1233,8 +1240,8 @@ __device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* co
     if (wide) { o[6] = faces; o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt; }
 }
 __global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
-                                                          const double* recvL, double* combL, int w) {
-    haloCombineLOf(blockIdx.x * kBlock + threadIdx.x, nShared, combOff, combSlots, ownL, recvL, combL, w);
+                                                          const double* recvL, double* combL, int w, int ownFold) {
+    haloCombineLOf(blockIdx.x * kBlock + threadIdx.x, nShared, combOff, combSlots, ownL, recvL, combL, w, ownFold);
 }
 
 // SM.C:246-272 isCloserPoint
@@ -1247,7 +1254,10 @@ __device__ __forceinline__ bool isCloserPoint(const V3& a, const V3& b) {
 
 // The three sequential syncs (SM.C:391-478) for a point with TWO sharers, both ranks' views in scalars: ra = this rank's
 // record, rb = the other rank's, selfFirst = this rank is the lower one (plusEqOp sums in ascending rank order).
-__device__ __forceinline__ void combineTwoSharers(const double* ra, const double* rb, bool selfFirst, V3& sum, V3& a1, V3& a2, V3& a3,
+// minMagSqrEqOp (x = (magSqr(x) <= magSqr(y)) ? x : y): syncTools::syncPointList folds once, master (lower rank) first, and both
+// ranks receive that value -- an exact tie hands the LOWER rank's vector to both, which is what lets isCloserPoint's equal-length
+// case fire on the upper rank; ownFold = each rank folds the other's value onto its own (a tie keeps the own vector on both).
+__device__ __forceinline__ void combineTwoSharers(const double* ra, const double* rb, bool selfFirst, int ownFold, V3& sum, V3& a1, V3& a2, V3& a3,
                                                   int& cnt, int& anyCommon) {
     const V3 sa = v3(ra[0], ra[1], ra[2]), sb = v3(rb[0], rb[1], rb[2]);
     sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;    // plusEqOp, ascending rank
@@ -1256,20 +1266,22 @@ __device__ __forceinline__ void combineTwoSharers(const double* ra, const double
     const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
     cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
     int hcA = (int)(pa >> 32), hcB = (int)(pb >> 32);
-    // minMagSqrEqOp folded from the own value: x = (magSqr(x) <= magSqr(y)) ? x : y
+    const bool aLeads = ownFold || selfFirst, bLeads = ownFold || !selfFirst;   // whose value starts the fold each rank receives
 #define SMGPU_FOLD2(X, Y) ((magSqr(X) <= magSqr(Y)) ? (X) : (Y))
-    {   // SM.C:397-419: both ranks exchange their first vectors
-        const V3 svA = SMGPU_FOLD2(a1, b1), svB = SMGPU_FOLD2(b1, a1);
+    {   // SM.C:397-419: the first vectors
+        const V3 fab = SMGPU_FOLD2(a1, b1), fba = SMGPU_FOLD2(b1, a1);
+        const V3 svA = aLeads ? fab : fba, svB = bLeads ? fba : fab;
         if (isCloserPoint(svA, a1)) { a3 = a2; a2 = a1; a1 = svA; hcA = 0; }
         if (isCloserPoint(svB, b1)) { b3 = b2; b2 = b1; b1 = svB; hcB = 0; }
     }
     {   // SM.C:424-445: the (updated) second vectors
-        const V3 svA = SMGPU_FOLD2(a2, b2), svB = SMGPU_FOLD2(b2, a2);
+        const V3 fab = SMGPU_FOLD2(a2, b2), fba = SMGPU_FOLD2(b2, a2);
+        const V3 svA = aLeads ? fab : fba, svB = bLeads ? fba : fab;
         if (isCloserPoint(svA, a2)) { a3 = a2; a2 = svA; hcA = 0; }
         if (isCloserPoint(svB, b2)) { b3 = b2; b2 = svB; hcB = 0; }
     }
     {   // SM.C:450-469: the (updated) third vectors
-        const V3 svA = SMGPU_FOLD2(a3, b3);
+        const V3 svA = aLeads ? SMGPU_FOLD2(a3, b3) : SMGPU_FOLD2(b3, a3);
         if (isCloserPoint(svA, a3)) a3 = svA;
     }
 #undef SMGPU_FOLD2
@@ -1283,12 +1295,12 @@ constexpr int kMaxSharers = 16;
 // was three dependent loads, this is two -- and the points with more sharers in the trailing workgroups.  No per-sharer
 // arrays here, so the kernel needs no scratch memory.
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
-                                             const double* ownA, const double* recvA, double* combA);
+                                             const double* ownA, const double* recvA, double* combA, int ownFold);
 __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
                                                 const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
-                                                const int* multiIdx, const int* multiSlots) {
+                                                const int* multiIdx, const int* multiSlots, int ownFold) {
     if (bx >= nBlocksTwo) {
-        combineMulti(bx - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
+        combineMulti(bx - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA, ownFold);
         return;
     }
     const int i = bx * kBlock + threadIdx.x;
@@ -1299,7 +1311,7 @@ __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* 
     const double* rb = recvA + (size_t)(pr & 0x3fffffff) * SMGPU_HALO_A_DOUBLES;
     V3 sum, a1, a2, a3;
     int cnt, any2;
-    combineTwoSharers(ra, rb, (pr & 0x40000000) != 0, sum, a1, a2, a3, cnt, any2);
+    combineTwoSharers(ra, rb, (pr & 0x40000000) != 0, ownFold, sum, a1, a2, a3, cnt, any2);
     double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
     o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
     o[3] = a1.x; o[4] = a1.y; o[5] = a1.z;
@@ -1309,26 +1321,27 @@ __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* 
 }
 __global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
                                                            const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
-                                                           const int* multiIdx, const int* multiSlots, PushWait pw) {
+                                                           const int* multiIdx, const int* multiSlots, PushWait pw, int ownFold) {
     pushWait(pw);
-    haloCombineA2Of((int)blockIdx.x, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots);
+    haloCombineA2Of((int)blockIdx.x, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots, ownFold);
 }
 
 // syncPointList semantics for one shared point (same model as oracle MultiDomain::syncA):
-// plusEqOp in ascending rank order; minMagSqrEqOp folds from the own value (ties keep own).
+// plusEqOp in ascending rank order; minMagSqrEqOp folds from the master's (lowest rank's) value in ascending rank order and every
+// sharer receives that result (ties keep the lower rank's vector) -- or, ownFold, from each sharer's own value.
 // Points with more than two sharers (processor edges and corners: few) are left to combineMulti when skipMulti
 // is set: their per-sharer arrays live in scratch memory and a single lane walking them cost ~70 us per launch.
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
-                                             const double* ownA, const double* recvA, double* combA);
+                                             const double* ownA, const double* recvA, double* combA, int ownFold);
 // The workgroups after the first nBlocksTwo handle the listed points with more than two sharers (combineMulti): one launch,
 // so that the latency of that small, dependent-load-bound part overlaps with the two-sharer part.
 __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
                                                           const double* ownA, const double* recvA, double* combA, int* err,
                                                           int skipMulti, int nBlocksTwo, int nMulti, const int* multiIdx,
-                                                          const int* multiSlots, PushWait pw) {
+                                                          const int* multiSlots, PushWait pw, int ownFold) {
     pushWait(pw);
     if ((int)blockIdx.x >= nBlocksTwo) {
-        combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA);
+        combineMulti((int)blockIdx.x - nBlocksTwo, nMulti, multiIdx, multiSlots, ownA, recvA, combA, ownFold);
         return;
     }
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1345,7 +1358,7 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
         const bool selfFirst = s0 < 0;
         V3 sum, a1, a2, a3;
         int cnt, any2;
-        combineTwoSharers(ra, rb, selfFirst, sum, a1, a2, a3, cnt, any2);
+        combineTwoSharers(ra, rb, selfFirst, ownFold, sum, a1, a2, a3, cnt, any2);
         double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
         o[3] = a1.x; o[4] = a1.y; o[5] = a1.z;
@@ -1371,9 +1384,10 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
         hc[j] = (int)(pk >> 32);
     }
     auto fold = [&](const V3* v, int me) {
-        V3 x = v[me];
+        const int lead = ownFold ? me : 0;         // whose value starts the fold: the own one, or the master's (lowest rank)
+        V3 x = v[lead];
         for (int k = 0; k < n; ++k) {
-            if (k == me) continue;
+            if (k == lead) continue;
             x = (magSqr(x) <= magSqr(v[k])) ? x : v[k];
         }
         return x;
@@ -1410,7 +1424,7 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int
 // multiSlots: 16 entries per listed point -- the recv slot of sharer j, -1 = this rank, -2 = no such sharer (one coalesced
 // load instead of the multiIdx -> combOff -> combSlots chain: this part is a handful of workgroups and latency bound)
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
-                                             const double* ownA, const double* recvA, double* combA) {
+                                             const double* ownA, const double* recvA, double* combA, int ownFold) {
     // 16 lanes per point, lane j = sharer j (ascending rank); the sharers' values travel by shuffles within the group -- no
     // LDS, no workgroup barriers (the LDS form spent most of the launch in its ten barriers)
     const int t = threadIdx.x, g = (blk * kBlock + t) >> 4, j = t & 15, base = t & 48;      // base: the group's first lane in the wave
@@ -1435,14 +1449,16 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
     V3 sum = v3(0, 0, 0);
     int cnt = 0;
     for (int k = 0; k < n; ++k) { sum = sum + SMGPU_FROM(sv0, k); cnt += __shfl(cntJ, base + k, 64); }
-    // minMagSqrEqOp folded from the own value over the others in ascending rank order
+    // minMagSqrEqOp folded from the master's value (lane 0 of the group: the lowest rank) over the others in ascending rank
+    // order, the same result on every lane -- or, ownFold, from the lane's own value
+    const int lead = ownFold ? j : 0;
 #define SMGPU_FOLD_ALL(SENT, OUT)                                                          \
     {                                                                                      \
         const V3 sent_ = (SENT);                                                           \
-        V3 x_ = sent_;                                                                     \
+        V3 x_ = ownFold ? sent_ : SMGPU_FROM(sent_, 0);                                    \
         for (int k = 0; k < n; ++k) {                                                      \
             const V3 y_ = SMGPU_FROM(sent_, k);                                            \
-            if (k != j) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;                         \
+            if (k != lead) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;                      \
         }                                                                                  \
         (OUT) = x_;                                                                        \
     }

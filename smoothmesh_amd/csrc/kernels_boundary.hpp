@@ -130,9 +130,9 @@ __global__ void __launch_bounds__(kBlock) k_halo_combineAL(int nShared, const in
                                                            double* combL, const int* sharedLocal, PushWait pw) {
     pushWait(pw);
     const int bx = (int)blockIdx.x;
-    if (bx < nA) { haloCombineA2Of(bx, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots); return; }
+    if (bx < nA) { haloCombineA2Of(bx, nShared, peer, ownA, recvA, combA, nBlocksTwo, nMulti, multiIdx, multiSlots, s.ownFold); return; }
     const int i = (bx - nA) * kBlock + (int)threadIdx.x;
-    haloCombineLOf(i, nShared, combOff, combSlots, ownL, recvL, combL, s.lStride);
+    haloCombineLOf(i, nShared, combOff, combSlots, ownL, recvL, combL, s.lStride, s.ownFold);
     if (bndOn) bndNormalsSharedOf(s, b, nShared, sharedLocal, i);     // reads the record this thread has just written
 }
 

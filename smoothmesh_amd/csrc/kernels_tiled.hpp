@@ -652,7 +652,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             if (s.inlineCombine && s.combOff[slot + 1] - cb == 2) {
                 const int s0 = s.combSlots[cb], s1 = s.combSlots[cb + 1];
                 combineTwoSharers(s.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES, s.recvA + (size_t)(s0 < 0 ? s1 : s0) * SMGPU_HALO_A_DOUBLES,
-                                  s0 < 0, sum, r1, r2, r3, count, hc);
+                                  s0 < 0, s.ownFold, sum, r1, r2, r3, count, hc);
             } else {
                 const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
                 sum = v3(r[0], r[1], r[2]);

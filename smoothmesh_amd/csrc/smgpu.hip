@@ -482,6 +482,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
+    { const char* sv = std::getenv("SMGPU_SYNC_VARIANT"); h->st.ownFold = (sv && std::string(sv) == "own") ? 1 : 0; }
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
@@ -829,6 +830,13 @@ int smgpu_set_foam_variant(smgpu_handle* h, int32_t variant) {
     if (variant != SMGPU_FOAM_COM && variant != SMGPU_FOAM_ORG) return fail("smgpu_set_foam_variant: unknown variant");
     h->foamOrg = variant == SMGPU_FOAM_ORG;
     h->geomAheadDone = false;
+    return 0;
+}
+
+int smgpu_set_sync_variant(smgpu_handle* h, int32_t variant) {
+    if (!h) return fail("null handle");
+    if (variant != SMGPU_SYNC_MASTER && variant != SMGPU_SYNC_OWN) return fail("smgpu_set_sync_variant: unknown variant");
+    h->st.ownFold = variant == SMGPU_SYNC_OWN ? 1 : 0;
     return 0;
 }
 
@@ -1965,14 +1973,14 @@ int smgpu_iter_mid(smgpu_handle* h) {
                 }
                 if (nTwo + nMultiBlocks > 0 && h->dMultiIdx && h->dPeer)
                     hipLaunchKernelGGL(k_halo_combineA2, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dPeer, h->dOwnA, h->recvA, h->dCombA,
-                                       nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots, pushWaitOf(h, 0));
+                                       nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots, pushWaitOf(h, 0), h->st.ownFold);
                 else if (nTwo + nMultiBlocks > 0)
                     hipLaunchKernelGGL(k_halo_combineA, dim3(nTwo + nMultiBlocks), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff, h->dCombSlots,
                                        h->dOwnA, h->recvA, h->dCombA, &h->st.acc->err, h->dMultiIdx ? 1 : 0, nTwo, h->nMulti, h->dMultiIdx, h->dMultiSlots,
-                                       pushWaitOf(h, 0));
+                                       pushWaitOf(h, 0), h->st.ownFold);
                 if (withL)
                     hipLaunchKernelGGL(k_halo_combineL, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dCombOff,
-                                       h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride);
+                                       h->dCombSlots, h->dOwnL, h->recvL, h->dCombL, h->st.lStride, h->st.ownFold);
                 if (h->bndOn)   // OBB.C:201-230 for the shared boundary points, on the sums
                     hipLaunchKernelGGL(k_bnd_normals_shared, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->st, h->bv, h->nShared, h->dSharedLocal);
             })) return 1;

@@ -130,3 +130,75 @@ def shared_point_table(subs: List[SubDomain]):
     idx = np.concatenate([np.arange(f, f + c) for f, c in zip(first[keep], cnt[keep])]) if keep.any() else np.zeros(0, np.int64)
     off = np.zeros(keep.sum() + 1, np.int32); np.cumsum(cnt[keep], out=off[1:])
     return off, d[idx], l[idx]
+
+
+def bfs_partition(mesh: PolyMesh, nRanks: int, seed: int = 0, island: bool = False) -> np.ndarray:
+    """Irregular partition, standing in for decomposePar's scotch method (testcase/system/decomposeParDict:9-11), which
+    is not available here: nRanks regions grown breadth-first over the cell-cell graph from random seed cells.  The
+    interfaces are ragged (no planes), sub-domain sizes differ, points are shared by 2..6 ranks off any lattice pattern.
+    island=True additionally hands a small blob of cells deep inside another region to rank 0, so that one sub-domain
+    is DISCONNECTED (scotch does produce those) and one rank sits inside another."""
+    rng = np.random.default_rng(seed)
+    C, nIF = mesh.nCells, mesh.nInternalFaces
+    own, nei = mesh.owner[:nIF].astype(np.int64), mesh.neighbour.astype(np.int64)
+    rank = np.full(C, -1, np.int32)
+    seeds = rng.choice(C, size=nRanks, replace=False)
+    rank[seeds] = np.arange(nRanks, dtype=np.int32)
+    order = rng.permutation(nIF)                      # which neighbour claims a cell when several could: random, reproducible
+    o, n = own[order], nei[order]
+    while (rank < 0).any():
+        before = int((rank < 0).sum())
+        ro, rn = rank[o], rank[n]
+        a = (ro >= 0) & (rn < 0)
+        b = (rn >= 0) & (ro < 0)
+        rank[n[a]] = ro[a]
+        rank[o[b]] = rn[b]
+        if int((rank < 0).sum()) == before:           # a mesh of several components: seed the next one
+            left = np.flatnonzero(rank < 0)
+            rank[left[0]] = int(rng.integers(nRanks))
+    if island and nRanks > 1:
+        # cells all of whose face neighbours are of the same (non-zero) rank: deep inside it; take one and its neighbours
+        same = np.ones(C, bool)
+        np.logical_and.at(same, own, rank[own] == rank[nei])
+        np.logical_and.at(same, nei, rank[own] == rank[nei])
+        cand = np.flatnonzero(same & (rank != 0))
+        if len(cand):
+            c = int(cand[rng.integers(len(cand))])
+            blob = np.concatenate([[c], nei[own == c], own[nei == c]])
+            rank[blob] = 0
+    return rank
+
+
+def random_partition(mesh: PolyMesh, nRanks: int, seed: int = 0) -> np.ndarray:
+    """every cell to a random rank: the worst case for the shared-point tables (nearly every point is shared, by up to
+    eight ranks; sub-domains are clouds of cells touching in faces, edges and single points)"""
+    rng = np.random.default_rng(seed)
+    r = rng.integers(nRanks, size=mesh.nCells).astype(np.int32)
+    r[rng.choice(mesh.nCells, size=nRanks, replace=False)] = np.arange(nRanks, dtype=np.int32)   # no empty rank
+    return r
+
+
+def merge_disjoint(a: PolyMesh, b: PolyMesh, offset=(0.0, 0.0, 0.0), suffix="_b") -> PolyMesh:
+    """two meshes that do not touch as ONE polyMesh (b's points moved by offset, its patches renamed): a rank that holds all of b
+    then has no shared point at all"""
+    nIa, nIb = a.nInternalFaces, b.nInternalFaces
+    Pa, Ca = a.nPoints, a.nCells
+
+    def faces(m, lo, hi, shift):
+        off = m.faceOffsets.astype(np.int64)
+        return np.diff(off[lo:hi + 1]), m.facePoints[off[lo]:off[hi]].astype(np.int64) + shift
+
+    parts = [faces(a, 0, nIa, 0), faces(b, 0, nIb, Pa), faces(a, nIa, a.nFaces, 0), faces(b, nIb, b.nFaces, Pa)]
+    sizes = np.concatenate([p[0] for p in parts])
+    off = np.zeros(len(sizes) + 1, np.int64); np.cumsum(sizes, out=off[1:])
+    owner = np.concatenate([a.owner[:nIa], b.owner[:nIb] + Ca, a.owner[nIa:], b.owner[nIb:] + Ca])
+    neighbour = np.concatenate([a.neighbour, b.neighbour + Ca])
+    patches = []
+    for p in a.patches:
+        patches.append(Patch(p.name, p.type, p.nFaces, p.startFace + nIb))
+    nBa = a.nFaces - nIa
+    for p in b.patches:
+        patches.append(Patch(p.name + suffix, p.type, p.nFaces, p.startFace - nIb + nIa + nIb + nBa))
+    pts = np.concatenate([a.points.reshape(-1, 3), b.points.reshape(-1, 3) + np.asarray(offset, np.float64)])
+    return PolyMesh(points=pts, faceOffsets=off.astype(np.int32), facePoints=np.concatenate([p[1] for p in parts]).astype(np.int32),
+                    owner=owner.astype(np.int32), neighbour=neighbour.astype(np.int32), patches=patches, nCells=Ca + b.nCells)

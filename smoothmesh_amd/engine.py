@@ -197,6 +197,11 @@ class SmoothEngine:
         cell centres follow (the reference builds against either, Allwmake:47)"""
         self._check(self._lib.smgpu_set_foam_variant(self._h, {"com": 0, "org": 1}[variant]))
 
+    def set_sync_variant(self, variant):
+        """"master" (default: globalMeshData::syncData -- the master's fold handed to every sharer) or "own" (every sharer folds the
+        others' values onto its own): the syncTools::syncPointList model of the multi-rank magnitude folds (include/smgpu.h)"""
+        self._check(self._lib.smgpu_set_sync_variant(self._h, {"master": 0, "own": 1}[variant]))
+
     # -- the loop ------------------------------------------------------------------------------
     def _layer_desc(self, lp: LayerParams, minEdgeLength: float):
         start, size, kind, sel = patch_arrays(self.mesh, lp.layerPatches)

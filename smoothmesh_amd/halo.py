@@ -71,11 +71,20 @@ class HaloTables:
         self.combSlots = np.array([s for p in per for s in p], dtype=np.int32) if nsh else np.zeros(0, np.int32)
 
 
-def combine_shared(tables, own, recv, op):
+def own_fold_default():
+    """the syncTools::syncPointList model (include/smgpu.h smgpu_set_sync_variant): False = the master's fold handed to every
+    sharer (default), True = every sharer folds onto its own value (SMGPU_SYNC_VARIANT=own, the engine reads the same variable)"""
+    return os.environ.get("SMGPU_SYNC_VARIANT", "") == "own"
+
+
+def combine_shared(tables, own, recv, op, own_fold=None):
     """syncTools::syncPointList for the shared points of one rank, on the host (set-up only).  own: (nShared, k) this
     rank's values, recv: (nRecv, k) the other sharers' values in recv-slot order.  op: "max" (maxEqOp), "sum" (plusEqOp,
-    ascending rank order), "maxmag" (maxMagSqrEqOp: fold the others onto the own value in ascending rank order, the
-    larger magnitude wins, ties keep)."""
+    ascending rank order), "maxmag" (maxMagSqrEqOp: globalMeshData::syncData folds the sharers' values once, starting from
+    the lowest rank's, in ascending rank order -- the larger magnitude wins, a tie keeps the lower rank's -- and every
+    sharer receives that value; own_fold: every sharer folds the others onto its own value instead)."""
+    if own_fold is None:
+        own_fold = own_fold_default()
     out = own.copy()
     off, slots = tables.combOffsets, tables.combSlots
     for i in range(len(own)):
@@ -90,10 +99,10 @@ def combine_shared(tables, own, recv, op):
                 acc = acc + (own[i] if s < 0 else recv[s])
             out[i] = acc
         elif op == "maxmag":
-            x = own[i]
-            for s in sl:
-                if s >= 0:
-                    y = recv[s]
+            x = own[i] if (own_fold or sl[0] < 0) else recv[sl[0]]
+            for s in (sl if own_fold else sl[1:]):
+                if s >= 0 or not own_fold:
+                    y = own[i] if s < 0 else recv[s]
                     # magSqr left to right in plain IEEE doubles (no BLAS / FMA), as the reference evaluates it
                     mx = float(x[0]) * float(x[0]) + float(x[1]) * float(x[1]) + float(x[2]) * float(x[2])
                     my = float(y[0]) * float(y[0]) + float(y[1]) * float(y[1]) + float(y[2]) * float(y[2])
@@ -265,6 +274,7 @@ class DistributedSmoother:
         self.xstream = None
         self.layers = False
         self.boundary = False
+        self.own_fold = own_fold_default()
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         assert sub.rank == self.rank and sub.nRanks == self.world
         if torch_device is None:
@@ -407,6 +417,12 @@ class DistributedSmoother:
     def set_params(self, p):
         self.engine.set_params(p)
 
+    def set_sync_variant(self, variant):
+        """"master" (default) / "own": the syncTools::syncPointList model of the magnitude folds, in the engine's combines and in
+        the host-side combines of the set-ups (include/smgpu.h smgpu_set_sync_variant)"""
+        self.own_fold = {"master": False, "own": True}[variant]
+        self.engine.set_sync_variant(variant)
+
     def set_layers(self, lp, minEdgeLength):
         """boundary layer treatment (-layerPatches under mpirun): step-wise set-up, the reference's syncPointList calls
         done with the same all_to_all as the per-iteration exchanges (values travel as doubles; set-up only)"""
@@ -425,7 +441,7 @@ class DistributedSmoother:
                     r = recv.to(self.device)
                     self.dist.all_to_all_single(r, send.to(self.device), self.counts, self.counts)
                     recv = r.cpu()
-            return [combine_shared(t, o, recv.numpy(), op)]
+            return [combine_shared(t, o, recv.numpy(), op, self.own_fold)]
         self.layers = setup_layers_stepwise([self.engine], exchange, lp, minEdgeLength)
         return self.layers
 
@@ -448,7 +464,7 @@ class DistributedSmoother:
                     r = recv.to(self.device)
                     self.dist.all_to_all_single(r, send.to(self.device), self.counts, self.counts)
                     recv = r.cpu()
-            return [combine_shared(t, o, recv.numpy(), op)]
+            return [combine_shared(t, o, recv.numpy(), op, self.own_fold)]
 
         def reduce_stats(stats):
             mn, bb = stats[0]
@@ -483,16 +499,19 @@ class DistributedSmoother:
             n = self.probe_slots
             recv, send = self._probe[recv.dtype]
             counts = [n]
-        elif self.world == 1 or (n == 0 and self.tables.nRecv == 0):
+        elif self.world == 1:
             n = 0
-        if n and self._staged():
+        # a rank without shared points (a sub-domain that touches no other: n == 0) still takes part in a COLLECTIVE -- the other
+        # ranks' all_to_all_single would wait for it for ever; the send / recv groups are pairwise, there it has nothing to do
+        collective = self.world > 1 and self.direct is None
+        if (n or collective) and self._staged():
             r = self.torch.empty_like(recv[:n], device="cpu")
             self.dist.all_to_all_single(r, send[:n].cpu(), counts, counts)
             recv[:n].copy_(r)
         elif n and self.direct is not None:
             self.direct.exchange(recv.data_ptr(), send.data_ptr(), counts, (recv.numel() // recv.shape[0]) * recv.element_size(),
                                  self.torch.cuda.current_stream(self.device).cuda_stream)
-        elif n:
+        elif n or collective:
             self.dist.all_to_all_single(recv[:n], send[:n], counts, counts)
         if overlap:
             overlap()
@@ -637,6 +656,7 @@ class LocalMultiSmoother:
         import torch
         self.torch = torch
         self.subs = subs
+        self.own_fold = own_fold_default()
         if torch_device is None:
             torch_device = torch.device("cuda", device)
         self.device = torch_device
@@ -671,6 +691,12 @@ class LocalMultiSmoother:
         for st in self.states:
             st.eng.set_params(p)
 
+    def set_sync_variant(self, variant):
+        """"master" (default) / "own": see DistributedSmoother.set_sync_variant"""
+        self.own_fold = {"master": False, "own": True}[variant]
+        for st in self.states:
+            st.eng.set_sync_variant(variant)
+
     def _exchange(self, which):
         for a, so, b, do, c in self.copies:
             src = getattr(self.states[a], "send" + which)
@@ -687,7 +713,7 @@ class LocalMultiSmoother:
             recv = [np.zeros((st.t.nRecv, own[0].shape[1])) for st in self.states]
             for a, so, b, do, c in self.copies:
                 recv[b][do:do + c] = own[a][self.states[a].t.sendShared[so:so + c]]
-            return [combine_shared(st.t, o, r, op) for st, o, r in zip(self.states, own, recv)]
+            return [combine_shared(st.t, o, r, op, self.own_fold) for st, o, r in zip(self.states, own, recv)]
         self.layers = setup_layers_stepwise([st.eng for st in self.states], exchange, lp, minEdgeLength)
         return self.layers
 
@@ -698,7 +724,7 @@ class LocalMultiSmoother:
             recv = [np.zeros((st.t.nRecv, own[0].shape[1])) for st in self.states]
             for a, so, b, do, c in self.copies:
                 recv[b][do:do + c] = own[a][self.states[a].t.sendShared[so:so + c]]
-            return [combine_shared(st.t, o, r, op) for st, o, r in zip(self.states, own, recv)]
+            return [combine_shared(st.t, o, r, op, self.own_fold) for st, o, r in zip(self.states, own, recv)]
         def reduce_stats(stats):
             bb = np.array([s[1] for s in stats])
             return min(s[0] for s in stats), np.array([bb[:, 0].min(), bb[:, 1].max(), bb[:, 2].min(), bb[:, 3].max(), bb[:, 4].min(), bb[:, 5].max()])

@@ -18,6 +18,16 @@ def test_random_cases(seed):
     assert r.stdout.count(" ok ") == 10
 
 
+@pytest.mark.parametrize("kinds,seed", [("irregular", 51), ("tied", 52), ("irregular,tied", 53)])
+def test_random_irregular_and_tied_cases(kinds, seed):
+    """the sweep restricted to irregular decompositions (breadth-first grown / random cellRank maps, 2..8 ranks, disconnected
+    pieces, hex and polyhedral) and to unjittered / exactly graded blocks on binary fractions (exact ties in the closest-point syncs)"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "10", str(seed)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, FUZZ_KINDS=kinds))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok ") == 10
+
+
 @pytest.mark.parametrize("env", [{"SMGPU_WALK": "fix"}, {"SMGPU_WALK": "fix", "SMGPU_WALK_STAR": "0", "SMGPU_WALK_BLOCKS": "7"},
                                  {"SMGPU_WALK": "host"}, {"SMGPU_FA_LISTS": "0", "SMGPU_FILTER": "0"}, {"SMGPU_WALK": "fix", "SMGPU_FA_SIDE_EXACT": "0"}])
 def test_random_cases_under_walk_knobs(env):

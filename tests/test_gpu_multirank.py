@@ -225,3 +225,97 @@ def test_distributed_smoother_polyhedral_over_rccl(world):
                        capture_output=True, text=True, env=env, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(": ok ") == 4 * world and "BAD" not in r.stdout
+
+
+def _graded_case(oracle_lib, grid, variant, constraints=False):
+    """the exactly graded block of tests/test_sync_tie_rule.py (dx = dy / 2, plane points moved by binary fractions: every
+    comparison of the +-x neighbours of a processor-plane point is an exact tie) cut into `grid` boxes"""
+    from test_sync_tie_rule import graded_block
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import decompose, grid_partition, shared_point_table
+    mesh = graded_block(32, 16, 16)
+    world = grid[0] * grid[1] * grid[2]
+    subs = decompose(mesh, grid_partition(mesh, grid), world)
+    ser = oracle_lib.Oracle(mesh)
+    prm = default_params(ser.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ser.set_params(prm)
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_lib.MultiOracle(orcs, *shared_point_table(subs))
+    mo.set_sync_variant(variant)
+    return mesh, subs, ser, orcs, mo, prm
+
+
+@pytest.mark.parametrize("grid,overlap,inline", [((2, 1, 1), 0, 0), ((2, 2, 2), 0, 0), ((2, 2, 2), 1, 0), ((2, 1, 1), 0, 1), ((2, 2, 1), 0, 1)])
+def test_tie_rule_master_fold_equals_serial_on_a_graded_block(oracle_lib, monkeypatch, grid, overlap, inline):
+    """SM.C:388-478 with syncTools::syncPointList's master fold (smgpu_set_sync_variant, default): on a mesh where the two
+    closest neighbours of every processor-plane point are at bit-equal distance the decomposed run equals the SERIAL oracle at
+    every point (<= 1e-13: the cell-centre sums are formed per rank), equals the oracle's MultiDomain bit for bit, and the
+    copies of a shared point stay identical.  Two-sharer kernel (k_halo_combineA2), 16-lane multi-sharer form (2x2x2: edge and
+    centre points with 4 / 8 sharers) and the smoothing kernel's inline combine."""
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    if inline:
+        monkeypatch.setenv("SMGPU_HALO_INLINE", "1")
+    mesh, subs, ser, orcs, mo, prm = _graded_case(oracle_lib, grid, "master")
+    ms = LocalMultiSmoother(subs, device=0, overlap=bool(overlap))
+    ms.set_params(prm)
+    iters = 3
+    ser.iterate(iters, 0.0)
+    mo.iterate(iters, 0.0)
+    ms.iterate(iters, 0.0)
+    sp = ser.points().reshape(-1, 3)
+    for s, o, pts in zip(subs, orcs, ms.get_points()):
+        assert np.array_equal(pts, o.points())                                        # the oracle's MultiDomain, bit for bit
+        assert np.max(np.abs(pts.reshape(-1, 3) - sp[s.pointProcAddressing])) <= 1e-13     # ... and the serial run
+    g = np.concatenate([s.pointProcAddressing for s in subs])
+    allp = np.concatenate([p.reshape(-1, 3) for p in ms.get_points()])
+    order = np.argsort(g, kind="stable")
+    same = g[order][1:] == g[order][:-1]
+    assert same.any() and np.array_equal(allp[order][1:][same], allp[order][:-1][same])
+
+
+@pytest.mark.parametrize("grid", [(2, 1, 1), (2, 2, 2)])
+def test_tie_rule_own_fold_switch_matches_its_oracle_and_not_the_serial_run(oracle_lib, grid):
+    """the A/B switch (SMGPU_SYNC_OWN): every sharer folds onto its own value, as rounds 1-3 did -- equal to the oracle's
+    MultiDomain with the same switch, and visibly NOT the serial result on the processor plane"""
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    mesh, subs, ser, orcs, mo, prm = _graded_case(oracle_lib, grid, "own")
+    ms = LocalMultiSmoother(subs, device=0, overlap=False)
+    ms.set_sync_variant("own")
+    ms.set_params(prm)
+    ser.iterate(1, 0.0); mo.iterate(1, 0.0); ms.iterate(1, 0.0)
+    sp = ser.points().reshape(-1, 3)
+    worst = 0.0
+    for s, o, pts in zip(subs, orcs, ms.get_points()):
+        assert np.array_equal(pts, o.points())
+        worst = max(worst, float(np.max(np.abs(pts.reshape(-1, 3) - sp[s.pointProcAddressing]))))
+    assert 1e-5 < worst < prm.maxStepLength
+
+
+def test_tie_rule_with_layers_on_an_unjittered_block(oracle_lib):
+    """the magnitude folds of the layer treatment (maxMagSqr of the propagated normals OBB.C:359-365 in the host-side set-up,
+    minMagSqr of the outer neighbour coordinates OBB.C:490-496 in k_halo_combineAL) on a block without jitter, where the
+    candidates tie exactly: GPU = the oracle's MultiDomain, bit for bit, copies identical"""
+    from smoothmesh_amd import LayerParams, default_params, patch_arrays
+    from smoothmesh_amd.decompose import decompose, grid_partition, shared_point_table
+    from smoothmesh_amd.halo import LocalMultiSmoother
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(12, 12, 12, jitter=0.0)
+    pts = mesh.points.reshape(-1, 3)
+    pts[6 + 13 * 6 + 169 * 6] += np.array([1 / 64, 1 / 128, 0.0])
+    pts[6 + 13 * 3 + 169 * 2] += np.array([0.0, 1 / 64, 1 / 64])
+    subs = decompose(mesh, grid_partition(mesh, (2, 2, 2)), 8)
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=False, faceAngleConstraint=False)
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_lib.MultiOracle(orcs, *shared_point_table(subs))
+    patches = ("xmin", "ymax", "zmin")
+    assert mo.setup_layers([patch_arrays(s.mesh, patches) for s in subs], 0.3, prm.minEdgeLength, 1.2, 1, 4)
+    ms = LocalMultiSmoother(subs, device=0, overlap=False)
+    ms.set_params(prm)
+    assert ms.set_layers(LayerParams(layerPatches=patches, layerExpansionRatio=1.2), prm.minEdgeLength)
+    mo.iterate(4, 0.0); ms.iterate(4, 0.0)
+    for o, p in zip(orcs, ms.get_points()):
+        assert np.array_equal(p, o.points())

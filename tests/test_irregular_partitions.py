@@ -1,0 +1,187 @@
+"""Irregular decompositions (the reference's tests decompose with scotch into 3 sub-domains,
+testcase/system/decomposeParDict:9-11, run_parallel:19): ragged interfaces, a disconnected sub-domain, a rank inside
+another, a rank without any shared point, points shared by 3..8 ranks off the lattice pattern.  CPU part: the partitioners,
+the oracle's MultiDomain against the serial oracle, and the product's host logic (HaloTables / DistributedSmoother over gloo,
+oracle rank engine) against MultiDomain.  The GPU part lives in tests/test_gpu_irregular.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_case(kind, nRanks, seed):
+    """(global mesh, cellRank) of the named irregular case -- deterministic, so that every process of a multi-process test
+    builds the same one"""
+    from smoothmesh_amd.decompose import bfs_partition, merge_disjoint, random_partition
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import cavity_mesh
+    if kind == "hex_bfs":
+        mesh = hex_block(9, 8, 7, jitter=0.3, seed=seed)
+        return mesh, bfs_partition(mesh, nRanks, seed=seed)
+    if kind == "hex_island":                       # rank 0 = its own region + a blob deep inside another rank's
+        mesh = hex_block(10, 9, 8, jitter=0.25, seed=seed)
+        return mesh, bfs_partition(mesh, nRanks, seed=seed, island=True)
+    if kind == "hex_random":                       # clouds of cells: nearly every point shared, by up to 8 ranks
+        mesh = hex_block(6, 6, 5, jitter=0.3, seed=seed)
+        cr = random_partition(mesh, nRanks, seed=seed)
+        if nRanks >= 8:                            # the eight cells around one vertex to eight different ranks
+            for q, (di, dj, dk) in enumerate((a, b, c) for c in (0, 1) for b in (0, 1) for a in (0, 1)):
+                cr[(2 + di) + 6 * (2 + dj) + 36 * (1 + dk)] = q
+        return mesh, cr
+    if kind == "poly_bfs":                         # castellated polyhedral cavity mesh (hanging-node faces on ragged interfaces)
+        mesh = cavity_mesh(10, jitter=0.2, seed=seed)
+        return mesh, bfs_partition(mesh, nRanks, seed=seed, island=True)
+    if kind == "poly_random":
+        mesh = cavity_mesh(8, jitter=0.2, seed=seed)
+        return mesh, random_partition(mesh, nRanks, seed=seed)
+    if kind == "two_blocks":                       # the last rank holds a block of its own: no shared point at all
+        a = hex_block(7, 6, 6, jitter=0.3, seed=seed)
+        b = hex_block(4, 4, 3, jitter=0.3, seed=seed + 1)
+        mesh = merge_disjoint(a, b, offset=(2.0, 0.0, 0.0))
+        r = np.concatenate([bfs_partition(a, nRanks - 1, seed=seed), np.full(b.nCells, nRanks - 1, np.int32)])
+        return mesh, r
+    raise ValueError(kind)
+
+
+CASES = [("hex_bfs", 3, 11), ("hex_island", 5, 12), ("hex_random", 8, 13), ("poly_bfs", 3, 14), ("poly_random", 5, 15), ("two_blocks", 3, 16)]
+
+
+def _n_components(mesh, cells):
+    """connected components of the face-neighbour graph restricted to `cells`"""
+    inset = np.zeros(mesh.nCells, bool); inset[cells] = True
+    nIF = mesh.nInternalFaces
+    o, n = mesh.owner[:nIF], mesh.neighbour
+    keep = inset[o] & inset[n]
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    g = coo_matrix((np.ones(keep.sum()), (o[keep], n[keep])), shape=(mesh.nCells, mesh.nCells))
+    ncomp, lab = connected_components(g, directed=False)
+    return len(np.unique(lab[cells]))
+
+
+def test_the_cases_are_what_they_claim():
+    from smoothmesh_amd.decompose import decompose, shared_point_table
+    seen_sharers = set()
+    for kind, nR, seed in CASES:
+        mesh, cr = build_case(kind, nR, seed)
+        assert sorted(np.unique(cr).tolist()) == list(range(nR))
+        subs = decompose(mesh, cr, nR)
+        off, dom, loc = shared_point_table(subs)
+        nsh = np.diff(off)
+        seen_sharers |= set(nsh.tolist())
+        assert nsh.max() <= 16                                    # the engine's limit (kMaxSharers)
+        # every point held by two ranks lies on a processor patch of both (the tables are built from those, as globalMeshData does)
+        for s in subs:
+            pp = set(s.processor_patch_points().tolist())
+            mine = s.pointProcAddressing[loc[dom == s.rank]]
+            assert set(mine.tolist()) <= pp
+        if kind == "hex_island":
+            assert _n_components(mesh, np.flatnonzero(cr == 0)) >= 2          # a disconnected sub-domain
+        if kind == "two_blocks":
+            assert not (dom == nR - 1).any() and len(subs[nR - 1].processor_patch_points()) == 0
+            assert not [p for p in subs[nR - 1].mesh.patches if p.type == "processor"]
+        if kind == "hex_bfs":
+            # ragged: the interface points do not lie in a plane
+            g = np.unique(np.concatenate([s.pointProcAddressing[loc[dom == s.rank]] for s in subs]))
+            x = mesh.points.reshape(-1, 3)[g]
+            assert min(np.ptp(np.round(x[:, a], 1)) for a in range(3)) > 0.3
+    assert {3, 4, 5, 6, 7} <= seen_sharers                         # 3..7 sharers, and 8 in the random hex case
+    assert 8 in seen_sharers
+
+
+def _oracles(oracle_lib, mesh, cr, nR, constraints):
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import decompose, shared_point_table
+    subs = decompose(mesh, cr, nR)
+    ser = oracle_lib.Oracle(mesh)
+    prm = default_params(ser.mesh_stats()[0], edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ser.set_params(prm)
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    for o in orcs:
+        o.set_params(prm)
+    return subs, ser, orcs, oracle_lib.MultiOracle(orcs, *shared_point_table(subs)), prm
+
+
+@pytest.mark.parametrize("kind,nR,seed", CASES)
+def test_multi_domain_on_irregular_partitions_equals_serial_without_constraints(oracle_lib, kind, nR, seed):
+    """with the constraints off every per-point quantity is combined over the ranks (sums, closest points, hasCommonCell, frozen
+    flags), so ANY decomposition reproduces the serial iteration up to the order of the cell-centre sums, and the copies of a
+    point stay identical -- EXCEPT where the reference itself depends on the decomposition: findInternalMeshPoints (SM.C:40-91)
+    is rank-local and never synchronised, so a point of the physical boundary held by a rank none of whose boundary faces
+    contains it (a cell touching the wall in an edge or a point only: the stair-stepped cavity wall under a ragged cut) is an
+    INTERNAL point on that rank -- it contributes cell centres (SM.C:116) and is not restored (SM.C:2387) there, while the other
+    sharers keep it fixed.  Those points are set aside here (one iteration: their neighbours feel them from the second on); the
+    oracle and the engine reproduce them as the reference would (GPU tests compare with MultiDomain, bit for bit)."""
+    mesh, cr = build_case(kind, nR, seed)
+    subs, ser, orcs, mo, prm = _oracles(oracle_lib, mesh, cr, nR, False)
+    n_s, res_s, frz_s = ser.iterate(1, 0.0)
+    n_m, res_m, frz_m = mo.iterate(1, 0.0)
+    assert n_s == n_m          # (nFrozenPoints counts a fixed boundary point once per rank that holds it, SM.C:2387-2396: not compared)
+    gInt = mesh.find_internal_points().astype(bool)
+    rogue = np.zeros(mesh.nPoints, bool)
+    for s in subs:
+        rogue[s.pointProcAddressing] |= s.mesh.find_internal_points().astype(bool) != gInt[s.pointProcAddressing]
+    assert rogue.any() == (kind in ("poly_bfs", "poly_random"))       # only the castellated wall produces them
+    sp = ser.points().reshape(-1, 3)
+    seen = np.full_like(sp, np.nan)
+    for s, o in zip(subs, orcs):
+        p = o.points().reshape(-1, 3)
+        g = s.pointProcAddressing
+        ok = ~rogue[g]
+        assert np.max(np.abs(p - sp[g])[ok]) <= 1e-13
+        had = ~np.isnan(seen[g, 0]) & ok
+        assert np.array_equal(seen[g][had], p[had])
+        seen[g] = p
+    if not rogue.any():
+        assert np.allclose(res_s, res_m, rtol=1e-9, atol=0)
+        # ... and over several iterations
+        ser.iterate(4, 0.0); mo.iterate(4, 0.0)
+        sp = ser.points().reshape(-1, 3)
+        for s, o in zip(subs, orcs):
+            assert np.max(np.abs(o.points().reshape(-1, 3) - sp[s.pointProcAddressing])) <= 1e-13
+
+
+def _worker(rank, world, port, kind, seed, constraints, iters, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle.oracle_ffi import OracleRankEngine
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import decompose
+    from smoothmesh_amd.halo import DistributedSmoother
+    from test_irregular_partitions import build_case
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mesh, cr = build_case(kind, world, seed)
+    sub = decompose(mesh, cr, world)[rank]
+    ds = DistributedSmoother(sub, engine_factory=OracleRankEngine, torch_device=torch.device("cpu"))
+    prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ds.set_params(prm)
+    n, res, frz = ds.iterate(iters, 0.0)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), n=n, res=res, frz=frz, pts=ds.get_points())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,nR,seed,constraints", [("hex_island", 3, 21, True), ("poly_bfs", 3, 22, True), ("hex_random", 5, 23, False),
+                                                      ("two_blocks", 3, 24, True)])
+def test_distributed_smoother_gloo_on_irregular_partitions(tmp_path, oracle_lib, kind, nR, seed, constraints):
+    """the product's host logic on an irregular cellRank: processor-patch candidates -> HaloTables (send / receive slots, combine
+    table in ascending rank order, ranks without neighbours) -> all_to_all with ragged counts -> stop rule; one process per rank"""
+    import torch.multiprocessing as mp
+    from test_halo_gloo import _free_port
+    iters = 5
+    mp.spawn(_worker, args=(nR, _free_port(), kind, seed, constraints, iters, str(tmp_path)), nprocs=nR, join=True)
+    mesh, cr = build_case(kind, nR, seed)
+    subs, ser, orcs, mo, prm = _oracles(oracle_lib, mesh, cr, nR, constraints)
+    # default_params from the GLOBAL min edge, as the workers reduce it
+    n_e, res_e, frz_e = mo.iterate(iters, 0.0)
+    for r in range(nR):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        assert int(d["n"]) == n_e
+        assert np.array_equal(d["res"], res_e) and np.array_equal(d["frz"], frz_e)
+        assert np.array_equal(d["pts"], orcs[r].points())
