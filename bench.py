@@ -372,6 +372,215 @@ def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
                 phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
 
 
+def make_subdomain(kind, n_side, grid, rank, world):
+    """this rank's sub-domain of the weak-scaling workload: hexN = an N^3 block per rank of the (Px N, Py N, Pz N) block; cavityN =
+    box `rank` of the castellated polyhedral mesh on a round(N world^(1/3))^3 base grid (every rank generates ITS box only)"""
+    if kind == "hex":
+        from smoothmesh_amd.meshgen import hex_subdomain
+        return hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345), None
+    from smoothmesh_amd.polymesh import cavity_subdomain
+    n_global = int(round(n_side * world ** (1.0 / 3.0)))
+    return cavity_subdomain(n_global, grid, rank, jitter=0.2, seed=12345), n_global
+
+
+def small_case_parity(kind, constraints, grid, rank, world, device, iters=6):
+    """parity_check (b) of an N > 1 line: a down-scaled case of the same family on the SAME processor grid, run through the SAME
+    transport in this very job (DistributedSmoother picks it exactly as for the timed workload), against the oracle's MultiDomain
+    (the reference under mpirun with the same decomposition).  Every rank builds the small expected result itself (a few
+    thousand cells) and compares its own sub-domain; the verdict is reduced over the ranks."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle_ffi
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import shared_point_table
+    from smoothmesh_amd.halo import DistributedSmoother
+    n_small = 12 if kind == "hex" else 24
+    if kind == "hex":
+        from smoothmesh_amd.meshgen import hex_subdomain
+        subs = [hex_subdomain((n_small,) * 3, grid, r, jitter=0.2, seed=12345) for r in range(world)]
+        what = f"{n_small}^3-cell hex block per rank"
+    else:
+        from smoothmesh_amd.polymesh import cavity_subdomain
+        subs = [cavity_subdomain(n_small, grid, r, jitter=0.2, seed=12345) for r in range(world)]
+        what = f"castellated polyhedral cavity mesh on a {n_small}^3 base grid"
+    orcs = [oracle_ffi.Oracle(sd.mesh) for sd in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_ffi.MultiOracle(orcs, *shared_point_table(subs))
+    n_o, res_o, frz_o = mo.iterate(iters, 0.0)
+    ds = DistributedSmoother(subs[rank], device=device)
+    ds.set_params(prm)
+    n_g, res_g, frz_g = ds.iterate(iters, 0.0)
+    mine, want = ds.get_points(), orcs[rank].points()
+    info = ds.transport_info()
+    ds.close()
+    for o in orcs:
+        o.close()
+    denom = float(np.max(np.abs(want)))
+    rel = float(np.max(np.abs(mine - want)) / (denom if denom > 0 else 1.0))
+    ok = bool(n_g == n_o and np.array_equal(np.asarray(frz_g), np.asarray(frz_o)) and rel <= 1e-10)
+    rdev = "cpu" if dist.get_backend() == "gloo" else torch.device("cuda", device)
+    t = torch.tensor([1.0 if ok else 0.0, -rel, 1.0 if np.array_equal(mine, want) else 0.0], dtype=torch.float64, device=rdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return {"case": f"{what}, cut {grid[0]}x{grid[1]}x{grid[2]}, {'constraints on' if constraints else 'constraints off'}, {iters} iterations",
+            "against": "oracle MultiDomain (the reference under mpirun, same decomposition), every rank its own sub-domain",
+            "transport": info["transport"], "ok": bool(t[0].item() == 1.0), "rel_linf_max_over_ranks": float(-t[1].item()),
+            "bitwise_equal_on_every_rank": bool(t[2].item() == 1.0), "nFrozenPoints": [int(x) for x in np.asarray(frz_g)[:4]], "tolerance": 1e-10}
+
+
+def shared_copies_check(ds, sub):
+    """parity_check (a) of an N > 1 line: after the timed steps, are the copies of every shared point bit-identical on all the
+    ranks that hold it?  One gather of (global point id, 64-bit hash of the three coordinates, internal-point flag) per shared
+    point to rank 0.  Points on which the sharers disagree about internal / boundary are set aside and counted: findInternalMeshPoints
+    is rank-local in the reference (SM.C:40-91), such a point is restored on one rank and moved on another there too."""
+    import numpy as np
+    dist = ds.dist
+    t = ds.tables
+    loc = np.asarray(t.sharedLocal, np.int64)
+    pts = np.ascontiguousarray(ds.get_points().reshape(-1, 3)[loc])
+    bits = pts.view(np.uint64).reshape(-1, 3)
+    with np.errstate(over="ignore"):
+        h = (bits[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (bits[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + np.uint64(0x165667B19E3779F9)) \
+            ^ ((bits[:, 2] << np.uint64(17)) | (bits[:, 2] >> np.uint64(47)))
+    gid = np.asarray(sub.pointProcAddressing, np.int64)[loc]
+    internal = np.asarray(sub.mesh.find_internal_points(), np.uint8)[loc]
+    box = [None] * ds.world if ds.rank == 0 else None
+    dist.gather_object((gid, h, internal), box, dst=0)
+    if ds.rank != 0:
+        return None
+    g = np.concatenate([b[0] for b in box]); hh = np.concatenate([b[1] for b in box]); ii = np.concatenate([b[2] for b in box])
+    order = np.argsort(g, kind="stable")
+    g, hh, ii = g[order], hh[order], ii[order]
+    first = np.concatenate([[True], g[1:] != g[:-1]]) if len(g) else np.zeros(0, bool)
+    run = np.cumsum(first) - 1
+    nrun = int(run[-1]) + 1 if len(g) else 0
+    hmin = np.full(nrun, np.iinfo(np.uint64).max, np.uint64); hmax = np.zeros(nrun, np.uint64)
+    imin = np.full(nrun, 255, np.uint8); imax = np.zeros(nrun, np.uint8)
+    np.minimum.at(hmin, run, hh); np.maximum.at(hmax, run, hh)
+    np.minimum.at(imin, run, ii); np.maximum.at(imax, run, ii)
+    rogue = imin != imax
+    bad = (hmin != hmax) & ~rogue
+    return {"shared_points": nrun, "copies": int(len(g)), "mismatching_points": int(bad.sum()),
+            "decomposition_dependent_points_set_aside": int(rogue.sum()), "ok": bool(not bad.any()),
+            "what": "after the timed steps: every copy of a shared point carries the same 64-bit coordinate hash on all ranks that hold it"}
+
+
+def rank0_cpu_baseline(sub, prm, budget_s, rank, world):
+    """cpu_baseline of an N > 1 line: rank 0's serial oracle on ITS OWN sub-domain (as a serial mesh: processor-patch points are
+    internal points there, nothing is combined), one core; the job's CPU rate with one core per rank would be ~ world x this"""
+    from oracle import oracle_ffi
+    if rank != 0:
+        return None
+    t0 = time.perf_counter()
+    o = oracle_ffi.Oracle(sub.mesh)
+    setup_s = time.perf_counter() - t0
+    o.set_params(prm)
+    t0 = time.perf_counter()
+    o.iterate(1, 0.0)
+    t1 = time.perf_counter() - t0
+    iters = max(1, min(39, int(budget_s / max(t1, 1e-3))))
+    t0 = time.perf_counter()
+    o.iterate(iters, 0.0)
+    dtc = time.perf_counter() - t0
+    o.close()
+    return {"value": sub.mesh.nPoints * iters / dtc, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} iterations (after one untimed) of RANK 0's sub-domain as a serial mesh ({sub.mesh.nPoints} points, "
+                      f"{sub.mesh.nCells} cells; its processor-patch points are internal points, nothing is exchanged), serial oracle "
+                      f"(g++ -O3 -ffp-contract=off), {dtc:.1f} s; omits OpenFOAM overheads, so it is faster than the real reference; "
+                      f"the reference under mpirun -np {world} with one core per rank would run at about {world} x this",
+            "host_cpus": os.cpu_count(), "oracle_setup_s": setup_s}
+
+
+def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=True, force_dist=False, oracle_budget_s=12.0):
+    """N ranks, one workload: per-rank sub-domain, exchange arrangement autotuned, clock pre-run, W warm-up + K timed steps between
+    barriers (max over ranks), the same K steps with per-kernel hipEvents; outside the timed region: parity_check (a) copies of
+    shared points identical across ranks, (b) a down-scaled case through the same transport against the oracle's MultiDomain;
+    cpu_baseline = rank 0's oracle on its own sub-domain; transport = how the records travelled (communicator size included)"""
+    import torch
+    import torch.distributed as dist
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.halo import DistributedSmoother
+    kind, n_side, constraints = parse_workload(workload)
+    layers, boundary = workload_layers(workload), workload_boundary(workload)
+    grid = proc_grid(world)
+    rdev = "cuda" if backend == "nccl" else "cpu"
+    small = None
+    if oracle and world > 1:
+        try:
+            small = small_case_parity(kind, constraints, grid, rank, world, local_rank)
+        except Exception as ex:   # noqa: BLE001 -- reported in the line, the measurement goes on (on every rank alike)
+            small = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+    t0 = time.perf_counter()
+    sub, n_global = make_subdomain(kind, n_side, grid, rank, world)
+    t_mesh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
+    prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
+    ds.set_params(prm)
+    if layers and not ds.set_layers(layer_params(kind), prm.minEdgeLength):
+        raise SystemExit("boundary layer treatment could not be enabled")
+    if boundary:   # hex: every rank is a unit cube of the global block [0, grid]; cavity: the global unit cube
+        hi = tuple(float(g) for g in grid) if kind == "hex" else (1.0, 1.0, 1.0)
+        if not ds.set_boundary_smoothing(boundary_params(kind, n_side, hi), prm.minEdgeLength)["enabled"]:
+            raise SystemExit("boundary point smoothing could not be enabled")
+    t_create = time.perf_counter() - t0
+    # exchange arrangement (in order on the engine's stream / on a communication stream next to the
+    # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
+    tune = ds.autotune(20) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None
+    if tune is None:
+        ds.set_overlap(os.environ["SMOOTHMESH_OVERLAP"] == "1")
+    pre = clock_warm(lambda k: ds.iterate(k, 0.0), ds.engine, lambda: (torch.cuda.synchronize(), dist.barrier()), fixed=200 if K >= 20 else 5)
+    if W:
+        ds.iterate(W, 0.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n, res, frz = ds.iterate(K, 0.0)
+    torch.cuda.synchronize()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0
+    tt = torch.tensor([dt_local], dtype=torch.float64, device=rdev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    npts = torch.tensor([sub.mesh.nPoints], dtype=torch.float64, device=rdev)
+    dist.all_reduce(npts, op=dist.ReduceOp.SUM)
+    total_points = int(npts.item())      # points of all sub-domains (shared points counted per rank,
+    eng = ds.engine                      # as the reference's per-rank loops process them)
+    copies = shared_copies_check(ds, sub) if world > 1 else None      # parity_check (a): the state the timed steps left
+    eng.reset_counters()
+    eng.enable_timing(True)
+    t0 = time.perf_counter()
+    ds.iterate(K, 0.0)
+    torch.cuda.synchronize()
+    dt_ev = time.perf_counter() - t0
+    eng.enable_timing(False)
+    ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
+    sizes = dict(eng.sizes())
+    info = ds.transport_info()
+    parallelism = (f"domain decomposition {grid[0]}x{grid[1]}x{grid[2]}, "
+                   + {"direct": "RCCL send/recv groups on the engine's stream, ", "push": "peer stores (the pack kernels write the peers' receive slots), ",
+                      "torch": f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, "}[info["transport"]] +
+                   f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
+                   + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
+    ds.close()               # streams drained, second communicator destroyed -- on every rank, before the group goes
+    t0 = time.perf_counter()
+    base = rank0_cpu_baseline(sub, prm, oracle_budget_s, rank, world) if oracle else None
+    t_oracle = time.perf_counter() - t0
+    dist.barrier()           # (the other ranks wait for rank 0's oracle here)
+    par = None
+    if world > 1 and oracle:
+        par = {"shared_point_copies": copies, "small_case": small,
+               "ok": bool((copies or {}).get("ok", rank != 0) and (small or {}).get("ok", False))}
+    return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_ev=dt_ev, ctr=ctr, sizes=sizes,
+                total_points=total_points, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par, transport=info,
+                parallelism=parallelism, n_global=n_global,
+                phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
+
+
 def self_launch(args):
     """--gpus N > 1 without a launcher: start the N ranks ourselves (one process per GPU, torch.distributed.run) BEFORE
     anything in this process touches the GPU, relay rank 0's JSON line and exit with the launcher's code"""
@@ -429,7 +638,8 @@ def main():
     torch.cuda.set_device(local_rank)
     K, W = args.steps, args.warmup
     n_global = None
-    single = None
+    single = multi = None
+    multi_subs = []
 
     # SMOOTHMESH_FORCE_DIST=1: run the N=1 case through the multi-rank code path (host-overhead measurements)
     force_dist = world == 1 and bool(os.environ.get("SMOOTHMESH_FORCE_DIST"))
@@ -444,73 +654,43 @@ def main():
         parallelism = "1 GPU"
     else:
         import torch.distributed as dist
-        from smoothmesh_amd import default_params
-        from smoothmesh_amd.halo import DistributedSmoother
-        from smoothmesh_amd.meshgen import hex_subdomain
         backend = os.environ.get("SMOOTHMESH_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; "gloo" = debug only
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-        grid = proc_grid(world)
-        if kind == "hex":      # weak scaling: every rank generates its own n^3 sub-domain of the global block
-            sub = hex_subdomain((n_side, n_side, n_side), grid, rank, jitter=0.2, seed=12345)
-        else:                  # polyhedral, weak scaling: base grid grown with the rank count, every rank generates ITS box only
-            from smoothmesh_amd.polymesh import cavity_subdomain
-            n_global = int(round(n_side * world ** (1.0 / 3.0)))
-            sub = cavity_subdomain(n_global, grid, rank, jitter=0.2, seed=12345)
-        ds = DistributedSmoother(sub, device=local_rank, probe_slots=60000 if force_dist else 0)
-        prm = default_params(ds.global_min_edge(), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
-        ds.set_params(prm)
-        if layers and not ds.set_layers(layer_params(kind), prm.minEdgeLength):
-            raise SystemExit("boundary layer treatment could not be enabled")
-        if boundary:   # hex: every rank is a unit cube of the global block [0, grid]; cavity: the global unit cube
-            hi = tuple(float(g) for g in grid) if kind == "hex" else (1.0, 1.0, 1.0)
-            if not ds.set_boundary_smoothing(boundary_params(kind, n_side, hi), prm.minEdgeLength)["enabled"]:
-                raise SystemExit("boundary point smoothing could not be enabled")
-        # exchange arrangement (in order on the engine's stream / on a communication stream next to the
-        # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
-        tune = ds.autotune(20) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None
-        if tune is None:
-            ds.set_overlap(os.environ["SMOOTHMESH_OVERLAP"] == "1")
-        pre = clock_warm(lambda k: ds.iterate(k, 0.0), ds.engine, lambda: (torch.cuda.synchronize(), dist.barrier()), fixed=200)
-        if W:
-            ds.iterate(W, 0.0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        n, res, frz = ds.iterate(K, 0.0)
-        torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        dt_local = time.perf_counter() - t0
-        rdev = "cuda" if backend == "nccl" else "cpu"
-        tt = torch.tensor([dt_local], dtype=torch.float64, device=rdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-        npts = torch.tensor([sub.mesh.nPoints], dtype=torch.float64, device=rdev)
-        dist.all_reduce(npts, op=dist.ReduceOp.SUM)
-        total_points = int(npts.item())      # points of all sub-domains (shared points counted per rank,
-        eng = ds.engine                      # as the reference's per-rank loops process them)
-        eng.reset_counters()
-        eng.enable_timing(True)
-        t0 = time.perf_counter()
-        ds.iterate(K, 0.0)
-        torch.cuda.synchronize()
-        dt_ev = time.perf_counter() - t0
-        eng.enable_timing(False)
-        ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
-        sizes = eng.sizes()
-        parallelism = (f"domain decomposition {grid[0]}x{grid[1]}x{grid[2]}, "
-                       + ("RCCL send/recv groups on the engine's stream, " if getattr(ds, "direct", None) is not None else
-                          f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, ") +
-                       f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
-                       + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
+        r = run_distributed(args.workload, K, W, rank, world, local_rank, backend, oracle=not args.no_cpu_baseline, force_dist=force_dist)
+        dt, dt_ev, ctr, sizes, total_points, res, frz = r["dt"], r["dt_ev"], r["ctr"], r["sizes"], r["total_points"], r["res"], r["frz"]
+        pre, parallelism, n_global = r["pre"], r["parallelism"], r["n_global"]
+        multi = r
+        # BASELINE configs[4] beside the weak-scaling headline: the polyhedral mesh, cavity215c per GPU (the 430^3-base, ~80 M-cell
+        # mesh on 8 GPUs), constraints on, BASELINE's 200 iterations -- in the same job, every rank taking part
+        names = [] if (args.no_configs or force_dist) else (args.configs.split(",") if args.configs is not None else
+                                                            (["cavity215c"] if args.workload == "hex100" else []))
+        multi_subs = []
+        for wl in [w for w in names if w]:
+            t0 = time.perf_counter()
+            k_, _, _ = parse_workload(wl)
+            Kc = args.config_steps or (100 if k_ == "hex" else 200)
+            rc = run_distributed(wl, Kc, min(W, 5), rank, world, local_rank, backend, oracle=not (args.no_parity or args.no_cpu_baseline),
+                                 oracle_budget_s=10.0 if k_ == "hex" else 30.0)
+            if rank == 0:
+                sub_ = {
+                    "workload": wl, "config": workload_text(rc["kind"], rc["n_side"], rc["constraints"], rc["layers"], rc["boundary"], world, rc["n_global"]),
+                    "n_gpus": world, "points": int(rc["total_points"]), "points_per_gpu": int(rc["sizes"]["nPoints"]), "cells_per_gpu": int(rc["sizes"]["nCells"]),
+                    "steps": Kc, "ms_per_step": rc["dt"] / Kc * 1e3, "value": rc["total_points"] * Kc / rc["dt"], "unit": "points/s",
+                    "parallelism": rc["parallelism"], "rccl": rc["transport"],
+                    **kernel_report(wl, rc["ctr"], Kc, rc["dt"], rc["dt_ev"]),
+                    "residual_last": float(rc["res"][-1]), "nFrozenPoints_last": int(rc["frz"][-1]), "phases": rc["phases"],
+                }
+                if rc["parity_check"]:
+                    sub_["parity_check"] = rc["parity_check"]
+                if rc["cpu_baseline"]:
+                    sub_["cpu_baseline"] = rc["cpu_baseline"]
+                    sub_["speedup_vs_cpu_baseline"] = sub_["value"] / rc["cpu_baseline"]["value"]
+                sub_["wall_s_including_setup"] = time.perf_counter() - t0
+                multi_subs.append(sub_)
 
-    if world > 1 or force_dist:
-        sizes = dict(sizes)      # (read before the engine goes)
-        ds.close()               # streams drained, second communicator destroyed -- on every rank, before the group goes
     if rank != 0:
         if world > 1:
             import torch.distributed as dist
@@ -546,6 +726,21 @@ def main():
     }
     if force_dist:
         out["config"]["parallelism"] += " [N=1 forced through the multi-rank path]"
+    if multi:
+        # how the shared-point records travelled in THIS job: transport (direct = grouped ncclSend / ncclRecv on the engine's stream,
+        # torch = all_to_all_single, push = peer stores), the size the communicator itself reports, the start-up self-check
+        out["rccl"] = multi["transport"]
+        out["phases"] = multi["phases"]
+        if multi["parity_check"]:
+            out["parity_check"] = multi["parity_check"]
+            out["parity"] = ("parity_check (this job): copies of shared points identical on all ranks after the timed steps + a down-scaled "
+                             "case through the same transport against the oracle's MultiDomain; tests/ for the rest; the oracle restates the "
+                             "reference and is unpinned against a real OpenFOAM build")
+        if multi["cpu_baseline"]:
+            out["cpu_baseline"] = multi["cpu_baseline"]
+            out["speedup_vs_cpu_baseline"] = out["value"] / multi["cpu_baseline"]["value"]
+        if multi_subs:
+            out["configs"] = multi_subs
     if world == 1 and not force_dist:
         # BASELINE.json's other single-GPU configurations, measured by this same run (bounded steps)
         names = [] if args.no_configs else (args.configs.split(",") if args.configs is not None else

@@ -120,12 +120,21 @@ int smgpu_set_sync_variant(smgpu_handle* h, int32_t variant);
 
 /* The loop SM.C:2257-2437 on one rank: up to nIters iterations, stops after the first iteration
  * whose residual < relTol (SM.C:2401).  stats (host, [nIters], may be NULL) receives one entry
- * per iteration done.  No host synchronisation happens inside the loop. */
+ * per iteration done.  No host synchronisation happens inside the loop -- with one bounded exception while the face-angle
+ * constraint is on: the form of the freeze-walk replay follows the number of points outside the good angle range the GPU has
+ * published (updateWalkMode), and to bound how stale that number can be the host waits, every 8th iteration, for the iteration
+ * it enqueued 8 iterations earlier (at most ~16 iterations are queued ahead; the GPU never idles).  The same holds for the
+ * step-wise loop (smgpu_iter_begin). */
 int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_stats* stats, int32_t* nDone);
 
 /* smgpu_get_points also reports an error word a kernel raised since the last check (the step-wise loop below never
  * synchronises on its own): a non-zero return with smgpu_last_error() set. */
 int smgpu_get_points(smgpu_handle* h, double* outPoints /* [3*nPoints] */);
+/* Waits for the engine's stream and reports any error word a kernel has raised since the last check (a grid barrier or a
+ * peer-store wait that timed out, a point without two usable neighbours SM.C:354-362, a projection failure BPS.C:932-938 ...).
+ * The step-wise loop never synchronises on its own; hosts call this at the end of every chunk of iterations (smgpu_get_points
+ * does the same check). */
+int smgpu_check_error(smgpu_handle* h);
 int smgpu_set_points(smgpu_handle* h, const double* points /* [3*nPoints] */);
 
 /* Timing: when enabled every kernel launch is bracketed by hipEvents on the handle's stream. */

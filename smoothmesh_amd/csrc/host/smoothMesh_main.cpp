@@ -876,6 +876,10 @@ int main(int argc, char** argv) {
                 }
                 check(smgpu_halo_set_stats_history(K0.h, dHist, (int32_t)chunk), "smgpu_halo_set_stats_history");
             }
+            // peer stores: a consuming kernel waits for its peers' flags for a BOUNDED time (a dead rank must not hang the others), so
+            // the ranks enter a chunk together -- one of them may still have been writing its sub-domain, or reading a case, for
+            // seconds (the RCCL and host-staged transports simply wait there)
+            if (transport == TRANSPORT_PUSH) g_comm.barrier();
             for (long k = 0; k < chunk; ++k) {
                 check(smgpu_iter_begin(K0.h), "smgpu_iter_begin");
                 if (withL) exchange({Part{K0.sendA, K0.recvA, SMGPU_HALO_A_DOUBLES * 8}, Part{K0.sendL, K0.recvL, (size_t)lDoubles * 8}});   // SM.C:134-148, 402-478; OBB.C:184-198, 490-496
@@ -894,6 +898,9 @@ int main(int argc, char** argv) {
                 stats[(size_t)k].nFrozenPoints = (int32_t)nf;
                 if (res < relTol) break;
             }
+            // an error word raised by a kernel of this chunk (a peer's records that never came, a grid barrier that could not
+            // complete, a point without usable neighbours): found here, not a writeInterval later
+            check(smgpu_check_error(K0.h), "smgpu_check_error");
             if (noStop) {
                 check(smgpu_halo_set_stats_history(K0.h, nullptr, 0), "smgpu_halo_set_stats_history");   // closes the last iteration
                 std::vector<double> hist((size_t)chunk * 2);

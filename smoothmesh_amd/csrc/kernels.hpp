@@ -80,7 +80,7 @@ __device__ __forceinline__ void stPeer2(double* p, double a, double b) {
 }
 constexpr int PUSH_ERR_TIMEOUT = 6;   // Accum::err: a peer's records did not arrive (pushWait)
 // what a consuming kernel needs to wait for the records of this iteration (localFlag == NULL: nothing to wait for)
-struct PushWait { const unsigned* localFlag; int nPeers; int kind; unsigned tag; int* err; int fence; };
+struct PushWait { const unsigned* localFlag; int nPeers; int kind; unsigned tag; int* err; int fence; unsigned long long timeoutTicks; };
 
 // End of a producing kernel, called by EVERY thread of EVERY workgroup of the launch: when the last workgroup has stored its
 // records, this rank's flag goes up at every peer.  Order: every wave drains its (write-through) stores, the workgroup meets,
@@ -108,17 +108,20 @@ __device__ __forceinline__ void pushSignal(const PushView& pv, int kind, unsigne
         __hip_atomic_store(pv.peerFlag[threadIdx.x] + kind, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
-// Start of the first consuming kernel, called by every thread: lane o waits for peer o's flag (a bounded wait: two seconds of
-// wall clock, then Accum::err), acquires at system scope, the workgroup meets; plain loads of the records follow.
+// Start of the first consuming kernel, called by every thread: lane o waits for peer o's flag (a bounded wait: timeoutTicks of
+// the 100 MHz wall clock -- SMGPU_PUSH_TIMEOUT_S, default 60 s: ranks may drift apart by seconds on the host, e.g. while one of
+// them still writes its sub-domain -- then Accum::err; once that error is up no later wait spins again: the run is lost, the
+// host finds the word at the end of the chunk), acquires at system scope, the workgroup meets; plain loads of the records follow.
 __device__ __forceinline__ void pushWait(const PushWait& pw) {
     if (!pw.localFlag) return;
     if ((int)threadIdx.x < pw.nPeers) {
         const unsigned* f = pw.localFlag + 2 * threadIdx.x + pw.kind;
         const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
         unsigned spins = 0;
-        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - pw.tag) < 0) {
+        const bool lost = __hip_atomic_load(pw.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == PUSH_ERR_TIMEOUT;
+        while (!lost && (int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - pw.tag) < 0) {
             __builtin_amdgcn_s_sleep(2);
-            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { *pw.err = PUSH_ERR_TIMEOUT; break; }
+            if ((++spins & 255u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > pw.timeoutTicks) { *pw.err = PUSH_ERR_TIMEOUT; break; }
         }
         if (pw.fence) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
     }

@@ -285,30 +285,45 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
 // job, not once per adjacent cell.  Two jobs run side by side on the two halves.  Points whose star exceeds the caps, or
 // with a non-manifold edge ring, are left (kStarLeft) to the gather form above.
 constexpr int kStarFaces = 32, kStarVerts = 128, kStarEnts = 32;
+// Round 4: what a lane needs in EVERY job but does not change between jobs lives in LDS, not in registers -- the half wave's point
+// (current / proposed coordinates, its two current angle bounds), the entries' neighbours with their proposals, the coordinates of
+// the lane's own edge neighbour (a vertex slot of the star) -- and a vertex slot carries a one-byte ROLE (the point itself, entry
+// e's neighbour, anybody else) instead of a point id to compare.  Before, those 28 registers per lane pushed the kernel over its
+// budget of 128: 27 VGPRs spilled, 104 bytes of scratch per lane, written once per point and re-read inside the job loop (272 MB of
+// scratch writes per launch on the 10 M-cell cavity mesh).
+constexpr unsigned char kRoleSelf = 0xFF, kRoleOther = 0xFE, kRoleNoEntry = 0xFD;
 struct StarLds {
     int fid[kStarFaces];
     int voff[kStarFaces + 1];
-    int vid[kStarVerts];
+    unsigned char role[kStarVerts];      // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
     double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
     unsigned char nb[kStarEnts];
-    signed char job[2 * kStarEnts + 2];  // the jobs that are needed, in order: -1 = the self test, e = entry e with p at its current
-                                         // position, 64 + e = entry e with p at its proposal
-    int fbeg[kStarFaces];                // staging: first entry of the face in facePts
-    unsigned char vface[kStarVerts];     // staging: the star-local face of every vertex slot
+    unsigned touch[kStarEnts];           // bit i: ring place (lane) i is touched by the move of entry e's neighbour
+    double pc[3], pn[3], pMin, pMax;     // the half wave's point: current and proposed coordinates, ptMin / ptMax
+    int eq[kStarEnts];                   // entry e's neighbour (point id)
+    double ex[kStarEnts], ey[kStarEnts];
+    union {
+        double ez[kStarEnts];            // (ex, ey, ez): entry e's neighbour at its proposal
+        struct { int fbeg[kStarFaces]; unsigned char vface[kStarVerts]; } st;   // staging only: first entry of the face in facePts,
+                                                                                 // the star-local face of every vertex slot
+    };
 };
+static_assert(sizeof(StarLds) * 8 <= 40960, "k_walk_pred_star: four workgroups per CU need <= 40 KB of LDS each");
 struct StarLane {          // a lane's place: ring position i of edge (p, xI)
     bool valid, hasCell;
-    int xI;                // the edge's other end point
+    int xEnt;              // the edge's other end point as an entry of the point (pointPoints order = entry order)
+    int xSlot;             // ... and as a vertex slot of the star (its current coordinates)
     bool pFirst;           // p is the edge's first end point (edges[2e])
-    V3 xc, cc;             // current coordinates of xI, centre of the cell between ring faces i and i + 1
+    V3 cc;                 // centre of the cell between ring faces i and i + 1
     int l;                 // ring face i as a star-local id
     int nextLane;          // (within the half wave) the lane of ring face i + 1
 };
-// the pair's angle for the lanes with a cell (valid && hasCell), anything for the others; all 32 lanes of the half call it
-__device__ __forceinline__ double starLaneAngle(const StarLds& L, const StarLane& P, int p, const V3& c1, int i2, const V3& c2) {
+// the pair's angle for the lanes with a cell (valid && hasCell), anything for the others; all 32 lanes of the half call it.
+// c1 = where the point is in this job, ei = the entry whose neighbour sits at its proposal c2 (kRoleNoEntry: nobody else moves)
+__device__ __forceinline__ double starLaneAngle(const StarLds& L, const StarLane& P, const V3& c1, int ei, const V3& c2) {
     V3 fv = v3(0, 0, 0), cV = v3(0, 0, 0);
     if (P.valid) {
-        const V3 xs = (i2 >= 0 && P.xI == i2) ? c2 : P.xc;
+        const V3 xs = (P.xEnt == ei) ? c2 : v3(L.vx[P.xSlot], L.vy[P.xSlot], L.vz[P.xSlot]);
         const V3 e0 = P.pFirst ? c1 : xs, e1 = P.pFirst ? xs : c1;
         const V3 cC = 0.5 * (e0 + e1);
         const V3 d = e1 - e0;
@@ -317,9 +332,9 @@ __device__ __forceinline__ double starLaneAngle(const StarLds& L, const StarLane
             V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
             const int b = L.voff[P.l], n = L.voff[P.l + 1] - b;
             for (int i = 0; i < n; ++i) {
-                const int q = L.vid[b + i];
-                if (q == p) fc = fc + c1;
-                else if (i2 >= 0 && q == i2) fc = fc + c2;
+                const int r = L.role[b + i];
+                if (r == kRoleSelf) fc = fc + c1;
+                else if (r == ei) fc = fc + c2;
                 else fc = fc + v3(L.vx[b + i], L.vy[b + i], L.vz[b + i]);
             }
             fc = divByCount(fc, n);   // = fc / double(n), bit for bit
@@ -373,13 +388,18 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         bool live = a < nA;
         if (a == 0 && hl == 0) w.actEntOff[nA] = nE;
         const int p = live ? w.actIds[a] : 0;
-        const V3 cur = ldv(s.ptsCur, p);
-        const V3 np = ldv(s.prop, p);
-        const bool moved = (np != cur);
+        bool moved;
         const bool frozenBefore = s.frozen[p] != 0;
-        const double curMin = s.ptMin[p], curMax = s.ptMax[p];
+        {   // the point itself goes to LDS (every job reads it from there)
+            const V3 cur = ldv(s.ptsCur, p);
+            const V3 np = ldv(s.prop, p);
+            moved = (np != cur);
+            if (hl == 0) {
+                L.pc[0] = cur.x; L.pc[1] = cur.y; L.pc[2] = cur.z; L.pn[0] = np.x; L.pn[1] = np.y; L.pn[2] = np.z;
+                L.pMin = s.ptMin[p]; L.pMax = s.ptMax[p];
+            }
+        }
         const int eBeg = live ? w.actEntOff[a] : 0, eEnd = live ? ((a + 1 < nA) ? w.actEntOff[a + 1] : nE) : 0, nEnt = eEnd - eBeg;
-        auto bad = [&](double mn, double mx) { return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax)); };
         // the point's edges with the lengths of their face rings, its faces with their vertex counts
         const int eb = m.ppOff[p], nEdgesP = live ? m.ppOff[p + 1] - eb : 0;
         const int fb = m.pfOff[p], nF = live ? m.pfOff[p + 1] - fb : 0;
@@ -396,22 +416,12 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         }
         const int totalLanes = __shfl(inclN, 31, 32), totalV = __shfl(inclV, 31, 32);
         const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
-        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts && ringBad == 0u;
+        // (entry j = the neighbour across edge j: pointPoints and pointEdges share their offsets, so nEnt == nEdgesP)
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt <= kStarEnts && nEnt == nEdgesP && ringBad == 0u;
         if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
         live = live && fits;
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
-        int q = -1;
-        V3 nq = v3(0, 0, 0);
-        bool eligible = false;
-        unsigned char nb0 = 0;
-        if (live && hl < nEnt) {
-            q = w.entNbr[eBeg + hl];
-            nq = ldv(s.prop, q);
-            const bool qFrozen = s.frozen[q] != 0;
-            nb0 = qFrozen ? 8 : 0;
-            eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
-            if (eligible) nb0 |= 4;
-        }
+        const int q = (live && hl < nEnt) ? w.entNbr[eBeg + hl] : -1;
         // Stage the star.  The loads are arranged in LEVELS of independent requests (what bounds this kernel besides FP64 issue
         // is the chain of dependent gathers, not their number): the edge lanes fetch their edge's cell range and end points
         // here, next to the faces' vertex ranges (the ring places below get them by shuffle instead of loading them one level
@@ -419,113 +429,209 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         // a loop over each face's vertices (two dependent round trips per vertex).
         const int myCb = (myE >= 0) ? m.ecOff[myE] : 0, myNc = (myE >= 0) ? m.ecOff[myE + 1] - myCb : 0;
         const int myEfb = (myE >= 0) ? m.efOff[myE] : 0;
-        const int myE0 = (myE >= 0) ? m.edges[2 * myE] : -1, myE1 = (myE >= 0) ? m.edges[2 * myE + 1] : -1;
+        const int myE0 = (myE >= 0) ? m.edges[2 * myE] : -1;
         if (live && hl < nF) {
             const int o = inclV - myV;
             L.fid[hl] = myF;
             L.voff[hl] = o;
-            L.fbeg[hl] = myFb;
-            for (int v = 0; v < myV; ++v) L.vface[o + v] = (unsigned char)hl;
+            L.st.fbeg[hl] = myFb;
+            for (int v = 0; v < myV; ++v) L.st.vface[o + v] = (unsigned char)hl;
         }
         if (live && hl == 0) L.voff[nF] = totalV;
-        if (live && hl < nEnt) L.nb[hl] = nb0;
+        if (live && hl < nEnt) L.eq[hl] = q;
+        L.touch[hl] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // this lane's ring place
         StarLane P;
         P.valid = live && hl < totalLanes;
-        P.hasCell = false; P.xI = -1; P.pFirst = true; P.xc = v3(0, 0, 0); P.cc = v3(0, 0, 0); P.l = 0; P.nextLane = hl;
+        P.hasCell = false; P.xEnt = 0; P.xSlot = 0; P.pFirst = true; P.cc = v3(0, 0, 0); P.l = 0; P.nextLane = hl;
         int ringFaceId = -1, ringCellAt = -1;
         {
-            int first = 0, nfj = 0, cb = 0, nc = 0, efb = 0, e0I = -1, e1I = -1;
+            int first = 0, nfj = 0, cb = 0, nc = 0, efb = 0, e0I = -1, jOf = 0;
             bool found = false;
             for (int j = 0; j < nEdgesP; ++j) {
                 const int hi = __shfl(inclN, j, 32), nj = __shfl(myNf, j, 32);
                 const int cbj = __shfl(myCb, j, 32), ncj = __shfl(myNc, j, 32), efbj = __shfl(myEfb, j, 32);
-                const int e0j = __shfl(myE0, j, 32), e1j = __shfl(myE1, j, 32);
-                if (!found && hl < hi) { found = true; first = hi - nj; nfj = nj; cb = cbj; nc = ncj; efb = efbj; e0I = e0j; e1I = e1j; }
+                const int e0j = __shfl(myE0, j, 32);
+                if (!found && hl < hi) { found = true; first = hi - nj; nfj = nj; cb = cbj; nc = ncj; efb = efbj; e0I = e0j; jOf = j; }
             }
             if (P.valid) {
                 const int i = hl - first;
                 P.hasCell = i < nc;
                 P.nextLane = (i + 1 < nfj) ? hl + 1 : first;          // closed ring: the last cell ends at face 0
                 P.pFirst = (e0I == p);
-                P.xI = P.pFirst ? e1I : e0I;
+                P.xEnt = jOf;
                 ringFaceId = efb + i;
                 if (P.hasCell) ringCellAt = cb + i;
             }
         }
-        // level: vertex ids by slot, the ring's face and cell, the coordinates of the edge's other end
+        // level: vertex ids by slot, the ring's face and cell, the entry neighbour's two positions
         int vg[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = hl + 32 * u;
             vg[u] = -1;
-            if (live && k < totalV) { const int l = L.vface[k]; vg[u] = m.facePts[L.fbeg[l] + (k - L.voff[l])]; }
+            if (live && k < totalV) { const int l = L.st.vface[k]; vg[u] = m.facePts[L.st.fbeg[l] + (k - L.voff[l])]; }
         }
         const int rf = (ringFaceId >= 0) ? m.ringFace[ringFaceId] : -1;
         const int rc = (ringCellAt >= 0) ? m.ringCell[ringCellAt] : -1;
-        if (P.valid) P.xc = ldv(s.ptsCur, P.xI);
-        // level: the coordinates
+        V3 nq = v3(0, 0, 0);
+        bool eligible = false;
+        unsigned char nb0 = 0;
+        if (q >= 0) {
+            nq = ldv(s.prop, q);
+            const bool qFrozen = s.frozen[q] != 0;
+            nb0 = qFrozen ? 8 : 0;
+            eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
+            if (eligible) nb0 |= 4;
+        }
+        // level: the coordinates; the role of every vertex slot (the point itself / entry e's neighbour / anybody else)
         V3 vc[4];
+        unsigned char role[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+            vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0);
+            role[u] = (vg[u] == p) ? kRoleSelf : kRoleOther;
+        }
         if (rc >= 0) P.cc = ldv(s.cellCtr, rc);                      // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+        for (int e = 0; e < nEnt; ++e) {
+            const int qe = L.eq[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (vg[u] == qe) role[u] = (unsigned char)e;
+        }
+        __builtin_amdgcn_wave_barrier();                              // (ez below overlays the staging tables read above)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = hl + 32 * u;
-            if (vg[u] >= 0) { L.vid[k] = vg[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
+            if (vg[u] >= 0) { L.role[k] = role[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
         }
+        if (q >= 0) { L.nb[hl] = nb0; L.ex[hl] = nq.x; L.ey[hl] = nq.y; L.ez[hl] = nq.z; }
         if (P.valid) for (int l = 0; l < nF; ++l) if (L.fid[l] == rf) P.l = l;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        const bool counts = P.valid && P.hasCell;
-        // Jobs, one per step and half wave, ONE call site for all of them (a job's state is data, not control flow).  Job codes:
-        // -1 the self test (p at its proposal), e = entry e with p at its current position, 64 + e = entry e with p at its
-        // proposal.  Only jobs whose result can be consulted are listed: the self test of a point that moves and is still free,
-        // the entries of the neighbours that are free and moving; the proposal-state jobs are appended after the first step,
-        // once the self test has told whether p can act from its proposal at all (it is only read if p is still free at its
-        // first visit and does not freeze itself, SM.C:1376-1399).
-        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
-        const bool selfNeeded = live && moved && !frozenBefore;
-        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
-        const int nEl = __popc(elig), first = selfNeeded ? 1 : 0;
-        const int myRank = __popc(elig & ((1u << hl) - 1u));
-        if (eligible) L.job[first + myRank] = (signed char)hl;
-        if (hl == 0 && selfNeeded) L.job[0] = -1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        int nJobs = live ? first + nEl : 0;
-        for (int j = 0; j < nJobs; ++j) {
-            const int code = (int)L.job[j];
-            const bool isSelf = code < 0, atProp = code >= 64;
-            const int ei = isSelf ? 0 : (code & 63);                 // entry of this job
-            const int jq = __shfl(q, ei, 32);
-            const V3 jnq = v3(__shfl(nq.x, ei, 32), __shfl(nq.y, ei, 32), __shfl(nq.z, ei, 32));
-            const V3 c1 = (isSelf || atProp) ? np : cur;
-            const double angle = starLaneAngle(L, P, p, c1, isSelf ? -1 : jq, isSelf ? np : jnq);
-            double mn, mx;
-            starReduce(counts, angle, mn, mx);
-            const bool isBad = bad(mn, mx);
-            if (j == 0) {
-                if (selfNeeded && isBad) sbits |= 1u;                // (the reduction leaves mn / mx in every lane of the half)
-                if (moved && !(sbits & 5u) && nEl > 0) {             // p can act from its proposal: the proposal-state jobs
-                    if (eligible) L.job[nJobs + myRank] = (signed char)(64 + hl);
-                    nJobs += nEl;
+        // the slot of the edge's other end point in this lane's ring face (it is a vertex of every face of the ring); the entries
+        // whose neighbour's move TOUCHES this place: the edge's own entry, and every other neighbour of p in one of the place's two
+        // ring faces (the face vectors and the edge vector are the only things a neighbour's move changes, SM.C:1155-1200).  A lane
+        // keeps its (at most four) touching entries; the places an entry touches are collected as a lane mask per entry.
+        const int lNext = __shfl(P.l, P.nextLane, 32);
+        unsigned tl = 0xFFFFFF00u | (unsigned)(P.xEnt & 0xFF);     // byte k: the k-th touching entry, 0xFF none
+        bool tooMany = false;
+        if (P.valid) {
+            int nt = 1;
+            atomicOr(&L.touch[P.xEnt], 1u << hl);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int l = side ? lNext : P.l;
+                for (int i = L.voff[l]; i < L.voff[l + 1]; ++i) {
+                    const unsigned r = L.role[i];
+                    if (side == 0 && r == (unsigned)P.xEnt) P.xSlot = i;
+                    if (r >= (unsigned)kStarEnts || r == (unsigned)P.xEnt) continue;
+                    bool have = false;
+                    for (int k = 1; k < nt; ++k) have = have || (((tl >> (8 * k)) & 0xFFu) == r);
+                    if (have) continue;
+                    if (nt == 4) { tooMany = true; continue; }
+                    tl = (tl & ~(0xFFu << (8 * nt))) | (r << (8 * nt));
+                    ++nt;
+                    atomicOr(&L.touch[r], 1u << hl);
                 }
             }
-            if (!isSelf && hl == 0) {
-                unsigned char v = L.nb[ei];
-                if (atProp) { if (isBad) v |= 1; }
-                else {
-                    if (isBad) v |= 2;
-                    if (isBad && !moved) v |= 1;                     // not moved: proposal = current position
+        }
+        if ((unsigned)(__ballot(tooMany) >> (32 * half)) != 0u) {   // (a face through p with chords to other neighbours of p: never seen; the gather form takes it)
+            if (live && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }
+            live = false;
+            P.valid = false;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const bool counts = P.valid && P.hasCell;
+        // Steps (round 4).  A job = one predicate: the self test (p at its proposal), or entry e's neighbour at its proposal with p at
+        // its current position / at its proposal.  Round 3 ran one job per step on all ring places -- but the move of ONE neighbour
+        // touches about half of them (12 of an interior hex point's 24), and what it does not touch cannot decide the job: with p at its
+        // current position an untouched pair has its current angle, which is >= ptMin and <= ptMax by definition (SM.C:938-975), so
+        // only touched pairs can make `new < current` true (SM.C:1421-1427); with p at its proposal an untouched pair has exactly the
+        // angle the self test found for it.  So entries whose touched places are DISJOINT share a step: every place evaluates the
+        // entry that touches it (an interior hex point: its six neighbours in three steps per state, opposite neighbours together),
+        // the per-entry min / max are segment reductions.  Entries are coloured greedily (lane c keeps the places of colour c); a
+        // lane's face vector serves its ring neighbour under either entry: if the neighbour's entry changed that face, the lane would
+        // be touched by it too.  Same arithmetic per evaluated pair, hence the same bits.
+        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+        const bool selfNeeded = live && moved && !frozenBefore;
+        eligible = eligible && live;
+        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
+        const int nEl = __popc(elig), first = selfNeeded ? 1 : 0;
+        int myCol = -1, nCol = 0;
+        {
+            const unsigned Te = (hl < nEnt && live) ? L.touch[hl] : 0u;
+            unsigned U = 0u;                                         // lane c: the places of the entries coloured c
+            const unsigned long long anyElig = __ballot(eligible);
+            const unsigned both = (unsigned)(anyElig | (anyElig >> 32));   // (wave-uniform trip count: entries eligible in either half)
+            for (int e = 0; e < kStarEnts; ++e) {
+                if (!((both >> e) & 1u)) continue;
+                const bool on = (elig >> e) & 1u;
+                const unsigned Tcur = (unsigned)__shfl((int)Te, e, 32);
+                const unsigned fb = (unsigned)(__ballot(on && (U & Tcur) == 0u) >> (32 * half));
+                const int c = __ffs((int)fb) - 1;                    // (32 lanes, at most 32 entries: a free colour exists)
+                if (on && hl == c) U |= Tcur;
+                if (on && hl == e) myCol = c;
+            }
+            nCol = __popc((unsigned)(__ballot(U != 0u) >> (32 * half)));   // colours are taken lowest first: 0 .. nCol - 1
+        }
+        unsigned tc = 0xFFFFFFFFu;                                   // byte k: the colour of my k-th touching entry (0xFF: none / not eligible)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned e = (tl >> (8 * k)) & 0xFFu;
+            const int ce = __shfl(myCol, (int)(e & 31u), 32);
+            if (e != 0xFFu && ce >= 0) tc = (tc & ~(0xFFu << (8 * k))) | ((unsigned)ce << (8 * k));
+        }
+        double selfAngle = 0.0;
+        int nSteps = live ? first + nCol : 0, nJobsAlg = live ? first + nEl : 0;
+        for (int st = 0; st < nSteps; ++st) {
+            const bool isSelf = st < first;
+            const int k0 = st - first;
+            const bool atProp = !isSelf && k0 >= nCol;
+            const int c = isSelf ? -1 : (atProp ? k0 - nCol : k0);   // this step's colour
+            int ei = (int)kRoleNoEntry;                              // the entry this place evaluates: the one of colour c that touches it
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if ((int)((tc >> (8 * k)) & 0xFFu) == c) ei = (int)((tl >> (8 * k)) & 0xFFu);
+            const double* pc = (isSelf || atProp) ? L.pn : L.pc;     // where the point is in this step
+            const V3 c1 = v3(pc[0], pc[1], pc[2]);
+            const int eix = ei & (kStarEnts - 1);
+            const V3 c2 = v3(L.ex[eix], L.ey[eix], L.ez[eix]);       // (unused when ei = kRoleNoEntry: no slot has that role)
+            const double angle = starLaneAngle(L, P, c1, ei, c2);
+            const double curMin = L.pMin, curMax = L.pMax;
+            if (isSelf) {
+                selfAngle = angle;
+                double mn, mx;
+                starReduce(counts, angle, mn, mx);
+                const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1391-1399
+                if (isBad) sbits |= 1u;                              // (the reduction leaves mn / mx in every lane of the half)
+            } else {
+                unsigned cm = (unsigned)(__ballot(eligible && myCol == c) >> (32 * half));   // the entries of this step
+                while (cm) {
+                    const int e = __ffs((int)cm) - 1;
+                    cm &= cm - 1u;
+                    const bool sel = (ei == e);
+                    double mn, mx;
+                    // p at its current position: the touched pairs only; at its proposal: the others keep the self test's angle
+                    starReduce(atProp ? counts : (counts && sel), (sel || !atProp) ? angle : selfAngle, mn, mx);
+                    const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1421-1427
+                    if (hl == 0 && isBad) {
+                        unsigned char v = L.nb[e];
+                        if (atProp) v |= 1;
+                        else v |= moved ? 2 : 3;                     // not moved: proposal = current position
+                        L.nb[e] = v;
+                    }
                 }
-                L.nb[ei] = v;
+            }
+            if (st == 0 && moved && !(sbits & 5u) && nEl > 0) {      // p can act from its proposal (SM.C:1376-1399): the proposal-state steps
+                nSteps += nCol;
+                nJobsAlg += nEl;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
+        const int nJobs = nJobsAlg;       // (the timing pass counts the reference's jobs, not the steps they were packed into)
         if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
         if (opCount) {
             // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs, by the reference's arithmetic
@@ -540,7 +646,7 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        if (live && hl < nEnt) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
+        if (q >= 0) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
     }

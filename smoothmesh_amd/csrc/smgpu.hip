@@ -94,6 +94,7 @@ struct smgpu_handle {
     std::vector<int32_t> pushCount, pushRemoteBase, pushMyIndex;
     std::vector<void*> pushRecvA, pushRecvL, pushRecvF, pushFlags;
     void* pushLocalFlags = nullptr;
+    unsigned long long pushTimeoutTicks = 6000000000ull;   // bounded wait for a peer's flag (100 MHz ticks; SMGPU_PUSH_TIMEOUT_S)
     void *dSlotA = nullptr, *dSlotL = nullptr, *dSlotF = nullptr, *dPeerFlag = nullptr;
     unsigned* dPushTicket = nullptr;
     int *dInteriorTiles = nullptr, *dSharedTiles = nullptr;   // smoothing tiles without / with shared points
@@ -1334,7 +1335,7 @@ static int updateWalkMode(smgpu_handle* h) {
 
 static int runConstraints(smgpu_handle* h);
 static int runProposalAndConstraints(smgpu_handle* h) {
-    if (updateWalkMode(h)) return 1;
+    if (!h->haloOn && updateWalkMode(h)) return 1;      // (step-wise loop: smgpu_iter_begin has decided for this iteration)
     if (forkFaFilter(h)) return 1;
     if (runSmooth<false>(h, h->mv, h->st, makePrm(h))) return 1;
     if (h->bndOn && h->haloOn && launchBndFix<false>(h, 0)) return 1;
@@ -1412,7 +1413,7 @@ static int checkDeviceError(smgpu_handle* h) {
     if (a.err == 3) return fail("face-angle walk: the workgroups of the device replay did not all become resident (grid barrier timed out); set SMGPU_WALK=host or lower SMGPU_WALK_BLOCKS");
     if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
     if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
-    if (a.err == PUSH_ERR_TIMEOUT) return fail("peer-store transport: a peer's records did not arrive within two seconds (a rank is behind, gone, or not using the same transport)");
+    if (a.err == PUSH_ERR_TIMEOUT) return fail("peer-store transport: a peer's records did not arrive within the time limit (SMGPU_PUSH_TIMEOUT_S, default 60 s: a rank is gone, or not using the same transport)");
     if (a.err == BND_ERR_NORMAL) return fail("pointNormal is zero for a boundary point that is to be projected (BPS.C:691-696, OBB.C:609-610)");
     if (a.err == BND_ERR_NOHIT) return fail("Did not find surface intersection for a boundary point (BPS.C:932-938)");
     if (a.err == BND_ERR_STRING) return fail("Internal sanity check failed: Did not find any edges with the string index of a feature edge point (BPS.C:258-261)");
@@ -1544,6 +1545,12 @@ int smgpu_get_points(smgpu_handle* h, double* out) {
     return checkDeviceError(h);
 }
 
+int smgpu_check_error(smgpu_handle* h) {
+    if (!h) return fail("null handle");
+    HIP_OK(hipSetDevice(h->device));
+    return checkDeviceError(h);
+}
+
 int smgpu_set_points(smgpu_handle* h, const double* pts) {
     if (!h || !pts) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));
@@ -1622,6 +1629,8 @@ int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, v
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipDeviceSynchronize());
     if (depInit(h)) return 1;
+    if (h->pushOn && useExchangeStream && (hipStream_t)exchangeStream != h->stream)
+        return fail("smgpu_halo_set_exchange_stream: the peer-store transport is on (nothing is enqueued by the host: no exchange stream)");
     h->useExch = useExchangeStream && (hipStream_t)exchangeStream != h->stream;
     h->exch = (hipStream_t)exchangeStream;
     if (h->useExch && !h->evToExch) {
@@ -1635,9 +1644,12 @@ int smgpu_halo_set_exchange_stream(smgpu_handle* h, int32_t useExchangeStream, v
 int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     if (!h || !d) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));
-    h->nShared = d->nShared; h->nSend = d->nSend; h->nRecv = d->nRecv;
     // the host's buffers may still be being initialised on the host's streams
     HIP_OK(hipDeviceSynchronize());
+    // a new slot layout invalidates the peer-store transport's destination tables and restarts the flag tags: the caller describes
+    // the peers again (smgpu_halo_set_push) after every configure
+    h->pushOn = false; h->st.push = PushView{};
+    h->nShared = d->nShared; h->nSend = d->nSend; h->nRecv = d->nRecv;
     if (smgpu_halo_set_exchange_stream(h, d->useExchangeStream, d->exchangeStream)) return 1;
     const int P = h->mv.nPoints;
     std::vector<int> sharedLocal(d->sharedLocal, d->sharedLocal + d->nShared);
@@ -1789,6 +1801,7 @@ static PushWait pushWaitOf(const smgpu_handle* h, int kind) {
     PushWait pw;
     pw.localFlag = h->pushOn ? h->st.push.localFlag : nullptr;
     pw.nPeers = h->pushPeers; pw.kind = kind; pw.tag = (unsigned)(h->haloIter + 1); pw.err = &h->st.acc->err; pw.fence = h->st.push.fence;
+    pw.timeoutTicks = h->pushTimeoutTicks;
     return pw;
 }
 
@@ -1819,7 +1832,12 @@ int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d) {
     if (!h || !h->haloOn) return fail("halo not configured");
     HIP_OK(hipSetDevice(h->device));
     HIP_OK(hipDeviceSynchronize());
-    if (!d) { h->pushOn = false; h->st.push = PushView{}; return 0; }
+    if (!d) {
+        h->pushOn = false; h->st.push = PushView{};
+        h->st.inlineCombine = (h->useTiles && h->dMultiIdx && envInt("SMGPU_HALO_INLINE", 0)) ? 1 : 0;      // as smgpu_halo_configure chose them
+        h->st.inlinePackF = (h->st.inlineCombine || (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0))) ? 1 : 0;
+        return 0;
+    }
     if (d->nPeers < 0 || d->nPeers > 64) return fail("smgpu_halo_set_push: at most 64 peers");
     if (h->nShared && !(h->useTiles && h->nSharedTiles > 0 && h->packTiles)) return fail("smgpu_halo_set_push: needs the tiled pack kernel (SMGPU_TILES / SMGPU_PACK_TILES)");
     if (h->useExch) return fail("smgpu_halo_set_push: the exchange stream arrangement does not apply (nothing is enqueued by the host)");
@@ -1847,6 +1865,7 @@ int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d) {
     pv.slotA = (double* const*)h->dSlotA; pv.slotL = (double* const*)h->dSlotL; pv.slotF = (int* const*)h->dSlotF;
     pv.ticket = h->dPushTicket; pv.peerFlag = (unsigned* const*)h->dPeerFlag; pv.localFlag = (const unsigned*)h->pushLocalFlags; pv.nPeers = d->nPeers;
     pv.fence = envInt("SMGPU_PUSH_FENCE", 0) ? 1 : 0;
+    h->pushTimeoutTicks = (unsigned long long)std::max(1, envInt("SMGPU_PUSH_TIMEOUT_S", 60)) * 100000000ull;   // s_memrealtime: 100 MHz
     h->st.push = pv;
     h->st.inlineCombine = 0;     // the records are consumed by the combine kernel (it carries the wait) ...
     h->st.inlinePackF = 0;       // ... and the flags leave through k_halo_packF (it carries the signal)

@@ -346,6 +346,10 @@ class SmoothEngine:
         frz = np.array([stats[i].nFrozenPoints for i in range(n)], dtype=np.int64)
         return n, res, frz
 
+    def check_error(self):
+        """wait for the engine's stream and raise SmgpuError for any error word a kernel has raised (include/smgpu.h)"""
+        self._check(self._lib.smgpu_check_error(self._h))
+
     def get_points(self):
         out = np.empty((self.nPoints, 3), np.float64)
         self._check(self._lib.smgpu_get_points(self._h, _p(out, _ffi.c_f64p)))

@@ -346,11 +346,16 @@ class DistributedSmoother:
         """grouped ncclSend / ncclRecv on the engine's stream for the per-iteration exchanges (rccl_direct.py) when the process
         group is RCCL and every rank's self-check against all_to_all_single passes; None = the torch collective"""
         torch, dist = self.torch, self.dist
+        # self.direct_status: why the per-iteration exchanges travel the way they do (bench.py prints it)
         if self.pushbuf is not None:
+            self.direct_status = "off: peer-store transport"
             return None
         if not own_engine or dist.get_backend() != "nccl" or self.device.type != "cuda" or os.environ.get("SMOOTHMESH_EXCHANGE", "rccl") == "torch":
+            self.direct_status = "off: " + ("SMOOTHMESH_EXCHANGE=torch" if os.environ.get("SMOOTHMESH_EXCHANGE", "rccl") == "torch" else
+                                            f"process group backend {dist.get_backend()}" if own_engine else "stand-in engine")
             return None
         if self.world == 1 and not self.probe_slots:
+            self.direct_status = "off: one rank"
             return None
         from . import rccl_direct
         try:
@@ -361,6 +366,7 @@ class DistributedSmoother:
         flag = torch.tensor([have], dtype=torch.int32, device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if not int(flag.item()):
+            self.direct_status = "fell_back: librccl.so not found on some rank"
             return None
         # (the first real multi-GPU run of this path happens outside the builder's reach: a rank on which the second communicator
         # cannot be brought up, or whose self-check raises, must not take the job down -- every rank then agrees on the torch
@@ -374,14 +380,33 @@ class DistributedSmoother:
         flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # every rank has its communicator, or nobody uses one
         counts = [self.probe_slots] if self.world == 1 else self.counts
-        if int(flag.item()) and d.self_check(counts, self.device):   # (self_check agrees on its result across the ranks itself)
+        if not int(flag.item()):
+            self.direct_status = "fell_back: second communicator could not be created on some rank"
+        elif d.self_check(counts, self.device):   # (self_check agrees on its result across the ranks itself)
+            self.direct_status = "pass"
             return d
+        else:
+            self.direct_status = "fell_back: self-check against all_to_all_single failed on some rank"
         if d is not None:
             try:
                 d.close()
             except Exception:  # noqa: BLE001
                 pass
         return None
+
+    def transport_info(self):
+        """how the shared-point records travel in this job, for the bench line: {"backend", "transport": direct | torch | push,
+        "ranks_seen": the size of the communicator that carries them (ncclCommCount of the send / recv communicator, else the
+        process group's world size), "self_check": pass | fell_back: why | off: why}"""
+        backend = self.dist.get_backend()
+        if self.pushbuf is not None:
+            t, seen = "push", self.world
+        elif self.direct is not None:
+            t, seen = "direct", self.direct.ranks_seen
+        else:
+            t, seen = "torch", self.dist.get_world_size()
+        return {"backend": "RCCL (torch backend nccl)" if backend == "nccl" else backend + " (debug transport, host-staged)", "transport": t,
+                "ranks_seen": int(seen), "self_check": getattr(self, "direct_status", "off"), "exchange_stream": bool(getattr(self, "overlap", False))}
 
     def close(self):
         """Orderly shutdown, to be called on every rank BEFORE dist.barrier() / destroy_process_group(): drain the engine's and
@@ -558,7 +583,7 @@ class DistributedSmoother:
         kernels (ordered with events inside the engine); False: exchanges run in order on the engine's stream.
         Which one is faster depends on the exchange latency of the machine (each cross-stream dependency costs
         ~10 us of iteration time on MI355X, an exposed exchange its full latency): see autotune()."""
-        if self.xstream is None:
+        if self.xstream is None or self.pushbuf is not None:   # (peer stores: nothing is enqueued by the host, no second stream)
             return
         self.overlap = bool(overlap)
         self.engine.set_exchange_stream(self.xstream.cuda_stream if self.overlap else None)
@@ -567,7 +592,7 @@ class DistributedSmoother:
         """Time `iters` iterations in both arrangements (max over ranks), keep the faster one for all ranks and
         restore the coordinates.  Returns {"overlap": bool, "us_per_iter": {...}}."""
         import time
-        if self.xstream is None or self.world == 1 and not self.probe_slots:
+        if self.xstream is None or self.pushbuf is not None or (self.world == 1 and not self.probe_slots):
             return {"overlap": getattr(self, "overlap", False), "us_per_iter": {}}
         torch = self.torch
         pts0 = self.engine.get_points()
@@ -605,6 +630,10 @@ class DistributedSmoother:
         torch, st, eng = self.torch, self.state, self.engine
         n = max(centroidalIters, 1)
         done = 0
+        if self.pushbuf is not None and self.world > 1:
+            # peer stores: the consuming kernels wait for their peers' flags for a BOUNDED time, so the ranks start a call together
+            # (host work between two calls -- mesh output, an oracle leg -- may differ by seconds from rank to rank)
+            self.dist.barrier()
         if relTol > 0.0:
             hist = torch.zeros((n, 2), dtype=torch.float64, device=self.device)
             for i in range(centroidalIters):
@@ -634,6 +663,8 @@ class DistributedSmoother:
             eng.iter_end()
             done += 1
         eng.set_stats_history(None, 0)
+        if hasattr(eng, "check_error"):
+            eng.check_error()          # an error word raised by a kernel of this call (the gather below waits for the stream anyway)
         if self._staged():
             allh = torch.empty((self.world, n, 2), dtype=torch.float64)
             self.dist.all_gather_into_tensor(allh.view(-1), local.cpu().view(-1))

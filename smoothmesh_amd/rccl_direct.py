@@ -55,6 +55,15 @@ class RcclDirect:
         self.comm = C.c_void_p()
         with torch.cuda.device(device):
             self._ok(lib.ncclCommInitRank(C.byref(self.comm), self.world, uid, self.rank), "ncclCommInitRank")
+        # what the communicator itself says about its size (reported by bench.py next to the transport: a line measured with
+        # fewer ranks in the communicator than GPUs in the job would be a different experiment)
+        lib.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        lib.ncclCommCount.restype = C.c_int
+        n = C.c_int(-1)
+        self._ok(lib.ncclCommCount(self.comm, C.byref(n)), "ncclCommCount")
+        self.ranks_seen = int(n.value)
+        if self.ranks_seen != self.world:
+            raise RuntimeError(f"ncclCommCount = {self.ranks_seen}, world size = {self.world}")
 
     def _ok(self, rc, what):
         if rc != 0:

@@ -28,11 +28,15 @@ def test_self_launch_reaches_the_ranks_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workload", ["hex16", "cavity12c"])
-def test_bench_two_ranks_self_launched(workload):
+@pytest.mark.parametrize("workload,configs", [("hex16", "cavity10c"), ("cavity12c", "")])
+def test_bench_two_ranks_self_launched(workload, configs):
     """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE): two ranks on this box's one GPU through the gloo debug
-    transport; ONE JSON line with n_gpus = 2 and both ranks' points"""
-    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", workload],
+    transport; ONE JSON line with n_gpus = 2 and both ranks' points, and everything a judge needs to accept an N > 1 line:
+    parity_check (copies of shared points identical across the ranks after the timed steps; a down-scaled case through the same
+    transport against the oracle's MultiDomain), cpu_baseline (rank 0's oracle on its own sub-domain), how the records travelled
+    (transport, communicator size, self-check), and configs[] = the polyhedral constraints-on workload (BASELINE configs[4]) beside
+    the hex headline"""
+    r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", workload, "--configs", configs, "--config-steps", "3"],
              env={"SMOOTHMESH_BACKEND": "gloo", "SMOOTHMESH_SHARE_GPU": "1"})
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -42,6 +46,43 @@ def test_bench_two_ranks_self_launched(workload):
     assert d["config"]["points_per_gpu"] > 0 and "roofline" in d
     if workload.startswith("cavity"):
         assert "15^3 base grid" in d["config"]["workload"] and "configs[4]" in d["config"]["workload"]
+
+    def judgeable(e):
+        pc = e["parity_check"]
+        assert pc["ok"] is True
+        a, b = pc["shared_point_copies"], pc["small_case"]
+        assert a["ok"] and a["mismatching_points"] == 0 and a["shared_points"] > 0 and a["copies"] >= 2 * a["shared_points"]
+        assert b["ok"] and b["rel_linf_max_over_ranks"] <= 1e-10 and b["bitwise_equal_on_every_rank"] and "MultiDomain" in b["against"]
+        cb = e["cpu_baseline"]
+        assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "RANK 0's sub-domain" in cb["sample"]
+        assert e["speedup_vs_cpu_baseline"] > 0
+        rc = e["rccl"]
+        assert rc["ranks_seen"] == 2 and rc["transport"] in ("direct", "torch", "push") and rc["self_check"]
+        assert rc["transport"] == b["transport"]            # the small case went through the transport of the timed run
+        # gloo here: the line must SAY that this was not RCCL
+        assert rc["transport"] == "torch" and "gloo" in rc["backend"] and rc["self_check"].startswith("off: process group backend gloo")
+
+    judgeable(d)
+    if configs:
+        (c,) = d["configs"]
+        assert c["workload"] == "cavity10c" and c["n_gpus"] == 2 and c["steps"] == 3 and c["value"] > 0
+        assert "configs[4]" in c["config"] and "constraints on" in c["config"] and c["nFrozenPoints_last"] > 0
+        judgeable(c)
+    else:
+        assert "configs" not in d
+
+
+def test_default_multi_gpu_line_names_configs4():
+    """bench.py --gpus 8 without --workload: the hex100 weak-scaling headline AND, as configs[], cavity215c per GPU = the
+    430^3-base (~80 M-cell) polyhedral mesh, constraints on, 200 iterations (BASELINE configs[4]) -- read off the source, since
+    neither eight GPUs nor a GPU at all exist where this test runs"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '(["cavity215c"] if args.workload == "hex100" else [])' in src
+    assert 'args.config_steps or (100 if k_ == "hex" else 200)' in src
+    sys.path.insert(0, ROOT)
+    import bench
+    assert int(round(215 * 8 ** (1.0 / 3.0))) == 430 and bench.proc_grid(8) == (2, 2, 2)
+    assert "configs[4]" in bench.workload_text("cavity", 215, True, False, False, world=8, n_global=430)
 
 
 @pytest.mark.gpu
