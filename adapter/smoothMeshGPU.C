@@ -435,7 +435,7 @@ int main(int argc, char *argv[])
     checkHip(hipGetDeviceCount(&nDev));
     const label device = args.optionLookupOrDefault("device", label(Pstream::parRun() ? Pstream::myProcNo() % max(nDev, 1) : 0));
 
-    smgpu_mesh_desc d;
+    smgpu_mesh_desc d = {};      // (every field zero: fields added to the struct later stay defined)
     d.nPoints = mesh.nPoints(); d.nCells = mesh.nCells(); d.nFaces = mesh.nFaces(); d.nInternalFaces = mesh.nInternalFaces();
     d.points = reinterpret_cast<const double*>(mesh.points().begin());      // Vector<double>: 3 packed doubles
     d.faceOffsets = faceOffsets.begin(); d.facePoints = facePoints.begin();
@@ -467,7 +467,7 @@ int main(int argc, char *argv[])
              << "than half of the minimum edge length! This may "
              << "cause unstability in smoothing." << endl << endl;
     }
-    smgpu_params prm;
+    smgpu_params prm = {};      // (every field zero: fields added to the struct later stay defined)
     prm.maxStepLength = maxStepLength;
     prm.relStepFrac = args.optionLookupOrDefault("relStepFrac", 0.5);
     prm.minEdgeLength = minEdgeLength;
@@ -518,7 +518,7 @@ int main(int argc, char *argv[])
         checkHip(hipMalloc(&sendF, nS * sizeof(int32_t)));
         checkHip(hipMalloc(&recvF, nR * sizeof(int32_t)));
         checkHip(hipMalloc(&localStats, 2 * sizeof(double)));
-        smgpu_halo_desc hd;
+        smgpu_halo_desc hd = {};      // (every field zero: fields added to the struct later stay defined)
         hd.nShared = int32_t(halo.sharedLocal.size()); hd.sharedLocal = halo.sharedLocal.data();
         hd.nSend = halo.nSend; hd.sendShared = halo.sendShared.data();
         hd.nRecv = halo.nRecv; hd.combOffsets = halo.combOffsets.data(); hd.combSlots = halo.combSlots.data();
@@ -531,7 +531,7 @@ int main(int argc, char *argv[])
     // ---- boundary layer treatment, SM.C:2024-2035, 2186-2221 ----------------------------------
     bool doLayerTreatment = false;
     const PatchTable layerTable(patchTable(mesh, layerPatchIds));
-    smgpu_layer_desc ld;
+    smgpu_layer_desc ld = {};      // (every field zero: fields added to the struct later stay defined)
     ld.nPatches = layerTable.start.size(); ld.patchStart = layerTable.start.begin(); ld.patchSize = layerTable.size.begin();
     ld.patchKind = layerTable.kind.begin(); ld.isLayerPatch = layerTable.selected.begin();
     ld.layerMaxBlendingFraction = layerMaxBlendingFraction;
@@ -613,7 +613,8 @@ int main(int argc, char *argv[])
         (smoothingPatchIds.size() > 0))
     {
         // the contents of the three files as flat arrays (SM.C:2131-2160)
-        triSurface surf(fileName(targetSurfacesFileString));
+        const fileName surfFile(targetSurfacesFileString);      // (a named object: `triSurface surf(fileName(x));` declares a function)
+        triSurface surf(surfFile);
         List<double> surfPts(3 * surf.points().size());
         forAll(surf.points(), i) { surfPts[3*i] = surf.points()[i].x(); surfPts[3*i+1] = surf.points()[i].y(); surfPts[3*i+2] = surf.points()[i].z(); }
         labelList surfTris(3 * surf.size());
@@ -622,7 +623,8 @@ int main(int argc, char *argv[])
         labelList ieEdges, teEdges;
         if (fileExists(initEdgesFileString))
         {
-            edgeMesh em(fileName(initEdgesFileString));
+            const fileName emFile(initEdgesFileString);
+            edgeMesh em(emFile);
             iePts.setSize(3 * em.points().size());
             forAll(em.points(), i) { iePts[3*i] = em.points()[i].x(); iePts[3*i+1] = em.points()[i].y(); iePts[3*i+2] = em.points()[i].z(); }
             ieEdges.setSize(2 * em.edges().size());
@@ -630,14 +632,15 @@ int main(int argc, char *argv[])
         }
         if (fileExists(targetEdgesFileString))
         {
-            edgeMesh em(fileName(targetEdgesFileString));
+            const fileName emFile(targetEdgesFileString);
+            edgeMesh em(emFile);
             tePts.setSize(3 * em.points().size());
             forAll(em.points(), i) { tePts[3*i] = em.points()[i].x(); tePts[3*i+1] = em.points()[i].y(); tePts[3*i+2] = em.points()[i].z(); }
             teEdges.setSize(2 * em.edges().size());
             forAll(em.edges(), i) { teEdges[2*i] = em.edges()[i].start(); teEdges[2*i+1] = em.edges()[i].end(); }
         }
         const PatchTable smoothTable(patchTable(mesh, smoothingPatchIds));
-        smgpu_boundary_desc bd;
+        smgpu_boundary_desc bd = {};      // (every field zero: fields added to the struct later stay defined)
         bd.nPatches = smoothTable.start.size(); bd.patchStart = smoothTable.start.begin(); bd.patchSize = smoothTable.size.begin();
         bd.patchKind = smoothTable.kind.begin(); bd.isSmoothingPatch = smoothTable.selected.begin();
         bd.nInitEdgePoints = iePts.size() / 3; bd.initEdgePoints = iePts.begin();
@@ -650,7 +653,7 @@ int main(int argc, char *argv[])
         bd.isFeatureEdgePointIO = labelIOListsHaveData ? isFeatureEdgePointIO.begin() : nullptr;
         bd.distanceTolerance = distanceTolerance;
         bd.internalSmoothingBlendingFraction = internalSmoothingBlendingFraction;
-        smgpu_boundary_info bi;
+        smgpu_boundary_info bi = {};      // (every field zero: fields added to the struct later stay defined)
         if (!Pstream::parRun())
         {
             check(smgpu_set_boundary_smoothing(h, &bd, &bi));

@@ -93,9 +93,12 @@ def test_cavity100_matches_oracle(oracle_lib, constraints):
 
 
 def test_cavity215c_matches_oracle(oracle_lib, cavity215):
-    """configs[3] itself: the 10 M-cell polyhedral mesh, constraints on -- two iterations on both sides (the second one starts
-    from coordinates, frozen marks and generation tags the first one left), then one more with the constraints off on the
-    same engine / oracle pair (parameters changed mid-run: the fused kernel path at 40 k tiles)."""
+    """configs[3] itself: the 10 M-cell polyhedral mesh, constraints on -- TWELVE iterations on both sides, compared after 1, 2, 6
+    and 12 (the components of the freeze walk's interaction graph start tiny and percolate within ten iterations: the causal
+    fixed-point replay, its warm start from the previous iteration and the mid-run change of the replay form are checked against
+    the oracle at configs[3]'s own size, not against the host replay), then one more with the constraints off on the same
+    engine / oracle pair (parameters changed mid-run: the fused kernel path at 40 k tiles).  The oracle costs ~50 s of set-up and
+    ~15-30 s per constrained iteration."""
     from smoothmesh_amd import SmoothEngine, default_params
     mesh = cavity215
     assert mesh.nCells > 9_500_000
@@ -104,12 +107,18 @@ def test_cavity215c_matches_oracle(oracle_lib, cavity215):
     try:
         p = default_params(o.mesh_stats()[0])
         o.set_params(p); e.set_params(p)
-        for it in range(2):
-            n_o, res_o, frz_o = o.iterate(1, 0.0)
-            n_g, res_g, frz_g = e.iterate(1, 0.0)
-            assert np.array_equal(frz_o, frz_g), (it, frz_o, frz_g)
-            assert rel_linf(e.get_points(), o.points()) <= COORD_TOL, it
-        assert frz_g[0] > 500_000
+        done, series = 0, []
+        for chunk in (1, 1, 4, 6):
+            n_o, res_o, frz_o = o.iterate(chunk, 0.0)
+            n_g, res_g, frz_g = e.iterate(chunk, 0.0)
+            done += chunk
+            assert n_o == n_g == chunk
+            assert np.array_equal(frz_o, frz_g), (done, frz_o, frz_g)
+            assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
+            assert rel_linf(e.get_points(), o.points()) <= COORD_TOL, done
+            series += [int(x) for x in frz_g]
+        assert done == 12 and series[0] > 500_000 and series[-1] != series[0]
+        assert np.array_equal(e.get_points(), o.points())                     # measured: bit-equal
         p2 = default_params(o.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False)
         o.set_params(p2); e.set_params(p2)
         n_o, res_o, frz_o = o.iterate(1, 0.0)
