@@ -202,13 +202,13 @@ KERNEL_UNITS = [
 ]
 
 
-def kernel_report(workload, ctr, K, dt, dt_ev):
+def kernel_report(workload, ctr, K, dt, dt_ev, sizes=None):
     """roofline objects + per-kernel table from the hipEvent counters of the second pass"""
     # HBM traffic per launch, measured separately under rocprofv3 --pmc (scripts/measure_traffic.sh) and
     # committed under profiles/; None when no measurement of this workload exists
     traffic = None
     tdoc = None
-    for rnd in ("r3", "r2", "r1"):
+    for rnd in ("r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{workload}.json")
         if os.path.exists(tpath):
             tdoc = json.load(open(tpath))
@@ -250,8 +250,13 @@ def kernel_report(workload, ctr, K, dt, dt_ev):
                 if kname.split("<")[0] == dom["name"].split("<")[0].replace("k_smooth", "k_smooth_tile"):
                     traffic = int(2 * kv["FETCH_SIZE_KB"] * 1024 + kv["WRITE_SIZE_KB"] * 1024)
                     roofline["traffic_source"] = f"profiles/{tdoc['_round']}/traffic_{workload}.json"
+                    # NOT measured by this run: a committed measurement of the same kernel on the same workload
+                    roofline["traffic_measured_by"] = ("builder, round " + tdoc["_round"][1:] + ", rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes "
+                                                       "(scripts/measure_traffic.sh; FETCH_SIZE x 2 on gfx950), read from the committed file -- "
+                                                       "not re-measured in this run")
         roofline["traffic"] = traffic
-        roofline["note"] = ("per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps; "
+        roofline["note"] = ("per-kernel durations from hipEvents on the engine's stream in a second pass over the same K steps, every kernel "
+                            "ALONE on the chip (the side streams are off in that pass); "
                             "meshes whose working set is < 256 MiB (e.g. 100^3) are Infinity-Cache resident: read their fraction as "
                             "cache-level throughput, not as an HBM-roofline test; valu_f64 = the rate of ALGORITHMIC FP64 instructions "
                             "(sqrt = 22, division = 11 as expanded, no FMA contraction) against 256 CUs x 64 lanes x 2.4 GHz")
@@ -275,10 +280,44 @@ def kernel_report(workload, ctr, K, dt, dt_ev):
                      **({"algo_f64_Tops": c["algoF64OpsPerLaunch"] / (us(c) * 1e-6) / 1e12} if c.get("algoF64OpsPerLaunch") else {}),
                      "_ms": c["ms"]})
     rows.sort(key=lambda r: -r.pop("_ms"))
+    # The centroid-gather kernel (BASELINE.json's 40 % target) with BOTH byte accountings: the fused kernel's own algorithmic bytes
+    # (centroid gather + closest points + clamp + edge-length freeze: K_cg + K_prop's lists) and SURVEY 8(d)'s K_cg bytes alone
+    # (4(P+1) + 4 nnz_pc + 24 C + 24 P + P + 24 P) -- the fused kernel does all of K_cg's traffic and more in that time, so the
+    # K_cg-only figure is a lower bound of what a kernel doing only K_cg would reach.
+    gather_obj = None
+    if gather is not None:
+        gather_obj = {**roof(gather), "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names), timed alone"}
+        if sizes:
+            P_, C_, npc = int(sizes["nPoints"]), int(sizes["nCells"]), int(sizes["nnzPointCells"])
+            kcg = 4 * (P_ + 1) + 4 * npc + 24 * C_ + 24 * P_ + P_ + 24 * P_
+            ach = kcg / (us(gather) * 1e-6) / 1e9
+            gather_obj["accountings"] = {
+                "fused (this kernel's algorithmic bytes)": {"bytes_per_launch": int(gather["algoBytesPerLaunch"]), "achieved_GBps": gather_obj.get("achieved"),
+                                                           "frac": gather_obj.get("frac")},
+                "K_cg only (SURVEY 8d)": {"bytes_per_launch": int(kcg), "achieved_GBps": ach, "frac": ach / HBM_PEAK_GBS}}
+    # Constraints on: the iteration is two chains that run side by side between the geometry kernel and the freeze walk -- the
+    # main stream (proposal, edge-angle evaluator) and the side stream (face-angle filter, list compaction, exact pass of the
+    # current coordinates).  Their kernels were timed alone; an iteration costs at least the longer chain plus the serial part.
+    by = {c["name"]: us(c) for c in ctr}
+    side_names = ["k_fa_edges_filter", "k_fa_edges", "k_fa_points"]
+    main_par = ["k_smooth<proposal>", "k_edge_angle_filter", "k_edge_angle"]
+    chains = None
+    if any(n in by for n in side_names):
+        side = sum(by.get(n, 0.0) for n in side_names)
+        mainp = sum(by.get(n, 0.0) for n in main_par)
+        serial = sum(v for n, v in by.items() if n not in side_names and n not in main_par)
+        chains = {"unit": "us per iteration, every kernel timed alone",
+                  "serial_part": {n: by[n] for n in by if n not in side_names and n not in main_par}, "serial_part_us": serial,
+                  "main_stream_chain": {n: by[n] for n in main_par if n in by}, "main_stream_chain_us": mainp,
+                  "side_stream_chain": {n: by[n] for n in side_names if n in by}, "side_stream_chain_us": side,
+                  "sum_all_alone_us": serial + mainp + side, "critical_path_us": serial + max(mainp, side),
+                  "ms_per_step_measured": dt / K * 1e3,
+                  "note": "ms_per_step (both chains side by side) lies between critical_path_us and sum_all_alone_us: kernels that share "
+                          "the chip slow each other down (both chains are FP64-issue bound)"}
     return {
         "roofline": roofline,
-        "roofline_centroid_gather": None if gather is None else {
-            **roof(gather), "note": "the fused centroid-gather + proposal kernel (the kernel BASELINE.json's 40 % target names)"},
+        "roofline_centroid_gather": gather_obj,
+        **({"chains": chains} if chains else {}),
         "kernels": rows,
         "ms_per_step_with_events": dt_ev / K * 1e3,
     }
@@ -680,7 +719,7 @@ def main():
                     "n_gpus": world, "points": int(rc["total_points"]), "points_per_gpu": int(rc["sizes"]["nPoints"]), "cells_per_gpu": int(rc["sizes"]["nCells"]),
                     "steps": Kc, "ms_per_step": rc["dt"] / Kc * 1e3, "value": rc["total_points"] * Kc / rc["dt"], "unit": "points/s",
                     "parallelism": rc["parallelism"], "rccl": rc["transport"],
-                    **kernel_report(wl, rc["ctr"], Kc, rc["dt"], rc["dt_ev"]),
+                    **kernel_report(wl, rc["ctr"], Kc, rc["dt"], rc["dt_ev"], rc["sizes"]),
                     "residual_last": float(rc["res"][-1]), "nFrozenPoints_last": int(rc["frz"][-1]), "phases": rc["phases"],
                 }
                 if rc["parity_check"]:
@@ -720,7 +759,7 @@ def main():
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
             "parallelism": parallelism,
         },
-        **kernel_report(args.workload, ctr, K, dt, dt_ev),
+        **kernel_report(args.workload, ctr, K, dt, dt_ev, sizes),
         "residual_last": float(res[-1]), "nFrozenPoints_last": int(frz[-1]),
         "parity": "HIP == CPU oracle (tests/); the oracle restates the reference and is unpinned against a real OpenFOAM build",
     }
@@ -758,7 +797,7 @@ def main():
                     "points": int(r["total_points"]), "cells": int(r["sizes"]["nCells"]), "steps": Kc,
                     "ms_per_step": r["dt"] / Kc * 1e3, "ms_per_step_cold": r["dt_cold"] / Kc * 1e3,
                     "value": r["total_points"] * Kc / r["dt"], "unit": "points/s",
-                    **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"]),
+                    **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"], r["sizes"]),
                     "residual_last": float(r["res"][-1]), "nFrozenPoints_last": int(r["frz"][-1]),
                     "phases": r["phases"],
                 }

@@ -12,4 +12,14 @@ for line in sys.stdin:
     d = json.loads(line)
     print(f"{d['config']['workload'][:60]}...  value={d['value']/1e9:.3f} Gpts/s  ms/step={d['ms_per_step']:.4f}  (with events {d['ms_per_step_with_events']:.4f})")
     for k in d["kernels"]:
-        print(f"   {k['name']:22s} {k['avg_us']:9.1f} us  {k['algo_GBps']:8.1f} GB/s algorithmic")
+        gb = f"{k['algo_GBps']:8.1f} GB/s algorithmic" if k.get("algo_GBps") else (f"{k['algo_f64_Tops']:8.2f} T FP64 instr/s algorithmic" if k.get("algo_f64_Tops") else "")
+        print(f"   {k['name'][:40]:40s} {k['avg_us']:9.1f} us  {gb}")
+        for kn, kv in (k.get("kernels") or {}).items():
+            print(f"        {kn:35s} {kv:9.1f} us")
+    ch = d.get("chains")
+    if ch:
+        print(f"   chains (us, kernels timed alone): serial {ch['serial_part_us']:.0f}  main {ch['main_stream_chain_us']:.0f}  side {ch['side_stream_chain_us']:.0f}  "
+              f"critical path {ch['critical_path_us']:.0f}  sum {ch['sum_all_alone_us']:.0f}  measured step {ch['ms_per_step_measured'] * 1e3:.0f}")
+    g = d.get("roofline_centroid_gather") or {}
+    for name, a in (g.get("accountings") or {}).items():
+        print(f"   centroid gather, {name}: {a['achieved_GBps']:.0f} GB/s = {a['frac']:.3f} of the HBM peak")

@@ -298,7 +298,8 @@ struct StarLds {
     unsigned char role[kStarVerts];      // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
     double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
     unsigned char nb[kStarEnts];
-    unsigned touch[kStarEnts];           // bit i: ring place (lane) i is touched by the move of entry e's neighbour
+    signed char job[2 * kStarEnts + 2];  // the jobs that are needed, in order: -1 = the self test, e = entry e with p at its current
+                                         // position, 64 + e = entry e with p at its proposal
     double pc[3], pn[3], pMin, pMax;     // the half wave's point: current and proposed coordinates, ptMin / ptMax
     int eq[kStarEnts];                   // entry e's neighbour (point id)
     double ex[kStarEnts], ey[kStarEnts];
@@ -439,7 +440,6 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         }
         if (live && hl == 0) L.voff[nF] = totalV;
         if (live && hl < nEnt) L.eq[hl] = q;
-        L.touch[hl] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // this lane's ring place
@@ -510,128 +510,63 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         if (P.valid) for (int l = 0; l < nF; ++l) if (L.fid[l] == rf) P.l = l;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        // the slot of the edge's other end point in this lane's ring face (it is a vertex of every face of the ring); the entries
-        // whose neighbour's move TOUCHES this place: the edge's own entry, and every other neighbour of p in one of the place's two
-        // ring faces (the face vectors and the edge vector are the only things a neighbour's move changes, SM.C:1155-1200).  A lane
-        // keeps its (at most four) touching entries; the places an entry touches are collected as a lane mask per entry.
-        const int lNext = __shfl(P.l, P.nextLane, 32);
-        unsigned tl = 0xFFFFFF00u | (unsigned)(P.xEnt & 0xFF);     // byte k: the k-th touching entry, 0xFF none
-        bool tooMany = false;
-        if (P.valid) {
-            int nt = 1;
-            atomicOr(&L.touch[P.xEnt], 1u << hl);
-#pragma unroll
-            for (int side = 0; side < 2; ++side) {
-                const int l = side ? lNext : P.l;
-                for (int i = L.voff[l]; i < L.voff[l + 1]; ++i) {
-                    const unsigned r = L.role[i];
-                    if (side == 0 && r == (unsigned)P.xEnt) P.xSlot = i;
-                    if (r >= (unsigned)kStarEnts || r == (unsigned)P.xEnt) continue;
-                    bool have = false;
-                    for (int k = 1; k < nt; ++k) have = have || (((tl >> (8 * k)) & 0xFFu) == r);
-                    if (have) continue;
-                    if (nt == 4) { tooMany = true; continue; }
-                    tl = (tl & ~(0xFFu << (8 * nt))) | (r << (8 * nt));
-                    ++nt;
-                    atomicOr(&L.touch[r], 1u << hl);
-                }
-            }
+        if (P.valid) {       // the slot of the edge's other end point in this lane's ring face (it is a vertex of every face of the ring)
+            for (int i = L.voff[P.l]; i < L.voff[P.l + 1]; ++i) if (L.role[i] == P.xEnt) P.xSlot = i;
         }
-        if ((unsigned)(__ballot(tooMany) >> (32 * half)) != 0u) {   // (a face through p with chords to other neighbours of p: never seen; the gather form takes it)
-            if (live && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }
-            live = false;
-            P.valid = false;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
         const bool counts = P.valid && P.hasCell;
-        // Steps (round 4).  A job = one predicate: the self test (p at its proposal), or entry e's neighbour at its proposal with p at
-        // its current position / at its proposal.  Round 3 ran one job per step on all ring places -- but the move of ONE neighbour
-        // touches about half of them (12 of an interior hex point's 24), and what it does not touch cannot decide the job: with p at its
-        // current position an untouched pair has its current angle, which is >= ptMin and <= ptMax by definition (SM.C:938-975), so
-        // only touched pairs can make `new < current` true (SM.C:1421-1427); with p at its proposal an untouched pair has exactly the
-        // angle the self test found for it.  So entries whose touched places are DISJOINT share a step: every place evaluates the
-        // entry that touches it (an interior hex point: its six neighbours in three steps per state, opposite neighbours together),
-        // the per-entry min / max are segment reductions.  Entries are coloured greedily (lane c keeps the places of colour c); a
-        // lane's face vector serves its ring neighbour under either entry: if the neighbour's entry changed that face, the lane would
-        // be touched by it too.  Same arithmetic per evaluated pair, hence the same bits.
+        // Jobs, one per step and half wave, ONE call site for all of them (a job's state is data, not control flow).  Job codes:
+        // -1 the self test (p at its proposal), e = entry e with p at its current position, 64 + e = entry e with p at its
+        // proposal.  Only jobs whose result can be consulted are listed: the self test of a point that moves and is still free,
+        // the entries of the neighbours that are free and moving; the proposal-state jobs are appended after the first step,
+        // once the self test has told whether p can act from its proposal at all (it is only read if p is still free at its
+        // first visit and does not freeze itself, SM.C:1376-1399).
+        // (Round 4, measured and removed: entries whose TOUCHED ring places are disjoint sharing a step -- the move of one
+        // neighbour touches about half of a star's places, an untouched pair keeps its current angle resp. the self test's, so
+        // opposite neighbours of a hex point can be evaluated side by side, exactly.  All tests bit-equal, but on the refinement
+        // interfaces that make up the active set a point has 2-4 eligible neighbours and they are ADJACENT, their places overlap:
+        // the colouring saved no steps -- 348 M against 328 M VALU wave instructions per launch on the 10 M-cell cavity mesh,
+        // profiles/r4/pmc_k_walk_pred_star.txt -- and cost 5 %.)
         unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
         const bool selfNeeded = live && moved && !frozenBefore;
-        eligible = eligible && live;
         const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
         const int nEl = __popc(elig), first = selfNeeded ? 1 : 0;
-        int myCol = -1, nCol = 0;
-        {
-            const unsigned Te = (hl < nEnt && live) ? L.touch[hl] : 0u;
-            unsigned U = 0u;                                         // lane c: the places of the entries coloured c
-            const unsigned long long anyElig = __ballot(eligible);
-            const unsigned both = (unsigned)(anyElig | (anyElig >> 32));   // (wave-uniform trip count: entries eligible in either half)
-            for (int e = 0; e < kStarEnts; ++e) {
-                if (!((both >> e) & 1u)) continue;
-                const bool on = (elig >> e) & 1u;
-                const unsigned Tcur = (unsigned)__shfl((int)Te, e, 32);
-                const unsigned fb = (unsigned)(__ballot(on && (U & Tcur) == 0u) >> (32 * half));
-                const int c = __ffs((int)fb) - 1;                    // (32 lanes, at most 32 entries: a free colour exists)
-                if (on && hl == c) U |= Tcur;
-                if (on && hl == e) myCol = c;
-            }
-            nCol = __popc((unsigned)(__ballot(U != 0u) >> (32 * half)));   // colours are taken lowest first: 0 .. nCol - 1
-        }
-        unsigned tc = 0xFFFFFFFFu;                                   // byte k: the colour of my k-th touching entry (0xFF: none / not eligible)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const unsigned e = (tl >> (8 * k)) & 0xFFu;
-            const int ce = __shfl(myCol, (int)(e & 31u), 32);
-            if (e != 0xFFu && ce >= 0) tc = (tc & ~(0xFFu << (8 * k))) | ((unsigned)ce << (8 * k));
-        }
-        double selfAngle = 0.0;
-        int nSteps = live ? first + nCol : 0, nJobsAlg = live ? first + nEl : 0;
-        for (int st = 0; st < nSteps; ++st) {
-            const bool isSelf = st < first;
-            const int k0 = st - first;
-            const bool atProp = !isSelf && k0 >= nCol;
-            const int c = isSelf ? -1 : (atProp ? k0 - nCol : k0);   // this step's colour
-            int ei = (int)kRoleNoEntry;                              // the entry this place evaluates: the one of colour c that touches it
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if ((int)((tc >> (8 * k)) & 0xFFu) == c) ei = (int)((tl >> (8 * k)) & 0xFFu);
-            const double* pc = (isSelf || atProp) ? L.pn : L.pc;     // where the point is in this step
+        const int myRank = __popc(elig & ((1u << hl) - 1u));
+        if (eligible) L.job[first + myRank] = (signed char)hl;
+        if (hl == 0 && selfNeeded) L.job[0] = -1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int nJobs = live ? first + nEl : 0;
+        for (int j = 0; j < nJobs; ++j) {
+            const int code = (int)L.job[j];
+            const bool isSelf = code < 0, atProp = code >= 64;
+            const int ei = isSelf ? 0 : (code & 63);                 // entry of this job
+            const double* pc = (isSelf || atProp) ? L.pn : L.pc;     // where the point is in this job
             const V3 c1 = v3(pc[0], pc[1], pc[2]);
-            const int eix = ei & (kStarEnts - 1);
-            const V3 c2 = v3(L.ex[eix], L.ey[eix], L.ez[eix]);       // (unused when ei = kRoleNoEntry: no slot has that role)
-            const double angle = starLaneAngle(L, P, c1, ei, c2);
+            const V3 c2 = v3(L.ex[ei], L.ey[ei], L.ez[ei]);          // (not used by the self test: no slot has the role kRoleNoEntry)
+            const double angle = starLaneAngle(L, P, c1, isSelf ? (int)kRoleNoEntry : ei, c2);
+            double mn, mx;
+            starReduce(counts, angle, mn, mx);
             const double curMin = L.pMin, curMax = L.pMax;
-            if (isSelf) {
-                selfAngle = angle;
-                double mn, mx;
-                starReduce(counts, angle, mn, mx);
-                const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1391-1399
-                if (isBad) sbits |= 1u;                              // (the reduction leaves mn / mx in every lane of the half)
-            } else {
-                unsigned cm = (unsigned)(__ballot(eligible && myCol == c) >> (32 * half));   // the entries of this step
-                while (cm) {
-                    const int e = __ffs((int)cm) - 1;
-                    cm &= cm - 1u;
-                    const bool sel = (ei == e);
-                    double mn, mx;
-                    // p at its current position: the touched pairs only; at its proposal: the others keep the self test's angle
-                    starReduce(atProp ? counts : (counts && sel), (sel || !atProp) ? angle : selfAngle, mn, mx);
-                    const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1421-1427
-                    if (hl == 0 && isBad) {
-                        unsigned char v = L.nb[e];
-                        if (atProp) v |= 1;
-                        else v |= moved ? 2 : 3;                     // not moved: proposal = current position
-                        L.nb[e] = v;
-                    }
+            const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1391-1399, 1421-1427
+            if (j == 0) {
+                if (selfNeeded && isBad) sbits |= 1u;                // (the reduction leaves mn / mx in every lane of the half)
+                if (moved && !(sbits & 5u) && nEl > 0) {             // p can act from its proposal: the proposal-state jobs
+                    if (eligible) L.job[nJobs + myRank] = (signed char)(64 + hl);
+                    nJobs += nEl;
                 }
             }
-            if (st == 0 && moved && !(sbits & 5u) && nEl > 0) {      // p can act from its proposal (SM.C:1376-1399): the proposal-state steps
-                nSteps += nCol;
-                nJobsAlg += nEl;
+            if (!isSelf && hl == 0) {
+                unsigned char v = L.nb[ei];
+                if (atProp) { if (isBad) v |= 1; }
+                else {
+                    if (isBad) v |= 2;
+                    if (isBad && !moved) v |= 1;                     // not moved: proposal = current position
+                }
+                L.nb[ei] = v;
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
         }
-        const int nJobs = nJobsAlg;       // (the timing pass counts the reference's jobs, not the steps they were packed into)
         if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
         if (opCount) {
             // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs, by the reference's arithmetic

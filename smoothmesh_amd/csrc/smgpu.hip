@@ -133,6 +133,7 @@ struct smgpu_handle {
     bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
+    bool faRing = true;        // SMGPU_FA_RING=0: the listed edges' exact face angles by one thread per edge (k_fa_edges_list) instead of one lane per ring place
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
@@ -480,6 +481,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
+    h->faRing = envInt("SMGPU_FA_RING", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
@@ -625,9 +627,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + (size_t)(SMGPU_GEOM_AOS ? kGF : 6) * (size_t)g.maxFaces);
             h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
             if (envInt("SMGPU_VERBOSE", 0))
-                std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
-                             h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, h->smoothT, h->stl.nTiles, h->smoothLds,
-                             v.maxCells, v.maxPoints);
+                std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d; staged faces x%.3f, points x%.3f of the mesh's)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
+                             h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, (double)h->gt.tfIds.size() / std::max(1, t.nFaces),
+                             (double)h->gt.tpIds.size() / std::max(1, t.nPoints), h->smoothT, h->stl.nTiles, h->smoothLds, v.maxCells, v.maxPoints);
         }
     }
     {
@@ -915,7 +917,7 @@ static int launchBndPre(smgpu_handle* h, const MeshView& m, const State& s, hipS
 // a side stream while the geometry kernel has the main one; runSmooth joins.
 static int runBndPre(smgpu_handle* h) {
     if (h->bndOn && h->bndInGeom && h->useTiles && h->bv.nB > 0) return 0;   // they ride in the geometry launch (k_geom_tile_bnd)
-    if (!h->bndOn || !h->bndSide || h->bndPreInFlight) return 0;
+    if (!h->bndOn || !h->bndSide || h->bndPreInFlight || h->timing) return 0;   // (timing passes: every kernel alone, see forkFaFilter)
     if (depSignal(h, DEP_BND_FORK, h->stream, h->evBndFork) || depWait(h, DEP_BND_FORK, h->bndSide, h->evBndFork)) return 1;
     if (launchBndPre(h, h->mv, h->st, h->bndSide)) return 1;
     if (depSignal(h, DEP_BND_JOIN, h->bndSide, h->evBndJoin)) return 1;
@@ -1256,7 +1258,8 @@ static int runFaExactPass(smgpu_handle* h, const State& s, const uint8_t* faMayb
         if (launchK(h, K_FA_EDGES, [&] {
                 hipLaunchKernelGGL(k_fa_list_count, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
                 hipLaunchKernelGGL(k_fa_list_fill, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
-                hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
+                if (h->faRing) hipLaunchKernelGGL(k_fa_edges_ring, dim3(256 * 8), dim3(kBlock), 0, stream, m, s);   // one lane per ring place
+                else hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
             }, stream)) return 1;
         return launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, stream, m, s, prm); }, stream);
     }
@@ -1268,6 +1271,9 @@ static int runFaExactPass(smgpu_handle* h, const State& s, const uint8_t* faMayb
 // launch the face-angle filter (needs only the geometry of the current coordinates) on the side stream
 static int forkFaFilter(smgpu_handle* h) {
     if (!h->side || !h->prm.faceAngleConstraint || !h->useFilter || h->exactAll || !h->edgeTilesOk || h->faFilterInFlight) return 0;
+    // per-kernel timing passes run every kernel ALONE on the main stream: a duration measured while another stream's kernel
+    // shares the chip is no kernel time (round 3's table priced the proposal kernel at 0.17 of the peak that way)
+    if (h->timing) return 0;
     const MeshView& m = h->mv;
     const Prm prm = makePrm(h);
     if (depSignal(h, DEP_FORK, h->stream, h->evFork) || depWait(h, DEP_FORK, h->side, h->evFork)) return 1;
