@@ -38,16 +38,30 @@ int main(int argc, char** argv) {
     ok += std::fread(internal.data(), 1, internal.size(), f);
     std::fclose(f);
     (void)ok;
+    // As smgpu_create pipelines it (smgpu.hip): the geometry tile tables start from Topology::build's afterCells hook, the smoothing
+    // tile tables from its afterPoints hook, both next to the rest of the addressing -- so that ThreadSanitizer and the checksum
+    // comparison (tests/test_host_sanitizers.py) cover the overlapped path: a later edit that writes a member a hook's reader
+    // still uses (maxFaceSize, pointPoints ...) shows up as a race or as a changed checksum.  SETUP_BENCH_PIPELINED=0: one after
+    // the other (the A/B the checksums are compared with).
+    const bool pipelined = !(std::getenv("SETUP_BENCH_PIPELINED") && std::atoi(std::getenv("SETUP_BENCH_PIPELINED")) == 0);
     Topology t;
-    double t0 = now();
-    const std::string e = t.build(nP, nC, nF, nIF, fo.data(), fp.data(), own.data(), nei.data());
-    double t1 = now();
-    if (!e.empty()) { std::printf("error %s\n", e.c_str()); return 1; }
-    std::fprintf(stderr, "addressing %.2f s\n", t1 - t0);
     GeomTiles gt; SmoothTiles st; EdgeTiles et;
-    auto fG = std::async(std::launch::async, [&] { return gt.build(t, pts.data(), true, 256, 128, 768, 512); });
+    std::future<std::string> fG, fS;
+    double t0 = now();
+    const std::string e = pipelined
+        ? t.build(nP, nC, nF, nIF, fo.data(), fp.data(), own.data(), nei.data(),
+                  [&] { fG = std::async(std::launch::async, [&] { return gt.build(t, pts.data(), true, 256, 128, 768, 512); }); },
+                  [&] { fS = std::async(std::launch::async, [&] { return st.build(t, pts.data(), internal.data(), true, 256, 512, 768); }); })
+        : t.build(nP, nC, nF, nIF, fo.data(), fp.data(), own.data(), nei.data());
+    double t1 = now();
+    if (!e.empty()) { if (fG.valid()) fG.wait(); if (fS.valid()) fS.wait(); std::printf("error %s\n", e.c_str()); return 1; }
+    std::fprintf(stderr, "addressing %.2f s%s\n", t1 - t0, pipelined ? " (tile tables started from its hooks)" : "");
+    if (!pipelined) {
+        fG = std::async(std::launch::async, [&] { return gt.build(t, pts.data(), true, 256, 128, 768, 512); });
+        fS = std::async(std::launch::async, [&] { return st.build(t, pts.data(), internal.data(), true, 256, 512, 768); });
+    }
     auto fE = std::async(std::launch::async, [&] { return et.build(t, pts.data(), true, 256, 512, 768, 512); });
-    const std::string e2 = st.build(t, pts.data(), internal.data(), true, 256, 512, 768);
+    const std::string e2 = fS.get();
     const std::string e1 = fG.get(), e3 = fE.get();
     double t2 = now();
     std::fprintf(stderr, "tiles %.2f s (%s|%s|%s)\n", t2 - t1, e1.c_str(), e2.c_str(), e3.c_str());

@@ -901,84 +901,10 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges_list(MeshView m, State s) {
     for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) faEdgeExact(m, s, s.faEdgeList[i]);
 }
 
-// The same job with one lane per RING PLACE (round 4).  A thread walking one edge's ring is a chain of dependent gathers per ring
-// face (list -> edge -> ring face -> vertex row -> coordinates), four to eight faces one after the other: 574 us for the ~600 k
-// listed edges of the 10 M-cell cavity mesh, for ~20 us worth of arithmetic.  Here a wave takes up to 16 consecutive listed edges
-// whose rings fit its 64 lanes (an inclusive scan of the ring lengths; what does not fit starts the next round), lane (edge j,
-// place i) forms ring face i's projected centre vector and cell i's, takes ring face i + 1's from the next lane (the ring's first
-// lane behind the last place), and min / max are reduced over the edge's lanes by a segmented shuffle reduction.  The arithmetic
-// per (edge, cell) pair is faEdgeExact's, operation for operation (min / max do not depend on the order); edges with a
-// non-manifold ring or more than 32 ring faces are done by one lane the plain way.
-constexpr int kRingBatch = 16;
-__global__ void __launch_bounds__(kBlock) k_fa_edges_ring(MeshView m, State s) {
-    if (s.acc->stop) return;
-    const int n = s.acc->nFaEdges;
-    const int lane = threadIdx.x & 63;
-    const int nWaves = gridDim.x * (kBlock / 64), wave = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-    const int per = (n + nWaves - 1) / nWaves;
-    int pos = wave * per;
-    const int end = (pos + per < n) ? pos + per : n;
-    while (pos < end) {                                            // (wave-uniform)
-        int e = -1, nf = 0, nc = 0, fb = 0, cb = 0;
-        bool coop = false;
-        if (lane < kRingBatch && pos + lane < end) {
-            e = s.faEdgeList[pos + lane];
-            fb = m.efOff[e]; nf = m.efOff[e + 1] - fb;
-            cb = m.ecOff[e]; nc = m.ecOff[e + 1] - cb;
-            coop = m.edgeRingOk[e] && nf <= 32;
-        }
-        const int need = coop ? nf : 0;
-        int incl = need;
-        for (int o = 1; o < kRingBatch; o <<= 1) {
-            const int t = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += t;
-        }
-        // the longest run of candidates from lane 0 whose places fit the wave (incl is monotone, so the fitting lanes are a prefix)
-        const unsigned long long fits = __ballot(e >= 0 && incl <= 64);
-        const int take = __ffsll((long long)~fits) - 1;            // >= 1: the first candidate needs at most 32 lanes
-        const int total = __shfl(incl, take - 1, 64);
-        if (lane < take && !coop) faEdgeExact(m, s, e);            // the few the cooperative form does not take
-        int jj = -1, first = 0;
-        for (int k = 0; k < take; ++k) {
-            const int hi = __shfl(incl, k, 64), nk = __shfl(need, k, 64);
-            if (jj < 0 && nk > 0 && lane < hi) { jj = k; first = hi - nk; }
-        }
-        const bool valid = jj >= 0 && lane < total;
-        const int src = valid ? jj : 0;
-        const int eE = __shfl(e, src, 64), eFb = __shfl(fb, src, 64), eNf = __shfl(nf, src, 64), eCb = __shfl(cb, src, 64), eNc = __shfl(nc, src, 64);
-        V3 fv = v3(0, 0, 0), cV = v3(0, 0, 0);
-        bool counts = false;
-        if (valid) {
-            const int i = lane - first;
-            const V3 e0 = ldv(s.ptsCur, m.edges[2 * eE]), e1 = ldv(s.ptsCur, m.edges[2 * eE + 1]);
-            const V3 cC = 0.5 * (e0 + e1);
-            const V3 d = e1 - e0;
-            const V3 eVec = d / mag(d);
-            auto project = [&](const V3& c) -> V3 {   // SM.C:1189-1196 / 1219-1223
-                const V3 cf = cC - c;
-                const double dp = dot(cf, eVec);
-                const V3 pC = c + dp * eVec;
-                const V3 w = pC - cC;
-                return w / mag(w);
-            };
-            fv = project(faceAverage(m, s, m.ringFace[eFb + i]));
-            counts = i < eNc;
-            if (counts) cV = project(ldv(s.cellCtr, m.ringCell[eCb + i]));   // mesh.C()[cellI], SM.C:1218
-        }
-        const int nextLane = valid ? ((lane - first + 1 < eNf) ? lane + 1 : first) : lane;   // closed ring: the last cell ends at face 0
-        const V3 fn = v3(__shfl(fv.x, nextLane, 64), __shfl(fv.y, nextLane, 64), __shfl(fv.z, nextLane, 64));
-        const double angle = clampAcos(dot(fv, cV)) + clampAcos(dot(cV, fn));   // SM.C:980-998
-        double mn = counts ? angle : 2.0 * SMGPU_PI, mx = counts ? angle : 0.0;
-        const int segEnd = first + eNf;
-        for (int o = 1; o < 32; o <<= 1) {                         // segmented reduction towards the ring's first lane
-            const double a = __shfl_down(mn, o, 64), b = __shfl_down(mx, o, 64);
-            if (valid && lane + o < segEnd) { if (a < mn) mn = a; if (b > mx) mx = b; }
-        }
-        if (valid && lane == first) { s.edgeMin[eE] = mn; s.edgeMax[eE] = mx; }
-        pos += take;
-    }
-}
-
+// (Round 4, measured and removed: the same job with one lane per RING PLACE -- a wave takes up to 16 listed edges whose rings fit
+// its 64 lanes, lane (edge, place) forms one face vector and one cell vector, segmented min / max.  Bit-equal, but no faster:
+// timed ALONE the list kernels take 165 us for the ~600 k listed edges of the 10 M-cell cavity mesh either way (the 574 us of round
+// 3's kernel trace were measured while the proposal kernel shared the chip), profiles/r4/.)
 // mapCurrentMinMaxFaceAnglesToPoints SM.C:938-975 as a gather over pointEdges, plus the
 // good-range test SM.C:1367-1369 -- one thread per point.
 __device__ __forceinline__ void faPointMinMax(const MeshView& m, const State& s, const Prm& prm, int p) {

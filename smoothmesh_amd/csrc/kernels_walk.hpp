@@ -535,7 +535,11 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
         if (hl == 0 && selfNeeded) L.job[0] = -1;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+#ifdef SMGPU_STAR_ABLATE_JOBS
+        int nJobs = 0;      // (measurement build: staging only)
+#else
         int nJobs = live ? first + nEl : 0;
+#endif
         for (int j = 0; j < nJobs; ++j) {
             const int code = (int)L.job[j];
             const bool isSelf = code < 0, atProp = code >= 64;

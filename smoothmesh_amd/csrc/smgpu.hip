@@ -133,7 +133,6 @@ struct smgpu_handle {
     bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
-    bool faRing = true;        // SMGPU_FA_RING=0: the listed edges' exact face angles by one thread per edge (k_fa_edges_list) instead of one lane per ring place
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
     int walkBlocks = 0;
@@ -481,7 +480,6 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
-    h->faRing = envInt("SMGPU_FA_RING", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
     { const char* fv = std::getenv("SMGPU_FOAM_VARIANT"); h->foamOrg = fv && std::string(fv) == "org"; }
@@ -1258,8 +1256,7 @@ static int runFaExactPass(smgpu_handle* h, const State& s, const uint8_t* faMayb
         if (launchK(h, K_FA_EDGES, [&] {
                 hipLaunchKernelGGL(k_fa_list_count, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
                 hipLaunchKernelGGL(k_fa_list_fill, dim3(chunkGrid(m.nPoints)), dim3(kBlock), 0, stream, m, s, faMaybe, h->wv.blkA, h->wv.blkE);
-                if (h->faRing) hipLaunchKernelGGL(k_fa_edges_ring, dim3(256 * 8), dim3(kBlock), 0, stream, m, s);   // one lane per ring place
-                else hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
+                hipLaunchKernelGGL(k_fa_edges_list, dim3(std::max(1, std::min(gridFor(m.nEdges), 256 * 32))), dim3(kBlock), 0, stream, m, s);
             }, stream)) return 1;
         return launchK(h, K_FA_POINTS, [&] { hipLaunchKernelGGL(k_fa_points_list, dim3(std::max(1, std::min(gP, 256 * 8))), dim3(kBlock), 0, stream, m, s, prm); }, stream);
     }

@@ -45,8 +45,13 @@ def test_threaded_table_builds_equal_the_serial_ones_and_are_race_free(tmp_path)
     exe, tsan = str(tmp_path / "setup_bench"), str(tmp_path / "setup_bench_tsan")
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", CSRC, "-o", exe] + src)
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=thread", "-I", CSRC, "-o", tsan] + src)
-    serial = subprocess.run([exe, mesh], capture_output=True, text=True, env=dict(os.environ, SMGPU_HOST_THREADS="1"), timeout=600)
+    # the reference output: one host thread, the tile tables built AFTER the addressing
+    serial = subprocess.run([exe, mesh], capture_output=True, text=True, env=dict(os.environ, SMGPU_HOST_THREADS="1", SETUP_BENCH_PIPELINED="0"), timeout=600)
     assert serial.returncode == 0 and "cellFacesGeom.val" in serial.stdout
+    # everything below runs as smgpu_create does: the geometry / smoothing tile tables started from Topology::build's afterCells /
+    # afterPoints hooks while build() is still filling the remaining addressing
+    piped = subprocess.run([exe, mesh], capture_output=True, text=True, env=dict(os.environ, SMGPU_HOST_THREADS="1"), timeout=600)
+    assert piped.returncode == 0 and piped.stdout == serial.stdout and "started from its hooks" in piped.stderr
     for threads, grain in (("3", "64"), ("8", "17")):
         env = dict(os.environ, SMGPU_HOST_THREADS=threads, SMGPU_HOST_GRAIN=grain)
         r = subprocess.run([exe, mesh], capture_output=True, text=True, env=env, timeout=600)
