@@ -195,9 +195,14 @@ static int envInt(const char* name, int def) {
 
 // rocprofv3 --pmc serialises kernels: a stream that waits for a value written behind a kernel of another stream would never
 // wake up (observed as a hang until the outer time limit).  Under counter collection the side streams stay off by default.
-static int sideStreamDefault() {
+// Otherwise the default follows the mesh size (round 4, measured with every kernel also timed alone, profiles/r4/side_stream_ab.txt):
+// on the 1 M-cell meshes the two evaluator chains side by side win 3-4 % (hex100c 0.231 against 0.239 ms, cavity100c 0.716 against
+// 0.747) -- their kernels are short, one chain's ramp-up and tail hide behind the other -- but on the 10 M-cell mesh every kernel
+// fills the chip on its own, both chains are FP64-issue bound, and sharing it costs 2.7 % (3.399 against 3.308 ms per iteration).
+static int sideStreamDefault(int64_t nPoints) {
     const char* v = std::getenv("ROCPROF_COUNTER_COLLECTION");
-    return (v && std::atoi(v) != 0) ? 0 : 1;
+    if (v && std::atoi(v) != 0) return 0;
+    return nPoints <= (int64_t)envInt("SMGPU_SIDE_STREAM_MAX_POINTS", 4000000) ? 1 : 0;
 }
 
 
@@ -612,7 +617,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;
                     if (envInt("SMGPU_VERBOSE", 0))
                         std::fprintf(stderr, "[smgpu] edge tiles: n=%d LDS=%zu B (maxP %d maxF %d maxC %d)\n", h->etl.nTiles, h->edgeLds, ev.maxPoints, ev.maxFaces, ev.maxCells);
-                    if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", sideStreamDefault())) {
+                    if (h->edgeTilesOk && envInt("SMGPU_SIDE_STREAM", sideStreamDefault(t.nPoints))) {
                         if (depInit(h)) return cleanup(1);
                         if (hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking) != hipSuccess ||
                             hipEventCreateWithFlags(&h->evFork, hipEventDisableTiming) != hipSuccess ||
@@ -2381,7 +2386,7 @@ static int bndTables(smgpu_handle* h) {
         if (devAlloc(h, &h->st.layerNormal, 3 * (size_t)P)) return 1;
         HIP_OK(hipMemsetAsync(h->st.layerNormal, 0, sizeof(double) * 3 * (size_t)P, h->stream));
     }
-    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", sideStreamDefault())) {
+    if (!h->bndSide && envInt("SMGPU_SIDE_STREAM", sideStreamDefault(h->mv.nPoints))) {
         if (depInit(h)) return 1;
         if (hipStreamCreateWithFlags(&h->bndSide, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&h->evBndFork, hipEventDisableTiming) != hipSuccess ||
