@@ -1,7 +1,7 @@
 #!/bin/bash
 # run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
-# usage: scripts/collect_profiles.sh [round tag, default r3]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
-tag=${1:-r3}
+# usage: scripts/collect_profiles.sh [round tag, default r4]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+tag=${1:-r4}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out

@@ -648,12 +648,11 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
         const int slot = R.slot;
         if (slot >= 0) {
-            const int cb = s.inlineCombine ? s.combOff[slot] : 0;
-            if (s.inlineCombine && s.combOff[slot + 1] - cb == 2) {
-                const int s0 = s.combSlots[cb], s1 = s.combSlots[cb + 1];
-                combineTwoSharers(s.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES, s.recvA + (size_t)(s0 < 0 ? s1 : s0) * SMGPU_HALO_A_DOUBLES,
-                                  s0 < 0, s.ownFold, sum, r1, r2, r3, count, hc);
-            } else {
+            // (the combined record of the shared point, left by k_halo_combineA*.  Combining two-sharer points HERE from the own and
+            // the received record was a knob until round 4 -- SMGPU_HALO_INLINE, measured slower in round 2 -- and is gone: its inlined
+            // code cost the kernel registers whether the knob was on or not: 64 VGPRs (7 waves per SIMD) without it, 89 (5) in round 3,
+            // 97 + spills (4) with the master fold's two selects per sync -- 34.1 / 36.7 / 43.9 us per launch on 100^3)
+            {
                 const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
                 sum = v3(r[0], r[1], r[2]);
                 r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);

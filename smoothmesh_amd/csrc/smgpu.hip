@@ -1776,8 +1776,8 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
     // MEASURED (one rank of eight, 30 k shared points): slower, 211 against 199 us per iteration -- the combine is a chain of
     // dependent loads (offset -> slot -> record) and stalls whole waves of the smoothing kernel (47 -> 59 us), which costs more
     // than the two small launches it removes.  Off by default (SMGPU_HALO_INLINE=1 selects it; results are the same).
-    h->st.inlineCombine = (h->useTiles && h->dMultiIdx && envInt("SMGPU_HALO_INLINE", 0)) ? 1 : 0;
-    h->st.inlinePackF = (h->st.inlineCombine || (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0))) ? 1 : 0;
+    h->st.inlineCombine = 0;     // (the knob SMGPU_HALO_INLINE is gone, see k_smooth_tile)
+    h->st.inlinePackF = (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0)) ? 1 : 0;
     h->packTiles = envInt("SMGPU_PACK_TILES", 1) != 0;
     if (h->useTiles) {
         ensureDynLds(k_pack_tile<64>, h->device, h->smoothLds);
@@ -1842,8 +1842,8 @@ int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d) {
     HIP_OK(hipDeviceSynchronize());
     if (!d) {
         h->pushOn = false; h->st.push = PushView{};
-        h->st.inlineCombine = (h->useTiles && h->dMultiIdx && envInt("SMGPU_HALO_INLINE", 0)) ? 1 : 0;      // as smgpu_halo_configure chose them
-        h->st.inlinePackF = (h->st.inlineCombine || (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0))) ? 1 : 0;
+        h->st.inlineCombine = 0;
+        h->st.inlinePackF = (h->useTiles && envInt("SMGPU_HALO_INLINE_PACKF", 0)) ? 1 : 0;      // as smgpu_halo_configure chose it
         return 0;
     }
     if (d->nPeers < 0 || d->nPeers > 64) return fail("smgpu_halo_set_push: at most 64 peers");

@@ -114,10 +114,10 @@ def test_polyhedral_decomposition_matches_multi_oracle(oracle_lib, N, grid, cons
     assert same.any() and np.array_equal(ps[1:][same], ps[:-1][same])
 
 
-def test_inline_combine_knob_gives_the_same_result(oracle_lib, monkeypatch):
-    """SMGPU_HALO_INLINE=1: two-sharer points combined, and their freeze flags packed, inside the smoothing kernel"""
+def test_inline_pack_knob_gives_the_same_result(oracle_lib, monkeypatch):
+    """SMGPU_HALO_INLINE_PACKF=1: the shared points' freeze flags packed inside the smoothing kernel (no k_halo_packF launch)"""
     from smoothmesh_amd.halo import LocalMultiSmoother
-    monkeypatch.setenv("SMGPU_HALO_INLINE", "1")
+    monkeypatch.setenv("SMGPU_HALO_INLINE_PACKF", "1")
     subs, orcs, prm, table, mo = _poly_case(oracle_lib, 12, (2, 2, 2), False)
     ms = LocalMultiSmoother(subs, device=0, overlap=False)
     ms.set_params(prm)
@@ -253,10 +253,10 @@ def test_tie_rule_master_fold_equals_serial_on_a_graded_block(oracle_lib, monkey
     closest neighbours of every processor-plane point are at bit-equal distance the decomposed run equals the SERIAL oracle at
     every point (<= 1e-13: the cell-centre sums are formed per rank), equals the oracle's MultiDomain bit for bit, and the
     copies of a shared point stay identical.  Two-sharer kernel (k_halo_combineA2), 16-lane multi-sharer form (2x2x2: edge and
-    centre points with 4 / 8 sharers) and the smoothing kernel's inline combine."""
+    centre points with 4 / 8 sharers), also with the freeze flags packed inside the smoothing kernel."""
     from smoothmesh_amd.halo import LocalMultiSmoother
     if inline:
-        monkeypatch.setenv("SMGPU_HALO_INLINE", "1")
+        monkeypatch.setenv("SMGPU_HALO_INLINE_PACKF", "1")
     mesh, subs, ser, orcs, mo, prm = _graded_case(oracle_lib, grid, "master")
     ms = LocalMultiSmoother(subs, device=0, overlap=bool(overlap))
     ms.set_params(prm)
