@@ -1224,8 +1224,7 @@ __device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* co
     const bool wide = w > SMGPU_HALO_L_LAYERS;   // the boundary point smoothing fields travel too
     V3 sum = v3(0, 0, 0), fsum = v3(0, 0, 0);
     double faces = 0.0, fcnt = 0.0;
-    const V3 great = v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT);
-    V3 x = v3(own[3], own[4], own[5]), y = wide ? v3(own[7], own[8], own[9]) : great;
+    V3 x = v3(own[3], own[4], own[5]), y = v3(wide ? own[7] : SMGPU_GREAT, wide ? own[8] : SMGPU_GREAT, wide ? own[9] : SMGPU_GREAT);
     for (int j = 0; j < n; ++j) {
         const int sl = combSlots[b + j];
         const double* r = (sl < 0) ? own : recvL + (size_t)sl * w;
@@ -1235,18 +1234,18 @@ __device__ __forceinline__ void haloCombineLOf(int i, int nShared, const int* co
             fsum = fsum + v3(r[10], r[11], r[12]);
             fcnt += r[13];
         }
-        const V3 x2 = v3(r[3], r[4], r[5]), y2 = wide ? v3(r[7], r[8], r[9]) : great;
+        const V3 x2 = v3(r[3], r[4], r[5]), y2 = v3(wide ? r[7] : SMGPU_GREAT, wide ? r[8] : SMGPU_GREAT, wide ? r[9] : SMGPU_GREAT);
         if (!ownFold && j == 0) { x = x2; y = y2; }        // the master's value starts the fold
         else if (!ownFold || sl >= 0) {
-            x = (magSqr(x) <= magSqr(x2)) ? x : x2;
-            if (wide) y = (magSqr(y) <= magSqr(y2)) ? y : y2;
+            { const bool k = magSqr(x) <= magSqr(x2); x = v3(k ? x.x : x2.x, k ? x.y : x2.y, k ? x.z : x2.z); }
+            if (wide) { const bool k = magSqr(y) <= magSqr(y2); y = v3(k ? y.x : y2.x, k ? y.y : y2.y, k ? y.z : y2.z); }
         }
     }
     double* o = combL + (size_t)i * w;
     o[0] = sum.x; o[1] = sum.y; o[2] = sum.z; o[3] = x.x; o[4] = x.y; o[5] = x.z;
     if (wide) { o[6] = faces; o[7] = y.x; o[8] = y.y; o[9] = y.z; o[10] = fsum.x; o[11] = fsum.y; o[12] = fsum.z; o[13] = fcnt; }
 }
-__global__ void __launch_bounds__(kBlock) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
+__global__ void __launch_bounds__(kBlock, 2) k_halo_combineL(int nShared, const int* combOff, const int* combSlots, const double* ownL,
                                                           const double* recvL, double* combL, int w, int ownFold) {
     haloCombineLOf(blockIdx.x * kBlock + threadIdx.x, nShared, combOff, combSlots, ownL, recvL, combL, w, ownFold);
 }
@@ -1274,21 +1273,23 @@ __device__ __forceinline__ void combineTwoSharers(const double* ra, const double
     cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
     int hcA = (int)(pa >> 32), hcB = (int)(pb >> 32);
     const bool aLeads = ownFold || selfFirst, bLeads = ownFold || !selfFirst;   // whose value starts the fold each rank receives
-#define SMGPU_FOLD2(X, Y) ((magSqr(X) <= magSqr(Y)) ? (X) : (Y))
+    // (selects by component: `c ? X : Y` on two V3 objects is a select of their ADDRESSES, which keeps both in scratch memory)
+    auto pick = [](bool c, const V3& x, const V3& y) { return v3(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z); };
+#define SMGPU_FOLD2(X, Y) pick(magSqr(X) <= magSqr(Y), (X), (Y))
     {   // SM.C:397-419: the first vectors
         const V3 fab = SMGPU_FOLD2(a1, b1), fba = SMGPU_FOLD2(b1, a1);
-        const V3 svA = aLeads ? fab : fba, svB = bLeads ? fba : fab;
+        const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
         if (isCloserPoint(svA, a1)) { a3 = a2; a2 = a1; a1 = svA; hcA = 0; }
         if (isCloserPoint(svB, b1)) { b3 = b2; b2 = b1; b1 = svB; hcB = 0; }
     }
     {   // SM.C:424-445: the (updated) second vectors
         const V3 fab = SMGPU_FOLD2(a2, b2), fba = SMGPU_FOLD2(b2, a2);
-        const V3 svA = aLeads ? fab : fba, svB = bLeads ? fba : fab;
+        const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
         if (isCloserPoint(svA, a2)) { a3 = a2; a2 = svA; hcA = 0; }
         if (isCloserPoint(svB, b2)) { b3 = b2; b2 = svB; hcB = 0; }
     }
     {   // SM.C:450-469: the (updated) third vectors
-        const V3 svA = aLeads ? SMGPU_FOLD2(a3, b3) : SMGPU_FOLD2(b3, a3);
+        const V3 svA = pick(aLeads, SMGPU_FOLD2(a3, b3), SMGPU_FOLD2(b3, a3));
         if (isCloserPoint(svA, a3)) a3 = svA;
     }
 #undef SMGPU_FOLD2
@@ -1326,7 +1327,9 @@ __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* 
     o[9] = a3.x; o[10] = a3.y; o[11] = a3.z;
     o[12] = __longlong_as_double(((long long)any2 << 32) | (long long)(unsigned int)cnt);
 }
-__global__ void __launch_bounds__(kBlock) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+// (launch bounds: two workgroups per CU suffice for these latency-bound launches; the default occupancy target capped the
+// registers at 80 and spilled the two ranks' vectors)
+__global__ void __launch_bounds__(kBlock, 2) k_halo_combineA2(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
                                                            const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
                                                            const int* multiIdx, const int* multiSlots, PushWait pw, int ownFold) {
     pushWait(pw);
@@ -1342,7 +1345,7 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
                                              const double* ownA, const double* recvA, double* combA, int ownFold);
 // The workgroups after the first nBlocksTwo handle the listed points with more than two sharers (combineMulti): one launch,
 // so that the latency of that small, dependent-load-bound part overlaps with the two-sharer part.
-__global__ void __launch_bounds__(kBlock) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
+__global__ void __launch_bounds__(kBlock, 2) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
                                                           const double* ownA, const double* recvA, double* combA, int* err,
                                                           int skipMulti, int nBlocksTwo, int nMulti, const int* multiIdx,
                                                           const int* multiSlots, PushWait pw, int ownFold) {
@@ -1462,10 +1465,11 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
 #define SMGPU_FOLD_ALL(SENT, OUT)                                                          \
     {                                                                                      \
         const V3 sent_ = (SENT);                                                           \
-        V3 x_ = ownFold ? sent_ : SMGPU_FROM(sent_, 0);                                    \
+        const V3 m0_ = SMGPU_FROM(sent_, 0);                                               \
+        V3 x_ = v3(ownFold ? sent_.x : m0_.x, ownFold ? sent_.y : m0_.y, ownFold ? sent_.z : m0_.z); \
         for (int k = 0; k < n; ++k) {                                                      \
             const V3 y_ = SMGPU_FROM(sent_, k);                                            \
-            if (k != lead) x_ = (magSqr(x_) <= magSqr(y_)) ? x_ : y_;                      \
+            if (k != lead) { const bool kp_ = magSqr(x_) <= magSqr(y_); x_ = v3(kp_ ? x_.x : y_.x, kp_ ? x_.y : y_.y, kp_ ? x_.z : y_.z); } \
         }                                                                                  \
         (OUT) = x_;                                                                        \
     }

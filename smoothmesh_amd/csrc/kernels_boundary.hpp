@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(kBlock) k_bnd_normals_shared(State s, BndView 
 }
 // exchange A's combine (k_halo_combineA2) and, in the workgroups after its nA, exchange L's (k_halo_combineL) followed for the
 // same point by OBB.C:201-230 (k_bnd_normals_shared) -- three launch-latency-bound launches in one
-__global__ void __launch_bounds__(kBlock) k_halo_combineAL(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
+__global__ void __launch_bounds__(kBlock, 2) k_halo_combineAL(int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
                                                            const double* __restrict__ recvA, double* __restrict__ combA, int nBlocksTwo, int nMulti,
                                                            const int* multiIdx, const int* multiSlots, int nA, State s, BndView b, int bndOn,
                                                            const int* combOff, const int* combSlots, const double* ownL, const double* recvL,
@@ -325,7 +325,7 @@ __device__ __forceinline__ V3 findIntersectionPair(const BndView& b, int* __rest
     V3 mine = undef, h;
     if (findLine(b, stack, origPoint, role ? endPoint2 : endPoint1, h)) mine = h;
     const V3 other = v3(__shfl_xor(mine.x, 1, 64), __shfl_xor(mine.y, 1, 64), __shfl_xor(mine.z, 1, 64));
-    const V3 hitPoint1 = role ? other : mine, hitPoint2 = role ? mine : other;
+    const V3 hitPoint1 = sel3(role, other, mine), hitPoint2 = sel3(role, mine, other);
     const double distance1 = mag(origPoint - hitPoint1);
     const double distance2 = mag(origPoint - hitPoint2);
     if (distance1 < distance2) return hitPoint1;

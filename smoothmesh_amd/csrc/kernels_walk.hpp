@@ -324,8 +324,8 @@ struct StarLane {          // a lane's place: ring position i of edge (p, xI)
 __device__ __forceinline__ double starLaneAngle(const StarLds& L, const StarLane& P, const V3& c1, int ei, const V3& c2) {
     V3 fv = v3(0, 0, 0), cV = v3(0, 0, 0);
     if (P.valid) {
-        const V3 xs = (P.xEnt == ei) ? c2 : v3(L.vx[P.xSlot], L.vy[P.xSlot], L.vz[P.xSlot]);
-        const V3 e0 = P.pFirst ? c1 : xs, e1 = P.pFirst ? xs : c1;
+        const V3 xs = sel3(P.xEnt == ei, c2, v3(L.vx[P.xSlot], L.vy[P.xSlot], L.vz[P.xSlot]));
+        const V3 e0 = sel3(P.pFirst, c1, xs), e1 = sel3(P.pFirst, xs, c1);
         const V3 cC = 0.5 * (e0 + e1);
         const V3 d = e1 - e0;
         const V3 eVec = d / mag(d);

@@ -47,6 +47,9 @@ SMGPU_HD V3 cross(const V3& a, const V3& b) {
     return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
 }
 SMGPU_HD double magSqr(const V3& a) { return a.x * a.x + a.y * a.y + a.z * a.z; }
+// c ? a : b by component.  (`c ? a : b` on two V3 OBJECTS selects between their addresses: the compiler then keeps both in scratch
+// memory -- 56 / 104 bytes per lane in the shared-point combine kernels until round 4.)
+SMGPU_HD V3 sel3(bool c, const V3& a, const V3& b) { V3 r; r.x = c ? a.x : b.x; r.y = c ? a.y : b.y; r.z = c ? a.z : b.z; return r; }
 SMGPU_HD double mag(const V3& a) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return sqrtExact(magSqr(a));   // sqrt's bits, fpexact.hpp
