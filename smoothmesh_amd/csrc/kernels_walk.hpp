@@ -591,6 +591,380 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
     }
 }
 
+
+// ---- the same predicates with the jobs' ring places PACKED over the wave (round 4) ------------------------------------------
+// k_walk_pred_star runs one job per step on ALL ring places of the point, two points per wave in lockstep: 37 of 64 lanes hold a
+// place, and the move of one neighbour touches about half of them.  What it does not touch cannot decide the job: with p at its
+// current position an untouched pair keeps its current angle, which is >= ptMin and <= ptMax by definition (SM.C:938-975), so
+// only touched pairs can make `new < current` true (SM.C:1421-1427); with p at its proposal an untouched pair has exactly the
+// angle the self test found for it.  So a job is only its TOUCHED places, and here the tasks (job, place) of both points of a
+// wave are dealt densely to the 64 lanes: a lane fetches its place's record from LDS (ring faces i and i + 1, the cell's centre,
+// the edge's far end), forms BOTH face vectors itself (no ring neighbour to take one from) and its cell's, and the per-job
+// min / max are LDS atomics on the angles' bit patterns (positive doubles order like unsigned integers).  Measured on the 10 M-cell
+// cavity mesh: 10.3 M tasks per launch against 29.3 M lane-steps of the star form.  The arithmetic per (edge, cell) pair is
+// starLaneAngle's, operation for operation.
+#ifndef SMGPU_PACK_WAVES
+#define SMGPU_PACK_WAVES 3
+#endif
+constexpr int kPackBlock = 256;
+struct PackPlace { double ccx, ccy, ccz; unsigned char l, lNext, xEnt, xSlot, pFirst, pad[3]; };
+struct PackLds {                         // per wave: two points
+    StarLds h[2];
+    PackPlace place[2][32];
+    unsigned touch[2][kStarEnts];        // [half][entry]: the counted places the entry's neighbour touches
+    unsigned long long jmin[64], jmax[64];   // per job: bit patterns of the smallest / largest angle
+    double selfAng[2][32];               // the self test's angle of every counted place
+    int off[65];                         // first task of every job
+    unsigned cmask[2];                   // counted places of the half
+    unsigned char jcode[64];             // job t: bit 7 = half, low bits = entry, 127 = the self test
+    unsigned char hflags[2], selfBad[2]; // bit 0 moved, bit 1 self test needed
+};
+static_assert(sizeof(PackLds) * (kPackBlock / 64) * SMGPU_PACK_WAVES <= 160 * 1024, "k_walk_pred_pack: LDS per CU");
+
+// position of the r-th (0-based) set bit of m (r < popcount(m))
+__device__ __forceinline__ int nthSetBit(unsigned m, int r) {
+    int pos = 0;
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1) {
+        const unsigned low = m & ((1u << w) - 1u);
+        const int c = __popc(low);
+        if (r >= c) { r -= c; m >>= w; pos += w; }
+        else m = low;
+    }
+    return pos;
+}
+
+// one task: the angle of place R of the half whose star is L, with p at c1 and entry ei's neighbour at c2 (ei = kRoleNoEntry: nobody)
+__device__ __forceinline__ double packTaskAngle(const StarLds& L, const PackPlace& R, const V3& c1, int ei, const V3& c2) {
+    const int xs_ = R.xSlot;
+    const V3 xs = sel3((int)R.xEnt == ei, c2, v3(L.vx[xs_], L.vy[xs_], L.vz[xs_]));
+    const bool pFirst = R.pFirst != 0;
+    const V3 e0 = sel3(pFirst, c1, xs), e1 = sel3(pFirst, xs, c1);
+    const V3 cC = 0.5 * (e0 + e1);
+    const V3 d = e1 - e0;
+    const V3 eVec = d / mag(d);
+    auto faceVec = [&](int l) -> V3 {
+        V3 fc = v3(0, 0, 0);   // calcFaceCenter SM.C:1103-1130
+        const int b = L.voff[l], n = L.voff[l + 1] - b;
+        // the vertex in slot k with the job's substitutions: read unconditionally, selected by component -- no branch between the LDS
+        // reads of a face, so that they are in flight together (the additions keep the vertex order)
+        auto vert = [&](int k) -> V3 {
+            const int r = L.role[k];
+            const V3 pv = v3(L.vx[k], L.vy[k], L.vz[k]);
+            return sel3(r == kRoleSelf, c1, sel3(r == ei, c2, pv));
+        };
+        int i = 0;
+        for (; i + 4 <= n; i += 4) {
+            const V3 q0 = vert(b + i), q1 = vert(b + i + 1), q2 = vert(b + i + 2), q3 = vert(b + i + 3);
+            fc = fc + q0; fc = fc + q1; fc = fc + q2; fc = fc + q3;
+        }
+        for (; i < n; ++i) fc = fc + vert(b + i);
+        fc = divByCount(fc, n);   // = fc / double(n), bit for bit
+        const V3 cf = cC - fc;
+        const double dp = dot(cf, eVec);
+        const V3 pC = fc + dp * eVec;
+        const V3 w = pC - cC;
+        return w / mag(w);
+    };
+    const V3 fv = faceVec(R.l), fn = faceVec(R.lNext);
+    const V3 cc = v3(R.ccx, R.ccy, R.ccz);
+    const V3 cf = cC - cc;
+    const double dp = dot(cf, eVec);
+    const V3 pC = cc + dp * eVec;
+    const V3 w = pC - cC;
+    const V3 cV = w / mag(w);
+    return clampAcos(dot(fv, cV)) + clampAcos(dot(cV, fn));   // calcEdgeCenterEdgeAngle SM.C:980-998
+}
+
+// the jobs W.jcode[0 .. nJobs) of the wave (phase 0: self tests and current-position entries; phase 1: proposal-position entries):
+// tasks dealt to the lanes, per-job min / max, verdicts into the halves' tables.  Called by all 64 lanes.
+__device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int phase, const Prm& prm) {
+    const unsigned long long twoPi = (unsigned long long)__double_as_longlong(2.0 * SMGPU_PI);
+    // lane t = job t: its places, their number, the running offsets
+    unsigned M = 0u;
+    int code = 0;
+    if (lane < nJobs) {
+        code = W.jcode[lane];
+        const int h = code >> 7, e = code & 127;
+        M = (e == 127) ? W.cmask[h] : (W.touch[h][e] & W.cmask[h]);
+        W.jmin[lane] = twoPi; W.jmax[lane] = 0ull;
+    }
+    const int c = __popc(M);
+    int incl = c;
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    const int T = __shfl(incl, 63, 64);
+    W.off[lane] = incl - c;
+    if (lane == 63) W.off[64] = T;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    // proposal-position jobs: the places an entry does NOT touch keep the self test's angle
+    if (phase == 1) {
+        const int h = lane >> 5, i = lane & 31;
+        if ((W.cmask[h] >> i) & 1u) {
+            const unsigned long long a = (unsigned long long)__double_as_longlong(W.selfAng[h][i]);
+            for (int t = 0; t < nJobs; ++t) {
+                const int cd = W.jcode[t];
+                if ((cd >> 7) != h) continue;
+                if ((W.touch[h][cd & 127] >> i) & 1u) continue;
+                atomicMin(&W.jmin[t], a); atomicMax(&W.jmax[t], a);
+            }
+        }
+    }
+    for (int k0 = 0; k0 < T; k0 += 64) {                            // (wave-uniform)
+        const int k = k0 + lane;
+        if (k < T) {
+            int lo = 0, hi = nJobs;                                 // the last job t with off[t] <= k (it has tasks: off[t + 1] > k)
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (W.off[mid] <= k) lo = mid; else hi = mid; }
+            const int t = lo, cd = W.jcode[t], h = cd >> 7, e = cd & 127;
+            const unsigned Mt = (e == 127) ? W.cmask[h] : (W.touch[h][e] & W.cmask[h]);
+            const int i = nthSetBit(Mt, k - W.off[t]);
+            const StarLds& L = W.h[h];
+            const bool isSelf = e == 127;
+            const double* pc = (isSelf || phase == 1) ? L.pn : L.pc;     // where the point is in this job
+            const V3 c1 = v3(pc[0], pc[1], pc[2]);
+            const int ex = isSelf ? 0 : e;
+            const V3 c2 = v3(L.ex[ex], L.ey[ex], L.ez[ex]);
+            const double angle = packTaskAngle(L, W.place[h][i], c1, isSelf ? (int)kRoleNoEntry : e, c2);
+            const unsigned long long ab = (unsigned long long)__double_as_longlong(angle);
+            atomicMin(&W.jmin[t], ab); atomicMax(&W.jmax[t], ab);
+            if (isSelf) W.selfAng[h][i] = angle;
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < nJobs) {                                              // the verdicts (SM.C:1391-1399, 1421-1427)
+        const int h = code >> 7, e = code & 127;
+        const double mn = __longlong_as_double((long long)W.jmin[lane]), mx = __longlong_as_double((long long)W.jmax[lane]);
+        const double curMin = W.h[h].pMin, curMax = W.h[h].pMax;
+        const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+        if (isBad) {
+            if (e == 127) W.selfBad[h] = 1;
+            else {
+                const bool moved = W.hflags[h] & 1;
+                unsigned char v = W.h[h].nb[e];
+                v |= (phase == 1) ? 1 : (moved ? 2 : 3);             // (not moved: proposal = current position)
+                W.h[h].nb[e] = v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// TWO active points per wave as in k_walk_pred_star (the staging is the same code), the jobs packed (packRunJobs)
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount) {
+    if (s.acc->stop) return;
+    if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    __shared__ PackLds plds[kPackBlock / 64];
+    PackLds& W = plds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    StarLds& L = W.h[half];
+    const int groups = gridDim.x * (kPackBlock / 32);
+    // the loop is wave-uniform (half 0 decides; half 1 of the last round may be without a point: live = false)
+    for (int a0 = (blockIdx.x * (kPackBlock / 64) + (threadIdx.x >> 6)) * 2; a0 < nA; a0 += groups) {
+        const int a = a0 + half;
+        bool live = a < nA;
+        if (a == 0 && hl == 0) w.actEntOff[nA] = nE;
+        const int p = live ? w.actIds[a] : 0;
+        bool moved;
+        const bool frozenBefore = s.frozen[p] != 0;
+        {   // the point itself goes to LDS (every job reads it from there)
+            const V3 cur = ldv(s.ptsCur, p);
+            const V3 np = ldv(s.prop, p);
+            moved = (np != cur);
+            if (hl == 0) {
+                L.pc[0] = cur.x; L.pc[1] = cur.y; L.pc[2] = cur.z; L.pn[0] = np.x; L.pn[1] = np.y; L.pn[2] = np.z;
+                L.pMin = s.ptMin[p]; L.pMax = s.ptMax[p];
+            }
+        }
+        const int eBeg = live ? w.actEntOff[a] : 0, eEnd = live ? ((a + 1 < nA) ? w.actEntOff[a + 1] : nE) : 0, nEnt = eEnd - eBeg;
+        // the point's edges with the lengths of their face rings, its faces with their vertex counts
+        const int eb = m.ppOff[p], nEdgesP = live ? m.ppOff[p + 1] - eb : 0;
+        const int fb = m.pfOff[p], nF = live ? m.pfOff[p + 1] - fb : 0;
+        const int myE = (hl < nEdgesP) ? m.peEdge[eb + hl] : -1;
+        const int myNf = (myE >= 0) ? m.efOff[myE + 1] - m.efOff[myE] : 0;
+        const bool myRingBad = (myE >= 0) && !m.edgeRingOk[myE];
+        const int myF = (hl < nF) ? m.pfFace[fb + hl] : -1;
+        const int myFb = (myF >= 0) ? m.faceOff[myF] : 0;
+        const int myV = (myF >= 0) ? m.faceOff[myF + 1] - myFb : 0;
+        int inclN = myNf, inclV = myV;
+        for (int o = 1; o < 32; o <<= 1) {
+            const int tn = __shfl_up(inclN, o, 32), tv = __shfl_up(inclV, o, 32);
+            if (hl >= o) { inclN += tn; inclV += tv; }
+        }
+        const int totalLanes = __shfl(inclN, 31, 32), totalV = __shfl(inclV, 31, 32);
+        const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
+        // (entry j = the neighbour across edge j: pointPoints and pointEdges share their offsets, so nEnt == nEdgesP)
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt < kStarEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
+        if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
+        live = live && fits;
+        // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
+        const int q = (live && hl < nEnt) ? w.entNbr[eBeg + hl] : -1;
+        // Stage the star.  The loads are arranged in LEVELS of independent requests (what bounds this kernel besides FP64 issue
+        // is the chain of dependent gathers, not their number): the edge lanes fetch their edge's cell range and end points
+        // here, next to the faces' vertex ranges (the ring places below get them by shuffle instead of loading them one level
+        // later), and the vertices are fetched by SLOT (four slots per lane: two round trips for the whole star) instead of by
+        // a loop over each face's vertices (two dependent round trips per vertex).
+        const int myCb = (myE >= 0) ? m.ecOff[myE] : 0, myNc = (myE >= 0) ? m.ecOff[myE + 1] - myCb : 0;
+        const int myEfb = (myE >= 0) ? m.efOff[myE] : 0;
+        const int myE0 = (myE >= 0) ? m.edges[2 * myE] : -1;
+        if (live && hl < nF) {
+            const int o = inclV - myV;
+            L.fid[hl] = myF;
+            L.voff[hl] = o;
+            L.st.fbeg[hl] = myFb;
+            for (int v = 0; v < myV; ++v) L.st.vface[o + v] = (unsigned char)hl;
+        }
+        if (live && hl == 0) L.voff[nF] = totalV;
+        if (live && hl < nEnt) L.eq[hl] = q;
+        W.touch[half][hl] = 0u;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // this lane's ring place
+        StarLane P;
+        P.valid = live && hl < totalLanes;
+        P.hasCell = false; P.xEnt = 0; P.xSlot = 0; P.pFirst = true; P.cc = v3(0, 0, 0); P.l = 0; P.nextLane = hl;
+        int ringFaceId = -1, ringCellAt = -1;
+        {
+            int first = 0, nfj = 0, cb = 0, nc = 0, efb = 0, e0I = -1, jOf = 0;
+            bool found = false;
+            for (int j = 0; j < nEdgesP; ++j) {
+                const int hi = __shfl(inclN, j, 32), nj = __shfl(myNf, j, 32);
+                const int cbj = __shfl(myCb, j, 32), ncj = __shfl(myNc, j, 32), efbj = __shfl(myEfb, j, 32);
+                const int e0j = __shfl(myE0, j, 32);
+                if (!found && hl < hi) { found = true; first = hi - nj; nfj = nj; cb = cbj; nc = ncj; efb = efbj; e0I = e0j; jOf = j; }
+            }
+            if (P.valid) {
+                const int i = hl - first;
+                P.hasCell = i < nc;
+                P.nextLane = (i + 1 < nfj) ? hl + 1 : first;          // closed ring: the last cell ends at face 0
+                P.pFirst = (e0I == p);
+                P.xEnt = jOf;
+                ringFaceId = efb + i;
+                if (P.hasCell) ringCellAt = cb + i;
+            }
+        }
+        // level: vertex ids by slot, the ring's face and cell, the entry neighbour's two positions
+        int vg[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = hl + 32 * u;
+            vg[u] = -1;
+            if (live && k < totalV) { const int l = L.st.vface[k]; vg[u] = m.facePts[L.st.fbeg[l] + (k - L.voff[l])]; }
+        }
+        const int rf = (ringFaceId >= 0) ? m.ringFace[ringFaceId] : -1;
+        const int rc = (ringCellAt >= 0) ? m.ringCell[ringCellAt] : -1;
+        V3 nq = v3(0, 0, 0);
+        bool eligible = false;
+        unsigned char nb0 = 0;
+        if (q >= 0) {
+            nq = ldv(s.prop, q);
+            const bool qFrozen = s.frozen[q] != 0;
+            nb0 = qFrozen ? 8 : 0;
+            eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
+            if (eligible) nb0 |= 4;
+        }
+        // level: the coordinates; the role of every vertex slot (the point itself / entry e's neighbour / anybody else)
+        V3 vc[4];
+        unsigned char role[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0);
+            role[u] = (vg[u] == p) ? kRoleSelf : kRoleOther;
+        }
+        if (rc >= 0) P.cc = ldv(s.cellCtr, rc);                      // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+        for (int e = 0; e < nEnt; ++e) {
+            const int qe = L.eq[e];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (vg[u] == qe) role[u] = (unsigned char)e;
+        }
+        __builtin_amdgcn_wave_barrier();                              // (ez below overlays the staging tables read above)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = hl + 32 * u;
+            if (vg[u] >= 0) { L.role[k] = role[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
+        }
+        if (q >= 0) { L.nb[hl] = nb0; L.ex[hl] = nq.x; L.ey[hl] = nq.y; L.ez[hl] = nq.z; }
+        if (P.valid) for (int l = 0; l < nF; ++l) if (L.fid[l] == rf) P.l = l;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        // the slot of the edge's other end point in this lane's ring face; the place's record for the packed steps; the places
+        // every entry TOUCHES: an angle depends on the neighbour q_e through the edge (its own entry) and through the vertices of
+        // the place's two ring faces (SM.C:1155-1200) -- nothing else
+        const int lNext = __shfl(P.l, P.nextLane, 32);
+        const bool counts = P.valid && P.hasCell;
+        if (P.valid) for (int i = L.voff[P.l]; i < L.voff[P.l + 1]; ++i) if (L.role[i] == P.xEnt) P.xSlot = i;
+        if (counts) {
+            atomicOr(&W.touch[half][P.xEnt], 1u << hl);
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                const int l = side ? lNext : P.l;
+                for (int i = L.voff[l]; i < L.voff[l + 1]; ++i) {
+                    const unsigned r = L.role[i];
+                    if (r < (unsigned)kStarEnts) atomicOr(&W.touch[half][r], 1u << hl);
+                }
+            }
+            PackPlace& R = W.place[half][hl];
+            R.ccx = P.cc.x; R.ccy = P.cc.y; R.ccz = P.cc.z;
+            R.l = (unsigned char)P.l; R.lNext = (unsigned char)lNext; R.xEnt = (unsigned char)P.xEnt; R.xSlot = (unsigned char)P.xSlot;
+            R.pFirst = P.pFirst ? 1 : 0;
+        }
+        const unsigned countedMask = (unsigned)(__ballot(counts) >> (32 * half));
+        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+        const bool selfNeeded = live && moved && !frozenBefore;
+        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
+        const int nEl = live ? __popc(elig) : 0, first = selfNeeded ? 1 : 0;
+        const int myRank = __popc(elig & ((1u << hl) - 1u));
+        // ---- phase 1: the self test (all counted places, p at its proposal) and every eligible entry with p at its CURRENT position
+        // (the places it touches).  Job t of the wave: half 0's jobs, then half 1's.
+        const int nJ = live ? first + nEl : 0;
+        const int nJ0 = __shfl(nJ, 0, 64), nJ1 = __shfl(nJ, 32, 64);
+        const int jb = half ? nJ0 : 0;
+        if (hl == 0) { W.hflags[half] = (unsigned char)((moved ? 1 : 0) | (selfNeeded ? 2 : 0)); W.selfBad[half] = 0; W.cmask[half] = countedMask; }
+        if (hl == 0 && selfNeeded) W.jcode[jb] = (unsigned char)((half << 7) | 127);
+        if (eligible && live) W.jcode[jb + first + myRank] = (unsigned char)((half << 7) | hl);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        packRunJobs(W, lane, nJ0 + nJ1, 0, prm);
+        // what phase 1 decided: the self tests; then whether the point can act from its proposal at all (SM.C:1376-1399)
+        if (selfNeeded && W.selfBad[half]) sbits |= 1u;
+        const bool propJobs = live && moved && !(sbits & 5u) && nEl > 0;
+        // ---- phase 2: the eligible entries of the points that act from their proposal, p at its PROPOSAL: the touched places are
+        // evaluated, the others keep the angle the self test found for them
+        const int nP = propJobs ? nEl : 0;
+        const int nP0 = __shfl(nP, 0, 64), nP1 = __shfl(nP, 32, 64);
+        if (nP0 + nP1 > 0) {                                        // (wave-uniform)
+            const int pb = half ? nP0 : 0;
+            if (propJobs && eligible) W.jcode[pb + myRank] = (unsigned char)((half << 7) | hl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            packRunJobs(W, lane, nP0 + nP1, 1, prm);
+        }
+        if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
+        const int nJobs = nJ + nP;
+        if (opCount) {
+            // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs, by the reference's arithmetic
+            // (SM.C:1135-1231 per (edge, cell) pair: two projected face-centre vectors 77 + 3 (n - 1) + (3 | 33) each for a face
+            // of n vertices, the projected cell centre 77, two clamped acos and their sum 95 -- sqrt = 22, division = 11 per
+            // component, acos = 40; per edge of the point 69 for the edge vector) times the jobs that were needed.  One add per
+            // point, spread over 64 words.
+            const int nv = counts ? L.voff[P.l + 1] - L.voff[P.l] : 0;
+            int ops = counts ? 2 * (77 + 3 * (nv - 1) + (((nv & (nv - 1)) == 0) ? 3 : 33)) + 77 + 95 : 0;
+            for (int o = 16; o > 0; o >>= 1) ops += __shfl_xor(ops, o, 32);
+            if (live && hl == 0) atomicAdd(&opCount[a & 63], (unsigned long long)nJobs * (unsigned long long)(ops + 69 * nEdgesP));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (q >= 0) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+
 // ---- second compaction (over active slots) ------------------------------------------------------------------
 __device__ __forceinline__ bool entryActs(uint8_t nb) { return (nb & 4) && (nb & 3); }   // moving neighbour, hurt in some state
 

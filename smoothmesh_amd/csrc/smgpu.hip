@@ -133,6 +133,7 @@ struct smgpu_handle {
     bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
+    bool walkPack = false;     // SMGPU_WALK_PACK=1: the walk predicates with the jobs' touched ring places packed over the wave (k_walk_pred_pack)
     int starBlocks = 256 * 32;   // workgroups of k_walk_pred_star (each wave walks the active points with this stride)
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
@@ -486,6 +487,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->starBlocks = std::max(1, envInt("SMGPU_STAR_BLOCKS", 256 * 32));
+    h->walkPack = envInt("SMGPU_WALK_PACK", 0) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
@@ -1137,7 +1139,8 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
+            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
+            else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
         })) return 1;
@@ -1222,7 +1225,8 @@ static int runFixWalk(smgpu_handle* h) {
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(h->starBlocks), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
+            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
+            else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(h->starBlocks), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
         })) return 1;
