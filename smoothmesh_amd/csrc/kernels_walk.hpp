@@ -292,11 +292,12 @@ constexpr int kStarFaces = 32, kStarVerts = 128, kStarEnts = 32;
 // budget of 128: 27 VGPRs spilled, 104 bytes of scratch per lane, written once per point and re-read inside the job loop (272 MB of
 // scratch writes per launch on the 10 M-cell cavity mesh).
 constexpr unsigned char kRoleSelf = 0xFF, kRoleOther = 0xFE, kRoleNoEntry = 0xFD;
-struct StarLds {
+template <int NV>
+struct StarLdsT {
     int fid[kStarFaces];
     int voff[kStarFaces + 1];
-    unsigned char role[kStarVerts];      // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
-    double vx[kStarVerts], vy[kStarVerts], vz[kStarVerts];
+    unsigned char role[NV];              // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
+    double vx[NV], vy[NV], vz[NV];
     unsigned char nb[kStarEnts];
     signed char job[2 * kStarEnts + 2];  // the jobs that are needed, in order: -1 = the self test, e = entry e with p at its current
                                          // position, 64 + e = entry e with p at its proposal
@@ -305,10 +306,11 @@ struct StarLds {
     double ex[kStarEnts], ey[kStarEnts];
     union {
         double ez[kStarEnts];            // (ex, ey, ez): entry e's neighbour at its proposal
-        struct { int fbeg[kStarFaces]; unsigned char vface[kStarVerts]; } st;   // staging only: first entry of the face in facePts,
+        struct { int fbeg[kStarFaces]; unsigned char vface[NV]; } st;   // staging only: first entry of the face in facePts,
                                                                                  // the star-local face of every vertex slot
     };
 };
+typedef StarLdsT<kStarVerts> StarLds;
 static_assert(sizeof(StarLds) * 8 <= 40960, "k_walk_pred_star: four workgroups per CU need <= 40 KB of LDS each");
 struct StarLane {          // a lane's place: ring position i of edge (p, xI)
     bool valid, hasCell;
@@ -607,9 +609,15 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
 #define SMGPU_PACK_WAVES 3
 #endif
 constexpr int kPackBlock = 256;
+// Vertex slots of a star: 128 as in k_walk_pred_star.  (An interior hex point has 48, the refinement interfaces of the castellated
+// meshes at most 60.  With 64 slots the wave's tables take 10 KB instead of 13.2 and FOUR waves per SIMD fit -- measured on the 10 M-cell
+// cavity mesh, profiles/r4/ab_walk_pred_pack.txt: 724 us at four waves (128 VGPRs, 36 of them spilled), 693 at three (168 VGPRs),
+// 697 at three with 128 slots: the kernel is not occupancy bound, so it keeps the larger stars.)
+constexpr int kPackVerts = 128;
+typedef StarLdsT<kPackVerts> PackStar;
 struct PackPlace { double ccx, ccy, ccz; unsigned char l, lNext, xEnt, xSlot, pFirst, pad[3]; };
 struct PackLds {                         // per wave: two points
-    StarLds h[2];
+    PackStar h[2];
     PackPlace place[2][32];
     unsigned touch[2][kStarEnts];        // [half][entry]: the counted places the entry's neighbour touches
     unsigned long long jmin[64], jmax[64];   // per job: bit patterns of the smallest / largest angle
@@ -635,7 +643,7 @@ __device__ __forceinline__ int nthSetBit(unsigned m, int r) {
 }
 
 // one task: the angle of place R of the half whose star is L, with p at c1 and entry ei's neighbour at c2 (ei = kRoleNoEntry: nobody)
-__device__ __forceinline__ double packTaskAngle(const StarLds& L, const PackPlace& R, const V3& c1, int ei, const V3& c2) {
+__device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPlace& R, const V3& c1, int ei, const V3& c2) {
     const int xs_ = R.xSlot;
     const V3 xs = sel3((int)R.xEnt == ei, c2, v3(L.vx[xs_], L.vy[xs_], L.vz[xs_]));
     const bool pFirst = R.pFirst != 0;
@@ -721,7 +729,7 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
             const int t = lo, cd = W.jcode[t], h = cd >> 7, e = cd & 127;
             const unsigned Mt = (e == 127) ? W.cmask[h] : (W.touch[h][e] & W.cmask[h]);
             const int i = nthSetBit(Mt, k - W.off[t]);
-            const StarLds& L = W.h[h];
+            const PackStar& L = W.h[h];
             const bool isSelf = e == 127;
             const double* pc = (isSelf || phase == 1) ? L.pn : L.pc;     // where the point is in this job
             const V3 c1 = v3(pc[0], pc[1], pc[2]);
@@ -761,7 +769,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
     __shared__ PackLds plds[kPackBlock / 64];
     PackLds& W = plds[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
-    StarLds& L = W.h[half];
+    PackStar& L = W.h[half];
     const int groups = gridDim.x * (kPackBlock / 32);
     // the loop is wave-uniform (half 0 decides; half 1 of the last round may be without a point: live = false)
     for (int a0 = (blockIdx.x * (kPackBlock / 64) + (threadIdx.x >> 6)) * 2; a0 < nA; a0 += groups) {
@@ -798,7 +806,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         const int totalLanes = __shfl(inclN, 31, 32), totalV = __shfl(inclV, 31, 32);
         const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
         // (entry j = the neighbour across edge j: pointPoints and pointEdges share their offsets, so nEnt == nEdgesP)
-        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kStarVerts && nEnt < kStarEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kPackVerts && nEnt < kStarEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
         if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
         live = live && fits;
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
@@ -848,9 +856,9 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             }
         }
         // level: vertex ids by slot, the ring's face and cell, the entry neighbour's two positions
-        int vg[4];
+        int vg[kPackVerts / 32];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kPackVerts / 32; ++u) {
             const int k = hl + 32 * u;
             vg[u] = -1;
             if (live && k < totalV) { const int l = L.st.vface[k]; vg[u] = m.facePts[L.st.fbeg[l] + (k - L.voff[l])]; }
@@ -868,10 +876,10 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             if (eligible) nb0 |= 4;
         }
         // level: the coordinates; the role of every vertex slot (the point itself / entry e's neighbour / anybody else)
-        V3 vc[4];
-        unsigned char role[4];
+        V3 vc[kPackVerts / 32];
+        unsigned char role[kPackVerts / 32];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kPackVerts / 32; ++u) {
             vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0);
             role[u] = (vg[u] == p) ? kRoleSelf : kRoleOther;
         }
@@ -879,11 +887,11 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         for (int e = 0; e < nEnt; ++e) {
             const int qe = L.eq[e];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) if (vg[u] == qe) role[u] = (unsigned char)e;
+            for (int u = 0; u < kPackVerts / 32; ++u) if (vg[u] == qe) role[u] = (unsigned char)e;
         }
         __builtin_amdgcn_wave_barrier();                              // (ez below overlays the staging tables read above)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < kPackVerts / 32; ++u) {
             const int k = hl + 32 * u;
             if (vg[u] >= 0) { L.role[k] = role[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
         }

@@ -133,7 +133,7 @@ struct smgpu_handle {
     bool bndPreDone = false;
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
-    bool walkPack = false;     // SMGPU_WALK_PACK=1: the walk predicates with the jobs' touched ring places packed over the wave (k_walk_pred_pack)
+    bool walkPack = true;      // SMGPU_WALK_PACK=0: k_walk_pred_star (one job per step on all ring places) instead of k_walk_pred_pack (the jobs' touched places packed over the wave)
     int starBlocks = 256 * 32;   // workgroups of k_walk_pred_star (each wave walks the active points with this stride)
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
@@ -487,7 +487,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->xcdMap = envInt("SMGPU_XCD_MAP", 1) != 0;
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->starBlocks = std::max(1, envInt("SMGPU_STAR_BLOCKS", 256 * 32));
-    h->walkPack = envInt("SMGPU_WALK_PACK", 0) != 0;
+    h->walkPack = envInt("SMGPU_WALK_PACK", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;

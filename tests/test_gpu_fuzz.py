@@ -28,10 +28,11 @@ def test_random_irregular_and_tied_cases(kinds, seed):
     assert r.stdout.count(" ok ") == 10
 
 
-@pytest.mark.parametrize("env", [{"SMGPU_WALK": "fix"}, {"SMGPU_WALK": "fix", "SMGPU_WALK_STAR": "0", "SMGPU_WALK_BLOCKS": "7"},
+@pytest.mark.parametrize("env", [{"SMGPU_WALK": "fix", "SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK": "fix"}, {"SMGPU_WALK": "fix", "SMGPU_WALK_STAR": "0", "SMGPU_WALK_BLOCKS": "7"},
                                  {"SMGPU_WALK": "host"}, {"SMGPU_FA_LISTS": "0", "SMGPU_FILTER": "0"}, {"SMGPU_WALK": "fix", "SMGPU_FA_SIDE_EXACT": "0"}])
 def test_random_cases_under_walk_knobs(env):
-    """the same sweep with the face-angle walk forced to the fixed-point device replay (also with the gather-form predicates and
+    """the same sweep with the face-angle walk forced to the fixed-point device replay (with the star form of the predicates --
+    one job per step -- and with the default packed form; also with the gather-form predicates and
     an odd number of workgroups in the persistent launch), to the host replay, and without filters / lists"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "8", "31"], capture_output=True, text=True,
                        timeout=900, env=dict(os.environ, **env))

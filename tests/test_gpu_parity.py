@@ -148,7 +148,7 @@ def test_bad_mesh_face_angle_walk(oracle_lib, monkeypatch, jit, seed, walk):
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
 
-@pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4}])
+@pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4}])
 @pytest.mark.parametrize("dims,jit,seed", [((14, 12, 10), 0.47, 3), ((20, 6, 5), 0.49, 8)])
 def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed, knobs):
     """a badly distorted block: the interaction graph has components of hundreds of points with long re-visit chains;
