@@ -376,7 +376,7 @@ __device__ __forceinline__ GeomCellIn geomCellLoad(const GeomTileView& g, const 
     in.qa = in.qb = make_ushort4(0, 0, 0, 0);
     if (in.mine) {
         in.c = g.cellOrder[ci];
-        if (tflags & 2u) {
+        if ((tflags & 2u)) {
             const ushort4* row = reinterpret_cast<const ushort4*>(g.cellFaces + tm.cfBase) + tid;
             in.qa = row[0]; in.qb = row[T];
         }
@@ -395,13 +395,16 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 #define SMGPU_PYR(E, FC)                                                                                   \
     {                                                                                                      \
         const V3 fA = ldsg(fax, fay, faz, kGF * ((E) & 0x7fff));                                                   \
-        double pyr3Vol = ((E) & 0x8000) ? dot(fA, cEst - (FC)) : dot(fA, (FC) - cEst);                     \
+        /* neighbour side: Sf . (cEst - Cf) = -(Sf . (Cf - cEst)) bit for bit (IEEE subtraction, multiplication and     \
+           addition are odd functions under round-to-nearest) -- one expression and a sign, no divergent branch per face */ \
+        double pyr3Vol = dot(fA, (FC) - cEst);                                                             \
+        pyr3Vol = ((E) & 0x8000) ? -pyr3Vol : pyr3Vol;                                                     \
         if (ORG) pyr3Vol = (pyr3Vol > SMGPU_VSMALL) ? pyr3Vol : SMGPU_VSMALL;   /* OpenFOAM.org: max(.., vSmall) */ \
         const V3 pc = (3.0 / 4.0) * (FC) + (1.0 / 4.0) * cEst;                                             \
         ctr = ctr + pyr3Vol * pc;                                                                          \
         vol += pyr3Vol;                                                                                    \
     }
-    if (tflags & 2u) {
+    if ((tflags & 2u)) {
         // the loops below unrolled for six faces, each face centre read once
         const ushort4 qa = in.qa, qb = in.qb;
         const unsigned e0 = qa.x, e1 = qa.y, e2 = qa.z, e3 = qa.w, e4 = qb.x, e5 = qb.y;
