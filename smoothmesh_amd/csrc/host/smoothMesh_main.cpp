@@ -481,6 +481,10 @@ int main(int argc, char** argv) {
             if (g_master) NCCLCHK(ncclGetUniqueId(&id));
             id = g_comm.broadcast(id, 0);
             NCCLCHK(ncclCommInitRank(&nccl, nRanks, id, myRank));
+            int seen = -1;
+            NCCLCHK(ncclCommCount(nccl, &seen));           // what the communicator itself says about its size
+            if (seen != nRanks) fatal("RCCL communicator has " + std::to_string(seen) + " ranks, the case has " + std::to_string(nRanks));
+            OUT("Shared-point records: RCCL send / recv groups on the engines' streams, communicator of %d ranks\n", seen);
         }
     }
 
@@ -826,7 +830,8 @@ int main(int argc, char** argv) {
         for (int o = 0; o < nRanks; ++o)
             for (int j = 0; j < K0.peerCount[o]; ++j)
                 good = good && got[(size_t)(K0.peerSendBase[o] + j)] == o * kMul + peerBaseOf[(size_t)o] + j;
-        if (!g_comm.reduceAnd(good))
+        if (g_comm.reduceAnd(good)) OUTS("RCCL exchange self-check: pass\n");
+        else
             fatal("RCCL exchange self-check failed: the records that arrived are not the ones the peers sent (set SMOOTHMESH_TRANSPORT=shm to run on the host-staged transport)");
     }
 
