@@ -757,6 +757,7 @@ def main():
         "config": {
             "workload": workload_text(kind, n_side, constraints, layers, boundary, world, n_global),
             "points_per_gpu": int(sizes["nPoints"]), "cells_per_gpu": int(sizes["nCells"]),
+            "device_bytes_per_gpu": int(sizes["deviceBytes"]),
             "parallelism": parallelism,
         },
         **kernel_report(args.workload, ctr, K, dt, dt_ev, sizes),
@@ -819,6 +820,8 @@ def main():
                              "unpinned against a real OpenFOAM build")
         if single:
             out["phases"] = single["phases"]
+    import resource
+    out["host_max_rss_gib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20   # rank 0's process
     print(json.dumps(out))
     if world > 1 or force_dist:
         import torch.distributed as dist

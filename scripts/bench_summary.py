@@ -11,6 +11,10 @@ for line in sys.stdin:
         continue
     d = json.loads(line)
     print(f"{d['config']['workload'][:60]}...  value={d['value']/1e9:.3f} Gpts/s  ms/step={d['ms_per_step']:.4f}  (with events {d['ms_per_step_with_events']:.4f})")
+    if d["config"].get("device_bytes_per_gpu"):
+        c = d["config"]
+        print(f"   {c['cells_per_gpu']} cells, {c['points_per_gpu']} points, {c['device_bytes_per_gpu'] / 2**30:.2f} GiB on the device "
+              f"({c['device_bytes_per_gpu'] / c['cells_per_gpu']:.0f} B per cell); host max RSS {d.get('host_max_rss_gib', 0):.1f} GiB; phases {d.get('phases')}")
     for k in d["kernels"]:
         gb = f"{k['algo_GBps']:8.1f} GB/s algorithmic" if k.get("algo_GBps") else (f"{k['algo_f64_Tops']:8.2f} T FP64 instr/s algorithmic" if k.get("algo_f64_Tops") else "")
         print(f"   {k['name'][:40]:40s} {k['avg_us']:9.1f} us  {gb}")

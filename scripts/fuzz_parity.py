@@ -2,7 +2,9 @@
 smoothing parameters, constraints, layer patches, boundary point smoothing (box and sphere targets), serial and decomposed -- into
 boxes, into IRREGULAR sub-domains (breadth-first grown or random cellRank maps, 2..8 ranks, disconnected pieces), and on
 UNJITTERED / exactly graded blocks whose points sit on binary fractions, where the edge-length comparisons of the closest-point
-syncs (SM.C:388-478) tie exactly.  Prints one line per case; exit code 1 on the first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
+syncs (SM.C:388-478) tie exactly -- and ("affine") meshes in other units and far from the origin (scale 1e-6 .. 1e6, offset up to
+1e7 mesh sizes: the f32 filters of the constraint evaluators work on f64 DIFFERENCES and must stay on the safe side, the
+constraints are always on there).  Prints one line per case; exit code 1 on the first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,8 +23,8 @@ KINDS = os.environ.get("FUZZ_KINDS", "hex,hex,cavity,multi,multi,irregular,tied"
 PATCHES = ["xmin", "xmax", "ymin", "ymax", "zmin", "zmax"]
 
 
-def params(mn):
-    over = dict(edgeAngleConstraint=bool(rng.integers(2)), faceAngleConstraint=bool(rng.integers(2)),
+def params(mn, constraints_on=False):
+    over = dict(edgeAngleConstraint=constraints_on or bool(rng.integers(2)), faceAngleConstraint=constraints_on or bool(rng.integers(2)),
                 minAngle=float(rng.choice([15.0, 35.0, 50.0])), maxAngle=float(rng.choice([140.0, 160.0, 175.0])),
                 relStepFrac=float(rng.choice([0.3, 0.5, 0.9])), totalMinFreeze=bool(rng.integers(2)))
     minEdge = float(rng.choice([0.3, 0.5, 0.9])) * mn
@@ -129,22 +131,37 @@ for case in range(n_cases):
             dims = tuple(int(x) for x in rng.integers(2, 14, size=3))
             mesh = hex_block(*dims, jitter=jitter, seed=seed)
             desc = f"hex {dims}"
+        elif kind == "affine":
+            if rng.random() < 0.5:
+                dims = tuple(int(x) for x in rng.integers(3, 14, size=3))
+                mesh = hex_block(*dims, jitter=jitter, seed=seed)
+                desc = f"affine hex {dims}"
+            else:
+                n = int(rng.integers(8, 15))
+                mesh = cavity_mesh(n, jitter=min(jitter, 0.3), seed=seed)
+                desc = f"affine cavity {n}"
+            scale = 10.0 ** float(rng.choice([-6, -3, 0, 2, 6]))
+            shift = float(rng.choice([0.0, 1e2, 1e4, 1e6, 1e7])) * np.array([1.0, -0.7, 0.3])[rng.permutation(3)]
+            P = mesh.points.reshape(-1, 3)
+            P[:] = scale * (P + shift)
+            desc += f" scale {scale:g} shift {np.max(np.abs(shift)):g}"
+            layers = False
         else:
             n = int(rng.integers(8, 15))
             mesh = cavity_mesh(n, jitter=min(jitter, 0.3), seed=seed)
             lp.layerPatches = ("cavity",) if rng.random() < 0.5 else lp.layerPatches
             desc = f"cavity {n}"
         o = oracle_ffi.Oracle(mesh); e = SmoothEngine(mesh)
-        prm = params(o.mesh_stats()[0])
+        prm = params(o.mesh_stats()[0], constraints_on=(kind == "affine"))
         o.set_params(prm); e.set_params(prm)
-        boundary = rng.random() < 0.5
+        boundary = kind != "affine" and rng.random() < 0.5
         st, sz, kd, sel = patch_arrays(mesh, lp.layerPatches if layers else ())
         lopt = (lp.layerMaxBlendingFraction, prm.minEdgeLength, lp.layerExpansionRatio, lp.minLayers, lp.maxLayers)
         if boundary:
             f = float(rng.choice([1.0, 1.0, 1.02]))
             warp = (lambda x: 0.5 + (x - 0.5) * f) if f != 1.0 else None
             m_e, m_s = int(rng.integers(1, 9)), int(rng.integers(1, 7))
-            if kind == "hex":
+            if kind == "hex":      # (kind "cavity" below; "affine" never gets here)
                 pats = tuple(rng.choice(PATCHES, size=int(rng.integers(1, 7)), replace=False)) if rng.random() < 0.5 else ('".*"',)
                 bp = BoundaryParams(initEdges=box_feature_edges(m_e), targetEdges=box_feature_edges(m_e, warp=warp) if warp else None,
                                     targetSurfaces=box_surface(m_s, warp=warp), smoothingPatches=pats,
@@ -178,7 +195,7 @@ for case in range(n_cases):
         a, b = e.get_points(), o.points()
     fin = ~np.isnan(b)
     ok = (n_o == n_g and np.array_equal(frz_o, frz_g) and np.array_equal(np.isnan(a), np.isnan(b)) and
-          (not fin.any() or np.max(np.abs(a[fin] - b[fin])) <= 1e-13 * max(1.0, np.max(np.abs(b[fin])))))
+          (not fin.any() or np.max(np.abs(a[fin] - b[fin])) <= 1e-13 * (max(1.0, np.max(np.abs(b[fin]))) if kind != "affine" else np.max(np.abs(b[fin])))))
     print(f"case {case:3d} {'ok ' if ok else 'BAD'} {desc} jitter {jitter} iters {iters} layers {lp.layerPatches if layers else '-'} "
           f"ea {prm.edgeAngleConstraint} fa {prm.faceAngleConstraint} frozen {frz_o[-1]} maxdiff {np.max(np.abs(a[fin] - b[fin])) if fin.any() else 0:.2e}", flush=True)
     bad += 0 if ok else 1

@@ -146,3 +146,29 @@ def test_walk_replay_places_agree_on_the_10M_cell_mesh(monkeypatch, cavity215):
     assert np.array_equal(outs["fix"][1], outs["host"][1])
     assert np.array_equal(outs["fix"][0], outs["host"][0])
     assert np.array_equal(outs["fix"][2], outs["host"][2])
+
+
+BIG = pytest.mark.skipif(not __import__("os").environ.get("SMOOTHMESH_BIG_TESTS"),
+                         reason="tens of GiB on host and device and minutes of serial oracle: set SMOOTHMESH_BIG_TESTS=1 "
+                                "(last run: profiles/r4/big_mesh_parity.txt)")
+
+
+@BIG
+def test_hex400_64M_cells_matches_oracle(oracle_lib):
+    """BEYOND the baseline sizes: a 64 M-cell block (82 GiB on the device, index products past 2^29), constraints off -- two
+    iterations, bit for bit.  The sizes at which 32-bit index arithmetic would first go wrong are only reachable this way."""
+    from smoothmesh_amd.meshgen import hex_block
+    mesh = hex_block(400, jitter=0.2, seed=12345)
+    frz, bitwise = _compare(mesh, oracle_lib, 2, check_every=[1, 1], edgeAngleConstraint=False, faceAngleConstraint=False)
+    assert np.all(frz == mesh.nPoints - 399 ** 3)
+    assert bitwise
+
+
+@BIG
+def test_cavity300c_26M_cells_matches_oracle(oracle_lib):
+    """the polyhedral mesh at 2.6 x configs[3]'s size, constraints on: two iterations, bit for bit"""
+    from smoothmesh_amd.polymesh import cavity_mesh
+    mesh = cavity_mesh(300, jitter=0.2, seed=12345)
+    assert mesh.nCells > 26_000_000
+    frz, bitwise = _compare(mesh, oracle_lib, 2, check_every=[1, 1])
+    assert bitwise

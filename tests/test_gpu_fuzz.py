@@ -28,6 +28,16 @@ def test_random_irregular_and_tied_cases(kinds, seed):
     assert r.stdout.count(" ok ") == 10
 
 
+@pytest.mark.parametrize("seed", [61, 62])
+def test_random_cases_in_other_units_and_far_from_the_origin(seed):
+    """the sweep on meshes scaled by 1e-6 .. 1e6 and moved up to 1e7 mesh sizes away from the origin, constraints on: the f32
+    filters see f64 differences only and must stay on the safe side (bit-equal decisions) whatever the coordinates' magnitude"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_parity.py"), "12", str(seed)], capture_output=True, text=True,
+                       timeout=900, env=dict(os.environ, FUZZ_KINDS="affine"))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.stdout.count(" ok ") == 12
+
+
 @pytest.mark.parametrize("env", [{"SMGPU_WALK": "fix", "SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK": "fix"}, {"SMGPU_WALK": "fix", "SMGPU_WALK_STAR": "0", "SMGPU_WALK_BLOCKS": "7"},
                                  {"SMGPU_WALK": "host"}, {"SMGPU_FA_LISTS": "0", "SMGPU_FILTER": "0"}, {"SMGPU_WALK": "fix", "SMGPU_FA_SIDE_EXACT": "0"}])
 def test_random_cases_under_walk_knobs(env):

@@ -148,6 +148,19 @@ def test_bad_mesh_face_angle_walk(oracle_lib, monkeypatch, jit, seed, walk):
     assert rel_linf(e.get_points(), o.points()) <= COORD_TOL
 
 
+def test_one_wave_walk_behind_many_workgroups(oracle_lib, monkeypatch):
+    """The one-wave replay forced on a mesh of several hundred workgroups, most of them with active points (the form the
+    engine picks by itself only when few points are active)."""
+    monkeypatch.setenv("SMGPU_WALK", "wave")
+    mesh = _mk(44, 40, 36, 0.46, 5)
+    o, e, p = _pair(mesh, oracle_lib)
+    n_o, res_o, frz_o = o.iterate(4, 0.0)
+    n_g, res_g, frz_g = e.iterate(4, 0.0)
+    assert frz_o[0] > 1000
+    assert np.array_equal(frz_o, frz_g)
+    assert np.array_equal(e.get_points(), o.points())
+
+
 @pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4}])
 @pytest.mark.parametrize("dims,jit,seed", [((14, 12, 10), 0.47, 3), ((20, 6, 5), 0.49, 8)])
 def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed, knobs):
