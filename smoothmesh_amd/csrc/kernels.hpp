@@ -171,6 +171,7 @@ struct Prm {
     double maxStep, relStepFrac, minEdge;
     int totalMinFreeze;
     double smallAngle, largeAngle;   // M_PI * deg / 180.0  (SM.C:921, 1364-1365)
+    float faCosLo, faCosHi;          // the f32 face-angle filter's thresholds on the cosine of an angle sum (kernels_filter.hpp)
     int layersOn;                    // boundary layer treatment enabled (SM.C:2024-2028)
     int bndOn;                       // boundary point smoothing enabled (SM.C:2080-2093): kernels_boundary.hpp
 };

@@ -15,13 +15,23 @@
 // clamp +-0.99999: < 5e-3 worst case at the clamp, < 1e-4 for |cos| < 0.999.  The margins below
 // (kFaMargin on angle sums, kEaMargin on cosines) are applied together with a guard that sends every
 // near-clamp cosine to the exact path.
+//
+// Face angles, round 4: the test "small + margin < acos(a) + acos(b) < large - margin" is made on the COSINE of the sum,
+//   c = a b - sqrt((1 - a^2)(1 - b^2)),
+// against thresholds the host prepares in f64 (Prm::faCosLo = cos(small) - M, Prm::faCosHi = cos(large) + M, smgpu.hip:makePrm)
+// -- two acosf (19 vector instructions each) become one v_sqrt_f32 and four multiply-adds, a fifth of the kernel's
+// instructions.  cos is 1-Lipschitz, so an error of the sum bounds the error of c: the same margin M = kFaMargin (+ 2e-5 for the
+// rounding of the formula itself: 1 - a^2 >= 2e-3 behind the near-clamp guard) keeps the same distance from the f32 error bound.
+// cos decreases on [0, pi] only, so "sum < large" is accepted only with a + b > kFaSumMin (true a + b > 0 <=> the sum is below
+// pi); a sum above pi has c rising again and fails "c < faCosLo" at worst -- UNSURE, never wrongly GOOD.
 #pragma once
 #include "kernels.hpp"
 #include "kernels_tiled.hpp"
 
 namespace smgpu {
 
-constexpr float kFaMargin = 2.0e-3f;     // rad, on acos(a) + acos(b)
+constexpr float kFaMargin = 2.0e-3f;     // rad, on acos(a) + acos(b): applied to the cosine of the sum (Prm::faCosLo / faCosHi)
+constexpr float kFaSumMin = 2.0e-3f;     // a + b above this: acos(a) + acos(b) < pi for sure
 constexpr float kEaMargin = 1.0e-3f;     // on a clamped cosine
 constexpr float kNearClamp = 0.999f;     // |cos| above this goes to the exact path
 
@@ -33,6 +43,12 @@ __device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
     const float n2 = fdot(a, a);
     ok = ok && (n2 > 1.0e-30f) && (n2 < 1.0e30f);
     return fscale(a, rsqrtf(n2));
+}
+
+// acos(a) + acos(b) inside (small + margin, large - margin) for sure, decided on the cosine of the sum (file header)
+__device__ __forceinline__ bool faSumInside(float a, float b, const Prm& prm) {
+    const float c = a * b - __builtin_amdgcn_sqrtf(fmaf(-a, a, 1.0f) * fmaf(-b, b, 1.0f));
+    return (c < prm.faCosLo) && (c > prm.faCosHi) && (a + b > kFaSumMin);
 }
 
 // ---- face angles: per edge GOOD (0) / UNSURE (1) -------------------------------------------------------
@@ -68,15 +84,13 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s,
         const int cb = m.ecOff[e], nc = m.ecOff[e + 1] - cb;
         const F3 first = project(ldv(s.fAvg, m.ringFace[fb]));
         F3 prev = first;
-        const float lo = (float)prm.smallAngle + kFaMargin, hi = (float)prm.largeAngle - kFaMargin;
         bool inside = true;
         for (int i = 0; i < nc; ++i) {
             const F3 next = (i + 1 < nf) ? project(ldv(s.fAvg, m.ringFace[fb + i + 1])) : first;
             const F3 cV = project(ldv(s.cellCtr, m.ringCell[cb + i]));
             const float a = fdot(prev, cV), b = fdot(cV, next);
             ok = ok && (fabsf(a) < kNearClamp) && (fabsf(b) < kNearClamp);
-            const float ang = acosf(a) + acosf(b);
-            inside = inside && (ang > lo) && (ang < hi);     // NaN -> false -> UNSURE
+            inside = inside && faSumInside(a, b, prm);      // NaN -> false -> UNSURE
             prev = next;
         }
         if (ok && inside && nc > 0) flag = 0;
@@ -355,7 +369,6 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         const V3 cC = 0.5 * (e0 + e1);
         bool ok = true, inside = true;
         const F3 eV = funit(f3(e1 - e0), ok);
-        const float lo = (float)prm.smallAngle + kFaMargin, hi = (float)prm.largeAngle - kFaMargin;
         F3 first = {0, 0, 0}, prev = {0, 0, 0}, cPend = {0, 0, 0};
         bool pend = false;
 #define SMGPU_FA_PROJECT(OUT, C)                                                        \
@@ -370,8 +383,7 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         {                                                                               \
             const float a_ = fdot(prev, cPend), b_ = fdot(cPend, (NEXT));               \
             ok = ok && (fabsf(a_) < kNearClamp) && (fabsf(b_) < kNearClamp);            \
-            const float ang_ = acosf(a_) + acosf(b_);                                   \
-            inside = inside && (ang_ > lo) && (ang_ < hi);                              \
+            inside = inside && faSumInside(a_, b_, prm);                                \
         }
 #define SMGPU_FA_STEP(J, FE, CE)                                                        \
         if ((FE) != kPad) {                                                             \

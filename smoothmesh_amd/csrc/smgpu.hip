@@ -238,6 +238,11 @@ static Prm makePrm(const smgpu_handle* h) {
     r.totalMinFreeze = p.totalMinFreeze;
     r.smallAngle = SMGPU_PI * p.minAngle / 180.0;   // SM.C:921,1364
     r.largeAngle = SMGPU_PI * p.maxAngle / 180.0;   // SM.C:1365
+    // the f32 face-angle filter tests cos(angle sum): GOOD for sure iff faCosHi < cos < faCosLo (and the sum is below pi); out-of-range
+    // parameters leave it undecided (every edge then takes the exact path); NaN compares false everywhere
+    const double M = (double)kFaMargin + 2.0e-5;
+    r.faCosLo = (r.smallAngle >= SMGPU_PI) ? -2.0f : (float)(std::cos(std::max(r.smallAngle, 0.0)) - M);
+    r.faCosHi = (r.largeAngle <= 0.0) ? 2.0f : (float)(std::cos(std::min(r.largeAngle, SMGPU_PI)) + M);
     return r;
 }
 

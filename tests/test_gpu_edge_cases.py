@@ -190,3 +190,16 @@ def test_openfoam_org_geometry_variant(oracle_lib, monkeypatch, mesh_kind, tiles
         e2.set_params(p)
         e2.iterate(5, 0.0)
         assert not np.array_equal(e2.get_points(), e.get_points())
+
+
+@pytest.mark.parametrize("angles", [(0.0, 180.0), (0.0, 90.0), (89.0, 91.0), (35.0, 179.9), (-5.0, 200.0), (60.0, 120.0), (120.0, 100.0),
+                                    (179.0, 180.0), (35.0, 0.0)])
+@pytest.mark.parametrize("kind", ["hex", "cavity"])
+def test_face_angle_filter_at_extreme_thresholds(oracle_lib, kind, angles):
+    """The f32 face-angle filter decides on the cosine of an angle sum against host-prepared thresholds (kernels_filter.hpp):
+    thresholds at and beyond the ends of [0, 180] degrees, a two-degree band around the block's own right angles (every edge
+    borderline), a band that excludes them, an empty and an inverted range -- the frozen sets must stay those of the oracle."""
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import cavity_mesh
+    m = hex_block(9, 8, 7, jitter=0.3, seed=4) if kind == "hex" else cavity_mesh(10, jitter=0.25, seed=4)
+    _compare(m, oracle_lib, iters=4, minAngle=angles[0], maxAngle=angles[1])
