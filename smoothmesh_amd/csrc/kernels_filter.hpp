@@ -309,7 +309,6 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
     const ushort4* fRow = reinterpret_cast<const ushort4*>(g.efEll + tm.efBase) + tid;
     const ushort4* cRow = reinterpret_cast<const ushort4*>(g.ecEll + tm.ecBase) + tid;
     const ushort4 padq = make_ushort4(0xFFFF, 0xFFFF, 0xFFFF, 0xFFFF);
-    int e = 0;
     unsigned ep = 0;
     ushort4 f0 = padq, f1 = padq, c0 = padq, c1 = padq;
     if (tm.nFaces <= 3 * T && tm.nCells <= 2 * T && tm.nPts <= 2 * T) {
@@ -323,7 +322,6 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         for (int u = 0; u < 2; ++u) { const int i = u * T + tid; c[u] = (i < tm.nPts) ? idP[i] : -1; }
         const int lane = mine ? tid : 0;
         const int ei = tm.edgeBeg + lane;
-        const int e1 = g.order[ei];
         const unsigned ep1 = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
         const ushort4* fl = reinterpret_cast<const ushort4*>(g.efEll + tm.efBase) + lane;
         const ushort4* cl = reinterpret_cast<const ushort4*>(g.ecEll + tm.ecBase) + lane;
@@ -342,7 +340,7 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int i = u * T + tid; if (c[u] >= 0) { px[i] = vc[u].x; py[i] = vc[u].y; pz[i] = vc[u].z; } }
         if (mine) {
-            e = e1; ep = ep1;
+            ep = ep1;
             f0 = g0; c0 = h0;
             if (wf4 > 1) f1 = g1;
             if (wc4 > 1) c1 = h1;
@@ -350,7 +348,6 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
     } else {
         if (mine) {
             const int ei = tm.edgeBeg + tid;
-            e = g.order[ei];
             ep = reinterpret_cast<const unsigned*>(g.epLoc)[ei];
             if (wf4 > 0) f0 = fRow[0];
             if (wf4 > 1) f1 = fRow[T];
@@ -412,7 +409,7 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
 #undef SMGPU_FA_PROJECT
         if (ok && inside) flag = 0;
     }
-    if (flag) markUnsureEdge(s, edges, e, faMaybe);
+    if (flag) markUnsureEdge(s, edges, g.order[tm.edgeBeg + tid], faMaybe);   // (the edge's id is needed here only: 4 bytes per edge not read)
 }
 
 }  // namespace smgpu
