@@ -144,3 +144,15 @@ def test_stand_in_headers_say_what_they_are():
     d = os.path.join(ROOT, "tests", "adapter_stubs")
     for f in os.listdir(d):
         assert "TEST INFRASTRUCTURE" in open(os.path.join(d, f)).read(), f
+
+
+def test_integration_md_names_every_entry_point():
+    """INTEGRATION.md's table 'Every entry point of include/smgpu.h' must name each declared function, and nothing that is
+    not declared"""
+    header = _strip_comments(open(os.path.join(ROOT, "include", "smgpu.h")).read())
+    declared = set(re.findall(r"\b(smgpu_[a-z_0-9]+)\s*\(", header))
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = doc[doc.index("## Every entry point of `include/smgpu.h`"):]
+    named = set(re.findall(r"`(smgpu_[a-z_0-9]+)`", table))
+    assert declared - named == set(), sorted(declared - named)
+    assert named - declared == set(), sorted(named - declared)
