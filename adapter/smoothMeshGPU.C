@@ -56,6 +56,7 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <set>
 #include <vector>
 
 #include "smgpu.h"
@@ -162,8 +163,10 @@ PatchTable patchTable(const fvMesh& mesh, const labelList& selectedIds)
 }
 
 // Shared-point tables of this rank (what smoothmesh_amd/halo.py:HaloTables builds):
-// candidates = global ids of the points on my processor patches; a point is shared with
-// rank r when r lists it too.  Slots: per peer in ascending rank, ascending global id.
+// Who shares a point with whom follows OpenFOAM's own globalPoints (what syncTools::syncPointList uses): the copies of a point
+// on the two sides of a processor patch are the same point, and so is everything connected through such pairs (a rank has
+// one local point per mesh point, which joins all its patches) -- and nothing else: the two sides of a baffle on different ranks
+// are different shared points, or none.  Slots: per peer in ascending rank, ascending global id.
 struct HaloTables
 {
     std::vector<int32_t> sharedLocal, sendShared, combOffsets, combSlots;
@@ -177,30 +180,96 @@ HaloTables buildHalo(const fvMesh& mesh, const labelList& pointProcAddressing)
 {
     HaloTables t;
     const label me = Pstream::myProcNo();
-    labelHashSet mine;
+    const label nProcs = Pstream::nProcs();
+    // my processor patches, flattened: {neighbour, count, global point ids ascending ...}*
+    std::vector<label> flat;
     forAll(mesh.boundaryMesh(), patchI)
     {
         const polyPatch& pp = mesh.boundaryMesh()[patchI];
         if (!isA<processorPolyPatch>(pp)) continue;
         const labelList& mp = pp.meshPoints();
-        forAll(mp, i) mine.insert(pointProcAddressing[mp[i]]);
+        std::set<label> ids;
+        forAll(mp, i) ids.insert(pointProcAddressing[mp[i]]);
+        flat.push_back(refCast<const processorPolyPatch>(pp).neighbProcNo());
+        flat.push_back(static_cast<label>(ids.size()));
+        flat.insert(flat.end(), ids.begin(), ids.end());
     }
-    List<labelList> all(Pstream::nProcs());
-    all[me] = mine.sortedToc();
+    List<labelList> all(nProcs);
+    all[me].setSize(static_cast<label>(flat.size()));
+    forAll(all[me], i) all[me][i] = flat[static_cast<size_t>(i)];
     Pstream::gatherList(all);
     Pstream::scatterList(all);
+
+    // per rank: neighbour -> ids, and the union of its patch points
+    std::vector<std::map<label, std::vector<label>>> patch(static_cast<size_t>(nProcs));
+    std::vector<std::vector<label>> ids(static_cast<size_t>(nProcs));
+    for (label o = 0; o < nProcs; ++o)
+    {
+        const labelList& v = all[o];
+        for (label k = 0; k + 1 < v.size();)
+        {
+            const label nb = v[k], c = v[k + 1];
+            std::vector<label>& dst = patch[static_cast<size_t>(o)][nb];
+            for (label j = 0; j < c; ++j) dst.push_back(v[k + 2 + j]);
+            k += 2 + c;
+        }
+        for (auto& kv : patch[static_cast<size_t>(o)])
+        {
+            std::sort(kv.second.begin(), kv.second.end());
+            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+            ids[static_cast<size_t>(o)].insert(ids[static_cast<size_t>(o)].end(), kv.second.begin(), kv.second.end());
+        }
+        std::vector<label>& io = ids[static_cast<size_t>(o)];
+        std::sort(io.begin(), io.end());
+        io.erase(std::unique(io.begin(), io.end()), io.end());
+    }
+    // union-find over (rank, point) nodes: one link per point of every matching patch pair
+    std::vector<size_t> nodeBase(static_cast<size_t>(nProcs) + 1, 0);
+    for (label o = 0; o < nProcs; ++o) nodeBase[static_cast<size_t>(o) + 1] = nodeBase[static_cast<size_t>(o)] + ids[static_cast<size_t>(o)].size();
+    std::vector<size_t> parent(nodeBase[static_cast<size_t>(nProcs)]);
+    for (size_t i = 0; i < parent.size(); ++i) parent[i] = i;
+    auto find = [&](size_t a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    auto node = [&](label o, label g)
+    {
+        const std::vector<label>& io = ids[static_cast<size_t>(o)];
+        return nodeBase[static_cast<size_t>(o)] + static_cast<size_t>(std::lower_bound(io.begin(), io.end(), g) - io.begin());
+    };
+    for (label a = 0; a < nProcs; ++a)
+    {
+        for (const auto& kv : patch[static_cast<size_t>(a)])
+        {
+            const label b = kv.first;
+            if (b <= a || b >= nProcs) continue;
+            const auto it = patch[static_cast<size_t>(b)].find(a);
+            if (it == patch[static_cast<size_t>(b)].end()) continue;
+            std::vector<label> common;
+            std::set_intersection(kv.second.begin(), kv.second.end(), it->second.begin(), it->second.end(), std::back_inserter(common));
+            for (label g : common)
+            {
+                const size_t x = find(node(a, g)), y = find(node(b, g));
+                if (x != y) parent[x] = y;
+            }
+        }
+    }
 
     std::map<label, label> localOf;      // global id -> local id
     forAll(pointProcAddressing, p) localOf[pointProcAddressing[p]] = p;
 
-    std::map<label, std::vector<int>> sharers;   // global id -> ranks holding it (ascending)
-    std::vector<std::vector<label>> with(Pstream::nProcs());
-    for (label r = 0; r < Pstream::nProcs(); ++r)
+    std::map<size_t, label> rootOfMine;  // root -> my point's global id
+    for (size_t i = 0; i < ids[static_cast<size_t>(me)].size(); ++i) rootOfMine[find(nodeBase[static_cast<size_t>(me)] + i)] = ids[static_cast<size_t>(me)][i];
+    std::map<label, std::vector<int>> sharers;   // global id -> the OTHER ranks of my point's group (ascending)
+    std::vector<std::vector<label>> with(static_cast<size_t>(nProcs));
+    for (label r = 0; r < nProcs; ++r)
     {
         if (r == me) continue;
-        std::set_intersection(all[me].begin(), all[me].end(), all[r].begin(), all[r].end(),
-                              std::back_inserter(with[r]));
-        for (label g : with[r]) sharers[g].push_back(r);
+        for (size_t i = 0; i < ids[static_cast<size_t>(r)].size(); ++i)
+        {
+            const auto it = rootOfMine.find(find(nodeBase[static_cast<size_t>(r)] + i));
+            if (it == rootOfMine.end()) continue;
+            with[static_cast<size_t>(r)].push_back(it->second);
+            sharers[it->second].push_back(static_cast<int>(r));
+        }
+        std::sort(with[static_cast<size_t>(r)].begin(), with[static_cast<size_t>(r)].end());
     }
     std::map<label, int32_t> sharedIndex;
     for (const auto& kv : sharers)

@@ -15,7 +15,7 @@ from smoothmesh_amd.meshgen import hex_subdomain
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 100
 grid = (2, 2, 2)
 subs = [hex_subdomain((n, n, n), grid, r, jitter=0.2, seed=12345) for r in range(8)]
-cands = [s.processor_patch_points() for s in subs]
+cands = [s.processor_patch_point_lists() for s in subs]
 sub = subs[0]
 sub.nRanks = 1          # the process group has one member; the tables below are those of rank 0 among 8
 real_gather = dist.all_gather_object

@@ -214,6 +214,7 @@ struct Rank {
     // halo
     std::vector<int32_t> sharedLocal, sendShared, combOff, combSlots;
     std::vector<int64_t> sharedGlobal;
+    std::vector<std::vector<int>> sharersOf;            // per shared point: the ranks of its group, ascending, this rank included
     std::vector<int> peerCount, peerSendBase;
     double *sendA = nullptr, *recvA = nullptr, *localStats = nullptr, *sendL = nullptr, *recvL = nullptr;
     int32_t *sendF = nullptr, *recvF = nullptr;
@@ -229,14 +230,73 @@ std::string findInstance(const std::string& root, const std::vector<std::pair<do
     return root + "/constant/polyMesh";
 }
 
-// the shared-point tables of this rank from every rank's processor-patch points (what smoothmesh_amd/halo.py:HaloTables builds)
-void buildHalo(Rank& K, int r, int n, const std::vector<std::vector<int64_t>>& cand) {
+// Who shares which point with this rank, as OpenFOAM's globalPoints finds it: the copies of a point on the two sides of a
+// PROCESSOR PATCH are the same point, and so is everything connected through such pairs (a rank has one local point per mesh
+// point, which joins all its patches) -- and nothing else: the two sides of a baffle (createBaffles, the reference's testcase6)
+// on different ranks are different shared points, or none (smoothmesh_amd/decompose.py:shared_point_components is the same rule).
+// lists[r] = rank r's processor patches, flattened: {neighbour, count, ids ascending ...}*
+// -> for every shared point of rank r (global id): the ranks of its group, ascending, r included
+std::map<int64_t, std::vector<int>> sharedGroupsOf(int r, int n, const std::vector<std::vector<int64_t>>& lists) {
+    std::vector<std::map<int, std::vector<int64_t>>> patch((size_t)n);
+    std::vector<std::vector<int64_t>> ids((size_t)n);
+    for (int o = 0; o < n; ++o) {
+        const auto& v = lists[(size_t)o];
+        for (size_t k = 0; k + 1 < v.size();) {
+            const int nb = (int)v[k]; const size_t c = (size_t)v[k + 1];
+            auto& dst = patch[(size_t)o][nb];
+            dst.insert(dst.end(), v.begin() + (ptrdiff_t)(k + 2), v.begin() + (ptrdiff_t)(k + 2 + c));
+            k += 2 + c;
+        }
+        for (auto& kv : patch[(size_t)o]) {
+            std::sort(kv.second.begin(), kv.second.end());
+            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
+            ids[(size_t)o].insert(ids[(size_t)o].end(), kv.second.begin(), kv.second.end());
+        }
+        std::sort(ids[(size_t)o].begin(), ids[(size_t)o].end());
+        ids[(size_t)o].erase(std::unique(ids[(size_t)o].begin(), ids[(size_t)o].end()), ids[(size_t)o].end());
+    }
+    std::vector<size_t> base((size_t)n + 1, 0);
+    for (int o = 0; o < n; ++o) base[(size_t)o + 1] = base[(size_t)o] + ids[(size_t)o].size();
+    std::vector<size_t> parent(base[(size_t)n]);
+    for (size_t i = 0; i < parent.size(); ++i) parent[i] = i;
+    auto find = [&](size_t a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    auto node = [&](int o, int64_t g) { return base[(size_t)o] + (size_t)(std::lower_bound(ids[(size_t)o].begin(), ids[(size_t)o].end(), g) - ids[(size_t)o].begin()); };
+    for (int a = 0; a < n; ++a)
+        for (const auto& kv : patch[(size_t)a]) {
+            const int b = kv.first;
+            if (b <= a || b >= n) continue;
+            const auto it = patch[(size_t)b].find(a);
+            if (it == patch[(size_t)b].end()) continue;
+            std::vector<int64_t> common;
+            std::set_intersection(kv.second.begin(), kv.second.end(), it->second.begin(), it->second.end(), std::back_inserter(common));
+            for (int64_t g : common) {
+                const size_t x = find(node(a, g)), y = find(node(b, g));
+                if (x != y) parent[x] = y;
+            }
+        }
+    std::map<size_t, std::vector<int>> members;        // root -> ranks (ascending: filled in rank order), only roots of r's nodes
+    std::map<size_t, int64_t> rootOfMine;
+    for (size_t i = 0; i < ids[(size_t)r].size(); ++i) rootOfMine[find(base[(size_t)r] + i)] = ids[(size_t)r][i];
+    for (int o = 0; o < n; ++o)
+        for (size_t i = 0; i < ids[(size_t)o].size(); ++i) {
+            const size_t root = find(base[(size_t)o] + i);
+            if (rootOfMine.count(root)) members[root].push_back(o);
+        }
+    std::map<int64_t, std::vector<int>> out;
+    for (const auto& kv : members)
+        if (kv.second.size() >= 2) out[rootOfMine.at(kv.first)] = kv.second;
+    return out;
+}
+
+// the shared-point tables of this rank from its points' groups (what smoothmesh_amd/halo.py:HaloTables builds)
+void buildHalo(Rank& K, int r, int n, const std::map<int64_t, std::vector<int>>& groups) {
     std::vector<std::vector<int64_t>> shared(n);
     std::set<int64_t> all;
-    for (int o = 0; o < n; ++o) {
-        if (o == r) continue;
-        std::set_intersection(cand[r].begin(), cand[r].end(), cand[o].begin(), cand[o].end(), std::back_inserter(shared[o]));
-        all.insert(shared[o].begin(), shared[o].end());
+    K.sharersOf.clear();
+    for (const auto& kv : groups) {                    // (ascending global id)
+        all.insert(kv.first);
+        K.sharersOf.push_back(kv.second);
+        for (int o : kv.second) if (o != r) shared[(size_t)o].push_back(kv.first);
     }
     K.sharedGlobal.assign(all.begin(), all.end());
     std::map<int64_t, int32_t> g2l;
@@ -269,14 +329,20 @@ void buildHalo(Rank& K, int r, int n, const std::vector<std::vector<int64_t>>& c
     }
 }
 
-std::vector<int64_t> processorPatchPoints(const Rank& K) {
-    std::set<int64_t> s;
+// this rank's processor patches as {neighbour, count, global point ids ascending ...}* (sharedGroupsOf)
+std::vector<int64_t> processorPatchLists(const Rank& K) {
+    std::vector<int64_t> out;
     const auto& m = K.mesh;
     for (const auto& p : m.patches)
-        if (p.type == "processor")
+        if (p.type == "processor") {
+            std::set<int64_t> s;
             for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
                 for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) s.insert(K.pointProc[(size_t)m.facePoints[k]]);
-    return std::vector<int64_t>(s.begin(), s.end());
+            out.push_back((int64_t)p.neighbProcNo);
+            out.push_back((int64_t)s.size());
+            out.insert(out.end(), s.begin(), s.end());
+        }
+    return out;
 }
 
 }  // namespace
@@ -543,7 +609,7 @@ int main(int argc, char** argv) {
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
     std::vector<std::vector<int64_t>> sharedGlobalOf;   // every rank's shared points (global ids, ascending): the set-up syncs
     if (opt.parallel) {
-        buildHalo(K0, myRank, nRanks, g_comm.allgatherVec(processorPatchPoints(K0)));
+        buildHalo(K0, myRank, nRanks, sharedGroupsOf(myRank, nRanks, g_comm.allgatherVec(processorPatchLists(K0))));
         sharedGlobalOf = g_comm.allgatherVec(K0.sharedGlobal);
         for (Rank& K : R) {
             HIPCHK(hipSetDevice(K.device));
@@ -615,13 +681,13 @@ int main(int argc, char** argv) {
             double* x = &v[i * width];
             if (op == 1) for (int c = 0; c < width; ++c) x[c] = 0.0;
             bool first = true;
-            for (int o = 0; o < nRanks; ++o) {
+            for (int o : K0.sharersOf[i]) {                              // the point's group (not every rank that holds the id)
                 const double* y = nullptr;
                 if (o == myRank) y = &mine[i * width];
                 else {
                     const auto& sg = sharedGlobalOf[(size_t)o];
                     const auto it = std::lower_bound(sg.begin(), sg.end(), g);
-                    if (it == sg.end() || *it != g) continue;           // rank o does not hold this point
+                    if (it == sg.end() || *it != g) fatal("shared-point tables disagree between ranks");
                     y = &sent[(size_t)o][(size_t)(it - sg.begin()) * width];
                 }
                 if (op == 1) { for (int c = 0; c < width; ++c) x[c] = x[c] + y[c]; continue; }

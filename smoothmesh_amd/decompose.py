@@ -40,6 +40,67 @@ class SubDomain:
         return np.unique(self.pointProcAddressing[np.concatenate(ids)])
 
 
+    def processor_patch_point_lists(self) -> dict:
+        """{neighbour rank: sorted unique GLOBAL ids of the points on this rank's processor patch to that neighbour}"""
+        m = self.mesh
+        out = {}
+        for p in m.patches:
+            if p.type == "processor" and p.nFaces:
+                a, b = m.faceOffsets[p.startFace], m.faceOffsets[p.startFace + p.nFaces]
+                ids = np.unique(self.pointProcAddressing[m.facePoints[a:b]])
+                o = int(p.neighbProcNo)
+                out[o] = np.union1d(out[o], ids) if o in out else ids
+        return out
+
+
+def shared_point_components(patch_lists):
+    """The copies of points that syncTools::syncPointList combines, as OpenFOAM's globalPoints finds them: the copies of a point
+    on the two sides of a PROCESSOR PATCH are the same point, and so is everything connected through such pairs (transitive
+    closure; a rank has one local point per mesh point, which joins all its patches) -- and nothing else.  Two ranks that hold
+    the same mesh point but are connected by no chain of processor faces through it do NOT share it: the two sides of a baffle
+    (createBaffles; the reference's testcase6) on different ranks, or two cells that touch in a point only across a solid
+    region.  On a manifold mesh this is "every rank that holds the point on a processor patch".
+    patch_lists[r] = {neighbour: sorted global ids on r's patch to it} (SubDomain.processor_patch_point_lists).
+    -> (node_rank, node_gid, comp, comp_size): one node per (rank, point on one of its processor patches), its component label
+    and that component's number of members."""
+    from scipy.sparse import coo_matrix
+    from scipy.sparse.csgraph import connected_components
+    nR = len(patch_lists)
+    ids = [np.unique(np.concatenate([np.asarray(v, np.int64) for v in lists.values()])) if lists else np.zeros(0, np.int64) for lists in patch_lists]
+    base = np.concatenate([[0], np.cumsum([len(i) for i in ids])]).astype(np.int64)
+    n = int(base[-1])
+    node_rank = np.concatenate([np.full(len(i), r, np.int32) for r, i in enumerate(ids)]) if n else np.zeros(0, np.int32)
+    node_gid = np.concatenate(ids) if n else np.zeros(0, np.int64)
+    ea, eb = [], []
+    for r, lists in enumerate(patch_lists):
+        for o, mine in lists.items():
+            o = int(o)
+            if o <= r or r not in patch_lists[o]:
+                continue
+            common = np.intersect1d(np.asarray(mine, np.int64), np.asarray(patch_lists[o][r], np.int64))
+            ea.append(base[r] + np.searchsorted(ids[r], common))
+            eb.append(base[o] + np.searchsorted(ids[o], common))
+    if n == 0:
+        return node_rank, node_gid, np.zeros(0, np.int32), np.zeros(0, np.int64)
+    ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
+    eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
+    _, comp = connected_components(coo_matrix((np.ones(len(ea), np.int8), (ea, eb)), shape=(n, n)), directed=False)
+    return node_rank, node_gid, comp.astype(np.int64), np.bincount(comp)[comp]
+
+
+def shared_point_groups(patch_lists):
+    """-> {global id: [sorted rank lists, one per group with >= 2 members]} (shared_point_components, for tests and small cases)"""
+    node_rank, node_gid, comp, size = shared_point_components(patch_lists)
+    groups = {}
+    by_comp = {}
+    for r, g, c, k in zip(node_rank.tolist(), node_gid.tolist(), comp.tolist(), size.tolist()):
+        if k >= 2:
+            by_comp.setdefault((g, c), []).append(r)
+    for (g, _), ranks in by_comp.items():
+        groups.setdefault(g, []).append(sorted(ranks))
+    return groups
+
+
 def grid_partition(mesh: PolyMesh, grid) -> np.ndarray:
     """decomposePar 'simple'-like geometric partition: split the bounding box of the cell-centre
     estimates (mean of the cell's face vertex averages) into grid[0] x grid[1] x grid[2] boxes."""
@@ -118,18 +179,25 @@ def decompose(mesh: PolyMesh, cellRank: np.ndarray, nRanks: int) -> List[SubDoma
 
 
 def shared_point_table(subs: List[SubDomain]):
-    """Global view (tests / single-process drivers): CSR over points held by >= 2 sub-domains ->
-    (offsets, domain ids ascending, local ids)."""
-    g = np.concatenate([s.pointProcAddressing for s in subs])
-    d = np.concatenate([np.full(len(s.pointProcAddressing), s.rank, np.int32) for s in subs])
-    l = np.concatenate([np.arange(len(s.pointProcAddressing), dtype=np.int32) for s in subs])
-    order = np.lexsort((d, g))
-    g, d, l = g[order], d[order], l[order]
-    uniq, first, cnt = np.unique(g, return_index=True, return_counts=True)
-    keep = cnt >= 2
-    idx = np.concatenate([np.arange(f, f + c) for f, c in zip(first[keep], cnt[keep])]) if keep.any() else np.zeros(0, np.int64)
-    off = np.zeros(keep.sum() + 1, np.int32); np.cumsum(cnt[keep], out=off[1:])
-    return off, d[idx], l[idx]
+    """Global view (tests / single-process drivers): CSR over the shared points (shared_point_components: copies connected
+    through processor patches) -> (offsets, domain ids ascending, local ids).  Ordered by global id, then by the lowest sharer."""
+    node_rank, node_gid, comp, size = shared_point_components([s.processor_patch_point_lists() for s in subs])
+    keep = size >= 2
+    node_rank, node_gid, comp = node_rank[keep], node_gid[keep], comp[keep]
+    if len(comp) == 0:
+        return np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32)
+    low = np.full(int(comp.max()) + 1, len(subs), np.int64)
+    np.minimum.at(low, comp, node_rank)
+    order = np.lexsort((node_rank, comp, low[comp], node_gid))
+    node_rank, node_gid, comp = node_rank[order], node_gid[order], comp[order]
+    first = np.concatenate([[True], (comp[1:] != comp[:-1])])
+    off = np.concatenate([np.flatnonzero(first), [len(comp)]]).astype(np.int32)
+    loc = np.zeros(len(comp), np.int32)
+    for s in subs:
+        m = node_rank == s.rank
+        o = np.argsort(s.pointProcAddressing, kind="stable")
+        loc[m] = o[np.searchsorted(s.pointProcAddressing[o], node_gid[m])]
+    return off, node_rank.astype(np.int32), loc
 
 
 def bfs_partition(mesh: PolyMesh, nRanks: int, seed: int = 0, island: bool = False) -> np.ndarray:

@@ -19,20 +19,20 @@ L_DOUBLES = 14  # SMGPU_HALO_L_DOUBLES (layer treatment / boundary point smoothi
 
 
 class HaloTables:
-    """Slot tables of one rank from the per-rank lists of processor-patch point ids."""
+    """Slot tables of one rank from every rank's processor-patch point lists."""
 
-    def __init__(self, rank, pointProcAddressing, candidates):
-        """candidates[r] = sorted unique global ids of rank r's processor-patch points"""
+    def __init__(self, rank, pointProcAddressing, patch_lists):
+        """patch_lists[r] = {neighbour: sorted unique global ids of the points on rank r's processor patch to it}
+        (SubDomain.processor_patch_point_lists).  Who shares a point with whom follows OpenFOAM's globalPoints
+        (decompose.shared_point_groups): copies connected through processor patches -- not "every rank that holds the id": the
+        two sides of a baffle on different ranks are different shared points, or none."""
+        from .decompose import shared_point_components
         self.rank = rank
-        n = len(candidates)
-        mine = candidates[rank]
-        shared_with = {}
-        for o in range(n):
-            if o == rank:
-                continue
-            s = np.intersect1d(mine, candidates[o], assume_unique=True)
-            if len(s):
-                shared_with[o] = s
+        n = len(patch_lists)
+        node_rank, node_gid, comp, size = shared_point_components(patch_lists)
+        mine = (node_rank == rank) & (size >= 2)         # (a rank has ONE local point per id: it is in at most one group per id)
+        others = np.isin(comp, comp[mine]) & (node_rank != rank)
+        shared_with = {int(o): np.sort(node_gid[others & (node_rank == o)]) for o in np.unique(node_rank[others])}
         allg = np.unique(np.concatenate(list(shared_with.values()))) if shared_with else np.zeros(0, np.int64)
         # local ids of the shared points, ordered by global id
         order = np.argsort(pointProcAddressing, kind="stable")
@@ -281,7 +281,7 @@ class DistributedSmoother:
             torch_device = torch.device("cuda", device)
         self.device = torch_device
         cands = [None] * self.world
-        dist.all_gather_object(cands, sub.processor_patch_points())
+        dist.all_gather_object(cands, sub.processor_patch_point_lists())
         self.tables = HaloTables(self.rank, sub.pointProcAddressing, cands)
         if engine_factory is None:
             from .engine import SmoothEngine
@@ -691,7 +691,7 @@ class LocalMultiSmoother:
         if torch_device is None:
             torch_device = torch.device("cuda", device)
         self.device = torch_device
-        cands = [s.processor_patch_points() for s in subs]
+        cands = [s.processor_patch_point_lists() for s in subs]
         self.states = []
         for s in subs:
             t = HaloTables(s.rank, s.pointProcAddressing, cands)

@@ -286,3 +286,47 @@ def extrude_surface(verts, faces2d, nLayers=15, thickness=1.5, direction=(0.0, 1
     return PolyMesh(points=pts, faceOffsets=off, facePoints=np.concatenate([np.asarray(f, np.int32) for f in allf]),
                     owner=np.asarray(owner, np.int32), neighbour=np.asarray([t[1] for t in internal], np.int32), patches=patches,
                     nCells=nF * nLayers)
+
+
+def add_baffle(mesh: PolyMesh, select, name="baffle") -> PolyMesh:
+    """createBaffles on a PolyMesh: the internal faces with select[f] true become PAIRS of boundary faces on the same points --
+    the owner's face in patch `<name>_master`, the neighbour's (reversed, so that it points out of its cell) in `<name>_slave` --
+    appended behind the existing patches; the remaining internal faces keep their order (the reference's testcase6 builds
+    such a mesh with createBaffles, `testcase6/system/createBafflesDict`)."""
+    nI = mesh.nInternalFaces
+    select = np.asarray(select, bool)
+    assert select.shape == (nI,) and select.any()
+    off, fp = mesh.faceOffsets, mesh.facePoints
+
+    def rows(ids, reverse=False):
+        out = []
+        for f in ids:
+            r = fp[off[f]:off[f + 1]]
+            out.append(np.concatenate([r[:1], r[:0:-1]]) if reverse else r)    # reversed face starts at the same point
+        return out
+
+    keep = np.flatnonzero(~select)
+    gone = np.flatnonzero(select)
+    old_b = np.arange(nI, mesh.nFaces)
+    faces = rows(keep) + rows(old_b) + rows(gone) + rows(gone, reverse=True)
+    owner = np.concatenate([mesh.owner[keep], mesh.owner[old_b], mesh.owner[gone], mesh.neighbour[gone]])
+    patches = [Patch(name=p.name, type=p.type, nFaces=p.nFaces, startFace=p.startFace - len(gone)) for p in mesh.patches]
+    start = mesh.nFaces - len(gone)
+    patches.append(Patch(name=name + "_master", type="wall", nFaces=len(gone), startFace=start))
+    patches.append(Patch(name=name + "_slave", type="wall", nFaces=len(gone), startFace=start + len(gone)))
+    sizes = np.array([len(r) for r in faces], np.int64)
+    return PolyMesh(points=mesh.points.copy(), faceOffsets=np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32),
+                    facePoints=np.concatenate(faces).astype(np.int32), owner=owner.astype(np.int32),
+                    neighbour=mesh.neighbour[keep].astype(np.int32), patches=patches, nCells=mesh.nCells)
+
+
+def baffle_in_plane(lattice: PolyMesh, axis, value, also=None) -> np.ndarray:
+    """selection for add_baffle: the internal faces of the UNJITTERED mesh `lattice` whose centre lies in the plane
+    coordinate[axis] = value (and satisfies also(centres))"""
+    nI = lattice.nInternalFaces
+    off = lattice.faceOffsets
+    n = off[1:nI + 1] - off[:nI]
+    assert (n == n[0]).all()                   # (hex lattices: all quadrilaterals)
+    ctr = lattice.points[lattice.facePoints[:off[nI]].reshape(nI, n[0])].mean(axis=1)
+    sel = np.abs(ctr[:, axis] - value) < 1e-9
+    return sel & also(ctr) if also is not None else sel

@@ -203,3 +203,33 @@ def test_face_angle_filter_at_extreme_thresholds(oracle_lib, kind, angles):
     from smoothmesh_amd.polymesh import cavity_mesh
     m = hex_block(9, 8, 7, jitter=0.3, seed=4) if kind == "hex" else cavity_mesh(10, jitter=0.25, seed=4)
     _compare(m, oracle_lib, iters=4, minAngle=angles[0], maxAngle=angles[1])
+
+
+@pytest.mark.parametrize("variant", ["defaults", "busy", "layers", "no-constraints", "walk-fix"])
+def test_baffle_inside_the_block(oracle_lib, monkeypatch, variant):
+    """A zero-thickness wall inside the mesh (createBaffles; the reference's testcase6): pairs of boundary faces on the SAME points,
+    edges whose face ring is cut open by the wall, boundary points with cells on both sides -- constraints on and busy, layers grown
+    from both sides of the baffle (`-layerPatches '("baffle.*")'`, testcase6/run_serial:24), the fixed-point walk."""
+    from smoothmesh_amd import LayerParams, SmoothEngine, default_params, patch_arrays
+    from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane, hex_block
+    jit = 0.45 if variant in ("busy", "walk-fix") else 0.25
+    m = add_baffle(hex_block(10, 9, 8, jitter=jit, seed=6), baffle_in_plane(hex_block(10, 9, 8), 0, 0.5, lambda c: (c[:, 1] < 0.7) & (c[:, 2] > 0.2)))
+    assert [p.name for p in m.patches][-2:] == ["baffle_master", "baffle_slave"]
+    if variant == "walk-fix":
+        monkeypatch.setenv("SMGPU_WALK", "fix")
+    over = {"busy": dict(minAngle=50.0), "walk-fix": dict(minAngle=50.0), "no-constraints": dict(edgeAngleConstraint=False, faceAngleConstraint=False)}.get(variant, {})
+    o = oracle_lib.Oracle(m)
+    e = SmoothEngine(m)
+    prm = default_params(o.mesh_stats()[0], **over)
+    o.set_params(prm); e.set_params(prm)
+    if variant == "layers":
+        L = LayerParams(layerPatches=('"baffle.*"',), layerExpansionRatio=1.2, maxLayers=3)
+        st, sz, kd, sel = patch_arrays(m, L.layerPatches)
+        assert sel.sum() == 2
+        assert o.setup_layers(st, sz, kd, sel, L.layerMaxBlendingFraction, prm.minEdgeLength, 1.2, 1, 3) == e.set_layers(L, prm.minEdgeLength)
+    n_o, res_o, frz_o = o.iterate(8, 0.0)
+    n_g, res_g, frz_g = e.iterate(8, 0.0)
+    assert n_o == n_g and np.array_equal(frz_o, frz_g)
+    if variant in ("busy", "walk-fix"):
+        assert frz_o[0] > int((1 - m.find_internal_points()).sum()) + 20      # the constraints froze interior points
+    assert np.array_equal(e.get_points(), o.points())

@@ -49,7 +49,7 @@ def test_local_multi_smoother_on_irregular_partitions(oracle_lib, kind, nR, seed
         assert same.any() and np.array_equal(allp[order][1:][same], allp[order][:-1][same])
 
 
-@pytest.mark.parametrize("kind,nR,seed", [("hex_island", 3, 31), ("poly_bfs", 5, 32), ("two_blocks", 3, 33)])
+@pytest.mark.parametrize("kind,nR,seed", [("hex_island", 3, 31), ("poly_bfs", 5, 32), ("two_blocks", 3, 33), ("hex_baffle", 4, 34)])
 def test_parallel_cli_on_irregular_processor_directories(tmp_path, oracle_lib, kind, nR, seed):
     from smoothmesh_amd.decompose import decompose
     from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
@@ -80,3 +80,40 @@ def test_distributed_smoother_irregular_processes(spec, world, port):
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert r.stdout.count(": ok ") == 4 * world and "BAD" not in r.stdout
+
+
+@pytest.mark.parametrize("host", ["cli", "engines"])
+def test_baffle_between_ranks_with_layers_grown_from_it(tmp_path, oracle_lib, host):
+    """The reference's testcase6 in parallel (`-layerPatches '(walls "baffle.*")'`, testcase6/run_parallel) with the wall BETWEEN
+    ranks: the copies of a baffle point on its two sides are connected by no processor face, so syncTools::syncPointList does
+    not combine them (OpenFOAM's globalPoints; decompose.shared_point_components) -- the layer normals summed over the sharers
+    (OBB.C:184-190) stay one-sided there.  Through `smoothMesh -parallel` (its own C++ grouping) and through N engines on
+    one device (halo.HaloTables), against the oracle's MultiDomain on the tables of decompose.shared_point_table."""
+    from smoothmesh_amd import LayerParams, patch_arrays
+    from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
+    mesh, cr = build_case("hex_baffle", 4, 35)
+    subs, ser, orcs, mo, prm = _oracles(oracle_lib, mesh, cr, 4, True)
+    pats = ['"baffle.*"', "ymax"]
+    assert mo.setup_layers([patch_arrays(s.mesh, pats) for s in subs], 0.3, prm.minEdgeLength, 1.2, 1, 3)
+    n, res, frz = mo.iterate(6, 0.0)
+    if host == "cli":
+        write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+        r = subprocess.run([BIN, "-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0", "-minEdgeLength", repr(prm.minEdgeLength),
+                            "-maxStepLength", repr(prm.maxStepLength), "-layerPatches", '("baffle.*" ymax)', "-layerExpansionRatio", "1.2", "-maxLayers", "3"],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert "Enabled boundary layer treatment" in r.stdout
+        assert [int(b) for _, b, _ in LINE.findall(r.stdout)] == frz.tolist()
+        for s, o in zip(subs, orcs):
+            d = tmp_path / f"processor{s.rank}"
+            got = read_polymesh(str(d / "constant" / "polyMesh"), pointsDir=str(d / "6" / "polyMesh")).points
+            assert np.array_equal(got.reshape(-1), o.points().reshape(-1))
+    else:
+        from smoothmesh_amd.halo import LocalMultiSmoother
+        ms = LocalMultiSmoother(subs, device=0, overlap=False)
+        ms.set_params(prm)
+        assert ms.set_layers(LayerParams(layerPatches=tuple(pats), layerExpansionRatio=1.2, maxLayers=3), prm.minEdgeLength)
+        n_g, res_g, frz_g = ms.iterate(6, 0.0)
+        assert n_g == n and np.array_equal(frz_g, frz)
+        for o, pts in zip(orcs, ms.get_points()):
+            assert np.array_equal(pts, o.points())

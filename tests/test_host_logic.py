@@ -148,7 +148,7 @@ def test_halo_tables_are_symmetric():
     from smoothmesh_amd.meshgen import hex_subdomain
     grid = (2, 2, 1)
     subs = [hex_subdomain((3, 3, 2), grid, r) for r in range(4)]
-    cands = [s.processor_patch_points() for s in subs]
+    cands = [s.processor_patch_point_lists() for s in subs]
     tabs = [HaloTables(r, subs[r].pointProcAddressing, cands) for r in range(4)]
     for a in range(4):
         for b in range(4):

@@ -37,6 +37,17 @@ def build_case(kind, nRanks, seed):
     if kind == "poly_random":
         mesh = cavity_mesh(8, jitter=0.2, seed=seed)
         return mesh, random_partition(mesh, nRanks, seed=seed)
+    if kind == "hex_baffle":
+        # a zero-thickness wall inside the block (createBaffles, the reference's testcase6) in the plane x = 1/2, for y < 0.7 and
+        # z > 0.2, and FOUR ranks: x < 1/2 is split at y = 1/3 between ranks 0 and 2, x > 1/2 between ranks 1 and 3.  On the baffle
+        # the line y = 1/3 holds points that exist TWICE as shared points (0-2 on one side, 1-3 on the other: no processor face
+        # crosses the wall), the rest of the baffle points held by two ranks that do not share them at all.
+        from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane
+        nx, ny, nz = 10, 9, 8
+        mesh = add_baffle(hex_block(nx, ny, nz, jitter=0.25, seed=seed), baffle_in_plane(hex_block(nx, ny, nz), 0, 0.5, lambda c: (c[:, 1] < 0.7) & (c[:, 2] > 0.2)))
+        c = np.arange(mesh.nCells)
+        ci, cj = c % nx, (c // nx) % ny
+        return mesh, ((ci >= nx // 2).astype(np.int32) + 2 * (cj >= ny // 3).astype(np.int32)).astype(np.int32)
     if kind == "two_blocks":                       # the last rank holds a block of its own: no shared point at all
         a = hex_block(7, 6, 6, jitter=0.3, seed=seed)
         b = hex_block(4, 4, 3, jitter=0.3, seed=seed + 1)
@@ -46,7 +57,7 @@ def build_case(kind, nRanks, seed):
     raise ValueError(kind)
 
 
-CASES = [("hex_bfs", 3, 11), ("hex_island", 5, 12), ("hex_random", 8, 13), ("poly_bfs", 3, 14), ("poly_random", 5, 15), ("two_blocks", 3, 16)]
+CASES = [("hex_bfs", 3, 11), ("hex_island", 5, 12), ("hex_random", 8, 13), ("poly_bfs", 3, 14), ("poly_random", 5, 15), ("two_blocks", 3, 16), ("hex_baffle", 4, 17)]
 
 
 def _n_components(mesh, cells):
@@ -83,6 +94,20 @@ def test_the_cases_are_what_they_claim():
         if kind == "two_blocks":
             assert not (dom == nR - 1).any() and len(subs[nR - 1].processor_patch_points()) == 0
             assert not [p for p in subs[nR - 1].mesh.patches if p.type == "processor"]
+        if kind == "hex_baffle":
+            # the same mesh point as TWO shared points (one per side of the wall), and points held by two ranks that share nothing
+            held = {}
+            for s in subs:
+                for g in s.pointProcAddressing.tolist():
+                    held.setdefault(g, set()).add(s.rank)
+            grp = {}
+            for i in range(len(nsh)):
+                g = int(subs[dom[off[i]]].pointProcAddressing[loc[off[i]]])
+                grp.setdefault(g, []).append(sorted(dom[off[i]:off[i + 1]].tolist()))
+            twice = [g for g, v in grp.items() if len(v) == 2]
+            assert len(twice) >= 5 and all(sorted(grp[g]) == [[0, 2], [1, 3]] for g in twice)
+            unshared = [g for g, r in held.items() if len(r) >= 2 and g not in grp]
+            assert len(unshared) >= 20
         if kind == "hex_bfs":
             # ragged: the interface points do not lie in a plane
             g = np.unique(np.concatenate([s.pointProcAddressing[loc[dom == s.rank]] for s in subs]))
