@@ -330,3 +330,48 @@ def baffle_in_plane(lattice: PolyMesh, axis, value, also=None) -> np.ndarray:
     ctr = lattice.points[lattice.facePoints[:off[nI]].reshape(nI, n[0])].mean(axis=1)
     sel = np.abs(ctr[:, axis] - value) < 1e-9
     return sel & also(ctr) if also is not None else sel
+
+
+def split_baffles(mesh: PolyMesh, prefix="baffle") -> PolyMesh:
+    """splitBaffles / mergeOrSplitBaffles -split (the reference's testcase6/run_serial:17-18) on the patches whose name starts
+    with `prefix`: a point of those patches around which the cells fall into two groups not connected through an internal face
+    that contains the point -- the interior of the wall, not its rim -- gets a twin with the same coordinates (appended behind
+    the existing points); the second group's cells, and their faces, use the twin.  The wall becomes a slit of zero width."""
+    off, fp = mesh.faceOffsets, mesh.facePoints.copy()
+    nI = mesh.nInternalFaces
+    cand = set()
+    for p in mesh.patches:
+        if p.name.startswith(prefix):
+            cand |= set(fp[off[p.startFace]:off[p.startFace + p.nFaces]].tolist())
+    faces_of = {}                                    # point -> faces that contain it
+    face_of_pos = np.repeat(np.arange(mesh.nFaces), np.diff(off))
+    for pos in np.flatnonzero(np.isin(fp, list(cand))):
+        faces_of.setdefault(int(fp[pos]), []).append(int(face_of_pos[pos]))
+    pts = [mesh.points]
+    nP = mesh.nPoints
+    for p in sorted(cand):
+        cells = {}
+        def find(c):
+            while cells.setdefault(c, c) != c:
+                cells[c] = cells[cells[c]]
+                c = cells[c]
+            return c
+        for f in faces_of[p]:
+            find(int(mesh.owner[f]))
+            if f < nI:
+                a, b = find(int(mesh.owner[f])), find(int(mesh.neighbour[f]))
+                if a != b:
+                    cells[a] = b
+        roots = sorted({find(c) for c in list(cells)})
+        if len(roots) < 2:
+            continue
+        assert len(roots) == 2
+        keep = find(min(cells))                      # the group of the lowest cell keeps the point
+        for f in faces_of[p]:
+            if find(int(mesh.owner[f])) != keep:     # (an internal face lies inside one group: its owner decides)
+                seg = fp[off[f]:off[f + 1]]
+                seg[seg == p] = nP
+        pts.append(mesh.points[p:p + 1])
+        nP += 1
+    return PolyMesh(points=np.concatenate(pts), faceOffsets=off.copy(), facePoints=fp, owner=mesh.owner.copy(), neighbour=mesh.neighbour.copy(),
+                    patches=[Patch(name=q.name, type=q.type, nFaces=q.nFaces, startFace=q.startFace) for q in mesh.patches], nCells=mesh.nCells)

@@ -205,16 +205,21 @@ def test_face_angle_filter_at_extreme_thresholds(oracle_lib, kind, angles):
     _compare(m, oracle_lib, iters=4, minAngle=angles[0], maxAngle=angles[1])
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("variant", ["defaults", "busy", "layers", "no-constraints", "walk-fix"])
-def test_baffle_inside_the_block(oracle_lib, monkeypatch, variant):
-    """A zero-thickness wall inside the mesh (createBaffles; the reference's testcase6): pairs of boundary faces on the SAME points,
-    edges whose face ring is cut open by the wall, boundary points with cells on both sides -- constraints on and busy, layers grown
+def test_baffle_inside_the_block(oracle_lib, monkeypatch, variant, split):
+    """A zero-thickness wall inside the mesh (createBaffles; the reference's testcase6): pairs of boundary faces on the SAME points
+    (or, split, on coincident twins), edges whose face ring is cut open by the wall, boundary points with cells on both sides -- constraints on and busy, layers grown
     from both sides of the baffle (`-layerPatches '("baffle.*")'`, testcase6/run_serial:24), the fixed-point walk."""
     from smoothmesh_amd import LayerParams, SmoothEngine, default_params, patch_arrays
-    from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane, hex_block
+    from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane, hex_block, split_baffles
     jit = 0.45 if variant in ("busy", "walk-fix") else 0.25
     m = add_baffle(hex_block(10, 9, 8, jitter=jit, seed=6), baffle_in_plane(hex_block(10, 9, 8), 0, 0.5, lambda c: (c[:, 1] < 0.7) & (c[:, 2] > 0.2)))
     assert [p.name for p in m.patches][-2:] == ["baffle_master", "baffle_slave"]
+    if split:      # splitBaffles (testcase6/run_serial:17-18): the wall's interior points twinned, a slit of zero width
+        nP = m.nPoints
+        m = split_baffles(m)
+        assert m.nPoints == nP + 36
     if variant == "walk-fix":
         monkeypatch.setenv("SMGPU_WALK", "fix")
     over = {"busy": dict(minAngle=50.0), "walk-fix": dict(minAngle=50.0), "no-constraints": dict(edgeAngleConstraint=False, faceAngleConstraint=False)}.get(variant, {})
