@@ -264,3 +264,32 @@ def test_boundary_smoothing_under_engine_knobs(oracle_lib, monkeypatch, env):
                               smoothingPatches=("cavity",))
     assert on
     _run_both(o, e, 6)
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_baffle_with_boundary_point_smoothing_and_layers(oracle_lib, split):
+    """the reference's testcase6 as a whole (run_serial:24: `-layerPatches '(walls "baffle.*")' -smoothingPatches '(".*")'` on a
+    mesh with a baffle, createBaffles + splitBaffles): the wall inside the block has its own target surface (a plane through
+    it) and its points start off that plane; with `split` the wall's interior points are
+    coincident twins (a slit of zero width) that are classified, projected and layered independently"""
+    from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane, hex_block, split_baffles
+    m = add_baffle(hex_block(10, 9, 8, jitter=0.2, seed=6), baffle_in_plane(hex_block(10, 9, 8), 0, 0.5, lambda c: (c[:, 1] < 0.7) & (c[:, 2] > 0.2)))
+    if split:
+        m = split_baffles(m)
+    m = tangential_jitter(m, 0.02, seed=4)
+    init, target, surf = boundary_inputs(10, 3)
+    quad = np.array([[0.5, -0.1, 0.1], [0.5, 0.8, 0.1], [0.5, 0.8, 1.1], [0.5, -0.1, 1.1]])
+    surf = (np.concatenate([surf[0], quad]), np.concatenate([surf[1], np.array([[0, 1, 2], [0, 2, 3]]) + len(surf[0])]))
+    o, e, prm, on = make_pair(m, oracle_lib, init, target, surf, constraints=True, layerPatches=("ymax", '"baffle.*"'))
+    assert on
+    onwall = np.zeros(m.nPoints, bool)
+    for p in m.patches:
+        if p.name.startswith("baffle"):
+            onwall[m.facePoints[m.faceOffsets[p.startFace]:m.faceOffsets[p.startFace + p.nFaces]]] = True
+    assert np.abs(m.points[onwall, 0] - 0.5).max() > 1e-3          # off the plane at the start
+    x0 = np.array(m.points).copy()
+    n_o, res_o, frz_o = o.iterate(30, 0.0)
+    n_g, res_g, frz_g = e.iterate(30, 0.0)
+    assert n_o == n_g and np.array_equal(frz_o, frz_g)
+    assert rel_linf(e.get_points(), o.points()) <= 1e-13
+    assert np.abs(o.points()[onwall] - x0[onwall]).max() > 1e-3          # the wall's points take part (both forms; what they do is the oracle's)
