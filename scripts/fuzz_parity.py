@@ -2,7 +2,8 @@
 smoothing parameters, constraints, layer patches, boundary point smoothing (box and sphere targets), serial and decomposed -- into
 boxes, into IRREGULAR sub-domains (breadth-first grown or random cellRank maps, 2..8 ranks, disconnected pieces), and on
 UNJITTERED / exactly graded blocks whose points sit on binary fractions, where the edge-length comparisons of the closest-point
-syncs (SM.C:388-478) tie exactly -- and ("affine") meshes in other units and far from the origin (scale 1e-6 .. 1e6, offset up to
+syncs (SM.C:388-478) tie exactly; irregular hex cases also with boundary point smoothing, and with a baffle inside the block (shared
+points or split twins, layers grown from it, ranks on its two sides) -- and ("affine") meshes in other units and far from the origin (scale 1e-6 .. 1e6, offset up to
 1e7 mesh sizes: the f32 filters of the constraint evaluators work on f64 DIFFERENCES and must stay on the safe side, the
 constraints are always on there).  Prints one line per case; exit code 1 on the first mismatch.  usage: python scripts/fuzz_parity.py [nCases] [seed]"""
 import os, sys
@@ -14,7 +15,7 @@ from smoothmesh_amd import BoundaryParams, LayerParams, SmoothEngine, SmgpuError
 from smoothmesh_amd.surfgen import box_feature_edges, box_surface, sphere_surface
 from smoothmesh_amd.decompose import bfs_partition, decompose, grid_partition, random_partition, shared_point_table
 from smoothmesh_amd.halo import LocalMultiSmoother
-from smoothmesh_amd.meshgen import hex_block, hex_subdomain
+from smoothmesh_amd.meshgen import add_baffle, baffle_in_plane, hex_block, hex_subdomain, split_baffles
 from smoothmesh_amd.polymesh import cavity_mesh
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 24
@@ -41,6 +42,7 @@ for case in range(n_cases):
                      minLayers=int(rng.integers(0, 3)), maxLayers=int(rng.integers(3, 6)))
     jitter = float(rng.choice([0.1, 0.3, 0.45]))
     seed = int(rng.integers(1 << 30))
+    baffle = ""
     if kind in ("multi", "irregular", "tied"):
         if kind == "multi":
             grid = tuple(int(x) for x in rng.choice([1, 2, 3], size=3))
@@ -53,13 +55,25 @@ for case in range(n_cases):
         elif kind == "irregular":
             world = int(rng.integers(2, 9))
             if rng.random() < 0.5:
-                gm = hex_block(*(int(x) for x in rng.integers(5, 11, size=3)), jitter=jitter, seed=seed)
+                dims = tuple(int(x) for x in rng.integers(5, 11, size=3))
+                gm = hex_block(*dims, jitter=jitter, seed=seed)
+                if rng.random() < 0.4:      # a wall inside the block (createBaffles), possibly split into twins (splitBaffles): ranks on its two sides
+                    ax = int(rng.integers(3))
+                    at = int(rng.integers(1, dims[ax])) / dims[ax]
+                    lim = float(rng.choice([0.45, 0.7, 2.0]))
+                    gm = add_baffle(gm, baffle_in_plane(hex_block(*dims), ax, at, lambda c: c[:, (ax + 1) % 3] < lim))
+                    baffle = " baffle"
+                    if rng.random() < 0.5:
+                        gm = split_baffles(gm)
+                        baffle = " split baffle"
+                    if rng.random() < 0.5:
+                        lp.layerPatches = ('"baffle.*"',) + tuple(lp.layerPatches[:1])
             else:
                 gm = cavity_mesh(int(rng.integers(8, 13)), jitter=min(jitter, 0.3), seed=seed)
             how = rng.choice(["bfs", "island", "random"])
             cr = random_partition(gm, world, seed=seed) if how == "random" else bfs_partition(gm, world, seed=seed, island=(how == "island"))
             subs = decompose(gm, cr, world)
-            desc = f"irregular {how} x{world} cells {gm.nCells}"
+            desc = f"irregular {how} x{world} cells {gm.nCells}{baffle}"
         else:
             # points on binary fractions: spacing 2^-4 (x possibly 2^-5: an exactly graded block), a tenth of the interior points moved
             # by multiples of 2^-10 -- equal lengths stay bit-equal, so the closest-point syncs see exact ties at the processor cuts
@@ -90,10 +104,11 @@ for case in range(n_cases):
             o.set_params(prm)
         off, dom, loc = shared_point_table(subs)
         mo = oracle_ffi.MultiOracle(orcs, off, dom, loc)
-        boundary = kind == "multi" and rng.random() < 0.5
-        layers = layers and (kind != "irregular" or "cavity" not in {p.name for p in subs[0].mesh.patches})
-        if boundary:      # every sub-domain is a unit cube of the block [0, grid]
-            hi = tuple(float(g) for g in grid)
+        unit_hex = kind == "irregular" and "cavity" not in {p.name for p in subs[0].mesh.patches}   # the unit cube, cut raggedly
+        boundary = (kind == "multi" or (unit_hex and not baffle)) and rng.random() < 0.5
+        layers = layers and (kind != "irregular" or unit_hex)
+        if boundary:      # multi: every sub-domain is a unit cube of the block [0, grid]
+            hi = tuple(float(g) for g in grid) if kind == "multi" else (1.0, 1.0, 1.0)
             f = float(rng.choice([1.0, 1.0, 1.02]))
             c = 0.5 * np.array(hi)
             warp = (lambda x: c + (x - c) * f) if f != 1.0 else None
