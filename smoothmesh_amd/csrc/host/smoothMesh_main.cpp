@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <regex>
 #include <set>
@@ -208,7 +209,7 @@ struct Rank {
     std::string root;            // case dir (serial) or processorN dir
     PolyMeshData mesh;
     std::vector<uint8_t> internal;
-    std::vector<int32_t> pointProc;
+    std::vector<int64_t> pointProc;            // local point -> global id (pointProcAddressing) or the label labelsFromPatches gives it
     smgpu_handle* h = nullptr;
     int device = 0;
     // halo
@@ -329,6 +330,77 @@ void buildHalo(Rank& K, int r, int n, const std::map<int64_t, std::vector<int>>&
     }
 }
 
+// Sub-domains WITHOUT pointProcAddressing (a mesh made in parallel, e.g. by snappyHexMesh -parallel: the files decomposePar writes
+// are absent or stale): the copies of a point are matched through the processor patches themselves, as OpenFOAM's globalPoints
+// does -- face i of rank a's patch to b is face i of b's patch to a, reversed about its first vertex (face::reverseFace:
+// the normal points out of either domain), so vertex k of one is vertex (n - k) % n of the other.  Every (rank, local point) on
+// a processor patch gets the label of its connected component, (lowest rank << 40) | that rank's local id; the other points
+// keep (own rank << 40) | local id.  The labels stand in for the global point ids everywhere below.
+// own = this rank's patches flattened: {neighbour, nFaces, {n, local ids ...} per face}*
+std::vector<int64_t> processorPatchFaces(const Rank& K) {
+    std::vector<int64_t> out;
+    const auto& m = K.mesh;
+    for (const auto& p : m.patches)
+        if (p.type == "processor") {
+            out.push_back((int64_t)p.neighbProcNo);
+            out.push_back((int64_t)p.nFaces);
+            for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f) {
+                out.push_back((int64_t)(m.faceOffsets[f + 1] - m.faceOffsets[f]));
+                for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k) out.push_back((int64_t)m.facePoints[k]);
+            }
+        }
+    return out;
+}
+std::string labelsFromPatches(Rank& K, int r, int n, const std::vector<std::vector<int64_t>>& all) {
+    struct PatchFaces { std::vector<size_t> at; };                  // per face: where its {n, ids...} record starts in all[rank]
+    std::vector<std::map<int, PatchFaces>> patch((size_t)n);
+    for (int o = 0; o < n; ++o) {
+        const auto& v = all[(size_t)o];
+        for (size_t k = 0; k + 1 < v.size();) {
+            const int nb = (int)v[k]; const int64_t nF = v[k + 1];
+            k += 2;
+            PatchFaces& pf = patch[(size_t)o][nb];
+            for (int64_t f = 0; f < nF; ++f) { pf.at.push_back(k); k += 1 + (size_t)v[k]; }
+        }
+    }
+    std::map<std::pair<int, int64_t>, std::pair<int, int64_t>> parent;   // (rank, local point) -> parent; the root is the lowest (rank, id)
+    typedef std::pair<int, int64_t> Node;
+    std::function<Node(Node)> find = [&](Node a) {
+        auto it = parent.find(a);
+        if (it == parent.end()) { parent[a] = a; return a; }
+        if (it->second == a) return a;
+        const Node root = find(it->second);
+        parent[a] = root;
+        return root;
+    };
+    for (int a = 0; a < n; ++a)
+        for (const auto& kv : patch[(size_t)a]) {
+            const int b = kv.first;
+            if (b <= a) continue;
+            if (b >= n) return "processor patch to a rank that does not exist";
+            const auto it = patch[(size_t)b].find(a);
+            if (it == patch[(size_t)b].end() || it->second.at.size() != kv.second.at.size())
+                return "processor patches " + std::to_string(a) + " <-> " + std::to_string(b) + " do not match";
+            for (size_t f = 0; f < kv.second.at.size(); ++f) {
+                const int64_t* fa = &all[(size_t)a][kv.second.at[f]];
+                const int64_t* fb = &all[(size_t)b][it->second.at[f]];
+                const int64_t nv = fa[0];
+                if (fb[0] != nv) return "processor patches " + std::to_string(a) + " <-> " + std::to_string(b) + ": face sizes differ";
+                for (int64_t k = 0; k < nv; ++k) {
+                    const Node x = find(Node(a, fa[1 + k])), y = find(Node(b, fb[1 + (nv - k) % nv]));
+                    if (x != y) { if (x < y) parent[y] = x; else parent[x] = y; }
+                }
+            }
+        }
+    K.pointProc.resize((size_t)K.mesh.nPoints());
+    for (int32_t p = 0; p < K.mesh.nPoints(); ++p) {
+        Node root(r, (int64_t)p);
+        if (parent.count(root)) root = find(root);
+        K.pointProc[(size_t)p] = ((int64_t)root.first << 40) | root.second;
+    }
+    return "";
+}
+
 // this rank's processor patches as {neighbour, count, global point ids ascending ...}* (sharedGroupsOf)
 std::vector<int64_t> processorPatchLists(const Rank& K) {
     std::vector<int64_t> out;
@@ -402,10 +474,16 @@ int main(int argc, char** argv) {
             readPolyMesh(meshDir, ptsDir == meshDir ? "" : ptsDir, K.mesh);
             K.internal = findInternalMeshPoints(K.mesh);
             if (opt.parallel) {
+                // shared points are matched by decomposePar's global ids where the file is there, and through the processor patches
+                // themselves where it is not (labelsFromPatches; SMGPU_MATCH_BY_PATCHES=1 forces that)
                 const std::string ppa = K.root + "/constant/polyMesh/pointProcAddressing";
-                if (!fileExists(ppa) && !fileExists(ppa + ".gz")) fatal(ppa + " not found (written by decomposePar; needed to match shared points)");
-                readLabelList(ppa, K.pointProc);
-                if ((int32_t)K.pointProc.size() != K.mesh.nPoints()) fatal(ppa + ": size does not match the number of points");
+                const char* force = std::getenv("SMGPU_MATCH_BY_PATCHES");
+                if (!(force && std::atoi(force)) && (fileExists(ppa) || fileExists(ppa + ".gz"))) {
+                    std::vector<int32_t> ids;
+                    readLabelList(ppa, ids);
+                    if ((int32_t)ids.size() != K.mesh.nPoints()) fatal(ppa + ": size does not match the number of points");
+                    K.pointProc.assign(ids.begin(), ids.end());
+                }
             }
         }
     } catch (const std::exception& e) { fatal(e.what()); }
@@ -609,6 +687,16 @@ int main(int argc, char** argv) {
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
     std::vector<std::vector<int64_t>> sharedGlobalOf;   // every rank's shared points (global ids, ascending): the set-up syncs
     if (opt.parallel) {
+        {   // every rank must take the same route: by global ids only if ALL of them have the file
+            const auto have = g_comm.allgatherVec(std::vector<int>(1, K0.pointProc.empty() ? 0 : 1));
+            bool all = true;
+            for (const auto& h : have) all = all && h[0];
+            if (!all) {
+                const std::string err = labelsFromPatches(K0, myRank, nRanks, g_comm.allgatherVec(processorPatchFaces(K0)));
+                if (!err.empty()) fatal(err);
+                if (myRank == 0) OUT("Shared points matched through the processor patches (no pointProcAddressing)\n\n");
+            }
+        }
         buildHalo(K0, myRank, nRanks, sharedGroupsOf(myRank, nRanks, g_comm.allgatherVec(processorPatchLists(K0))));
         sharedGlobalOf = g_comm.allgatherVec(K0.sharedGlobal);
         for (Rank& K : R) {

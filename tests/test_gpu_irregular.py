@@ -50,16 +50,24 @@ def test_local_multi_smoother_on_irregular_partitions(oracle_lib, kind, nR, seed
 
 
 @pytest.mark.parametrize("kind,nR,seed", [("hex_island", 3, 31), ("poly_bfs", 5, 32), ("two_blocks", 3, 33), ("hex_baffle", 4, 34)])
-def test_parallel_cli_on_irregular_processor_directories(tmp_path, oracle_lib, kind, nR, seed):
+@pytest.mark.parametrize("match", ["ids", "patches"])
+def test_parallel_cli_on_irregular_processor_directories(tmp_path, oracle_lib, kind, nR, seed, match):
+    """match = "patches": the sub-domains WITHOUT pointProcAddressing (a mesh made in parallel, e.g. by snappyHexMesh -parallel, has
+    none): the front-end then finds the copies of a point through the processor patches themselves, vertex by vertex of the
+    matching faces, as OpenFOAM's globalPoints does -- same tables, same result."""
     from smoothmesh_amd.decompose import decompose
     from smoothmesh_amd.polymesh import read_polymesh, write_decomposed_case
     mesh, cr = build_case(kind, nR, seed)
     subs, ser, orcs, mo, prm = _oracles(oracle_lib, mesh, cr, nR, True)
     write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+    if match == "patches":
+        for s in subs:
+            os.remove(tmp_path / f"processor{s.rank}" / "constant" / "polyMesh" / "pointProcAddressing")
     r = subprocess.run([BIN, "-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0", "-minEdgeLength", repr(prm.minEdgeLength),
                         "-maxStepLength", repr(prm.maxStepLength)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"nProcs : {nR}" in r.stdout
+    assert ("Shared points matched through the processor patches" in r.stdout) == (match == "patches")
     n, res, frz = mo.iterate(6, 0.0)
     lines = LINE.findall(r.stdout)
     assert [int(b) for _, b, _ in lines] == frz.tolist()
@@ -82,7 +90,7 @@ def test_distributed_smoother_irregular_processes(spec, world, port):
     assert r.stdout.count(": ok ") == 4 * world and "BAD" not in r.stdout
 
 
-@pytest.mark.parametrize("host", ["cli", "engines"])
+@pytest.mark.parametrize("host", ["cli", "cli-no-ids", "engines"])
 def test_baffle_between_ranks_with_layers_grown_from_it(tmp_path, oracle_lib, host):
     """The reference's testcase6 in parallel (`-layerPatches '(walls "baffle.*")'`, testcase6/run_parallel) with the wall BETWEEN
     ranks: the copies of a baffle point on its two sides are connected by no processor face, so syncTools::syncPointList does
@@ -96,8 +104,11 @@ def test_baffle_between_ranks_with_layers_grown_from_it(tmp_path, oracle_lib, ho
     pats = ['"baffle.*"', "ymax"]
     assert mo.setup_layers([patch_arrays(s.mesh, pats) for s in subs], 0.3, prm.minEdgeLength, 1.2, 1, 3)
     n, res, frz = mo.iterate(6, 0.0)
-    if host == "cli":
+    if host.startswith("cli"):
         write_decomposed_case(str(tmp_path), subs, binary=True, writeFormat="binary")
+        if host == "cli-no-ids":
+            for s in subs:
+                os.remove(tmp_path / f"processor{s.rank}" / "constant" / "polyMesh" / "pointProcAddressing")
         r = subprocess.run([BIN, "-case", str(tmp_path), "-parallel", "-centroidalIters", "6", "-relTol", "0", "-minEdgeLength", repr(prm.minEdgeLength),
                             "-maxStepLength", repr(prm.maxStepLength), "-layerPatches", '("baffle.*" ymax)', "-layerExpansionRatio", "1.2", "-maxLayers", "3"],
                            capture_output=True, text=True, timeout=600)
