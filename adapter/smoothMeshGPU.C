@@ -54,6 +54,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <fstream>
 #include <map>
 #include <set>
@@ -166,7 +167,10 @@ PatchTable patchTable(const fvMesh& mesh, const labelList& selectedIds)
 // Who shares a point with whom follows OpenFOAM's own globalPoints (what syncTools::syncPointList uses): the copies of a point
 // on the two sides of a processor patch are the same point, and so is everything connected through such pairs (a rank has
 // one local point per mesh point, which joins all its patches) -- and nothing else: the two sides of a baffle on different ranks
-// are different shared points, or none.  Slots: per peer in ascending rank, ascending global id.
+// are different shared points, or none.  The copies are matched through the patches themselves -- face i of my patch to b is
+// face i of b's patch to me reversed about its first vertex (face::reverseFace), so my vertex k is its vertex (n - k) % n --
+// and no pointProcAddressing is needed (a mesh made in parallel has none).  A shared point is known by the lowest (rank, local
+// point) of its copies.  Slots: per peer in ascending rank, ascending key.
 struct HaloTables
 {
     std::vector<int32_t> sharedLocal, sendShared, combOffsets, combSlots;
@@ -176,23 +180,26 @@ struct HaloTables
     int32_t nSend = 0, nRecv = 0;
 };
 
-HaloTables buildHalo(const fvMesh& mesh, const labelList& pointProcAddressing)
+HaloTables buildHalo(const fvMesh& mesh)
 {
+    typedef std::pair<label, label> Node;            // (rank, local point)
     HaloTables t;
     const label me = Pstream::myProcNo();
     const label nProcs = Pstream::nProcs();
-    // my processor patches, flattened: {neighbour, count, global point ids ascending ...}*
+    // my processor patches, flattened: {neighbour, nFaces, {n, mesh points ...} per face}*
     std::vector<label> flat;
     forAll(mesh.boundaryMesh(), patchI)
     {
         const polyPatch& pp = mesh.boundaryMesh()[patchI];
         if (!isA<processorPolyPatch>(pp)) continue;
-        const labelList& mp = pp.meshPoints();
-        std::set<label> ids;
-        forAll(mp, i) ids.insert(pointProcAddressing[mp[i]]);
         flat.push_back(refCast<const processorPolyPatch>(pp).neighbProcNo());
-        flat.push_back(static_cast<label>(ids.size()));
-        flat.insert(flat.end(), ids.begin(), ids.end());
+        flat.push_back(pp.size());
+        for (label i = 0; i < pp.size(); ++i)
+        {
+            const face& f = mesh.faces()[pp.start() + i];
+            flat.push_back(f.size());
+            forAll(f, k) flat.push_back(f[k]);
+        }
     }
     List<labelList> all(nProcs);
     all[me].setSize(static_cast<label>(flat.size()));
@@ -200,93 +207,87 @@ HaloTables buildHalo(const fvMesh& mesh, const labelList& pointProcAddressing)
     Pstream::gatherList(all);
     Pstream::scatterList(all);
 
-    // per rank: neighbour -> ids, and the union of its patch points
-    std::vector<std::map<label, std::vector<label>>> patch(static_cast<size_t>(nProcs));
-    std::vector<std::vector<label>> ids(static_cast<size_t>(nProcs));
+    // per rank and neighbour: where each face's {n, points...} record starts
+    std::vector<std::map<label, std::vector<label>>> faceAt(static_cast<size_t>(nProcs));
     for (label o = 0; o < nProcs; ++o)
     {
         const labelList& v = all[o];
         for (label k = 0; k + 1 < v.size();)
         {
-            const label nb = v[k], c = v[k + 1];
-            std::vector<label>& dst = patch[static_cast<size_t>(o)][nb];
-            for (label j = 0; j < c; ++j) dst.push_back(v[k + 2 + j]);
-            k += 2 + c;
+            const label nb = v[k], nF = v[k + 1];
+            k += 2;
+            std::vector<label>& at = faceAt[static_cast<size_t>(o)][nb];
+            for (label f = 0; f < nF; ++f) { at.push_back(k); k += 1 + v[k]; }
         }
-        for (auto& kv : patch[static_cast<size_t>(o)])
-        {
-            std::sort(kv.second.begin(), kv.second.end());
-            kv.second.erase(std::unique(kv.second.begin(), kv.second.end()), kv.second.end());
-            ids[static_cast<size_t>(o)].insert(ids[static_cast<size_t>(o)].end(), kv.second.begin(), kv.second.end());
-        }
-        std::vector<label>& io = ids[static_cast<size_t>(o)];
-        std::sort(io.begin(), io.end());
-        io.erase(std::unique(io.begin(), io.end()), io.end());
     }
-    // union-find over (rank, point) nodes: one link per point of every matching patch pair
-    std::vector<size_t> nodeBase(static_cast<size_t>(nProcs) + 1, 0);
-    for (label o = 0; o < nProcs; ++o) nodeBase[static_cast<size_t>(o) + 1] = nodeBase[static_cast<size_t>(o)] + ids[static_cast<size_t>(o)].size();
-    std::vector<size_t> parent(nodeBase[static_cast<size_t>(nProcs)]);
-    for (size_t i = 0; i < parent.size(); ++i) parent[i] = i;
-    auto find = [&](size_t a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
-    auto node = [&](label o, label g)
+    std::map<Node, Node> parent;                     // the root of a component is its lowest node
+    std::function<Node(Node)> find = [&](Node a)
     {
-        const std::vector<label>& io = ids[static_cast<size_t>(o)];
-        return nodeBase[static_cast<size_t>(o)] + static_cast<size_t>(std::lower_bound(io.begin(), io.end(), g) - io.begin());
+        std::map<Node, Node>::iterator it = parent.find(a);
+        if (it == parent.end()) { parent[a] = a; return a; }
+        if (it->second == a) return a;
+        const Node root = find(it->second);
+        parent[a] = root;
+        return root;
     };
     for (label a = 0; a < nProcs; ++a)
     {
-        for (const auto& kv : patch[static_cast<size_t>(a)])
+        for (const auto& kv : faceAt[static_cast<size_t>(a)])
         {
             const label b = kv.first;
             if (b <= a || b >= nProcs) continue;
-            const auto it = patch[static_cast<size_t>(b)].find(a);
-            if (it == patch[static_cast<size_t>(b)].end()) continue;
-            std::vector<label> common;
-            std::set_intersection(kv.second.begin(), kv.second.end(), it->second.begin(), it->second.end(), std::back_inserter(common));
-            for (label g : common)
+            const auto it = faceAt[static_cast<size_t>(b)].find(a);
+            if (it == faceAt[static_cast<size_t>(b)].end() || it->second.size() != kv.second.size())
+                FatalErrorInFunction << "processor patches " << a << " <-> " << b << " do not match" << exit(FatalError);
+            for (size_t f = 0; f < kv.second.size(); ++f)
             {
-                const size_t x = find(node(a, g)), y = find(node(b, g));
-                if (x != y) parent[x] = y;
+                const label pa = kv.second[f], pb = it->second[f];
+                const label nv = all[a][pa];
+                if (all[b][pb] != nv)
+                    FatalErrorInFunction << "processor patches " << a << " <-> " << b << ": face sizes differ" << exit(FatalError);
+                for (label k = 0; k < nv; ++k)
+                {
+                    const Node x = find(Node(a, all[a][pa + 1 + k])), y = find(Node(b, all[b][pb + 1 + (nv - k) % nv]));
+                    if (x != y) { if (x < y) parent[y] = x; else parent[x] = y; }
+                }
             }
         }
     }
-
-    std::map<label, label> localOf;      // global id -> local id
-    forAll(pointProcAddressing, p) localOf[pointProcAddressing[p]] = p;
-
-    std::map<size_t, label> rootOfMine;  // root -> my point's global id
-    for (size_t i = 0; i < ids[static_cast<size_t>(me)].size(); ++i) rootOfMine[find(nodeBase[static_cast<size_t>(me)] + i)] = ids[static_cast<size_t>(me)][i];
-    std::map<label, std::vector<int>> sharers;   // global id -> the OTHER ranks of my point's group (ascending)
-    std::vector<std::vector<label>> with(static_cast<size_t>(nProcs));
-    for (label r = 0; r < nProcs; ++r)
+    // the components this rank takes part in: key = root, my copy, the other ranks
+    std::map<Node, label> localOf;
+    std::map<Node, std::vector<int>> sharers;        // key -> the OTHER ranks of the group (ascending)
+    std::vector<std::vector<Node>> with(static_cast<size_t>(nProcs));
     {
-        if (r == me) continue;
-        for (size_t i = 0; i < ids[static_cast<size_t>(r)].size(); ++i)
+        std::vector<Node> nodes;
+        for (const auto& kv : parent) nodes.push_back(kv.first);
+        for (const Node& nd : nodes) if (nd.first == me) localOf[find(nd)] = nd.second;
+        for (const Node& nd : nodes)                 // (ascending rank: the map is ordered by (rank, point))
         {
-            const auto it = rootOfMine.find(find(nodeBase[static_cast<size_t>(r)] + i));
-            if (it == rootOfMine.end()) continue;
-            with[static_cast<size_t>(r)].push_back(it->second);
-            sharers[it->second].push_back(static_cast<int>(r));
+            if (nd.first == me) continue;
+            const Node key = find(nd);
+            if (!localOf.count(key)) continue;
+            sharers[key].push_back(static_cast<int>(nd.first));
+            with[static_cast<size_t>(nd.first)].push_back(key);
         }
-        std::sort(with[static_cast<size_t>(r)].begin(), with[static_cast<size_t>(r)].end());
+        for (auto& w : with) std::sort(w.begin(), w.end());
     }
-    std::map<label, int32_t> sharedIndex;
+    std::map<Node, int32_t> sharedIndex;
     for (const auto& kv : sharers)
     {
         sharedIndex[kv.first] = static_cast<int32_t>(t.sharedLocal.size());
         t.sharedLocal.push_back(static_cast<int32_t>(localOf[kv.first]));
     }
     std::map<int, int32_t> base;
-    for (label r = 0; r < Pstream::nProcs(); ++r)
+    for (label r = 0; r < nProcs; ++r)
     {
-        if (with[r].empty()) continue;
+        const std::vector<Node>& w = with[static_cast<size_t>(r)];
+        if (w.empty()) continue;
         t.peers.push_back(r);
-        t.counts.push_back(static_cast<int32_t>(with[r].size()));
+        t.counts.push_back(static_cast<int32_t>(w.size()));
         t.base.push_back(t.nSend);
         base[r] = t.nSend;
-        for (label g : with[r]) t.sendShared.push_back(sharedIndex[g]);
-        t.nSend += static_cast<int32_t>(with[r].size());
+        for (const Node& g : w) t.sendShared.push_back(sharedIndex[g]);
+        t.nSend += static_cast<int32_t>(w.size());
     }
     t.nRecv = t.nSend;                     // the lists are symmetric
     t.combOffsets.push_back(0);
@@ -298,7 +299,7 @@ HaloTables buildHalo(const fvMesh& mesh, const labelList& pointProcAddressing)
         for (int r : ranks)
         {
             if (r == me) { t.combSlots.push_back(-1); continue; }
-            const std::vector<label>& w = with[r];
+            const std::vector<Node>& w = with[static_cast<size_t>(r)];
             const int32_t k = static_cast<int32_t>(std::lower_bound(w.begin(), w.end(), kv.first) - w.begin());
             t.combSlots.push_back(base[r] + k);
         }
@@ -572,12 +573,7 @@ int main(int argc, char *argv[])
     }
     if (Pstream::parRun())
     {
-        labelIOList pointProcAddressing
-        (
-            IOobject("pointProcAddressing", mesh.facesInstance(), polyMesh::meshSubDir, mesh,
-                     IOobject::MUST_READ, IOobject::NO_WRITE)
-        );
-        halo = buildHalo(mesh, pointProcAddressing);
+        halo = buildHalo(mesh);
         checkHip(hipSetDevice(device));
         const size_t nS = size_t(max(halo.nSend, 1)), nR = size_t(max(halo.nRecv, 1));
         checkHip(hipMalloc(&sendA, nS * SMGPU_HALO_A_DOUBLES * sizeof(double)));
