@@ -409,3 +409,21 @@ def test_filtered_path_makes_the_same_decisions(oracle_lib, monkeypatch, kind, a
     assert np.array_equal(out["1"][0], out["0"][0]) and np.array_equal(out["1"][1], out["0"][1])
     assert np.array_equal(out["1"][0], o.field("frozenAfterFaceAngle"))
     assert np.array_equal(out["1"][1].astype(bool), act_ref)
+
+
+@pytest.mark.parametrize("A,frac", [(0.4375, 0.0), (0.703125, 0.5), (0.8203125, 0.75), (1.0, 1.0)])
+def test_aspect_ratio_blend_known_answers_on_the_gpu(A, frac):
+    """The analytic answers of tests/test_oracle_known_answers.py::test_aspect_ratio_blend_known_answers asked of the ENGINE itself
+    (no oracle in between): box cells on binary fractions, the interior point of a 2x2x2 block ends at
+    z = (1 - f) (s2 - s1) / 4 + f (s2 - s1) / 2 with f = clamp((A / s2 - 1.5) / 1.5) (SM.C:489-543, 548-591), exactly."""
+    from test_oracle_known_answers import _lattice_2x2x2
+    from smoothmesh_amd import SmoothEngine, SmoothParams
+    s1, s2 = 0.25, 0.3125
+    m = _lattice_2x2x2((-A, 0.0, A), (-A, 0.0, A), (-s1, 0.0, s2))
+    e = SmoothEngine(m)
+    e.set_params(SmoothParams(maxStepLength=10.0, minEdgeLength=1e-6, relStepFrac=1.0, edgeAngleConstraint=False, faceAngleConstraint=False))
+    n, res, frz = e.iterate(1, 0.0)
+    z = (1.0 - frac) * (s2 - s1) / 4 + frac * (s2 - s1) / 2
+    got = e.get_points()
+    assert np.allclose(got[13], [0.0, 0.0, z], atol=1e-16) and frz[0] == 26 and abs(res[0] - z / 10.0) <= 1e-17
+    assert np.array_equal(np.delete(got, 13, axis=0), np.delete(np.array(m.points), 13, axis=0))     # boundary points stay
