@@ -379,3 +379,67 @@ def test_edge_shortening_freeze_known_answers(oracle_lib):
         assert np.array_equal(o.points()[13], [0.0, 0.0, 0.03125] if moved else [0.0, 0.0, 0.0])
         # residual = largest step / maxStepLength (SM.C:1546-1565): 0.03125 / 10, or nothing moved
         assert res[0] == (0.03125 / 10.0 if moved else 0.0)
+
+
+def _numpy_geometry(mesh):
+    """OpenFOAM.com v2412 primitiveMeshFaceCentresAndAreas.C / primitiveMeshCellCentresAndVols.C written a SECOND time, in numpy,
+    from the published algorithm (an independent formulation next to oracle/smooth_oracle.cpp: loops over faces instead of
+    accumulation in the face order, float sums in another order -- hence a tolerance, not bits)"""
+    P = np.asarray(mesh.points, float)
+    off, fp = mesh.faceOffsets, mesh.facePoints
+    F, C, nI = mesh.nFaces, mesh.nCells, mesh.nInternalFaces
+    fC, fA = np.zeros((F, 3)), np.zeros((F, 3))
+    for f in range(F):
+        v = P[fp[off[f]:off[f + 1]]]
+        n = len(v)
+        if n == 3:
+            fC[f] = v.sum(axis=0) / 3.0
+            fA[f] = 0.5 * np.cross(v[1] - v[0], v[2] - v[0])
+            continue
+        c0 = v.mean(axis=0)
+        nxt = np.roll(v, -1, axis=0)
+        nn = np.cross(nxt - v, c0 - v)
+        a = np.linalg.norm(nn, axis=1)
+        if a.sum() < 1.5e-154:
+            fC[f], fA[f] = c0, 0.0
+        else:
+            fC[f] = ((a[:, None] * (v + nxt + c0)).sum(axis=0) / a.sum()) / 3.0
+            fA[f] = 0.5 * nn.sum(axis=0)
+    own, nei = mesh.owner, mesh.neighbour
+    cEst, nF = np.zeros((C, 3)), np.zeros(C)
+    np.add.at(cEst, own, fC); np.add.at(nF, own, 1)
+    np.add.at(cEst, nei, fC[:nI]); np.add.at(nF, nei, 1)
+    cEst /= nF[:, None]
+    cC, vol = np.zeros((C, 3)), np.zeros(C)
+    pyr = np.einsum("ij,ij->i", fA, fC - cEst[own])
+    np.add.at(cC, own, pyr[:, None] * (0.75 * fC + 0.25 * cEst[own])); np.add.at(vol, own, pyr)
+    pyr = np.einsum("ij,ij->i", fA[:nI], cEst[nei] - fC[:nI])
+    np.add.at(cC, nei, pyr[:, None] * (0.75 * fC[:nI] + 0.25 * cEst[nei])); np.add.at(vol, nei, pyr)
+    return fC, fA, cC / vol[:, None], vol / 3.0
+
+
+@pytest.mark.parametrize("kind", ["hex", "polyhedral", "prisms"])
+def test_geometry_against_a_second_formulation(oracle_lib, kind):
+    """face centres / area vectors and cell centres of warped quadrilaterals, polygons with hanging nodes, triangles and prisms:
+    the oracle against the numpy restatement above, to 1e-13 of the cell size"""
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import cavity_mesh
+    if kind == "hex":
+        m = hex_block(6, 5, 4, jitter=0.35, seed=9)
+        rng = np.random.default_rng(9)
+        m.points[:] = np.array(m.points) + 0.02 * rng.standard_normal(m.points.shape)      # boundary faces warped too
+    elif kind == "polyhedral":
+        m = cavity_mesh(8, jitter=0.3, seed=9)
+    else:
+        from test_gpu_edge_cases import _fan_mesh
+        m = _fan_mesh(7, nLayers=3, jitter=0.1, seed=2)
+    o = oracle_lib.Oracle(m)
+    from smoothmesh_amd import default_params
+    o.set_params(default_params(o.mesh_stats()[0]))
+    o.phaseA()
+    fC, fA, cC, vol = _numpy_geometry(m)
+    h = o.mesh_stats()[0]
+    assert np.abs(o.field("faceCentres").reshape(-1, 3) - fC).max() <= 1e-13 * max(1.0, np.abs(fC).max())
+    assert np.abs(o.field("faceAreas").reshape(-1, 3) - fA).max() <= 1e-13
+    assert np.abs(o.field("cellCentres").reshape(-1, 3) - cC).max() <= 1e-12 * max(1.0, np.abs(cC).max())
+    assert (vol > 0).all() and h > 0
