@@ -579,3 +579,39 @@ def test_face_angles_against_a_second_formulation(oracle_lib, kind):
     assert np.abs(o.field("pointMinAngle") - pmin).max() <= 1e-12
     assert np.abs(o.field("pointMaxAngle") - pmax).max() <= 1e-12
     assert pmin.min() < np.pi / 2 - 0.2 and pmax.max() > np.pi / 2 + 0.2          # a distorted mesh: the angles are not all 90 degrees
+
+
+def test_edge_angle_freeze_against_a_second_formulation(oracle_lib):
+    """calc_min_edge_angles / restrictMinEdgeAngleDecrease (SM.C:766-930) a second time in Python: per point and face the angle
+    between its two edges in that face -- now, and with the point / its two neighbours at their proposals in the four combinations
+    the reference takes the smallest of -- and the freeze `minN < small && minN < minC`, applied to the points the edge-length
+    rule left free.  A heavily jittered block with minAngle 80 so that the rule fires often."""
+    import math
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(7, 6, 5, jitter=0.42, seed=10)
+    o = oracle_lib.Oracle(m)
+    prm = default_params(o.mesh_stats()[0], minAngle=80.0, faceAngleConstraint=False)
+    o.set_params(prm)
+    o.phaseA(); o.phaseB()
+    P, N = np.asarray(m.points, float), o.field("newPoints").reshape(-1, 3)
+    off, fp = m.faceOffsets, m.facePoints
+
+    def angle(c, a, b):
+        v1, v2 = a - c, b - c
+        v1, v2 = v1 / math.sqrt((v1 ** 2).sum()), v2 / math.sqrt((v2 ** 2).sum())
+        return math.acos(max(-0.99999, min(0.99999, float(v1 @ v2))))
+    minC, minN = np.full(len(P), np.inf), np.full(len(P), np.inf)
+    for f in range(m.nFaces):
+        v = fp[off[f]:off[f + 1]].tolist()
+        for k, p in enumerate(v):
+            a, b = v[k - 1], v[(k + 1) % len(v)]
+            minC[p] = min(minC[p], angle(P[p], P[a], P[b]))
+            minN[p] = min(minN[p], angle(N[p], P[a], P[b]), angle(N[p], N[a], N[b]), angle(N[p], P[a], N[b]), angle(N[p], N[a], P[b]))
+    before = o.field("frozenAfterEdgeLen").astype(bool)
+    free = ~before
+    assert np.abs(o.field("eaMinC") - minC)[free].max() <= 1e-13 and np.abs(o.field("eaMinN") - minN)[free].max() <= 1e-13
+    small = math.pi * 80.0 / 180.0
+    froze = free & (minN < small) & (minN < minC)
+    assert froze.sum() >= 3          # (smoothing mostly opens the small angles: few points are caught, all by this rule)
+    assert np.array_equal(o.field("frozenAfterEdgeAngle").astype(bool), before | froze)
