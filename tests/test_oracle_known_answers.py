@@ -615,3 +615,107 @@ def test_edge_angle_freeze_against_a_second_formulation(oracle_lib):
     froze = free & (minN < small) & (minN < minC)
     assert froze.sum() >= 3          # (smoothing mostly opens the small angles: few points are caught, all by this rule)
     assert np.array_equal(o.field("frozenAfterEdgeAngle").astype(bool), before | froze)
+
+
+class _PyFaceAngleModel:
+    """calcMinMaxFaceAngleForEdge / ForPoint with points moved hypothetically (SM.C:1103-1231, 1272-1304) and
+    restrictFaceAngleDeterioration's stack walk (SM.C:1320-1437), a second time in Python"""
+
+    def __init__(self, mesh, cellCentres):
+        self.P = np.asarray(mesh.points, float)
+        self.cc = cellCentres
+        self.off, self.fp = mesh.faceOffsets, mesh.facePoints
+        self.edge_cells, self.nbrs = {}, [set() for _ in range(len(self.P))]
+        for f in range(mesh.nFaces):
+            v = self.fp[self.off[f]:self.off[f + 1]].tolist()
+            cells = [int(mesh.owner[f])] + ([int(mesh.neighbour[f])] if f < mesh.nInternalFaces else [])
+            for k in range(len(v)):
+                a, b = v[k], v[(k + 1) % len(v)]
+                self.nbrs[a].add(b); self.nbrs[b].add(a)
+                d = self.edge_cells.setdefault((min(a, b), max(a, b)), {})
+                for c in cells:
+                    d.setdefault(c, []).append(f)
+
+    def _at(self, p, sub):
+        return sub.get(p, self.P[p])
+
+    def edge_min_max(self, a, b, sub):
+        import math
+        e0, e1 = self._at(a, sub), self._at(b, sub)          # (a < b: the edge's start and end, upper-triangular order)
+        cC = 0.5 * (e0 + e1)
+        d = e1 - e0
+        eV = d / math.sqrt((d ** 2).sum())
+
+        def projected(x):
+            w = (x + ((cC - x) @ eV) * eV) - cC
+            return w / math.sqrt((w ** 2).sum())
+
+        def face_centre(f):
+            v = self.fp[self.off[f]:self.off[f + 1]].tolist()
+            s = np.zeros(3)
+            for p in v:
+                s = s + self._at(p, sub)
+            return s / float(len(v))
+        clamp = lambda c: max(-0.99999, min(0.99999, c))
+        lo, hi = 2.0 * math.pi, 0.0
+        pv = {}
+        for c, two in self.edge_cells[(a, b)].items():
+            for f in two:
+                if f not in pv:
+                    pv[f] = projected(face_centre(f))
+            cV = projected(self.cc[c])
+            ang = math.acos(clamp(float(pv[two[0]] @ cV))) + math.acos(clamp(float(cV @ pv[two[1]])))
+            lo, hi = min(lo, ang), max(hi, ang)
+        return lo, hi
+
+    def point_min_max(self, p, sub):
+        import math
+        lo, hi = 2.0 * math.pi, 0.0
+        for q in sorted(self.nbrs[p]):
+            l, h = self.edge_min_max(min(p, q), max(p, q), sub)
+            lo, hi = min(lo, l), max(hi, h)
+        return lo, hi
+
+    def walk(self, newPoints, frozen, small, large):
+        frozen = frozen.copy()
+        cur = [self.point_min_max(p, {}) for p in range(len(self.P))]
+        stack = list(range(len(self.P)))
+        bad = lambda mm, p: (mm[0] < small and mm[0] < cur[p][0]) or (mm[1] > large and mm[1] > cur[p][1])
+        while stack:
+            p = stack.pop()
+            if cur[p][0] > small and cur[p][1] < large:
+                continue
+            n = self.P[p] if frozen[p] else newPoints[p]
+            if not np.array_equal(n, self.P[p]):
+                if bad(self.point_min_max(p, {p: n}), p):
+                    n = self.P[p]
+                    frozen[p] = True
+            for q in sorted(self.nbrs[p]):
+                if frozen[q] or np.array_equal(newPoints[q], self.P[q]):
+                    continue
+                if bad(self.point_min_max(p, {p: n, q: newPoints[q]}), p):
+                    frozen[q] = True
+                    stack.append(q)
+        return frozen
+
+
+@pytest.mark.parametrize("kind,jit,seed", [("hex", 0.45, 7), ("hex", 0.48, 11), ("polyhedral", 0.3, 5)])
+def test_face_angle_freeze_walk_against_a_second_formulation(oracle_lib, kind, jit, seed):
+    """the ordered freeze walk (SM.C:1320-1437: self freezes, neighbour freezes, LIFO re-visits) with the hypothetical-move
+    evaluations behind it, on badly jittered blocks and on the polyhedral mesh: the set of points the ORACLE freezes against the
+    set the Python restatement above freezes from the same proposals and the same flags of the earlier rules"""
+    import math
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.meshgen import hex_block
+    from smoothmesh_amd.polymesh import cavity_mesh
+    m = hex_block(8, 7, 6, jitter=jit, seed=seed) if kind == "hex" else cavity_mesh(8, jitter=jit, seed=seed)
+    o = oracle_lib.Oracle(m)
+    prm = default_params(o.mesh_stats()[0])
+    o.set_params(prm)
+    o.phaseA(); o.phaseB()
+    model = _PyFaceAngleModel(m, o.field("cellCentres").reshape(-1, 3))
+    before = o.field("frozenAfterEdgeAngle").astype(bool)
+    want = model.walk(o.field("newPoints").reshape(-1, 3), before, math.pi * prm.minAngle / 180.0, math.pi * prm.maxAngle / 180.0)
+    got = o.field("frozenAfterFaceAngle").astype(bool)
+    assert (want & ~before).sum() >= 3             # the walk froze points of its own
+    assert np.array_equal(got, want)
