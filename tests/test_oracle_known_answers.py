@@ -794,3 +794,155 @@ def test_whole_iterations_against_a_second_formulation(oracle_lib, kind, iters):
     assert len(set(frz_p)) > 1 or kind != "hex"                 # the frozen set changes from iteration to iteration
     assert np.abs(np.array(res_p) - res_o).max() <= 1e-11
     assert np.abs(np.asarray(mine.points) - o.points()).max() <= 1e-11
+
+
+def _python_multi_iteration(subs, prm, table):
+    """ONE pass of the loop under -parallel, a second time in Python: every rank does what _python_iteration does on ITS
+    sub-domain (processor-patch points are internal there, SM.C:49-58) and the per-point values meet where the reference calls
+    syncTools::syncPointList -- the cell-centre sums and counts (plusEqOp, SM.C:134-148), the three closest points one position
+    after the other with minMagSqrEqOp and isCloserPoint (SM.C:391-469), hasCommonCell and the frozen flags (orEqOp, SM.C:471-478,
+    2374) -- each as globalMeshData::syncData does it: the value of the lowest rank, the others folded onto it in ascending rank
+    order, the result handed to every sharer.  table = decompose.shared_point_table(subs).  -> (sum of the ranks' nFrozenPoints,
+    largest residual)"""
+    import math
+    GREAT = 1.0e15
+    off, dom, loc = table
+    groups = [[(int(dom[k]), int(loc[k])) for k in range(off[i], off[i + 1])] for i in range(len(off) - 1)]     # ascending rank
+    R = len(subs)
+    st = []
+    for s in subs:
+        m = s.mesh
+        P = np.asarray(m.points, float).copy()
+        internal = m.find_internal_points().astype(bool)
+        fC, fA, cC, vol = _numpy_geometry(m)
+        cent, c1, c2, c3, hcc, _ = _numpy_targets(m, cC)
+        model = _PyFaceAngleModel(m, cC)
+        cells_of = [set() for _ in range(len(P))]
+        for f in range(m.nFaces):
+            for p in m.facePoints[m.faceOffsets[f]:m.faceOffsets[f + 1]].tolist():
+                cells_of[p].add(int(m.owner[f]))
+                if f < m.nInternalFaces:
+                    cells_of[p].add(int(m.neighbour[f]))
+        ssum, cnt = np.zeros((len(P), 3)), np.zeros(len(P), int)
+        for p in range(len(P)):
+            if internal[p]:
+                for c in sorted(cells_of[p]):
+                    ssum[p] = ssum[p] + cC[c]
+                cnt[p] = len(cells_of[p])
+        c3 = np.where(np.isnan(c3), GREAT, c3)
+        st.append(dict(P=P, internal=internal, model=model, ssum=ssum, cnt=cnt, c1=c1.copy(), c2=c2.copy(), c3=c3, hcc=hcc.copy(), cC=cC))
+
+    def sync(field, op):
+        for g in groups:
+            x = st[g[0][0]][field][g[0][1]].copy()
+            for r, l in g[1:]:
+                x = op(x, st[r][field][l])
+            for r, l in g:
+                st[r][field][l] = x
+    magsqr = lambda v: float((v * v).sum())
+    minmag = lambda x, y: x if magsqr(x) <= magsqr(y) else y
+    sync("ssum", lambda x, y: x + y); sync("cnt", lambda x, y: x + y)
+
+    def closer(a, b):                                   # isCloserPoint SM.C:246-272
+        if np.array_equal(a, b):
+            return False
+        d = math.sqrt(magsqr(a)) - math.sqrt(magsqr(b))
+        if d < 1e-300:
+            return True
+        return abs(d) < 1e-300 and tuple(a) < tuple(b)
+    for pos in (1, 2, 3):
+        for S in st:
+            S["sy"] = S["c%d" % pos].copy()
+        sync("sy", minmag)
+        for S in st:
+            for p in range(len(S["P"])):
+                if closer(S["sy"][p], S["c%d" % pos][p]):
+                    if pos == 1:
+                        S["c3"][p] = S["c2"][p]; S["c2"][p] = S["c1"][p]; S["c1"][p] = S["sy"][p]; S["hcc"][p] = False
+                    elif pos == 2:
+                        S["c3"][p] = S["c2"][p]; S["c2"][p] = S["sy"][p]; S["hcc"][p] = False
+                    else:
+                        S["c3"][p] = S["sy"][p]
+    sync("hcc", lambda x, y: x or y)
+    for S in st:
+        P, internal = S["P"], S["internal"]
+        new = P.copy()
+        for p in range(len(P)):
+            if S["cnt"][p]:
+                new[p] = S["ssum"][p] / float(S["cnt"][p])
+            cen = new[p].copy()
+            c1, c2, c3 = S["c1"][p], S["c2"][p], S["c3"][p]
+            frac = 0.0
+            if not S["hcc"][p] and magsqr(c1) > 0 and magsqr(c2) > 0:
+                r1, r2 = math.sqrt(magsqr(c2)) / math.sqrt(magsqr(c1)), math.sqrt(magsqr(c3)) / math.sqrt(magsqr(c2))
+                if internal[p]:
+                    frac = min(1.0, max(0.0, (r2 - 1.5) / 1.5)) if (r1 < 1.5 and r2 > 1.5) else 0.0
+                else:
+                    frac = min(1.0, max(0.0, (r1 - 1.0) / 1.0))
+            if frac > 0.0:
+                new[p] = (1.0 - frac) * cen + frac * (P[p] + (c1 + c2) / 2.0)
+            step = new[p] - P[p]
+            ln = math.sqrt(magsqr(step))
+            scale = prm.maxStepLength / (ln * prm.relStepFrac) if ln > prm.maxStepLength else 1.0
+            new[p] = P[p] + prm.relStepFrac * scale * step
+        frozen = np.zeros(len(P), bool)
+        nb = S["model"].nbrs
+        dist = lambda a, b: math.sqrt(magsqr(a - b))
+        for p in range(len(P)):
+            sc = min(dist(P[q], P[p]) for q in nb[p]); sn = min(dist(P[q], new[p]) for q in nb[p])
+            if (prm.totalMinFreeze and min(sn, sc) < prm.minEdgeLength) or (sn < prm.minEdgeLength and sn < sc):
+                frozen[p] = True
+        S["new"], S["frozen"] = new, frozen
+    sync("frozen", lambda x, y: x or y)
+    nFrozen, res = 0, 0.0
+    for S, s in zip(st, subs):
+        keep = S["frozen"] | ~S["internal"]
+        S["new"][keep] = S["P"][keep]
+        nFrozen += int(keep.sum())
+        res = max(res, max(math.sqrt(magsqr(S["new"][p] - S["P"][p])) / prm.maxStepLength for p in range(len(S["P"]))))
+        s.mesh.points[:] = S["new"]
+    return nFrozen, res
+
+
+@pytest.mark.parametrize("case", ["graded boxes", "ragged", "baffle"])
+def test_parallel_iterations_against_a_second_formulation(oracle_lib, case):
+    """the loop under -parallel (constraints off: everything a rank computes for a shared point is combined) by the Python
+    restatement above against the oracle's MultiDomain: an EXACTLY graded block cut by processor planes (the closest-point syncs tie
+    there: the master's fold and isCloserPoint decide), five ragged sub-domains, and the block with a baffle between its ranks"""
+    import copy
+    from smoothmesh_amd import default_params
+    from smoothmesh_amd.decompose import bfs_partition, decompose, grid_partition, shared_point_table
+    from smoothmesh_amd.meshgen import hex_block
+    from test_irregular_partitions import build_case
+    if case == "graded boxes":
+        from test_sync_tie_rule import graded_block
+        gm = graded_block(8, 4, 4)        # dx = dy / 2 = dz / 2, the points of the plane x = 1/2 moved in y: their +-x distances tie exactly
+        subs = decompose(gm, grid_partition(gm, (2, 2, 1)), 4)
+    elif case == "ragged":
+        gm = hex_block(7, 6, 5, lengths=(1.0, 1.0, 0.3), jitter=0.25, seed=3)
+        subs = decompose(gm, bfs_partition(gm, 5, seed=3, island=True), 5)
+    else:
+        gm, cr = build_case("hex_baffle", 4, 17)
+        subs = decompose(gm, cr, 4)
+    table = shared_point_table(subs)
+    orcs = [oracle_lib.Oracle(s.mesh) for s in subs]
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=False, faceAngleConstraint=False)
+    for o in orcs:
+        o.set_params(prm)
+    mo = oracle_lib.MultiOracle(orcs, *table)
+    n, res_o, frz_o = mo.iterate(4, 0.0)
+    mine = copy.deepcopy(subs)
+    out = [_python_multi_iteration(mine, prm, table) for _ in range(4)]
+    assert [f for f, _ in out] == frz_o.tolist()
+    assert np.abs(np.array([r for _, r in out]) - res_o).max() <= 1e-11
+    for s, o in zip(mine, orcs):
+        assert np.abs(np.asarray(s.mesh.points) - o.points()).max() <= 1e-11
+    if case == "graded boxes":
+        # the case tells the fold models apart: the oracle with every sharer folding onto ITS OWN value (rounds 1-3's model) is off
+        orcs2 = [oracle_lib.Oracle(s.mesh) for s in subs]
+        for o in orcs2:
+            o.set_params(prm)
+        mo2 = oracle_lib.MultiOracle(orcs2, *table)
+        mo2.set_sync_variant("own")
+        mo2.iterate(4, 0.0)
+        assert max(np.abs(np.asarray(s.mesh.points) - o.points()).max() for s, o in zip(mine, orcs2)) > 1e-5
