@@ -609,12 +609,28 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
 #define SMGPU_PACK_WAVES 3
 #endif
 constexpr int kPackBlock = 256;
-// Vertex slots of a star: 128 as in k_walk_pred_star.  (An interior hex point has 48, the refinement interfaces of the castellated
-// meshes at most 60.  With 64 slots the wave's tables take 10 KB instead of 13.2 and FOUR waves per SIMD fit -- measured on the 10 M-cell
+// Vertex slots of a star: 96 (k_walk_pred_star: 128; an interior hex point has 48, the refinement interfaces of the castellated
+// meshes at most 60; a larger star is left to the general kernels).  (Measured with 128 and 64 slots:  With 64 slots the wave's tables take 10 KB instead of 13.2 and FOUR waves per SIMD fit -- measured on the 10 M-cell
 // cavity mesh, profiles/r4/ab_walk_pred_pack.txt: 724 us at four waves (128 VGPRs, 36 of them spilled), 693 at three (168 VGPRs),
 // 697 at three with 128 slots: the kernel is not occupancy bound, so it keeps the larger stars.)
-constexpr int kPackVerts = 128;
-typedef StarLdsT<kPackVerts> PackStar;
+constexpr int kPackVerts = 96;
+// One coordinate table per half: the vertex slots [0, kPackVerts), behind them the proposals of the point's entries
+// [kPackVerts, + kStarEnts) and the point itself, current (kPackCur) and proposed (kPackProp).  A job moves the point and one
+// entry's neighbour hypothetically: a vertex slot whose role says "the point" / "that neighbour" is then read from the other
+// INDEX of the same table -- two 32-bit selects per vertex instead of six 64-bit ones on its coordinates (selecting a V3 by
+// value cost 12 v_cndmask per vertex, a quarter of a task's vector instructions).
+constexpr int kPackEnt0 = kPackVerts, kPackCur = kPackVerts + kStarEnts, kPackProp = kPackCur + 1, kPackSlots = kPackProp + 1;
+struct PackStar {
+    int fid[kStarFaces];
+    int voff[kStarFaces + 1];
+    unsigned char role[kPackVerts];      // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
+    double vx[kPackSlots], vy[kPackSlots], vz[kPackSlots];
+    unsigned char nb[kStarEnts];
+    double pMin, pMax;                   // ptMin / ptMax of the half wave's point
+    int eq[kStarEnts];                   // entry e's neighbour (point id)
+    struct { int fbeg[kStarFaces]; unsigned char vface[kPackVerts]; } st;   // staging only: first entry of the face in facePts,
+                                                                             // the star-local face of every vertex slot
+};
 struct PackPlace { double ccx, ccy, ccz; unsigned char l, lNext, xEnt, xSlot, pFirst, pad[3]; };
 struct PackLds {                         // per wave: two points
     PackStar h[2];
@@ -643,9 +659,13 @@ __device__ __forceinline__ int nthSetBit(unsigned m, int r) {
 }
 
 // one task: the angle of place R of the half whose star is L, with p at c1 and entry ei's neighbour at c2 (ei = kRoleNoEntry: nobody)
-__device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPlace& R, const V3& c1, int ei, const V3& c2) {
-    const int xs_ = R.xSlot;
-    const V3 xs = sel3((int)R.xEnt == ei, c2, v3(L.vx[xs_], L.vy[xs_], L.vz[xs_]));
+__device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPlace& R, int selfIdx, int ei) {
+    // selfIdx: where the point is in this job (kPackCur / kPackProp); ei: the entry whose neighbour sits at its proposal
+    // (kRoleNoEntry: nobody); both are read through their slots of the coordinate table
+    const int entIdx = kPackEnt0 + (ei < kStarEnts ? ei : 0);
+    const V3 c1 = v3(L.vx[selfIdx], L.vy[selfIdx], L.vz[selfIdx]);
+    const int xs_ = ((int)R.xEnt == ei) ? entIdx : (int)R.xSlot;
+    const V3 xs = v3(L.vx[xs_], L.vy[xs_], L.vz[xs_]);
     const bool pFirst = R.pFirst != 0;
     const V3 e0 = sel3(pFirst, c1, xs), e1 = sel3(pFirst, xs, c1);
     const V3 cC = 0.5 * (e0 + e1);
@@ -658,8 +678,8 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
         // reads of a face, so that they are in flight together (the additions keep the vertex order)
         auto vert = [&](int k) -> V3 {
             const int r = L.role[k];
-            const V3 pv = v3(L.vx[k], L.vy[k], L.vz[k]);
-            return sel3(r == kRoleSelf, c1, sel3(r == ei, c2, pv));
+            const int at = (r == kRoleSelf) ? selfIdx : (r == ei) ? entIdx : k;
+            return v3(L.vx[at], L.vy[at], L.vz[at]);
         };
         int i = 0;
         for (; i + 4 <= n; i += 4) {
@@ -731,11 +751,8 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
             const int i = nthSetBit(Mt, k - W.off[t]);
             const PackStar& L = W.h[h];
             const bool isSelf = e == 127;
-            const double* pc = (isSelf || phase == 1) ? L.pn : L.pc;     // where the point is in this job
-            const V3 c1 = v3(pc[0], pc[1], pc[2]);
-            const int ex = isSelf ? 0 : e;
-            const V3 c2 = v3(L.ex[ex], L.ey[ex], L.ez[ex]);
-            const double angle = packTaskAngle(L, W.place[h][i], c1, isSelf ? (int)kRoleNoEntry : e, c2);
+            const int selfIdx = (isSelf || phase == 1) ? kPackProp : kPackCur;     // where the point is in this job
+            const double angle = packTaskAngle(L, W.place[h][i], selfIdx, isSelf ? (int)kRoleNoEntry : e);
             const unsigned long long ab = (unsigned long long)__double_as_longlong(angle);
             atomicMin(&W.jmin[t], ab); atomicMax(&W.jmax[t], ab);
             if (isSelf) W.selfAng[h][i] = angle;
@@ -784,7 +801,8 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             const V3 np = ldv(s.prop, p);
             moved = (np != cur);
             if (hl == 0) {
-                L.pc[0] = cur.x; L.pc[1] = cur.y; L.pc[2] = cur.z; L.pn[0] = np.x; L.pn[1] = np.y; L.pn[2] = np.z;
+                L.vx[kPackCur] = cur.x; L.vy[kPackCur] = cur.y; L.vz[kPackCur] = cur.z;
+                L.vx[kPackProp] = np.x; L.vy[kPackProp] = np.y; L.vz[kPackProp] = np.z;
                 L.pMin = s.ptMin[p]; L.pMax = s.ptMax[p];
             }
         }
@@ -889,13 +907,13 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
 #pragma unroll
             for (int u = 0; u < kPackVerts / 32; ++u) if (vg[u] == qe) role[u] = (unsigned char)e;
         }
-        __builtin_amdgcn_wave_barrier();                              // (ez below overlays the staging tables read above)
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int u = 0; u < kPackVerts / 32; ++u) {
             const int k = hl + 32 * u;
             if (vg[u] >= 0) { L.role[k] = role[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
         }
-        if (q >= 0) { L.nb[hl] = nb0; L.ex[hl] = nq.x; L.ey[hl] = nq.y; L.ez[hl] = nq.z; }
+        if (q >= 0) { L.nb[hl] = nb0; L.vx[kPackEnt0 + hl] = nq.x; L.vy[kPackEnt0 + hl] = nq.y; L.vz[kPackEnt0 + hl] = nq.z; }
         if (P.valid) for (int l = 0; l < nF; ++l) if (L.fid[l] == rf) P.l = l;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
