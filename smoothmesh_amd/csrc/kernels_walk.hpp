@@ -663,11 +663,10 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
     // selfIdx: where the point is in this job (kPackCur / kPackProp); ei: the entry whose neighbour sits at its proposal
     // (kRoleNoEntry: nobody); both are read through their slots of the coordinate table
     const int entIdx = kPackEnt0 + (ei < kStarEnts ? ei : 0);
-    const V3 c1 = v3(L.vx[selfIdx], L.vy[selfIdx], L.vz[selfIdx]);
-    const int xs_ = ((int)R.xEnt == ei) ? entIdx : (int)R.xSlot;
-    const V3 xs = v3(L.vx[xs_], L.vy[xs_], L.vz[xs_]);
+    const int xs_ = ((int)R.xEnt == ei) ? entIdx : (int)R.xSlot;       // the edge's far end, possibly the moved neighbour
     const bool pFirst = R.pFirst != 0;
-    const V3 e0 = sel3(pFirst, c1, xs), e1 = sel3(pFirst, xs, c1);
+    const int i0 = pFirst ? selfIdx : xs_, i1 = pFirst ? xs_ : selfIdx;    // the edge's start and end (edges[2e], edges[2e + 1])
+    const V3 e0 = v3(L.vx[i0], L.vy[i0], L.vz[i0]), e1 = v3(L.vx[i1], L.vy[i1], L.vz[i1]);
     const V3 cC = 0.5 * (e0 + e1);
     const V3 d = e1 - e0;
     const V3 eVec = d / mag(d);
