@@ -610,9 +610,9 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
 #endif
 constexpr int kPackBlock = 256;
 // Vertex slots of a star: 96 (k_walk_pred_star: 128; an interior hex point has 48, the refinement interfaces of the castellated
-// meshes at most 60; a larger star is left to the general kernels).  (Measured with 128 and 64 slots:  With 64 slots the wave's tables take 10 KB instead of 13.2 and FOUR waves per SIMD fit -- measured on the 10 M-cell
-// cavity mesh, profiles/r4/ab_walk_pred_pack.txt: 724 us at four waves (128 VGPRs, 36 of them spilled), 693 at three (168 VGPRs),
-// 697 at three with 128 slots: the kernel is not occupancy bound, so it keeps the larger stars.)
+// meshes at most 60; a larger star is left to the general kernels).  Measured before the coordinate table below, on the 10 M-cell
+// cavity mesh (profiles/r4/ab_walk_pred_pack.txt): 64 slots and FOUR waves per SIMD 724 us (128 VGPRs, 36 of them spilled), 64
+// slots at three waves 693 (168 VGPRs), 128 slots at three waves 697 -- the kernel is not occupancy bound.
 constexpr int kPackVerts = 96;
 // One coordinate table per half: the vertex slots [0, kPackVerts), behind them the proposals of the point's entries
 // [kPackVerts, + kStarEnts) and the point itself, current (kPackCur) and proposed (kPackProp).  A job moves the point and one
