@@ -640,6 +640,54 @@ def self_launch(args):
     raise SystemExit(r.returncode)
 
 
+def _parity_ok(par):
+    return par is None or bool(par.get("ok", False))
+
+
+def finalize_line(out):
+    """Last step before printing: (1) append `configs_summary` as the LAST key -- one short object per measured configuration
+    (headline first), so that a reader who only keeps the tail of the ~15 KB line still sees every configuration's rate, parity
+    verdict and CPU ratio; (2) the process exit code: non-zero when any parity_check is not ok or any configs[] entry carries an
+    error (the line is printed either way; a wrong or missing result must not look like a pass).  Returns (out, exit_code)."""
+    def brief(wl, e):
+        par = e.get("parity_check")
+        b = {"workload": wl, "steps": e.get("steps"), "ms_per_step": e.get("ms_per_step"), "points_per_s": e.get("value"),
+             "parity_ok": None if par is None else bool(par.get("ok", False)),
+             "bitwise_equal": None if par is None else par.get("bitwise_equal"),
+             "cpu_ratio": e.get("speedup_vs_cpu_baseline")}
+        if "error" in e:
+            b["error"] = e["error"]
+        return b
+    out.pop("configs_summary", None)
+    entries = [(out.get("workload_name", "headline"), out)] + [(c.get("workload", "?"), c) for c in out.get("configs", [])]
+    failures = []
+    for wl, e in entries:
+        if "error" in e:
+            failures.append(f"{wl}: {e['error']}")
+        elif not _parity_ok(e.get("parity_check")):
+            failures.append(f"{wl}: parity_check not ok")
+    out["exit_code"] = 1 if failures else 0
+    if failures:
+        out["failures"] = failures
+    out["configs_summary"] = [brief(wl, e) for wl, e in entries]       # LAST key: survives a tail of the line
+    return out, out["exit_code"]
+
+
+def emit(out):
+    """the exit path: finalize, print the ONE JSON line, return the process exit code (main() raises SystemExit with it after the
+    process group is gone).  SMOOTHMESH_BENCH_FALSIFY=<workload> flips that entry's parity verdict -- the test hook that shows a
+    failed comparison reaches the exit code."""
+    fals = os.environ.get("SMOOTHMESH_BENCH_FALSIFY")
+    if fals:
+        for e in [out] + list(out.get("configs", [])):
+            if e.get("workload_name", e.get("workload")) == fals and e.get("parity_check"):
+                e["parity_check"]["ok"] = False
+                e["parity_check"]["falsified_by_test_hook"] = True
+    out, code = finalize_line(out)
+    print(json.dumps(out), flush=True)
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -739,6 +787,7 @@ def main():
 
     out = {
         "metric": "mesh-points smoothed/sec/node (100 iters) + achieved HBM GB/s vs roofline",
+        "workload_name": args.workload,
         "value": total_points * K / dt,
         "unit": "points/s",
         "n_gpus": world,
@@ -822,11 +871,13 @@ def main():
             out["phases"] = single["phases"]
     import resource
     out["host_max_rss_gib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20   # rank 0's process
-    print(json.dumps(out))
+    code = emit(out)
     if world > 1 or force_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if code:
+        raise SystemExit(code)
 
 
 if __name__ == "__main__":

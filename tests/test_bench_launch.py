@@ -85,6 +85,68 @@ def test_default_multi_gpu_line_names_configs4():
     assert "configs[4]" in bench.workload_text("cavity", 215, True, False, False, world=8, n_global=430)
 
 
+def _line(**kw):
+    par = {"ok": True, "bitwise_equal": True, "rel_linf": 0.0}
+    d = {"metric": "m", "workload_name": "hex100", "value": 1e10, "steps": 100, "ms_per_step": 0.08, "parity_check": dict(par),
+         "speedup_vs_cpu_baseline": 3000.0,
+         "configs": [{"workload": "hex100c", "steps": 100, "ms_per_step": 0.2, "value": 5e9, "parity_check": dict(par), "speedup_vs_cpu_baseline": 4000.0},
+                     {"workload": "cavity215c", "steps": 200, "ms_per_step": 3.0, "value": 3e9, "parity_check": dict(par), "speedup_vs_cpu_baseline": 5000.0}]}
+    d.update(kw)
+    return d
+
+
+def test_finalize_line_fails_closed_and_is_tail_safe():
+    """the line's LAST key is the compact per-configuration summary (a reader of the tail sees configs[1..3]); a parity_check
+    that is not ok, or a configs[] entry with an error, turns into a non-zero exit code"""
+    sys.path.insert(0, ROOT)
+    import bench
+    out, code = bench.finalize_line(_line())
+    assert code == 0 and out["exit_code"] == 0 and "failures" not in out
+    assert list(out)[-1] == "configs_summary"
+    assert [c["workload"] for c in out["configs_summary"]] == ["hex100", "hex100c", "cavity215c"]
+    assert all(c["parity_ok"] is True and c["ms_per_step"] > 0 and c["points_per_s"] > 0 and c["cpu_ratio"] > 0 for c in out["configs_summary"])
+    assert len(json.dumps(out["configs_summary"])) < 1200          # stays inside a short tail
+    # a falsified parity object in a configs[] entry
+    bad = _line()
+    bad["configs"][1]["parity_check"]["ok"] = False
+    out, code = bench.finalize_line(bad)
+    assert code == 1 and out["failures"] == ["cavity215c: parity_check not ok"] and out["configs_summary"][2]["parity_ok"] is False
+    # ... in the headline
+    bad = _line()
+    bad["parity_check"] = {"ok": False}
+    assert bench.finalize_line(bad)[1] == 1
+    # a sub-run that raised
+    bad = _line()
+    bad["configs"][0] = {"workload": "hex100c", "error": "RuntimeError: boom"}
+    out, code = bench.finalize_line(bad)
+    assert code == 1 and "hex100c: RuntimeError: boom" in out["failures"] and out["configs_summary"][1]["error"].endswith("boom")
+    assert list(out)[-1] == "configs_summary"
+    # a line without an oracle leg (--no-cpu-baseline) is not a failure, and says that nothing was compared
+    out, code = bench.finalize_line({"workload_name": "hex100", "value": 1.0, "steps": 1, "ms_per_step": 1.0})
+    assert code == 0 and out["configs_summary"][0]["parity_ok"] is None
+
+
+def test_exit_path_carries_a_falsified_parity_object():
+    """through the real exit path (emit -> SystemExit) in a process of its own: the line is printed AND the exit code is 1"""
+    prog = ("import sys, json; sys.path.insert(0, %r); import bench; sys.path.insert(0, %r); from test_bench_launch import _line; "
+            "raise SystemExit(bench.emit(_line()))" % (ROOT, os.path.join(ROOT, "tests")))
+    ok = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY=""))
+    assert ok.returncode == 0 and json.loads(ok.stdout)["exit_code"] == 0
+    bad = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY="cavity215c"))
+    d = json.loads(bad.stdout)
+    assert bad.returncode == 1 and d["exit_code"] == 1 and d["failures"] == ["cavity215c: parity_check not ok"]
+    assert list(d)[-1] == "configs_summary"
+
+
+@pytest.mark.gpu
+def test_bench_exits_nonzero_when_a_comparison_fails():
+    r = _run(["--steps", "3", "--warmup", "1", "--workload", "hex10", "--configs", "hex10c", "--config-steps", "2"],
+             env={"SMOOTHMESH_BENCH_FALSIFY": "hex10c"})
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert r.returncode == 1 and d["exit_code"] == 1 and d["failures"] == ["hex10c: parity_check not ok"]
+    assert d["parity_check"]["ok"] and list(d)[-1] == "configs_summary"
+
+
 @pytest.mark.gpu
 def test_bench_single_gpu_line_carries_the_other_configs():
     r = _run(["--steps", "5", "--warmup", "1", "--workload", "hex12", "--configs", "hex12c,cavity10c", "--config-steps", "3"])
@@ -92,6 +154,10 @@ def test_bench_single_gpu_line_carries_the_other_configs():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["frac"] > 0
     assert [c["workload"] for c in d["configs"]] == ["hex12c", "cavity10c"]
+    # tail-safe: the compact summary of every configuration is the line's last key
+    assert list(d)[-1] == "configs_summary" and d["exit_code"] == 0
+    assert [c["workload"] for c in d["configs_summary"]] == ["hex12", "hex12c", "cavity10c"]
+    assert all(c["parity_ok"] and c["bitwise_equal"] and c["cpu_ratio"] > 0 for c in d["configs_summary"])
     assert d["parity_check"]["ok"] and d["parity_check"]["rel_linf"] <= 1e-10 and d["ms_per_step_cold"] > 0
     for c in d["configs"]:
         assert "error" not in c, c
