@@ -36,6 +36,7 @@
 #include "fvMesh.H"
 #include "syncTools.H"
 #include "processorPolyPatch.H"
+#include "processorCyclicPolyPatch.H"
 #include "emptyPolyPatch.H"
 #include "labelIOList.H"
 #include "wordReList.H"
@@ -186,19 +187,26 @@ HaloTables buildHalo(const fvMesh& mesh)
     HaloTables t;
     const label me = Pstream::myProcNo();
     const label nProcs = Pstream::nProcs();
-    // my processor patches, flattened: {neighbour, nFaces, {n, mesh points ...} per face}*
+    // my processor patches, flattened: {neighbour, nFaces, {n, mesh points ...} per face}*  (+ the listed vertices' coordinates)
     std::vector<label> flat;
+    std::vector<point> flatPts;
     forAll(mesh.boundaryMesh(), patchI)
     {
         const polyPatch& pp = mesh.boundaryMesh()[patchI];
         if (!isA<processorPolyPatch>(pp)) continue;
+        // (isA<processorPolyPatch> is also true for a processorCyclicPolyPatch: the copies of a point across a cyclic are NOT one
+        // point -- their positions differ by the patch transform -- and nothing here transforms positions or sums; the C++
+        // front-end refuses such cases too)
+        if (isA<processorCyclicPolyPatch>(pp))
+            FatalErrorInFunction << "patch " << pp.name() << " is a processorCyclic patch: cyclic coupling between sub-domains is not supported"
+                                 << exit(FatalError);
         flat.push_back(refCast<const processorPolyPatch>(pp).neighbProcNo());
         flat.push_back(pp.size());
         for (label i = 0; i < pp.size(); ++i)
         {
             const face& f = mesh.faces()[pp.start() + i];
             flat.push_back(f.size());
-            forAll(f, k) flat.push_back(f[k]);
+            forAll(f, k) { flat.push_back(f[k]); flatPts.push_back(mesh.points()[f[k]]); }
         }
     }
     List<labelList> all(nProcs);
@@ -206,18 +214,25 @@ HaloTables buildHalo(const fvMesh& mesh)
     forAll(all[me], i) all[me][i] = flat[static_cast<size_t>(i)];
     Pstream::gatherList(all);
     Pstream::scatterList(all);
+    List<pointField> allPts(nProcs);
+    allPts[me].setSize(static_cast<label>(flatPts.size()));
+    forAll(allPts[me], i) allPts[me][i] = flatPts[static_cast<size_t>(i)];
+    Pstream::gatherList(allPts);
+    Pstream::scatterList(allPts);
 
-    // per rank and neighbour: where each face's {n, points...} record starts
-    std::vector<std::map<label, std::vector<label>>> faceAt(static_cast<size_t>(nProcs));
+    // per rank and neighbour: where each face's {n, points...} record starts (and where its coordinates start)
+    std::vector<std::map<label, std::vector<label>>> faceAt(static_cast<size_t>(nProcs)), coordAt(static_cast<size_t>(nProcs));
     for (label o = 0; o < nProcs; ++o)
     {
         const labelList& v = all[o];
+        label co = 0;
         for (label k = 0; k + 1 < v.size();)
         {
             const label nb = v[k], nF = v[k + 1];
             k += 2;
             std::vector<label>& at = faceAt[static_cast<size_t>(o)][nb];
-            for (label f = 0; f < nF; ++f) { at.push_back(k); k += 1 + v[k]; }
+            std::vector<label>& cat = coordAt[static_cast<size_t>(o)][nb];
+            for (label f = 0; f < nF; ++f) { at.push_back(k); cat.push_back(co); co += v[k]; k += 1 + v[k]; }
         }
     }
     std::map<Node, Node> parent;                     // the root of a component is its lowest node
@@ -245,8 +260,16 @@ HaloTables buildHalo(const fvMesh& mesh)
                 const label nv = all[a][pa];
                 if (all[b][pb] != nv)
                     FatalErrorInFunction << "processor patches " << a << " <-> " << b << ": face sizes differ" << exit(FatalError);
+                // vertex k of one side is vertex (n - k) mod n of the other (the face reversed about its first vertex): nothing but the
+                // coordinates can tell whether the two sides really list their faces that way -- OpenFOAM's matchTolerance
+                const label ca = coordAt[static_cast<size_t>(a)][b][f], cb = coordAt[static_cast<size_t>(b)][a][f];
+                scalar ext = 0;
+                for (label k = 1; k < nv; ++k) ext = max(ext, mag(allPts[a][ca + k] - allPts[a][ca]));
                 for (label k = 0; k < nv; ++k)
                 {
+                    if (mag(allPts[a][ca + k] - allPts[b][cb + (nv - k) % nv]) > 1e-4 * ext)
+                        FatalErrorInFunction << "processor patches " << a << " <-> " << b << ": face " << label(f) << " vertex " << k
+                                             << " does not coincide with its copy on the other side" << exit(FatalError);
                     const Node x = find(Node(a, all[a][pa + 1 + k])), y = find(Node(b, all[b][pb + 1 + (nv - k) % nv]));
                     if (x != y) { if (x < y) parent[y] = x; else parent[x] = y; }
                 }
@@ -260,7 +283,15 @@ HaloTables buildHalo(const fvMesh& mesh)
     {
         std::vector<Node> nodes;
         for (const auto& kv : parent) nodes.push_back(kv.first);
-        for (const Node& nd : nodes) if (nd.first == me) localOf[find(nd)] = nd.second;
+        for (const Node& nd : nodes)
+        {
+            if (nd.first != me) continue;
+            const Node key = find(nd);
+            // a rank has ONE local point per mesh point: two of them in one component mean the patches do not pair up as assumed
+            if (localOf.count(key) && localOf[key] != nd.second)
+                FatalErrorInFunction << "local points " << localOf[key] << " and " << nd.second << " are matched to the same shared point" << exit(FatalError);
+            localOf[key] = nd.second;
+        }
         for (const Node& nd : nodes)                 // (ascending rank: the map is ordered by (rank, point))
         {
             if (nd.first == me) continue;
@@ -866,6 +897,7 @@ int main(int argc, char *argv[])
             double ls[2];
             checkHip(hipMemcpyAsync(ls, localStats, sizeof(ls), hipMemcpyDeviceToHost, stream));
             checkHip(hipStreamSynchronize(stream));
+            check(smgpu_check_error(h));        // an error word raised by a kernel of this iteration (include/smgpu.h)
             scalar residual = ls[0];
             label nFrozenPoints = label(ls[1]);
             reduce(residual, maxOp<scalar>());                                                     // SM.C:1567

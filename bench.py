@@ -483,7 +483,9 @@ def shared_copies_check(ds, sub):
     with np.errstate(over="ignore"):
         h = (bits[:, 0] * np.uint64(0x9E3779B97F4A7C15)) ^ (bits[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) + np.uint64(0x165667B19E3779F9)) \
             ^ ((bits[:, 2] << np.uint64(17)) | (bits[:, 2] >> np.uint64(47)))
-    gid = np.asarray(sub.pointProcAddressing, np.int64)[loc]
+    # a shared point is named by (global id, group): the id alone is not enough once a baffle lies between ranks (one mesh point,
+    # two shared points, HaloTables.sharedComp); the groups' labels are the same on every rank
+    gid = np.asarray(sub.pointProcAddressing, np.int64)[loc] * np.int64(1 << 20) + (np.asarray(t.sharedComp, np.int64) % np.int64(1 << 20))
     internal = np.asarray(sub.mesh.find_internal_points(), np.uint8)[loc]
     box = [None] * ds.world if ds.rank == 0 else None
     dist.gather_object((gid, h, internal), box, dst=0)
@@ -551,6 +553,12 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
             small = small_case_parity(kind, constraints, grid, rank, world, local_rank)
         except Exception as ex:   # noqa: BLE001 -- reported in the line, the measurement goes on (on every rank alike)
             small = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+        # a failure on SOME ranks only (an oracle mismatch that raised, a device error) must become every rank's verdict before the
+        # next collective; a rank that died inside a collective cannot be helped from here
+        bad = torch.tensor([0 if (small or {}).get("ok") or "error" not in (small or {}) else 1], dtype=torch.int32, device=rdev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) and "error" not in small:
+            small = {"ok": False, "error": "small case raised on another rank"}
     t0 = time.perf_counter()
     sub, n_global = make_subdomain(kind, n_side, grid, rank, world)
     t_mesh = time.perf_counter() - t0

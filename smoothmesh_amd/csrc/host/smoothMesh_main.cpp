@@ -393,10 +393,78 @@ std::string labelsFromPatches(Rank& K, int r, int n, const std::vector<std::vect
             }
         }
     K.pointProc.resize((size_t)K.mesh.nPoints());
+    std::map<Node, int32_t> firstOfRoot;      // a rank has ONE local point per mesh point: two of them in one component mean the
+                                              // patches do not pair up the way globalPoints assumes (rotated faces, stale processorN data)
     for (int32_t p = 0; p < K.mesh.nPoints(); ++p) {
         Node root(r, (int64_t)p);
-        if (parent.count(root)) root = find(root);
+        if (parent.count(root)) {
+            root = find(root);
+            const auto ins = firstOfRoot.emplace(root, p);
+            if (!ins.second)
+                return "processor patches of rank " + std::to_string(r) + ": local points " + std::to_string(ins.first->second) + " and " + std::to_string(p) +
+                       " are matched to the same shared point (faces of a processor patch pair are not in corresponding order)";
+        }
         K.pointProc[(size_t)p] = ((int64_t)root.first << 40) | root.second;
+    }
+    return "";
+}
+
+// The coordinates behind processorPatchFaces, in the same order (three doubles per listed vertex) ...
+std::vector<double> processorPatchCoords(const Rank& K) {
+    std::vector<double> out;
+    const auto& m = K.mesh;
+    for (const auto& p : m.patches)
+        if (p.type == "processor")
+            for (int32_t f = p.startFace; f < p.startFace + p.nFaces; ++f)
+                for (int32_t k = m.faceOffsets[f]; k < m.faceOffsets[f + 1]; ++k)
+                    for (int c = 0; c < 3; ++c) out.push_back(m.points[3 * (size_t)m.facePoints[k] + (size_t)c]);
+    return out;
+}
+// ... and the check nothing else makes: face i of rank a's patch to b is face i of b's patch to a reversed about its first vertex
+// (OpenFOAM's processorPolyPatch convention, what globalPoints and labelsFromPatches rely on), so the matched vertices must
+// coincide -- within OpenFOAM's own matchTolerance (1e-4 of the face's extent).  A patch pair with rotated faces or processorN
+// directories from two different decompositions would otherwise give wrong halo tables without a word.
+std::string checkProcessorPatchCoords(int r, int n, const std::vector<std::vector<int64_t>>& faces, const std::vector<std::vector<double>>& coords) {
+    struct Rec { size_t at, co; };                                    // per face: start of its {n, ids...} record / of its coordinates
+    std::vector<std::map<int, std::vector<Rec>>> patch((size_t)n);
+    for (int o = 0; o < n; ++o) {
+        const auto& v = faces[(size_t)o];
+        size_t co = 0;
+        for (size_t k = 0; k + 1 < v.size();) {
+            const int nb = (int)v[k]; const int64_t nF = v[k + 1];
+            k += 2;
+            auto& pf = patch[(size_t)o][nb];
+            for (int64_t f = 0; f < nF; ++f) { pf.push_back(Rec{k, co}); co += 3 * (size_t)v[k]; k += 1 + (size_t)v[k]; }
+        }
+        if (co != coords[(size_t)o].size()) return "processor patch coordinates of rank " + std::to_string(o) + " do not match its face list";
+    }
+    for (const auto& kv : patch[(size_t)r]) {
+        const int b = kv.first;
+        if (b < 0 || b >= n) return "processor patch to a rank that does not exist";
+        const auto it = patch[(size_t)b].find(r);
+        if (it == patch[(size_t)b].end() || it->second.size() != kv.second.size())
+            return "processor patches " + std::to_string(r) + " <-> " + std::to_string(b) + " do not match";
+        for (size_t f = 0; f < kv.second.size(); ++f) {
+            const int64_t nv = faces[(size_t)r][kv.second[f].at];
+            if (faces[(size_t)b][it->second[f].at] != nv) return "processor patches " + std::to_string(r) + " <-> " + std::to_string(b) + ": face sizes differ";
+            const double* xa = &coords[(size_t)r][kv.second[f].co];
+            const double* xb = &coords[(size_t)b][it->second[f].co];
+            double ext = 0.0;
+            for (int64_t k = 1; k < nv; ++k) {
+                double d2 = 0.0;
+                for (int c = 0; c < 3; ++c) { const double d = xa[3 * k + c] - xa[c]; d2 += d * d; }
+                ext = std::max(ext, std::sqrt(d2));
+            }
+            for (int64_t k = 0; k < nv; ++k) {
+                const int64_t kb = (nv - k) % nv;
+                double d2 = 0.0;
+                for (int c = 0; c < 3; ++c) { const double d = xa[3 * k + c] - xb[3 * kb + c]; d2 += d * d; }
+                if (!(std::sqrt(d2) <= 1e-4 * ext))
+                    return "processor patches " + std::to_string(r) + " <-> " + std::to_string(b) + ": face " + std::to_string(f) + " vertex " + std::to_string(k) +
+                           " lies " + std::to_string(std::sqrt(d2)) + " away from its copy on the other side (face extent " + std::to_string(ext) +
+                           "): the two sides are not in corresponding order, or the processor directories are not from one decomposition";
+            }
+        }
     }
     return "";
 }
@@ -687,12 +755,21 @@ int main(int argc, char** argv) {
     for (Rank& K : R) check(smgpu_set_params(K.h, &prm), "smgpu_set_params");
     std::vector<std::vector<int64_t>> sharedGlobalOf;   // every rank's shared points (global ids, ascending): the set-up syncs
     if (opt.parallel) {
+        // the copies of a point across a processorCyclic patch are not one point (their positions differ by the patch transform):
+        // nothing here transforms positions or sums, so such a case is refused instead of being coupled wrongly or not at all
+        for (const auto& p : K0.mesh.patches)
+            if (p.type == "processorCyclic") fatal("patch " + p.name + " is a processorCyclic patch: cyclic coupling between sub-domains is not supported");
         {   // every rank must take the same route: by global ids only if ALL of them have the file
             const auto have = g_comm.allgatherVec(std::vector<int>(1, K0.pointProc.empty() ? 0 : 1));
             bool all = true;
             for (const auto& h : have) all = all && h[0];
+            const auto allFaces = g_comm.allgatherVec(processorPatchFaces(K0));
+            {   // either route assumes that the two sides of a processor patch pair list their faces in corresponding order
+                const std::string err = checkProcessorPatchCoords(myRank, nRanks, allFaces, g_comm.allgatherVec(processorPatchCoords(K0)));
+                if (!err.empty()) fatal(err);
+            }
             if (!all) {
-                const std::string err = labelsFromPatches(K0, myRank, nRanks, g_comm.allgatherVec(processorPatchFaces(K0)));
+                const std::string err = labelsFromPatches(K0, myRank, nRanks, allFaces);
                 if (!err.empty()) fatal(err);
                 if (myRank == 0) OUT("Shared points matched through the processor patches (no pointProcAddressing)\n\n");
             }

@@ -86,15 +86,18 @@ struct PushWait { const unsigned* localFlag; int nPeers; int kind; unsigned tag;
 // records, this rank's flag goes up at every peer.  Order: every wave drains its (write-through) stores, the workgroup meets,
 // one lane takes a ticket; the workgroup that draws the last ticket resets the counter for the next launch and stores the
 // flags (system scope).
-__device__ __forceinline__ void pushSignal(const PushView& pv, int kind, unsigned tag) {
+// nBlocks: the workgroups of the launch that call this (default: all of them; a launch whose workgroups play several roles
+// passes the size of the producing role)
+__device__ __forceinline__ void pushSignal(const PushView& pv, int kind, unsigned tag, unsigned nBlocks = 0) {
     if (!pv.ticket) return;
+    if (nBlocks == 0) nBlocks = gridDim.x;
     __shared__ int lastWg;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
         if (pv.fence) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, ""); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
         const unsigned t = __hip_atomic_fetch_add(&pv.ticket[kind], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        lastWg = (t == gridDim.x - 1) ? 1 : 0;
+        lastWg = (t == nBlocks - 1) ? 1 : 0;
     }
     __syncthreads();
     if (!lastWg) return;
@@ -128,6 +131,70 @@ __device__ __forceinline__ void pushWait(const PushWait& pw) {
     __syncthreads();
 }
 
+// ---- dependencies BETWEEN the workgroups of one launch (kernels whose workgroups play several roles, kernels_tiled.hpp) ----
+// A record written by one workgroup and read by another of the same launch, possibly on another XCD (each XCD has its own L2,
+// and nothing snoops between them inside a kernel): stored and loaded with agent-scope accesses (sc1: the store goes through to
+// memory, the load does not trust a line of the local L2), 8 bytes at a time.  An agent-scope release FENCE would do for plain
+// stores, but it is a write-back of everything dirty in the XCD's L2, per producing workgroup.
+__device__ __forceinline__ void stCoh(double* p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ldCoh(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ V3 ldvCoh(const double* base, int i) {
+    const double* p = base + 3 * (size_t)i;
+    return v3(ldCoh(p), ldCoh(p + 1), ldCoh(p + 2));
+}
+__device__ __forceinline__ void stvCoh(double* base, int i, const V3& v) {
+    double* p = base + 3 * (size_t)i;
+    stCoh(p, v.x); stCoh(p + 1, v.y); stCoh(p + 2, v.z);
+}
+// "the producing role's workgroups are done".  Counters and flag are monotone (no reset between launches: targets are multiples of
+// the launch's serial number).  The producers COUNT -- on a counter per XCD (eight words on eight cache lines: a returning atomic
+// on one word runs at ~90 per microsecond chip-wide, 900 arrivals on one word are 10 us), the last arrival of an XCD on a second
+// level, the last of those raises the FLAG word -- and the consumers poll the flag with plain agent-scope loads.  (First version:
+// consumers polling the counter itself.  275 polling workgroups and 900 arrivals on one word: the arrivals queued behind the
+// polls, the count reached its target ~30 us late.)
+// Producer side: called by every thread of the workgroup after its coherent stores; consumer side: by every thread before its
+// coherent loads (bounded wait: a role order the hardware does not dispatch in -- or a device shared with other engines' spinning
+// launches -- raises Accum::err instead of hanging).
+constexpr int ROLE_ERR_TIMEOUT = 7;   // Accum::err: a role of a multi-role launch waited for an earlier role for too long
+constexpr int kRoleStride = 32;       // unsigned words between two counters (128 bytes)
+constexpr int kRoleWords = 10 * kRoleStride;   // [0..7] per-XCD arrivals, [8] XCDs done, [9] flag
+// nPerXcd: producing workgroups per XCD (the role's workgroup count is a multiple of 8 and starts at a multiple of 8)
+__device__ __forceinline__ void roleDone(unsigned* tk, unsigned serial, unsigned nPerXcd) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = __hip_atomic_fetch_add(tk + (blockIdx.x & 7u) * kRoleStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a + 1u == serial * nPerXcd) {
+            const unsigned b = __hip_atomic_fetch_add(tk + 8 * kRoleStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (b + 1u == serial * 8u) __hip_atomic_store(tk + 9 * kRoleStride, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+// a role of a few workgroups anywhere in the grid: one counter ([8]), then the flag
+__device__ __forceinline__ void roleDoneSmall(unsigned* tk, unsigned serial, unsigned nBlocks) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned b = __hip_atomic_fetch_add(tk + 8 * kRoleStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b + 1u == serial * nBlocks) __hip_atomic_store(tk + 9 * kRoleStride, serial, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+__device__ __forceinline__ void roleWait(const unsigned* tk, unsigned serial, int* err) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        unsigned spins = 0;
+        while ((int)(__hip_atomic_load(tk + 9 * kRoleStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - serial) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if ((++spins & 63u) == 0u && __builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) { *err = ROLE_ERR_TIMEOUT; break; }   // 2 s
+        }
+    }
+    __syncthreads();
+}
+
 struct State {
     double* ptsCur; double* ptsNext; double* prop;
     double* stepSqr;   // != NULL: the proposal kernel leaves |proposal - current|^2 per point for k_apply_swap
@@ -145,6 +212,11 @@ struct State {
     double* blkMax; int* blkCnt;   // per-workgroup partials of (max step, frozen count); reduced by k_finish
     smgpu_iter_stats* stats;
     const int* sharedSlot;     // multi-rank: per point slot into combA, or -1 (NULL on one rank)
+    const int* posSlot;        // ... the same per smoothing-tile POSITION (k_smooth_halo: the regular tiles skip the shared points)
+    // the shared points' OWN tiles (smgpu_halo_configure: SmoothTiles over the shared points only), per tile position: the point's
+    // slot, the two-sharer point's peer code (the other rank's receive slot | this rank is the lower one << 30) or -1, its
+    // number of send slots and the first of them (most shared points have one: no walk through sendOff / sendSlots)
+    const int* spSlot; const int* spPeer; const int* spDst0; const int* spNDst;
     const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
     // multi-rank, tiled kernels: a point with TWO sharers (nearly all shared points) is combined by the smoothing kernel
     // itself from the own and the received record (inlineCombine), and its freeze flag goes straight to its send slots
@@ -1297,12 +1369,64 @@ __device__ __forceinline__ void combineTwoSharers(const double* ra, const double
     anyCommon = hcA | hcB;
 }
 
+// The same three syncs written for few live registers (k_smooth_halo combines inside the smoothing launch, where the kernel's
+// register count is the maximum over all roles): what a rank's state needs from an earlier step is a decision bit, and the
+// vectors come from memory again when a step asks for them -- at most two vectors of each rank are live at a time, every final
+// value is stored as soon as it stands.  Same operations on the same operands as combineTwoSharers, hence the same bits
+// (tests/test_gpu_multirank.py runs both forms against the oracle, the tie cases included).
+__device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra, const double* __restrict__ rb, bool selfFirst, int ownFold,
+                                                   double* __restrict__ o) {
+    auto ld3 = [](const double* p) { return v3(p[0], p[1], p[2]); };
+    auto pick = [](bool c, const V3& x, const V3& y) { return v3(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z); };
+    {   // plusEqOp, ascending rank
+        const V3 sa = ld3(ra), sb = ld3(rb);
+        const V3 sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;
+        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
+    }
+    const bool aLeads = ownFold || selfFirst, bLeads = ownFold || !selfFirst;
+#define SMGPU_FOLD2(X, Y) pick(magSqr(X) <= magSqr(Y), (X), (Y))
+    bool dA1, dB1, dA2, dB2;
+    V3 a2, b2;      // the ranks' (updated) second vectors
+    {   // SM.C:397-419
+        const V3 a1 = ld3(ra + 3), b1 = ld3(rb + 3);
+        const V3 fab = SMGPU_FOLD2(a1, b1), fba = SMGPU_FOLD2(b1, a1);
+        const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
+        dA1 = isCloserPoint(svA, a1); dB1 = isCloserPoint(svB, b1);
+        const V3 f1 = pick(dA1, svA, a1);
+        o[3] = f1.x; o[4] = f1.y; o[5] = f1.z;
+        a2 = pick(dA1, a1, ld3(ra + 6));
+        b2 = pick(dB1, b1, ld3(rb + 6));
+    }
+    V3 a3, b3;      // ... third vectors
+    {   // SM.C:424-445
+        const V3 fab = SMGPU_FOLD2(a2, b2), fba = SMGPU_FOLD2(b2, a2);
+        const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
+        dA2 = isCloserPoint(svA, a2); dB2 = isCloserPoint(svB, b2);
+        const V3 f2 = pick(dA2, svA, a2);
+        o[6] = f2.x; o[7] = f2.y; o[8] = f2.z;
+        // the third vector before this step: the original second one if the first step shifted, else the original third one
+        a3 = pick(dA2, a2, ld3(ra + (dA1 ? 6 : 9)));
+        b3 = pick(dB2, b2, ld3(rb + (dB1 ? 6 : 9)));
+    }
+    {   // SM.C:450-469
+        const V3 svA = pick(aLeads, SMGPU_FOLD2(a3, b3), SMGPU_FOLD2(b3, a3));
+        const V3 f3 = pick(isCloserPoint(svA, a3), svA, a3);
+        o[9] = f3.x; o[10] = f3.y; o[11] = f3.z;
+    }
+#undef SMGPU_FOLD2
+    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
+    const int cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
+    const int hcA = (dA1 || dA2) ? 0 : (int)(pa >> 32), hcB = (dB1 || dB2) ? 0 : (int)(pb >> 32);
+    o[12] = __longlong_as_double(((long long)(hcA | hcB) << 32) | (long long)(unsigned int)cnt);
+}
+
 constexpr int kMaxSharers = 16;
 
 // k_halo_combineA for the usual case (no point with more than 16 sharers): the two-sharer points from a per-point table of
 // the other rank's receive slot (bit 30: this rank is the lower one; -1: not a two-sharer point) -- offset -> slot -> record
 // was three dependent loads, this is two -- and the points with more sharers in the trailing workgroups.  No per-sharer
 // arrays here, so the kernel needs no scratch memory.
+template <bool COH = false>
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
                                              const double* ownA, const double* recvA, double* combA, int ownFold);
 __device__ __forceinline__ void haloCombineA2Of(int bx, int nShared, const int* __restrict__ peer, const double* __restrict__ ownA,
@@ -1342,8 +1466,6 @@ __global__ void __launch_bounds__(kBlock, 2) k_halo_combineA2(int nShared, const
 // sharer receives that result (ties keep the lower rank's vector) -- or, ownFold, from each sharer's own value.
 // Points with more than two sharers (processor edges and corners: few) are left to combineMulti when skipMulti
 // is set: their per-sharer arrays live in scratch memory and a single lane walking them cost ~70 us per launch.
-__device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
-                                             const double* ownA, const double* recvA, double* combA, int ownFold);
 // The workgroups after the first nBlocksTwo handle the listed points with more than two sharers (combineMulti): one launch,
 // so that the latency of that small, dependent-load-bound part overlaps with the two-sharer part.
 __global__ void __launch_bounds__(kBlock, 2) k_halo_combineA(int nShared, const int* combOff, const int* combSlots,
@@ -1434,6 +1556,8 @@ __global__ void __launch_bounds__(kBlock, 2) k_halo_combineA(int nShared, const 
 // measured ~4x slower here).  multiIdx lists those points.
 // multiSlots: 16 entries per listed point -- the recv slot of sharer j, -1 = this rank, -2 = no such sharer (one coalesced
 // load instead of the multiIdx -> combOff -> combSlots chain: this part is a handful of workgroups and latency bound)
+// COH: the combined record is read by other workgroups of the SAME launch (k_smooth_halo): coherent stores
+template <bool COH>
 __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* multiIdx, const int* multiSlots,
                                              const double* ownA, const double* recvA, double* combA, int ownFold) {
     // 16 lanes per point, lane j = sharer j (ascending rank); the sharers' values travel by shuffles within the group -- no
@@ -1487,11 +1611,10 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
     for (int k = 0; k < n; ++k) any |= __shfl(hc, base + k, 64);
     if (mine && sl < 0) {
         double* o = combA + (size_t)i * SMGPU_HALO_A_DOUBLES;
-        o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
-        o[3] = r1.x; o[4] = r1.y; o[5] = r1.z;
-        o[6] = r2.x; o[7] = r2.y; o[8] = r2.z;
-        o[9] = r3.x; o[10] = r3.y; o[11] = r3.z;
-        o[12] = __longlong_as_double(((long long)any << 32) | (long long)(unsigned int)cnt);
+        const double rec[SMGPU_HALO_A_DOUBLES] = {sum.x, sum.y, sum.z, r1.x, r1.y, r1.z, r2.x, r2.y, r2.z, r3.x, r3.y, r3.z,
+                                                  __longlong_as_double(((long long)any << 32) | (long long)(unsigned int)cnt)};
+#pragma unroll
+        for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) { if (COH) stCoh(o + q, rec[q]); else o[q] = rec[q]; }
     }
 }
 

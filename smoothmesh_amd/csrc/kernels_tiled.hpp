@@ -61,7 +61,7 @@ __device__ __forceinline__ int launchTile(int n, int xcdMap, int b = (int)blockI
     const int i = (b & 7) * per + (b >> 3);
     return i < n ? i : -1;
 }
-inline int tileGrid(int n, int xcdMap) { return xcdMap ? ((n + 7) >> 3) << 3 : n; }
+__host__ __device__ inline int tileGrid(int n, int xcdMap) { return xcdMap ? ((n + 7) >> 3) << 3 : n; }
 
 __device__ __forceinline__ V3 ldsv(const double* x, const double* y, const double* z, int i) { return v3(x[i], y[i], z[i]); }
 
@@ -178,6 +178,12 @@ __device__ __forceinline__ void stageRecordsPair(const double* __restrict__ s1, 
             if (id[u] >= 0) { x1[i] = va[u].x; y1[i] = va[u].y; z1[i] = va[u].z; x2[i] = vb[u].x; y2[i] = vb[u].y; z2[i] = vb[u].z; }
         }
     }
+}
+
+// records written by other workgroups of the same launch (tiles beyond the fixed staging rounds: rare, plain loop)
+template <int T>
+__device__ __forceinline__ void stageRecordsCoh(const double* src, const int* __restrict__ ids, int n, double* x, double* y, double* z, int tid) {
+    for (int i = tid; i < n; i += T) { const V3 v = ldvCoh(src, ids[i]); x[i] = v.x; y[i] = v.y; z[i] = v.z; }
 }
 
 // Cell centres of the current coordinates for one tile of consecutive cells:
@@ -383,8 +389,13 @@ __device__ __forceinline__ GeomCellIn geomCellLoad(const GeomTileView& g, const 
     }
     return in;
 }
+// coh (workgroup-uniform): the cell centre is read by another workgroup of the SAME launch (the pack role of k_geom_halo):
+// coherent store.  A run-time flag, not a template parameter: k_geom_halo must hold ONE copy of this code (41 KB; with three
+// inlined copies the kernel was 135 KB against a 64 KB instruction cache, and roles running side by side on a CU evicted each
+// other's code: 92 us for geometry + pack instead of 51 + 23)
 template <int T, bool ORG>
-__device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, const GeomTileMeta& tm, int tid, unsigned tflags, const GeomCellIn& in) {
+__device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, const GeomLds& L, const GeomTileMeta& tm, int tid, unsigned tflags, const GeomCellIn& in,
+                                         bool coh = false) {
     const double *fcx = L.fcx, *fcy = L.fcy, *fcz = L.fcz, *fax = L.fax, *fay = L.fay, *faz = L.faz;
     if (!in.mine) return;
     const int c = in.c;
@@ -429,7 +440,7 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 #undef SMGPU_PYR
     if (fabs(vol) > SMGPU_VSMALL) ctr = divExact(ctr, vol);
     else ctr = cEst;
-    stv(s.cellCtr, c, ctr);
+    if (coh) stvCoh(s.cellCtr, c, ctr); else stv(s.cellCtr, c, ctr);
 }
 
 // deferN > 0: the first workgroup also closes the PREVIOUS iteration (reduction of its deferN workgroup partials into
@@ -496,7 +507,7 @@ __device__ __forceinline__ void geomFaces(const State& s, const GeomTileView& g,
 // flight at once was built and measured: no gain on hex meshes, 17 % slower on the polyhedral one -- DESIGN 9.)
 template <int T, bool ORG>
 __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, const GeomTileView& g, int wantAvg, int writeFaces, const int* tileList,
-                                             int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal, double* deferHist, int bid) {
+                                             int nLaunch, int xcdMap, int deferN, int deferIter, double* deferLocal, double* deferHist, int bid, bool coh = false) {
     // the "loop has stopped" flag (relTol reached, SM.C:2401) is tested after the staging: a dependent global load in front of
     // everything else put its latency on every workgroup's critical path; a stopped run stages one tile in vain
     const int stopped = s.acc->stop;
@@ -518,7 +529,7 @@ __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, 
     __syncthreads();
     geomFaces<T, ORG>(s, g, L, tm, r, tid, wantAvg, writeFaces);  // phase 1: every face of the tile once
     __syncthreads();
-    geomCell<T, ORG>(s, g, L, tm, tid, (unsigned)tm.flags, r.cin);   // phase 2: one thread per cell
+    geomCell<T, ORG>(s, g, L, tm, tid, (unsigned)tm.flags, r.cin, coh);   // phase 2: one thread per cell
 }
 template <int T, bool ORG>
 __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(MeshView m, State s, GeomTileView g, int wantAvg, int writeFaces, const int* tileList,
@@ -542,6 +553,7 @@ __device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileView
 }
 struct SmoothRow {
     bool mine; int p, selfL, wn4, wc4, slot;
+    int peer, dst0, ndst;  // shared-point tiles: the two-sharer point's peer code (State::spPeer) or -1, first send slot, send slots
     unsigned fl;
     const ushort4 *ppRow, *pcRow;
     ushort4 pp0, pp1, pc0, pc1;
@@ -563,10 +575,16 @@ __device__ __forceinline__ unsigned pairBits(const SmoothTileView& g, const Smoo
 // LDS slot and first two chunks of both ELL rows; (2) the records, the point's flags and its shared-point slot.  No branch
 // between the loads of a round (lanes without a point read the row of lane 0): conditional loads made the compiler wait for
 // each of them separately -- eight round trips per tile before.
-template <int T>
+// COHC: the cell centres were written by other workgroups of the SAME launch (pack role of k_geom_halo): coherent loads.
+// SLOTS: where a point's shared-point slot comes from -- 0: nowhere (a tile without shared points), 1: State::sharedSlot[p]
+// (a load that depends on the point id: second round), 2: tables by tile position (first round): `tb`, the shared points' own
+// tiles (State::spSlot / spPeer / spDst0 / spNDst) or the regular tiles of k_smooth_halo (State::posSlot only)
+struct SlotTabs { const int* slot; const int* peer; const int* dst0; const int* ndst; };
+template <int T, bool COHC = false, int SLOTS = 1>
 __device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State& s, const SmoothTileView& g, const SmoothTileMeta& tm,
-                                                 const SmoothLds& L, int tid) {
+                                                 const SmoothLds& L, int tid, const SlotTabs& tb = SlotTabs{nullptr, nullptr, nullptr, nullptr}) {
     SmoothRow r;
+    r.peer = -1; r.dst0 = -1; r.ndst = 0;
     r.mine = tid < tm.nPts;
     r.wn4 = tm.ppWidth >> 2; r.wc4 = tm.pcWidth >> 2;
     const int lane = r.mine ? tid : 0;
@@ -590,20 +608,22 @@ __device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State&
         const ushort4 pp0 = ppl[0], pp1 = ppl[r.wn4 > 1 ? T : 0], pc0 = pcl[0], pc1 = pcl[r.wc4 > 1 ? T : 0];
         const ushort4* pel = reinterpret_cast<const ushort4*>((g.usePairShare ? g.pairEll : g.ppEll) + tm.ppBase) + lane;
         r.pe0 = pel[0]; r.pe1 = pel[r.wn4 > 1 ? T : 0];
+        int slot = -1, peer = -1, dst0 = -1, ndst = 0;
+        if (SLOTS == 2) { slot = tb.slot[pi]; if (tb.peer) { peer = tb.peer[pi]; dst0 = tb.dst0[pi]; ndst = tb.ndst[pi]; } }
         // round 2
         V3 va[2], vb[3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) va[u] = (a[u] >= 0) ? ldv(s.cellCtr, a[u]) : v3(0, 0, 0);
+        for (int u = 0; u < 2; ++u) va[u] = (a[u] >= 0) ? (COHC ? ldvCoh(s.cellCtr, a[u]) : ldv(s.cellCtr, a[u])) : v3(0, 0, 0);
 #pragma unroll
         for (int u = 0; u < 3; ++u) vb[u] = (b[u] >= 0) ? ldv(s.ptsCur, b[u]) : v3(0, 0, 0);
         const unsigned fl = m.pflags[p];
-        const int slot = s.sharedSlot ? s.sharedSlot[p] : -1;
+        if (SLOTS == 1) slot = s.sharedSlot ? s.sharedSlot[p] : -1;
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const int i = u * T + tid; if (a[u] >= 0) { L.cx[i] = va[u].x; L.cy[i] = va[u].y; L.cz[i] = va[u].z; } }
 #pragma unroll
         for (int u = 0; u < 3; ++u) { const int i = u * T + tid; if (b[u] >= 0) { L.nx[i] = vb[u].x; L.ny[i] = vb[u].y; L.nz[i] = vb[u].z; } }
         r.p = r.mine ? p : 0; r.selfL = r.mine ? selfL : 0;
-        r.fl = fl; r.slot = r.mine ? slot : -1;
+        r.fl = fl; r.slot = r.mine ? slot : -1; r.peer = r.mine ? peer : -1; r.dst0 = dst0; r.ndst = r.mine ? ndst : 0;
         r.pp0 = r.mine ? pp0 : padq; r.pp1 = (r.mine && r.wn4 > 1) ? pp1 : padq;
         r.pc0 = r.mine ? pc0 : padq; r.pc1 = (r.mine && r.wc4 > 1) ? pc1 : padq;
         return r;
@@ -625,23 +645,30 @@ __device__ __forceinline__ SmoothRow smoothStage(const MeshView& m, const State&
         if (r.wc4 > 0) r.pc0 = r.pcRow[0];
         if (r.wc4 > 1) r.pc1 = r.pcRow[T];
         r.fl = m.pflags[r.p];
-        r.slot = s.sharedSlot ? s.sharedSlot[r.p] : -1;
+        if (SLOTS == 1) r.slot = s.sharedSlot ? s.sharedSlot[r.p] : -1;
+        if (SLOTS == 2) { r.slot = tb.slot[pi]; if (tb.peer) { r.peer = tb.peer[pi]; r.dst0 = tb.dst0[pi]; r.ndst = tb.ndst[pi]; } }
     }
-    stageRecords<T, 2>(s.cellCtr, g.tcIds + tm.tcOff, tm.nCells, L.cx, L.cy, L.cz, tid);
+    if (COHC) stageRecordsCoh<T>(s.cellCtr, g.tcIds + tm.tcOff, tm.nCells, L.cx, L.cy, L.cz, tid);
+    else stageRecords<T, 2>(s.cellCtr, g.tcIds + tm.tcOff, tm.nCells, L.cx, L.cy, L.cz, tid);
     stageRecords<T, 3>(s.ptsCur, g.tnIds + tm.tnOff, tm.nNbrs, L.nx, L.ny, L.nz, tid);
     return r;
 }
 
 // the thread's point of the tile, from the staged cell centres / neighbour coordinates (see k_smooth for the steps)
-template <bool FINAL, int T>
+// MODE 0: a shared point's combined record comes from State::combA (k_halo_combineA*); 1: the tile holds no shared point;
+// 2 (k_smooth_halo; ONE copy of the code for both kinds of tiles, see geomCell) -- spTile, the shared points' own tiles: the
+// combined record of a two-sharer point was left in combA by THIS thread before the staging (plain load), that of a point with
+// more sharers by the launch's first workgroups (coherent loads), and the freeze flag goes straight to its send slots (exchange
+// F, SM.C:2374); !spTile, the regular tiles: shared points are skipped -- their own tiles do them
+template <bool FINAL, int T, int MODE = 0>
 __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, const Prm& prm, const SmoothTileView& g, const SmoothLds& L,
-                                            const SmoothRow& R, const SmoothTileMeta& tm, int tid, double& dist, int& fcount) {
+                                            const SmoothRow& R, const SmoothTileMeta& tm, int tid, double& dist, int& fcount, bool spTile = false) {
     const double *cx = L.cx, *cy = L.cy, *cz = L.cz, *nx = L.nx, *ny = L.ny, *nz = L.nz;
     const bool mine = R.mine;
     const int p = R.p, selfL = R.selfL, wn4 = R.wn4, wc4 = R.wc4;
     const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
     const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
-    if (mine) {
+    if (mine && !(MODE == 2 && !spTile && R.slot >= 0)) {
         const unsigned fl = R.fl;
         const bool internal = fl & PF_INTERNAL;
         const V3 cur = ldsv(nx, ny, nz, selfL);
@@ -649,7 +676,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         double m1 = 0.0, m2 = 0.0, m3 = 0.0;   // mag(closestPoint1..3), SM.C:509-510
         int count = 0, hc = 0;
         double shortestCur = SMGPU_GREAT;   // SM.C:621; min over ALL neighbours of the current edge lengths
-        const int slot = R.slot;
+        const int slot = (MODE == 1 || (MODE == 2 && !spTile)) ? -1 : R.slot;
         if (slot >= 0) {
             // (the combined record of the shared point, left by k_halo_combineA*.  Combining two-sharer points HERE from the own and
             // the received record was a knob until round 4 -- SMGPU_HALO_INLINE, measured slower in round 2 -- and is gone: its inlined
@@ -657,9 +684,12 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             // 97 + spills (4) with the master fold's two selects per sync -- 34.1 / 36.7 / 43.9 us per launch on 100^3)
             {
                 const double* r = s.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
-                sum = v3(r[0], r[1], r[2]);
-                r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);
-                const long long pk = __double_as_longlong(r[12]);
+                double w[SMGPU_HALO_A_DOUBLES];
+#pragma unroll
+                for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) w[q] = (MODE == 2 && R.peer < 0) ? ldCoh(r + q) : r[q];
+                sum = v3(w[0], w[1], w[2]);
+                r1 = v3(w[3], w[4], w[5]); r2 = v3(w[6], w[7], w[8]); r3 = v3(w[9], w[10], w[11]);
+                const long long pk = __double_as_longlong(w[12]);
                 count = (int)(pk & 0xffffffffll);
                 hc = (int)(pk >> 32);
             }
@@ -748,7 +778,15 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             // k_shared_fix finishes it after exchange F
             stv(s.prop, p, np);
             s.frozen[p] = frozen ? 1 : 0;
-            if (s.inlinePackF)
+            if (MODE == 2) {                                                     // exchange F, SM.C:2374
+                const int v = frozen ? 1 : 0;
+                if (R.ndst == 1) { if (s.push.slotF) stPeer(s.push.slotF[R.dst0], v); else s.sendF[R.dst0] = v; }
+                else
+                    for (int k = s.sendOff[slot]; k < s.sendOff[slot + 1]; ++k) {
+                        const int sl = s.sendSlots[k];
+                        if (s.push.slotF) stPeer(s.push.slotF[sl], v); else s.sendF[sl] = v;
+                    }
+            } else if (s.inlinePackF)
                 for (int k = s.sendOff[slot]; k < s.sendOff[slot + 1]; ++k) s.sendF[s.sendSlots[k]] = frozen ? 1 : 0;   // exchange F, SM.C:2374
         } else if (FINAL) {
             if (frozen || (!internal && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
@@ -790,16 +828,18 @@ struct PackView {
     int centroidAll;            // boundary point smoothing: boundary points gather cell centres too (SM.C:116)
 };
 // (the first nLBlocks workgroups, a multiple of 8, pack exchange L's records instead -- k_halo_packL's work without its launch)
-template <int T>
+// bid: the workgroup's index among the pack workgroups; COHC: see smoothStage (pack role of k_geom_halo); SP: g = the shared
+// points' own tiles (every point of a tile is a shared point; slots and first send slot by tile position)
+template <int T, bool COHC = false, bool SP = false>
 __device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, const SmoothTileView& g, const PackView& pk, const int* tileList, int nLaunch,
-                                             int xcdMap, int nLBlocks) {
-    const int li = launchTile(nLaunch, xcdMap, (int)blockIdx.x - nLBlocks);
+                                             int xcdMap, int bid) {
+    const int li = launchTile(nLaunch, xcdMap, bid);
     if (li < 0) return;
     extern __shared__ double lds[];
     const SmoothLds L = smoothLds(lds, g);
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
     const SmoothTileMeta tm = loadTileMeta(g, tile);
-    const SmoothRow R = smoothStage<T>(m, s, g, tm, L, tid);
+    const SmoothRow R = smoothStage<T, COHC, SP ? 2 : 1>(m, s, g, tm, L, tid, SlotTabs{s.spSlot, s.spPeer, s.spDst0, s.spNDst});
     __syncthreads();
     if (!R.mine) return;
     const int p = R.p;
@@ -851,12 +891,14 @@ __device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, 
     double* o = pk.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES;
 #pragma unroll
     for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) o[q] = rec[q];
-    for (int k = pk.sendOff[slot]; k < pk.sendOff[slot + 1]; ++k) {
+    const int kBeg = (SP && R.ndst == 1) ? 0 : pk.sendOff[slot], kEnd = (SP && R.ndst == 1) ? 1 : pk.sendOff[slot + 1];
+    for (int k = kBeg; k < kEnd; ++k) {
+        const int sl = (SP && R.ndst == 1) ? R.dst0 : pk.sendSlots[k];
         // the record goes where it is consumed: the peer's receive slot with the peer-store transport, else the send buffer
         if (s.push.slotA) {
             // 13 doubles = 104 bytes: every other slot starts 8 bytes off a 16-byte boundary -- six 16-byte stores and one
             // 8-byte store either way
-            double* d = s.push.slotA[pk.sendSlots[k]];
+            double* d = s.push.slotA[sl];
             if (((size_t)d & 8u) == 0) {
 #pragma unroll
                 for (int q = 0; q < 12; q += 2) stPeer2(d + q, rec[q], rec[q + 1]);
@@ -868,7 +910,7 @@ __device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, 
             }
             continue;
         }
-        double* d = pk.sendA + (size_t)pk.sendSlots[k] * SMGPU_HALO_A_DOUBLES;
+        double* d = pk.sendA + (size_t)sl * SMGPU_HALO_A_DOUBLES;
 #pragma unroll
         for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) d[q] = rec[q];
     }
@@ -878,8 +920,104 @@ __global__ void __launch_bounds__(T) k_pack_tile(MeshView m, State s, SmoothTile
                                                   int xcdMap, PackLArgs la, int nLBlocks, unsigned tag) {
     if (s.acc->stop) return;
     if ((int)blockIdx.x < nLBlocks) haloPackLOf(s, la, (int)blockIdx.x * T + (int)threadIdx.x);
-    else packTileBody<T>(m, s, g, pk, tileList, nLaunch, xcdMap, nLBlocks);
+    else packTileBody<T>(m, s, g, pk, tileList, nLaunch, xcdMap, (int)blockIdx.x - nLBlocks);
     pushSignal(s.push, 0, tag);      // exchange A and L leave together (no-op without the peer-store transport)
+}
+
+// ---- multi-rank, constraints off: launches whose workgroups play several roles ---------------------------------------------------
+// One rank of a decomposed run did, per iteration, geometry | pack | [exchange A] | combine | smoothing | packF | [exchange F] |
+// shared-fix: four of the six kernels are small and latency bound (one rank of eight on 100^3: 143-153 us against 101 us for the
+// same sub-domain alone).  Here the iteration is geometry+pack | [A] | combine+smoothing+packF | [F] | shared-fix, and all the
+// halo work runs on tiles of the SHARED POINTS ONLY (State::sp*, smgpu_halo_configure: ~110 shared points per tile instead of the
+// ~40 a regular smoothing tile near a processor patch holds -- a third of the workgroups and of the staging):
+//  * k_geom_halo: [the geometry tiles with a shared point: coherent stores of their cell centres, one ticket per workgroup]
+//    [a first batch of the other geometry tiles] [the pack role on the shared points' tiles: waits for the ticket count, stages
+//    the cell centres with coherent loads] [the rest of the geometry tiles];
+//  * k_smooth_halo: [combine of the points with more than two sharers, 16 lanes per point] [the shared points' tiles: wait for the
+//    peers' records where the transport needs it, two-sharer points combined by their own thread, freeze flags straight into the
+//    send slots / the peers' receive slots] [ALL regular tiles, skipping their shared points: no dependence on the exchange].
+// A halo workgroup is a chain of ~10 dependent round trips: at the tail of a launch it costs its full length (first version,
+// measured: 74 + 50 us against 51 + 40 us for the plain kernels), in front of the bulk it runs next to it -- but every such
+// workgroup holds a slot sized for the launch's fattest role, so there must be few of them (770 pack workgroups on the regular
+// tiles in second place: 111 us).
+// Workgroups are dispatched in index order per XCD, so a role only ever waits for workgroups that were dispatched before it;
+// every wait is bounded (roleWait / pushWait raise Accum::err).
+struct HaloG {
+    const int* geomS; int nGeomS; const int* geomI; int nGeomI;   // geometry tiles with / without a shared point
+    int nI1;                                                      // ... of the latter, how many go in front of the pack role
+    int nPack;                                                    // the shared points' tiles
+    unsigned* ticket; unsigned serial;                            // "the first role's workgroups of THIS launch are done" (roleDone / roleWait)
+    unsigned tagA;
+    int debug;                                                    // measurement aid (SMGPU_HALO_DEBUG): 1 = pack role returns at once, 2 = does not wait
+};
+template <int T, bool ORG>
+__global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_halo(MeshView m, State s, GeomTileView g, int writeFaces, HaloG hg, int xcdMap, int deferN,
+                                                                              int deferIter, double* deferLocal, double* deferHist, SmoothTileView sg, PackView pk) {
+    const int bid = (int)blockIdx.x, gS = tileGrid(hg.nGeomS, xcdMap), g1 = tileGrid(hg.nI1, xcdMap), gP = tileGrid(hg.nPack, xcdMap);
+    if (bid >= gS + g1 && bid < gS + g1 + gP) {
+        if (s.acc->stop || (hg.debug & 1)) return;
+        if (!(hg.debug & 2)) roleWait(hg.ticket, hg.serial, &s.acc->err);
+        packTileBody<T, true, true>(m, s, sg, pk, nullptr, hg.nPack, xcdMap, bid - gS - g1);
+        pushSignal(s.push, 0, hg.tagA, (unsigned)gP);      // exchange A leaves (peer-store transport)
+        return;
+    }
+    // the three geometry roles through ONE copy of the tile code (see geomCell)
+    const bool first = bid < gS, second = !first && bid < gS + g1;
+    const int* list = first ? hg.geomS : (second ? hg.geomI : hg.geomI + hg.nI1);
+    const int n = first ? hg.nGeomS : (second ? hg.nI1 : hg.nGeomI - hg.nI1);
+    const int b = first ? bid : (second ? bid - gS : bid - gS - g1 - gP);
+    geomTileBody<T, ORG>(m, s, g, 0, writeFaces, list, n, xcdMap, first ? deferN : 0, deferIter, deferLocal, deferHist, b, first);
+    if (first) roleDone(hg.ticket, hg.serial, (unsigned)gS >> 3);      // (every workgroup of the role, padding included)
+}
+
+struct HaloS {
+    int nTiles;                              // regular smoothing tiles (all of them; they skip their shared points)
+    int nSp;                                 // the shared points' tiles
+    int gM, nMultiBlocks, nMulti;            // first role: gM workgroups (a multiple of 8), nMultiBlocks of them with work
+    const int* multiIdx; const int* multiSlots; double* combA;
+    unsigned* ticket; unsigned serial;       // "the first role's workgroups of THIS launch are done" (roleDoneSmall / roleWait)
+    PushWait pwA; unsigned tagF;
+};
+template <int T>
+__global__ void __launch_bounds__(T) k_smooth_halo(MeshView m, State s, Prm prm, SmoothTileView g, SmoothTileView sg, HaloS hs, int xcdMap) {
+    const int bid = (int)blockIdx.x, tid = threadIdx.x;
+    if (bid < hs.gM) {
+        if (bid >= hs.nMultiBlocks) return;
+        pushWait(hs.pwA);
+        combineMulti<true>(bid, hs.nMulti, hs.multiIdx, hs.multiSlots, s.ownA, s.recvA, hs.combA, s.ownFold);
+        roleDoneSmall(hs.ticket, hs.serial, (unsigned)hs.nMultiBlocks);
+        return;
+    }
+    extern __shared__ double lds[];
+    const int gSp = tileGrid(hs.nSp, xcdMap);
+    const bool spTile = bid < hs.gM + gSp;                  // (workgroup-uniform)
+    const SmoothTileView& v = spTile ? sg : g;
+    const int li = spTile ? launchTile(hs.nSp, xcdMap, bid - hs.gM) : launchTile(hs.nTiles, xcdMap, bid - hs.gM - gSp);
+    if (li < 0 && !spTile) return;
+    const int tile = li >= 0 ? li : 0;      // (a padding workgroup of the shared points' role stages the first tile in vain: it still signals)
+    const SmoothLds L = smoothLds(lds, v);
+    const SmoothTileMeta tm = loadTileMeta(v, tile);
+    if (spTile) {
+        // exchange A's combine for the thread's own point, FIRST -- while nothing else is live in registers (the two ranks' records
+        // are 52 VGPRs: inside smoothPoint they took the kernel from 64 to 97) -- with the master's fold of the three sequential
+        // syncs (combineTwoToMemory, SM.C:391-478); the record goes to combA and comes back in smoothPoint
+        const int pi = tm.ptBeg + ((tid < tm.nPts) ? tid : 0);
+        const int slot = (li >= 0 && tid < tm.nPts) ? s.spSlot[pi] : -1, peer = (slot >= 0) ? s.spPeer[pi] : -1;
+        pushWait(hs.pwA);
+        if (peer >= 0)
+            combineTwoToMemory(s.ownA + (size_t)slot * SMGPU_HALO_A_DOUBLES, s.recvA + (size_t)(peer & 0x3fffffff) * SMGPU_HALO_A_DOUBLES,
+                               (peer & 0x40000000) != 0, s.ownFold, hs.combA + (size_t)slot * SMGPU_HALO_A_DOUBLES);
+    }
+    // both kinds of tiles through ONE copy of the staging and of the per-point code (see geomCell)
+    const SlotTabs tb{spTile ? s.spSlot : s.posSlot, spTile ? s.spPeer : nullptr, s.spDst0, s.spNDst};
+    const SmoothRow R = smoothStage<T, false, 2>(m, s, v, tm, L, tid, tb);
+    if (spTile && hs.nMultiBlocks > 0) roleWait(hs.ticket, hs.serial, &s.acc->err);
+    __syncthreads();
+    double dist = 0.0;
+    int fcount = 0;
+    if (li >= 0) smoothPoint<true, T, 2>(m, s, prm, v, L, R, tm, tid, dist, fcount, spTile);
+    if (spTile) pushSignal(s.push, 1, hs.tagF, (unsigned)gSp);      // exchange F leaves (peer-store transport); k_shared_fix finishes these points
+    else blockPublish<T>(s, dist, fcount, tile);
 }
 
 }  // namespace smgpu

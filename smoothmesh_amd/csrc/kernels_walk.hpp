@@ -752,6 +752,9 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
             const bool isSelf = e == 127;
             const int selfIdx = (isSelf || phase == 1) ? kPackProp : kPackCur;     // where the point is in this job
             const double angle = packTaskAngle(L, W.place[h][i], selfIdx, isSelf ? (int)kRoleNoEntry : e);
+            // (positive doubles order like their bit patterns.  The angle is never NaN: it is a sum of two clampAcos values, and
+            // clampAcos -- the reference's std::max(-MAX, std::min(MAX, cosA)), SM.C:782-783, 992-995 -- maps a NaN cosine, e.g.
+            // from a zero-length projected vector of a collapsed cell, to acos(MAX); the star form and the oracle see the same)
             const unsigned long long ab = (unsigned long long)__double_as_longlong(angle);
             atomicMin(&W.jmin[t], ab); atomicMax(&W.jmax[t], ab);
             if (isSelf) W.selfAng[h][i] = angle;

@@ -103,6 +103,16 @@ struct smgpu_handle {
     int *dGeomInterior = nullptr, *dGeomShared = nullptr;     // geometry tiles without / with a shared point
     int nGeomInterior = 0, nGeomShared = 0;
     bool geomAheadDone = false;
+    // launches whose workgroups play several roles (k_geom_halo / k_smooth_halo, kernels_tiled.hpp): constraints off, in order
+    int* dPosSlot = nullptr;                        // per smoothing-tile position: shared-point slot or -1
+    SmoothTiles shr;                                // tiles over the shared points only (the halo roles run on these)
+    SmoothTileView hv{};
+    size_t haloLds = 0;
+    std::vector<uint8_t> isInternalHost;            // findInternalMeshPoints' mask as given to smgpu_create (the tile builder marks internal neighbours)
+    unsigned* dRoleTickets = nullptr;               // two sets of kRoleWords words (kernels.hpp roleDone): k_geom_halo's, k_smooth_halo's
+    unsigned roleLaunches[2] = {0, 0};
+    bool mergedWanted = true;                       // SMGPU_HALO_MERGED=0: the one-kernel-per-step form (the A/B)
+    bool mergedIter = false;                        // this iteration's geometry + pack went out as k_geom_halo
     // LDS staging tiles (tiles.hpp)
     bool useTiles = false;
     int geomT = 128, smoothT = 256;
@@ -387,6 +397,39 @@ static void computeAlgoBytes(smgpu_handle* h) {
     h->algoF64[K_GEOM_TILE] = ops;
 }
 
+// the device view of a set of smoothing tiles (the shared points' own tiles, smgpu_halo_configure)
+static int uploadSmoothView(smgpu_handle* h, const SmoothTiles& st, SmoothTileView& v, int usePairShare) {
+    int rc = 0;
+    rc |= devUpload(h, &v.ptOrder, st.order);
+    rc |= devUpload(h, &v.ptBeg, st.ptBeg);
+    rc |= devUpload(h, &v.tcOff, st.tcOff);
+    rc |= devUpload(h, &v.tcIds, st.tcIds);
+    rc |= devUpload(h, &v.tnOff, st.tnOff);
+    rc |= devUpload(h, &v.tnIds, st.tnIds);
+    rc |= devUpload(h, &v.selfLoc, st.selfLoc);
+    rc |= devUpload(h, &v.pcBase, st.pcBase);
+    rc |= devUpload(h, &v.pcWidth, st.pcWidth);
+    rc |= devUpload(h, &v.pcEll, st.pcEll);
+    rc |= devUpload(h, &v.ppBase, st.ppBase);
+    rc |= devUpload(h, &v.ppWidth, st.ppWidth);
+    rc |= devUpload(h, &v.ppEll, st.ppEll);
+    rc |= devUpload(h, &v.pairEll, st.pairEll);
+    rc |= devUpload(h, &v.pfBase, st.pfBase);
+    rc |= devUpload(h, &v.pfWidth, st.pfWidth);
+    rc |= devUpload(h, &v.pfEll, st.pfEll);
+    std::vector<int> meta((size_t)kSmoothMetaInts * (size_t)std::max(st.nTiles, 1), 0);
+    for (int t = 0; t < st.nTiles; ++t) {
+        int* r = meta.data() + (size_t)kSmoothMetaInts * t;
+        r[0] = st.ptBeg[t]; r[1] = st.ptBeg[t + 1] - st.ptBeg[t]; r[2] = st.tcOff[t]; r[3] = st.tcOff[t + 1] - st.tcOff[t];
+        r[4] = st.tnOff[t]; r[5] = st.tnOff[t + 1] - st.tnOff[t]; r[6] = st.pcBase[t]; r[7] = st.pcWidth[t];
+        r[8] = st.ppBase[t]; r[9] = st.ppWidth[t]; r[10] = st.pfBase[t]; r[11] = st.pfWidth[t];
+    }
+    rc |= devUpload(h, &v.meta, meta);
+    v.maxCells = st.maxCells; v.maxPoints = st.maxPoints;
+    v.usePairShare = usePairShare;
+    return rc;
+}
+
 extern "C" {
 
 const char* smgpu_last_error(void) { return g_err.c_str(); }
@@ -426,6 +469,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 if (fPointOrder.valid()) pointOrder = fPointOrder.get();
                 internalMask.resize((size_t)d->nPoints);
                 for (int p = 0; p < d->nPoints; ++p) internalMask[(size_t)p] = d->isInternalPoint[p] ? 1 : 0;
+                h->isInternalHost = internalMask;
                 fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0] {
                     return h->stl.build(h->topo, d->points, internalMask.data(), mortonTiles, smoothT0, capSC0, capSN0,
                                         (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr); });
@@ -1429,9 +1473,13 @@ static int checkDeviceError(smgpu_handle* h) {
     Accum a;
     HIP_OK(hipMemcpyAsync(&a, h->st.acc, sizeof(Accum), hipMemcpyDeviceToHost, h->stream));
     HIP_OK(hipStreamSynchronize(h->stream));
+    // reported once: the word is cleared, so that the handle stays usable (a peer-store wait that timed out makes every later
+    // wait of the run return at once -- until the host has seen the error and, say, reconfigured the halo)
+    if (a.err != 0) HIP_OK(hipMemsetAsync(&h->st.acc->err, 0, sizeof(int), h->stream));
     if (a.err == 3) return fail("face-angle walk: the workgroups of the device replay did not all become resident (grid barrier timed out); set SMGPU_WALK=host or lower SMGPU_WALK_BLOCKS");
     if (a.err == 1) return fail("Failed to find cLabel1/cLabel2: a point has fewer than two usable edge neighbours (SM.C:354-362)");
     if (a.err == 2) return fail("a shared point has more sharing ranks than supported");
+    if (a.err == ROLE_ERR_TIMEOUT) return fail("a role of a multi-role launch (k_geom_halo / k_smooth_halo) waited two seconds for the workgroups of an earlier role; set SMGPU_HALO_MERGED=0");
     if (a.err == PUSH_ERR_TIMEOUT) return fail("peer-store transport: a peer's records did not arrive within the time limit (SMGPU_PUSH_TIMEOUT_S, default 60 s: a rank is gone, or not using the same transport)");
     if (a.err == BND_ERR_NORMAL) return fail("pointNormal is zero for a boundary point that is to be projected (BPS.C:691-696, OBB.C:609-610)");
     if (a.err == BND_ERR_NOHIT) return fail("Did not find surface intersection for a boundary point (BPS.C:932-938)");
@@ -1774,12 +1822,56 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         if (devUpload(h, &pc, gi) || devUpload(h, &pd, gs)) return 1;
         h->dGeomInterior = (int*)pc; h->dGeomShared = (int*)pd;
         h->nGeomInterior = (int)gi.size(); h->nGeomShared = (int)gs.size();
+        // per tile position of the regular tiles: the point's shared slot (k_smooth_halo's regular tiles skip their shared points)
+        std::vector<int> posSlot((size_t)P, -1);
+        for (int pi = 0; pi < P; ++pi) posSlot[(size_t)pi] = slot[(size_t)h->stl.order[(size_t)pi]];
+        const int* pe = nullptr;
+        if (devUpload(h, &pe, posSlot)) return 1;
+        h->dPosSlot = (int*)pe;
+        // tiles over the shared points only, in the regular tiles' (Morton) order: the halo roles of k_geom_halo / k_smooth_halo
+        h->shr = SmoothTiles();
+        h->hv = SmoothTileView{};
+        h->haloLds = 0;
+        if (d->nShared > 0 && (int)h->isInternalHost.size() == P) {
+            std::vector<int32_t> sub;
+            sub.reserve((size_t)d->nShared);
+            for (int pi = 0; pi < P; ++pi) if (posSlot[(size_t)pi] >= 0) sub.push_back(h->stl.order[(size_t)pi]);
+            std::vector<double> pts(3 * (size_t)P);      // (the builder only reads coordinates when it orders the points itself)
+            const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500)), capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
+            const std::string err = h->shr.build(h->topo, pts.data(), h->isInternalHost.data(), false, h->smoothT, capSC, capSN, nullptr, &sub);
+            if (!err.empty()) return fail("shared-point tiles: " + err);
+            if (uploadSmoothView(h, h->shr, h->hv, h->sv.usePairShare)) return 1;
+            h->haloLds = sizeof(double) * 3 * ((size_t)h->shr.maxCells + (size_t)h->shr.maxPoints);
+            // per position of those tiles: slot, two-sharer peer code (k_halo_combineA2's table), send slots
+            const size_t nS = sub.size();
+            std::vector<int> spSlot(nS), spPeer(nS, -1), spDst0(nS, -1), spNDst(nS, 0);
+            for (size_t i = 0; i < nS; ++i) {
+                const int sl = slot[(size_t)sub[i]];
+                spSlot[i] = sl;
+                const int b = combOff[(size_t)sl];
+                if (combOff[(size_t)sl + 1] - b == 2) {
+                    const int s0 = combSlots[(size_t)b], s1 = combSlots[(size_t)b + 1];
+                    const int other = s0 < 0 ? s1 : s0;
+                    if (other >= 0 && other < 0x40000000) spPeer[i] = other | (s0 < 0 ? 0x40000000 : 0);
+                }
+                spNDst[i] = sendOff[(size_t)sl + 1] - sendOff[(size_t)sl];
+                if (spNDst[i] > 0) spDst0[i] = sendSlots[(size_t)sendOff[(size_t)sl]];
+            }
+            const int *qa = nullptr, *qb = nullptr, *qc = nullptr, *qd = nullptr;
+            if (devUpload(h, &qa, spSlot) || devUpload(h, &qb, spPeer) || devUpload(h, &qc, spDst0) || devUpload(h, &qd, spNDst)) return 1;
+            h->st.spSlot = qa; h->st.spPeer = qb; h->st.spDst0 = qc; h->st.spNDst = qd;
+        }
+        if (!h->dRoleTickets) { if (devAlloc(h, &h->dRoleTickets, 2 * (size_t)kRoleWords)) return 1; }
+        HIP_OK(hipMemset(h->dRoleTickets, 0, 2 * (size_t)kRoleWords * sizeof(unsigned)));
+        h->roleLaunches[0] = h->roleLaunches[1] = 0;
+        h->mergedWanted = envInt("SMGPU_HALO_MERGED", 1) != 0;
     }
     {   // partial slots: tiles (or point blocks) + the blocks of k_shared_fix
         const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2 * (size_t)gridFor(P) + 2;
         if (devAlloc(h, &h->st.blkMax, nPart) || devAlloc(h, &h->st.blkCnt, nPart)) return 1;
     }
     h->st.sharedSlot = h->dSharedSlot;
+    h->st.posSlot = h->dPosSlot;
     h->st.combA = h->dCombA;
     h->st.combOff = h->dCombOff; h->st.combSlots = h->dCombSlots; h->st.ownA = h->dOwnA; h->st.recvA = h->recvA;
     h->st.sendOff = h->dSendOff; h->st.sendSlots = h->dSendSlots; h->st.sendF = h->sendF;
@@ -1794,6 +1886,9 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         ensureDynLds(k_pack_tile<64>, h->device, h->smoothLds);
         ensureDynLds(k_pack_tile<128>, h->device, h->smoothLds);
         ensureDynLds(k_pack_tile<256>, h->device, h->smoothLds);
+        ensureDynLds(k_smooth_halo<256>, h->device, std::max(h->smoothLds, h->haloLds));
+        ensureDynLds(k_geom_halo<256, false>, h->device, std::max(h->geomLds, h->haloLds));
+        ensureDynLds(k_geom_halo<256, true>, h->device, std::max(h->geomLds, h->haloLds));
     }
     h->st.lStride = SMGPU_HALO_L_LAYERS;
     h->haloOn = true;
@@ -1920,6 +2015,63 @@ int smgpu_push_open(int32_t device, const void* ipcHandle64, void** ptr) {
 int smgpu_push_close(void* ptr) { if (ptr) HIP_OK(hipIpcCloseMemHandle(ptr)); return 0; }
 int smgpu_push_free(void* ptr) { if (ptr) HIP_OK(hipFree(ptr)); return 0; }
 
+// Constraints off, tiled kernels, exchanges in order (or peer stores): the iteration as two multi-role launches + k_shared_fix
+// (kernels_tiled.hpp: k_geom_halo, k_smooth_halo) instead of six kernels.
+static bool mergedOk(const smgpu_handle* h) {
+    const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
+    return h->mergedWanted && fused && h->useTiles && h->geomT == 256 && h->smoothT == 256 && h->nShared > 0 && h->shr.nTiles > 0 && h->nGeomShared > 0 &&
+           h->packTiles && h->dMultiIdx && h->dPeer && h->dPosSlot && h->dRoleTickets && !h->layersOn && !h->bndOn && !h->useExch && !h->geomAheadDone &&
+           !h->st.inlinePackF &&
+           // several engines on one device with the peer-store transport: workgroups that spin for a peer's flag hold their slots
+           // while the peer's launches need some -- fine for a handful of tiles, not for a chip full of them
+           !(h->pushOn && h->deviceShare > 1 && h->shr.nTiles > 256);
+}
+static int runMergedGeomPack(smgpu_handle* h) {
+    const MeshView& m = h->mv;
+    const State s = h->st;
+    // the pack role goes behind the geometry tiles with a shared point and a first batch of the others: by the time its workgroups
+    // are dispatched (the second generation of the launch) the first role has finished, so they hardly spin
+    const int slots = 4 * 256;      // (4 workgroups per CU: k_geom_halo's launch bounds)
+    const int gS = tileGrid(h->nGeomShared, h->xcdMap);
+    const int nI1 = std::min(h->nGeomInterior, std::max(0, envInt("SMGPU_HALO_PACK_AFTER", slots + slots / 2) - gS) & ~7);
+    const int g1 = tileGrid(nI1, h->xcdMap), g2 = tileGrid(h->nGeomInterior - nI1, h->xcdMap), gP = tileGrid(h->shr.nTiles, h->xcdMap);
+    HaloG hg;
+    hg.geomS = h->dGeomShared; hg.nGeomS = h->nGeomShared; hg.geomI = h->dGeomInterior; hg.nGeomI = h->nGeomInterior; hg.nI1 = nI1;
+    hg.nPack = h->shr.nTiles;
+    hg.ticket = h->dRoleTickets; hg.serial = ++h->roleLaunches[0];
+    hg.tagA = (unsigned)(h->haloIter + 1);
+    hg.debug = envInt("SMGPU_HALO_DEBUG", 0);
+    const PackView pk{h->dOwnA, h->sendA, h->dSendOff, h->dSendSlots, 0};
+    const size_t lds = std::max(h->geomLds, h->haloLds);
+    const int rc = launchKDispatch(h, K_GEOM_TILE, [&](hipEvent_t evA, hipEvent_t evB) {
+        if (h->foamOrg)
+            hipExtLaunchKernelGGL((k_geom_halo<256, true>), dim3(gS + g1 + gP + g2), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, m, s, h->gv, h->writeFaces ? 1 : 0, hg,
+                                  h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->hv, pk);
+        else
+            hipExtLaunchKernelGGL((k_geom_halo<256, false>), dim3(gS + g1 + gP + g2), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, m, s, h->gv, h->writeFaces ? 1 : 0, hg,
+                                  h->xcdMap, h->deferN, h->deferIter, h->deferLocal, h->deferHist, h->hv, pk);
+    });
+    h->deferN = 0;
+    h->deferLocal = h->deferHist = nullptr;
+    return rc;
+}
+static int runMergedSmooth(smgpu_handle* h) {
+    const Prm prm = makePrm(h);
+    HaloS hs;
+    hs.nTiles = h->stl.nTiles; hs.nSp = h->shr.nTiles;
+    hs.nMulti = h->nMulti; hs.nMultiBlocks = h->nMulti ? gridFor((int64_t)h->nMulti * 16) : 0;
+    hs.gM = ((hs.nMultiBlocks + 7) / 8) * 8;
+    hs.multiIdx = h->dMultiIdx; hs.multiSlots = h->dMultiSlots; hs.combA = h->dCombA;
+    hs.ticket = h->dRoleTickets + kRoleWords;
+    hs.serial = hs.nMultiBlocks ? ++h->roleLaunches[1] : 0u;
+    hs.pwA = pushWaitOf(h, 0); hs.tagF = (unsigned)(h->haloIter + 1);
+    const int grid = hs.gM + tileGrid(h->shr.nTiles, h->xcdMap) + tileGrid(h->stl.nTiles, h->xcdMap);
+    const size_t lds = std::max(h->smoothLds, h->haloLds);
+    return launchKDispatch(h, K_SMOOTH_FINAL, [&](hipEvent_t evA, hipEvent_t evB) {
+        hipExtLaunchKernelGGL((k_smooth_halo<256>), dim3(grid), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, h->mv, h->st, prm, h->sv, h->hv, hs, h->xcdMap);
+    });
+}
+
 int smgpu_iter_begin(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     if (!h->prmSet) return fail("smgpu_set_params has not been called");
@@ -1927,6 +2079,12 @@ int smgpu_iter_begin(smgpu_handle* h) {
     if (h->pushOn && h->pushStride != (h->st.lStride > 0 ? h->st.lStride : SMGPU_HALO_L_LAYERS)) {   // the L records grew (boundary set-up)
         HIP_OK(hipStreamSynchronize(h->stream));
         if (pushBuildTables(h)) return 1;
+    }
+    h->mergedIter = mergedOk(h);
+    if (h->mergedIter) {      // geometry and exchange A's pack in one launch
+        if (runMergedGeomPack(h)) return 1;
+        if (updateWalkMode(h)) return 1;
+        return exchAfterCompute(h);
     }
     if (runBndPre(h)) return 1;
     if (h->geomAheadDone) {
@@ -1981,7 +2139,7 @@ int smgpu_iter_interior(smgpu_handle* h) {
     HIP_OK(hipSetDevice(h->device));
     // without an exchange stream nothing runs next to the exchange: splitting the launch would only add ramp-up and
     // drain time (measured on 100^3 with 30 k shared points: 2 x 32.7 us instead of 45 us), so smgpu_iter_mid does it all
-    if (!h->useTiles || h->interiorDone || !h->useExch) return 0;
+    if (!h->useTiles || h->interiorDone || !h->useExch || h->mergedIter) return 0;
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const Prm prm = makePrm(h);
     if (fused) { if (runSmooth<true>(h, h->mv, h->st, prm, h->dInteriorTiles, h->nInteriorTiles)) return 1; }
@@ -1995,6 +2153,10 @@ int smgpu_iter_mid(smgpu_handle* h) {
     HIP_OK(hipSetDevice(h->device));
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const Prm prm = makePrm(h);
+    if (h->mergedIter) {      // combine, smoothing and exchange F's pack in one launch
+        if (runMergedSmooth(h)) return 1;
+        return exchAfterCompute(h);
+    }
     if (h->useTiles && !h->interiorDone && smgpu_iter_interior(h)) return 1;
     if (computeAfterExch(h)) return 1;      // exchange A has been enqueued by the host
     if (h->nShared)
@@ -2047,7 +2209,7 @@ int smgpu_iter_ahead(smgpu_handle* h) {
     if (!h || !h->haloOn) return fail("halo not configured");
     HIP_OK(hipSetDevice(h->device));
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
-    if (!h->useTiles || !fused || h->geomAheadDone || !h->useExch) return 0;   // see smgpu_iter_interior
+    if (!h->useTiles || !fused || h->geomAheadDone || !h->useExch || h->mergedIter) return 0;   // see smgpu_iter_interior
     if (runGeometry(h, h->dGeomInterior, h->nGeomInterior, true)) return 1;
     h->geomAheadDone = true;
     return 0;

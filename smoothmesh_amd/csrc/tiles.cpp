@@ -328,11 +328,14 @@ void chainCorners(std::vector<std::pair<int32_t, int32_t>>& corners, ChainScratc
 }  // namespace
 
 std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
-                               int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder) {
+                               int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset) {
     threads = nThreads;
-    PhaseTimer tm("smoothing");
-    if (morton) order = pointOrder ? *pointOrder : mortonOrder(t.nPoints, xyz);
+    PhaseTimer tm(subset ? "shared-point" : "smoothing");
+    if (subset) order = *subset;
+    else if (morton) order = pointOrder ? *pointOrder : mortonOrder(t.nPoints, xyz);
     else order = naturalOrder(t.nPoints);
+    const int32_t nPos = (int32_t)order.size();      // positions = points to tile (all of them, or the subset)
+    maxCells = maxPoints = 0;
     tm.lap("order");
     const int32_t capTile = threads;
     const auto& pc = t.pointCells;
@@ -340,7 +343,7 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
     std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
     ptBeg.assign(1, 0);
     int32_t tile = 0, nC = 0, nN = 0, nT = 0;
-    for (int32_t pi = 0; pi < t.nPoints; ++pi) {
+    for (int32_t pi = 0; pi < nPos; ++pi) {
         const int32_t p = order[(size_t)pi];
         for (int attempt = 0; attempt < 2; ++attempt) {
             int32_t addC = 0, addN = 0;
@@ -359,12 +362,13 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
             break;
         }
     }
-    ptBeg.push_back(t.nPoints);
-    nTiles = (int32_t)ptBeg.size() - 1;
+    ptBeg.push_back(nPos);
+    nTiles = (nPos > 0) ? (int32_t)ptBeg.size() - 1 : 0;
+    if (nPos == 0) ptBeg.assign(1, 0);
     { std::vector<int32_t>().swap(stampC); std::vector<int32_t>().swap(stampN); }
     tm.lap("boundaries");
 
-    selfLoc.assign((size_t)t.nPoints, 0);
+    selfLoc.assign((size_t)nPos, 0);
     const bool pairs = t.maxPointPoints <= 16;
     struct Part {
         std::vector<int32_t> tcIds, tnIds, nCl, nPt, pcBase, ppBase, pfBase;

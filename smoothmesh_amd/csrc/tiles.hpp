@@ -81,8 +81,11 @@ struct SmoothTiles {
     std::vector<int32_t> order;     // tile order: position -> point id (see GeomTiles::order)
     // isInternal (SM.C:40-91) marks bit 15 of the ppEll entries whose neighbour is an internal point (SM.C:294)
     // pointOrder (optional): mortonOrderOf(nPoints, points), computed by the caller (it also serves the edge tiles)
+    // subset (optional): tiles over THESE points only, in the given order (multi-rank: the shared points get tiles of their own,
+    // smgpu_halo_configure) -- `order`, `selfLoc` and the ELL rows then have subset->size() positions
     std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
-                      int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder = nullptr);
+                      int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder = nullptr,
+                      const std::vector<int32_t>* subset = nullptr);
 };
 
 // ---- face-angle filter: tile = edges (Morton order of the edge midpoints); LDS holds the points, the

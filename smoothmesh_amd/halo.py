@@ -41,6 +41,12 @@ class HaloTables:
         assert np.array_equal(sorted_g[pos], allg), "shared point not present in pointProcAddressing"
         self.sharedGlobal = allg
         self.sharedLocal = order[pos].astype(np.int32)
+        # the group (connected component) of each shared point: every rank labels the components of the same all-gathered lists the
+        # same way, so (global id, component) names a shared point on all its sharers -- the global id alone does not (a baffle
+        # between ranks: one mesh point, two shared points)
+        mg, mc = node_gid[mine], comp[mine]
+        o2 = np.argsort(mg, kind="stable")
+        self.sharedComp = mc[o2][np.searchsorted(mg[o2], allg)].astype(np.int64) if len(allg) else np.zeros(0, np.int64)
         self.counts = np.zeros(n, np.int64)         # send == recv counts per peer (symmetric lists)
         send = []
         base = {}
@@ -663,8 +669,21 @@ class DistributedSmoother:
             eng.iter_end()
             done += 1
         eng.set_stats_history(None, 0)
+        # an error word raised by a kernel of this call (a peer's records that never came, a point without usable neighbours): every
+        # rank must learn of it BEFORE the gather below -- a rank that raised on its own would leave the others inside the collective
+        err = None
         if hasattr(eng, "check_error"):
-            eng.check_error()          # an error word raised by a kernel of this call (the gather below waits for the stream anyway)
+            try:
+                eng.check_error()
+            except Exception as ex:  # noqa: BLE001 -- re-raised below, on every rank
+                err = ex
+        if self.world > 1:
+            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cpu" if self._staged() else self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if int(flag.item()) and err is None:
+                err = RuntimeError("another rank reported a device error in this call (see its message)")
+        if err is not None:
+            raise err
         if self._staged():
             allh = torch.empty((self.world, n, 2), dtype=torch.float64)
             self.dist.all_gather_into_tensor(allh.view(-1), local.cpu().view(-1))
