@@ -142,6 +142,12 @@ __device__ __forceinline__ void stCoh(double* p, double v) {
 __device__ __forceinline__ double ldCoh(const double* p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// a record another KERNEL has written while this one was running (the host's exchange on its own stream, ordered by flag words
+// instead of kernel boundaries -- smgpu.hip, the "flagged" arrangement): system-scope loads, past both cache levels
+__device__ __forceinline__ double ldSys(const double* p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+}
+__device__ __forceinline__ int ldSys(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ V3 ldvCoh(const double* base, int i) {
     const double* p = base + 3 * (size_t)i;
     return v3(ldCoh(p), ldCoh(p + 1), ldCoh(p + 2));
@@ -1376,10 +1382,13 @@ __device__ __forceinline__ void combineTwoSharers(const double* ra, const double
 // (tests/test_gpu_multirank.py runs both forms against the oracle, the tie cases included).
 __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra, const double* __restrict__ rb, bool selfFirst, int ownFold,
                                                    double* __restrict__ o) {
+    // (the received record with system-scope loads: with the flagged arrangement it was written by the host's exchange kernel
+    // while this launch was already running)
     auto ld3 = [](const double* p) { return v3(p[0], p[1], p[2]); };
+    auto ld3s = [](const double* p) { return v3(ldSys(p), ldSys(p + 1), ldSys(p + 2)); };
     auto pick = [](bool c, const V3& x, const V3& y) { return v3(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z); };
     {   // plusEqOp, ascending rank
-        const V3 sa = ld3(ra), sb = ld3(rb);
+        const V3 sa = ld3(ra), sb = ld3s(rb);
         const V3 sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
     }
@@ -1388,14 +1397,14 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
     bool dA1, dB1, dA2, dB2;
     V3 a2, b2;      // the ranks' (updated) second vectors
     {   // SM.C:397-419
-        const V3 a1 = ld3(ra + 3), b1 = ld3(rb + 3);
+        const V3 a1 = ld3(ra + 3), b1 = ld3s(rb + 3);
         const V3 fab = SMGPU_FOLD2(a1, b1), fba = SMGPU_FOLD2(b1, a1);
         const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
         dA1 = isCloserPoint(svA, a1); dB1 = isCloserPoint(svB, b1);
         const V3 f1 = pick(dA1, svA, a1);
         o[3] = f1.x; o[4] = f1.y; o[5] = f1.z;
         a2 = pick(dA1, a1, ld3(ra + 6));
-        b2 = pick(dB1, b1, ld3(rb + 6));
+        b2 = pick(dB1, b1, ld3s(rb + 6));
     }
     V3 a3, b3;      // ... third vectors
     {   // SM.C:424-445
@@ -1406,7 +1415,7 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
         o[6] = f2.x; o[7] = f2.y; o[8] = f2.z;
         // the third vector before this step: the original second one if the first step shifted, else the original third one
         a3 = pick(dA2, a2, ld3(ra + (dA1 ? 6 : 9)));
-        b3 = pick(dB2, b2, ld3(rb + (dB1 ? 6 : 9)));
+        b3 = pick(dB2, b2, ld3s(rb + (dB1 ? 6 : 9)));
     }
     {   // SM.C:450-469
         const V3 svA = pick(aLeads, SMGPU_FOLD2(a3, b3), SMGPU_FOLD2(b3, a3));
@@ -1414,7 +1423,7 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
         o[9] = f3.x; o[10] = f3.y; o[11] = f3.z;
     }
 #undef SMGPU_FOLD2
-    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rb[12]);
+    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(ldSys(rb + 12));
     const int cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
     const int hcA = (dA1 || dA2) ? 0 : (int)(pa >> 32), hcB = (dB1 || dB2) ? 0 : (int)(pb >> 32);
     o[12] = __longlong_as_double(((long long)(hcA | hcB) << 32) | (long long)(unsigned int)cnt);
@@ -1573,9 +1582,12 @@ __device__ __forceinline__ void combineMulti(int blk, int nMulti, const int* mul
     V3 sv0 = v3(0, 0, 0), r1 = sv0, r2 = sv0, r3 = sv0;
     int cntJ = 0, hc = 0;
     if (mine) {
-        sv0 = v3(r[0], r[1], r[2]);
-        r1 = v3(r[3], r[4], r[5]); r2 = v3(r[6], r[7], r[8]); r3 = v3(r[9], r[10], r[11]);
-        const long long pk = __double_as_longlong(r[12]);
+        double w[SMGPU_HALO_A_DOUBLES];
+#pragma unroll
+        for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) w[q] = (COH && sl >= 0) ? ldSys(r + q) : r[q];      // (see combineTwoToMemory)
+        sv0 = v3(w[0], w[1], w[2]);
+        r1 = v3(w[3], w[4], w[5]); r2 = v3(w[6], w[7], w[8]); r3 = v3(w[9], w[10], w[11]);
+        const long long pk = __double_as_longlong(w[12]);
         cntJ = (int)(pk & 0xffffffffll);
         hc = (int)(pk >> 32);
     }
@@ -1646,7 +1658,7 @@ __global__ void __launch_bounds__(kBlock) k_halo_orF(int nShared, const int* sha
 // flags (SM.C:2374), restores / counts (SM.C:2384-2392), writes the new coordinates and publishes the
 // residual partials of the shared points (partial slots after the tile slots).
 __global__ void __launch_bounds__(kBlock) k_shared_fix(MeshView m, State s, Prm prm, int nShared, const int* sharedLocal,
-                                                       const int* combOff, const int* combSlots, const int* recvF, int partialBase, PushWait pw) {
+                                                       const int* combOff, const int* combSlots, const int* recvF, int partialBase, PushWait pw, int sysLoads = 0) {
     if (s.acc->stop) return;
     pushWait(pw);
     const int i = blockIdx.x * kBlock + threadIdx.x;
@@ -1657,7 +1669,7 @@ __global__ void __launch_bounds__(kBlock) k_shared_fix(MeshView m, State s, Prm 
         int frz = s.frozen[p];
         for (int k = combOff[i]; k < combOff[i + 1]; ++k) {
             const int sl = combSlots[k];
-            if (sl >= 0) frz |= recvF[sl];
+            if (sl >= 0) frz |= sysLoads ? ldSys(recvF + sl) : recvF[sl];
         }
         s.frozen[p] = frz ? 1 : 0;
         const uint8_t fl = m.pflags[p];

@@ -112,6 +112,17 @@ struct smgpu_handle {
     unsigned* dRoleTickets = nullptr;               // two sets of kRoleWords words (kernels.hpp roleDone): k_geom_halo's, k_smooth_halo's
     unsigned roleLaunches[2] = {0, 0};
     bool mergedWanted = true;                       // SMGPU_HALO_MERGED=0: the one-kernel-per-step form (the A/B)
+    // the "flagged" arrangement of the multi-role launches with an exchange stream: the host's exchanges are ordered against the
+    // kernels by FLAG WORDS instead of kernel boundaries -- the role that packs an exchange raises a word the exchange stream
+    // waits for (hipStreamWaitValue32), the exchange stream writes a word (hipStreamWriteValue32) the consuming role polls --
+    // so both exchanges run next to the bulk of the two launches.  Records leave through write-through stores into the send
+    // buffers (a PushView onto this rank's own buffers).
+    bool flagWanted = true;                         // SMGPU_HALO_FLAGGED=0: exchange stream ordered by events / stream ops around whole launches
+    bool flagBuilt = false;
+    uint32_t* dFlagWords = nullptr;                 // [0], [1]: raised by the kernels (A packed, F packed); [16], [17]: written by the exchange stream
+    void *dSelfSlotA = nullptr, *dSelfSlotF = nullptr, *dSelfPeerFlag = nullptr;
+    unsigned* dSelfTicket = nullptr;
+    PushView flagView{};
     bool mergedIter = false;                        // this iteration's geometry + pack went out as k_geom_halo
     // LDS staging tiles (tiles.hpp)
     bool useTiles = false;
@@ -1865,6 +1876,8 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
         HIP_OK(hipMemset(h->dRoleTickets, 0, 2 * (size_t)kRoleWords * sizeof(unsigned)));
         h->roleLaunches[0] = h->roleLaunches[1] = 0;
         h->mergedWanted = envInt("SMGPU_HALO_MERGED", 1) != 0;
+        h->flagWanted = envInt("SMGPU_HALO_FLAGGED", 1) != 0;
+        h->flagBuilt = false;
     }
     {   // partial slots: tiles (or point blocks) + the blocks of k_shared_fix
         const size_t nPart = (size_t)std::max(gridFor(P), h->useTiles ? h->stl.nTiles : 0) + (size_t)gridFor(d->nShared) + 2 * (size_t)gridFor(P) + 2;
@@ -1913,6 +1926,11 @@ static int computeAfterExch(smgpu_handle* h) {
 // what the first kernel that consumes exchange `kind` (0 = A + L, 1 = F) of this iteration waits for
 static PushWait pushWaitOf(const smgpu_handle* h, int kind) {
     PushWait pw;
+    if (h->mergedIter && h->useExch) {      // the flagged arrangement: the word the exchange stream writes behind the host's exchange
+        pw.localFlag = h->flagView.localFlag; pw.nPeers = 1; pw.kind = kind; pw.tag = (unsigned)(h->haloIter + 1); pw.err = &h->st.acc->err; pw.fence = 0;
+        pw.timeoutTicks = (unsigned long long)std::max(1, envInt("SMGPU_PUSH_TIMEOUT_S", 60)) * 100000000ull;
+        return pw;
+    }
     pw.localFlag = h->pushOn ? h->st.push.localFlag : nullptr;
     pw.nPeers = h->pushPeers; pw.kind = kind; pw.tag = (unsigned)(h->haloIter + 1); pw.err = &h->st.acc->err; pw.fence = h->st.push.fence;
     pw.timeoutTicks = h->pushTimeoutTicks;
@@ -2017,18 +2035,49 @@ int smgpu_push_free(void* ptr) { if (ptr) HIP_OK(hipFree(ptr)); return 0; }
 
 // Constraints off, tiled kernels, exchanges in order (or peer stores): the iteration as two multi-role launches + k_shared_fix
 // (kernels_tiled.hpp: k_geom_halo, k_smooth_halo) instead of six kernels.
+static bool flagUsable(const smgpu_handle* h) {
+    const char* v = std::getenv("ROCPROF_COUNTER_COLLECTION");      // (counter collection serialises kernels: a role would spin for a kernel that cannot start)
+    return h->useExch && h->flagWanted && h->streamOps && !h->pushOn && h->deviceShare == 1 && !(v && std::atoi(v) != 0) && h->sendA && h->sendF;
+}
+// the PushView onto this rank's own send buffers and flag words (built once per halo configuration)
+static int ensureFlagView(smgpu_handle* h) {
+    if (h->flagBuilt) return 0;
+    const size_t n = (size_t)std::max(h->nSend, 1);
+    if (!h->dFlagWords) {
+        void **a = nullptr, **f = nullptr, **pf = nullptr;
+        if (devAlloc(h, &h->dFlagWords, 64) || devAlloc(h, &a, n) || devAlloc(h, &f, n) || devAlloc(h, &pf, 1) || devAlloc(h, &h->dSelfTicket, 2)) return 1;
+        h->dSelfSlotA = a; h->dSelfSlotF = f; h->dSelfPeerFlag = pf;
+    }
+    std::vector<void*> a(n, nullptr), f(n, nullptr);
+    for (int k = 0; k < h->nSend; ++k) { a[(size_t)k] = h->sendA + (size_t)k * SMGPU_HALO_A_DOUBLES; f[(size_t)k] = h->sendF + k; }
+    void* w = h->dFlagWords;
+    HIP_OK(hipMemcpy(h->dSelfSlotA, a.data(), n * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->dSelfSlotF, f.data(), n * sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(h->dSelfPeerFlag, &w, sizeof(void*), hipMemcpyHostToDevice));
+    HIP_OK(hipMemset(h->dFlagWords, 0, 64 * sizeof(uint32_t)));
+    HIP_OK(hipMemset(h->dSelfTicket, 0, 2 * sizeof(unsigned)));
+    PushView pv{};
+    pv.slotA = (double* const*)h->dSelfSlotA; pv.slotL = nullptr; pv.slotF = (int* const*)h->dSelfSlotF;
+    pv.ticket = h->dSelfTicket; pv.peerFlag = (unsigned* const*)h->dSelfPeerFlag; pv.localFlag = (const unsigned*)(h->dFlagWords + 16); pv.nPeers = 1;
+    pv.fence = 0;
+    h->flagView = pv;
+    h->flagBuilt = true;
+    return 0;
+}
 static bool mergedOk(const smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     return h->mergedWanted && fused && h->useTiles && h->geomT == 256 && h->smoothT == 256 && h->nShared > 0 && h->shr.nTiles > 0 && h->nGeomShared > 0 &&
-           h->packTiles && h->dMultiIdx && h->dPeer && h->dPosSlot && h->dRoleTickets && !h->layersOn && !h->bndOn && !h->useExch && !h->geomAheadDone &&
+           h->packTiles && h->dMultiIdx && h->dPeer && h->dPosSlot && h->dRoleTickets && !h->layersOn && !h->bndOn && (!h->useExch || flagUsable(h)) && !h->geomAheadDone &&
            !h->st.inlinePackF &&
            // several engines on one device with the peer-store transport: workgroups that spin for a peer's flag hold their slots
            // while the peer's launches need some -- fine for a handful of tiles, not for a chip full of them
            !(h->pushOn && h->deviceShare > 1 && h->shr.nTiles > 256);
 }
+static bool flagged(const smgpu_handle* h) { return h->mergedIter && h->useExch; }
 static int runMergedGeomPack(smgpu_handle* h) {
     const MeshView& m = h->mv;
-    const State s = h->st;
+    State s = h->st;
+    if (flagged(h)) s.push = h->flagView;
     // the pack role goes behind the geometry tiles with a shared point and a first batch of the others: by the time its workgroups
     // are dispatched (the second generation of the launch) the first role has finished, so they hardly spin
     const int slots = 4 * 256;      // (4 workgroups per CU: k_geom_halo's launch bounds)
@@ -2067,8 +2116,10 @@ static int runMergedSmooth(smgpu_handle* h) {
     hs.pwA = pushWaitOf(h, 0); hs.tagF = (unsigned)(h->haloIter + 1);
     const int grid = hs.gM + tileGrid(h->shr.nTiles, h->xcdMap) + tileGrid(h->stl.nTiles, h->xcdMap);
     const size_t lds = std::max(h->smoothLds, h->haloLds);
+    State s = h->st;
+    if (flagged(h)) s.push = h->flagView;
     return launchKDispatch(h, K_SMOOTH_FINAL, [&](hipEvent_t evA, hipEvent_t evB) {
-        hipExtLaunchKernelGGL((k_smooth_halo<256>), dim3(grid), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, h->mv, h->st, prm, h->sv, h->hv, hs, h->xcdMap);
+        hipExtLaunchKernelGGL((k_smooth_halo<256>), dim3(grid), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, h->mv, s, prm, h->sv, h->hv, hs, h->xcdMap);
     });
 }
 
@@ -2082,8 +2133,13 @@ int smgpu_iter_begin(smgpu_handle* h) {
     }
     h->mergedIter = mergedOk(h);
     if (h->mergedIter) {      // geometry and exchange A's pack in one launch
+        if (h->useExch && ensureFlagView(h)) return 1;
         if (runMergedGeomPack(h)) return 1;
         if (updateWalkMode(h)) return 1;
+        if (h->useExch) {     // the host's exchange A may start as soon as the pack ROLE is through (not the launch)
+            HIP_OK(hipStreamWaitValue32(h->exch, h->dFlagWords + 0, (uint32_t)(h->haloIter + 1), hipStreamWaitValueGte, 0xffffffffu));
+            return 0;
+        }
         return exchAfterCompute(h);
     }
     if (runBndPre(h)) return 1;
@@ -2154,6 +2210,12 @@ int smgpu_iter_mid(smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const Prm prm = makePrm(h);
     if (h->mergedIter) {      // combine, smoothing and exchange F's pack in one launch
+        if (h->useExch) {     // exchange A has been enqueued on the exchange stream: the word the shared points' role polls goes up behind it
+            HIP_OK(hipStreamWriteValue32(h->exch, h->dFlagWords + 16, (uint32_t)(h->haloIter + 1), 0));
+            if (runMergedSmooth(h)) return 1;
+            HIP_OK(hipStreamWaitValue32(h->exch, h->dFlagWords + 1, (uint32_t)(h->haloIter + 1), hipStreamWaitValueGte, 0xffffffffu));
+            return 0;
+        }
         if (runMergedSmooth(h)) return 1;
         return exchAfterCompute(h);
     }
@@ -2223,7 +2285,9 @@ int smgpu_iter_end(smgpu_handle* h) {
     const Prm prm = makePrm(h);
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const bool fusedTiles = fused && h->useTiles;
-    if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
+    const bool flg = flagged(h);
+    if (flg) HIP_OK(hipStreamWriteValue32(h->exch, h->dFlagWords + 17, (uint32_t)(h->haloIter + 1), 0));      // behind exchange F: k_shared_fix polls it
+    else if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
     s.stats = nullptr;                      // per-iteration results go to localStats in this mode
     int nPart;
     if (fusedTiles) {
@@ -2232,7 +2296,7 @@ int smgpu_iter_end(smgpu_handle* h) {
         if (h->nShared)
             if (launchK(h, K_HALO, [&] {
                     hipLaunchKernelGGL(k_shared_fix, dim3(gS), dim3(kBlock), 0, h->stream, m, s, prm, h->nShared, h->dSharedLocal, h->dCombOff,
-                                       h->dCombSlots, h->recvF, h->stl.nTiles, pushWaitOf(h, 1));
+                                       h->dCombSlots, h->recvF, h->stl.nTiles, pushWaitOf(h, 1), flg ? 1 : 0);
                 })) return 1;
         nPart = h->stl.nTiles + (h->bndOn ? gridFor(h->nShared) + gridFor(2 * (int64_t)h->bv.nB) : (h->nShared ? gS : 0));
     } else {
@@ -2254,6 +2318,9 @@ int smgpu_iter_end(smgpu_handle* h) {
     std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     h->interiorDone = false;
+    // (flagged arrangement with a stats history: nobody reads localStats per iteration, and an exchange stream that waited for the
+    // whole iteration here could not start the next exchange A next to the next geometry launch)
+    if (flg && hist) return 0;
     return exchAfterCompute(h);             // localStats is complete: the host may reduce / copy it
 }
 

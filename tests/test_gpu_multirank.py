@@ -206,6 +206,25 @@ def test_direct_rccl_exchange_of_the_python_driver():
     assert "direct exchange: ok" in r.stdout
 
 
+@pytest.mark.parametrize("transport", ["rccl", "push"])
+def test_every_arrangement_of_the_iteration_gives_the_same_bits(transport):
+    """one rank of eight with its real halo tables and a self-exchange (scripts/check_arrangements.py): one kernel per step in
+    order / with an exchange stream, the multi-role launches (k_geom_halo / k_smooth_halo on tiles of the shared points) in order,
+    with an exchange stream ordered around whole launches, and flagged (the exchanges next to the launches, ordered by flag words)
+    -- bit-identical coordinates, residuals and nFrozenPoints; the same with the peer-store transport onto the own receive slots"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if transport == "push":
+        env["SMOOTHMESH_EXCHANGE"] = "push"
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "check_arrangements.py")], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "arrangements: ok" in r.stdout and "DIFFERENT" not in r.stdout
+    assert r.stdout.count("same bits") == (1 if transport == "push" else 4)
+
+
 @pytest.mark.parametrize("world", [2, 8])
 def test_distributed_smoother_polyhedral_over_rccl(world):
     """The production transport: one process per GPU, RCCL (send / recv groups on the engines' streams, torch's collectives
