@@ -201,6 +201,25 @@ __device__ __forceinline__ void roleWait(const unsigned* tk, unsigned serial, in
     __syncthreads();
 }
 
+// One wave on the host's exchange stream (the flagged arrangement, smgpu.hip): raise a word behind the exchange that was enqueued
+// in front of this kernel (the role that consumes the records polls it) and / or wait for the word the role that packs the NEXT
+// exchange raises -- what hipStreamWriteValue32 + hipStreamWaitValue32 do as two kernels with a dispatch gap between them.
+__global__ void __launch_bounds__(64) k_flag_relay(unsigned* writeWord, unsigned writeValue, const unsigned* waitWord, unsigned waitValue, int* err,
+                                                    unsigned long long timeoutTicks) {
+    if (threadIdx.x != 0) return;
+    if (writeWord) __hip_atomic_store(writeWord, writeValue, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (!waitWord) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned spins = 0;
+    while ((int)(__hip_atomic_load(waitWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - waitValue) < 0) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;      // (the run is lost already)
+            if (__builtin_amdgcn_s_memrealtime() - t0 > timeoutTicks) { *err = PUSH_ERR_TIMEOUT; break; }
+        }
+    }
+}
+
 struct State {
     double* ptsCur; double* ptsNext; double* prop;
     double* stepSqr;   // != NULL: the proposal kernel leaves |proposal - current|^2 per point for k_apply_swap
@@ -223,6 +242,7 @@ struct State {
     // slot, the two-sharer point's peer code (the other rank's receive slot | this rank is the lower one << 30) or -1, its
     // number of send slots and the first of them (most shared points have one: no walk through sendOff / sendSlots)
     const int* spSlot; const int* spPeer; const int* spDst0; const int* spNDst;
+    int* ownF;                 // != NULL (k_smooth_halo with its fix role): the local freeze flag of every shared point, by slot
     const double* combA;       // multi-rank: combined exchange-A records (13 doubles per shared point)
     // multi-rank, tiled kernels: a point with TWO sharers (nearly all shared points) is combined by the smoothing kernel
     // itself from the own and the received record (inlineCombine), and its freeze flag goes straight to its send slots
@@ -1384,11 +1404,15 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
                                                    double* __restrict__ o) {
     // (the received record with system-scope loads: with the flagged arrangement it was written by the host's exchange kernel
     // while this launch was already running)
+    // The whole received record in ONE round trip, up front (13 independent loads: 26 registers, which this place can afford --
+    // nothing else is live yet); the own record comes from the local L2 as the steps ask for it.
     auto ld3 = [](const double* p) { return v3(p[0], p[1], p[2]); };
-    auto ld3s = [](const double* p) { return v3(ldSys(p), ldSys(p + 1), ldSys(p + 2)); };
     auto pick = [](bool c, const V3& x, const V3& y) { return v3(c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z); };
+    double rbv[SMGPU_HALO_A_DOUBLES];
+#pragma unroll
+    for (int q = 0; q < SMGPU_HALO_A_DOUBLES; ++q) rbv[q] = ldSys(rb + q);
     {   // plusEqOp, ascending rank
-        const V3 sa = ld3(ra), sb = ld3s(rb);
+        const V3 sa = ld3(ra), sb = v3(rbv[0], rbv[1], rbv[2]);
         const V3 sum = selfFirst ? (v3(0, 0, 0) + sa) + sb : (v3(0, 0, 0) + sb) + sa;
         o[0] = sum.x; o[1] = sum.y; o[2] = sum.z;
     }
@@ -1397,14 +1421,14 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
     bool dA1, dB1, dA2, dB2;
     V3 a2, b2;      // the ranks' (updated) second vectors
     {   // SM.C:397-419
-        const V3 a1 = ld3(ra + 3), b1 = ld3s(rb + 3);
+        const V3 a1 = ld3(ra + 3), b1 = v3(rbv[3], rbv[4], rbv[5]);
         const V3 fab = SMGPU_FOLD2(a1, b1), fba = SMGPU_FOLD2(b1, a1);
         const V3 svA = pick(aLeads, fab, fba), svB = pick(bLeads, fba, fab);
         dA1 = isCloserPoint(svA, a1); dB1 = isCloserPoint(svB, b1);
         const V3 f1 = pick(dA1, svA, a1);
         o[3] = f1.x; o[4] = f1.y; o[5] = f1.z;
         a2 = pick(dA1, a1, ld3(ra + 6));
-        b2 = pick(dB1, b1, ld3s(rb + 6));
+        b2 = pick(dB1, b1, v3(rbv[6], rbv[7], rbv[8]));
     }
     V3 a3, b3;      // ... third vectors
     {   // SM.C:424-445
@@ -1415,7 +1439,7 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
         o[6] = f2.x; o[7] = f2.y; o[8] = f2.z;
         // the third vector before this step: the original second one if the first step shifted, else the original third one
         a3 = pick(dA2, a2, ld3(ra + (dA1 ? 6 : 9)));
-        b3 = pick(dB2, b2, ld3s(rb + (dB1 ? 6 : 9)));
+        b3 = pick(dB2, b2, pick(dB1, v3(rbv[6], rbv[7], rbv[8]), v3(rbv[9], rbv[10], rbv[11])));
     }
     {   // SM.C:450-469
         const V3 svA = pick(aLeads, SMGPU_FOLD2(a3, b3), SMGPU_FOLD2(b3, a3));
@@ -1423,7 +1447,7 @@ __device__ __forceinline__ void combineTwoToMemory(const double* __restrict__ ra
         o[9] = f3.x; o[10] = f3.y; o[11] = f3.z;
     }
 #undef SMGPU_FOLD2
-    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(ldSys(rb + 12));
+    const long long pa = __double_as_longlong(ra[12]), pb = __double_as_longlong(rbv[12]);
     const int cnt = (int)(pa & 0xffffffffll) + (int)(pb & 0xffffffffll);
     const int hcA = (dA1 || dA2) ? 0 : (int)(pa >> 32), hcB = (dB1 || dB2) ? 0 : (int)(pb >> 32);
     o[12] = __longlong_as_double(((long long)(hcA | hcB) << 32) | (long long)(unsigned int)cnt);

@@ -42,6 +42,18 @@ struct SmoothTileView {
     int maxCells, maxPoints, usePairShare;
 };
 
+// a ? x : y member by member (workgroup-uniform a: scalar selects).  `a ? x : y` on the two OBJECTS is a select of their addresses,
+// for which the compiler copies both kernel arguments to scratch memory (160 bytes per lane in k_smooth_halo)
+__device__ __forceinline__ SmoothTileView pickView(bool a, const SmoothTileView& x, const SmoothTileView& y) {
+    SmoothTileView v;
+#define SMGPU_PICK(F) v.F = a ? x.F : y.F;
+    SMGPU_PICK(ptOrder) SMGPU_PICK(ptBeg) SMGPU_PICK(tcOff) SMGPU_PICK(tcIds) SMGPU_PICK(tnOff) SMGPU_PICK(tnIds) SMGPU_PICK(selfLoc)
+    SMGPU_PICK(pcBase) SMGPU_PICK(pcWidth) SMGPU_PICK(pcEll) SMGPU_PICK(ppBase) SMGPU_PICK(ppWidth) SMGPU_PICK(ppEll) SMGPU_PICK(pairEll)
+    SMGPU_PICK(pfBase) SMGPU_PICK(pfWidth) SMGPU_PICK(pfEll) SMGPU_PICK(meta) SMGPU_PICK(maxCells) SMGPU_PICK(maxPoints) SMGPU_PICK(usePairShare)
+#undef SMGPU_PICK
+    return v;
+}
+
 struct SmoothTileMeta { int ptBeg, nPts, tcOff, nCells, tnOff, nNbrs, pcBase, pcWidth, ppBase, ppWidth, pfBase, pfWidth; };
 constexpr int kSmoothMetaInts = 12;
 __device__ __forceinline__ SmoothTileMeta loadTileMeta(const SmoothTileView& g, int tile) {
@@ -776,7 +788,10 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         else if (FINAL && slot >= 0) {
             // shared point (multi-rank): its freeze flag still has to be OR-ed over the ranks (SM.C:2374);
             // k_shared_fix finishes it after exchange F
-            stv(s.prop, p, np);
+            if (MODE == 2 && s.ownF) {      // the fix role of the SAME launch reads both (k_smooth_halo): coherent stores
+                stvCoh(s.prop, p, np);
+                __hip_atomic_store(s.ownF + slot, frozen ? 1 : 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else stv(s.prop, p, np);
             s.frozen[p] = frozen ? 1 : 0;
             if (MODE == 2) {                                                     // exchange F, SM.C:2374
                 const int v = frozen ? 1 : 0;
@@ -956,6 +971,7 @@ __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_halo(M
     const int bid = (int)blockIdx.x, gS = tileGrid(hg.nGeomS, xcdMap), g1 = tileGrid(hg.nI1, xcdMap), gP = tileGrid(hg.nPack, xcdMap);
     if (bid >= gS + g1 && bid < gS + g1 + gP) {
         if (s.acc->stop || (hg.debug & 1)) return;
+        __builtin_amdgcn_s_setprio(3);      // (a chain of dependent steps the exchange waits for: issue priority over the tiles' waves)
         if (!(hg.debug & 2)) roleWait(hg.ticket, hg.serial, &s.acc->err);
         packTileBody<T, true, true>(m, s, sg, pk, nullptr, hg.nPack, xcdMap, bid - gS - g1);
         pushSignal(s.push, 0, hg.tagA, (unsigned)gP);      // exchange A leaves (peer-store transport)
@@ -970,30 +986,77 @@ __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_halo(M
     if (first) roleDone(hg.ticket, hg.serial, (unsigned)gS >> 3);      // (every workgroup of the role, padding included)
 }
 
+struct HaloFix {                             // the fix role of k_smooth_halo (k_shared_fix's work inside the launch), or nFix = 0
+    int nFix;                                // workgroups (a multiple of 8; nShared / T of them with work)
+    int nShared; const int* sharedLocal; const int* combOff; const int* combSlots; const int* recvF; int partialBase;
+    PushWait pwF;
+    unsigned* ticket; unsigned serial;       // "the shared points' role of THIS launch is done" (roleDone / roleWait)
+    int sysLoads;
+};
 struct HaloS {
     int nTiles;                              // regular smoothing tiles (all of them; they skip their shared points)
+    int nA;                                  // ... of which this many go in front of the fix role
     int nSp;                                 // the shared points' tiles
     int gM, nMultiBlocks, nMulti;            // first role: gM workgroups (a multiple of 8), nMultiBlocks of them with work
     const int* multiIdx; const int* multiSlots; double* combA;
     unsigned* ticket; unsigned serial;       // "the first role's workgroups of THIS launch are done" (roleDoneSmall / roleWait)
     PushWait pwA; unsigned tagF;
 };
+// SM.C:2374-2392 for the shared points inside the smoothing launch (k_shared_fix's work, see there): after the shared points'
+// role of this launch (their proposals and local freeze flags: coherent loads) and exchange F (the peers' flags / the exchange
+// stream's word), OR the flags, restore / count, write the new coordinates, publish the residual partials
 template <int T>
-__global__ void __launch_bounds__(T) k_smooth_halo(MeshView m, State s, Prm prm, SmoothTileView g, SmoothTileView sg, HaloS hs, int xcdMap) {
+__device__ __forceinline__ void haloFixBody(const MeshView& m, const State& s, const Prm& prm, const HaloFix& hf, int blk) {
+    roleWait(hf.ticket, hf.serial, &s.acc->err);
+    pushWait(hf.pwF);
+    const int i = blk * T + (int)threadIdx.x;
+    double dist = 0.0;
+    int fcount = 0;
+    if (i < hf.nShared) {
+        const int p = hf.sharedLocal[i];
+        int frz = __hip_atomic_load(s.ownF + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int k = hf.combOff[i]; k < hf.combOff[i + 1]; ++k) {
+            const int sl = hf.combSlots[k];
+            if (sl >= 0) frz |= hf.sysLoads ? ldSys(hf.recvF + sl) : hf.recvF[sl];
+        }
+        s.frozen[p] = frz ? 1 : 0;
+        const uint8_t fl = m.pflags[p];
+        const V3 cur = ldv(s.ptsCur, p);
+        V3 np = ldvCoh(s.prop, p);
+        if (frz || (!(fl & PF_INTERNAL) && !(fl & PF_SMOOTHSURF))) { np = cur; fcount = 1; }
+        dist = mag(np - cur) / prm.maxStep;
+        stv(s.ptsNext, p, np);
+    }
+    blockPublish<T>(s, dist, fcount, hf.partialBase + blk);
+}
+template <int T>
+__global__ void __launch_bounds__(T) k_smooth_halo(MeshView m, State s, Prm prm, SmoothTileView g, SmoothTileView sg, HaloS hs, int xcdMap, HaloFix hf) {
     const int bid = (int)blockIdx.x, tid = threadIdx.x;
     if (bid < hs.gM) {
         if (bid >= hs.nMultiBlocks) return;
+        __builtin_amdgcn_s_setprio(3);
         pushWait(hs.pwA);
         combineMulti<true>(bid, hs.nMulti, hs.multiIdx, hs.multiSlots, s.ownA, s.recvA, hs.combA, s.ownFold);
         roleDoneSmall(hs.ticket, hs.serial, (unsigned)hs.nMultiBlocks);
         return;
     }
     extern __shared__ double lds[];
-    const int gSp = tileGrid(hs.nSp, xcdMap);
+    const int gSp = tileGrid(hs.nSp, xcdMap), gA = tileGrid(hs.nA, xcdMap);
     const bool spTile = bid < hs.gM + gSp;                  // (workgroup-uniform)
-    const SmoothTileView& v = spTile ? sg : g;
-    const int li = spTile ? launchTile(hs.nSp, xcdMap, bid - hs.gM) : launchTile(hs.nTiles, xcdMap, bid - hs.gM - gSp);
+    if (!spTile && bid >= hs.gM + gSp + gA && bid < hs.gM + gSp + gA + hf.nFix) {
+        const int blk = bid - hs.gM - gSp - gA;
+        __builtin_amdgcn_s_setprio(3);
+        if (blk * T < hf.nShared) haloFixBody<T>(m, s, prm, hf, blk);
+        return;
+    }
+    if (spTile) __builtin_amdgcn_s_setprio(3);
+    const SmoothTileView v = pickView(spTile, sg, g);
+    // the regular tiles in two batches, in front of and behind the fix role
+    const bool batchA = bid < hs.gM + gSp + gA;
+    int li = spTile ? launchTile(hs.nSp, xcdMap, bid - hs.gM)
+                    : (batchA ? launchTile(hs.nA, xcdMap, bid - hs.gM - gSp) : launchTile(hs.nTiles - hs.nA, xcdMap, bid - hs.gM - gSp - gA - hf.nFix));
     if (li < 0 && !spTile) return;
+    if (!spTile && !batchA) li += hs.nA;
     const int tile = li >= 0 ? li : 0;      // (a padding workgroup of the shared points' role stages the first tile in vain: it still signals)
     const SmoothLds L = smoothLds(lds, v);
     const SmoothTileMeta tm = loadTileMeta(v, tile);
@@ -1016,8 +1079,10 @@ __global__ void __launch_bounds__(T) k_smooth_halo(MeshView m, State s, Prm prm,
     double dist = 0.0;
     int fcount = 0;
     if (li >= 0) smoothPoint<true, T, 2>(m, s, prm, v, L, R, tm, tid, dist, fcount, spTile);
-    if (spTile) pushSignal(s.push, 1, hs.tagF, (unsigned)gSp);      // exchange F leaves (peer-store transport); k_shared_fix finishes these points
-    else blockPublish<T>(s, dist, fcount, tile);
+    if (spTile) {
+        if (hf.nFix > 0) roleDone(hf.ticket, hf.serial, (unsigned)gSp >> 3);      // the fix role of this launch may read the proposals
+        pushSignal(s.push, 1, hs.tagF, (unsigned)gSp);      // exchange F leaves (peer-store transport / flagged arrangement)
+    } else blockPublish<T>(s, dist, fcount, tile);
 }
 
 }  // namespace smgpu

@@ -110,7 +110,9 @@ struct smgpu_handle {
     size_t haloLds = 0;
     std::vector<uint8_t> isInternalHost;            // findInternalMeshPoints' mask as given to smgpu_create (the tile builder marks internal neighbours)
     unsigned* dRoleTickets = nullptr;               // two sets of kRoleWords words (kernels.hpp roleDone): k_geom_halo's, k_smooth_halo's
-    unsigned roleLaunches[2] = {0, 0};
+    unsigned roleLaunches[3] = {0, 0, 0};
+    int* dOwnF = nullptr;                           // local freeze flags of the shared points (k_smooth_halo's fix role)
+    bool fixInSmooth = false;                       // this iteration's k_shared_fix work went out inside k_smooth_halo
     bool mergedWanted = true;                       // SMGPU_HALO_MERGED=0: the one-kernel-per-step form (the A/B)
     // the "flagged" arrangement of the multi-role launches with an exchange stream: the host's exchanges are ordered against the
     // kernels by FLAG WORDS instead of kernel boundaries -- the role that packs an exchange raises a word the exchange stream
@@ -1872,9 +1874,10 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             if (devUpload(h, &qa, spSlot) || devUpload(h, &qb, spPeer) || devUpload(h, &qc, spDst0) || devUpload(h, &qd, spNDst)) return 1;
             h->st.spSlot = qa; h->st.spPeer = qb; h->st.spDst0 = qc; h->st.spNDst = qd;
         }
-        if (!h->dRoleTickets) { if (devAlloc(h, &h->dRoleTickets, 2 * (size_t)kRoleWords)) return 1; }
-        HIP_OK(hipMemset(h->dRoleTickets, 0, 2 * (size_t)kRoleWords * sizeof(unsigned)));
-        h->roleLaunches[0] = h->roleLaunches[1] = 0;
+        if (!h->dRoleTickets) { if (devAlloc(h, &h->dRoleTickets, 3 * (size_t)kRoleWords)) return 1; }
+        HIP_OK(hipMemset(h->dRoleTickets, 0, 3 * (size_t)kRoleWords * sizeof(unsigned)));
+        h->roleLaunches[0] = h->roleLaunches[1] = h->roleLaunches[2] = 0;
+        if (devAlloc(h, &h->dOwnF, (size_t)std::max(d->nShared, 1))) return 1;
         h->mergedWanted = envInt("SMGPU_HALO_MERGED", 1) != 0;
         h->flagWanted = envInt("SMGPU_HALO_FLAGGED", 1) != 0;
         h->flagBuilt = false;
@@ -2064,6 +2067,15 @@ static int ensureFlagView(smgpu_handle* h) {
     h->flagBuilt = true;
     return 0;
 }
+// one wave on the exchange stream: raise `writeWord` (behind what the host has enqueued there) and / or wait for `waitWord`
+static int flagRelay(smgpu_handle* h, int writeIdx, int waitIdx) {
+    const unsigned tag = (unsigned)(h->haloIter + 1);
+    const unsigned long long ticks = (unsigned long long)std::max(1, envInt("SMGPU_PUSH_TIMEOUT_S", 60)) * 100000000ull;
+    hipLaunchKernelGGL(k_flag_relay, dim3(1), dim3(64), 0, h->exch, writeIdx >= 0 ? h->dFlagWords + writeIdx : nullptr, tag,
+                       waitIdx >= 0 ? (const unsigned*)(h->dFlagWords + waitIdx) : nullptr, tag, &h->st.acc->err, ticks);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
 static bool mergedOk(const smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     return h->mergedWanted && fused && h->useTiles && h->geomT == 256 && h->smoothT == 256 && h->nShared > 0 && h->shr.nTiles > 0 && h->nGeomShared > 0 &&
@@ -2082,7 +2094,9 @@ static int runMergedGeomPack(smgpu_handle* h) {
     // are dispatched (the second generation of the launch) the first role has finished, so they hardly spin
     const int slots = 4 * 256;      // (4 workgroups per CU: k_geom_halo's launch bounds)
     const int gS = tileGrid(h->nGeomShared, h->xcdMap);
-    const int nI1 = std::min(h->nGeomInterior, std::max(0, envInt("SMGPU_HALO_PACK_AFTER", slots + slots / 2) - gS) & ~7);
+    // (flagged arrangement: the exchange stream's chain -- pack, exchange A, flag, shared points' role, exchange F, flag -- is what
+    // bounds the iteration, so the pack role goes right behind the first role and spins for it)
+    const int nI1 = std::min(h->nGeomInterior, std::max(0, envInt("SMGPU_HALO_PACK_AFTER", flagged(h) ? 0 : slots + slots / 2) - gS) & ~7);
     const int g1 = tileGrid(nI1, h->xcdMap), g2 = tileGrid(h->nGeomInterior - nI1, h->xcdMap), gP = tileGrid(h->shr.nTiles, h->xcdMap);
     HaloG hg;
     hg.geomS = h->dGeomShared; hg.nGeomS = h->nGeomShared; hg.geomI = h->dGeomInterior; hg.nGeomI = h->nGeomInterior; hg.nI1 = nI1;
@@ -2114,12 +2128,31 @@ static int runMergedSmooth(smgpu_handle* h) {
     hs.ticket = h->dRoleTickets + kRoleWords;
     hs.serial = hs.nMultiBlocks ? ++h->roleLaunches[1] : 0u;
     hs.pwA = pushWaitOf(h, 0); hs.tagF = (unsigned)(h->haloIter + 1);
-    const int grid = hs.gM + tileGrid(h->shr.nTiles, h->xcdMap) + tileGrid(h->stl.nTiles, h->xcdMap);
+    // k_shared_fix's work as a role of this launch, where exchange F completes while the launch runs: the peers' kernels move the
+    // flags (peer stores; one rank of eight: 120.6 -> 114.6 us).  In the middle of the regular tiles: by then the shared points'
+    // role (first in the launch) is through and exchange F has had ~20 us.  NOT with the flagged arrangement by default: there
+    // exchange F is a chain on the exchange stream (flag, exchange kernel, flag: ~35 us behind the shared points' role) that ends
+    // about when the launch does -- a role inside would stretch the launch (measured 124-127 against 122-123 us with k_shared_fix
+    // behind it; SMGPU_HALO_FIX_INSIDE=1 forces the role).
+    HaloFix hf{};
+    h->fixInSmooth = envInt("SMGPU_HALO_FIX_INSIDE", h->pushOn ? 1 : 0) != 0 && (h->pushOn || flagged(h));
+    hs.nA = h->stl.nTiles;
+    if (h->fixInSmooth) {
+        hs.nA = (int)((int64_t)h->stl.nTiles * std::min(100, std::max(0, envInt("SMGPU_HALO_FIX_AT", flagged(h) ? 85 : 55))) / 100) & ~7;
+        hf.nFix = ((gridFor(h->nShared) + 7) / 8) * 8;
+        hf.nShared = h->nShared; hf.sharedLocal = h->dSharedLocal; hf.combOff = h->dCombOff; hf.combSlots = h->dCombSlots; hf.recvF = h->recvF;
+        hf.partialBase = h->stl.nTiles;
+        hf.pwF = pushWaitOf(h, 1);
+        hf.ticket = h->dRoleTickets + 2 * kRoleWords; hf.serial = ++h->roleLaunches[2];
+        hf.sysLoads = flagged(h) ? 1 : 0;
+    }
+    const int grid = hs.gM + tileGrid(h->shr.nTiles, h->xcdMap) + tileGrid(hs.nA, h->xcdMap) + hf.nFix + tileGrid(h->stl.nTiles - hs.nA, h->xcdMap);
     const size_t lds = std::max(h->smoothLds, h->haloLds);
     State s = h->st;
     if (flagged(h)) s.push = h->flagView;
+    s.ownF = h->fixInSmooth ? h->dOwnF : nullptr;
     return launchKDispatch(h, K_SMOOTH_FINAL, [&](hipEvent_t evA, hipEvent_t evB) {
-        hipExtLaunchKernelGGL((k_smooth_halo<256>), dim3(grid), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, h->mv, s, prm, h->sv, h->hv, hs, h->xcdMap);
+        hipExtLaunchKernelGGL((k_smooth_halo<256>), dim3(grid), dim3(256), (uint32_t)lds, h->stream, evA, evB, 0, h->mv, s, prm, h->sv, h->hv, hs, h->xcdMap, hf);
     });
 }
 
@@ -2136,10 +2169,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
         if (h->useExch && ensureFlagView(h)) return 1;
         if (runMergedGeomPack(h)) return 1;
         if (updateWalkMode(h)) return 1;
-        if (h->useExch) {     // the host's exchange A may start as soon as the pack ROLE is through (not the launch)
-            HIP_OK(hipStreamWaitValue32(h->exch, h->dFlagWords + 0, (uint32_t)(h->haloIter + 1), hipStreamWaitValueGte, 0xffffffffu));
-            return 0;
-        }
+        if (h->useExch) return flagRelay(h, -1, 0);      // the host's exchange A may start as soon as the pack ROLE is through (not the launch)
         return exchAfterCompute(h);
     }
     if (runBndPre(h)) return 1;
@@ -2210,11 +2240,11 @@ int smgpu_iter_mid(smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const Prm prm = makePrm(h);
     if (h->mergedIter) {      // combine, smoothing and exchange F's pack in one launch
-        if (h->useExch) {     // exchange A has been enqueued on the exchange stream: the word the shared points' role polls goes up behind it
-            HIP_OK(hipStreamWriteValue32(h->exch, h->dFlagWords + 16, (uint32_t)(h->haloIter + 1), 0));
-            if (runMergedSmooth(h)) return 1;
-            HIP_OK(hipStreamWaitValue32(h->exch, h->dFlagWords + 1, (uint32_t)(h->haloIter + 1), hipStreamWaitValueGte, 0xffffffffu));
-            return 0;
+        if (h->useExch) {
+            // exchange A has been enqueued on the exchange stream: the word the shared points' role polls goes up behind it, and the
+            // same wave waits for that role's "exchange F is packed" (exchange F is enqueued behind it)
+            if (flagRelay(h, 16, 1)) return 1;
+            return runMergedSmooth(h);
         }
         if (runMergedSmooth(h)) return 1;
         return exchAfterCompute(h);
@@ -2286,14 +2316,14 @@ int smgpu_iter_end(smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const bool fusedTiles = fused && h->useTiles;
     const bool flg = flagged(h);
-    if (flg) HIP_OK(hipStreamWriteValue32(h->exch, h->dFlagWords + 17, (uint32_t)(h->haloIter + 1), 0));      // behind exchange F: k_shared_fix polls it
+    if (flg) { if (flagRelay(h, 17, -1)) return 1; }      // behind exchange F: the fix role / k_shared_fix polls it
     else if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
     s.stats = nullptr;                      // per-iteration results go to localStats in this mode
     int nPart;
     if (fusedTiles) {
         // every non-shared point is already final; finish the shared ones (or of the freeze flags included)
         const int gS = gridFor(h->nShared);
-        if (h->nShared)
+        if (h->nShared && !(h->mergedIter && h->fixInSmooth))      // (else: the fix role of k_smooth_halo has done it)
             if (launchK(h, K_HALO, [&] {
                     hipLaunchKernelGGL(k_shared_fix, dim3(gS), dim3(kBlock), 0, h->stream, m, s, prm, h->nShared, h->dSharedLocal, h->dCombOff,
                                        h->dCombSlots, h->recvF, h->stl.nTiles, pushWaitOf(h, 1), flg ? 1 : 0);
