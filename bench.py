@@ -132,6 +132,10 @@ def oracle_leg(kind, n_side, constraints, eng, prm, budget_s=12.0, layers=False,
             o.setup_boundary(st, sz, kd, sel, patch_arrays(mesh, bp.smoothingPatches)[3], lopt, bp.initEdges, bp.targetEdges, bp.targetSurfaces)
         else:
             o.setup_layers(st, sz, kd, sel, *lopt)
+    # census of the oracle's threshold comparisons of angles (SM.C:923, 1367, 1391-1394, 1421-1424) over these iterations: the engine
+    # takes acos with another algorithm than glibc (csrc/smacos.hpp, at most the last bit apart) -- how many comparisons had their
+    # two sides within 8 ulp, i.e. could have been decided by that bit?  (a counter increment per comparison: not measurable in the rate)
+    oracle_ffi.acos_census(True)
     t0 = time.perf_counter()
     _, res1, frz1 = o.iterate(1, 0.0)            # first iteration untimed: it also first-touches the oracle's work arrays
     t1 = time.perf_counter() - t0
@@ -140,6 +144,7 @@ def oracle_leg(kind, n_side, constraints, eng, prm, budget_s=12.0, layers=False,
     _, res2, frz2 = o.iterate(iters, 0.0)
     dt = time.perf_counter() - t0
     n = 1 + iters
+    census = oracle_ffi.acos_census(False)
     res_o, frz_o = np.concatenate([res1, res2]), np.concatenate([frz1, frz2])
     pts_o = o.points()
     if not plain:
@@ -166,6 +171,9 @@ def oracle_leg(kind, n_side, constraints, eng, prm, budget_s=12.0, layers=False,
         "residual_max_rel_diff": float(np.max(np.abs(res_g - res_o) / np.maximum(np.abs(res_o), 1e-300))) if n_g == n else None,
         "nFrozenPoints": [int(x) for x in frz_g[:4]],
         "tolerance": 1e-10,
+        "acos_census": {**census, "what": "the oracle's comparisons of an angle with a threshold / another angle in these iterations (oracle: "
+                        "glibc acos, engine: csrc/smacos.hpp, at most the last bit apart); within_8ulp = sides 1..8 ulp apart, i.e. comparisons "
+                        "the last bit could decide; equal = both sides the same function of the same inputs"},
     }
     par["ok"] = bool(par["rel_linf"] <= par["tolerance"] and par["nFrozen_equal"])
     return base, par
@@ -614,6 +622,28 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
                    f"exchange {'overlapped on a communication stream' if getattr(ds, 'overlap', False) else 'in order'}"
                    + (f" (autotuned: {tune['us_per_iter']})" if tune and tune['us_per_iter'] else ""))
     ds.close()               # streams drained, second communicator destroyed -- on every rank, before the group goes
+    # what the multi-rank code path costs per iteration BEFORE any byte crosses a link: every rank's own sub-domain as a serial mesh
+    # (its processor-patch points are plain internal points, nothing is packed, combined or exchanged) through the single-rank loop,
+    # same W + K steps, max over the ranks
+    halo_cost = None
+    if not (layers or boundary) and (world > 1 or force_dist):
+        from smoothmesh_amd import SmoothEngine
+        se = SmoothEngine(sub.mesh, device=local_rank)
+        se.set_params(prm)
+        se.iterate(max(W, 5), 0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        se.iterate(K, 0.0)
+        torch.cuda.synchronize()
+        ts = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
+        se.close()
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        dt_s = float(ts.item())
+        halo_cost = {"serial_ms_per_step": dt_s / K * 1e3, "ms_per_step": dt / K * 1e3, "halo_overhead_us": (dt - dt_s) / K * 1e6,
+                     "weak_efficiency_bound": dt_s / dt,
+                     "note": "serial = every rank's own sub-domain as a serial mesh through the single-rank loop (nothing packed, combined or "
+                             "exchanged), same steps, max over ranks; the difference is the multi-rank code path (halo roles, exchanges, "
+                             "k_shared_fix) plus link time; bound = serial / multi-rank"}
     t0 = time.perf_counter()
     base = rank0_cpu_baseline(sub, prm, oracle_budget_s, rank, world) if oracle else None
     t_oracle = time.perf_counter() - t0
@@ -624,7 +654,7 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
                "ok": bool((copies or {}).get("ok", rank != 0) and (small or {}).get("ok", False))}
     return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_ev=dt_ev, ctr=ctr, sizes=sizes,
                 total_points=total_points, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par, transport=info,
-                parallelism=parallelism, n_global=n_global,
+                parallelism=parallelism, n_global=n_global, halo_cost=halo_cost,
                 phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
 
 
@@ -775,6 +805,8 @@ def main():
                     "n_gpus": world, "points": int(rc["total_points"]), "points_per_gpu": int(rc["sizes"]["nPoints"]), "cells_per_gpu": int(rc["sizes"]["nCells"]),
                     "steps": Kc, "ms_per_step": rc["dt"] / Kc * 1e3, "value": rc["total_points"] * Kc / rc["dt"], "unit": "points/s",
                     "parallelism": rc["parallelism"], "rccl": rc["transport"],
+                    **({"halo_overhead_us": rc["halo_cost"]["halo_overhead_us"], "weak_efficiency_bound": rc["halo_cost"]["weak_efficiency_bound"],
+                        "halo_cost": rc["halo_cost"]} if rc["halo_cost"] else {}),
                     **kernel_report(wl, rc["ctr"], Kc, rc["dt"], rc["dt_ev"], rc["sizes"]),
                     "residual_last": float(rc["res"][-1]), "nFrozenPoints_last": int(rc["frz"][-1]), "phases": rc["phases"],
                 }
@@ -828,6 +860,10 @@ def main():
         # torch = all_to_all_single, push = peer stores), the size the communicator itself reports, the start-up self-check
         out["rccl"] = multi["transport"]
         out["phases"] = multi["phases"]
+        if multi["halo_cost"]:
+            out["halo_overhead_us"] = multi["halo_cost"]["halo_overhead_us"]
+            out["weak_efficiency_bound"] = multi["halo_cost"]["weak_efficiency_bound"]
+            out["halo_cost"] = multi["halo_cost"]
         if multi["parity_check"]:
             out["parity_check"] = multi["parity_check"]
             out["parity"] = ("parity_check (this job): copies of shared points identical on all ranks after the timed steps + a down-scaled "

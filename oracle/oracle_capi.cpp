@@ -3,7 +3,10 @@
 #include <cstring>
 #include <string>
 
+#include <cmath>
+
 #include "smooth_oracle.hpp"
+#include "../smoothmesh_amd/csrc/smacos.hpp"
 
 using namespace orc;
 
@@ -30,6 +33,17 @@ void* orc_create(int nPoints, int nCells, int nFaces, int nInternalFaces, const 
 
 void orc_destroy(void* h) { delete static_cast<Domain*>(h); }
 
+// process-wide: 0 = glibc acos (the reference's arithmetic), 1 = the device kernels' algorithm (smacos.hpp)
+void orc_set_acos_variant(int variant) { setAcosVariant(variant); }
+int orc_get_acos_variant() { return acosVariant(); }
+void orc_acos_census_enable(int on) { censusEnable(on != 0); if (on) censusReset(); }
+// out = {comparisons, of them with equal sides, with sides 1..8 ulp apart, smallest distance of unequal sides in ulp (or -1)}
+void orc_acos_census(long long* out) {
+    const AcosCensus c = censusGet();
+    out[0] = c.comparisons; out[1] = c.equal; out[2] = c.within8ulp;
+    out[3] = (c.minUlp == ~0ull || c.minUlp > 0x7fffffffffffffffull) ? -1 : (long long)c.minUlp;
+}
+double orc_acos(double x, int variant) { return variant ? smacos::acosX(x) : std::acos(x); }
 void orc_set_foam_variant(void* h, int variant) { static_cast<Domain*>(h)->foamVariant = variant; }
 // syncPointList model of the rank-engine combines below: 0 = master fold (globalMeshData::syncData), 1 = own-value fold
 void orc_set_sync_variant(void* h, int variant) { static_cast<Domain*>(h)->syncVariant = variant; }

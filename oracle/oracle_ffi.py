@@ -31,6 +31,12 @@ def lib():
         l.orc_create.restype = C.c_void_p
         l.orc_create.argtypes = [C.c_int] * 4 + [f64p, i32p, i32p, i32p, i32p, u8p, u8p]
         l.orc_destroy.argtypes = [C.c_void_p]
+        l.orc_set_acos_variant.argtypes = [C.c_int]
+        l.orc_get_acos_variant.restype = C.c_int
+        l.orc_acos_census_enable.argtypes = [C.c_int]
+        l.orc_acos_census.argtypes = [C.POINTER(C.c_longlong)]
+        l.orc_acos.restype = C.c_double
+        l.orc_acos.argtypes = [C.c_double, C.c_int]
         l.orc_set_foam_variant.argtypes = [C.c_void_p, C.c_int]
         l.orc_set_sync_variant.argtypes = [C.c_void_p, C.c_int]
         l.orc_multi_set_sync_variant.argtypes = [C.c_void_p, C.c_int]
@@ -425,6 +431,35 @@ class MultiOracle:
         if getattr(self, "_h", None):
             self._lib.orc_multi_destroy(self._h)
             self._h = None
+
+
+ACOS_VARIANTS = {"glibc": 0, "device": 1}
+
+
+def set_acos_variant(variant):
+    """process-wide: "glibc" (default: std::acos, the reference's arithmetic) / "device" (the algorithm the kernels evaluate,
+    smoothmesh_amd/csrc/smacos.hpp: a fixed sequence of IEEE operations, bit-identical on CPU and GPU -- with it the engine's angle
+    fields are compared bit for bit).  Returns the previous variant's name."""
+    l = lib()
+    prev = {v: k for k, v in ACOS_VARIANTS.items()}[l.orc_get_acos_variant()]
+    l.orc_set_acos_variant(ACOS_VARIANTS[variant])
+    return prev
+
+
+def acos(x, variant="device"):
+    return float(lib().orc_acos(float(x), ACOS_VARIANTS[variant]))
+
+
+def acos_census(enable=None):
+    """enable=True: reset and start counting the threshold comparisons of angles (SM.C:923, 1367, 1391-1394, 1421-1424); False: stop.
+    Returns {"comparisons", "equal" (both sides the same bits: the same function of the same inputs), "within_8ulp" (sides 1 .. 8 ulp
+    apart: what a last-bit difference between two acos implementations could flip), "min_ulp" (over the unequal pairs)}."""
+    l = lib()
+    if enable is not None:
+        l.orc_acos_census_enable(1 if enable else 0)
+    out = (C.c_longlong * 4)()
+    l.orc_acos_census(out)
+    return {"comparisons": int(out[0]), "equal": int(out[1]), "within_8ulp": int(out[2]), "min_ulp": None if out[3] < 0 else int(out[3])}
 
 
 def edge_strings(nPoints, edges):

@@ -17,9 +17,46 @@
 #include <cstdlib>
 #include <map>
 #include <numeric>
+#include <cstring>
 #include <stack>
 
+#include "../smoothmesh_amd/csrc/smacos.hpp"      // the product's acos as a fixed sequence of IEEE operations (host path: plain C++)
+
 namespace orc {
+
+// acos variant: 0 = glibc's std::acos, the reference's arithmetic (default); 1 = the algorithm the device kernels evaluate
+// (smacos::acosX, bit-identical on CPU and GPU) -- with it the engine's angle fields can be compared with ANGLE_TOL = 0.
+// Process-wide: edgeEdgeAngle / calcEdgeCenterEdgeAngle are free functions, as in the reference.
+static int g_acosVariant = 0;
+void setAcosVariant(int v) { g_acosVariant = v; }
+int acosVariant() { return g_acosVariant; }
+static inline double acosV(double c) { return g_acosVariant ? smacos::acosX(c) : std::acos(c); }
+
+// census of the threshold comparisons an angle takes part in (SM.C:923, 1367, 1391-1394, 1421-1424): how many there were and how
+// many had their two sides within 8 ulp of each other -- the comparisons a last-bit difference between two acos implementations
+// could flip.  Counted while enabled (tests / bench oracle legs); not thread-safe, like the loop itself.
+static AcosCensus g_census;
+static bool g_censusOn = false;
+void censusEnable(bool on) { g_censusOn = on; }
+void censusReset() { g_census = AcosCensus(); }
+AcosCensus censusGet() { return g_census; }
+static inline void censusNote(double a, double b) {
+    if (!g_censusOn) return;
+    ++g_census.comparisons;
+    if (!(a == a) || !(b == b)) return;
+    long long ia, ib;
+    std::memcpy(&ia, &a, 8); std::memcpy(&ib, &b, 8);
+    if (ia < 0) ia = (long long)0x8000000000000000ull - ia;      // (monotone map of the doubles onto the integers)
+    if (ib < 0) ib = (long long)0x8000000000000000ull - ib;
+    const unsigned long long d = ia > ib ? (unsigned long long)ia - (unsigned long long)ib : (unsigned long long)ib - (unsigned long long)ia;
+    // (equal sides: the same function of the same inputs on both sides -- a point that does not move, an angle that is its own
+    // minimum -- which no implementation of acos can tell apart; counted on their own)
+    if (d == 0ull) { ++g_census.equal; return; }
+    if (d <= 8ull) ++g_census.within8ulp;
+    if (d < g_census.minUlp) g_census.minUlp = d;
+}
+static inline bool lessC(double a, double b) { censusNote(a, b); return a < b; }
+static inline bool greaterC(double a, double b) { censusNote(a, b); return a > b; }
 
 // SM.C:172-180
 static inline double getPointDistance(const Vec3& coords1, const Vec3& coords2) {
@@ -37,7 +74,7 @@ double edgeEdgeAngle(const Vec3& cCoords, const Vec3& p1Coords, const Vec3& p2Co
     const double MAX = 0.99999;
     // std::max/std::min argument order kept: a NaN cosA maps to +MAX
     const double cosAlpha = std::max(-MAX, std::min(MAX, cosA));
-    return std::acos(cosAlpha);
+    return acosV(cosAlpha);
 }
 
 // SM.C:980-998
@@ -46,9 +83,9 @@ double calcEdgeCenterEdgeAngle(const Vec3& p0, const Vec3& cC, const Vec3& p1) {
     const double cosA1 = dot(cC, p1);
     const double MAX = 0.99999;
     const double cosAlpha0 = std::max(-MAX, std::min(MAX, cosA0));
-    const double angle0 = std::acos(cosAlpha0);
+    const double angle0 = acosV(cosAlpha0);
     const double cosAlpha1 = std::max(-MAX, std::min(MAX, cosA1));
-    const double angle1 = std::acos(cosAlpha1);
+    const double angle1 = acosV(cosAlpha1);
     return angle0 + angle1;
 }
 
@@ -781,7 +818,7 @@ void Domain::phaseB() {
             eaMinC[pointI] = minCAngle;
             eaMinN[pointI] = minNAngle;
             const double smallAngle = M_PI * prm.minAngle / 180.0;
-            if ((minNAngle < smallAngle) && (minNAngle < minCAngle)) isFrozenPoint[pointI] = 1;
+            if (lessC(minNAngle, smallAngle) && lessC(minNAngle, minCAngle)) isFrozenPoint[pointI] = 1;
         }
     }
     frozenAfterEdgeAngle = isFrozenPoint;
@@ -817,15 +854,15 @@ void Domain::phaseB() {
         while (!pointStack.empty()) {
             const int pointI = pointStack.top();
             pointStack.pop();
-            if ((pointMinAngle[pointI] > smallAngle) && (pointMaxAngle[pointI] < largeAngle)) continue;
+            if (greaterC(pointMinAngle[pointI], smallAngle) && lessC(pointMaxAngle[pointI], largeAngle)) continue;
             const Vec3 cCoords = mp[pointI];
             Vec3 nCoords = newPoints[pointI];
             if (isFrozenPoint[pointI]) nCoords = cCoords;
             if (nCoords != cCoords) {
                 double newMinFaceAngle, newMaxFaceAngle;
                 calcMinMaxFaceAngleForPoint(pointI, nCoords, -1, nCoords, newMinFaceAngle, newMaxFaceAngle);
-                if (((newMinFaceAngle < smallAngle) && (newMinFaceAngle < pointMinAngle[pointI])) ||
-                    ((newMaxFaceAngle > largeAngle) && (newMaxFaceAngle > pointMaxAngle[pointI]))) {
+                if ((lessC(newMinFaceAngle, smallAngle) && lessC(newMinFaceAngle, pointMinAngle[pointI])) ||
+                    (greaterC(newMaxFaceAngle, largeAngle) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI]))) {
                     nCoords = cCoords;
                     isFrozenPoint[pointI] = 1;
                 }
@@ -837,8 +874,8 @@ void Domain::phaseB() {
                 double newMinFaceAngle, newMaxFaceAngle;
                 calcMinMaxFaceAngleForPoint(pointI, nCoords, neighPointI, neighCoords, newMinFaceAngle,
                                             newMaxFaceAngle);
-                if (((newMinFaceAngle < smallAngle) && (newMinFaceAngle < pointMinAngle[pointI])) ||
-                    ((newMaxFaceAngle > largeAngle) && (newMaxFaceAngle > pointMaxAngle[pointI]))) {
+                if ((lessC(newMinFaceAngle, smallAngle) && lessC(newMinFaceAngle, pointMinAngle[pointI])) ||
+                    (greaterC(newMaxFaceAngle, largeAngle) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI]))) {
                     isFrozenPoint[neighPointI] = 1;
                     pointStack.push(neighPointI);
                 }

@@ -23,6 +23,17 @@
 
 namespace orc {
 
+// acos variant (process-wide): 0 = std::acos (glibc: the reference's arithmetic, default), 1 = the device kernels' algorithm
+// (smoothmesh_amd/csrc/smacos.hpp, bit-identical on CPU and GPU)
+void setAcosVariant(int v);
+int acosVariant();
+// census of the threshold comparisons of angles (smooth_oracle.cpp)
+struct AcosCensus { long long comparisons = 0, equal = 0, within8ulp = 0; unsigned long long minUlp = ~0ull; };   // minUlp: over the unequal pairs
+void censusEnable(bool on);
+void censusReset();
+AcosCensus censusGet();
+
+
 // OpenFOAM double-precision constants (doubleScalar.H), used at SM.C:259,621,1333,1486.
 constexpr double GREAT = 1.0e+15;
 constexpr double VGREAT = 1.0e+300;

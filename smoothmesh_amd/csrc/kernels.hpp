@@ -12,6 +12,7 @@
 
 #include "../../include/smgpu.h"
 #include "vec3.hpp"
+#include "smacos.hpp"
 
 namespace smgpu {
 
@@ -281,7 +282,7 @@ __device__ __forceinline__ double clampAcos(double cosA) {
     // std::max(-MAX, std::min(MAX, cosA)) with the std:: comparison forms (NaN -> +MAX)
     const double t = (cosA < MAXC) ? cosA : MAXC;
     const double c = (-MAXC < t) ? t : -MAXC;
-    return acos(c);
+    return smacos::acosX(c);      // (a fixed sequence of IEEE operations the checker can repeat bit for bit: smacos.hpp)
 }
 __device__ __forceinline__ V3 unitTo(const V3& from, const V3& to) {
     const V3 v = to - from;
@@ -730,7 +731,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s,
         maxN = (on > maxN) ? on : maxN;
     }
     // one acos evaluation per wave serves both extremes: lane 0 of each group takes maxC, lane 1 maxN
-    const double ang = acos((g == 0) ? maxC : maxN);
+    const double ang = smacos::acosX((g == 0) ? maxC : maxN);
     const double minN = __shfl_down(ang, 1, 64);   // lane 0 of the group reads lane 1's value
     if (active && g == 0 && nf > 0) {
         const double minC = ang;

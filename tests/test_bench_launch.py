@@ -56,6 +56,8 @@ def test_bench_two_ranks_self_launched(workload, configs):
         cb = e["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "RANK 0's sub-domain" in cb["sample"]
         assert e["speedup_vs_cpu_baseline"] > 0
+        # the cost of the multi-rank code path against the rank's sub-domain as a serial mesh, and the bound it puts on weak scaling
+        assert e["halo_cost"]["serial_ms_per_step"] > 0 and 0 < e["weak_efficiency_bound"] < 1.5 and e["halo_overhead_us"] == e["halo_cost"]["halo_overhead_us"]
         rc = e["rccl"]
         assert rc["ranks_seen"] == 2 and rc["transport"] in ("direct", "torch", "push") and rc["self_check"]
         assert rc["transport"] == b["transport"]            # the small case went through the transport of the timed run
