@@ -339,6 +339,11 @@ int smgpu_set_device_share(smgpu_handle* h, int32_t nEngines);
  * often the automatic choice has changed since smgpu_set_params -- it follows the number of points outside the good range as
  * the run goes (results never depend on it); *lastCount = that number for the last iteration the GPU has closed (-1: none). */
 int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int32_t* lastCount);
+/* how the LAST smgpu_iter_begin / mid / end went out (multi-rank): multiRole = geometry + pack and combine + smoothing + packF as
+ * the two multi-role launches on tiles of the shared points (constraints off; 0 = one kernel per step), flagged = the host's
+ * exchanges on the exchange stream ordered by flag words next to those launches, fixInside = k_shared_fix's work as a role of
+ * the smoothing launch (peer-store transport) */
+int smgpu_debug_halo_mode(smgpu_handle* h, int32_t* multiRole, int32_t* flagged, int32_t* fixInside);
 
 /* self-test of the geometry kernel's range-tested square root / division fast paths (csrc/fpexact.hpp) against the plain
  * IEEE operators on n generated arguments (random, zeros, denormals, inf / nan, both ends of the exponent range) on the

@@ -43,6 +43,11 @@ for name, env, overlap in cases:
     ds.set_params(default_params(ds.global_min_edge(), edgeAngleConstraint=False, faceAngleConstraint=False))
     done, res, frz = ds.iterate(iters, 0.0)
     pts = ds.get_points()
+    hm = ds.engine.debug_halo_mode()
+    want = {"multi_role": "multi-role" in name, "flagged": "flagged" in name}
+    if (hm["multi_role"], hm["flagged"]) != (want["multi_role"], want["flagged"]):
+        print(f"{name}: the engine took another path: {hm}")
+        bad += 1
     ds.close()
     got = (done, res.copy(), frz.copy(), pts.copy())
     if ref is None:

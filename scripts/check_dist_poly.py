@@ -55,6 +55,8 @@ for constraints in (False, True):
         diff = float(np.max(np.abs(ds.engine.get_points() - orcs[rank].points())))
         ok = n_o == n_g and np.array_equal(np.asarray(frz_o), np.asarray(frz_g)) and diff <= 1e-13
         transport = "peer stores" if ds.pushbuf is not None else ("send/recv groups" if ds.direct is not None else backend)
+        hm = ds.engine.debug_halo_mode()
+        transport += ", " + ("multi-role launches" + (", flagged" if hm["flagged"] else "") + (", fix inside" if hm["fix_inside"] else "") if hm["multi_role"] else "one kernel per step")
         print(f"rank {rank} constraints {constraints} overlap {overlap} [{transport}]: {'ok' if ok else 'BAD'} max diff {diff:.2e} frozen {list(frz_g)[-1]}", flush=True)
         bad += 0 if ok else 1
         ds.close()

@@ -31,6 +31,13 @@ run rccl_python_2      python3 -m pytest -x -q -m gpu "tests/test_gpu_multirank.
 if [ "$N" -ge 8 ]; then run rccl_python_8 python3 -m pytest -x -q -m gpu "tests/test_gpu_multirank.py::test_distributed_smoother_polyhedral_over_rccl[8]"; fi
 run rccl_cli_2         python3 -m pytest -x -q -m gpu "tests/test_gpu_cli.py::test_parallel_case_over_rccl_when_the_box_has_two_gpus"
 
+# 1b. the same two-rank case with the one-kernel-per-step form of the iteration (the A/B of the multi-role launches: step 1 ran
+#     k_geom_halo / k_smooth_halo in order and -- overlap True -- flagged, the log lines say which) and, traced: one profiler per
+#     rank started by the launcher (which never touches the GPU; the interpreter directly behind `--`), so that the first run also
+#     yields the exchange timeline (kernel trace + statistics per rank under $OUT/trace/)
+run rccl_one_kernel_per_step env SMGPU_HALO_MERGED=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29552 scripts/check_dist_poly.py
+run rccl_traced        sh -c "cd /tmp && TMPDIR=/tmp python3 -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29553 rocprofv3 --kernel-trace --stats --output-format csv -d $PWD/$OUT/trace -- python3 $PWD/scripts/check_dist_poly.py"
+
 # 2. irregular sub-domains over RCCL (a rank without shared points, ragged counts), one process per device
 run rccl_irregular     env CHECK_IRREGULAR=two_blocks:41 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29551 scripts/check_dist_poly.py
 

@@ -108,6 +108,7 @@ SYMBOLS = {
     "smgpu_push_free": (C.c_int, [C.c_void_p]),
     "smgpu_set_device_share": (C.c_int, [C.c_void_p, C.c_int32]),
     "smgpu_debug_walk_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "smgpu_debug_halo_mode": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "smgpu_debug_selftest_fpexact": (C.c_int, [C.c_int32, C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
     "smgpu_iterate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(IterStats), c_i32p]),
     "smgpu_get_points": (C.c_int, [C.c_void_p, c_f64p]),

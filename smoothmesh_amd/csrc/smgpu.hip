@@ -1615,6 +1615,14 @@ int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int
     return 0;
 }
 
+int smgpu_debug_halo_mode(smgpu_handle* h, int32_t* multiRole, int32_t* flaggedOut, int32_t* fixInside) {
+    if (!h || !multiRole || !flaggedOut || !fixInside) return fail("null argument");
+    *multiRole = h->mergedIter ? 1 : 0;
+    *flaggedOut = (h->mergedIter && h->useExch) ? 1 : 0;
+    *fixInside = (h->mergedIter && h->fixInSmooth) ? 1 : 0;
+    return 0;
+}
+
 int smgpu_get_points(smgpu_handle* h, double* out) {
     if (!h || !out) return fail("null argument");
     HIP_OK(hipSetDevice(h->device));

@@ -444,6 +444,12 @@ class SmoothEngine:
         self.last_active_count = cnt.value
         return mode.value, sw.value
 
+    def debug_halo_mode(self):
+        """how the last multi-rank iteration went out: {"multi_role", "flagged", "fix_inside"} (include/smgpu.h)"""
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._check(self._lib.smgpu_debug_halo_mode(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"multi_role": bool(a.value), "flagged": bool(b.value), "fix_inside": bool(c.value)}
+
     def set_device_share(self, n_engines):
         """n_engines engines compute on this device at the same time: the persistent walk replay takes its share of the chip"""
         self._check(self._lib.smgpu_set_device_share(self._h, int(n_engines)))

@@ -11,6 +11,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the record of a run shows where its time went (the GPU suite has a wall-clock limit at the driver)
+    if getattr(config.option, "durations", None) is None:
+        config.option.durations = 10
 
 
 def rel_linf(a, b):

@@ -9,6 +9,8 @@ coordinates within 1e-13 relative L-inf (north star: 1e-10; measured: bit-equal)
 Cost: the serial oracle takes ~0.25 / 1.3 / 1.7 s per iteration on the 1 M-cell meshes and ~50 s of set-up plus ~30 s per
 constrained iteration on the 10 M-cell mesh -- k is sized accordingly.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -108,7 +110,11 @@ def test_cavity215c_matches_oracle(oracle_lib, cavity215):
         p = default_params(o.mesh_stats()[0])
         o.set_params(p); e.set_params(p)
         done, series = 0, []
-        for chunk in (1, 1, 4, 6):
+        # (SMOOTHMESH_BIG_TESTS=1: twelve iterations as in rounds 3-4; the default selection stops at eight -- the serial oracle is
+        # ~20 s per constrained iteration at this size, and the whole GPU suite has to stay well inside the driver's time limit;
+        # BASELINE's full 200 iterations of this configuration are compared in profiles/r4/parity_long.jsonl)
+        big = bool(os.environ.get("SMOOTHMESH_BIG_TESTS"))
+        for chunk in ((1, 1, 4, 6) if big else (1, 1, 2, 4)):
             n_o, res_o, frz_o = o.iterate(chunk, 0.0)
             n_g, res_g, frz_g = e.iterate(chunk, 0.0)
             done += chunk
@@ -117,7 +123,7 @@ def test_cavity215c_matches_oracle(oracle_lib, cavity215):
             assert np.max(np.abs(res_o - res_g) / np.maximum(res_o, 1e-300)) <= 1e-10
             assert rel_linf(e.get_points(), o.points()) <= COORD_TOL, done
             series += [int(x) for x in frz_g]
-        assert done == 12 and series[0] > 500_000 and series[-1] != series[0]
+        assert done == (12 if big else 8) and series[0] > 500_000 and series[-1] != series[0]
         assert np.array_equal(e.get_points(), o.points())                     # measured: bit-equal
         p2 = default_params(o.mesh_stats()[0], edgeAngleConstraint=False, faceAngleConstraint=False)
         o.set_params(p2); e.set_params(p2)
