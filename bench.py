@@ -216,7 +216,7 @@ def kernel_report(workload, ctr, K, dt, dt_ev, sizes=None):
     # committed under profiles/; None when no measurement of this workload exists
     traffic = None
     tdoc = None
-    for rnd in ("r4", "r3", "r2", "r1"):
+    for rnd in ("r5", "r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{workload}.json")
         if os.path.exists(tpath):
             tdoc = json.load(open(tpath))
@@ -691,7 +691,7 @@ def finalize_line(out):
         par = e.get("parity_check")
         b = {"workload": wl, "steps": e.get("steps"), "ms_per_step": e.get("ms_per_step"), "points_per_s": e.get("value"),
              "parity_ok": None if par is None else bool(par.get("ok", False)),
-             "bitwise_equal": None if par is None else par.get("bitwise_equal"),
+             "bitwise_equal": None if par is None else par.get("bitwise_equal", (par.get("small_case") or {}).get("bitwise_equal_on_every_rank")),
              "cpu_ratio": e.get("speedup_vs_cpu_baseline")}
         if "error" in e:
             b["error"] = e["error"]

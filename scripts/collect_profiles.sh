@@ -1,7 +1,7 @@
 #!/bin/bash
 # run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
-# usage: scripts/collect_profiles.sh [round tag, default r4]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
-tag=${1:-r4}
+# usage: scripts/collect_profiles.sh [round tag, default r5]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+tag=${1:-r5}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
@@ -46,4 +46,11 @@ cp gpurun_out/probe_timeline/timeline_boundary.txt $out/probe_rank_of_8_timeline
 SMOOTHMESH_EXCHANGE=push timeout 900 bash scripts/probe_timeline.sh > /dev/null 2>&1
 cp gpurun_out/probe_timeline/probe.txt $out/probe_rank_of_8_push.txt; cp gpurun_out/probe_timeline/timeline.txt $out/probe_rank_of_8_timeline_push.txt
 cp gpurun_out/probe_timeline/timeline_boundary.txt $out/probe_rank_of_8_timeline_boundary_push.txt
+# the same probe with the absolute timeline of all streams (in order / exchange stream), the arrangement equality check, and the
+# set-up phases on this box's host
+timeout 600 bash scripts/probe_timeline2.sh > /dev/null 2>&1
+cp gpurun_out/probe_timeline2/inorder.txt $out/probe_rank_of_8_abs_timeline_inorder_rccl.txt; cp gpurun_out/probe_timeline2/overlap.txt $out/probe_rank_of_8_abs_timeline_flagged_rccl.txt
+(timeout 300 python3 scripts/check_arrangements.py 2>&1 | grep -E "reference|same bits|DIFFERENT|arrangements"; SMOOTHMESH_EXCHANGE=push timeout 300 python3 scripts/check_arrangements.py 2>&1 | grep -E "reference|same bits|DIFFERENT|arrangements") > $out/check_arrangements.txt
+SMGPU_HALO_MERGED=0 timeout 300 python3 scripts/probe_rank_of_8.py 2>&1 | grep -E "rank 0 of 8|inorder|overlap|serial|transport" > $out/probe_rank_of_8_rccl_one_kernel_per_step.txt
+SMGPU_HALO_MERGED=0 SMOOTHMESH_EXCHANGE=push timeout 300 python3 scripts/probe_rank_of_8.py 2>&1 | grep -E "rank 0 of 8|inorder|overlap|serial|transport" > $out/probe_rank_of_8_push_one_kernel_per_step.txt
 ls -la $out

@@ -38,6 +38,9 @@ run rccl_cli_2         python3 -m pytest -x -q -m gpu "tests/test_gpu_cli.py::te
 run rccl_one_kernel_per_step env SMGPU_HALO_MERGED=0 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29552 scripts/check_dist_poly.py
 run rccl_traced        sh -c "cd /tmp && TMPDIR=/tmp python3 -m torch.distributed.run --no-python --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29553 rocprofv3 --kernel-trace --stats --output-format csv -d $PWD/$OUT/trace -- python3 $PWD/scripts/check_dist_poly.py"
 
+# 1c. the C++ front-end with its exchanges on a stream of their own (flagged arrangement; opt-in there until this step has passed)
+run rccl_cli_2_exchange_stream env SMOOTHMESH_EXCHANGE_STREAM=1 python3 -m pytest -x -q -m gpu "tests/test_gpu_cli.py::test_parallel_case_over_rccl_when_the_box_has_two_gpus"
+
 # 2. irregular sub-domains over RCCL (a rank without shared points, ragged counts), one process per device
 run rccl_irregular     env CHECK_IRREGULAR=two_blocks:41 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 3 --master-addr 127.0.0.1 --master-port 29551 scripts/check_dist_poly.py
 

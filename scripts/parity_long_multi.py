@@ -24,6 +24,10 @@ from smoothmesh_amd.polymesh import cavity_mesh  # noqa: E402
 def run(spec):
     kind, iters = spec.split(":")
     iters = int(iters)
+    # a trailing "_off": constraints off -- the iteration then goes out as the two multi-role launches on tiles of the shared points
+    # (k_geom_halo / k_smooth_halo, round 5); the engine says which form ran (`form` in the line)
+    constraints = not kind.endswith("_off")
+    kind = kind[:-4] if not constraints else kind
     if kind == "boxes":          # configs[1]/[2]'s family: 2 x 2 x 2 boxes of 32^3 cells, constraints on
         subs = [hex_subdomain((32, 32, 32), (2, 2, 2), r, jitter=0.2, seed=12345) for r in range(8)]
         what = "2x2x2 boxes of 32^3 hex cells"
@@ -32,7 +36,7 @@ def run(spec):
         subs = decompose(gm, bfs_partition(gm, 5, seed=7, island=True), 5)
         what = f"polyhedral cavity mesh ({gm.nCells} cells), five breadth-first grown sub-domains, one of them disconnected"
     orcs = [oracle_ffi.Oracle(s.mesh) for s in subs]
-    prm = default_params(min(o.mesh_stats()[0] for o in orcs))
+    prm = default_params(min(o.mesh_stats()[0] for o in orcs), edgeAngleConstraint=constraints, faceAngleConstraint=constraints)
     for o in orcs:
         o.set_params(prm)
     mo = oracle_ffi.MultiOracle(orcs, *shared_point_table(subs))
@@ -53,7 +57,9 @@ def run(spec):
         same = all(np.array_equal(p, o.points()) for p, o in zip(ms.get_points(), orcs))
         bitwise = bitwise and same
         checkpoints.append({"after": done, "bitwise_equal": bool(same), "nFrozenPoints": int(frz_g[-1]), "residual": float(res_g[-1])})
-    return {"case": kind, "what": what, "ranks": len(subs), "points": int(sum(s.mesh.nPoints for s in subs)), "iterations": iters,
+    hm = ms.states[0].eng.debug_halo_mode()
+    return {"case": kind + ("" if constraints else "_off"), "what": what + (", constraints on" if constraints else ", constraints off"),
+            "form": "multi-role launches" if hm["multi_role"] else "one kernel per step", "ranks": len(subs), "points": int(sum(s.mesh.nPoints for s in subs)), "iterations": iters,
             "compared_every": chunk, "bitwise_equal": bitwise, "nFrozen_series_equal": frozen_equal, "ok": bitwise and frozen_equal,
             "oracle_seconds": t_or, "wall_seconds": time.perf_counter() - t0, "checkpoints": checkpoints}
 

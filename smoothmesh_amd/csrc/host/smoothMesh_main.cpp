@@ -489,6 +489,10 @@ std::vector<int64_t> processorPatchLists(const Rank& K) {
 
 int main(int argc, char** argv) {
     const auto t0 = std::chrono::steady_clock::now();
+    // where the ClockTime of the last line goes (the reference prints the total only, SM.C:2439): read the case, set the engine up
+    // (addressing, tile tables, upload, halo tables), the smoothing loop itself, mesh output
+    double tRead = 0.0, tCreate = 0.0, tLoop = 0.0, tWrite = 0.0;
+    auto secondsSince = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     const Options opt = parseArgs(argc, argv);
     const std::string& cd = opt.caseDir;
 
@@ -539,7 +543,7 @@ int main(int argc, char** argv) {
         for (Rank& K : R) {
             const std::string meshDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "faces");
             const std::string ptsDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "points");
-            readPolyMesh(meshDir, ptsDir == meshDir ? "" : ptsDir, K.mesh);
+            { const auto tr = std::chrono::steady_clock::now(); readPolyMesh(meshDir, ptsDir == meshDir ? "" : ptsDir, K.mesh); tRead += secondsSince(tr); }
             K.internal = findInternalMeshPoints(K.mesh);
             if (opt.parallel) {
                 // shared points are matched by decomposePar's global ids where the file is there, and through the processor patches
@@ -660,7 +664,7 @@ int main(int argc, char** argv) {
         d.isInternalPoint = K.internal.data(); d.isSmoothingSurfacePoint = nullptr;
         K.device = (dev0 + myRank) % nDev;
         d.device = K.device; d.stream = nullptr; d.useCallerStream = 0;
-        check(smgpu_create(&d, &K.h), "smgpu_create");
+        { const auto tc = std::chrono::steady_clock::now(); check(smgpu_create(&d, &K.h), "smgpu_create"); tCreate += secondsSince(tc); }
         // several ranks on one device (a debugging arrangement): every rank's persistent walk replay needs all of its workgroups
         // resident at once, so each takes its share of the chip (the engine's default is sized for a device of its own)
         if (nRanks > nDev) check(smgpu_set_device_share(K.h, (nRanks + nDev - 1) / nDev), "smgpu_set_device_share");
@@ -998,6 +1002,22 @@ int main(int argc, char** argv) {
     // in the same group: one collective kernel); nothing waits on the host.  shm: the same records staged through the ranks'
     // mapping (D2H, barrier, H2D, barrier).
     struct Part { const void* send; void* recv; size_t bytesPerSlot; };
+    // SMOOTHMESH_EXCHANGE_STREAM=1 (RCCL transport, opt-in until it has run on a node with several GPUs -- scripts/first_multi_gpu.sh):
+    // the send / recv groups go onto a high-priority stream of their own and the engine orders them against its kernels with flag
+    // words (include/smgpu.h, smgpu_halo_set_exchange_stream: with the constraints off the two multi-role launches then run next
+    // to both exchanges -- one rank of eight: 123 instead of 135 us per iteration in the Python driver's probe).  Set behind the
+    // start-up self-check below, which uses the engine's stream.
+    hipStream_t xchgStream = engineStream;
+    auto enableExchangeStream = [&]() {
+        const char* v = std::getenv("SMOOTHMESH_EXCHANGE_STREAM");
+        if (!(v && std::atoi(v) != 0) || transport != TRANSPORT_RCCL || !opt.parallel) return;
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));      // (hi = the numerically lowest value = the highest priority)
+        HIPCHK(hipStreamCreateWithPriority(&xchgStream, hipStreamNonBlocking, hi));
+        check(smgpu_halo_set_exchange_stream(K0.h, 1, (void*)xchgStream), "smgpu_halo_set_exchange_stream");
+        if (myRank == 0) OUT("Exchanges on a stream of their own (SMOOTHMESH_EXCHANGE_STREAM)\n\n");
+    };
+    auto syncExchangeStream = [&]() { if (xchgStream != engineStream) HIPCHK(hipStreamSynchronize(xchgStream)); };
     auto exchange = [&](std::initializer_list<Part> parts) {
         if (transport == TRANSPORT_PUSH) return;   // the pack kernels have stored the records at the peers themselves
         if (transport == TRANSPORT_RCCL) {
@@ -1007,8 +1027,8 @@ int main(int argc, char** argv) {
                     const size_t c = (size_t)K0.peerCount[o];
                     if (!c) continue;
                     const size_t off = (size_t)K0.peerSendBase[o] * pt.bytesPerSlot;
-                    NCCLCHK(ncclSend((const char*)pt.send + off, c * pt.bytesPerSlot, ncclChar, o, nccl, engineStream));
-                    NCCLCHK(ncclRecv((char*)pt.recv + off, c * pt.bytesPerSlot, ncclChar, o, nccl, engineStream));
+                    NCCLCHK(ncclSend((const char*)pt.send + off, c * pt.bytesPerSlot, ncclChar, o, nccl, xchgStream));
+                    NCCLCHK(ncclRecv((char*)pt.recv + off, c * pt.bytesPerSlot, ncclChar, o, nccl, xchgStream));
                 }
             NCCLCHK(ncclGroupEnd());
             return;
@@ -1065,8 +1085,11 @@ int main(int argc, char** argv) {
         else
             fatal("RCCL exchange self-check failed: the records that arrived are not the ones the peers sent (set SMOOTHMESH_TRANSPORT=shm to run on the host-staged transport)");
     }
+    enableExchangeStream();
 
     auto writeMesh = [&](double timeValue) {
+        const auto tw = std::chrono::steady_clock::now();
+        struct Stop { double& acc; std::chrono::steady_clock::time_point a; ~Stop() { acc += std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); } } stop{tWrite, tw};
         const std::string tn = timeName(timeValue);
         OUT("Writing new mesh to time %s\n\n", tn.c_str());
         for (Rank& K : R) {
@@ -1098,6 +1121,7 @@ int main(int argc, char** argv) {
         long chunk = std::min(centroidalIters - i, writeInterval - (i % writeInterval));
         int32_t done = 0;
         stats.assign((size_t)chunk, smgpu_iter_stats{});
+        const auto tl = std::chrono::steady_clock::now();
         if (!opt.parallel) {
             check(smgpu_iterate(R[0].h, (int32_t)chunk, relTol, stats.data(), &done), "smgpu_iterate");
         } else {
@@ -1137,6 +1161,7 @@ int main(int argc, char** argv) {
             // an error word raised by a kernel of this chunk (a peer's records that never came, a grid barrier that could not
             // complete, a point without usable neighbours): found here, not a writeInterval later
             check(smgpu_check_error(K0.h), "smgpu_check_error");
+            syncExchangeStream();
             if (noStop) {
                 check(smgpu_halo_set_stats_history(K0.h, nullptr, 0), "smgpu_halo_set_stats_history");   // closes the last iteration
                 std::vector<double> hist((size_t)chunk * 2);
@@ -1151,6 +1176,7 @@ int main(int argc, char** argv) {
                 }
             }
         }
+        tLoop += secondsSince(tl);
         for (int32_t k = 0; k < done; ++k)
             OUT("Smoothing iteration=%ld nFrozenPoints=%d residual=%g\n", i + k + 1, stats[(size_t)k].nFrozenPoints, stats[(size_t)k].residual);
         i += done;
@@ -1163,7 +1189,7 @@ int main(int argc, char** argv) {
         if (done == 0) break;
     }
 
-    if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); NCCLCHK(ncclCommDestroy(nccl)); }
+    if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); syncExchangeStream(); NCCLCHK(ncclCommDestroy(nccl)); }
     if (transport == TRANSPORT_PUSH && opt.parallel) {
         HIPCHK(hipStreamSynchronize(engineStream));
         g_comm.barrier();                          // nobody unmaps a buffer a peer may still store into
@@ -1174,6 +1200,8 @@ int main(int argc, char** argv) {
     for (Rank& K : R) smgpu_destroy(K.h);
     g_comm.barrier();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    OUT("ClockTime breakdown: read %.2f s, engine set-up %.2f s, smoothing loop %.3f s, write %.2f s, other %.2f s\n", tRead, tCreate, tLoop, tWrite,
+        std::max(0.0, secs - tRead - tCreate - tLoop - tWrite));
     OUT("ClockTime = %d s.\n\nEnd\n", (int)secs);
     return 0;
 }

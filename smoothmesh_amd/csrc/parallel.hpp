@@ -13,8 +13,9 @@ namespace smgpu {
 inline unsigned hostThreads() {
     static const unsigned n = [] {
         const char* e = std::getenv("SMGPU_HOST_THREADS");
-        const unsigned h = e ? (unsigned)std::atoi(e) : std::thread::hardware_concurrency();
-        return std::max(1u, std::min(h, 32u));
+        // (the default stops at 32; an explicit setting may go up to 256 -- the phases are memory-bound scatters and merges)
+        if (e) return std::max(1u, std::min((unsigned)std::atoi(e), 256u));
+        return std::max(1u, std::min(std::thread::hardware_concurrency(), 32u));
     }();
     return n;
 }
