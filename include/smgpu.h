@@ -343,6 +343,10 @@ int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int
  * the two multi-role launches on tiles of the shared points (constraints off; 0 = one kernel per step), flagged = the host's
  * exchanges on the exchange stream ordered by flag words next to those launches, fixInside = k_shared_fix's work as a role of
  * the smoothing launch (peer-store transport) */
+/* FNV-1a checksums of every array of the addressing in a fixed order (SMGPU_TOPO_CHECKSUMS words; [0] = sizes and maxima): the
+ * engine's (built on the device where the mesh allows, csrc/topology_dev.hip) against smgpu_topology_checksums of the host build */
+#define SMGPU_TOPO_CHECKSUMS 32
+int smgpu_debug_addressing_checksums(smgpu_handle* h, uint64_t* out /* [SMGPU_TOPO_CHECKSUMS] */);
 int smgpu_debug_halo_mode(smgpu_handle* h, int32_t* multiRole, int32_t* flagged, int32_t* fixInside);
 
 /* self-test of the geometry kernel's range-tested square root / division fast paths (csrc/fpexact.hpp) against the plain
@@ -370,6 +374,7 @@ typedef struct smgpu_topology smgpu_topology;
 int smgpu_topology_create(const smgpu_mesh_desc* desc, smgpu_topology** out);
 int smgpu_topology_get(smgpu_topology* t, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz);
 int smgpu_topology_num_edges(smgpu_topology* t, int32_t* nEdges);
+int smgpu_topology_checksums(smgpu_topology* t, uint64_t* out /* [SMGPU_TOPO_CHECKSUMS], see smgpu_debug_addressing_checksums */);
 int smgpu_topology_destroy(smgpu_topology* t);
 
 #ifdef __cplusplus

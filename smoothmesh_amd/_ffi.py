@@ -145,6 +145,8 @@ SYMBOLS = {
     "smgpu_topology_create": (C.c_int, [C.POINTER(MeshDesc), C.POINTER(C.c_void_p)]),
     "smgpu_topology_get": (C.c_int, [C.c_void_p, C.c_char_p, c_i32p, c_i32p, C.POINTER(C.c_int64)]),
     "smgpu_topology_num_edges": (C.c_int, [C.c_void_p, c_i32p]),
+    "smgpu_topology_checksums": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "smgpu_debug_addressing_checksums": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "smgpu_topology_destroy": (C.c_int, [C.c_void_p]),
 }
 

@@ -468,16 +468,16 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     std::future<std::string> fGeom, fSmooth;
     std::vector<int32_t> pointOrder;
     std::vector<uint8_t> internalMask;
+    DeviceTopologyArrays devTopo;      // a device build's arrays: the kernels read them as they are (no upload of the host copy)
     {
         const int geomT0 = envInt("SMGPU_GEOM_T", 256), smoothT0 = envInt("SMGPU_SMOOTH_T", 256);
         const int geomCells0 = envInt("SMGPU_GEOM_CELLS", geomT0 / 2);
         const int capGP0 = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells0, 1400)), capGF0 = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells0, 1400));
         const int capSC0 = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * smoothT0, 1500)), capSN0 = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * smoothT0, 1500));
         const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256, smoothOk = smoothT0 == 64 || smoothT0 == 128 || smoothT0 == 256;
-        const std::string terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour,
-            [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0] {
-                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); },
-            [&] {
+        const auto afterCells = [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0] {
+                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); };
+        const auto afterPoints = [&] {
                 if (!(wantTiles && geomOk && smoothOk)) return;
                 if (fPointOrder.valid()) pointOrder = fPointOrder.get();
                 internalMask.resize((size_t)d->nPoints);
@@ -486,7 +486,28 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0] {
                     return h->stl.build(h->topo, d->points, internalMask.data(), mortonTiles, smoothT0, capSC0, capSN0,
                                         (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr); });
-            });
+            };
+        // the addressing on the device (topology_dev.hip: sorts + per-edge kernels, ~0.2 s for 10 M cells against 3.5 s of host
+        // loops); the host build where the device path hands the mesh back (unusual meshes; it also words the reference's errors)
+        std::string terr;
+        int dev = envInt("SMGPU_DEVICE_TOPOLOGY", 1) ? 1 : -1;
+        if (dev > 0) {
+            std::string why;
+            dev = buildTopologyOnDevice(h->topo, d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour, h->device, why,
+                                        afterCells, afterPoints, &devTopo);
+            if (dev == 2) {
+                if (fGeom.valid()) fGeom.wait();
+                if (fSmooth.valid()) fSmooth.wait();
+                if (fPointOrder.valid()) fPointOrder.wait();
+                delete h;
+                return fail("smgpu_create: device addressing: " + why);
+            }
+            if (envInt("SMGPU_VERBOSE", 0) >= 1) std::fprintf(stderr, "[smgpu] addressing on the %s (%.2f s since create)\n", dev == 0 ? "device" : "host (device path handed the mesh back)", sinceCreate());
+        }
+        if (dev != 0) {
+            h->topo = Topology();
+            terr = h->topo.build(d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour, afterCells, afterPoints);
+        }
         if (!terr.empty()) {
             if (fGeom.valid()) fGeom.wait();
             if (fSmooth.valid()) fSmooth.wait();
@@ -495,10 +516,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             return fail("smgpu_create: " + terr);
         }
     }
+    bool devAdopted = false;
     auto cleanup = [&](int rc) {   // (the host threads still read the handle's tables)
         if (fGeom.valid()) fGeom.wait();
         if (fSmooth.valid()) fSmooth.wait();
         if (fPointOrder.valid()) fPointOrder.wait();
+        if (devTopo.valid && !devAdopted)      // a device build's arrays the handle has not taken over yet
+            for (const DeviceTopologyArrays::Arr* a : {&devTopo.faceOff, &devTopo.facePts, &devTopo.cfOff, &devTopo.cfVal, &devTopo.pcOff, &devTopo.pcVal, &devTopo.ppOff,
+                                                       &devTopo.ppPt, &devTopo.peEdge, &devTopo.pfOff, &devTopo.pfFace, &devTopo.pfPrev, &devTopo.pfNext, &devTopo.pfPrevSlot,
+                                                       &devTopo.pfNextSlot, &devTopo.ringFace, &devTopo.ringCell, &devTopo.edgeRingOk, &devTopo.edges, &devTopo.efOff,
+                                                       &devTopo.efFace, &devTopo.ecOff, &devTopo.ecCell, &devTopo.ecF0, &devTopo.ecF1})
+                if (a->p) (void)hipFree(a->p);
         smgpu_destroy(h);
         return rc;
     };
@@ -510,39 +538,83 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     }
     const Topology& t = h->topo;
     MeshView& m = h->mv;
+    // the edge tile tables (face-angle filter) need the whole addressing: they start here, next to the uploads below and to the
+    // other two tile builds (before round 5 they started behind the uploads)
+    std::future<std::string> fEdge;
+    const double tTopo = sinceCreate();
+    if (wantTiles) {
+        if (fPointOrder.valid()) pointOrder = fPointOrder.get();
+        const std::vector<int32_t>* po = (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr;
+        const bool wantFilter = envInt("SMGPU_FILTER", 1) != 0;
+        fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles]() -> std::string {
+            return wantFilter ? h->etl.build(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po) : std::string("not built");
+        });
+    }
+    auto cleanupE = [&](int rc0) { if (fEdge.valid()) fEdge.wait(); return cleanup(rc0); };
     m.nPoints = t.nPoints; m.nCells = t.nCells; m.nFaces = t.nFaces; m.nInternalFaces = t.nInternalFaces; m.nEdges = t.nEdges;
     std::vector<uint8_t> flags(t.nPoints);
     for (int p = 0; p < t.nPoints; ++p)
         flags[p] = (d->isInternalPoint[p] ? PF_INTERNAL : 0) |
                    ((d->isSmoothingSurfacePoint && d->isSmoothingSurfacePoint[p]) ? PF_SMOOTHSURF : 0);
     int rc = 0;
-    rc |= devUpload(h, &m.faceOff, t.facePoints.off);
-    rc |= devUpload(h, &m.facePts, t.facePoints.val);
-    rc |= devUpload(h, &m.cfOff, t.cellFacesGeom.off);
-    rc |= devUpload(h, &m.cfVal, t.cellFacesGeom.val);
-    rc |= devUpload(h, &m.pcOff, t.pointCells.off);
-    rc |= devUpload(h, &m.pcVal, t.pointCells.val);
-    rc |= devUpload(h, &m.ppOff, t.pointEdges.off);
-    rc |= devUpload(h, &m.ppPt, t.pointPoints);
-    rc |= devUpload(h, &m.peEdge, t.pointEdges.val);
-    rc |= devUpload(h, &m.pfOff, t.pointFaces.off);
-    rc |= devUpload(h, &m.pfFace, t.pointFaces.val);
-    rc |= devUpload(h, &m.pfPrev, t.pfPrev);
-    rc |= devUpload(h, &m.pfNext, t.pfNext);
-    rc |= devUpload(h, &m.pfPrevSlot, t.pfPrevSlot);
-    rc |= devUpload(h, &m.pfNextSlot, t.pfNextSlot);
-    rc |= devUpload(h, &m.ringFace, t.ringFace);
-    rc |= devUpload(h, &m.ringCell, t.ringCell);
-    rc |= devUpload(h, &m.edgeRingOk, t.edgeRingOk);
-    rc |= devUpload(h, &m.edges, t.edges);
-    rc |= devUpload(h, &m.efOff, t.edgeFaces.off);
-    rc |= devUpload(h, &m.efFace, t.edgeFaces.val);
-    rc |= devUpload(h, &m.ecOff, t.edgeCells.off);
-    rc |= devUpload(h, &m.ecCell, t.edgeCells.val);
-    rc |= devUpload(h, &m.ecF0, t.ecFace0);
-    rc |= devUpload(h, &m.ecF1, t.ecFace1);
+    // the addressing on the device: a device build's own arrays (topology_dev.hip), else uploads of the host build's lists
+    auto adopt = [&](auto*& dst, const DeviceTopologyArrays::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
+    if (devTopo.valid) {
+        devAdopted = true;
+        adopt(m.faceOff, devTopo.faceOff);
+        adopt(m.facePts, devTopo.facePts);
+        adopt(m.cfOff, devTopo.cfOff);
+        adopt(m.cfVal, devTopo.cfVal);
+        adopt(m.pcOff, devTopo.pcOff);
+        adopt(m.pcVal, devTopo.pcVal);
+        adopt(m.ppOff, devTopo.ppOff);
+        adopt(m.ppPt, devTopo.ppPt);
+        adopt(m.peEdge, devTopo.peEdge);
+        adopt(m.pfOff, devTopo.pfOff);
+        adopt(m.pfFace, devTopo.pfFace);
+        adopt(m.pfPrev, devTopo.pfPrev);
+        adopt(m.pfNext, devTopo.pfNext);
+        adopt(m.pfPrevSlot, devTopo.pfPrevSlot);
+        adopt(m.pfNextSlot, devTopo.pfNextSlot);
+        adopt(m.ringFace, devTopo.ringFace);
+        adopt(m.ringCell, devTopo.ringCell);
+        adopt(m.edgeRingOk, devTopo.edgeRingOk);
+        adopt(m.edges, devTopo.edges);
+        adopt(m.efOff, devTopo.efOff);
+        adopt(m.efFace, devTopo.efFace);
+        adopt(m.ecOff, devTopo.ecOff);
+        adopt(m.ecCell, devTopo.ecCell);
+        adopt(m.ecF0, devTopo.ecF0);
+        adopt(m.ecF1, devTopo.ecF1);
+    } else {
+        rc |= devUpload(h, &m.faceOff, t.facePoints.off);
+        rc |= devUpload(h, &m.facePts, t.facePoints.val);
+        rc |= devUpload(h, &m.cfOff, t.cellFacesGeom.off);
+        rc |= devUpload(h, &m.cfVal, t.cellFacesGeom.val);
+        rc |= devUpload(h, &m.pcOff, t.pointCells.off);
+        rc |= devUpload(h, &m.pcVal, t.pointCells.val);
+        rc |= devUpload(h, &m.ppOff, t.pointEdges.off);
+        rc |= devUpload(h, &m.ppPt, t.pointPoints);
+        rc |= devUpload(h, &m.peEdge, t.pointEdges.val);
+        rc |= devUpload(h, &m.pfOff, t.pointFaces.off);
+        rc |= devUpload(h, &m.pfFace, t.pointFaces.val);
+        rc |= devUpload(h, &m.pfPrev, t.pfPrev);
+        rc |= devUpload(h, &m.pfNext, t.pfNext);
+        rc |= devUpload(h, &m.pfPrevSlot, t.pfPrevSlot);
+        rc |= devUpload(h, &m.pfNextSlot, t.pfNextSlot);
+        rc |= devUpload(h, &m.ringFace, t.ringFace);
+        rc |= devUpload(h, &m.ringCell, t.ringCell);
+        rc |= devUpload(h, &m.edgeRingOk, t.edgeRingOk);
+        rc |= devUpload(h, &m.edges, t.edges);
+        rc |= devUpload(h, &m.efOff, t.edgeFaces.off);
+        rc |= devUpload(h, &m.efFace, t.edgeFaces.val);
+        rc |= devUpload(h, &m.ecOff, t.edgeCells.off);
+        rc |= devUpload(h, &m.ecCell, t.edgeCells.val);
+        rc |= devUpload(h, &m.ecF0, t.ecFace0);
+        rc |= devUpload(h, &m.ecF1, t.ecFace1);
+    }
     rc |= devUpload(h, &m.pflags, flags);
-    if (rc) return cleanup(1);
+    if (rc) return cleanupE(1);
     // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
@@ -558,26 +630,19 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (h->useTiles) {
         h->geomT = envInt("SMGPU_GEOM_T", 256);
         h->smoothT = envInt("SMGPU_SMOOTH_T", 256);
-        if (h->geomT != 64 && h->geomT != 128 && h->geomT != 256) return cleanup(fail("SMGPU_GEOM_T must be 64, 128 or 256"));
-        if (h->smoothT != 64 && h->smoothT != 128 && h->smoothT != 256) return cleanup(fail("SMGPU_SMOOTH_T must be 64, 128 or 256"));
+        if (h->geomT != 64 && h->geomT != 128 && h->geomT != 256) return cleanupE(fail("SMGPU_GEOM_T must be 64, 128 or 256"));
+        if (h->smoothT != 64 && h->smoothT != 128 && h->smoothT != 256) return cleanupE(fail("SMGPU_SMOOTH_T must be 64, 128 or 256"));
         // capacities sized for a 160 KiB LDS: a tile must leave room for >= 2 workgroups per CU
         const int geomCells = envInt("SMGPU_GEOM_CELLS", h->geomT / 2);   // cells per tile (<= threads)
         const int capGP = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells, 1400));
         const int capGF = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells, 1400));   // two rounds of 256 face threads at 128 cells
         const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500));
         const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
-        const bool morton = mortonTiles;
-        const double tTopo = sinceCreate();
-        if (fPointOrder.valid()) pointOrder = fPointOrder.get();
-        const std::vector<int32_t>* po = (morton && !pointOrder.empty()) ? &pointOrder : nullptr;
-        // (the geometry and smoothing tables were started by Topology::build's hooks; SMGPU_GEOM_T etc. were read there)
+        // (the geometry and smoothing tables were started by the addressing's hooks, the edge tables behind it; SMGPU_GEOM_T etc. were read there)
         (void)geomCells; (void)capGP; (void)capGF; (void)capSC; (void)capSN;
-        auto fEdge = std::async(std::launch::async, [&]() -> std::string {
-            return h->useFilter ? h->etl.build(t, d->points, morton, 256, 512, 768, 512, po) : std::string("not built");
-        });
         const std::string e2 = fSmooth.valid() ? fSmooth.get() : std::string("not built");
         const std::string e1 = fGeom.valid() ? fGeom.get() : std::string("not built");
-        const std::string e3 = fEdge.get();
+        const std::string e3 = fEdge.valid() ? fEdge.get() : std::string("not built");
         if (envInt("SMGPU_VERBOSE", 0))
             std::fprintf(stderr, "[smgpu] set-up: addressing %.2f s, tile tables (3 host threads) %.2f s\n", tTopo, sinceCreate() - tTopo);
         if (!e1.empty() || !e2.empty()) {
@@ -2884,6 +2949,33 @@ static int topoGet(const Topology& t, const char* kind, int32_t* offsets, int32_
     return 0;
 }
 
+// FNV-1a checksum of every array of the addressing, in a fixed order (SMGPU_TOPO_CHECKSUMS entries): the device build
+// (topology_dev.hip, what an engine holds) against the host build (smgpu_topology_create) in tests/test_gpu_topology.py
+static uint64_t fnv1a(const void* p, size_t n, uint64_t hh = 1469598103934665603ull) {
+    const unsigned char* b = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { hh ^= b[i]; hh *= 1099511628211ull; }
+    return hh;
+}
+static void topoChecksums(const Topology& t, uint64_t* out) {
+    int k = 0;
+    const int32_t sizes[9] = {t.nPoints, t.nCells, t.nFaces, t.nInternalFaces, t.nEdges, t.maxFaceSize, t.maxEdgeFaces, t.maxPointCells, t.maxPointPoints};
+    out[k++] = fnv1a(sizes, sizeof(sizes));
+    auto add = [&](const auto& v) { out[k++] = fnv1a(v.data(), v.size() * sizeof(v[0])) ^ (uint64_t)v.size(); };
+    add(t.facePoints.off); add(t.facePoints.val); add(t.owner); add(t.neighbour);
+    add(t.cellFacesGeom.off); add(t.cellFacesGeom.val);
+    add(t.pointFaces.off); add(t.pointFaces.val); add(t.pfPrev); add(t.pfNext); add(t.pfPrevSlot); add(t.pfNextSlot);
+    add(t.pointCells.off); add(t.pointCells.val);
+    add(t.edges); add(t.pointEdges.off); add(t.pointEdges.val); add(t.pointPoints);
+    add(t.edgeFaces.off); add(t.edgeFaces.val); add(t.edgeCells.off); add(t.edgeCells.val); add(t.ecFace0); add(t.ecFace1);
+    add(t.ringFace); add(t.ringCell); add(t.edgeRingOk);
+    while (k < SMGPU_TOPO_CHECKSUMS) out[k++] = 0;
+}
+int smgpu_debug_addressing_checksums(smgpu_handle* h, uint64_t* out) {
+    if (!h || !out) return fail("null argument");
+    topoChecksums(h->topo, out);
+    return 0;
+}
+
 int smgpu_debug_get_addressing(smgpu_handle* h, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
     if (!h || !kind || !nnz) return fail("null argument");
     return topoGet(h->topo, kind, offsets, values, nnz);
@@ -2903,6 +2995,11 @@ int smgpu_topology_create(const smgpu_mesh_desc* d, smgpu_topology** out) {
 int smgpu_topology_get(smgpu_topology* t, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
     if (!t || !kind || !nnz) return fail("null argument");
     return topoGet(t->t, kind, offsets, values, nnz);
+}
+int smgpu_topology_checksums(smgpu_topology* t, uint64_t* out) {
+    if (!t || !out) return fail("null argument");
+    topoChecksums(t->t, out);
+    return 0;
 }
 int smgpu_topology_num_edges(smgpu_topology* t, int32_t* nEdges) {
     if (!t || !nEdges) return fail("null argument");

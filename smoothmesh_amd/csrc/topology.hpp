@@ -69,4 +69,21 @@ struct Topology {
                       const std::function<void()>& afterPoints = nullptr);
 };
 
+// the device arrays of a device build that the kernels read as they are (MeshView): handed to the caller instead of being freed
+struct DeviceTopologyArrays {
+    struct Arr { void* p = nullptr; size_t bytes = 0; };
+    Arr faceOff, facePts, cfOff, cfVal, pcOff, pcVal, ppOff, ppPt, peEdge, pfOff, pfFace, pfPrev, pfNext, pfPrevSlot, pfNextSlot, ringFace, ringCell,
+        edgeRingOk, edges, efOff, efFace, ecOff, ecCell, ecF0, ecF1;
+    bool valid = false;
+};
+
+// The same addressing built on the device (topology_dev.hip: radix sorts of (row, value) keys + per-edge kernels) and copied into
+// t.  0: done; 1: not handled there -- the caller runs Topology::build (meshes it reports an error for, edges with more than 16
+// faces, points with more than 255 neighbours, lists beyond 2^30 entries -- decided BEFORE a hook is called); 2: a HIP error (why).
+// afterCells / afterPoints: as Topology::build's hooks, called once the respective lists have arrived on the host.
+int buildTopologyOnDevice(Topology& t, int32_t nPoints, int32_t nCells, int32_t nFaces, int32_t nInternalFaces, const int32_t* faceOffsets,
+                          const int32_t* facePts, const int32_t* owner, const int32_t* neighbour, int device, std::string& why,
+                          const std::function<void()>& afterCells = nullptr, const std::function<void()>& afterPoints = nullptr,
+                          DeviceTopologyArrays* keep = nullptr);
+
 }  // namespace smgpu

@@ -101,6 +101,12 @@ def make_desc(mesh: PolyMesh, isInternalPoint, isSmoothingSurfacePoint, device=0
     return d, keep
 
 
+TOPO_ARRAYS = ["sizes and maxima", "facePoints.off", "facePoints.val", "owner", "neighbour", "cellFacesGeom.off", "cellFacesGeom.val",
+               "pointFaces.off", "pointFaces.val", "pfPrev", "pfNext", "pfPrevSlot", "pfNextSlot", "pointCells.off", "pointCells.val",
+               "edges", "pointEdges.off", "pointEdges.val", "pointPoints", "edgeFaces.off", "edgeFaces.val", "edgeCells.off", "edgeCells.val",
+               "ecFace0", "ecFace1", "ringFace", "ringCell", "edgeRingOk"]
+
+
 class HostTopology:
     """Host-only addressing build (no GPU): the library's derived lists, for checks and hosts."""
 
@@ -131,6 +137,13 @@ class HostTopology:
         n = C.c_int32()
         self._lib.smgpu_topology_num_edges(self._h, C.byref(n))
         return n.value
+
+    def checksums(self):
+        """FNV-1a checksums of every array of the addressing, TOPO_ARRAYS order (include/smgpu.h smgpu_topology_checksums)"""
+        out = (C.c_uint64 * 32)()
+        if self._lib.smgpu_topology_checksums(self._h, out):
+            raise SmgpuError(self._lib.smgpu_last_error().decode())
+        return [int(x) for x in out][:len(TOPO_ARRAYS)]
 
     def close(self):
         if self._h:
@@ -443,6 +456,12 @@ class SmoothEngine:
         self._check(self._lib.smgpu_debug_walk_mode(self._h, C.byref(mode), C.byref(sw), C.byref(cnt)))
         self.last_active_count = cnt.value
         return mode.value, sw.value
+
+    def debug_addressing_checksums(self):
+        """checksums of the engine's addressing (built on the device where the mesh allows), TOPO_ARRAYS order"""
+        out = (C.c_uint64 * 32)()
+        self._check(self._lib.smgpu_debug_addressing_checksums(self._h, out))
+        return [int(x) for x in out][:len(TOPO_ARRAYS)]
 
     def debug_halo_mode(self):
         """how the last multi-rank iteration went out: {"multi_role", "flagged", "fix_inside"} (include/smgpu.h)"""
