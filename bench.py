@@ -430,7 +430,7 @@ def make_subdomain(kind, n_side, grid, rank, world):
     return cavity_subdomain(n_global, grid, rank, jitter=0.2, seed=12345), n_global
 
 
-def small_case_parity(kind, constraints, grid, rank, world, device, iters=6):
+def small_case_parity(kind, constraints, grid, rank, world, device, iters=6, overlap=False):
     """parity_check (b) of an N > 1 line: a down-scaled case of the same family on the SAME processor grid, run through the SAME
     transport in this very job (DistributedSmoother picks it exactly as for the timed workload), against the oracle's MultiDomain
     (the reference under mpirun with the same decomposition).  Every rank builds the small expected result itself (a few
@@ -457,11 +457,13 @@ def small_case_parity(kind, constraints, grid, rank, world, device, iters=6):
         o.set_params(prm)
     mo = oracle_ffi.MultiOracle(orcs, *shared_point_table(subs))
     n_o, res_o, frz_o = mo.iterate(iters, 0.0)
-    ds = DistributedSmoother(subs[rank], device=device)
+    ds = DistributedSmoother(subs[rank], device=device, overlap=overlap)
     ds.set_params(prm)
     n_g, res_g, frz_g = ds.iterate(iters, 0.0)
     mine, want = ds.get_points(), orcs[rank].points()
     info = ds.transport_info()
+    hm = ds.engine.debug_halo_mode() if hasattr(ds.engine, "debug_halo_mode") else {}
+    info["form"] = ("multi-role launches" + (", flagged" if hm.get("flagged") else "")) if hm.get("multi_role") else "one kernel per step"
     ds.close()
     for o in orcs:
         o.close()
@@ -473,7 +475,8 @@ def small_case_parity(kind, constraints, grid, rank, world, device, iters=6):
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return {"case": f"{what}, cut {grid[0]}x{grid[1]}x{grid[2]}, {'constraints on' if constraints else 'constraints off'}, {iters} iterations",
             "against": "oracle MultiDomain (the reference under mpirun, same decomposition), every rank its own sub-domain",
-            "transport": info["transport"], "ok": bool(t[0].item() == 1.0), "rel_linf_max_over_ranks": float(-t[1].item()),
+            "transport": info["transport"], "form": info["form"], "exchange_stream": bool(overlap),
+            "ok": bool(t[0].item() == 1.0), "rel_linf_max_over_ranks": float(-t[1].item()),
             "bitwise_equal_on_every_rank": bool(t[2].item() == 1.0), "nFrozenPoints": [int(x) for x in np.asarray(frz_g)[:4]], "tolerance": 1e-10}
 
 
@@ -581,9 +584,31 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
         if not ds.set_boundary_smoothing(boundary_params(kind, n_side, hi), prm.minEdgeLength)["enabled"]:
             raise SystemExit("boundary point smoothing could not be enabled")
     t_create = time.perf_counter() - t0
+    # The exchange-stream arrangement (with the constraints off: the two multi-role launches with the exchanges NEXT TO them, ordered
+    # by flag words -- never run between two devices before the first multi-GPU node) is only a candidate of the autotune below if
+    # the down-scaled case gives the oracle's MultiDomain result through it on every rank of THIS job; waits are bounded (10 s here)
+    flagged_check = None
+    allow_overlap = world == 1
+    if oracle and world > 1 and backend == "nccl" and os.environ.get("SMOOTHMESH_EXCHANGE", "") != "push" and os.environ.get("SMOOTHMESH_OVERLAP") is None:
+        prev_to = os.environ.get("SMGPU_PUSH_TIMEOUT_S")
+        os.environ["SMGPU_PUSH_TIMEOUT_S"] = "10"
+        try:
+            flagged_check = small_case_parity(kind, constraints, grid, rank, world, local_rank, overlap=True)
+        except Exception as ex:   # noqa: BLE001
+            flagged_check = {"ok": False, "error": f"{type(ex).__name__}: {ex}"}
+        finally:
+            if prev_to is None:
+                os.environ.pop("SMGPU_PUSH_TIMEOUT_S", None)
+            else:
+                os.environ["SMGPU_PUSH_TIMEOUT_S"] = prev_to
+        okf = torch.tensor([1 if flagged_check.get("ok") else 0], dtype=torch.int32, device=rdev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        allow_overlap = bool(int(okf.item()))
+        if not allow_overlap:
+            flagged_check["ok"] = False
     # exchange arrangement (in order on the engine's stream / on a communication stream next to the
     # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
-    tune = ds.autotune(20) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None
+    tune = ds.autotune(20, allow_overlap=allow_overlap) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None
     if tune is None:
         ds.set_overlap(os.environ["SMOOTHMESH_OVERLAP"] == "1")
     pre = clock_warm(lambda k: ds.iterate(k, 0.0), ds.engine, lambda: (torch.cuda.synchronize(), dist.barrier()), fixed=200 if K >= 20 else 5)
@@ -616,6 +641,11 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
     ctr = [c for c in eng.counters() if c["launches"] > 0 and c["ms"] > 0]
     sizes = dict(eng.sizes())
     info = ds.transport_info()
+    hm = eng.debug_halo_mode() if hasattr(eng, "debug_halo_mode") else {}
+    info["iteration_form"] = (("multi-role launches (k_geom_halo / k_smooth_halo on tiles of the shared points)" + (", flagged" if hm.get("flagged") else "")
+                               + (", fix role inside" if hm.get("fix_inside") else "")) if hm.get("multi_role") else "one kernel per step")
+    if flagged_check is not None:
+        info["exchange_stream_check"] = flagged_check
     parallelism = (f"domain decomposition {grid[0]}x{grid[1]}x{grid[2]}, "
                    + {"direct": "RCCL send/recv groups on the engine's stream, ", "push": "peer stores (the pack kernels write the peers' receive slots), ",
                       "torch": f"{'RCCL' if backend == 'nccl' else backend + ' (debug)'} all_to_all halo, "}[info["transport"]] +

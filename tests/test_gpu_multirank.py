@@ -161,7 +161,7 @@ def test_peer_store_transport_two_processes():
         assert r.returncode == 0, script + r.stdout[-3000:] + r.stderr[-3000:]
         assert "BAD" not in r.stdout
         if marks:
-            assert r.stdout.count(": ok ") == marks and r.stdout.count("[peer stores]") == marks
+            assert r.stdout.count(": ok ") == marks and r.stdout.count("[peer stores") == marks
 
 
 @pytest.mark.parametrize("overlap", [False, True])
