@@ -782,7 +782,17 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
 }
 
 // TWO active points per wave as in k_walk_pred_star (the staging is the same code), the jobs packed (packRunJobs)
-__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount) {
+// memo (measurement aid, SMGPU_WALK_MEMO_STATS=1; NULL otherwise): [0] stars whose inputs have the bits they had in the point's previous
+// walk, [1] stars seen, [2 + p] the hash of point p's star inputs -- everything its jobs read: the vertex slots with their roles,
+// the entries' proposals and states, the point's two positions and angle bounds, the ring places' cell centres.  Would an exact
+// memo of the predicates pay?  
+__device__ __forceinline__ unsigned long long memoMix(unsigned long long h, unsigned long long v) {
+    h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+    return h ^ (h >> 33);
+}
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount,
+                                                                                 unsigned long long* memo = nullptr) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
     __shared__ PackLds plds[kPackBlock / 64];
@@ -939,6 +949,41 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             R.ccx = P.cc.x; R.ccy = P.cc.y; R.ccz = P.cc.z;
             R.l = (unsigned char)P.l; R.lNext = (unsigned char)lNext; R.xEnt = (unsigned char)P.xEnt; R.xSlot = (unsigned char)P.xSlot;
             R.pFirst = P.pFirst ? 1 : 0;
+        }
+        if (memo) {      // (wave-uniform) the hash of the star's inputs against the one of the point's previous walk
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            unsigned long long hsh = 0ull;
+            if (live) {
+                for (int k = hl; k < kPackSlots; k += 32) {
+                    const bool used = k < totalV || (k >= kPackEnt0 && k < kPackEnt0 + nEnt) || k >= kPackCur;
+                    if (!used) continue;
+                    unsigned long long x = memoMix(0x1234567ull + (unsigned long long)k, (unsigned long long)__double_as_longlong(L.vx[k]));
+                    x = memoMix(x, (unsigned long long)__double_as_longlong(L.vy[k]));
+                    x = memoMix(x, (unsigned long long)__double_as_longlong(L.vz[k]));
+                    if (k < totalV) x = memoMix(x, (unsigned long long)L.role[k]);
+                    hsh ^= x;
+                }
+                if (hl < nEnt) hsh ^= memoMix(0x777ull + hl, (unsigned long long)nb0 | ((unsigned long long)(unsigned)q << 8));
+                if (counts) {
+                    unsigned long long x = memoMix(0x999ull + hl, (unsigned long long)__double_as_longlong(P.cc.x));
+                    x = memoMix(x, (unsigned long long)__double_as_longlong(P.cc.y));
+                    x = memoMix(x, (unsigned long long)__double_as_longlong(P.cc.z));
+                    x = memoMix(x, ((unsigned long long)(unsigned)P.l << 24) | ((unsigned long long)(unsigned)lNext << 16) | ((unsigned long long)(unsigned)P.xEnt << 8) | (unsigned long long)(unsigned)P.xSlot);
+                    hsh ^= x;
+                }
+                if (hl == 0) {
+                    hsh ^= memoMix(0xabcull, (unsigned long long)__double_as_longlong(L.pMin));
+                    hsh ^= memoMix(0xdefull, (unsigned long long)__double_as_longlong(L.pMax));
+                    hsh ^= memoMix(0x555ull, (unsigned long long)(frozenBefore ? 1 : 0));
+                }
+            }
+            for (int o = 16; o > 0; o >>= 1) hsh ^= __shfl_xor(hsh, o, 32);
+            if (live && hl == 0) {
+                if (memo[2 + (size_t)p] == hsh) atomicAdd(&memo[0], 1ull);
+                atomicAdd(&memo[1], 1ull);
+                memo[2 + (size_t)p] = hsh;
+            }
         }
         const unsigned countedMask = (unsigned)(__ballot(counts) >> (32 * half));
         unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);

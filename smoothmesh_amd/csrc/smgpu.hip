@@ -144,6 +144,8 @@ struct smgpu_handle {
     long walkDecisions = 0;
     hipEvent_t evWalkLag[2] = {nullptr, nullptr};
     unsigned long long* dWalkOps = nullptr;   // [64] algorithmic FP64 instructions of the walk predicates, counted in timing passes
+    unsigned long long* dWalkMemo = nullptr;  // SMGPU_WALK_MEMO_STATS=1: [0] matches, [1] stars, [2 + p] hash of the star inputs of point p (k_walk_pred_pack)
+    unsigned long long walkMemoLast[2] = {0, 0};
     bool walkAlloc = false;
     WalkView wv{};
     FixView fxw{};             // state of the device replay (walkMode 2, k_walk_fix)
@@ -1121,6 +1123,10 @@ static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList
 static int ensureWalkBuffers(smgpu_handle* h) {
     if (h->walkAlloc) return 0;
     const Topology& t = h->topo;
+    if (envInt("SMGPU_WALK_MEMO_STATS", 0) && !h->dWalkMemo) {
+        if (devAlloc(h, &h->dWalkMemo, (size_t)t.nPoints + 2)) return 1;
+        HIP_OK(hipMemset(h->dWalkMemo, 0, ((size_t)t.nPoints + 2) * sizeof(unsigned long long)));
+    }
     const size_t P = t.nPoints, E = (size_t)t.pointEdges.nnz();
     h->walkBlocks = gridFor(t.nPoints);
     WalkView& w = h->wv;
@@ -1266,7 +1272,7 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
+            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
             else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
@@ -1352,7 +1358,7 @@ static int runFixWalk(smgpu_handle* h) {
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
+            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
             else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(h->starBlocks), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
@@ -1656,6 +1662,13 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     h->st.stepSqr = nullptr;
     h->st.stats = nullptr;
     if (drainTimers(h)) return 1;
+    if (h->dWalkMemo) {      // per smgpu_iterate call: stars whose inputs repeat the point's previous walk bit for bit
+        unsigned long long v[2];
+        HIP_OK(hipMemcpy(v, h->dWalkMemo, sizeof(v), hipMemcpyDeviceToHost));
+        const unsigned long long dm = v[0] - h->walkMemoLast[0], dt = v[1] - h->walkMemoLast[1];
+        if (dt > 0) std::fprintf(stderr, "[smgpu] walk memo: %llu of %llu stars (%.1f %%) had the inputs of the point's previous walk, over %d iterations\n", dm, dt, 100.0 * (double)dm / (double)dt, done);
+        h->walkMemoLast[0] = v[0]; h->walkMemoLast[1] = v[1];
+    }
     if (h->fixAlloc && envInt("SMGPU_WALK_STATS", 0)) {
         int v[16];
         HIP_OK(hipMemcpy(v, h->fxw.flags, sizeof(v), hipMemcpyDeviceToHost));
