@@ -16,3 +16,9 @@ for c in range(chunks):
     n_, res, frz = eng.iterate(10, 0.0)
     done += 10
     print(f"{wl}: after {done} iterations nFrozenPoints {int(frz[-1])} residual {float(res[-1]):.4g}", file=sys.stderr, flush=True)
+# sanity of the hash itself: the SAME iteration twice from the same coordinates must match for every star
+p0 = eng.get_points()
+eng.iterate(1, 0.0)
+eng.set_points(p0)
+print(f"{wl}: control -- the next line repeats the last iteration from the same coordinates: expect 100 %", file=sys.stderr, flush=True)
+eng.iterate(1, 0.0)
