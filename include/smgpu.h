@@ -345,8 +345,10 @@ int smgpu_debug_walk_mode(smgpu_handle* h, int32_t* mode, int32_t* switches, int
  * the smoothing launch (peer-store transport) */
 /* FNV-1a checksums of every array of the addressing in a fixed order (SMGPU_TOPO_CHECKSUMS words; [0] = sizes and maxima): the
  * engine's (built on the device where the mesh allows, csrc/topology_dev.hip) against smgpu_topology_checksums of the host build */
-#define SMGPU_TOPO_CHECKSUMS 32
+#define SMGPU_TOPO_CHECKSUMS 64
 int smgpu_debug_addressing_checksums(smgpu_handle* h, uint64_t* out /* [SMGPU_TOPO_CHECKSUMS] */);
+/* the same for the geometry tile tables as the kernels read them (device build, csrc/tiles_dev.hip, against SMGPU_DEVICE_TILES=0) */
+int smgpu_debug_tile_checksums(smgpu_handle* h, uint64_t* out /* [SMGPU_TOPO_CHECKSUMS] */);
 int smgpu_debug_halo_mode(smgpu_handle* h, int32_t* multiRole, int32_t* flagged, int32_t* fixInside);
 
 /* self-test of the geometry kernel's range-tested square root / division fast paths (csrc/fpexact.hpp) against the plain

@@ -147,6 +147,7 @@ SYMBOLS = {
     "smgpu_topology_num_edges": (C.c_int, [C.c_void_p, c_i32p]),
     "smgpu_topology_checksums": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "smgpu_debug_addressing_checksums": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "smgpu_debug_tile_checksums": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "smgpu_topology_destroy": (C.c_int, [C.c_void_p]),
 }
 

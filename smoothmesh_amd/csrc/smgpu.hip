@@ -130,6 +130,8 @@ struct smgpu_handle {
     bool useTiles = false;
     int geomT = 128, smoothT = 256;
     GeomTiles gt;
+    GeomTilesDev gtDev;        // the geometry tile tables of a device build (tiles_dev.hip): read where they were built
+    EdgeTilesDev etDev;        // ... and the edge tile tables
     SmoothTiles stl;
     GeomTileView gv{};
     SmoothTileView sv{};
@@ -477,8 +479,22 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const int capGP0 = envInt("SMGPU_GEOM_CAPP", std::min(6 * geomCells0, 1400)), capGF0 = envInt("SMGPU_GEOM_CAPF", std::min(4 * geomCells0, 1400));
         const int capSC0 = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * smoothT0, 1500)), capSN0 = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * smoothT0, 1500));
         const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256, smoothOk = smoothT0 == 64 || smoothT0 == 128 || smoothT0 == 256;
-        const auto afterCells = [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0] {
-                      return h->gt.build(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0); }); };
+        // tile boundaries on the host, the tables on the device where the addressing was built there (tiles_dev.hip), else on the host
+        const bool devTiles = envInt("SMGPU_DEVICE_TILES", 1) != 0;
+        const auto afterCells = [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
+                      const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0);
+                      if (!e.empty()) return e;
+                      if (devTiles && devTopo.valid) {
+                          std::string why;
+                          const auto t0 = std::chrono::steady_clock::now();
+                          const int rc = buildGeomTablesOnDevice(h->gt, devTopo, d->nCells, h->device, h->gtDev, why);
+                          if (envInt("SMGPU_VERBOSE", 0) >= 2)
+                              std::fprintf(stderr, "[smgpu] geometry tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                          if (rc == 0) return std::string();
+                          if (rc == 2) return "device tile tables: " + why;
+                      }
+                      return h->gt.buildTables(h->topo); }); };
         const auto afterPoints = [&] {
                 if (!(wantTiles && geomOk && smoothOk)) return;
                 if (fPointOrder.valid()) pointOrder = fPointOrder.get();
@@ -548,8 +564,23 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         if (fPointOrder.valid()) pointOrder = fPointOrder.get();
         const std::vector<int32_t>* po = (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr;
         const bool wantFilter = envInt("SMGPU_FILTER", 1) != 0;
-        fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles]() -> std::string {
-            return wantFilter ? h->etl.build(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po) : std::string("not built");
+        const bool devTilesE = envInt("SMGPU_DEVICE_TILES", 1) != 0 && devTopo.valid;
+        const DeviceTopologyArrays* dt = &devTopo;
+        fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles, devTilesE, dt]() -> std::string {
+            if (!wantFilter) return std::string("not built");
+            const std::string e = h->etl.buildBoundaries(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po);
+            if (!e.empty()) return e;
+            if (devTilesE) {
+                std::string why;
+                const auto t0 = std::chrono::steady_clock::now();
+                const int rc = buildEdgeTablesOnDevice(h->etl, *dt, h->topo.nEdges, h->device, h->etDev, why);
+                if (envInt("SMGPU_VERBOSE", 0) >= 2)
+                    std::fprintf(stderr, "[smgpu] edge tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                if (rc == 0) return std::string();
+                if (rc == 2) return "device tile tables: " + why;
+            }
+            return h->etl.buildTables(h->topo);
         });
     }
     auto cleanupE = [&](int rc0) { if (fEdge.valid()) fEdge.wait(); return cleanup(rc0); };
@@ -652,20 +683,27 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         } else {
             GeomTileView& g = h->gv;
             SmoothTileView& v = h->sv;
-            rc |= devUpload(h, &g.cellOrder, h->gt.order);
-            rc |= devUpload(h, &g.cellBeg, h->gt.cellBeg);
+            auto adoptT = [&](auto*& dst, const GeomTilesDev::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
+            if (h->gtDev.valid) {      // a device build's tables stay where they are
+                adoptT(g.cellOrder, h->gtDev.cellOrder); adoptT(g.cellBeg, h->gtDev.cellBeg); adoptT(g.tpIds, h->gtDev.tpIds); adoptT(g.tfIds, h->gtDev.tfIds);
+                adoptT(g.faceVerts, h->gtDev.faceVerts); adoptT(g.cellFaces, h->gtDev.cellFaces); adoptT(g.meta, h->gtDev.meta);
+                h->gtDev.valid = false;      // (the handle's allocation list owns them now)
+            } else {
+                rc |= devUpload(h, &g.cellOrder, h->gt.order);
+                rc |= devUpload(h, &g.cellBeg, h->gt.cellBeg);
+                rc |= devUpload(h, &g.tpIds, h->gt.tpIds);
+                rc |= devUpload(h, &g.tfIds, h->gt.tfIds);
+                rc |= devUpload(h, &g.faceVerts, h->gt.faceVerts);
+                rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
+            }
             rc |= devUpload(h, &g.tpOff, h->gt.tpOff);
-            rc |= devUpload(h, &g.tpIds, h->gt.tpIds);
             rc |= devUpload(h, &g.tfOff, h->gt.tfOff);
-            rc |= devUpload(h, &g.tfIds, h->gt.tfIds);
             rc |= devUpload(h, &g.fvBase, h->gt.fvBase);
             rc |= devUpload(h, &g.fvWidth, h->gt.fvWidth);
-            rc |= devUpload(h, &g.faceVerts, h->gt.faceVerts);
             rc |= devUpload(h, &g.cfBase, h->gt.cfBase);
             rc |= devUpload(h, &g.cfWidth, h->gt.cfWidth);
-            rc |= devUpload(h, &g.cellFaces, h->gt.cellFaces);
             rc |= devUpload(h, &g.tileFlags, h->gt.tileFlags);
-            {   // the per-tile scalars once more, one record per tile (GeomTileMeta: scalar loads in the kernel)
+            if (!g.meta) {   // the per-tile scalars once more, one record per tile (GeomTileMeta: scalar loads in the kernel)
                 const auto& gt = h->gt;
                 std::vector<int> meta((size_t)kGeomMetaInts * (size_t)gt.nTiles, 0);
                 for (int t = 0; t < gt.nTiles; ++t) {
@@ -712,29 +750,43 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     EdgeTileView& ev = h->ev;
                     // the filter reads the face averages where the geometry tiles store them: position of every face
                     // in the face list of its owner's tile
-                    {
+                    const size_t nGeomTf = (size_t)h->gt.tfOff.back();
+                    h->avgPackedCount = nGeomTf;
+                    if (h->etDev.valid) {      // a device build: the remap there too, the tables stay where they are
+                        std::string why;
+                        if (remapEdgeFaceIdsOnDevice(g.tfIds, (long long)nGeomTf, t.nFaces, (int*)h->etDev.tfIds.p, h->etDev.nTf, h->device, why))
+                            return cleanup(fail("smgpu_create: edge tile face positions: " + why));
+                        auto adoptE = [&](auto*& dst, const EdgeTilesDev::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
+                        adoptE(ev.order, h->etDev.order); adoptE(ev.edgeBeg, h->etDev.edgeBeg); adoptE(ev.tpIds, h->etDev.tpIds); adoptE(ev.tfIds, h->etDev.tfIds);
+                        adoptE(ev.tcIds, h->etDev.tcIds); adoptE(ev.epLoc, h->etDev.epLoc); adoptE(ev.efEll, h->etDev.efEll); adoptE(ev.ecEll, h->etDev.ecEll);
+                        adoptE(ev.meta, h->etDev.meta);
+                        h->etDev.valid = false;
+                    } else {
+                        if (h->gt.tfIds.size() != nGeomTf) {      // (a device build of the geometry tables that kept its face ids there)
+                            h->gt.tfIds.resize(nGeomTf);
+                            if (hipMemcpy(h->gt.tfIds.data(), g.tfIds, nGeomTf * 4, hipMemcpyDeviceToHost) != hipSuccess) return cleanup(fail("smgpu_create: download of the tile face ids failed"));
+                        }
                         std::vector<int32_t> facePos((size_t)t.nFaces, -1);
                         for (size_t k = 0; k < h->gt.tfIds.size(); ++k)
                             if (h->gt.tfIds[k] < 0) facePos[(size_t)(h->gt.tfIds[k] & 0x7fffffff)] = (int32_t)k;
                         for (int32_t& f : h->etl.tfIds) f = facePos[(size_t)f];
-                        h->avgPackedCount = h->gt.tfIds.size();
+                        rc |= devUpload(h, &ev.order, h->etl.order);
+                        rc |= devUpload(h, &ev.edgeBeg, h->etl.edgeBeg);
+                        rc |= devUpload(h, &ev.tpIds, h->etl.tpIds);
+                        rc |= devUpload(h, &ev.tfIds, h->etl.tfIds);
+                        rc |= devUpload(h, &ev.tcIds, h->etl.tcIds);
+                        rc |= devUpload(h, &ev.epLoc, h->etl.epLoc);
+                        rc |= devUpload(h, &ev.efEll, h->etl.efEll);
+                        rc |= devUpload(h, &ev.ecEll, h->etl.ecEll);
                     }
-                    rc |= devUpload(h, &ev.order, h->etl.order);
-                    rc |= devUpload(h, &ev.edgeBeg, h->etl.edgeBeg);
                     rc |= devUpload(h, &ev.tpOff, h->etl.tpOff);
-                    rc |= devUpload(h, &ev.tpIds, h->etl.tpIds);
                     rc |= devUpload(h, &ev.tfOff, h->etl.tfOff);
-                    rc |= devUpload(h, &ev.tfIds, h->etl.tfIds);
                     rc |= devUpload(h, &ev.tcOff, h->etl.tcOff);
-                    rc |= devUpload(h, &ev.tcIds, h->etl.tcIds);
-                    rc |= devUpload(h, &ev.epLoc, h->etl.epLoc);
                     rc |= devUpload(h, &ev.efBase, h->etl.efBase);
                     rc |= devUpload(h, &ev.ecBase, h->etl.ecBase);
                     rc |= devUpload(h, &ev.efWidth, h->etl.efWidth);
                     rc |= devUpload(h, &ev.ecWidth, h->etl.ecWidth);
-                    rc |= devUpload(h, &ev.efEll, h->etl.efEll);
-                    rc |= devUpload(h, &ev.ecEll, h->etl.ecEll);
-                    {   // EdgeTileMeta records
+                    if (!ev.meta) {   // EdgeTileMeta records
                         const auto& et = h->etl;
                         std::vector<int> meta((size_t)kEdgeMetaInts * (size_t)et.nTiles, 0);
                         for (int ti = 0; ti < et.nTiles; ++ti) {
@@ -764,8 +816,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
             if (envInt("SMGPU_VERBOSE", 0))
                 std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d; staged faces x%.3f, points x%.3f of the mesh's)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
-                             h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, (double)h->gt.tfIds.size() / std::max(1, t.nFaces),
-                             (double)h->gt.tpIds.size() / std::max(1, t.nPoints), h->smoothT, h->stl.nTiles, h->smoothLds, v.maxCells, v.maxPoints);
+                             h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, (double)h->gt.tfOff.back() / std::max(1, t.nFaces),
+                             (double)h->gt.tpOff.back() / std::max(1, t.nPoints), h->smoothT, h->stl.nTiles, h->smoothLds, v.maxCells, v.maxPoints);
         }
     }
     {
@@ -846,6 +898,12 @@ int smgpu_destroy(smgpu_handle* h) {
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->freeEvents) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->etDev.valid)
+        for (const EdgeTilesDev::Arr* a : {&h->etDev.order, &h->etDev.edgeBeg, &h->etDev.tpIds, &h->etDev.tfIds, &h->etDev.tcIds, &h->etDev.epLoc, &h->etDev.efEll, &h->etDev.ecEll, &h->etDev.meta})
+            if (a->p) (void)hipFree(a->p);
+    if (h->gtDev.valid)      // (a create that failed before the handle took the device-built tile tables over)
+        for (const GeomTilesDev::Arr* a : {&h->gtDev.cellOrder, &h->gtDev.cellBeg, &h->gtDev.tpIds, &h->gtDev.tfIds, &h->gtDev.faceVerts, &h->gtDev.cellFaces, &h->gtDev.meta})
+            if (a->p) (void)hipFree(a->p);
     if (h->pinned) (void)hipHostFree(h->pinned);
     if (h->nActiveHost) (void)hipHostFree(h->nActiveHost);
     for (hipEvent_t e : h->evWalkLag) if (e) (void)hipEventDestroy(e);
@@ -2983,6 +3041,46 @@ static void topoChecksums(const Topology& t, uint64_t* out) {
     add(t.ringFace); add(t.ringCell); add(t.edgeRingOk);
     while (k < SMGPU_TOPO_CHECKSUMS) out[k++] = 0;
 }
+// checksums of the geometry tile tables as the kernels read them (downloaded from the device), in a fixed order: the device
+// build of the tables (tiles_dev.hip) against the host build (SMGPU_DEVICE_TILES=0) in tests/test_gpu_topology.py
+int smgpu_debug_tile_checksums(smgpu_handle* h, uint64_t* out) {
+    if (!h || !out) return fail("null argument");
+    for (int i = 0; i < SMGPU_TOPO_CHECKSUMS; ++i) out[i] = 0;
+    if (!h->useTiles) return 0;
+    HIP_OK(hipSetDevice(h->device));
+    const GeomTiles& gt = h->gt;
+    const int nT = gt.nTiles;
+    int k = 0;
+    auto host = [&](const auto& v) { out[k++] = fnv1a(v.data(), v.size() * sizeof(v[0])) ^ (uint64_t)v.size(); };
+    auto dev = [&](const void* p, size_t bytes) -> int {
+        std::vector<unsigned char> buf(bytes);
+        if (bytes) HIP_OK(hipMemcpy(buf.data(), p, bytes, hipMemcpyDeviceToHost));
+        out[k++] = fnv1a(buf.data(), bytes) ^ (uint64_t)bytes;
+        return 0;
+    };
+    host(gt.cellBeg); host(gt.tpOff); host(gt.tfOff); host(gt.fvBase); host(gt.fvWidth); host(gt.cfBase); host(gt.cfWidth); host(gt.tileFlags);
+    const int32_t mx[2] = {gt.maxPoints, gt.maxFaces};
+    out[k++] = fnv1a(mx, sizeof(mx));
+    const size_t nTp = (size_t)gt.tpOff.back(), nTf = (size_t)gt.tfOff.back();
+    const size_t nFv = nT ? (size_t)gt.fvBase[(size_t)nT - 1] + (size_t)(gt.tfOff[(size_t)nT] - gt.tfOff[(size_t)nT - 1]) * gt.fvWidth[(size_t)nT - 1] : 0;
+    const size_t nCf = nT ? (size_t)gt.cfBase[(size_t)nT - 1] + (size_t)gt.cfWidth[(size_t)nT - 1] * (size_t)gt.threads : 0;
+    if (dev(h->gv.cellOrder, (size_t)h->mv.nCells * 4) || dev(h->gv.tpIds, nTp * 4) || dev(h->gv.tfIds, nTf * 4) || dev(h->gv.faceVerts, nFv * 2) ||
+        dev(h->gv.cellFaces, nCf * 2) || dev(h->gv.meta, (size_t)nT * kGeomMetaInts * 4)) return 1;
+    if (h->useFilter && h->ev.meta) {      // the edge tiles
+        const EdgeTiles& et = h->etl;
+        const int nE = et.nTiles;
+        host(et.tpOff); host(et.tfOff); host(et.tcOff); host(et.efBase); host(et.ecBase); host(et.efWidth); host(et.ecWidth);
+        const int32_t mxE[3] = {et.maxPoints, et.maxFaces, et.maxCells};
+        out[k++] = fnv1a(mxE, sizeof(mxE));
+        const size_t nEf = nE ? (size_t)et.efBase[(size_t)nE - 1] + (size_t)et.efWidth[(size_t)nE - 1] * (size_t)et.threads : 0;
+        const size_t nEc = nE ? (size_t)et.ecBase[(size_t)nE - 1] + (size_t)et.ecWidth[(size_t)nE - 1] * (size_t)et.threads : 0;
+        if (dev(h->ev.order, (size_t)h->mv.nEdges * 4) || dev(h->ev.edgeBeg, ((size_t)nE + 1) * 4) || dev(h->ev.tpIds, (size_t)et.tpOff.back() * 4) ||
+            dev(h->ev.tfIds, (size_t)et.tfOff.back() * 4) || dev(h->ev.tcIds, (size_t)et.tcOff.back() * 4) || dev(h->ev.epLoc, (size_t)h->mv.nEdges * 4) ||
+            dev(h->ev.efEll, nEf * 2) || dev(h->ev.ecEll, nEc * 2) || dev(h->ev.meta, (size_t)nE * kEdgeMetaInts * 4)) return 1;
+    }
+    return 0;
+}
+
 int smgpu_debug_addressing_checksums(smgpu_handle* h, uint64_t* out) {
     if (!h || !out) return fail("null argument");
     topoChecksums(h->topo, out);

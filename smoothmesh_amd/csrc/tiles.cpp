@@ -96,6 +96,12 @@ static std::vector<int32_t> naturalOrder(int32_t n) {
 
 std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
                              int32_t capPoints, int32_t capFaces) {
+    const std::string e = buildBoundaries(t, pts, morton, nThreads, capCells, capPoints, capFaces);
+    return e.empty() ? buildTables(t) : e;
+}
+
+std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
+                                       int32_t capPoints, int32_t capFaces) {
     threads = nThreads;
     PhaseTimer tm("geometry");
     if (capCells > threads) capCells = threads;
@@ -162,7 +168,13 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
         nTiles = (int32_t)cellBeg.size() - 1;
     }
     tm.lap("boundaries");
+    return "";
+}
 
+std::string GeomTiles::buildTables(const Topology& t) {
+    PhaseTimer tm("geometry");
+    const auto& cf = t.cellFacesGeom;
+    const auto& fp = t.facePoints;
     // pass 2: per tile unique lists (ascending), local indices, ELL tables -- tile ranges on host threads, every range
     // builds its share of the tables, the shares are concatenated in tile order (local indices by binary search in the
     // tile's sorted lists: no mesh-sized scratch per thread)
@@ -523,6 +535,12 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
 
 std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
                              int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder) {
+    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capPoints, capFaces, capCells, pointOrder);
+    return e.empty() ? buildTables(t) : e;
+}
+
+std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
+                                       int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder) {
     threads = nThreads;
     PhaseTimer tm("edge");
     const int32_t nE = t.nEdges;
@@ -549,7 +567,7 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     // pass 1: greedy tile boundaries.  On large meshes the edge sequence is cut into a few segments that are tiled side by side
     // (each with stamp arrays of its own); a segment starts a fresh tile, so the tiling differs from the one-segment tiling by
     // at most one partial tile per cut -- any tiling is as good as any other for the results.
-    const int segs = (nE >= (4 << 20)) ? (int)std::min<unsigned>(hostThreads(), 4u) : 1;
+    const int segs = (nE >= (4 << 20)) ? (int)std::min<unsigned>(hostThreads(), 8u) : 1;
     std::vector<std::vector<int32_t>> segBeg((size_t)segs);
     std::vector<std::string> segErr((size_t)segs);
     parallelRanges(nE, segs, [&](int sg, int64_t e0, int64_t e1) {
@@ -583,6 +601,14 @@ std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, 
     edgeBeg.push_back(nE);
     nTiles = (int32_t)edgeBeg.size() - 1;
     tm.lap("boundaries");
+    return "";
+}
+
+std::string EdgeTiles::buildTables(const Topology& t) {
+    PhaseTimer tm("edge");
+    const int32_t nE = t.nEdges;
+    const auto& ef = t.edgeFaces;
+    const auto& ec = t.edgeCells;
     epLoc.assign(2 * (size_t)nE, 0);
     struct Part {
         std::vector<int32_t> tpIds, tfIds, tcIds, nP, nF, nC, efBase, ecBase;

@@ -51,7 +51,22 @@ struct GeomTiles {
     std::vector<int32_t> order;
     std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
                       int32_t capPoints, int32_t capFaces);
+    // the two halves of build(): tile order + greedy boundaries (host), and the per-tile tables -- which tiles_dev.hip builds on
+    // the device from the boundaries where it can (buildGeomTablesOnDevice)
+    std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
+                                int32_t capPoints, int32_t capFaces);
+    std::string buildTables(const Topology& t);
 };
+// the tables of a device build (tiles_dev.hip) that the kernels read where they were built; the caller owns the arrays
+struct GeomTilesDev {
+    struct Arr { void* p = nullptr; size_t bytes = 0; };
+    Arr cellOrder, cellBeg, tpIds, tfIds, faceVerts, cellFaces, meta;
+    bool valid = false;
+};
+struct DeviceTopologyArrays;
+// 0: built (gt holds the offsets / widths / flags / tfIds / maxima the host reads, `out` the device arrays); 1: not handled there
+// (the caller runs gt.buildTables); 2: a HIP error (why)
+int buildGeomTablesOnDevice(GeomTiles& gt, const DeviceTopologyArrays& td, int32_t nCells, int device, GeomTilesDev& out, std::string& why);
 
 // ---- smoothing: tile = consecutive points; LDS holds the cell centres and neighbour points -------
 struct SmoothTiles {
@@ -105,6 +120,18 @@ struct EdgeTiles {
     // point) instead of a sort of their own over the 3x as many edge midpoints -- a tile is still a compact cluster of edges
     std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
                       int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr);
+    // the two halves of build(), as GeomTiles'
+    std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
+                                int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr);
+    std::string buildTables(const Topology& t);
 };
+struct EdgeTilesDev {
+    struct Arr { void* p = nullptr; size_t bytes = 0; };
+    Arr order, edgeBeg, tpIds, tfIds, tcIds, epLoc, efEll, ecEll, meta;
+    long long nTf = 0;
+    bool valid = false;
+};
+int buildEdgeTablesOnDevice(EdgeTiles& et, const DeviceTopologyArrays& td, int32_t nEdges, int device, EdgeTilesDev& out, std::string& why);
+int remapEdgeFaceIdsOnDevice(const int* geomTfIds, long long nGeomTf, int32_t nFaces, int* edgeTfIds, long long nEdgeTf, int device, std::string& why);
 
 }  // namespace smgpu

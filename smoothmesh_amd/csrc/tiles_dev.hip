@@ -1,0 +1,424 @@
+// tiles_dev.hip -- the per-tile TABLES of tiles.cpp built on the device (round 5).  The tile boundaries stay the host's greedy pass
+// (tiles.cpp, on segments of the Z-curve); given them, a tile's tables are a pure function of the addressing: the sorted unique ids
+// of the records it stages, every list entry's position in those (binary search), the sliced-ELL rows.  One workgroup per tile:
+// candidates into LDS, bitonic sort, duplicates out, searches -- twice, once to COUNT (the tables' offsets are prefix sums over the
+// tiles) and once to FILL.  The host spent 1.0 / 1.2 / 0.9 s per table set for 10 M cells on 32 threads (1.5 / 2.2 / 0.9 s side by
+// side); here a set is a few milliseconds, and the kernels read the arrays where they were built.  Same bytes as the host build
+// (tests/test_gpu_topology.py compares checksums of every table of both builds); a tile the buffers below cannot hold hands the whole
+// set back to the host build.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+
+#include <rocprim/device/device_scan.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "tiles.hpp"
+
+namespace smgpu {
+
+namespace {
+
+constexpr int kT = 256;                 // threads per workgroup = threads per tile of the kernels that use the tables
+constexpr int kBuf = 4096;              // candidates per list a tile may have before duplicates are removed
+constexpr int kPadKey = 0x7fffffff;
+typedef unsigned long long u64;
+
+#define TL_OK(expr)                                                                                             \
+    do {                                                                                                        \
+        hipError_t e__ = (expr);                                                                                \
+        if (e__ != hipSuccess) { why = std::string(#expr) + ": " + hipGetErrorString(e__); return 2; }          \
+    } while (0)
+
+// exclusive prefix sum over the workgroup; total = sum of all (all threads call)
+__device__ __forceinline__ int blockExclusive(int v, int* sh /* [kT / 64 + 1] */, int& total) {
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((threadIdx.x & 63) >= o) incl += t; }
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) sh[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int i = 0; i < w; ++i) base += sh[i];
+    total = 0;
+    for (int i = 0; i < kT / 64; ++i) total += sh[i];
+    return base + incl - v;
+}
+__device__ __forceinline__ int blockMax(int v, int* sh) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int m = sh[0];
+    for (int i = 1; i < kT / 64; ++i) m = max(m, sh[i]);
+    return m;
+}
+// buf[0 .. n) ascending without duplicates; returns the new length.  buf has room for the next power of two >= n (<= kBuf).
+__device__ __forceinline__ int sortUnique(int* buf, int n, int* sh) {
+    int N = 64;
+    while (N < n) N <<= 1;
+    for (int i = n + (int)threadIdx.x; i < N; i += kT) buf[i] = kPadKey;
+    __syncthreads();
+    for (int k = 2; k <= N; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < N; i += kT) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const int a = buf[i], b = buf[l];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { buf[i] = b; buf[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    // duplicates out: every thread takes a contiguous chunk, counts its heads, scans, and writes them into the front -- in two
+    // steps through registers (a chunk's heads never land behind the chunk's own start, but may land in an earlier chunk's range)
+    const int per = (n + kT - 1) / kT, lo = min(n, (int)threadIdx.x * per), hi = min(n, lo + per);
+    int heads = 0;
+    for (int i = lo; i < hi; ++i) heads += (i == 0 || buf[i] != buf[i - 1]) ? 1 : 0;
+    int total;
+    const int at = blockExclusive(heads, sh, total);
+    int keep[kBuf / kT];      // (per <= kBuf / kT)
+    int c = 0;
+    for (int i = lo; i < hi; ++i) if (i == 0 || buf[i] != buf[i - 1]) keep[c++] = buf[i];
+    __syncthreads();
+    for (int i = 0; i < c; ++i) buf[at + i] = keep[i];
+    __syncthreads();
+    return total;
+}
+__device__ __forceinline__ int lowerBound(const int* v, int n, int x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (v[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int roundUp4d(int v) { return (v + 3) & ~3; }
+
+// ---- geometry tiles ------------------------------------------------------------------------------------------------------------
+struct GeomIn {
+    const int* order; const int* cellBeg; int nTiles;
+    const int* cfOff; const int* cfVal; const int* faceOff; const int* facePts; const int* owner; const int* cellTile;
+};
+struct GeomSizes { int* nPts; int* nFcs; int* fw; int* cw; int* flags; int* bad; };
+struct GeomOut {
+    const long long* tpOff; const long long* tfOff; const long long* fvBase; const long long* cfBase;
+    int* tpIds; int* tfIds; uint16_t* faceVerts; uint16_t* cellFaces; int* meta;
+};
+__global__ void __launch_bounds__(kT) k_tl_cellTile(GeomIn in, int* cellTile) {
+    const int ti = blockIdx.x, cb = in.cellBeg[ti], n = in.cellBeg[ti + 1] - cb;
+    for (int i = threadIdx.x; i < n; i += kT) cellTile[in.order[cb + i]] = ti;
+}
+template <bool FILL>
+__global__ void __launch_bounds__(kT) k_tl_geom(GeomIn in, GeomSizes sz, GeomOut out) {
+    __shared__ int sFaces[kBuf], sPts[kBuf], sh[kT / 64 + 1];
+    const int ti = blockIdx.x, tid = threadIdx.x;
+    const int cb = in.cellBeg[ti], nC = in.cellBeg[ti + 1] - cb;
+    // the tile's faces
+    const int c = (tid < nC) ? in.order[cb + tid] : -1;
+    const int fb = (c >= 0) ? in.cfOff[c] : 0, nfc = (c >= 0) ? in.cfOff[c + 1] - fb : 0;
+    int rawF;
+    const int atF = blockExclusive(nfc, sh, rawF);
+    if (rawF > kBuf || nC > kT) { if (tid == 0) *sz.bad = 1; return; }      // (workgroup-uniform)
+    for (int k = 0; k < nfc; ++k) sFaces[atF + k] = in.cfVal[fb + k] & 0x7fffffff;
+    __syncthreads();
+    const int nF = sortUnique(sFaces, rawF, sh);
+    // ... and their points
+    int rawP = 0;
+    int myCount = 0;
+    for (int i = tid; i < nF; i += kT) myCount += in.faceOff[sFaces[i] + 1] - in.faceOff[sFaces[i]];
+    int atP = blockExclusive(myCount, sh, rawP);
+    if (rawP > kBuf) { if (tid == 0) *sz.bad = 1; return; }
+    int fwMax = 0;
+    bool quads = true;
+    for (int i = tid; i < nF; i += kT) {
+        const int f = sFaces[i], b = in.faceOff[f], nv = in.faceOff[f + 1] - b;
+        fwMax = max(fwMax, nv);
+        quads = quads && nv == 4;
+        for (int k = 0; k < nv; ++k) sPts[atP++] = in.facePts[b + k];
+    }
+    __syncthreads();
+    const int nP = sortUnique(sPts, rawP, sh);
+    const int fw = roundUp4d(blockMax(fwMax, sh)), cw = roundUp4d(blockMax(nfc, sh));
+    const int notQuads = blockMax(quads ? 0 : 1, sh), notHex = blockMax((c >= 0 && nfc != 6) ? 1 : 0, sh);
+    if (nP > 32767 || nF > 32767 || cw > 252 || fw > 252) { if (tid == 0) *sz.bad = 1; return; }
+    if (!FILL) {
+        if (tid == 0) { sz.nPts[ti] = nP; sz.nFcs[ti] = nF; sz.fw[ti] = fw; sz.cw[ti] = cw; sz.flags[ti] = (notQuads ? 0 : 1) | (notHex ? 0 : 2); }
+        return;
+    }
+    const long long tp = out.tpOff[ti], tf = out.tfOff[ti], fv = out.fvBase[ti], cfb = out.cfBase[ti];
+    for (int i = tid; i < nP; i += kT) out.tpIds[tp + i] = sPts[i];
+    for (int i = tid; i < nF; i += kT) {
+        const int f = sFaces[i];
+        out.tfIds[tf + i] = (in.cellTile[in.owner[f]] == ti) ? (int)(0x80000000u | (unsigned)f) : f;
+        const int b = in.faceOff[f], nv = in.faceOff[f + 1] - b;
+        uint16_t* row = out.faceVerts + fv + (long long)i * fw;
+        for (int j = 0; j < fw; ++j) row[j] = (j < nv) ? (uint16_t)lowerBound(sPts, nP, in.facePts[b + j]) : (uint16_t)0xFFFF;
+    }
+    // cell faces: sliced ELL, entry (j, t) at ((j / 4) * T + t) * 4 + j % 4; the rows were filled with pads by a memset
+    if (c >= 0)
+        for (int j = 0; j < nfc; ++j) {
+            const int v = in.cfVal[fb + j];
+            out.cellFaces[cfb + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)(lowerBound(sFaces, nF, v & 0x7fffffff) | (v < 0 ? 0x8000 : 0));
+        }
+    if (tid == 0) {
+        int* r = out.meta + 12ll * ti;
+        r[0] = (int)tp; r[1] = nP; r[2] = (int)tf; r[3] = nF; r[4] = (int)fv; r[5] = fw; r[6] = cb; r[7] = nC; r[8] = (int)cfb; r[9] = cw;
+        r[10] = (notQuads ? 0 : 1) | (notHex ? 0 : 2); r[11] = 0;
+    }
+}
+// per tile: the four running sums the tables' offsets are
+__global__ void __launch_bounds__(kT) k_tl_geomTerms(int nTiles, GeomSizes sz, long long* a, long long* b, long long* c, long long* d) {
+    const int ti = blockIdx.x * kT + threadIdx.x;
+    if (ti >= nTiles) return;
+    a[ti] = sz.nPts[ti]; b[ti] = sz.nFcs[ti]; c[ti] = (long long)sz.nFcs[ti] * sz.fw[ti]; d[ti] = (long long)sz.cw[ti] * kT;
+}
+
+
+// ---- edge tiles (face-angle filter) -------------------------------------------------------------------------------------------------
+struct EdgeIn {
+    const int* order; const int* edgeBeg; int nTiles;
+    const int* edges; const int* efOff; const int* efFace; const int* ecOff; const int* ecCell; const int* ringFace; const int* ringCell; const uint8_t* ringOk;
+};
+struct EdgeSizes { int* nPts; int* nFcs; int* nCls; int* wf; int* wc; int* bad; };
+struct EdgeOut {
+    const long long* tpOff; const long long* tfOff; const long long* tcOff; const long long* efBase; const long long* ecBase;
+    int* tpIds; int* tfIds; int* tcIds; uint16_t* epLoc; uint16_t* efEll; uint16_t* ecEll; int* meta;
+};
+template <bool FILL>
+__global__ void __launch_bounds__(kT) k_tl_edge(EdgeIn in, EdgeSizes sz, EdgeOut out) {
+    __shared__ int sFcs[kBuf], sCls[kBuf], sPts[2 * kT], sh[kT / 64 + 1];
+    const int ti = blockIdx.x, tid = threadIdx.x;
+    const int eb = in.edgeBeg[ti], nEd = in.edgeBeg[ti + 1] - eb;
+    if (nEd > kT) { if (tid == 0) *sz.bad = 1; return; }
+    const int e = (tid < nEd) ? in.order[eb + tid] : -1;
+    const int fb = (e >= 0) ? in.efOff[e] : 0, nf = (e >= 0) ? in.efOff[e + 1] - fb : 0;
+    const int cb = (e >= 0) ? in.ecOff[e] : 0, nc = (e >= 0) ? in.ecOff[e + 1] - cb : 0;
+    int rawF, rawC;
+    const int atF = blockExclusive(nf, sh, rawF);
+    const int atC = blockExclusive(nc, sh, rawC);
+    if (rawF > kBuf || rawC > kBuf) { if (tid == 0) *sz.bad = 1; return; }
+    for (int k = 0; k < nf; ++k) sFcs[atF + k] = in.efFace[fb + k];
+    for (int k = 0; k < nc; ++k) sCls[atC + k] = in.ecCell[cb + k];
+    if (e >= 0) { sPts[2 * tid] = in.edges[2 * e]; sPts[2 * tid + 1] = in.edges[2 * e + 1]; }
+    __syncthreads();
+    const int nF = sortUnique(sFcs, rawF, sh);
+    const int nC = sortUnique(sCls, rawC, sh);
+    const int nP = sortUnique(sPts, 2 * nEd, sh);
+    const int wf = roundUp4d(blockMax(nf, sh)), wc = roundUp4d(blockMax(nc, sh));
+    if (nP > 32766 || nF > 32766 || nC > 32766 || wf > 252 || wc > 252) { if (tid == 0) *sz.bad = 1; return; }
+    if (!FILL) {
+        if (tid == 0) { sz.nPts[ti] = nP; sz.nFcs[ti] = nF; sz.nCls[ti] = nC; sz.wf[ti] = wf; sz.wc[ti] = wc; }
+        return;
+    }
+    const long long tp = out.tpOff[ti], tf = out.tfOff[ti], tc = out.tcOff[ti], efb = out.efBase[ti], ecb = out.ecBase[ti];
+    for (int i = tid; i < nP; i += kT) out.tpIds[tp + i] = sPts[i];
+    for (int i = tid; i < nF; i += kT) out.tfIds[tf + i] = sFcs[i];
+    for (int i = tid; i < nC; i += kT) out.tcIds[tc + i] = sCls[i];
+    if (e >= 0) {
+        out.epLoc[2 * (long long)(eb + tid)] = (uint16_t)lowerBound(sPts, nP, in.edges[2 * e]);
+        out.epLoc[2 * (long long)(eb + tid) + 1] = (uint16_t)lowerBound(sPts, nP, in.edges[2 * e + 1]);
+        if (in.ringOk[e]) {      // (else all-pad rows: the filter flags the edge UNSURE)
+            for (int j = 0; j < nf; ++j) out.efEll[efb + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)lowerBound(sFcs, nF, in.ringFace[fb + j]);
+            for (int j = 0; j < nc; ++j) out.ecEll[ecb + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)lowerBound(sCls, nC, in.ringCell[cb + j]);
+        }
+    }
+    if (tid == 0) {
+        int* r = out.meta + 12ll * ti;
+        r[0] = eb; r[1] = nEd; r[2] = (int)tp; r[3] = nP; r[4] = (int)tf; r[5] = nF; r[6] = (int)tc; r[7] = nC; r[8] = (int)efb; r[9] = wf; r[10] = (int)ecb; r[11] = wc;
+    }
+}
+__global__ void __launch_bounds__(kT) k_tl_edgeTerms(int nTiles, EdgeSizes sz, long long* a, long long* b, long long* c, long long* d, long long* e) {
+    const int ti = blockIdx.x * kT + threadIdx.x;
+    if (ti >= nTiles) return;
+    a[ti] = sz.nPts[ti]; b[ti] = sz.nFcs[ti]; c[ti] = sz.nCls[ti]; d[ti] = (long long)sz.wf[ti] * kT; e[ti] = (long long)sz.wc[ti] * kT;
+}
+// the face ids of the edge tiles as positions in the geometry tiles' face lists (where the geometry kernel stores the face vertex
+// averages the filter reads): facePos[f] = position of f in its owner's tile
+__global__ void __launch_bounds__(kT) k_tl_facePos(long long n, const int* __restrict__ geomTfIds, int* __restrict__ facePos) {
+    const long long k = (long long)blockIdx.x * kT + threadIdx.x;
+    if (k < n && geomTfIds[k] < 0) facePos[geomTfIds[k] & 0x7fffffff] = (int)k;
+}
+__global__ void __launch_bounds__(kT) k_tl_remap(long long n, int* __restrict__ ids, const int* __restrict__ facePos) {
+    const long long k = (long long)blockIdx.x * kT + threadIdx.x;
+    if (k < n) ids[k] = facePos[ids[k]];
+}
+
+struct DevBuf {
+    std::vector<void*> all;
+    ~DevBuf() { for (void* p : all) (void)hipFree(p); }
+    template <class T> T* get(size_t n) {
+        void* p = nullptr;
+        if (hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        all.push_back(p);
+        return (T*)p;
+    }
+    void release(void* p) { auto it = std::find(all.begin(), all.end(), p); if (it != all.end()) all.erase(it); }
+};
+
+}  // namespace
+
+// gt.order / gt.cellBeg / gt.nTiles / gt.threads stand (host: GeomTiles::buildBoundaries).  0: the tables are in `out` (device) and
+// gt holds what the host reads (offsets, widths, flags, tfIds, maxima); 1: not handled here (host tables); 2: a HIP error.
+int buildGeomTablesOnDevice(GeomTiles& gt, const DeviceTopologyArrays& td, int32_t nCells, int device, GeomTilesDev& out, std::string& why) {
+    if (!td.valid || !td.owner.p || gt.threads != kT || gt.nTiles <= 0) return 1;
+    TL_OK(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    TL_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+    const int nT = gt.nTiles;
+    DevBuf D;
+    int *dOrder = D.get<int>((size_t)nCells), *dBeg = D.get<int>((size_t)nT + 1), *cellTile = D.get<int>((size_t)nCells);
+    int *nPts = D.get<int>((size_t)nT), *nFcs = D.get<int>((size_t)nT), *fw = D.get<int>((size_t)nT), *cw = D.get<int>((size_t)nT), *flags = D.get<int>((size_t)nT), *bad = D.get<int>(1);
+    long long* terms = D.get<long long>(8 * ((size_t)nT + 1));
+    if (!dOrder || !dBeg || !cellTile || !nPts || !nFcs || !fw || !cw || !flags || !bad || !terms) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemcpyAsync(dOrder, gt.order.data(), (size_t)nCells * 4, hipMemcpyHostToDevice, st));
+    TL_OK(hipMemcpyAsync(dBeg, gt.cellBeg.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice, st));
+    TL_OK(hipMemsetAsync(bad, 0, 4, st));
+    GeomIn in{dOrder, dBeg, nT, (const int*)td.cfOff.p, (const int*)td.cfVal.p, (const int*)td.faceOff.p, (const int*)td.facePts.p, (const int*)td.owner.p, cellTile};
+    GeomSizes sz{nPts, nFcs, fw, cw, flags, bad};
+    hipLaunchKernelGGL(k_tl_cellTile, dim3(nT), dim3(kT), 0, st, in, cellTile);
+    hipLaunchKernelGGL(k_tl_geom<false>, dim3(nT), dim3(kT), 0, st, in, sz, GeomOut{});
+    // offsets: exclusive scans of the four per-tile terms (64-bit: the totals are checked against int32 addressing below)
+    long long *tA = terms, *tB = tA + nT + 1, *tC = tB + nT + 1, *tD = tC + nT + 1, *oA = tD + nT + 1, *oB = oA + nT + 1, *oC = oB + nT + 1, *oD = oC + nT + 1;
+    TL_OK(hipMemsetAsync(terms, 0, 8 * ((size_t)nT + 1) * 8, st));
+    hipLaunchKernelGGL(k_tl_geomTerms, dim3((nT + kT - 1) / kT), dim3(kT), 0, st, nT, sz, tA, tB, tC, tD);
+    size_t tempBytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, tempBytes, tA, oA, 0ll, (size_t)nT + 1, rocprim::plus<long long>(), st);
+    void* temp = D.get<char>(tempBytes + 256);
+    if (!temp) { why = "device allocation failed"; return 2; }
+    for (int q = 0; q < 4; ++q) {
+        size_t b = tempBytes;
+        TL_OK(rocprim::exclusive_scan(temp, b, tA + (size_t)q * (nT + 1), oA + (size_t)q * (nT + 1), 0ll, (size_t)nT + 1, rocprim::plus<long long>(), st));
+    }
+    std::vector<long long> offs(4 * ((size_t)nT + 1));
+    int hbad = 0;
+    TL_OK(hipMemcpyAsync(offs.data(), oA, offs.size() * 8, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    if (hbad) return 1;
+    const long long nTp = offs[(size_t)nT], nTf = offs[(size_t)(nT + 1) + nT], nFv = offs[2 * (size_t)(nT + 1) + nT], nCf = offs[3 * (size_t)(nT + 1) + nT];
+    if (nTp > 0x7fffffffll || nTf > 0x7fffffffll || nFv > 0x7fffffffll || nCf > 0x7fffffffll) return 1;      // (the host build words the error)
+    int *tpIds = D.get<int>((size_t)nTp), *tfIds = D.get<int>((size_t)nTf), *meta = D.get<int>(12 * (size_t)nT);
+    uint16_t *faceVerts = D.get<uint16_t>((size_t)nFv), *cellFaces = D.get<uint16_t>((size_t)nCf);
+    if (!tpIds || !tfIds || !meta || !faceVerts || !cellFaces) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemsetAsync(cellFaces, 0xFF, (size_t)nCf * 2, st));
+    hipLaunchKernelGGL(k_tl_geom<true>, dim3(nT), dim3(kT), 0, st, in, sz, GeomOut{oA, oB, oC, oD, tpIds, tfIds, faceVerts, cellFaces, meta});
+    // what the host reads: offsets, widths, flags, maxima, the face ids (the face-angle filter's positions come from them)
+    std::vector<int> hN((size_t)nT), hF((size_t)nT), hFw((size_t)nT), hCw((size_t)nT), hFl((size_t)nT);
+    gt.tfIds.resize((size_t)nTf);
+    TL_OK(hipMemcpyAsync(hN.data(), nPts, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hF.data(), nFcs, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hFw.data(), fw, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hCw.data(), cw, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hFl.data(), flags, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(gt.tfIds.data(), tfIds, (size_t)nTf * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    TL_OK(hipGetLastError());
+    gt.tpOff.resize((size_t)nT + 1); gt.tfOff.resize((size_t)nT + 1); gt.fvBase.resize((size_t)nT); gt.cfBase.resize((size_t)nT);
+    gt.fvWidth.resize((size_t)nT); gt.cfWidth.resize((size_t)nT); gt.tileFlags.resize((size_t)nT);
+    gt.maxPoints = gt.maxFaces = 0;
+    for (int i = 0; i <= nT; ++i) { gt.tpOff[(size_t)i] = (int32_t)offs[(size_t)i]; gt.tfOff[(size_t)i] = (int32_t)offs[(size_t)(nT + 1) + i]; }
+    for (int i = 0; i < nT; ++i) {
+        gt.fvBase[(size_t)i] = (int32_t)offs[2 * (size_t)(nT + 1) + i]; gt.cfBase[(size_t)i] = (int32_t)offs[3 * (size_t)(nT + 1) + i];
+        gt.fvWidth[(size_t)i] = (uint8_t)hFw[(size_t)i]; gt.cfWidth[(size_t)i] = (uint8_t)hCw[(size_t)i]; gt.tileFlags[(size_t)i] = (uint8_t)hFl[(size_t)i];
+        gt.maxPoints = std::max(gt.maxPoints, hN[(size_t)i]); gt.maxFaces = std::max(gt.maxFaces, hF[(size_t)i]);
+    }
+    gt.tpIds.clear(); gt.faceVerts.clear(); gt.cellFaces.clear();      // (device only: tpIds' length is tpOff.back())
+    auto give = [&](GeomTilesDev::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
+    give(out.cellOrder, dOrder, (size_t)nCells * 4); give(out.cellBeg, dBeg, ((size_t)nT + 1) * 4);
+    give(out.tpIds, tpIds, (size_t)nTp * 4); give(out.tfIds, tfIds, (size_t)nTf * 4);
+    give(out.faceVerts, faceVerts, (size_t)nFv * 2); give(out.cellFaces, cellFaces, (size_t)nCf * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
+    out.valid = true;
+    return 0;
+}
+
+// et.order / et.edgeBeg / et.nTiles / et.threads stand (host: EdgeTiles::buildBoundaries).  Return values as buildGeomTablesOnDevice.
+int buildEdgeTablesOnDevice(EdgeTiles& et, const DeviceTopologyArrays& td, int32_t nEdges, int device, EdgeTilesDev& out, std::string& why) {
+    if (!td.valid || et.threads != kT || et.nTiles <= 0) return 1;
+    TL_OK(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    TL_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+    const int nT = et.nTiles;
+    DevBuf D;
+    int *dOrder = D.get<int>((size_t)nEdges), *dBeg = D.get<int>((size_t)nT + 1);
+    int *nPts = D.get<int>((size_t)nT), *nFcs = D.get<int>((size_t)nT), *nCls = D.get<int>((size_t)nT), *wf = D.get<int>((size_t)nT), *wc = D.get<int>((size_t)nT), *bad = D.get<int>(1);
+    long long* terms = D.get<long long>(10 * ((size_t)nT + 1));
+    if (!dOrder || !dBeg || !nPts || !nFcs || !nCls || !wf || !wc || !bad || !terms) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemcpyAsync(dOrder, et.order.data(), (size_t)nEdges * 4, hipMemcpyHostToDevice, st));
+    TL_OK(hipMemcpyAsync(dBeg, et.edgeBeg.data(), ((size_t)nT + 1) * 4, hipMemcpyHostToDevice, st));
+    TL_OK(hipMemsetAsync(bad, 0, 4, st));
+    EdgeIn in{dOrder, dBeg, nT, (const int*)td.edges.p, (const int*)td.efOff.p, (const int*)td.efFace.p, (const int*)td.ecOff.p, (const int*)td.ecCell.p,
+              (const int*)td.ringFace.p, (const int*)td.ringCell.p, (const uint8_t*)td.edgeRingOk.p};
+    EdgeSizes sz{nPts, nFcs, nCls, wf, wc, bad};
+    hipLaunchKernelGGL(k_tl_edge<false>, dim3(nT), dim3(kT), 0, st, in, sz, EdgeOut{});
+    const size_t S = (size_t)nT + 1;
+    TL_OK(hipMemsetAsync(terms, 0, 10 * S * 8, st));
+    hipLaunchKernelGGL(k_tl_edgeTerms, dim3((nT + kT - 1) / kT), dim3(kT), 0, st, nT, sz, terms, terms + S, terms + 2 * S, terms + 3 * S, terms + 4 * S);
+    long long* offsD = terms + 5 * S;
+    size_t tempBytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, tempBytes, terms, offsD, 0ll, S, rocprim::plus<long long>(), st);
+    void* temp = D.get<char>(tempBytes + 256);
+    if (!temp) { why = "device allocation failed"; return 2; }
+    for (int q = 0; q < 5; ++q) { size_t b = tempBytes; TL_OK(rocprim::exclusive_scan(temp, b, terms + (size_t)q * S, offsD + (size_t)q * S, 0ll, S, rocprim::plus<long long>(), st)); }
+    std::vector<long long> offs(5 * S);
+    int hbad = 0;
+    TL_OK(hipMemcpyAsync(offs.data(), offsD, offs.size() * 8, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    if (hbad) return 1;
+    const long long nTp = offs[(size_t)nT], nTf = offs[S + nT], nTc = offs[2 * S + nT], nEf = offs[3 * S + nT], nEc = offs[4 * S + nT];
+    if (nTp > 0x7fffffffll || nTf > 0x7fffffffll || nTc > 0x7fffffffll || nEf > 0x7fffffffll || nEc > 0x7fffffffll) return 1;
+    int *tpIds = D.get<int>((size_t)nTp), *tfIds = D.get<int>((size_t)nTf), *tcIds = D.get<int>((size_t)nTc), *meta = D.get<int>(12 * (size_t)nT);
+    uint16_t *epLoc = D.get<uint16_t>(2 * (size_t)nEdges), *efEll = D.get<uint16_t>((size_t)nEf), *ecEll = D.get<uint16_t>((size_t)nEc);
+    if (!tpIds || !tfIds || !tcIds || !meta || !epLoc || !efEll || !ecEll) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemsetAsync(efEll, 0xFF, (size_t)nEf * 2, st));
+    TL_OK(hipMemsetAsync(ecEll, 0xFF, (size_t)nEc * 2, st));
+    TL_OK(hipMemsetAsync(epLoc, 0, 2 * (size_t)nEdges * 2, st));
+    hipLaunchKernelGGL(k_tl_edge<true>, dim3(nT), dim3(kT), 0, st, in, sz, EdgeOut{offsD, offsD + S, offsD + 2 * S, offsD + 3 * S, offsD + 4 * S, tpIds, tfIds, tcIds, epLoc, efEll, ecEll, meta});
+    std::vector<int> hP((size_t)nT), hF((size_t)nT), hC((size_t)nT), hWf((size_t)nT), hWc((size_t)nT);
+    TL_OK(hipMemcpyAsync(hP.data(), nPts, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hF.data(), nFcs, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hC.data(), nCls, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hWf.data(), wf, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipMemcpyAsync(hWc.data(), wc, (size_t)nT * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    TL_OK(hipGetLastError());
+    et.tpOff.resize(S); et.tfOff.resize(S); et.tcOff.resize(S); et.efBase.resize((size_t)nT); et.ecBase.resize((size_t)nT); et.efWidth.resize((size_t)nT); et.ecWidth.resize((size_t)nT);
+    et.maxPoints = et.maxFaces = et.maxCells = 0;
+    for (size_t i = 0; i < S; ++i) { et.tpOff[i] = (int32_t)offs[i]; et.tfOff[i] = (int32_t)offs[S + i]; et.tcOff[i] = (int32_t)offs[2 * S + i]; }
+    for (int i = 0; i < nT; ++i) {
+        et.efBase[(size_t)i] = (int32_t)offs[3 * S + i]; et.ecBase[(size_t)i] = (int32_t)offs[4 * S + i];
+        et.efWidth[(size_t)i] = (uint8_t)hWf[(size_t)i]; et.ecWidth[(size_t)i] = (uint8_t)hWc[(size_t)i];
+        et.maxPoints = std::max(et.maxPoints, hP[(size_t)i]); et.maxFaces = std::max(et.maxFaces, hF[(size_t)i]); et.maxCells = std::max(et.maxCells, hC[(size_t)i]);
+    }
+    et.tpIds.clear(); et.tfIds.clear(); et.tcIds.clear(); et.epLoc.clear(); et.efEll.clear(); et.ecEll.clear();
+    auto give = [&](EdgeTilesDev::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
+    give(out.order, dOrder, (size_t)nEdges * 4); give(out.edgeBeg, dBeg, S * 4);
+    give(out.tpIds, tpIds, (size_t)nTp * 4); give(out.tfIds, tfIds, (size_t)nTf * 4); give(out.tcIds, tcIds, (size_t)nTc * 4);
+    give(out.epLoc, epLoc, 2 * (size_t)nEdges * 2); give(out.efEll, efEll, (size_t)nEf * 2); give(out.ecEll, ecEll, (size_t)nEc * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
+    out.nTf = nTf;
+    out.valid = true;
+    return 0;
+}
+
+// ids[k] = position of face ids[k] in the geometry tiles' face lists (device arrays); 0 ok, 2 HIP error
+int remapEdgeFaceIdsOnDevice(const int* geomTfIds, long long nGeomTf, int32_t nFaces, int* edgeTfIds, long long nEdgeTf, int device, std::string& why) {
+    TL_OK(hipSetDevice(device));
+    int* facePos = nullptr;
+    TL_OK(hipMalloc((void**)&facePos, std::max<size_t>((size_t)nFaces, 1) * 4));
+    struct Free { int* p; ~Free() { (void)hipFree(p); } } guard{facePos};
+    TL_OK(hipMemset(facePos, 0xFF, (size_t)nFaces * 4));
+    hipLaunchKernelGGL(k_tl_facePos, dim3((unsigned)((nGeomTf + kT - 1) / kT)), dim3(kT), 0, nullptr, nGeomTf, geomTfIds, facePos);
+    hipLaunchKernelGGL(k_tl_remap, dim3((unsigned)((nEdgeTf + kT - 1) / kT)), dim3(kT), 0, nullptr, nEdgeTf, edgeTfIds, facePos);
+    TL_OK(hipDeviceSynchronize());
+    TL_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace smgpu

@@ -72,6 +72,7 @@ struct Topology {
 // the device arrays of a device build that the kernels read as they are (MeshView): handed to the caller instead of being freed
 struct DeviceTopologyArrays {
     struct Arr { void* p = nullptr; size_t bytes = 0; };
+    Arr owner, neighbour;      // (not read by the loop's kernels: the device builds of the tile tables do, tiles_dev.hip)
     Arr faceOff, facePts, cfOff, cfVal, pcOff, pcVal, ppOff, ppPt, peEdge, pfOff, pfFace, pfPrev, pfNext, pfPrevSlot, pfNextSlot, ringFace, ringCell,
         edgeRingOk, edges, efOff, efFace, ecOff, ecCell, ecF0, ecF1;
     bool valid = false;

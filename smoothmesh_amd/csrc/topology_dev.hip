@@ -470,6 +470,21 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
         if (failed) copyFailed = true;
         jobs.clear();
     };
+    if (keep) {      // what the kernels read as it is stays on the device, owned by the caller -- from here on (the hooks below start
+                     // tile-table builds that read these arrays); a later failure leaves the caller to free them
+        auto give = [&](DeviceTopologyArrays::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
+        give(keep->faceOff, dFo, ((size_t)nF + 1) * 4); give(keep->facePts, dFp, (size_t)nnz * 4);
+        give(keep->cfOff, cfOff, ((size_t)nC + 1) * 4); give(keep->cfVal, cfVal, (size_t)nCF * 4);
+        give(keep->pcOff, pcOff, ((size_t)nP + 1) * 4); give(keep->pcVal, pcVal, (size_t)nPC * 4);
+        give(keep->ppOff, ppOff, ((size_t)nP + 1) * 4); give(keep->ppPt, ppPt, 2 * (size_t)nE * 4); give(keep->peEdge, peEdge, 2 * (size_t)nE * 4);
+        give(keep->pfOff, pfOff, ((size_t)nP + 1) * 4); give(keep->pfFace, pfFace, (size_t)nnz * 4); give(keep->pfPrev, pfPrev, (size_t)nnz * 4); give(keep->pfNext, pfNext, (size_t)nnz * 4);
+        give(keep->pfPrevSlot, prevSlot, (size_t)nnz); give(keep->pfNextSlot, nextSlot, (size_t)nnz);
+        give(keep->ringFace, ringFace, (size_t)nnz * 4); give(keep->ringCell, ringCell, (size_t)nEC * 4); give(keep->edgeRingOk, ringOk, (size_t)nE);
+        give(keep->edges, edges, 2 * (size_t)nE * 4); give(keep->efOff, efOff, ((size_t)nE + 1) * 4); give(keep->efFace, efFace, (size_t)nnz * 4);
+        give(keep->ecOff, ecOff, ((size_t)nE + 1) * 4); give(keep->ecCell, ecCell, (size_t)nEC * 4); give(keep->ecF0, ecF0, (size_t)nEC); give(keep->ecF1, ecF1, (size_t)nEC);
+        give(keep->owner, dOwn, (size_t)nF * 4); give(keep->neighbour, dNei, (size_t)std::max(nIF, 1) * 4);
+        keep->valid = true;
+    }
     t.facePoints.off.assign(faceOffsets, faceOffsets + nF + 1);
     t.facePoints.val.assign(facePts, facePts + nnz);
     t.owner.assign(own, own + nF);
@@ -496,19 +511,6 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     flush();
     if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
     lap("download: edge lists");
-    if (keep) {      // what the kernels read as it is stays on the device, owned by the caller
-        auto give = [&](DeviceTopologyArrays::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
-        give(keep->faceOff, dFo, ((size_t)nF + 1) * 4); give(keep->facePts, dFp, (size_t)nnz * 4);
-        give(keep->cfOff, cfOff, ((size_t)nC + 1) * 4); give(keep->cfVal, cfVal, (size_t)nCF * 4);
-        give(keep->pcOff, pcOff, ((size_t)nP + 1) * 4); give(keep->pcVal, pcVal, (size_t)nPC * 4);
-        give(keep->ppOff, ppOff, ((size_t)nP + 1) * 4); give(keep->ppPt, ppPt, 2 * (size_t)nE * 4); give(keep->peEdge, peEdge, 2 * (size_t)nE * 4);
-        give(keep->pfOff, pfOff, ((size_t)nP + 1) * 4); give(keep->pfFace, pfFace, (size_t)nnz * 4); give(keep->pfPrev, pfPrev, (size_t)nnz * 4); give(keep->pfNext, pfNext, (size_t)nnz * 4);
-        give(keep->pfPrevSlot, prevSlot, (size_t)nnz); give(keep->pfNextSlot, nextSlot, (size_t)nnz);
-        give(keep->ringFace, ringFace, (size_t)nnz * 4); give(keep->ringCell, ringCell, (size_t)nEC * 4); give(keep->edgeRingOk, ringOk, (size_t)nE);
-        give(keep->edges, edges, 2 * (size_t)nE * 4); give(keep->efOff, efOff, ((size_t)nE + 1) * 4); give(keep->efFace, efFace, (size_t)nnz * 4);
-        give(keep->ecOff, ecOff, ((size_t)nE + 1) * 4); give(keep->ecCell, ecCell, (size_t)nEC * 4); give(keep->ecF0, ecF0, (size_t)nEC); give(keep->ecF1, ecF1, (size_t)nEC);
-        keep->valid = true;
-    }
     return 0;
 }
 

@@ -140,7 +140,7 @@ class HostTopology:
 
     def checksums(self):
         """FNV-1a checksums of every array of the addressing, TOPO_ARRAYS order (include/smgpu.h smgpu_topology_checksums)"""
-        out = (C.c_uint64 * 32)()
+        out = (C.c_uint64 * 64)()
         if self._lib.smgpu_topology_checksums(self._h, out):
             raise SmgpuError(self._lib.smgpu_last_error().decode())
         return [int(x) for x in out][:len(TOPO_ARRAYS)]
@@ -459,9 +459,15 @@ class SmoothEngine:
 
     def debug_addressing_checksums(self):
         """checksums of the engine's addressing (built on the device where the mesh allows), TOPO_ARRAYS order"""
-        out = (C.c_uint64 * 32)()
+        out = (C.c_uint64 * 64)()
         self._check(self._lib.smgpu_debug_addressing_checksums(self._h, out))
         return [int(x) for x in out][:len(TOPO_ARRAYS)]
+
+    def debug_tile_checksums(self):
+        """checksums of the geometry tile tables as the kernels read them (include/smgpu.h smgpu_debug_tile_checksums)"""
+        out = (C.c_uint64 * 64)()
+        self._check(self._lib.smgpu_debug_tile_checksums(self._h, out))
+        return [int(x) for x in out]
 
     def debug_halo_mode(self):
         """how the last multi-rank iteration went out: {"multi_role", "flagged", "fix_inside"} (include/smgpu.h)"""
