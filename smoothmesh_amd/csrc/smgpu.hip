@@ -132,6 +132,8 @@ struct smgpu_handle {
     GeomTiles gt;
     GeomTilesDev gtDev;        // the geometry tile tables of a device build (tiles_dev.hip): read where they were built
     EdgeTilesDev etDev;        // ... and the edge tile tables
+    SmoothTilesDev stDev;      // ... and the smoothing tile tables
+    DeviceTopologyArrays devLists;   // (not owning: the adopted arrays of a device build, for downloadDeferredLists)
     SmoothTiles stl;
     GeomTileView gv{};
     SmoothTileView sv{};
@@ -374,7 +376,7 @@ static bool swapApplyOn(const smgpu_handle* h) {
 static void computeAlgoBytes(smgpu_handle* h) {
     const Topology& t = h->topo;
     const int64_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
-    const int64_t nfp = t.facePoints.nnz(), npc = t.pointCells.nnz(), npp = t.pointEdges.nnz(), npf = t.pointFaces.nnz();
+    const int64_t nfp = t.facePoints.nnz(), npc = t.pointCells.nnz(), npp = (int64_t)t.pointPoints.size(), npf = t.facePoints.nnz();      // (sizes of lists that are on the host in every build)
     const int64_t nef = t.edgeFaces.nnz(), nec = t.edgeCells.nnz(), ncf = t.cellFacesGeom.nnz();
     const bool fa = h->prm.faceAngleConstraint;
     int64_t* b = h->algoBytes;
@@ -452,6 +454,13 @@ extern "C" {
 const char* smgpu_last_error(void) { return g_err.c_str(); }
 const char* smgpu_version(void) { return "smgpu 0.1 (gfx950)"; }
 
+// the lists of a device build that stayed on the device only (topology.hpp, downloadDeferredLists), for the few host readers
+static int ensureHostLists(smgpu_handle* h, int groups) {
+    if (!h->devLists.valid) return 0;
+    std::string why;
+    return downloadDeferredLists(h->topo, h->devLists, h->device, why, groups) ? fail("device -> host copy of the addressing: " + why) : 0;
+}
+
 int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (!d || !out) return fail("smgpu_create: null argument");
     *out = nullptr;
@@ -469,7 +478,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     const bool mortonTiles = envInt("SMGPU_TILE_MORTON", 1) != 0;
     std::future<std::vector<int32_t>> fPointOrder;
     if (wantTiles && mortonTiles) fPointOrder = std::async(std::launch::async, [&] { return mortonOrderOf(d->nPoints, d->points); });
-    std::future<std::string> fGeom, fSmooth;
+    std::future<std::string> fGeom, fSmooth, fEdge;
+    std::function<void()> startEdge;
+    static const char* const kHostTablesPending = "\x01host tables pending";      // a tile task of a device build that leaves its tables to the host
     std::vector<int32_t> pointOrder;
     std::vector<uint8_t> internalMask;
     DeviceTopologyArrays devTopo;      // a device build's arrays: the kernels read them as they are (no upload of the host copy)
@@ -480,19 +491,21 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const int capSC0 = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * smoothT0, 1500)), capSN0 = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * smoothT0, 1500));
         const bool geomOk = geomT0 == 64 || geomT0 == 128 || geomT0 == 256, smoothOk = smoothT0 == 64 || smoothT0 == 128 || smoothT0 == 256;
         // tile boundaries on the host, the tables on the device where the addressing was built there (tiles_dev.hip), else on the host
+        // (SMGPU_DEVICE_TILES=2: as if the device builds handed their tables back -- the tests' way into that path)
         const bool devTiles = envInt("SMGPU_DEVICE_TILES", 1) != 0;
         const auto afterCells = [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
                       const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0);
                       if (!e.empty()) return e;
-                      if (devTiles && devTopo.valid) {
+                      if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);      // (the host's lists are still arriving)
+                      if (devTopo.valid) {
                           std::string why;
                           const auto t0 = std::chrono::steady_clock::now();
-                          const int rc = buildGeomTablesOnDevice(h->gt, devTopo, d->nCells, h->device, h->gtDev, why);
+                          const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildGeomTablesOnDevice(h->gt, devTopo, d->nCells, h->device, h->gtDev, why);
                           if (envInt("SMGPU_VERBOSE", 0) >= 2)
                               std::fprintf(stderr, "[smgpu] geometry tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
                                            std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
                           if (rc == 0) return std::string();
-                          if (rc == 2) return "device tile tables: " + why;
+                          return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);      // (the host's lists are still arriving)
                       }
                       return h->gt.buildTables(h->topo); }); };
         const auto afterPoints = [&] {
@@ -501,10 +514,48 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 internalMask.resize((size_t)d->nPoints);
                 for (int p = 0; p < d->nPoints; ++p) internalMask[(size_t)p] = d->isInternalPoint[p] ? 1 : 0;
                 h->isInternalHost = internalMask;
-                fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0] {
-                    return h->stl.build(h->topo, d->points, internalMask.data(), mortonTiles, smoothT0, capSC0, capSN0,
-                                        (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr); });
+                fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0, devTiles]() -> std::string {
+                    const std::string e = h->stl.buildBoundaries(h->topo, d->points, mortonTiles, smoothT0, capSC0, capSN0, (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr);
+                    if (!e.empty()) return e;
+                    if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);
+                    if (devTopo.valid) {
+                        std::string why;
+                        const auto t0 = std::chrono::steady_clock::now();
+                        const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildSmoothTablesOnDevice(h->stl, devTopo, d->nPoints, h->topo.maxPointPoints, internalMask.data(), h->device, h->stDev, why);
+                        if (envInt("SMGPU_VERBOSE", 0) >= 2)
+                            std::fprintf(stderr, "[smgpu] smoothing tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                        if (rc == 0) return std::string();
+                        return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);
+                    }
+                    return h->stl.buildTables(h->topo, internalMask.data()); });
             };
+        // the edge tiles (face-angle filter): behind the edge lists of a device build (its afterEdges hook), else behind the addressing
+        startEdge = [&, devTiles] {
+            if (!wantTiles) return;
+            if (fPointOrder.valid()) pointOrder = fPointOrder.get();
+            const std::vector<int32_t>* po = (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr;
+            const bool wantFilter = envInt("SMGPU_FILTER", 1) != 0;
+            const bool devTilesE = devTiles && devTopo.valid, devLists = devTopo.valid;
+            const DeviceTopologyArrays* dt = &devTopo;
+            fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles, devTilesE, devLists, dt]() -> std::string {
+                if (!wantFilter) return std::string("not built");
+                const std::string e = h->etl.buildBoundaries(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po);
+                if (!e.empty()) return e;
+                if (devLists && !devTilesE) return std::string(kHostTablesPending);
+                if (devTilesE) {
+                    std::string why;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildEdgeTablesOnDevice(h->etl, *dt, h->topo.nEdges, h->device, h->etDev, why);
+                    if (envInt("SMGPU_VERBOSE", 0) >= 2)
+                        std::fprintf(stderr, "[smgpu] edge tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                    if (rc == 0) return std::string();
+                    return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);
+                }
+                return h->etl.buildTables(h->topo);
+            });
+        };
         // the addressing on the device (topology_dev.hip: sorts + per-edge kernels, ~0.2 s for 10 M cells against 3.5 s of host
         // loops); the host build where the device path hands the mesh back (unusual meshes; it also words the reference's errors)
         std::string terr;
@@ -512,10 +563,11 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         if (dev > 0) {
             std::string why;
             dev = buildTopologyOnDevice(h->topo, d->nPoints, d->nCells, d->nFaces, d->nInternalFaces, d->faceOffsets, d->facePoints, d->owner, d->neighbour, h->device, why,
-                                        afterCells, afterPoints, &devTopo);
+                                        afterCells, afterPoints, &devTopo, startEdge, devTiles && wantTiles);
             if (dev == 2) {
                 if (fGeom.valid()) fGeom.wait();
                 if (fSmooth.valid()) fSmooth.wait();
+                if (fEdge.valid()) fEdge.wait();
                 if (fPointOrder.valid()) fPointOrder.wait();
                 delete h;
                 return fail("smgpu_create: device addressing: " + why);
@@ -533,12 +585,14 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             delete h;
             return fail("smgpu_create: " + terr);
         }
+        if (!fEdge.valid()) startEdge();
     }
     bool devAdopted = false;
     auto cleanup = [&](int rc) {   // (the host threads still read the handle's tables)
         if (fGeom.valid()) fGeom.wait();
         if (fSmooth.valid()) fSmooth.wait();
         if (fPointOrder.valid()) fPointOrder.wait();
+        if (fEdge.valid()) fEdge.wait();
         if (devTopo.valid && !devAdopted)      // a device build's arrays the handle has not taken over yet
             for (const DeviceTopologyArrays::Arr* a : {&devTopo.faceOff, &devTopo.facePts, &devTopo.cfOff, &devTopo.cfVal, &devTopo.pcOff, &devTopo.pcVal, &devTopo.ppOff,
                                                        &devTopo.ppPt, &devTopo.peEdge, &devTopo.pfOff, &devTopo.pfFace, &devTopo.pfPrev, &devTopo.pfNext, &devTopo.pfPrevSlot,
@@ -556,33 +610,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     }
     const Topology& t = h->topo;
     MeshView& m = h->mv;
-    // the edge tile tables (face-angle filter) need the whole addressing: they start here, next to the uploads below and to the
-    // other two tile builds (before round 5 they started behind the uploads)
-    std::future<std::string> fEdge;
     const double tTopo = sinceCreate();
-    if (wantTiles) {
-        if (fPointOrder.valid()) pointOrder = fPointOrder.get();
-        const std::vector<int32_t>* po = (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr;
-        const bool wantFilter = envInt("SMGPU_FILTER", 1) != 0;
-        const bool devTilesE = envInt("SMGPU_DEVICE_TILES", 1) != 0 && devTopo.valid;
-        const DeviceTopologyArrays* dt = &devTopo;
-        fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles, devTilesE, dt]() -> std::string {
-            if (!wantFilter) return std::string("not built");
-            const std::string e = h->etl.buildBoundaries(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po);
-            if (!e.empty()) return e;
-            if (devTilesE) {
-                std::string why;
-                const auto t0 = std::chrono::steady_clock::now();
-                const int rc = buildEdgeTablesOnDevice(h->etl, *dt, h->topo.nEdges, h->device, h->etDev, why);
-                if (envInt("SMGPU_VERBOSE", 0) >= 2)
-                    std::fprintf(stderr, "[smgpu] edge tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
-                                 std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-                if (rc == 0) return std::string();
-                if (rc == 2) return "device tile tables: " + why;
-            }
-            return h->etl.buildTables(h->topo);
-        });
-    }
+    double tLap = tTopo;
+    auto lapC = [&](const char* what) { if (envInt("SMGPU_VERBOSE", 0) >= 2) { const double now = sinceCreate(); std::fprintf(stderr, "[smgpu] create: %-28s %.3f s\n", what, now - tLap); tLap = now; } };
     auto cleanupE = [&](int rc0) { if (fEdge.valid()) fEdge.wait(); return cleanup(rc0); };
     m.nPoints = t.nPoints; m.nCells = t.nCells; m.nFaces = t.nFaces; m.nInternalFaces = t.nInternalFaces; m.nEdges = t.nEdges;
     std::vector<uint8_t> flags(t.nPoints);
@@ -594,6 +624,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     auto adopt = [&](auto*& dst, const DeviceTopologyArrays::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
     if (devTopo.valid) {
         devAdopted = true;
+        h->devLists = devTopo;
         adopt(m.faceOff, devTopo.faceOff);
         adopt(m.facePts, devTopo.facePts);
         adopt(m.cfOff, devTopo.cfOff);
@@ -648,6 +679,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     }
     rc |= devUpload(h, &m.pflags, flags);
     if (rc) return cleanupE(1);
+    lapC("addressing adopted / uploaded");
     // LDS staging tiles; SMGPU_TILES=0 keeps the direct-gather kernels (A/B and fallback)
     h->useTiles = envInt("SMGPU_TILES", 1) != 0;
     h->useFilter = envInt("SMGPU_FILTER", 1) != 0;
@@ -673,11 +705,17 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         const int capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
         // (the geometry and smoothing tables were started by the addressing's hooks, the edge tables behind it; SMGPU_GEOM_T etc. were read there)
         (void)geomCells; (void)capGP; (void)capGF; (void)capSC; (void)capSN;
-        const std::string e2 = fSmooth.valid() ? fSmooth.get() : std::string("not built");
-        const std::string e1 = fGeom.valid() ? fGeom.get() : std::string("not built");
-        const std::string e3 = fEdge.valid() ? fEdge.get() : std::string("not built");
+        std::string e2 = fSmooth.valid() ? fSmooth.get() : std::string("not built");
+        std::string e1 = fGeom.valid() ? fGeom.get() : std::string("not built");
+        std::string e3 = fEdge.valid() ? fEdge.get() : std::string("not built");
+        // (a device build that handed a table set back: the host builds it now that all of its lists have arrived)
+        if (e1 == kHostTablesPending) e1 = h->gt.buildTables(h->topo);
+        std::string whyD;
+        if (e2 == kHostTablesPending) e2 = downloadDeferredLists(h->topo, devTopo, h->device, whyD, 1) ? "device -> host copy of the addressing: " + whyD : h->stl.buildTables(h->topo, internalMask.data());
+        if (e3 == kHostTablesPending) e3 = downloadDeferredLists(h->topo, devTopo, h->device, whyD, 2) ? "device -> host copy of the addressing: " + whyD : h->etl.buildTables(h->topo);
         if (envInt("SMGPU_VERBOSE", 0))
             std::fprintf(stderr, "[smgpu] set-up: addressing %.2f s, tile tables (3 host threads) %.2f s\n", tTopo, sinceCreate() - tTopo);
+        lapC("tile tasks joined");
         if (!e1.empty() || !e2.empty()) {
             h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
         } else {
@@ -715,23 +753,31 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 rc |= devUpload(h, &g.meta, meta);
             }
             g.maxPoints = h->gt.maxPoints; g.maxFaces = h->gt.maxFaces;
-            rc |= devUpload(h, &v.ptOrder, h->stl.order);
-            rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
+            if (h->stDev.valid) {
+                auto adoptS = [&](auto*& dst, const SmoothTilesDev::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
+                adoptS(v.ptOrder, h->stDev.order); adoptS(v.ptBeg, h->stDev.ptBeg); adoptS(v.tcIds, h->stDev.tcIds); adoptS(v.tnIds, h->stDev.tnIds); adoptS(v.selfLoc, h->stDev.selfLoc);
+                adoptS(v.pcEll, h->stDev.pcEll); adoptS(v.ppEll, h->stDev.ppEll); adoptS(v.pairEll, h->stDev.pairEll); adoptS(v.pfEll, h->stDev.pfEll); adoptS(v.meta, h->stDev.meta);
+                h->stDev.valid = false;
+            } else {
+                rc |= devUpload(h, &v.ptOrder, h->stl.order);
+                rc |= devUpload(h, &v.ptBeg, h->stl.ptBeg);
+                rc |= devUpload(h, &v.tcIds, h->stl.tcIds);
+                rc |= devUpload(h, &v.tnIds, h->stl.tnIds);
+                rc |= devUpload(h, &v.selfLoc, h->stl.selfLoc);
+                rc |= devUpload(h, &v.pcEll, h->stl.pcEll);
+                rc |= devUpload(h, &v.ppEll, h->stl.ppEll);
+                rc |= devUpload(h, &v.pairEll, h->stl.pairEll);
+                rc |= devUpload(h, &v.pfEll, h->stl.pfEll);
+            }
             rc |= devUpload(h, &v.tcOff, h->stl.tcOff);
-            rc |= devUpload(h, &v.tcIds, h->stl.tcIds);
             rc |= devUpload(h, &v.tnOff, h->stl.tnOff);
-            rc |= devUpload(h, &v.tnIds, h->stl.tnIds);
-            rc |= devUpload(h, &v.selfLoc, h->stl.selfLoc);
             rc |= devUpload(h, &v.pcBase, h->stl.pcBase);
             rc |= devUpload(h, &v.pcWidth, h->stl.pcWidth);
-            rc |= devUpload(h, &v.pcEll, h->stl.pcEll);
             rc |= devUpload(h, &v.ppBase, h->stl.ppBase);
             rc |= devUpload(h, &v.ppWidth, h->stl.ppWidth);
-            rc |= devUpload(h, &v.ppEll, h->stl.ppEll);
-            rc |= devUpload(h, &v.pairEll, h->stl.pairEll);
             rc |= devUpload(h, &v.pfBase, h->stl.pfBase);
             rc |= devUpload(h, &v.pfWidth, h->stl.pfWidth);
-            {   // SmoothTileMeta records
+            if (!v.meta) {   // SmoothTileMeta records
                 const auto& st = h->stl;
                 std::vector<int> meta((size_t)kSmoothMetaInts * (size_t)st.nTiles, 0);
                 for (int t = 0; t < st.nTiles; ++t) {
@@ -742,7 +788,6 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 }
                 rc |= devUpload(h, &v.meta, meta);
             }
-            rc |= devUpload(h, &v.pfEll, h->stl.pfEll);
             v.maxCells = h->stl.maxCells; v.maxPoints = h->stl.maxPoints;
             v.usePairShare = t.maxPointPoints <= 16 ? 1 : 0;
             if (h->useFilter) {
@@ -829,6 +874,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         }
         if (sizeof(double) * 9 * (size_t)h->eaMaxEntries > 60 * 1024) h->eaCoop = false;   // extreme valences: per-point form
     }
+    lapC("tile tables adopted / uploaded");
     State& s = h->st;
     const size_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
     rc |= devAlloc(h, &h->bufA, 3 * P);
@@ -851,7 +897,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.faPointList, P);
     rc |= devAlloc(h, &h->dEaMaybe, P);
     rc |= devAlloc(h, &s.faS, P);
-    rc |= devAlloc(h, &s.faN, (size_t)t.pointEdges.nnz());
+    rc |= devAlloc(h, &s.faN, t.pointPoints.size());
     rc |= devAlloc(h, &s.walkStack, P + 64);
     rc |= devAlloc(h, &s.acc, 1);
     {
@@ -861,12 +907,14 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         rc |= devAlloc(h, &s.blkCnt, nPart);
     }
     if (rc) return cleanup(1);
+    lapC("work arrays allocated");
     if (hipMemset(s.acc, 0, sizeof(Accum)) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemset(s.frozen, 0, P) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemcpy(h->bufA, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail("upload of points failed"));
-    if (hipMemcpy(s.prop, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+    if (hipMemcpy(s.prop, h->bufA, 3 * P * sizeof(double), hipMemcpyDeviceToDevice) != hipSuccess)
         return cleanup(fail("upload of points failed"));
+    lapC("points uploaded");
     s.ptsCur = h->bufA;
     s.ptsNext = h->bufB;
     s.stats = nullptr;
@@ -898,6 +946,9 @@ int smgpu_destroy(smgpu_handle* h) {
     for (auto& p : h->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (auto e : h->freeEvents) (void)hipEventDestroy(e);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->stDev.valid)
+        for (const SmoothTilesDev::Arr* a : {&h->stDev.order, &h->stDev.ptBeg, &h->stDev.tcIds, &h->stDev.tnIds, &h->stDev.selfLoc, &h->stDev.pcEll, &h->stDev.ppEll, &h->stDev.pairEll, &h->stDev.pfEll, &h->stDev.meta})
+            if (a->p) (void)hipFree(a->p);
     if (h->etDev.valid)
         for (const EdgeTilesDev::Arr* a : {&h->etDev.order, &h->etDev.edgeBeg, &h->etDev.tpIds, &h->etDev.tfIds, &h->etDev.tcIds, &h->etDev.epLoc, &h->etDev.efEll, &h->etDev.ecEll, &h->etDev.meta})
             if (a->p) (void)hipFree(a->p);
@@ -925,8 +976,8 @@ int smgpu_get_sizes(smgpu_handle* h, smgpu_sizes* o) {
     if (!h || !o) return fail("null argument");
     const Topology& t = h->topo;
     o->nPoints = t.nPoints; o->nCells = t.nCells; o->nFaces = t.nFaces; o->nInternalFaces = t.nInternalFaces; o->nEdges = t.nEdges;
-    o->nnzFacePoints = t.facePoints.nnz(); o->nnzPointCells = t.pointCells.nnz(); o->nnzPointPoints = t.pointEdges.nnz();
-    o->nnzPointFaces = t.pointFaces.nnz(); o->nnzEdgeFaces = t.edgeFaces.nnz(); o->nnzEdgeCells = t.edgeCells.nnz();
+    o->nnzFacePoints = t.facePoints.nnz(); o->nnzPointCells = t.pointCells.nnz(); o->nnzPointPoints = (int64_t)t.pointPoints.size();
+    o->nnzPointFaces = t.facePoints.nnz(); o->nnzEdgeFaces = t.edgeFaces.nnz(); o->nnzEdgeCells = t.edgeCells.nnz();
     o->nnzCellFaces = t.cellFacesGeom.nnz();
     o->deviceBytes = h->deviceBytes;
     return 0;
@@ -1185,7 +1236,7 @@ static int ensureWalkBuffers(smgpu_handle* h) {
         if (devAlloc(h, &h->dWalkMemo, (size_t)t.nPoints + 2)) return 1;
         HIP_OK(hipMemset(h->dWalkMemo, 0, ((size_t)t.nPoints + 2) * sizeof(unsigned long long)));
     }
-    const size_t P = t.nPoints, E = (size_t)t.pointEdges.nnz();
+    const size_t P = t.nPoints, E = t.pointPoints.size();
     h->walkBlocks = gridFor(t.nPoints);
     WalkView& w = h->wv;
     int rc = 0;
@@ -1409,7 +1460,7 @@ static int runFixWalk(smgpu_handle* h) {
     WalkView w = h->wv;
     const FixView fx = h->fxw;
     const int P = m.nPoints;
-    const int64_t maxEntries = (int64_t)h->topo.pointEdges.nnz();
+    const int64_t maxEntries = (int64_t)h->topo.pointPoints.size();
     // grids: enough workgroups to fill the chip several times over; the kernels stride over the device-side counts
     const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
     const int gChunks = chunkGrid(P), gRel = relGrid(P);
@@ -1995,6 +2046,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             for (int pi = 0; pi < P; ++pi) if (posSlot[(size_t)pi] >= 0) sub.push_back(h->stl.order[(size_t)pi]);
             std::vector<double> pts(3 * (size_t)P);      // (the builder only reads coordinates when it orders the points itself)
             const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500)), capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
+            if (ensureHostLists(h, 1)) return 1;      // (the tables' corner lists: pointFaces with prev / next)
             const std::string err = h->shr.build(h->topo, pts.data(), h->isInternalHost.data(), false, h->smoothT, capSC, capSN, nullptr, &sub);
             if (!err.empty()) return fail("shared-point tiles: " + err);
             if (uploadSmoothView(h, h->shr, h->hv, h->sv.usePairShare)) return 1;
@@ -3066,6 +3118,19 @@ int smgpu_debug_tile_checksums(smgpu_handle* h, uint64_t* out) {
     const size_t nCf = nT ? (size_t)gt.cfBase[(size_t)nT - 1] + (size_t)gt.cfWidth[(size_t)nT - 1] * (size_t)gt.threads : 0;
     if (dev(h->gv.cellOrder, (size_t)h->mv.nCells * 4) || dev(h->gv.tpIds, nTp * 4) || dev(h->gv.tfIds, nTf * 4) || dev(h->gv.faceVerts, nFv * 2) ||
         dev(h->gv.cellFaces, nCf * 2) || dev(h->gv.meta, (size_t)nT * kGeomMetaInts * 4)) return 1;
+    {      // the smoothing tiles
+        const SmoothTiles& st = h->stl;
+        const int nS = st.nTiles;
+        host(st.ptBeg); host(st.tcOff); host(st.tnOff); host(st.pcBase); host(st.pcWidth); host(st.ppBase); host(st.ppWidth); host(st.pfBase); host(st.pfWidth);
+        const int32_t mxS[2] = {st.maxCells, st.maxPoints};
+        out[k++] = fnv1a(mxS, sizeof(mxS));
+        const size_t nPc = nS ? (size_t)st.pcBase[(size_t)nS - 1] + (size_t)st.pcWidth[(size_t)nS - 1] * (size_t)st.threads : 0;
+        const size_t nPp = nS ? (size_t)st.ppBase[(size_t)nS - 1] + (size_t)st.ppWidth[(size_t)nS - 1] * (size_t)st.threads : 0;
+        const size_t nPfE = nS ? (size_t)st.pfBase[(size_t)nS - 1] + (size_t)st.pfWidth[(size_t)nS - 1] * (size_t)st.threads : 0;
+        if (dev(h->sv.ptOrder, (size_t)h->mv.nPoints * 4) || dev(h->sv.tcIds, (size_t)st.tcOff.back() * 4) || dev(h->sv.tnIds, (size_t)st.tnOff.back() * 4) ||
+            dev(h->sv.selfLoc, (size_t)h->mv.nPoints * 2) || dev(h->sv.pcEll, nPc * 2) || dev(h->sv.ppEll, nPp * 2) || dev(h->sv.pairEll, nPp * 2) || dev(h->sv.pfEll, nPfE * 2) ||
+            dev(h->sv.meta, (size_t)nS * kSmoothMetaInts * 4)) return 1;
+    }
     if (h->useFilter && h->ev.meta) {      // the edge tiles
         const EdgeTiles& et = h->etl;
         const int nE = et.nTiles;
@@ -3083,12 +3148,14 @@ int smgpu_debug_tile_checksums(smgpu_handle* h, uint64_t* out) {
 
 int smgpu_debug_addressing_checksums(smgpu_handle* h, uint64_t* out) {
     if (!h || !out) return fail("null argument");
+    if (ensureHostLists(h, 3)) return 1;
     topoChecksums(h->topo, out);
     return 0;
 }
 
 int smgpu_debug_get_addressing(smgpu_handle* h, const char* kind, int32_t* offsets, int32_t* values, int64_t* nnz) {
     if (!h || !kind || !nnz) return fail("null argument");
+    if (ensureHostLists(h, 1)) return 1;
     return topoGet(h->topo, kind, offsets, values, nnz);
 }
 

@@ -356,6 +356,12 @@ void chainCorners(std::vector<std::pair<int32_t, int32_t>>& corners, ChainScratc
 
 std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
                                int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset) {
+    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capCells, capPoints, pointOrder, subset);
+    return e.empty() ? buildTables(t, isInternal, subset != nullptr) : e;
+}
+
+std::string SmoothTiles::buildBoundaries(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capCells,
+                                         int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset) {
     threads = nThreads;
     PhaseTimer tm(subset ? "shared-point" : "smoothing");
     if (subset) order = *subset;
@@ -407,7 +413,14 @@ std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8
         if (nPos == 0) ptBeg.assign(1, 0);
     }
     tm.lap("boundaries");
+    return "";
+}
 
+std::string SmoothTiles::buildTables(const Topology& t, const uint8_t* isInternal, bool subset) {
+    PhaseTimer tm(subset ? "shared-point" : "smoothing");
+    const int32_t nPos = (int32_t)order.size();
+    const auto& pc = t.pointCells;
+    const auto& pe = t.pointEdges;   // offsets shared with pointPoints
     selfLoc.assign((size_t)nPos, 0);
     const bool pairs = t.maxPointPoints <= 16;
     struct Part {

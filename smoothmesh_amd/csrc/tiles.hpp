@@ -101,7 +101,19 @@ struct SmoothTiles {
     std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
                       int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder = nullptr,
                       const std::vector<int32_t>* subset = nullptr);
+    // the two halves of build(), as GeomTiles'
+    std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells, int32_t capPoints,
+                                const std::vector<int32_t>* pointOrder = nullptr, const std::vector<int32_t>* subset = nullptr);
+    std::string buildTables(const Topology& t, const uint8_t* isInternal, bool subset = false);
 };
+struct SmoothTilesDev {
+    struct Arr { void* p = nullptr; size_t bytes = 0; };
+    Arr order, ptBeg, tcIds, tnIds, selfLoc, pcEll, ppEll, pairEll, pfEll, meta;
+    bool valid = false;
+};
+// (maxPointPoints: Topology's; the neighbour-pair masks exist while it is <= 16)
+int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, int32_t nPoints, int32_t maxPointPoints, const uint8_t* isInternal, int device,
+                              SmoothTilesDev& out, std::string& why);
 
 // ---- face-angle filter: tile = edges (Morton order of the edge midpoints); LDS holds the points, the
 // face vertex averages and the cell centres the tile's edges need ------------------------------------------

@@ -248,6 +248,159 @@ __global__ void __launch_bounds__(kT) k_tl_remap(long long n, int* __restrict__ 
     if (k < n) ids[k] = facePos[ids[k]];
 }
 
+// ---- smoothing tiles ----------------------------------------------------------------------------------------------------------------
+// The face corners of every point in the order of Euler trails: tiles.cpp's chainCorners, statement for statement (the order is part
+// of the tables' bytes), one thread per point on arrays in its private memory.  It depends on the point only, not on the tiling:
+// one pass over the points, the tile kernel below maps the result to local indices.
+constexpr int kCh = 64;                 // corners (= faces) per point this kernel handles; a mesh beyond goes back to the host build
+__global__ void __launch_bounds__(64) k_tl_chain(int nPoints, const int* __restrict__ pfOff, const int* __restrict__ pfPrev, const int* __restrict__ pfNext,
+                                                 int* __restrict__ chPrev, int* __restrict__ chNext, int* bad) {
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= nPoints) return;
+    const int b = pfOff[p], n = pfOff[p + 1] - b;
+    if (n > kCh) { *bad = 1; return; }
+    if (n < 2) { for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; } return; }
+    int verts[2 * kCh];
+    uint8_t ea[2 * kCh], eb[2 * kCh], deg[2 * kCh], used[2 * kCh], stackV[2 * kCh + 1], compE[2 * kCh], compV[2 * kCh], adjEdge[4 * kCh];
+    short stackE[2 * kCh + 1];
+    unsigned short adjOff[2 * kCh + 1], next[2 * kCh];
+    int outA[kCh], outB[kCh];
+    for (int k = 0; k < n; ++k) { verts[2 * k] = pfPrev[b + k]; verts[2 * k + 1] = pfNext[b + k]; }
+    for (int i = 1; i < 2 * n; ++i) { const int x = verts[i]; int j = i - 1; while (j >= 0 && verts[j] > x) { verts[j + 1] = verts[j]; --j; } verts[j + 1] = x; }
+    int nv = 0;
+    for (int i = 0; i < 2 * n; ++i) if (i == 0 || verts[i] != verts[i - 1]) verts[nv++] = verts[i];
+    for (int k = 0; k < n; ++k) { ea[k] = (uint8_t)lowerBound(verts, nv, pfPrev[b + k]); eb[k] = (uint8_t)lowerBound(verts, nv, pfNext[b + k]); }
+    for (int v = 0; v < nv; ++v) deg[v] = 0;
+    for (int e = 0; e < n; ++e) { ++deg[ea[e]]; ++deg[eb[e]]; }
+    int ne = n, pending = -1;
+    for (int v = 0; v < nv; ++v)
+        if (deg[v] & 1) {
+            if (pending < 0) pending = v;
+            else { ea[ne] = (uint8_t)pending; eb[ne] = (uint8_t)v; ++ne; ++deg[pending]; ++deg[v]; pending = -1; }
+        }
+    for (int v = 0; v <= nv; ++v) adjOff[v] = 0;
+    for (int e = 0; e < ne; ++e) { ++adjOff[ea[e] + 1]; ++adjOff[eb[e] + 1]; }
+    for (int v = 0; v < nv; ++v) adjOff[v + 1] = (unsigned short)(adjOff[v + 1] + adjOff[v]);
+    for (int v = 0; v < nv; ++v) next[v] = adjOff[v];
+    for (int e = 0; e < ne; ++e) { adjEdge[next[ea[e]]++] = (uint8_t)e; adjEdge[next[eb[e]]++] = (uint8_t)e; }
+    for (int e = 0; e < ne; ++e) used[e] = 0;
+    for (int v = 0; v < nv; ++v) next[v] = adjOff[v];
+    int nOut = 0;
+    for (int start = 0; start < nv; ++start) {
+        if (next[start] >= adjOff[start + 1]) continue;
+        int sp = 1, nComp = 0;
+        stackV[0] = (uint8_t)start; stackE[0] = -1;
+        while (sp > 0) {
+            const int v = stackV[sp - 1];
+            int e = -1;
+            while (next[v] < adjOff[v + 1]) {
+                const int cand = adjEdge[next[v]++];
+                if (!used[cand]) { e = cand; break; }
+            }
+            if (e >= 0) {
+                used[e] = 1;
+                const int to = (ea[e] == v) ? eb[e] : ea[e];
+                stackV[sp] = (uint8_t)to; stackE[sp] = (short)e; ++sp;
+            } else {
+                const int eIn = stackE[sp - 1];
+                --sp;
+                if (eIn >= 0) { compE[nComp] = (uint8_t)eIn; compV[nComp] = stackV[sp - 1]; ++nComp; }
+            }
+        }
+        for (int i = nComp; i-- > 0;) {
+            const int e = compE[i], from = compV[i];
+            if (e >= n) continue;
+            const int to = (ea[e] == from) ? eb[e] : ea[e];
+            if (nOut < kCh) { outA[nOut] = verts[from]; outB[nOut] = verts[to]; }
+            ++nOut;
+        }
+    }
+    if (nOut == n) for (int k = 0; k < n; ++k) { chPrev[b + k] = outA[k]; chNext[b + k] = outB[k]; }
+    else for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; }
+}
+
+struct SmoothIn {
+    const int* order; const int* ptBeg; int nTiles; int pairs;
+    const int* pcOff; const int* pcVal; const int* ppOff; const int* ppPt; const int* pfOff; const int* chPrev; const int* chNext; const uint8_t* isInternal;
+};
+struct SmoothSizes { int* nCl; int* nPt; int* wc; int* wn; int* wf; int* bad; };
+struct SmoothOut {
+    const long long* tcOff; const long long* tnOff; const long long* pcBase; const long long* ppBase; const long long* pfBase;
+    int* tcIds; int* tnIds; uint16_t* selfLoc; uint16_t* pcEll; uint16_t* ppEll; uint16_t* pairEll; uint16_t* pfEll; int* meta;
+};
+template <bool FILL>
+__global__ void __launch_bounds__(kT) k_tl_smooth(SmoothIn in, SmoothSizes sz, SmoothOut out) {
+    __shared__ int sCells[kBuf], sPts[kBuf], sh[kT / 64 + 1];
+    const int ti = blockIdx.x, tid = threadIdx.x;
+    const int pb = in.ptBeg[ti], nPos = in.ptBeg[ti + 1] - pb;
+    if (nPos > kT) { if (tid == 0) *sz.bad = 1; return; }
+    const int p = (tid < nPos) ? in.order[pb + tid] : -1;
+    const int cb = (p >= 0) ? in.pcOff[p] : 0, nc = (p >= 0) ? in.pcOff[p + 1] - cb : 0;
+    const int nb = (p >= 0) ? in.ppOff[p] : 0, nn = (p >= 0) ? in.ppOff[p + 1] - nb : 0;
+    const int fb = (p >= 0) ? in.pfOff[p] : 0, nf = (p >= 0) ? in.pfOff[p + 1] - fb : 0;
+    int rawC, rawN;
+    const int atC = blockExclusive(nc, sh, rawC);
+    const int atN = blockExclusive((p >= 0) ? nn + 1 : 0, sh, rawN);
+    if (rawC > kBuf || rawN > kBuf) { if (tid == 0) *sz.bad = 1; return; }
+    for (int k = 0; k < nc; ++k) sCells[atC + k] = in.pcVal[cb + k];
+    if (p >= 0) { sPts[atN] = p; for (int k = 0; k < nn; ++k) sPts[atN + 1 + k] = in.ppPt[nb + k]; }
+    __syncthreads();
+    const int nC = sortUnique(sCells, rawC, sh);
+    const int nN = sortUnique(sPts, rawN, sh);
+    const int wc = roundUp4d(blockMax(nc, sh)), wn = roundUp4d(blockMax(nn, sh)), wf = roundUp4d(blockMax(2 * nf, sh));
+    if (nC > 32766 || nN > 32766 || wc > 252 || wn > 252 || wf > 252) { if (tid == 0) *sz.bad = 1; return; }
+    if (!FILL) {
+        if (tid == 0) { sz.nCl[ti] = nC; sz.nPt[ti] = nN; sz.wc[ti] = wc; sz.wn[ti] = wn; sz.wf[ti] = wf; }
+        return;
+    }
+    const long long tc = out.tcOff[ti], tn = out.tnOff[ti], cbase = out.pcBase[ti], nbase = out.ppBase[ti], fbase = out.pfBase[ti];
+    for (int i = tid; i < nC; i += kT) out.tcIds[tc + i] = sCells[i];
+    for (int i = tid; i < nN; i += kT) out.tnIds[tn + i] = sPts[i];
+    if (p >= 0) {
+        out.selfLoc[pb + tid] = (uint16_t)lowerBound(sPts, nN, p);
+        for (int c = 0; c < nf; ++c) {
+            const int j = 2 * c;
+            out.pfEll[fbase + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)lowerBound(sPts, nN, in.chPrev[fb + c]);
+            out.pfEll[fbase + ((long long)((j + 1) / 4) * kT + tid) * 4 + ((j + 1) % 4)] = (uint16_t)lowerBound(sPts, nN, in.chNext[fb + c]);
+        }
+        for (int j = 0; j < nc; ++j) out.pcEll[cbase + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)lowerBound(sCells, nC, in.pcVal[cb + j]);
+        for (int j = 0; j < nn; ++j) {
+            const int q = in.ppPt[nb + j];
+            out.ppEll[nbase + ((long long)(j / 4) * kT + tid) * 4 + (j % 4)] = (uint16_t)(lowerBound(sPts, nN, q) | (in.isInternal[q] ? 0x8000 : 0));
+        }
+        if (in.pairs) {      // neighbours i, j of p share a cell  <=>  pointCells(q_i) and pointCells(q_j) intersect (nn <= 16 here)
+            unsigned masks[16];
+            for (int i = 0; i < 16; ++i) masks[i] = 0;
+            for (int i = 0; i < nn; ++i) {
+                const int qi = in.ppPt[nb + i];
+                const int a0 = in.pcOff[qi], ae = in.pcOff[qi + 1];
+                for (int j = i + 1; j < nn; ++j) {
+                    const int qj = in.ppPt[nb + j];
+                    int a = a0, c = in.pcOff[qj];
+                    const int ce = in.pcOff[qj + 1];
+                    bool hit = false;
+                    while (a < ae && c < ce) {
+                        const int va = in.pcVal[a], vc = in.pcVal[c];
+                        if (va == vc) { hit = true; break; }
+                        if (va < vc) ++a; else ++c;
+                    }
+                    if (hit) { masks[i] |= 1u << j; masks[j] |= 1u << i; }
+                }
+            }
+            for (int i = 0; i < nn; ++i) out.pairEll[nbase + ((long long)(i / 4) * kT + tid) * 4 + (i % 4)] = (uint16_t)masks[i];
+        }
+    }
+    if (tid == 0) {
+        int* r = out.meta + 12ll * ti;
+        r[0] = pb; r[1] = nPos; r[2] = (int)tc; r[3] = nC; r[4] = (int)tn; r[5] = nN; r[6] = (int)cbase; r[7] = wc; r[8] = (int)nbase; r[9] = wn; r[10] = (int)fbase; r[11] = wf;
+    }
+}
+__global__ void __launch_bounds__(kT) k_tl_smoothTerms(int nTiles, SmoothSizes sz, long long* a, long long* b, long long* c, long long* d, long long* e) {
+    const int ti = blockIdx.x * kT + threadIdx.x;
+    if (ti >= nTiles) return;
+    a[ti] = sz.nCl[ti]; b[ti] = sz.nPt[ti]; c[ti] = (long long)sz.wc[ti] * kT; d[ti] = (long long)sz.wn[ti] * kT; e[ti] = (long long)sz.wf[ti] * kT;
+}
+
 struct DevBuf {
     std::vector<void*> all;
     ~DevBuf() { for (void* p : all) (void)hipFree(p); }
@@ -403,6 +556,84 @@ int buildEdgeTablesOnDevice(EdgeTiles& et, const DeviceTopologyArrays& td, int32
     give(out.tpIds, tpIds, (size_t)nTp * 4); give(out.tfIds, tfIds, (size_t)nTf * 4); give(out.tcIds, tcIds, (size_t)nTc * 4);
     give(out.epLoc, epLoc, 2 * (size_t)nEdges * 2); give(out.efEll, efEll, (size_t)nEf * 2); give(out.ecEll, ecEll, (size_t)nEc * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
     out.nTf = nTf;
+    out.valid = true;
+    return 0;
+}
+
+// st.order / st.ptBeg / st.nTiles / st.threads stand (host: SmoothTiles::buildBoundaries).  Return values as buildGeomTablesOnDevice.
+int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, int32_t nPoints, int32_t maxPointPoints, const uint8_t* isInternal, int device,
+                              SmoothTilesDev& out, std::string& why) {
+    if (!td.valid || st.threads != kT || st.nTiles <= 0 || (int64_t)st.order.size() != nPoints) return 1;
+    TL_OK(hipSetDevice(device));
+    hipStream_t sm = nullptr;
+    TL_OK(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{sm};
+    const int nT = st.nTiles;
+    const size_t S = (size_t)nT + 1, nPf = td.pfPrev.bytes / 4;
+    DevBuf D;
+    int *dOrder = D.get<int>((size_t)nPoints), *dBeg = D.get<int>(S), *chPrev = D.get<int>(nPf), *chNext = D.get<int>(nPf);
+    uint8_t* dInt = D.get<uint8_t>((size_t)nPoints);
+    int *nCl = D.get<int>((size_t)nT), *nPt = D.get<int>((size_t)nT), *wc = D.get<int>((size_t)nT), *wn = D.get<int>((size_t)nT), *wf = D.get<int>((size_t)nT), *bad = D.get<int>(1);
+    long long* terms = D.get<long long>(10 * S);
+    if (!dOrder || !dBeg || !chPrev || !chNext || !dInt || !nCl || !nPt || !wc || !wn || !wf || !bad || !terms) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemsetAsync(bad, 0, 4, sm));
+    hipLaunchKernelGGL(k_tl_chain, dim3((nPoints + 63) / 64), dim3(64), 0, sm, nPoints, (const int*)td.pfOff.p, (const int*)td.pfPrev.p, (const int*)td.pfNext.p, chPrev, chNext, bad);
+    TL_OK(hipMemcpyAsync(dOrder, st.order.data(), (size_t)nPoints * 4, hipMemcpyHostToDevice, sm));
+    TL_OK(hipMemcpyAsync(dBeg, st.ptBeg.data(), S * 4, hipMemcpyHostToDevice, sm));
+    TL_OK(hipMemcpyAsync(dInt, isInternal, (size_t)nPoints, hipMemcpyHostToDevice, sm));
+    SmoothIn in{dOrder, dBeg, nT, maxPointPoints <= 16 ? 1 : 0, (const int*)td.pcOff.p, (const int*)td.pcVal.p, (const int*)td.ppOff.p, (const int*)td.ppPt.p,
+                (const int*)td.pfOff.p, chPrev, chNext, dInt};
+    SmoothSizes sz{nCl, nPt, wc, wn, wf, bad};
+    hipLaunchKernelGGL(k_tl_smooth<false>, dim3(nT), dim3(kT), 0, sm, in, sz, SmoothOut{});
+    TL_OK(hipMemsetAsync(terms, 0, 10 * S * 8, sm));
+    hipLaunchKernelGGL(k_tl_smoothTerms, dim3((nT + kT - 1) / kT), dim3(kT), 0, sm, nT, sz, terms, terms + S, terms + 2 * S, terms + 3 * S, terms + 4 * S);
+    long long* offsD = terms + 5 * S;
+    size_t tempBytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, tempBytes, terms, offsD, 0ll, S, rocprim::plus<long long>(), sm);
+    void* temp = D.get<char>(tempBytes + 256);
+    if (!temp) { why = "device allocation failed"; return 2; }
+    for (int q = 0; q < 5; ++q) { size_t b = tempBytes; TL_OK(rocprim::exclusive_scan(temp, b, terms + (size_t)q * S, offsD + (size_t)q * S, 0ll, S, rocprim::plus<long long>(), sm)); }
+    std::vector<long long> offs(5 * S);
+    int hbad = 0;
+    TL_OK(hipMemcpyAsync(offs.data(), offsD, offs.size() * 8, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipMemcpyAsync(&hbad, bad, 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipStreamSynchronize(sm));
+    if (hbad) return 1;
+    const long long nTc = offs[(size_t)nT], nTn = offs[S + nT], nPc = offs[2 * S + nT], nPp = offs[3 * S + nT], nPfE = offs[4 * S + nT];
+    if (nTc > 0x7fffffffll || nTn > 0x7fffffffll || nPc > 0x7fffffffll || nPp > 0x7fffffffll || nPfE > 0x7fffffffll) return 1;
+    int *tcIds = D.get<int>((size_t)nTc), *tnIds = D.get<int>((size_t)nTn), *meta = D.get<int>(12 * (size_t)nT);
+    uint16_t *selfLoc = D.get<uint16_t>((size_t)nPoints), *pcEll = D.get<uint16_t>((size_t)nPc), *ppEll = D.get<uint16_t>((size_t)nPp), *pairEll = D.get<uint16_t>((size_t)nPp),
+             *pfEll = D.get<uint16_t>((size_t)nPfE);
+    if (!tcIds || !tnIds || !meta || !selfLoc || !pcEll || !ppEll || !pairEll || !pfEll) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemsetAsync(pcEll, 0xFF, (size_t)nPc * 2, sm));
+    TL_OK(hipMemsetAsync(ppEll, 0xFF, (size_t)nPp * 2, sm));
+    TL_OK(hipMemsetAsync(pfEll, 0xFF, (size_t)nPfE * 2, sm));
+    TL_OK(hipMemsetAsync(pairEll, 0, (size_t)nPp * 2, sm));
+    TL_OK(hipMemsetAsync(selfLoc, 0, (size_t)nPoints * 2, sm));
+    hipLaunchKernelGGL(k_tl_smooth<true>, dim3(nT), dim3(kT), 0, sm, in, sz,
+                       SmoothOut{offsD, offsD + S, offsD + 2 * S, offsD + 3 * S, offsD + 4 * S, tcIds, tnIds, selfLoc, pcEll, ppEll, pairEll, pfEll, meta});
+    std::vector<int> hC((size_t)nT), hN((size_t)nT), hWc((size_t)nT), hWn((size_t)nT), hWf((size_t)nT);
+    TL_OK(hipMemcpyAsync(hC.data(), nCl, (size_t)nT * 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipMemcpyAsync(hN.data(), nPt, (size_t)nT * 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipMemcpyAsync(hWc.data(), wc, (size_t)nT * 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipMemcpyAsync(hWn.data(), wn, (size_t)nT * 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipMemcpyAsync(hWf.data(), wf, (size_t)nT * 4, hipMemcpyDeviceToHost, sm));
+    TL_OK(hipStreamSynchronize(sm));
+    TL_OK(hipGetLastError());
+    st.tcOff.resize(S); st.tnOff.resize(S);
+    st.pcBase.resize((size_t)nT); st.ppBase.resize((size_t)nT); st.pfBase.resize((size_t)nT); st.pcWidth.resize((size_t)nT); st.ppWidth.resize((size_t)nT); st.pfWidth.resize((size_t)nT);
+    st.maxCells = st.maxPoints = 0;
+    for (size_t i = 0; i < S; ++i) { st.tcOff[i] = (int32_t)offs[i]; st.tnOff[i] = (int32_t)offs[S + i]; }
+    for (int i = 0; i < nT; ++i) {
+        st.pcBase[(size_t)i] = (int32_t)offs[2 * S + i]; st.ppBase[(size_t)i] = (int32_t)offs[3 * S + i]; st.pfBase[(size_t)i] = (int32_t)offs[4 * S + i];
+        st.pcWidth[(size_t)i] = (uint8_t)hWc[(size_t)i]; st.ppWidth[(size_t)i] = (uint8_t)hWn[(size_t)i]; st.pfWidth[(size_t)i] = (uint8_t)hWf[(size_t)i];
+        st.maxCells = std::max(st.maxCells, hC[(size_t)i]); st.maxPoints = std::max(st.maxPoints, hN[(size_t)i]);
+    }
+    st.tcIds.clear(); st.tnIds.clear(); st.selfLoc.clear(); st.pcEll.clear(); st.ppEll.clear(); st.pairEll.clear(); st.pfEll.clear();
+    auto give = [&](SmoothTilesDev::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
+    give(out.order, dOrder, (size_t)nPoints * 4); give(out.ptBeg, dBeg, S * 4); give(out.tcIds, tcIds, (size_t)nTc * 4); give(out.tnIds, tnIds, (size_t)nTn * 4);
+    give(out.selfLoc, selfLoc, (size_t)nPoints * 2); give(out.pcEll, pcEll, (size_t)nPc * 2); give(out.ppEll, ppEll, (size_t)nPp * 2); give(out.pairEll, pairEll, (size_t)nPp * 2);
+    give(out.pfEll, pfEll, (size_t)nPfE * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
     out.valid = true;
     return 0;
 }

@@ -81,10 +81,18 @@ struct DeviceTopologyArrays {
 // The same addressing built on the device (topology_dev.hip: radix sorts of (row, value) keys + per-edge kernels) and copied into
 // t.  0: done; 1: not handled there -- the caller runs Topology::build (meshes it reports an error for, edges with more than 16
 // faces, points with more than 255 neighbours, lists beyond 2^30 entries -- decided BEFORE a hook is called); 2: a HIP error (why).
-// afterCells / afterPoints: as Topology::build's hooks, called once the respective lists have arrived on the host.
+// The hooks are called while the lists still arrive on the host, each once the lists a tile-BOUNDARY pass reads stand there
+// (tiles.hpp): afterCells -- facePoints, owner / neighbour, cellFacesGeom; afterEdges -- also edges, edgeFaces, edgeCells;
+// afterPoints -- also pointCells, the pointEdges offsets, pointPoints.  The rest stands when the function returns: a host build
+// of tile TABLES has to wait for that.  deferUnread (with keep): the rest stays on the device only -- nothing in the loop and
+// nothing in the layer / boundary set-up reads it on the host once the tile tables were built on the device (1.9 + 1.5 GB for
+// 10 M cells, 0.5 s of the set-up).  downloadDeferredLists fetches it into t for whoever asks after all: groups bit 0 --
+// pointFaces with prev / next, pointEdges' edge ids (the shared points' tiles of a multi-rank run, the getters); bit 1 -- the
+// prev / next slots, the edge cells' face pairs, the rings (checksums, a host build of the edge tables).
 int buildTopologyOnDevice(Topology& t, int32_t nPoints, int32_t nCells, int32_t nFaces, int32_t nInternalFaces, const int32_t* faceOffsets,
                           const int32_t* facePts, const int32_t* owner, const int32_t* neighbour, int device, std::string& why,
                           const std::function<void()>& afterCells = nullptr, const std::function<void()>& afterPoints = nullptr,
-                          DeviceTopologyArrays* keep = nullptr);
+                          DeviceTopologyArrays* keep = nullptr, const std::function<void()>& afterEdges = nullptr, bool deferUnread = false);
+int downloadDeferredLists(Topology& t, const DeviceTopologyArrays& td, int device, std::string& why, int groups = 3);
 
 }  // namespace smgpu

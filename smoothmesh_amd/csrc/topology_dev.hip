@@ -272,12 +272,48 @@ struct DevBuf {
 
 int bitsFor(int64_t rows) { int b = 1; while (((int64_t)1 << b) < rows + 1 && b < 31) ++b; return b; }
 
+// device -> host copies of whole lists: the arrays are sized by one thread each (first touch of fresh pages) and copied in 32 MB
+// pieces by four threads with a stream each (one pageable copy at a time ran at ~1.1 GB/s: 1.4 s of the 1.65 s the build took
+// for 10 M cells)
+struct DownJob { std::function<void*()> size; const void* src; size_t bytes; void* dst; };
+template <class Vec, class T> void wantDown(std::vector<DownJob>& jobs, Vec& vec, const T* src, size_t n) {
+    Vec* v = &vec;
+    jobs.push_back(DownJob{[v, n]() -> void* { v->resize(n); return (void*)v->data(); }, (const void*)src, n * sizeof(T), nullptr});
+}
+bool runDown(std::vector<DownJob>& jobs, int device) {
+    {   // sizes first (a thread per array), then the copies
+        std::vector<std::thread> th;
+        for (DownJob& j : jobs) th.emplace_back([&j] { j.dst = j.size(); });
+        for (auto& x : th) x.join();
+    }
+    struct Piece { char* dst; const char* src; size_t bytes; };
+    std::vector<Piece> pieces;
+    const size_t chunk = (size_t)32 << 20;
+    for (const DownJob& j : jobs)
+        for (size_t o = 0; o < j.bytes; o += chunk) pieces.push_back(Piece{(char*)j.dst + o, (const char*)j.src + o, std::min(chunk, j.bytes - o)});
+    std::atomic<size_t> next{0};
+    std::atomic<int> failed{0};
+    std::vector<std::thread> th;
+    for (int w = 0; w < 4; ++w)
+        th.emplace_back([&] {
+            if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
+            hipStream_t s2 = nullptr;
+            if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
+            for (size_t i = next++; i < pieces.size(); i = next++)
+                if (hipMemcpyAsync(pieces[i].dst, pieces[i].src, pieces[i].bytes, hipMemcpyDeviceToHost, s2) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) failed = 1;
+            (void)hipStreamDestroy(s2);
+        });
+    for (auto& x : th) x.join();
+    jobs.clear();
+    return failed == 0;
+}
+
 }  // namespace
 
 // 0: t holds the addressing (device build); 1: not handled here (the caller runs the host build); 2: a HIP error (why)
 int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32_t nIF, const int32_t* faceOffsets, const int32_t* facePts, const int32_t* own,
                           const int32_t* nei, int device, std::string& why, const std::function<void()>& afterCells, const std::function<void()>& afterPoints,
-                          DeviceTopologyArrays* keep) {
+                          DeviceTopologyArrays* keep, const std::function<void()>& afterEdges, bool deferUnread) {
     const bool verbose = std::getenv("SMGPU_VERBOSE") && std::atoi(std::getenv("SMGPU_VERBOSE")) >= 2;
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
@@ -436,40 +472,10 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     // function took for 10 M cells).
     t.nPoints = nP; t.nCells = nC; t.nFaces = nF; t.nInternalFaces = nIF; t.nEdges = nE;
     t.maxFaceSize = hf.maxFace; t.maxEdgeFaces = hf.maxEdgeFaces; t.maxPointCells = hf.maxPointCells; t.maxPointPoints = hf.maxPointPoints;
-    struct Job { std::function<void*()> size; const void* src; size_t bytes; void* dst; };
-    std::vector<Job> jobs;
-    auto want = [&](auto& vec, const auto* src, size_t n) {
-        auto* v = &vec;
-        jobs.push_back(Job{[v, n]() -> void* { v->resize(n); return (void*)v->data(); }, (const void*)src, n * sizeof(*src), nullptr});
-    };
+    std::vector<DownJob> jobs;
+    auto want = [&](auto& vec, const auto* src, size_t n) { wantDown(jobs, vec, src, n); };
     bool copyFailed = false;
-    auto flush = [&]() {
-        {   // sizes first (a thread per array), then the copies
-            std::vector<std::thread> th;
-            for (Job& j : jobs) th.emplace_back([&j] { j.dst = j.size(); });
-            for (auto& x : th) x.join();
-        }
-        struct Piece { char* dst; const char* src; size_t bytes; };
-        std::vector<Piece> pieces;
-        const size_t chunk = (size_t)32 << 20;
-        for (const Job& j : jobs)
-            for (size_t o = 0; o < j.bytes; o += chunk) pieces.push_back(Piece{(char*)j.dst + o, (const char*)j.src + o, std::min(chunk, j.bytes - o)});
-        std::atomic<size_t> next{0};
-        std::atomic<int> failed{0};
-        std::vector<std::thread> th;
-        for (int w = 0; w < 4; ++w)
-            th.emplace_back([&] {
-                if (hipSetDevice(device) != hipSuccess) { failed = 1; return; }
-                hipStream_t s2 = nullptr;
-                if (hipStreamCreateWithFlags(&s2, hipStreamNonBlocking) != hipSuccess) { failed = 1; return; }
-                for (size_t i = next++; i < pieces.size(); i = next++)
-                    if (hipMemcpyAsync(pieces[i].dst, pieces[i].src, pieces[i].bytes, hipMemcpyDeviceToHost, s2) != hipSuccess || hipStreamSynchronize(s2) != hipSuccess) failed = 1;
-                (void)hipStreamDestroy(s2);
-            });
-        for (auto& x : th) x.join();
-        if (failed) copyFailed = true;
-        jobs.clear();
-    };
+    auto flush = [&]() { if (!runDown(jobs, device)) copyFailed = true; };
     if (keep) {      // what the kernels read as it is stays on the device, owned by the caller -- from here on (the hooks below start
                      // tile-table builds that read these arrays); a later failure leaves the caller to free them
         auto give = [&](DeviceTopologyArrays::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
@@ -494,23 +500,53 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
     lap("download: cell lists");
     if (afterCells) afterCells();
-    want(t.pointFaces.off, pfOff, (size_t)nP + 1); want(t.pointFaces.val, pfFace, (size_t)nnz);
-    want(t.pfPrev, pfPrev, (size_t)nnz); want(t.pfNext, pfNext, (size_t)nnz);
-    want(t.pointCells.off, pcOff, (size_t)nP + 1); want(t.pointCells.val, pcVal, (size_t)nPC);
+    // (the order of the stages: what the three tile-boundary passes read first -- the longest of them, the edge pass, early --
+    // then the lists only the halo / layer set-up and the getters read)
     want(t.edges, edges, 2 * (size_t)nE);
-    want(t.pointEdges.off, ppOff, (size_t)nP + 1); want(t.pointEdges.val, peEdge, 2 * (size_t)nE); want(t.pointPoints, ppPt, 2 * (size_t)nE);
+    want(t.edgeFaces.off, efOff, (size_t)nE + 1); want(t.edgeFaces.val, efFace, (size_t)nnz);
+    want(t.edgeCells.off, ecOff, (size_t)nE + 1); want(t.edgeCells.val, ecCell, (size_t)nEC);
+    flush();
+    if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
+    lap("download: edge lists");
+    if (afterEdges) afterEdges();
+    want(t.pointCells.off, pcOff, (size_t)nP + 1); want(t.pointCells.val, pcVal, (size_t)nPC);
+    want(t.pointEdges.off, ppOff, (size_t)nP + 1); want(t.pointPoints, ppPt, 2 * (size_t)nE);
     flush();
     if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
     lap("download: point lists");
     if (afterPoints) afterPoints();
-    want(t.pfPrevSlot, prevSlot, (size_t)nnz); want(t.pfNextSlot, nextSlot, (size_t)nnz);
-    want(t.edgeFaces.off, efOff, (size_t)nE + 1); want(t.edgeFaces.val, efFace, (size_t)nnz);
-    want(t.edgeCells.off, ecOff, (size_t)nE + 1); want(t.edgeCells.val, ecCell, (size_t)nEC);
-    want(t.ecFace0, ecF0, (size_t)nEC); want(t.ecFace1, ecF1, (size_t)nEC);
-    want(t.ringFace, ringFace, (size_t)nnz); want(t.ringCell, ringCell, (size_t)nEC); want(t.edgeRingOk, ringOk, (size_t)nE);
-    flush();
-    if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
-    lap("download: edge lists");
+    if (!(deferUnread && keep)) {      // (else fetched when someone asks: downloadDeferredLists)
+        want(t.pointFaces.off, pfOff, (size_t)nP + 1); want(t.pointFaces.val, pfFace, (size_t)nnz);
+        want(t.pfPrev, pfPrev, (size_t)nnz); want(t.pfNext, pfNext, (size_t)nnz);
+        want(t.pointEdges.val, peEdge, 2 * (size_t)nE);
+        want(t.pfPrevSlot, prevSlot, (size_t)nnz); want(t.pfNextSlot, nextSlot, (size_t)nnz);
+        want(t.ecFace0, ecF0, (size_t)nEC); want(t.ecFace1, ecF1, (size_t)nEC);
+        want(t.ringFace, ringFace, (size_t)nnz); want(t.ringCell, ringCell, (size_t)nEC); want(t.edgeRingOk, ringOk, (size_t)nE);
+        flush();
+        if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
+    }
+    lap("download: the rest");
+    return 0;
+}
+
+int downloadDeferredLists(Topology& t, const DeviceTopologyArrays& td, int device, std::string& why, int groups) {
+    if (!td.valid) return 0;
+    std::vector<DownJob> jobs;
+    auto fetch = [&](auto& vec, const DeviceTopologyArrays::Arr& a, size_t n) {
+        typedef std::remove_reference_t<decltype(vec[0])> T;
+        if (vec.size() != n) wantDown(jobs, vec, (const T*)a.p, n);
+    };
+    const size_t nnz = t.facePoints.val.size(), nEC = t.edgeCells.val.size(), nP = (size_t)t.nPoints, nE = (size_t)t.nEdges;
+    if (groups & 1) {
+        fetch(t.pointFaces.off, td.pfOff, nP + 1); fetch(t.pointFaces.val, td.pfFace, nnz); fetch(t.pfPrev, td.pfPrev, nnz); fetch(t.pfNext, td.pfNext, nnz);
+        fetch(t.pointEdges.val, td.peEdge, 2 * nE);
+    }
+    if (groups & 2) {
+        fetch(t.pfPrevSlot, td.pfPrevSlot, nnz); fetch(t.pfNextSlot, td.pfNextSlot, nnz);
+        fetch(t.ecFace0, td.ecF0, nEC); fetch(t.ecFace1, td.ecF1, nEC);
+        fetch(t.ringFace, td.ringFace, nnz); fetch(t.ringCell, td.ringCell, nEC); fetch(t.edgeRingOk, td.edgeRingOk, nE);
+    }
+    if (!jobs.empty() && !runDown(jobs, device)) { why = "device -> host copy of the addressing failed"; return 2; }
     return 0;
 }
 

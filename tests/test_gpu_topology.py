@@ -100,22 +100,24 @@ def test_meshes_the_device_path_hands_back(capfd, monkeypatch):
 
 @pytest.mark.parametrize("which", [0, 3, 4, 5])
 def test_device_tile_tables_equal_the_host_build(which, monkeypatch, capfd):
-    """the geometry and edge tile tables built on the device from the host's tile boundaries (csrc/tiles_dev.hip) against the host
+    """the geometry, smoothing and edge tile tables built on the device from the host's tile boundaries (csrc/tiles_dev.hip) against the host
     build (SMGPU_DEVICE_TILES=0): every table the kernels read, byte for byte -- and the same smoothing result"""
     import numpy as np
     from smoothmesh_amd import SmoothEngine, default_params
     name, mesh = list(_meshes())[which]
     got = []
     monkeypatch.setenv("SMGPU_VERBOSE", "2")
-    for dev in ("1", "0"):
+    for dev in ("1", "0", "2"):      # 2: the device builds hand their tables back to the host while its lists still arrive
         monkeypatch.setenv("SMGPU_DEVICE_TILES", dev)
         e = SmoothEngine(mesh)
         log = capfd.readouterr().err
-        assert ("geometry tiles: tables on the device" in log and "edge tiles: tables on the device" in log) == (dev == "1"), log
+        for which_tables in ("geometry", "smoothing", "edge"):
+            assert (which_tables + " tiles: tables on the device" in log) == (dev == "1"), log
         sums = e.debug_tile_checksums()
         e.set_params(default_params(e.mesh_stats()[0]))
         e.iterate(3, 0.0)
         got.append((sums, e.get_points().copy()))
         e.close()
-    assert got[0][0] == got[1][0], (name, [i for i, (a, b) in enumerate(zip(*[g[0] for g in got])) if a != b])
-    assert any(got[0][0]) and np.array_equal(got[0][1], got[1][1])
+    for other in got[1:]:
+        assert got[0][0] == other[0], (name, [i for i, (a, b) in enumerate(zip(got[0][0], other[0])) if a != b])
+        assert any(got[0][0]) and np.array_equal(got[0][1], other[1])
