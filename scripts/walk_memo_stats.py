@@ -1,6 +1,8 @@
 """How many of the walk predicates' stars have, bit for bit, the inputs they had in the point's previous walk (SMGPU_WALK_MEMO_STATS=1,
 k_walk_pred_pack: vertex slots with roles, entries' proposals and states, the point's two positions and angle bounds, the ring places'
-cell centres)?  Decides whether an exact memo of the predicates could pay.  usage: walk_memo_stats.py [workload] [chunks of 10 iterations]"""
+cell centres)?  Needs a measuring build of the library (the hash block is not in the product kernel):
+    make -C smoothmesh_amd/csrc HIPFLAGS+=-DSMGPU_WALK_MEMO=1 SMGPU_LIB=/tmp/libsmgpu_memo.so  ->  SMOOTHMESH_SMGPU_LIB=/tmp/libsmgpu_memo.so
+Decides whether an exact memo of the predicates could pay.  usage: walk_memo_stats.py [workload] [chunks of 10 iterations]"""
 import os, sys
 os.environ["SMGPU_WALK_MEMO_STATS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -563,6 +563,35 @@ __device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileView
     L.nx = L.cz + g.maxCells;   L.ny = L.nx + g.maxPoints; L.nz = L.ny + g.maxPoints;
     return L;
 }
+// The three shortest incident edges in list order (stable: a later edge of equal length stays behind, SM.C:325-387), kept as
+// (length, word) with word = list position << 16 | ELL entry (0xFFFFFFFF: empty).  The reference's if / else-if chain
+//     if (k1 < 0 || len < l1) {3 <- 2, 2 <- 1, 1 <- new} else if (k2 < 0 || len < l2) {3 <- 2, 2 <- new} else if (k3 < 0 || len < l3) {3 <- new}
+// as selects: b1, b2, b3 are the chain's three branches, so the result is the chain's for every input (NaN lengths included).
+// The nested branches cost ~33 register moves per neighbour (the compiler rotates the nine values at every join, and in a wave
+// of 64 lanes every level is taken by someone); the selects are 15.
+// -DSMGPU_ABLATE=<bits>: timing experiments on smoothPoint (WRONG results; never in the product build) -- 1: no square root per
+// neighbour, 2: every LDS gather reads record 0 (no bank conflicts), 4: no freeze loop, 8: no cell loop, 16: nothing after the staging
+#ifndef SMGPU_ABLATE
+#define SMGPU_ABLATE 0
+#endif
+struct Top3 {
+    double l1 = 0, l2 = 0, l3 = 0;
+    unsigned w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu, w3 = 0xFFFFFFFFu;
+    __device__ __forceinline__ void offer(double len, int j, unsigned e, bool take) {
+        const unsigned w = ((unsigned)j << 16) | e;
+        const bool b1 = take && (w1 == 0xFFFFFFFFu || len < l1);
+        const bool b2 = take && !b1 && (w2 == 0xFFFFFFFFu || len < l2);
+        const bool b3 = take && !b1 && !b2 && (w3 == 0xFFFFFFFFu || len < l3);
+        const bool b12 = b1 || b2;
+        l3 = b12 ? l2 : (b3 ? len : l3);  w3 = b12 ? w2 : (b3 ? w : w3);
+        l2 = b1 ? l1 : (b2 ? len : l2);   w2 = b1 ? w1 : (b2 ? w : w2);
+        l1 = b1 ? len : l1;               w1 = b1 ? w : w1;
+    }
+    __device__ __forceinline__ bool has2() const { return w2 != 0xFFFFFFFFu; }
+    __device__ __forceinline__ bool has3() const { return w3 != 0xFFFFFFFFu; }
+    __device__ __forceinline__ int k1() const { return (int)(w1 >> 16); }
+    __device__ __forceinline__ int k2() const { return (int)(w2 >> 16); }
+};
 struct SmoothRow {
     bool mine; int p, selfL, wn4, wc4, slot;
     int peer, dst0, ndst;  // shared-point tiles: the two-sharer point's peer code (State::spPeer) or -1, first send slot, send slots
@@ -680,6 +709,7 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
     const int p = R.p, selfL = R.selfL, wn4 = R.wn4, wc4 = R.wc4;
     const ushort4 *ppRow = R.ppRow, *pcRow = R.pcRow;
     const ushort4 pp0 = R.pp0, pp1 = R.pp1, pc0 = R.pc0, pc1 = R.pc1;
+    if ((SMGPU_ABLATE & 16) && !spTile) { if (mine) stv(FINAL ? s.ptsNext : s.prop, p, ldsv(nx, ny, nz, selfL)); return; }
     if (mine && !(MODE == 2 && !spTile && R.slot >= 0)) {
         const unsigned fl = R.fl;
         const bool internal = fl & PF_INTERNAL;
@@ -713,36 +743,32 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             })
         } else {
             if (internal || prm.bndOn) {   // SM.C:116-130 (boundary points too with doBoundarySmoothing)
+                if (!(SMGPU_ABLATE & 8))
                 SMGPU_ELL_FOREACH_PRE(pc0, pc1, pcRow, wc4, T, {
-                    sum = sum + ldsv(cx, cy, cz, e);
+                    sum = sum + ldsv(cx, cy, cz, (SMGPU_ABLATE & 2) ? 0 : e);
                     count = j + 1;
                 })
             }
             // SM.C:325-387 (stable top three; boundary points look at boundary neighbours only)
-            double l1 = 0, l2 = 0, l3 = 0;
-            int k1 = -1, k2 = -1, k3 = -1;
-            unsigned q1 = 0, q2 = 0, q3 = 0;
+            Top3 t3;
             SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 // getPointDistance(neigh, cCoords) = |cCoords - neigh|; the same value serves SM.C:626
-                const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
+                const V3 dv_ = cur - ldsv(nx, ny, nz, (SMGPU_ABLATE & 2) ? 0 : (e & 0x7fff));
+                const double len = (SMGPU_ABLATE & 1) ? magSqr(dv_) : mag(dv_);
                 if (len < shortestCur) shortestCur = len;
-                if (internal || !(e & 0x8000)) {
-                    if (k1 < 0 || len < l1) { l3 = l2; k3 = k2; q3 = q2; l2 = l1; k2 = k1; q2 = q1; l1 = len; k1 = j; q1 = e; }
-                    else if (k2 < 0 || len < l2) { l3 = l2; k3 = k2; q3 = q2; l2 = len; k2 = j; q2 = e; }
-                    else if (k3 < 0 || len < l3) { l3 = len; k3 = j; q3 = e; }
-                }
+                t3.offer(len, j, e, internal || !(e & 0x8000));
             })
-            if (k2 < 0) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
+            if (!t3.has2()) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
             else {
-                r1 = ldsv(nx, ny, nz, q1 & 0x7fff) - cur;
-                r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
-                r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
-                m1 = l1; m2 = l2; m3 = (k3 < 0) ? mag(r3) : l3;
+                r1 = ldsv(nx, ny, nz, t3.w1 & 0x7fff) - cur;
+                r2 = ldsv(nx, ny, nz, t3.w2 & 0x7fff) - cur;
+                r3 = !t3.has3() ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, t3.w3 & 0x7fff) - cur;
+                m1 = t3.l1; m2 = t3.l2; m3 = !t3.has3() ? mag(r3) : t3.l3;
                 if (g.usePairShare) {
-                    hc = (pairBits<T>(g, tm, R, tid, k1) >> k2) & 1;
+                    hc = (pairBits<T>(g, tm, R, tid, t3.k1()) >> t3.k2()) & 1;
                 } else {
                     const int nb = m.ppOff[p];
-                    hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
+                    hc = shareCell(m, m.ppPt[nb + t3.k1()], m.ppPt[nb + t3.k2()]) ? 1 : 0;
                 }
             }
         }
@@ -773,9 +799,10 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             // IS the root of the minimum of the squares -- one sqrt instead of one per neighbour, the same bits
             // (NaN squares are skipped as NaN lengths were; lengths not below the loop's start value GREAT never won)
             double minSqr = __builtin_inf();
+            if (!(SMGPU_ABLATE & 4))
             SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 (void)j;
-                const double t2 = magSqr(np - ldsv(nx, ny, nz, e & 0x7fff));
+                const double t2 = magSqr(np - ldsv(nx, ny, nz, (SMGPU_ABLATE & 2) ? 0 : (e & 0x7fff)));
                 if (t2 < minSqr) minSqr = t2;
             })
             const double rootMin = sqrtExact(minSqr);
@@ -874,27 +901,21 @@ __device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, 
             count = j + 1;
         })
     }
-    double l1 = 0, l2 = 0, l3 = 0;
-    int k1 = -1, k2 = -1, k3 = -1;
-    unsigned q1 = 0, q2 = 0, q3 = 0;
+    Top3 t3;
     SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
         const double len = mag(cur - ldsv(nx, ny, nz, e & 0x7fff));
-        if (internal || !(e & 0x8000)) {
-            if (k1 < 0 || len < l1) { l3 = l2; k3 = k2; q3 = q2; l2 = l1; k2 = k1; q2 = q1; l1 = len; k1 = j; q1 = e; }
-            else if (k2 < 0 || len < l2) { l3 = l2; k3 = k2; q3 = q2; l2 = len; k2 = j; q2 = e; }
-            else if (k3 < 0 || len < l3) { l3 = len; k3 = j; q3 = e; }
-        }
+        t3.offer(len, j, e, internal || !(e & 0x8000));
     })
-    if (k2 < 0) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
+    if (!t3.has2()) { s.acc->err = 1; r1 = r2 = r3 = v3(0, 0, 0); }
     else {
-        r1 = ldsv(nx, ny, nz, q1 & 0x7fff) - cur;
-        r2 = ldsv(nx, ny, nz, q2 & 0x7fff) - cur;
-        r3 = (k3 < 0) ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, q3 & 0x7fff) - cur;
+        r1 = ldsv(nx, ny, nz, t3.w1 & 0x7fff) - cur;
+        r2 = ldsv(nx, ny, nz, t3.w2 & 0x7fff) - cur;
+        r3 = !t3.has3() ? v3(SMGPU_GREAT, SMGPU_GREAT, SMGPU_GREAT) : ldsv(nx, ny, nz, t3.w3 & 0x7fff) - cur;
         if (g.usePairShare) {
-            hc = (pairBits<T>(g, tm, R, tid, k1) >> k2) & 1;
+            hc = (pairBits<T>(g, tm, R, tid, t3.k1()) >> t3.k2()) & 1;
         } else {
             const int nb = m.ppOff[p];
-            hc = shareCell(m, m.ppPt[nb + k1], m.ppPt[nb + k2]) ? 1 : 0;
+            hc = shareCell(m, m.ppPt[nb + t3.k1()], m.ppPt[nb + t3.k2()]) ? 1 : 0;
         }
     }
     double rec[SMGPU_HALO_A_DOUBLES];

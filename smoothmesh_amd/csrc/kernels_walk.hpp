@@ -786,6 +786,11 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
 // walk, [1] stars seen, [2 + p] the hash of point p's star inputs -- everything its jobs read: the vertex slots with their roles,
 // the entries' proposals and states, the point's two positions and angle bounds, the ring places' cell centres.  Would an exact
 // memo of the predicates pay?  
+// The block is compiled in by -DSMGPU_WALK_MEMO=1 only (a measuring build, scripts/walk_memo_stats.py): in the product kernel its
+// registers cost 28 VGPR spills.
+#ifndef SMGPU_WALK_MEMO
+#define SMGPU_WALK_MEMO 0
+#endif
 __device__ __forceinline__ unsigned long long memoMix(unsigned long long h, unsigned long long v) {
     h ^= v + 0x9e3779b97f4a7c15ull + (h << 6) + (h >> 2);
     h *= 0xff51afd7ed558ccdull;
@@ -950,7 +955,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             R.l = (unsigned char)P.l; R.lNext = (unsigned char)lNext; R.xEnt = (unsigned char)P.xEnt; R.xSlot = (unsigned char)P.xSlot;
             R.pFirst = P.pFirst ? 1 : 0;
         }
-        if (memo) {      // (wave-uniform) the hash of the star's inputs against the one of the point's previous walk
+        if (SMGPU_WALK_MEMO && memo) {      // (wave-uniform) the hash of the star's inputs against the one of the point's previous walk
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
             unsigned long long hsh = 0ull;

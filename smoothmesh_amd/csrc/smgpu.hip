@@ -1232,6 +1232,7 @@ static int runGeometry(smgpu_handle* h, const int* tileList = nullptr, int nList
 static int ensureWalkBuffers(smgpu_handle* h) {
     if (h->walkAlloc) return 0;
     const Topology& t = h->topo;
+    if (envInt("SMGPU_WALK_MEMO_STATS", 0) && !SMGPU_WALK_MEMO) return fail("SMGPU_WALK_MEMO_STATS needs a build with -DSMGPU_WALK_MEMO=1 (make HIPFLAGS+=-DSMGPU_WALK_MEMO=1)");
     if (envInt("SMGPU_WALK_MEMO_STATS", 0) && !h->dWalkMemo) {
         if (devAlloc(h, &h->dWalkMemo, (size_t)t.nPoints + 2)) return 1;
         HIP_OK(hipMemset(h->dWalkMemo, 0, ((size_t)t.nPoints + 2) * sizeof(unsigned long long)));
