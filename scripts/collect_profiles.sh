@@ -39,6 +39,12 @@ done
 cd $root
 python3 scripts/pmc_summary.py $out > $out/pmc_sq_hex100.txt 2>/dev/null
 rm -rf $out/sq1 $out/sq2 $out/sq3
+# what every kernel executes per launch, by instruction type (SQ_INSTS_VALU_* etc.)
+for wl in hex100 cavity215 cavity215c; do
+  timeout 900 bash scripts/pmc_inst_mix.sh $wl 10 > /dev/null 2>&1
+  cp gpurun_out/inst_mix_$wl/summary.txt $out/inst_mix_$wl.txt 2>/dev/null; rm -rf gpurun_out/inst_mix_$wl
+done
+SMGPU_VERBOSE=2 timeout 300 python3 scripts/create_time.py cavity215 > $out/setup_phases_cavity215_final.txt 2>&1
 # one rank of eight: both transports (RCCL send / recv groups; peer stores with a self-mapping), with kernel timelines
 timeout 900 bash scripts/probe_timeline.sh > /dev/null 2>&1
 cp gpurun_out/probe_timeline/probe.txt $out/probe_rank_of_8_rccl.txt; cp gpurun_out/probe_timeline/timeline.txt $out/probe_rank_of_8_timeline_rccl.txt
