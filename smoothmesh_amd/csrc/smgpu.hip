@@ -2047,10 +2047,37 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             for (int pi = 0; pi < P; ++pi) if (posSlot[(size_t)pi] >= 0) sub.push_back(h->stl.order[(size_t)pi]);
             std::vector<double> pts(3 * (size_t)P);      // (the builder only reads coordinates when it orders the points itself)
             const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500)), capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
-            if (ensureHostLists(h, 1)) return 1;      // (the tables' corner lists: pointFaces with prev / next)
-            const std::string err = h->shr.build(h->topo, pts.data(), h->isInternalHost.data(), false, h->smoothT, capSC, capSN, nullptr, &sub);
+            std::string err = h->shr.buildBoundaries(h->topo, pts.data(), false, h->smoothT, capSC, capSN, nullptr, &sub);
             if (!err.empty()) return fail("shared-point tiles: " + err);
-            if (uploadSmoothView(h, h->shr, h->hv, h->sv.usePairShare)) return 1;
+            // the tables on the device where the addressing lives there (tiles_dev.hip; the corner lists they read stayed there),
+            // else on the host -- which first fetches those lists
+            int onDev = 1;
+            SmoothTilesDev sd;
+            if (h->devLists.valid && envInt("SMGPU_DEVICE_TILES", 1) == 1) {
+                std::string why;
+                onDev = buildSmoothTablesOnDevice(h->shr, h->devLists, P, h->topo.maxPointPoints, h->isInternalHost.data(), h->device, sd, why);
+                if (onDev == 2) return fail("shared-point tiles: " + why);
+            }
+            if (onDev == 0) {
+                SmoothTileView& v = h->hv;
+                auto adoptS = [&](auto*& dst, const SmoothTilesDev::Arr& a) { dst = (std::remove_reference_t<decltype(dst)>)a.p; h->allocs.push_back(a.p); h->deviceBytes += (int64_t)a.bytes; };
+                adoptS(v.ptOrder, sd.order); adoptS(v.ptBeg, sd.ptBeg); adoptS(v.tcIds, sd.tcIds); adoptS(v.tnIds, sd.tnIds); adoptS(v.selfLoc, sd.selfLoc);
+                adoptS(v.pcEll, sd.pcEll); adoptS(v.ppEll, sd.ppEll); adoptS(v.pairEll, sd.pairEll); adoptS(v.pfEll, sd.pfEll); adoptS(v.meta, sd.meta);
+                int rcU = 0;
+                rcU |= devUpload(h, &v.tcOff, h->shr.tcOff); rcU |= devUpload(h, &v.tnOff, h->shr.tnOff);
+                rcU |= devUpload(h, &v.pcBase, h->shr.pcBase); rcU |= devUpload(h, &v.pcWidth, h->shr.pcWidth);
+                rcU |= devUpload(h, &v.ppBase, h->shr.ppBase); rcU |= devUpload(h, &v.ppWidth, h->shr.ppWidth);
+                rcU |= devUpload(h, &v.pfBase, h->shr.pfBase); rcU |= devUpload(h, &v.pfWidth, h->shr.pfWidth);
+                if (rcU) return 1;
+                v.maxCells = h->shr.maxCells; v.maxPoints = h->shr.maxPoints;
+                v.usePairShare = h->sv.usePairShare;
+            } else {
+                if (ensureHostLists(h, 1)) return 1;      // (the tables' corner lists: pointFaces with prev / next)
+                err = h->shr.buildTables(h->topo, h->isInternalHost.data(), true);
+                if (!err.empty()) return fail("shared-point tiles: " + err);
+                if (uploadSmoothView(h, h->shr, h->hv, h->sv.usePairShare)) return 1;
+            }
+            if (envInt("SMGPU_VERBOSE", 0) >= 2) std::fprintf(stderr, "[smgpu] shared-point tiles: %d tiles, tables on the %s\n", h->shr.nTiles, onDev == 0 ? "device" : "host");
             h->haloLds = sizeof(double) * 3 * ((size_t)h->shr.maxCells + (size_t)h->shr.maxPoints);
             // per position of those tiles: slot, two-sharer peer code (k_halo_combineA2's table), send slots
             const size_t nS = sub.size();

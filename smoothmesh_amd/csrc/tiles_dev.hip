@@ -253,10 +253,11 @@ __global__ void __launch_bounds__(kT) k_tl_remap(long long n, int* __restrict__ 
 // of the tables' bytes), one thread per point on arrays in its private memory.  It depends on the point only, not on the tiling:
 // one pass over the points, the tile kernel below maps the result to local indices.
 constexpr int kCh = 64;                 // corners (= faces) per point this kernel handles; a mesh beyond goes back to the host build
-__global__ void __launch_bounds__(64) k_tl_chain(int nPoints, const int* __restrict__ pfOff, const int* __restrict__ pfPrev, const int* __restrict__ pfNext,
-                                                 int* __restrict__ chPrev, int* __restrict__ chNext, int* bad) {
-    const int p = blockIdx.x * 64 + threadIdx.x;
-    if (p >= nPoints) return;
+__global__ void __launch_bounds__(64) k_tl_chain(int nPos, const int* __restrict__ ids /* the points to do, or NULL: all */, const int* __restrict__ pfOff,
+                                                 const int* __restrict__ pfPrev, const int* __restrict__ pfNext, int* __restrict__ chPrev, int* __restrict__ chNext, int* bad) {
+    const int i_ = blockIdx.x * 64 + threadIdx.x;
+    if (i_ >= nPos) return;
+    const int p = ids ? ids[i_] : i_;
     const int b = pfOff[p], n = pfOff[p + 1] - b;
     if (n > kCh) { *bad = 1; return; }
     if (n < 2) { for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; } return; }
@@ -563,7 +564,8 @@ int buildEdgeTablesOnDevice(EdgeTiles& et, const DeviceTopologyArrays& td, int32
 // st.order / st.ptBeg / st.nTiles / st.threads stand (host: SmoothTiles::buildBoundaries).  Return values as buildGeomTablesOnDevice.
 int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, int32_t nPoints, int32_t maxPointPoints, const uint8_t* isInternal, int device,
                               SmoothTilesDev& out, std::string& why) {
-    if (!td.valid || st.threads != kT || st.nTiles <= 0 || (int64_t)st.order.size() != nPoints) return 1;
+    if (!td.valid || st.threads != kT || st.nTiles <= 0 || st.order.empty()) return 1;
+    const int nPos = (int)st.order.size();      // (all points, or the subset the tiles are made of)
     TL_OK(hipSetDevice(device));
     hipStream_t sm = nullptr;
     TL_OK(hipStreamCreateWithFlags(&sm, hipStreamNonBlocking));
@@ -571,14 +573,15 @@ int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, i
     const int nT = st.nTiles;
     const size_t S = (size_t)nT + 1, nPf = td.pfPrev.bytes / 4;
     DevBuf D;
-    int *dOrder = D.get<int>((size_t)nPoints), *dBeg = D.get<int>(S), *chPrev = D.get<int>(nPf), *chNext = D.get<int>(nPf);
+    int *dOrder = D.get<int>((size_t)nPos), *dBeg = D.get<int>(S), *chPrev = D.get<int>(nPf), *chNext = D.get<int>(nPf);
     uint8_t* dInt = D.get<uint8_t>((size_t)nPoints);
     int *nCl = D.get<int>((size_t)nT), *nPt = D.get<int>((size_t)nT), *wc = D.get<int>((size_t)nT), *wn = D.get<int>((size_t)nT), *wf = D.get<int>((size_t)nT), *bad = D.get<int>(1);
     long long* terms = D.get<long long>(10 * S);
     if (!dOrder || !dBeg || !chPrev || !chNext || !dInt || !nCl || !nPt || !wc || !wn || !wf || !bad || !terms) { why = "device allocation failed"; return 2; }
     TL_OK(hipMemsetAsync(bad, 0, 4, sm));
-    hipLaunchKernelGGL(k_tl_chain, dim3((nPoints + 63) / 64), dim3(64), 0, sm, nPoints, (const int*)td.pfOff.p, (const int*)td.pfPrev.p, (const int*)td.pfNext.p, chPrev, chNext, bad);
-    TL_OK(hipMemcpyAsync(dOrder, st.order.data(), (size_t)nPoints * 4, hipMemcpyHostToDevice, sm));
+    TL_OK(hipMemcpyAsync(dOrder, st.order.data(), (size_t)nPos * 4, hipMemcpyHostToDevice, sm));
+    hipLaunchKernelGGL(k_tl_chain, dim3((nPos + 63) / 64), dim3(64), 0, sm, nPos, nPos == nPoints ? (const int*)nullptr : (const int*)dOrder, (const int*)td.pfOff.p,
+                       (const int*)td.pfPrev.p, (const int*)td.pfNext.p, chPrev, chNext, bad);
     TL_OK(hipMemcpyAsync(dBeg, st.ptBeg.data(), S * 4, hipMemcpyHostToDevice, sm));
     TL_OK(hipMemcpyAsync(dInt, isInternal, (size_t)nPoints, hipMemcpyHostToDevice, sm));
     SmoothIn in{dOrder, dBeg, nT, maxPointPoints <= 16 ? 1 : 0, (const int*)td.pcOff.p, (const int*)td.pcVal.p, (const int*)td.ppOff.p, (const int*)td.ppPt.p,
@@ -602,14 +605,14 @@ int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, i
     const long long nTc = offs[(size_t)nT], nTn = offs[S + nT], nPc = offs[2 * S + nT], nPp = offs[3 * S + nT], nPfE = offs[4 * S + nT];
     if (nTc > 0x7fffffffll || nTn > 0x7fffffffll || nPc > 0x7fffffffll || nPp > 0x7fffffffll || nPfE > 0x7fffffffll) return 1;
     int *tcIds = D.get<int>((size_t)nTc), *tnIds = D.get<int>((size_t)nTn), *meta = D.get<int>(12 * (size_t)nT);
-    uint16_t *selfLoc = D.get<uint16_t>((size_t)nPoints), *pcEll = D.get<uint16_t>((size_t)nPc), *ppEll = D.get<uint16_t>((size_t)nPp), *pairEll = D.get<uint16_t>((size_t)nPp),
+    uint16_t *selfLoc = D.get<uint16_t>((size_t)nPos), *pcEll = D.get<uint16_t>((size_t)nPc), *ppEll = D.get<uint16_t>((size_t)nPp), *pairEll = D.get<uint16_t>((size_t)nPp),
              *pfEll = D.get<uint16_t>((size_t)nPfE);
     if (!tcIds || !tnIds || !meta || !selfLoc || !pcEll || !ppEll || !pairEll || !pfEll) { why = "device allocation failed"; return 2; }
     TL_OK(hipMemsetAsync(pcEll, 0xFF, (size_t)nPc * 2, sm));
     TL_OK(hipMemsetAsync(ppEll, 0xFF, (size_t)nPp * 2, sm));
     TL_OK(hipMemsetAsync(pfEll, 0xFF, (size_t)nPfE * 2, sm));
     TL_OK(hipMemsetAsync(pairEll, 0, (size_t)nPp * 2, sm));
-    TL_OK(hipMemsetAsync(selfLoc, 0, (size_t)nPoints * 2, sm));
+    TL_OK(hipMemsetAsync(selfLoc, 0, (size_t)nPos * 2, sm));
     hipLaunchKernelGGL(k_tl_smooth<true>, dim3(nT), dim3(kT), 0, sm, in, sz,
                        SmoothOut{offsD, offsD + S, offsD + 2 * S, offsD + 3 * S, offsD + 4 * S, tcIds, tnIds, selfLoc, pcEll, ppEll, pairEll, pfEll, meta});
     std::vector<int> hC((size_t)nT), hN((size_t)nT), hWc((size_t)nT), hWn((size_t)nT), hWf((size_t)nT);
@@ -631,8 +634,8 @@ int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, i
     }
     st.tcIds.clear(); st.tnIds.clear(); st.selfLoc.clear(); st.pcEll.clear(); st.ppEll.clear(); st.pairEll.clear(); st.pfEll.clear();
     auto give = [&](SmoothTilesDev::Arr& a, void* p, size_t bytes) { a.p = p; a.bytes = std::max<size_t>(bytes, 1); D.release(p); };
-    give(out.order, dOrder, (size_t)nPoints * 4); give(out.ptBeg, dBeg, S * 4); give(out.tcIds, tcIds, (size_t)nTc * 4); give(out.tnIds, tnIds, (size_t)nTn * 4);
-    give(out.selfLoc, selfLoc, (size_t)nPoints * 2); give(out.pcEll, pcEll, (size_t)nPc * 2); give(out.ppEll, ppEll, (size_t)nPp * 2); give(out.pairEll, pairEll, (size_t)nPp * 2);
+    give(out.order, dOrder, (size_t)nPos * 4); give(out.ptBeg, dBeg, S * 4); give(out.tcIds, tcIds, (size_t)nTc * 4); give(out.tnIds, tnIds, (size_t)nTn * 4);
+    give(out.selfLoc, selfLoc, (size_t)nPos * 2); give(out.pcEll, pcEll, (size_t)nPc * 2); give(out.ppEll, ppEll, (size_t)nPp * 2); give(out.pairEll, pairEll, (size_t)nPp * 2);
     give(out.pfEll, pfEll, (size_t)nPfE * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
     out.valid = true;
     return 0;
