@@ -480,6 +480,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (wantTiles && mortonTiles) fPointOrder = std::async(std::launch::async, [&] { return mortonOrderOf(d->nPoints, d->points); });
     std::future<std::string> fGeom, fSmooth, fEdge;
     std::function<void()> startEdge;
+    CornerChains chains;       // (tiles_dev.hip; released by the smoothing task's device build, or below)
+    struct ChainsGuard { CornerChains& c; std::future<std::string>& f; ~ChainsGuard() { if (f.valid()) f.wait(); releaseCornerChains(c); } } chainsGuard{chains, fSmooth};
     static const char* const kHostTablesPending = "\x01host tables pending";      // a tile task of a device build that leaves its tables to the host
     std::vector<int32_t> pointOrder;
     std::vector<uint8_t> internalMask;
@@ -493,7 +495,14 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         // tile boundaries on the host, the tables on the device where the addressing was built there (tiles_dev.hip), else on the host
         // (SMGPU_DEVICE_TILES=2: as if the device builds handed their tables back -- the tests' way into that path)
         const bool devTiles = envInt("SMGPU_DEVICE_TILES", 1) != 0;
-        const auto afterCells = [&] { if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
+        const auto afterCells = [&] {
+                      // (the corner chains of the smoothing tables need the device addressing only: started here, they run beside the
+                      // rest of the download and the host's boundary passes)
+                      if (wantTiles && geomOk && smoothOk && devTiles && devTopo.valid && envInt("SMGPU_DEVICE_TILES", 1) == 1) {
+                          std::string why;
+                          if (startCornerChains(devTopo, d->nPoints, h->device, chains, why) == 2) chains = CornerChains();
+                      }
+                      if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
                       const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0);
                       if (!e.empty()) return e;
                       if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);      // (the host's lists are still arriving)
@@ -521,7 +530,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     if (devTopo.valid) {
                         std::string why;
                         const auto t0 = std::chrono::steady_clock::now();
-                        const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildSmoothTablesOnDevice(h->stl, devTopo, d->nPoints, h->topo.maxPointPoints, internalMask.data(), h->device, h->stDev, why);
+                        const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildSmoothTablesOnDevice(h->stl, devTopo, d->nPoints, h->topo.maxPointPoints, internalMask.data(), h->device, h->stDev, why, &chains);
                         if (envInt("SMGPU_VERBOSE", 0) >= 2)
                             std::fprintf(stderr, "[smgpu] smoothing tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
                                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());

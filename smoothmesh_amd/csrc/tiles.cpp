@@ -100,6 +100,13 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
     return e.empty() ? buildTables(t) : e;
 }
 
+// segments of the Z-curve the greedy boundary passes tile side by side on large meshes (SMGPU_TILE_SEGMENTS; every cut costs one
+// partial tile and a pair of mesh-sized stamp arrays)
+static unsigned tileSegments() {
+    static const unsigned n = [] { const char* e = std::getenv("SMGPU_TILE_SEGMENTS"); return e ? std::max(1u, std::min((unsigned)std::atoi(e), 64u)) : 8u; }();
+    return n;
+}
+
 std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
                                        int32_t capPoints, int32_t capFaces) {
     threads = nThreads;
@@ -130,7 +137,7 @@ std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, boo
     // (as the edge tiles do): a segment starts a fresh tile, so the tiling differs from the one-segment tiling by at most one
     // partial tile per cut -- any tiling is as good as any other for the results.  (One pass over 10 M cells: 0.95 s.)
     {
-        const int segs = (t.nCells >= (2 << 20)) ? (int)std::min<unsigned>(hostThreads(), 8u) : 1;
+        const int segs = (t.nCells >= (2 << 20)) ? (int)std::min<unsigned>(hostThreads(), tileSegments()) : 1;
         std::vector<std::vector<int32_t>> segBeg((size_t)segs);
         std::vector<std::string> segErr((size_t)segs);
         parallelRanges(t.nCells, segs, [&](int sg, int64_t c0, int64_t c1) {
@@ -375,7 +382,7 @@ std::string SmoothTiles::buildBoundaries(const Topology& t, const double* xyz, b
     const auto& pe = t.pointEdges;   // offsets shared with pointPoints
     // (segments tiled side by side on large point sets, see GeomTiles::build)
     {
-        const int segs = (nPos >= (2 << 20)) ? (int)std::min<unsigned>(hostThreads(), 8u) : 1;
+        const int segs = (nPos >= (2 << 20)) ? (int)std::min<unsigned>(hostThreads(), tileSegments()) : 1;
         std::vector<std::vector<int32_t>> segBeg((size_t)segs);
         std::vector<std::string> segErr((size_t)segs);
         parallelRanges(nPos, segs, [&](int sg, int64_t p0, int64_t p1) {
@@ -580,7 +587,7 @@ std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, boo
     // pass 1: greedy tile boundaries.  On large meshes the edge sequence is cut into a few segments that are tiled side by side
     // (each with stamp arrays of its own); a segment starts a fresh tile, so the tiling differs from the one-segment tiling by
     // at most one partial tile per cut -- any tiling is as good as any other for the results.
-    const int segs = (nE >= (4 << 20)) ? (int)std::min<unsigned>(hostThreads(), 8u) : 1;
+    const int segs = (nE >= (4 << 20)) ? (int)std::min<unsigned>(hostThreads(), tileSegments()) : 1;
     std::vector<std::vector<int32_t>> segBeg((size_t)segs);
     std::vector<std::string> segErr((size_t)segs);
     parallelRanges(nE, segs, [&](int sg, int64_t e0, int64_t e1) {

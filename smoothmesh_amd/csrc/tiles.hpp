@@ -111,9 +111,13 @@ struct SmoothTilesDev {
     Arr order, ptBeg, tcIds, tnIds, selfLoc, pcEll, ppEll, pairEll, pfEll, meta;
     bool valid = false;
 };
-// (maxPointPoints: Topology's; the neighbour-pair masks exist while it is <= 16)
+// the corner chains of all points computed ahead of the tables (tiles_dev.hip: startCornerChains)
+struct CornerChains { int* chPrev = nullptr; int* chNext = nullptr; int* bad = nullptr; void* stream = nullptr; int32_t nPoints = 0; bool started = false; };
+int startCornerChains(const DeviceTopologyArrays& td, int32_t nPoints, int device, CornerChains& c, std::string& why);
+void releaseCornerChains(CornerChains& c);
+// (maxPointPoints: Topology's; the neighbour-pair masks exist while it is <= 16; chains: taken over and freed, or NULL)
 int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, int32_t nPoints, int32_t maxPointPoints, const uint8_t* isInternal, int device,
-                              SmoothTilesDev& out, std::string& why);
+                              SmoothTilesDev& out, std::string& why, CornerChains* chains = nullptr);
 
 // ---- face-angle filter: tile = edges (Morton order of the edge midpoints); LDS holds the points, the
 // face vertex averages and the cell centres the tile's edges need ------------------------------------------
