@@ -37,7 +37,12 @@ constexpr float kNearClamp = 0.999f;     // |cos| above this goes to the exact p
 
 struct F3 { float x, y, z; };
 __device__ __forceinline__ F3 f3(const V3& v) { F3 r; r.x = (float)v.x; r.y = (float)v.y; r.z = (float)v.z; return r; }
-__device__ __forceinline__ float fdot(const F3& a, const F3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// (explicit fused multiply-adds: the library is built with -ffp-contract=off for the reference's f64 arithmetic, which left the
+// filters' f32 dot products as three multiplies and two adds -- they are estimates behind margins, any rounding serves, and the
+// filter kernels are bound by vector issue)
+__device__ __forceinline__ float fdot(const F3& a, const F3& b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+// a - t b
+__device__ __forceinline__ F3 fsubScaled(const F3& a, float t, const F3& b) { F3 r; r.x = fmaf(-t, b.x, a.x); r.y = fmaf(-t, b.y, a.y); r.z = fmaf(-t, b.z, a.z); return r; }
 __device__ __forceinline__ F3 fscale(const F3& a, float s) { F3 r; r.x = a.x * s; r.y = a.y * s; r.z = a.z * s; return r; }
 __device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
     const float n2 = fdot(a, a);
@@ -47,7 +52,7 @@ __device__ __forceinline__ F3 funit(const F3& a, bool& ok) {
 
 // acos(a) + acos(b) inside (small + margin, large - margin) for sure, decided on the cosine of the sum (file header)
 __device__ __forceinline__ bool faSumInside(float a, float b, const Prm& prm) {
-    const float c = a * b - __builtin_amdgcn_sqrtf(fmaf(-a, a, 1.0f) * fmaf(-b, b, 1.0f));
+    const float c = fmaf(a, b, -__builtin_amdgcn_sqrtf(fmaf(-a, a, 1.0f) * fmaf(-b, b, 1.0f)));
     return (c < prm.faCosLo) && (c > prm.faCosHi) && (a + b > kFaSumMin);
 }
 
@@ -75,7 +80,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_edges_filter(MeshView m, State s,
         auto project = [&](const V3& c) -> F3 {
             const F3 d = f3(c - cC);
             const float t = fdot(d, eV);
-            F3 w; w.x = d.x - t * eV.x; w.y = d.y - t * eV.y; w.z = d.z - t * eV.z;
+            const F3 w = fsubScaled(d, t, eV);
             const float w2 = fdot(w, w), d2 = fdot(d, d);
             ok = ok && (w2 > 1.0e-4f * d2);          // in-plane part keeps > 1 % of the vector
             return funit(w, ok);
@@ -133,6 +138,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_filter(MeshView m, State 
 // proposed) pair of each neighbour goes through packed two-wide f32 instructions (v_pk_mul_f32 / v_pk_add_f32): the kernel is
 // bound by VALU issue, and the f64 subtract + convert of every vector was a quarter of it.
 typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pkfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }      // v_pk_fma_f32 (see fdot)
 constexpr float kRelGuard = 2.0e-6f;
 
 // block-wide maximum of a non-negative float (all T threads call it); red: T/64 floats of LDS
@@ -241,7 +247,7 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
 #define SMGPU_EA_UNIT(UX, UY, UZ, A)                                                                              \
     {                                                                                                             \
         const f2 vx_ = {cx[(A)] - p0x, nx[(A)] - p0x}, vy_ = {cy[(A)] - p0y, ny[(A)] - p0y}, vz_ = {cz[(A)] - p0z, nz[(A)] - p0z}; \
-        const f2 n2_ = vx_ * vx_ + vy_ * vy_ + vz_ * vz_;                                                         \
+        const f2 n2_ = pkfma(vx_, vx_, pkfma(vy_, vy_, vz_ * vz_));                                               \
         ok = ok && (n2_.x > minN2) && (n2_.y > minN2);            /* NaN -> false -> exact path */                 \
         const f2 rs_ = {__builtin_amdgcn_rsqf(n2_.x), __builtin_amdgcn_rsqf(n2_.y)};                               \
         UX = vx_ * rs_; UY = vy_ * rs_; UZ = vz_ * rs_;                                                           \
@@ -251,8 +257,8 @@ __global__ void __launch_bounds__(T) k_ea_filter_tile(MeshView m, State s, Smoot
         if ((int)(A1) != heldId) SMGPU_EA_UNIT(hx, hy, hz, (A1))                                                  \
         f2 ux, uy, uz;                                                                                            \
         SMGPU_EA_UNIT(ux, uy, uz, (A2))                                                                           \
-        const f2 d0 = hx * ux + hy * uy + hz * uz;               /* (x1 . x2, n1 . n2): nAngle0, nAngle1 */        \
-        const f2 d1 = hx * ux.yx + hy * uy.yx + hz * uz.yx;      /* (x1 . n2, n1 . x2): nAngle2, nAngle3 */        \
+        const f2 d0 = pkfma(hx, ux, pkfma(hy, uy, hz * uz));     /* (x1 . x2, n1 . n2): nAngle0, nAngle1 */        \
+        const f2 d1 = pkfma(hx, ux.yx, pkfma(hy, uy.yx, hz * uz.yx));   /* (x1 . n2, n1 . x2): nAngle2, nAngle3 */ \
         below = below && (d0.x < thr) && (d0.y < thr) && (d1.x < thr) && (d1.y < thr);                            \
         hx = ux; hy = uy; hz = uz; heldId = (int)(A2);                                                            \
     }
@@ -372,7 +378,7 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
         {                                                                               \
             const F3 d_ = f3((C) - cC);                                                 \
             const float t_ = fdot(d_, eV);                                              \
-            F3 w_; w_.x = d_.x - t_ * eV.x; w_.y = d_.y - t_ * eV.y; w_.z = d_.z - t_ * eV.z; \
+            const F3 w_ = fsubScaled(d_, t_, eV);                                       \
             ok = ok && (fdot(w_, w_) > 1.0e-4f * fdot(d_, d_));                        \
             OUT = funit(w_, ok);                                                        \
         }
