@@ -53,6 +53,24 @@ class SubDomain:
         return out
 
 
+def _connected_components(n, ea, eb):
+    """labels 0 .. k-1 of the connected components of the undirected graph on n nodes with edges (ea[i], eb[i]), numbered in the
+    order of their smallest node (the numbering scipy.sparse.csgraph.connected_components gives; numpy only: minimum-label
+    propagation with pointer jumping -- the graphs here are chains of a few copies of a point, a handful of rounds)"""
+    lab = np.arange(n, dtype=np.int64)
+    ea = np.asarray(ea, np.int64); eb = np.asarray(eb, np.int64)
+    while len(ea):
+        m = np.minimum(lab[ea], lab[eb])
+        new = lab.copy()
+        np.minimum.at(new, ea, m)
+        np.minimum.at(new, eb, m)
+        new = new[new]
+        if np.array_equal(new, lab):
+            break
+        lab = new
+    return np.unique(lab, return_inverse=True)[1].astype(np.int64)
+
+
 def shared_point_components(patch_lists):
     """The copies of points that syncTools::syncPointList combines, as OpenFOAM's globalPoints finds them: the copies of a point
     on the two sides of a PROCESSOR PATCH are the same point, and so is everything connected through such pairs (transitive
@@ -63,8 +81,6 @@ def shared_point_components(patch_lists):
     patch_lists[r] = {neighbour: sorted global ids on r's patch to it} (SubDomain.processor_patch_point_lists).
     -> (node_rank, node_gid, comp, comp_size): one node per (rank, point on one of its processor patches), its component label
     and that component's number of members."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
     nR = len(patch_lists)
     ids = [np.unique(np.concatenate([np.asarray(v, np.int64) for v in lists.values()])) if lists else np.zeros(0, np.int64) for lists in patch_lists]
     base = np.concatenate([[0], np.cumsum([len(i) for i in ids])]).astype(np.int64)
@@ -84,7 +100,7 @@ def shared_point_components(patch_lists):
         return node_rank, node_gid, np.zeros(0, np.int32), np.zeros(0, np.int64)
     ea = np.concatenate(ea) if ea else np.zeros(0, np.int64)
     eb = np.concatenate(eb) if eb else np.zeros(0, np.int64)
-    _, comp = connected_components(coo_matrix((np.ones(len(ea), np.int8), (ea, eb)), shape=(n, n)), directed=False)
+    comp = _connected_components(n, ea, eb)
     return node_rank, node_gid, comp.astype(np.int64), np.bincount(comp)[comp]
 
 
