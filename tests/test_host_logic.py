@@ -188,3 +188,28 @@ def test_rccl_unique_id_marshalling_keeps_all_128_bytes():
     v = _UniqueId()
     C.memmove(C.byref(v), blob, 128)
     assert bytes(v.internal) == raw
+
+
+def test_connected_components_numbering():
+    """decompose._connected_components (numpy only) against a plain union-find: same partition, components numbered in the order of
+    their smallest node"""
+    import numpy as np
+    from smoothmesh_amd.decompose import _connected_components
+    rng = np.random.default_rng(5)
+    for _ in range(100):
+        n = int(rng.integers(1, 50))
+        e = int(rng.integers(0, 70))
+        ea, eb = rng.integers(0, n, e), rng.integers(0, n, e)
+        parent = list(range(n))
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        for a, b in zip(ea, eb):
+            ra, rb = find(int(a)), find(int(b))
+            if ra != rb:
+                parent[max(ra, rb)] = min(ra, rb)
+        roots = [find(i) for i in range(n)]
+        order = {r: k for k, r in enumerate(sorted(set(roots)))}
+        assert np.array_equal(_connected_components(n, ea, eb), [order[r] for r in roots])
