@@ -303,13 +303,14 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
     extern __shared__ double lds[];
-    double* px = lds;                 double* py = px + g.maxPoints; double* pz = py + g.maxPoints;
-    double* fx = pz + g.maxPoints;    double* fy = fx + g.maxFaces;  double* fz = fy + g.maxFaces;
-    double* cx = fz + g.maxFaces;     double* cy = cx + g.maxCells;  double* cz = cy + g.maxCells;
     const int tile = li, tid = threadIdx.x;
     // prologue in two dependent round trips (see smoothStage): (1) the three id lists, the edge's id, end-point slots and the
     // first two chunks of its face and cell rows; (2) the records
     const EdgeTileMeta tm = loadTileMeta(g, tile);
+    // (laid out by the tile's own counts, see smoothLds: the launch's LDS is 24 B x the largest record total of one tile)
+    double* px = lds;                 double* py = px + tm.nPts;     double* pz = py + tm.nPts;
+    double* fx = pz + tm.nPts;        double* fy = fx + tm.nFaces;   double* fz = fy + tm.nFaces;
+    double* cx = fz + tm.nFaces;      double* cy = cx + tm.nCells;   double* cz = cy + tm.nCells;
     const bool mine = tid < tm.nEdges;
     const int wf4 = tm.efWidth >> 2, wc4 = tm.ecWidth >> 2;
     const ushort4* fRow = reinterpret_cast<const ushort4*>(g.efEll + tm.efBase) + tid;

@@ -557,10 +557,13 @@ __global__ void __launch_bounds__(T, (SMGPU_GEOM_WAVES * T) / 256) k_geom_tile(M
 // LDS arrays of one smoothing tile and the per-thread prologue (what a thread reads from global memory besides the
 // staged records: point id, own LDS slot, the first two ELL chunks of both rows)
 struct SmoothLds { double *cx, *cy, *cz, *nx, *ny, *nz; };
-__device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileView& g) {
+// The arrays are laid out by the TILE's own record counts (wave-uniform, from its meta record), not by the maxima over all tiles:
+// the launch's LDS size is then 24 B x the largest (cells + neighbours) of any ONE tile -- which the greedy boundary pass caps
+// (SmoothTiles::buildBoundaries, capTotal) -- instead of the sum of two maxima reached by different tiles.
+__device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileMeta& tm) {
     SmoothLds L;
-    L.cx = lds;                 L.cy = L.cx + g.maxCells;  L.cz = L.cy + g.maxCells;
-    L.nx = L.cz + g.maxCells;   L.ny = L.nx + g.maxPoints; L.nz = L.ny + g.maxPoints;
+    L.cx = lds;                 L.cy = L.cx + tm.nCells;  L.cz = L.cy + tm.nCells;
+    L.nx = L.cz + tm.nCells;    L.ny = L.nx + tm.nNbrs;   L.nz = L.ny + tm.nNbrs;
     return L;
 }
 // The three shortest incident edges in list order (stable: a later edge of equal length stays behind, SM.C:325-387), kept as
@@ -849,9 +852,9 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
     extern __shared__ double lds[];
-    const SmoothLds L = smoothLds(lds, g);
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
     const SmoothTileMeta tm = loadTileMeta(g, tile);
+    const SmoothLds L = smoothLds(lds, tm);
     const SmoothRow R = smoothStage<T>(m, s, g, tm, L, tid);
     if (stopped) return;
     __syncthreads();
@@ -878,9 +881,9 @@ __device__ __forceinline__ void packTileBody(const MeshView& m, const State& s, 
     const int li = launchTile(nLaunch, xcdMap, bid);
     if (li < 0) return;
     extern __shared__ double lds[];
-    const SmoothLds L = smoothLds(lds, g);
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
     const SmoothTileMeta tm = loadTileMeta(g, tile);
+    const SmoothLds L = smoothLds(lds, tm);
     const SmoothRow R = smoothStage<T, COHC, SP ? 2 : 1>(m, s, g, tm, L, tid, SlotTabs{s.spSlot, s.spPeer, s.spDst0, s.spNDst});
     __syncthreads();
     if (!R.mine) return;
@@ -1079,8 +1082,8 @@ __global__ void __launch_bounds__(T) k_smooth_halo(MeshView m, State s, Prm prm,
     if (li < 0 && !spTile) return;
     if (!spTile && !batchA) li += hs.nA;
     const int tile = li >= 0 ? li : 0;      // (a padding workgroup of the shared points' role stages the first tile in vain: it still signals)
-    const SmoothLds L = smoothLds(lds, v);
     const SmoothTileMeta tm = loadTileMeta(v, tile);
+    const SmoothLds L = smoothLds(lds, tm);
     if (spTile) {
         // exchange A's combine for the thread's own point, FIRST -- while nothing else is live in registers (the two ranks' records
         // are 52 VGPRs: inside smoothPoint they took the kernel from 64 to 97) -- with the master's fold of the three sequential

@@ -417,6 +417,25 @@ static void computeAlgoBytes(smgpu_handle* h) {
 }
 
 // the device view of a set of smoothing tiles (the shared points' own tiles, smgpu_halo_configure)
+// Records a tile may stage in total: its LDS footprint, which is what sets the kernels' occupancy (the LDS is allocated in
+// 512-byte steps).  Smoothing tiles of 256 points: 1 112 records of 24 bytes = 26.7 KB -- SIX workgroups per CU; the greedy pass
+// otherwise reaches 512 cells + 619..623 neighbours on the large meshes = 27.2 KB and five (same box, alternating three times: gather
+// kernel 335.4 -> 329.4 us on the 10 M-cell polyhedral mesh, 340.1 -> 333.0 us on hex215; the 1 M-cell block sits below by itself).
+// Edge tiles of 256 edges: 852 records = 20 448 B -- EIGHT workgroups of the face-angle filter per CU instead of seven (the
+// face-angle group 716 -> 705 us on the 10 M-cell mesh, the iteration 3.066 -> 3.047 ms; a tighter cap makes too many tiles: 720 us).
+// largest sum over the tiles of the entries of some per-tile offset lists (a tile's staged records of all kinds)
+static size_t maxTileTotal(int nTiles, std::initializer_list<const std::vector<int32_t>*> offs) {
+    size_t mx = 0;
+    for (int t = 0; t < nTiles; ++t) {
+        size_t n = 0;
+        for (const std::vector<int32_t>* o : offs) n += (size_t)((*o)[(size_t)t + 1] - (*o)[(size_t)t]);
+        mx = std::max(mx, n);
+    }
+    return mx;
+}
+static int defaultSmoothCapTotal(int T) { return T == 256 ? 1112 : 0x7fffffff; }
+static int defaultEdgeCapTotal() { return 852; }
+
 static int uploadSmoothView(smgpu_handle* h, const SmoothTiles& st, SmoothTileView& v, int usePairShare) {
     int rc = 0;
     rc |= devUpload(h, &v.ptOrder, st.order);
@@ -524,7 +543,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 for (int p = 0; p < d->nPoints; ++p) internalMask[(size_t)p] = d->isInternalPoint[p] ? 1 : 0;
                 h->isInternalHost = internalMask;
                 fSmooth = std::async(std::launch::async, [&, smoothT0, capSC0, capSN0, devTiles]() -> std::string {
-                    const std::string e = h->stl.buildBoundaries(h->topo, d->points, mortonTiles, smoothT0, capSC0, capSN0, (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr);
+                    const std::string e = h->stl.buildBoundaries(h->topo, d->points, mortonTiles, smoothT0, capSC0, capSN0, (mortonTiles && !pointOrder.empty()) ? &pointOrder : nullptr, nullptr,
+                                                                  envInt("SMGPU_SMOOTH_CAPTOTAL", defaultSmoothCapTotal(smoothT0)));
                     if (!e.empty()) return e;
                     if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);
                     if (devTopo.valid) {
@@ -549,7 +569,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             const DeviceTopologyArrays* dt = &devTopo;
             fEdge = std::async(std::launch::async, [h, d, po, wantFilter, mortonTiles, devTilesE, devLists, dt]() -> std::string {
                 if (!wantFilter) return std::string("not built");
-                const std::string e = h->etl.buildBoundaries(h->topo, d->points, mortonTiles, 256, 512, 768, 512, po);
+                const std::string e = h->etl.buildBoundaries(h->topo, d->points, mortonTiles, 256, envInt("SMGPU_EDGE_CAPP", 512), envInt("SMGPU_EDGE_CAPF", 768), envInt("SMGPU_EDGE_CAPC", 512), po,
+                                                                  envInt("SMGPU_EDGE_CAPTOTAL", defaultEdgeCapTotal()));
                 if (!e.empty()) return e;
                 if (devLists && !devTilesE) return std::string(kHostTablesPending);
                 if (devTilesE) {
@@ -852,7 +873,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                         rc |= devUpload(h, &ev.meta, meta);
                     }
                     ev.maxPoints = h->etl.maxPoints; ev.maxFaces = h->etl.maxFaces; ev.maxCells = h->etl.maxCells;
-                    h->edgeLds = sizeof(double) * 3 * ((size_t)ev.maxPoints + ev.maxFaces + ev.maxCells);
+                    h->edgeLds = sizeof(double) * 3 * maxTileTotal(h->etl.nTiles, {&h->etl.tpOff, &h->etl.tfOff, &h->etl.tcOff});
                     h->edgeTilesOk = h->edgeLds <= 64 * 1024;
                     if (envInt("SMGPU_VERBOSE", 0))
                         std::fprintf(stderr, "[smgpu] edge tiles: n=%d LDS=%zu B (maxP %d maxF %d maxC %d)\n", h->etl.nTiles, h->edgeLds, ev.maxPoints, ev.maxFaces, ev.maxCells);
@@ -867,7 +888,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
             }
             if (rc) return cleanup(1);
             h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + (size_t)(SMGPU_GEOM_AOS ? kGF : 6) * (size_t)g.maxFaces);
-            h->smoothLds = sizeof(double) * 3 * ((size_t)v.maxCells + (size_t)v.maxPoints);
+            h->smoothLds = sizeof(double) * 3 * maxTileTotal(h->stl.nTiles, {&h->stl.tcOff, &h->stl.tnOff});
             if (envInt("SMGPU_VERBOSE", 0))
                 std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d; staged faces x%.3f, points x%.3f of the mesh's)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",
                              h->geomT, h->gt.nTiles, h->geomLds, g.maxPoints, g.maxFaces, (double)h->gt.tfOff.back() / std::max(1, t.nFaces),
@@ -2056,7 +2077,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             for (int pi = 0; pi < P; ++pi) if (posSlot[(size_t)pi] >= 0) sub.push_back(h->stl.order[(size_t)pi]);
             std::vector<double> pts(3 * (size_t)P);      // (the builder only reads coordinates when it orders the points itself)
             const int capSC = envInt("SMGPU_SMOOTH_CAPC", std::min(2 * h->smoothT, 1500)), capSN = envInt("SMGPU_SMOOTH_CAPN", std::min(3 * h->smoothT, 1500));
-            std::string err = h->shr.buildBoundaries(h->topo, pts.data(), false, h->smoothT, capSC, capSN, nullptr, &sub);
+            std::string err = h->shr.buildBoundaries(h->topo, pts.data(), false, h->smoothT, capSC, capSN, nullptr, &sub, envInt("SMGPU_SMOOTH_CAPTOTAL", defaultSmoothCapTotal(h->smoothT)));
             if (!err.empty()) return fail("shared-point tiles: " + err);
             // the tables on the device where the addressing lives there (tiles_dev.hip; the corner lists they read stayed there),
             // else on the host -- which first fetches those lists
@@ -2087,7 +2108,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
                 if (uploadSmoothView(h, h->shr, h->hv, h->sv.usePairShare)) return 1;
             }
             if (envInt("SMGPU_VERBOSE", 0) >= 2) std::fprintf(stderr, "[smgpu] shared-point tiles: %d tiles, tables on the %s\n", h->shr.nTiles, onDev == 0 ? "device" : "host");
-            h->haloLds = sizeof(double) * 3 * ((size_t)h->shr.maxCells + (size_t)h->shr.maxPoints);
+            h->haloLds = sizeof(double) * 3 * maxTileTotal(h->shr.nTiles, {&h->shr.tcOff, &h->shr.tnOff});
             // per position of those tiles: slot, two-sharer peer code (k_halo_combineA2's table), send slots
             const size_t nS = sub.size();
             std::vector<int> spSlot(nS), spPeer(nS, -1), spDst0(nS, -1), spNDst(nS, 0);

@@ -362,13 +362,13 @@ void chainCorners(std::vector<std::pair<int32_t, int32_t>>& corners, ChainScratc
 }  // namespace
 
 std::string SmoothTiles::build(const Topology& t, const double* xyz, const uint8_t* isInternal, bool morton, int32_t nThreads,
-                               int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset) {
-    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capCells, capPoints, pointOrder, subset);
+                               int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset, int32_t capTotal) {
+    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capCells, capPoints, pointOrder, subset, capTotal);
     return e.empty() ? buildTables(t, isInternal, subset != nullptr) : e;
 }
 
 std::string SmoothTiles::buildBoundaries(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capCells,
-                                         int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset) {
+                                         int32_t capPoints, const std::vector<int32_t>* pointOrder, const std::vector<int32_t>* subset, int32_t capTotal) {
     threads = nThreads;
     PhaseTimer tm(subset ? "shared-point" : "smoothing");
     if (subset) order = *subset;
@@ -398,7 +398,7 @@ std::string SmoothTiles::buildBoundaries(const Topology& t, const double* xyz, b
                     if (stampN[p] != tile) { stampN[p] = tile; ++addN; }
                     for (int32_t k = pe.off[p]; k < pe.off[p + 1]; ++k)
                         if (stampN[t.pointPoints[k]] != tile) { stampN[t.pointPoints[k]] = tile; ++addN; }
-                    if (nT > 0 && (nT + 1 > capTile || nC + addC > capCells || nN + addN > capPoints)) {
+                    if (nT > 0 && (nT + 1 > capTile || nC + addC > capCells || nN + addN > capPoints || nC + addC + nN + addN > capTotal)) {
                         beg.push_back(pi);
                         ++tile; nC = nN = nT = 0;
                         continue;
@@ -554,13 +554,13 @@ std::string SmoothTiles::buildTables(const Topology& t, const uint8_t* isInterna
 }
 
 std::string EdgeTiles::build(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
-                             int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder) {
-    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capPoints, capFaces, capCells, pointOrder);
+                             int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder, int32_t capTotal) {
+    const std::string e = buildBoundaries(t, xyz, morton, nThreads, capPoints, capFaces, capCells, pointOrder, capTotal);
     return e.empty() ? buildTables(t) : e;
 }
 
 std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, bool morton, int32_t nThreads, int32_t capPoints,
-                                       int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder) {
+                                       int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder, int32_t capTotal) {
     threads = nThreads;
     PhaseTimer tm("edge");
     const int32_t nE = t.nEdges;
@@ -601,7 +601,7 @@ std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, boo
                 for (int k = 0; k < 2; ++k) { const int32_t p = t.edges[2 * e + k]; if (stP[p] != tile) { stP[p] = tile; ++aP; } }
                 for (int32_t k = ef.off[e]; k < ef.off[e + 1]; ++k) { const int32_t f = ef.val[k]; if (stF[f] != tile) { stF[f] = tile; ++aF; } }
                 for (int32_t k = ec.off[e]; k < ec.off[e + 1]; ++k) { const int32_t cI = ec.val[k]; if (stC[cI] != tile) { stC[cI] = tile; ++aC; } }
-                if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells)) {
+                if (nT > 0 && (nT + 1 > threads || nP + aP > capPoints || nF + aF > capFaces || nC + aC > capCells || nP + aP + nF + aF + nC + aC > capTotal)) {
                     beg.push_back(ei);
                     ++tile; nP = nF = nC = nT = 0;
                     continue;

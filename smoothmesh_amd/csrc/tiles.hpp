@@ -98,12 +98,13 @@ struct SmoothTiles {
     // pointOrder (optional): mortonOrderOf(nPoints, points), computed by the caller (it also serves the edge tiles)
     // subset (optional): tiles over THESE points only, in the given order (multi-rank: the shared points get tiles of their own,
     // smgpu_halo_configure) -- `order`, `selfLoc` and the ELL rows then have subset->size() positions
+    // capTotal: cells + points a tile may stage together (what its LDS footprint is made of; the kernels' occupancy is set by it)
     std::string build(const Topology& t, const double* points, const uint8_t* isInternal, bool morton, int32_t threads,
                       int32_t capCells, int32_t capPoints, const std::vector<int32_t>* pointOrder = nullptr,
-                      const std::vector<int32_t>* subset = nullptr);
+                      const std::vector<int32_t>* subset = nullptr, int32_t capTotal = 0x7fffffff);
     // the two halves of build(), as GeomTiles'
     std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells, int32_t capPoints,
-                                const std::vector<int32_t>* pointOrder = nullptr, const std::vector<int32_t>* subset = nullptr);
+                                const std::vector<int32_t>* pointOrder = nullptr, const std::vector<int32_t>* subset = nullptr, int32_t capTotal = 0x7fffffff);
     std::string buildTables(const Topology& t, const uint8_t* isInternal, bool subset = false);
 };
 struct SmoothTilesDev {
@@ -135,10 +136,10 @@ struct EdgeTiles {
     // pointOrder (optional, with morton): the edges follow the Z-curve of their START points (edges are stored grouped by start
     // point) instead of a sort of their own over the 3x as many edge midpoints -- a tile is still a compact cluster of edges
     std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
-                      int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr);
+                      int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr, int32_t capTotal = 0x7fffffff);
     // the two halves of build(), as GeomTiles'
     std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capPoints,
-                                int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr);
+                                int32_t capFaces, int32_t capCells, const std::vector<int32_t>* pointOrder = nullptr, int32_t capTotal = 0x7fffffff);
     std::string buildTables(const Topology& t);
 };
 struct EdgeTilesDev {
