@@ -5,6 +5,27 @@
 #pragma once
 #include "kernels.hpp"
 
+// -DSMGPU_STAGGER=<n> (experiment): the workgroups of a launch's FIRST round start n x 64 cycles apart per wave slot, so that the
+// workgroups sharing a CU are not all staging (or all computing) at the same time
+#ifndef SMGPU_STAGGER
+#define SMGPU_STAGGER 0
+#endif
+__device__ __forceinline__ void staggerFirstRound(int bid, int resident) {
+#if SMGPU_STAGGER
+    if (bid < resident) {
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 15u;      // HW_REG_HW_ID.wave_id
+        for (unsigned k = 0; k < slot; ++k) __builtin_amdgcn_s_sleep(SMGPU_STAGGER);
+    }
+#else
+    (void)bid; (void)resident;
+#endif
+}
+// -DSMGPU_ABLATE=<bits>: timing experiments on smoothPoint (WRONG results; never in the product build) -- 1: no square root per
+// neighbour, 2: every LDS gather reads record 0 (no bank conflicts), 4: no freeze loop, 8: no cell loop, 16: nothing after the staging;
+// k_geom_tile -- 32: nothing after the staging, 64: no cell phase
+#ifndef SMGPU_ABLATE
+#define SMGPU_ABLATE 0
+#endif
 namespace smgpu {
 
 constexpr unsigned kPad = 0xFFFFu;
@@ -230,8 +251,11 @@ __device__ __forceinline__ V3 ldsg(const double* x, const double* y, const doubl
 }
 // (a face record is padded to an odd number of doubles: with 6 the records of consecutive faces -- what a wave writes in the
 // face phase -- fall on 8 of the 16 bank pairs, a two-way conflict on every access; SMGPU_GEOM_FACE_STRIDE=6 restores that)
+// Round 5: back to 6.  With five workgroups per CU (SMGPU_GEOM_WAVES) the LDS footprint decides whether a 128-cell tile fits the
+// 31.8 KB line as it is (6: 27.7 KB) or has to be cut earlier (7: 6 % more tiles); same box, alternating three times, 5 workgroups
+// both ways: 49.6 -> 47.9 us on 100^3, 538 -> 527 us on the 10 M-cell polyhedral mesh.
 #ifndef SMGPU_GEOM_FACE_STRIDE
-#define SMGPU_GEOM_FACE_STRIDE 7
+#define SMGPU_GEOM_FACE_STRIDE 6
 #endif
 constexpr int kGF = SMGPU_GEOM_AOS ? SMGPU_GEOM_FACE_STRIDE : 1;   // index stride of a face in fcx .. faz
 struct GeomLds {
@@ -239,17 +263,19 @@ struct GeomLds {
     double *fcx, *fcy, *fcz;     // face centres
     double *fax, *fay, *faz;     // face area vectors
 };
-__device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileView& g) {
+// (laid out by the TILE's own counts, as smoothLds: the launch's LDS is the largest 3 nPts + kGF nFaces doubles of one tile, which
+// GeomTiles::buildBoundaries caps -- capWeighted -- so that FIVE workgroups share a CU)
+__device__ __forceinline__ GeomLds geomLds(double* lds, const GeomTileMeta& tm) {
     GeomLds L;
     if (SMGPU_GEOM_AOS) {
         L.px = lds;                      L.py = L.px + 1;  L.pz = L.px + 2;
-        L.fcx = L.px + 3 * g.maxPoints;  L.fcy = L.fcx + 1; L.fcz = L.fcx + 2;
+        L.fcx = L.px + 3 * tm.nPts;      L.fcy = L.fcx + 1; L.fcz = L.fcx + 2;
         L.fax = L.fcx + 3;               L.fay = L.fcx + 4; L.faz = L.fcx + 5;
         return L;
     }
-    L.px = lds;                  L.py = L.px + g.maxPoints;  L.pz = L.py + g.maxPoints;
-    L.fcx = L.pz + g.maxPoints;  L.fcy = L.fcx + g.maxFaces; L.fcz = L.fcy + g.maxFaces;
-    L.fax = L.fcz + g.maxFaces;  L.fay = L.fax + g.maxFaces; L.faz = L.fay + g.maxFaces;
+    L.px = lds;                  L.py = L.px + tm.nPts;    L.pz = L.py + tm.nPts;
+    L.fcx = L.pz + tm.nPts;      L.fcy = L.fcx + tm.nFaces; L.fcz = L.fcy + tm.nFaces;
+    L.fax = L.fcz + tm.nFaces;   L.fay = L.fax + tm.nFaces; L.faz = L.fay + tm.nFaces;
     return L;
 }
 
@@ -458,8 +484,10 @@ __device__ __forceinline__ void geomCell(const State& s, const GeomTileView& g, 
 // deferN > 0: the first workgroup also closes the PREVIOUS iteration (reduction of its deferN workgroup partials into
 // stats[deferIter], reset of the per-iteration counters) -- with relTol <= 0 nothing can stop the loop, so that work does
 // not need a launch of its own between the iterations (k_finish, ~6 us of launch latency per iteration).
+// (waves per SIMD the geometry kernels are compiled for.  Round 5: 5 -- 96 VGPRs instead of 118, no spills -- together with an LDS
+// footprint of at most 31.8 KB per tile: same box, 555 -> 538 us on the 10 M-cell polyhedral mesh, nothing on the 1 M-cell block)
 #ifndef SMGPU_GEOM_WAVES
-#define SMGPU_GEOM_WAVES 4
+#define SMGPU_GEOM_WAVES 5
 #endif
 // ---- the workgroup's work ---------------------------------------------------------------------------------------------------
 // round 1 of the prologue for one tile: the point id list (first two rounds of T)
@@ -525,12 +553,13 @@ __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, 
     const int stopped = s.acc->stop;
     const int li = launchTile(nLaunch, xcdMap, bid);
     if (li < 0) return;
+    staggerFirstRound(bid, 256 * 4);
     if (deferN > 0 && bid == 0) { if (stopped) return; finishPartials<T>(s, deferN, deferIter, -1.0, deferLocal, deferHist); __syncthreads(); }
     extern __shared__ double lds[];
     const int tid = threadIdx.x;
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li;
     const GeomTileMeta tm = loadTileMeta(g, tile);
-    const GeomLds L = geomLds(lds, g);
+    const GeomLds L = geomLds(lds, tm);
     int id[2];
     geomLoadIds<T>(g, tm, tid, id);                               // round 1 (the id list first: the point records depend on it)
     const GeomRows r = geomLoadRows<T, ORG>(g, tm, tid);
@@ -539,8 +568,10 @@ __device__ __forceinline__ void geomTileBody(const MeshView& m, const State& s, 
     geomStorePoints<T>(s, g, tm, L, id, v, tid);
     if (stopped) return;
     __syncthreads();
+    if (SMGPU_ABLATE & 32) { if (tid < tm.nCells) stv(s.cellCtr, ((const_int_ptr)g.cellOrder)[tm.cellBeg + tid], v3(L.px[tid], 0.0, 0.0)); return; }   // (timing experiment: staging only)
     geomFaces<T, ORG>(s, g, L, tm, r, tid, wantAvg, writeFaces);  // phase 1: every face of the tile once
     __syncthreads();
+    if (SMGPU_ABLATE & 64) return;                                // (timing experiment: no cell phase)
     geomCell<T, ORG>(s, g, L, tm, tid, (unsigned)tm.flags, r.cin, coh);   // phase 2: one thread per cell
 }
 template <int T, bool ORG>
@@ -572,11 +603,6 @@ __device__ __forceinline__ SmoothLds smoothLds(double* lds, const SmoothTileMeta
 // as selects: b1, b2, b3 are the chain's three branches, so the result is the chain's for every input (NaN lengths included).
 // The nested branches cost ~33 register moves per neighbour (the compiler rotates the nine values at every join, and in a wave
 // of 64 lanes every level is taken by someone); the selects are 15.
-// -DSMGPU_ABLATE=<bits>: timing experiments on smoothPoint (WRONG results; never in the product build) -- 1: no square root per
-// neighbour, 2: every LDS gather reads record 0 (no bank conflicts), 4: no freeze loop, 8: no cell loop, 16: nothing after the staging
-#ifndef SMGPU_ABLATE
-#define SMGPU_ABLATE 0
-#endif
 struct Top3 {
     double l1 = 0, l2 = 0, l3 = 0;
     unsigned w1 = 0xFFFFFFFFu, w2 = 0xFFFFFFFFu, w3 = 0xFFFFFFFFu;
@@ -851,6 +877,7 @@ __global__ void __launch_bounds__(T) k_smooth_tile(MeshView m, State s, Prm prm,
     const int stopped = s.acc->stop;   // tested after the staging, see k_geom_tile
     const int li = launchTile(nLaunch, xcdMap);
     if (li < 0) return;
+    staggerFirstRound((int)blockIdx.x, 256 * 6);
     extern __shared__ double lds[];
     const int tile = tileList ? ((const_int_ptr)tileList)[li] : li, tid = threadIdx.x;
     const SmoothTileMeta tm = loadTileMeta(g, tile);

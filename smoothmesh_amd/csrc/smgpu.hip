@@ -433,6 +433,10 @@ static size_t maxTileTotal(int nTiles, std::initializer_list<const std::vector<i
     }
     return mx;
 }
+// Geometry tiles: 3 x points + 7 x faces doubles; 3 980 = 31 840 B -- five workgroups per CU (32 256 B each with the kernel's 48
+// static bytes at the 512-byte granularity), which the kernel's 96 VGPRs (SMGPU_GEOM_WAVES = 5) allow.  A hexahedral tile of 128
+// cells (~250 points, ~450 faces = 3 900) fits as it is; the polyhedral ones are cut a little earlier.
+static int defaultGeomCapWeighted(int T) { return (T == 256 && SMGPU_GEOM_WAVES >= 5) ? 3980 : 0x7fffffff; }
 static int defaultSmoothCapTotal(int T) { return T == 256 ? 1112 : 0x7fffffff; }
 static int defaultEdgeCapTotal() { return 852; }
 
@@ -522,7 +526,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                           if (startCornerChains(devTopo, d->nPoints, h->device, chains, why) == 2) chains = CornerChains();
                       }
                       if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
-                      const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0);
+                      const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0,
+                                                                  envInt("SMGPU_GEOM_CAPWEIGHTED", defaultGeomCapWeighted(geomT0)), SMGPU_GEOM_AOS ? kGF : 6);
                       if (!e.empty()) return e;
                       if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);      // (the host's lists are still arriving)
                       if (devTopo.valid) {
@@ -887,7 +892,13 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 }
             }
             if (rc) return cleanup(1);
-            h->geomLds = sizeof(double) * (3 * (size_t)g.maxPoints + (size_t)(SMGPU_GEOM_AOS ? kGF : 6) * (size_t)g.maxFaces);
+            {   // the largest footprint of one tile (geomLds lays the arrays out by the tile's own counts)
+                size_t mx = 0;
+                for (int ti = 0; ti < h->gt.nTiles; ++ti)
+                    mx = std::max(mx, 3 * (size_t)(h->gt.tpOff[(size_t)ti + 1] - h->gt.tpOff[(size_t)ti]) +
+                                          (size_t)(SMGPU_GEOM_AOS ? kGF : 6) * (size_t)(h->gt.tfOff[(size_t)ti + 1] - h->gt.tfOff[(size_t)ti]));
+                h->geomLds = sizeof(double) * mx;
+            }
             h->smoothLds = sizeof(double) * 3 * maxTileTotal(h->stl.nTiles, {&h->stl.tcOff, &h->stl.tnOff});
             if (envInt("SMGPU_VERBOSE", 0))
                 std::fprintf(stderr, "[smgpu] tiles: geom T=%d n=%d LDS=%zu B (maxP %d maxF %d; staged faces x%.3f, points x%.3f of the mesh's)  smooth T=%d n=%d LDS=%zu B (maxC %d maxN %d)\n",

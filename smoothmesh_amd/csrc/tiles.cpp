@@ -95,8 +95,8 @@ static std::vector<int32_t> naturalOrder(int32_t n) {
 }
 
 std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
-                             int32_t capPoints, int32_t capFaces) {
-    const std::string e = buildBoundaries(t, pts, morton, nThreads, capCells, capPoints, capFaces);
+                             int32_t capPoints, int32_t capFaces, int32_t capWeighted, int32_t faceWeight) {
+    const std::string e = buildBoundaries(t, pts, morton, nThreads, capCells, capPoints, capFaces, capWeighted, faceWeight);
     return e.empty() ? buildTables(t) : e;
 }
 
@@ -108,7 +108,7 @@ static unsigned tileSegments() {
 }
 
 std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
-                                       int32_t capPoints, int32_t capFaces) {
+                                       int32_t capPoints, int32_t capFaces, int32_t capWeighted, int32_t faceWeight) {
     threads = nThreads;
     PhaseTimer tm("geometry");
     if (capCells > threads) capCells = threads;
@@ -154,7 +154,8 @@ std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, boo
                         for (int32_t j = fp.off[f]; j < fp.off[f + 1]; ++j)
                             if (stampP[fp.val[j]] != tile) { stampP[fp.val[j]] = tile; ++addP; }
                     }
-                    if (nC > 0 && (nC + 1 > capCells || nP + addP > capPoints || nF + addF > capFaces)) {
+                    if (nC > 0 && (nC + 1 > capCells || nP + addP > capPoints || nF + addF > capFaces ||
+                                   3 * (int64_t)(nP + addP) + (int64_t)faceWeight * (nF + addF) > capWeighted)) {
                         beg.push_back(ci);  // close the tile before this cell and re-add the cell to a fresh one
                         ++tile; nP = nF = nC = 0;
                         continue;

@@ -49,12 +49,13 @@ struct GeomTiles {
     // that a run of consecutive positions is a compact 3-D brick (fewer faces / points shared with other
     // tiles => less duplicated face work, smaller LDS footprint).  Results do not depend on it.
     std::vector<int32_t> order;
+    // capWeighted: 3 x points + faceWeight x faces a tile may stage (its LDS footprint in doubles)
     std::string build(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
-                      int32_t capPoints, int32_t capFaces);
+                      int32_t capPoints, int32_t capFaces, int32_t capWeighted = 0x7fffffff, int32_t faceWeight = 7);
     // the two halves of build(): tile order + greedy boundaries (host), and the per-tile tables -- which tiles_dev.hip builds on
     // the device from the boundaries where it can (buildGeomTablesOnDevice)
     std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
-                                int32_t capPoints, int32_t capFaces);
+                                int32_t capPoints, int32_t capFaces, int32_t capWeighted = 0x7fffffff, int32_t faceWeight = 7);
     std::string buildTables(const Topology& t);
 };
 // the tables of a device build (tiles_dev.hip) that the kernels read where they were built; the caller owns the arrays
