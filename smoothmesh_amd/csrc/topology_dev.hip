@@ -329,6 +329,17 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     const int64_t nnz = faceOffsets[nF];
     if (nnz >= ((int64_t)1 << 30) || nnz < 3) return 1;      // (2 * nnz keys must index with int32)
     TD_OK(hipSetDevice(device));
+    // Host pages are touched ahead of the copies that fill them: the copies of the caller's lists and the sizing of the lists to be
+    // downloaded (first touch of 2 GB of fresh pages for 10 M cells) run on threads of their own beside the uploads, the kernels
+    // and the earlier stages of the download -- they were 0.2 s of the download's critical path.  (Joined before any return.)
+    struct Background {
+        std::vector<std::thread> th;
+        void join() { for (auto& x : th) if (x.joinable()) x.join(); th.clear(); }
+        ~Background() { join(); }
+    } bg;
+    bg.th.emplace_back([&t, faceOffsets, own, nei, nF, nIF] { t.facePoints.off.assign(faceOffsets, faceOffsets + nF + 1); t.owner.assign(own, own + nF); t.neighbour.assign(nei, nei + nIF); });
+    bg.th.emplace_back([&t, facePts, nnz] { t.facePoints.val.assign(facePts, facePts + nnz); });
+    bg.th.emplace_back([&t, nC, nF, nIF] { t.cellFacesGeom.off.resize((size_t)nC + 1); t.cellFacesGeom.val.resize((size_t)nF + (size_t)nIF); });
     hipStream_t st = nullptr;
     DevBuf D;
     Flags* fl = D.get<Flags>(1, why);
@@ -415,6 +426,13 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     TD_OK(hipStreamSynchronize(st));
     int* edges = D.get<int>(2 * (size_t)nE, why);
     if (!edges) return 2;
+    {   // the sizes of the edge and point lists are known from here on
+        const size_t e2 = 2 * (size_t)nE, ne1 = (size_t)nE + 1, np1 = (size_t)nP + 1, npc = (size_t)nPC, nz = (size_t)nnz;
+        bg.th.emplace_back([&t, e2, ne1] { t.edges.resize(e2); t.edgeFaces.off.resize(ne1); t.edgeCells.off.resize(ne1); });
+        bg.th.emplace_back([&t, nz] { t.edgeFaces.val.resize(nz); });
+        bg.th.emplace_back([&t, e2, np1] { t.pointPoints.resize(e2); t.pointEdges.off.resize(np1); t.pointCells.off.resize(np1); });
+        bg.th.emplace_back([&t, npc] { t.pointCells.val.resize(npc); });
+    }
     hipLaunchKernelGGL(k_td_edgeScatter, dim3(gridOf(nnz)), dim3(kTB), 0, st, nnz, kB, vB, rank, edges, faceEdge);
     D.drop(rank);
     lap("edges");
@@ -455,6 +473,7 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     TD_OK(hipMemcpyAsync(&hf, fl, sizeof(Flags), hipMemcpyDeviceToHost, st));
     TD_OK(hipStreamSynchronize(st));
     if (hf.bad || hf.maxEdgeFaces > kMaxEdgeFaces || hf.maxPointPoints > 255) return 1;      // (the host build handles it, or words the error)
+    { const size_t n = (size_t)nEC; bg.th.emplace_back([&t, n] { t.edgeCells.val.resize(n); }); }
     int* ecCell = D.get<int>((size_t)nEC, why);
     uint8_t *ecF0 = D.get<uint8_t>((size_t)nEC, why), *ecF1 = D.get<uint8_t>((size_t)nEC, why);
     int *ringFace = D.get<int>((size_t)nnz, why), *ringCell = D.get<int>((size_t)nEC, why);
@@ -493,10 +512,9 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
         give(keep->owner, dOwn, (size_t)nF * 4); give(keep->neighbour, dNei, (size_t)std::max(nIF, 1) * 4);
         keep->valid = true;
     }
-    t.facePoints.off.assign(faceOffsets, faceOffsets + nF + 1);
-    t.facePoints.val.assign(facePts, facePts + nnz);
-    t.owner.assign(own, own + nF);
-    t.neighbour.assign(nei, nei + nIF);
+    // (t.facePoints / owner / neighbour: copied by the background threads; the first three of them are waited for here, the
+    // sizing of the later stages' lists goes on beside this stage's copy)
+    for (size_t i = 0; i < 3 && i < bg.th.size(); ++i) if (bg.th[i].joinable()) bg.th[i].join();
     want(t.cellFacesGeom.off, cfOff, (size_t)nC + 1); want(t.cellFacesGeom.val, cfVal, (size_t)nCF);
     flush();
     if (copyFailed) { why = "device -> host copy of the addressing failed"; return 2; }
@@ -504,6 +522,7 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     if (afterCells) afterCells();
     // (the order of the stages: what the three tile-boundary passes read first -- the longest of them, the edge pass, early --
     // then the lists only the halo / layer set-up and the getters read)
+    bg.join();
     want(t.edges, edges, 2 * (size_t)nE);
     want(t.edgeFaces.off, efOff, (size_t)nE + 1); want(t.edgeFaces.val, efFace, (size_t)nnz);
     want(t.edgeCells.off, ecOff, (size_t)nE + 1); want(t.edgeCells.val, ecCell, (size_t)nEC);
