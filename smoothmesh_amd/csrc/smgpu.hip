@@ -526,8 +526,14 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                           if (startCornerChains(devTopo, d->nPoints, h->device, chains, why) == 2) chains = CornerChains();
                       }
                       if (wantTiles && geomOk) fGeom = std::async(std::launch::async, [&, geomT0, geomCells0, capGP0, capGF0, devTiles]() -> std::string {
+                      std::vector<int32_t> cellOrder;      // (a device build: the Z-curve of the cells there too -- the order the host would find)
+                      if (mortonTiles && devTiles && devTopo.valid && envInt("SMGPU_DEVICE_TILES", 1) == 1) {
+                          std::string why;
+                          if (cellMortonOrderOnDevice(devTopo, d->nCells, d->nPoints, d->points, h->device, cellOrder, why) != 0) cellOrder.clear();
+                      }
                       const std::string e = h->gt.buildBoundaries(h->topo, d->points, mortonTiles, geomT0, geomCells0, capGP0, capGF0,
-                                                                  envInt("SMGPU_GEOM_CAPWEIGHTED", defaultGeomCapWeighted(geomT0)), SMGPU_GEOM_AOS ? kGF : 6);
+                                                                  envInt("SMGPU_GEOM_CAPWEIGHTED", defaultGeomCapWeighted(geomT0)), SMGPU_GEOM_AOS ? kGF : 6,
+                                                                  cellOrder.empty() ? nullptr : &cellOrder);
                       if (!e.empty()) return e;
                       if (devTopo.valid && !devTiles) return std::string(kHostTablesPending);      // (the host's lists are still arriving)
                       if (devTopo.valid) {

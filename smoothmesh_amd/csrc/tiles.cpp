@@ -108,13 +108,14 @@ static unsigned tileSegments() {
 }
 
 std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
-                                       int32_t capPoints, int32_t capFaces, int32_t capWeighted, int32_t faceWeight) {
+                                       int32_t capPoints, int32_t capFaces, int32_t capWeighted, int32_t faceWeight, const std::vector<int32_t>* cellOrder) {
     threads = nThreads;
     PhaseTimer tm("geometry");
     if (capCells > threads) capCells = threads;
     const auto& cf = t.cellFacesGeom;
     const auto& fp = t.facePoints;
-    if (morton) {
+    if (morton && cellOrder && (int64_t)cellOrder->size() == t.nCells) order = *cellOrder;
+    else if (morton) {
         std::vector<double> cc(3 * (size_t)t.nCells, 0.0);
         parallelRanges(t.nCells, rangeParts(t.nCells), [&](int, int64_t cb0, int64_t ce0) {
             for (int32_t c = (int32_t)cb0; c < (int32_t)ce0; ++c) {

@@ -54,8 +54,10 @@ struct GeomTiles {
                       int32_t capPoints, int32_t capFaces, int32_t capWeighted = 0x7fffffff, int32_t faceWeight = 7);
     // the two halves of build(): tile order + greedy boundaries (host), and the per-tile tables -- which tiles_dev.hip builds on
     // the device from the boundaries where it can (buildGeomTablesOnDevice)
+    // cellOrder (optional): the cells' Morton order computed elsewhere (tiles_dev.hip: cellMortonOrderOnDevice, the same order)
     std::string buildBoundaries(const Topology& t, const double* points, bool morton, int32_t threads, int32_t capCells,
-                                int32_t capPoints, int32_t capFaces, int32_t capWeighted = 0x7fffffff, int32_t faceWeight = 7);
+                                int32_t capPoints, int32_t capFaces, int32_t capWeighted = 0x7fffffff, int32_t faceWeight = 7,
+                                const std::vector<int32_t>* cellOrder = nullptr);
     std::string buildTables(const Topology& t);
 };
 // the tables of a device build (tiles_dev.hip) that the kernels read where they were built; the caller owns the arrays
@@ -67,6 +69,7 @@ struct GeomTilesDev {
 struct DeviceTopologyArrays;
 // 0: built (gt holds the offsets / widths / flags / tfIds / maxima the host reads, `out` the device arrays); 1: not handled there
 // (the caller runs gt.buildTables); 2: a HIP error (why)
+int cellMortonOrderOnDevice(const DeviceTopologyArrays& td, int32_t nCells, int32_t nPoints, const double* points, int device, std::vector<int32_t>& order, std::string& why);
 int buildGeomTablesOnDevice(GeomTiles& gt, const DeviceTopologyArrays& td, int32_t nCells, int device, GeomTilesDev& out, std::string& why);
 
 // ---- smoothing: tile = consecutive points; LDS holds the cell centres and neighbour points -------

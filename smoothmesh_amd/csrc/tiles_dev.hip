@@ -10,6 +10,7 @@
 
 #include <cstring>
 
+#include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 #include <algorithm>
@@ -402,6 +403,57 @@ __global__ void __launch_bounds__(kT) k_tl_smoothTerms(int nTiles, SmoothSizes s
     a[ti] = sz.nCl[ti]; b[ti] = sz.nPt[ti]; c[ti] = (long long)sz.wc[ti] * kT; d[ti] = (long long)sz.wn[ti] * kT; e[ti] = (long long)sz.wf[ti] * kT;
 }
 
+// ---- the cells along the Z-curve (GeomTiles' order) ------------------------------------------------------------------------------
+// tiles.cpp's mortonOrder on the cells' vertex averages, operation for operation: the average over the faces' points in
+// cellFacesGeom order, one isotropic scale from the bounding box, 21 bits per axis interleaved, ties in id order (a stable sort of
+// ids that start ascending).  0.28 s of the geometry tiles' chain on the host for 10 M cells, ~10 ms here.
+__global__ void __launch_bounds__(kT) k_tl_cellAvg(int nCells, const int* __restrict__ cfOff, const int* __restrict__ cfVal, const int* __restrict__ faceOff,
+                                                   const int* __restrict__ facePts, const double* __restrict__ pts, double* __restrict__ cc, double* __restrict__ part) {
+    __shared__ double sh[6][kT / 64];
+    const int c = blockIdx.x * kT + threadIdx.x;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    if (c < nCells) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        int n = 0;
+        for (int k = cfOff[c]; k < cfOff[c + 1]; ++k) {
+            const int f = cfVal[k] & 0x7fffffff;
+            for (int j = faceOff[f]; j < faceOff[f + 1]; ++j, ++n) {
+                const double* q = pts + 3 * (size_t)facePts[j];
+                s0 += q[0]; s1 += q[1]; s2 += q[2];
+            }
+        }
+        const double v[3] = {n ? s0 / n : 0.0, n ? s1 / n : 0.0, n ? s2 / n : 0.0};
+        for (int a = 0; a < 3; ++a) { cc[3 * (size_t)c + a] = v[a]; lo[a] = v[a]; hi[a] = v[a]; }
+    }
+    for (int a = 0; a < 3; ++a)
+        for (int o = 32; o > 0; o >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o, 64)); }
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { sh[a][threadIdx.x >> 6] = lo[a]; sh[3 + a][threadIdx.x >> 6] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double m = sh[threadIdx.x][0];
+        for (int i = 1; i < kT / 64; ++i) m = threadIdx.x < 3 ? fmin(m, sh[threadIdx.x][i]) : fmax(m, sh[threadIdx.x][i]);
+        part[6 * (size_t)blockIdx.x + threadIdx.x] = m;
+    }
+}
+__device__ __forceinline__ u64 spread21d(u64 v) {
+    v &= 0x1fffff;
+    v = (v | v << 32) & 0x1f00000000ffffull;
+    v = (v | v << 16) & 0x1f0000ff0000ffull;
+    v = (v | v << 8) & 0x100f00f00f00f00full;
+    v = (v | v << 4) & 0x10c30c30c30c30c3ull;
+    v = (v | v << 2) & 0x1249249249249249ull;
+    return v;
+}
+__global__ void __launch_bounds__(kT) k_tl_mortonKeys(int n, const double* __restrict__ xyz, double lo0, double lo1, double lo2, double scale, u64* __restrict__ keys, int* __restrict__ ids) {
+    const int i = blockIdx.x * kT + threadIdx.x;
+    if (i >= n) return;
+    const double lo[3] = {lo0, lo1, lo2};
+    u64 k = 0;
+    for (int a = 0; a < 3; ++a) k |= spread21d((u64)((xyz[3 * (size_t)i + a] - lo[a]) * scale)) << a;
+    keys[i] = k;
+    ids[i] = i;
+}
+
 struct DevBuf {
     std::vector<void*> all;
     ~DevBuf() { for (void* p : all) (void)hipFree(p); }
@@ -681,6 +733,44 @@ int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, i
     give(out.selfLoc, selfLoc, (size_t)nPos * 2); give(out.pcEll, pcEll, (size_t)nPc * 2); give(out.ppEll, ppEll, (size_t)nPp * 2); give(out.pairEll, pairEll, (size_t)nPp * 2);
     give(out.pfEll, pfEll, (size_t)nPfE * 2); give(out.meta, meta, 12 * (size_t)nT * 4);
     out.valid = true;
+    return 0;
+}
+
+// order = the cells sorted along the Z-curve of their vertex averages, as tiles.cpp's mortonOrder gives it.  0 done; 1 not handled;
+// 2 a HIP error
+int cellMortonOrderOnDevice(const DeviceTopologyArrays& td, int32_t nCells, int32_t nPoints, const double* points, int device, std::vector<int32_t>& order, std::string& why) {
+    if (!td.valid || nCells <= 0 || nPoints <= 0) return 1;
+    TL_OK(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    TL_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { (void)hipStreamDestroy(s); } } guard{st};
+    const int nB = (nCells + kT - 1) / kT;
+    DevBuf D;
+    double *dPts = D.get<double>(3 * (size_t)nPoints), *cc = D.get<double>(3 * (size_t)nCells), *part = D.get<double>(6 * (size_t)nB);
+    u64 *kA = D.get<u64>((size_t)nCells), *kB = D.get<u64>((size_t)nCells);
+    int *iA = D.get<int>((size_t)nCells), *iB = D.get<int>((size_t)nCells);
+    if (!dPts || !cc || !part || !kA || !kB || !iA || !iB) { why = "device allocation failed"; return 2; }
+    TL_OK(hipMemcpyAsync(dPts, points, 3 * (size_t)nPoints * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_tl_cellAvg, dim3(nB), dim3(kT), 0, st, nCells, (const int*)td.cfOff.p, (const int*)td.cfVal.p, (const int*)td.faceOff.p, (const int*)td.facePts.p, dPts, cc, part);
+    std::vector<double> hp(6 * (size_t)nB);
+    TL_OK(hipMemcpyAsync(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int b = 0; b < nB; ++b)
+        for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], hp[6 * (size_t)b + a]); hi[a] = std::max(hi[a], hp[6 * (size_t)b + 3 + a]); }
+    double ext = 0.0;
+    for (int a = 0; a < 3; ++a) ext = std::max(ext, hi[a] - lo[a]);
+    const double scale = ext > 0.0 ? 2097151.0 / ext : 0.0;
+    hipLaunchKernelGGL(k_tl_mortonKeys, dim3(nB), dim3(kT), 0, st, nCells, cc, lo[0], lo[1], lo[2], scale, kA, iA);
+    size_t tempBytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tempBytes, kA, kB, iA, iB, (size_t)nCells, 0, 63, st);
+    void* temp = D.get<char>(tempBytes + 256);
+    if (!temp) { why = "device allocation failed"; return 2; }
+    TL_OK(rocprim::radix_sort_pairs(temp, tempBytes, kA, kB, iA, iB, (size_t)nCells, 0, 63, st));
+    order.resize((size_t)nCells);
+    TL_OK(hipMemcpyAsync(order.data(), iB, (size_t)nCells * 4, hipMemcpyDeviceToHost, st));
+    TL_OK(hipStreamSynchronize(st));
+    TL_OK(hipGetLastError());
     return 0;
 }
 
