@@ -571,10 +571,17 @@ std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, boo
         std::vector<int32_t> startOff((size_t)t.nPoints + 1, 0);
         for (int32_t e = 0; e < nE; ++e) ++startOff[(size_t)t.edges[2 * e] + 1];
         for (int32_t p = 0; p < t.nPoints; ++p) startOff[(size_t)p + 1] += startOff[(size_t)p];
-        order.clear();
-        order.reserve((size_t)nE);
-        for (int32_t p : *pointOrder)
-            for (int32_t e = startOff[(size_t)p]; e < startOff[(size_t)p + 1]; ++e) order.push_back(e);
+        // (where every point's block of edges starts in the order: a prefix sum along the Z-curve; the blocks are then written side by side)
+        const std::vector<int32_t>& po = *pointOrder;
+        std::vector<int32_t> outOff(po.size() + 1, 0);
+        for (size_t i = 0; i < po.size(); ++i) outOff[i + 1] = outOff[i] + (startOff[(size_t)po[i] + 1] - startOff[(size_t)po[i]]);
+        order.assign((size_t)nE, 0);
+        parallelRanges((int64_t)po.size(), rangeParts((int64_t)po.size()), [&](int, int64_t b, int64_t e1) {
+            for (int64_t i = b; i < e1; ++i) {
+                int32_t o = outOff[(size_t)i];
+                for (int32_t e = startOff[(size_t)po[(size_t)i]]; e < startOff[(size_t)po[(size_t)i] + 1]; ++e) order[(size_t)o++] = e;
+            }
+        });
     } else if (morton) {
         std::vector<double> mid(3 * (size_t)nE);
         parallelRanges(nE, rangeParts(nE), [&](int, int64_t b, int64_t e1) {
