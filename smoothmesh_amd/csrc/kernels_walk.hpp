@@ -613,7 +613,10 @@ constexpr int kPackBlock = 256;
 // meshes at most 60; a larger star is left to the general kernels).  Measured before the coordinate table below, on the 10 M-cell
 // cavity mesh (profiles/r4/ab_walk_pred_pack.txt): 64 slots and FOUR waves per SIMD 724 us (128 VGPRs, 36 of them spilled), 64
 // slots at three waves 693 (168 VGPRs), 128 slots at three waves 697 -- the kernel is not occupancy bound.
-constexpr int kPackVerts = 96;
+#ifndef SMGPU_PACK_VERTS
+#define SMGPU_PACK_VERTS 96
+#endif
+constexpr int kPackVerts = SMGPU_PACK_VERTS;
 // One coordinate table per half: the vertex slots [0, kPackVerts), behind them the proposals of the point's entries
 // [kPackVerts, + kStarEnts) and the point itself, current (kPackCur) and proposed (kPackProp).  A job moves the point and one
 // entry's neighbour hypothetically: a vertex slot whose role says "the point" / "that neighbour" is then read from the other

@@ -156,7 +156,7 @@ def test_walk_replay_places_agree_on_the_10M_cell_mesh(monkeypatch, cavity215):
 
 BIG = pytest.mark.skipif(not __import__("os").environ.get("SMOOTHMESH_BIG_TESTS"),
                          reason="tens of GiB on host and device and minutes of serial oracle: set SMOOTHMESH_BIG_TESTS=1 "
-                                "(last run: profiles/r4/big_mesh_parity.txt)")
+                                "(last run: profiles/r5/big_mesh_parity.txt)")
 
 
 @BIG
