@@ -612,7 +612,9 @@ constexpr int kPackBlock = 256;
 // Vertex slots of a star: 96 (k_walk_pred_star: 128; an interior hex point has 48, the refinement interfaces of the castellated
 // meshes at most 60; a larger star is left to the general kernels).  Measured before the coordinate table below, on the 10 M-cell
 // cavity mesh (profiles/r4/ab_walk_pred_pack.txt): 64 slots and FOUR waves per SIMD 724 us (128 VGPRs, 36 of them spilled), 64
-// slots at three waves 693 (168 VGPRs), 128 slots at three waves 697 -- the kernel is not occupancy bound.
+// slots at three waves 693 (168 VGPRs), 128 slots at three waves 697 -- the kernel is not occupancy bound.  Round 5, with the other
+// kernels' occupancy steps in mind, once more: -DSMGPU_PACK_WAVES=4 -DSMGPU_PACK_VERTS=60 (40.3 KB per block, 128 VGPRs with 41 spilled) 937
+// against 673 us for the launch group: four waves only help if the registers fit, and they do not.
 #ifndef SMGPU_PACK_VERTS
 #define SMGPU_PACK_VERTS 96
 #endif
