@@ -143,29 +143,6 @@ __device__ __forceinline__ void sqrtExact4(double m0, double m1, double m2, doub
         }                                                                 \
     }
 
-// The same walk with the LDS records of a chunk's four entries requested TOGETHER, ahead of the four bodies (pads read record 0 and
-// are skipped as before): one wait per chunk instead of one per entry -- the bodies are separate exec regions, which kept the
-// compiler from hoisting the reads itself.  BODY sees `j`, `e` and `rec` = the record at (e & MASK) of the arrays X, Y, Z.
-#define SMGPU_ELL_CHUNK_LD(C, Q, X, Y, Z, MASK, BODY)                                                                       \
-    {                                                                                                                       \
-        const unsigned e0_ = (Q).x, e1_ = (Q).y, e2_ = (Q).z, e3_ = (Q).w;                                                  \
-        const V3 r0_ = ldsv(X, Y, Z, e0_ != kPad ? (int)(e0_ & (MASK)) : 0), r1_ = ldsv(X, Y, Z, e1_ != kPad ? (int)(e1_ & (MASK)) : 0), \
-                 r2_ = ldsv(X, Y, Z, e2_ != kPad ? (int)(e2_ & (MASK)) : 0), r3_ = ldsv(X, Y, Z, e3_ != kPad ? (int)(e3_ & (MASK)) : 0); \
-        { const int j = 4 * (C) + 0; const unsigned e = e0_; const V3 rec = r0_; if (e != kPad) { BODY } }                   \
-        { const int j = 4 * (C) + 1; const unsigned e = e1_; const V3 rec = r1_; if (e != kPad) { BODY } }                   \
-        { const int j = 4 * (C) + 2; const unsigned e = e2_; const V3 rec = r2_; if (e != kPad) { BODY } }                   \
-        { const int j = 4 * (C) + 3; const unsigned e = e3_; const V3 rec = r3_; if (e != kPad) { BODY } }                   \
-    }
-#define SMGPU_ELL_FOREACH_PRE_LD(Q0, Q1, ROWS, W4, STRIDE, X, Y, Z, MASK, BODY)                                              \
-    {                                                                                                                       \
-        if ((W4) > 0) SMGPU_ELL_CHUNK_LD(0, Q0, X, Y, Z, MASK, BODY)                                                        \
-        if ((W4) > 1) SMGPU_ELL_CHUNK_LD(1, Q1, X, Y, Z, MASK, BODY)                                                        \
-        for (int c_ = 2; c_ < (W4); ++c_) {                                                                                 \
-            const ushort4 q_ = (ROWS)[(size_t)c_ * (STRIDE)];                                                               \
-            SMGPU_ELL_CHUNK_LD(c_, q_, X, Y, Z, MASK, BODY)                                                                 \
-        }                                                                                                                   \
-    }
-
 // Stage n elements (24-byte records picked by an ascending id list) into SoA LDS arrays.  All id loads
 // of a thread are issued first, then all record loads, then the LDS stores: two memory round trips per
 // tile instead of two per 256 elements.
@@ -796,16 +773,16 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
         } else {
             if (internal || prm.bndOn) {   // SM.C:116-130 (boundary points too with doBoundarySmoothing)
                 if (!(SMGPU_ABLATE & 8))
-                SMGPU_ELL_FOREACH_PRE_LD(pc0, pc1, pcRow, wc4, T, cx, cy, cz, 0xffffu, {
-                    sum = sum + rec;
+                SMGPU_ELL_FOREACH_PRE(pc0, pc1, pcRow, wc4, T, {
+                    sum = sum + ldsv(cx, cy, cz, (SMGPU_ABLATE & 2) ? 0 : e);
                     count = j + 1;
                 })
             }
             // SM.C:325-387 (stable top three; boundary points look at boundary neighbours only)
             Top3 t3;
-            SMGPU_ELL_FOREACH_PRE_LD(pp0, pp1, ppRow, wn4, T, nx, ny, nz, 0x7fffu, {
+            SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
                 // getPointDistance(neigh, cCoords) = |cCoords - neigh|; the same value serves SM.C:626
-                const V3 dv_ = cur - rec;
+                const V3 dv_ = cur - ldsv(nx, ny, nz, (SMGPU_ABLATE & 2) ? 0 : (e & 0x7fff));
                 const double len = (SMGPU_ABLATE & 1) ? magSqr(dv_) : mag(dv_);
                 if (len < shortestCur) shortestCur = len;
                 t3.offer(len, j, e, internal || !(e & 0x8000));
@@ -852,9 +829,9 @@ __device__ __forceinline__ void smoothPoint(const MeshView& m, const State& s, c
             // (NaN squares are skipped as NaN lengths were; lengths not below the loop's start value GREAT never won)
             double minSqr = __builtin_inf();
             if (!(SMGPU_ABLATE & 4))
-            SMGPU_ELL_FOREACH_PRE_LD(pp0, pp1, ppRow, wn4, T, nx, ny, nz, 0x7fffu, {
-                (void)j; (void)e;
-                const double t2 = magSqr(np - rec);
+            SMGPU_ELL_FOREACH_PRE(pp0, pp1, ppRow, wn4, T, {
+                (void)j;
+                const double t2 = magSqr(np - ldsv(nx, ny, nz, (SMGPU_ABLATE & 2) ? 0 : (e & 0x7fff)));
                 if (t2 < minSqr) minSqr = t2;
             })
             const double rootMin = sqrtExact(minSqr);
