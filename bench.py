@@ -216,7 +216,7 @@ def kernel_report(workload, ctr, K, dt, dt_ev, sizes=None):
     # committed under profiles/; None when no measurement of this workload exists
     traffic = None
     tdoc = None
-    for rnd in ("r5", "r4", "r3", "r2", "r1"):
+    for rnd in ("r6", "r5", "r4", "r3", "r2", "r1"):
         tpath = os.path.join(ROOT, "profiles", rnd, f"traffic_{workload}.json")
         if os.path.exists(tpath):
             tdoc = json.load(open(tpath))
@@ -723,8 +723,19 @@ def finalize_line(out):
              "parity_ok": None if par is None else bool(par.get("ok", False)),
              "bitwise_equal": None if par is None else par.get("bitwise_equal", (par.get("small_case") or {}).get("bitwise_equal_on_every_rank")),
              "cpu_ratio": e.get("speedup_vs_cpu_baseline")}
+        rf = _roof_brief(e.get("roofline"))
+        if rf:      # the dominant kernel of THIS configuration: name, launch time, HBM fraction, and the ceiling that binds it
+            b.update({"dominant_kernel": rf["kernel"], "avg_launch_us": rf["avg_launch_us"], "roofline_bound": rf["bound"],
+                      "roofline_frac": rf["frac"], "binding": rf["binding"]})
+            if "valu_f64_frac" in rf:
+                b["valu_f64_frac"] = rf["valu_f64_frac"]
+            if rf.get("traffic") is not None and rf.get("algorithmic_bytes_per_launch"):
+                b["traffic_over_algorithmic"] = rf["traffic"] / rf["algorithmic_bytes_per_launch"]
+        g = _gather_brief(e.get("roofline_centroid_gather"))
+        if g and g.get("frac_K_cg") is not None:
+            b["gather_frac_K_cg"] = g["frac_K_cg"]
         if "error" in e:
-            b["error"] = e["error"]
+            b["error"] = e["error"][:200]
         return b
     out.pop("configs_summary", None)
     entries = [(out.get("workload_name", "headline"), out)] + [(c.get("workload", "?"), c) for c in out.get("configs", [])]
@@ -741,10 +752,107 @@ def finalize_line(out):
     return out, out["exit_code"]
 
 
+COMPACT_LIMIT = 4096     # bytes: the driver's reader keeps a bounded tail of stdout; round 5's 20 KB line came back unparsed
+
+
+def _sig(x, n=6):
+    """floats to n significant digits (the compact line is a record, not a checkpoint); everything else as it is"""
+    if isinstance(x, float):
+        return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, n) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, n) for v in x]
+    return x
+
+
+def _roof_brief(r):
+    """the contract's roofline object (bound / achieved / peak / unit / frac / traffic) + which ceiling really binds the kernel:
+    `bound` names the roofline the bytes are priced against (the metric is HBM GB/s); `binding` = the ceiling with the larger
+    fraction (k_geom_tile: the FP64 vector issue rate, valu_f64), with both fractions side by side"""
+    if not r:
+        return None
+    b = {k: r.get(k) for k in ("kernel", "avg_launch_us", "bound", "achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic")}
+    v = r.get("valu_f64")
+    if v:
+        b["valu_f64_frac"] = v["frac"]
+        b["binding"] = "valu_f64" if v["frac"] > (r.get("frac") or 0.0) else r.get("bound")
+    else:
+        b["binding"] = r.get("bound")
+    if r.get("bound") == "hbm":
+        b["hbm_frac"] = r.get("frac")
+    return b
+
+
+def _gather_brief(g):
+    if not g:
+        return None
+    acc = g.get("accountings") or {}
+    kcg = acc.get("K_cg only (SURVEY 8d)") or {}
+    fus = acc.get("fused (this kernel's algorithmic bytes)") or {}
+    return {"kernel": g.get("kernel"), "avg_launch_us": g.get("avg_launch_us"), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac_K_cg": kcg.get("frac"), "achieved_K_cg": kcg.get("achieved_GBps"),
+            "frac_fused": fus.get("frac", g.get("frac")), "achieved_fused": fus.get("achieved_GBps", g.get("achieved"))}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line stdout carries: <= COMPACT_LIMIT bytes, strict JSON (no NaN / Infinity), the contract's keys + roofline +
+    cpu_baseline + parity + one short object per measured configuration.  Everything else (per-kernel tables, chains, halo cost,
+    phases, the acos census ...) is in the detail document (bench_detail.json; also printed to stderr)."""
+    def short(sv, n):
+        return sv if sv is None or len(sv) <= n else sv[:n - 3] + "..."
+    cfg = out.get("config") or {}
+    par = out.get("parity_check")
+    cb = out.get("cpu_baseline")
+    c = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_cold", "higher_is_better",
+                                 "scaling", "vs_baseline", "dtype", "data")}
+    c["config"] = {"workload": short(cfg.get("workload"), 330), "name": out.get("workload_name"), "points_per_gpu": cfg.get("points_per_gpu"),
+                   "cells_per_gpu": cfg.get("cells_per_gpu"), "parallelism": short(cfg.get("parallelism"), 120)}
+    c["roofline"] = _roof_brief(out.get("roofline"))
+    c["roofline_centroid_gather"] = _gather_brief(out.get("roofline_centroid_gather"))
+    if cb:
+        c["cpu_baseline"] = {"value": cb.get("value"), "unit": cb.get("unit"), "cores": cb.get("cores"), "kind": cb.get("kind"),
+                             "sample": short(cb.get("sample"), 200), "host_cpus": cb.get("host_cpus")}
+        c["speedup_vs_cpu_baseline"] = out.get("speedup_vs_cpu_baseline")
+    if par:
+        sc = par.get("small_case") or {}
+        c["parity_check"] = {"ok": bool(par.get("ok", False)), "bitwise_equal": par.get("bitwise_equal", sc.get("bitwise_equal_on_every_rank")),
+                             "iters": par.get("iters", sc.get("iters")), "rel_linf": par.get("rel_linf", sc.get("rel_linf_max_over_ranks")),
+                             "tolerance": par.get("tolerance", 1e-10), "against": "CPU oracle (unpinned restatement of the reference)"}
+    if out.get("rccl"):
+        rc = out["rccl"]
+        c["rccl"] = {"transport": rc.get("transport"), "backend": short(str(rc.get("backend")), 60), "ranks_seen": rc.get("ranks_seen")}
+    for k in ("halo_overhead_us", "weak_efficiency_bound"):
+        if k in out:
+            c[k] = out[k]
+    c["exit_code"] = out.get("exit_code", 0)
+    if out.get("failures"):
+        c["failures"] = [short(f, 160) for f in out["failures"]][:4]
+    c["detail"] = detail_path
+    c["configs_summary"] = out.get("configs_summary")
+    c = _sig(c)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    # never longer than the limit: drop the optional parts in this order until it fits
+    for drop in (("cpu_baseline", "sample"), ("config", "workload"), ("roofline_centroid_gather", None), ("failures", None), ("rccl", None)):
+        if len(line.encode()) <= COMPACT_LIMIT:
+            break
+        if drop[1] is None:
+            c.pop(drop[0], None)
+        elif isinstance(c.get(drop[0]), dict):
+            c[drop[0]][drop[1]] = short(c[drop[0]].get(drop[1]), 60)
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    while len(line.encode()) > COMPACT_LIMIT and c.get("configs_summary"):
+        c["configs_summary"] = c["configs_summary"][:-1]
+        c["configs_summary_truncated"] = True
+        line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    return line
+
+
 def emit(out):
-    """the exit path: finalize, print the ONE JSON line, return the process exit code (main() raises SystemExit with it after the
-    process group is gone).  SMOOTHMESH_BENCH_FALSIFY=<workload> flips that entry's parity verdict -- the test hook that shows a
-    failed comparison reaches the exit code."""
+    """the exit path: finalize, write the full document to the detail file (SMOOTHMESH_BENCH_DETAIL, default bench_detail.json
+    beside this script; "" = no file) and to stderr, print the ONE compact JSON line on stdout, return the process exit code
+    (main() raises SystemExit with it after the process group is gone).  SMOOTHMESH_BENCH_FALSIFY=<workload> flips that entry's
+    parity verdict -- the test hook that shows a failed comparison reaches the exit code."""
     fals = os.environ.get("SMOOTHMESH_BENCH_FALSIFY")
     if fals:
         for e in [out] + list(out.get("configs", [])):
@@ -752,7 +860,21 @@ def emit(out):
                 e["parity_check"]["ok"] = False
                 e["parity_check"]["falsified_by_test_hook"] = True
     out, code = finalize_line(out)
-    print(json.dumps(out), flush=True)
+    detail = os.environ.get("SMOOTHMESH_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    full = json.dumps(_sig(out, 12), allow_nan=False)
+    written = None
+    if detail:
+        try:
+            with open(detail, "w") as f:
+                f.write(full + "\n")
+            written = os.path.relpath(detail, ROOT) if os.path.abspath(detail).startswith(ROOT) else detail
+        except OSError as ex:
+            print(f"bench.py: could not write {detail}: {ex}", file=sys.stderr)
+    if os.environ.get("SMOOTHMESH_BENCH_FULL"):      # the builder's own scripts (scripts/*.sh) read the full document from stdout
+        print(full, flush=True)
+        return code
+    print("BENCH_DETAIL " + full, file=sys.stderr, flush=True)
+    print(compact_line(out, written), flush=True)
     return code
 
 

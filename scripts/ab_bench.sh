@@ -2,6 +2,7 @@
 # usage (on the GPU box): scripts/ab_bench.sh <workload> <steps> [variant.so ...]
 # one bench.py line per library build (the in-tree libsmgpu.so first, then every variant given), printed as
 # "<lib> ms_per_step [kernel avg_us ...]" -- A/B of build-time switches (variants are built into smoothmesh_amd/csrc/variants/).
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 wl=$1; steps=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out/ab

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): scripts/ab_env.sh <workload> <steps> "VAR=val VAR2=val" ["..." ...]
 # one bench.py line per environment setting (the first argument set may be "" = defaults): A/B of run-time knobs
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 wl=$1; steps=$2; shift 2
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $root/gpurun_out/ab

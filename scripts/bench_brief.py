@@ -7,7 +7,7 @@ extra = []
 if "--" in args:
     i = args.index("--"); extra = args[i + 1:]; args = args[:i]
 for wl in args or ["hex100"]:
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-configs"] + extra, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", wl, "--no-cpu-baseline", "--no-configs"] + extra, capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FULL="1"))
     try:
         d = json.loads(r.stdout.strip().split("\n")[-1])
     except Exception:

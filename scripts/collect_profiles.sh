@@ -1,6 +1,7 @@
 #!/bin/bash
 # run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
 # usage: scripts/collect_profiles.sh [round tag, default r5]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 tag=${1:-r5}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag

@@ -4,6 +4,7 @@
 # or re-exec'd), every step exits non-zero on a mismatch, and the script stops at the first failure.
 #   usage: scripts/first_multi_gpu.sh [nGPUs]      (default: all visible; run from the repository root)
 # Writes one log per step under gpurun_out/first_multi_gpu/.
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 set -u
 cd "$(dirname "$0")/.."
 export HSA_ENABLE_IPC_MODE_LEGACY=0 MASTER_ADDR=127.0.0.1

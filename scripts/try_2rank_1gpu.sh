@@ -1,5 +1,6 @@
 #!/bin/bash
 # experiment: two ranks on the single GPU of a gpurun box (RCCL normally rejects duplicate GPUs)
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 export SMOOTHMESH_SHARE_GPU=1

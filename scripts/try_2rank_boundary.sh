@@ -1,5 +1,6 @@
 #!/bin/bash
 # two ranks on the single GPU of a gpurun box through the gloo debug backend: DistributedSmoother + boundary point smoothing
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0 SMOOTHMESH_SHARE_GPU=1 SMOOTHMESH_BACKEND=gloo
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 scripts/check_dist_boundary.py > gpurun_out/dist_bnd.log 2>&1

@@ -1,5 +1,6 @@
 #!/bin/bash
 # two ranks on the single GPU of a gpurun box through the gloo debug backend: hex, hex + layers, polyhedral
+export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
 mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0 SMOOTHMESH_SHARE_GPU=1 SMOOTHMESH_BACKEND=gloo
 for wl in hex40 hex40L cavity40c cavity40L; do

@@ -9,11 +9,24 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, env=None, timeout=900):
+def _run(args, env=None, timeout=900, detail=None):
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    if detail is not None:
+        e["SMOOTHMESH_BENCH_DETAIL"] = str(detail)
     e.update(env or {})
     return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def _compact(r):
+    """stdout carries exactly ONE JSON line, it is the last line, shorter than 4 KB and strict JSON"""
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and r.stdout.rstrip().splitlines()[-1] == lines[0]
+    assert len(lines[0].encode()) < 4096
+
+    def no_const(x):
+        raise ValueError(f"non-strict JSON constant {x}")
+    return json.loads(lines[0], parse_constant=no_const)
 
 
 def test_self_launch_reaches_the_ranks_without_a_gpu():
@@ -29,7 +42,7 @@ def test_self_launch_reaches_the_ranks_without_a_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("workload,configs", [("hex16", "cavity10c"), ("cavity12c", "")])
-def test_bench_two_ranks_self_launched(workload, configs):
+def test_bench_two_ranks_self_launched(workload, configs, tmp_path):
     """`python bench.py --gpus 2` as the driver calls it (no WORLD_SIZE): two ranks on this box's one GPU through the gloo debug
     transport; ONE JSON line with n_gpus = 2 and both ranks' points, and everything a judge needs to accept an N > 1 line:
     parity_check (copies of shared points identical across the ranks after the timed steps; a down-scaled case through the same
@@ -37,11 +50,12 @@ def test_bench_two_ranks_self_launched(workload, configs):
     (transport, communicator size, self-check), and configs[] = the polyhedral constraints-on workload (BASELINE configs[4]) beside
     the hex headline"""
     r = _run(["--gpus", "2", "--steps", "4", "--warmup", "1", "--workload", workload, "--configs", configs, "--config-steps", "3"],
-             env={"SMOOTHMESH_BACKEND": "gloo", "SMOOTHMESH_SHARE_GPU": "1"})
+             env={"SMOOTHMESH_BACKEND": "gloo", "SMOOTHMESH_SHARE_GPU": "1"}, detail=tmp_path / "detail.json")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    c_ = _compact(r)
+    assert c_["n_gpus"] == 2 and c_["steps"] == 4 and c_["parity_check"]["ok"] and c_["rccl"]["ranks_seen"] == 2 and c_["cpu_baseline"]["value"] > 0
+    d = json.load(open(tmp_path / "detail.json"))          # the full document
+    assert d["value"] == pytest.approx(c_["value"], rel=1e-4)
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["points_per_gpu"] > 0 and "roofline" in d
     if workload.startswith("cavity"):
@@ -132,28 +146,84 @@ def test_exit_path_carries_a_falsified_parity_object():
     """through the real exit path (emit -> SystemExit) in a process of its own: the line is printed AND the exit code is 1"""
     prog = ("import sys, json; sys.path.insert(0, %r); import bench; sys.path.insert(0, %r); from test_bench_launch import _line; "
             "raise SystemExit(bench.emit(_line()))" % (ROOT, os.path.join(ROOT, "tests")))
-    ok = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY=""))
-    assert ok.returncode == 0 and json.loads(ok.stdout)["exit_code"] == 0
-    bad = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY="cavity215c"))
-    d = json.loads(bad.stdout)
+    ok = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY="", SMOOTHMESH_BENCH_DETAIL=""))
+    assert ok.returncode == 0 and _compact(ok)["exit_code"] == 0
+    bad = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, SMOOTHMESH_BENCH_FALSIFY="cavity215c", SMOOTHMESH_BENCH_DETAIL=""))
+    d = _compact(bad)
     assert bad.returncode == 1 and d["exit_code"] == 1 and d["failures"] == ["cavity215c: parity_check not ok"]
     assert list(d)[-1] == "configs_summary"
+    # the full document went to stderr, one line, for a reader without the detail file
+    full = [l for l in bad.stderr.splitlines() if l.startswith("BENCH_DETAIL {")]
+    assert len(full) == 1 and json.loads(full[0][len("BENCH_DETAIL "):])["configs"][1]["parity_check"]["falsified_by_test_hook"]
+
+
+def test_compact_line_is_short_strict_and_complete():
+    """what the driver parses: the LAST stdout line, < 4096 bytes, strict JSON, carrying the contract's keys, the dominant kernel's
+    roofline (with the ceiling that binds it), the centroid-gather kernel's fractions, cpu_baseline, parity and one short object per
+    configuration (round 5's 20 KB line came back with parsed = null)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    roof = {"kernel": "k_geom_tile", "avg_launch_us": 47.7, "bound": "hbm", "achieved": 2877.9, "peak": 8000.0, "unit": "GB/s", "frac": 0.3597,
+            "algorithmic_bytes_per_launch": 137327232, "valu_f64": {"frac": 0.5769}, "traffic": 112907499, "note": "x" * 900}
+    gather = {"kernel": "k_smooth<final>", "avg_launch_us": 33.7, "bound": "hbm", "frac": 0.5156, "achieved": 4125.0,
+              "accountings": {"fused (this kernel's algorithmic bytes)": {"frac": 0.5156, "achieved_GBps": 4125.0},
+                              "K_cg only (SURVEY 8d)": {"frac": 0.4097, "achieved_GBps": 3277.0}}}
+    big = _line(n_gpus=1, warmup=5, unit="points/s", dtype="f64", data="synthetic", scaling="weak", higher_is_better=True, vs_baseline=None,
+                ms_per_step_cold=float("nan"), roofline=roof, roofline_centroid_gather=gather,
+                config={"workload": "w" * 2000, "points_per_gpu": 1030301, "cells_per_gpu": 1000000, "parallelism": "1 GPU"},
+                cpu_baseline={"value": 3.5e6, "unit": "points/s", "cores": 1, "kind": "port", "sample": "s" * 3000, "host_cpus": 256},
+                kernels=[{"name": "k", "avg_us": 1.0}] * 400)
+    for c in big["configs"]:
+        c["roofline"] = dict(roof)
+        c["roofline_centroid_gather"] = dict(gather)
+    big["configs"] += [dict(big["configs"][0], workload=f"extra{i}") for i in range(3)]
+    out, code = bench.finalize_line(big)
+    line = bench.compact_line(out, "bench_detail.json")
+    assert len(line.encode()) < 4096 and "\n" not in line
+
+    def no_const(x):
+        raise ValueError(x)
+    d = json.loads(line, parse_constant=no_const)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "roofline_centroid_gather", "cpu_baseline", "parity_check", "exit_code", "configs_summary"):
+        assert k in d, k
+    assert d["ms_per_step_cold"] is None                      # NaN never reaches the line
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["binding"] == "valu_f64" and r["frac"] == pytest.approx(0.3597) and r["valu_f64_frac"] == pytest.approx(0.5769)
+    assert r["traffic"] == 112907499 and r["algorithmic_bytes_per_launch"] == 137327232 and r["peak"] == 8000.0
+    g = d["roofline_centroid_gather"]
+    assert g["frac_K_cg"] == pytest.approx(0.4097) and g["frac_fused"] == pytest.approx(0.5156)
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and len(d["cpu_baseline"]["sample"]) <= 200
+    assert d["parity_check"] == {"ok": True, "bitwise_equal": True, "iters": None, "rel_linf": 0.0, "tolerance": 1e-10,
+                                 "against": "CPU oracle (unpinned restatement of the reference)"}
+    assert [c["workload"] for c in d["configs_summary"]][:3] == ["hex100", "hex100c", "cavity215c"]
+    assert all(c["dominant_kernel"] == "k_geom_tile" and c["roofline_frac"] > 0 and c["binding"] == "valu_f64" for c in d["configs_summary"])
 
 
 @pytest.mark.gpu
-def test_bench_exits_nonzero_when_a_comparison_fails():
+def test_bench_exits_nonzero_when_a_comparison_fails(tmp_path):
     r = _run(["--steps", "3", "--warmup", "1", "--workload", "hex10", "--configs", "hex10c", "--config-steps", "2"],
-             env={"SMOOTHMESH_BENCH_FALSIFY": "hex10c"})
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+             env={"SMOOTHMESH_BENCH_FALSIFY": "hex10c"}, detail=tmp_path / "detail.json")
+    d = _compact(r)
     assert r.returncode == 1 and d["exit_code"] == 1 and d["failures"] == ["hex10c: parity_check not ok"]
     assert d["parity_check"]["ok"] and list(d)[-1] == "configs_summary"
+    assert d["configs_summary"][1]["parity_ok"] is False
 
 
 @pytest.mark.gpu
-def test_bench_single_gpu_line_carries_the_other_configs():
-    r = _run(["--steps", "5", "--warmup", "1", "--workload", "hex12", "--configs", "hex12c,cavity10c", "--config-steps", "3"])
+def test_bench_single_gpu_line_carries_the_other_configs(tmp_path):
+    r = _run(["--steps", "5", "--warmup", "1", "--workload", "hex12", "--configs", "hex12c,cavity10c", "--config-steps", "3"],
+             detail=tmp_path / "detail.json")
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    c_ = _compact(r)
+    # what the driver's parsed record will hold
+    assert c_["n_gpus"] == 1 and c_["steps"] == 5 and c_["warmup"] == 1 and c_["value"] > 0 and c_["dtype"] == "f64"
+    assert c_["roofline"]["frac"] > 0 and c_["roofline"]["bound"] in ("hbm", "valu_f64") and c_["roofline"]["binding"]
+    assert c_["cpu_baseline"]["kind"] == "port" and c_["cpu_baseline"]["cores"] == 1 and c_["cpu_baseline"]["value"] > 0
+    assert c_["parity_check"]["ok"] and c_["parity_check"]["bitwise_equal"] and c_["detail"]
+    assert [c["workload"] for c in c_["configs_summary"]] == ["hex12", "hex12c", "cavity10c"]
+    assert all(c["dominant_kernel"] and c["roofline_frac"] > 0 for c in c_["configs_summary"])
+    d = json.load(open(tmp_path / "detail.json"))          # the full document
     assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["frac"] > 0
     assert [c["workload"] for c in d["configs"]] == ["hex12c", "cavity10c"]
     # tail-safe: the compact summary of every configuration is the line's last key
