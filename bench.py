@@ -606,6 +606,42 @@ def run_distributed(workload, K, W, rank, world, local_rank, backend, oracle=Tru
         allow_overlap = bool(int(okf.item()))
         if not allow_overlap:
             flagged_check["ok"] = False
+    # ... and only if the REAL workload (far more shared tiles than the down-scaled case: spinning shared-point workgroups, the
+    # RCCL kernel and the relay compete for resident slots) gives the in-order result bit for bit over a few iterations
+    if allow_overlap and world > 1 and flagged_check is not None and getattr(ds, "xstream", None) is not None:
+        import numpy as np
+        real = {"iters": 3}
+        prev_to = os.environ.get("SMGPU_PUSH_TIMEOUT_S")
+        os.environ["SMGPU_PUSH_TIMEOUT_S"] = "10"
+        try:
+            p0 = ds.engine.get_points()
+            ds.set_overlap(False)
+            ds.iterate(3, 0.0)
+            a = ds.engine.get_points()
+            ds.engine.set_points(p0)
+            ds.set_overlap(True)
+            ds.iterate(3, 0.0)
+            b = ds.engine.get_points()
+            real["bitwise_equal_to_inorder"] = bool(np.array_equal(a, b))
+            real["ok"] = real["bitwise_equal_to_inorder"]
+        except Exception as ex:   # noqa: BLE001
+            real.update({"ok": False, "error": f"{type(ex).__name__}: {ex}"})
+        finally:
+            if prev_to is None:
+                os.environ.pop("SMGPU_PUSH_TIMEOUT_S", None)
+            else:
+                os.environ["SMGPU_PUSH_TIMEOUT_S"] = prev_to
+        okf = torch.tensor([1 if real.get("ok") else 0], dtype=torch.int32, device=rdev)
+        dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+        allow_overlap = bool(int(okf.item()))
+        ds.set_overlap(False)
+        try:
+            ds.engine.set_points(p0)
+        except Exception:   # noqa: BLE001 -- (p0 unset: get_points itself failed; the run below will say so)
+            pass
+        flagged_check["real_workload"] = real
+        if not allow_overlap:
+            flagged_check["ok"] = False
     # exchange arrangement (in order on the engine's stream / on a communication stream next to the
     # exchange-independent kernels): timed on this machine before the warm-up, same choice on every rank
     tune = ds.autotune(20, allow_overlap=allow_overlap) if os.environ.get("SMOOTHMESH_OVERLAP") is None else None

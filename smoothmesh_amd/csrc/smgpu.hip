@@ -484,6 +484,21 @@ static int ensureHostLists(smgpu_handle* h, int groups) {
     return downloadDeferredLists(h->topo, h->devLists, h->device, why, groups) ? fail("device -> host copy of the addressing: " + why) : 0;
 }
 
+// A device build's owner / neighbour arrays are read by the device builds of the tile tables only and never join the handle's
+// allocation list: freed once those builds are joined (and on every failure path).
+static void freeOwnerNeighbour(DeviceTopologyArrays& dt) {
+    for (DeviceTopologyArrays::Arr* a : {&dt.owner, &dt.neighbour})
+        if (a->p) { (void)hipFree(a->p); a->p = nullptr; a->bytes = 0; }
+}
+static void freeDevTopo(DeviceTopologyArrays& dt) {
+    freeOwnerNeighbour(dt);
+    for (DeviceTopologyArrays::Arr* a : {&dt.faceOff, &dt.facePts, &dt.cfOff, &dt.cfVal, &dt.pcOff, &dt.pcVal, &dt.ppOff, &dt.ppPt, &dt.peEdge, &dt.pfOff, &dt.pfFace,
+                                         &dt.pfPrev, &dt.pfNext, &dt.pfPrevSlot, &dt.pfNextSlot, &dt.ringFace, &dt.ringCell, &dt.edgeRingOk, &dt.edges, &dt.efOff,
+                                         &dt.efFace, &dt.ecOff, &dt.ecCell, &dt.ecF0, &dt.ecF1})
+        if (a->p) { (void)hipFree(a->p); a->p = nullptr; a->bytes = 0; }
+    dt.valid = false;
+}
+
 int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (!d || !out) return fail("smgpu_create: null argument");
     *out = nullptr;
@@ -610,6 +625,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                 if (fSmooth.valid()) fSmooth.wait();
                 if (fEdge.valid()) fEdge.wait();
                 if (fPointOrder.valid()) fPointOrder.wait();
+                freeDevTopo(devTopo);       // (arrays the failed device build had already handed over)
                 delete h;
                 return fail("smgpu_create: device addressing: " + why);
             }
@@ -634,12 +650,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         if (fSmooth.valid()) fSmooth.wait();
         if (fPointOrder.valid()) fPointOrder.wait();
         if (fEdge.valid()) fEdge.wait();
-        if (devTopo.valid && !devAdopted)      // a device build's arrays the handle has not taken over yet
-            for (const DeviceTopologyArrays::Arr* a : {&devTopo.faceOff, &devTopo.facePts, &devTopo.cfOff, &devTopo.cfVal, &devTopo.pcOff, &devTopo.pcVal, &devTopo.ppOff,
-                                                       &devTopo.ppPt, &devTopo.peEdge, &devTopo.pfOff, &devTopo.pfFace, &devTopo.pfPrev, &devTopo.pfNext, &devTopo.pfPrevSlot,
-                                                       &devTopo.pfNextSlot, &devTopo.ringFace, &devTopo.ringCell, &devTopo.edgeRingOk, &devTopo.edges, &devTopo.efOff,
-                                                       &devTopo.efFace, &devTopo.ecOff, &devTopo.ecCell, &devTopo.ecF0, &devTopo.ecF1})
-                if (a->p) (void)hipFree(a->p);
+        if (!devAdopted) freeDevTopo(devTopo);      // a device build's arrays the handle has not taken over yet
+        else freeOwnerNeighbour(devTopo);           // (never adopted: only the tile-table builds read them)
         smgpu_destroy(h);
         return rc;
     };
@@ -756,6 +768,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         if (e3 == kHostTablesPending) e3 = downloadDeferredLists(h->topo, devTopo, h->device, whyD, 2) ? "device -> host copy of the addressing: " + whyD : h->etl.buildTables(h->topo);
         if (envInt("SMGPU_VERBOSE", 0))
             std::fprintf(stderr, "[smgpu] set-up: addressing %.2f s, tile tables (3 host threads) %.2f s\n", tTopo, sinceCreate() - tTopo);
+        freeOwnerNeighbour(devTopo);      // read by the device builds of the tile tables only, all joined now (4 (nFaces + nInternalFaces) bytes)
         lapC("tile tasks joined");
         if (!e1.empty() || !e2.empty()) {
             h->useTiles = false;   // meshes with huge cells / valences: direct-gather kernels still apply
@@ -981,6 +994,9 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
         }
     }
     computeAlgoBytes(h);
+    if (fEdge.valid()) fEdge.wait();
+    freeOwnerNeighbour(devTopo);          // (meshes without tile tables come past here with the two arrays still held)
+    h->devLists.owner = h->devLists.neighbour = DeviceTopologyArrays::Arr();     // the handle's copy never owns them
     if (envInt("SMGPU_VERBOSE", 0)) std::fprintf(stderr, "[smgpu] set-up: total %.2f s\n", sinceCreate());
     *out = h;
     return 0;
@@ -2352,6 +2368,8 @@ static bool mergedOk(const smgpu_handle* h) {
     return h->mergedWanted && fused && h->useTiles && h->geomT == 256 && h->smoothT == 256 && h->nShared > 0 && h->shr.nTiles > 0 && h->nGeomShared > 0 &&
            h->packTiles && h->dMultiIdx && h->dPeer && h->dPosSlot && h->dRoleTickets && !h->layersOn && !h->bndOn && (!h->useExch || flagUsable(h)) && !h->geomAheadDone &&
            !h->st.inlinePackF &&
+           // roleDone() counts one arrival per XCD slot: every role's workgroup count must be a multiple of 8 (tileGrid rounds up with the XCD map only)
+           h->xcdMap != 0 &&
            // several engines on one device with the peer-store transport: workgroups that spin for a peer's flag hold their slots
            // while the peer's launches need some -- fine for a handful of tiles, not for a chip full of them
            !(h->pushOn && h->deviceShare > 1 && h->shr.nTiles > 256);
@@ -2514,8 +2532,10 @@ int smgpu_iter_mid(smgpu_handle* h) {
         if (h->useExch) {
             // exchange A has been enqueued on the exchange stream: the word the shared points' role polls goes up behind it, and the
             // same wave waits for that role's "exchange F is packed" (exchange F is enqueued behind it)
-            if (flagRelay(h, 16, 1)) return 1;
-            return runMergedSmooth(h);
+            // (the kernel first: were its launch refused, a relay already enqueued would spin on the high-priority exchange stream
+            // until its time-out with everything that synchronises that stream behind it; the exchange stream's order is the same)
+            if (runMergedSmooth(h)) return 1;
+            return flagRelay(h, 16, 1);
         }
         if (runMergedSmooth(h)) return 1;
         return exchAfterCompute(h);

@@ -414,7 +414,8 @@ class DistributedSmoother:
         else:
             t, seen = "torch", self.dist.get_world_size()
         return {"backend": "RCCL (torch backend nccl)" if backend == "nccl" else backend + " (debug transport, host-staged)", "transport": t,
-                "ranks_seen": int(seen), "self_check": getattr(self, "direct_status", "off"), "exchange_stream": bool(getattr(self, "overlap", False))}
+                "ranks_seen": int(seen), "self_check": getattr(self, "direct_status", "off"), "exchange_stream": bool(getattr(self, "overlap", False)),
+                "had_error": getattr(self, "had_error", None)}
 
     def close(self):
         """Orderly shutdown, to be called on every rank BEFORE dist.barrier() / destroy_process_group(): drain the engine's and
@@ -578,6 +579,26 @@ class DistributedSmoother:
             self._a2a(l_view(st.recvL, eng.l_doubles()), l_view(st.sendL, eng.l_doubles()))   # OBB.C:184-198, 490-496
         self._a2a(st.recvA, st.sendA, overlap)   # SM.C:134-148, 402-478
 
+    def _agree_on_error(self):
+        """Wait for the engine's stream, read its error word (include/smgpu.h) and let EVERY rank raise when any rank has one: a
+        rank raising on its own would leave the others inside the next collective.  The engine clears the word once it has been
+        reported, so the handle keeps a sticky `had_error` for later readers (transport_info, bench.py)."""
+        torch, eng = self.torch, self.engine
+        err = None
+        if hasattr(eng, "check_error"):
+            try:
+                eng.check_error()
+            except Exception as ex:  # noqa: BLE001 -- re-raised below, on every rank
+                err = ex
+        if self.world > 1:
+            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cpu" if self._staged() else self.device)
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+            if int(flag.item()) and err is None:
+                err = RuntimeError("another rank reported a device error in this call (see its message)")
+        if err is not None:
+            self.had_error = str(err)
+            raise err
+
     def _gather_stats(self):
         if self._staged():
             out = self.torch.empty((self.world, 2), dtype=self.torch.float64)
@@ -651,6 +672,7 @@ class DistributedSmoother:
                 eng.iter_mid()
                 self._a2a(st.recvF, st.sendF, eng.iter_ahead)   # SM.C:2374
                 eng.iter_end()
+                self._agree_on_error()                      # (this branch reads the residual on the host every iteration anyway)
                 self._gather_stats()                        # SM.C:1567, 2396
                 hist[i, 0] = self.allStats[:, 0].max()
                 hist[i, 1] = self.allStats[:, 1].sum()
@@ -674,19 +696,7 @@ class DistributedSmoother:
         eng.set_stats_history(None, 0)
         # an error word raised by a kernel of this call (a peer's records that never came, a point without usable neighbours): every
         # rank must learn of it BEFORE the gather below -- a rank that raised on its own would leave the others inside the collective
-        err = None
-        if hasattr(eng, "check_error"):
-            try:
-                eng.check_error()
-            except Exception as ex:  # noqa: BLE001 -- re-raised below, on every rank
-                err = ex
-        if self.world > 1:
-            flag = torch.tensor([1 if err is not None else 0], dtype=torch.int32, device="cpu" if self._staged() else self.device)
-            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
-            if int(flag.item()) and err is None:
-                err = RuntimeError("another rank reported a device error in this call (see its message)")
-        if err is not None:
-            raise err
+        self._agree_on_error()
         if self._staged():
             allh = torch.empty((self.world, n, 2), dtype=torch.float64)
             self.dist.all_gather_into_tensor(allh.view(-1), local.cpu().view(-1))
