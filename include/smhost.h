@@ -45,6 +45,9 @@ int smhost_write_points(const char* polyMeshDir, const char* location, int32_t n
                         int32_t binary, int32_t precision);
 /* labelList file (pointProcAddressing etc.): n = -1 on input to query the size into *n. */
 int smhost_read_label_list(const char* file, int32_t* out, int64_t* n);
+/* points file alone (vectorField; a later time directory's polyMesh/points, SM.C:2430 written, read back on restart):
+ * *n = number of scalars (3 per point); out == NULL or *n too small: only the size is returned. */
+int smhost_read_points(const char* file, double* out, int64_t* n);
 /* Wavefront OBJ inputs of the boundary point smoothing (constant/geometry/ .obj files, SM.C:1924-1926), read the way
  * OpenFOAM's readers do: kind 0 = surface (triSurface: polygons as triangle fans about their first vertex; 3 ids per
  * element), kind 1 = edge mesh (edgeMesh: consecutive pairs of every "l" record, unused points dropped; 2 ids per

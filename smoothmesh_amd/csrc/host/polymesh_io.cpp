@@ -1,11 +1,18 @@
 // polymesh_io.cpp -- see polymesh_io.hpp.
 #include "polymesh_io.hpp"
 
+#include <fcntl.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
+#include <charconv>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -13,6 +20,7 @@
 #include <map>
 #include <sstream>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 namespace smhost {
@@ -71,7 +79,142 @@ static std::string slurp(const std::string& file) {
     return s;
 }
 
+// ---- host threads of the list readers / writers ------------------------------------------------------------------------------
+// The big lists of a polyMesh directory (points, faces, owner, neighbour) are cut into contiguous pieces, one per thread, each
+// piece parsed / formatted on its own and the results joined in order: exactly what the serial loop reads or writes (the tests
+// compare byte for byte).  SMHOST_IO_THREADS caps the thread count (default: the hardware's, at most 64; 1 = the serial loops).
+static unsigned ioThreads() {
+    static const unsigned n = [] {
+        if (const char* e = std::getenv("SMHOST_IO_THREADS")) return std::max(1u, std::min((unsigned)std::atoi(e), 256u));
+        return std::max(1u, std::min(std::thread::hardware_concurrency(), 64u));
+    }();
+    return n;
+}
+static int64_t ioGrain() {     // smallest piece worth a thread (bytes or records); tests lower it to cut small files too
+    if (const char* e = std::getenv("SMHOST_IO_GRAIN")) return std::max<int64_t>(1, std::atoll(e));
+    return 1 << 16;
+}
+static int ioParts(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ioThreads(), n / ioGrain())); }
+
+template <class F>
+static void parallelParts(int parts, F&& f) {      // f(part) on its own thread; the first exception is re-thrown
+    if (parts <= 1) { f(0); return; }
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err((size_t)parts);
+    th.reserve((size_t)parts);
+    for (int t = 0; t < parts; ++t) th.emplace_back([&f, &err, t] { try { f(t); } catch (...) { err[(size_t)t] = std::current_exception(); } });
+    for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
+}
+static void parallelCopy(void* dst, const void* src, size_t bytes) {     // (first touch of the destination and page faults of a mapped source on all threads)
+    const int parts = ioParts((int64_t)bytes);
+    parallelParts(parts, [&](int t) {
+        const size_t b = bytes * (size_t)t / (size_t)parts, e = bytes * (size_t)(t + 1) / (size_t)parts;
+        std::memcpy((char*)dst + b, (const char*)src + b, e - b);
+    });
+}
+
+// A file's bytes: mapped (the readers never need a terminating NUL: every number is parsed within [p, end)), or -- <file>.gz
+// where <file> is missing -- inflated into memory
+struct FileBuf {
+    const char* data = nullptr;
+    size_t size = 0;
+    void* map = nullptr;
+    std::string owned;
+    explicit FileBuf(const std::string& file) {
+        const int fd = ::open(file.c_str(), O_RDONLY);
+        if (fd < 0) {
+            if (fileExists(file + ".gz")) { owned = slurpGz(file + ".gz"); data = owned.data(); size = owned.size(); return; }
+            throw std::runtime_error("cannot open " + file);
+        }
+        struct stat st;
+        if (::fstat(fd, &st) != 0) { ::close(fd); throw std::runtime_error("cannot stat " + file); }
+        size = (size_t)st.st_size;
+        if (size > 0) {
+            map = ::mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (map == MAP_FAILED) {      // (file systems without mmap: plain read)
+                map = nullptr;
+                ::close(fd);
+                owned = slurp(file);
+                data = owned.data(); size = owned.size();
+                return;
+            }
+            (void)::madvise(map, size, MADV_WILLNEED);
+            data = (const char*)map;
+        }
+        ::close(fd);
+    }
+    ~FileBuf() { if (map) ::munmap(map, size); }
+    FileBuf(const FileBuf&) = delete;
+    FileBuf& operator=(const FileBuf&) = delete;
+};
+
 namespace {
+// ---- numbers within [p, end): no terminating NUL is needed (mapped files) ---------------------------------------------------
+inline const char* parseInt(const char* p, const char* end, long long& out) {
+    const char* q = p;
+    bool neg = false;
+    if (q < end && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    if (q >= end || *q < '0' || *q > '9') return nullptr;
+    unsigned long long v = 0;
+    while (q < end && *q >= '0' && *q <= '9') v = v * 10 + (unsigned)(*q++ - '0');
+    out = neg ? -(long long)v : (long long)v;
+    return q;
+}
+// the token at p through strtod (any form strtod takes; a private NUL-terminated copy)
+const char* parseDoubleSlow(const char* p, const char* end, double& out) {
+    const char* q = p;
+    while (q < end && !std::strchr(" \t\n\r;(){}", *q)) ++q;
+    const std::string tok(p, q);
+    char* e = nullptr;
+    out = std::strtod(tok.c_str(), &e);
+    if (e == tok.c_str()) return nullptr;
+    return p + (e - tok.c_str());
+}
+// Decimal text -> double, correctly rounded like strtod: a mantissa of at most 19 digits that fits 2^53 times / over an exactly
+// representable power of ten (|exponent| <= 22) is ONE correctly rounded IEEE operation on exact operands (Clinger's fast path);
+// everything else (17-digit mantissas beyond 2^53, huge exponents, nan / inf, hex floats) goes through strtod itself.
+inline const char* parseDouble(const char* p, const char* end, double& out) {
+    static const double kPow10[23] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+    const char* q = p;
+    bool neg = false;
+    if (q < end && (*q == '-' || *q == '+')) { neg = *q == '-'; ++q; }
+    unsigned long long w = 0;
+    int digits = 0, sig = 0, e10 = 0;
+    while (q < end && *q >= '0' && *q <= '9') {
+        if (sig > 0 || *q != '0') { if (sig < 19) { w = w * 10 + (unsigned)(*q - '0'); ++sig; } else return parseDoubleSlow(p, end, out); }
+        ++digits; ++q;
+    }
+    if (q < end && *q == '.') {
+        ++q;
+        while (q < end && *q >= '0' && *q <= '9') {
+            if (sig > 0 || *q != '0') { if (sig < 19) { w = w * 10 + (unsigned)(*q - '0'); ++sig; } else return parseDoubleSlow(p, end, out); }
+            --e10; ++digits; ++q;
+        }
+    }
+    if (digits == 0) return parseDoubleSlow(p, end, out);      // nan, inf, or not a number at all
+    if (q < end && (*q == 'e' || *q == 'E')) {
+        const char* r = q + 1;
+        bool eneg = false;
+        if (r < end && (*r == '-' || *r == '+')) { eneg = *r == '-'; ++r; }
+        if (r < end && *r >= '0' && *r <= '9') {
+            int ex = 0;
+            while (r < end && *r >= '0' && *r <= '9') { if (ex < 100000) ex = ex * 10 + (*r - '0'); ++r; }
+            e10 += eneg ? -ex : ex;
+            q = r;
+        }
+    }
+    if (q < end && (*q == 'x' || *q == 'X' || *q == 'p' || *q == 'P')) return parseDoubleSlow(p, end, out);     // (hex float)
+    if (w <= (1ull << 53) && e10 >= -22 && e10 <= 22) {
+        double v = (double)w;
+        if (e10 < 0) v /= kPow10[-e10]; else v *= kPow10[e10];
+        out = neg ? -v : v;
+        return q;
+    }
+    if (w == 0) { out = neg ? -0.0 : 0.0; return q; }
+    return parseDoubleSlow(p, end, out);
+}
+
 struct Scanner {
     const char* p;
     const char* end;
@@ -99,17 +242,17 @@ struct Scanner {
     }
     long long readInt() {
         skipWs();
-        char* e = nullptr;
-        const long long v = std::strtoll(p, &e, 10);
-        if (e == p) fail("expected an integer");
+        long long v;
+        const char* e = parseInt(p, end, v);
+        if (!e) fail("expected an integer");
         p = e;
         return v;
     }
     double readDouble() {
         skipWs();
-        char* e = nullptr;
-        const double v = std::strtod(p, &e);
-        if (e == p) fail("expected a number");
+        double v;
+        const char* e = parseDouble(p, end, v);
+        if (!e) fail("expected a number");
         p = e;
         return v;
     }
@@ -180,30 +323,111 @@ Header readHeader(Scanner& s) {
     return h;
 }
 
-void readLabels(Scanner& s, const Header& h, std::vector<int32_t>& out) {
+// ---- ascii list bodies on several threads ------------------------------------------------------------------------------------
+// [b, e) = the body of a list between its outer brackets, cut into `parts` pieces; a cut is moved forward to just behind the next
+// character of `delims` (a record never straddles two pieces).  Bodies with comments (never written by OpenFOAM inside a list)
+// or anything else a piece cannot take make parsePiece return false: the caller then reads the list with the serial Scanner,
+// which also words the errors.
+inline bool plainWs(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\r'; }
+std::vector<const char*> cutBody(const char* b, const char* e, int parts, const char* delims) {
+    std::vector<const char*> cut((size_t)parts + 1);
+    cut[0] = b;
+    cut[(size_t)parts] = e;
+    for (int t = 1; t < parts; ++t) {
+        const char* q = b + (size_t)(e - b) * (size_t)t / (size_t)parts;
+        q = std::max(q, cut[(size_t)t - 1]);
+        while (q < e && !std::strchr(delims, *q)) ++q;
+        cut[(size_t)t] = q < e ? q + 1 : e;
+    }
+    return cut;
+}
+// the outer closing bracket of the list that starts at `open` ('('): the last ')' of the file that is followed by nothing but white
+// space and comments without brackets (the footer line); nullptr when the file does not look like that
+const char* lastCloser(const char* open, const char* end) {
+    const char* q = end;
+    while (q > open && q[-1] != ')') { if (q[-1] == '(') return nullptr; --q; }
+    return q > open + 0 && q[-1] == ')' ? q - 1 : nullptr;
+}
+
+template <class T>
+void joinPieces(std::vector<T>& out, std::vector<std::vector<T>>& pieces) {
+    std::vector<size_t> base(pieces.size() + 1, 0);
+    for (size_t i = 0; i < pieces.size(); ++i) base[i + 1] = base[i] + pieces[i].size();
+    out.resize(base.back());
+    parallelParts((int)pieces.size(), [&](int t) {
+        if (!pieces[(size_t)t].empty()) std::memcpy(out.data() + base[(size_t)t], pieces[(size_t)t].data(), pieces[(size_t)t].size() * sizeof(T));
+        std::vector<T>().swap(pieces[(size_t)t]);
+    });
+}
+
+// n labels between s.p ('(' already taken) and the closing bracket; false: not taken (s.p untouched)
+bool readLabelBodyParallel(Scanner& s, long long n, std::vector<int32_t>& out) {
+    const char* close = lastCloser(s.p, s.end);
+    if (!close) return false;
+    const int parts = ioParts((int64_t)(close - s.p));
+    if (parts <= 1) return false;
+    // (a label list may be followed by a second list in the same file -- faceCompactList -- whose brackets lastCloser would see:
+    // the caller only comes here for the LAST list of a file)
+    const auto cut = cutBody(s.p, close, parts, " \n\t\r");
+    std::vector<std::vector<int32_t>> pieces((size_t)parts);
+    std::atomic<bool> ok{true};
+    parallelParts(parts, [&](int t) {
+        const char* q = cut[(size_t)t];
+        const char* e = cut[(size_t)t + 1];
+        auto& v = pieces[(size_t)t];
+        v.reserve((size_t)(e - q) / 6 + 16);
+        while (true) {
+            while (q < e && plainWs(*q)) ++q;
+            if (q >= e) break;
+            long long x;
+            const char* r = parseInt(q, e, x);
+            if (!r || (r < e && !plainWs(*r))) { ok = false; return; }
+            v.push_back((int32_t)x);
+            q = r;
+        }
+    });
+    if (!ok) return false;
+    size_t total = 0;
+    for (auto& v : pieces) total += v.size();
+    if ((long long)total != n) return false;
+    joinPieces(out, pieces);
+    s.p = close + 1;
+    return true;
+}
+
+// `last`: this is the file's last list (the several-thread ascii reader looks for the closing bracket from the file's end)
+void readLabels(Scanner& s, const Header& h, std::vector<int32_t>& out, bool last = true) {
     const long long n = s.readInt();
     if (n < 0) s.fail("negative list size");
-    out.resize((size_t)n);
     const char c = s.peek();
     if (c == '{') {   // uniform list N{v}
         ++s.p;
         const long long v = s.readInt();
         s.expect('}');
-        std::fill(out.begin(), out.end(), (int32_t)v);
+        out.assign((size_t)n, (int32_t)v);
         return;
     }
-    if (n == 0 && c != '(') return;
+    if (n == 0 && c != '(') { out.clear(); return; }
     if (h.binary) {
-        if (*s.p != '(') s.fail("expected '(' before binary data");
+        if (c != '(') s.fail("expected '(' before binary data");
         ++s.p;
         const size_t bytes = (size_t)n * h.labelBytes;
         if ((size_t)(s.end - s.p) < bytes) s.fail("truncated binary label list");
-        if (h.labelBytes == 4) std::memcpy(out.data(), s.p, bytes);
-        else for (long long i = 0; i < n; ++i) { int64_t v; std::memcpy(&v, s.p + 8 * i, 8); out[(size_t)i] = (int32_t)v; }
+        out.resize((size_t)n);
+        if (h.labelBytes == 4) parallelCopy(out.data(), s.p, bytes);
+        else {
+            const int parts = ioParts(n);
+            const char* src = s.p;
+            parallelParts(parts, [&](int t) {
+                for (long long i = n * t / parts, e = n * (t + 1) / parts; i < e; ++i) { int64_t v; std::memcpy(&v, src + 8 * i, 8); out[(size_t)i] = (int32_t)v; }
+            });
+        }
         s.p += bytes;
         s.expect(')');
     } else {
         s.expect('(');
+        if (last && readLabelBodyParallel(s, n, out)) return;
+        out.resize((size_t)n);
         for (long long i = 0; i < n; ++i) out[(size_t)i] = (int32_t)s.readInt();
         s.expect(')');
     }
@@ -253,25 +477,69 @@ void closeOut(FILE* f, const std::string& file) {
 }
 }  // namespace
 
+// n "(x y z)" records between s.p (the outer '(' already taken) and the closing bracket, on several threads; false: not taken
+static bool readPointBodyParallel(Scanner& s, long long n, std::vector<double>& pts) {
+    const char* close = lastCloser(s.p, s.end);
+    if (!close) return false;
+    const int parts = ioParts((int64_t)(close - s.p));
+    if (parts <= 1) return false;
+    const auto cut = cutBody(s.p, close, parts, ")");
+    std::vector<std::vector<double>> pieces((size_t)parts);
+    std::atomic<bool> ok{true};
+    parallelParts(parts, [&](int t) {
+        const char* q = cut[(size_t)t];
+        const char* e = cut[(size_t)t + 1];
+        auto& v = pieces[(size_t)t];
+        v.reserve((size_t)(e - q) / 8 + 16);
+        auto ws = [&] { while (q < e && plainWs(*q)) ++q; };
+        while (true) {
+            ws();
+            if (q >= e) break;
+            if (*q != '(') { ok = false; return; }
+            ++q;
+            for (int k = 0; k < 3; ++k) {
+                ws();
+                double x;
+                const char* r = q < e ? parseDouble(q, e, x) : nullptr;
+                if (!r) { ok = false; return; }
+                v.push_back(x);
+                q = r;
+            }
+            ws();
+            if (q >= e || *q != ')') { ok = false; return; }
+            ++q;
+        }
+    });
+    if (!ok) return false;
+    size_t total = 0;
+    for (auto& v : pieces) total += v.size();
+    if ((long long)total != 3 * n) return false;
+    joinPieces(pts, pieces);
+    s.p = close + 1;
+    return true;
+}
+
 void readPoints(const std::string& file, std::vector<double>& pts) {
-    const std::string buf = slurp(file);
-    Scanner s{buf.data(), buf.data() + buf.size(), file};
+    const FileBuf buf(file);
+    Scanner s{buf.data, buf.data + buf.size, file};
     const Header h = readHeader(s);
     const long long n = s.readInt();
     if (n < 0) s.fail("negative point count");
-    pts.resize((size_t)n * 3);
     if (h.binary) {
         s.skipWs();
-        if (*s.p != '(') s.fail("expected '(' before binary data");
+        if (s.p >= s.end || *s.p != '(') s.fail("expected '(' before binary data");
         ++s.p;
         const size_t bytes = (size_t)n * 3 * h.scalarBytes;
         if ((size_t)(s.end - s.p) < bytes) s.fail("truncated binary point list");
-        if (h.scalarBytes == 8) std::memcpy(pts.data(), s.p, bytes);
+        pts.resize((size_t)n * 3);
+        if (h.scalarBytes == 8) parallelCopy(pts.data(), s.p, bytes);
         else for (long long i = 0; i < 3 * n; ++i) { float v; std::memcpy(&v, s.p + 4 * i, 4); pts[(size_t)i] = v; }
         s.p += bytes;
         s.expect(')');
     } else {
         s.expect('(');
+        if (readPointBodyParallel(s, n, pts)) return;
+        pts.resize((size_t)n * 3);
         for (long long i = 0; i < n; ++i) {
             s.expect('(');
             pts[3 * i] = s.readDouble(); pts[3 * i + 1] = s.readDouble(); pts[3 * i + 2] = s.readDouble();
@@ -282,24 +550,82 @@ void readPoints(const std::string& file, std::vector<double>& pts) {
 }
 
 void readLabelList(const std::string& file, std::vector<int32_t>& out) {
-    const std::string buf = slurp(file);
-    Scanner s{buf.data(), buf.data() + buf.size(), file};
+    const FileBuf buf(file);
+    Scanner s{buf.data, buf.data + buf.size, file};
     const Header h = readHeader(s);
     readLabels(s, h, out);
 }
 
+// n "k(a b ...)" records of an ascii faceList on several threads (s.p behind the outer '('); false: not taken
+static bool readFaceBodyParallel(Scanner& s, long long n, std::vector<int32_t>& off, std::vector<int32_t>& val) {
+    const char* close = lastCloser(s.p, s.end);
+    if (!close) return false;
+    const int parts = ioParts((int64_t)(close - s.p));
+    if (parts <= 1) return false;
+    const auto cut = cutBody(s.p, close, parts, ")");
+    std::vector<std::vector<int32_t>> sizes((size_t)parts), vals((size_t)parts);
+    std::atomic<bool> ok{true};
+    parallelParts(parts, [&](int t) {
+        const char* q = cut[(size_t)t];
+        const char* e = cut[(size_t)t + 1];
+        auto& sz = sizes[(size_t)t];
+        auto& v = vals[(size_t)t];
+        sz.reserve((size_t)(e - q) / 24 + 16);
+        v.reserve((size_t)(e - q) / 6 + 16);
+        auto ws = [&] { while (q < e && plainWs(*q)) ++q; };
+        while (true) {
+            ws();
+            if (q >= e) break;
+            long long k;
+            const char* r = parseInt(q, e, k);
+            if (!r || k < 0) { ok = false; return; }
+            q = r;
+            ws();
+            if (q >= e || *q != '(') { ok = false; return; }
+            ++q;
+            for (long long j = 0; j < k; ++j) {
+                ws();
+                long long x;
+                r = q < e ? parseInt(q, e, x) : nullptr;
+                if (!r) { ok = false; return; }
+                v.push_back((int32_t)x);
+                q = r;
+            }
+            ws();
+            if (q >= e || *q != ')') { ok = false; return; }
+            ++q;
+            sz.push_back((int32_t)k);
+        }
+    });
+    if (!ok) return false;
+    std::vector<size_t> fBase((size_t)parts + 1, 0), vBase((size_t)parts + 1, 0);
+    for (int t = 0; t < parts; ++t) { fBase[(size_t)t + 1] = fBase[(size_t)t] + sizes[(size_t)t].size(); vBase[(size_t)t + 1] = vBase[(size_t)t] + vals[(size_t)t].size(); }
+    if ((long long)fBase.back() != n || vBase.back() > (size_t)INT32_MAX) return false;
+    off.resize((size_t)n + 1);
+    off[0] = 0;
+    parallelParts(parts, [&](int t) {
+        int32_t o = (int32_t)vBase[(size_t)t];
+        int32_t* dst = off.data() + fBase[(size_t)t] + 1;
+        for (int32_t k : sizes[(size_t)t]) { o += k; *dst++ = o; }
+    });
+    joinPieces(val, vals);
+    s.p = close + 1;
+    return true;
+}
+
 static void readFaces(const std::string& file, std::vector<int32_t>& off, std::vector<int32_t>& val) {
-    const std::string buf = slurp(file);
-    Scanner s{buf.data(), buf.data() + buf.size(), file};
+    const FileBuf buf(file);
+    Scanner s{buf.data, buf.data + buf.size, file};
     const Header h = readHeader(s);
     if (h.binary || h.cls == "faceCompactList") {
-        readLabels(s, h, off);     // offsets (nFaces + 1)
-        readLabels(s, h, val);
+        readLabels(s, h, off, false);     // offsets (nFaces + 1)
+        readLabels(s, h, val, true);
         if (off.empty()) off.push_back(0);
         return;
     }
     const long long n = s.readInt();
     s.expect('(');
+    if (readFaceBodyParallel(s, n, off, val)) return;
     off.assign(1, 0);
     off.reserve((size_t)n + 1);
     val.clear();
@@ -315,8 +641,8 @@ static void readFaces(const std::string& file, std::vector<int32_t>& off, std::v
 }
 
 static void readBoundary(const std::string& file, std::vector<PatchInfo>& patches) {
-    const std::string buf = slurp(file);
-    Scanner s{buf.data(), buf.data() + buf.size(), file};
+    const FileBuf buf(file);
+    Scanner s{buf.data, buf.data + buf.size, file};
     readHeader(s);
     const long long n = s.readInt();
     s.expect('(');
@@ -338,28 +664,112 @@ static void readBoundary(const std::string& file, std::vector<PatchInfo>& patche
 }
 
 void readPolyMesh(const std::string& dir, const std::string& pointsDir, PolyMeshData& m) {
+    const bool verbose = std::getenv("SMHOST_IO_VERBOSE") != nullptr;
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!verbose) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[smhost] read %-10s %.3f s (%u threads)\n", what, std::chrono::duration<double>(t1 - t0).count(), ioThreads());
+        t0 = t1;
+    };
     readPoints((pointsDir.empty() ? dir : pointsDir) + "/points", m.points);
+    lap("points");
     readFaces(dir + "/faces", m.faceOffsets, m.facePoints);
+    lap("faces");
     readLabelList(dir + "/owner", m.owner);
+    lap("owner");
     readLabelList(dir + "/neighbour", m.neighbour);
+    lap("neighbour");
     while (!m.neighbour.empty() && m.neighbour.back() < 0) m.neighbour.pop_back();   // old-style padded neighbour list
     readBoundary(dir + "/boundary", m.patches);
     const int32_t nF = (int32_t)m.faceOffsets.size() - 1;
     if ((int32_t)m.owner.size() != nF) throw std::runtime_error(dir + ": owner size does not match the number of faces");
     if (m.neighbour.size() > m.owner.size()) throw std::runtime_error(dir + ": more neighbours than faces");
-    int32_t nc = -1;
-    for (int32_t c : m.owner) nc = std::max(nc, c);
-    for (int32_t c : m.neighbour) nc = std::max(nc, c);
-    m.nCells = nc + 1;
+    auto maxOf = [](const std::vector<int32_t>& v) {
+        const int parts = ioParts((int64_t)v.size());
+        std::vector<int32_t> mx((size_t)parts, -1);
+        parallelParts(parts, [&](int t) {
+            int32_t m0 = -1;
+            for (size_t i = v.size() * (size_t)t / (size_t)parts, e = v.size() * (size_t)(t + 1) / (size_t)parts; i < e; ++i) m0 = std::max(m0, v[i]);
+            mx[(size_t)t] = m0;
+        });
+        return *std::max_element(mx.begin(), mx.end());
+    };
+    m.nCells = std::max(maxOf(m.owner), maxOf(m.neighbour)) + 1;
     const int32_t nP = m.nPoints();
-    for (int32_t v : m.facePoints) if (v < 0 || v >= nP) throw std::runtime_error(dir + "/faces: point label out of range");
+    {
+        const auto& v = m.facePoints;
+        const int parts = ioParts((int64_t)v.size());
+        std::atomic<bool> bad{false};
+        parallelParts(parts, [&](int t) {
+            bool b = false;
+            for (size_t i = v.size() * (size_t)t / (size_t)parts, e = v.size() * (size_t)(t + 1) / (size_t)parts; i < e; ++i) b |= (v[i] < 0 || v[i] >= nP);
+            if (b) bad = true;
+        });
+        if (bad) throw std::runtime_error(dir + "/faces: point label out of range");
+    }
     int32_t expectStart = m.nInternalFaces();
     for (const auto& p : m.patches) {
         if (p.startFace != expectStart || p.nFaces < 0) throw std::runtime_error(dir + "/boundary: patch " + p.name + " is not contiguous");
         expectStart += p.nFaces;
     }
     if (expectStart != nF) throw std::runtime_error(dir + "/boundary: patches do not cover all boundary faces");
+    lap("checks");
 }
+
+namespace {
+// printf("%.*g", precision, v) without the format interpreter: std::to_chars(general, precision) is specified to give exactly
+// those characters in the C locale (tests/test_polymesh_io.py compares the two writers byte for byte); non-finite values and
+// anything to_chars refuses go through snprintf itself
+inline char* putG(char* out, char* cap, double v, int precision) {
+    if (std::isfinite(v)) {
+        const auto r = std::to_chars(out, cap, v, std::chars_format::general, precision);
+        if (r.ec == std::errc()) return r.ptr;
+    }
+    return out + std::snprintf(out, (size_t)(cap - out), "%.*g", precision, v);
+}
+inline char* putInt(char* out, char* cap, long long v) { return std::to_chars(out, cap, v).ptr; }
+
+// n records, record i appended by fmt(i, out) (at most maxRec bytes each), formatted on several threads into per-thread buffers
+// and written behind what f holds so far, in order
+template <class Fmt>
+void writeRecords(FILE* f, const std::string& file, int64_t n, size_t maxRec, Fmt fmt) {
+    const int parts = ioParts(n);
+    std::vector<std::vector<char>> bufs((size_t)parts);
+    parallelParts(parts, [&](int t) {
+        const int64_t b = n * t / parts, e = n * (t + 1) / parts;
+        auto& buf = bufs[(size_t)t];
+        buf.resize(std::max<size_t>((size_t)(e - b) * std::min<size_t>(maxRec, 48) + maxRec, 4096));
+        size_t used = 0;
+        for (int64_t i = b; i < e; ++i) {
+            if (buf.size() - used < maxRec) buf.resize(buf.size() + buf.size() / 2 + maxRec);
+            used = (size_t)(fmt(i, buf.data() + used, buf.data() + buf.size()) - buf.data());
+        }
+        buf.resize(used);
+    });
+    if (parts == 1) {
+        if (!bufs[0].empty() && std::fwrite(bufs[0].data(), 1, bufs[0].size(), f) != bufs[0].size()) throw std::runtime_error("write error on " + file);
+        return;
+    }
+    // every thread writes its own piece at its own offset
+    if (std::fflush(f) != 0) throw std::runtime_error("write error on " + file);
+    const off_t base = ::ftello(f);
+    std::vector<off_t> at((size_t)parts + 1, base);
+    for (int t = 0; t < parts; ++t) at[(size_t)t + 1] = at[(size_t)t] + (off_t)bufs[(size_t)t].size();
+    const int fd = ::fileno(f);
+    if (::ftruncate(fd, at.back()) != 0) throw std::runtime_error("cannot size " + file);
+    parallelParts(parts, [&](int t) {
+        const auto& buf = bufs[(size_t)t];
+        size_t done = 0;
+        while (done < buf.size()) {
+            const ssize_t w = ::pwrite(fd, buf.data() + done, buf.size() - done, at[(size_t)t] + (off_t)done);
+            if (w <= 0) throw std::runtime_error("write error on " + file);
+            done += (size_t)w;
+        }
+    });
+    if (::fseeko(f, at.back(), SEEK_SET) != 0) throw std::runtime_error("write error on " + file);
+}
+}  // namespace
 
 void writePoints(const std::string& dir, const std::string& location, int32_t nPoints, const double* pts, bool binary, int precision) {
     makeDirs(dir);
@@ -370,8 +780,15 @@ void writePoints(const std::string& dir, const std::string& location, int32_t nP
         std::fwrite(pts, sizeof(double), (size_t)nPoints * 3, f);
     } else {
         std::fputc('\n', f);
-        for (int32_t i = 0; i < nPoints; ++i)
-            std::fprintf(f, "(%.*g %.*g %.*g)\n", precision, pts[3 * i], precision, pts[3 * i + 1], precision, pts[3 * i + 2]);
+        const int prec = precision < 0 ? 6 : std::max(precision, 1);      // (printf: "%.0g" means one digit, a negative precision the default)
+        const size_t maxRec = 3 * ((size_t)prec + 32) + 8;
+        writeRecords(f, dir + "/points", nPoints, maxRec, [&](int64_t i, char* o, char* cap) {
+            *o++ = '(';
+            o = putG(o, cap, pts[3 * i], prec); *o++ = ' ';
+            o = putG(o, cap, pts[3 * i + 1], prec); *o++ = ' ';
+            o = putG(o, cap, pts[3 * i + 2], prec); *o++ = ')'; *o++ = '\n';
+            return o;
+        });
     }
     std::fputs(")\n", f);
     writeFooter(f);
@@ -384,7 +801,10 @@ void writeLabelList(const std::string& file, const std::string& location, const 
     writeHeader(f, binary, cls, location, object, note);
     std::fprintf(f, "%lld\n(", (long long)n);
     if (binary) std::fwrite(v, sizeof(int32_t), (size_t)n, f);
-    else { std::fputc('\n', f); for (int64_t i = 0; i < n; ++i) std::fprintf(f, "%d\n", v[i]); }
+    else {
+        std::fputc('\n', f);
+        writeRecords(f, file, n, 16, [&](int64_t i, char* o, char* cap) { o = putInt(o, cap, v[i]); *o++ = '\n'; return o; });
+    }
     std::fputs(")\n", f);
     writeFooter(f);
     closeOut(f, file);
@@ -468,12 +888,15 @@ void writePolyMesh(const std::string& dir, const std::string& location, const Po
             std::fputs(")\n", f);
         } else {
             std::fprintf(f, "%d\n(\n", nF);
-            for (int32_t i = 0; i < nF; ++i) {
+            int32_t widest = 0;
+            for (int32_t i = 0; i < nF; ++i) widest = std::max(widest, m.faceOffsets[i + 1] - m.faceOffsets[i]);
+            writeRecords(f, dir + "/faces", nF, 16 + 12 * (size_t)widest, [&](int64_t i, char* o, char* cap) {
                 const int32_t b = m.faceOffsets[i], e = m.faceOffsets[i + 1];
-                std::fprintf(f, "%d(", e - b);
-                for (int32_t k = b; k < e; ++k) std::fprintf(f, k + 1 < e ? "%d " : "%d", m.facePoints[k]);
-                std::fputs(")\n", f);
-            }
+                o = putInt(o, cap, e - b); *o++ = '(';
+                for (int32_t k = b; k < e; ++k) { o = putInt(o, cap, m.facePoints[k]); if (k + 1 < e) *o++ = ' '; }
+                *o++ = ')'; *o++ = '\n';
+                return o;
+            });
             std::fputs(")\n", f);
         }
         writeFooter(f);

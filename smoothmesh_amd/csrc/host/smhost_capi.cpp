@@ -97,6 +97,14 @@ int smhost_read_label_list(const char* file, int32_t* out, int64_t* n) {
         *n = (int64_t)v.size();
     });
 }
+int smhost_read_points(const char* file, double* out, int64_t* n) {
+    return guarded([&] {
+        std::vector<double> v;
+        readPoints(file, v);
+        if (out && *n >= (int64_t)v.size()) std::memcpy(out, v.data(), v.size() * sizeof(double));
+        *n = (int64_t)v.size();
+    });
+}
 int smhost_read_obj(const char* file, int32_t kind, double* points, int64_t* nPoints, int32_t* elements, int64_t* nElements) {
     return guarded([&] {
         std::vector<double> p;

@@ -151,3 +151,116 @@ def test_obj_readers_on_the_reference_test_cases():
         b = read_obj(f, kind)
         assert len(a[1]) > 0 and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), f
         assert a[1].min() == 0 and a[1].max() == len(a[0]) - 1 if kind == "edges" else a[1].max() < len(a[0])
+
+
+# ---- the several-thread readers / writers (round 6): the same bytes and the same numbers as the serial loops ------------------
+def _run_py(code, env):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r)\n" % root + code], capture_output=True, text=True,
+                       env=dict(os.environ, **env), timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def _nasty_doubles(n, seed=7):
+    """every kind of value the %.{p}g formatter and the decimal parser treat differently: random bit patterns over the whole
+    exponent range, subnormals, exact integers, halves (round-half-even ties at low precision), powers of ten and their
+    neighbours, +-0, huge and tiny magnitudes"""
+    rng = np.random.default_rng(seed)
+    bits = rng.integers(0, 2**63, size=n, dtype=np.uint64) | (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63))
+    v = bits.view(np.float64).copy()
+    v = v[np.isfinite(v)]
+    extra = [0.0, -0.0, 1.0, -1.0, 0.5, 0.25, 0.125, 1.5, 2.5, 1e-5, 1e-4, 9.9999e-5, 0.0001, 123456789.0, 1234567890123456789.0, 1e15, 1e16,
+             1e17, 1e21, 1e22, 1e23, 9007199254740992.0, 9007199254740993.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308,
+             0.1, 0.2, 0.3, 1 / 3, 2 / 3, 1e-10, 0.30000000000000004, 99999.5, 999999.5, 9999995.0, 0.00012345678901234567]
+    extra += [10.0 ** k for k in range(-30, 31)] + [np.nextafter(10.0 ** k, 0) for k in range(-20, 21)] + [np.nextafter(10.0 ** k, np.inf) for k in range(-20, 21)]
+    near = rng.uniform(-2, 2, size=n)             # coordinates of a real mesh
+    return np.concatenate([v, np.array(extra), -np.array(extra), near, np.round(near, 3), np.round(near * 1000)])
+
+
+@pytest.mark.parametrize("precision", [1, 6, 10, 12, 17])
+def test_threaded_point_writer_is_printf_byte_for_byte(tmp_path, precision):
+    """writePoints formats with std::to_chars(general, precision) on several threads; the reference's mesh.write() is printf's
+    %.{precision}g per coordinate (SM.C:2425 sets the precision): the file must be what a one-thread printf loop writes, byte for
+    byte, for every kind of value"""
+    from smoothmesh_amd.polymesh import write_points
+    v = _nasty_doubles(20000)
+    v = v[: (len(v) // 3) * 3].reshape(-1, 3)
+    np.save(tmp_path / "v.npy", v)
+    code = ("import numpy as np; from smoothmesh_amd.polymesh import write_points; "
+            f"write_points({str(tmp_path / 'T')!r}, np.load({str(tmp_path / 'v.npy')!r}), 'T', precision={precision})")
+    _run_py(code, {"SMHOST_IO_THREADS": "7", "SMHOST_IO_GRAIN": "500"})
+    got = open(tmp_path / "T" / "points", "rb").read()
+    body = got[got.index(b"\n(\n") + 3: got.rindex(b"\n)\n") + 1].decode()
+    want = "".join("(%s %s %s)\n" % tuple("%.*g" % (precision, x) for x in row) for row in v)     # Python's % is C's printf
+    assert len(body) == len(want) and body == want
+    # ... and with one thread (the same code without the cutting)
+    code1 = code.replace("'T'", "'S'").replace(str(tmp_path / "T"), str(tmp_path / "S"))
+    _run_py(code1, {"SMHOST_IO_THREADS": "1"})
+    assert open(tmp_path / "S" / "points", "rb").read().replace(b'"S"', b'"T"') == got
+
+
+def test_threaded_ascii_readers_equal_the_serial_ones(tmp_path):
+    """a whole polyMesh directory read with the lists cut into many pieces == read by the serial scanner == what was written;
+    17 digits round-trip every coordinate exactly through the decimal parser (fast path and strtod path alike)"""
+    from smoothmesh_amd.polymesh import cavity_mesh, write_polymesh
+    m = cavity_mesh(8, jitter=0.2, seed=5)
+    m.points[:, :] = _nasty_doubles(m.points.size, seed=11)[: m.points.size].reshape(-1, 3)      # (readers do not look at geometry)
+    d = str(tmp_path / "constant" / "polyMesh")
+    write_polymesh(d, m, binary=False, precision=17)
+    code = ("import numpy as np; from smoothmesh_amd.polymesh import read_polymesh; "
+            f"r = read_polymesh({d!r}); np.savez({str(tmp_path)!r} + '/out_' + TAG, p=r.points, fo=r.faceOffsets, fp=r.facePoints, o=r.owner, n=r.neighbour)")
+    _run_py("TAG = 'par'; " + code, {"SMHOST_IO_THREADS": "13", "SMHOST_IO_GRAIN": "300"})
+    _run_py("TAG = 'ser'; " + code, {"SMHOST_IO_THREADS": "1"})
+    a, b = np.load(tmp_path / "out_par.npz"), np.load(tmp_path / "out_ser.npz")
+    for k in ("p", "fo", "fp", "o", "n"):
+        assert np.array_equal(a[k], b[k]), k
+    assert np.array_equal(a["p"].view(np.uint64), m.points.view(np.uint64))         # bit for bit, -0.0 included
+    assert np.array_equal(a["fo"], m.faceOffsets) and np.array_equal(a["fp"], m.facePoints)
+    assert np.array_equal(a["o"], m.owner) and np.array_equal(a["n"], m.neighbour)
+
+
+def test_decimal_parser_is_strtod(tmp_path):
+    """the point reader's decimal -> double conversion (exact fast path for short mantissas, strtod for the rest) gives Python's
+    float() -- a correctly rounded conversion like glibc's strtod -- for every spelling OpenFOAM or a user may write"""
+    from smoothmesh_amd.polymesh import read_polymesh, write_polymesh
+    from smoothmesh_amd.meshgen import hex_block
+    m = hex_block(2, jitter=0.0)
+    d = str(tmp_path / "constant" / "polyMesh")
+    write_polymesh(d, m)
+    toks = ["0", "-0", "+1", "1.", ".5", "-.5e1", "1e0", "1E+2", "1e-2", "123456789012345678", "1234567890123456789012", "0.1", "0.10000000000000001",
+            "9007199254740993", "9007199254740992e1", "1e22", "1e23", "1e-22", "1e-23", "4.9e-324", "2.4703282292062328e-324", "1.7976931348623157e308",
+            "0.000000000000000000000000000001", "100000000000000000000000", "3.14159265358979323846264338327950288", "1e400", "-1e400", "1e-400",
+            "nan", "inf", "-inf", "12345.678e-3", "00012.5000", "5e-1", "7.0e+00"]
+    rng = np.random.default_rng(3)
+    for _ in range(3000):
+        mant = "".join(rng.choice(list("0123456789"), size=rng.integers(1, 22)))
+        cutp = rng.integers(0, len(mant) + 1)
+        t = ("-" if rng.random() < 0.3 else "") + (mant[:cutp] or "0") + ("." + mant[cutp:] if cutp < len(mant) else "")
+        if rng.random() < 0.5:
+            t += "e%+d" % rng.integers(-330, 330)
+        toks.append(t)
+    while len(toks) % 3:
+        toks.append("0")
+    n = len(toks) // 3
+    body = "".join("(%s %s %s)\n" % tuple(toks[3 * i: 3 * i + 3]) for i in range(n))
+    head = open(os.path.join(d, "points")).read()
+    head = head[: head.index("\n27\n")]
+    with open(os.path.join(d, "points"), "w") as f:
+        f.write(head + "\n%d\n(\n" % n + body + ")\n\n// ***** //\n")
+    from smoothmesh_amd.polymesh import lib, _check, _p
+    import ctypes as C
+    want = np.array([float(t) for t in toks])
+    for env in ({"SMHOST_IO_THREADS": "5", "SMHOST_IO_GRAIN": "200"}, {"SMHOST_IO_THREADS": "1"}):
+        code = ("import numpy as np, ctypes as C; from smoothmesh_amd import polymesh as pm; L = pm.lib(); "
+                f"L.smhost_read_points.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]; n = C.c_int64(-1); "
+                f"assert L.smhost_read_points({os.path.join(d, 'points')!r}.encode(), None, C.byref(n)) == 0, L.smhost_last_error(); "
+                f"a = np.empty(n.value); assert L.smhost_read_points({os.path.join(d, 'points')!r}.encode(), a.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n)) == 0; "
+                f"np.save({str(tmp_path / 'got.npy')!r}, a)")
+        _run_py(code, env)
+        got = np.load(tmp_path / "got.npy")
+        assert got.shape == want.shape
+        same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
+        assert same.all(), [(toks[i], got[i], want[i]) for i in np.nonzero(~same)[0][:5]]
