@@ -412,10 +412,13 @@ def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
     if oracle:
         base, par = oracle_leg(kind, n_side, constraints, eng, prm, budget_s=oracle_budget_s, layers=layers, boundary=boundary)
     t_oracle = time.perf_counter() - t0
+    # near-tie census of everything this engine ran (include/smgpu.h): angle comparisons with sides within 4 ulp -- the decisions
+    # the reference's acos could take the other way; zero = none
+    near = eng.near_ties() if hasattr(eng, "near_ties") else None
     eng.close()
     del eng
     return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_cold=dt_cold, dt_ev=dt_ev,
-                ctr=ctr, sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par,
+                ctr=ctr, sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par, near_ties=near,
                 phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
 
 
@@ -770,6 +773,8 @@ def finalize_line(out):
         g = _gather_brief(e.get("roofline_centroid_gather"))
         if g and g.get("frac_K_cg") is not None:
             b["gather_frac_K_cg"] = g["frac_K_cg"]
+        if e.get("near_ties") is not None:      # angle comparisons within 4 ulp (the reference's acos could decide them the other way)
+            b["near_ties"] = e["near_ties"]["total"]
         if "error" in e:
             b["error"] = e["error"][:200]
         return b
@@ -1081,6 +1086,7 @@ def main():
                     "value": r["total_points"] * Kc / r["dt"], "unit": "points/s",
                     **kernel_report(wl, r["ctr"], Kc, r["dt"], r["dt_ev"], r["sizes"]),
                     "residual_last": float(r["res"][-1]), "nFrozenPoints_last": int(r["frz"][-1]),
+                    "near_ties": r["near_ties"],
                     "phases": r["phases"],
                 }
                 if r["cpu_baseline"]:
@@ -1101,6 +1107,7 @@ def main():
                              "unpinned against a real OpenFOAM build")
         if single:
             out["phases"] = single["phases"]
+            out["near_ties"] = single["near_ties"]
     import resource
     out["host_max_rss_gib"] = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 2**20   # rank 0's process
     code = emit(out)

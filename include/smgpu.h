@@ -64,7 +64,10 @@ typedef struct smgpu_params {
 typedef struct smgpu_iter_stats {
     double residual;
     int32_t nFrozenPoints;
-    int32_t pad;
+    /* Near-tie census of this iteration (0 in a normal run): comparisons of an angle with minAngle / maxAngle or with the point's
+     * current angle (SM.C:923, 1367, 1391-1394, 1421-1424) whose two sides were 1 .. 4 ulp apart.  The engine's acos and the
+     * reference's (glibc) may differ in the last bit, so only such a comparison could be decided differently by the reference. */
+    int32_t nNearTies;
 } smgpu_iter_stats;
 
 /* Mesh sizes derived by the library (for byte accounting and logs). */
@@ -135,6 +138,10 @@ int smgpu_get_points(smgpu_handle* h, double* outPoints /* [3*nPoints] */);
  * The step-wise loop never synchronises on its own; hosts call this at the end of every chunk of iterations (smgpu_get_points
  * does the same check). */
 int smgpu_check_error(smgpu_handle* h);
+/* Near-tie census since smgpu_create (see smgpu_iter_stats::nNearTies; also counted in the step-wise multi-rank loop):
+ * out = {total, edge-angle test SM.C:923, good-range test SM.C:1367, walk verdicts SM.C:1391-1394 / 1421-1424}.  The front-ends
+ * print a warning when the total is not zero.  Window: SMGPU_NEARTIE_ULPS (default 4). */
+int smgpu_get_near_ties(smgpu_handle* h, int64_t out[4]);
 int smgpu_set_points(smgpu_handle* h, const double* points /* [3*nPoints] */);
 
 /* Timing: when enabled every kernel launch is bracketed by hipEvents on the handle's stream. */

@@ -43,6 +43,9 @@ void orc_acos_census(long long* out) {
     out[0] = c.comparisons; out[1] = c.equal; out[2] = c.within8ulp;
     out[3] = (c.minUlp == ~0ull || c.minUlp > 0x7fffffffffffffffull) ? -1 : (long long)c.minUlp;
 }
+// the engine's near-tie census on the oracle's side: window in ulp (default 4), counts by class {SM.C:923, SM.C:1367 per point, walk verdicts}
+void orc_acos_census_window(long long ulps) { censusWindow(ulps < 0 ? 0ull : (unsigned long long)ulps); }
+void orc_acos_census_near(long long* out) { const AcosCensus c = censusGet(); out[0] = c.near[0]; out[1] = c.near[1]; out[2] = c.near[2]; }
 double orc_acos(double x, int variant) { return variant ? smacos::acosX(x) : std::acos(x); }
 void orc_set_foam_variant(void* h, int variant) { static_cast<Domain*>(h)->foamVariant = variant; }
 // syncPointList model of the rank-engine combines below: 0 = master fold (globalMeshData::syncData), 1 = own-value fold

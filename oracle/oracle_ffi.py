@@ -35,6 +35,8 @@ def lib():
         l.orc_get_acos_variant.restype = C.c_int
         l.orc_acos_census_enable.argtypes = [C.c_int]
         l.orc_acos_census.argtypes = [C.POINTER(C.c_longlong)]
+        l.orc_acos_census_window.argtypes = [C.c_longlong]
+        l.orc_acos_census_near.argtypes = [C.POINTER(C.c_longlong)]
         l.orc_acos.restype = C.c_double
         l.orc_acos.argtypes = [C.c_double, C.c_int]
         l.orc_set_foam_variant.argtypes = [C.c_void_p, C.c_int]
@@ -450,6 +452,11 @@ def acos(x, variant="device"):
     return float(lib().orc_acos(float(x), ACOS_VARIANTS[variant]))
 
 
+def acos_census_window(ulps=4):
+    """window of the near-tie classes of acos_census (the engine's SMGPU_NEARTIE_ULPS)"""
+    lib().orc_acos_census_window(int(ulps))
+
+
 def acos_census(enable=None):
     """enable=True: reset and start counting the threshold comparisons of angles (SM.C:923, 1367, 1391-1394, 1421-1424); False: stop.
     Returns {"comparisons", "equal" (both sides the same bits: the same function of the same inputs), "within_8ulp" (sides 1 .. 8 ulp
@@ -459,7 +466,11 @@ def acos_census(enable=None):
         l.orc_acos_census_enable(1 if enable else 0)
     out = (C.c_longlong * 4)()
     l.orc_acos_census(out)
-    return {"comparisons": int(out[0]), "equal": int(out[1]), "within_8ulp": int(out[2]), "min_ulp": None if out[3] < 0 else int(out[3])}
+    near = (C.c_longlong * 3)()
+    l.orc_acos_census_near(near)
+    # near = the engine's near-tie census (include/smgpu.h) counted on the oracle's side: sides 1 .. window ulp apart, by comparison
+    return {"comparisons": int(out[0]), "equal": int(out[1]), "within_8ulp": int(out[2]), "min_ulp": None if out[3] < 0 else int(out[3]),
+            "near": {"edge_angle": int(near[0]), "good_range": int(near[1]), "walk": int(near[2])}}
 
 
 def edge_strings(nPoints, edges):

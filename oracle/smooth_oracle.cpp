@@ -40,7 +40,10 @@ static bool g_censusOn = false;
 void censusEnable(bool on) { g_censusOn = on; }
 void censusReset() { g_census = AcosCensus(); }
 AcosCensus censusGet() { return g_census; }
-static inline void censusNote(double a, double b) {
+static unsigned long long g_censusWindow = 4ull;
+void censusWindow(unsigned long long ulps) { g_censusWindow = ulps; }
+// cls < 0: counted in the totals only (a re-visit of a point the engine's census sees once per iteration)
+static inline void censusNote(double a, double b, int cls) {
     if (!g_censusOn) return;
     ++g_census.comparisons;
     if (!(a == a) || !(b == b)) return;
@@ -53,10 +56,11 @@ static inline void censusNote(double a, double b) {
     // minimum -- which no implementation of acos can tell apart; counted on their own)
     if (d == 0ull) { ++g_census.equal; return; }
     if (d <= 8ull) ++g_census.within8ulp;
+    if (cls >= 0 && d <= g_censusWindow) ++g_census.near[cls];
     if (d < g_census.minUlp) g_census.minUlp = d;
 }
-static inline bool lessC(double a, double b) { censusNote(a, b); return a < b; }
-static inline bool greaterC(double a, double b) { censusNote(a, b); return a > b; }
+static inline bool lessC(double a, double b, int cls) { censusNote(a, b, cls); return a < b; }
+static inline bool greaterC(double a, double b, int cls) { censusNote(a, b, cls); return a > b; }
 
 // SM.C:172-180
 static inline double getPointDistance(const Vec3& coords1, const Vec3& coords2) {
@@ -818,7 +822,7 @@ void Domain::phaseB() {
             eaMinC[pointI] = minCAngle;
             eaMinN[pointI] = minNAngle;
             const double smallAngle = M_PI * prm.minAngle / 180.0;
-            if (lessC(minNAngle, smallAngle) && lessC(minNAngle, minCAngle)) isFrozenPoint[pointI] = 1;
+            if (lessC(minNAngle, smallAngle, 0) && lessC(minNAngle, minCAngle, 0)) isFrozenPoint[pointI] = 1;
         }
     }
     frozenAfterEdgeAngle = isFrozenPoint;
@@ -849,20 +853,23 @@ void Domain::phaseB() {
         // SM.C:1347-1434 stack walk
         std::stack<int> pointStack;
         for (int pointI = 0; pointI < nPoints; ++pointI) pointStack.push(pointI);
+        std::vector<char> rangeSeen(nPoints, 0);
         const double smallAngle = M_PI * prm.minAngle / 180.0;
         const double largeAngle = M_PI * prm.maxAngle / 180.0;
         while (!pointStack.empty()) {
             const int pointI = pointStack.top();
             pointStack.pop();
-            if (greaterC(pointMinAngle[pointI], smallAngle) && lessC(pointMaxAngle[pointI], largeAngle)) continue;
+            const int rangeCls = rangeSeen[pointI] ? -1 : 1;      // (a point pushed again is tested again: the census' class counts points)
+            rangeSeen[pointI] = 1;
+            if (greaterC(pointMinAngle[pointI], smallAngle, rangeCls) && lessC(pointMaxAngle[pointI], largeAngle, rangeCls)) continue;
             const Vec3 cCoords = mp[pointI];
             Vec3 nCoords = newPoints[pointI];
             if (isFrozenPoint[pointI]) nCoords = cCoords;
             if (nCoords != cCoords) {
                 double newMinFaceAngle, newMaxFaceAngle;
                 calcMinMaxFaceAngleForPoint(pointI, nCoords, -1, nCoords, newMinFaceAngle, newMaxFaceAngle);
-                if ((lessC(newMinFaceAngle, smallAngle) && lessC(newMinFaceAngle, pointMinAngle[pointI])) ||
-                    (greaterC(newMaxFaceAngle, largeAngle) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI]))) {
+                if ((lessC(newMinFaceAngle, smallAngle, 2) && lessC(newMinFaceAngle, pointMinAngle[pointI], 2)) ||
+                    (greaterC(newMaxFaceAngle, largeAngle, 2) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI], 2))) {
                     nCoords = cCoords;
                     isFrozenPoint[pointI] = 1;
                 }
@@ -874,8 +881,8 @@ void Domain::phaseB() {
                 double newMinFaceAngle, newMaxFaceAngle;
                 calcMinMaxFaceAngleForPoint(pointI, nCoords, neighPointI, neighCoords, newMinFaceAngle,
                                             newMaxFaceAngle);
-                if ((lessC(newMinFaceAngle, smallAngle) && lessC(newMinFaceAngle, pointMinAngle[pointI])) ||
-                    (greaterC(newMaxFaceAngle, largeAngle) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI]))) {
+                if ((lessC(newMinFaceAngle, smallAngle, 2) && lessC(newMinFaceAngle, pointMinAngle[pointI], 2)) ||
+                    (greaterC(newMaxFaceAngle, largeAngle, 2) && greaterC(newMaxFaceAngle, pointMaxAngle[pointI], 2))) {
                     isFrozenPoint[neighPointI] = 1;
                     pointStack.push(neighPointI);
                 }

@@ -28,7 +28,10 @@ namespace orc {
 void setAcosVariant(int v);
 int acosVariant();
 // census of the threshold comparisons of angles (smooth_oracle.cpp)
-struct AcosCensus { long long comparisons = 0, equal = 0, within8ulp = 0; unsigned long long minUlp = ~0ull; };   // minUlp: over the unequal pairs
+// minUlp: over the unequal pairs.  near[c]: comparisons with sides 1 .. window ulp apart, by class as the engine's near-tie census
+// counts them (include/smgpu.h, smgpu_get_near_ties): 0 = SM.C:923, 1 = SM.C:1367 (once per point and iteration), 2 = SM.C:1391-1394 / 1421-1424
+struct AcosCensus { long long comparisons = 0, equal = 0, within8ulp = 0; unsigned long long minUlp = ~0ull; long long near[3] = {0, 0, 0}; };
+void censusWindow(unsigned long long ulps);
 void censusEnable(bool on);
 void censusReset();
 AcosCensus censusGet();

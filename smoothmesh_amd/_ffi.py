@@ -28,7 +28,7 @@ class Params(C.Structure):
 
 
 class IterStats(C.Structure):
-    _fields_ = [("residual", C.c_double), ("nFrozenPoints", C.c_int32), ("pad", C.c_int32)]
+    _fields_ = [("residual", C.c_double), ("nFrozenPoints", C.c_int32), ("nNearTies", C.c_int32)]
 
 
 class Sizes(C.Structure):
@@ -113,6 +113,7 @@ SYMBOLS = {
     "smgpu_iterate": (C.c_int, [C.c_void_p, C.c_int32, C.c_double, C.POINTER(IterStats), c_i32p]),
     "smgpu_get_points": (C.c_int, [C.c_void_p, c_f64p]),
     "smgpu_check_error": (C.c_int, [C.c_void_p]),
+    "smgpu_get_near_ties": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "smgpu_set_points": (C.c_int, [C.c_void_p, c_f64p]),
     "smgpu_enable_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "smgpu_get_counters": (C.c_int, [C.c_void_p, C.POINTER(Counters)]),

@@ -1189,6 +1189,17 @@ int main(int argc, char** argv) {
         if (done == 0) break;
     }
 
+    // Near-tie census (include/smgpu.h): the engine's acos may differ from the reference's in the last bit, so only an angle
+    // comparison with sides a few ulp apart could have been decided the other way by the reference -- say so when there was one
+    {
+        int64_t nt[4] = {0, 0, 0, 0};
+        check(smgpu_get_near_ties(K0.h, nt), "smgpu_get_near_ties");
+        const long tot = g_comm.reduceSum((long)nt[0]);
+        if (tot > 0)
+            OUT("WARNING: %ld angle comparison(s) of this run had their two sides within 4 ulp of each other (edge angle %lld, face-angle range %lld, "
+                "face-angle walk %lld on the master): the reference's acos may decide such a comparison the other way\n",
+                tot, (long long)nt[1], (long long)nt[2], (long long)nt[3]);
+    }
     if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); syncExchangeStream(); NCCLCHK(ncclCommDestroy(nccl)); }
     if (transport == TRANSPORT_PUSH && opt.parallel) {
         HIPCHK(hipStreamSynchronize(engineStream));

@@ -44,6 +44,7 @@ struct Accum {                 // device-side loop state
     int stop;                  // set once residual < relTol (SM.C:2401)
     int err;                   // 1 = fewer than two closest points (SM.C:354-362), 2 = too many sharing ranks, 3 = walk barrier timed out
     int nFaPts, nFaEdges;      // face-angle pass: points / edges listed for the exact evaluation (this iteration; adjacent: one scan writes both)
+    int nNearTies;             // angle comparisons of this iteration whose two sides were 1 .. Prm::nearUlps ulp apart (noteNear below)
 };
 
 // Peer-store transport of the shared-point records (multi-rank; smgpu_halo_set_push).  Every rank maps its peers' receive
@@ -264,6 +265,7 @@ struct State {
     PushView push;             // multi-rank, peer-store transport (smgpu_halo_set_push): all NULL = the host moves the records
     int* nActiveHost;          // pinned host word (or NULL): the end-of-iteration reduction leaves the iteration's nActive there,
                                // from which the host re-decides the walk's replay form (smgpu.hip:updateWalkMode)
+    unsigned long long* nearTotal;   // [3] near-tie census since smgpu_create, by comparison: 0 = SM.C:923, 1 = SM.C:1367, 2 = SM.C:1391-1394 / 1421-1424
 };
 
 struct Prm {
@@ -273,6 +275,7 @@ struct Prm {
     float faCosLo, faCosHi;          // the f32 face-angle filter's thresholds on the cosine of an angle sum (kernels_filter.hpp)
     int layersOn;                    // boundary layer treatment enabled (SM.C:2024-2028)
     int bndOn;                       // boundary point smoothing enabled (SM.C:2080-2093): kernels_boundary.hpp
+    long long nearUlps;              // near-tie window in ulp (default 4; SMGPU_NEARTIE_ULPS), see noteNear
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -283,6 +286,28 @@ __device__ __forceinline__ double clampAcos(double cosA) {
     const double t = (cosA < MAXC) ? cosA : MAXC;
     const double c = (-MAXC < t) ? t : -MAXC;
     return smacos::acosX(c);      // (a fixed sequence of IEEE operations the checker can repeat bit for bit: smacos.hpp)
+}
+// Near-tie census.  The engine's acos (smacos.hpp) and glibc's -- the reference's -- differ in the last bit for ~6 % of the
+// arguments, so a comparison of an angle with a threshold or with another angle (SM.C:923, 1367, 1391-1394, 1421-1424) whose two
+// sides are only a few ulp apart could be decided the other way by the reference.  Every such comparison the exact kernels make
+// is counted (sides with EQUAL bits are the same function of the same inputs on both sides and are not): per iteration in
+// smgpu_iter_stats::nNearTies, since create in smgpu_get_near_ties.  Zero -- the normal case -- means no decision of the run hung
+// on a last bit.  Elements the f32 filters decide are not counted: their margins are many orders of magnitude wider.
+// (angles and thresholds are positive finite doubles: they order like their bit patterns)
+__device__ __forceinline__ int nearTie(double a, double b, long long ulps) {
+    const long long d = __double_as_longlong(a) - __double_as_longlong(b);
+    return (d != 0 && (d < 0 ? -d : d) <= ulps) ? 1 : 0;
+}
+__device__ __forceinline__ void noteNear(const State& s, int cls, int n) {
+    if (n) { atomicAdd(&s.acc->nNearTies, n); if (s.nearTotal) atomicAdd(&s.nearTotal[cls], (unsigned long long)n); }
+}
+// the comparisons of `(mn < small && mn < curMin) || (mx > large && mx > curMax)` the reference evaluates (short circuits included)
+__device__ __forceinline__ int nearVerdict(double mn, double mx, double curMin, double curMax, const Prm& prm) {
+    int n = nearTie(mn, prm.smallAngle, prm.nearUlps);
+    bool first = false;
+    if (mn < prm.smallAngle) { n += nearTie(mn, curMin, prm.nearUlps); first = mn < curMin; }
+    if (!first) { n += nearTie(mx, prm.largeAngle, prm.nearUlps); if (mx > prm.largeAngle) n += nearTie(mx, curMax, prm.nearUlps); }
+    return n;
 }
 __device__ __forceinline__ V3 unitTo(const V3& from, const V3& to) {
     const V3 v = to - from;
@@ -643,6 +668,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle(MeshView m, State s, Prm 
         if (nAngle < minN) minN = nAngle;
     }
     if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
+    noteNear(s, 0, nearTie(minN, prm.smallAngle, prm.nearUlps) + ((minN < prm.smallAngle) ? nearTie(minN, minC, prm.nearUlps) : 0));
 }
 
 // restrictMinEdgeAngleDecrease SM.C:900-930, wave-cooperative form: 4 lanes per point (measured best of 2, 4, 8).
@@ -736,6 +762,7 @@ __global__ void __launch_bounds__(kBlock) k_edge_angle_coop(MeshView m, State s,
     if (active && g == 0 && nf > 0) {
         const double minC = ang;
         if ((minN < prm.smallAngle) && (minN < minC)) s.frozen[p] = 1;
+        noteNear(s, 0, nearTie(minN, prm.smallAngle, prm.nearUlps) + ((minN < prm.smallAngle) ? nearTie(minN, minC, prm.nearUlps) : 0));
     }
 }
 
@@ -1018,6 +1045,7 @@ __device__ __forceinline__ void faPointMinMax(const MeshView& m, const State& s,
     s.ptMin[p] = mn;
     s.ptMax[p] = mx;
     const bool good = (mn > prm.smallAngle) && (mx < prm.largeAngle);
+    noteNear(s, 1, nearTie(mn, prm.smallAngle, prm.nearUlps) + ((mn > prm.smallAngle) ? nearTie(mx, prm.largeAngle, prm.nearUlps) : 0));
     s.faActive[p] = good ? 0 : s.faGen;
     // one add per wave (the lanes that are here together), not one per point: 136 k same-address atomics per iteration on the
     // 10 M-cell cavity mesh otherwise
@@ -1067,6 +1095,7 @@ __global__ void __launch_bounds__(kBlock) k_fa_pred(MeshView m, State s, Prm prm
     const V3 np = ldv(s.prop, p);
     const double curMin = s.ptMin[p], curMax = s.ptMax[p];
     auto bad = [&](double mn, double mx) {
+        noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
         return ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
     };
     const bool moved = (np != cur);
@@ -1192,6 +1221,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_swap(MeshView m, State s, Prm 
 // End of iteration: reduce the workgroup partials, publish the log-line values (SM.C:2396), stop test
 // (SM.C:2401), reset accumulators.  One workgroup of 1024 threads, 4 independent loads in flight per thread.
 constexpr int kFinishBlock = 1024;
+constexpr int kStatsWritten = 1 << 30;
 // the reduction by one workgroup of T threads (all of them call it)
 template <int T>
 __device__ __forceinline__ void finishPartials(const State& s, int nPartials, int iter, double relTol, double* localStats,
@@ -1223,7 +1253,8 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     if (threadIdx.x != 0) return;
     for (int i = 1; i < T / 64; ++i) { d = (shMax[i] > d) ? shMax[i] : d; c += shCnt[i]; }
     const double res = d;
-    if (s.stats && iter >= 0) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].pad = 1; }
+    // (nNearTies on the device: bit 30 = "record written" for the host's read-back, the count below it)
+    if (s.stats && iter >= 0) { s.stats[iter].residual = res; s.stats[iter].nFrozenPoints = c; s.stats[iter].nNearTies = kStatsWritten | (a->nNearTies < kStatsWritten ? a->nNearTies : kStatsWritten - 1); }
     if (localStats) { localStats[0] = res; localStats[1] = (double)c; }
     if (history) { history[0] = res; history[1] = (double)c; }
     if (res < relTol) a->stop = 1;
@@ -1233,6 +1264,7 @@ __device__ __forceinline__ void finishPartials(const State& s, int nPartials, in
     a->nFaMaybe = 0;
     a->nFaEdges = 0;
     a->nFaPts = 0;
+    a->nNearTies = 0;
 }
 __global__ void __launch_bounds__(kFinishBlock) k_finish(State s, int nPartials, int iter, double relTol, double* localStats,
                                                           double* history) {

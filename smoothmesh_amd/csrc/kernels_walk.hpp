@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred_self(MeshView m, State s, 
             groupPointFaceAngles(m, s, p, np, -1, np, lane, mn, mx);
             const double curMin = s.ptMin[p], curMax = s.ptMax[p];
             if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) sb |= 1;
+            if (lane == 0) noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
         }
         if (lane == 0) w.actBits[t] = sb | (onlyLeft ? kStarLeft : 0);
     }
@@ -260,12 +261,14 @@ __global__ void __launch_bounds__(kBlock) k_walk_pred(MeshView m, State s, Prm p
             double mn, mx;
             groupPointFaceAngles(m, s, p, cur, q, nq, lane, mn, mx);   // this point held at its current position
             const bool badF = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+            if (lane == 0) noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
             if (badF) nb |= 2;
             if (!(sb & 2)) { if (badF) nb |= 1; }           // not moved: proposal = current position
             else if (!(sb & 5)) {                           // acts from its proposal if it is still free at its first visit, SM.C:1419
                 const V3 np = ldv(s.prop, p);
                 groupPointFaceAngles(m, s, p, np, q, nq, lane, mn, mx);
                 if (((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax))) nb |= 1;
+                if (lane == 0) noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
             }
         }
         if (lane == 0) { w.entBits[e] = nb; w.entSlot[e] = activeSlotOf(s, w, q); }
@@ -554,6 +557,7 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
             starReduce(counts, angle, mn, mx);
             const double curMin = L.pMin, curMax = L.pMax;
             const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));   // SM.C:1391-1399, 1421-1427
+            if (hl == 0) noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
             if (j == 0) {
                 if (selfNeeded && isBad) sbits |= 1u;                // (the reduction leaves mn / mx in every lane of the half)
                 if (moved && !(sbits & 5u) && nEl > 0) {             // p can act from its proposal: the proposal-state jobs
@@ -710,7 +714,7 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
 
 // the jobs W.jcode[0 .. nJobs) of the wave (phase 0: self tests and current-position entries; phase 1: proposal-position entries):
 // tasks dealt to the lanes, per-job min / max, verdicts into the halves' tables.  Called by all 64 lanes.
-__device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int phase, const Prm& prm) {
+__device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int phase, const Prm& prm, const State& s) {
     const unsigned long long twoPi = (unsigned long long)__double_as_longlong(2.0 * SMGPU_PI);
     // lane t = job t: its places, their number, the running offsets
     unsigned M = 0u;
@@ -772,6 +776,7 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
         const double mn = __longlong_as_double((long long)W.jmin[lane]), mx = __longlong_as_double((long long)W.jmax[lane]);
         const double curMin = W.h[h].pMin, curMax = W.h[h].pMax;
         const bool isBad = ((mn < prm.smallAngle) && (mn < curMin)) || ((mx > prm.largeAngle) && (mx > curMax));
+        noteNear(s, 2, nearVerdict(mn, mx, curMin, curMax, prm));
         if (isBad) {
             if (e == 127) W.selfBad[h] = 1;
             else {
@@ -1011,7 +1016,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         if (eligible && live) W.jcode[jb + first + myRank] = (unsigned char)((half << 7) | hl);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        packRunJobs(W, lane, nJ0 + nJ1, 0, prm);
+        packRunJobs(W, lane, nJ0 + nJ1, 0, prm, s);
         // what phase 1 decided: the self tests; then whether the point can act from its proposal at all (SM.C:1376-1399)
         if (selfNeeded && W.selfBad[half]) sbits |= 1u;
         const bool propJobs = live && moved && !(sbits & 5u) && nEl > 0;
@@ -1024,7 +1029,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             if (propJobs && eligible) W.jcode[pb + myRank] = (unsigned char)((half << 7) | hl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            packRunJobs(W, lane, nP0 + nP1, 1, prm);
+            packRunJobs(W, lane, nP0 + nP1, 1, prm, s);
         }
         if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
         const int nJobs = nJ + nP;

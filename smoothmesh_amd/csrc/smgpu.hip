@@ -272,6 +272,8 @@ static Prm makePrm(const smgpu_handle* h) {
     const double M = (double)kFaMargin + 2.0e-5;
     r.faCosLo = (r.smallAngle >= SMGPU_PI) ? -2.0f : (float)(std::cos(std::max(r.smallAngle, 0.0)) - M);
     r.faCosHi = (r.largeAngle <= 0.0) ? 2.0f : (float)(std::cos(std::min(r.largeAngle, SMGPU_PI)) + M);
+    static const long long nearUlps = [] { const char* e = std::getenv("SMGPU_NEARTIE_ULPS"); return e ? std::max(0ll, std::atoll(e)) : 4ll; }();   // (tests widen the window to see the census count)
+    r.nearUlps = nearUlps;
     return r;
 }
 
@@ -960,6 +962,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     rc |= devAlloc(h, &s.faN, t.pointPoints.size());
     rc |= devAlloc(h, &s.walkStack, P + 64);
     rc |= devAlloc(h, &s.acc, 1);
+    rc |= devAlloc(h, &s.nearTotal, 4);
     {
         // + the boundary points' partials when k_bnd_fix finishes them (smgpu_set_boundary_smoothing)
         const size_t nPart = (size_t)std::max(gridFor(t.nPoints), h->useTiles ? h->stl.nTiles : 0) + 2 * (size_t)gridFor(t.nPoints) + 1;
@@ -969,6 +972,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (rc) return cleanup(1);
     lapC("work arrays allocated");
     if (hipMemset(s.acc, 0, sizeof(Accum)) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    if (hipMemset(s.nearTotal, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemset(s.frozen, 0, P) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemcpy(h->bufA, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail("upload of points failed"));
@@ -1825,8 +1829,8 @@ int smgpu_iterate(smgpu_handle* h, int32_t nIters, double relTol, smgpu_iter_sta
     HIP_OK(hipMemcpyAsync(hs.data(), h->dStats, sizeof(smgpu_iter_stats) * (size_t)launched, hipMemcpyDeviceToHost, h->stream));
     if (checkDeviceError(h)) return 1;
     int done = 0;
-    while (done < launched && hs[done].pad == 1) ++done;
-    for (int i = 0; i < done; ++i) hs[i].pad = 0;
+    while (done < launched && (hs[done].nNearTies & kStatsWritten)) ++done;
+    for (int i = 0; i < done; ++i) hs[i].nNearTies &= kStatsWritten - 1;
     if (stats) std::memcpy(stats, hs.data(), sizeof(smgpu_iter_stats) * (size_t)done);
     if (nDone) *nDone = done;
     // the coordinates of iteration `done` live in buf1 when done is odd, buf0 when even
@@ -1882,6 +1886,17 @@ int smgpu_get_points(smgpu_handle* h, double* out) {
     // barrier or peer-store wait that timed out, a point without usable neighbours ...) surfaces here at the latest, with the
     // coordinates it spoiled
     return checkDeviceError(h);
+}
+
+int smgpu_get_near_ties(smgpu_handle* h, int64_t out[4]) {
+    if (!h || !out) return fail("null argument");
+    HIP_OK(hipSetDevice(h->device));
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_OK(hipMemcpyAsync(v, h->st.nearTotal, sizeof(v), hipMemcpyDeviceToHost, h->stream));
+    HIP_OK(hipStreamSynchronize(h->stream));
+    out[1] = (int64_t)v[0]; out[2] = (int64_t)v[1]; out[3] = (int64_t)v[2];
+    out[0] = out[1] + out[2] + out[3];
+    return 0;
 }
 
 int smgpu_check_error(smgpu_handle* h) {

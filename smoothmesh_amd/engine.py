@@ -357,7 +357,16 @@ class SmoothEngine:
         n = nDone.value
         res = np.array([stats[i].residual for i in range(n)], dtype=np.float64)
         frz = np.array([stats[i].nFrozenPoints for i in range(n)], dtype=np.int64)
+        self.last_near_ties = np.array([stats[i].nNearTies for i in range(n)], dtype=np.int64)     # per iteration of this call
         return n, res, frz
+
+    def near_ties(self):
+        """Near-tie census since the engine was created (include/smgpu.h, smgpu_get_near_ties): {"total", "edge_angle" (SM.C:923),
+        "good_range" (SM.C:1367), "walk" (SM.C:1391-1394 / 1421-1424)} -- angle comparisons whose two sides were 1 .. 4 ulp apart,
+        i.e. decisions the reference's acos could have taken the other way.  All zero in a normal run."""
+        out = (C.c_int64 * 4)()
+        self._check(self._lib.smgpu_get_near_ties(self._h, out))
+        return {"total": int(out[0]), "edge_angle": int(out[1]), "good_range": int(out[2]), "walk": int(out[3])}
 
     def check_error(self):
         """wait for the engine's stream and raise SmgpuError for any error word a kernel has raised (include/smgpu.h)"""

@@ -223,6 +223,7 @@ def test_bench_single_gpu_line_carries_the_other_configs(tmp_path):
     assert c_["parity_check"]["ok"] and c_["parity_check"]["bitwise_equal"] and c_["detail"]
     assert [c["workload"] for c in c_["configs_summary"]] == ["hex12", "hex12c", "cavity10c"]
     assert all(c["dominant_kernel"] and c["roofline_frac"] > 0 for c in c_["configs_summary"])
+    assert all(c["near_ties"] == 0 for c in c_["configs_summary"])      # no decision of these runs hung on a last bit of an angle
     d = json.load(open(tmp_path / "detail.json"))          # the full document
     assert d["n_gpus"] == 1 and d["cpu_baseline"]["kind"] == "port" and d["roofline"]["frac"] > 0
     assert [c["workload"] for c in d["configs"]] == ["hex12c", "cavity10c"]

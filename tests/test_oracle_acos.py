@@ -82,3 +82,32 @@ def test_both_acos_variants_lead_to_the_same_decisions(oracle_lib, k):
 
 def frozen_busy(frz):
     return int(np.max(frz)) > 0
+
+
+def test_near_tie_classes_of_the_census(oracle_lib):
+    """the engine's near-tie census (include/smgpu.h: smgpu_iter_stats::nNearTies, smgpu_get_near_ties) counted on the oracle's side:
+    by comparison (SM.C:923 / 1367 / walk verdicts), sides 1 .. window ulp apart.  With the default window (4 ulp) nothing on these
+    meshes; a window as wide as the doubles catches every comparison with unequal sides, class by class"""
+    from smoothmesh_amd import default_params
+    name, mesh, over, iters = _cases()[1]            # the block with the thresholds at its own right angles
+    o = oracle_lib.Oracle(mesh)
+    o.set_params(default_params(o.mesh_stats()[0], edgeAngleConstraint=True, faceAngleConstraint=True, **over))
+    try:
+        oracle_ffi.acos_census_window(4)
+        oracle_ffi.acos_census(True)
+        o.iterate(2, 0.0)
+        c4 = oracle_ffi.acos_census(False)
+        assert c4["near"] == {"edge_angle": 0, "good_range": 0, "walk": 0} and c4["within_8ulp"] == 0
+        o.set_points(mesh.points)
+        oracle_ffi.acos_census_window(2 ** 62)
+        oracle_ffi.acos_census(True)
+        o.iterate(2, 0.0)
+        cw = oracle_ffi.acos_census(False)
+    finally:
+        oracle_ffi.acos_census_window(4)
+        o.close()
+    near = cw["near"]
+    assert near["edge_angle"] > mesh.nPoints // 2 and near["good_range"] >= mesh.nPoints and near["walk"] > 0
+    # every comparison with unequal sides is in exactly one class, except re-visits of a point by the walk (SM.C:1367 again)
+    assert sum(near.values()) <= cw["comparisons"] - cw["equal"]
+    assert near["good_range"] <= 2 * 2 * mesh.nPoints          # at most two comparisons per point and iteration
