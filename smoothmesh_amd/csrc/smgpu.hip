@@ -375,6 +375,13 @@ static bool swapApplyOn(const smgpu_handle* h) {
            envInt("SMGPU_APPLY_SWAP", 1);
 }
 
+// ... and in the step-wise multi-rank loop with the constraints on (smgpu_iter_end): the OR of the received freeze flags first
+// (k_halo_orF, SM.C:2374), then the same pointer swap -- k_apply cost 117 us per iteration on configs[4]'s rank against 40
+static bool swapApplyHalo(const smgpu_handle* h) {
+    return (h->prm.edgeAngleConstraint || h->prm.faceAngleConstraint) && h->useTiles && !h->bndOn && !h->layersOn && h->haloOn && h->dStepSqr &&
+           envInt("SMGPU_APPLY_SWAP", 1);
+}
+
 static void computeAlgoBytes(smgpu_handle* h) {
     const Topology& t = h->topo;
     const int64_t P = t.nPoints, C = t.nCells, F = t.nFaces, E = t.nEdges;
@@ -2468,6 +2475,7 @@ int smgpu_iter_begin(smgpu_handle* h) {
         HIP_OK(hipStreamSynchronize(h->stream));
         if (pushBuildTables(h)) return 1;
     }
+    h->st.stepSqr = swapApplyHalo(h) ? h->dStepSqr : nullptr;      // (decided per iteration: parameters and the optional features may change between calls)
     h->mergedIter = mergedOk(h);
     if (h->mergedIter) {      // geometry and exchange A's pack in one launch
         if (h->useExch && ensureFlagView(h)) return 1;
@@ -2622,6 +2630,7 @@ int smgpu_iter_end(smgpu_handle* h) {
     const bool fused = !h->prm.edgeAngleConstraint && !h->prm.faceAngleConstraint;
     const bool fusedTiles = fused && h->useTiles;
     const bool flg = flagged(h);
+    const bool swapHalo = !fusedTiles && s.stepSqr != nullptr;      // (as smgpu_iter_begin decided for this iteration)
     if (flg) { if (flagRelay(h, 17, -1)) return 1; }      // behind exchange F: the fix role / k_shared_fix polls it
     else if (computeAfterExch(h)) return 1;      // exchange F has been enqueued by the host
     s.stats = nullptr;                      // per-iteration results go to localStats in this mode
@@ -2641,8 +2650,14 @@ int smgpu_iter_end(smgpu_handle* h) {
                     hipLaunchKernelGGL(k_halo_orF, dim3(gridFor(h->nShared)), dim3(kBlock), 0, h->stream, h->nShared, h->dSharedLocal,
                                        h->dCombOff, h->dCombSlots, h->recvF, h->st.frozen, pushWaitOf(h, 1));
                 })) return 1;
-        if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
-        nPart = gridFor(m.nPoints);
+        if (swapHalo) {
+            const int gSwap = (int)((m.nPoints + (int64_t)kApplyPer * kBlock - 1) / ((int64_t)kApplyPer * kBlock));
+            if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply_swap, dim3(gSwap), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+            nPart = gSwap;
+        } else {
+            if (launchK(h, K_APPLY, [&] { hipLaunchKernelGGL(k_apply, dim3(gridFor(m.nPoints)), dim3(kBlock), 0, h->stream, m, s, prm); })) return 1;
+            nPart = gridFor(m.nPoints);
+        }
     }
     // relTol = -1: the stop decision needs the all-rank residual and is the host's (SM.C:1567,2401)
     double* hist = (h->statsHistory && h->statsHistoryCap > 0) ? h->statsHistory + 2 * (size_t)(h->statsHistoryN++ % h->statsHistoryCap) : nullptr;
@@ -2651,7 +2666,8 @@ int smgpu_iter_end(smgpu_handle* h) {
     if (hist && fusedTiles && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
         h->deferN = nPart; h->deferIter = -1 /* no stats[] record in this mode */; h->deferLocal = h->localStats; h->deferHist = hist;
     } else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
-    std::swap(h->st.ptsCur, h->st.ptsNext);
+    if (swapHalo) std::swap(h->st.ptsCur, h->st.prop);      // the proposal array is the next coordinates (k_apply_swap restored the points that stay)
+    else std::swap(h->st.ptsCur, h->st.ptsNext);
     h->haloIter++;
     h->interiorDone = false;
     // (flagged arrangement with a stats history: nobody reads localStats per iteration, and an exchange stream that waited for the

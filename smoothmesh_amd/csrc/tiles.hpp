@@ -117,7 +117,7 @@ struct SmoothTilesDev {
     bool valid = false;
 };
 // the corner chains of all points computed ahead of the tables (tiles_dev.hip: startCornerChains)
-struct CornerChains { int* chPrev = nullptr; int* chNext = nullptr; int* bad = nullptr; void* stream = nullptr; int32_t nPoints = 0; bool started = false; };
+struct CornerChains { int* chPrev = nullptr; int* chNext = nullptr; int* bad = nullptr; int* big = nullptr; void* stream = nullptr; int32_t nPoints = 0; bool started = false; };
 int startCornerChains(const DeviceTopologyArrays& td, int32_t nPoints, int device, CornerChains& c, std::string& why);
 void releaseCornerChains(CornerChains& c);
 // (maxPointPoints: Topology's; the neighbour-pair masks exist while it is <= 16; chains: taken over and freed, or NULL)

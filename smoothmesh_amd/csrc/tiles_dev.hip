@@ -253,72 +253,147 @@ __global__ void __launch_bounds__(kT) k_tl_remap(long long n, int* __restrict__ 
 // The face corners of every point in the order of Euler trails: tiles.cpp's chainCorners, statement for statement (the order is part
 // of the tables' bytes), one thread per point on arrays in its private memory.  It depends on the point only, not on the tiling:
 // one pass over the points, the tile kernel below maps the result to local indices.
-constexpr int kCh = 64;                 // corners (= faces) per point this kernel handles; a mesh beyond goes back to the host build
+constexpr int kCh = 64;                 // corners (= faces) per point the kernels handle; a mesh beyond goes back to the host build
+constexpr int kChLds = 16;              // ... per point of the LDS form (hex meshes: 12, the castellated polyhedral meshes: <= 16 for nearly all)
+// the working arrays of one point's walk, as the two kernels below hold them: arrays in the thread's private (scratch) memory, or
+// columns of LDS arrays (element i of lane l at [i][l]: bank-conflict free)
+template <int CH>
+struct ChainPrivate {
+    int verts_[2 * CH];
+    uint8_t ea_[2 * CH], eb_[2 * CH], deg_[2 * CH], used_[2 * CH], stackV_[2 * CH + 1], compE_[2 * CH], compV_[2 * CH], adjEdge_[4 * CH];
+    short stackE_[2 * CH + 1];
+    unsigned short adjOff_[2 * CH + 1], next_[2 * CH];
+    __device__ __forceinline__ int& verts(int i) { return verts_[i]; }
+    __device__ __forceinline__ uint8_t& ea(int i) { return ea_[i]; }
+    __device__ __forceinline__ uint8_t& eb(int i) { return eb_[i]; }
+    __device__ __forceinline__ uint8_t& deg(int i) { return deg_[i]; }
+    __device__ __forceinline__ uint8_t& used(int i) { return used_[i]; }
+    __device__ __forceinline__ uint8_t& stackV(int i) { return stackV_[i]; }
+    __device__ __forceinline__ uint8_t& compE(int i) { return compE_[i]; }
+    __device__ __forceinline__ uint8_t& compV(int i) { return compV_[i]; }
+    __device__ __forceinline__ uint8_t& adjEdge(int i) { return adjEdge_[i]; }
+    __device__ __forceinline__ short& stackE(int i) { return stackE_[i]; }
+    __device__ __forceinline__ unsigned short& adjOff(int i) { return adjOff_[i]; }
+    __device__ __forceinline__ unsigned short& next(int i) { return next_[i]; }
+};
+template <int CH>
+struct ChainLdsBlock {       // one wave's arrays (64 lanes)
+    int verts[2 * CH][64];
+    uint8_t ea[2 * CH][64], eb[2 * CH][64], deg[2 * CH][64], used[2 * CH][64], stackV[2 * CH + 1][64], compE[2 * CH][64], compV[2 * CH][64], adjEdge[4 * CH][64];
+    short stackE[2 * CH + 1][64];
+    unsigned short adjOff[2 * CH + 1][64], next[2 * CH][64];
+};
+template <int CH>
+struct ChainLds {
+    ChainLdsBlock<CH>* B; int l;
+    __device__ __forceinline__ int& verts(int i) { return B->verts[i][l]; }
+    __device__ __forceinline__ uint8_t& ea(int i) { return B->ea[i][l]; }
+    __device__ __forceinline__ uint8_t& eb(int i) { return B->eb[i][l]; }
+    __device__ __forceinline__ uint8_t& deg(int i) { return B->deg[i][l]; }
+    __device__ __forceinline__ uint8_t& used(int i) { return B->used[i][l]; }
+    __device__ __forceinline__ uint8_t& stackV(int i) { return B->stackV[i][l]; }
+    __device__ __forceinline__ uint8_t& compE(int i) { return B->compE[i][l]; }
+    __device__ __forceinline__ uint8_t& compV(int i) { return B->compV[i][l]; }
+    __device__ __forceinline__ uint8_t& adjEdge(int i) { return B->adjEdge[i][l]; }
+    __device__ __forceinline__ short& stackE(int i) { return B->stackE[i][l]; }
+    __device__ __forceinline__ unsigned short& adjOff(int i) { return B->adjOff[i][l]; }
+    __device__ __forceinline__ unsigned short& next(int i) { return B->next[i][l]; }
+};
+template <class W>
+__device__ __forceinline__ int chainLowerBound(W& w, int n, int x) {      // (lowerBound on w.verts)
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (w.verts(mid) < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// the chain of point p's n >= 2 corners (rows b .. b + n of pfPrev / pfNext) into chPrev / chNext.  The trail's edges go straight
+// to the output rows (there are never more than n of them); a walk that does not return all n corners leaves the input order.
+template <class W>
+__device__ __forceinline__ void chainOfPoint(W& w, int b, int n, const int* __restrict__ pfPrev, const int* __restrict__ pfNext, int* __restrict__ chPrev, int* __restrict__ chNext) {
+    for (int k = 0; k < n; ++k) { w.verts(2 * k) = pfPrev[b + k]; w.verts(2 * k + 1) = pfNext[b + k]; }
+    for (int i = 1; i < 2 * n; ++i) { const int x = w.verts(i); int j = i - 1; while (j >= 0 && w.verts(j) > x) { w.verts(j + 1) = w.verts(j); --j; } w.verts(j + 1) = x; }
+    int nv = 0;
+    for (int i = 0; i < 2 * n; ++i) if (i == 0 || w.verts(i) != w.verts(i - 1)) { const int x = w.verts(i); w.verts(nv++) = x; }
+    for (int k = 0; k < n; ++k) { w.ea(k) = (uint8_t)chainLowerBound(w, nv, pfPrev[b + k]); w.eb(k) = (uint8_t)chainLowerBound(w, nv, pfNext[b + k]); }
+    for (int v = 0; v < nv; ++v) w.deg(v) = 0;
+    for (int e = 0; e < n; ++e) { ++w.deg(w.ea(e)); ++w.deg(w.eb(e)); }
+    int ne = n, pending = -1;
+    for (int v = 0; v < nv; ++v)
+        if (w.deg(v) & 1) {
+            if (pending < 0) pending = v;
+            else { w.ea(ne) = (uint8_t)pending; w.eb(ne) = (uint8_t)v; ++ne; ++w.deg(pending); ++w.deg(v); pending = -1; }
+        }
+    for (int v = 0; v <= nv; ++v) w.adjOff(v) = 0;
+    for (int e = 0; e < ne; ++e) { ++w.adjOff(w.ea(e) + 1); ++w.adjOff(w.eb(e) + 1); }
+    for (int v = 0; v < nv; ++v) w.adjOff(v + 1) = (unsigned short)(w.adjOff(v + 1) + w.adjOff(v));
+    for (int v = 0; v < nv; ++v) w.next(v) = w.adjOff(v);
+    for (int e = 0; e < ne; ++e) { w.adjEdge(w.next(w.ea(e))++) = (uint8_t)e; w.adjEdge(w.next(w.eb(e))++) = (uint8_t)e; }
+    for (int e = 0; e < ne; ++e) w.used(e) = 0;
+    for (int v = 0; v < nv; ++v) w.next(v) = w.adjOff(v);
+    int nOut = 0;
+    for (int start = 0; start < nv; ++start) {
+        if (w.next(start) >= w.adjOff(start + 1)) continue;
+        int sp = 1, nComp = 0;
+        w.stackV(0) = (uint8_t)start; w.stackE(0) = -1;
+        while (sp > 0) {
+            const int v = w.stackV(sp - 1);
+            int e = -1;
+            while (w.next(v) < w.adjOff(v + 1)) {
+                const int cand = w.adjEdge(w.next(v)++);
+                if (!w.used(cand)) { e = cand; break; }
+            }
+            if (e >= 0) {
+                w.used(e) = 1;
+                const int to = (w.ea(e) == v) ? w.eb(e) : w.ea(e);
+                w.stackV(sp) = (uint8_t)to; w.stackE(sp) = (short)e; ++sp;
+            } else {
+                const int eIn = w.stackE(sp - 1);
+                --sp;
+                if (eIn >= 0) { w.compE(nComp) = (uint8_t)eIn; w.compV(nComp) = w.stackV(sp - 1); ++nComp; }
+            }
+        }
+        for (int i = nComp; i-- > 0;) {
+            const int e = w.compE(i), from = w.compV(i);
+            if (e >= n) continue;
+            const int to = (w.ea(e) == from) ? w.eb(e) : w.ea(e);
+            if (nOut < n) { chPrev[b + nOut] = w.verts(from); chNext[b + nOut] = w.verts(to); }
+            ++nOut;
+        }
+    }
+    if (nOut != n) for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; }
+}
+// One thread per point, its arrays as LDS columns (a sequential graph walk per thread: on arrays in scratch memory -- 3 KB per
+// lane -- the kernel took 180 ms for the 10 M points of the cavity mesh, every step a round trip beyond the L1).  Points with more
+// than kChLds corners go to `big` (count in big[-1 .. ]: bigCount) for k_tl_chain_big.
 __global__ void __launch_bounds__(64) k_tl_chain(int nPos, const int* __restrict__ ids /* the points to do, or NULL: all */, const int* __restrict__ pfOff,
-                                                 const int* __restrict__ pfPrev, const int* __restrict__ pfNext, int* __restrict__ chPrev, int* __restrict__ chNext, int* bad) {
+                                                 const int* __restrict__ pfPrev, const int* __restrict__ pfNext, int* __restrict__ chPrev, int* __restrict__ chNext,
+                                                 int* __restrict__ big, int* __restrict__ bigCount) {
+    __shared__ ChainLdsBlock<kChLds> blk;
     const int i_ = blockIdx.x * 64 + threadIdx.x;
     if (i_ >= nPos) return;
     const int p = ids ? ids[i_] : i_;
     const int b = pfOff[p], n = pfOff[p + 1] - b;
-    if (n > kCh) { *bad = 1; return; }
+    if (n > kChLds) { big[atomicAdd(bigCount, 1)] = p; return; }
     if (n < 2) { for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; } return; }
-    int verts[2 * kCh];
-    uint8_t ea[2 * kCh], eb[2 * kCh], deg[2 * kCh], used[2 * kCh], stackV[2 * kCh + 1], compE[2 * kCh], compV[2 * kCh], adjEdge[4 * kCh];
-    short stackE[2 * kCh + 1];
-    unsigned short adjOff[2 * kCh + 1], next[2 * kCh];
-    int outA[kCh], outB[kCh];
-    for (int k = 0; k < n; ++k) { verts[2 * k] = pfPrev[b + k]; verts[2 * k + 1] = pfNext[b + k]; }
-    for (int i = 1; i < 2 * n; ++i) { const int x = verts[i]; int j = i - 1; while (j >= 0 && verts[j] > x) { verts[j + 1] = verts[j]; --j; } verts[j + 1] = x; }
-    int nv = 0;
-    for (int i = 0; i < 2 * n; ++i) if (i == 0 || verts[i] != verts[i - 1]) verts[nv++] = verts[i];
-    for (int k = 0; k < n; ++k) { ea[k] = (uint8_t)lowerBound(verts, nv, pfPrev[b + k]); eb[k] = (uint8_t)lowerBound(verts, nv, pfNext[b + k]); }
-    for (int v = 0; v < nv; ++v) deg[v] = 0;
-    for (int e = 0; e < n; ++e) { ++deg[ea[e]]; ++deg[eb[e]]; }
-    int ne = n, pending = -1;
-    for (int v = 0; v < nv; ++v)
-        if (deg[v] & 1) {
-            if (pending < 0) pending = v;
-            else { ea[ne] = (uint8_t)pending; eb[ne] = (uint8_t)v; ++ne; ++deg[pending]; ++deg[v]; pending = -1; }
-        }
-    for (int v = 0; v <= nv; ++v) adjOff[v] = 0;
-    for (int e = 0; e < ne; ++e) { ++adjOff[ea[e] + 1]; ++adjOff[eb[e] + 1]; }
-    for (int v = 0; v < nv; ++v) adjOff[v + 1] = (unsigned short)(adjOff[v + 1] + adjOff[v]);
-    for (int v = 0; v < nv; ++v) next[v] = adjOff[v];
-    for (int e = 0; e < ne; ++e) { adjEdge[next[ea[e]]++] = (uint8_t)e; adjEdge[next[eb[e]]++] = (uint8_t)e; }
-    for (int e = 0; e < ne; ++e) used[e] = 0;
-    for (int v = 0; v < nv; ++v) next[v] = adjOff[v];
-    int nOut = 0;
-    for (int start = 0; start < nv; ++start) {
-        if (next[start] >= adjOff[start + 1]) continue;
-        int sp = 1, nComp = 0;
-        stackV[0] = (uint8_t)start; stackE[0] = -1;
-        while (sp > 0) {
-            const int v = stackV[sp - 1];
-            int e = -1;
-            while (next[v] < adjOff[v + 1]) {
-                const int cand = adjEdge[next[v]++];
-                if (!used[cand]) { e = cand; break; }
-            }
-            if (e >= 0) {
-                used[e] = 1;
-                const int to = (ea[e] == v) ? eb[e] : ea[e];
-                stackV[sp] = (uint8_t)to; stackE[sp] = (short)e; ++sp;
-            } else {
-                const int eIn = stackE[sp - 1];
-                --sp;
-                if (eIn >= 0) { compE[nComp] = (uint8_t)eIn; compV[nComp] = stackV[sp - 1]; ++nComp; }
-            }
-        }
-        for (int i = nComp; i-- > 0;) {
-            const int e = compE[i], from = compV[i];
-            if (e >= n) continue;
-            const int to = (ea[e] == from) ? eb[e] : ea[e];
-            if (nOut < kCh) { outA[nOut] = verts[from]; outB[nOut] = verts[to]; }
-            ++nOut;
-        }
+    ChainLds<kChLds> w{&blk, (int)threadIdx.x};
+    chainOfPoint(w, b, n, pfPrev, pfNext, chPrev, chNext);
+}
+// the points k_tl_chain left (more than kChLds corners), on private arrays; beyond kCh corners the mesh goes back to the host build
+__global__ void __launch_bounds__(64) k_tl_chain_big(const int* __restrict__ big, const int* __restrict__ bigCount, const int* __restrict__ pfOff,
+                                                     const int* __restrict__ pfPrev, const int* __restrict__ pfNext, int* __restrict__ chPrev, int* __restrict__ chNext, int* bad) {
+    const int nBig = *bigCount;
+    for (int i_ = blockIdx.x * 64 + threadIdx.x; i_ < nBig; i_ += gridDim.x * 64) {
+        const int p = big[i_];
+        const int b = pfOff[p], n = pfOff[p + 1] - b;
+        if (n > kCh) { *bad = 1; continue; }
+        ChainPrivate<kCh> w;
+        chainOfPoint(w, b, n, pfPrev, pfNext, chPrev, chNext);
     }
-    if (nOut == n) for (int k = 0; k < n; ++k) { chPrev[b + k] = outA[k]; chNext[b + k] = outB[k]; }
-    else for (int k = 0; k < n; ++k) { chPrev[b + k] = pfPrev[b + k]; chNext[b + k] = pfNext[b + k]; }
+}
+// both launches on stream st; big = nPos + 1 ints of scratch (the count in big[nPos])
+static void launchChains(hipStream_t st, int nPos, const int* ids, const int* pfOff, const int* pfPrev, const int* pfNext, int* chPrev, int* chNext, int* big, int* bad) {
+    (void)hipMemsetAsync(big + nPos, 0, 4, st);
+    hipLaunchKernelGGL(k_tl_chain, dim3((nPos + 63) / 64), dim3(64), 0, st, nPos, ids, pfOff, pfPrev, pfNext, chPrev, chNext, big, big + nPos);
+    hipLaunchKernelGGL(k_tl_chain_big, dim3(std::max(1, std::min((nPos + 63) / 64, 2048))), dim3(64), 0, st, (const int*)big, (const int*)(big + nPos), pfOff, pfPrev, pfNext, chPrev, chNext, bad);
 }
 
 struct SmoothIn {
@@ -623,19 +698,20 @@ int startCornerChains(const DeviceTopologyArrays& td, int32_t nPoints, int devic
     const size_t nPf = td.pfPrev.bytes / 4;
     hipStream_t st = nullptr;
     TL_OK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    int *a = nullptr, *b = nullptr, *bad = nullptr;
-    if (hipMalloc((void**)&a, std::max<size_t>(nPf, 1) * 4) != hipSuccess || hipMalloc((void**)&b, std::max<size_t>(nPf, 1) * 4) != hipSuccess || hipMalloc((void**)&bad, 4) != hipSuccess) {
+    int *a = nullptr, *b = nullptr, *bad = nullptr, *big = nullptr;
+    if (hipMalloc((void**)&a, std::max<size_t>(nPf, 1) * 4) != hipSuccess || hipMalloc((void**)&b, std::max<size_t>(nPf, 1) * 4) != hipSuccess || hipMalloc((void**)&bad, 4) != hipSuccess ||
+        hipMalloc((void**)&big, ((size_t)nPoints + 1) * 4) != hipSuccess) {
         (void)hipGetLastError();
         if (a) (void)hipFree(a);
         if (b) (void)hipFree(b);
+        if (bad) (void)hipFree(bad);
         (void)hipStreamDestroy(st);
         why = "device allocation failed";
         return 2;
     }
-    c.chPrev = a; c.chNext = b; c.bad = bad; c.stream = (void*)st; c.nPoints = nPoints;
+    c.chPrev = a; c.chNext = b; c.bad = bad; c.big = big; c.stream = (void*)st; c.nPoints = nPoints;
     (void)hipMemsetAsync(bad, 0, 4, st);
-    hipLaunchKernelGGL(k_tl_chain, dim3((nPoints + 63) / 64), dim3(64), 0, st, nPoints, (const int*)nullptr, (const int*)td.pfOff.p, (const int*)td.pfPrev.p, (const int*)td.pfNext.p,
-                       a, b, bad);
+    launchChains(st, nPoints, nullptr, (const int*)td.pfOff.p, (const int*)td.pfPrev.p, (const int*)td.pfNext.p, a, b, big, bad);
     c.started = true;
     return 0;
 }
@@ -644,6 +720,7 @@ void releaseCornerChains(CornerChains& c) {
     (void)hipStreamSynchronize((hipStream_t)c.stream);
     (void)hipStreamDestroy((hipStream_t)c.stream);
     (void)hipFree(c.chPrev); (void)hipFree(c.chNext); (void)hipFree(c.bad);
+    if (c.big) (void)hipFree(c.big);
     c = CornerChains();
 }
 
@@ -674,9 +751,11 @@ int buildSmoothTablesOnDevice(SmoothTiles& st, const DeviceTopologyArrays& td, i
         int cb = 0;
         TL_OK(hipMemcpy(&cb, chains->bad, 4, hipMemcpyDeviceToHost));
         if (cb) return 1;
-    } else
-        hipLaunchKernelGGL(k_tl_chain, dim3((nPos + 63) / 64), dim3(64), 0, sm, nPos, nPos == nPoints ? (const int*)nullptr : (const int*)dOrder, (const int*)td.pfOff.p,
-                           (const int*)td.pfPrev.p, (const int*)td.pfNext.p, chPrev, chNext, bad);
+    } else {
+        int* big = D.get<int>((size_t)nPos + 1);
+        if (!big) { why = "device allocation failed"; return 2; }
+        launchChains(sm, nPos, nPos == nPoints ? (const int*)nullptr : (const int*)dOrder, (const int*)td.pfOff.p, (const int*)td.pfPrev.p, (const int*)td.pfNext.p, chPrev, chNext, big, bad);
+    }
     TL_OK(hipMemcpyAsync(dBeg, st.ptBeg.data(), S * 4, hipMemcpyHostToDevice, sm));
     TL_OK(hipMemcpyAsync(dInt, isInternal, (size_t)nPoints, hipMemcpyHostToDevice, sm));
     SmoothIn in{dOrder, dBeg, nT, maxPointPoints <= 16 ? 1 : 0, (const int*)td.pcOff.p, (const int*)td.pcVal.p, (const int*)td.ppOff.p, (const int*)td.ppPt.p,
