@@ -24,6 +24,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <thread>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -524,6 +526,28 @@ int main(int argc, char** argv) {
     }
     const int myRank = g_comm.rank;
     Rank& K0 = R[0];
+    // The HIP runtime comes up (device discovery, context, first allocation: a few tenths of a second per process) on a thread of its
+    // own while this one reads the case -- in every rank, after the ranks were started (nothing touches HIP before that)
+    std::atomic<int> warmDevices{-1};
+    std::thread hipWarm([&warmDevices, &opt, myRank] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { warmDevices = 0; return; }
+        if (hipSetDevice(((int)opt.getL("device", 0) + myRank) % n) == hipSuccess) {
+            // (the runtime builds its queues and loads its copy / fill kernels at their first use, ~0.2 s: use each once)
+            void* p = nullptr;
+            char b[64] = {0};
+            if (hipMalloc(&p, 1 << 20) == hipSuccess) {
+                (void)hipMemset(p, 0, 1 << 20);
+                (void)hipMemcpy(p, b, sizeof b, hipMemcpyHostToDevice);
+                (void)hipMemcpy(b, p, sizeof b, hipMemcpyDeviceToHost);
+                (void)hipDeviceSynchronize();
+                (void)hipFree(p);
+            }
+            (void)hipGetLastError();
+        }
+        warmDevices = n;
+    });
+    struct JoinWarm { std::thread& t; ~JoinWarm() { if (t.joinable()) t.join(); } } joinWarm{hipWarm};
 
     // start time (SM.C:1791-1803; controlDict startFrom latestTime)
     const auto times = listTimes(R[0].root);
@@ -652,6 +676,7 @@ int main(int argc, char** argv) {
         OUTS("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
 
     // engine: this rank's sub-domain on its device
+    if (hipWarm.joinable()) hipWarm.join();
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) fatal("no HIP device available (this build has no CPU fallback)");
     const int dev0 = (int)opt.getL("device", 0);

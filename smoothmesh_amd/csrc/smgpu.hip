@@ -22,6 +22,7 @@
 #include "boundary.hpp"
 #include "tiles.hpp"
 #include "topology.hpp"
+#include "parallel.hpp"
 
 using namespace smgpu;
 
@@ -517,6 +518,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     smgpu_handle* h = new smgpu_handle();
     h->device = d->device;
     const auto tCreate0 = std::chrono::steady_clock::now();
+    setupClockStart() = tCreate0;
     auto sinceCreate = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - tCreate0).count(); };
     // The one-off host work is pipelined: the Z-curve of the points (needs the coordinates only) starts at once; the geometry
     // tile tables start as soon as the cell -> face lists stand (Topology::build's afterCells hook) and are built next to the
@@ -565,8 +567,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                           const auto t0 = std::chrono::steady_clock::now();
                           const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildGeomTablesOnDevice(h->gt, devTopo, d->nCells, h->device, h->gtDev, why);
                           if (envInt("SMGPU_VERBOSE", 0) >= 2)
-                              std::fprintf(stderr, "[smgpu] geometry tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
-                                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                              std::fprintf(stderr, "[smgpu] geometry tiles: tables on the %s %.2f s   (done at +%.3f s)\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), setupClock());
                           if (rc == 0) return std::string();
                           return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);      // (the host's lists are still arriving)
                       }
@@ -587,8 +589,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                         const auto t0 = std::chrono::steady_clock::now();
                         const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildSmoothTablesOnDevice(h->stl, devTopo, d->nPoints, h->topo.maxPointPoints, internalMask.data(), h->device, h->stDev, why, &chains);
                         if (envInt("SMGPU_VERBOSE", 0) >= 2)
-                            std::fprintf(stderr, "[smgpu] smoothing tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
-                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                            std::fprintf(stderr, "[smgpu] smoothing tiles: tables on the %s %.2f s   (done at +%.3f s)\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), setupClock());
                         if (rc == 0) return std::string();
                         return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);
                     }
@@ -613,8 +615,8 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
                     const auto t0 = std::chrono::steady_clock::now();
                     const int rc = envInt("SMGPU_DEVICE_TILES", 1) == 2 ? 1 : buildEdgeTablesOnDevice(h->etl, *dt, h->topo.nEdges, h->device, h->etDev, why);
                     if (envInt("SMGPU_VERBOSE", 0) >= 2)
-                        std::fprintf(stderr, "[smgpu] edge tiles: tables on the %s %.2f s\n", rc == 0 ? "device" : "host (device build handed them back)",
-                                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+                        std::fprintf(stderr, "[smgpu] edge tiles: tables on the %s %.2f s   (done at +%.3f s)\n", rc == 0 ? "device" : "host (device build handed them back)",
+                                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), setupClock());
                     if (rc == 0) return std::string();
                     return rc == 2 ? "device tile tables: " + why : std::string(kHostTablesPending);
                 }
@@ -674,7 +676,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     MeshView& m = h->mv;
     const double tTopo = sinceCreate();
     double tLap = tTopo;
-    auto lapC = [&](const char* what) { if (envInt("SMGPU_VERBOSE", 0) >= 2) { const double now = sinceCreate(); std::fprintf(stderr, "[smgpu] create: %-28s %.3f s\n", what, now - tLap); tLap = now; } };
+    auto lapC = [&](const char* what) { if (envInt("SMGPU_VERBOSE", 0) >= 2) { const double now = sinceCreate(); std::fprintf(stderr, "[smgpu] create: %-28s %.3f s   (at +%.3f s)\n", what, now - tLap, now); tLap = now; } };
     auto cleanupE = [&](int rc0) { if (fEdge.valid()) fEdge.wait(); return cleanup(rc0); };
     m.nPoints = t.nPoints; m.nCells = t.nCells; m.nFaces = t.nFaces; m.nInternalFaces = t.nInternalFaces; m.nEdges = t.nEdges;
     std::vector<uint8_t> flags(t.nPoints);

@@ -17,7 +17,7 @@ struct PhaseTimer {
     explicit PhaseTimer(const char* w) : who(w), on(std::getenv("SMGPU_VERBOSE") && std::atoi(std::getenv("SMGPU_VERBOSE")) >= 2), t(std::chrono::steady_clock::now()) {}
     void lap(const char* what) {
         const auto now = std::chrono::steady_clock::now();
-        if (on) std::fprintf(stderr, "[smgpu] %s tiles: %-18s %.2f s\n", who, what, std::chrono::duration<double>(now - t).count());
+        if (on) std::fprintf(stderr, "[smgpu] %s tiles: %-18s %.2f s   (done at +%.3f s)\n", who, what, std::chrono::duration<double>(now - t).count(), setupClock());
         t = now;
     }
 };
@@ -103,9 +103,27 @@ std::string GeomTiles::build(const Topology& t, const double* pts, bool morton, 
 // segments of the Z-curve the greedy boundary passes tile side by side on large meshes (SMGPU_TILE_SEGMENTS; every cut costs one
 // partial tile and a pair of mesh-sized stamp arrays)
 static unsigned tileSegments() {
-    static const unsigned n = [] { const char* e = std::getenv("SMGPU_TILE_SEGMENTS"); return e ? std::max(1u, std::min((unsigned)std::atoi(e), 64u)) : 8u; }();
+    static const unsigned n = [] { const char* e = std::getenv("SMGPU_TILE_SEGMENTS"); return e ? std::max(1u, std::min((unsigned)std::atoi(e), 64u)) : 16u; }();
     return n;
 }
+// The mesh-sized "last tile that saw this element" arrays of the greedy passes: zero pages straight from the OS, as transparent
+// huge pages (a fault zeroes 2 MB at memory speed; with 4 KB pages the passes' random accesses took a page fault each, 48 threads
+// in the kernel's fault path at once: slower than the value-initialised vectors they replaced, which wrote 200 MB per segment
+// before the first cell was looked at).  Tiles are numbered from 1 for the stamps.
+struct Stamps {
+    int32_t* p;
+    size_t bytes;
+    explicit Stamps(size_t n) : bytes(std::max<size_t>(n, 1) * sizeof(int32_t)) {
+        void* m = ::mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        p = (int32_t*)m;
+        adviseHuge(m, bytes);
+    }
+    ~Stamps() { ::munmap(p, bytes); }
+    Stamps(const Stamps&) = delete;
+    Stamps& operator=(const Stamps&) = delete;
+    int32_t& operator[](size_t i) { return p[i]; }
+};
 
 std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, bool morton, int32_t nThreads, int32_t capCells,
                                        int32_t capPoints, int32_t capFaces, int32_t capWeighted, int32_t faceWeight, const std::vector<int32_t>* cellOrder) {
@@ -142,9 +160,9 @@ std::string GeomTiles::buildBoundaries(const Topology& t, const double* pts, boo
         std::vector<std::vector<int32_t>> segBeg((size_t)segs);
         std::vector<std::string> segErr((size_t)segs);
         parallelRanges(t.nCells, segs, [&](int sg, int64_t c0, int64_t c1) {
-            std::vector<int32_t> stampP((size_t)t.nPoints, -1), stampF((size_t)t.nFaces, -1);
+            Stamps stampP((size_t)t.nPoints), stampF((size_t)t.nFaces);
             std::vector<int32_t>& beg = segBeg[(size_t)sg];
-            int32_t tile = 0, nP = 0, nF = 0, nC = 0;
+            int32_t tile = 1, nP = 0, nF = 0, nC = 0;
             for (int32_t ci = (int32_t)c0; ci < (int32_t)c1; ++ci) {
                 const int32_t c = order[(size_t)ci];
                 for (int attempt = 0; attempt < 2; ++attempt) {
@@ -388,9 +406,9 @@ std::string SmoothTiles::buildBoundaries(const Topology& t, const double* xyz, b
         std::vector<std::vector<int32_t>> segBeg((size_t)segs);
         std::vector<std::string> segErr((size_t)segs);
         parallelRanges(nPos, segs, [&](int sg, int64_t p0, int64_t p1) {
-            std::vector<int32_t> stampC((size_t)t.nCells, -1), stampN((size_t)t.nPoints, -1);
+            Stamps stampC((size_t)t.nCells), stampN((size_t)t.nPoints);
             std::vector<int32_t>& beg = segBeg[(size_t)sg];
-            int32_t tile = 0, nC = 0, nN = 0, nT = 0;
+            int32_t tile = 1, nC = 0, nN = 0, nT = 0;
             for (int32_t pi = (int32_t)p0; pi < (int32_t)p1; ++pi) {
                 const int32_t p = order[(size_t)pi];
                 for (int attempt = 0; attempt < 2; ++attempt) {
@@ -568,14 +586,21 @@ std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, boo
     const int32_t nE = t.nEdges;
     if (morton && pointOrder) {
         // edges are stored in upper-triangular order, i.e. grouped by their start point: walk the points along their Z-curve
-        std::vector<int32_t> startOff((size_t)t.nPoints + 1, 0);
-        for (int32_t e = 0; e < nE; ++e) ++startOff[(size_t)t.edges[2 * e] + 1];
-        for (int32_t p = 0; p < t.nPoints; ++p) startOff[(size_t)p + 1] += startOff[(size_t)p];
+        // (startOff[p] = the first edge whose start point is >= p: the edges are sorted by start point, so every stretch of them fills
+        // the entries of the points it passes)
+        std::vector<int32_t> startOff((size_t)t.nPoints + 1);
+        parallelRanges(nE, rangeParts(nE), [&](int, int64_t b, int64_t e1) {
+            for (int64_t e = b; e < e1; ++e) {
+                const int32_t p = t.edges[2 * e], prev = e > 0 ? t.edges[2 * (e - 1)] : -1;
+                for (int32_t q = prev + 1; q <= p; ++q) startOff[(size_t)q] = (int32_t)e;
+            }
+        });
+        for (int32_t q = (nE > 0 ? t.edges[2 * ((size_t)nE - 1)] : -1) + 1; q <= t.nPoints; ++q) startOff[(size_t)q] = nE;
         // (where every point's block of edges starts in the order: a prefix sum along the Z-curve; the blocks are then written side by side)
         const std::vector<int32_t>& po = *pointOrder;
         std::vector<int32_t> outOff(po.size() + 1, 0);
         for (size_t i = 0; i < po.size(); ++i) outOff[i + 1] = outOff[i] + (startOff[(size_t)po[i] + 1] - startOff[(size_t)po[i]]);
-        order.assign((size_t)nE, 0);
+        resizeHuge(order, (size_t)nE);
         parallelRanges((int64_t)po.size(), rangeParts((int64_t)po.size()), [&](int, int64_t b, int64_t e1) {
             for (int64_t i = b; i < e1; ++i) {
                 int32_t o = outOff[(size_t)i];
@@ -600,9 +625,9 @@ std::string EdgeTiles::buildBoundaries(const Topology& t, const double* xyz, boo
     std::vector<std::vector<int32_t>> segBeg((size_t)segs);
     std::vector<std::string> segErr((size_t)segs);
     parallelRanges(nE, segs, [&](int sg, int64_t e0, int64_t e1) {
-        std::vector<int32_t> stP((size_t)t.nPoints, -1), stF((size_t)t.nFaces, -1), stC((size_t)t.nCells, -1);
+        Stamps stP((size_t)t.nPoints), stF((size_t)t.nFaces), stC((size_t)t.nCells);
         std::vector<int32_t>& beg = segBeg[(size_t)sg];
-        int32_t tile = 0, nP = 0, nF = 0, nC = 0, nT = 0;
+        int32_t tile = 1, nP = 0, nF = 0, nC = 0, nT = 0;
         for (int32_t ei = (int32_t)e0; ei < (int32_t)e1; ++ei) {
             const int32_t e = order[(size_t)ei];
             for (int attempt = 0; attempt < 2; ++attempt) {

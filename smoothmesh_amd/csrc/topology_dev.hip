@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <memory>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,7 @@
 #include <vector>
 
 #include "topology.hpp"
+#include "parallel.hpp"
 
 namespace smgpu {
 
@@ -272,6 +274,53 @@ struct DevBuf {
     void release(void* p) { auto it = std::find(all.begin(), all.end(), p); if (it != all.end()) all.erase(it); }      // the caller owns it now
 };
 
+// Host -> device copies of the caller's (pageable) lists: chunks are copied into pinned staging buffers by several threads and sent
+// from there, the next chunk being filled while the last one travels.  A plain hipMemcpyAsync from pageable memory went at
+// 4.7 GB/s beside the set-up's other host threads (0.18 s for the 856 MB of the 10 M-cell mesh); the staged form runs at the
+// link's ~53 GB/s (scripts/native/xfer_bench.cpp).
+struct StagedUpload {
+    static constexpr size_t kChunk = (size_t)32 << 20;
+    static constexpr int kBufs = 4, kThreads = 8;
+    char* stage = nullptr;
+    hipEvent_t ev[kBufs] = {};
+    int turn = 0;
+    bool ok = false;
+    double tFill = 0.0, tWait = 0.0, tAlloc = 0.0;      // (SMGPU_VERBOSE >= 2: where an upload's time went)
+    static double nowS() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    StagedUpload() {
+        const double t0 = nowS();
+        struct Done { double& t; double t0; ~Done() { t = nowS() - t0; } } done{tAlloc, t0};
+        if (hipHostMalloc((void**)&stage, kChunk * kBufs, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); stage = nullptr; return; }
+        for (auto& e : ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        ok = true;
+    }
+    ~StagedUpload() {
+        for (auto& e : ev) if (e) { (void)hipEventSynchronize(e); (void)hipEventDestroy(e); }
+        if (stage) (void)hipHostFree(stage);
+    }
+    hipError_t copy(void* dst, const void* src, size_t bytes, hipStream_t st) {
+        if (!ok || bytes < kChunk / 4) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st);
+        for (size_t off = 0; off < bytes; off += kChunk, ++turn) {
+            const size_t len = std::min(kChunk, bytes - off);
+            char* b = stage + (size_t)(turn % kBufs) * kChunk;
+            double t0 = nowS();
+            if (turn >= kBufs) { const hipError_t e = hipEventSynchronize(ev[turn % kBufs]); if (e != hipSuccess) return e; }
+            tWait += nowS() - t0;
+            t0 = nowS();
+            std::vector<std::thread> th;
+            const char* from = (const char*)src + off;
+            for (int t = 1; t < kThreads; ++t) th.emplace_back([=] { const size_t lo = len * t / kThreads, hi = len * (t + 1) / kThreads; std::memcpy(b + lo, from + lo, hi - lo); });
+            std::memcpy(b, from, len / kThreads);
+            for (auto& x : th) x.join();
+            tFill += nowS() - t0;
+            hipError_t e = hipMemcpyAsync((char*)dst + off, b, len, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipEventRecord(ev[turn % kBufs], st);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+};
+
 int bitsFor(int64_t rows) { int b = 1; while (((int64_t)1 << b) < rows + 1 && b < 31) ++b; return b; }
 
 // device -> host copies of whole lists: the arrays are sized by one thread each (first touch of fresh pages) and copied in 32 MB
@@ -280,7 +329,7 @@ int bitsFor(int64_t rows) { int b = 1; while (((int64_t)1 << b) < rows + 1 && b 
 struct DownJob { std::function<void*()> size; const void* src; size_t bytes; void* dst; };
 template <class Vec, class T> void wantDown(std::vector<DownJob>& jobs, Vec& vec, const T* src, size_t n) {
     Vec* v = &vec;
-    jobs.push_back(DownJob{[v, n]() -> void* { v->resize(n); return (void*)v->data(); }, (const void*)src, n * sizeof(T), nullptr});
+    jobs.push_back(DownJob{[v, n]() -> void* { resizeHuge(*v, n); return (void*)v->data(); }, (const void*)src, n * sizeof(T), nullptr});
 }
 bool runDown(std::vector<DownJob>& jobs, int device) {
     {   // sizes first (a thread per array), then the copies
@@ -320,15 +369,17 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (!verbose) return;
-        (void)hipDeviceSynchronize();
+        static const bool sync = std::atoi(std::getenv("SMGPU_VERBOSE")) >= 3;      // (3: every stage waited for -- its own duration, not the pipeline's)
+        if (sync) (void)hipDeviceSynchronize();
         const auto now = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[smgpu] device addressing: %-20s %.3f s\n", what, std::chrono::duration<double>(now - t0).count());
+        std::fprintf(stderr, "[smgpu] device addressing: %-20s %.3f s   (%s at +%.3f s)\n", what, std::chrono::duration<double>(now - t0).count(), sync ? "done" : "enqueued", setupClock());
         t0 = now;
     };
     if (nP <= 0 || nC <= 0 || nF <= 0 || nIF < 0 || nIF > nF) return 1;
     const int64_t nnz = faceOffsets[nF];
     if (nnz >= ((int64_t)1 << 30) || nnz < 3) return 1;      // (2 * nnz keys must index with int32)
     TD_OK(hipSetDevice(device));
+    lap("HIP context");
     // Host pages are touched ahead of the copies that fill them: the copies of the caller's lists and the sizing of the lists to be
     // downloaded (first touch of 2 GB of fresh pages for 10 M cells) run on threads of their own beside the uploads, the kernels
     // and the earlier stages of the download -- they were 0.2 s of the download's critical path.  (Joined before any return.)
@@ -337,9 +388,12 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
         void join() { for (auto& x : th) if (x.joinable()) x.join(); th.clear(); }
         ~Background() { join(); }
     } bg;
-    bg.th.emplace_back([&t, faceOffsets, own, nei, nF, nIF] { t.facePoints.off.assign(faceOffsets, faceOffsets + nF + 1); t.owner.assign(own, own + nF); t.neighbour.assign(nei, nei + nIF); });
-    bg.th.emplace_back([&t, facePts, nnz] { t.facePoints.val.assign(facePts, facePts + nnz); });
-    bg.th.emplace_back([&t, nC, nF, nIF] { t.cellFacesGeom.off.resize((size_t)nC + 1); t.cellFacesGeom.val.resize((size_t)nF + (size_t)nIF); });
+    bg.th.emplace_back([&t, faceOffsets, own, nei, nF, nIF] {
+        reserveHuge(t.facePoints.off, (size_t)nF + 1); t.facePoints.off.assign(faceOffsets, faceOffsets + nF + 1);
+        reserveHuge(t.owner, (size_t)nF); t.owner.assign(own, own + nF);
+        reserveHuge(t.neighbour, (size_t)nIF); t.neighbour.assign(nei, nei + nIF); });
+    bg.th.emplace_back([&t, facePts, nnz] { reserveHuge(t.facePoints.val, (size_t)nnz); t.facePoints.val.assign(facePts, facePts + nnz); });
+    bg.th.emplace_back([&t, nC, nF, nIF] { resizeHuge(t.cellFacesGeom.off, (size_t)nC + 1); resizeHuge(t.cellFacesGeom.val, (size_t)nF + (size_t)nIF); });
     hipStream_t st = nullptr;
     DevBuf D;
     Flags* fl = D.get<Flags>(1, why);
@@ -349,11 +403,20 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     u64 *kA = D.get<u64>(maxKeys, why), *kB = D.get<u64>(maxKeys, why);
     int *vA = D.get<int>((size_t)nnz, why), *vB = D.get<int>((size_t)nnz, why);
     if (!fl || !dFo || !dFp || !dOwn || !dNei || !faceOf || !kA || !kB || !vA || !vB) return why.empty() ? 1 : 2;
+    lap("device buffers");
     TD_OK(hipMemsetAsync(fl, 0, sizeof(Flags), st));
-    TD_OK(hipMemcpyAsync(dFo, faceOffsets, ((size_t)nF + 1) * 4, hipMemcpyHostToDevice, st));
-    TD_OK(hipMemcpyAsync(dFp, facePts, (size_t)nnz * 4, hipMemcpyHostToDevice, st));
-    TD_OK(hipMemcpyAsync(dOwn, own, (size_t)nF * 4, hipMemcpyHostToDevice, st));
-    if (nIF) TD_OK(hipMemcpyAsync(dNei, nei, (size_t)nIF * 4, hipMemcpyHostToDevice, st));
+    {
+        std::unique_ptr<StagedUpload> up(new StagedUpload());
+        TD_OK(up->copy(dFo, faceOffsets, ((size_t)nF + 1) * 4, st));
+        TD_OK(up->copy(dFp, facePts, (size_t)nnz * 4, st));
+        TD_OK(up->copy(dOwn, own, (size_t)nF * 4, st));
+        if (nIF) TD_OK(up->copy(dNei, nei, (size_t)nIF * 4, st));
+        if (verbose) std::fprintf(stderr, "[smgpu] staged upload: staging buffers %.3f s, filling them %.3f s, waiting for the link %.3f s\n", up->tAlloc, up->tFill, up->tWait);
+        // (releasing pinned memory waits for the copies and costs as much as pinning it: on a thread of its own, joined with the others)
+        StagedUpload* u = up.release();
+        bg.th.emplace_back([u, verbose] { const double t0 = StagedUpload::nowS(); delete u; if (verbose) std::fprintf(stderr, "[smgpu] staged upload: buffers released in %.3f s\n", StagedUpload::nowS() - t0); });
+    }
+    lap("upload");
     // rocPRIM temporary storage: sized for the largest sort / scan of the build
     size_t tempBytes = 0;
     {
@@ -370,7 +433,7 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
         return rocprim::radix_sort_keys(temp, b, in, out, n, 0, (unsigned)std::min(64, 32 + rowBits), st);
     };
     hipLaunchKernelGGL(k_td_faces, dim3(gridOf(nF)), dim3(kTB), 0, st, nF, nIF, nP, nC, dFo, dFp, dOwn, dNei, faceOf, fl);
-    lap("upload + faces");
+    lap("faces");
 
     // ---- cell -> faces (geometry accumulation order) ----
     const int64_t nCF = (int64_t)nF + nIF;
@@ -428,10 +491,10 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     if (!edges) return 2;
     {   // the sizes of the edge and point lists are known from here on
         const size_t e2 = 2 * (size_t)nE, ne1 = (size_t)nE + 1, np1 = (size_t)nP + 1, npc = (size_t)nPC, nz = (size_t)nnz;
-        bg.th.emplace_back([&t, e2, ne1] { t.edges.resize(e2); t.edgeFaces.off.resize(ne1); t.edgeCells.off.resize(ne1); });
-        bg.th.emplace_back([&t, nz] { t.edgeFaces.val.resize(nz); });
-        bg.th.emplace_back([&t, e2, np1] { t.pointPoints.resize(e2); t.pointEdges.off.resize(np1); t.pointCells.off.resize(np1); });
-        bg.th.emplace_back([&t, npc] { t.pointCells.val.resize(npc); });
+        bg.th.emplace_back([&t, e2, ne1] { resizeHuge(t.edges, e2); resizeHuge(t.edgeFaces.off, ne1); resizeHuge(t.edgeCells.off, ne1); });
+        bg.th.emplace_back([&t, nz] { resizeHuge(t.edgeFaces.val, nz); });
+        bg.th.emplace_back([&t, e2, np1] { resizeHuge(t.pointPoints, e2); resizeHuge(t.pointEdges.off, np1); resizeHuge(t.pointCells.off, np1); });
+        bg.th.emplace_back([&t, npc] { resizeHuge(t.pointCells.val, npc); });
     }
     hipLaunchKernelGGL(k_td_edgeScatter, dim3(gridOf(nnz)), dim3(kTB), 0, st, nnz, kB, vB, rank, edges, faceEdge);
     D.drop(rank);
@@ -473,7 +536,7 @@ int buildTopologyOnDevice(Topology& t, int32_t nP, int32_t nC, int32_t nF, int32
     TD_OK(hipMemcpyAsync(&hf, fl, sizeof(Flags), hipMemcpyDeviceToHost, st));
     TD_OK(hipStreamSynchronize(st));
     if (hf.bad || hf.maxEdgeFaces > kMaxEdgeFaces || hf.maxPointPoints > 255) return 1;      // (the host build handles it, or words the error)
-    { const size_t n = (size_t)nEC; bg.th.emplace_back([&t, n] { t.edgeCells.val.resize(n); }); }
+    { const size_t n = (size_t)nEC; bg.th.emplace_back([&t, n] { resizeHuge(t.edgeCells.val, n); }); }
     int* ecCell = D.get<int>((size_t)nEC, why);
     uint8_t *ecF0 = D.get<uint8_t>((size_t)nEC, why), *ecF1 = D.get<uint8_t>((size_t)nEC, why);
     int *ringFace = D.get<int>((size_t)nnz, why), *ringCell = D.get<int>((size_t)nEC, why);
