@@ -2665,7 +2665,9 @@ int smgpu_iter_end(smgpu_handle* h) {
     double* hist = (h->statsHistory && h->statsHistoryCap > 0) ? h->statsHistory + 2 * (size_t)(h->statsHistoryN++ % h->statsHistoryCap) : nullptr;
     // with a stats history nobody reads the record before the loop ends: the reduction then rides in the next geometry
     // launch (first launch of smgpu_iter_begin) as in smgpu_iterate; flushDeferred closes the last iteration
-    if (hist && fusedTiles && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
+    // (constraints on: the partials are k_apply_swap's, as in smgpu_iterate -- nothing between here and the next geometry launch
+    // reads the counters the reduction resets)
+    if (hist && (fusedTiles || swapHalo) && h->geomT >= 64 && envInt("SMGPU_DEFER_FINISH", 1)) {
         h->deferN = nPart; h->deferIter = -1 /* no stats[] record in this mode */; h->deferLocal = h->localStats; h->deferHist = hist;
     } else if (launchK(h, K_FINISH, [&] { hipLaunchKernelGGL(k_finish, dim3(1), dim3(kFinishBlock), 0, h->stream, s, nPart, h->haloIter, -1.0, h->localStats, hist); })) return 1;
     if (swapHalo) std::swap(h->st.ptsCur, h->st.prop);      // the proposal array is the next coordinates (k_apply_swap restored the points that stay)
