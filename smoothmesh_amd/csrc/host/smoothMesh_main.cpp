@@ -1222,7 +1222,8 @@ int main(int argc, char** argv) {
         const long tot = g_comm.reduceSum((long)nt[0]);
         if (tot > 0)
             OUT("WARNING: %ld angle comparison(s) of this run had their two sides within 4 ulp of each other (edge angle %lld, face-angle range %lld, "
-                "face-angle walk %lld on the master): the reference's acos may decide such a comparison the other way\n",
+                "face-angle walk %lld on the master): the reference's acos may decide such a comparison the other way "
+                "(expected where points move by a few ulp only, i.e. in converged regions)\n",
                 tot, (long long)nt[1], (long long)nt[2], (long long)nt[3]);
     }
     if (nccl) { HIPCHK(hipStreamSynchronize(engineStream)); syncExchangeStream(); NCCLCHK(ncclCommDestroy(nccl)); }
