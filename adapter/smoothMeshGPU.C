@@ -925,6 +925,17 @@ int main(int argc, char *argv[])
         checkHip(hipFree(sendA)); checkHip(hipFree(recvA)); checkHip(hipFree(sendF)); checkHip(hipFree(recvF));
         checkHip(hipFree(sendL)); checkHip(hipFree(recvL)); checkHip(hipFree(localStats));
     }
+    {
+        // near-tie census (include/smgpu.h): the engine's acos may differ from glibc's in the last bit; only an angle comparison
+        // whose two sides were a few ulp apart could have been decided the other way by the CPU tool
+        int64_t nearTies[4] = {0, 0, 0, 0};
+        check(smgpu_get_near_ties(h, nearTies));
+        label nTies = label(nearTies[0]);
+        reduce(nTies, sumOp<label>());
+        if (nTies > 0)
+            Info<< "WARNING: " << nTies << " angle comparison(s) of this run had their two sides within 4 ulp of each other:"
+                << " the CPU smoothMesh may decide such a comparison the other way" << nl << endl;
+    }
     check(smgpu_destroy(h));
     Info<< "ClockTime = " << runTime.elapsedClockTime() << " s." << nl << endl;
     Info<< "End" << nl << endl;

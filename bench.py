@@ -364,7 +364,7 @@ def clock_warm(iterate, engine, sync, fixed=0):
     return done
 
 
-def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
+def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0, nominal100=False):
     """one GPU, one workload: W warm-up + K timed steps on a cold GPU (ms_per_step_cold), the clock pre-run, W + K again (the
     reported value; inputs resident), the same K steps with per-kernel hipEvents, and -- outside every timed region -- the
     oracle leg (parity_check + cpu_baseline on this workload's own mesh)"""
@@ -401,6 +401,18 @@ def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
     pre = clock_warm(lambda k: eng.iterate(k, 0.0), eng, torch.cuda.synchronize)
     dt, res, frz = timed()
     near_timed = eng.last_near_ties.sum() if hasattr(eng, "last_near_ties") else 0
+    # the metric says "(100 iters)": when the contract's K is shorter (the driver runs 20 steps = 1.7 ms on the hex block), the same
+    # loop once more over 100 steps from the initial coordinates, reported beside the K-step value
+    dt100 = None
+    if K < 100 and nominal100:
+        eng.set_points(mesh.points)
+        if W:
+            eng.iterate(W, 0.0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.iterate(100, 0.0)
+        torch.cuda.synchronize()
+        dt100 = time.perf_counter() - t0
     # second pass over the same K steps with per-kernel hipEvent brackets (on the engine's stream)
     eng.reset_counters()
     eng.enable_timing(True)
@@ -424,7 +436,7 @@ def run_single(workload, K, W, device, oracle=True, oracle_budget_s=12.0):
     eng.close()
     del eng
     return dict(kind=kind, n_side=n_side, constraints=constraints, layers=layers, boundary=boundary, dt=dt, dt_cold=dt_cold, dt_ev=dt_ev,
-                ctr=ctr, sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par, near_ties=near,
+                ctr=ctr, sizes=sizes, total_points=nPoints, res=res, frz=frz, pre=pre, cpu_baseline=base, parity_check=par, near_ties=near, dt100=dt100,
                 phases={"mesh_generation_s": t_mesh, "engine_setup_s": t_create, "oracle_leg_s": t_oracle})
 
 
@@ -873,6 +885,8 @@ def compact_line(out, detail_path=None):
     for k in ("halo_overhead_us", "weak_efficiency_bound"):
         if k in out:
             c[k] = out[k]
+    if out.get("at_100_iters"):
+        c["at_100_iters"] = {k: out["at_100_iters"][k] for k in ("steps", "ms_per_step", "value")}
     c["exit_code"] = out.get("exit_code", 0)
     if out.get("failures"):
         c["failures"] = [short(f, 160) for f in out["failures"]][:4]
@@ -972,7 +986,7 @@ def main():
         for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29577")):
             os.environ.setdefault(k, v)
     if world == 1 and not force_dist:
-        r = run_single(args.workload, K, W, local_rank, oracle=not args.no_cpu_baseline)
+        r = run_single(args.workload, K, W, local_rank, oracle=not args.no_cpu_baseline, nominal100=True)
         dt, dt_ev, ctr, sizes, total_points, res, frz = r["dt"], r["dt_ev"], r["ctr"], r["sizes"], r["total_points"], r["res"], r["frz"]
         pre = r["pre"]
         single = r
@@ -1112,6 +1126,9 @@ def main():
             out["parity_check"] = single["parity_check"]
             out["parity"] = ("HIP == CPU oracle: parity_check (this run, this mesh) + tests/; the oracle restates the reference and is "
                              "unpinned against a real OpenFOAM build")
+        if single and single.get("dt100"):
+            out["at_100_iters"] = {"steps": 100, "ms_per_step": single["dt100"] / 100 * 1e3, "value": total_points * 100 / single["dt100"], "unit": "points/s",
+                                   "note": "the metric's nominal iteration count, timed like the K steps, from the initial coordinates"}
         if single:
             out["phases"] = single["phases"]
             out["near_ties"] = single["near_ties"]
