@@ -13,6 +13,7 @@
 #include <charconv>
 #include <chrono>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,6 +96,21 @@ static int64_t ioGrain() {     // smallest piece worth a thread (bytes or record
     return 1 << 16;
 }
 static int ioParts(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>((int64_t)ioThreads(), n / ioGrain())); }
+
+// fresh pages of the big lists as transparent huge pages (THP mode "madvise" on the GPU boxes): first touch of 4 KB pages runs at
+// ~6 GB/s per thread and ~20 GB/s on all threads together (the kernel's fault path), of 2 MB pages at 17 and > 100 GB/s
+static void adviseHuge(void* p, size_t bytes) {
+    const uintptr_t huge = (uintptr_t)2 << 20;
+    if (!p || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + huge - 1) & ~(huge - 1), e = ((uintptr_t)p + bytes) & ~(huge - 1);
+    if (e > a) (void)::madvise((void*)a, (size_t)(e - a), MADV_HUGEPAGE);
+}
+template <class V>
+static void reserveHuge(V& v, size_t n) {      // (for vectors that are still empty)
+    if (v.capacity() >= n) return;
+    v.reserve(n);
+    adviseHuge((void*)v.data(), v.capacity() * sizeof(typename V::value_type));
+}
 
 template <class F>
 static void parallelParts(int parts, F&& f) {      // f(part) on its own thread; the first exception is re-thrown
@@ -212,6 +228,27 @@ inline const char* parseDouble(const char* p, const char* end, double& out) {
         return q;
     }
     if (w == 0) { out = neg ? -0.0 : 0.0; return q; }
+#if defined(__x86_64__) && defined(__LDBL_MANT_DIG__) && (__LDBL_MANT_DIG__ == 64)
+    // 17 .. 19 digit mantissas (coordinates written with precision 17): w < 2^64 and 10^|e10| (<= 10^27 < 2^90, an odd factor
+    // 5^27 < 2^63) are exact in the x87 extended format, so ONE extended operation gives the quotient / product rounded to 64
+    // mantissa bits, at most half a unit of that format from the exact value.  Rounding it once more to 53 bits is the correctly
+    // rounded double unless the extended result sits within one unit of a midpoint between two doubles (low 11 bits 0x3ff ..
+    // 0x401) -- then, and only then, strtod decides.  (The magnitudes, 1e-27 .. 1.9e46, are far from the ends of the double range.)
+    if (e10 >= -27 && e10 <= 27) {
+        static const long double kPow10L[28] = {1e0L, 1e1L, 1e2L, 1e3L, 1e4L, 1e5L, 1e6L, 1e7L, 1e8L, 1e9L, 1e10L, 1e11L, 1e12L, 1e13L, 1e14L,
+                                                1e15L, 1e16L, 1e17L, 1e18L, 1e19L, 1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+        long double v = (long double)w;
+        if (e10 < 0) v /= kPow10L[-e10]; else v *= kPow10L[e10];
+        unsigned long long mant;
+        std::memcpy(&mant, &v, 8);      // (the 64 explicit mantissa bits of the extended format)
+        const unsigned low = (unsigned)(mant & 0x7ffull);
+        if (low < 0x3ffu || low > 0x401u) {
+            const double dv = (double)v;
+            out = neg ? -dv : dv;
+            return q;
+        }
+    }
+#endif
     return parseDoubleSlow(p, end, out);
 }
 
@@ -353,6 +390,7 @@ template <class T>
 void joinPieces(std::vector<T>& out, std::vector<std::vector<T>>& pieces) {
     std::vector<size_t> base(pieces.size() + 1, 0);
     for (size_t i = 0; i < pieces.size(); ++i) base[i + 1] = base[i] + pieces[i].size();
+    { std::vector<T> fresh; reserveHuge(fresh, base.back()); out.swap(fresh); }
     out.resize(base.back());
     parallelParts((int)pieces.size(), [&](int t) {
         if (!pieces[(size_t)t].empty()) std::memcpy(out.data() + base[(size_t)t], pieces[(size_t)t].data(), pieces[(size_t)t].size() * sizeof(T));
@@ -375,7 +413,7 @@ bool readLabelBodyParallel(Scanner& s, long long n, std::vector<int32_t>& out) {
         const char* q = cut[(size_t)t];
         const char* e = cut[(size_t)t + 1];
         auto& v = pieces[(size_t)t];
-        v.reserve((size_t)(e - q) / 6 + 16);
+        reserveHuge(v, (size_t)(e - q) / 6 + 16);
         while (true) {
             while (q < e && plainWs(*q)) ++q;
             if (q >= e) break;
@@ -413,6 +451,7 @@ void readLabels(Scanner& s, const Header& h, std::vector<int32_t>& out, bool las
         ++s.p;
         const size_t bytes = (size_t)n * h.labelBytes;
         if ((size_t)(s.end - s.p) < bytes) s.fail("truncated binary label list");
+        { std::vector<int32_t> fresh; reserveHuge(fresh, (size_t)n); out.swap(fresh); }
         out.resize((size_t)n);
         if (h.labelBytes == 4) parallelCopy(out.data(), s.p, bytes);
         else {
@@ -490,7 +529,7 @@ static bool readPointBodyParallel(Scanner& s, long long n, std::vector<double>& 
         const char* q = cut[(size_t)t];
         const char* e = cut[(size_t)t + 1];
         auto& v = pieces[(size_t)t];
-        v.reserve((size_t)(e - q) / 8 + 16);
+        reserveHuge(v, (size_t)(e - q) / 8 + 16);
         auto ws = [&] { while (q < e && plainWs(*q)) ++q; };
         while (true) {
             ws();
@@ -531,6 +570,7 @@ void readPoints(const std::string& file, std::vector<double>& pts) {
         ++s.p;
         const size_t bytes = (size_t)n * 3 * h.scalarBytes;
         if ((size_t)(s.end - s.p) < bytes) s.fail("truncated binary point list");
+        { std::vector<double> fresh; reserveHuge(fresh, (size_t)n * 3); pts.swap(fresh); }
         pts.resize((size_t)n * 3);
         if (h.scalarBytes == 8) parallelCopy(pts.data(), s.p, bytes);
         else for (long long i = 0; i < 3 * n; ++i) { float v; std::memcpy(&v, s.p + 4 * i, 4); pts[(size_t)i] = v; }
@@ -570,8 +610,8 @@ static bool readFaceBodyParallel(Scanner& s, long long n, std::vector<int32_t>& 
         const char* e = cut[(size_t)t + 1];
         auto& sz = sizes[(size_t)t];
         auto& v = vals[(size_t)t];
-        sz.reserve((size_t)(e - q) / 24 + 16);
-        v.reserve((size_t)(e - q) / 6 + 16);
+        reserveHuge(sz, (size_t)(e - q) / 24 + 16);
+        reserveHuge(v, (size_t)(e - q) / 6 + 16);
         auto ws = [&] { while (q < e && plainWs(*q)) ++q; };
         while (true) {
             ws();
@@ -601,6 +641,7 @@ static bool readFaceBodyParallel(Scanner& s, long long n, std::vector<int32_t>& 
     std::vector<size_t> fBase((size_t)parts + 1, 0), vBase((size_t)parts + 1, 0);
     for (int t = 0; t < parts; ++t) { fBase[(size_t)t + 1] = fBase[(size_t)t] + sizes[(size_t)t].size(); vBase[(size_t)t + 1] = vBase[(size_t)t] + vals[(size_t)t].size(); }
     if ((long long)fBase.back() != n || vBase.back() > (size_t)INT32_MAX) return false;
+    { std::vector<int32_t> fresh; reserveHuge(fresh, (size_t)n + 1); off.swap(fresh); }
     off.resize((size_t)n + 1);
     off[0] = 0;
     parallelParts(parts, [&](int t) {

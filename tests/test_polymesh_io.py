@@ -242,6 +242,21 @@ def test_decimal_parser_is_strtod(tmp_path):
         if rng.random() < 0.5:
             t += "e%+d" % rng.integers(-330, 330)
         toks.append(t)
+    # the extended-precision path (17 .. 19 digit mantissas, |exponent| <= 27): coordinates as precision 17 writes them, 19-digit
+    # mantissas, and values constructed to sit next to a midpoint between two doubles (where only strtod may decide)
+    toks += ["%.17g" % x for x in rng.uniform(-2, 2, 120000)] + ["%.16e" % x for x in rng.uniform(-1e3, 1e3, 40000)]
+    for _ in range(40000):
+        mant = "".join(rng.choice(list("0123456789"), size=19)).lstrip("0") or "1"
+        toks.append(("-" if rng.random() < 0.5 else "") + mant[0] + "." + mant[1:] + "e%+d" % rng.integers(-9, 9))
+    for x in rng.uniform(0.5, 2, 4000):
+        lo = np.float64(x)
+        hi = np.nextafter(lo, np.inf)
+        from fractions import Fraction
+        mid = (Fraction(float(lo)) + Fraction(float(hi))) / 2                  # exactly between two doubles
+        for k in (-3, -1, 0, 1, 3):                                           # ... and a few units of the 19th digit around it
+            v = mid + Fraction(k, 10 ** 18)
+            digits = str(int(v * 10 ** 18))
+            toks.append(digits[:-18] + "." + digits[-18:])
     while len(toks) % 3:
         toks.append("0")
     n = len(toks) // 3
