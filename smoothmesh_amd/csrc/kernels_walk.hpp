@@ -610,17 +610,30 @@ __global__ void __launch_bounds__(kBlock, SMGPU_STAR_WAVES) k_walk_pred_star(Mes
 // cavity mesh: 10.3 M tasks per launch against 29.3 M lane-steps of the star form.  The arithmetic per (edge, cell) pair is
 // starLaneAngle's, operation for operation.
 #ifndef SMGPU_PACK_WAVES
-#define SMGPU_PACK_WAVES 3
+#define SMGPU_PACK_WAVES 4
+#endif
+#ifndef SMGPU_PACK_SEQ
+#define SMGPU_PACK_SEQ 0
+#endif
+#ifndef SMGPU_PACK_UNROLL
+#define SMGPU_PACK_UNROLL 2      // vertices of a ring face fetched together (4 / 2 / 1)
 #endif
 constexpr int kPackBlock = 256;
-// Vertex slots of a star: 96 (k_walk_pred_star: 128; an interior hex point has 48, the refinement interfaces of the castellated
-// meshes at most 60; a larger star is left to the general kernels).  Measured before the coordinate table below, on the 10 M-cell
+// Vertex slots of a star: 64 since round 6, 96 before (k_walk_pred_star: 128; an interior hex point has 48, the refinement interfaces
+// of the castellated meshes at most 60; a larger star is left to the general kernels).  Measured before the coordinate table below, on the 10 M-cell
 // cavity mesh (profiles/r4/ab_walk_pred_pack.txt): 64 slots and FOUR waves per SIMD 724 us (128 VGPRs, 36 of them spilled), 64
 // slots at three waves 693 (168 VGPRs), 128 slots at three waves 697 -- the kernel is not occupancy bound.  Round 5, with the other
 // kernels' occupancy steps in mind, once more: -DSMGPU_PACK_WAVES=4 -DSMGPU_PACK_VERTS=60 (40.3 KB per block, 128 VGPRs with 41 spilled) 937
 // against 673 us for the launch group: four waves only help if the registers fit, and they do not.
+// Round 6: FOUR waves per SIMD after all (k_fa_pred 685 -> 620 us on the 10 M-cell cavity mesh, 188 -> 173 on the 1 M-cell one, same box,
+// bit-equal; profiles/r6/ab_walk_four_waves.txt).  What made the registers fit: the job loop on its own needs 126 VGPRs, and with
+// the ring faces' vertices fetched two at a time instead of four (SMGPU_PACK_UNROLL) the compiler keeps it free of scratch under a
+// 128-VGPR cap -- the 17 values it still spills are staging state touched once per pair of stars; and the LDS: 64 vertex slots and 16
+// entries (kPackEnts) are 9.2 KB per wave, 16 waves per CU.  (Round 4's four-wave build -- 64 slots, the four-vertex fetch -- had 36
+// spills inside the job loop: 724 us against 693; round 5's used 60 slots, which is not a multiple of the 32 a lane deals at a time
+// (now a static_assert), and 41 spills: 937 us.)
 #ifndef SMGPU_PACK_VERTS
-#define SMGPU_PACK_VERTS 96
+#define SMGPU_PACK_VERTS 64
 #endif
 constexpr int kPackVerts = SMGPU_PACK_VERTS;
 // One coordinate table per half: the vertex slots [0, kPackVerts), behind them the proposals of the point's entries
@@ -628,15 +641,20 @@ constexpr int kPackVerts = SMGPU_PACK_VERTS;
 // entry's neighbour hypothetically: a vertex slot whose role says "the point" / "that neighbour" is then read from the other
 // INDEX of the same table -- two 32-bit selects per vertex instead of six 64-bit ones on its coordinates (selecting a V3 by
 // value cost 12 v_cndmask per vertex, a quarter of a task's vector instructions).
-constexpr int kPackEnt0 = kPackVerts, kPackCur = kPackVerts + kStarEnts, kPackProp = kPackCur + 1, kPackSlots = kPackProp + 1;
+#ifndef SMGPU_PACK_ENTS
+#define SMGPU_PACK_ENTS 16
+#endif
+constexpr int kPackEnts = SMGPU_PACK_ENTS;      // entries (neighbours) of a star in this kernel (<= kStarEnts; hexahedral and castellated meshes: 6)
+static_assert(kPackVerts % 32 == 0 && kPackEnts <= kStarEnts, "k_walk_pred_pack: vertex slots are dealt 32 at a time");
+constexpr int kPackEnt0 = kPackVerts, kPackCur = kPackVerts + kPackEnts, kPackProp = kPackCur + 1, kPackSlots = kPackProp + 1;
 struct PackStar {
     int fid[kStarFaces];
     int voff[kStarFaces + 1];
     unsigned char role[kPackVerts];      // kRoleSelf: the point itself, e < kStarEnts: the neighbour of entry e, kRoleOther
     double vx[kPackSlots], vy[kPackSlots], vz[kPackSlots];
-    unsigned char nb[kStarEnts];
+    unsigned char nb[kPackEnts];
     double pMin, pMax;                   // ptMin / ptMax of the half wave's point
-    int eq[kStarEnts];                   // entry e's neighbour (point id)
+    int eq[kPackEnts];                   // entry e's neighbour (point id)
     struct { int fbeg[kStarFaces]; unsigned char vface[kPackVerts]; } st;   // staging only: first entry of the face in facePts,
                                                                              // the star-local face of every vertex slot
 };
@@ -644,7 +662,7 @@ struct PackPlace { double ccx, ccy, ccz; unsigned char l, lNext, xEnt, xSlot, pF
 struct PackLds {                         // per wave: two points
     PackStar h[2];
     PackPlace place[2][32];
-    unsigned touch[2][kStarEnts];        // [half][entry]: the counted places the entry's neighbour touches
+    unsigned touch[2][kPackEnts];        // [half][entry]: the counted places the entry's neighbour touches
     unsigned long long jmin[64], jmax[64];   // per job: bit patterns of the smallest / largest angle
     double selfAng[2][32];               // the self test's angle of every counted place
     int off[65];                         // first task of every job
@@ -671,7 +689,7 @@ __device__ __forceinline__ int nthSetBit(unsigned m, int r) {
 __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPlace& R, int selfIdx, int ei) {
     // selfIdx: where the point is in this job (kPackCur / kPackProp); ei: the entry whose neighbour sits at its proposal
     // (kRoleNoEntry: nobody); both are read through their slots of the coordinate table
-    const int entIdx = kPackEnt0 + (ei < kStarEnts ? ei : 0);
+    const int entIdx = kPackEnt0 + (ei < kPackEnts ? ei : 0);
     const int xs_ = ((int)R.xEnt == ei) ? entIdx : (int)R.xSlot;       // the edge's far end, possibly the moved neighbour
     const bool pFirst = R.pFirst != 0;
     const int i0 = pFirst ? selfIdx : xs_, i1 = pFirst ? xs_ : selfIdx;    // the edge's start and end (edges[2e], edges[2e + 1])
@@ -690,10 +708,17 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
             return v3(L.vx[at], L.vy[at], L.vz[at]);
         };
         int i = 0;
+#if SMGPU_PACK_UNROLL == 4
         for (; i + 4 <= n; i += 4) {
             const V3 q0 = vert(b + i), q1 = vert(b + i + 1), q2 = vert(b + i + 2), q3 = vert(b + i + 3);
             fc = fc + q0; fc = fc + q1; fc = fc + q2; fc = fc + q3;
         }
+#elif SMGPU_PACK_UNROLL == 2
+        for (; i + 2 <= n; i += 2) {
+            const V3 q0 = vert(b + i), q1 = vert(b + i + 1);
+            fc = fc + q0; fc = fc + q1;
+        }
+#endif
         for (; i < n; ++i) fc = fc + vert(b + i);
         fc = divByCount(fc, n);   // = fc / double(n), bit for bit
         const V3 cf = cC - fc;
@@ -702,6 +727,23 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
         const V3 w = pC - cC;
         return w / mag(w);
     };
+#if SMGPU_PACK_SEQ
+    // one sub-computation at a time (scheduling barriers): the cell's vector, then each face's vector straight into its cosine --
+    // fewer values alive at once (four waves per SIMD need <= 128 VGPRs)
+    __builtin_amdgcn_sched_barrier(0);
+    const V3 cc = v3(R.ccx, R.ccy, R.ccz);
+    const V3 cf = cC - cc;
+    const double dp = dot(cf, eVec);
+    const V3 pC = cc + dp * eVec;
+    const V3 w = pC - cC;
+    const V3 cV = w / mag(w);
+    __builtin_amdgcn_sched_barrier(0);
+    const double c0 = dot(faceVec(R.l), cV);
+    __builtin_amdgcn_sched_barrier(0);
+    const double c1 = dot(cV, faceVec(R.lNext));
+    __builtin_amdgcn_sched_barrier(0);
+    return clampAcos(c0) + clampAcos(c1);   // calcEdgeCenterEdgeAngle SM.C:980-998
+#else
     const V3 fv = faceVec(R.l), fn = faceVec(R.lNext);
     const V3 cc = v3(R.ccx, R.ccy, R.ccz);
     const V3 cf = cC - cc;
@@ -710,6 +752,7 @@ __device__ __forceinline__ double packTaskAngle(const PackStar& L, const PackPla
     const V3 w = pC - cC;
     const V3 cV = w / mag(w);
     return clampAcos(dot(fv, cV)) + clampAcos(dot(cV, fn));   // calcEdgeCenterEdgeAngle SM.C:980-998
+#endif
 }
 
 // the jobs W.jcode[0 .. nJobs) of the wave (phase 0: self tests and current-position entries; phase 1: proposal-position entries):
@@ -851,7 +894,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         const int totalLanes = __shfl(inclN, 31, 32), totalV = __shfl(inclV, 31, 32);
         const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
         // (entry j = the neighbour across edge j: pointPoints and pointEdges share their offsets, so nEnt == nEdgesP)
-        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kPackVerts && nEnt < kStarEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
+        const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kPackVerts && nEnt < kPackEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
         if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
         live = live && fits;
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
@@ -873,7 +916,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         }
         if (live && hl == 0) L.voff[nF] = totalV;
         if (live && hl < nEnt) L.eq[hl] = q;
-        W.touch[half][hl] = 0u;
+        if (hl < kPackEnts) W.touch[half][hl] = 0u;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         // this lane's ring place
@@ -957,7 +1000,7 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
                 const int l = side ? lNext : P.l;
                 for (int i = L.voff[l]; i < L.voff[l + 1]; ++i) {
                     const unsigned r = L.role[i];
-                    if (r < (unsigned)kStarEnts) atomicOr(&W.touch[half][r], 1u << hl);
+                    if (r < (unsigned)kPackEnts) atomicOr(&W.touch[half][r], 1u << hl);
                 }
             }
             PackPlace& R = W.place[half][hl];
