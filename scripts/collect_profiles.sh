@@ -1,8 +1,8 @@
 #!/bin/bash
 # run on the GPU box: benchmark lines + rocprofv3 kernel statistics + PMC traffic / SQ counters for the round's profiles/
-# usage: scripts/collect_profiles.sh [round tag, default r5]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
+# usage: scripts/collect_profiles.sh [round tag, default r6]   -> gpurun_out/profiles_<tag>/ (copy what is to be judged to profiles/<tag>/)
 export SMOOTHMESH_BENCH_FULL=1   # bench.py prints its full document (not the compact driver line) on stdout
-tag=${1:-r5}
+tag=${1:-r6}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/profiles_$tag
 rm -rf $out; mkdir -p $out
@@ -60,4 +60,7 @@ cp gpurun_out/probe_timeline2/inorder.txt $out/probe_rank_of_8_abs_timeline_inor
 (timeout 300 python3 scripts/check_arrangements.py 2>&1 | grep -E "reference|same bits|DIFFERENT|arrangements"; SMOOTHMESH_EXCHANGE=push timeout 300 python3 scripts/check_arrangements.py 2>&1 | grep -E "reference|same bits|DIFFERENT|arrangements") > $out/check_arrangements.txt
 SMGPU_HALO_MERGED=0 timeout 300 python3 scripts/probe_rank_of_8.py 2>&1 | grep -E "rank 0 of 8|inorder|overlap|serial|transport" > $out/probe_rank_of_8_rccl_one_kernel_per_step.txt
 SMGPU_HALO_MERGED=0 SMOOTHMESH_EXCHANGE=push timeout 300 python3 scripts/probe_rank_of_8.py 2>&1 | grep -E "rank 0 of 8|inorder|overlap|serial|transport" > $out/probe_rank_of_8_push_one_kernel_per_step.txt
+# round 6: configs[4]'s rank (the 430^3-base polyhedral mesh's box 0, constraints on) and the tool a user runs, end to end
+timeout 900 python3 scripts/probe_rank_of_8.py cavity215c 2>&1 | grep -v "^\[W\|Warning" > $out/probe_rank_of_8_cavity215c_rccl.txt
+timeout 900 python3 scripts/cli_clocktime.py 215 --serial-io > $out/cli_cavity215c_clocktime.txt 2>&1
 ls -la $out
