@@ -1059,7 +1059,9 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         if (eligible && live) W.jcode[jb + first + myRank] = (unsigned char)((half << 7) | hl);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+#ifndef SMGPU_PACK_ABLATE_JOBS      // (measurement build: staging only)
         packRunJobs(W, lane, nJ0 + nJ1, 0, prm, s);
+#endif
         // what phase 1 decided: the self tests; then whether the point can act from its proposal at all (SM.C:1376-1399)
         if (selfNeeded && W.selfBad[half]) sbits |= 1u;
         const bool propJobs = live && moved && !(sbits & 5u) && nEl > 0;
@@ -1072,7 +1074,9 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             if (propJobs && eligible) W.jcode[pb + myRank] = (unsigned char)((half << 7) | hl);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+#ifndef SMGPU_PACK_ABLATE_JOBS
             packRunJobs(W, lane, nP0 + nP1, 1, prm, s);
+#endif
         }
         if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
         const int nJobs = nJ + nP;
