@@ -672,6 +672,31 @@ struct PackLds {                         // per wave: two points
 };
 static_assert(sizeof(PackLds) * (kPackBlock / 64) * SMGPU_PACK_WAVES <= 160 * 1024, "k_walk_pred_pack: LDS per CU");
 
+// ---- the STATIC part of a star, kept between iterations (round 6) ----------------------------------------------------------------
+// Staging a star was 228 of the kernel's 598 us on the 10 M-cell cavity mesh (a build without the job loops): five levels of
+// dependent gathers through the addressing (the point's edge and face lists -> their ranges -> vertex ids, ring faces and cells ->
+// coordinates), the roles of the vertex slots, the ring places with their face slots, the places every entry touches.  All of it but
+// the coordinates and the neighbours' states is TOPOLOGY: the same every iteration a point is active -- and the points outside the
+// good range are the same few per cent of the mesh iteration after iteration (refinement interfaces).  So the first walk a point
+// takes part in leaves its record here (k_walk_star_build: the dynamic staging, dumped), and every later one (k_walk_pred_cached)
+// reads the record with coalesced loads and gathers coordinates only: ONE level of dependent loads.  A pool of records with a bump
+// counter; slot[p]: -1 not built yet, -2 the star does not fit the packed form (the general kernels take it), -3 the pool was full
+// (k_walk_pred_pack_rest stages the star every iteration, as before).
+struct StarRec {
+    int vid[kPackVerts];                       // vertex slot -> point id, -1 beyond the star's slots
+    unsigned char role[kPackVerts];
+    unsigned char voff[kStarFaces + 4];        // first vertex slot of every face (<= kPackVerts <= 255), one behind the last
+    int q[kPackEnts];                          // the entries' neighbours, -1 beyond the point's entries
+    unsigned touch[kPackEnts];                 // the counted places every entry touches
+    struct Place { int rc; unsigned char l, lNext, xEnt, xSlot, pFirst, counts, pad[2]; } place[32];
+    unsigned cmask;                            // the counted places
+    int opsPerJob;                             // packJobOps (timing passes)
+    unsigned char nEnt, nFaces, totalV, nPlaces;
+    int pad[4];
+};
+static_assert(kPackVerts <= 255 && sizeof(StarRec) % 16 == 0, "StarRec: 16-byte records");
+struct StarCache { int* slot; StarRec* pool; int* count; int capacity; };
+
 // position of the r-th (0-based) set bit of m (r < popcount(m))
 __device__ __forceinline__ int nthSetBit(unsigned m, int r) {
     int pos = 0;
@@ -834,6 +859,69 @@ __device__ __forceinline__ void packRunJobs(PackLds& W, int lane, int nJobs, int
     __builtin_amdgcn_wave_barrier();
 }
 
+// The algorithmic FP64 instructions of ONE job of a star, by the reference's arithmetic (SM.C:1135-1231 per (edge, cell) pair: two
+// projected face-centre vectors 77 + 3 (n - 1) + (3 | 33) each for a face of n vertices, the projected cell centre 77, two clamped
+// acos and their sum 95 -- sqrt = 22, division = 11 per component, acos = 40; per edge of the point 69 for the edge vector).  Called by
+// the 32 lanes of a half; nv = the vertex count of the lane's ring face (counted places only).
+__device__ __forceinline__ int packJobOps(bool counts, int nv, int nEdgesP) {
+    int ops = counts ? 2 * (77 + 3 * (nv - 1) + (((nv & (nv - 1)) == 0) ? 3 : 33)) + 77 + 95 : 0;
+    for (int o = 16; o > 0; o >>= 1) ops += __shfl_xor(ops, o, 32);
+    return ops + 69 * nEdgesP;
+}
+// Everything behind the staging of a pair of stars (k_walk_pred_pack / k_walk_pred_cached): the job lists of both phases, the
+// verdicts, the point's and the entries' bits.  Called by all 64 lanes.
+__device__ __forceinline__ void packFinish(PackLds& W, PackStar& L, const State& s, const WalkView& w, const Prm& prm, int lane, int half, int hl, int a,
+                                           bool live, bool moved, bool frozenBefore, bool eligible, int q, int eBeg, bool counts, int opsPerJob,
+                                           unsigned long long* opCount) {
+        const unsigned countedMask = (unsigned)(__ballot(counts) >> (32 * half));
+        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
+        const bool selfNeeded = live && moved && !frozenBefore;
+        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
+        const int nEl = live ? __popc(elig) : 0, first = selfNeeded ? 1 : 0;
+        const int myRank = __popc(elig & ((1u << hl) - 1u));
+        // ---- phase 1: the self test (all counted places, p at its proposal) and every eligible entry with p at its CURRENT position
+        // (the places it touches).  Job t of the wave: half 0's jobs, then half 1's.
+        const int nJ = live ? first + nEl : 0;
+        const int nJ0 = __shfl(nJ, 0, 64), nJ1 = __shfl(nJ, 32, 64);
+        const int jb = half ? nJ0 : 0;
+        if (hl == 0) { W.hflags[half] = (unsigned char)((moved ? 1 : 0) | (selfNeeded ? 2 : 0)); W.selfBad[half] = 0; W.cmask[half] = countedMask; }
+        if (hl == 0 && selfNeeded) W.jcode[jb] = (unsigned char)((half << 7) | 127);
+        if (eligible && live) W.jcode[jb + first + myRank] = (unsigned char)((half << 7) | hl);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#ifndef SMGPU_PACK_ABLATE_JOBS      // (measurement build: staging only)
+        packRunJobs(W, lane, nJ0 + nJ1, 0, prm, s);
+#endif
+        // what phase 1 decided: the self tests; then whether the point can act from its proposal at all (SM.C:1376-1399)
+        if (selfNeeded && W.selfBad[half]) sbits |= 1u;
+        const bool propJobs = live && moved && !(sbits & 5u) && nEl > 0;
+        // ---- phase 2: the eligible entries of the points that act from their proposal, p at its PROPOSAL: the touched places are
+        // evaluated, the others keep the angle the self test found for them
+        const int nP = propJobs ? nEl : 0;
+        const int nP0 = __shfl(nP, 0, 64), nP1 = __shfl(nP, 32, 64);
+        if (nP0 + nP1 > 0) {                                        // (wave-uniform)
+            const int pb = half ? nP0 : 0;
+            if (propJobs && eligible) W.jcode[pb + myRank] = (unsigned char)((half << 7) | hl);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#ifndef SMGPU_PACK_ABLATE_JOBS
+            packRunJobs(W, lane, nP0 + nP1, 1, prm, s);
+#endif
+        }
+        if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
+        const int nJobs = nJ + nP;
+        if (opCount) {
+            // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs (opsPerJob: packJobOps below) times the jobs
+            // that were needed.  One add per point, spread over 64 words.
+            if (live && hl == 0) atomicAdd(&opCount[a & 63], (unsigned long long)nJobs * (unsigned long long)opsPerJob);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (q >= 0) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+}
+
 // TWO active points per wave as in k_walk_pred_star (the staging is the same code), the jobs packed (packRunJobs)
 // memo (measurement aid, SMGPU_WALK_MEMO_STATS=1; NULL otherwise): [0] stars whose inputs have the bits they had in the point's previous
 // walk, [1] stars seen, [2 + p] the hash of point p's star inputs -- everything its jobs read: the vertex slots with their roles,
@@ -849,8 +937,10 @@ __device__ __forceinline__ unsigned long long memoMix(unsigned long long h, unsi
     h *= 0xff51afd7ed558ccdull;
     return h ^ (h >> 33);
 }
-__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount,
-                                                                                 unsigned long long* memo = nullptr) {
+// DUMP: build the records of the active points that have none yet (k_walk_star_build) instead of evaluating anything
+template <bool DUMP>
+__device__ __forceinline__ void packKernelBody(const MeshView& m, const State& s, const Prm& prm, const WalkView& w, int nA, int nE, unsigned long long* opCount,
+                                               unsigned long long* memo, const StarCache& sc) {
     if (s.acc->stop) return;
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
     __shared__ PackLds plds[kPackBlock / 64];
@@ -864,6 +954,13 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         bool live = a < nA;
         if (a == 0 && hl == 0) w.actEntOff[nA] = nE;
         const int p = live ? w.actIds[a] : 0;
+        if (DUMP) {      // (wave-uniform) only the points without a record
+            live = live && sc.slot[p] == -1;
+            if (!__any(live)) continue;
+        } else if (sc.slot) {      // behind k_walk_pred_cached: only the points the full pool could not take
+            live = live && sc.slot[p] == -3;
+            if (!__any(live)) continue;
+        }
         bool moved;
         const bool frozenBefore = s.frozen[p] != 0;
         {   // the point itself goes to LDS (every job reads it from there)
@@ -895,7 +992,8 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
         const unsigned ringBad = (unsigned)(__ballot(myRingBad) >> (32 * half));
         // (entry j = the neighbour across edge j: pointPoints and pointEdges share their offsets, so nEnt == nEdgesP)
         const bool fits = nEdgesP <= 32 && nF <= kStarFaces && totalLanes <= 32 && totalV <= kPackVerts && nEnt < kPackEnts && nEnt == nEdgesP && ringBad == 0u;   // (< : self + entries <= 32 jobs per half)
-        if (live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
+        if (!DUMP && live && !fits && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }   // left to k_walk_pred_self / k_walk_pred (onlyLeft)
+        if (DUMP && live && !fits && hl == 0) sc.slot[p] = -2;
         live = live && fits;
         // the entries of the point: lane i holds entry i (its neighbour, whether that one is free and moving)
         const int q = (live && hl < nEnt) ? w.entNbr[eBeg + hl] : -1;
@@ -1008,6 +1106,33 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
             R.l = (unsigned char)P.l; R.lNext = (unsigned char)lNext; R.xEnt = (unsigned char)P.xEnt; R.xSlot = (unsigned char)P.xSlot;
             R.pFirst = P.pFirst ? 1 : 0;
         }
+        if (DUMP) {      // the static part of both stars into their records
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const unsigned cm = (unsigned)(__ballot(counts) >> (32 * half));
+            const int ops = packJobOps(counts, counts ? L.voff[P.l + 1] - L.voff[P.l] : 0, nEdgesP);
+            int slot = -3;
+            if (live && hl == 0) { slot = atomicAdd(sc.count, 1); if (slot >= sc.capacity) slot = -3; }      // (-3: the pool is full -- k_walk_pred_pack stages the star every time)
+            slot = __shfl(slot, 0, 32);
+            if (live && slot >= 0) {
+                StarRec& R = sc.pool[slot];
+#pragma unroll
+                for (int u = 0; u < kPackVerts / 32; ++u) { const int k = hl + 32 * u; R.vid[k] = vg[u]; R.role[k] = role[u]; }
+                R.voff[hl] = (unsigned char)((hl <= nF) ? L.voff[hl] : 0);
+                if (hl < 4) R.voff[32 + hl] = (unsigned char)((hl == 0 && nF == 32) ? L.voff[32] : 0);
+                if (hl < kPackEnts) { R.q[hl] = q; R.touch[hl] = W.touch[half][hl]; }
+                StarRec::Place pl;
+                pl.rc = rc; pl.l = (unsigned char)P.l; pl.lNext = (unsigned char)lNext; pl.xEnt = (unsigned char)P.xEnt; pl.xSlot = (unsigned char)P.xSlot;
+                pl.pFirst = P.pFirst ? 1 : 0; pl.counts = counts ? 1 : 0; pl.pad[0] = pl.pad[1] = 0;
+                R.place[hl] = pl;
+                if (hl == 0) {
+                    R.cmask = cm; R.opsPerJob = ops; R.nEnt = (unsigned char)nEnt; R.nFaces = (unsigned char)nF; R.totalV = (unsigned char)totalV;
+                    R.nPlaces = (unsigned char)totalLanes; R.pad[0] = R.pad[1] = R.pad[2] = R.pad[3] = 0;
+                }
+            }
+            if (live && hl == 0) sc.slot[p] = slot;
+            continue;
+        }
         if (SMGPU_WALK_MEMO && memo) {      // (wave-uniform) the hash of the star's inputs against the one of the point's previous walk
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -1043,59 +1168,105 @@ __global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack
                 memo[2 + (size_t)p] = hsh;
             }
         }
-        const unsigned countedMask = (unsigned)(__ballot(counts) >> (32 * half));
-        unsigned sbits = (moved ? 2u : 0u) | (frozenBefore ? 4u : 0u);
-        const bool selfNeeded = live && moved && !frozenBefore;
-        const unsigned elig = (unsigned)(__ballot(eligible) >> (32 * half));
-        const int nEl = live ? __popc(elig) : 0, first = selfNeeded ? 1 : 0;
-        const int myRank = __popc(elig & ((1u << hl) - 1u));
-        // ---- phase 1: the self test (all counted places, p at its proposal) and every eligible entry with p at its CURRENT position
-        // (the places it touches).  Job t of the wave: half 0's jobs, then half 1's.
-        const int nJ = live ? first + nEl : 0;
-        const int nJ0 = __shfl(nJ, 0, 64), nJ1 = __shfl(nJ, 32, 64);
-        const int jb = half ? nJ0 : 0;
-        if (hl == 0) { W.hflags[half] = (unsigned char)((moved ? 1 : 0) | (selfNeeded ? 2 : 0)); W.selfBad[half] = 0; W.cmask[half] = countedMask; }
-        if (hl == 0 && selfNeeded) W.jcode[jb] = (unsigned char)((half << 7) | 127);
-        if (eligible && live) W.jcode[jb + first + myRank] = (unsigned char)((half << 7) | hl);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-#ifndef SMGPU_PACK_ABLATE_JOBS      // (measurement build: staging only)
-        packRunJobs(W, lane, nJ0 + nJ1, 0, prm, s);
-#endif
-        // what phase 1 decided: the self tests; then whether the point can act from its proposal at all (SM.C:1376-1399)
-        if (selfNeeded && W.selfBad[half]) sbits |= 1u;
-        const bool propJobs = live && moved && !(sbits & 5u) && nEl > 0;
-        // ---- phase 2: the eligible entries of the points that act from their proposal, p at its PROPOSAL: the touched places are
-        // evaluated, the others keep the angle the self test found for them
-        const int nP = propJobs ? nEl : 0;
-        const int nP0 = __shfl(nP, 0, 64), nP1 = __shfl(nP, 32, 64);
-        if (nP0 + nP1 > 0) {                                        // (wave-uniform)
-            const int pb = half ? nP0 : 0;
-            if (propJobs && eligible) W.jcode[pb + myRank] = (unsigned char)((half << 7) | hl);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-#ifndef SMGPU_PACK_ABLATE_JOBS
-            packRunJobs(W, lane, nP0 + nP1, 1, prm, s);
-#endif
+        const int opsPerJob = opCount ? packJobOps(counts, counts ? L.voff[P.l + 1] - L.voff[P.l] : 0, nEdgesP) : 0;
+        packFinish(W, L, s, w, prm, lane, half, hl, a, live, moved, frozenBefore, eligible, q, eBeg, counts, opsPerJob, opCount);
+    }
+}
+
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount,
+                                                                                 unsigned long long* memo = nullptr) {
+    packKernelBody<false>(m, s, prm, w, nA, nE, opCount, memo, StarCache{nullptr, nullptr, nullptr, 0});
+}
+// ... for the points whose records found no room in the pool (StarCache::slot == -3), behind k_walk_pred_cached
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_pack_rest(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount,
+                                                                                      StarCache sc) {
+    packKernelBody<false>(m, s, prm, w, nA, nE, opCount, nullptr, sc);
+}
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_star_build(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, StarCache sc) {
+    packKernelBody<true>(m, s, prm, w, nA, nE, nullptr, nullptr, sc);
+}
+
+// The same predicates from the stars' records (StarRec): the static tables arrive with coalesced loads, the only dependent level
+// left is the coordinates -- the star's vertices, its ring cells' centres, the entries' proposals -- and the neighbours' states.
+// Points without a record (slot < 0: the star does not fit, or the pool is full) are left to the general kernels like the stars
+// k_walk_pred_pack cannot take.  What the jobs read is, array for array, what k_walk_pred_pack's staging leaves in LDS.
+__global__ void __launch_bounds__(kPackBlock, SMGPU_PACK_WAVES) k_walk_pred_cached(MeshView m, State s, Prm prm, WalkView w, int nA, int nE, unsigned long long* opCount,
+                                                                                   StarCache sc) {
+    if (s.acc->stop) return;
+    if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
+    __shared__ PackLds plds[kPackBlock / 64];
+    PackLds& W = plds[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63, half = lane >> 5, hl = lane & 31;
+    PackStar& L = W.h[half];
+    const int groups = gridDim.x * (kPackBlock / 32);
+    for (int a0 = (blockIdx.x * (kPackBlock / 64) + (threadIdx.x >> 6)) * 2; a0 < nA; a0 += groups) {
+        const int a = a0 + half;
+        bool live = a < nA;
+        if (a == 0 && hl == 0) w.actEntOff[nA] = nE;
+        const int p = live ? w.actIds[a] : 0;
+        const int slot = live ? sc.slot[p] : -1;
+        const int eBeg = live ? w.actEntOff[a] : 0, eEnd = live ? ((a + 1 < nA) ? w.actEntOff[a + 1] : nE) : 0, nEnt = eEnd - eBeg;
+        const StarRec& R = sc.pool[slot >= 0 ? slot : 0];
+        // round 1: the record (static) and the point itself
+        const bool frozenBefore = s.frozen[p] != 0;
+        const V3 cur = ldv(s.ptsCur, p);
+        const V3 np = ldv(s.prop, p);
+        const double pMin = s.ptMin[p], pMax = s.ptMax[p];
+        int vg[kPackVerts / 32];
+        unsigned char role[kPackVerts / 32];
+#pragma unroll
+        for (int u = 0; u < kPackVerts / 32; ++u) { vg[u] = R.vid[hl + 32 * u]; role[u] = R.role[hl + 32 * u]; }
+        const unsigned voffWord = reinterpret_cast<const unsigned*>(R.voff)[hl < (kStarFaces + 4) / 4 ? hl : 0];
+        const int qRec = R.q[hl < kPackEnts ? hl : 0];
+        const unsigned touchRec = R.touch[hl < kPackEnts ? hl : 0];
+        const StarRec::Place pl = R.place[hl];
+        const int recEnt = R.nEnt, opsPerJob = R.opsPerJob;
+        const bool fits = slot >= 0 && recEnt == nEnt;
+        // (slot -3: k_walk_pred_pack_rest takes the point; everything else without a usable record is left to k_walk_pred_self / k_walk_pred)
+        if (live && !fits && slot != -3 && hl == 0) { w.actBits[a] = kStarLeft; atomicAdd(&w.header[2], 1); }
+        live = live && fits;
+        const bool moved = (np != cur);
+        const int q = (live && hl < nEnt) ? qRec : -1;
+        const bool counts = live && pl.counts != 0;
+        // round 2: the coordinates and the neighbours' states
+        V3 vc[kPackVerts / 32];
+#pragma unroll
+        for (int u = 0; u < kPackVerts / 32; ++u) { if (!live) vg[u] = -1; vc[u] = (vg[u] >= 0) ? ldv(s.ptsCur, vg[u]) : v3(0, 0, 0); }
+        V3 cc = v3(0, 0, 0);
+        if (counts && pl.rc >= 0) cc = ldv(s.cellCtr, pl.rc);        // mesh.C()[cellI] of the CURRENT mesh, SM.C:1218
+        V3 nq = v3(0, 0, 0);
+        bool eligible = false;
+        unsigned char nb0 = 0;
+        if (q >= 0) {
+            nq = ldv(s.prop, q);
+            const bool qFrozen = s.frozen[q] != 0;
+            nb0 = qFrozen ? 8 : 0;
+            eligible = !qFrozen && nq != ldv(s.ptsCur, q);   // SM.C:1411-1414
+            if (eligible) nb0 |= 4;
         }
-        if (live && hl == 0) w.actBits[a] = (uint8_t)sbits;
-        const int nJobs = nJ + nP;
-        if (opCount) {
-            // timing passes only: the ALGORITHMIC FP64 instructions of this point's jobs, by the reference's arithmetic
-            // (SM.C:1135-1231 per (edge, cell) pair: two projected face-centre vectors 77 + 3 (n - 1) + (3 | 33) each for a face
-            // of n vertices, the projected cell centre 77, two clamped acos and their sum 95 -- sqrt = 22, division = 11 per
-            // component, acos = 40; per edge of the point 69 for the edge vector) times the jobs that were needed.  One add per
-            // point, spread over 64 words.
-            const int nv = counts ? L.voff[P.l + 1] - L.voff[P.l] : 0;
-            int ops = counts ? 2 * (77 + 3 * (nv - 1) + (((nv & (nv - 1)) == 0) ? 3 : 33)) + 77 + 95 : 0;
-            for (int o = 16; o > 0; o >>= 1) ops += __shfl_xor(ops, o, 32);
-            if (live && hl == 0) atomicAdd(&opCount[a & 63], (unsigned long long)nJobs * (unsigned long long)(ops + 69 * nEdgesP));
+        // into LDS, as k_walk_pred_pack's staging leaves it
+        if (hl == 0) {
+            L.vx[kPackCur] = cur.x; L.vy[kPackCur] = cur.y; L.vz[kPackCur] = cur.z;
+            L.vx[kPackProp] = np.x; L.vy[kPackProp] = np.y; L.vz[kPackProp] = np.z;
+            L.pMin = pMin; L.pMax = pMax;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (q >= 0) { w.entBits[eBeg + hl] = L.nb[hl]; w.entSlot[eBeg + hl] = activeSlotOf(s, w, q); }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        if (live && hl < (kStarFaces + 4) / 4) {
+#pragma unroll
+            for (int b = 0; b < 4; ++b) if (4 * hl + b <= kStarFaces) L.voff[4 * hl + b] = (int)((voffWord >> (8 * b)) & 0xffu);
+        }
+#pragma unroll
+        for (int u = 0; u < kPackVerts / 32; ++u) {
+            const int k = hl + 32 * u;
+            if (vg[u] >= 0) { L.role[k] = role[u]; L.vx[k] = vc[u].x; L.vy[k] = vc[u].y; L.vz[k] = vc[u].z; }
+        }
+        if (q >= 0) { L.nb[hl] = nb0; L.vx[kPackEnt0 + hl] = nq.x; L.vy[kPackEnt0 + hl] = nq.y; L.vz[kPackEnt0 + hl] = nq.z; }
+        if (hl < kPackEnts) W.touch[half][hl] = live ? touchRec : 0u;
+        if (counts) {
+            PackPlace& Rp = W.place[half][hl];
+            Rp.ccx = cc.x; Rp.ccy = cc.y; Rp.ccz = cc.z;
+            Rp.l = pl.l; Rp.lNext = pl.lNext; Rp.xEnt = pl.xEnt; Rp.xSlot = pl.xSlot; Rp.pFirst = pl.pFirst;
+        }
+        packFinish(W, L, s, w, prm, lane, half, hl, a, live, moved, frozenBefore, eligible, q, eBeg, counts, opsPerJob, opCount);
     }
 }
 

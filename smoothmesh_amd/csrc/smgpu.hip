@@ -164,6 +164,8 @@ struct smgpu_handle {
     bool faSideExact = true;   // SMGPU_FA_SIDE_EXACT=0: the exact face-angle pass on the main stream after the edge-angle kernels
     bool faExactOnSide = false;
     bool walkPack = true;      // SMGPU_WALK_PACK=0: k_walk_pred_star (one job per step on all ring places) instead of k_walk_pred_pack (the jobs' touched places packed over the wave)
+    bool walkCache = true;     // SMGPU_WALK_CACHE=0: every star staged from the addressing in every iteration (k_walk_pred_pack) instead of from its record (StarCache)
+    StarCache starCache{nullptr, nullptr, nullptr, 0};
     int starBlocks = 256 * 32;   // workgroups of k_walk_pred_star (each wave walks the active points with this stride)
     bool faLists = true;       // SMGPU_FA_LISTS=0: exact face-angle kernels over all edges / points asking the filter's marks
     bool walkStar = true;      // SMGPU_WALK_STAR=0: per-entry gather form of the walk predicates (k_walk_pred_self + k_walk_pred)    // SMGPU_WALK_BLOCKS: workgroups of the persistent replay launch (all must be resident at once)
@@ -751,6 +753,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     h->walkStar = envInt("SMGPU_WALK_STAR", 1) != 0;
     h->starBlocks = std::max(1, envInt("SMGPU_STAR_BLOCKS", 256 * 32));
     h->walkPack = envInt("SMGPU_WALK_PACK", 1) != 0;
+    h->walkCache = envInt("SMGPU_WALK_CACHE", 1) != 0;
     h->faLists = envInt("SMGPU_FA_LISTS", 1) != 0;
     h->faSideExact = envInt("SMGPU_FA_SIDE_EXACT", 1) != 0;
     h->bndInGeom = envInt("SMGPU_BND_IN_GEOM", 1) != 0;
@@ -1336,6 +1339,15 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     rc |= devAlloc(h, &h->dWalkOps, 64);
     if (rc) return 1;
     HIP_OK(hipMemset(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
+    // the stars' static records (kernels_walk.hpp: StarCache): a pool for an eighth of the points (the points outside the good range
+    // are a few per cent of a mesh worth smoothing; records beyond the pool are staged from the addressing every iteration, as before)
+    if (h->walkStar && h->walkPack && h->walkCache && !SMGPU_WALK_MEMO) {
+        StarCache& c = h->starCache;
+        c.capacity = std::max(1, envInt("SMGPU_WALK_CACHE_CAP", (int)std::max<size_t>(131072, P / 8)));
+        if (devAlloc(h, &c.slot, P) || devAlloc(h, &c.pool, (size_t)c.capacity) || devAlloc(h, &c.count, 4)) return 1;
+        HIP_OK(hipMemset(c.slot, 0xFF, P * sizeof(int)));      // -1: no record yet
+        HIP_OK(hipMemset(c.count, 0, 4 * sizeof(int)));
+    }
     h->walkAlloc = true;
     return 0;
 }
@@ -1458,7 +1470,11 @@ static int runHostWalk(smgpu_handle* h) {
     const int nA = hdr[0], nE = hdr[1];
     if (nA <= 0) return 0;
     if (launchK(h, K_FA_PRED, [&] {
-            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
+            if (h->walkStar && h->walkPack && h->starCache.pool) {
+                hipLaunchKernelGGL(k_walk_star_build, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->starCache);
+                hipLaunchKernelGGL(k_walk_pred_cached, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr, h->starCache);
+                hipLaunchKernelGGL(k_walk_pred_pack_rest, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr, h->starCache);
+            } else if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3((nA + 7) / 8), dim3(kPackBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
             else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3((nA + 7) / 8), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(gridFor(32 * (int64_t)nA)), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(std::max(1, gridFor(32 * (int64_t)nE))), dim3(kBlock), 0, h->stream, m, s, prm, w, nA, nE, h->walkStar ? 1 : 0);
@@ -1544,7 +1560,11 @@ static int runFixWalk(smgpu_handle* h) {
     if (launchK(h, K_FA_PRED, [&] {
             hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
             hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
+            if (h->walkStar && h->walkPack && h->starCache.pool) {
+                hipLaunchKernelGGL(k_walk_star_build, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->starCache);
+                hipLaunchKernelGGL(k_walk_pred_cached, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->starCache);
+                hipLaunchKernelGGL(k_walk_pred_pack_rest, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->starCache);
+            } else if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
             else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(h->starBlocks), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
             hipLaunchKernelGGL(k_walk_pred, dim3(h->walkStar ? 256 * 8 : 256 * 64), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);

@@ -89,7 +89,7 @@ def test_natural_tile_order(oracle_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"SMGPU_XCD_MAP": "0"}, {"SMGPU_WALK_STAR": "0"}, {"SMGPU_WALK_PACK": "0"}, {"SMGPU_TILE_MORTON": "0"}, {"SMGPU_FA_SIDE_EXACT": "0"},
-                                 {"SMGPU_SIDE_STREAM": "0"}])
+                                 {"SMGPU_SIDE_STREAM": "0"}, {"SMGPU_WALK_CACHE": "0"}, {"SMGPU_WALK_CACHE_CAP": "100"}])
 def test_launch_variants_give_the_same_result(oracle_lib, monkeypatch, env):
     """launch arrangements (round-robin tile launch, natural tile order, gather-form walk predicates, exact face-angle pass on
     the main stream, no side streams): tuning knobs, same bits; meshes with quadrilateral-only and mixed tiles"""

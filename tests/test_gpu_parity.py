@@ -173,13 +173,16 @@ def test_one_wave_walk_behind_many_workgroups(oracle_lib, monkeypatch):
     assert np.array_equal(e.get_points(), o.points())
 
 
-@pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4}])
+@pytest.mark.parametrize("knobs", [{}, {"SMGPU_WALK_PACK": "0"}, {"SMGPU_WALK_WARM": "0"}, {"SMGPU_WALK_LOCAL": "0"}, {"SMGPU_WALK_SWEEPS": "1"}, {"share": 4},
+                                   {"SMGPU_WALK_CACHE": "0"}, {"SMGPU_WALK_CACHE_CAP": "40"}])
 @pytest.mark.parametrize("dims,jit,seed", [((14, 12, 10), 0.47, 3), ((20, 6, 5), 0.49, 8)])
 def test_fixed_point_walk_on_large_components(oracle_lib, monkeypatch, dims, jit, seed, knobs):
     """a badly distorted block: the interaction graph has components of hundreds of points with long re-visit chains;
     the fixed-point device replay must still reproduce the reference's order -- from the previous iteration's set or from the
     empty one, with the sweeps in LDS or in global memory, one or several sweeps between two grid barriers, with the full
-    persistent launch or a quarter of it (smgpu_set_device_share).  Coordinates are written from the host in the middle (the
+    persistent launch or a quarter of it (smgpu_set_device_share); with the stars' static records (the default), without them
+    (every star staged from the addressing every iteration), and with a pool of 40 records (most points staged, a few from their
+    records, in the same launch group).  Coordinates are written from the host in the middle (the
     warm start then begins from a set that belongs to other coordinates)."""
     monkeypatch.setenv("SMGPU_WALK", "fix")
     for k, v in knobs.items():
