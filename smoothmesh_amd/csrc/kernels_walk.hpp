@@ -86,8 +86,11 @@ struct FixView {
 // fill launch, no scan launch in between (the chunk* helpers of kernels.hpp).  k_walk_fill leaves {nActive, nEntries, 0} in
 // w.header.  activeSlot[p] is only written for active points: it is valid iff faActive[p] carries this iteration's tag
 // (activeSlotOf) -- no 4-byte store per mesh point and iteration.
-__global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w) {
+// (StarCache, below: count[1] / count[2] say whether this iteration has a point without a record / a point the full pool could not take
+// -- the two launches that serve those leave at once otherwise)
+__global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, WalkView w, int* starNeed = nullptr) {
     if (s.acc->stop) return;
+    if (starNeed && blockIdx.x == 0 && threadIdx.x == 0) { starNeed[0] = 0; starNeed[1] = 0; }
     const int base = blockIdx.x * kChunk + threadIdx.x * kChunkPer;
     const uint4 q = chunkMarks(s.faActive, base, m.nPoints);
     int a = 0, e = 0;
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_count(MeshView m, State s, Walk
 }
 __device__ __forceinline__ int activeSlotOf(const State& s, const WalkView& w, int q) { return (s.faActive[q] == s.faGen) ? w.activeSlot[q] : -1; }
 
-__global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w) {
+__global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkView w, const int* starSlot = nullptr, int* starNeed = nullptr) {
     if (s.acc->stop) return;
     __shared__ uint16_t list[kChunk];
     const int cb = blockIdx.x * kChunk, base = cb + threadIdx.x * kChunkPer;
@@ -119,6 +122,7 @@ __global__ void __launch_bounds__(kBlock) k_walk_fill(MeshView m, State s, WalkV
             w.activeSlot[p] = slot;
             w.actIds[slot] = p;
             w.actEntOff[slot] = eo;
+            if (starSlot) { const int sl = starSlot[p]; if (sl == -1) starNeed[0] = 1; else if (sl == -3) starNeed[1] = 1; }
             for (int j = 0; j < deg; ++j) { w.entOwner[eo + j] = slot; w.entNbr[eo + j] = m.ppPt[nb + j]; }
         }
         running += tot;
@@ -695,7 +699,7 @@ struct StarRec {
     int pad[4];
 };
 static_assert(kPackVerts <= 255 && sizeof(StarRec) % 16 == 0, "StarRec: 16-byte records");
-struct StarCache { int* slot; StarRec* pool; int* count; int capacity; };
+struct StarCache { int* slot; StarRec* pool; int* count; int capacity; };      // count: [0] records handed out, [1] / [2] this iteration's needs (k_walk_count / k_walk_fill)
 
 // position of the r-th (0-based) set bit of m (r < popcount(m))
 __device__ __forceinline__ int nthSetBit(unsigned m, int r) {
@@ -942,6 +946,8 @@ template <bool DUMP>
 __device__ __forceinline__ void packKernelBody(const MeshView& m, const State& s, const Prm& prm, const WalkView& w, int nA, int nE, unsigned long long* opCount,
                                                unsigned long long* memo, const StarCache& sc) {
     if (s.acc->stop) return;
+    if (DUMP && sc.count[1] == 0) return;                 // every active point of this iteration has its record (k_walk_fill looked)
+    if (!DUMP && sc.slot && sc.count[2] == 0) return;     // k_walk_pred_pack_rest: nobody was turned away by a full pool
     if (nA < 0) { nA = w.header[0]; nE = w.header[1]; }
     __shared__ PackLds plds[kPackBlock / 64];
     PackLds& W = plds[threadIdx.x >> 6];
@@ -1112,7 +1118,7 @@ __device__ __forceinline__ void packKernelBody(const MeshView& m, const State& s
             const unsigned cm = (unsigned)(__ballot(counts) >> (32 * half));
             const int ops = packJobOps(counts, counts ? L.voff[P.l + 1] - L.voff[P.l] : 0, nEdgesP);
             int slot = -3;
-            if (live && hl == 0) { slot = atomicAdd(sc.count, 1); if (slot >= sc.capacity) slot = -3; }      // (-3: the pool is full -- k_walk_pred_pack stages the star every time)
+            if (live && hl == 0) { slot = atomicAdd(sc.count, 1); if (slot >= sc.capacity) { slot = -3; sc.count[2] = 1; } }      // (-3: the pool is full -- k_walk_pred_pack stages the star every time)
             slot = __shfl(slot, 0, 32);
             if (live && slot >= 0) {
                 StarRec& R = sc.pool[slot];

@@ -1461,8 +1461,8 @@ static int runHostWalk(smgpu_handle* h) {
     if (ensurePinned(h, 64)) return 1;
     const int gChunks = chunkGrid(m.nPoints);
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w, h->starCache.pool ? h->starCache.count + 1 : (int*)nullptr);
+            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w, h->starCache.pool ? (const int*)h->starCache.slot : (const int*)nullptr, h->starCache.pool ? h->starCache.count + 1 : (int*)nullptr);
         })) return 1;
     int* hdr = (int*)h->pinned;
     HIP_OK(hipMemcpyAsync(hdr, w.header, 2 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1558,12 +1558,13 @@ static int runFixWalk(smgpu_handle* h) {
     const int gItems = (int)std::min<int64_t>(((int64_t)P + maxEntries + kBlock - 1) / kBlock, 256 * 8);
     const int gChunks = chunkGrid(P), gRel = relGrid(P);
     if (launchK(h, K_FA_PRED, [&] {
-            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
-            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w);
+            hipLaunchKernelGGL(k_walk_count, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w, h->starCache.pool ? h->starCache.count + 1 : (int*)nullptr);
+            hipLaunchKernelGGL(k_walk_fill, dim3(gChunks), dim3(kBlock), 0, h->stream, m, s, w, h->starCache.pool ? (const int*)h->starCache.slot : (const int*)nullptr, h->starCache.pool ? h->starCache.count + 1 : (int*)nullptr);
             if (h->walkStar && h->walkPack && h->starCache.pool) {
-                hipLaunchKernelGGL(k_walk_star_build, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->starCache);
+                // (the two launches around the cached one leave at once in an iteration that has nothing for them: small grids)
+                hipLaunchKernelGGL(k_walk_star_build, dim3(std::min(h->starBlocks, 2048)), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->starCache);
                 hipLaunchKernelGGL(k_walk_pred_cached, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->starCache);
-                hipLaunchKernelGGL(k_walk_pred_pack_rest, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->starCache);
+                hipLaunchKernelGGL(k_walk_pred_pack_rest, dim3(std::min(h->starBlocks, 2048)), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->starCache);
             } else if (h->walkStar && h->walkPack) hipLaunchKernelGGL(k_walk_pred_pack, dim3(h->starBlocks), dim3(kPackBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr, h->dWalkMemo);
             else if (h->walkStar) hipLaunchKernelGGL(k_walk_pred_star, dim3(h->starBlocks), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->timing ? h->dWalkOps : nullptr);
             hipLaunchKernelGGL(k_walk_pred_self, dim3(h->walkStar ? 256 * 4 : 256 * 32), dim3(kBlock), 0, h->stream, m, s, prm, w, -1, -1, h->walkStar ? 1 : 0);
