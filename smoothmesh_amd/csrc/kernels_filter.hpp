@@ -367,6 +367,10 @@ __global__ void __launch_bounds__(T) k_fa_filter_tile(State s, Prm prm, EdgeTile
     }
     __syncthreads();
     if (!mine) return;
+#ifdef SMGPU_FA_FILTER_ABLATE      // (measurement build: staging only)
+    if (px[0] == 1.2345e300) markUnsureEdge(s, edges, g.order[tm.edgeBeg + tid], faMaybe);
+    return;
+#endif
     uint8_t flag = 1;
     if (f0.x != kPad) {
         const V3 e0 = ldsv(px, py, pz, ep & 0xffff), e1 = ldsv(px, py, pz, ep >> 16);
