@@ -984,7 +984,7 @@ int smgpu_create(const smgpu_mesh_desc* d, smgpu_handle** out) {
     if (rc) return cleanup(1);
     lapC("work arrays allocated");
     if (hipMemset(s.acc, 0, sizeof(Accum)) != hipSuccess) return cleanup(fail("hipMemset failed"));
-    if (hipMemset(s.nearTotal, 0, 4 * sizeof(unsigned long long)) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    if (hipMemsetAsync(s.nearTotal, 0, 4 * sizeof(unsigned long long), h->stream) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemset(s.frozen, 0, P) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (hipMemcpy(h->bufA, d->points, 3 * P * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
         return cleanup(fail("upload of points failed"));
@@ -1345,8 +1345,10 @@ static int ensureWalkBuffers(smgpu_handle* h) {
         StarCache& c = h->starCache;
         c.capacity = std::max(1, envInt("SMGPU_WALK_CACHE_CAP", (int)std::max<size_t>(131072, P / 8)));
         if (devAlloc(h, &c.slot, P) || devAlloc(h, &c.pool, (size_t)c.capacity) || devAlloc(h, &c.count, 4)) return 1;
-        HIP_OK(hipMemset(c.slot, 0xFF, P * sizeof(int)));      // -1: no record yet
-        HIP_OK(hipMemset(c.count, 0, 4 * sizeof(int)));
+        // (on the engine's stream: it is a non-blocking stream, which a hipMemset on the null stream does not order with -- with several
+        // processes on one device the first walk's kernels overtook the fill and read slots that were not -1 yet)
+        HIP_OK(hipMemsetAsync(c.slot, 0xFF, P * sizeof(int), h->stream));      // -1: no record yet
+        HIP_OK(hipMemsetAsync(c.count, 0, 4 * sizeof(int), h->stream));
     }
     h->walkAlloc = true;
     return 0;
