@@ -328,13 +328,20 @@ static int launchKDispatch(smgpu_handle* h, int k, F&& f) {
     return 0;
 }
 
+// memset on the null stream + wait: the engine's streams are non-blocking (not ordered with the null stream), and a memset of
+// device memory may return before it has run -- anything a kernel on those streams reads has to be complete here
+static hipError_t zeroNow(void* p, int v, size_t bytes) {
+    hipError_t e = hipMemset(p, v, bytes);
+    return e != hipSuccess ? e : hipStreamSynchronize(nullptr);
+}
+
 enum { DEP_FORK = 0, DEP_JOIN = 1, DEP_TO_EXCH = 2, DEP_FROM_EXCH = 3, DEP_BND_FORK = 4, DEP_BND_JOIN = 5, DEP_COUNT = 6 };
 static int depInit(smgpu_handle* h) {
     if (h->depWords || !envInt("SMGPU_STREAM_OPS", 1)) return 0;
     int can = 0;
     if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, h->device) != hipSuccess || !can) { (void)hipGetLastError(); return 0; }
     if (hipMalloc((void**)&h->depWords, DEP_COUNT * 64) != hipSuccess) { (void)hipGetLastError(); h->depWords = nullptr; return 0; }
-    if (hipMemset(h->depWords, 0, DEP_COUNT * 64) != hipSuccess) return fail("hipMemset failed");
+    if (zeroNow(h->depWords, 0, DEP_COUNT * 64) != hipSuccess) return fail("hipMemset failed");
     h->streamOps = true;
     return 0;
 }
@@ -1314,7 +1321,7 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     if (envInt("SMGPU_WALK_MEMO_STATS", 0) && !SMGPU_WALK_MEMO) return fail("SMGPU_WALK_MEMO_STATS needs a build with -DSMGPU_WALK_MEMO=1 (make HIPFLAGS+=-DSMGPU_WALK_MEMO=1)");
     if (envInt("SMGPU_WALK_MEMO_STATS", 0) && !h->dWalkMemo) {
         if (devAlloc(h, &h->dWalkMemo, (size_t)t.nPoints + 2)) return 1;
-        HIP_OK(hipMemset(h->dWalkMemo, 0, ((size_t)t.nPoints + 2) * sizeof(unsigned long long)));
+        HIP_OK(zeroNow(h->dWalkMemo, 0, ((size_t)t.nPoints + 2) * sizeof(unsigned long long)));
     }
     const size_t P = t.nPoints, E = t.pointPoints.size();
     h->walkBlocks = gridFor(t.nPoints);
@@ -1338,7 +1345,7 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     rc |= devAlloc(h, &w.items, E + P);
     rc |= devAlloc(h, &h->dWalkOps, 64);
     if (rc) return 1;
-    HIP_OK(hipMemset(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
+    HIP_OK(zeroNow(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
     // the stars' static records (kernels_walk.hpp: StarCache): a pool for an eighth of the points (the points outside the good range
     // are a few per cent of a mesh worth smoothing; records beyond the pool are staged from the addressing every iteration, as before)
     if (h->walkStar && h->walkPack && h->walkCache && !SMGPU_WALK_MEMO) {
@@ -1542,7 +1549,7 @@ static int runFixWalk(smgpu_handle* h) {
         const size_t P = (size_t)h->topo.nPoints;
         FixView& f = h->fxw;
         if (devAlloc(h, &f.T, P) || devAlloc(h, &f.act, P) || devAlloc(h, &f.bar, 16) || devAlloc(h, &f.flags, 16)) return 1;
-        if (envInt("SMGPU_WALK_WARM", 1)) { if (devAlloc(h, &f.actPrev, P)) return 1; HIP_OK(hipMemset(f.actPrev, 0, P)); }
+        if (envInt("SMGPU_WALK_WARM", 1)) { if (devAlloc(h, &f.actPrev, P)) return 1; HIP_OK(zeroNow(f.actPrev, 0, P)); }
         // every workgroup of the persistent launch has to be resident at once: far fewer than the chip holds (2 x 256)
         h->walkFixBlocks = std::max(1, std::min(envInt("SMGPU_WALK_BLOCKS", std::max(8, 128 / std::max(1, h->deviceShare))), 256));
         h->walkSweeps = std::max(1, envInt("SMGPU_WALK_SWEEPS", 8));
@@ -1978,7 +1985,7 @@ int smgpu_get_counters(smgpu_handle* h, smgpu_counters* o) {
 int smgpu_reset_counters(smgpu_handle* h) {
     if (!h) return fail("null handle");
     if (drainTimers(h)) return 1;
-    if (h->dWalkOps) HIP_OK(hipMemset(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
+    if (h->dWalkOps) HIP_OK(zeroNow(h->dWalkOps, 0, 64 * sizeof(unsigned long long)));
     for (int k = 0; k < K_COUNT; ++k) { h->ms[k] = 0; h->launches[k] = 0; }
     return 0;
 }
@@ -2209,7 +2216,7 @@ int smgpu_halo_configure(smgpu_handle* h, const smgpu_halo_desc* d) {
             h->st.spSlot = qa; h->st.spPeer = qb; h->st.spDst0 = qc; h->st.spNDst = qd;
         }
         if (!h->dRoleTickets) { if (devAlloc(h, &h->dRoleTickets, 3 * (size_t)kRoleWords)) return 1; }
-        HIP_OK(hipMemset(h->dRoleTickets, 0, 3 * (size_t)kRoleWords * sizeof(unsigned)));
+        HIP_OK(zeroNow(h->dRoleTickets, 0, 3 * (size_t)kRoleWords * sizeof(unsigned)));
         h->roleLaunches[0] = h->roleLaunches[1] = h->roleLaunches[2] = 0;
         if (devAlloc(h, &h->dOwnF, (size_t)std::max(d->nShared, 1))) return 1;
         h->mergedWanted = envInt("SMGPU_HALO_MERGED", 1) != 0;
@@ -2327,7 +2334,7 @@ int smgpu_halo_set_push(smgpu_handle* h, const smgpu_push_desc* d) {
         void **a = nullptr, **l = nullptr, **f = nullptr, **pf = nullptr;
         if (devAlloc(h, &a, n) || devAlloc(h, &l, n) || devAlloc(h, &f, n) || devAlloc(h, &pf, 64) || devAlloc(h, &h->dPushTicket, 2)) return 1;
         h->dSlotA = a; h->dSlotL = l; h->dSlotF = f; h->dPeerFlag = pf;
-        HIP_OK(hipMemset(h->dPushTicket, 0, 2 * sizeof(unsigned)));
+        HIP_OK(zeroNow(h->dPushTicket, 0, 2 * sizeof(unsigned)));
     }
     if (pushBuildTables(h)) return 1;
     PushView pv;
@@ -2391,8 +2398,8 @@ static int ensureFlagView(smgpu_handle* h) {
     HIP_OK(hipMemcpy(h->dSelfSlotA, a.data(), n * sizeof(void*), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(h->dSelfSlotF, f.data(), n * sizeof(void*), hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(h->dSelfPeerFlag, &w, sizeof(void*), hipMemcpyHostToDevice));
-    HIP_OK(hipMemset(h->dFlagWords, 0, 64 * sizeof(uint32_t)));
-    HIP_OK(hipMemset(h->dSelfTicket, 0, 2 * sizeof(unsigned)));
+    HIP_OK(zeroNow(h->dFlagWords, 0, 64 * sizeof(uint32_t)));
+    HIP_OK(zeroNow(h->dSelfTicket, 0, 2 * sizeof(unsigned)));
     PushView pv{};
     pv.slotA = (double* const*)h->dSelfSlotA; pv.slotL = nullptr; pv.slotF = (int* const*)h->dSelfSlotF;
     pv.ticket = h->dSelfTicket; pv.peerFlag = (unsigned* const*)h->dSelfPeerFlag; pv.localFlag = (const unsigned*)(h->dFlagWords + 16); pv.nPeers = 1;
