@@ -458,6 +458,7 @@ bool readLabelBodyParallel(Scanner& s, long long n, std::vector<int32_t>& out) {
 void readLabels(Scanner& s, const Header& h, std::vector<int32_t>& out, bool last = true) {
     const long long n = s.readInt();
     if (n < 0) s.fail("negative list size");
+    if (n > INT32_MAX) s.fail("list size beyond 32-bit labels");
     const char c = s.peek();
     if (c == '{') {   // uniform list N{v}
         ++s.p;
@@ -467,6 +468,7 @@ void readLabels(Scanner& s, const Header& h, std::vector<int32_t>& out, bool las
         return;
     }
     if (n == 0 && c != '(') { out.clear(); return; }
+    if (n > s.end - s.p) s.fail("list size exceeds the file");     // (every element takes at least a byte: nothing is allocated for a bad count)
     if (h.binary) {
         if (c != '(') s.fail("expected '(' before binary data");
         ++s.p;
@@ -586,6 +588,8 @@ void readPoints(const std::string& file, std::vector<double>& pts) {
     const Header h = readHeader(s);
     const long long n = s.readInt();
     if (n < 0) s.fail("negative point count");
+    if (n > INT32_MAX) s.fail("point count beyond 32-bit labels");
+    if (n > s.end - s.p) s.fail("point count exceeds the file");
     if (h.binary) {
         s.skipWs();
         if (s.p >= s.end || *s.p != '(') s.fail("expected '(' before binary data");
@@ -690,6 +694,8 @@ static void readFaces(const std::string& file, std::vector<int32_t>& off, std::v
         return;
     }
     const long long n = s.readInt();
+    if (n < 0 || n >= INT32_MAX) s.fail("bad face count");
+    if (n > s.end - s.p) s.fail("face count exceeds the file");
     s.expect('(');
     if (readFaceBodyParallel(s, n, off, val)) return;
     off.assign(1, 0);
@@ -698,6 +704,7 @@ static void readFaces(const std::string& file, std::vector<int32_t>& off, std::v
     val.reserve((size_t)n * 4);
     for (long long i = 0; i < n; ++i) {
         const long long k = s.readInt();
+        if (k < 0 || k > s.end - s.p) s.fail("bad face size");
         s.expect('(');
         for (long long j = 0; j < k; ++j) val.push_back((int32_t)s.readInt());
         s.expect(')');

@@ -279,3 +279,113 @@ def test_decimal_parser_is_strtod(tmp_path):
         assert got.shape == want.shape
         same = (got.view(np.uint64) == want.view(np.uint64)) | (np.isnan(got) & np.isnan(want))
         assert same.all(), [(toks[i], got[i], want[i]) for i in np.nonzero(~same)[0][:5]]
+
+
+def test_odd_and_broken_ascii_lists_threaded_equals_serial(tmp_path):
+    """OpenFOAM's ascii lists may carry comments, any white space, uniform forms; files get truncated.  Whatever the several-thread
+    readers cannot take they must hand to the serial scanner: for every mutant of a small case both settings either return the
+    same arrays or raise the same message -- and neither crashes the process or allocates for a count the file cannot hold"""
+    import json
+    from smoothmesh_amd.polymesh import cavity_mesh, write_polymesh
+    m = cavity_mesh(6, jitter=0.2, seed=3)
+    base = tmp_path / "base" / "constant" / "polyMesh"
+    write_polymesh(str(base), m, binary=False, precision=12)
+    rng = np.random.default_rng(2024)
+    files = {n: open(base / n, "rb").read() for n in ("points", "faces", "owner", "neighbour", "boundary")}
+
+    def body_span(b):
+        i = b.index(b"\n(\n") + 3
+        return i, b.rindex(b"\n)\n")
+
+    mutants = []            # (name, file, bytes)
+    for name in ("points", "faces", "owner", "neighbour"):
+        b = files[name]
+        i, j = body_span(b)
+        mid = i + (j - i) // 2
+        nl = b.index(b"\n", mid) + 1
+        mutants += [
+            (f"{name}: line comment inside", name, b[:nl] + b"// a remark (with brackets)\n" + b[nl:]),
+            (f"{name}: block comment inside", name, b[:nl] + b"/* a remark\n over lines ) */\n" + b[nl:]),
+            (f"{name}: tabs and CRLF", name, b[:i] + b[i:j].replace(b"\n", b"\r\n").replace(b" ", b"\t ") + b[j:]),
+            (f"{name}: one line", name, b[:i] + b[i:j].replace(b"\n", b" ") + b[j:]),
+            (f"{name}: truncated", name, b[:mid]),
+            (f"{name}: truncated at a record", name, b[:nl]),
+            (f"{name}: garbage byte", name, b[:nl] + b"x" + b[nl:]),
+            (f"{name}: stray closer", name, b[:nl] + b")\n" + b[nl:]),
+            (f"{name}: stray opener", name, b[:nl] + b"(\n" + b[nl:]),
+            (f"{name}: no footer", name, b[:j + 3]),
+            (f"{name}: nothing after the closer", name, b[:j + 2]),
+            (f"{name}: count one too many", name, None),
+            (f"{name}: count huge", name, None),
+            (f"{name}: count negative", name, None),
+            (f"{name}: one record short", name, b[:b.rindex(b"\n", i, j) + 1] + b[j + 1:]),
+        ]
+        for _ in range(6):           # random single-byte damage inside the body
+            k = int(rng.integers(i, j))
+            c = bytes([int(rng.choice(list(b" ()\n-.e9x/;{")))])
+            mutants.append((f"{name}: byte {k - i} -> {c!r}", name, b[:k] + c + b[k + 1:]))
+    # the counts: the line before "(\n"
+    fixed = []
+    for label, name, data in mutants:
+        if data is None:
+            b = files[name]
+            i, _ = body_span(b)
+            k = b.rindex(b"\n", 0, i - 3) + 1
+            n = int(b[k:i - 3])
+            new = {"count one too many": n + 1, "count huge": 10 ** 15, "count negative": -3}[label.split(": ")[1]]
+            data = b[:k] + str(new).encode() + b[i - 3:]
+        fixed.append((label, name, data))
+    p = files["points"]
+    i, j = body_span(p)
+    first = p.index(b"\n", i) + 1
+    fixed += [
+        ("points: four numbers in a record", "points", p[:i] + b"(0 0 0 0)\n" + p[first:]),
+        ("points: two numbers in a record", "points", p[:i] + b"(0 0)\n" + p[first:]),
+        ("points: numbers glued by signs", "points", p[:i] + b"(1-2+3)\n" + p[first:]),
+        ("points: nan and inf", "points", p[:i] + b"(nan inf -inf)\n" + p[first:]),
+        ("points: hex float", "points", p[:i] + b"(0x1p-3 1e400 1e-400)\n" + p[first:]),
+        ("owner: uniform list", "owner", files["owner"][:files["owner"].rindex(b"\n", 0, body_span(files["owner"])[0] - 3) + 1] + b"%d{0}\n" % (len(m.owner),)),
+    ]
+    cases = []
+    for k, (label, name, data) in enumerate(fixed):
+        d = tmp_path / f"m{k}" / "constant" / "polyMesh"
+        os.makedirs(d)
+        for n, b in files.items():
+            open(d / n, "wb").write(data if n == name else b)
+        cases.append((label, str(d)))
+    json.dump(cases, open(tmp_path / "cases.json", "w"))
+    code = f"""
+import json, hashlib, numpy as np
+from smoothmesh_amd.polymesh import read_polymesh
+out = []
+for label, d in json.load(open({str(tmp_path / 'cases.json')!r})):
+    try:
+        r = read_polymesh(d)
+        h = hashlib.sha256()
+        for a in (r.points, r.faceOffsets, r.facePoints, r.owner, r.neighbour):
+            h.update(np.ascontiguousarray(a).tobytes())
+        out.append([label, 'ok', h.hexdigest(), int(r.nPoints), int(r.nFaces)])
+    except Exception as e:
+        out.append([label, 'error', str(e)])
+json.dump(out, open({str(tmp_path)!r} + '/out_' + TAG + '.json', 'w'))
+"""
+    _run_py("TAG = 'par'\n" + code, {"SMHOST_IO_THREADS": "11", "SMHOST_IO_GRAIN": "64"})
+    _run_py("TAG = 'ser'\n" + code, {"SMHOST_IO_THREADS": "1"})
+    a = json.load(open(tmp_path / "out_par.json"))
+    b = json.load(open(tmp_path / "out_ser.json"))
+    assert len(a) == len(b) == len(cases)
+    for x, y in zip(a, b):
+        assert x == y, (x, y)
+    verdict = {x[0]: x[1] for x in a}
+    # what must be read, what must be refused
+    for name in ("points", "faces", "owner", "neighbour"):
+        for ok in ("line comment inside", "block comment inside", "tabs and CRLF", "one line", "no footer", "nothing after the closer"):
+            assert verdict[f"{name}: {ok}"] == "ok", (name, ok, [x for x in a if x[0] == f"{name}: {ok}"])
+        for bad in ("truncated", "truncated at a record", "garbage byte", "stray closer", "count one too many", "count huge", "count negative", "one record short"):
+            assert verdict[f"{name}: {bad}"] == "error", (name, bad)
+    good = [x for x in a if x[0] == "points: line comment inside"][0]
+    for name in ("points", "faces", "owner", "neighbour"):
+        for ok in ("line comment inside", "block comment inside", "tabs and CRLF", "one line", "no footer"):
+            assert [x for x in a if x[0] == f"{name}: {ok}"][0][2:] == good[2:]          # the same mesh as the undamaged files
+    assert verdict["points: four numbers in a record"] == "error" and verdict["points: two numbers in a record"] == "error"
+    assert verdict["points: nan and inf"] == "ok" and verdict["points: hex float"] == "ok" and verdict["owner: uniform list"] in ("ok", "error")
