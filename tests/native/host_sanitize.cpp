@@ -2,6 +2,8 @@
 // polyhedral mesh.  Built and run by tests/test_host_sanitizers.py with -fsanitize=address,undefined.
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../../smoothmesh_amd/csrc/host/polymesh_io.hpp"
@@ -94,6 +96,39 @@ int main(int argc, char** argv) {
             }
         if (leafTris != 300) { std::fprintf(stderr, "bvh: %ld triangles in leaves\n", leafTris); return 1; }
     }
-    std::printf("ok points %d cells %d edges %d mapped %ld\n", m.nPoints(), m.nCells, t.nEdges, mapped);
+    // polyMesh I/O (argv[2] = scratch directory): ascii and binary round trips, then the ascii lists cut short at many places --
+    // every read of a damaged file must end in an exception, nothing else (the test runs this with several I/O threads and a
+    // small grain, so the pieces of the several-thread readers / writers are a few records each)
+    long refused = 0;
+    if (argc > 2) {
+        const std::string root = argv[2];
+        for (int binary = 0; binary < 2; ++binary) {
+            const std::string d = root + (binary ? "/bin/constant/polyMesh" : "/asc/constant/polyMesh");
+            smhost::writePolyMesh(d, "constant", m, binary != 0, 17);
+            smhost::PolyMeshData r;
+            smhost::readPolyMesh(d, "", r);
+            if (r.points != m.points || r.faceOffsets != m.faceOffsets || r.facePoints != m.facePoints || r.owner != m.owner ||
+                r.neighbour != m.neighbour || r.nCells != m.nCells) { std::fprintf(stderr, "io: round trip differs (binary %d)\n", binary); return 1; }
+        }
+        const std::string d = root + "/asc/constant/polyMesh";
+        for (const char* name : {"points", "faces", "owner", "neighbour"}) {
+            const std::string file = d + "/" + name;
+            std::string all;
+            { FILE* f = std::fopen(file.c_str(), "rb"); if (!f) return 1; char buf[65536]; size_t k; while ((k = std::fread(buf, 1, sizeof buf, f)) > 0) all.append(buf, k); std::fclose(f); }
+            const size_t body = all.find("\n(\n");
+            for (int cutAt = 1; cutAt <= 12; ++cutAt) {
+                const size_t len = body + (all.size() - body) * (size_t)cutAt / 13;
+                { FILE* f = std::fopen(file.c_str(), "wb"); std::fwrite(all.data(), 1, len, f); std::fclose(f); }
+                smhost::PolyMeshData r;
+                try { smhost::readPolyMesh(d, "", r); std::fprintf(stderr, "io: %s cut at %zu was read\n", name, len); return 1; }
+                catch (const std::exception&) { ++refused; }
+            }
+            { FILE* f = std::fopen(file.c_str(), "wb"); std::fwrite(all.data(), 1, all.size(), f); std::fclose(f); }
+        }
+        smhost::PolyMeshData r;
+        smhost::readPolyMesh(d, "", r);
+        if (r.points != m.points) { std::fprintf(stderr, "io: restored case differs\n"); return 1; }
+    }
+    std::printf("ok points %d cells %d edges %d mapped %ld refused %ld\n", m.nPoints(), m.nCells, t.nEdges, mapped, refused);
     return 0;
 }

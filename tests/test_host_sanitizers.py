@@ -15,12 +15,27 @@ def test_host_code_is_clean_under_asan_ubsan(tmp_path):
     exe = str(tmp_path / "host_sanitize")
     src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
           [os.path.join(CSRC, f) for f in ("topology.cpp", "tiles.cpp", "layers.cpp", "boundary.cpp", "host/meshgen.cpp", "host/polymesh_io.cpp")]
-    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-fsanitize=address,undefined",
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-pthread", "-fsanitize=address,undefined",
                            "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-o", exe] + src + ["-lz"])
-    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1")
-    r = subprocess.run([exe, "14"], capture_output=True, text=True, env=env, timeout=600)
-    assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.startswith("ok points") and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+    # polyMesh I/O with the lists cut into pieces of a few records for five threads (round trips + truncated files), and serially
+    for k, io in enumerate(({"SMHOST_IO_THREADS": "5", "SMHOST_IO_GRAIN": "64"}, {"SMHOST_IO_THREADS": "1"})):
+        env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", UBSAN_OPTIONS="print_stacktrace=1", **io)
+        r = subprocess.run([exe, "14", str(tmp_path / f"case{k}")], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert r.stdout.startswith("ok points") and "refused 48" in r.stdout and "ERROR" not in r.stderr and "runtime error" not in r.stderr
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="needs g++")
+def test_threaded_polymesh_io_is_race_free(tmp_path):
+    """the same driver under ThreadSanitizer: per-thread pieces of the ascii readers, the pwrite writers, the parallel copies"""
+    exe = str(tmp_path / "host_tsan")
+    src = [os.path.join(ROOT, "tests", "native", "host_sanitize.cpp")] + \
+          [os.path.join(CSRC, f) for f in ("topology.cpp", "tiles.cpp", "layers.cpp", "boundary.cpp", "host/meshgen.cpp", "host/polymesh_io.cpp")]
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-ffp-contract=off", "-pthread", "-fsanitize=thread", "-o", exe] + src + ["-lz"])
+    env = dict(os.environ, SMHOST_IO_THREADS="6", SMHOST_IO_GRAIN="64", SMGPU_HOST_THREADS="3", SMGPU_HOST_GRAIN="64")
+    r = subprocess.run([exe, "10", str(tmp_path / "case")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr[-3000:]
+    assert r.stdout.startswith("ok points") and "ThreadSanitizer" not in r.stderr, r.stderr[-3000:]
 
 
 def _dump_mesh(path, n):
