@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--serial-io", action="store_true")
 ap.add_argument("--dir", default="/tmp/cli_case")
 ap.add_argument("--formats", default="ascii,binary")
+ap.add_argument("--timeline", action="store_true", help="SMOOTHMESH_TIMELINE=1 SMGPU_VERBOSE=2 SMHOST_IO_VERBOSE=1: the stages' stderr lines")
 args = ap.parse_args()
 
 from smoothmesh_amd.polymesh import cavity_mesh, write_case  # noqa: E402
@@ -39,6 +40,8 @@ for fmt in args.formats.split(","):
         env = dict(os.environ)
         if env_io:
             env["SMHOST_IO_THREADS"] = env_io
+        if args.timeline:
+            env.update(SMOOTHMESH_TIMELINE="1", SMGPU_VERBOSE="2", SMHOST_IO_VERBOSE="1")
         for d_ in os.listdir(case):
             if d_.isdigit() and d_ != "0":
                 shutil.rmtree(os.path.join(case, d_))
@@ -55,5 +58,7 @@ for fmt in args.formats.split(","):
         print(f"{fmt:6s} io_threads={'default' if not env_io else env_io:7s} process wall {wall:.2f} s, points written {omb:.0f} MB")
         for ln in lines:
             print("       " + ln)
+        if args.timeline:
+            print("\n".join("       | " + ln for ln in r.stderr.splitlines()))
         sys.stdout.flush()
 shutil.rmtree(args.dir, ignore_errors=True)

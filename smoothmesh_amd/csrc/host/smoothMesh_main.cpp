@@ -497,6 +497,9 @@ int main(int argc, char** argv) {
     auto secondsSince = [](std::chrono::steady_clock::time_point a) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - a).count(); };
     const Options opt = parseArgs(argc, argv);
     const std::string& cd = opt.caseDir;
+    // SMOOTHMESH_TIMELINE=1: where this process's wall time goes, one stderr line per stage (seconds since main started)
+    const bool timeline = std::getenv("SMOOTHMESH_TIMELINE") && std::atoi(std::getenv("SMOOTHMESH_TIMELINE")) > 0;
+    auto mark = [&](const char* what) { if (timeline) std::fprintf(stderr, "[smoothMesh %8.3f s] %s\n", secondsSince(t0), what); };
 
     // createTime.H: deltaT sanity (SM.C:1805-1812)
     const auto control = readControlDict(cd + "/system/controlDict");
@@ -568,7 +571,9 @@ int main(int argc, char** argv) {
             const std::string meshDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "faces");
             const std::string ptsDir = findInstance(K.root, listTimes(K.root), startValue, startIsConstant, "points");
             { const auto tr = std::chrono::steady_clock::now(); readPolyMesh(meshDir, ptsDir == meshDir ? "" : ptsDir, K.mesh); tRead += secondsSince(tr); }
+            mark("case read");
             K.internal = findInternalMeshPoints(K.mesh);
+            mark("internal points found");
             if (opt.parallel) {
                 // shared points are matched by decomposePar's global ids where the file is there, and through the processor patches
                 // themselves where it is not (labelsFromPatches; SMGPU_MATCH_BY_PATCHES=1 forces that)
@@ -676,7 +681,9 @@ int main(int argc, char** argv) {
         OUTS("WARNING: Boundary layer treatment will be done without boundary point smoothing. This can result in distorted boundary cells.\n");
 
     // engine: this rank's sub-domain on its device
+    mark("options and boundary set-up read");
     if (hipWarm.joinable()) hipWarm.join();
+    mark("HIP runtime up");
     int nDev = 0;
     if (hipGetDeviceCount(&nDev) != hipSuccess || nDev <= 0) fatal("no HIP device available (this build has no CPU fallback)");
     const int dev0 = (int)opt.getL("device", 0);
@@ -690,6 +697,7 @@ int main(int argc, char** argv) {
         K.device = (dev0 + myRank) % nDev;
         d.device = K.device; d.stream = nullptr; d.useCallerStream = 0;
         { const auto tc = std::chrono::steady_clock::now(); check(smgpu_create(&d, &K.h), "smgpu_create"); tCreate += secondsSince(tc); }
+        mark("engine created");
         // several ranks on one device (a debugging arrangement): every rank's persistent walk replay needs all of its workgroups
         // resident at once, so each takes its share of the chip (the engine's default is sized for a device of its own)
         if (nRanks > nDev) check(smgpu_set_device_share(K.h, (nRanks + nDev - 1) / nDev), "smgpu_set_device_share");
@@ -1202,6 +1210,7 @@ int main(int argc, char** argv) {
             }
         }
         tLoop += secondsSince(tl);
+        mark("a stretch of the loop done");
         for (int32_t k = 0; k < done; ++k)
             OUT("Smoothing iteration=%ld nFrozenPoints=%d residual=%g\n", i + k + 1, stats[(size_t)k].nFrozenPoints, stats[(size_t)k].residual);
         i += done;
@@ -1234,7 +1243,9 @@ int main(int argc, char** argv) {
         for (void* m : pushMapped) check(smgpu_push_close(m), "smgpu_push_close");
         g_comm.barrier();
     }
+    mark("loop and output done");
     for (Rank& K : R) smgpu_destroy(K.h);
+    mark("engine destroyed");
     g_comm.barrier();
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     OUT("ClockTime breakdown: read %.2f s, engine set-up %.2f s, smoothing loop %.3f s, write %.2f s, other %.2f s\n", tRead, tCreate, tLoop, tWrite,
