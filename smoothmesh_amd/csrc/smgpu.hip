@@ -1351,7 +1351,25 @@ static int ensureWalkBuffers(smgpu_handle* h) {
     if (h->walkStar && h->walkPack && h->walkCache && !SMGPU_WALK_MEMO) {
         StarCache& c = h->starCache;
         c.capacity = std::max(1, envInt("SMGPU_WALK_CACHE_CAP", (int)std::max<size_t>(131072, P / 8)));
-        if (devAlloc(h, &c.slot, P) || devAlloc(h, &c.pool, (size_t)c.capacity) || devAlloc(h, &c.count, 4)) return 1;
+        // the pool is an accelerator, not a necessity (112 bytes per mesh point by default): a device that cannot hold it runs every
+        // star through k_walk_pred_pack as with SMGPU_WALK_CACHE=0; a smaller pool is tried first
+        void* pool = nullptr;
+        while (hipMalloc(&pool, (size_t)c.capacity * sizeof(StarRec)) != hipSuccess) {
+            (void)hipGetLastError();
+            pool = nullptr;
+            if (c.capacity <= 4096) break;
+            c.capacity /= 4;
+        }
+        if (!pool) {
+            if (envInt("SMGPU_VERBOSE", 0) >= 1) std::fprintf(stderr, "[smgpu] no device memory for the stars' records: every star is staged from the addressing\n");
+            c = StarCache{nullptr, nullptr, nullptr, 0};
+            h->walkAlloc = true;
+            return 0;
+        }
+        h->allocs.push_back(pool);
+        h->deviceBytes += (int64_t)((size_t)c.capacity * sizeof(StarRec));
+        c.pool = (StarRec*)pool;
+        if (devAlloc(h, &c.slot, P) || devAlloc(h, &c.count, 4)) return 1;
         // (on the engine's stream: it is a non-blocking stream, which a hipMemset on the null stream does not order with -- with several
         // processes on one device the first walk's kernels overtook the fill and read slots that were not -1 yet)
         HIP_OK(hipMemsetAsync(c.slot, 0xFF, P * sizeof(int), h->stream));      // -1: no record yet
