@@ -364,7 +364,7 @@ void genCavitySubdomain(int N, double radius, double shell, double jitter, uint6
 
 void genCavityMesh(int N, double radius, double shell, double jitter, uint64_t seed, PolyMeshData& out) {
     const int grid[3] = {1, 1, 1};
-    if (N > 400) throw std::runtime_error("genCavityMesh: N out of range");
+    if (N > 500) throw std::runtime_error("genCavityMesh: N out of range");      // (32-bit face-vertex offsets: 4 x 3 x N^3 entries)
     genCavitySubdomain(N, radius, shell, jitter, seed, grid, 0, out, nullptr, nullptr);
 }
 
